@@ -1,0 +1,3 @@
+// Build shim: see ImfShim.h
+#pragma once
+#include "ImfShim.h"
