@@ -1,0 +1,430 @@
+/*
+ * wf_abi.h — C ABI of the MI355X wavefront path-tracing back end (libwfhip.so).
+ *
+ * This is the drop-in boundary described in SURVEY.md §8(b).  In the reference the boundary is
+ *   (1) class WavefrontAggregate                     src/pbrt/wavefront/integrator.h:32-54
+ *   (2) the lambda dispatchers ParallelFor/Do        src/pbrt/wavefront/integrator.h:91-113
+ *       and ForAllQueued                             src/pbrt/wavefront/workqueue.h:118-137
+ *   (3) the memory resource handed to the integrator src/pbrt/wavefront/integrator.h:88-89
+ * i.e. "the lambda is the kernel".  Here every lambda body is a named, hand-written HIP kernel and
+ * every launch site is one extern "C" function; the host loop (pbrt-v4_amd/csrc/host/integrator.cpp)
+ * is a restatement of WavefrontPathIntegrator::Render (src/pbrt/wavefront/integrator.cpp:290-493)
+ * that calls them in the same order.
+ *
+ * Conventions
+ *  - plain C: PODs, raw pointers, sizes.  No C++/torch types cross this boundary.
+ *  - every entry point returns 0 on success or a non-zero hipError_t-like code; wf_last_error()
+ *    returns a message.  (The reference aborts via CUDA_CHECK -> LOG_FATAL, gpu/util.h:35-49; the
+ *    host wrapper does the same on a non-zero return.)
+ *  - one in-order HIP stream per context; no entry point synchronises the host except
+ *    wf_sync / wf_*_download.
+ *  - scene tables are flat, index-addressed arrays (no host pointers live on the device).  The same
+ *    wf_scene_desc (host memory) is what oracle/ consumes, so HIP and oracle see identical inputs.
+ */
+#ifndef WF_ABI_H
+#define WF_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_ABI_VERSION 1
+#define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
+#define WF_LAMBDA_MIN 360
+#define WF_LAMBDA_MAX 830
+#define WF_NDENSE 471            /* WF_LAMBDA_MAX - WF_LAMBDA_MIN + 1 */
+
+/* ------------------------------------------------------------------------------------------- */
+/* Scene description: flat host tables                                                          */
+/* ------------------------------------------------------------------------------------------- */
+
+typedef struct wf_transform {    /* util/transform.h:Transform — m and its inverse, row major */
+    float m[4][4];
+    float mInv[4][4];
+} wf_transform;
+
+/* Spectrum (util/spectrum.h:48-67 TaggedPointer family) flattened to a 32-byte descriptor.
+ * Sample values live in wf_scene_desc::spectrum_data (float pool). */
+enum wf_spectrum_type {
+    WF_SPEC_NONE = 0,
+    WF_SPEC_CONSTANT = 1,        /* c0 = value */
+    WF_SPEC_DENSE = 2,           /* offset -> 471 floats for 360..830 nm (DenselySampledSpectrum) */
+    WF_SPEC_PIECEWISE = 3,       /* offset -> n lambdas followed by n values */
+    WF_SPEC_RGB_ALBEDO = 4,      /* sigmoid polynomial c0,c1,c2 (util/color.h:332-364) */
+    WF_SPEC_RGB_UNBOUNDED = 5,   /* scale * sigmoid */
+    WF_SPEC_RGB_ILLUMINANT = 6,  /* scale * sigmoid * dense illuminant at offset */
+    WF_SPEC_BLACKBODY = 7        /* c0 = T, c1 = normalization factor */
+};
+typedef struct wf_spectrum {
+    int32_t type;
+    int32_t offset;
+    int32_t n;
+    float scale;
+    float c0, c1, c2;
+    int32_t pad;
+} wf_spectrum;
+
+/* Textures (textures.h).  Round 1 implements the "basic" evaluator set that the configs need. */
+enum wf_texture_type {
+    WF_TEX_FLOAT_CONSTANT = 0,     /* f0 */
+    WF_TEX_SPECTRUM_CONSTANT = 1,  /* spectrum */
+    WF_TEX_FLOAT_SCALE = 2,        /* tex0 * tex1 (float) */
+    WF_TEX_SPECTRUM_SCALE = 3,     /* spectrum tex0 * float tex1 */
+    WF_TEX_FLOAT_MIX = 4,          /* lerp(amount tex2, tex0, tex1) */
+    WF_TEX_SPECTRUM_MIX = 5,
+    WF_TEX_FLOAT_IMAGE = 6,        /* image id in i0, mapping in map */
+    WF_TEX_SPECTRUM_IMAGE = 7
+};
+typedef struct wf_texture {
+    int32_t type;
+    int32_t spectrum;            /* index into spectra, or -1 */
+    int32_t tex0, tex1, tex2;    /* child texture ids, or -1 */
+    int32_t i0;                  /* image id / spectrum type for image textures */
+    float f0, f1;                /* constant value / scale, invert flag etc. */
+    float map[8];                /* UVMapping: su, sv, du, dv (textures.h:76-104) */
+} wf_texture;
+
+/* Materials (materials.h).  tex[] holds texture ids; meaning per type is listed in DESIGN.md and
+ * mirrored by the WF_MT_* index constants below. */
+enum wf_material_type {
+    WF_MAT_INTERFACE = 0,            /* "interface": null material, ray passes through */
+    WF_MAT_DIFFUSE = 1,              /* materials.h:449-482 */
+    WF_MAT_CONDUCTOR = 2,            /* materials.h:485-548 */
+    WF_MAT_DIELECTRIC = 3,           /* materials.h:144-215 */
+    WF_MAT_THIN_DIELECTRIC = 4,      /* materials.h:218-264 */
+    WF_MAT_DIFFUSE_TRANSMISSION = 5, /* materials.h:672-720 */
+    WF_MAT_COATED_DIFFUSE = 6,       /* materials.h:551-608 */
+    WF_MAT_COATED_CONDUCTOR = 7,     /* materials.h:611-669 */
+    WF_MAT_NTYPES = 8
+};
+/* tex[] slots */
+#define WF_MT_REFLECTANCE 0   /* diffuse / conductor(reflectance) / difftrans / coated diffuse */
+#define WF_MT_TRANSMITTANCE 1 /* difftrans */
+#define WF_MT_ETA 1           /* conductor eta (spectrum tex) ; dielectric: spectra[eta_spectrum] */
+#define WF_MT_K 2             /* conductor k */
+#define WF_MT_UROUGH 3
+#define WF_MT_VROUGH 4
+#define WF_MT_THICKNESS 5     /* coated */
+#define WF_MT_G 6             /* coated */
+#define WF_MT_ALBEDO 7        /* coated */
+#define WF_MT_NTEX 12
+/* coated conductor: interface roughness in UROUGH/VROUGH, conductor in slots 8..11 */
+#define WF_MT_COND_UROUGH 8
+#define WF_MT_COND_VROUGH 9
+#define WF_MT_COND_ETA 10
+#define WF_MT_COND_K 11
+typedef struct wf_material {
+    int32_t type;
+    int32_t flags;               /* bit0 remaproughness, bit1 conductor given by reflectance */
+    int32_t tex[WF_MT_NTEX];
+    int32_t eta_spectrum;        /* dielectric / coated: spectrum id of eta (Spectrum eta) */
+    int32_t maxdepth, nsamples;  /* coated */
+    float scale;                 /* difftrans scale */
+    int32_t displacement;        /* float texture id or -1 */
+    int32_t normalmap;           /* image id or -1 */
+} wf_material;
+#define WF_MATFLAG_REMAP_ROUGHNESS 1
+#define WF_MATFLAG_CONDUCTOR_REFLECTANCE 2
+
+/* Lights (lights.h). */
+enum wf_light_type {
+    WF_LIGHT_POINT = 0,
+    WF_LIGHT_DISTANT = 1,
+    WF_LIGHT_SPOT = 2,
+    WF_LIGHT_DIFFUSE_AREA = 3,
+    WF_LIGHT_UNIFORM_INFINITE = 4,
+    WF_LIGHT_IMAGE_INFINITE = 5
+};
+typedef struct wf_light {
+    int32_t type;
+    int32_t flags;               /* bit0 twoSided (area), bit1 delta-position via zero alpha */
+    int32_t spectrum_offset;     /* DenselySampledSpectrum (471 floats) in spectrum_data */
+    float scale;
+    int32_t tri;                 /* DIFFUSE_AREA: global triangle id */
+    float area;                  /* DIFFUSE_AREA: shape.Area() */
+    int32_t bit_trail;           /* BVH light sampler: lightToBitTrail value, -1 if not in light BVH */
+    int32_t infinite_index;      /* index in infinite_lights, or -1 */
+    float pos[3];                /* POINT/SPOT: renderFromLight(0,0,0);  DISTANT: direction w (normalized) */
+    float cosFalloffStart, cosFalloffEnd; /* SPOT */
+    float sceneCenter[3];        /* DISTANT / infinite: set by Preprocess (lights.h:243,546) */
+    float sceneRadius;
+    int32_t xform;               /* index into light_transforms (SPOT / IMAGE_INFINITE), or -1 */
+    int32_t image;               /* IMAGE_INFINITE image table id */
+    int32_t pad[2];
+} wf_light;
+#define WF_LIGHTFLAG_TWOSIDED 1
+
+/* Light BVH node, 32 bytes, same content as LightBVHNode/CompactLightBounds (lightsamplers.h:101-257) */
+typedef struct wf_light_bvh_node {
+    uint16_t w_oct[2];           /* OctahedralVector */
+    float phi;
+    uint32_t cos_bits;           /* qCosTheta_o:15 | qCosTheta_e:15 << 15 | twoSided << 30 */
+    uint16_t qb[2][3];
+    uint32_t child_or_light;     /* childOrLightIndex:31 | isLeaf << 31 */
+    uint32_t pad;
+} wf_light_bvh_node;
+
+/* Geometry BVH node: the reference's LinearBVHNode (cpu/aggregates.cpp:129-137), 32 bytes. */
+typedef struct wf_bvh_node {
+    float bmin[3];
+    float bmax[3];
+    int32_t offset;              /* primitivesOffset (leaf) | secondChildOffset (interior) */
+    uint16_t nprims;             /* 0 -> interior */
+    uint8_t axis;
+    uint8_t pad;
+} wf_bvh_node;
+
+/* Per-mesh record (util/mesh.h:TriangleMesh + the primitive wrapper, cpu/primitive.h) */
+typedef struct wf_mesh {
+    int32_t first_tri;           /* first global triangle id */
+    int32_t ntris;
+    int32_t first_vertex;        /* offset into P/N/UV */
+    int32_t nverts;
+    int32_t flags;               /* WF_MESH_* */
+    int32_t material;            /* material id; -1 = interface (no material) */
+    int32_t first_light;         /* light id of this mesh's first triangle's area light, or -1 */
+    int32_t alpha_tex;           /* float texture id or -1 */
+    int32_t medium_inside, medium_outside; /* medium ids or -1; both -1 = no MediumInterface */
+    int32_t pad[2];
+} wf_mesh;
+#define WF_MESH_HAS_N 1
+#define WF_MESH_HAS_UV 2
+#define WF_MESH_FLIP_NORMAL 4    /* reverseOrientation ^ transformSwapsHandedness */
+#define WF_MESH_HAS_MEDIUM_INTERFACE 8
+
+enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1 };
+typedef struct wf_camera {
+    int32_t type;
+    wf_transform cameraFromRaster;      /* cameras.h:ProjectiveCamera */
+    wf_transform renderFromCamera;      /* CameraTransform::renderFromCamera.startTransform */
+    float lensRadius, focalDistance;
+    float shutterOpen, shutterClose;
+    float dxCamera[3], dyCamera[3];
+    float minPosDifferentialX[3], minPosDifferentialY[3];
+    float minDirDifferentialX[3], minDirDifferentialY[3];
+    int32_t medium;
+} wf_camera;
+
+enum wf_filter_type { WF_FILTER_BOX = 0, WF_FILTER_GAUSSIAN = 1, WF_FILTER_MITCHELL = 2,
+                      WF_FILTER_SINC = 3, WF_FILTER_TRIANGLE = 4 };
+typedef struct wf_filter {
+    int32_t type;
+    float radius[2];
+    /* FilterSampler tables (filters.h:26-45, filters.cpp:133-147): f[ny][nx], and the
+       PiecewiseConstant2D over it: per row func[nx] + cdf[nx+1], marginal func[ny] + cdf[ny+1]. */
+    int32_t nx, ny;
+    int32_t f_offset;            /* all offsets into filter_data (floats) */
+    int32_t cond_func_offset, cond_cdf_offset, cond_int_offset;
+    int32_t marg_func_offset, marg_cdf_offset;
+    float marg_int;
+    float domain_min[2], domain_max[2];
+} wf_filter;
+
+typedef struct wf_film {
+    int32_t full_res[2];
+    int32_t pixel_min[2], pixel_max[2];   /* pixelBounds */
+    float imaging_ratio;                  /* PixelSensor::imagingRatio */
+    float max_component_value;
+    int32_t rbar_offset, gbar_offset, bbar_offset; /* dense spectra in spectrum_data */
+    float XYZFromSensorRGB[3][3];
+    float outputRGBFromSensorRGB[3][3];
+} wf_film;
+
+enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1 };
+enum wf_randomize { WF_RAND_NONE = 0, WF_RAND_PERMUTE_DIGITS = 1, WF_RAND_FAST_OWEN = 2, WF_RAND_OWEN = 3 };
+typedef struct wf_sampler {
+    int32_t type;
+    int32_t spp;
+    int32_t seed;
+    int32_t randomize;
+    int32_t log2spp, nBase4Digits;        /* ZSobol (samplers.h:228-240) */
+} wf_sampler;
+
+enum wf_light_sampler_type { WF_LS_UNIFORM = 0, WF_LS_POWER = 1, WF_LS_BVH = 2 };
+
+typedef struct wf_options {               /* BasicPBRTOptions subset read by kernels (options.h:22-34) */
+    int32_t seed;
+    int32_t disable_pixel_jitter, disable_wavelength_jitter, disable_texture_filtering;
+} wf_options;
+
+typedef struct wf_scene_desc {
+    int32_t abi_version;
+    /* geometry */
+    int32_t n_vertices, n_triangles, n_meshes, n_bvh_nodes;
+    const float *P;              /* [n_vertices][3] render space */
+    const float *N;              /* [n_vertices][3] (zero for meshes without normals) */
+    const float *UV;             /* [n_vertices][2] */
+    const int32_t *tri_indices;  /* [n_triangles][3] global vertex ids */
+    const int32_t *tri_mesh;     /* [n_triangles] mesh id */
+    const wf_mesh *meshes;
+    const wf_bvh_node *bvh_nodes;
+    const int32_t *bvh_prims;    /* [n_triangles] triangle ids in BVH leaf order */
+    float scene_bounds[6];
+    /* shading */
+    int32_t n_spectra, n_spectrum_floats, n_textures, n_materials;
+    const wf_spectrum *spectra;
+    const float *spectrum_data;
+    const wf_texture *textures;
+    const wf_material *materials;
+    /* lights */
+    int32_t n_lights, n_infinite_lights, n_light_bvh_nodes, n_light_transforms;
+    const wf_light *lights;
+    const int32_t *infinite_lights;
+    const wf_light_bvh_node *light_bvh_nodes;
+    const wf_transform *light_transforms;
+    float all_light_bounds[6];
+    int32_t light_sampler;       /* wf_light_sampler_type */
+    const float *power_alias;    /* POWER: n_lights * {q, p, alias(as int bits)} */
+    /* camera / film / filter / sampler */
+    wf_camera camera;
+    wf_film film;
+    wf_filter filter;
+    int32_t n_filter_floats;
+    const float *filter_data;
+    wf_sampler sampler;
+    /* integrator */
+    int32_t max_depth;
+    int32_t regularize;
+    int32_t have_media;
+    wf_options options;
+} wf_scene_desc;
+
+/* ------------------------------------------------------------------------------------------- */
+/* Work queues: SoA views (wavefront/workitems.soa, workqueue.h)                                 */
+/* Every member is its own capacity-element device array; spectra/wavelengths are float4 arrays. */
+/* ------------------------------------------------------------------------------------------- */
+
+typedef struct wf_f4 { float x, y, z, w; } wf_f4;
+
+/* PixelSampleState, wavefront/workitems.h:107-116 (visibleSurface omitted: RGBFilm never reads it) */
+typedef struct wf_pixel_state {
+    int32_t capacity;
+    float *filterWeight;
+    int32_t *pPixel_x, *pPixel_y;
+    wf_f4 *lambda, *lambda_pdf;
+    wf_f4 *L;
+    wf_f4 *cameraRayWeight;
+    /* RaySamples, workitems.h:41-104: direct{uc,u}, indirect{uc,u,rr} */
+    wf_f4 *samples0;             /* direct.uc, direct.u.x, direct.u.y, indirect.uc */
+    wf_f4 *samples1;             /* indirect.u.x, indirect.u.y, indirect.rr, unused */
+} wf_pixel_state;
+
+/* RayWorkItem, workitems.h:119-130 */
+typedef struct wf_ray_queue {
+    int32_t capacity;
+    int32_t *size;
+    float *ox, *oy, *oz, *dx, *dy, *dz;
+    float *time;
+    int32_t *medium;
+    int32_t *depth;
+    int32_t *pixelIndex;
+    wf_f4 *lambda, *lambda_pdf;
+    wf_f4 *beta, *r_u, *r_l;
+    /* prevIntrCtx: LightSampleContext {Point3fi pi; Normal3f n, ns} */
+    float *ctx_pi_lo_x, *ctx_pi_lo_y, *ctx_pi_lo_z, *ctx_pi_hi_x, *ctx_pi_hi_y, *ctx_pi_hi_z;
+    float *ctx_n_x, *ctx_n_y, *ctx_n_z, *ctx_ns_x, *ctx_ns_y, *ctx_ns_z;
+    float *etaScale;
+    int32_t *flags;              /* bit0 specularBounce, bit1 anyNonSpecularBounces */
+} wf_ray_queue;
+
+/* Result of IntersectClosest per ray, used by parity tests and by the counting variant. */
+typedef struct wf_hit_record {
+    int32_t prim;                /* global triangle id or -1 */
+    float t, b0, b1, b2;
+    int32_t nodes_visited, tris_tested;
+    int32_t pad;
+} wf_hit_record;
+
+typedef struct wf_ctx wf_ctx;    /* opaque: device, stream, uploaded scene, queues, film */
+
+typedef struct wf_render_stats { /* WavefrontPathIntegrator::Stats, integrator.h:174-181 */
+    uint64_t camera_rays;
+    uint64_t indirect_rays[64];
+    uint64_t shadow_rays[64];
+} wf_render_stats;
+
+typedef struct wf_kernel_profile_entry {
+    char name[64];
+    int32_t launches;
+    float total_ms, min_ms, max_ms;
+} wf_kernel_profile_entry;
+
+/* ------------------------------------------------------------------------------------------- */
+/* Entry points                                                                                  */
+/* ------------------------------------------------------------------------------------------- */
+
+const char *wf_last_error(void);
+int wf_abi_version(void);
+
+/* gpu/util.cpp:28-110 GPUInit + gpu/memory.cpp: context, stream, plain hipMalloc arena */
+int wf_ctx_create(int device, wf_ctx **out);
+int wf_ctx_destroy(wf_ctx *ctx);
+int wf_sync(wf_ctx *ctx);                                   /* GPUWait(), gpu/util.h:122 */
+void *wf_stream(wf_ctx *ctx);                               /* hipStream_t as void* */
+
+/* OptiXAggregate ctor + scene managed-memory residency (gpu/optix/aggregate.cpp:1183-1668):
+   uploads the flat tables; BVH is built on the host (host/bvh_build.cpp) and arrives in desc. */
+int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *desc);
+int wf_aggregate_bounds(wf_ctx *ctx, float out_bounds[6]);  /* WavefrontAggregate::Bounds */
+
+/* integrator.cpp:227-274 queue sizing + allocation; film pixels (film.h:302-307) */
+int wf_queues_alloc(wf_ctx *ctx, int max_queue_size);
+int wf_film_clear(wf_ctx *ctx);
+
+/* K1: "Reset ray queue"/"Reset queues before tracing rays"/"Reset shadowRayQueue" (integrator.cpp:357-397,581-585) */
+int wf_reset_ray_queue(wf_ctx *ctx, int which);
+int wf_reset_stage_queues(wf_ctx *ctx, int depth);          /* also accumulates ray stats */
+/* K2: GenerateCameraRays (wavefront/camera.cpp:31-80) */
+int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index);
+/* K3: GenerateRaySamples (wavefront/samples.cpp:29-66) */
+int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index);
+/* K4: WavefrontAggregate::IntersectClosest (integrator.h:37-43) */
+int wf_intersect_closest(wf_ctx *ctx, int depth);
+/* K7/K8: HandleEscapedRays / HandleEmissiveIntersection (integrator.cpp:495-573) */
+int wf_handle_escaped(wf_ctx *ctx);
+int wf_handle_emissive(wf_ctx *ctx);
+/* K9: EvaluateMaterialAndBSDF<M> (wavefront/surfscatter.cpp:57-328), one launch per material type */
+int wf_eval_material(wf_ctx *ctx, int material_type, int depth);
+/* K10: WavefrontAggregate::IntersectShadow (integrator.h:45-46) + RecordShadowRayResult */
+int wf_intersect_shadow(wf_ctx *ctx, int depth);
+/* K13: UpdateFilm (wavefront/film.cpp:14-38) */
+int wf_update_film(wf_ctx *ctx);
+
+/* whole wavefront pass for one sample index over scanlines [y0, y0+scanlinesPerPass): the sequence
+   integrator.cpp:357-434, enqueued without host synchronisation. */
+int wf_render_pass(wf_ctx *ctx, int y0, int sample_index);
+
+/* results */
+int wf_film_download(wf_ctx *ctx, double *rgb_sum_weight /* [H][W][4] */);
+int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes); /* for the RCCL film reduce */
+int wf_film_upload(wf_ctx *ctx, const double *rgb_sum_weight);
+int wf_stats_download(wf_ctx *ctx, wf_render_stats *out);
+int wf_profile_report(wf_ctx *ctx, wf_kernel_profile_entry *entries, int max_entries, int *n_out);
+int wf_profile_enable(wf_ctx *ctx, int enabled);           /* per-launch hipEvent pairs, gpu/util.cpp:136-209 */
+
+/* Stand-alone traversal entry points used by parity tests and the roofline counters:
+   rays given as host arrays (o[3], d[3], tMax), results as wf_hit_record / occluded flags. */
+int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax,
+                          wf_hit_record *out, int count_visits);
+int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax,
+                      int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested);
+/* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample */
+int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index,
+                     int start_dim, int ndims, float *out);
+/* debug/parity access to queues: downloads the named SoA member */
+int wf_queue_size(wf_ctx *ctx, const char *queue, int *size);
+int wf_queue_download(wf_ctx *ctx, const char *queue, const char *member, void *dst, uint64_t nbytes);
+/* algorithmic-byte counters accumulated by the traversal kernels when enabled */
+typedef struct wf_traversal_counters {
+    uint64_t closest_rays, closest_nodes, closest_tris, closest_hits;
+    uint64_t shadow_rays, shadow_nodes, shadow_tris, shadow_unoccluded;
+} wf_traversal_counters;
+int wf_counters_enable(wf_ctx *ctx, int enabled);
+int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WF_ABI_H */

@@ -1,0 +1,156 @@
+// scene.h — host scene description: the .pbrt parser front end (parser.cpp) records entities the way
+// BasicSceneBuilder/BasicScene do (src/pbrt/scene.{h,cpp}, parser.{h,cpp}, paramdict.{h,cpp}), and
+// BuildSceneTables (scene_build.cpp) flattens them into the index-addressed tables of wf_scene_desc.
+#pragma once
+
+#include "hmath.h"
+#include "spectra.h"
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace wf {
+
+// ---- parameters (paramdict.h) ---------------------------------------------------------------------
+struct Param {
+    std::string type, name;
+    std::vector<float> floats;
+    std::vector<int> ints;
+    std::vector<std::string> strings;
+    std::vector<uint8_t> bools;
+    const ColorSpace *colorSpace = nullptr;
+    mutable bool lookedUp = false;
+    std::string loc;
+};
+enum class SpectrumType { Illuminant, Albedo, Unbounded };
+
+class ParamSet {
+  public:
+    std::vector<Param> params;
+    const ColorSpace *colorSpace = nullptr;
+    float GetOneFloat(const std::string &name, float def) const;
+    int GetOneInt(const std::string &name, int def) const;
+    bool GetOneBool(const std::string &name, bool def) const;
+    std::string GetOneString(const std::string &name, const std::string &def) const;
+    std::vector<float> GetFloatArray(const std::string &name) const;
+    std::vector<int> GetIntArray(const std::string &name) const;
+    std::vector<V3> GetPoint3fArray(const std::string &name) const;   // also vector3/normal
+    std::vector<V2> GetPoint2fArray(const std::string &name) const;
+    std::vector<V3> GetTuple3Array(const std::string &name, const char *type) const;
+    bool HasParam(const std::string &name) const;
+    V3 GetOnePoint3f(const std::string &name, V3 def) const;
+    V3 GetOneVector3f(const std::string &name, V3 def) const;
+    // spectrum-valued parameter ("rgb", "spectrum", "blackbody"); null if absent (paramdict.cpp:384-455)
+    SpectrumP GetOneSpectrum(const std::string &name, SpectrumP def, SpectrumType st) const;
+    std::string GetTexture(const std::string &name) const;  // "texture name" parameter or ""
+    const Param *Find(const std::string &name) const;
+    void ReportUnused(const std::string &what) const;
+};
+
+// ---- recorded entities (scene.h:SceneEntity family) -------------------------------------------------
+struct Entity {
+    std::string name;   // implementation name ("perspective", "diffuse", ...)
+    ParamSet params;
+    std::string loc;
+};
+struct TextureEntity : Entity {
+    std::string texName, texType;  // "float" | "spectrum"
+    Transform renderFromTexture;
+};
+struct LightEntity : Entity {
+    Transform renderFromLight;
+    std::string medium;
+};
+struct ShapeEntity : Entity {
+    Transform renderFromObject;
+    bool reverseOrientation = false;
+    int materialIndex = -1;
+    std::string materialName;
+    int lightIndex = -1;
+    std::string insideMedium, outsideMedium;
+};
+struct InstanceDefinition { std::string name; std::vector<ShapeEntity> shapes; };
+struct InstanceUse { std::string name; Transform renderFromInstance; };
+
+struct RenderOptions {  // subset of PBRTOptions (options.h)
+    int seed = 0;
+    int nThreads = 0;
+    bool quiet = false;
+    bool disablePixelJitter = false, disableWavelengthJitter = false, disableTextureFiltering = false;
+    int pixelSamples = -1;               // --spp override
+    int pixelBounds[4] = {0, 0, 0, 0};   // --pixelbounds x0,x1,y0,y1 (all zero = unset)
+    float cropWindow[4] = {0, 0, 0, 0};  // --cropwindow
+    bool hasPixelBounds = false, hasCropWindow = false;
+    std::string imageFile;
+};
+
+struct ParsedScene {
+    Entity camera, film, sampler, filter, integrator, accelerator;
+    Transform cameraFromWorld, worldFromCamera;  // CTM at Camera
+    std::string cameraMedium;
+    const ColorSpace *filmColorSpace = nullptr;
+    std::vector<TextureEntity> textures;
+    std::vector<std::pair<std::string, Entity>> namedMaterials;
+    std::vector<Entity> materials;
+    std::vector<LightEntity> lights;
+    std::vector<Entity> areaLights;
+    std::vector<ShapeEntity> shapes;
+    std::map<std::string, InstanceDefinition> instanceDefinitions;
+    std::vector<InstanceUse> instances;
+    std::vector<std::pair<std::string, Entity>> media;
+    std::map<std::string, Transform> mediaTransforms;
+    std::string baseDir;
+};
+
+// Parses the given files (parser.cpp).  Exits with a message on syntax errors, like the reference.
+void ParseFiles(const std::vector<std::string> &files, RenderOptions *opt, ParsedScene *scene);
+void ParseString(const std::string &text, RenderOptions *opt, ParsedScene *scene);
+
+// ---- flattened scene ------------------------------------------------------------------------------
+// Owns every array wf_scene_desc points into.
+struct SceneTables {
+    wf_scene_desc desc{};
+    std::vector<float> P, N, UV;
+    std::vector<int32_t> triIndices, triMesh, bvhPrims, infiniteLights;
+    std::vector<wf_mesh> meshes;
+    std::vector<wf_bvh_node> bvhNodes;
+    SpectrumPool pool;
+    std::vector<wf_texture> textures;
+    std::vector<wf_material> materials;
+    std::vector<wf_light> lights;
+    std::vector<wf_light_bvh_node> lightBvh;
+    std::vector<wf_transform> lightTransforms;
+    std::vector<float> filterData, powerAlias;
+    std::string imageFile;
+    int spp = 1;
+    // wavefront geometry (integrator.cpp:227-236)
+    int scanlinesPerPass = 0, maxQueueSize = 0, nPasses = 0;
+    bool materialTypePresent[WF_MAT_NTYPES] = {};
+    void Finalize();  // fills desc pointers/counters from the vectors
+};
+
+void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *out);
+
+// geometry BVH (bvh_build.cpp): SAH build restating BVHAggregate (cpu/aggregates.cpp:140-387,505-521)
+void BuildBVH(const std::vector<float> &P, const std::vector<int32_t> &triIndices, int maxPrimsInNode,
+              std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims);
+// light BVH (lightbvh_build.cpp): BVHLightSampler ctor (lightsamplers.cpp:105-232)
+struct LightBoundsH {
+    B3 bounds;
+    float phi = 0;
+    V3 w{0, 0, 0};
+    float cosTheta_o = 0, cosTheta_e = 0;
+    bool twoSided = false;
+    V3 Centroid() const { return (bounds.pMin + bounds.pMax) / 2; }
+};
+void BuildLightBVH(const std::vector<std::pair<int, LightBoundsH>> &bvhLightsIn, const B3 &allLightBounds,
+                   std::vector<wf_light_bvh_node> *nodes, std::vector<wf_light> *lights);
+
+// image output (image_io.cpp)
+bool WritePFM(const std::string &path, const float *rgb, int w, int h);
+bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);
+bool WriteImage(const std::string &path, const float *rgb, int w, int h);  // by extension: .pfm, .exr
+
+}  // namespace wf

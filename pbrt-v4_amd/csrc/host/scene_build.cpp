@@ -1,0 +1,939 @@
+// scene_build.cpp — flattens a ParsedScene into the index-addressed tables of wf_scene_desc.
+// Restates the object construction the reference spreads over BasicScene::Create* (scene.cpp:835-1591)
+// and the per-class ::Create functions, for the feature subset the wavefront kernels implement:
+//   film.cpp:66-172,213-253,484-497,573-585   FilmBaseParameters / PixelSensor / RGBFilm
+//   filters.cpp:26-147                         filters + FilterSampler
+//   cameras.cpp:27-57,269-281,486-528          CameraTransform / Perspective / Orthographic
+//   samplers.cpp:146-170                       ZSobol
+//   materials.cpp:51-659                       material parameter defaults
+//   lights.cpp:120-166,684-941,1345-1380       light parameter handling, scale normalisation, Bounds()
+//   util/mesh.cpp:25-75, shapes.cpp:283-307,368-438  triangle meshes (vertices transformed to render space)
+#include "scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace wf {
+
+[[noreturn]] static void Die(const std::string &loc, const std::string &msg) {
+    fprintf(stderr, "Error: %s: %s\n", loc.c_str(), msg.c_str());
+    exit(1);
+}
+
+void SceneTables::Finalize() {
+    desc.abi_version = WF_ABI_VERSION;
+    desc.n_vertices = (int)P.size() / 3;
+    desc.n_triangles = (int)triIndices.size() / 3;
+    desc.n_meshes = (int)meshes.size();
+    desc.n_bvh_nodes = (int)bvhNodes.size();
+    desc.P = P.data(); desc.N = N.data(); desc.UV = UV.data();
+    desc.tri_indices = triIndices.data(); desc.tri_mesh = triMesh.data();
+    desc.meshes = meshes.data(); desc.bvh_nodes = bvhNodes.data(); desc.bvh_prims = bvhPrims.data();
+    desc.n_spectra = (int)pool.spectra.size(); desc.n_spectrum_floats = (int)pool.data.size();
+    desc.spectra = pool.spectra.data(); desc.spectrum_data = pool.data.data();
+    desc.n_textures = (int)textures.size(); desc.textures = textures.data();
+    desc.n_materials = (int)materials.size(); desc.materials = materials.data();
+    desc.n_lights = (int)lights.size(); desc.lights = lights.data();
+    desc.n_infinite_lights = (int)infiniteLights.size(); desc.infinite_lights = infiniteLights.data();
+    desc.n_light_bvh_nodes = (int)lightBvh.size(); desc.light_bvh_nodes = lightBvh.data();
+    desc.n_light_transforms = (int)lightTransforms.size(); desc.light_transforms = lightTransforms.data();
+    desc.power_alias = powerAlias.data();
+    desc.n_filter_floats = (int)filterData.size(); desc.filter_data = filterData.data();
+}
+
+namespace {
+
+// ---- textures & materials ---------------------------------------------------------------------------
+struct TexBuilder {
+    SceneTables *T;
+    std::map<std::string, int> floatTextures, spectrumTexturesAlbedo, spectrumTexturesUnbounded, spectrumTexturesIllum;
+    const ParsedScene *scene;
+
+    int AddTex(const wf_texture &t) { T->textures.push_back(t); return (int)T->textures.size() - 1; }
+    int FloatConst(float v) {
+        wf_texture t{};
+        t.type = WF_TEX_FLOAT_CONSTANT; t.f0 = v; t.spectrum = t.tex0 = t.tex1 = t.tex2 = -1;
+        return AddTex(t);
+    }
+    int SpectrumConst(const SpectrumH &s) {
+        wf_texture t{};
+        t.type = WF_TEX_SPECTRUM_CONSTANT; t.spectrum = T->pool.Add(s); t.tex0 = t.tex1 = t.tex2 = -1;
+        return AddTex(t);
+    }
+    std::map<std::string, int> &SpecMap(SpectrumType st) {
+        return st == SpectrumType::Albedo ? spectrumTexturesAlbedo : (st == SpectrumType::Unbounded ? spectrumTexturesUnbounded : spectrumTexturesIllum);
+    }
+    // TextureParameterDictionary::GetFloatTextureOrNull (paramdict.cpp:700-745)
+    int GetFloatTextureOrNull(const ParamSet &ps, const std::string &name) {
+        for (const Param &p : ps.params) {
+            if (p.name != name) continue;
+            if (p.type == "texture") {
+                p.lookedUp = true;
+                auto it = floatTextures.find(p.strings.at(0));
+                if (it == floatTextures.end()) Die(p.loc, "Couldn't find float texture named \"" + p.strings[0] + "\" for parameter \"" + name + "\"");
+                return it->second;
+            } else if (p.type == "float") {
+                p.lookedUp = true;
+                return FloatConst(p.floats.at(0));
+            }
+        }
+        return -1;
+    }
+    int GetFloatTexture(const ParamSet &ps, const std::string &name, float def) {
+        int t = GetFloatTextureOrNull(ps, name);
+        return t >= 0 ? t : FloatConst(def);
+    }
+    // TextureParameterDictionary::GetSpectrumTextureOrNull (paramdict.cpp:747-820)
+    int GetSpectrumTextureOrNull(const ParamSet &ps, const std::string &name, SpectrumType st) {
+        for (const Param &p : ps.params) {
+            if (p.name != name) continue;
+            if (p.type == "texture") {
+                p.lookedUp = true;
+                auto &m = SpecMap(st);
+                auto it = m.find(p.strings.at(0));
+                if (it == m.end()) Die(p.loc, "Couldn't find spectrum texture named \"" + p.strings[0] + "\" for parameter \"" + name + "\"");
+                return it->second;
+            } else if (p.type == "rgb" || p.type == "spectrum" || p.type == "blackbody") {
+                SpectrumP s = ps.GetOneSpectrum(name, nullptr, st);
+                if (s) return SpectrumConst(*s);
+            }
+        }
+        return -1;
+    }
+    int GetSpectrumTexture(const ParamSet &ps, const std::string &name, const SpectrumH &def, SpectrumType st) {
+        int t = GetSpectrumTextureOrNull(ps, name, st);
+        return t >= 0 ? t : SpectrumConst(def);
+    }
+
+    void CreateNamedTextures() {
+        for (const TextureEntity &te : scene->textures) {
+            const ParamSet &ps = te.params;
+            if (te.texType == "float") {
+                wf_texture t{};
+                t.spectrum = t.tex0 = t.tex1 = t.tex2 = -1;
+                if (te.name == "constant") { t.type = WF_TEX_FLOAT_CONSTANT; t.f0 = ps.GetOneFloat("value", 1.f); }
+                else if (te.name == "scale") {
+                    t.type = WF_TEX_FLOAT_SCALE;
+                    t.tex0 = GetFloatTexture(ps, "tex", 1.f);
+                    t.tex1 = GetFloatTexture(ps, "scale", 1.f);
+                } else if (te.name == "mix") {
+                    t.type = WF_TEX_FLOAT_MIX;
+                    t.tex0 = GetFloatTexture(ps, "tex1", 0.f);
+                    t.tex1 = GetFloatTexture(ps, "tex2", 1.f);
+                    t.tex2 = GetFloatTexture(ps, "amount", 0.5f);
+                } else Die(te.loc, te.name + ": float texture type not supported by this build");
+                if (floatTextures.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
+                floatTextures[te.texName] = AddTex(t);
+            } else {
+                // the reference instantiates each spectrum texture three times, once per SpectrumType
+                for (SpectrumType st : {SpectrumType::Albedo, SpectrumType::Unbounded, SpectrumType::Illuminant}) {
+                    wf_texture t{};
+                    t.spectrum = t.tex0 = t.tex1 = t.tex2 = -1;
+                    if (te.name == "constant") {
+                        SpectrumP one = MakeConstant(1.f);
+                        SpectrumP s = ps.GetOneSpectrum("value", one, st);
+                        t.type = WF_TEX_SPECTRUM_CONSTANT; t.spectrum = T->pool.Add(*s);
+                    } else if (te.name == "scale") {
+                        t.type = WF_TEX_SPECTRUM_SCALE;
+                        t.tex0 = GetSpectrumTexture(ps, "tex", *MakeConstant(1.f), st);
+                        t.tex1 = GetFloatTexture(ps, "scale", 1.f);
+                    } else if (te.name == "mix") {
+                        t.type = WF_TEX_SPECTRUM_MIX;
+                        t.tex0 = GetSpectrumTexture(ps, "tex1", *MakeConstant(0.f), st);
+                        t.tex1 = GetSpectrumTexture(ps, "tex2", *MakeConstant(1.f), st);
+                        t.tex2 = GetFloatTexture(ps, "amount", 0.5f);
+                    } else Die(te.loc, te.name + ": spectrum texture type not supported by this build");
+                    auto &m = SpecMap(st);
+                    if (st == SpectrumType::Albedo && m.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
+                    m[te.texName] = AddTex(t);
+                }
+            }
+        }
+    }
+
+    SpectrumP GetEta(const ParamSet &ps, const std::string &name) {
+        std::vector<float> fa = ps.GetFloatArray(name);
+        if (!fa.empty()) return MakeConstant(fa[0]);
+        SpectrumP eta = ps.GetOneSpectrum(name, nullptr, SpectrumType::Unbounded);
+        if (!eta) eta = MakeConstant(1.5f);
+        return eta;
+    }
+
+    int CreateMaterial(const Entity &e) {
+        const ParamSet &ps = e.params;
+        wf_material m{};
+        for (int &t : m.tex) t = -1;
+        m.eta_spectrum = -1;
+        m.displacement = GetFloatTextureOrNull(ps, "displacement");
+        m.normalmap = -1;
+        if (!ps.GetOneString("normalmap", "").empty()) Die(e.loc, "normalmap is not supported by this build");
+        if (m.displacement >= 0) Die(e.loc, "displacement (bump mapping) is not supported by this build");
+        const std::string &name = e.name;
+        auto roughness = [&](const char *u, const char *v, const char *r, int us, int vs) {
+            int ur = GetFloatTextureOrNull(ps, u), vr = GetFloatTextureOrNull(ps, v);
+            if (ur < 0) ur = GetFloatTexture(ps, r, 0.f);
+            if (vr < 0) vr = GetFloatTexture(ps, r, 0.f);
+            m.tex[us] = ur; m.tex[vs] = vr;
+        };
+        auto conductorParams = [&](const char *etaName, const char *kName, int etaSlot, int kSlot) {
+            int eta = GetSpectrumTextureOrNull(ps, etaName, SpectrumType::Unbounded);
+            int k = GetSpectrumTextureOrNull(ps, kName, SpectrumType::Unbounded);
+            int refl = GetSpectrumTextureOrNull(ps, "reflectance", SpectrumType::Albedo);
+            if (refl >= 0 && (eta >= 0 || k >= 0)) Die(e.loc, "both \"reflectance\" and \"eta\" and \"k\" can't be provided.");
+            if (refl < 0) {
+                if (eta < 0) eta = SpectrumConst(*SpectralData::Get().Named("metal-Cu-eta"));
+                if (k < 0) k = SpectrumConst(*SpectralData::Get().Named("metal-Cu-k"));
+            } else m.flags |= WF_MATFLAG_CONDUCTOR_REFLECTANCE;
+            m.tex[etaSlot] = eta; m.tex[kSlot] = k; m.tex[WF_MT_REFLECTANCE] = refl;
+        };
+        if (name == "diffuse") {
+            m.type = WF_MAT_DIFFUSE;
+            m.tex[WF_MT_REFLECTANCE] = GetSpectrumTexture(ps, "reflectance", *MakeConstant(0.5f), SpectrumType::Albedo);
+        } else if (name == "conductor") {
+            m.type = WF_MAT_CONDUCTOR;
+            conductorParams("eta", "k", WF_MT_ETA, WF_MT_K);
+            roughness("uroughness", "vroughness", "roughness", WF_MT_UROUGH, WF_MT_VROUGH);
+            if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
+        } else if (name == "dielectric") {
+            m.type = WF_MAT_DIELECTRIC;
+            m.eta_spectrum = T->pool.Add(*GetEta(ps, "eta"));
+            roughness("uroughness", "vroughness", "roughness", WF_MT_UROUGH, WF_MT_VROUGH);
+            if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
+        } else if (name == "thindielectric") {
+            m.type = WF_MAT_THIN_DIELECTRIC;
+            m.eta_spectrum = T->pool.Add(*GetEta(ps, "eta"));
+        } else if (name == "diffusetransmission") {
+            m.type = WF_MAT_DIFFUSE_TRANSMISSION;
+            m.tex[WF_MT_REFLECTANCE] = GetSpectrumTexture(ps, "reflectance", *MakeConstant(0.25f), SpectrumType::Albedo);
+            m.tex[WF_MT_TRANSMITTANCE] = GetSpectrumTexture(ps, "transmittance", *MakeConstant(0.25f), SpectrumType::Albedo);
+            m.scale = ps.GetOneFloat("scale", 1.f);
+        } else if (name == "coateddiffuse") {
+            m.type = WF_MAT_COATED_DIFFUSE;
+            m.tex[WF_MT_REFLECTANCE] = GetSpectrumTexture(ps, "reflectance", *MakeConstant(0.5f), SpectrumType::Albedo);
+            roughness("uroughness", "vroughness", "roughness", WF_MT_UROUGH, WF_MT_VROUGH);
+            m.tex[WF_MT_THICKNESS] = GetFloatTexture(ps, "thickness", .01f);
+            m.eta_spectrum = T->pool.Add(*GetEta(ps, "eta"));
+            m.maxdepth = ps.GetOneInt("maxdepth", 10);
+            m.nsamples = ps.GetOneInt("nsamples", 1);
+            m.tex[WF_MT_G] = GetFloatTexture(ps, "g", 0.f);
+            m.tex[WF_MT_ALBEDO] = GetSpectrumTexture(ps, "albedo", *MakeConstant(0.f), SpectrumType::Albedo);
+            if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
+        } else if (name == "coatedconductor") {
+            m.type = WF_MAT_COATED_CONDUCTOR;
+            roughness("interface.uroughness", "interface.vroughness", "interface.roughness", WF_MT_UROUGH, WF_MT_VROUGH);
+            m.tex[WF_MT_THICKNESS] = GetFloatTexture(ps, "thickness", .01f);
+            m.eta_spectrum = T->pool.Add(*GetEta(ps, "interface.eta"));
+            roughness("conductor.uroughness", "conductor.vroughness", "conductor.roughness", WF_MT_COND_UROUGH, WF_MT_COND_VROUGH);
+            conductorParams("conductor.eta", "conductor.k", WF_MT_COND_ETA, WF_MT_COND_K);
+            m.maxdepth = ps.GetOneInt("maxdepth", 10);
+            m.nsamples = ps.GetOneInt("nsamples", 1);
+            m.tex[WF_MT_G] = GetFloatTexture(ps, "g", 0.f);
+            m.tex[WF_MT_ALBEDO] = GetSpectrumTexture(ps, "albedo", *MakeConstant(0.f), SpectrumType::Albedo);
+            if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
+        } else if (name == "interface" || name == "none" || name.empty()) {
+            m.type = WF_MAT_INTERFACE;
+        } else Die(e.loc, name + ": material type not supported by this build");
+        T->materialTypePresent[m.type] = true;
+        T->materials.push_back(m);
+        return (int)T->materials.size() - 1;
+    }
+};
+
+// ---- filter ---------------------------------------------------------------------------------------
+struct FilterH {
+    int type;
+    float rx, ry, sigma = 0.5f, expX = 0, expY = 0, b = 1.f / 3.f, c = 1.f / 3.f, tau = 3.f;
+    static float Sinc(float x) {  // util/math.h:227-231, SinXOverX :340-344
+        float px = Pi * x;
+        if (1 - px * px == 1) return 1;
+        return std::sin(px) / px;
+    }
+    static float WindowedSinc(float x, float radius, float tau) {
+        if (std::abs(x) > radius) return 0;
+        return Sinc(x) * Sinc(x / tau);
+    }
+    float Mitchell1D(float x) const {
+        x = std::abs(x);
+        if (x <= 1) return ((12 - 9 * b - 6 * c) * x * x * x + (-18 + 12 * b + 6 * c) * x * x + (6 - 2 * b)) * (1.f / 6.f);
+        else if (x <= 2) return ((-b - 6 * c) * x * x * x + (6 * b + 30 * c) * x * x + (-12 * b - 48 * c) * x + (8 * b + 24 * c)) * (1.f / 6.f);
+        else return 0;
+    }
+    float Evaluate(float px, float py) const {
+        switch (type) {
+        case WF_FILTER_BOX: return (std::abs(px) <= rx && std::abs(py) <= ry) ? 1 : 0;
+        case WF_FILTER_GAUSSIAN: return std::max<float>(0, Gaussian(px, 0, sigma) - expX) * std::max<float>(0, Gaussian(py, 0, sigma) - expY);
+        case WF_FILTER_MITCHELL: return Mitchell1D(2 * px / rx) * Mitchell1D(2 * py / ry);
+        case WF_FILTER_SINC: return WindowedSinc(px, rx, tau) * WindowedSinc(py, ry, tau);
+        case WF_FILTER_TRIANGLE: return std::max<float>(0, rx - std::abs(px)) * std::max<float>(0, ry - std::abs(py));
+        }
+        return 0;
+    }
+};
+
+// PiecewiseConstant1D construction (util/sampling.h:620-645)
+void BuildPC1D(const float *f, int n, float mn, float mx, std::vector<float> *func, std::vector<float> *cdf, float *funcInt) {
+    func->assign(f, f + n);
+    cdf->assign(n + 1, 0.f);
+    for (float &v : *func) v = std::abs(v);
+    (*cdf)[0] = 0;
+    for (int i = 1; i < n + 1; ++i) (*cdf)[i] = (*cdf)[i - 1] + (*func)[i - 1] * (mx - mn) / n;
+    *funcInt = (*cdf)[n];
+    if (*funcInt == 0) for (int i = 1; i < n + 1; ++i) (*cdf)[i] = float(i) / float(n);
+    else for (int i = 1; i < n + 1; ++i) (*cdf)[i] /= *funcInt;
+}
+
+void BuildFilter(const ParsedScene &scene, SceneTables *T) {
+    const Entity &e = scene.filter;
+    const ParamSet &ps = e.params;
+    FilterH f{};
+    wf_filter &wfF = T->desc.filter;
+    if (e.name == "box") { f.type = WF_FILTER_BOX; f.rx = ps.GetOneFloat("xradius", 0.5f); f.ry = ps.GetOneFloat("yradius", 0.5f); }
+    else if (e.name == "gaussian") {
+        f.type = WF_FILTER_GAUSSIAN; f.rx = ps.GetOneFloat("xradius", 1.5f); f.ry = ps.GetOneFloat("yradius", 1.5f);
+        f.sigma = ps.GetOneFloat("sigma", 0.5f);
+        f.expX = Gaussian(f.rx, 0, f.sigma); f.expY = Gaussian(f.ry, 0, f.sigma);
+    } else if (e.name == "mitchell") {
+        f.type = WF_FILTER_MITCHELL; f.rx = ps.GetOneFloat("xradius", 2.f); f.ry = ps.GetOneFloat("yradius", 2.f);
+        f.b = ps.GetOneFloat("B", 1.f / 3.f); f.c = ps.GetOneFloat("C", 1.f / 3.f);
+    } else if (e.name == "sinc") {
+        f.type = WF_FILTER_SINC; f.rx = ps.GetOneFloat("xradius", 4.f); f.ry = ps.GetOneFloat("yradius", 4.f);
+        f.tau = ps.GetOneFloat("tau", 3.f);
+    } else if (e.name == "triangle") { f.type = WF_FILTER_TRIANGLE; f.rx = ps.GetOneFloat("xradius", 2.f); f.ry = ps.GetOneFloat("yradius", 2.f); }
+    else Die(e.loc, e.name + ": filter type unknown.");
+    ps.ReportUnused("PixelFilter");
+    wfF.type = f.type; wfF.radius[0] = f.rx; wfF.radius[1] = f.ry;
+    wfF.domain_min[0] = -f.rx; wfF.domain_min[1] = -f.ry; wfF.domain_max[0] = f.rx; wfF.domain_max[1] = f.ry;
+    wfF.nx = wfF.ny = 0;
+    if (f.type == WF_FILTER_BOX || f.type == WF_FILTER_TRIANGLE) return;  // analytic Sample()
+    // FilterSampler (filters.cpp:133-147)
+    int nx = int(32 * f.rx), ny = int(32 * f.ry);
+    wfF.nx = nx; wfF.ny = ny;
+    std::vector<float> tab((size_t)nx * ny);
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            float tx = (x + 0.5f) / nx, ty = (y + 0.5f) / ny;
+            // Bounds2f::Lerp: (Lerp(t.x, pMin.x, pMax.x), Lerp(t.y, pMin.y, pMax.y))
+            float px = Lerp(tx, -f.rx, f.rx), py = Lerp(ty, -f.ry, f.ry);
+            tab[(size_t)y * nx + x] = f.Evaluate(px, py);
+        }
+    std::vector<float> &D = T->filterData;
+    wfF.f_offset = (int)D.size();
+    D.insert(D.end(), tab.begin(), tab.end());
+    // PiecewiseConstant2D (util/sampling.h:706-722)
+    std::vector<float> condFunc, condCdf, condInt(ny);
+    for (int v = 0; v < ny; ++v) {
+        std::vector<float> fn, cdf;
+        float fi;
+        BuildPC1D(&tab[(size_t)v * nx], nx, -f.rx, f.rx, &fn, &cdf, &fi);
+        condFunc.insert(condFunc.end(), fn.begin(), fn.end());
+        condCdf.insert(condCdf.end(), cdf.begin(), cdf.end());
+        condInt[v] = fi;
+    }
+    std::vector<float> mFunc, mCdf;
+    float mInt;
+    BuildPC1D(condInt.data(), ny, -f.ry, f.ry, &mFunc, &mCdf, &mInt);
+    wfF.cond_func_offset = (int)D.size(); D.insert(D.end(), condFunc.begin(), condFunc.end());
+    wfF.cond_cdf_offset = (int)D.size(); D.insert(D.end(), condCdf.begin(), condCdf.end());
+    wfF.cond_int_offset = (int)D.size(); D.insert(D.end(), condInt.begin(), condInt.end());
+    wfF.marg_func_offset = (int)D.size(); D.insert(D.end(), mFunc.begin(), mFunc.end());
+    wfF.marg_cdf_offset = (int)D.size(); D.insert(D.end(), mCdf.begin(), mCdf.end());
+    wfF.marg_int = mInt;
+}
+
+// ---- film / sampler / camera -------------------------------------------------------------------------
+void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
+    const ParamSet &ps = scene.film.params;
+    if (scene.film.name != "rgb") Die(scene.film.loc, scene.film.name + ": only the \"rgb\" film is supported by this build");
+    wf_film &F = T->desc.film;
+    float exposureTime = scene.camera.params.GetOneFloat("shutterclose", 1.f) - scene.camera.params.GetOneFloat("shutteropen", 0.f);
+    F.max_component_value = ps.GetOneFloat("maxcomponentvalue", WF_INFINITY);
+    ps.GetOneBool("savefp16", true);
+    // PixelSensor::Create (film.cpp:213-253)
+    float ISO = ps.GetOneFloat("iso", 100.f);
+    float whiteBalanceTemp = ps.GetOneFloat("whitebalance", 0);
+    std::string sensorName = ps.GetOneString("sensor", "cie1931");
+    if (sensorName != "cie1931") Die(scene.film.loc, sensorName + ": only the \"cie1931\" sensor is supported by this build");
+    F.imaging_ratio = exposureTime * ISO / 100;
+    const SpectralData &sd = SpectralData::Get();
+    const ColorSpace *cs = scene.filmColorSpace;
+    Mat3 XYZFromSensorRGB = Mat3::Identity();
+    if (whiteBalanceTemp != 0) Die(scene.film.loc, "whitebalance is not supported by this build");
+    F.rbar_offset = T->pool.AddDense(*sd.X);
+    F.gbar_offset = T->pool.AddDense(*sd.Y);
+    F.bbar_offset = T->pool.AddDense(*sd.Z);
+    Mat3 out = cs->RGBFromXYZ * XYZFromSensorRGB;  // film.cpp:496
+    std::memcpy(F.XYZFromSensorRGB, XYZFromSensorRGB.m, sizeof(F.XYZFromSensorRGB));
+    std::memcpy(F.outputRGBFromSensorRGB, out.m, sizeof(F.outputRGBFromSensorRGB));
+    // FilmBaseParameters (film.cpp:66-172)
+    T->imageFile = ps.GetOneString("filename", "");
+    if (!opt.imageFile.empty()) T->imageFile = opt.imageFile;
+    else if (T->imageFile.empty()) T->imageFile = "pbrt.pfm";
+    F.full_res[0] = ps.GetOneInt("xresolution", 1280);
+    F.full_res[1] = ps.GetOneInt("yresolution", 720);
+    int pb[4] = {0, 0, F.full_res[0], F.full_res[1]};  // xmin, ymin, xmax, ymax
+    auto intersect = [&](int x0, int y0, int x1, int y1) {
+        pb[0] = std::max(pb[0], x0); pb[1] = std::max(pb[1], y0); pb[2] = std::min(pb[2], x1); pb[3] = std::min(pb[3], y1);
+    };
+    std::vector<int> pbv = ps.GetIntArray("pixelbounds");
+    if (opt.hasPixelBounds) intersect(opt.pixelBounds[0], opt.pixelBounds[2], opt.pixelBounds[1], opt.pixelBounds[3]);
+    else if (pbv.size() == 4) intersect(pbv[0], pbv[2], pbv[1], pbv[3]);
+    std::vector<float> cr = ps.GetFloatArray("cropwindow");
+    const float *crop = nullptr;
+    float cropv[4];
+    if (opt.hasCropWindow) crop = opt.cropWindow;
+    else if (cr.size() == 4) { std::memcpy(cropv, cr.data(), 16); crop = cropv; }
+    if (crop) {
+        float c0 = Clamp(crop[0], 0.f, 1.f), c1 = Clamp(crop[1], 0.f, 1.f), c2 = Clamp(crop[2], 0.f, 1.f), c3 = Clamp(crop[3], 0.f, 1.f);
+        pb[0] = (int)std::ceil(F.full_res[0] * c0); pb[1] = (int)std::ceil(F.full_res[1] * c2);
+        pb[2] = (int)std::ceil(F.full_res[0] * c1); pb[3] = (int)std::ceil(F.full_res[1] * c3);
+    }
+    if (pb[0] >= pb[2] || pb[1] >= pb[3]) Die(scene.film.loc, "Degenerate pixel bounds provided to film");
+    F.pixel_min[0] = pb[0]; F.pixel_min[1] = pb[1]; F.pixel_max[0] = pb[2]; F.pixel_max[1] = pb[3];
+    ps.GetOneFloat("diagonal", 35.f);
+    ps.ReportUnused("Film");
+}
+
+void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
+    const ParamSet &ps = scene.sampler.params;
+    wf_sampler &S = T->desc.sampler;
+    int nsamp = ps.GetOneInt("pixelsamples", 16);
+    if (opt.pixelSamples > 0) nsamp = opt.pixelSamples;
+    S.seed = ps.GetOneInt("seed", opt.seed);
+    if (scene.sampler.name == "zsobol") {
+        S.type = WF_SAMPLER_ZSOBOL;
+        std::string s = ps.GetOneString("randomization", "fastowen");
+        if (s == "none") S.randomize = WF_RAND_NONE;
+        else if (s == "permutedigits") S.randomize = WF_RAND_PERMUTE_DIGITS;
+        else if (s == "fastowen") S.randomize = WF_RAND_FAST_OWEN;
+        else if (s == "owen") S.randomize = WF_RAND_OWEN;
+        else Die(scene.sampler.loc, s + ": unknown randomization strategy given to ZSobolSampler");
+        if (nsamp & (nsamp - 1)) fprintf(stderr, "Warning: Sobol samplers with non power-of-two sample counts (%d) are suboptimal.\n", nsamp);
+        // samplers.h:228-240
+        auto Log2Int = [](uint32_t v) { return 31 - __builtin_clz(v); };
+        auto RoundUpPow2 = [](int32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; };
+        S.log2spp = Log2Int((uint32_t)nsamp);
+        int res = RoundUpPow2(std::max(T->desc.film.full_res[0], T->desc.film.full_res[1]));
+        int log4spp = (S.log2spp + 1) / 2;
+        S.nBase4Digits = Log2Int((uint32_t)res) + log4spp;
+        S.spp = 1 << S.log2spp;
+    } else if (scene.sampler.name == "independent") {
+        S.type = WF_SAMPLER_INDEPENDENT;
+        S.spp = nsamp;
+    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, independent)");
+    T->spp = S.spp;
+    ps.ReportUnused("Sampler");
+}
+
+void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, SceneTables *T) {
+    const ParamSet &ps = scene.camera.params;
+    wf_camera &C = T->desc.camera;
+    const wf_film &F = T->desc.film;
+    C.shutterOpen = ps.GetOneFloat("shutteropen", 0.f);
+    C.shutterClose = ps.GetOneFloat("shutterclose", 1.f);
+    if (C.shutterClose < C.shutterOpen) std::swap(C.shutterClose, C.shutterOpen);
+    C.medium = -1;
+    Transform renderFromCamera = renderFromWorld * scene.worldFromCamera;  // cameras.cpp:52-56
+    C.renderFromCamera = renderFromCamera.abi();
+    float lensradius = ps.GetOneFloat("lensradius", 0.f);
+    float focaldistance = ps.GetOneFloat("focaldistance", 1e6f);
+    float frame = ps.GetOneFloat("frameaspectratio", float(F.full_res[0]) / float(F.full_res[1]));
+    float sMinX, sMaxX, sMinY, sMaxY;
+    if (frame > 1.f) { sMinX = -frame; sMaxX = frame; sMinY = -1.f; sMaxY = 1.f; }
+    else { sMinX = -1.f; sMaxX = 1.f; sMinY = -1.f / frame; sMaxY = 1.f / frame; }
+    std::vector<float> sw = ps.GetFloatArray("screenwindow");
+    if (sw.size() == 4) { sMinX = sw[0]; sMaxX = sw[1]; sMinY = sw[2]; sMaxY = sw[3]; }
+    Transform screenFromCamera;
+    if (scene.camera.name == "perspective") {
+        C.type = WF_CAMERA_PERSPECTIVE;
+        float fov = ps.GetOneFloat("fov", 90.f);
+        screenFromCamera = Perspective(fov, 1e-2f, 1000.f);
+    } else if (scene.camera.name == "orthographic") {
+        C.type = WF_CAMERA_ORTHOGRAPHIC;
+        screenFromCamera = Orthographic(0, 1);
+    } else Die(scene.camera.loc, scene.camera.name + ": camera type not supported by this build (perspective, orthographic)");
+    // ProjectiveCamera (cameras.h:243-263)
+    Transform NDCFromScreen = Scale(1 / (sMaxX - sMinX), 1 / (sMaxY - sMinY), 1) * Translate(V3{-sMinX, -sMaxY, 0});
+    Transform rasterFromNDC = Scale((float)F.full_res[0], -(float)F.full_res[1], 1);
+    Transform rasterFromScreen = rasterFromNDC * NDCFromScreen;
+    Transform screenFromRaster = Inverse(rasterFromScreen);
+    Transform cameraFromRaster = Inverse(screenFromCamera) * screenFromRaster;
+    C.cameraFromRaster = cameraFromRaster.abi();
+    C.lensRadius = lensradius;
+    C.focalDistance = focaldistance;
+    V3 dx, dy;
+    if (C.type == WF_CAMERA_PERSPECTIVE) {
+        dx = cameraFromRaster.Point(V3{1, 0, 0}) - cameraFromRaster.Point(V3{0, 0, 0});
+        dy = cameraFromRaster.Point(V3{0, 1, 0}) - cameraFromRaster.Point(V3{0, 0, 0});
+    } else {
+        dx = cameraFromRaster.Vector(V3{1, 0, 0});
+        dy = cameraFromRaster.Vector(V3{0, 1, 0});
+        for (int i = 0; i < 3; ++i) { C.minPosDifferentialX[i] = dx[i]; C.minPosDifferentialY[i] = dy[i]; }
+    }
+    for (int i = 0; i < 3; ++i) { C.dxCamera[i] = dx[i]; C.dyCamera[i] = dy[i]; }
+    ps.ReportUnused("Camera");
+}
+
+// ---- shapes -----------------------------------------------------------------------------------------
+struct MeshSource {
+    std::vector<int> indices;
+    std::vector<V3> P, N;
+    std::vector<V2> uv;
+};
+
+bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err);
+
+bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSource *m) {
+    const ParamSet &ps = sh.params;
+    if (sh.name == "trianglemesh") {
+        m->indices = ps.GetIntArray("indices");
+        m->P = ps.GetPoint3fArray("P");
+        m->uv = ps.GetPoint2fArray("uv");
+        m->N = ps.GetTuple3Array("N", "normal");
+        if (m->N.empty()) m->N = ps.GetTuple3Array("N", "normal3");
+        if (m->indices.empty()) {
+            if (m->P.size() == 3) m->indices = {0, 1, 2};
+            else { fprintf(stderr, "Error: %s: Vertex indices \"indices\" must be provided with triangle mesh.\n", sh.loc.c_str()); return false; }
+        } else while (m->indices.size() % 3) m->indices.pop_back();
+        if (m->P.empty()) { fprintf(stderr, "Error: %s: Vertex positions \"P\" must be provided with triangle mesh.\n", sh.loc.c_str()); return false; }
+        if (!m->uv.empty() && m->uv.size() != m->P.size()) m->uv.clear();
+        if (!m->N.empty() && m->N.size() != m->P.size()) m->N.clear();
+        for (int vi : m->indices) if (vi < 0 || vi >= (int)m->P.size()) { fprintf(stderr, "Error: %s: trianglemesh has out of-bounds vertex index %d\n", sh.loc.c_str(), vi); return false; }
+        if (!ps.GetTuple3Array("S", "vector3").empty()) fprintf(stderr, "Warning: %s: \"S\" tangents are ignored by this build\n", sh.loc.c_str());
+        return true;
+    } else if (sh.name == "plymesh") {
+        std::string fn = ps.GetOneString("filename", "");
+        if (!fn.empty() && fn[0] != '/') fn = baseDir + "/" + fn;
+        std::string err;
+        if (!ReadPLY(fn, m, &err)) Die(sh.loc, fn + ": " + err);
+        if (!ps.GetTexture("displacement").empty()) Die(sh.loc, "plymesh displacement is not supported by this build");
+        return true;
+    }
+    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh)");
+}
+
+// Minimal PLY reader (ascii + binary_little_endian; vertex x,y,z[,nx,ny,nz][,u,v|s,t], face vertex_indices
+// with triangles or quads split as (0,1,2),(0,2,3) — TriQuadMesh::ReadPLY + ConvertToOnlyTriangles, util/mesh.cpp:158-420)
+bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
+    std::ifstream in(fn, std::ios::binary);
+    if (!in) { *err = "unable to open PLY file"; return false; }
+    std::string line;
+    std::getline(in, line);
+    if (line.substr(0, 3) != "ply") { *err = "not a PLY file"; return false; }
+    enum { ASCII, BLE, BBE } fmt = ASCII;
+    struct Prop { std::string name, type, countType; bool list = false; };
+    struct Elem { std::string name; long count = 0; std::vector<Prop> props; };
+    std::vector<Elem> elems;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ls(line);
+        std::string kw;
+        ls >> kw;
+        if (kw == "format") { std::string f; ls >> f; fmt = f == "ascii" ? ASCII : (f == "binary_little_endian" ? BLE : BBE); }
+        else if (kw == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+        else if (kw == "property") {
+            Prop p; std::string t; ls >> t;
+            if (t == "list") { p.list = true; ls >> p.countType >> p.type >> p.name; }
+            else { p.type = t; ls >> p.name; }
+            if (elems.empty()) { *err = "property before element"; return false; }
+            elems.back().props.push_back(p);
+        } else if (kw == "end_header") break;
+    }
+    if (fmt == BBE) { *err = "big-endian PLY is not supported"; return false; }
+    auto typeSize = [](const std::string &t) {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+        return 8;
+    };
+    auto readNum = [&](const std::string &t) -> double {
+        if (fmt == ASCII) { double v; in >> v; return v; }
+        char buf[8];
+        int n = typeSize(t);
+        in.read(buf, n);
+        if (t == "char" || t == "int8") return *(int8_t *)buf;
+        if (t == "uchar" || t == "uint8") return *(uint8_t *)buf;
+        if (t == "short" || t == "int16") { int16_t v; memcpy(&v, buf, 2); return v; }
+        if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, buf, 2); return v; }
+        if (t == "int" || t == "int32") { int32_t v; memcpy(&v, buf, 4); return v; }
+        if (t == "uint" || t == "uint32") { uint32_t v; memcpy(&v, buf, 4); return v; }
+        if (t == "float" || t == "float32") { float v; memcpy(&v, buf, 4); return v; }
+        double v; memcpy(&v, buf, 8); return v;
+    };
+    for (const Elem &e : elems) {
+        if (e.name == "vertex") {
+            bool hasN = false, hasUV = false;
+            for (const Prop &p : e.props) { if (p.name == "nx") hasN = true; if (p.name == "u" || p.name == "s" || p.name == "texture_u" || p.name == "texture_s") hasUV = true; }
+            out->P.resize(e.count);
+            if (hasN) out->N.resize(e.count);
+            if (hasUV) out->uv.resize(e.count);
+            for (long i = 0; i < e.count; ++i)
+                for (const Prop &p : e.props) {
+                    if (p.list) { int n = (int)readNum(p.countType); for (int k = 0; k < n; ++k) readNum(p.type); continue; }
+                    float v = (float)readNum(p.type);
+                    if (p.name == "x") out->P[i].x = v; else if (p.name == "y") out->P[i].y = v; else if (p.name == "z") out->P[i].z = v;
+                    else if (p.name == "nx") out->N[i].x = v; else if (p.name == "ny") out->N[i].y = v; else if (p.name == "nz") out->N[i].z = v;
+                    else if (p.name == "u" || p.name == "s" || p.name == "texture_u" || p.name == "texture_s") out->uv[i].x = v;
+                    else if (p.name == "v" || p.name == "t" || p.name == "texture_v" || p.name == "texture_t") out->uv[i].y = v;
+                }
+        } else if (e.name == "face") {
+            std::vector<int> quads;
+            for (long i = 0; i < e.count; ++i)
+                for (const Prop &p : e.props) {
+                    if (!p.list) { readNum(p.type); continue; }
+                    int n = (int)readNum(p.countType);
+                    std::vector<int> idx(n);
+                    for (int k = 0; k < n; ++k) idx[k] = (int)readNum(p.type);
+                    if (p.name != "vertex_indices" && p.name != "vertex_index") continue;
+                    if (n == 3) out->indices.insert(out->indices.end(), idx.begin(), idx.end());
+                    else if (n == 4) quads.insert(quads.end(), idx.begin(), idx.end());
+                    else { *err = "only triangles and quads are supported"; return false; }
+                }
+            // ConvertToOnlyTriangles (util/mesh.cpp:407-428): quads appended after the triangles as (0,1,3),(0,3,2)
+            for (size_t q = 0; q + 3 < quads.size(); q += 4) {
+                out->indices.push_back(quads[q]); out->indices.push_back(quads[q + 1]); out->indices.push_back(quads[q + 3]);
+                out->indices.push_back(quads[q]); out->indices.push_back(quads[q + 3]); out->indices.push_back(quads[q + 2]);
+            }
+        } else {
+            for (long i = 0; i < e.count; ++i)
+                for (const Prop &p : e.props) {
+                    if (p.list) { int n = (int)readNum(p.countType); for (int k = 0; k < n; ++k) readNum(p.type); }
+                    else readNum(p.type);
+                }
+        }
+    }
+    for (int vi : out->indices) if (vi < 0 || vi >= (int)out->P.size()) { *err = "vertex index out of bounds"; return false; }
+    return true;
+}
+
+}  // namespace
+
+// ---- main entry ---------------------------------------------------------------------------------------
+void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
+    const SpectralData &sd = SpectralData::Get();
+    (void)sd;
+    // rendering space: camera-world (cameras.cpp:35-41)
+    V3 pCamera = scene.worldFromCamera.Point(V3{0, 0, 0});
+    Transform worldFromRender = Translate(pCamera);
+    Transform renderFromWorld = Inverse(worldFromRender);
+
+    BuildFilter(scene, T);
+    BuildFilm(scene, opt, T);
+    BuildSampler(scene, opt, T);
+    BuildCamera(scene, renderFromWorld, T);
+
+    T->desc.options.seed = opt.seed;
+    T->desc.options.disable_pixel_jitter = opt.disablePixelJitter;
+    T->desc.options.disable_wavelength_jitter = opt.disableWavelengthJitter;
+    T->desc.options.disable_texture_filtering = opt.disableTextureFiltering;
+
+    // integrator (wavefront/integrator.cpp:183-198)
+    const ParamSet &ip = scene.integrator.params;
+    if (scene.integrator.name != "path" && scene.integrator.name != "volpath")
+        fprintf(stderr, "Warning: Ignoring specified integrator \"%s\": the wavefront integrator always uses a \"volpath\" integrator.\n", scene.integrator.name.c_str());
+    T->desc.regularize = ip.GetOneBool("regularize", false);
+    T->desc.max_depth = ip.GetOneInt("maxdepth", 5);
+    std::string lightSamplerName = ip.GetOneString("lightsampler", "bvh");
+
+    if (!scene.media.empty()) Die(scene.media[0].second.loc, "participating media are not supported by this build yet");
+
+    // textures and materials (scene.cpp:1110-1171)
+    TexBuilder tb;
+    tb.T = T;
+    tb.scene = &scene;
+    tb.CreateNamedTextures();
+    std::map<std::string, int> namedMaterialIds;
+    for (const auto &nm : scene.namedMaterials) namedMaterialIds[nm.first] = tb.CreateMaterial(nm.second);
+    std::vector<int> materialIds;
+    for (const Entity &m : scene.materials) materialIds.push_back(tb.CreateMaterial(m));
+
+    // shapes -> meshes; instances are flattened (each use re-instantiates the definition's triangles
+    // with renderFromInstance applied) — see DESIGN.md "Instancing".
+    struct PendingAreaLight { int mesh; int lightEntity; Transform renderFromObject; };
+    std::vector<PendingAreaLight> pendingArea;
+    auto addShape = [&](const ShapeEntity &sh, const Transform *extra) {
+        MeshSource src;
+        if (!LoadShapeGeometry(sh, scene.baseDir, &src)) return;
+        Transform rfo = sh.renderFromObject;
+        if (extra) rfo = Transform(((*extra) * sh.renderFromObject).m);
+        wf_mesh mesh{};
+        mesh.first_tri = (int)T->triIndices.size() / 3;
+        mesh.ntris = (int)src.indices.size() / 3;
+        mesh.first_vertex = (int)T->P.size() / 3;
+        mesh.nverts = (int)src.P.size();
+        bool swaps = rfo.SwapsHandedness();
+        mesh.flags = 0;
+        if (!src.N.empty()) mesh.flags |= WF_MESH_HAS_N;
+        if (!src.uv.empty()) mesh.flags |= WF_MESH_HAS_UV;
+        if (sh.reverseOrientation ^ swaps) mesh.flags |= WF_MESH_FLIP_NORMAL;
+        for (size_t i = 0; i < src.P.size(); ++i) {
+            V3 p = rfo.Point(src.P[i]);
+            T->P.push_back(p.x); T->P.push_back(p.y); T->P.push_back(p.z);
+            N3 n{0, 0, 0};
+            if (!src.N.empty()) {
+                n = rfo.Normal(toN(src.N[i]));
+                if (sh.reverseOrientation) n = -n;
+            }
+            T->N.push_back(n.x); T->N.push_back(n.y); T->N.push_back(n.z);
+            V2 uv{0, 0};
+            if (!src.uv.empty()) uv = src.uv[i];
+            T->UV.push_back(uv.x); T->UV.push_back(uv.y);
+        }
+        int meshId = (int)T->meshes.size();
+        for (int vi : src.indices) T->triIndices.push_back(mesh.first_vertex + vi);
+        for (int i = 0; i < mesh.ntris; ++i) T->triMesh.push_back(meshId);
+        // material
+        if (!sh.materialName.empty()) {
+            auto it = namedMaterialIds.find(sh.materialName);
+            if (it == namedMaterialIds.end()) Die(sh.loc, sh.materialName + ": no named material defined.");
+            mesh.material = it->second;
+        } else mesh.material = materialIds.at(sh.materialIndex);
+        if (T->materials[mesh.material].type == WF_MAT_INTERFACE) mesh.material = -1;
+        mesh.first_light = -1;
+        mesh.alpha_tex = -1;
+        std::string alphaTex = sh.params.GetTexture("alpha");
+        float alpha = sh.params.GetOneFloat("alpha", 1.f);
+        if (!alphaTex.empty() || alpha < 1.f) Die(sh.loc, "alpha textures are not supported by this build yet");
+        mesh.medium_inside = mesh.medium_outside = -1;
+        if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) Die(sh.loc, "MediumInterface is not supported by this build yet");
+        T->meshes.push_back(mesh);
+        if (sh.lightIndex >= 0 && !extra) {
+            if (mesh.material < 0) fprintf(stderr, "Warning: %s: Ignoring area light specification for shape with \"interface\" material.\n", sh.loc.c_str());
+            else pendingArea.push_back({meshId, sh.lightIndex, rfo});
+        }
+        sh.params.ReportUnused("Shape");
+    };
+    for (const ShapeEntity &sh : scene.shapes) addShape(sh, nullptr);
+    for (const InstanceUse &u : scene.instances) {
+        auto it = scene.instanceDefinitions.find(u.name);
+        if (it == scene.instanceDefinitions.end()) Die("", u.name + ": object instance not defined");
+        for (const ShapeEntity &sh : it->second.shapes) addShape(sh, &u.renderFromInstance);
+    }
+    if (T->triIndices.empty()) Die("", "scene has no geometry");
+
+    // ---- lights: area lights first (scene.cpp:1290-1340), then the others ----
+    auto triVerts = [&](int tri, V3 *p0, V3 *p1, V3 *p2) {
+        const int32_t *v = &T->triIndices[3 * (size_t)tri];
+        auto P = [&](int i) { return V3{T->P[3 * (size_t)i], T->P[3 * (size_t)i + 1], T->P[3 * (size_t)i + 2]}; };
+        *p0 = P(v[0]); *p1 = P(v[1]); *p2 = P(v[2]);
+    };
+    std::vector<std::pair<int, LightBoundsH>> bvhLights;
+    B3 allLightBounds;
+    auto addLightBounds = [&](int lightId, const LightBoundsH &lb) {
+        if (lb.phi > 0) { bvhLights.emplace_back(lightId, lb); allLightBounds = Union(allLightBounds, lb.bounds); }
+    };
+    for (const PendingAreaLight &pa : pendingArea) {
+        const Entity &al = scene.areaLights[pa.lightEntity];
+        if (al.name != "diffuse") Die(al.loc, al.name + ": area light type unknown.");
+        const ParamSet &ps = al.params;
+        const ColorSpace *cs = ps.colorSpace;
+        // DiffuseAreaLight::Create (lights.cpp:873-941)
+        SpectrumP L = ps.GetOneSpectrum("L", nullptr, SpectrumType::Illuminant);
+        float scale = ps.GetOneFloat("scale", 1);
+        bool twoSided = ps.GetOneBool("twosided", false);
+        if (!ps.GetOneString("filename", "").empty()) Die(al.loc, "image-textured area lights are not supported by this build");
+        if (!L) L = cs->illuminant;
+        scale /= SpectrumToPhotometric(*L);
+        float phi_v = ps.GetOneFloat("power", -1.0f);
+        wf_mesh &mesh = T->meshes[pa.mesh];
+        mesh.first_light = (int)T->lights.size();
+        int specOff = T->pool.AddDense(*L);
+        float LemitMax = MakeDense(*L)->MaxValue();
+        for (int t = 0; t < mesh.ntris; ++t) {
+            int tri = mesh.first_tri + t;
+            V3 p0, p1, p2;
+            triVerts(tri, &p0, &p1, &p2);
+            float area = 0.5f * Length(Cross(p1 - p0, p2 - p0));  // Triangle::Area (shapes.h:852-858)
+            float sc = scale;
+            if (phi_v > 0) {
+                float k_e = 1;
+                k_e *= (twoSided ? 2 : 1) * area * Pi;
+                sc *= phi_v / k_e;
+            }
+            wf_light l{};
+            l.type = WF_LIGHT_DIFFUSE_AREA;
+            l.flags = twoSided ? WF_LIGHTFLAG_TWOSIDED : 0;
+            l.spectrum_offset = specOff;
+            l.scale = sc;
+            l.tri = tri;
+            l.area = area;
+            l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = -1;
+            int lightId = (int)T->lights.size();
+            T->lights.push_back(l);
+            // DiffuseAreaLight::Bounds (lights.cpp:788-806) + Triangle::NormalBounds (shapes.cpp:292-307)
+            float phi = LemitMax;
+            phi *= sc * area * Pi;
+            N3 n = Normalize(toN(Cross(p1 - p0, p2 - p0)));
+            if (mesh.flags & WF_MESH_HAS_N) {
+                const int32_t *v = &T->triIndices[3 * (size_t)tri];
+                auto NN = [&](int i) { return N3{T->N[3 * (size_t)i], T->N[3 * (size_t)i + 1], T->N[3 * (size_t)i + 2]}; };
+                N3 ns = NN(v[0]) + NN(v[1]) + NN(v[2]);
+                n = FaceForward(n, ns);
+            } else if (mesh.flags & WF_MESH_FLIP_NORMAL) n = n * -1.f;
+            LightBoundsH lb;
+            B3 b;
+            b.pMin = {fmin(p0.x, p1.x), fmin(p0.y, p1.y), fmin(p0.z, p1.z)};
+            b.pMax = {fmax(p0.x, p1.x), fmax(p0.y, p1.y), fmax(p0.z, p1.z)};
+            lb.bounds = Union(b, p2);
+            lb.w = Normalize(Normalize(toV(n)));  // DirectionCone(Vector3f(n)) normalizes; LightBounds ctor normalizes again
+            lb.phi = phi;
+            lb.cosTheta_o = 1.f;                  // DirectionCone(w) => cosTheta 1
+            lb.cosTheta_e = std::cos(Pi / 2);
+            lb.twoSided = twoSided;
+            addLightBounds(lightId, lb);
+        }
+        ps.ReportUnused("AreaLightSource");
+    }
+    for (const LightEntity &le : scene.lights) {
+        const ParamSet &ps = le.params;
+        const ColorSpace *cs = ps.colorSpace;
+        wf_light l{};
+        l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = -1; l.tri = -1;
+        int lightId = (int)T->lights.size();
+        if (le.name == "point") {
+            SpectrumP I = ps.GetOneSpectrum("I", cs->illuminant, SpectrumType::Illuminant);
+            float sc = ps.GetOneFloat("scale", 1);
+            sc /= SpectrumToPhotometric(*I);
+            float phi_v = ps.GetOneFloat("power", -1);
+            if (phi_v > 0) { float k_e = 4 * Pi; sc *= phi_v / k_e; }
+            V3 from = ps.GetOnePoint3f("from", V3{0, 0, 0});
+            Transform tf = Translate(from);
+            Transform rfl = le.renderFromLight * tf;
+            V3 p = rfl.Point(V3{0, 0, 0});
+            l.type = WF_LIGHT_POINT; l.scale = sc; l.spectrum_offset = T->pool.AddDense(*I);
+            l.pos[0] = p.x; l.pos[1] = p.y; l.pos[2] = p.z;
+            T->lights.push_back(l);
+            LightBoundsH lb;
+            lb.bounds.pMin = lb.bounds.pMax = p;
+            lb.w = Normalize(V3{0, 0, 1});
+            lb.phi = 4 * Pi * sc * MakeDense(*I)->MaxValue();
+            lb.cosTheta_o = std::cos(Pi); lb.cosTheta_e = std::cos(Pi / 2); lb.twoSided = false;
+            addLightBounds(lightId, lb);
+        } else if (le.name == "spot") {
+            SpectrumP I = ps.GetOneSpectrum("I", cs->illuminant, SpectrumType::Illuminant);
+            float sc = ps.GetOneFloat("scale", 1);
+            float coneangle = ps.GetOneFloat("coneangle", 30.f);
+            float conedelta = ps.GetOneFloat("conedeltaangle", 5.f);
+            V3 from = ps.GetOnePoint3f("from", V3{0, 0, 0});
+            V3 to = ps.GetOnePoint3f("to", V3{0, 0, 1});
+            Frame fr = Frame::FromZ(Normalize(to - from));
+            Transform dirToZ(M4(fr.x.x, fr.x.y, fr.x.z, 0, fr.y.x, fr.y.y, fr.y.z, 0, fr.z.x, fr.z.y, fr.z.z, 0, 0, 0, 0, 1));
+            Transform t = Translate(from) * Inverse(dirToZ);
+            Transform rfl = le.renderFromLight * t;
+            sc /= SpectrumToPhotometric(*I);
+            float phi_v = ps.GetOneFloat("power", -1);
+            if (phi_v > 0) {
+                float cosFalloffEnd = std::cos(Radians(coneangle));
+                float cosFalloffStart = std::cos(Radians(coneangle - conedelta));
+                float k_e = 2 * Pi * ((1 - cosFalloffStart) + (cosFalloffStart - cosFalloffEnd) / 2);
+                sc *= phi_v / k_e;
+            }
+            l.type = WF_LIGHT_SPOT; l.scale = sc; l.spectrum_offset = T->pool.AddDense(*I);
+            l.cosFalloffEnd = std::cos(Radians(coneangle));
+            l.cosFalloffStart = std::cos(Radians(coneangle - conedelta));
+            V3 p = rfl.Point(V3{0, 0, 0});
+            l.pos[0] = p.x; l.pos[1] = p.y; l.pos[2] = p.z;
+            l.xform = (int)T->lightTransforms.size();
+            T->lightTransforms.push_back(rfl.abi());
+            T->lights.push_back(l);
+            LightBoundsH lb;
+            lb.bounds.pMin = lb.bounds.pMax = p;
+            lb.w = Normalize(Normalize(rfl.Vector(V3{0, 0, 1})));
+            lb.phi = sc * MakeDense(*I)->MaxValue() * 4 * Pi;
+            float cosTheta_e = std::cos(std::acos(l.cosFalloffEnd) - std::acos(l.cosFalloffStart));
+            if (cosTheta_e == 1 && l.cosFalloffEnd != l.cosFalloffStart) cosTheta_e = 0.999f;
+            lb.cosTheta_o = l.cosFalloffStart; lb.cosTheta_e = cosTheta_e; lb.twoSided = false;
+            addLightBounds(lightId, lb);
+        } else if (le.name == "distant") {
+            SpectrumP L = ps.GetOneSpectrum("L", cs->illuminant, SpectrumType::Illuminant);
+            float sc = ps.GetOneFloat("scale", 1);
+            V3 from = ps.GetOnePoint3f("from", V3{0, 0, 0});
+            V3 to = ps.GetOnePoint3f("to", V3{0, 0, 1});
+            V3 w = Normalize(from - to);
+            V3 v1, v2;
+            CoordinateSystem(w, &v1, &v2);
+            Transform t(M4(v1.x, v2.x, w.x, 0, v1.y, v2.y, w.y, 0, v1.z, v2.z, w.z, 0, 0, 0, 0, 1));
+            Transform rfl = le.renderFromLight * t;
+            sc /= SpectrumToPhotometric(*L);
+            float E_v = ps.GetOneFloat("illuminance", -1);
+            if (E_v > 0) sc *= E_v;
+            l.type = WF_LIGHT_DISTANT; l.scale = sc; l.spectrum_offset = T->pool.AddDense(*L);
+            V3 wi = Normalize(rfl.Vector(V3{0, 0, 1}));  // DistantLight::SampleLi (lights.h:262)
+            l.pos[0] = wi.x; l.pos[1] = wi.y; l.pos[2] = wi.z;
+            l.infinite_index = (int)T->infiniteLights.size();  // no Bounds(): sampled with the infinite lights
+            T->infiniteLights.push_back(lightId);
+            T->lights.push_back(l);
+        } else if (le.name == "infinite") {
+            std::vector<V3> portal = ps.GetPoint3fArray("portal");
+            std::string filename = ps.GetOneString("filename", "");
+            if (!portal.empty() || !filename.empty()) Die(le.loc, "image / portal infinite lights are not supported by this build yet");
+            SpectrumP L = ps.GetOneSpectrum("L", nullptr, SpectrumType::Illuminant);
+            float scale = ps.GetOneFloat("scale", 1);
+            float E_v = ps.GetOneFloat("illuminance", -1);
+            if (!L) L = cs->illuminant;
+            scale /= SpectrumToPhotometric(*L);
+            if (E_v > 0) { float k_e = Pi; scale *= E_v / k_e; }
+            l.type = WF_LIGHT_UNIFORM_INFINITE; l.scale = scale; l.spectrum_offset = T->pool.AddDense(*L);
+            l.infinite_index = (int)T->infiniteLights.size();
+            T->infiniteLights.push_back(lightId);
+            T->lights.push_back(l);
+        } else Die(le.loc, le.name + ": light type not supported by this build (point, spot, distant, infinite)");
+        ps.ReportUnused("LightSource");
+    }
+    if (T->lights.empty()) Die("", "No light sources specified");
+
+    // ---- acceleration structure (scene.cpp:1575-1591, cpu/aggregates.cpp:725-744) ----
+    if (scene.accelerator.name != "bvh") fprintf(stderr, "Warning: accelerator \"%s\" is replaced by the BVH\n", scene.accelerator.name.c_str());
+    std::string split = scene.accelerator.params.GetOneString("splitmethod", "sah");
+    if (split != "sah") fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str());
+    int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
+    BuildBVH(T->P, T->triIndices, maxPrims, &T->bvhNodes, &T->bvhPrims);
+    B3 sceneBounds;
+    for (int c = 0; c < 3; ++c) { sceneBounds.pMin[c] = T->bvhNodes[0].bmin[c]; sceneBounds.pMax[c] = T->bvhNodes[0].bmax[c]; }
+    for (int c = 0; c < 3; ++c) { T->desc.scene_bounds[c] = sceneBounds.pMin[c]; T->desc.scene_bounds[3 + c] = sceneBounds.pMax[c]; }
+
+    // Light::Preprocess(sceneBounds) (integrator.cpp:172-173; lights.h:243-246,546-549)
+    {
+        V3 center = (sceneBounds.pMin + sceneBounds.pMax) / 2;
+        float radius = Inside(center, sceneBounds) ? Distance(center, sceneBounds.pMax) : 0;
+        for (wf_light &l : T->lights)
+            if (l.type == WF_LIGHT_DISTANT || l.type == WF_LIGHT_UNIFORM_INFINITE || l.type == WF_LIGHT_IMAGE_INFINITE) {
+                l.sceneCenter[0] = center.x; l.sceneCenter[1] = center.y; l.sceneCenter[2] = center.z;
+                l.sceneRadius = radius;
+            }
+    }
+
+    // ---- light sampler (integrator.cpp:181-187, lightsamplers.cpp:28-62) ----
+    if (T->lights.size() == 1) lightSamplerName = "uniform";
+    if (lightSamplerName == "uniform") T->desc.light_sampler = WF_LS_UNIFORM;
+    else if (lightSamplerName == "bvh") {
+        T->desc.light_sampler = WF_LS_BVH;
+        // lights without Bounds() (distant, infinite) are the BVH sampler's "infiniteLights" — already listed
+        BuildLightBVH(bvhLights, allLightBounds, &T->lightBvh, &T->lights);
+    } else if (lightSamplerName == "power") Die(scene.integrator.loc, "the \"power\" light sampler is not supported by this build yet");
+    else {
+        fprintf(stderr, "Warning: Light sample distribution type \"%s\" unknown. Using \"bvh\".\n", lightSamplerName.c_str());
+        T->desc.light_sampler = WF_LS_BVH;
+        BuildLightBVH(bvhLights, allLightBounds, &T->lightBvh, &T->lights);
+    }
+    for (int c = 0; c < 3; ++c) { T->desc.all_light_bounds[c] = allLightBounds.pMin[c]; T->desc.all_light_bounds[3 + c] = allLightBounds.pMax[c]; }
+    T->desc.have_media = 0;
+    for (const wf_mesh &m : T->meshes) if (m.material < 0) T->desc.have_media = 1;  // interface material (integrator.cpp:52)
+
+    // wavefront pass geometry (integrator.cpp:227-236)
+    {
+        const wf_film &F = T->desc.film;
+        int resx = F.pixel_max[0] - F.pixel_min[0], resy = F.pixel_max[1] - F.pixel_min[1];
+        int maxSamples = 1024 * 1024;
+        T->scanlinesPerPass = std::max(1, maxSamples / resx);
+        T->nPasses = (resy + T->scanlinesPerPass - 1) / T->scanlinesPerPass;
+        T->scanlinesPerPass = (resy + T->nPasses - 1) / T->nPasses;
+        T->maxQueueSize = resx * T->scanlinesPerPass;
+    }
+    ip.ReportUnused("Integrator");
+    T->Finalize();
+}
+
+}  // namespace wf
