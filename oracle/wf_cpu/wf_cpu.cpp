@@ -1,0 +1,218 @@
+// oracle/wf_cpu/wf_cpu.cpp — TEST INFRASTRUCTURE ONLY.  Never linked into, loaded by, or called from the
+// product (libwfhip.so / libwfhost.so / the pbrt_amd CLI); only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may run it, and only as the checker.
+//
+// CPU restatement ("port") of the reference's wavefront path: the loop of
+// WavefrontPathIntegrator::Render (wavefront/integrator.cpp:290-493) over the stage bodies restated in
+// pbrt-v4_amd/csrc/common/wf_*.h (each function there cites the reference file:line it follows), with
+// CPUAggregate-style traversal (wavefront/aggregate.cpp:34-68: int nodesToVisit[64] stack,
+// cpu/aggregates.cpp:529-624).  It exists so that (a) the restated arithmetic can be pinned against the
+// real reference (oracle/_ref/pbrt_ref --wavefront, built from /root/reference by oracle/ref_build) on a
+// machine without a GPU, and (b) the HIP kernels can be compared with it item by item on the GPU box,
+// where /root/reference does not exist.  Pinning status: see DESIGN.md "Oracle".
+//
+// usage: wf_cpu [--spp N] [--seed N] [--nthreads N] [--outfile out.pfm] [--dump-film film.bin]
+//               [--datadir DIR] [--trace rays.bin hits.bin] scene.pbrt
+#include "../../pbrt-v4_amd/csrc/common/wf_kernels.h"
+#include "../../pbrt-v4_amd/csrc/host/scene.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace wf;
+
+static int gThreads = 1;
+static void ParallelFor(int n, const std::function<void(int)> &f) {
+    if (n <= 0) return;
+    int nt = std::min(gThreads, std::max(1, n / 64));
+    if (nt <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next{0};
+    const int chunk = std::max(64, n / (8 * nt));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            while (true) {
+                int b = next.fetch_add(chunk);
+                if (b >= n) break;
+                int e = std::min(n, b + chunk);
+                for (int i = b; i < e; ++i) f(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
+template <typename T> static T *Alloc(size_t n) { return (T *)calloc(n, sizeof(T)); }
+
+static void AllocRayQueue(RayQueueV *q, int n) {
+    q->o = Alloc<F4>(n); q->d = Alloc<F4>(n); q->beta = Alloc<F4>(n); q->r_u = Alloc<F4>(n); q->r_l = Alloc<F4>(n);
+    q->ctx0 = Alloc<F4>(n); q->ctx1 = Alloc<F4>(n); q->ctx2 = Alloc<F4>(n); q->meta = Alloc<I4>(n);
+}
+
+SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
+    SceneView sv{};
+    sv.P = d.P; sv.N = d.N; sv.UV = d.UV; sv.triIndices = d.tri_indices; sv.triMesh = d.tri_mesh; sv.meshes = d.meshes;
+    sv.bvhNodes = d.bvh_nodes; sv.bvhPrims = d.bvh_prims; sv.nTriangles = d.n_triangles; sv.nBvhNodes = d.n_bvh_nodes;
+    sv.spectra = d.spectra; sv.spectrumData = d.spectrum_data; sv.textures = d.textures; sv.materials = d.materials;
+    sv.lights = d.lights; sv.infiniteLights = d.infinite_lights; sv.lightBvh = d.light_bvh_nodes; sv.lightXforms = d.light_transforms;
+    sv.nLights = d.n_lights; sv.nInfiniteLights = d.n_infinite_lights; sv.nLightBvhNodes = d.n_light_bvh_nodes; sv.lightSampler = d.light_sampler;
+    for (int i = 0; i < 6; ++i) sv.allLightBounds[i] = d.all_light_bounds[i];
+    sv.camera = d.camera; sv.film = d.film; sv.filter = d.filter; sv.filterData = d.filter_data; sv.sampler = d.sampler;
+    sv.sobol = sobol;
+    sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;
+    return sv;
+}
+
+int main(int argc, char **argv) {
+    RenderOptions opt;
+    std::string scenePath, dumpFilm, dataDir, traceRays, traceHits;
+    gThreads = std::max(1u, std::thread::hardware_concurrency());
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value after %s\n", a.c_str()); exit(1); } return argv[++i]; };
+        if (a == "--spp") opt.pixelSamples = atoi(next().c_str());
+        else if (a == "--seed") opt.seed = atoi(next().c_str());
+        else if (a == "--nthreads") gThreads = atoi(next().c_str());
+        else if (a == "--outfile") opt.imageFile = next();
+        else if (a == "--dump-film") dumpFilm = next();
+        else if (a == "--datadir") dataDir = next();
+        else if (a == "--quiet") opt.quiet = true;
+        else if (a == "--trace") { traceRays = next(); traceHits = next(); }
+        else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+        else scenePath = a;
+    }
+    if (scenePath.empty()) { fprintf(stderr, "usage: wf_cpu [options] scene.pbrt\n"); return 1; }
+    if (dataDir.empty()) {
+        // <repo>/pbrt-v4_amd/data relative to this binary's usual location oracle/_build/wf_cpu
+        std::string self = argv[0];
+        size_t p = self.rfind('/');
+        dataDir = (p == std::string::npos ? std::string(".") : self.substr(0, p)) + "/../../pbrt-v4_amd/data";
+    }
+    SpectralData::Init(dataDir, dataDir + "/cache");
+    ParsedScene parsed;
+    ParseFiles({scenePath}, &opt, &parsed);
+    SceneTables T;
+    BuildSceneTables(parsed, opt, &T);
+    uint32_t sobol[104];
+    FillSobol2D(sobol);
+    SceneView sv = MakeHostView(T.desc, sobol);
+
+    // stand-alone traversal mode: rays.bin = n x {o[3], d[3], tMax} floats -> hits.bin = n x wf_hit_record
+    if (!traceRays.empty()) {
+        FILE *f = fopen(traceRays.c_str(), "rb");
+        if (!f) { perror(traceRays.c_str()); return 1; }
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        int n = (int)(sz / (7 * sizeof(float)));
+        std::vector<float> rays((size_t)n * 7);
+        if (fread(rays.data(), sizeof(float), rays.size(), f) != rays.size()) return 1;
+        fclose(f);
+        std::vector<wf_hit_record> hits(n);
+        ParallelFor(n, [&](int i) {
+            const float *r = &rays[(size_t)i * 7];
+            ArrayStack st;
+            ClosestHit ch;
+            bool found = BVHIntersectClosest(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &ch);
+            wf_hit_record &h = hits[i];
+            h.prim = found ? ch.prim : -1;
+            h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;
+            h.nodes_visited = ch.nodesVisited; h.tris_tested = ch.trisTested; h.pad = 0;
+        });
+        f = fopen(traceHits.c_str(), "wb");
+        fwrite(hits.data(), sizeof(wf_hit_record), hits.size(), f);
+        fclose(f);
+        return 0;
+    }
+
+    const int n = T.maxQueueSize;
+    WorkState ws{};
+    ws.maxQueueSize = n;
+    ws.filterWeight = Alloc<float>(n); ws.pPixel = Alloc<I2>(n);
+    ws.lambda = Alloc<F4>(n); ws.lambdaPdf = Alloc<F4>(n); ws.L = Alloc<F4>(n); ws.cameraRayWeight = Alloc<F4>(n);
+    ws.samples0 = Alloc<F4>(n); ws.samples1 = Alloc<F4>(n);
+    AllocRayQueue(&ws.rq[0], n); AllocRayQueue(&ws.rq[1], n);
+    ws.hit = Alloc<F4>(n);
+    ws.escapedQ = Alloc<int32_t>(n); ws.hitLightQ = Alloc<int32_t>(n);
+    for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.matQ[m] = Alloc<int32_t>(T.materialTypePresent[m] ? n : 1);
+    ws.sq.o = Alloc<F4>(n); ws.sq.d = Alloc<F4>(n); ws.sq.Ld = Alloc<F4>(n); ws.sq.r_u = Alloc<F4>(n); ws.sq.r_l = Alloc<F4>(n);
+    ws.counters = Alloc<int32_t>(CNT_COUNT);
+    const wf_film &F = T.desc.film;
+    const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
+    ws.film = Alloc<double>((size_t)W * H * 4);
+    ws.stats = Alloc<unsigned long long>(129);
+    unsigned long long nodesVisited = 0, trisTested = 0;
+
+    auto t0 = std::chrono::steady_clock::now();
+    const int maxDepth = T.desc.max_depth;
+    for (int sampleIndex = 0; sampleIndex < T.spp; ++sampleIndex) {
+        for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
+            ws.counters[CNT_RAY0] = 0;
+            ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex); });
+            ws.stats[0] += ws.counters[CNT_RAY0];
+            for (int depth = 0; true; ++depth) {
+                const int cur = depth & 1;
+                ws.counters[CNT_RAY0 + (cur ^ 1)] = 0;
+                ws.counters[CNT_ESCAPED] = ws.counters[CNT_HITLIGHT] = 0;
+                for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.counters[CNT_MAT0 + m] = 0;
+                const int nRays = ws.counters[CNT_RAY0 + cur];
+                ws.stats[1 + depth] += nRays;
+                ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex); });
+                std::atomic<unsigned long long> nv{0}, nt{0};
+                ParallelFor(nRays, [&](int i) {
+                    F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+                    ArrayStack st;
+                    ClosestHit ch;
+                    bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
+                    nv += ch.nodesVisited; nt += ch.trisTested;
+                    KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.b0, ch.h.b1, ch.h.b2);
+                });
+                nodesVisited += nv; trisTested += nt;
+                ParallelFor(ws.counters[CNT_ESCAPED], [&](int i) { KHandleEscaped(sv, ws, cur, i); });
+                ParallelFor(ws.counters[CNT_HITLIGHT], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
+                if (depth == maxDepth) break;
+                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_DIFFUSE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE>(sv, ws, cur, i); });
+                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_CONDUCTOR], [&](int i) { KEvalMaterial<WF_MAT_CONDUCTOR>(sv, ws, cur, i); });
+                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_DIELECTRIC], [&](int i) { KEvalMaterial<WF_MAT_DIELECTRIC>(sv, ws, cur, i); });
+                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_THIN_DIELECTRIC], [&](int i) { KEvalMaterial<WF_MAT_THIN_DIELECTRIC>(sv, ws, cur, i); });
+                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i); });
+                const int nShadow = ws.counters[CNT_SHADOW];
+                ParallelFor(nShadow, [&](int i) {
+                    F4 o = ws.sq.o[i], d = ws.sq.d[i];
+                    ArrayStack st;
+                    bool occluded = BVHIntersectAny(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, nullptr, nullptr);
+                    KRecordShadowRay(ws, i, occluded);
+                });
+                ws.stats[65 + depth] += nShadow;
+                ws.counters[CNT_SHADOW] = 0;
+            }
+            ParallelFor(n, [&](int i) { KUpdateFilm(sv, ws, i); });
+        }
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    unsigned long long rays = ws.stats[0];
+    for (int d = 0; d < 64; ++d) rays += ws.stats[1 + d] * (d > 0) + ws.stats[65 + d];
+    // stats[1+0] are the camera rays again (indirect[0] counts the depth-0 queue); do not double count
+    if (!opt.quiet)
+        fprintf(stderr, "wf_cpu: %dx%d %d spp, %d threads: %.3f s, %.3f Msamples/s, %.3f Mray/s (nodes %llu tris %llu)\n", W, H, T.spp,
+                gThreads, secs, (double)W * H * T.spp / secs / 1e6, rays / secs / 1e6, nodesVisited, trisTested);
+    printf("{\"seconds\": %.6f, \"width\": %d, \"height\": %d, \"spp\": %d, \"threads\": %d, \"rays\": %llu, \"camera_rays\": %llu}\n", secs, W, H,
+           T.spp, gThreads, rays, ws.stats[0]);
+
+    if (!dumpFilm.empty()) {
+        FILE *f = fopen(dumpFilm.c_str(), "wb");
+        fwrite(ws.film, sizeof(double), (size_t)W * H * 4, f);
+        fclose(f);
+    }
+    // RGBFilm::GetPixelRGB (film.h:258-275) + GetImage (film.cpp:533-565), float output
+    std::vector<float> rgb((size_t)W * H * 3);
+    FilmToRGB(F, ws.film, W, H, rgb.data(), T.saveFP16);
+    if (!T.imageFile.empty()) WriteImage(T.imageFile, rgb.data(), W, H);
+    return 0;
+}

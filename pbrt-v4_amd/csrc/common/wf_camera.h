@@ -1,0 +1,222 @@
+// wf_camera.h — sampler, pixel filter, camera: everything GenerateCameraRays / GenerateRaySamples
+// evaluate per pixel sample (wavefront/camera.cpp:31-80, wavefront/samples.cpp:29-66).
+#pragma once
+
+#include "wf_scene.h"
+
+namespace wf {
+
+// ---------------------------------------------------------------------------------------------
+// Sobol' sample generation (util/lowdiscrepancy.h:165-180) with the scramblers (:223-268)
+WF_HD uint32_t FastOwenScramble(uint32_t v, uint32_t seed) {
+    v = ReverseBits32(v);
+    v ^= v * 0x3d20adea;
+    v += seed;
+    v *= (seed >> 16) | 1;
+    v ^= v * 0x05526c56;
+    v ^= v * 0x53a22864;
+    return ReverseBits32(v);
+}
+WF_HD uint32_t OwenScramble(uint32_t v, uint32_t seed) {
+    if (seed & 1) v ^= 1u << 31;
+    for (int b = 1; b < 32; ++b) {
+        uint32_t mask = (~0u) << (32 - b);
+        if ((uint32_t)MixBits((v & mask) ^ seed) & (1u << b)) v ^= 1u << (31 - b);
+    }
+    return v;
+}
+WF_HD float SobolSample(const uint32_t *sobol, int64_t a, int dimension, int randomize, uint32_t hash) {
+    uint32_t v = 0;
+    for (int i = dimension * 52; a != 0; a >>= 1, i++)
+        if (a & 1) v ^= sobol[i];
+    if (randomize == WF_RAND_PERMUTE_DIGITS) v = hash ^ v;
+    else if (randomize == WF_RAND_FAST_OWEN) v = FastOwenScramble(v, hash);
+    else if (randomize == WF_RAND_OWEN) v = OwenScramble(v, hash);
+    return fmin(v * 0x1p-32f, OneMinusEpsilon);
+}
+
+// ZSobolSampler (samplers.h:225-370)
+struct ZSobol {
+    const uint32_t *sobol;
+    int log2spp, nBase4Digits, randomize, seed;
+    int dimension;
+    uint64_t mortonIndex;
+
+    WF_HD ZSobol(const SceneView &sv)
+        : sobol(sv.sobol), log2spp(sv.sampler.log2spp), nBase4Digits(sv.sampler.nBase4Digits),
+          randomize(sv.sampler.randomize), seed(sv.sampler.seed), dimension(0), mortonIndex(0) {}
+    WF_HD void StartPixelSample(int px, int py, int index, int dim) {
+        dimension = dim;
+        mortonIndex = (EncodeMorton2((uint32_t)px, (uint32_t)py) << log2spp) | (uint64_t)index;
+    }
+    WF_HD static int Perm(int p, int digit) {
+        // the 24 permutations of {0,1,2,3} in the reference's order (samplers.h:296-322), packed 2 bits
+        // per element, element 0 in the low bits
+        const uint8_t perms[24] = {
+            0xE4, 0xB4, 0xD8, 0x78, 0x6C, 0x9C, 0xE1, 0xB1, 0xC9, 0x39, 0x2D, 0x8D,
+            0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
+        return (perms[p] >> (2 * digit)) & 3;
+    }
+    WF_HD uint64_t GetSampleIndex() const {
+        uint64_t sampleIndex = 0;
+        bool pow2Samples = log2spp & 1;
+        int lastDigit = pow2Samples ? 1 : 0;
+        for (int i = nBase4Digits - 1; i >= lastDigit; --i) {
+            int digitShift = 2 * i - (pow2Samples ? 1 : 0);
+            int digit = (int)((mortonIndex >> digitShift) & 3);
+            uint64_t higherDigits = mortonIndex >> (digitShift + 2);
+            int p = (int)((MixBits(higherDigits ^ (0x55555555u * (uint32_t)dimension)) >> 24) % 24);
+            digit = Perm(p, digit);
+            sampleIndex |= uint64_t(digit) << digitShift;
+        }
+        if (pow2Samples) {
+            int digit = (int)(mortonIndex & 1);
+            sampleIndex |= (uint64_t)(digit ^ (int)(MixBits((mortonIndex >> 1) ^ (0x55555555u * (uint32_t)dimension)) & 1));
+        }
+        return sampleIndex;
+    }
+    WF_HD float Get1D() {
+        uint64_t sampleIndex = GetSampleIndex();
+        ++dimension;
+        uint32_t sampleHash = (uint32_t)Hash2i(dimension, seed);
+        return SobolSample(sobol, (int64_t)sampleIndex, 0, randomize, sampleHash);
+    }
+    WF_HD V2 Get2D() {
+        uint64_t sampleIndex = GetSampleIndex();
+        dimension += 2;
+        uint64_t bits = Hash2i(dimension, seed);
+        uint32_t h0 = (uint32_t)bits, h1 = (uint32_t)(bits >> 32);
+        return V2{SobolSample(sobol, (int64_t)sampleIndex, 0, randomize, h0),
+                  SobolSample(sobol, (int64_t)sampleIndex, 1, randomize, h1)};
+    }
+    WF_HD V2 GetPixel2D() { return Get2D(); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Filter::Sample (filters.h): box/triangle analytic, the others through FilterSampler (filters.h:26-45)
+// = PiecewiseConstant2D::Sample (util/sampling.h:760-770) over PiecewiseConstant1D::Sample (:657-675).
+WF_HD float PC1DSample(const float *func, const float *cdf, int n, float funcInt, float mn, float mx, float u,
+                       float *pdf, int *offset) {
+    int o = FindInterval(n + 1, [&](int index) { return cdf[index] <= u; });
+    *offset = o;
+    float du = u - cdf[o];
+    if (cdf[o + 1] - cdf[o] > 0) du /= cdf[o + 1] - cdf[o];
+    *pdf = (funcInt > 0) ? func[o] / funcInt : 0;
+    return Lerp((o + du) / n, mn, mx);
+}
+WF_HD float SampleTent(float u, float r) {
+    // util/sampling.h:247-258
+    // SampleDiscrete({0.5, 0.5}, u, nullptr, &u)
+    float up = u * 1.f;  // sum of weights 0.5 + 0.5
+    if (up == 1.f) up = NextFloatDown(up);
+    int offset = 0;
+    float sum = 0;
+    while (sum + 0.5f <= up) { sum += 0.5f; ++offset; }
+    float ur = fmin((up - sum) / 0.5f, OneMinusEpsilon);
+    if (offset == 0) return -r + r * SampleLinear(ur, 0, 1);
+    else return r * SampleLinear(ur, 1, 0);
+}
+struct FilterSampleR { V2 p; float weight; };
+WF_HD FilterSampleR FilterSample(const SceneView &sv, V2 u) {
+    const wf_filter &F = sv.filter;
+    if (F.type == WF_FILTER_BOX) {
+        // filters.h:67-70
+        return {V2{Lerp(u.x, -F.radius[0], F.radius[0]), Lerp(u.y, -F.radius[1], F.radius[1])}, 1.f};
+    }
+    if (F.type == WF_FILTER_TRIANGLE) {
+        // filters.h TriangleFilter::Sample
+        return {V2{SampleTent(u.x, F.radius[0]), SampleTent(u.y, F.radius[1])}, 1.f};
+    }
+    const float *D = sv.filterData;
+    float pdf1, pdf0;
+    int iv, iu;
+    float d1 = PC1DSample(D + F.marg_func_offset, D + F.marg_cdf_offset, F.ny, F.marg_int, F.domain_min[1],
+                          F.domain_max[1], u.y, &pdf1, &iv);
+    float d0 = PC1DSample(D + F.cond_func_offset + iv * F.nx, D + F.cond_cdf_offset + iv * (F.nx + 1), F.nx,
+                          D[F.cond_int_offset + iv], F.domain_min[0], F.domain_max[0], u.x, &pdf0, &iu);
+    float pdf = pdf0 * pdf1;
+    return {V2{d0, d1}, D[F.f_offset + iv * F.nx + iu] / pdf};
+}
+
+// ---------------------------------------------------------------------------------------------
+// transforms applied on the device (util/transform.h:310-348, 133-176)
+WF_HD V3 XfPoint(const float m[4][4], V3 p) {
+    float xp = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
+    float yp = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
+    float zp = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
+    float wp = m[3][0] * p.x + m[3][1] * p.y + m[3][2] * p.z + m[3][3];
+    if (wp == 1) return V3{xp, yp, zp};
+    return V3{xp, yp, zp} / wp;
+}
+WF_HD V3 XfVector(const float m[4][4], V3 v) {
+    return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
+              m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
+}
+WF_HD N3 XfNormal(const float mInv[4][4], N3 n) {
+    return N3{mInv[0][0] * n.x + mInv[1][0] * n.y + mInv[2][0] * n.z, mInv[0][1] * n.x + mInv[1][1] * n.y + mInv[2][1] * n.z,
+              mInv[0][2] * n.x + mInv[1][2] * n.y + mInv[2][2] * n.z};
+}
+// Interval addition of an exact float to [lo,hi] with outward rounding, then the midpoint
+// (util/math.h:873-875 with the host AddRoundDown/Up = NextFloatDown/Up(a+b), util/float.h:204-216)
+WF_HD float IntervalAddMid(float lo, float hi, float v) {
+    float l = NextFloatDown(lo + v), h = NextFloatUp(hi + v);
+    return (l + h) / 2;
+}
+// Transform::operator()(const Ray &) for an exact origin: util/transform.h:336-348
+WF_HD void XfRay(const float m[4][4], V3 *o, V3 *d) {
+    float x = o->x, y = o->y, z = o->z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    float wp = (m[3][0] * x + m[3][1] * y) + (m[3][2] * z + m[3][3]);
+    V3 pe;
+    pe.x = gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z) + abs(m[0][3]));
+    pe.y = gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z) + abs(m[1][3]));
+    pe.z = gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z) + abs(m[2][3]));
+    P3i oi = MakeP3i(V3{xp, yp, zp}, pe);
+    (void)wp;  // affine transforms only (wp == 1): camera and identity motion
+    V3 dd = XfVector(m, *d);
+    float lengthSquared = LengthSquared(dd);
+    if (lengthSquared > 0) {
+        float dt = Dot(Abs(dd), oi.err()) / lengthSquared;
+        V3 off = dd * dt;
+        o->x = IntervalAddMid(oi.lo.x, oi.hi.x, off.x);
+        o->y = IntervalAddMid(oi.lo.y, oi.hi.y, off.y);
+        o->z = IntervalAddMid(oi.lo.z, oi.hi.z, off.z);
+    } else *o = oi.mid();
+    *d = dd;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GetCameraSample (samplers.h:796-814) + Perspective/OrthographicCamera::GenerateRay
+// (cameras.cpp:404-428, 283-307) + the identity "movingFromCamera" the wavefront loop applies
+// (wavefront/camera.cpp:64, integrator.cpp:364-368)
+struct CameraRayR { V3 o, d; float time; bool valid; };
+WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSample, V2 pLens) {
+    const wf_camera &C = sv.camera;
+    V3 pCamera = XfPoint(C.cameraFromRaster.m, V3{pFilm.x, pFilm.y, 0});
+    V3 o, d;
+    if (C.type == WF_CAMERA_PERSPECTIVE) {
+        o = V3{0, 0, 0};
+        d = Normalize(pCamera);
+    } else {
+        o = pCamera;
+        d = V3{0, 0, 1};
+    }
+    float time = Lerp(timeSample, C.shutterOpen, C.shutterClose);
+    if (C.lensRadius > 0) {
+        V2 dl = SampleUniformDiskConcentric(pLens);
+        V2 pl{C.lensRadius * dl.x, C.lensRadius * dl.y};
+        float ft = C.focalDistance / d.z;
+        V3 pFocus = o + d * ft;
+        o = V3{pl.x, pl.y, 0};  // both projective cameras (cameras.cpp:301,422)
+        d = Normalize(pFocus - o);
+    }
+    XfRay(C.renderFromCamera.m, &o, &d);
+    // movingFromCamera == identity Transform
+    const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    XfRay(I, &o, &d);
+    return {o, d, time, true};
+}
+
+}  // namespace wf

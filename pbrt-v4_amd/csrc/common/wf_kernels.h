@@ -1,0 +1,456 @@
+// wf_kernels.h — the per-item bodies of the wavefront stages: what the reference writes as lambdas passed
+// to ParallelFor / ForAllQueued (wavefront/integrator.h:91-113, workqueue.h:118-137) are named functions
+// here, launched by the hand-written HIP kernels in csrc/hip/ (and looped over by the CPU checker under
+// oracle/).  One function per K-row of SURVEY.md §2.3.
+//
+// Queue layout (HBM, SoA, one array per member; everything 16 bytes wide where the data allows so a wave
+// reads/writes 1 KiB per instruction):
+//   PixelSampleState  per pixel of the pass        workitems.h:107-116 (visibleSurface dropped: RGBFilm)
+//   RayQueue x2       144 B/ray                    workitems.h:119-130 (lambda is read through pixelIndex:
+//                                                  it always equals PixelSampleState.lambda)
+//   HitRecord         16 B per ray slot            {triangle id, b0, b1, b2}: the MaterialEvalWorkItem /
+//                                                  HitAreaLightWorkItem payloads (252 B / 192 B in the
+//                                                  reference, workitems.h:133-172,265-325) are NOT written
+//                                                  out: the consumers rebuild the SurfaceInteraction from
+//                                                  the triangle and the barycentrics, bit-identically.
+//   index queues      4 B per entry                escaped rays, emitter hits, one per material type
+//   ShadowRayQueue    80 B/ray                     workitems.h:160-172
+#pragma once
+
+#include "wf_bxdf.h"
+#include "wf_camera.h"
+#include "wf_lights.h"
+
+namespace wf {
+
+struct alignas(16) F4 { float x, y, z, w; };
+struct alignas(16) I4 { int32_t x, y, z, w; };
+struct alignas(8) I2 { int32_t x, y; };
+WF_HD F4 toF4(S4 s) { return F4{s[0], s[1], s[2], s[3]}; }
+WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
+
+enum {
+    CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
+    CNT_COUNT = CNT_MAT0 + WF_MAT_NTYPES
+};
+enum { RAYFLAG_SPECULAR_BOUNCE = 1, RAYFLAG_ANY_NONSPECULAR = 2 };
+
+struct RayQueueV {
+    F4 *o;     // o.xyz, time
+    F4 *d;     // d.xyz, etaScale
+    F4 *beta, *r_u, *r_l;
+    F4 *ctx0;  // prevIntrCtx.pi lo.xyz, hi.x
+    F4 *ctx1;  // prevIntrCtx.pi hi.yz, n.xy
+    F4 *ctx2;  // n.z, ns.xyz
+    I4 *meta;  // pixelIndex, depth, flags, medium
+};
+struct ShadowQueueV {
+    F4 *o;     // o.xyz, tMax
+    F4 *d;     // d.xyz, pixelIndex (int bits)
+    F4 *Ld, *r_u, *r_l;
+};
+struct WorkState {
+    int maxQueueSize;
+    // PixelSampleState
+    float *filterWeight;
+    I2 *pPixel;
+    F4 *lambda, *lambdaPdf, *L, *cameraRayWeight;
+    F4 *samples0;  // direct.uc, direct.u.x, direct.u.y, indirect.uc
+    F4 *samples1;  // indirect.u.x, indirect.u.y, indirect.rr, -
+    RayQueueV rq[2];
+    F4 *hit;       // per ray slot of the current queue: triangle id (int bits), b0, b1, b2
+    int32_t *escapedQ, *hitLightQ;
+    int32_t *matQ[WF_MAT_NTYPES];
+    ShadowQueueV sq;
+    int32_t *counters;              // CNT_*
+    double *film;                   // [pixels][4]: rgbSum[3], weightSum (film.h:302-307)
+    unsigned long long *stats;      // cameraRays, indirect[64], shadow[64]
+    unsigned long long *trav;       // wf_traversal_counters (8 x u64) or null
+};
+
+// ---------------------------------------------------------------------------------------------
+// WorkQueue::AllocateEntry (workqueue.h:92-102).  On the device: one atomic per wave per destination
+// queue (ballot + popcount prefix), the slot broadcast from the leader lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline int QueueAlloc(int32_t *counter) {
+    int result = 0;
+    bool done = false;
+    while (!done) {
+        // waterfall over the distinct counters addressed by the active lanes
+        unsigned long long mine = (unsigned long long)counter;
+        unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)mine);
+        unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(mine >> 32));
+        unsigned long long first = ((unsigned long long)hi << 32) | lo;
+        if (mine == first) {
+            unsigned long long mask = __ballot(1);
+            unsigned int lane = __lane_id();
+            unsigned int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            int base = 0;
+            int leader = __ffsll((long long)mask) - 1;
+            if (rank == 0) base = atomicAdd(counter, (int)__popcll(mask));
+            base = __shfl(base, leader);
+            result = base + (int)rank;
+            done = true;
+        }
+    }
+    return result;
+}
+#else
+inline int QueueAlloc(int32_t *counter) { return __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED); }
+#endif
+
+WF_HD Wavelengths LoadLambda(const WorkState &ws, int pixelIndex) {
+    F4 l = ws.lambda[pixelIndex], p = ws.lambdaPdf[pixelIndex];
+    Wavelengths w;
+    w.lambda[0] = l.x; w.lambda[1] = l.y; w.lambda[2] = l.z; w.lambda[3] = l.w;
+    w.pdf[0] = p.x; w.pdf[1] = p.y; w.pdf[2] = p.z; w.pdf[3] = p.w;
+    return w;
+}
+WF_HD void StoreLambda(const WorkState &ws, int pixelIndex, const Wavelengths &w) {
+    ws.lambda[pixelIndex] = F4{w.lambda[0], w.lambda[1], w.lambda[2], w.lambda[3]};
+    ws.lambdaPdf[pixelIndex] = F4{w.pdf[0], w.pdf[1], w.pdf[2], w.pdf[3]};
+}
+WF_HD LightCtx LoadCtx(const RayQueueV &q, int i) {
+    F4 a = q.ctx0[i], b = q.ctx1[i], c = q.ctx2[i];
+    LightCtx ctx;
+    ctx.pi.lo = V3{a.x, a.y, a.z};
+    ctx.pi.hi = V3{a.w, b.x, b.y};
+    ctx.n = N3{b.z, b.w, c.x};
+    ctx.ns = N3{c.y, c.z, c.w};
+    return ctx;
+}
+WF_HD void StoreCtx(const RayQueueV &q, int i, const LightCtx &ctx) {
+    q.ctx0[i] = F4{ctx.pi.lo.x, ctx.pi.lo.y, ctx.pi.lo.z, ctx.pi.hi.x};
+    q.ctx1[i] = F4{ctx.pi.hi.y, ctx.pi.hi.z, ctx.n.x, ctx.n.y};
+    q.ctx2[i] = F4{ctx.n.z, ctx.ns.x, ctx.ns.y, ctx.ns.z};
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: GenerateCameraRays, wavefront/camera.cpp:35-79
+WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixelIndex, int y0, int sampleIndex) {
+    const wf_film &F = sv.film;
+    int xResolution = F.pixel_max[0] - F.pixel_min[0];
+    int px = F.pixel_min[0] + pixelIndex % xResolution;
+    int py = y0 + pixelIndex / xResolution;
+    ws.pPixel[pixelIndex] = I2{px, py};
+    if (!(px >= F.pixel_min[0] && px < F.pixel_max[0] && py >= F.pixel_min[1] && py < F.pixel_max[1])) return;
+    ZSobol sampler(sv);
+    sampler.StartPixelSample(px, py, sampleIndex, 0);
+    float lu = sampler.Get1D();
+    if (sv.options.disable_wavelength_jitter) lu = 0.5f;
+    Wavelengths lambda = SampleVisible(lu);
+    // GetCameraSample, samplers.h:796-814
+    FilterSampleR fs = FilterSample(sv, sampler.GetPixel2D());
+    V2 pFilm{px + fs.p.x + 0.5f, py + fs.p.y + 0.5f};
+    float time = sampler.Get1D();
+    V2 pLens = sampler.Get2D();
+    float filterWeight = fs.weight;
+    if (sv.options.disable_pixel_jitter) {
+        pFilm = V2{px + 0.5f, py + 0.5f};
+        time = 0.5f;
+        pLens = V2{0.5f, 0.5f};
+        filterWeight = 1;
+    }
+    CameraRayR cr = GenerateCameraRay(sv, pFilm, time, pLens);
+    ws.L[pixelIndex] = F4{0, 0, 0, 0};
+    StoreLambda(ws, pixelIndex, lambda);
+    ws.filterWeight[pixelIndex] = filterWeight;
+    if (cr.valid) {
+        // RayQueue::PushCameraRay, workitems.h:346-361
+        const RayQueueV &q = ws.rq[0];
+        int index = QueueAlloc(&ws.counters[CNT_RAY0]);
+        q.o[index] = F4{cr.o.x, cr.o.y, cr.o.z, cr.time};
+        q.d[index] = F4{cr.d.x, cr.d.y, cr.d.z, 1.f};
+        q.beta[index] = F4{1, 1, 1, 1};
+        q.r_u[index] = F4{1, 1, 1, 1};
+        q.r_l[index] = F4{1, 1, 1, 1};
+        q.meta[index] = I4{pixelIndex, 0, 0, sv.camera.medium};
+        ws.cameraRayWeight[pixelIndex] = F4{1, 1, 1, 1};
+    } else ws.cameraRayWeight[pixelIndex] = F4{0, 0, 0, 0};
+}
+
+// K3: GenerateRaySamples, wavefront/samples.cpp:35-65 (no subsurface: dimension = 6 + 7*depth)
+WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur, int i, int sampleIndex) {
+    I4 m = ws.rq[cur].meta[i];
+    int pixelIndex = m.x, depth = m.y;
+    int dimension = 6 + 7 * depth;
+    ZSobol sampler(sv);
+    I2 pp = ws.pPixel[pixelIndex];
+    sampler.StartPixelSample(pp.x, pp.y, sampleIndex, dimension);
+    float duc = sampler.Get1D();
+    V2 du = sampler.Get2D();
+    float iuc = sampler.Get1D();
+    V2 iu = sampler.Get2D();
+    float rr = sampler.Get1D();
+    ws.samples0[pixelIndex] = F4{duc, du.x, du.y, iuc};
+    ws.samples1[pixelIndex] = F4{iu.x, iu.y, rr, 0.f};
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 tail: EnqueueWorkAfterMiss / EnqueueWorkAfterIntersection (wavefront/intersect.h:16-29,48-156) for
+// surfaces without media.  `next` = index of the queue that receives rays re-spawned through "interface"
+// surfaces.
+WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, float b0, float b1, float b2) {
+    if (!found) {
+        if (sv.nInfiniteLights > 0) {
+            int slot = QueueAlloc(&ws.counters[CNT_ESCAPED]);
+            ws.escapedQ[slot] = i;
+        }
+        return;
+    }
+    uint32_t primBits = (uint32_t)prim;
+    ws.hit[i] = F4{BitsToFloat(primBits), b0, b1, b2};
+    const wf_mesh mesh = sv.meshes[sv.triMesh[prim]];
+    if (mesh.material < 0) {
+        // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
+        const RayQueueV &q = ws.rq[cur];
+        const RayQueueV &nq = ws.rq[cur ^ 1];
+        SurfIntr si;
+        TriangleInteraction(sv, prim, b0, b1, b2, &si);
+        F4 o = q.o[i], d = q.d[i];
+        V3 rd{d.x, d.y, d.z};
+        V3 no = OffsetRayOrigin(si.pi, si.n, rd);
+        int slot = QueueAlloc(&ws.counters[CNT_RAY0 + (cur ^ 1)]);
+        nq.o[slot] = F4{no.x, no.y, no.z, o.w};
+        nq.d[slot] = d;
+        nq.beta[slot] = q.beta[i];
+        nq.r_u[slot] = q.r_u[i];
+        nq.r_l[slot] = q.r_l[i];
+        nq.ctx0[slot] = q.ctx0[i];
+        nq.ctx1[slot] = q.ctx1[i];
+        nq.ctx2[slot] = q.ctx2[i];
+        nq.meta[slot] = q.meta[i];
+        return;
+    }
+    if (mesh.first_light >= 0) {
+        int slot = QueueAlloc(&ws.counters[CNT_HITLIGHT]);
+        ws.hitLightQ[slot] = i;
+    }
+    int mtype = sv.materials[mesh.material].type;
+    int slot = QueueAlloc(&ws.counters[CNT_MAT0 + mtype]);
+    ws.matQ[mtype][slot] = i;
+}
+
+// K7: HandleEscapedRays, wavefront/integrator.cpp:495-537
+WF_HD void KHandleEscaped(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    int i = ws.escapedQ[qi];
+    const RayQueueV &q = ws.rq[cur];
+    I4 m = q.meta[i];
+    int pixelIndex = m.x, depth = m.y;
+    bool specularBounce = m.z & RAYFLAG_SPECULAR_BOUNCE;
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    F4 d4 = q.d[i];
+    V3 rayd{d4.x, d4.y, d4.z};
+    S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]), r_l0 = toS4(q.r_l[i]);
+    S4 L = S4c(0.f);
+    for (int k = 0; k < sv.nInfiniteLights; ++k) {
+        int lightId = sv.infiniteLights[k];
+        const wf_light &light = sv.lights[lightId];
+        S4 Le = LightLe(sv, light, rayd, lambda);
+        if (Le) {
+            if (depth == 0 || specularBounce) {
+                L = L + beta * Le / r_u.Average();
+            } else {
+                LightCtx ctx = LoadCtx(q, i);
+                float lightChoicePDF = LightSamplerPMF(sv, ctx, lightId);
+                S4 r_l = r_l0 * lightChoicePDF * LightPDF_Li(sv, light, ctx, rayd, true);
+                L = L + beta * Le / (r_u + r_l).Average();
+            }
+        }
+    }
+    if (L) {
+        L = L + toS4(ws.L[pixelIndex]);
+        ws.L[pixelIndex] = toF4(L);
+    }
+}
+
+// K8: HandleEmissiveIntersection, wavefront/integrator.cpp:539-573
+WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    int i = ws.hitLightQ[qi];
+    const RayQueueV &q = ws.rq[cur];
+    I4 m = q.meta[i];
+    int pixelIndex = m.x, depth = m.y;
+    bool specularBounce = m.z & RAYFLAG_SPECULAR_BOUNCE;
+    F4 h = ws.hit[i];
+    int prim = (int)FloatToBits(h.x);
+    SurfIntr si;
+    TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
+    const wf_mesh &mesh = sv.meshes[si.mesh];
+    int lightId = mesh.first_light + (prim - mesh.first_tri);
+    const wf_light &light = sv.lights[lightId];
+    F4 d4 = q.d[i];
+    V3 wo{-d4.x, -d4.y, -d4.z};
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    S4 Le = AreaLightL(sv, light, si.n, wo, lambda);
+    if (!Le) return;
+    S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]);
+    S4 L;
+    if (depth == 0 || specularBounce) {
+        L = beta * Le / r_u.Average();
+    } else {
+        V3 wi = -wo;
+        LightCtx ctx = LoadCtx(q, i);
+        float lightChoicePDF = LightSamplerPMF(sv, ctx, lightId);
+        float lightPDF = lightChoicePDF * LightPDF_Li(sv, light, ctx, wi, true);
+        S4 r_l = toS4(q.r_l[i]) * lightPDF;
+        L = beta * Le / (r_u + r_l).Average();
+    }
+    L = L + toS4(ws.L[pixelIndex]);
+    ws.L[pixelIndex] = toF4(L);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K9: EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>, wavefront/surfscatter.cpp:57-328
+template <int MAT> struct MatBxDF;
+template <> struct MatBxDF<WF_MAT_DIFFUSE> {
+    using T = DiffuseBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDiffuseBxDF(sv, m, l); }
+};
+template <> struct MatBxDF<WF_MAT_CONDUCTOR> {
+    using T = ConductorBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetConductorBxDF(sv, m, l); }
+};
+template <> struct MatBxDF<WF_MAT_DIELECTRIC> {
+    using T = DielectricBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDielectricBxDF(sv, m, l); }
+};
+template <> struct MatBxDF<WF_MAT_THIN_DIELECTRIC> {
+    using T = ThinDielectricBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetThinDielectricBxDF(sv, m, l); }
+};
+template <> struct MatBxDF<WF_MAT_DIFFUSE_TRANSMISSION> {
+    using T = DiffuseTransmissionBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDiffuseTransmissionBxDF(sv, m, l); }
+};
+
+template <int MAT>
+WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    using BxDF = typename MatBxDF<MAT>::T;
+    int i = ws.matQ[MAT][qi];
+    const RayQueueV &q = ws.rq[cur];
+    const RayQueueV &nq = ws.rq[cur ^ 1];
+    I4 meta = q.meta[i];
+    int pixelIndex = meta.x, depth = meta.y;
+    bool anyNonSpecularBounces0 = meta.z & RAYFLAG_ANY_NONSPECULAR;
+    F4 h = ws.hit[i];
+    int prim = (int)FloatToBits(h.x);
+    SurfIntr si;
+    TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
+    const wf_mesh &mesh = sv.meshes[si.mesh];
+    const wf_material &mat = sv.materials[mesh.material];
+    F4 o4 = q.o[i], d4 = q.d[i];
+    float time = o4.w, etaScale0 = d4.w;
+    V3 wo{-d4.x, -d4.y, -d4.z};
+    // (texture-filtering differentials, surfscatter.cpp:75-104, only feed image textures; the textures
+    // evaluated here are position-independent)
+    N3 ns = si.ns;
+    V3 dpdus = si.dpdus;
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda);
+    BSDF<BxDF> bsdf(ns, dpdus, bxdf);
+    if (lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
+    if (sv.regularize && anyNonSpecularBounces0) bsdf.Regularize();
+
+    S4 wbeta = toS4(q.beta[i]), wr_u = toS4(q.r_u[i]);
+    F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
+    // Sample BSDF and enqueue indirect ray
+    BSDFSample bs = bsdf.Sample_f(wo, s0.w, V2{s1.x, s1.y});
+    if (bs.valid) {
+        V3 wi = bs.wi;
+        S4 beta = wbeta * bs.f * AbsDot(wi, ns) / bs.pdf;
+        S4 r_u = wr_u, r_l;
+        if (bs.pdfIsProportional) r_l = r_u / bsdf.PDF(wo, bs.wi);
+        else r_l = r_u / bs.pdf;
+        float etaScale = etaScale0;
+        if (bs.IsTransmission()) etaScale *= Sqr(bs.eta);
+        S4 rrBeta = beta * etaScale / r_u.Average();
+        if (rrBeta.MaxComponentValue() < 1 && depth >= 1) {
+            float qq = fmax(0.f, 1 - rrBeta.MaxComponentValue());
+            if (s1.z < qq) beta = S4c(0.f);
+            else beta = beta / (1 - qq);
+        }
+        if (beta) {
+            V3 ro = OffsetRayOrigin(si.pi, si.n, wi);
+            int medium = -1;
+            if (sv.haveMedia) medium = Dot(wi, si.n) > 0 ? mesh.medium_outside : mesh.medium_inside;
+            bool anyNonSpecularBounces = !bs.IsSpecularS() || anyNonSpecularBounces0;
+            LightCtx ctx{si.pi, si.n, ns};
+            int slot = QueueAlloc(&ws.counters[CNT_RAY0 + (cur ^ 1)]);
+            nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
+            nq.d[slot] = F4{wi.x, wi.y, wi.z, etaScale};
+            nq.beta[slot] = toF4(beta);
+            nq.r_u[slot] = toF4(r_u);
+            nq.r_l[slot] = toF4(r_l);
+            StoreCtx(nq, slot, ctx);
+            nq.meta[slot] = I4{pixelIndex, depth + 1,
+                               (bs.IsSpecularS() ? RAYFLAG_SPECULAR_BOUNCE : 0) | (anyNonSpecularBounces ? RAYFLAG_ANY_NONSPECULAR : 0), medium};
+        }
+    }
+
+    // Sample light and enqueue shadow ray
+    int flags = bsdf.Flags();
+    if (IsNonSpecular(flags)) {
+        LightCtx ctx{si.pi, si.n, ns};
+        if (IsReflective(flags) && !IsTransmissive(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, wo));
+        else if (IsTransmissive(flags) && IsReflective(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, -wo));
+        float lightPMF;
+        int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
+        if (lightId < 0) return;
+        const wf_light &light = sv.lights[lightId];
+        LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+        if (!ls.valid || !ls.L || ls.pdf == 0) return;
+        V3 wi = ls.wi;
+        S4 f = bsdf.f(wo, wi);
+        if (!f) return;
+        S4 beta = wbeta * f * AbsDot(wi, ns);
+        float lightPDF = ls.pdf * lightPMF;
+        float bsdfPDF = IsDeltaLight(light.type) ? 0.f : bsdf.PDF(wo, wi);
+        S4 r_u = wr_u * bsdfPDF;
+        S4 r_l = wr_u * lightPDF;
+        S4 Ld = beta * ls.L;
+        RayOD sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
+        int slot = QueueAlloc(&ws.counters[CNT_SHADOW]);
+        ws.sq.o[slot] = F4{sr.o.x, sr.o.y, sr.o.z, 1 - ShadowEpsilon};
+        ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)pixelIndex)};
+        ws.sq.Ld[slot] = toF4(Ld);
+        ws.sq.r_u[slot] = toF4(r_u);
+        ws.sq.r_l[slot] = toF4(r_l);
+    }
+}
+
+// K10 tail: RecordShadowRayResult, wavefront/intersect.h:31-46
+WF_HD void KRecordShadowRay(const WorkState &ws, int i, bool occluded) {
+    if (occluded) return;
+    S4 Ld = toS4(ws.sq.Ld[i]) / (toS4(ws.sq.r_u[i]) + toS4(ws.sq.r_l[i])).Average();
+    int pixelIndex = (int)FloatToBits(ws.sq.d[i].w);
+    S4 Lpixel = toS4(ws.L[pixelIndex]);
+    ws.L[pixelIndex] = toF4(Lpixel + Ld);
+}
+
+// K13: UpdateFilm (wavefront/film.cpp:14-38) -> RGBFilm::AddSample (film.h:239-255) -> PixelSensor::ToSensorRGB (film.h:95-101)
+WF_HD void KUpdateFilm(const SceneView &sv, const WorkState &ws, int pixelIndex) {
+    const wf_film &F = sv.film;
+    I2 pp = ws.pPixel[pixelIndex];
+    if (!(pp.x >= F.pixel_min[0] && pp.x < F.pixel_max[0] && pp.y >= F.pixel_min[1] && pp.y < F.pixel_max[1])) return;
+    S4 Lw = toS4(ws.L[pixelIndex]) * toS4(ws.cameraRayWeight[pixelIndex]);
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    float filterWeight = ws.filterWeight[pixelIndex];
+    S4 L = SafeDiv(Lw, lambda.PDF());
+    float r = F.imaging_ratio * (DenseSample(sv, F.rbar_offset, lambda) * L).Average();
+    float g = F.imaging_ratio * (DenseSample(sv, F.gbar_offset, lambda) * L).Average();
+    float b = F.imaging_ratio * (DenseSample(sv, F.bbar_offset, lambda) * L).Average();
+    float m = fmax(fmax(r, g), b);
+    if (m > F.max_component_value) {
+        float s = F.max_component_value / m;
+        r *= s; g *= s; b *= s;
+    }
+    int width = F.pixel_max[0] - F.pixel_min[0];
+    size_t idx = (size_t)(pp.y - F.pixel_min[1]) * width + (pp.x - F.pixel_min[0]);
+    double *px = ws.film + 4 * idx;
+    px[0] += filterWeight * r;
+    px[1] += filterWeight * g;
+    px[2] += filterWeight * b;
+    px[3] += filterWeight;
+}
+
+}  // namespace wf

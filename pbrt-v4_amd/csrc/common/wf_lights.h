@@ -1,0 +1,233 @@
+// wf_lights.h — Light::SampleLi / PDF_Li / L / Le and the light samplers over the flat light table.
+// Restates lights.h:205-233 (point), 262-290 (distant), 441-470 + lights.cpp:739-767 (diffuse area),
+// 771-783 + lights.cpp:1360-1363 (spot), lights.cpp:950-972 (uniform infinite),
+// lightsamplers.h:26-60 (uniform), 101-257 (CompactLightBounds), 260-358 (BVH sampler).
+#pragma once
+
+#include "wf_shapes.h"
+
+namespace wf {
+
+// LightSampleContext, base/light.h:120-160
+struct LightCtx {
+    P3i pi;
+    N3 n, ns;
+    WF_HD V3 p() const { return pi.mid(); }
+};
+
+struct LightLiSample {
+    S4 L;
+    V3 wi;
+    float pdf;
+    P3i pLightPi;  // pLight.pi
+    N3 pLightN;    // pLight.n
+    bool valid;
+};
+
+WF_HD bool IsDeltaLight(int type) { return type == WF_LIGHT_POINT || type == WF_LIGHT_SPOT || type == WF_LIGHT_DISTANT; }
+
+WF_HD float SmoothStep(float x, float a, float b) {
+    if (a == b) return (x < a) ? 0 : 1;
+    float t = Clamp((x - a) / (b - a), 0.f, 1.f);
+    return t * t * (3 - 2 * t);
+}
+WF_HD V3 SampleUniformSphere(V2 u) {
+    float z = 1 - 2 * u.x;
+    float r = SafeSqrt(1 - Sqr(z));
+    float phi = 2 * Pi * u.y;
+    return {r * cos(phi), r * sin(phi), z};
+}
+
+// DiffuseAreaLight::L, lights.h:441-463 (no alpha, no image)
+WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, N3 n, V3 w, const Wavelengths &lambda) {
+    if (!(l.flags & WF_LIGHTFLAG_TWOSIDED) && Dot(n, w) < 0) return S4c(0.f);
+    return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+}
+
+WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V2 u,
+                                  const Wavelengths &lambda, bool allowIncompletePDF) {
+    LightLiSample ls{};
+    ls.valid = false;
+    switch (l.type) {
+    case WF_LIGHT_DIFFUSE_AREA: {
+        ShapeSampleR ss = TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
+        if (!ss.valid || ss.pdf == 0 || LengthSquared(ss.pi.mid() - ctx.p()) == 0) return ls;
+        V3 wi = Normalize(ss.pi.mid() - ctx.p());
+        S4 Le = AreaLightL(sv, l, ss.n, -wi, lambda);
+        if (!Le) return ls;
+        ls.L = Le; ls.wi = wi; ls.pdf = ss.pdf; ls.pLightPi = ss.pi; ls.pLightN = ss.n; ls.valid = true;
+        return ls;
+    }
+    case WF_LIGHT_POINT: {
+        V3 p{l.pos[0], l.pos[1], l.pos[2]};
+        V3 wi = Normalize(p - ctx.p());
+        S4 Li = l.scale * DenseSample(sv, l.spectrum_offset, lambda) / DistanceSquared(p, ctx.p());
+        ls.L = Li; ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(p); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
+    case WF_LIGHT_SPOT: {
+        V3 p{l.pos[0], l.pos[1], l.pos[2]};
+        V3 wi = Normalize(p - ctx.p());
+        const wf_transform &X = sv.lightXforms[l.xform];
+        V3 mw = -wi;
+        V3 wl{X.mInv[0][0] * mw.x + X.mInv[0][1] * mw.y + X.mInv[0][2] * mw.z,
+              X.mInv[1][0] * mw.x + X.mInv[1][1] * mw.y + X.mInv[1][2] * mw.z,
+              X.mInv[2][0] * mw.x + X.mInv[2][1] * mw.y + X.mInv[2][2] * mw.z};
+        V3 wLight = Normalize(wl);
+        S4 I = SmoothStep(wLight.z, l.cosFalloffEnd, l.cosFalloffStart) * l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+        S4 Li = I / DistanceSquared(p, ctx.p());
+        if (!Li) return ls;
+        ls.L = Li; ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(p); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
+    case WF_LIGHT_DISTANT: {
+        V3 wi{l.pos[0], l.pos[1], l.pos[2]};
+        V3 pOutside = ctx.p() + wi * (2 * l.sceneRadius);
+        ls.L = l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+        ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(pOutside); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
+    case WF_LIGHT_UNIFORM_INFINITE: {
+        if (allowIncompletePDF) return ls;
+        V3 wi = SampleUniformSphere(u);
+        ls.L = l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+        ls.wi = wi; ls.pdf = Inv4Pi;
+        ls.pLightPi = MakeP3i(ctx.p() + wi * (2 * l.sceneRadius)); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
+    default: return ls;
+    }
+}
+
+WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V3 wi, bool allowIncompletePDF) {
+    switch (l.type) {
+    case WF_LIGHT_DIFFUSE_AREA: return TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
+    case WF_LIGHT_UNIFORM_INFINITE: return allowIncompletePDF ? 0.f : Inv4Pi;
+    default: return 0.f;
+    }
+}
+// Light::Le for infinite lights (lights.h:172-174 for the others)
+WF_HD S4 LightLe(const SceneView &sv, const wf_light &l, V3 rayd, const Wavelengths &lambda) {
+    if (l.type == WF_LIGHT_UNIFORM_INFINITE) return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+    return S4c(0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CompactLightBounds::Importance, lightsamplers.h:144-201
+WF_HD float LightBoundsImportance(const SceneView &sv, const wf_light_bvh_node &nd, V3 p, N3 n) {
+    const float *ab = sv.allLightBounds;
+    B3 bounds;
+    bounds.pMin = V3{Lerp(nd.qb[0][0] / 65535.f, ab[0], ab[3]), Lerp(nd.qb[0][1] / 65535.f, ab[1], ab[4]), Lerp(nd.qb[0][2] / 65535.f, ab[2], ab[5])};
+    bounds.pMax = V3{Lerp(nd.qb[1][0] / 65535.f, ab[0], ab[3]), Lerp(nd.qb[1][1] / 65535.f, ab[1], ab[4]), Lerp(nd.qb[1][2] / 65535.f, ab[2], ab[5])};
+    uint32_t qo = nd.cos_bits & 0x7fffu, qe = (nd.cos_bits >> 15) & 0x7fffu;
+    bool twoSided = (nd.cos_bits >> 30) & 1u;
+    float cosTheta_o = 2 * (qo / 32767.f) - 1, cosTheta_e = 2 * (qe / 32767.f) - 1;
+    V3 pc = (bounds.pMin + bounds.pMax) / 2;
+    float d2 = DistanceSquared(p, pc);
+    d2 = fmax(d2, Length(bounds.Diagonal()) / 2);
+    auto cosSubClamped = [](float sinTheta_a, float cosTheta_a, float sinTheta_b, float cosTheta_b) -> float {
+        if (cosTheta_a > cosTheta_b) return 1;
+        return cosTheta_a * cosTheta_b + sinTheta_a * sinTheta_b;
+    };
+    auto sinSubClamped = [](float sinTheta_a, float cosTheta_a, float sinTheta_b, float cosTheta_b) -> float {
+        if (cosTheta_a > cosTheta_b) return 0;
+        return sinTheta_a * cosTheta_b - cosTheta_a * sinTheta_b;
+    };
+    V3 wi = Normalize(p - pc);
+    V3 w = OctahedralToVector(nd.w_oct[0], nd.w_oct[1]);
+    float cosTheta_w = Dot(w, wi);
+    if (twoSided) cosTheta_w = abs(cosTheta_w);
+    float sinTheta_w = SafeSqrt(1 - Sqr(cosTheta_w));
+    float cosTheta_b = BoundSubtendedDirections(bounds, p).cosTheta;
+    float sinTheta_b = SafeSqrt(1 - Sqr(cosTheta_b));
+    float sinTheta_o = SafeSqrt(1 - Sqr(cosTheta_o));
+    float cosTheta_x = cosSubClamped(sinTheta_w, cosTheta_w, sinTheta_o, cosTheta_o);
+    float sinTheta_x = sinSubClamped(sinTheta_w, cosTheta_w, sinTheta_o, cosTheta_o);
+    float cosThetap = cosSubClamped(sinTheta_x, cosTheta_x, sinTheta_b, cosTheta_b);
+    if (cosThetap <= cosTheta_e) return 0;
+    float importance = nd.phi * cosThetap / d2;
+    if (!IsZero(n)) {
+        float cosTheta_i = AbsDot(wi, n);
+        float sinTheta_i = SafeSqrt(1 - Sqr(cosTheta_i));
+        float cosThetap_i = cosSubClamped(sinTheta_i, cosTheta_i, sinTheta_b, cosTheta_b);
+        importance *= cosThetap_i;
+    }
+    importance = fmax(importance, 0.f);
+    return importance;
+}
+
+// LightSampler::Sample(ctx, u): returns light id or -1, and its pmf
+WF_HD int LightSamplerSample(const SceneView &sv, const LightCtx &ctx, float u, float *pmfOut) {
+    if (sv.lightSampler == WF_LS_UNIFORM) {
+        // lightsamplers.h:33-38
+        if (sv.nLights == 0) return -1;
+        int lightIndex = (int)(u * sv.nLights);
+        if (lightIndex > sv.nLights - 1) lightIndex = sv.nLights - 1;
+        *pmfOut = 1.f / sv.nLights;
+        return lightIndex;
+    }
+    // BVHLightSampler::Sample, lightsamplers.h:266-320
+    int nInf = sv.nInfiniteLights;
+    bool nodesEmpty = sv.nLightBvhNodes == 0;
+    float pInfinite = float(nInf) / float(nInf + (nodesEmpty ? 0 : 1));
+    if (u < pInfinite) {
+        u /= pInfinite;
+        int index = (int)(u * nInf);
+        if (index > nInf - 1) index = nInf - 1;
+        *pmfOut = pInfinite / nInf;
+        return sv.infiniteLights[index];
+    }
+    if (nodesEmpty) return -1;
+    V3 p = ctx.p();
+    N3 n = ctx.ns;
+    u = fmin((u - pInfinite) / (1 - pInfinite), OneMinusEpsilon);
+    int nodeIndex = 0;
+    float pmf = 1 - pInfinite;
+    while (true) {
+        wf_light_bvh_node node = sv.lightBvh[nodeIndex];
+        bool isLeaf = node.child_or_light >> 31;
+        int childOrLight = (int)(node.child_or_light & 0x7fffffffu);
+        if (!isLeaf) {
+            float ci0 = LightBoundsImportance(sv, sv.lightBvh[nodeIndex + 1], p, n);
+            float ci1 = LightBoundsImportance(sv, sv.lightBvh[childOrLight], p, n);
+            if (ci0 == 0 && ci1 == 0) return -1;
+            float nodePMF;
+            int child = SampleDiscrete2(ci0, ci1, u, &nodePMF, &u);
+            pmf *= nodePMF;
+            nodeIndex = (child == 0) ? (nodeIndex + 1) : childOrLight;
+        } else {
+            if (nodeIndex > 0 || LightBoundsImportance(sv, node, p, n) > 0) {
+                *pmfOut = pmf;
+                return childOrLight;
+            }
+            return -1;
+        }
+    }
+}
+
+// LightSampler::PMF(ctx, light)
+WF_HD float LightSamplerPMF(const SceneView &sv, const LightCtx &ctx, int lightId) {
+    if (sv.lightSampler == WF_LS_UNIFORM) return sv.nLights == 0 ? 0.f : 1.f / sv.nLights;
+    // BVHLightSampler::PMF, lightsamplers.h:323-358
+    const wf_light &l = sv.lights[lightId];
+    int nInf = sv.nInfiniteLights;
+    bool nodesEmpty = sv.nLightBvhNodes == 0;
+    if (l.bit_trail < 0) return 1.f / (nInf + (nodesEmpty ? 0 : 1));
+    uint32_t bitTrail = (uint32_t)l.bit_trail;
+    V3 p = ctx.p();
+    N3 n = ctx.ns;
+    float pInfinite = float(nInf) / float(nInf + (nodesEmpty ? 0 : 1));
+    float pmf = 1 - pInfinite;
+    int nodeIndex = 0;
+    while (true) {
+        const wf_light_bvh_node node = sv.lightBvh[nodeIndex];
+        if (node.child_or_light >> 31) return pmf;
+        int child1 = (int)(node.child_or_light & 0x7fffffffu);
+        float ci[2] = {LightBoundsImportance(sv, sv.lightBvh[nodeIndex + 1], p, n), LightBoundsImportance(sv, sv.lightBvh[child1], p, n)};
+        pmf *= ci[bitTrail & 1] / (ci[0] + ci[1]);
+        nodeIndex = (bitTrail & 1) ? child1 : (nodeIndex + 1);
+        bitTrail >>= 1;
+    }
+}
+
+}  // namespace wf

@@ -1,0 +1,188 @@
+// wf_scene.h — the read-only scene as the kernels see it: one struct of raw pointers into the flat,
+// index-addressed tables of wf_scene_desc (include/wf_abi.h).  On the GPU the pointers are device
+// addresses (csrc/hip/wf_backend.hip uploads them); the CPU checker under oracle/ points the same struct
+// at the host tables.  No host pointers, no virtual calls, no tagged pointers cross to the device: the
+// reference's TaggedPointer dispatch (util/taggedptr.h:736-870) becomes a switch on an integer tag.
+#pragma once
+
+#include "wf_math.h"
+#include "../../../include/wf_abi.h"
+
+namespace wf {
+
+struct SceneView {
+    // geometry (util/mesh.h TriangleMesh buffers, flattened over all meshes)
+    const float *P, *N, *UV;
+    const int32_t *triIndices, *triMesh;
+    const wf_mesh *meshes;
+    const wf_bvh_node *bvhNodes;
+    const int32_t *bvhPrims;
+    int nTriangles, nBvhNodes;
+    // shading
+    const wf_spectrum *spectra;
+    const float *spectrumData;
+    const wf_texture *textures;
+    const wf_material *materials;
+    // lights
+    const wf_light *lights;
+    const int32_t *infiniteLights;
+    const wf_light_bvh_node *lightBvh;
+    const wf_transform *lightXforms;
+    int nLights, nInfiniteLights, nLightBvhNodes, lightSampler;
+    float allLightBounds[6];
+    // camera / film / filter / sampler
+    wf_camera camera;
+    wf_film film;
+    wf_filter filter;
+    const float *filterData;
+    wf_sampler sampler;
+    const uint32_t *sobol;  // SobolMatrices32 rows for dimensions 0 and 1 (2 x 52)
+    // integrator
+    int maxDepth, regularize, haveMedia;
+    wf_options options;
+};
+
+// SobolMatrices32 dimensions 0 and 1 (util/sobolmatrices.cpp:40-58).  Dimension 0 is the van der Corput
+// identity matrix, dimension 1 the Pascal-triangle matrix v[i] = v[i-1] ^ (v[i-1] >> 1); both are padded
+// to SobolMatrixSize = 52 columns the way the reference table is (zeros, resp. the period-32 repeat).
+// The ZSobol sampler (samplers.h:261-291) only ever asks for these two dimensions.
+inline void FillSobol2D(uint32_t out[104]) {
+    uint32_t v = 0x80000000u;
+    uint32_t d1[32];
+    for (int i = 0; i < 32; ++i) { d1[i] = v; v ^= v >> 1; }
+    for (int i = 0; i < 52; ++i) {
+        out[i] = i < 32 ? (0x80000000u >> i) : 0u;
+        out[52 + i] = d1[i & 31];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spectrum::Sample (util/spectrum.h) over the flattened descriptors
+WF_HD S4 DenseSample(const SceneView &sv, int offset, const Wavelengths &lambda) {
+    // DenselySampledSpectrum::Sample, util/spectrum.h:387-397 (lambda_min = 360, 471 values)
+    S4 s;
+    for (int i = 0; i < 4; ++i) {
+        int o = (int)lround(lambda.lambda[i]) - WF_LAMBDA_MIN;
+        s[i] = (o < 0 || o >= WF_NDENSE) ? 0.f : sv.spectrumData[offset + o];
+    }
+    return s;
+}
+WF_HD float PiecewiseEval(const float *lambdas, const float *values, int n, float lambda) {
+    // util/spectrum.cpp:64-74
+    if (n == 0 || lambda < lambdas[0] || lambda > lambdas[n - 1]) return 0;
+    int o = FindInterval(n, [&](int i) { return lambdas[i] <= lambda; });
+    float t = (lambda - lambdas[o]) / (lambdas[o + 1] - lambdas[o]);
+    return Lerp(t, values[o], values[o + 1]);
+}
+WF_HD S4 SpectrumSample(const SceneView &sv, int id, const Wavelengths &lambda) {
+    const wf_spectrum sp = sv.spectra[id];
+    S4 s;
+    switch (sp.type) {
+    case WF_SPEC_CONSTANT: return S4c(sp.c0);
+    case WF_SPEC_DENSE: return DenseSample(sv, sp.offset, lambda);
+    case WF_SPEC_PIECEWISE:
+        for (int i = 0; i < 4; ++i)
+            s[i] = PiecewiseEval(sv.spectrumData + sp.offset, sv.spectrumData + sp.offset + sp.n, sp.n, lambda.lambda[i]);
+        return s;
+    case WF_SPEC_RGB_ALBEDO:
+        for (int i = 0; i < 4; ++i) s[i] = SigmoidPoly(lambda.lambda[i], sp.c0, sp.c1, sp.c2);
+        return s;
+    case WF_SPEC_RGB_UNBOUNDED:
+        for (int i = 0; i < 4; ++i) s[i] = sp.scale * SigmoidPoly(lambda.lambda[i], sp.c0, sp.c1, sp.c2);
+        return s;
+    case WF_SPEC_RGB_ILLUMINANT:
+        for (int i = 0; i < 4; ++i) s[i] = sp.scale * SigmoidPoly(lambda.lambda[i], sp.c0, sp.c1, sp.c2);
+        return s * DenseSample(sv, sp.offset, lambda);
+    case WF_SPEC_BLACKBODY:
+        for (int i = 0; i < 4; ++i) s[i] = Blackbody(lambda.lambda[i], sp.c0) * sp.c1;
+        return s;
+    default: return S4c(0.f);
+    }
+}
+// Spectrum::operator()(lambda) for a single wavelength (materials.h:162 eta(lambda[0]))
+WF_HD float SpectrumEval(const SceneView &sv, int id, float lambda) {
+    const wf_spectrum sp = sv.spectra[id];
+    switch (sp.type) {
+    case WF_SPEC_CONSTANT: return sp.c0;
+    case WF_SPEC_DENSE: {
+        // DenselySampledSpectrum::operator(), util/spectrum.h:432-438
+        int o = (int)lround(lambda) - WF_LAMBDA_MIN;
+        return (o < 0 || o >= WF_NDENSE) ? 0.f : sv.spectrumData[sp.offset + o];
+    }
+    case WF_SPEC_PIECEWISE:
+        return PiecewiseEval(sv.spectrumData + sp.offset, sv.spectrumData + sp.offset + sp.n, sp.n, lambda);
+    case WF_SPEC_RGB_ALBEDO: return SigmoidPoly(lambda, sp.c0, sp.c1, sp.c2);
+    case WF_SPEC_RGB_UNBOUNDED: return sp.scale * SigmoidPoly(lambda, sp.c0, sp.c1, sp.c2);
+    case WF_SPEC_RGB_ILLUMINANT: {
+        int o = (int)lround(lambda) - WF_LAMBDA_MIN;
+        float ill = (o < 0 || o >= WF_NDENSE) ? 0.f : sv.spectrumData[sp.offset + o];
+        return sp.scale * SigmoidPoly(lambda, sp.c0, sp.c1, sp.c2) * ill;
+    }
+    case WF_SPEC_BLACKBODY: return Blackbody(lambda, sp.c0) * sp.c1;
+    default: return 0.f;
+    }
+}
+WF_HD bool SpectrumIsConstant(const SceneView &sv, int id) { return sv.spectra[id].type == WF_SPEC_CONSTANT; }
+
+// ---------------------------------------------------------------------------------------------
+// BasicTextureEvaluator over the flattened texture nodes (textures.h:1092-1137): constant, scale, mix.
+// The node tree is walked with a compile-time depth bound (WF_TEX_MAX_DEPTH, enforced by the host
+// builder) so the device code has no recursion and inlines completely.  Image textures arrive with the
+// image-texture row of SURVEY.md §8(f).
+#define WF_TEX_MAX_DEPTH 3
+template <int D>
+WF_HD float EvalFloatTextureD(const SceneView &sv, int id) {
+    const wf_texture t = sv.textures[id];
+    if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
+    if constexpr (D > 0) {
+        if (t.type == WF_TEX_FLOAT_SCALE) {
+            // FloatScaledTexture::Evaluate, textures.h:1039-1044
+            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1);
+            if (sc == 0) return 0;
+            return EvalFloatTextureD<D - 1>(sv, t.tex0) * sc;
+        }
+        if (t.type == WF_TEX_FLOAT_MIX) {
+            // FloatMixTexture::Evaluate, textures.h:810-818
+            float amt = EvalFloatTextureD<D - 1>(sv, t.tex2);
+            float t1 = 0, t2 = 0;
+            if (amt != 1) t1 = EvalFloatTextureD<D - 1>(sv, t.tex0);
+            if (amt != 0) t2 = EvalFloatTextureD<D - 1>(sv, t.tex1);
+            return (1 - amt) * t1 + amt * t2;
+        }
+    }
+    return 0.f;
+}
+WF_HD float EvalFloatTexture(const SceneView &sv, int id) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(sv, id); }
+template <int D>
+WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda) {
+    const wf_texture t = sv.textures[id];
+    if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
+    if constexpr (D > 0) {
+        if (t.type == WF_TEX_SPECTRUM_SCALE) {
+            // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
+            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1);
+            if (sc == 0) return S4c(0.f);
+            return EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda) * sc;
+        }
+        if (t.type == WF_TEX_SPECTRUM_MIX) {
+            // SpectrumMixTexture::Evaluate, textures.h:840-850
+            float amt = EvalFloatTextureD<D - 1>(sv, t.tex2);
+            S4 t1 = S4c(0.f), t2 = S4c(0.f);
+            if (amt != 1) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda);
+            if (amt != 0) t2 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda);
+            return (1 - amt) * t1 + amt * t2;
+        }
+    }
+    return S4c(0.f);
+}
+WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda) {
+    return EvalSpectrumTextureD<WF_TEX_MAX_DEPTH>(sv, id, lambda);
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry accessors
+WF_HD V3 LoadP(const SceneView &sv, int v) { return V3{sv.P[3 * v], sv.P[3 * v + 1], sv.P[3 * v + 2]}; }
+WF_HD N3 LoadN(const SceneView &sv, int v) { return N3{sv.N[3 * v], sv.N[3 * v + 1], sv.N[3 * v + 2]}; }
+WF_HD V2 LoadUV(const SceneView &sv, int v) { return V2{sv.UV[2 * v], sv.UV[2 * v + 1]}; }
+
+}  // namespace wf

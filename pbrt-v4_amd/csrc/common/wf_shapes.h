@@ -1,0 +1,423 @@
+// wf_shapes.h — ray/triangle and ray/box arithmetic, the BVH walk, surface-interaction reconstruction
+// and triangle sampling.  Operation-for-operation restatements of
+//   shapes.cpp:168-269        IntersectTriangle (watertight test, fp64 edge fallback, delta-t bound)
+//   shapes.h:884-1010         Triangle::InteractionFromIntersection
+//   shapes.h:1013-1180        Triangle::Sample / PDF (area + spherical-triangle sampling)
+//   util/vecmath.h:1574-1608  Bounds3::IntersectP (slab test with the 1+2*gamma(3) widening)
+//   cpu/aggregates.cpp:529-624 BVHAggregate::Intersect / IntersectP (near-child-first by dirIsNeg[axis])
+// so that hits, barycentrics and error bounds are bit-identical to the reference's CPU path.
+#pragma once
+
+#include "wf_scene.h"
+
+namespace wf {
+
+struct TriHit { float b0, b1, b2, t; };
+
+WF_HD bool IntersectTriangle(V3 ro, V3 rd, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
+    if (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0) return false;
+    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    int kz = MaxComponentIndex(Abs(rd));
+    int kx = kz + 1;
+    if (kx == 3) kx = 0;
+    int ky = kx + 1;
+    if (ky == 3) ky = 0;
+    V3 d = Permute(rd, kx, ky, kz);
+    p0t = Permute(p0t, kx, ky, kz);
+    p1t = Permute(p1t, kx, ky, kz);
+    p2t = Permute(p2t, kx, ky, kz);
+    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1 / d.z;
+    p0t.x += Sx * p0t.z;
+    p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z;
+    p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z;
+    p2t.y += Sy * p2t.z;
+    float e0 = DifferenceOfProducts(p1t.x, p2t.y, p1t.y, p2t.x);
+    float e1 = DifferenceOfProducts(p2t.x, p0t.y, p2t.y, p0t.x);
+    float e2 = DifferenceOfProducts(p0t.x, p1t.y, p0t.y, p1t.x);
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y;
+        double p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y;
+        double p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y;
+        double p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= Sz;
+    p1t.z *= Sz;
+    p2t.z *= Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return false;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    float maxZt = MaxComponentValue(Abs(V3{p0t.z, p1t.z, p2t.z}));
+    float deltaZ = gamma(3) * maxZt;
+    float maxXt = MaxComponentValue(Abs(V3{p0t.x, p1t.x, p2t.x}));
+    float maxYt = MaxComponentValue(Abs(V3{p0t.y, p1t.y, p2t.y}));
+    float deltaX = gamma(5) * (maxXt + maxZt);
+    float deltaY = gamma(5) * (maxYt + maxZt);
+    float deltaE = 2 * (gamma(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = MaxComponentValue(Abs(V3{e0, e1, e2}));
+    float deltaT = 3 * (gamma(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * abs(invDet);
+    if (t <= deltaT) return false;
+    hit->b0 = b0; hit->b1 = b1; hit->b2 = b2; hit->t = t;
+    return true;
+}
+
+// Bounds3::IntersectP with precomputed invDir/dirIsNeg.  dirIsNeg travels as a 3-bit mask (bit a = ray
+// direction negative along axis a) so that nothing is a runtime-indexed private array on the device.
+WF_HD bool BoxIntersectP(const float bmin[3], const float bmax[3], V3 o, float raytMax, V3 invDir, int negMask) {
+    const bool n0 = negMask & 1, n1 = negMask & 2, n2 = negMask & 4;
+    float tMin = ((n0 ? bmax[0] : bmin[0]) - o.x) * invDir.x;
+    float tMax = ((n0 ? bmin[0] : bmax[0]) - o.x) * invDir.x;
+    float tyMin = ((n1 ? bmax[1] : bmin[1]) - o.y) * invDir.y;
+    float tyMax = ((n1 ? bmin[1] : bmax[1]) - o.y) * invDir.y;
+    tMax *= 1 + 2 * gamma(3);
+    tyMax *= 1 + 2 * gamma(3);
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((n2 ? bmax[2] : bmin[2]) - o.z) * invDir.z;
+    float tzMax = ((n2 ? bmin[2] : bmax[2]) - o.z) * invDir.z;
+    tzMax *= 1 + 2 * gamma(3);
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    return (tMin < raytMax) && (tMax > 0);
+}
+
+WF_HD void TriVerts(const SceneView &sv, int tri, V3 *p0, V3 *p1, V3 *p2) {
+    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    *p0 = LoadP(sv, v[0]); *p1 = LoadP(sv, v[1]); *p2 = LoadP(sv, v[2]);
+}
+
+// Reference-order BVH walk.  Stack is any type with push(int)/pop()/empty(); the HIP kernels pass an
+// LDS-backed short stack (csrc/hip/wf_traverse.hip), the CPU checker a plain array.
+struct ClosestHit { int prim; TriHit h; int nodesVisited, trisTested; };
+
+template <typename Stack>
+WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, ClosestHit *out) {
+    out->prim = -1;
+    out->nodesVisited = 0;
+    out->trisTested = 0;
+    V3 invDir{1 / d.x, 1 / d.y, 1 / d.z};
+    int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
+    int currentNodeIndex = 0;
+    while (true) {
+        ++out->nodesVisited;
+        const wf_bvh_node *node = &sv.bvhNodes[currentNodeIndex];
+        if (BoxIntersectP(node->bmin, node->bmax, o, tMax, invDir, negMask)) {
+            if (node->nprims > 0) {
+                for (int i = 0; i < node->nprims; ++i) {
+                    int tri = sv.bvhPrims[node->offset + i];
+                    V3 p0, p1, p2;
+                    TriVerts(sv, tri, &p0, &p1, &p2);
+                    TriHit h;
+                    ++out->trisTested;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) {
+                        out->prim = tri;
+                        out->h = h;
+                        tMax = h.t;
+                    }
+                }
+                if (stack.empty()) break;
+                currentNodeIndex = stack.pop();
+            } else {
+                if ((negMask >> node->axis) & 1) {
+                    stack.push(currentNodeIndex + 1);
+                    currentNodeIndex = node->offset;
+                } else {
+                    stack.push(node->offset);
+                    currentNodeIndex = currentNodeIndex + 1;
+                }
+            }
+        } else {
+            if (stack.empty()) break;
+            currentNodeIndex = stack.pop();
+        }
+    }
+    return out->prim >= 0;
+}
+
+template <typename Stack>
+WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, int *nodesVisited, int *trisTested) {
+    V3 invDir{1.f / d.x, 1.f / d.y, 1.f / d.z};
+    int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
+    int currentNodeIndex = 0;
+    int nv = 0, nt = 0;
+    bool found = false;
+    while (true) {
+        ++nv;
+        const wf_bvh_node *node = &sv.bvhNodes[currentNodeIndex];
+        if (BoxIntersectP(node->bmin, node->bmax, o, tMax, invDir, negMask)) {
+            if (node->nprims > 0) {
+                for (int i = 0; i < node->nprims && !found; ++i) {
+                    int tri = sv.bvhPrims[node->offset + i];
+                    V3 p0, p1, p2;
+                    TriVerts(sv, tri, &p0, &p1, &p2);
+                    TriHit h;
+                    ++nt;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) found = true;
+                }
+                if (found || stack.empty()) break;
+                currentNodeIndex = stack.pop();
+            } else {
+                if ((negMask >> node->axis) & 1) {
+                    stack.push(currentNodeIndex + 1);
+                    currentNodeIndex = node->offset;
+                } else {
+                    stack.push(node->offset);
+                    currentNodeIndex = currentNodeIndex + 1;
+                }
+            }
+        } else {
+            if (stack.empty()) break;
+            currentNodeIndex = stack.pop();
+        }
+    }
+    if (nodesVisited) *nodesVisited = nv;
+    if (trisTested) *trisTested = nt;
+    return found;
+}
+
+struct ArrayStack {  // int nodesToVisit[64], cpu/aggregates.cpp:538
+    int s[64];
+    int n = 0;
+    WF_HD void push(int v) { s[n++] = v; }
+    WF_HD int pop() { return s[--n]; }
+    WF_HD bool empty() const { return n == 0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// SurfaceInteraction as the material kernels need it (interaction.h:131-260)
+struct SurfIntr {
+    P3i pi;
+    N3 n;
+    V2 uv;
+    V3 dpdu, dpdv;
+    N3 dndu, dndv;
+    N3 ns;            // shading.n
+    V3 dpdus, dpdvs;  // shading.dpdu/dpdv
+    N3 dndus, dndvs;
+    int mesh;
+};
+
+// vector-valued DifferenceOfProducts(float, Tuple, float, Tuple) (util/math.h:569-575 over Tuple3 FMA)
+WF_HD V3 DifferenceOfProductsV(float a, V3 b, float c, V3 d) {
+    return V3{DifferenceOfProducts(a, b.x, c, d.x), DifferenceOfProducts(a, b.y, c, d.y), DifferenceOfProducts(a, b.z, c, d.z)};
+}
+WF_HD N3 DifferenceOfProductsN(float a, N3 b, float c, N3 d) {
+    return N3{DifferenceOfProducts(a, b.x, c, d.x), DifferenceOfProducts(a, b.y, c, d.y), DifferenceOfProducts(a, b.z, c, d.z)};
+}
+
+// Triangle::InteractionFromIntersection, shapes.h:884-1010.  `full` = also the shading derivatives.
+WF_HD void TriangleInteraction(const SceneView &sv, int tri, float b0, float b1, float b2, SurfIntr *si) {
+    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const int meshId = sv.triMesh[tri];
+    const wf_mesh mesh = sv.meshes[meshId];
+    si->mesh = meshId;
+    V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
+    V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
+    if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+    V2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float determinant = DifferenceOfProducts(duv02.x, duv12.y, duv02.y, duv12.x);
+    V3 dpdu{0, 0, 0}, dpdv{0, 0, 0};
+    bool degenerateUV = abs(determinant) < 1e-9f;
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        dpdu = DifferenceOfProductsV(duv12.y, dp02, duv02.y, dp12) * invdet;
+        dpdv = DifferenceOfProductsV(duv02.x, dp12, duv12.x, dp02) * invdet;
+    }
+    if (degenerateUV || LengthSquared(Cross(dpdu, dpdv)) == 0) {
+        V3 ng = Cross(p2 - p0, p1 - p0);
+        if (LengthSquared(ng) == 0) {
+            // Cross(Vector3<double>, Vector3<double>) — the double DifferenceOfProducts, util/math.h:569
+            V3 a = p2 - p0, b = p1 - p0;
+            double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+            auto dop = [](double a, double b, double c, double d) {
+                double cd = c * d;
+                double r = ::fma(a, b, -cd);
+                double e = ::fma(-c, d, cd);
+                return r + e;
+            };
+            ng = V3{(float)dop(ay, bz, az, by), (float)dop(az, bx, ax, bz), (float)dop(ax, by, ay, bx)};
+        }
+        CoordinateSystem(Normalize(ng), &dpdu, &dpdv);
+    }
+    V3 pHit = b0 * p0 + b1 * p1 + b2 * p2;
+    V2 uvHit{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
+    bool flipNormal = (mesh.flags & WF_MESH_FLIP_NORMAL) != 0;
+    V3 pAbsSum = Abs(b0 * p0) + Abs(b1 * p1) + Abs(b2 * p2);
+    V3 pError = gamma(7) * pAbsSum;
+    si->pi = MakeP3i(pHit, pError);
+    si->uv = uvHit;
+    si->dpdu = dpdu;
+    si->dpdv = dpdv;
+    si->dndu = si->dndv = N3{0, 0, 0};
+    // SurfaceInteraction ctor (interaction.h:164-183) computes n from dpdu x dpdv and flips it; the
+    // triangle then overrides n and shading.n (shapes.h:936-938)
+    N3 n = toN(Normalize(Cross(dp02, dp12)));
+    if (flipNormal) n = -n;
+    si->n = n;
+    si->ns = n;
+    si->dpdus = dpdu;
+    si->dpdvs = dpdv;
+    si->dndus = si->dndvs = N3{0, 0, 0};
+    if (mesh.flags & WF_MESH_HAS_N) {
+        N3 n0 = LoadN(sv, v[0]), n1 = LoadN(sv, v[1]), n2 = LoadN(sv, v[2]);
+        N3 ns = b0 * n0 + b1 * n1 + b2 * n2;
+        ns = LengthSquared(ns) > 0 ? Normalize(ns) : si->n;
+        V3 ss = si->dpdu;
+        V3 ts = Cross(ns, ss);
+        if (LengthSquared(ts) > 0) ss = Cross(ts, ns);
+        else CoordinateSystem(toV(ns), &ss, &ts);
+        N3 dndu, dndv;
+        N3 dn1 = n0 - n2, dn2 = n1 - n2;
+        float det2 = DifferenceOfProducts(duv02.x, duv12.y, duv02.y, duv12.x);
+        bool degUV = abs(det2) < 1e-9;  // double comparison in the reference (shapes.h:984)
+        if (degUV) {
+            V3 dn = Cross(toV(n2 - n0), toV(n1 - n0));
+            if (LengthSquared(dn) == 0) dndu = dndv = N3{0, 0, 0};
+            else {
+                V3 dnu, dnv;
+                CoordinateSystem(dn, &dnu, &dnv);
+                dndu = toN(dnu);
+                dndv = toN(dnv);
+            }
+        } else {
+            float invDet = 1 / det2;
+            dndu = DifferenceOfProductsN(duv12.y, dn1, duv02.y, dn2) * invDet;
+            dndv = DifferenceOfProductsN(duv02.x, dn2, duv12.x, dn1) * invDet;
+        }
+        // SetShadingGeometry(ns, ss, ts, dndu, dndv, true), interaction.h:194-214
+        si->ns = ns;
+        si->n = FaceForward(si->n, si->ns);
+        si->dpdus = ss;
+        si->dpdvs = ts;
+        si->dndus = dndu;
+        si->dndvs = dndv;
+        while (LengthSquared(si->dpdus) > 1e16f || LengthSquared(si->dpdvs) > 1e16f) {
+            si->dpdus = si->dpdus / 1e8f;
+            si->dpdvs = si->dpdvs / 1e8f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangle sampling (shapes.h:845-880, 1013-1180)
+WF_HD float TriangleArea(V3 p0, V3 p1, V3 p2) { return 0.5f * Length(Cross(p1 - p0, p2 - p0)); }
+WF_HD float TriangleSolidAngle(V3 p0, V3 p1, V3 p2, V3 p) {
+    return SphericalTriangleArea(Normalize(p0 - p), Normalize(p1 - p), Normalize(p2 - p));
+}
+constexpr float MinSphericalSampleArea = 3e-4;
+constexpr float MaxSphericalSampleArea = 6.22;
+
+struct ShapeSampleR { P3i pi; N3 n; V2 uv; float pdf; bool valid; };
+
+WF_HD N3 TriSampleNormal(const SceneView &sv, const wf_mesh &mesh, const int32_t *v, V3 p0, V3 p1, V3 p2, float b0, float b1) {
+    N3 n = Normalize(toN(Cross(p1 - p0, p2 - p0)));
+    if (mesh.flags & WF_MESH_HAS_N) {
+        N3 ns = b0 * LoadN(sv, v[0]) + b1 * LoadN(sv, v[1]) + (1 - b0 - b1) * LoadN(sv, v[2]);
+        n = FaceForward(n, ns);
+    } else if (mesh.flags & WF_MESH_FLIP_NORMAL) n = n * -1.f;
+    return n;
+}
+WF_HD V2 TriSampleUV(const SceneView &sv, const wf_mesh &mesh, const int32_t *v, const float b[3]) {
+    V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
+    if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+    return V2{b[0] * uv0.x + b[1] * uv1.x + b[2] * uv2.x, b[0] * uv0.y + b[1] * uv1.y + b[2] * uv2.y};
+}
+
+// Triangle::Sample(const ShapeSampleContext &, Point2f u).  ctx: reference point interval, n, ns.
+WF_HD ShapeSampleR TriangleSample(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxNs, V2 u) {
+    ShapeSampleR r{};
+    r.valid = false;
+    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const wf_mesh mesh = sv.meshes[sv.triMesh[tri]];
+    V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
+    V3 rp = ctxPi.mid();
+    float solidAngle = TriangleSolidAngle(p0, p1, p2, rp);
+    if (solidAngle < MinSphericalSampleArea || solidAngle > MaxSphericalSampleArea) {
+        // Triangle::Sample(Point2f u), shapes.h:1013-1047
+        float b[3];
+        SampleUniformTriangle(u, b);
+        V3 p = b[0] * p0 + b[1] * p1 + b[2] * p2;
+        N3 n = TriSampleNormal(sv, mesh, v, p0, p1, p2, b[0], b[1]);
+        V2 uvS = TriSampleUV(sv, mesh, v, b);
+        V3 pAbsSum = Abs(b[0] * p0) + Abs(b[1] * p1) + Abs((1 - b[0] - b[1]) * p2);
+        V3 pError = gamma(6) * pAbsSum;
+        r.pi = MakeP3i(p, pError);
+        r.n = n;
+        r.uv = uvS;
+        r.pdf = 1 / TriangleArea(p0, p1, p2);
+        V3 wi = r.pi.mid() - rp;
+        if (LengthSquared(wi) == 0) return r;
+        wi = Normalize(wi);
+        r.pdf /= AbsDot(r.n, -wi) / DistanceSquared(rp, r.pi.mid());
+        if (IsInf(r.pdf)) return r;
+        r.valid = true;
+        return r;
+    }
+    float pdf = 1;
+    if (!IsZero(ctxNs)) {
+        V3 wi0 = Normalize(p0 - rp), wi1 = Normalize(p1 - rp), wi2 = Normalize(p2 - rp);
+        float w[4] = {fmax(0.01f, AbsDot(ctxNs, wi1)), fmax(0.01f, AbsDot(ctxNs, wi1)), fmax(0.01f, AbsDot(ctxNs, wi0)),
+                      fmax(0.01f, AbsDot(ctxNs, wi2))};
+        u = SampleBilinear(u, w);
+        pdf = BilinearPDF(u, w);
+    }
+    float triPDF;
+    float b[3];
+    SampleSphericalTriangle(p0, p1, p2, rp, u, b, &triPDF);
+    if (triPDF == 0) return r;
+    pdf *= triPDF;
+    V3 pAbsSum = Abs(b[0] * p0) + Abs(b[1] * p1) + Abs((1 - b[0] - b[1]) * p2);
+    V3 pError = gamma(6) * pAbsSum;
+    V3 p = b[0] * p0 + b[1] * p1 + b[2] * p2;
+    r.n = TriSampleNormal(sv, mesh, v, p0, p1, p2, b[0], b[1]);
+    r.uv = TriSampleUV(sv, mesh, v, b);
+    r.pi = MakeP3i(p, pError);
+    r.pdf = pdf;
+    r.valid = true;
+    return r;
+}
+
+// Triangle::PDF(const ShapeSampleContext &, Vector3f wi), shapes.h:1133-1171
+WF_HD float TrianglePDF(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxN, N3 ctxNs, V3 wi) {
+    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
+    V3 rp = ctxPi.mid();
+    float solidAngle = TriangleSolidAngle(p0, p1, p2, rp);
+    if (solidAngle < MinSphericalSampleArea || solidAngle > MaxSphericalSampleArea) {
+        // ctx.SpawnRay(wi) (shapes.h:63-90), Triangle::Intersect with tMax = Infinity
+        V3 o = OffsetRayOrigin(ctxPi, ctxN, wi);
+        TriHit h;
+        if (!IntersectTriangle(o, wi, WF_INFINITY, p0, p1, p2, &h)) return 0;
+        SurfIntr si;
+        TriangleInteraction(sv, tri, h.b0, h.b1, h.b2, &si);
+        float pdf = (1 / TriangleArea(p0, p1, p2)) / (AbsDot(si.n, -wi) / DistanceSquared(rp, si.pi.mid()));
+        if (IsInf(pdf)) pdf = 0;
+        return pdf;
+    }
+    float pdf = 1 / solidAngle;
+    if (!IsZero(ctxNs)) {
+        V2 u = InvertSphericalTriangleSample(p0, p1, p2, rp, wi);
+        V3 wi0 = Normalize(p0 - rp), wi1 = Normalize(p1 - rp), wi2 = Normalize(p2 - rp);
+        float w[4] = {fmax(0.01f, AbsDot(ctxNs, wi1)), fmax(0.01f, AbsDot(ctxNs, wi1)), fmax(0.01f, AbsDot(ctxNs, wi0)),
+                      fmax(0.01f, AbsDot(ctxNs, wi2))};
+        pdf *= BilinearPDF(u, w);
+    }
+    return pdf;
+}
+
+}  // namespace wf

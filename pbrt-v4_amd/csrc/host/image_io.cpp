@@ -71,6 +71,53 @@ static bool WriteEXR(const std::string &path, const float *rgb, int w, int h) {
     return true;
 }
 
+// float -> half -> float with round-to-nearest-even (util/float.h Half(float) ctor), what storing into a
+// PixelFormat::Half image and reading it back does (film.cpp:536, util/image.h)
+static float RoundToHalf(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = x & 0x80000000u, mag = x & 0x7fffffffu;
+    if (mag >= 0x7f800000u) return f;  // inf / nan
+    float a;
+    memcpy(&a, &mag, 4);
+    if (a >= 65520.f) { uint32_t inf = sign | 0x7f800000u; float r; memcpy(&r, &inf, 4); return r; }
+    float r;
+    if (a < 6.103515625e-05f) {  // half subnormal range: quantum 2^-24
+        float q = a * 16777216.f;             // exact
+        float rq = __builtin_nearbyintf(q);   // RN-even in the default rounding mode
+        r = rq / 16777216.f;
+    } else {
+        uint32_t m = mag;
+        uint32_t rem = m & 0x1fffu, base = m & ~0x1fffu;
+        if (rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) base += 0x2000u;
+        memcpy(&r, &base, 4);
+    }
+    uint32_t rb;
+    memcpy(&rb, &r, 4);
+    rb |= sign;
+    memcpy(&r, &rb, 4);
+    return r;
+}
+
+// RGBFilm::GetPixelRGB (film.h:258-275, no splats) + RGBFilm::GetImage (film.cpp:533-565)
+void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, bool saveFP16) {
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        const double *px = film + 4 * i;
+        float c[3] = {(float)px[0], (float)px[1], (float)px[2]};
+        float weightSum = (float)px[3];
+        if (weightSum != 0) { c[0] /= weightSum; c[1] /= weightSum; c[2] /= weightSum; }
+        float o[3];
+        for (int r = 0; r < 3; ++r) {
+            o[r] = 0;
+            for (int k = 0; k < 3; ++k) o[r] += F.outputRGBFromSensorRGB[r][k] * c[k];
+        }
+        if (saveFP16) {
+            for (int r = 0; r < 3; ++r) { if (o[r] > 65504.f) o[r] = 65504.f; o[r] = RoundToHalf(o[r]); }
+        }
+        rgb[3 * i] = o[0]; rgb[3 * i + 1] = o[1]; rgb[3 * i + 2] = o[2];
+    }
+}
+
 bool WriteImage(const std::string &path, const float *rgb, int w, int h) {
     size_t dot = path.find_last_of('.');
     std::string ext = dot == std::string::npos ? "" : path.substr(dot);

@@ -124,6 +124,7 @@ struct SceneTables {
     std::vector<wf_transform> lightTransforms;
     std::vector<float> filterData, powerAlias;
     std::string imageFile;
+    bool saveFP16 = true;  // Film "savefp16" (film.cpp:579)
     int spp = 1;
     // wavefront geometry (integrator.cpp:227-236)
     int scanlinesPerPass = 0, maxQueueSize = 0, nPasses = 0;
@@ -152,5 +153,7 @@ void BuildLightBVH(const std::vector<std::pair<int, LightBoundsH>> &bvhLightsIn,
 bool WritePFM(const std::string &path, const float *rgb, int w, int h);
 bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);
 bool WriteImage(const std::string &path, const float *rgb, int w, int h);  // by extension: .pfm, .exr
+// film accumulators ([h][w][4] doubles: rgbSum, weightSum) -> output RGB, as RGBFilm::GetImage does
+void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, bool saveFP16);
 
 }  // namespace wf

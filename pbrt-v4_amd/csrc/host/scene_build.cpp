@@ -350,7 +350,7 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
     wf_film &F = T->desc.film;
     float exposureTime = scene.camera.params.GetOneFloat("shutterclose", 1.f) - scene.camera.params.GetOneFloat("shutteropen", 0.f);
     F.max_component_value = ps.GetOneFloat("maxcomponentvalue", WF_INFINITY);
-    ps.GetOneBool("savefp16", true);
+    T->saveFP16 = ps.GetOneBool("savefp16", true);
     // PixelSensor::Create (film.cpp:213-253)
     float ISO = ps.GetOneFloat("iso", 100.f);
     float whiteBalanceTemp = ps.GetOneFloat("whitebalance", 0);
