@@ -383,8 +383,8 @@ int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index);
 /* K4: WavefrontAggregate::IntersectClosest (integrator.h:37-43) */
 int wf_intersect_closest(wf_ctx *ctx, int depth);
 /* K7/K8: HandleEscapedRays / HandleEmissiveIntersection (integrator.cpp:495-573) */
-int wf_handle_escaped(wf_ctx *ctx);
-int wf_handle_emissive(wf_ctx *ctx);
+int wf_handle_escaped(wf_ctx *ctx, int depth);
+int wf_handle_emissive(wf_ctx *ctx, int depth);
 /* K9: EvaluateMaterialAndBSDF<M> (wavefront/surfscatter.cpp:57-328), one launch per material type */
 int wf_eval_material(wf_ctx *ctx, int material_type, int depth);
 /* K10: WavefrontAggregate::IntersectShadow (integrator.h:45-46) + RecordShadowRayResult */

@@ -1,0 +1,50 @@
+/*
+ * wf_host.h — C entry points of libwfhost.so: the host half of the wavefront renderer (scene parser,
+ * flat-table builder, render loop) for non-C++ callers.  It mirrors, for this path only, what the
+ * reference's CLI does between main() and RenderWavefront() (src/pbrt/cmd/pbrt.cpp:280-288,
+ * src/pbrt/wavefront/wavefront.cpp:14-70).  The device work goes through include/wf_abi.h.
+ */
+#ifndef WF_HOST_H
+#define WF_HOST_H
+
+#include "wf_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wfh_scene wfh_scene;
+
+typedef struct wfh_info {
+    int32_t width, height, spp;
+    int32_t max_queue_size, n_passes, scanlines_per_pass;   /* wavefront/integrator.cpp:227-236 */
+    int32_t n_triangles, n_bvh_nodes, n_lights, max_depth;
+    int32_t save_fp16, y0;
+} wfh_info;
+
+/* InitPBRT's table setup (pbrt.cpp:100-110): spectral tables + RGB->spectrum tables (generated on first
+   use and cached under <data_dir>/cache) */
+int wfh_init(const char *data_dir);
+/* ParseFiles + BasicScene::Create* for the supported subset; spp_override <= 0 keeps the file's value
+   (--spp); seed as --seed.  Parse errors exit the process with a message, as the reference does. */
+wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed);
+wfh_scene *wfh_scene_load_string(const char *text, int spp_override, int seed);
+void wfh_scene_free(wfh_scene *s);
+const wf_scene_desc *wfh_scene_desc(wfh_scene *s);
+int wfh_scene_info(wfh_scene *s, wfh_info *out);
+/* WavefrontPathIntegrator ctor on HIP device `device` */
+int wfh_renderer_create(wfh_scene *s, int device);
+wf_ctx *wfh_renderer_ctx(wfh_scene *s);
+/* Render(): sample indices begin, begin+step, ... < end; returns wall seconds (negative on error) */
+double wfh_render(wfh_scene *s, int sample_begin, int sample_end, int sample_step, int fused);
+int wfh_clear_film(wfh_scene *s);
+int wfh_download_film(wfh_scene *s, double *dst /* [H][W][4] */);
+int wfh_stats(wfh_scene *s, wf_render_stats *out);
+/* RGBFilm::GetImage */
+int wfh_film_to_rgb(wfh_scene *s, const double *film, float *rgb /* [H][W][3] */);
+int wfh_write_image(const char *path, const float *rgb, int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

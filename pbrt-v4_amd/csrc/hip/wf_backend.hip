@@ -1,0 +1,725 @@
+// wf_backend.hip — libwfhip.so: the HIP/CDNA4 (gfx950) back end behind include/wf_abi.h.
+//
+// What the reference does with one generic kernel template instantiated per lambda (gpu/util.h:77-114)
+// plus OptiX programs (gpu/optix/optix.cu), this file does with named, hand-written kernels:
+//   k_gen_camera_rays / k_gen_ray_samples / k_handle_escaped / k_handle_emissive / k_eval_material<M> /
+//   k_update_film            grid-stride "for all queued" kernels (sizes are read on the device; the host
+//                            never reads a queue size, as in wavefront/workqueue.h:118-137)
+//   k_intersect_closest      BVH closest hit, replaces OptiX __raygen__findClosest + closest-hit programs
+//   k_intersect_shadow       BVH any hit + RecordShadowRayResult, replaces __raygen__shadow
+//   k_reset                  the one-thread "Reset queues" / stats kernels of integrator.cpp:357-397
+// Traversal keeps the node stack in LDS (one column per lane, STACK_LDS entries; deeper levels spill to a
+// per-lane HBM column) — no private-memory (scratch) arrays anywhere in the hot loop.
+// Queue pushes are wave-aggregated (wf_kernels.h: QueueAlloc): one atomic per wave per destination queue.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the only fused operations are the explicit
+// fma calls of the restated arithmetic, as in the reference's CPU build).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../common/wf_kernels.h"
+
+using namespace wf;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code ? code : -1;
+}
+#define HIPCHK(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+constexpr int BLOCK = 256;
+constexpr int STACK_LDS = 24;   // LDS stack entries per lane: 24 x 4 B x 256 lanes = 24 KiB per workgroup
+constexpr int STACK_MAX = 64;   // nodesToVisit[64], cpu/aggregates.cpp:538
+constexpr int MAX_GRID = 256 * 8;  // 256 CUs x up to 8 resident 256-thread workgroups
+
+struct wf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    SceneView svHost{};          // device pointers inside
+    SceneView *svDev = nullptr;
+    WorkState ws{};
+    int maxQueueSize = 0;
+    int *stackSpill = nullptr;   // [STACK_MAX-STACK_LDS][MAX_GRID*BLOCK]
+    bool matPresent[WF_MAT_NTYPES] = {};
+    int W = 0, H = 0;
+    int maxDepth = 5;
+    float sceneBounds[6] = {};
+    bool sceneLoaded = false, queuesAllocated = false;
+    // profiling (gpu/util.cpp:136-209)
+    bool profile = false;
+    struct Ev { std::string name; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    std::vector<hipEvent_t> eventPool;
+    bool countTraversal = false;
+};
+
+template <typename T>
+static int devAlloc(wf_ctx *c, T **p, size_t n) {
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(hipMemsetAsync(d, 0, bytes, c->stream));
+    c->allocs.push_back(d);
+    *p = (T *)d;
+    return 0;
+}
+template <typename T>
+static int devUpload(wf_ctx *c, const T **p, const T *src, size_t n) {
+    T *d = nullptr;
+    if (int e = devAlloc(c, &d, n)) return e;
+    if (n && src) HIPCHK(hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *p = d;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+__global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, int statSlot, int statCounter) {
+    // mask bit i: zero counters[i].  statSlot >= 0: stats[statSlot] += counters[statCounter] first.
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (statSlot >= 0) ws.stats[statSlot] += (unsigned long long)ws.counters[statCounter];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) ws.counters[threadIdx.x] = 0;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView *svp, WorkState ws, int y0, int sampleIndex) {
+    const SceneView &sv = *svp;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
+        KGenerateCameraRay(sv, ws, i, y0, sampleIndex);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView *svp, WorkState ws, int cur, int sampleIndex) {
+    const SceneView &sv = *svp;
+    const int n = ws.counters[CNT_RAY0 + cur];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleIndex);
+}
+
+// LDS short stack with HBM spill (one column per lane)
+struct LdsStack {
+    int *lds;     // &sstack[threadIdx.x], stride BLOCK
+    int *spill;   // &stackSpill[global thread], stride = total threads
+    int spillStride;
+    int n;
+    __device__ void push(int v) {
+        if (n < STACK_LDS) lds[n * BLOCK] = v;
+        else spill[(size_t)(n - STACK_LDS) * spillStride] = v;
+        ++n;
+    }
+    __device__ int pop() {
+        --n;
+        return n < STACK_LDS ? lds[n * BLOCK] : spill[(size_t)(n - STACK_LDS) * spillStride];
+    }
+    __device__ bool empty() const { return n == 0; }
+};
+
+__device__ inline unsigned long long waveSum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView *svp, WorkState ws, int cur, int *stackSpill) {
+    __shared__ int sstack[STACK_LDS * BLOCK];
+    const SceneView &sv = *svp;
+    const int n = ws.counters[CNT_RAY0 + cur];
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    unsigned long long nv = 0, nt = 0, nh = 0, nr = 0;
+    for (int i = gtid; i < n; i += stride) {
+        F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+        ClosestHit ch;
+        st.n = 0;
+        bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
+        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.b0, ch.h.b1, ch.h.b2);
+        if (COUNT) { nv += ch.nodesVisited; nt += ch.trisTested; nh += found; nr += 1; }
+    }
+    if (COUNT) {
+        nv = waveSum(nv); nt = waveSum(nt); nh = waveSum(nh); nr = waveSum(nr);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ws.trav[0], nr); atomicAdd(&ws.trav[1], nv); atomicAdd(&ws.trav[2], nt); atomicAdd(&ws.trav[3], nh);
+        }
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView *svp, WorkState ws, int *stackSpill) {
+    __shared__ int sstack[STACK_LDS * BLOCK];
+    const SceneView &sv = *svp;
+    const int n = ws.counters[CNT_SHADOW];
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    unsigned long long nv = 0, nt = 0, nu = 0, nr = 0;
+    for (int i = gtid; i < n; i += stride) {
+        F4 o = ws.sq.o[i], d = ws.sq.d[i];
+        int v = 0, t = 0;
+        st.n = 0;
+        bool occluded = BVHIntersectAny(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t);
+        KRecordShadowRay(ws, i, occluded);
+        if (COUNT) { nv += v; nt += t; nu += !occluded; nr += 1; }
+    }
+    if (COUNT) {
+        nv = waveSum(nv); nt = waveSum(nt); nu = waveSum(nu); nr = waveSum(nr);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ws.trav[4], nr); atomicAdd(&ws.trav[5], nv); atomicAdd(&ws.trav[6], nt); atomicAdd(&ws.trav[7], nu);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView *svp, WorkState ws, int cur) {
+    const SceneView &sv = *svp;
+    const int n = ws.counters[CNT_ESCAPED];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEscaped(sv, ws, cur, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView *svp, WorkState ws, int cur) {
+    const SceneView &sv = *svp;
+    const int n = ws.counters[CNT_HITLIGHT];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEmissive(sv, ws, cur, i);
+}
+template <int MAT>
+__global__ void __launch_bounds__(BLOCK) k_eval_material(const SceneView *svp, WorkState ws, int cur) {
+    const SceneView &sv = *svp;
+    const int n = ws.counters[CNT_MAT0 + MAT];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KEvalMaterial<MAT>(sv, ws, cur, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView *svp, WorkState ws) {
+    const SceneView &sv = *svp;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK) KUpdateFilm(sv, ws, i);
+}
+
+// stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
+__global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView *svp, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
+    __shared__ int sstack[STACK_LDS * BLOCK];
+    const SceneView &sv = *svp;
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride) {
+        const float *r = rays + (size_t)7 * i;
+        ClosestHit ch;
+        st.n = 0;
+        bool found = BVHIntersectClosest(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &ch);
+        wf_hit_record h;
+        h.prim = found ? ch.prim : -1;
+        h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;
+        h.nodes_visited = ch.nodesVisited; h.tris_tested = ch.trisTested; h.pad = 0;
+        out[i] = h;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_trace_any(const SceneView *svp, int n, const float *rays, int32_t *occluded, int32_t *nodes, int32_t *tris, int *stackSpill) {
+    __shared__ int sstack[STACK_LDS * BLOCK];
+    const SceneView &sv = *svp;
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride) {
+        const float *r = rays + (size_t)7 * i;
+        int v = 0, t = 0;
+        st.n = 0;
+        bool occ = BVHIntersectAny(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &v, &t);
+        occluded[i] = occ;
+        if (nodes) nodes[i] = v;
+        if (tris) tris[i] = t;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_sampler_probe(const SceneView *svp, int n, const int32_t *px, const int32_t *py, const int32_t *si, int startDim, int ndims, float *out) {
+    const SceneView &sv = *svp;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        ZSobol s(sv);
+        s.StartPixelSample(px[i], py[i], si[i], startDim);
+        for (int d = 0; d < ndims; ++d) out[(size_t)i * ndims + d] = s.Get1D();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int gridFor(int n) {
+    int g = (n + BLOCK - 1) / BLOCK;
+    if (g < 1) g = 1;
+    return g > MAX_GRID ? MAX_GRID : g;
+}
+
+struct Prof {
+    wf_ctx *c;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char *name;
+    Prof(wf_ctx *c, const char *name) : c(c), name(name) {
+        if (!c->profile) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->eventPool.empty()) { e = c->eventPool.back(); c->eventPool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get(); b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Prof() {
+        if (!c->profile) return;
+        (void)hipEventRecord(b, c->stream);
+        c->events.push_back({name, a, b});
+    }
+};
+
+#define LAUNCH(name, kernel, grid, ...)                                                    \
+    do {                                                                                   \
+        Prof prof_(ctx, name);                                                             \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, __VA_ARGS__);  \
+    } while (0)
+
+static int checkReady(wf_ctx *ctx) {
+    if (!ctx) return fail(-1, "null context");
+    if (!ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (!ctx->queuesAllocated) return fail(-1, "queues not allocated (wf_queues_alloc)");
+    return 0;
+}
+
+extern "C" {
+
+const char *wf_last_error(void) { return g_err; }
+int wf_abi_version(void) { return WF_ABI_VERSION; }
+
+int wf_ctx_create(int device, wf_ctx **out) {
+    if (!out) return fail(-1, "null out");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(-1, "no HIP device visible: libwfhip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(-1, "device %d out of range (0..%d)", device, ndev - 1);
+    HIPCHK(hipSetDevice(device));
+    wf_ctx *c = new wf_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return 0;
+}
+
+int wf_ctx_destroy(wf_ctx *ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : ctx->eventPool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int wf_sync(wf_ctx *ctx) {
+    if (!ctx) return fail(-1, "null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+void *wf_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
+    if (!ctx || !d) return fail(-1, "null argument");
+    if (d->abi_version != WF_ABI_VERSION) return fail(-1, "ABI version mismatch: desc %d, library %d", d->abi_version, WF_ABI_VERSION);
+    if (ctx->sceneLoaded) return fail(-1, "a scene is already uploaded to this context");
+    HIPCHK(hipSetDevice(ctx->device));
+    SceneView &sv = ctx->svHost;
+    int e = 0;
+    if ((e = devUpload(ctx, &sv.P, d->P, (size_t)3 * d->n_vertices))) return e;
+    if ((e = devUpload(ctx, &sv.N, d->N, (size_t)3 * d->n_vertices))) return e;
+    if ((e = devUpload(ctx, &sv.UV, d->UV, (size_t)2 * d->n_vertices))) return e;
+    if ((e = devUpload(ctx, &sv.triIndices, d->tri_indices, (size_t)3 * d->n_triangles))) return e;
+    if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles))) return e;
+    if ((e = devUpload(ctx, &sv.meshes, d->meshes, (size_t)d->n_meshes))) return e;
+    if ((e = devUpload(ctx, &sv.bvhNodes, d->bvh_nodes, (size_t)d->n_bvh_nodes))) return e;
+    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles))) return e;
+    sv.nTriangles = d->n_triangles;
+    sv.nBvhNodes = d->n_bvh_nodes;
+    if ((e = devUpload(ctx, &sv.spectra, d->spectra, (size_t)d->n_spectra))) return e;
+    if ((e = devUpload(ctx, &sv.spectrumData, d->spectrum_data, (size_t)d->n_spectrum_floats))) return e;
+    if ((e = devUpload(ctx, &sv.textures, d->textures, (size_t)d->n_textures))) return e;
+    if ((e = devUpload(ctx, &sv.materials, d->materials, (size_t)d->n_materials))) return e;
+    if ((e = devUpload(ctx, &sv.lights, d->lights, (size_t)d->n_lights))) return e;
+    if ((e = devUpload(ctx, &sv.infiniteLights, d->infinite_lights, (size_t)d->n_infinite_lights))) return e;
+    if ((e = devUpload(ctx, &sv.lightBvh, d->light_bvh_nodes, (size_t)d->n_light_bvh_nodes))) return e;
+    if ((e = devUpload(ctx, &sv.lightXforms, d->light_transforms, (size_t)d->n_light_transforms))) return e;
+    sv.nLights = d->n_lights;
+    sv.nInfiniteLights = d->n_infinite_lights;
+    sv.nLightBvhNodes = d->n_light_bvh_nodes;
+    sv.lightSampler = d->light_sampler;
+    for (int i = 0; i < 6; ++i) sv.allLightBounds[i] = d->all_light_bounds[i];
+    sv.camera = d->camera;
+    sv.film = d->film;
+    sv.filter = d->filter;
+    if ((e = devUpload(ctx, &sv.filterData, d->filter_data, (size_t)d->n_filter_floats))) return e;
+    sv.sampler = d->sampler;
+    if (d->sampler.type != WF_SAMPLER_ZSOBOL) return fail(-1, "only the zsobol sampler is implemented by the HIP kernels");
+    uint32_t sobol[104];
+    FillSobol2D(sobol);
+    if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)104))) return e;
+    sv.maxDepth = d->max_depth;
+    sv.regularize = d->regularize;
+    sv.haveMedia = d->have_media;
+    sv.options = d->options;
+    for (int m = 0; m < WF_MAT_NTYPES; ++m) ctx->matPresent[m] = false;
+    for (int i = 0; i < d->n_materials; ++i) {
+        int t = d->materials[i].type;
+        if (t < 0 || t >= WF_MAT_NTYPES) return fail(-1, "material %d has unknown type %d", i, t);
+        if (t == WF_MAT_COATED_DIFFUSE || t == WF_MAT_COATED_CONDUCTOR)
+            return fail(-1, "material %d: layered (coated*) materials are not implemented by the HIP kernels yet", i);
+        ctx->matPresent[t] = true;
+    }
+    if ((e = devAlloc(ctx, &ctx->svDev, 1))) return e;
+    HIPCHK(hipMemcpyAsync(ctx->svDev, &sv, sizeof(SceneView), hipMemcpyHostToDevice, ctx->stream));
+    ctx->W = d->film.pixel_max[0] - d->film.pixel_min[0];
+    ctx->H = d->film.pixel_max[1] - d->film.pixel_min[1];
+    ctx->maxDepth = d->max_depth;
+    for (int i = 0; i < 6; ++i) ctx->sceneBounds[i] = d->scene_bounds[i];
+    if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)(STACK_MAX - STACK_LDS) * MAX_GRID * BLOCK))) return e;
+    if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
+    if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)129))) return e;
+    if ((e = devAlloc(ctx, &ctx->ws.trav, (size_t)8))) return e;
+    if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT))) return e;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // sv / sobol live on the host stack
+    ctx->sceneLoaded = true;
+    return 0;
+}
+
+int wf_aggregate_bounds(wf_ctx *ctx, float out_bounds[6]) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    for (int i = 0; i < 6; ++i) out_bounds[i] = ctx->sceneBounds[i];
+    return 0;
+}
+
+static int allocRayQueue(wf_ctx *c, RayQueueV *q, size_t n) {
+    int e;
+    if ((e = devAlloc(c, &q->o, n)) || (e = devAlloc(c, &q->d, n)) || (e = devAlloc(c, &q->beta, n)) || (e = devAlloc(c, &q->r_u, n)) ||
+        (e = devAlloc(c, &q->r_l, n)) || (e = devAlloc(c, &q->ctx0, n)) || (e = devAlloc(c, &q->ctx1, n)) || (e = devAlloc(c, &q->ctx2, n)) ||
+        (e = devAlloc(c, &q->meta, n)))
+        return e;
+    return 0;
+}
+
+int wf_queues_alloc(wf_ctx *ctx, int max_queue_size) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (ctx->queuesAllocated) return fail(-1, "queues already allocated");
+    if (max_queue_size <= 0) return fail(-1, "max_queue_size must be positive");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)max_queue_size;
+    WorkState &ws = ctx->ws;
+    ws.maxQueueSize = max_queue_size;
+    int e;
+    if ((e = devAlloc(ctx, &ws.filterWeight, n)) || (e = devAlloc(ctx, &ws.pPixel, n)) || (e = devAlloc(ctx, &ws.lambda, n)) ||
+        (e = devAlloc(ctx, &ws.lambdaPdf, n)) || (e = devAlloc(ctx, &ws.L, n)) || (e = devAlloc(ctx, &ws.cameraRayWeight, n)) ||
+        (e = devAlloc(ctx, &ws.samples0, n)) || (e = devAlloc(ctx, &ws.samples1, n)))
+        return e;
+    if ((e = allocRayQueue(ctx, &ws.rq[0], n)) || (e = allocRayQueue(ctx, &ws.rq[1], n))) return e;
+    if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n))) return e;
+    for (int m = 0; m < WF_MAT_NTYPES; ++m)
+        if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
+    if ((e = devAlloc(ctx, &ws.sq.o, n)) || (e = devAlloc(ctx, &ws.sq.d, n)) || (e = devAlloc(ctx, &ws.sq.Ld, n)) ||
+        (e = devAlloc(ctx, &ws.sq.r_u, n)) || (e = devAlloc(ctx, &ws.sq.r_l, n)))
+        return e;
+    ctx->maxQueueSize = max_queue_size;
+    ctx->queuesAllocated = true;
+    return 0;
+}
+
+int wf_film_clear(wf_ctx *ctx) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    HIPCHK(hipMemsetAsync(ctx->ws.film, 0, (size_t)ctx->W * ctx->H * 4 * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->ws.stats, 0, 129 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->ws.trav, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    return 0;
+}
+
+int wf_reset_ray_queue(wf_ctx *ctx, int which) {
+    if (int e = checkReady(ctx)) return e;
+    LAUNCH("Reset ray queue", k_reset, 1, ctx->ws, 1u << (CNT_RAY0 + (which & 1)), -1, 0);
+    return 0;
+}
+int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    const int cur = depth & 1;
+    unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
+    for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
+    // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
+    LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + depth, CNT_RAY0 + cur);
+    return 0;
+}
+int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
+    if (int e = checkReady(ctx)) return e;
+    LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, y0, sample_index);
+    LAUNCH("Update camera ray stats", k_reset, 1, ctx->ws, 0u, 0, CNT_RAY0);
+    return 0;
+}
+int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index) {
+    if (int e = checkReady(ctx)) return e;
+    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1, sample_index);
+    return 0;
+}
+int wf_intersect_closest(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (ctx->countTraversal)
+        LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1, ctx->stackSpill);
+    else
+        LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1, ctx->stackSpill);
+    return 0;
+}
+int wf_handle_escaped(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (ctx->svHost.nInfiniteLights == 0) return 0;  // escapedRayQueue == nullptr (integrator.cpp:496-497)
+    LAUNCH("Handle escaped rays", k_handle_escaped, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1);
+    return 0;
+}
+int wf_handle_emissive(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    LAUNCH("Handle emitters hit by indirect rays", k_handle_emissive, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1);
+    return 0;
+}
+int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    const int g = gridFor(ctx->maxQueueSize), cur = depth & 1;
+    switch (material_type) {
+    case WF_MAT_DIFFUSE: LAUNCH("DiffuseMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE>, g, ctx->svDev, ctx->ws, cur); break;
+    case WF_MAT_CONDUCTOR: LAUNCH("ConductorMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_CONDUCTOR>, g, ctx->svDev, ctx->ws, cur); break;
+    case WF_MAT_DIELECTRIC: LAUNCH("DielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIELECTRIC>, g, ctx->svDev, ctx->ws, cur); break;
+    case WF_MAT_THIN_DIELECTRIC: LAUNCH("ThinDielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_THIN_DIELECTRIC>, g, ctx->svDev, ctx->ws, cur); break;
+    case WF_MAT_DIFFUSE_TRANSMISSION: LAUNCH("DiffuseTransmissionMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE_TRANSMISSION>, g, ctx->svDev, ctx->ws, cur); break;
+    case WF_MAT_INTERFACE: break;
+    default: return fail(-1, "material type %d has no HIP kernel", material_type);
+    }
+    return 0;
+}
+int wf_intersect_shadow(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (ctx->countTraversal)
+        LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, ctx->stackSpill);
+    else
+        LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, ctx->stackSpill);
+    // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, 1u << CNT_SHADOW, 65 + depth, CNT_SHADOW);
+    return 0;
+}
+int wf_update_film(wf_ctx *ctx) {
+    if (int e = checkReady(ctx)) return e;
+    LAUNCH("Update film", k_update_film, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws);
+    return 0;
+}
+
+// integrator.cpp:357-434 for one (y0, sampleIndex): everything is enqueued, nothing synchronises
+int wf_render_pass(wf_ctx *ctx, int y0, int sample_index) {
+    if (int e = checkReady(ctx)) return e;
+    int e;
+    if ((e = wf_reset_ray_queue(ctx, 0))) return e;
+    if ((e = wf_gen_camera_rays(ctx, y0, sample_index))) return e;
+    for (int depth = 0; true; ++depth) {
+        if ((e = wf_reset_stage_queues(ctx, depth))) return e;
+        if ((e = wf_gen_ray_samples(ctx, depth, sample_index))) return e;
+        if ((e = wf_intersect_closest(ctx, depth))) return e;
+        if ((e = wf_handle_escaped(ctx, depth))) return e;
+        if ((e = wf_handle_emissive(ctx, depth))) return e;
+        if (depth == ctx->maxDepth) break;
+        for (int m = 0; m < WF_MAT_NTYPES; ++m)
+            if (ctx->matPresent[m] && m != WF_MAT_INTERFACE)
+                if ((e = wf_eval_material(ctx, m, depth))) return e;
+        if ((e = wf_intersect_shadow(ctx, depth))) return e;
+    }
+    return wf_update_film(ctx);
+}
+
+int wf_film_download(wf_ctx *ctx, double *dst) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    HIPCHK(hipMemcpyAsync(dst, ctx->ws.film, (size_t)ctx->W * ctx->H * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_film_upload(wf_ctx *ctx, const double *src) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    HIPCHK(hipMemcpyAsync(ctx->ws.film, src, (size_t)ctx->W * ctx->H * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    *dptr = ctx->ws.film;
+    *nbytes = (uint64_t)ctx->W * ctx->H * 4 * sizeof(double);
+    return 0;
+}
+int wf_stats_download(wf_ctx *ctx, wf_render_stats *out) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    unsigned long long h[129];
+    HIPCHK(hipMemcpyAsync(h, ctx->ws.stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    out->camera_rays = h[0];
+    for (int i = 0; i < 64; ++i) { out->indirect_rays[i] = h[1 + i]; out->shadow_rays[i] = h[65 + i]; }
+    return 0;
+}
+
+int wf_profile_enable(wf_ctx *ctx, int enabled) {
+    if (!ctx) return fail(-1, "null context");
+    ctx->profile = enabled != 0;
+    return 0;
+}
+int wf_profile_report(wf_ctx *ctx, wf_kernel_profile_entry *entries, int max_entries, int *n_out) {
+    if (!ctx) return fail(-1, "null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::map<std::string, wf_kernel_profile_entry> agg;
+    std::vector<std::string> order;
+    for (auto &e : ctx->events) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        auto it = agg.find(e.name);
+        if (it == agg.end()) {
+            wf_kernel_profile_entry pe{};
+            snprintf(pe.name, sizeof(pe.name), "%s", e.name.c_str());
+            pe.launches = 1; pe.total_ms = pe.min_ms = pe.max_ms = ms;
+            agg[e.name] = pe;
+            order.push_back(e.name);
+        } else {
+            it->second.launches++;
+            it->second.total_ms += ms;
+            if (ms < it->second.min_ms) it->second.min_ms = ms;
+            if (ms > it->second.max_ms) it->second.max_ms = ms;
+        }
+        ctx->eventPool.push_back(e.a);
+        ctx->eventPool.push_back(e.b);
+    }
+    ctx->events.clear();
+    int n = 0;
+    for (auto &name : order) {
+        if (n >= max_entries) break;
+        entries[n++] = agg[name];
+    }
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+int wf_counters_enable(wf_ctx *ctx, int enabled) {
+    if (!ctx) return fail(-1, "null context");
+    ctx->countTraversal = enabled != 0;
+    return 0;
+}
+int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    unsigned long long h[8];
+    HIPCHK(hipMemcpyAsync(h, ctx->ws.trav, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    out->closest_rays = h[0]; out->closest_nodes = h[1]; out->closest_tris = h[2]; out->closest_hits = h[3];
+    out->shadow_rays = h[4]; out->shadow_nodes = h[5]; out->shadow_tris = h[6]; out->shadow_unoccluded = h[7];
+    return 0;
+}
+
+int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, wf_hit_record *out, int count_visits) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    (void)count_visits;
+    if (n <= 0) return 0;
+    std::vector<float> rays((size_t)n * 7);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { rays[(size_t)i * 7 + k] = o[3 * i + k]; rays[(size_t)i * 7 + 3 + k] = d[3 * i + k]; }
+        rays[(size_t)i * 7 + 6] = tmax[i];
+    }
+    float *dr = nullptr;
+    wf_hit_record *dh = nullptr;
+    HIPCHK(hipMalloc((void **)&dr, rays.size() * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&dh, (size_t)n * sizeof(wf_hit_record)));
+    HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svDev, n, dr, dh, ctx->stackSpill);
+    HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(dr));
+    HIPCHK(hipFree(dh));
+    return 0;
+}
+int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (n <= 0) return 0;
+    std::vector<float> rays((size_t)n * 7);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { rays[(size_t)i * 7 + k] = o[3 * i + k]; rays[(size_t)i * 7 + 3 + k] = d[3 * i + k]; }
+        rays[(size_t)i * 7 + 6] = tmax[i];
+    }
+    float *dr = nullptr;
+    int32_t *dres = nullptr;
+    HIPCHK(hipMalloc((void **)&dr, rays.size() * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&dres, (size_t)3 * n * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svDev, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
+    HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (tris_tested) HIPCHK(hipMemcpyAsync(tris_tested, dres + 2 * (size_t)n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(dr));
+    HIPCHK(hipFree(dres));
+    return 0;
+}
+int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index, int start_dim, int ndims, float *out) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (n <= 0) return 0;
+    int32_t *din = nullptr;
+    float *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&din, (size_t)3 * n * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)n * ndims * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(din, px, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(din + n, py, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(din + 2 * (size_t)n, sample_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH("sampler probe", k_sampler_probe, gridFor(n), ctx->svDev, n, din, din + n, din + 2 * (size_t)n, start_dim, ndims, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * ndims * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(din));
+    HIPCHK(hipFree(dout));
+    return 0;
+}
+
+int wf_queue_size(wf_ctx *ctx, const char *queue, int *size) {
+    if (int e = checkReady(ctx)) return e;
+    static const std::map<std::string, int> idx = {{"ray0", CNT_RAY0}, {"ray1", CNT_RAY1}, {"escaped", CNT_ESCAPED}, {"hitlight", CNT_HITLIGHT},
+                                                   {"shadow", CNT_SHADOW}, {"mat_diffuse", CNT_MAT0 + WF_MAT_DIFFUSE},
+                                                   {"mat_conductor", CNT_MAT0 + WF_MAT_CONDUCTOR}, {"mat_dielectric", CNT_MAT0 + WF_MAT_DIELECTRIC},
+                                                   {"mat_thindielectric", CNT_MAT0 + WF_MAT_THIN_DIELECTRIC},
+                                                   {"mat_diffusetransmission", CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION}};
+    auto it = idx.find(queue ? queue : "");
+    if (it == idx.end()) return fail(-1, "unknown queue \"%s\"", queue ? queue : "(null)");
+    HIPCHK(hipMemcpyAsync(size, ctx->ws.counters + it->second, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_queue_download(wf_ctx *ctx, const char *queue, const char *member, void *dst, uint64_t nbytes) {
+    if (int e = checkReady(ctx)) return e;
+    const WorkState &ws = ctx->ws;
+    std::string q = queue ? queue : "", m = member ? member : "";
+    const void *src = nullptr;
+    auto rayMember = [&](const RayQueueV &r) -> const void * {
+        if (m == "o") return r.o; if (m == "d") return r.d; if (m == "beta") return r.beta; if (m == "r_u") return r.r_u;
+        if (m == "r_l") return r.r_l; if (m == "ctx0") return r.ctx0; if (m == "ctx1") return r.ctx1; if (m == "ctx2") return r.ctx2;
+        if (m == "meta") return r.meta;
+        return nullptr;
+    };
+    if (q == "ray0") src = rayMember(ws.rq[0]);
+    else if (q == "ray1") src = rayMember(ws.rq[1]);
+    else if (q == "pixel") {
+        if (m == "L") src = ws.L; else if (m == "lambda") src = ws.lambda; else if (m == "lambda_pdf") src = ws.lambdaPdf;
+        else if (m == "pPixel") src = ws.pPixel; else if (m == "filterWeight") src = ws.filterWeight;
+        else if (m == "cameraRayWeight") src = ws.cameraRayWeight; else if (m == "samples0") src = ws.samples0; else if (m == "samples1") src = ws.samples1;
+    } else if (q == "hit") src = ws.hit;
+    else if (q == "shadow") {
+        if (m == "o") src = ws.sq.o; else if (m == "d") src = ws.sq.d; else if (m == "Ld") src = ws.sq.Ld;
+        else if (m == "r_u") src = ws.sq.r_u; else if (m == "r_l") src = ws.sq.r_l;
+    }
+    if (!src) return fail(-1, "unknown queue member \"%s\".\"%s\"", q.c_str(), m.c_str());
+    HIPCHK(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// integrator.cpp — host side of the wavefront path integrator: a restatement of
+// WavefrontPathIntegrator::Render (wavefront/integrator.cpp:290-493) that issues one C-ABI call
+// (include/wf_abi.h -> libwfhip.so) where the reference launches a kernel or calls the
+// WavefrontAggregate.  Everything is enqueued on one in-order HIP stream; the host synchronises once,
+// at the end (GPUWait(), integrator.cpp:483-485).  There is no CPU code path here: without libwfhip.so and
+// a visible gfx950 device, construction fails.
+#include "integrator.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+namespace wf {
+
+static void Check(int rc, const char *what) {
+    if (rc != 0) {
+        // CUDA_CHECK -> LOG_FATAL in the reference (gpu/util.h:35-49)
+        fprintf(stderr, "Fatal: %s failed: %s\n", what, wf_last_error());
+        abort();
+    }
+}
+
+WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device) : T(tables) {
+    Check(wf_ctx_create(device, &ctx), "wf_ctx_create");
+    Check(wf_scene_upload(ctx, &T.desc), "wf_scene_upload");
+    Check(wf_queues_alloc(ctx, T.maxQueueSize), "wf_queues_alloc");
+    Check(wf_film_clear(ctx), "wf_film_clear");
+    Check(wf_sync(ctx), "wf_sync");
+}
+
+WavefrontRenderer::~WavefrontRenderer() {
+    if (ctx) wf_ctx_destroy(ctx);
+}
+
+void WavefrontRenderer::ClearFilm() {
+    Check(wf_film_clear(ctx), "wf_film_clear");
+}
+
+// Render sample indices sampleBegin, sampleBegin+sampleStep, ... < sampleEnd over every pass of the
+// image.  (A single GPU renders [0, spp) with step 1; with N GPUs rank r renders r, r+N, ... — the
+// per-pixel sample sets are those of the single-GPU render because the sampler is keyed on
+// (pixel, sampleIndex, dimension) only, samplers.h:252-255.)
+double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep, bool fused) {
+    const wf_film &F = T.desc.film;
+    auto t0 = std::chrono::steady_clock::now();
+    const int maxDepth = T.desc.max_depth;
+    for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep) {
+        for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
+            if (fused) {
+                Check(wf_render_pass(ctx, y0, sampleIndex), "wf_render_pass");
+                continue;
+            }
+            // integrator.cpp:357-371
+            Check(wf_reset_ray_queue(ctx, 0), "wf_reset_ray_queue");
+            Check(wf_gen_camera_rays(ctx, y0, sampleIndex), "wf_gen_camera_rays");
+            // integrator.cpp:374-432
+            for (int wavefrontDepth = 0; true; ++wavefrontDepth) {
+                Check(wf_reset_stage_queues(ctx, wavefrontDepth), "wf_reset_stage_queues");
+                Check(wf_gen_ray_samples(ctx, wavefrontDepth, sampleIndex), "wf_gen_ray_samples");
+                Check(wf_intersect_closest(ctx, wavefrontDepth), "wf_intersect_closest");
+                Check(wf_handle_escaped(ctx, wavefrontDepth), "wf_handle_escaped");
+                Check(wf_handle_emissive(ctx, wavefrontDepth), "wf_handle_emissive");
+                if (wavefrontDepth == maxDepth) break;
+                for (int m = 0; m < WF_MAT_NTYPES; ++m)
+                    if (T.materialTypePresent[m] && m != WF_MAT_INTERFACE)
+                        Check(wf_eval_material(ctx, m, wavefrontDepth), "wf_eval_material");
+                Check(wf_intersect_shadow(ctx, wavefrontDepth), "wf_intersect_shadow");
+            }
+            Check(wf_update_film(ctx), "wf_update_film");
+        }
+    }
+    Check(wf_sync(ctx), "wf_sync");
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void WavefrontRenderer::DownloadFilm(double *dst) { Check(wf_film_download(ctx, dst), "wf_film_download"); }
+void WavefrontRenderer::UploadFilm(const double *src) { Check(wf_film_upload(ctx, src), "wf_film_upload"); }
+void WavefrontRenderer::Stats(wf_render_stats *s) { Check(wf_stats_download(ctx, s), "wf_stats_download"); }
+
+}  // namespace wf

@@ -1,0 +1,109 @@
+// main.cpp — pbrt_amd: command-line front end with the reference CLI's flags for this path
+// (src/pbrt/cmd/pbrt.cpp:105-213: --spp, --seed, --outfile, --quiet, --stats, --pixelbounds, --cropwindow,
+// --gpu-device; --gpu/--wavefront are accepted and implied).  It always renders with the HIP wavefront
+// back end: there is no CPU renderer in this program.
+#include "integrator.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace wf;
+
+static void usage() {
+    fprintf(stderr,
+            "usage: pbrt_amd [options] <scene.pbrt>\n"
+            "  --spp <n>              override samples per pixel\n"
+            "  --seed <n>             random seed\n"
+            "  --outfile <file>       output image (.pfm or .exr)\n"
+            "  --gpu-device <n>       HIP device index (default 0)\n"
+            "  --pixelbounds x0,x1,y0,y1 / --cropwindow x0,x1,y0,y1\n"
+            "  --disable-pixel-jitter / --disable-wavelength-jitter / --disable-texture-filtering\n"
+            "  --datadir <dir>        directory holding spectral_tables.txt\n"
+            "  --stats                print ray counts and the per-kernel profile\n"
+            "  --quiet, --gpu, --wavefront (accepted)\n");
+}
+
+int main(int argc, char **argv) {
+    RenderOptions opt;
+    std::string scenePath, dataDir;
+    int device = 0;
+    bool stats = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto value = [&]() -> std::string {
+            size_t eq = a.find('=');
+            if (eq != std::string::npos) return a.substr(eq + 1);
+            if (i + 1 >= argc) { fprintf(stderr, "missing value after %s\n", a.c_str()); exit(1); }
+            return argv[++i];
+        };
+        auto is = [&](const char *name) { return a == name || a.rfind(std::string(name) + "=", 0) == 0; };
+        if (is("--spp")) opt.pixelSamples = atoi(value().c_str());
+        else if (is("--seed")) opt.seed = atoi(value().c_str());
+        else if (is("--outfile")) opt.imageFile = value();
+        else if (is("--gpu-device")) device = atoi(value().c_str());
+        else if (is("--datadir")) dataDir = value();
+        else if (is("--pixelbounds")) {
+            if (sscanf(value().c_str(), "%d,%d,%d,%d", &opt.pixelBounds[0], &opt.pixelBounds[1], &opt.pixelBounds[2], &opt.pixelBounds[3]) != 4) { usage(); return 1; }
+            opt.hasPixelBounds = true;
+        } else if (is("--cropwindow")) {
+            if (sscanf(value().c_str(), "%f,%f,%f,%f", &opt.cropWindow[0], &opt.cropWindow[1], &opt.cropWindow[2], &opt.cropWindow[3]) != 4) { usage(); return 1; }
+            opt.hasCropWindow = true;
+        } else if (a == "--disable-pixel-jitter") opt.disablePixelJitter = true;
+        else if (a == "--disable-wavelength-jitter") opt.disableWavelengthJitter = true;
+        else if (a == "--disable-texture-filtering") opt.disableTextureFiltering = true;
+        else if (a == "--quiet") opt.quiet = true;
+        else if (a == "--stats") stats = true;
+        else if (a == "--gpu" || a == "--wavefront") {}
+        else if (a == "--help" || a == "-h") { usage(); return 0; }
+        else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 1; }
+        else scenePath = a;
+    }
+    if (scenePath.empty()) { usage(); return 1; }
+    if (dataDir.empty()) {
+        std::string self = argv[0];
+        size_t p = self.rfind('/');
+        dataDir = (p == std::string::npos ? std::string(".") : self.substr(0, p)) + "/../data";
+    }
+    SpectralData::Init(dataDir, dataDir + "/cache");
+    ParsedScene parsed;
+    ParseFiles({scenePath}, &opt, &parsed);
+    SceneTables T;
+    BuildSceneTables(parsed, opt, &T);
+    const wf_film &F = T.desc.film;
+    const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
+
+    WavefrontRenderer renderer(T, device);
+    if (stats) wf_profile_enable(renderer.Context(), 1);
+    double seconds = renderer.Render(0, T.spp, 1);
+    if (!opt.quiet) fprintf(stderr, "Rendering finished: %.3f s, %.2f Msamples/s\n", seconds, (double)W * H * T.spp / seconds / 1e6);
+    if (stats) {
+        wf_render_stats st;
+        renderer.Stats(&st);
+        unsigned long long total = st.camera_rays;
+        printf("  Wavefront integrator\n    Camera rays %20llu\n", (unsigned long long)st.camera_rays);
+        for (int d = 1; d < 64; ++d)
+            if (st.indirect_rays[d]) { printf("    Indirect rays, depth %-3d %12llu\n", d, (unsigned long long)st.indirect_rays[d]); total += st.indirect_rays[d]; }
+        for (int d = 0; d < 64; ++d)
+            if (st.shadow_rays[d]) { printf("    Shadow rays, depth %-3d   %12llu\n", d, (unsigned long long)st.shadow_rays[d]); total += st.shadow_rays[d]; }
+        printf("    Total rays %21llu  (%.2f Mray/s)\n", total, total / seconds / 1e6);
+        std::vector<wf_kernel_profile_entry> ent(64);
+        int n = 0;
+        wf_profile_report(renderer.Context(), ent.data(), (int)ent.size(), &n);
+        float sum = 0;
+        for (int i = 0; i < n; ++i) sum += ent[i].total_ms;
+        printf("  Wavefront Kernel Profile\n");
+        for (int i = 0; i < n; ++i)
+            printf("    %-52s %6d launches %10.2f ms / %5.1f%% (avg %8.3f, min %8.3f, max %8.3f)\n", ent[i].name, ent[i].launches, ent[i].total_ms,
+                   100.f * ent[i].total_ms / sum, ent[i].total_ms / ent[i].launches, ent[i].min_ms, ent[i].max_ms);
+        printf("    Total GPU time: %.2f ms\n", sum);
+    }
+    std::vector<double> film((size_t)W * H * 4);
+    renderer.DownloadFilm(film.data());
+    std::vector<float> rgb((size_t)W * H * 3);
+    FilmToRGB(F, film.data(), W, H, rgb.data(), T.saveFP16);
+    if (!WriteImage(T.imageFile, rgb.data(), W, H)) { fprintf(stderr, "Error: couldn't write %s\n", T.imageFile.c_str()); return 1; }
+    return 0;
+}

@@ -2,6 +2,8 @@
 // cmd/rgb2spec_opt.cpp (all /root/reference/src/pbrt/).
 #include "spectra.h"
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -304,6 +306,7 @@ const RGBToSpectrumTable *SpectralData::GetTable(const std::string &gamut) const
     }
     if (!ok) {
         GenerateRGBToSpectrumTable(gamut, t.get());
+        ::mkdir(cacheDir.c_str(), 0755);
         if (FILE *f = fopen(path.c_str(), "wb")) {
             fwrite(t->zNodes.data(), 4, nz, f);
             fwrite(t->coeffs.data(), 4, nc, f);

@@ -1,0 +1,109 @@
+// wfhost_api.cpp — C entry points of libwfhost.so (include/wf_host.h): scene loading (parser + table
+// builder) and the render loop, for callers that are not C++ (tests/, bench.py, __graft_entry__.py via
+// ctypes).  The render itself goes through libwfhip.so's C ABI (include/wf_abi.h).
+#include "integrator.h"
+#include "../../../include/wf_host.h"
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+using namespace wf;
+
+struct wfh_scene {
+    RenderOptions opt;
+    ParsedScene parsed;
+    SceneTables T;
+    std::unique_ptr<WavefrontRenderer> renderer;
+};
+
+static bool g_init = false;
+
+extern "C" {
+
+int wfh_init(const char *data_dir) {
+    if (g_init) return 0;
+    std::string d = data_dir ? data_dir : "";
+    if (d.empty()) return -1;
+    SpectralData::Init(d, d + "/cache");
+    g_init = true;
+    return 0;
+}
+
+wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed) {
+    if (!g_init || !path) return nullptr;
+    auto *s = new wfh_scene();
+    s->opt.pixelSamples = spp_override;
+    s->opt.seed = seed;
+    s->opt.quiet = true;
+    ParseFiles({path}, &s->opt, &s->parsed);
+    BuildSceneTables(s->parsed, s->opt, &s->T);
+    return s;
+}
+wfh_scene *wfh_scene_load_string(const char *text, int spp_override, int seed) {
+    if (!g_init || !text) return nullptr;
+    auto *s = new wfh_scene();
+    s->opt.pixelSamples = spp_override;
+    s->opt.seed = seed;
+    s->opt.quiet = true;
+    ParseString(text, &s->opt, &s->parsed);
+    BuildSceneTables(s->parsed, s->opt, &s->T);
+    return s;
+}
+void wfh_scene_free(wfh_scene *s) { delete s; }
+
+const wf_scene_desc *wfh_scene_desc(wfh_scene *s) { return s ? &s->T.desc : nullptr; }
+
+int wfh_scene_info(wfh_scene *s, wfh_info *out) {
+    if (!s || !out) return -1;
+    const wf_film &F = s->T.desc.film;
+    out->width = F.pixel_max[0] - F.pixel_min[0];
+    out->height = F.pixel_max[1] - F.pixel_min[1];
+    out->spp = s->T.spp;
+    out->max_queue_size = s->T.maxQueueSize;
+    out->n_passes = s->T.nPasses;
+    out->scanlines_per_pass = s->T.scanlinesPerPass;
+    out->n_triangles = s->T.desc.n_triangles;
+    out->n_bvh_nodes = s->T.desc.n_bvh_nodes;
+    out->n_lights = s->T.desc.n_lights;
+    out->max_depth = s->T.desc.max_depth;
+    out->save_fp16 = s->T.saveFP16;
+    out->y0 = F.pixel_min[1];
+    return 0;
+}
+
+int wfh_renderer_create(wfh_scene *s, int device) {
+    if (!s) return -1;
+    s->renderer = std::make_unique<WavefrontRenderer>(s->T, device);
+    return 0;
+}
+wf_ctx *wfh_renderer_ctx(wfh_scene *s) { return (s && s->renderer) ? s->renderer->Context() : nullptr; }
+
+double wfh_render(wfh_scene *s, int sample_begin, int sample_end, int sample_step, int fused) {
+    if (!s || !s->renderer) return -1.0;
+    return s->renderer->Render(sample_begin, sample_end, sample_step, fused != 0);
+}
+int wfh_clear_film(wfh_scene *s) {
+    if (!s || !s->renderer) return -1;
+    s->renderer->ClearFilm();
+    return 0;
+}
+int wfh_download_film(wfh_scene *s, double *dst) {
+    if (!s || !s->renderer) return -1;
+    s->renderer->DownloadFilm(dst);
+    return 0;
+}
+int wfh_stats(wfh_scene *s, wf_render_stats *out) {
+    if (!s || !s->renderer) return -1;
+    s->renderer->Stats(out);
+    return 0;
+}
+int wfh_film_to_rgb(wfh_scene *s, const double *film, float *rgb) {
+    if (!s) return -1;
+    const wf_film &F = s->T.desc.film;
+    FilmToRGB(F, film, F.pixel_max[0] - F.pixel_min[0], F.pixel_max[1] - F.pixel_min[1], rgb, s->T.saveFP16);
+    return 0;
+}
+int wfh_write_image(const char *path, const float *rgb, int w, int h) { return WriteImage(path, rgb, w, h) ? 0 : -1; }
+
+}  // extern "C"
