@@ -400,9 +400,15 @@ int wf_render_pass(wf_ctx *ctx, int y0, int sample_index);
 int wf_film_download(wf_ctx *ctx, double *rgb_sum_weight /* [H][W][4] */);
 int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes); /* for the RCCL film reduce */
 int wf_film_upload(wf_ctx *ctx, const double *rgb_sum_weight);
+int wf_film_copy_to_device(wf_ctx *ctx, void *dst_device);         /* D2D, wf_film_device_ptr's size */
+int wf_film_copy_from_device(wf_ctx *ctx, const void *src_device);
 int wf_stats_download(wf_ctx *ctx, wf_render_stats *out);
 int wf_profile_report(wf_ctx *ctx, wf_kernel_profile_entry *entries, int max_entries, int *n_out);
-int wf_profile_enable(wf_ctx *ctx, int enabled);           /* per-launch hipEvent pairs, gpu/util.cpp:136-209 */
+/* per-launch hipEvent pairs on the context's stream (gpu/util.cpp:136-209): 0 off, 1 every launch,
+   2 only the traversal kernels ("Intersect closest" / "Intersect shadow") */
+int wf_profile_enable(wf_ctx *ctx, int enabled);
+/* sum of the recorded durations of the named kernel since the last wf_profile_report */
+int wf_kernel_time_ms(wf_ctx *ctx, const char *name, double *total_ms, int *launches);
 
 /* Stand-alone traversal entry points used by parity tests and the roofline counters:
    rays given as host arrays (o[3], d[3], tMax), results as wf_hit_record / occluded flags. */

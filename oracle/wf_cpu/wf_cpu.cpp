@@ -12,7 +12,8 @@
 // where /root/reference does not exist.  Pinning status: see DESIGN.md "Oracle".
 //
 // usage: wf_cpu [--spp N] [--seed N] [--nthreads N] [--outfile out.pfm] [--dump-film film.bin]
-//               [--datadir DIR] [--trace rays.bin hits.bin] scene.pbrt
+//               [--datadir DIR] [--trace rays.bin hits.bin] [--samples begin end step]
+//               [--sampler-probe in.bin out.bin startDim ndims] scene.pbrt
 #include "../../pbrt-v4_amd/csrc/common/wf_kernels.h"
 #include "../../pbrt-v4_amd/csrc/host/scene.h"
 
@@ -70,7 +71,8 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
 
 int main(int argc, char **argv) {
     RenderOptions opt;
-    std::string scenePath, dumpFilm, dataDir, traceRays, traceHits;
+    std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut;
+    int sampleBegin = 0, sampleEnd = -1, sampleStep = 1, probeStartDim = 0, probeNDims = 0;
     gThreads = std::max(1u, std::thread::hardware_concurrency());
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -83,6 +85,8 @@ int main(int argc, char **argv) {
         else if (a == "--datadir") dataDir = next();
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
+        else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
+        else if (a == "--sampler-probe") { probeIn = next(); probeOut = next(); probeStartDim = atoi(next().c_str()); probeNDims = atoi(next().c_str()); }
         else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
         else scenePath = a;
     }
@@ -101,6 +105,29 @@ int main(int argc, char **argv) {
     uint32_t sobol[104];
     FillSobol2D(sobol);
     SceneView sv = MakeHostView(T.desc, sobol);
+
+    // sampler probe: in = n x {px, py, sampleIndex} int32 -> out = n x ndims floats (Get1D from startDim)
+    if (!probeIn.empty()) {
+        FILE *f = fopen(probeIn.c_str(), "rb");
+        if (!f) { perror(probeIn.c_str()); return 1; }
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        int n = (int)(sz / (3 * sizeof(int32_t)));
+        std::vector<int32_t> in((size_t)n * 3);
+        if (fread(in.data(), 4, in.size(), f) != in.size()) return 1;
+        fclose(f);
+        std::vector<float> out((size_t)n * probeNDims);
+        for (int i = 0; i < n; ++i) {
+            ZSobol s(sv);
+            s.StartPixelSample(in[3 * i], in[3 * i + 1], in[3 * i + 2], probeStartDim);
+            for (int d = 0; d < probeNDims; ++d) out[(size_t)i * probeNDims + d] = s.Get1D();
+        }
+        f = fopen(probeOut.c_str(), "wb");
+        fwrite(out.data(), 4, out.size(), f);
+        fclose(f);
+        return 0;
+    }
 
     // stand-alone traversal mode: rays.bin = n x {o[3], d[3], tMax} floats -> hits.bin = n x wf_hit_record
     if (!traceRays.empty()) {
@@ -150,7 +177,8 @@ int main(int argc, char **argv) {
 
     auto t0 = std::chrono::steady_clock::now();
     const int maxDepth = T.desc.max_depth;
-    for (int sampleIndex = 0; sampleIndex < T.spp; ++sampleIndex) {
+    if (sampleEnd < 0) sampleEnd = T.spp;
+    for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep) {
         for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
             ws.counters[CNT_RAY0] = 0;
             ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex); });

@@ -64,7 +64,7 @@ struct wf_ctx {
     float sceneBounds[6] = {};
     bool sceneLoaded = false, queuesAllocated = false;
     // profiling (gpu/util.cpp:136-209)
-    bool profile = false;
+    int profile = 0;             // 0 off, 1 every launch, 2 traversal kernels only
     struct Ev { std::string name; hipEvent_t a, b; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> eventPool;
@@ -258,8 +258,10 @@ struct Prof {
     wf_ctx *c;
     hipEvent_t a = nullptr, b = nullptr;
     const char *name;
+    bool on;
     Prof(wf_ctx *c, const char *name) : c(c), name(name) {
-        if (!c->profile) return;
+        on = c->profile == 1 || (c->profile == 2 && strncmp(name, "Intersect", 9) == 0);
+        if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
             if (!c->eventPool.empty()) { e = c->eventPool.back(); c->eventPool.pop_back(); }
@@ -270,7 +272,7 @@ struct Prof {
         (void)hipEventRecord(a, c->stream);
     }
     ~Prof() {
-        if (!c->profile) return;
+        if (!on) return;
         (void)hipEventRecord(b, c->stream);
         c->events.push_back({name, a, b});
     }
@@ -556,6 +558,20 @@ int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes) {
     *nbytes = (uint64_t)ctx->W * ctx->H * 4 * sizeof(double);
     return 0;
 }
+// device-to-device copies of the film accumulators, for the multi-GPU film reduce: the caller owns a
+// device buffer of wf_film_device_ptr's size (e.g. a torch tensor handed to RCCL)
+int wf_film_copy_to_device(wf_ctx *ctx, void *dst_device) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    HIPCHK(hipMemcpyAsync(dst_device, ctx->ws.film, (size_t)ctx->W * ctx->H * 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_film_copy_from_device(wf_ctx *ctx, const void *src_device) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    HIPCHK(hipMemcpyAsync(ctx->ws.film, src_device, (size_t)ctx->W * ctx->H * 4 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 int wf_stats_download(wf_ctx *ctx, wf_render_stats *out) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     unsigned long long h[129];
@@ -568,7 +584,24 @@ int wf_stats_download(wf_ctx *ctx, wf_render_stats *out) {
 
 int wf_profile_enable(wf_ctx *ctx, int enabled) {
     if (!ctx) return fail(-1, "null context");
-    ctx->profile = enabled != 0;
+    ctx->profile = enabled;
+    return 0;
+}
+// total milliseconds and launch count of the named kernel since the last report (drains nothing)
+int wf_kernel_time_ms(wf_ctx *ctx, const char *name, double *total_ms, int *launches) {
+    if (!ctx || !name) return fail(-1, "null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double sum = 0;
+    int n = 0;
+    for (auto &e : ctx->events)
+        if (e.name == name) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            sum += ms;
+            ++n;
+        }
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = n;
     return 0;
 }
 int wf_profile_report(wf_ctx *ctx, wf_kernel_profile_entry *entries, int max_entries, int *n_out) {

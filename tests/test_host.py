@@ -1,0 +1,87 @@
+"""Host logic: .pbrt parsing, flat-table construction (BVH, light BVH, film/sampler/camera), wavefront pass
+geometry.  No GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, ROOT
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("offset", C.c_int32), ("nprims", C.c_uint16), ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+def desc_fields(wfpt, scene):
+    """read the leading integer fields + pointers of wf_scene_desc via ctypes"""
+    host, _ = wfpt.libs()
+    p = host.wfh_scene_desc(scene.h)
+
+    class Head(C.Structure):
+        _fields_ = [("abi_version", C.c_int32), ("n_vertices", C.c_int32), ("n_triangles", C.c_int32), ("n_meshes", C.c_int32),
+                    ("n_bvh_nodes", C.c_int32), ("P", C.c_void_p), ("N", C.c_void_p), ("UV", C.c_void_p), ("tri_indices", C.c_void_p),
+                    ("tri_mesh", C.c_void_p), ("meshes", C.c_void_p), ("bvh_nodes", C.c_void_p), ("bvh_prims", C.c_void_p)]
+    return Head.from_address(p)
+
+
+def test_cornell_tables(wfpt):
+    s = wfpt.Scene(path=os.path.join(ROOT, "scenes", "cornell-box.pbrt"))
+    assert (s.width, s.height, s.spp) == (400, 400, 16)
+    assert s.info.n_triangles == 2 + 5 * 2 + 2 * 10
+    assert s.info.n_lights == 2  # one DiffuseAreaLight per emissive triangle (scene.cpp:1290-1340)
+    assert s.info.max_depth == 5
+    # wavefront/integrator.cpp:227-236
+    assert (s.info.max_queue_size, s.info.n_passes, s.info.scanlines_per_pass) == (160000, 1, 400)
+    h = desc_fields(wfpt, s)
+    assert h.abi_version == 1 and h.n_triangles == 32
+    nodes = (BvhNode * h.n_bvh_nodes).from_address(h.bvh_nodes)
+    prims = np.ctypeslib.as_array((C.c_int32 * h.n_triangles).from_address(h.bvh_prims))
+    assert sorted(prims.tolist()) == list(range(32))  # every triangle exactly once
+    # LinearBVHNode invariants (cpu/aggregates.cpp:129-137,505-521): children inside the parent, leaves cover all prims
+    covered = 0
+    for i in range(h.n_bvh_nodes):
+        nd = nodes[i]
+        if nd.nprims > 0:
+            covered += nd.nprims
+            assert nd.nprims <= 4
+        else:
+            assert nd.axis in (0, 1, 2)
+            for c in (i + 1, nd.offset):
+                ch = nodes[c]
+                for k in range(3):
+                    assert ch.bmin[k] >= nd.bmin[k] and ch.bmax[k] <= nd.bmax[k]
+    assert covered == 32
+    s.close()
+
+
+def test_1080p_wavefront_geometry(wfpt):
+    text = open(os.path.join(ROOT, "scenes", "cornell-box.pbrt")).read().replace(
+        '"integer xresolution" [ 400 ] "integer yresolution" [ 400 ]', '"integer xresolution" [ 1920 ] "integer yresolution" [ 1080 ]')
+    s = wfpt.Scene(text=text, spp=64)
+    assert (s.info.max_queue_size, s.info.n_passes, s.info.scanlines_per_pass) == (1036800, 2, 540)
+    assert s.spp == 64
+    s.close()
+
+
+def test_spp_override_and_blobs_scene(wfpt):
+    s = wfpt.Scene(path=os.path.join(GOLDEN, "blobs_small.pbrt"), spp=8)
+    assert s.spp == 8
+    assert s.info.n_triangles == 2 * (2 * 20 * 13) + 2 + 10 + 4
+    assert s.info.n_lights == 4
+    s.close()
+
+
+def test_film_to_rgb_matches_getpixelrgb(wfpt):
+    """RGBFilm::GetPixelRGB (film.h:258-275): rgb = outputRGBFromSensorRGB * (rgbSum / weightSum)"""
+    s = wfpt.Scene(path=os.path.join(GOLDEN, "cornell64.pbrt"))
+    film = np.zeros((64, 64, 4))
+    film[..., :3] = 2.0
+    film[..., 3] = 4.0
+    film[0, 0] = 0  # weightSum == 0 -> no division
+    rgb = s.film_to_rgb(film)
+    assert rgb.shape == (64, 64, 3)
+    assert (rgb[0, 0] == 0).all()
+    assert np.allclose(rgb[1, 1], rgb[5, 7])
+    # sRGB output space: X=Y=Z=0.5 maps to a slightly pink-ish white; luminance row sums to ~0.5
+    assert 0.3 < rgb[1, 1].mean() < 0.7
+    s.close()

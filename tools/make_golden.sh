@@ -1,0 +1,21 @@
+#!/bin/bash
+# tools/make_golden.sh — regenerates tests/golden/ from the REAL reference (needs /root/reference and the
+# shimmed build oracle/_ref/{ref_probe,pbrt_ref}: `make -C oracle ref`).  Run in the build container;
+# the outputs are committed so that the GPU box (which has no /root/reference) can check against them.
+set -e
+cd "$(dirname "$0")/.."
+G=tests/golden
+mkdir -p $G
+oracle/_ref/ref_probe $G
+sed 's/"integer xresolution" \[ 400 \] "integer yresolution" \[ 400 \]/"integer xresolution" [ 64 ] "integer yresolution" [ 64 ] "bool savefp16" [ false ]/' scenes/cornell-box.pbrt > $G/cornell64.pbrt
+python3 - <<'PY'
+import sys
+sys.path.insert(0, "tools")
+import make_scenes
+make_scenes.killeroo_like("tests/golden/blobs_small.pbrt", (96, 54), 4, rings=14, segs=20)
+PY
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_ref.pfm $G/cornell64.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_small_ref.pfm $G/blobs_small.pbrt
+# the named physical oracle (not sample-aligned): VolPathIntegrator at high spp, for mean comparisons
+oracle/_ref/pbrt_ref --quiet --seed 0 --spp 256 --outfile $G/cornell64_volpath256.pfm $G/cornell64.pbrt
+ls -la $G
