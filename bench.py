@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
 

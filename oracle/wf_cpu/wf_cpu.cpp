@@ -66,6 +66,8 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.camera = d.camera; sv.film = d.film; sv.filter = d.filter; sv.filterData = d.filter_data; sv.sampler = d.sampler;
     sv.sobol = sobol;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;
+    sv.matTypeMask = 0;
+    for (int i = 0; i < d.n_materials; ++i) sv.matTypeMask |= 1 << d.materials[i].type;
     return sv;
 }
 
@@ -168,7 +170,7 @@ int main(int argc, char **argv) {
     ws.escapedQ = Alloc<int32_t>(n); ws.hitLightQ = Alloc<int32_t>(n);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.matQ[m] = Alloc<int32_t>(T.materialTypePresent[m] ? n : 1);
     ws.sq.o = Alloc<F4>(n); ws.sq.d = Alloc<F4>(n); ws.sq.Ld = Alloc<F4>(n); ws.sq.r_u = Alloc<F4>(n); ws.sq.r_l = Alloc<F4>(n);
-    ws.counters = Alloc<int32_t>(CNT_COUNT);
+    ws.counters = Alloc<int32_t>(CNT_COUNT * CNT_STRIDE);
     const wf_film &F = T.desc.film;
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
     ws.film = Alloc<double>((size_t)W * H * 4);
@@ -180,15 +182,15 @@ int main(int argc, char **argv) {
     if (sampleEnd < 0) sampleEnd = T.spp;
     for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep) {
         for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
-            ws.counters[CNT_RAY0] = 0;
+            ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0);
             ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex); });
-            ws.stats[0] += ws.counters[CNT_RAY0];
+            ws.stats[0] += ws.counters[(CNT_RAY0) * CNT_STRIDE];
             for (int depth = 0; true; ++depth) {
                 const int cur = depth & 1;
-                ws.counters[CNT_RAY0 + (cur ^ 1)] = 0;
-                ws.counters[CNT_ESCAPED] = ws.counters[CNT_HITLIGHT] = 0;
-                for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.counters[CNT_MAT0 + m] = 0;
-                const int nRays = ws.counters[CNT_RAY0 + cur];
+                ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE] = 0;
+                ws.counters[(CNT_ESCAPED) * CNT_STRIDE] = ws.counters[(CNT_HITLIGHT) * CNT_STRIDE] = 0;
+                for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.counters[(CNT_MAT0 + m) * CNT_STRIDE] = 0;
+                const int nRays = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
                 ws.stats[1 + depth] += nRays;
                 ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex); });
                 std::atomic<unsigned long long> nv{0}, nt{0};
@@ -201,15 +203,15 @@ int main(int argc, char **argv) {
                     KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.b0, ch.h.b1, ch.h.b2);
                 });
                 nodesVisited += nv; trisTested += nt;
-                ParallelFor(ws.counters[CNT_ESCAPED], [&](int i) { KHandleEscaped(sv, ws, cur, i); });
-                ParallelFor(ws.counters[CNT_HITLIGHT], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
+                ParallelFor(ws.counters[(CNT_ESCAPED) * CNT_STRIDE], [&](int i) { KHandleEscaped(sv, ws, cur, i); });
+                ParallelFor(ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
                 if (depth == maxDepth) break;
-                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_DIFFUSE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE>(sv, ws, cur, i); });
-                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_CONDUCTOR], [&](int i) { KEvalMaterial<WF_MAT_CONDUCTOR>(sv, ws, cur, i); });
-                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_DIELECTRIC], [&](int i) { KEvalMaterial<WF_MAT_DIELECTRIC>(sv, ws, cur, i); });
-                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_THIN_DIELECTRIC], [&](int i) { KEvalMaterial<WF_MAT_THIN_DIELECTRIC>(sv, ws, cur, i); });
-                ParallelFor(ws.counters[CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i); });
-                const int nShadow = ws.counters[CNT_SHADOW];
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_CONDUCTOR>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIELECTRIC>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_THIN_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_THIN_DIELECTRIC>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i, true); });
+                const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
                 ParallelFor(nShadow, [&](int i) {
                     F4 o = ws.sq.o[i], d = ws.sq.d[i];
                     ArrayStack st;
@@ -217,7 +219,7 @@ int main(int argc, char **argv) {
                     KRecordShadowRay(ws, i, occluded);
                 });
                 ws.stats[65 + depth] += nShadow;
-                ws.counters[CNT_SHADOW] = 0;
+                ws.counters[(CNT_SHADOW) * CNT_STRIDE] = 0;
             }
             ParallelFor(n, [&](int i) { KUpdateFilm(sv, ws, i); });
         }

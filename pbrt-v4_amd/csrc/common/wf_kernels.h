@@ -31,8 +31,13 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_COUNT = CNT_MAT0 + WF_MAT_NTYPES
+    CNT_NEXT_CLOSEST = CNT_MAT0 + WF_MAT_NTYPES,  // ray cursors of the persistent traversal kernels
+    CNT_NEXT_SHADOW = CNT_NEXT_CLOSEST + 1,
+    CNT_COUNT = CNT_NEXT_SHADOW + 1
 };
+// every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
+// (~88 returning atomics/us on MI355X), and with adjacent ints every queue of a stage shared that budget
+constexpr int CNT_STRIDE = 64;
 enum { RAYFLAG_SPECULAR_BOUNCE = 1, RAYFLAG_ANY_NONSPECULAR = 2 };
 
 struct RayQueueV {
@@ -62,7 +67,7 @@ struct WorkState {
     int32_t *escapedQ, *hitLightQ;
     int32_t *matQ[WF_MAT_NTYPES];
     ShadowQueueV sq;
-    int32_t *counters;              // CNT_*
+    int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
     double *film;                   // [pixels][4]: rgbSum[3], weightSum (film.h:302-307)
     unsigned long long *stats;      // cameraRays, indirect[64], shadow[64]
     unsigned long long *trav;       // wf_traversal_counters (8 x u64) or null
@@ -71,8 +76,8 @@ struct WorkState {
 // ---------------------------------------------------------------------------------------------
 // WorkQueue::AllocateEntry (workqueue.h:92-102).  On the device: one atomic per wave per destination
 // queue (ballot + popcount prefix), the slot broadcast from the leader lane.
+WF_HD int QueueAlloc(int32_t *counter) {
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ inline int QueueAlloc(int32_t *counter) {
     int result = 0;
     bool done = false;
     while (!done) {
@@ -94,10 +99,40 @@ __device__ inline int QueueAlloc(int32_t *counter) {
         }
     }
     return result;
-}
 #else
-inline int QueueAlloc(int32_t *counter) { return __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED); }
+    return __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED);
 #endif
+}
+
+// Block-aggregated AllocateEntry: EVERY thread of the workgroup must call it at the same program point
+// (`want` says whether this thread needs a slot).  One atomic per workgroup per call instead of one per wave:
+// a single queue counter sustains only ~88 returning atomics/us, which at one atomic per wave is the
+// floor of every stage (~190 us per million items).  Returns the slot, or -1 if !want.
+WF_HD int BlockAlloc(int32_t *counter, bool want) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int s_waveCount[16];
+    __shared__ int s_base;
+    const unsigned long long mask = __ballot(want);
+    const unsigned lane = __lane_id();
+    const int wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_waveCount[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < nWaves; ++w) total += s_waveCount[w];
+        s_base = total > 0 ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    int prefix = 0;
+    for (int w = 0; w < wave; ++w) prefix += s_waveCount[w];
+    const int slot = s_base + prefix + rank;
+    __syncthreads();  // s_waveCount / s_base are reused by the next call
+    return want ? slot : -1;
+#else
+    return want ? __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED) : -1;
+#endif
+}
 
 WF_HD Wavelengths LoadLambda(const WorkState &ws, int pixelIndex) {
     F4 l = ws.lambda[pixelIndex], p = ws.lambdaPdf[pixelIndex];
@@ -156,9 +191,11 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     StoreLambda(ws, pixelIndex, lambda);
     ws.filterWeight[pixelIndex] = filterWeight;
     if (cr.valid) {
-        // RayQueue::PushCameraRay, workitems.h:346-361
+        // RayQueue::PushCameraRay, workitems.h:346-361.  Both projective cameras always produce a ray and
+        // the in-bounds pixels of a pass are exactly pixelIndex < rows*width, so the slot is the pixel index
+        // itself (queue in pixel order, no atomic); KCameraRayCount sets the queue size.
         const RayQueueV &q = ws.rq[0];
-        int index = QueueAlloc(&ws.counters[CNT_RAY0]);
+        int index = pixelIndex;
         q.o[index] = F4{cr.o.x, cr.o.y, cr.o.z, cr.time};
         q.d[index] = F4{cr.d.x, cr.d.y, cr.d.z, 1.f};
         q.beta[index] = F4{1, 1, 1, 1};
@@ -167,6 +204,17 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
         q.meta[index] = I4{pixelIndex, 0, 0, sv.camera.medium};
         ws.cameraRayWeight[pixelIndex] = F4{1, 1, 1, 1};
     } else ws.cameraRayWeight[pixelIndex] = F4{0, 0, 0, 0};
+}
+
+// number of camera rays of the pass starting at scanline y0 (the in-bounds pixels, row-major)
+WF_HD int KCameraRayCount(const SceneView &sv, const WorkState &ws, int y0) {
+    const wf_film &F = sv.film;
+    int xResolution = F.pixel_max[0] - F.pixel_min[0];
+    int rows = F.pixel_max[1] - y0;
+    int maxRows = ws.maxQueueSize / xResolution;
+    if (rows > maxRows) rows = maxRows;
+    if (rows < 0) rows = 0;
+    return rows * xResolution;
 }
 
 // K3: GenerateRaySamples, wavefront/samples.cpp:35-65 (no subsurface: dimension = 6 + 7*depth)
@@ -193,7 +241,7 @@ WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur
 WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, float b0, float b1, float b2) {
     if (!found) {
         if (sv.nInfiniteLights > 0) {
-            int slot = QueueAlloc(&ws.counters[CNT_ESCAPED]);
+            int slot = QueueAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE]);
             ws.escapedQ[slot] = i;
         }
         return;
@@ -210,7 +258,7 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
         F4 o = q.o[i], d = q.d[i];
         V3 rd{d.x, d.y, d.z};
         V3 no = OffsetRayOrigin(si.pi, si.n, rd);
-        int slot = QueueAlloc(&ws.counters[CNT_RAY0 + (cur ^ 1)]);
+        int slot = QueueAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
         nq.o[slot] = F4{no.x, no.y, no.z, o.w};
         nq.d[slot] = d;
         nq.beta[slot] = q.beta[i];
@@ -223,12 +271,62 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
         return;
     }
     if (mesh.first_light >= 0) {
-        int slot = QueueAlloc(&ws.counters[CNT_HITLIGHT]);
+        int slot = QueueAlloc(&ws.counters[(CNT_HITLIGHT) * CNT_STRIDE]);
         ws.hitLightQ[slot] = i;
     }
     int mtype = sv.materials[mesh.material].type;
-    int slot = QueueAlloc(&ws.counters[CNT_MAT0 + mtype]);
+    int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + mtype) * CNT_STRIDE]);
     ws.matQ[mtype][slot] = i;
+}
+
+// The same routing with block-aggregated pushes (BlockAlloc): every thread of the workgroup calls it once
+// per batch, `valid` = the thread has a ray.  Used by the production traversal kernel, whose workgroup
+// finishes a batch of rays together.
+WF_HD void KAfterClosestHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, float b0, float b1, float b2) {
+    const bool found = valid && prim >= 0;
+    if (sv.nInfiniteLights > 0) {
+        int slot = BlockAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE], valid && !found);
+        if (slot >= 0) ws.escapedQ[slot] = i;
+    }
+    int material = -1, firstLight = -1, mtype = -1;
+    if (found) {
+        ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
+        const wf_mesh &mesh = sv.meshes[sv.triMesh[prim]];
+        material = mesh.material;
+        firstLight = mesh.first_light;
+        if (material >= 0) mtype = sv.materials[material].type;
+    }
+    if (sv.haveMedia) {
+        // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
+        const bool isInterface = found && material < 0;
+        int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], isInterface);
+        if (isInterface) {
+            const RayQueueV &q = ws.rq[cur];
+            const RayQueueV &nq = ws.rq[cur ^ 1];
+            SurfIntr si;
+            TriangleInteraction(sv, prim, b0, b1, b2, &si);
+            F4 o = q.o[i], d = q.d[i];
+            V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
+            nq.o[slot] = F4{no.x, no.y, no.z, o.w};
+            nq.d[slot] = d;
+            nq.beta[slot] = q.beta[i];
+            nq.r_u[slot] = q.r_u[i];
+            nq.r_l[slot] = q.r_l[i];
+            nq.ctx0[slot] = q.ctx0[i];
+            nq.ctx1[slot] = q.ctx1[i];
+            nq.ctx2[slot] = q.ctx2[i];
+            nq.meta[slot] = q.meta[i];
+        }
+    }
+    {
+        int slot = BlockAlloc(&ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], found && material >= 0 && firstLight >= 0);
+        if (slot >= 0) ws.hitLightQ[slot] = i;
+    }
+    for (int t = 1; t < WF_MAT_NTYPES; ++t) {
+        if (!((sv.matTypeMask >> t) & 1)) continue;
+        int slot = BlockAlloc(&ws.counters[(CNT_MAT0 + t) * CNT_STRIDE], mtype == t);
+        if (slot >= 0) ws.matQ[t][slot] = i;
+    }
 }
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537
@@ -324,97 +422,123 @@ template <> struct MatBxDF<WF_MAT_DIFFUSE_TRANSMISSION> {
 };
 
 template <int MAT>
-WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid) {
+    // `valid` = this thread has an item.  The two queue pushes go through BlockAlloc, which every thread of
+    // the workgroup must reach: control flow below is flattened into the flags pushRay / pushShadow.
     using BxDF = typename MatBxDF<MAT>::T;
-    int i = ws.matQ[MAT][qi];
     const RayQueueV &q = ws.rq[cur];
     const RayQueueV &nq = ws.rq[cur ^ 1];
-    I4 meta = q.meta[i];
-    int pixelIndex = meta.x, depth = meta.y;
-    bool anyNonSpecularBounces0 = meta.z & RAYFLAG_ANY_NONSPECULAR;
-    F4 h = ws.hit[i];
-    int prim = (int)FloatToBits(h.x);
-    SurfIntr si;
-    TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
-    const wf_mesh &mesh = sv.meshes[si.mesh];
-    const wf_material &mat = sv.materials[mesh.material];
-    F4 o4 = q.o[i], d4 = q.d[i];
-    float time = o4.w, etaScale0 = d4.w;
-    V3 wo{-d4.x, -d4.y, -d4.z};
-    // (texture-filtering differentials, surfscatter.cpp:75-104, only feed image textures; the textures
-    // evaluated here are position-independent)
-    N3 ns = si.ns;
-    V3 dpdus = si.dpdus;
-    Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda);
-    BSDF<BxDF> bsdf(ns, dpdus, bxdf);
-    if (lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
-    if (sv.regularize && anyNonSpecularBounces0) bsdf.Regularize();
+    bool pushRay = false, pushShadow = false;
+    // next-ray payload
+    V3 ro{0, 0, 0}, rwi{0, 0, 0};
+    S4 rbeta = S4c(0.f), rr_u = S4c(0.f), rr_l = S4c(0.f);
+    float retaScale = 0, time = 0;
+    int rflags = 0, rmedium = -1, pixelIndex = 0, depth = 0;
+    LightCtx rctx{};
+    // shadow-ray payload
+    RayOD sr{V3{0, 0, 0}, V3{0, 0, 0}};
+    S4 sLd = S4c(0.f), sr_u = S4c(0.f), sr_l = S4c(0.f);
+    if (valid) {
+        int i = ws.matQ[MAT][qi];
+        I4 meta = q.meta[i];
+        pixelIndex = meta.x;
+        depth = meta.y;
+        bool anyNonSpecularBounces0 = meta.z & RAYFLAG_ANY_NONSPECULAR;
+        F4 h = ws.hit[i];
+        int prim = (int)FloatToBits(h.x);
+        SurfIntr si;
+        TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
+        const wf_mesh &mesh = sv.meshes[si.mesh];
+        const wf_material &mat = sv.materials[mesh.material];
+        F4 o4 = q.o[i], d4 = q.d[i];
+        time = o4.w;
+        float etaScale0 = d4.w;
+        V3 wo{-d4.x, -d4.y, -d4.z};
+        // (texture-filtering differentials, surfscatter.cpp:75-104, only feed image textures; the textures
+        // evaluated here are position-independent)
+        N3 ns = si.ns;
+        V3 dpdus = si.dpdus;
+        Wavelengths lambda = LoadLambda(ws, pixelIndex);
+        BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda);
+        BSDF<BxDF> bsdf(ns, dpdus, bxdf);
+        if (lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
+        if (sv.regularize && anyNonSpecularBounces0) bsdf.Regularize();
 
-    S4 wbeta = toS4(q.beta[i]), wr_u = toS4(q.r_u[i]);
-    F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
-    // Sample BSDF and enqueue indirect ray
-    BSDFSample bs = bsdf.Sample_f(wo, s0.w, V2{s1.x, s1.y});
-    if (bs.valid) {
-        V3 wi = bs.wi;
-        S4 beta = wbeta * bs.f * AbsDot(wi, ns) / bs.pdf;
-        S4 r_u = wr_u, r_l;
-        if (bs.pdfIsProportional) r_l = r_u / bsdf.PDF(wo, bs.wi);
-        else r_l = r_u / bs.pdf;
-        float etaScale = etaScale0;
-        if (bs.IsTransmission()) etaScale *= Sqr(bs.eta);
-        S4 rrBeta = beta * etaScale / r_u.Average();
-        if (rrBeta.MaxComponentValue() < 1 && depth >= 1) {
-            float qq = fmax(0.f, 1 - rrBeta.MaxComponentValue());
-            if (s1.z < qq) beta = S4c(0.f);
-            else beta = beta / (1 - qq);
+        S4 wbeta = toS4(q.beta[i]), wr_u = toS4(q.r_u[i]);
+        F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
+        // Sample BSDF and enqueue indirect ray
+        BSDFSample bs = bsdf.Sample_f(wo, s0.w, V2{s1.x, s1.y});
+        if (bs.valid) {
+            V3 wi = bs.wi;
+            S4 beta = wbeta * bs.f * AbsDot(wi, ns) / bs.pdf;
+            S4 r_u = wr_u, r_l;
+            if (bs.pdfIsProportional) r_l = r_u / bsdf.PDF(wo, bs.wi);
+            else r_l = r_u / bs.pdf;
+            float etaScale = etaScale0;
+            if (bs.IsTransmission()) etaScale *= Sqr(bs.eta);
+            S4 rrBeta = beta * etaScale / r_u.Average();
+            if (rrBeta.MaxComponentValue() < 1 && depth >= 1) {
+                float qq = fmax(0.f, 1 - rrBeta.MaxComponentValue());
+                if (s1.z < qq) beta = S4c(0.f);
+                else beta = beta / (1 - qq);
+            }
+            if (beta) {
+                pushRay = true;
+                ro = OffsetRayOrigin(si.pi, si.n, wi);
+                rwi = wi;
+                if (sv.haveMedia) rmedium = Dot(wi, si.n) > 0 ? mesh.medium_outside : mesh.medium_inside;
+                bool anyNonSpecularBounces = !bs.IsSpecularS() || anyNonSpecularBounces0;
+                rctx = LightCtx{si.pi, si.n, ns};
+                rbeta = beta; rr_u = r_u; rr_l = r_l; retaScale = etaScale;
+                rflags = (bs.IsSpecularS() ? RAYFLAG_SPECULAR_BOUNCE : 0) | (anyNonSpecularBounces ? RAYFLAG_ANY_NONSPECULAR : 0);
+            }
         }
-        if (beta) {
-            V3 ro = OffsetRayOrigin(si.pi, si.n, wi);
-            int medium = -1;
-            if (sv.haveMedia) medium = Dot(wi, si.n) > 0 ? mesh.medium_outside : mesh.medium_inside;
-            bool anyNonSpecularBounces = !bs.IsSpecularS() || anyNonSpecularBounces0;
+
+        // Sample light and enqueue shadow ray
+        int flags = bsdf.Flags();
+        if (IsNonSpecular(flags)) {
             LightCtx ctx{si.pi, si.n, ns};
-            int slot = QueueAlloc(&ws.counters[CNT_RAY0 + (cur ^ 1)]);
-            nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
-            nq.d[slot] = F4{wi.x, wi.y, wi.z, etaScale};
-            nq.beta[slot] = toF4(beta);
-            nq.r_u[slot] = toF4(r_u);
-            nq.r_l[slot] = toF4(r_l);
-            StoreCtx(nq, slot, ctx);
-            nq.meta[slot] = I4{pixelIndex, depth + 1,
-                               (bs.IsSpecularS() ? RAYFLAG_SPECULAR_BOUNCE : 0) | (anyNonSpecularBounces ? RAYFLAG_ANY_NONSPECULAR : 0), medium};
+            if (IsReflective(flags) && !IsTransmissive(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, wo));
+            else if (IsTransmissive(flags) && IsReflective(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, -wo));
+            float lightPMF = 0;
+            int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
+            if (lightId >= 0) {
+                const wf_light &light = sv.lights[lightId];
+                LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+                if (ls.valid && ls.L && ls.pdf != 0) {
+                    V3 wi = ls.wi;
+                    S4 f = bsdf.f(wo, wi);
+                    if (f) {
+                        S4 beta = wbeta * f * AbsDot(wi, ns);
+                        float lightPDF = ls.pdf * lightPMF;
+                        float bsdfPDF = IsDeltaLight(light.type) ? 0.f : bsdf.PDF(wo, wi);
+                        sr_u = wr_u * bsdfPDF;
+                        sr_l = wr_u * lightPDF;
+                        sLd = beta * ls.L;
+                        sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
+                        pushShadow = true;
+                    }
+                }
+            }
         }
     }
-
-    // Sample light and enqueue shadow ray
-    int flags = bsdf.Flags();
-    if (IsNonSpecular(flags)) {
-        LightCtx ctx{si.pi, si.n, ns};
-        if (IsReflective(flags) && !IsTransmissive(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, wo));
-        else if (IsTransmissive(flags) && IsReflective(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, -wo));
-        float lightPMF;
-        int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
-        if (lightId < 0) return;
-        const wf_light &light = sv.lights[lightId];
-        LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
-        if (!ls.valid || !ls.L || ls.pdf == 0) return;
-        V3 wi = ls.wi;
-        S4 f = bsdf.f(wo, wi);
-        if (!f) return;
-        S4 beta = wbeta * f * AbsDot(wi, ns);
-        float lightPDF = ls.pdf * lightPMF;
-        float bsdfPDF = IsDeltaLight(light.type) ? 0.f : bsdf.PDF(wo, wi);
-        S4 r_u = wr_u * bsdfPDF;
-        S4 r_l = wr_u * lightPDF;
-        S4 Ld = beta * ls.L;
-        RayOD sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
-        int slot = QueueAlloc(&ws.counters[CNT_SHADOW]);
+    int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], pushRay);
+    if (pushRay) {
+        nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
+        nq.d[slot] = F4{rwi.x, rwi.y, rwi.z, retaScale};
+        nq.beta[slot] = toF4(rbeta);
+        nq.r_u[slot] = toF4(rr_u);
+        nq.r_l[slot] = toF4(rr_l);
+        StoreCtx(nq, slot, rctx);
+        nq.meta[slot] = I4{pixelIndex, depth + 1, rflags, rmedium};
+    }
+    slot = BlockAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE], pushShadow);
+    if (pushShadow) {
         ws.sq.o[slot] = F4{sr.o.x, sr.o.y, sr.o.z, 1 - ShadowEpsilon};
         ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)pixelIndex)};
-        ws.sq.Ld[slot] = toF4(Ld);
-        ws.sq.r_u[slot] = toF4(r_u);
-        ws.sq.r_l[slot] = toF4(r_l);
+        ws.sq.Ld[slot] = toF4(sLd);
+        ws.sq.r_u[slot] = toF4(sr_u);
+        ws.sq.r_l[slot] = toF4(sr_l);
     }
 }
 

@@ -39,6 +39,7 @@ struct SceneView {
     const uint32_t *sobol;  // SobolMatrices32 rows for dimensions 0 and 1 (2 x 52)
     // integrator
     int maxDepth, regularize, haveMedia;
+    int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
     wf_options options;
 };
 

@@ -17,15 +17,14 @@ struct TriHit { float b0, b1, b2, t; };
 WF_HD bool IntersectTriangle(V3 ro, V3 rd, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
     if (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0) return false;
     V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    // Permute(v, {kx, ky, kz}) with kx = (kz+1)%3, ky = (kx+1)%3 is one of three rotations; written as
+    // selects so that nothing is a runtime-indexed array on the device
     int kz = MaxComponentIndex(Abs(rd));
-    int kx = kz + 1;
-    if (kx == 3) kx = 0;
-    int ky = kx + 1;
-    if (ky == 3) ky = 0;
-    V3 d = Permute(rd, kx, ky, kz);
-    p0t = Permute(p0t, kx, ky, kz);
-    p1t = Permute(p1t, kx, ky, kz);
-    p2t = Permute(p2t, kx, ky, kz);
+    auto rot = [kz](V3 v) { return kz == 0 ? V3{v.y, v.z, v.x} : (kz == 1 ? V3{v.z, v.x, v.y} : v); };
+    V3 d = rot(rd);
+    p0t = rot(p0t);
+    p1t = rot(p1t);
+    p2t = rot(p2t);
     float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1 / d.z;
     p0t.x += Sx * p0t.z;
     p0t.y += Sy * p0t.z;

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../common/wf_kernels.h"
+#include "wf_traverse.h"
 
 using namespace wf;
 
@@ -53,11 +54,14 @@ struct wf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
-    SceneView svHost{};          // device pointers inside
-    SceneView *svDev = nullptr;
+    SceneView svHost{};          // device pointers inside; passed to every kernel by value (kernarg)
     WorkState ws{};
     int maxQueueSize = 0;
     int *stackSpill = nullptr;   // [STACK_MAX-STACK_LDS][MAX_GRID*BLOCK]
+    FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
+    bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
+    int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels
+    int32_t *probeCursor = nullptr;
     bool matPresent[WF_MAT_NTYPES] = {};
     int W = 0, H = 0;
     int maxDepth = 5;
@@ -93,40 +97,43 @@ static int devUpload(wf_ctx *c, const T **p, const T *src, size_t n) {
 // ---------------------------------------------------------------------------------------------
 // kernels
 __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, int statSlot, int statCounter) {
-    // mask bit i: zero counters[i].  statSlot >= 0: stats[statSlot] += counters[statCounter] first.
+    // mask bit i: zero counters[(i) * CNT_STRIDE].  statSlot >= 0: stats[statSlot] += counters[(statCounter) * CNT_STRIDE] first.
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (statSlot >= 0) ws.stats[statSlot] += (unsigned long long)ws.counters[statCounter];
+        if (statSlot >= 0) ws.stats[statSlot] += (unsigned long long)ws.counters[(statCounter) * CNT_STRIDE];
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) ws.counters[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) ws.counters[(threadIdx.x) * CNT_STRIDE] = 0;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView *svp, WorkState ws, int y0, int sampleIndex) {
-    const SceneView &sv = *svp;
+__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleIndex) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0);
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
         KGenerateCameraRay(sv, ws, i, y0, sampleIndex);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView *svp, WorkState ws, int cur, int sampleIndex) {
-    const SceneView &sv = *svp;
-    const int n = ws.counters[CNT_RAY0 + cur];
+__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleIndex) {
+    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleIndex);
 }
 
-// LDS short stack with HBM spill (one column per lane)
+// LDS short stack with HBM spill: one column per lane ([entry][lane] so a wave's same-depth accesses hit
+// 64 consecutive banks).  The array lives at file scope so every access is a ds_read/ds_write (LDS address
+// space), never a flat access.
+__shared__ int g_sstack[STACK_LDS * BLOCK];
 struct LdsStack {
-    int *lds;     // &sstack[threadIdx.x], stride BLOCK
     int *spill;   // &stackSpill[global thread], stride = total threads
     int spillStride;
     int n;
     __device__ void push(int v) {
-        if (n < STACK_LDS) lds[n * BLOCK] = v;
+        if (n < STACK_LDS) g_sstack[n * BLOCK + threadIdx.x] = v;
         else spill[(size_t)(n - STACK_LDS) * spillStride] = v;
         ++n;
     }
     __device__ int pop() {
         --n;
-        return n < STACK_LDS ? lds[n * BLOCK] : spill[(size_t)(n - STACK_LDS) * spillStride];
+        int v = g_sstack[(n < STACK_LDS ? n : 0) * BLOCK + threadIdx.x];  // always a ds_read
+        if (__builtin_expect(n >= STACK_LDS, 0)) v = spill[(size_t)(n - STACK_LDS) * spillStride];
+        return v;
     }
     __device__ bool empty() const { return n == 0; }
 };
@@ -137,12 +144,10 @@ __device__ inline unsigned long long waveSum(unsigned long long v) {
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView *svp, WorkState ws, int cur, int *stackSpill) {
-    __shared__ int sstack[STACK_LDS * BLOCK];
-    const SceneView &sv = *svp;
-    const int n = ws.counters[CNT_RAY0 + cur];
+__global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv, WorkState ws, int cur, int *stackSpill) {
+    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    LdsStack st{stackSpill + gtid, stride, 0};
     unsigned long long nv = 0, nt = 0, nh = 0, nr = 0;
     for (int i = gtid; i < n; i += stride) {
         F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
@@ -161,12 +166,10 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView *sv
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView *svp, WorkState ws, int *stackSpill) {
-    __shared__ int sstack[STACK_LDS * BLOCK];
-    const SceneView &sv = *svp;
-    const int n = ws.counters[CNT_SHADOW];
+__global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, WorkState ws, int *stackSpill) {
+    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    LdsStack st{stackSpill + gtid, stride, 0};
     unsigned long long nv = 0, nt = 0, nu = 0, nr = 0;
     for (int i = gtid; i < n; i += stride) {
         F4 o = ws.sq.o[i], d = ws.sq.d[i];
@@ -184,33 +187,163 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView *svp
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView *svp, WorkState ws, int cur) {
-    const SceneView &sv = *svp;
-    const int n = ws.counters[CNT_ESCAPED];
+// ---- production traversal: persistent waves over QNode/LeafTri with the tree top in LDS (wf_traverse.h) ----
+__shared__ int g_tstack[TSTACK * TBLOCK];
+__shared__ U4 g_top[2 * TOP_NODES];
+// the HBM spill path of the stack is out of line so that the compiler cannot merge it with the LDS path
+// into a pointer select (which turns every pop into a flat load)
+__device__ __attribute__((noinline)) int SpillRead(const int *p) { return *p; }
+__device__ __attribute__((noinline)) void SpillWrite(int *p, int v) { *p = v; }
+struct LdsStackT {
+    int *spill;   // &stackSpill[global thread], stride = total threads
+    int spillStride;
+    int n;
+    __device__ void push(int v) {
+        if (__builtin_expect(n < TSTACK, 1)) g_tstack[n * TBLOCK + threadIdx.x] = v;
+        else SpillWrite(&spill[(size_t)(n - TSTACK) * spillStride], v);
+        ++n;
+    }
+    __device__ int pop() {
+        --n;
+        int v = g_tstack[(n < TSTACK ? n : 0) * TBLOCK + threadIdx.x];  // always a ds_read
+        if (__builtin_expect(n >= TSTACK, 0)) v = SpillRead(&spill[(size_t)(n - TSTACK) * spillStride]);
+        return v;
+    }
+    __device__ bool empty() const { return n == 0; }
+};
+
+__device__ inline void LoadTreeTop(const FastBVH &bvh) {
+    const U4 *src = reinterpret_cast<const U4 *>(bvh.nodes);
+    const int n = 2 * (bvh.nNodes < TOP_NODES ? bvh.nNodes : TOP_NODES);
+    for (int i = threadIdx.x; i < n; i += TBLOCK) g_top[i] = src[i];
+    __syncthreads();
+}
+
+// One batch of TBLOCK rays per workgroup iteration: ray index = thread index within the batch (no cursor
+// atomic).  Waves walk independently ("while-while": all lanes descend interior nodes until every one of
+// them sits at a leaf or is done, then the leaves are processed together); `finish` runs once per batch for
+// the whole workgroup, so its queue pushes are block-aggregated (BlockAlloc).
+template <bool ANY, typename Fetch, typename Finish>
+__device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
+    LoadTreeTop(bvh);
+    for (int base = blockIdx.x * TBLOCK; base < n; base += gridDim.x * TBLOCK) {
+        const int idx = base + threadIdx.x;
+        const bool valid = idx < n;
+        RayWalk w;
+        w.node = NODE_NONE;
+        w.prim = -1;
+        w.b0 = w.b1 = w.b2 = 0;
+        if (valid) {
+            V3 o, d;
+            float tMax;
+            fetch(idx, &o, &d, &tMax);
+            WalkInit(w, o, d, tMax);
+            st.n = 0;
+        }
+        while (__any(w.node != NODE_NONE)) {
+            while (__any(w.node >= 0)) {
+                // tree top: nodes served from LDS (ds_read_b128) — kept in its own loop so the compiler never
+                // merges the two fetch paths into one flat load
+                while (__any((unsigned)w.node < (unsigned)TOP_NODES)) {
+                    if ((unsigned)w.node < (unsigned)TOP_NODES) {
+                        const U4 a = g_top[2 * w.node], b = g_top[2 * w.node + 1];
+                        InteriorStep(bvh, w, st, a, b);
+                    }
+                }
+                // below the cached levels: one global fetch (2 x dwordx4) per visit
+                if (w.node >= TOP_NODES) {
+                    const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
+                    const U4 a = p[0], b = p[1];
+                    InteriorStep(bvh, w, st, a, b);
+                }
+            }
+            if (w.node != NODE_NONE) LeafStep<ANY>(bvh, w, st);
+        }
+        finish(idx, valid, w);
+    }
+}
+
+__global__ void __launch_bounds__(TBLOCK) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
+    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    const RayQueueV q = ws.rq[cur];
+    BatchTrace<false>(
+        bvh, n, st,
+        [&](int i, V3 *o, V3 *d, float *tMax) {
+            F4 o4 = q.o[i], d4 = q.d[i];
+            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
+        },
+        [&](int i, bool valid, const RayWalk &w) { KAfterClosestHitBlock(sv, ws, cur, i, valid, w.prim, w.b0, w.b1, w.b2); });
+}
+__global__ void __launch_bounds__(TBLOCK) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    BatchTrace<true>(
+        bvh, n, st,
+        [&](int i, V3 *o, V3 *d, float *tMax) {
+            F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
+            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
+        },
+        [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
+}
+__global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    BatchTrace<false>(
+        bvh, n, st,
+        [&](int i, V3 *o, V3 *d, float *tMax) {
+            const float *r = rays + (size_t)7 * i;
+            *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
+        },
+        [&](int i, bool valid, const RayWalk &w) {
+            if (!valid) return;
+            wf_hit_record h;
+            bool found = w.prim >= 0;
+            h.prim = w.prim;
+            h.t = found ? w.tMax : 0; h.b0 = w.b0; h.b1 = w.b1; h.b2 = w.b2;
+            h.nodes_visited = 0; h.tris_tested = 0; h.pad = 0;
+            out[i] = h;
+        });
+}
+__global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    BatchTrace<true>(
+        bvh, n, st,
+        [&](int i, V3 *o, V3 *d, float *tMax) {
+            const float *r = rays + (size_t)7 * i;
+            *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
+        },
+        [&](int i, bool valid, const RayWalk &w) { if (valid) occluded[i] = w.prim >= 0; });
+}
+
+__global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_ESCAPED) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEscaped(sv, ws, cur, i);
 }
-__global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView *svp, WorkState ws, int cur) {
-    const SceneView &sv = *svp;
-    const int n = ws.counters[CNT_HITLIGHT];
+__global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_HITLIGHT) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEmissive(sv, ws, cur, i);
 }
 template <int MAT>
-__global__ void __launch_bounds__(BLOCK) k_eval_material(const SceneView *svp, WorkState ws, int cur) {
-    const SceneView &sv = *svp;
-    const int n = ws.counters[CNT_MAT0 + MAT];
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KEvalMaterial<MAT>(sv, ws, cur, i);
+__global__ void __launch_bounds__(BLOCK) k_eval_material(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE];
+    // block-uniform trip count: BlockAlloc inside the body synchronises the workgroup
+    for (int base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
+        const int i = base + threadIdx.x;
+        KEvalMaterial<MAT>(sv, ws, cur, i, i < n);
+    }
 }
-__global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView *svp, WorkState ws) {
-    const SceneView &sv = *svp;
+__global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK) KUpdateFilm(sv, ws, i);
 }
 
 // stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
-__global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView *svp, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
-    __shared__ int sstack[STACK_LDS * BLOCK];
-    const SceneView &sv = *svp;
+__global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride) {
         const float *r = rays + (size_t)7 * i;
         ClosestHit ch;
@@ -223,11 +356,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView *svp, i
         out[i] = h;
     }
 }
-__global__ void __launch_bounds__(BLOCK) k_trace_any(const SceneView *svp, int n, const float *rays, int32_t *occluded, int32_t *nodes, int32_t *tris, int *stackSpill) {
-    __shared__ int sstack[STACK_LDS * BLOCK];
-    const SceneView &sv = *svp;
+__global__ void __launch_bounds__(BLOCK) k_trace_any(const SceneView sv, int n, const float *rays, int32_t *occluded, int32_t *nodes, int32_t *tris, int *stackSpill) {
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
-    LdsStack st{&sstack[threadIdx.x], stackSpill + gtid, stride, 0};
+    LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride) {
         const float *r = rays + (size_t)7 * i;
         int v = 0, t = 0;
@@ -238,8 +369,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_any(const SceneView *svp, int n
         if (tris) tris[i] = t;
     }
 }
-__global__ void __launch_bounds__(BLOCK) k_sampler_probe(const SceneView *svp, int n, const int32_t *px, const int32_t *py, const int32_t *si, int startDim, int ndims, float *out) {
-    const SceneView &sv = *svp;
+__global__ void __launch_bounds__(BLOCK) k_sampler_probe(const SceneView sv, int n, const int32_t *px, const int32_t *py, const int32_t *si, int startDim, int ndims, float *out) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         ZSobol s(sv);
         s.StartPixelSample(px[i], py[i], si[i], startDim);
@@ -284,11 +414,107 @@ struct Prof {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, __VA_ARGS__);  \
     } while (0)
 
+#define LAUNCHT(name, kernel, grid, ...)                                                   \
+    do {                                                                                   \
+        Prof prof_(ctx, name);                                                             \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(TBLOCK), 0, ctx->stream, __VA_ARGS__); \
+    } while (0)
+
 static int checkReady(wf_ctx *ctx) {
     if (!ctx) return fail(-1, "null context");
     if (!ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     if (!ctx->queuesAllocated) return fail(-1, "queues not allocated (wf_queues_alloc)");
     return 0;
+}
+
+// Reference LinearBVHNode array (depth-first: left child = i + 1, right child = offset) -> QNode (breadth-first
+// numbering, quantised child boxes) + LeafTri (vertices in leaf order).  See wf_traverse.h.
+static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, FastBVH *out) {
+    const wf_bvh_node *L = d->bvh_nodes;
+    const int n = d->n_bvh_nodes;
+    if (n == 0 || (size_t)d->n_triangles >= (1u << 27)) return false;
+    for (int i = 0; i < n; ++i)
+        if (L[i].nprims > 16) return false;
+    tris->resize((size_t)d->n_triangles);
+    for (int k = 0; k < d->n_triangles; ++k) {
+        int t = d->bvh_prims[k];
+        const int32_t *v = d->tri_indices + 3 * (size_t)t;
+        const float *p0 = d->P + 3 * (size_t)v[0], *p1 = d->P + 3 * (size_t)v[1], *p2 = d->P + 3 * (size_t)v[2];
+        LeafTri lt;
+        lt.a = F4{p0[0], p0[1], p0[2], p1[0]};
+        lt.b = F4{p1[1], p1[2], p2[0], p2[1]};
+        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), 0.f, 0.f};
+        (*tris)[k] = lt;
+    }
+    // quantisation grid over the root bounds; cell rounded up so that 65535 cells cover the extent
+    for (int a = 0; a < 3; ++a) {
+        out->base[a] = L[0].bmin[a];
+        double ext = (double)L[0].bmax[a] - (double)L[0].bmin[a];
+        float cell = (float)(ext / 65535.0);
+        if (!(cell > 0)) cell = 1e-30f;
+        cell = NextFloatUp(NextFloatUp(cell));
+        out->cell[a] = cell;
+    }
+    auto deq = [&](int q, int a) { return ::fmaf((float)q, out->cell[a], out->base[a]); };  // == the device's dequantisation
+    auto qlo = [&](float v, int a) {
+        int q = (int)std::floor(((double)v - out->base[a]) / out->cell[a]);
+        q = std::min(std::max(q, 0), 65535);
+        while (q > 0 && deq(q, a) > v) --q;
+        return (uint32_t)q;
+    };
+    auto qhi = [&](float v, int a) {
+        int q = (int)std::ceil(((double)v - out->base[a]) / out->cell[a]);
+        q = std::min(std::max(q, 0), 65535);
+        while (q < 65535 && deq(q, a) < v) ++q;
+        return (uint32_t)q;
+    };
+    // conservative check at the grid's end (cell was rounded up twice)
+    for (int a = 0; a < 3; ++a)
+        if (deq(65535, a) < L[0].bmax[a]) return false;
+    auto leafRef = [&](int i) { return (int)~(((unsigned)L[i].offset << 4) | (unsigned)(L[i].nprims - 1)); };
+    // breadth-first numbering of the interior nodes
+    std::vector<int> order;  // BFS list of linear indices of interior nodes
+    std::vector<int> bfsIndex(n, -1);
+    if (L[0].nprims == 0) {
+        order.push_back(0);
+        bfsIndex[0] = 0;
+        for (size_t h = 0; h < order.size(); ++h) {
+            int i = order[h];
+            for (int c : {i + 1, (int)L[i].offset})
+                if (L[c].nprims == 0) { bfsIndex[c] = (int)order.size(); order.push_back(c); }
+        }
+    }
+    auto packBox = [&](const wf_bvh_node &b, uint32_t q[6], int slot) {
+        uint32_t v[6] = {qlo(b.bmin[0], 0), qlo(b.bmin[1], 1), qlo(b.bmin[2], 2), qhi(b.bmax[0], 0), qhi(b.bmax[1], 1), qhi(b.bmax[2], 2)};
+        for (int k = 0; k < 6; ++k) {
+            int e = slot * 6 + k;  // element index among the 12 u16
+            if (e & 1) q[e >> 1] |= v[k] << 16;
+            else q[e >> 1] |= v[k];
+        }
+    };
+    if (order.empty()) {
+        // the whole scene is one leaf: a root node whose left child is that leaf and whose right child is absent
+        QNode qn{};
+        packBox(L[0], qn.q, 0);
+        packBox(L[0], qn.q, 1);
+        qn.left = leafRef(0);
+        qn.right = NODE_NONE;
+        nodes->assign(1, qn);
+    } else {
+        nodes->resize(order.size());
+        for (size_t h = 0; h < order.size(); ++h) {
+            int i = order[h];
+            int l = i + 1, r = L[i].offset;
+            QNode qn{};
+            packBox(L[l], qn.q, 0);
+            packBox(L[r], qn.q, 1);
+            qn.left = L[l].nprims == 0 ? bfsIndex[l] : leafRef(l);
+            qn.right = L[r].nprims == 0 ? bfsIndex[r] : leafRef(r);
+            (*nodes)[h] = qn;
+        }
+    }
+    out->nNodes = (int)nodes->size();
+    return true;
 }
 
 extern "C" {
@@ -374,24 +600,44 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.haveMedia = d->have_media;
     sv.options = d->options;
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ctx->matPresent[m] = false;
+    sv.matTypeMask = 0;
     for (int i = 0; i < d->n_materials; ++i) {
         int t = d->materials[i].type;
         if (t < 0 || t >= WF_MAT_NTYPES) return fail(-1, "material %d has unknown type %d", i, t);
         if (t == WF_MAT_COATED_DIFFUSE || t == WF_MAT_COATED_CONDUCTOR)
             return fail(-1, "material %d: layered (coated*) materials are not implemented by the HIP kernels yet", i);
         ctx->matPresent[t] = true;
+        sv.matTypeMask |= 1 << t;
     }
-    if ((e = devAlloc(ctx, &ctx->svDev, 1))) return e;
-    HIPCHK(hipMemcpyAsync(ctx->svDev, &sv, sizeof(SceneView), hipMemcpyHostToDevice, ctx->stream));
     ctx->W = d->film.pixel_max[0] - d->film.pixel_min[0];
     ctx->H = d->film.pixel_max[1] - d->film.pixel_min[1];
     ctx->maxDepth = d->max_depth;
     for (int i = 0; i < 6; ++i) ctx->sceneBounds[i] = d->scene_bounds[i];
     if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)(STACK_MAX - STACK_LDS) * MAX_GRID * BLOCK))) return e;
+    {
+        std::vector<QNode> qn;
+        std::vector<LeafTri> lt;
+        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &ctx->fast);
+        if (ctx->fastOk) {
+            if ((e = devUpload(ctx, &ctx->fast.nodes, qn.data(), qn.size()))) return e;
+            if ((e = devUpload(ctx, &ctx->fast.tris, lt.data(), lt.size()))) return e;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        int perCU = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_closest_fast, TBLOCK, 0));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+        int g = std::max(1, perCU) * prop.multiProcessorCount;
+        if (const char *m = getenv("WF_PGRID_MULT")) g = (int)(g * atof(m));
+        const int maxG = MAX_GRID * BLOCK / TBLOCK;  // stackSpill is sized for MAX_GRID * BLOCK threads
+        ctx->persistentGrid = g > maxG ? maxG : (g < 1 ? 1 : g);
+        if (getenv("WF_NO_FAST")) ctx->fastOk = false;
+        if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
+    }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)129))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.trav, (size_t)8))) return e;
-    if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT))) return e;
+    if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT * CNT_STRIDE))) return e;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sv / sobol live on the host stack
     ctx->sceneLoaded = true;
     return 0;
@@ -453,7 +699,7 @@ int wf_reset_ray_queue(wf_ctx *ctx, int which) {
 int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     const int cur = depth & 1;
-    unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
+    unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT) | (1u << CNT_NEXT_CLOSEST);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + depth, CNT_RAY0 + cur);
@@ -461,43 +707,47 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
 }
 int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, y0, sample_index);
+    LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index);
     LAUNCH("Update camera ray stats", k_reset, 1, ctx->ws, 0u, 0, CNT_RAY0);
     return 0;
 }
 int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1, sample_index);
+    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, sample_index);
     return 0;
 }
 int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
+    // counting on: the reference-order walk (its visit counts define the algorithmic bytes);
+    // otherwise the production traversal (wf_traverse.h)
     if (ctx->countTraversal)
-        LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1, ctx->stackSpill);
+        LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
+    else if (ctx->fastOk)
+        LAUNCHT("Intersect closest", k_closest_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
     else
-        LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1, ctx->stackSpill);
+        LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     return 0;
 }
 int wf_handle_escaped(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->svHost.nInfiniteLights == 0) return 0;  // escapedRayQueue == nullptr (integrator.cpp:496-497)
-    LAUNCH("Handle escaped rays", k_handle_escaped, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1);
+    LAUNCH("Handle escaped rays", k_handle_escaped, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
 }
 int wf_handle_emissive(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Handle emitters hit by indirect rays", k_handle_emissive, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, depth & 1);
+    LAUNCH("Handle emitters hit by indirect rays", k_handle_emissive, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
 }
 int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     if (int e = checkReady(ctx)) return e;
     const int g = gridFor(ctx->maxQueueSize), cur = depth & 1;
     switch (material_type) {
-    case WF_MAT_DIFFUSE: LAUNCH("DiffuseMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE>, g, ctx->svDev, ctx->ws, cur); break;
-    case WF_MAT_CONDUCTOR: LAUNCH("ConductorMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_CONDUCTOR>, g, ctx->svDev, ctx->ws, cur); break;
-    case WF_MAT_DIELECTRIC: LAUNCH("DielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIELECTRIC>, g, ctx->svDev, ctx->ws, cur); break;
-    case WF_MAT_THIN_DIELECTRIC: LAUNCH("ThinDielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_THIN_DIELECTRIC>, g, ctx->svDev, ctx->ws, cur); break;
-    case WF_MAT_DIFFUSE_TRANSMISSION: LAUNCH("DiffuseTransmissionMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE_TRANSMISSION>, g, ctx->svDev, ctx->ws, cur); break;
+    case WF_MAT_DIFFUSE: LAUNCH("DiffuseMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE>, g, ctx->svHost, ctx->ws, cur); break;
+    case WF_MAT_CONDUCTOR: LAUNCH("ConductorMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_CONDUCTOR>, g, ctx->svHost, ctx->ws, cur); break;
+    case WF_MAT_DIELECTRIC: LAUNCH("DielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIELECTRIC>, g, ctx->svHost, ctx->ws, cur); break;
+    case WF_MAT_THIN_DIELECTRIC: LAUNCH("ThinDielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_THIN_DIELECTRIC>, g, ctx->svHost, ctx->ws, cur); break;
+    case WF_MAT_DIFFUSE_TRANSMISSION: LAUNCH("DiffuseTransmissionMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE_TRANSMISSION>, g, ctx->svHost, ctx->ws, cur); break;
     case WF_MAT_INTERFACE: break;
     default: return fail(-1, "material type %d has no HIP kernel", material_type);
     }
@@ -506,16 +756,18 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
 int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->countTraversal)
-        LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, ctx->stackSpill);
+        LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    else if (ctx->fastOk)
+        LAUNCHT("Intersect shadow", k_shadow_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
-        LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws, ctx->stackSpill);
+        LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
-    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, 1u << CNT_SHADOW, 65 + depth, CNT_SHADOW);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW) | (1u << CNT_NEXT_SHADOW), 65 + depth, CNT_SHADOW);
     return 0;
 }
 int wf_update_film(wf_ctx *ctx) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Update film", k_update_film, gridFor(ctx->maxQueueSize), ctx->svDev, ctx->ws);
+    LAUNCH("Update film", k_update_film, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws);
     return 0;
 }
 
@@ -655,7 +907,6 @@ int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out) {
 
 int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, wf_hit_record *out, int count_visits) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
-    (void)count_visits;
     if (n <= 0) return 0;
     std::vector<float> rays((size_t)n * 7);
     for (int i = 0; i < n; ++i) {
@@ -667,7 +918,11 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     HIPCHK(hipMalloc((void **)&dr, rays.size() * sizeof(float)));
     HIPCHK(hipMalloc((void **)&dh, (size_t)n * sizeof(wf_hit_record)));
     HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svDev, n, dr, dh, ctx->stackSpill);
+    if (count_visits || !ctx->fastOk) {
+        LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill);
+    } else {
+        LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
+    }
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(dr));
@@ -687,7 +942,11 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     HIPCHK(hipMalloc((void **)&dr, rays.size() * sizeof(float)));
     HIPCHK(hipMalloc((void **)&dres, (size_t)3 * n * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svDev, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
+    if (nodes_visited || tris_tested || !ctx->fastOk) {
+        LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svHost, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
+    } else {
+        LAUNCHT("trace any fast (host rays)", k_trace_any_fast, ctx->persistentGrid, ctx->fast, n, dr, dres, ctx->stackSpill);
+    }
     HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (tris_tested) HIPCHK(hipMemcpyAsync(tris_tested, dres + 2 * (size_t)n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -706,7 +965,7 @@ int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, c
     HIPCHK(hipMemcpyAsync(din, px, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(din + n, py, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(din + 2 * (size_t)n, sample_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    LAUNCH("sampler probe", k_sampler_probe, gridFor(n), ctx->svDev, n, din, din + n, din + 2 * (size_t)n, start_dim, ndims, dout);
+    LAUNCH("sampler probe", k_sampler_probe, gridFor(n), ctx->svHost, n, din, din + n, din + 2 * (size_t)n, start_dim, ndims, dout);
     HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * ndims * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(din));
@@ -723,7 +982,7 @@ int wf_queue_size(wf_ctx *ctx, const char *queue, int *size) {
                                                    {"mat_diffusetransmission", CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION}};
     auto it = idx.find(queue ? queue : "");
     if (it == idx.end()) return fail(-1, "unknown queue \"%s\"", queue ? queue : "(null)");
-    HIPCHK(hipMemcpyAsync(size, ctx->ws.counters + it->second, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(size, ctx->ws.counters + it->second * CNT_STRIDE, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -116,6 +116,7 @@ def libs():
     _hip.wf_trace_any_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _hip.wf_sampler_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _hip.wf_kernel_time_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    _hip.wf_aggregate_bounds.argtypes = [C.c_void_p, C.c_void_p]
     _hip.wf_render_pass.argtypes = [C.c_void_p, C.c_int, C.c_int]
     if _host.wfh_init(DATA.encode()) != 0:
         raise WfError("wfh_init failed (data dir %s)" % DATA)
@@ -210,18 +211,27 @@ class Scene:
         return st["camera_rays"] + sum(st["indirect_rays"][1:]) + sum(st["shadow_rays"])
 
     # ---- direct C-ABI access used by the parity tests and bench.py ----
-    def trace_closest(self, o, d, tmax):
+    def trace_closest(self, o, d, tmax, reference_order=True):
+        """reference_order=True: the reference-order walk (fills nodes_visited / tris_tested);
+        False: the production traversal kernel (wf_traverse.h)"""
         _, hip = libs()
         o = np.ascontiguousarray(o, dtype=np.float32)
         d = np.ascontiguousarray(d, dtype=np.float32)
         tmax = np.ascontiguousarray(tmax, dtype=np.float32)
         n = o.shape[0]
         out = (HitRecord * n)()
-        _check(hip.wf_trace_closest_host(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, out, 1), "wf_trace_closest_host")
+        _check(hip.wf_trace_closest_host(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, out, 1 if reference_order else 0), "wf_trace_closest_host")
         return np.frombuffer(out, dtype=np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
                                                   ("nodes_visited", "<i4"), ("tris_tested", "<i4"), ("pad", "<i4")])).copy()
 
-    def trace_any(self, o, d, tmax):
+    def bounds(self):
+        """WavefrontAggregate::Bounds() in rendering space: (pMin[3], pMax[3])"""
+        _, hip = libs()
+        b = (C.c_float * 6)()
+        _check(hip.wf_aggregate_bounds(self.ctx, b), "wf_aggregate_bounds")
+        return np.array(b[:3], dtype=np.float32), np.array(b[3:], dtype=np.float32)
+
+    def trace_any(self, o, d, tmax, reference_order=True):
         _, hip = libs()
         o = np.ascontiguousarray(o, dtype=np.float32)
         d = np.ascontiguousarray(d, dtype=np.float32)
@@ -230,7 +240,8 @@ class Scene:
         occ = np.empty(n, dtype=np.int32)
         nodes = np.empty(n, dtype=np.int32)
         tris = np.empty(n, dtype=np.int32)
-        _check(hip.wf_trace_any_host(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data, nodes.ctypes.data, tris.ctypes.data),
+        _check(hip.wf_trace_any_host(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, occ.ctypes.data,
+                                     nodes.ctypes.data if reference_order else None, tris.ctypes.data if reference_order else None),
                "wf_trace_any_host")
         return occ, nodes, tris
 
