@@ -7,6 +7,7 @@
 #include <pbrt/pbrt.h>
 
 #include <pbrt/bxdfs.h>
+#include <pbrt/options.h>
 #include <pbrt/samplers.h>
 #include <pbrt/shapes.h>
 #include <pbrt/util/math.h>
@@ -39,6 +40,7 @@ struct Lcg {  // input generator shared with nothing: inputs are stored, not reg
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: ref_probe <outdir>\n"); return 1; }
     std::string dir = argv[1];
+    Options = new PBRTOptions;  // GetOptions().seed == 0 (LayeredBxDF seeds its RNG from it, bxdfs.h:510)
 
     // ---- zsobol: in {px, py, sampleIndex} int32; out 12 floats: Get1D x 12 from dimension 0
     //      sampler = ZSobolSampler(16 spp, 400x400, FastOwen, seed 0)  (scenes/cornell-box.pbrt)
@@ -128,15 +130,16 @@ int main(int argc, char **argv) {
         writeBin(dir + "/sphtri_out.bin", out.data(), out.size() * 4);
     }
     // ---- bxdfs: in {type, wo[3], wi[3], uc, u[2], eta, ax, ay, k} 13 floats (type 0 diffuse R=0.5, 1 dielectric,
-    //      2 conductor eta=(eta,..) k=(k,..), 3 thin dielectric, 4 diffuse transmission R=.25 T=.5)
+    //      2 conductor eta=(eta,..) k=(k,..), 3 thin dielectric, 4 diffuse transmission R=.25 T=.5, 5 coated diffuse,
+//      6 coated conductor; GetOptions().seed == 0)
     //      out {f[4](wo,wi), pdf(wo,wi), sample valid, sample f[4], sample wi[3], sample pdf, flags, eta} 16 floats
     {
-        const int n = 6000;
+        const int n = 7000;
         Lcg g(5);
         std::vector<float> in((size_t)n * 13), out((size_t)n * 16);
         for (int i = 0; i < n; ++i) {
             float *r = &in[(size_t)i * 13];
-            int type = i % 5;
+            int type = i % 7;
             Vector3f wo = Normalize(Vector3f(g.range(-1, 1), g.range(-1, 1), g.range(-1, 1)));
             Vector3f wi = Normalize(Vector3f(g.range(-1, 1), g.range(-1, 1), g.range(-1, 1)));
             float uc = g.f01();
@@ -168,8 +171,17 @@ int main(int argc, char **argv) {
                 ThinDielectricBxDF b(eta);
                 f = b.f(wo, wi, TransportMode::Radiance); pdf = b.PDF(wo, wi, TransportMode::Radiance, BxDFReflTransFlags::All);
                 bs = b.Sample_f(wo, uc, u, TransportMode::Radiance, BxDFReflTransFlags::All);
-            } else {
+            } else if (type == 4) {
                 DiffuseTransmissionBxDF b(SampledSpectrum(0.25f), SampledSpectrum(0.5f));
+                f = b.f(wo, wi, TransportMode::Radiance); pdf = b.PDF(wo, wi, TransportMode::Radiance); bs = b.Sample_f(wo, uc, u, TransportMode::Radiance);
+            } else if (type == 5) {
+                // coated diffuse: thickness 0.01, albedo 0 or 0.3 (every other record), g = 0.2, maxDepth 10, nSamples 1 or 2
+                CoatedDiffuseBxDF b(DielectricBxDF(eta, distrib), DiffuseBxDF(SampledSpectrum(0.5f)), 0.01f,
+                                    SampledSpectrum((i / 7) % 2 ? 0.3f : 0.f), 0.2f, 10, 1 + (i / 14) % 2);
+                f = b.f(wo, wi, TransportMode::Radiance); pdf = b.PDF(wo, wi, TransportMode::Radiance); bs = b.Sample_f(wo, uc, u, TransportMode::Radiance);
+            } else {
+                CoatedConductorBxDF b(DielectricBxDF(eta, distrib), ConductorBxDF(TrowbridgeReitzDistribution(ay, ax), SampledSpectrum(eta), SampledSpectrum(kk)),
+                                      0.01f, SampledSpectrum((i / 7) % 2 ? 0.3f : 0.f), 0.2f, 10, 1 + (i / 14) % 2);
                 f = b.f(wo, wi, TransportMode::Radiance); pdf = b.PDF(wo, wi, TransportMode::Radiance); bs = b.Sample_f(wo, uc, u, TransportMode::Radiance);
             }
             for (int c = 0; c < 4; ++c) w[c] = f[c];
@@ -179,7 +191,7 @@ int main(int argc, char **argv) {
             w[10] = bs ? bs->wi.x : 0; w[11] = bs ? bs->wi.y : 0; w[12] = bs ? bs->wi.z : 0;
             w[13] = bs ? bs->pdf : 0;
             w[14] = bs ? (float)(int)bs->flags : 0;
-            w[15] = bs ? bs->eta : 0;
+            w[15] = bs ? (bs->eta + (bs->pdfIsProportional ? 100.f : 0.f)) : 0;
         }
         writeBin(dir + "/bxdf_in.bin", in.data(), in.size() * 4);
         writeBin(dir + "/bxdf_out.bin", out.data(), out.size() * 4);

@@ -73,7 +73,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
 
 int main(int argc, char **argv) {
     RenderOptions opt;
-    std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut;
+    std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
     int sampleBegin = 0, sampleEnd = -1, sampleStep = 1, probeStartDim = 0, probeNDims = 0;
     gThreads = std::max(1u, std::thread::hardware_concurrency());
     for (int i = 1; i < argc; ++i) {
@@ -87,6 +87,7 @@ int main(int argc, char **argv) {
         else if (a == "--datadir") dataDir = next();
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
+        else if (a == "--dump-stages") dumpStages = next();
         else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
         else if (a == "--sampler-probe") { probeIn = next(); probeOut = next(); probeStartDim = atoi(next().c_str()); probeNDims = atoi(next().c_str()); }
         else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
@@ -185,6 +186,16 @@ int main(int argc, char **argv) {
             ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0);
             ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex); });
             ws.stats[0] += ws.counters[(CNT_RAY0) * CNT_STRIDE];
+            const bool dumpNow = !dumpStages.empty() && sampleIndex == sampleBegin && y0 == F.pixel_min[1];
+            if (dumpNow) {
+                FILE *f = fopen((dumpStages + "/camera_rays.bin").c_str(), "wb");
+                for (int i = 0; i < ws.counters[(CNT_RAY0) * CNT_STRIDE]; ++i) {
+                    F4 o = ws.rq[0].o[i], d = ws.rq[0].d[i];
+                    float rec[8] = {(float)ws.rq[0].meta[i].x, o.x, o.y, o.z, d.x, d.y, d.z, o.w};
+                    fwrite(rec, 4, 8, f);
+                }
+                fclose(f);
+            }
             for (int depth = 0; true; ++depth) {
                 const int cur = depth & 1;
                 ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE] = 0;
@@ -203,6 +214,31 @@ int main(int argc, char **argv) {
                     KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.b0, ch.h.b1, ch.h.b2);
                 });
                 nodesVisited += nv; trisTested += nt;
+                if (dumpNow && depth == 0) {
+                    // same record as oracle/ref_build/ref_stages.cpp::dumpMat
+                    FILE *f = fopen((dumpStages + "/mat_items.bin").c_str(), "wb");
+                    for (int m = 1; m < WF_MAT_NTYPES; ++m)
+                        for (int k = 0; k < ws.counters[(CNT_MAT0 + m) * CNT_STRIDE]; ++k) {
+                            int i = ws.matQ[m][k];
+                            F4 h = ws.hit[i], d = ws.rq[cur].d[i];
+                            SurfIntr si;
+                            TriangleInteraction(sv, (int)FloatToBits(h.x), h.y, h.z, h.w, &si);
+                            V3 wo_ = Normalize(V3{-d.x, -d.y, -d.z});
+                            float rec[28] = {(float)m, (float)ws.rq[cur].meta[i].x, si.pi.lo.x, si.pi.lo.y, si.pi.lo.z, si.pi.hi.x, si.pi.hi.y, si.pi.hi.z,
+                                             si.n.x, si.n.y, si.n.z, si.ns.x, si.ns.y, si.ns.z, si.dpdus.x, si.dpdus.y, si.dpdus.z, wo_.x, wo_.y, wo_.z,
+                                             si.uv.x, si.uv.y, si.dpdu.x, si.dpdu.y, si.dpdu.z, si.dpdv.x, si.dpdv.y, si.dpdv.z};
+                            fwrite(rec, 4, 28, f);
+                        }
+                    fclose(f);
+                    f = fopen((dumpStages + "/samples.bin").c_str(), "wb");
+                    for (int i = 0; i < nRays; ++i) {
+                        int pi = ws.rq[cur].meta[i].x;
+                        F4 a = ws.samples0[pi], b = ws.samples1[pi];
+                        float rec[8] = {(float)pi, a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+                        fwrite(rec, 4, 8, f);
+                    }
+                    fclose(f);
+                }
                 ParallelFor(ws.counters[(CNT_ESCAPED) * CNT_STRIDE], [&](int i) { KHandleEscaped(sv, ws, cur, i); });
                 ParallelFor(ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
                 if (depth == maxDepth) break;
@@ -211,6 +247,8 @@ int main(int argc, char **argv) {
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIELECTRIC>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_THIN_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_THIN_DIELECTRIC>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_DIFFUSE>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_CONDUCTOR>(sv, ws, cur, i, true); });
                 const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
                 ParallelFor(nShadow, [&](int i) {
                     F4 o = ws.sq.o[i], d = ws.sq.d[i];

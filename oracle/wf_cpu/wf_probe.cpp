@@ -42,7 +42,7 @@ static void evalBxDF(const B &b, V3 wo, V3 wi, float uc, V2 u, float *w) {
     w[10] = bs.valid ? bs.wi.x : 0; w[11] = bs.valid ? bs.wi.y : 0; w[12] = bs.valid ? bs.wi.z : 0;
     w[13] = bs.valid ? bs.pdf : 0;
     w[14] = bs.valid ? (float)bs.flags : 0;
-    w[15] = bs.valid ? bs.eta : 0;
+    w[15] = bs.valid ? (bs.eta + (bs.pdfIsProportional ? 100.f : 0.f)) : 0;
 }
 
 int main(int argc, char **argv) {
@@ -120,7 +120,15 @@ int main(int argc, char **argv) {
             else if (type == 1) evalBxDF(DielectricBxDF{eta, distrib}, wo, wi, uc, u, w);
             else if (type == 2) evalBxDF(ConductorBxDF{distrib, S4c(eta), S4c(kk)}, wo, wi, uc, u, w);
             else if (type == 3) evalBxDF(ThinDielectricBxDF{eta}, wo, wi, uc, u, w);
-            else evalBxDF(DiffuseTransmissionBxDF{S4c(0.25f), S4c(0.5f)}, wo, wi, uc, u, w);
+            else if (type == 4) evalBxDF(DiffuseTransmissionBxDF{S4c(0.25f), S4c(0.5f)}, wo, wi, uc, u, w);
+            else if (type == 5)
+                evalBxDF(CoatedDiffuseBxDF{DielectricBxDF{eta, distrib}, DiffuseBxDF{S4c(0.5f)}, 0.01f, 0.2f, S4c((i / 7) % 2 ? 0.3f : 0.f), 10,
+                                           1 + (i / 14) % 2, 0},
+                         wo, wi, uc, u, w);
+            else
+                evalBxDF(CoatedConductorBxDF{DielectricBxDF{eta, distrib}, ConductorBxDF{TrowbridgeReitz(ay, ax), S4c(eta), S4c(kk)}, 0.01f, 0.2f,
+                                             S4c((i / 7) % 2 ? 0.3f : 0.f), 10, 1 + (i / 14) % 2, 0},
+                         wo, wi, uc, u, w);
         }
         writeBin(od + "/bxdf_out.bin", out.data(), out.size() * 4);
     }

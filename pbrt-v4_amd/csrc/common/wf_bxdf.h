@@ -420,6 +420,308 @@ struct ConductorBxDF {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Henyey-Greenstein phase function (util/scattering.h:48-58, util/sampling.cpp:348-374, media.h:43-70)
+WF_HD float ClampG(float g) {
+    // Clamp(g, -.99, .99) with double bounds (comparison in double, result converted back)
+    if ((double)g < -.99) return (float)-.99;
+    if ((double)g > .99) return (float).99;
+    return g;
+}
+WF_HD float HenyeyGreenstein(float cosTheta, float g) {
+    g = ClampG(g);
+    float denom = 1 + Sqr(g) + 2 * g * cosTheta;
+    return Inv4Pi * (1 - Sqr(g)) / (denom * SafeSqrt(denom));
+}
+WF_HD V3 SphericalDirection(float sinTheta, float cosTheta, float phi) {
+    return V3{Clamp(sinTheta, -1.f, 1.f) * cos(phi), Clamp(sinTheta, -1.f, 1.f) * sin(phi), Clamp(cosTheta, -1.f, 1.f)};
+}
+WF_HD V3 SampleHenyeyGreenstein(V3 wo, float g, V2 u, float *pdf) {
+    g = ClampG(g);
+    float cosTheta;
+    if (abs(g) < 1e-3f) cosTheta = 1 - 2 * u.x;
+    else cosTheta = -1 / (2 * g) * (1 + Sqr(g) - Sqr((1 - Sqr(g)) / (1 + g - 2 * g * u.x)));
+    float sinTheta = SafeSqrt(1 - Sqr(cosTheta));
+    float phi = 2 * Pi * u.y;
+    Frame wFrame = Frame::FromZ(wo);
+    V3 wi = wFrame.FromLocal(SphericalDirection(sinTheta, cosTheta, phi));
+    if (pdf) *pdf = HenyeyGreenstein(cosTheta, g);
+    return wi;
+}
+WF_HD float SampleExponential(float u, float a) { return -log(1 - u) / a; }
+WF_HD float PowerHeuristic(int nf, float fPdf, int ng, float gPdf) {
+    float f = nf * fPdf, g = ng * gPdf;
+    if (IsInf(Sqr(f))) return 1;
+    return Sqr(f) / (Sqr(f) + Sqr(g));
+}
+// Hash(int, Vector3f) / Hash(Vector3f) / Hash(Float, Point2f): util/hash.h:100-107 packs the arguments back to back
+WF_HD uint64_t HashIntV3(int a, V3 v) {
+    uint32_t w[4] = {(uint32_t)a, FloatToBits(v.x), FloatToBits(v.y), FloatToBits(v.z)};
+    return HashWords(w, 4);
+}
+WF_HD uint64_t HashF3(float a, V2 u) {
+    uint32_t w[3] = {FloatToBits(a), FloatToBits(u.x), FloatToBits(u.y)};
+    return HashWords(w, 3);
+}
+
+// LayeredBxDF<Top, Bottom, twoSided>, bxdfs.h:432-905
+template <typename TopBxDF, typename BottomBxDF, bool twoSided>
+struct LayeredBxDF {
+    TopBxDF top;
+    BottomBxDF bottom;
+    float thickness, g;
+    S4 albedo;
+    int maxDepth, nSamples;
+    int seed;  // GetOptions().seed
+
+    // TopOrBottomBxDF (bxdfs.h:386-429) as a flag
+    struct IF {
+        const LayeredBxDF *l;
+        bool isTop;
+        WF_HD S4 f(V3 wo, V3 wi, int mode) const { return isTop ? l->top.f(wo, wi, mode) : l->bottom.f(wo, wi, mode); }
+        WF_HD BSDFSample Sample_f(V3 wo, float uc, V2 u, int mode, int sampleFlags = REFLTRANS_ALL) const {
+            return isTop ? l->top.Sample_f(wo, uc, u, mode, sampleFlags) : l->bottom.Sample_f(wo, uc, u, mode, sampleFlags);
+        }
+        WF_HD float PDF(V3 wo, V3 wi, int mode, int sampleFlags = REFLTRANS_ALL) const {
+            return isTop ? l->top.PDF(wo, wi, mode, sampleFlags) : l->bottom.PDF(wo, wi, mode, sampleFlags);
+        }
+        WF_HD int Flags() const { return isTop ? l->top.Flags() : l->bottom.Flags(); }
+    };
+    WF_HD static bool Bad(const BSDFSample &b) { return !b.valid || !b.f || b.pdf == 0 || b.wi.z == 0; }
+    WF_HD static float Tr(float dz, V3 w) {
+        if (abs(dz) <= 1.17549435e-38f) return 1;  // numeric_limits<float>::min()
+        return FastExp(-abs(dz / w.z));
+    }
+    WF_HD void Regularize() { top.Regularize(); bottom.Regularize(); }
+    WF_HD int Flags() const {
+        int topFlags = top.Flags(), bottomFlags = bottom.Flags();
+        int flags = BXDF_REFLECTION;
+        if (IsSpecular(topFlags)) flags |= BXDF_SPECULAR;
+        if (IsDiffuse(topFlags) || IsDiffuse(bottomFlags) || albedo) flags |= BXDF_DIFFUSE;
+        else if (IsGlossy(topFlags) || IsGlossy(bottomFlags)) flags |= BXDF_GLOSSY;
+        if (IsTransmissive(topFlags) && IsTransmissive(bottomFlags)) flags |= BXDF_TRANSMISSION;
+        return flags;
+    }
+    WF_HD S4 f(V3 wo, V3 wi, int mode) const {
+        S4 f = S4c(0.f);
+        if (twoSided && wo.z < 0) { wo = -wo; wi = -wi; }
+        bool enteredTop = twoSided || wo.z > 0;
+        IF enterInterface{this, enteredTop};
+        bool exitIsBottom = SameHemisphere(wo, wi) ^ enteredTop;
+        IF exitInterface{this, !exitIsBottom}, nonExitInterface{this, exitIsBottom};
+        float exitZ = exitIsBottom ? 0 : thickness;
+        if (SameHemisphere(wo, wi)) f = nSamples * enterInterface.f(wo, wi, mode);
+        RNG rng(HashIntV3(seed, wo), Hash3f(wi));
+        auto r = [&rng]() { return fmin(rng.UniformFloat(), OneMinusEpsilon); };
+        for (int s = 0; s < nSamples; ++s) {
+            // NOTE on sample order: the reference writes Point2f(r(), r()) / f(x, r(), {r(), r()}) — function
+            // arguments, whose evaluation order C++ leaves unspecified.  The oracle is the reference as g++
+            // compiles it: arguments right to left (braced lists left to right inside).  Restated explicitly.
+            float uc = r();
+            float uy = r(), ux = r();
+            BSDFSample wos = enterInterface.Sample_f(wo, uc, V2{ux, uy}, mode, REFLTRANS_TRANSMISSION);
+            if (Bad(wos)) continue;
+            uc = r();
+            uy = r(); ux = r();
+            BSDFSample wis = exitInterface.Sample_f(wi, uc, V2{ux, uy}, !mode, REFLTRANS_TRANSMISSION);
+            if (Bad(wis)) continue;
+            S4 beta = wos.f * AbsCosTheta(wos.wi) / wos.pdf;
+            float z = enteredTop ? thickness : 0;
+            V3 w = wos.wi;
+            for (int depth = 0; depth < maxDepth; ++depth) {
+                if (depth > 3 && beta.MaxComponentValue() < 0.25f) {
+                    float q = fmax(0.f, 1 - beta.MaxComponentValue());
+                    if (r() < q) break;
+                    beta = beta / (1 - q);
+                }
+                if (!albedo) {
+                    z = (z == thickness) ? 0 : thickness;
+                    beta = beta * Tr(thickness, w);
+                } else {
+                    float sigma_t = 1;
+                    float dz = SampleExponential(r(), sigma_t / abs(w.z));
+                    float zp = w.z > 0 ? (z + dz) : (z - dz);
+                    if (z == zp) continue;
+                    if (0 < zp && zp < thickness) {
+                        float wt = 1;
+                        if (!IsSpecular(exitInterface.Flags())) wt = PowerHeuristic(1, wis.pdf, 1, HenyeyGreenstein(Dot(-w, -wis.wi), g));
+                        f = f + beta * albedo * HenyeyGreenstein(Dot(-w, -wis.wi), g) * wt * Tr(zp - exitZ, wis.wi) * wis.f / wis.pdf;
+                        float u0 = r(), u1 = r();
+                        float ppdf;
+                        V3 pwi = SampleHenyeyGreenstein(-w, g, V2{u0, u1}, &ppdf);
+                        if (ppdf == 0 || pwi.z == 0) continue;
+                        beta = beta * (albedo * ppdf / ppdf);
+                        w = pwi;
+                        z = zp;
+                        if (((z < exitZ && w.z > 0) || (z > exitZ && w.z < 0)) && !IsSpecular(exitInterface.Flags())) {
+                            S4 fExit = exitInterface.f(-w, wi, mode);
+                            if (fExit) {
+                                float exitPDF = exitInterface.PDF(-w, wi, mode, REFLTRANS_TRANSMISSION);
+                                float wt2 = PowerHeuristic(1, ppdf, 1, exitPDF);
+                                f = f + beta * Tr(zp - exitZ, pwi) * fExit * wt2;
+                            }
+                        }
+                        continue;
+                    }
+                    z = Clamp(zp, 0.f, thickness);
+                }
+                if (z == exitZ) {
+                    float uc2 = r();
+                    float vy = r(), vx = r();
+                    BSDFSample bs = exitInterface.Sample_f(-w, uc2, V2{vx, vy}, mode, REFLTRANS_REFLECTION);
+                    if (Bad(bs)) break;
+                    beta = beta * (bs.f * AbsCosTheta(bs.wi) / bs.pdf);
+                    w = bs.wi;
+                } else {
+                    if (!IsSpecular(nonExitInterface.Flags())) {
+                        float wt = 1;
+                        if (!IsSpecular(exitInterface.Flags())) wt = PowerHeuristic(1, wis.pdf, 1, nonExitInterface.PDF(-w, -wis.wi, mode));
+                        f = f + beta * nonExitInterface.f(-w, -wis.wi, mode) * AbsCosTheta(wis.wi) * wt * Tr(thickness, wis.wi) * wis.f / wis.pdf;
+                    }
+                    float uc2 = r();
+                    float vy = r(), vx = r();
+                    BSDFSample bs = nonExitInterface.Sample_f(-w, uc2, V2{vx, vy}, mode, REFLTRANS_REFLECTION);
+                    if (Bad(bs)) break;
+                    beta = beta * (bs.f * AbsCosTheta(bs.wi) / bs.pdf);
+                    w = bs.wi;
+                    if (!IsSpecular(exitInterface.Flags())) {
+                        S4 fExit = exitInterface.f(-w, wi, mode);
+                        if (fExit) {
+                            float wt = 1;
+                            if (!IsSpecular(nonExitInterface.Flags())) {
+                                float exitPDF = exitInterface.PDF(-w, wi, mode, REFLTRANS_TRANSMISSION);
+                                wt = PowerHeuristic(1, bs.pdf, 1, exitPDF);
+                            }
+                            f = f + beta * Tr(thickness, bs.wi) * fExit * wt;
+                        }
+                    }
+                }
+            }
+        }
+        return f / (float)nSamples;
+    }
+    WF_HD BSDFSample Sample_f(V3 wo, float uc, V2 u, int mode, int sampleFlags = REFLTRANS_ALL) const {
+        bool flipWi = false;
+        if (twoSided && wo.z < 0) { wo = -wo; flipWi = true; }
+        bool enteredTop = twoSided || wo.z > 0;
+        BSDFSample bs = enteredTop ? top.Sample_f(wo, uc, u, mode) : bottom.Sample_f(wo, uc, u, mode);
+        if (Bad(bs)) return {};
+        if (bs.IsReflection()) {
+            if (flipWi) bs.wi = -bs.wi;
+            bs.pdfIsProportional = true;
+            return bs;
+        }
+        V3 w = bs.wi;
+        bool specularPath = bs.IsSpecularS();
+        RNG rng(HashIntV3(seed, wo), HashF3(uc, u));
+        auto r = [&rng]() { return fmin(rng.UniformFloat(), OneMinusEpsilon); };
+        S4 f = bs.f * AbsCosTheta(bs.wi);
+        float pdf = bs.pdf;
+        float z = enteredTop ? thickness : 0;
+        for (int depth = 0; depth < maxDepth; ++depth) {
+            float rrBeta = f.MaxComponentValue() / pdf;
+            if (depth > 3 && rrBeta < 0.25f) {
+                float q = fmax(0.f, 1 - rrBeta);
+                if (r() < q) return {};
+                pdf *= 1 - q;
+            }
+            if (w.z == 0) return {};
+            if (albedo) {
+                float sigma_t = 1;
+                float dz = SampleExponential(r(), sigma_t / AbsCosTheta(w));
+                float zp = w.z > 0 ? (z + dz) : (z - dz);
+                if (zp == z) return {};
+                if (0 < zp && zp < thickness) {
+                    float u1 = r(), u0 = r();
+                    float ppdf;
+                    V3 pwi = SampleHenyeyGreenstein(-w, g, V2{u0, u1}, &ppdf);
+                    if (ppdf == 0 || pwi.z == 0) return {};
+                    f = f * (albedo * ppdf);
+                    pdf *= ppdf;
+                    specularPath = false;
+                    w = pwi;
+                    z = zp;
+                    continue;
+                }
+                z = Clamp(zp, 0.f, thickness);
+            } else {
+                z = (z == thickness) ? 0 : thickness;
+                f = f * Tr(thickness, w);
+            }
+            IF interface{this, z != 0};
+            float uc2 = r();
+            float vy = r(), vx = r();
+            BSDFSample b2 = interface.Sample_f(-w, uc2, V2{vx, vy}, mode);
+            if (Bad(b2)) return {};
+            f = f * b2.f;
+            pdf *= b2.pdf;
+            specularPath &= b2.IsSpecularS();
+            w = b2.wi;
+            if (b2.IsTransmission()) {
+                int flags = SameHemisphere(wo, w) ? BXDF_REFLECTION : BXDF_TRANSMISSION;
+                flags |= specularPath ? BXDF_SPECULAR : BXDF_GLOSSY;
+                if (flipWi) w = -w;
+                return MakeSample(f, w, pdf, flags, 1.f, true);
+            }
+            f = f * AbsCosTheta(b2.wi);
+        }
+        return {};
+    }
+    WF_HD float PDF(V3 wo, V3 wi, int mode, int sampleFlags = REFLTRANS_ALL) const {
+        if (twoSided && wo.z < 0) { wo = -wo; wi = -wi; }
+        RNG rng(HashIntV3(seed, wi), Hash3f(wo));
+        auto r = [&rng]() { return fmin(rng.UniformFloat(), OneMinusEpsilon); };
+        bool enteredTop = twoSided || wo.z > 0;
+        float pdfSum = 0;
+        if (SameHemisphere(wo, wi)) {
+            pdfSum += enteredTop ? nSamples * top.PDF(wo, wi, mode, REFLTRANS_REFLECTION) : nSamples * bottom.PDF(wo, wi, mode, REFLTRANS_REFLECTION);
+        }
+        for (int s = 0; s < nSamples; ++s) {
+            if (SameHemisphere(wo, wi)) {
+                IF rInterface{this, !enteredTop}, tInterface{this, enteredTop};
+                float a1 = r(), a2 = r(), a0 = r();
+                BSDFSample wos = tInterface.Sample_f(wo, a0, V2{a1, a2}, mode, REFLTRANS_TRANSMISSION);
+                float b1 = r(), b2 = r(), b0 = r();
+                BSDFSample wis = tInterface.Sample_f(wi, b0, V2{b1, b2}, !mode, REFLTRANS_TRANSMISSION);
+                if (wos.valid && wos.f && wos.pdf > 0 && wis.valid && wis.f && wis.pdf > 0) {
+                    if (!IsNonSpecular(tInterface.Flags())) pdfSum += rInterface.PDF(-wos.wi, -wis.wi, mode);
+                    else {
+                        float c1 = r(), c2 = r(), c0 = r();
+                        BSDFSample rs = rInterface.Sample_f(-wos.wi, c0, V2{c1, c2}, mode);
+                        if (rs.valid && rs.f && rs.pdf > 0) {
+                            if (!IsNonSpecular(rInterface.Flags())) pdfSum += tInterface.PDF(-rs.wi, wi, mode);
+                            else {
+                                float rPDF = rInterface.PDF(-wos.wi, -wis.wi, mode);
+                                float wt = PowerHeuristic(1, wis.pdf, 1, rPDF);
+                                pdfSum += wt * rPDF;
+                                float tPDF = tInterface.PDF(-rs.wi, wi, mode);
+                                wt = PowerHeuristic(1, rs.pdf, 1, tPDF);
+                                pdfSum += wt * tPDF;
+                            }
+                        }
+                    }
+                }
+            } else {
+                IF toInterface{this, enteredTop}, tiInterface{this, !enteredTop};
+                float uc = r();
+                float uy = r(), ux = r();
+                BSDFSample wos = toInterface.Sample_f(wo, uc, V2{ux, uy}, mode);
+                if (Bad(wos) || wos.IsReflection()) continue;
+                uc = r();
+                uy = r(); ux = r();
+                BSDFSample wis = tiInterface.Sample_f(wi, uc, V2{ux, uy}, !mode);
+                if (Bad(wis) || wis.IsReflection()) continue;
+                if (IsSpecular(toInterface.Flags())) pdfSum += tiInterface.PDF(-wos.wi, wi, mode);
+                else if (IsSpecular(tiInterface.Flags())) pdfSum += toInterface.PDF(wo, -wis.wi, mode);
+                else pdfSum += (toInterface.PDF(wo, -wis.wi, mode) + tiInterface.PDF(-wos.wi, wi, mode)) / 2;
+            }
+        }
+        return Lerp(0.9f, 1 / (4 * Pi), pdfSum / nSamples);
+    }
+};
+using CoatedDiffuseBxDF = LayeredBxDF<DielectricBxDF, DiffuseBxDF, true>;
+using CoatedConductorBxDF = LayeredBxDF<DielectricBxDF, ConductorBxDF, true>;
+
+// ---------------------------------------------------------------------------------------------
 // BSDF (bsdf.h:19-152): shading frame + the concrete BxDF
 template <typename BxDF>
 struct BSDF {
@@ -504,6 +806,58 @@ WF_HD ConductorBxDF GetConductorBxDF(const SceneView &sv, const wf_material &m, 
         ks = 2 * Sqrt(r) / Sqrt(ClampZero(S4c(1.f) - r));
     }
     return ConductorBxDF{TrowbridgeReitz(uRough, vRough), etas, ks};
+}
+
+WF_HD CoatedDiffuseBxDF GetCoatedDiffuseBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+    // materials.cpp:255-284
+    S4 r = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda));
+    float urough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH]);
+    float vrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH]);
+    if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
+        urough = TrowbridgeReitz::RoughnessToAlpha(urough);
+        vrough = TrowbridgeReitz::RoughnessToAlpha(vrough);
+    }
+    TrowbridgeReitz distrib(urough, vrough);
+    float thick = EvalFloatTexture(sv, m.tex[WF_MT_THICKNESS]);
+    float sampledEta = SampledEta(sv, m, lambda);
+    S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda));
+    float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G]), -1.f, 1.f);
+    return CoatedDiffuseBxDF{DielectricBxDF{sampledEta, distrib}, DiffuseBxDF{r}, fmax(thick, 1.17549435e-38f), gg, a, m.maxdepth, m.nsamples,
+                             sv.options.seed};
+}
+WF_HD CoatedConductorBxDF GetCoatedConductorBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+    // materials.cpp:346-392
+    float iurough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH]);
+    float ivrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH]);
+    if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
+        iurough = TrowbridgeReitz::RoughnessToAlpha(iurough);
+        ivrough = TrowbridgeReitz::RoughnessToAlpha(ivrough);
+    }
+    TrowbridgeReitz interfaceDistrib(iurough, ivrough);
+    float thick = EvalFloatTexture(sv, m.tex[WF_MT_THICKNESS]);
+    float ieta = SampledEta(sv, m, lambda);
+    S4 ce, ck;
+    if (!(m.flags & WF_MATFLAG_CONDUCTOR_REFLECTANCE)) {
+        ce = EvalSpectrumTexture(sv, m.tex[WF_MT_COND_ETA], lambda);
+        ck = EvalSpectrumTexture(sv, m.tex[WF_MT_COND_K], lambda);
+    } else {
+        S4 r = ClampS(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda), 0.f, .9999f);
+        ce = S4c(1.f);
+        ck = 2 * Sqrt(r) / Sqrt(ClampZero(S4c(1.f) - r));
+    }
+    ce = ce / ieta;
+    ck = ck / ieta;
+    float curough = EvalFloatTexture(sv, m.tex[WF_MT_COND_UROUGH]);
+    float cvrough = EvalFloatTexture(sv, m.tex[WF_MT_COND_VROUGH]);
+    if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
+        curough = TrowbridgeReitz::RoughnessToAlpha(curough);
+        cvrough = TrowbridgeReitz::RoughnessToAlpha(cvrough);
+    }
+    TrowbridgeReitz conductorDistrib(curough, cvrough);
+    S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda));
+    float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G]), -1.f, 1.f);
+    return CoatedConductorBxDF{DielectricBxDF{ieta, interfaceDistrib}, ConductorBxDF{conductorDistrib, ce, ck}, fmax(thick, 1.17549435e-38f), gg, a,
+                               m.maxdepth, m.nsamples, sv.options.seed};
 }
 
 }  // namespace wf

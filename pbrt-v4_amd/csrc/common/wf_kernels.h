@@ -377,7 +377,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     int lightId = mesh.first_light + (prim - mesh.first_tri);
     const wf_light &light = sv.lights[lightId];
     F4 d4 = q.d[i];
-    V3 wo{-d4.x, -d4.y, -d4.z};
+    V3 wo = Normalize(V3{-d4.x, -d4.y, -d4.z});  // intr.wo is normalised by the Interaction ctor (interaction.h:40-43)
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
     S4 Le = AreaLightL(sv, light, si.n, wo, lambda);
     if (!Le) return;
@@ -421,6 +421,15 @@ template <> struct MatBxDF<WF_MAT_DIFFUSE_TRANSMISSION> {
     WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDiffuseTransmissionBxDF(sv, m, l); }
 };
 
+template <> struct MatBxDF<WF_MAT_COATED_DIFFUSE> {
+    using T = CoatedDiffuseBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetCoatedDiffuseBxDF(sv, m, l); }
+};
+template <> struct MatBxDF<WF_MAT_COATED_CONDUCTOR> {
+    using T = CoatedConductorBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetCoatedConductorBxDF(sv, m, l); }
+};
+
 template <int MAT>
 WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid) {
     // `valid` = this thread has an item.  The two queue pushes go through BlockAlloc, which every thread of
@@ -453,7 +462,8 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         F4 o4 = q.o[i], d4 = q.d[i];
         time = o4.w;
         float etaScale0 = d4.w;
-        V3 wo{-d4.x, -d4.y, -d4.z};
+        // intr.wo: the Interaction constructor normalises it (interaction.h:40-43), also for unit-length ray.d
+        V3 wo = Normalize(V3{-d4.x, -d4.y, -d4.z});
         // (texture-filtering differentials, surfscatter.cpp:75-104, only feed image textures; the textures
         // evaluated here are position-independent)
         N3 ns = si.ns;

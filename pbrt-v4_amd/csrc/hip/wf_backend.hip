@@ -602,8 +602,6 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     for (int i = 0; i < d->n_materials; ++i) {
         int t = d->materials[i].type;
         if (t < 0 || t >= WF_MAT_NTYPES) return fail(-1, "material %d has unknown type %d", i, t);
-        if (t == WF_MAT_COATED_DIFFUSE || t == WF_MAT_COATED_CONDUCTOR)
-            return fail(-1, "material %d: layered (coated*) materials are not implemented by the HIP kernels yet", i);
         ctx->matPresent[t] = true;
         sv.matTypeMask |= 1 << t;
     }
@@ -746,6 +744,8 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     case WF_MAT_DIELECTRIC: LAUNCH("DielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIELECTRIC>, g, ctx->svHost, ctx->ws, cur); break;
     case WF_MAT_THIN_DIELECTRIC: LAUNCH("ThinDielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_THIN_DIELECTRIC>, g, ctx->svHost, ctx->ws, cur); break;
     case WF_MAT_DIFFUSE_TRANSMISSION: LAUNCH("DiffuseTransmissionMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE_TRANSMISSION>, g, ctx->svHost, ctx->ws, cur); break;
+    case WF_MAT_COATED_DIFFUSE: LAUNCH("CoatedDiffuseMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_COATED_DIFFUSE>, g, ctx->svHost, ctx->ws, cur); break;
+    case WF_MAT_COATED_CONDUCTOR: LAUNCH("CoatedConductorMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_COATED_CONDUCTOR>, g, ctx->svHost, ctx->ws, cur); break;
     case WF_MAT_INTERFACE: break;
     default: return fail(-1, "material type %d has no HIP kernel", material_type);
     }
@@ -977,7 +977,9 @@ int wf_queue_size(wf_ctx *ctx, const char *queue, int *size) {
                                                    {"shadow", CNT_SHADOW}, {"mat_diffuse", CNT_MAT0 + WF_MAT_DIFFUSE},
                                                    {"mat_conductor", CNT_MAT0 + WF_MAT_CONDUCTOR}, {"mat_dielectric", CNT_MAT0 + WF_MAT_DIELECTRIC},
                                                    {"mat_thindielectric", CNT_MAT0 + WF_MAT_THIN_DIELECTRIC},
-                                                   {"mat_diffusetransmission", CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION}};
+                                                   {"mat_diffusetransmission", CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION},
+                                                   {"mat_coateddiffuse", CNT_MAT0 + WF_MAT_COATED_DIFFUSE},
+                                                   {"mat_coatedconductor", CNT_MAT0 + WF_MAT_COATED_CONDUCTOR}};
     auto it = idx.find(queue ? queue : "");
     if (it == idx.end()) return fail(-1, "unknown queue \"%s\"", queue ? queue : "(null)");
     HIPCHK(hipMemcpyAsync(size, ctx->ws.counters + it->second * CNT_STRIDE, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -114,7 +114,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small"])
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
     s = wfpt.Scene(path=path, spp=4)
@@ -124,10 +124,17 @@ def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     assert s.stats()["camera_rays"] == j["camera_rays"]
     assert s.total_rays() == j["rays"]
     ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))  # the reference's own CPU wavefront render
+    assert (cpu.view(np.uint32) == ref.view(np.uint32)).all()  # the port IS the reference, bit for bit
+    # layered (coated*) BxDFs seed their random walk from a hash of wo/wi: a 1-ulp difference in a bounce
+    # direction (device sin/cos vs glibc) re-rolls the whole walk for that sample, so that scene gets a
+    # larger outlier allowance and a statistical mean check
+    frac_allowed = 0.03 if name == "materials_lights" else FRAC_OUTLIERS
+    mean_tol = 3e-3 if name == "materials_lights" else 2e-4
     for other in (cpu, ref):
         rel = image_error(img, other)
-        assert (rel > REL_TOL).mean() <= FRAC_OUTLIERS, (rel > REL_TOL).mean()
-        assert abs(img.mean() - other.mean()) <= 2e-4 * other.mean()
+        print(name, "frac over tol", (rel > REL_TOL).mean(), "max rel", rel.max(), "means", img.mean(), other.mean())
+        assert (rel > REL_TOL).mean() <= frac_allowed, (rel > REL_TOL).mean()
+        assert abs(img.mean() - other.mean()) <= mean_tol * other.mean()
     assert np.isfinite(img).all()
     s.close()
 

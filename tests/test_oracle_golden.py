@@ -40,19 +40,17 @@ def test_triangle_golden_covers_hits_misses_edges():
     assert np.allclose(b.sum(axis=1), 1, atol=1e-5)
 
 
-@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("blobs_small", 4)])
+@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("blobs_small", 4), ("materials_lights", 4)])
 def test_cpu_checker_image_matches_reference_wavefront(built, tmp_path, scene, spp):
     """Whole path, sample-aligned: oracle/wf_cpu vs the reference's CPU WavefrontPathIntegrator
-    (pbrt --wavefront) on the same .pbrt, same seed.  Tolerance: 1e-3 relative L-inf (north_star), and in
-    practice >= 85 % of the values are bit-identical."""
+    (pbrt --wavefront) on the same .pbrt, same seed: BIT-IDENTICAL images — every material (incl. the
+    hash-seeded layered BxDFs) and every light type implemented (materials_lights scene)."""
     ref = read_pfm(os.path.join(GOLDEN, scene + "_ref.pfm"))
     out = str(tmp_path / "cpu.pfm")
     run_wf_cpu(os.path.join(GOLDEN, scene + ".pbrt"), out, spp)
     img = read_pfm(out)
     assert img.shape == ref.shape
-    rel = image_error(img, ref, floor=1e-3)
-    assert rel.max() < 1e-3, rel.max()
-    assert (img == ref).mean() > 0.85
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()
 
 
 def test_cpu_checker_mean_matches_volpath(built, tmp_path):
