@@ -19,7 +19,9 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define WF_HD __host__ __device__ inline
+// always_inline: a kernel must never fall back to real calls (the by-value scene struct would be spilled to
+// scratch and the callee would run on a private stack)
+#define WF_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define WF_HD inline
 #endif

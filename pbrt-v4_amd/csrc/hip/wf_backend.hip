@@ -73,6 +73,7 @@ struct wf_ctx {
     std::vector<Ev> events;
     std::vector<hipEvent_t> eventPool;
     bool countTraversal = false;
+    bool traceLaunch = false;    // WF_TRACE_LAUNCH=1: print every launch and synchronise after it (debugging)
 };
 
 template <typename T>
@@ -325,14 +326,10 @@ __global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, W
     const int n = ws.counters[(CNT_HITLIGHT) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEmissive(sv, ws, cur, i);
 }
-template <int MAT>
-__global__ void __launch_bounds__(BLOCK) k_eval_material(const SceneView sv, WorkState ws, int cur) {
-    const int n = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE];
-    // block-uniform trip count: BlockAlloc inside the body synchronises the workgroup
-    for (int base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
-        const int i = base + threadIdx.x;
-        KEvalMaterial<MAT>(sv, ws, cur, i, i < n);
-    }
+// the material kernels live in wf_mat.hip (one translation unit per material type)
+extern "C" {
+#define WF_DECL_MAT(n) void wf_launch_eval_material_##n(hipStream_t, int, const SceneView *, const WorkState *, int);
+WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7)
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK) KUpdateFilm(sv, ws, i);
@@ -388,6 +385,7 @@ struct Prof {
     const char *name;
     bool on;
     Prof(wf_ctx *c, const char *name) : c(c), name(name) {
+        if (c->traceLaunch) { fprintf(stderr, "[wf] launch %s\n", name); fflush(stderr); }
         on = c->profile == 1 || (c->profile == 2 && strncmp(name, "Intersect", 9) == 0);
         if (!on) return;
         auto get = [&]() {
@@ -400,6 +398,10 @@ struct Prof {
         (void)hipEventRecord(a, c->stream);
     }
     ~Prof() {
+        if (c->traceLaunch) {
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { fprintf(stderr, "[wf] %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
+        }
         if (!on) return;
         (void)hipEventRecord(b, c->stream);
         c->events.push_back({name, a, b});
@@ -530,6 +532,7 @@ int wf_ctx_create(int device, wf_ctx **out) {
     wf_ctx *c = new wf_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->traceLaunch = getenv("WF_TRACE_LAUNCH") != nullptr;
     *out = c;
     return 0;
 }
@@ -738,16 +741,23 @@ int wf_handle_emissive(wf_ctx *ctx, int depth) {
 int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     if (int e = checkReady(ctx)) return e;
     const int g = gridFor(ctx->maxQueueSize), cur = depth & 1;
-    switch (material_type) {
-    case WF_MAT_DIFFUSE: LAUNCH("DiffuseMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_CONDUCTOR: LAUNCH("ConductorMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_CONDUCTOR>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_DIELECTRIC: LAUNCH("DielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIELECTRIC>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_THIN_DIELECTRIC: LAUNCH("ThinDielectricMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_THIN_DIELECTRIC>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_DIFFUSE_TRANSMISSION: LAUNCH("DiffuseTransmissionMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_DIFFUSE_TRANSMISSION>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_COATED_DIFFUSE: LAUNCH("CoatedDiffuseMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_COATED_DIFFUSE>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_COATED_CONDUCTOR: LAUNCH("CoatedConductorMaterial + BxDF eval (Basic tex)", k_eval_material<WF_MAT_COATED_CONDUCTOR>, g, ctx->svHost, ctx->ws, cur); break;
-    case WF_MAT_INTERFACE: break;
-    default: return fail(-1, "material type %d has no HIP kernel", material_type);
+    static const char *names[WF_MAT_NTYPES] = {"", "DiffuseMaterial + BxDF eval (Basic tex)", "ConductorMaterial + BxDF eval (Basic tex)",
+                                               "DielectricMaterial + BxDF eval (Basic tex)", "ThinDielectricMaterial + BxDF eval (Basic tex)",
+                                               "DiffuseTransmissionMaterial + BxDF eval (Basic tex)", "CoatedDiffuseMaterial + BxDF eval (Basic tex)",
+                                               "CoatedConductorMaterial + BxDF eval (Basic tex)"};
+    if (material_type == WF_MAT_INTERFACE) return 0;
+    if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
+    {
+        Prof prof_(ctx, names[material_type]);
+        switch (material_type) {
+        case 1: wf_launch_eval_material_1(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 2: wf_launch_eval_material_2(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 3: wf_launch_eval_material_3(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 4: wf_launch_eval_material_4(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 5: wf_launch_eval_material_5(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 6: wf_launch_eval_material_6(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 7: wf_launch_eval_material_7(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        }
     }
     return 0;
 }
