@@ -45,10 +45,13 @@ def load_pkg():
     return m
 
 
-def make_scene(path, spp):
+def make_scene(path, spp, workload="killeroo-like", meshes=1600):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_scenes
-    make_scenes.killeroo_like(path, (W, H), spp)
+    if workload == "sanmiguel-like":
+        make_scenes.sanmiguel_like(path, (W, H), spp, n_meshes=meshes)
+    else:
+        make_scenes.killeroo_like(path, (W, H), spp)
 
 
 def closest_bytes(c, stats_hits_emitter=0):
@@ -90,6 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like"], default="killeroo-like",
+                    help="killeroo-like = BASELINE configs[1] stand-in (default, the metric's config); sanmiguel-like = configs[2] stand-in")
+    ap.add_argument("--meshes", type=int, default=1600, help="sanmiguel-like: number of 6272-triangle meshes (1600 = 10 M triangles)")
     a = ap.parse_args()
 
     import torch
@@ -114,7 +120,7 @@ def main():
         spp_total *= 2
     td = tempfile.mkdtemp(prefix="wfbench_")
     scene_path = os.path.join(td, "killeroo-like.pbrt")
-    make_scene(scene_path, spp_total)
+    make_scene(scene_path, spp_total, a.workload, a.meshes)
     scene = wfpt.Scene(path=scene_path, spp=spp_total)
     scene.create_renderer(local_rank)
     info = scene.info
@@ -175,8 +181,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "mray_per_s": total_rays / T / 1e6,
-            "config": {"workload": "killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
-                                   "diffuse + dielectric, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
+            "config": {"workload": ("killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
+                                    "diffuse + dielectric, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
+                                    if a.workload == "killeroo-like" else
+                                    "San Miguel 1080p (BASELINE.json configs[2]) on the sanmiguel-like stand-in: %d triangles, diffuse/coated "
+                                    "diffuse/dielectric/conductor, sun + sky + 400 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
                                    % (info.n_triangles, info.max_depth),
                        "resolution": [info.width, info.height], "spp": K, "partition": "sample-index round-robin x%d + RCCL film all-reduce" % world
                        if world > 1 else "single GPU"},

@@ -73,6 +73,7 @@ struct wf_ctx {
     std::vector<Ev> events;
     std::vector<hipEvent_t> eventPool;
     bool countTraversal = false;
+    int plThreshold = 0;         // WF_PL_THRESHOLD > 0: per-lane-refill traversal kernels (k_closest_pl / k_shadow_pl)
     bool traceLaunch = false;    // WF_TRACE_LAUNCH=1: print every launch and synchronise after it (debugging)
 };
 
@@ -262,7 +263,7 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
     }
 }
 
-__global__ void __launch_bounds__(TBLOCK) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
+__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(TBLOCK) k_closest_fast(const SceneView sv, Wor
         },
         [&](int i, bool valid, const RayWalk &w) { KAfterClosestHitBlock(sv, ws, cur, i, valid, w.prim, w.b0, w.b1, w.b2); });
 }
-__global__ void __launch_bounds__(TBLOCK) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
@@ -287,6 +288,124 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_fast(const SceneView sv, Work
         },
         [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
 }
+// ---- variant: persistent waves with PER-LANE refill from a register-resident prefetch batch ----
+// A wave keeps one prefetched ray per lane (64 consecutive queue entries, loaded with one atomic).  Lanes
+// whose ray has finished store its 16-byte result (fire and forget — the queue routing is a separate
+// streaming kernel, k_route_hits) and take the next unconsumed prefetched ray through ds_bpermute; the batch
+// is reloaded when it runs dry.  Refills happen when fewer than `threshold` lanes are still walking.
+template <bool ANY, typename Fetch, typename Store>
+__device__ inline void RefillTrace(const FastBVH &bvh, int n, int32_t *cursor, int threshold, LdsStackT &st, Fetch fetch, Store store) {
+    LoadTreeTop(bvh);
+    const unsigned lane = __lane_id();
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    int pfUsed = 0, pfCount = 0;   // wave-uniform
+    bool more = true;              // wave-uniform: the cursor has not run past n
+    V3 po{0, 0, 0}, pd{0, 0, 1};
+    float ptmax = 0;
+    auto loadBatch = [&]() {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
+        pfUsed = 0;
+        int c = n - base;
+        pfCount = c < 0 ? 0 : (c > 64 ? 64 : c);
+        if (base + 64 >= n) more = false;
+        if ((int)lane < pfCount) fetch(base + (int)lane, &po, &pd, &ptmax);
+        return base;
+    };
+    int pfBase = loadBatch();
+    RayWalk w;
+    w.node = NODE_NONE;
+    w.prim = -1;
+    w.b0 = w.b1 = w.b2 = 0;
+    int idx = -1;
+    while (true) {
+        if (w.node == NODE_NONE && idx >= 0) {
+            store(idx, w);
+            idx = -1;
+        }
+        bool need = idx < 0;
+        while (true) {
+            unsigned long long needMask = __ballot(need);
+            if (!needMask) break;
+            int avail = pfCount - pfUsed;
+            if (avail <= 0) {
+                if (!more) break;
+                pfBase = loadBatch();
+                avail = pfCount;
+                if (avail <= 0) break;
+            }
+            int rank = __popcll(needMask & ltMask);
+            int src = pfUsed + rank;
+            bool take = need && rank < avail;
+            int srcc = src < 63 ? src : 63;
+            float ox = __shfl(po.x, srcc), oy = __shfl(po.y, srcc), oz = __shfl(po.z, srcc);
+            float dx = __shfl(pd.x, srcc), dy = __shfl(pd.y, srcc), dz = __shfl(pd.z, srcc);
+            float tm = __shfl(ptmax, srcc);
+            if (take) {
+                WalkInit(w, V3{ox, oy, oz}, V3{dx, dy, dz}, tm);
+                st.n = 0;
+                idx = pfBase + src;
+                need = false;
+            }
+            int taken = __popcll(needMask);
+            pfUsed += taken < avail ? taken : avail;
+        }
+        if (!__any(w.node != NODE_NONE)) break;
+        do {
+            while (__any(w.node >= 0)) {
+                if (w.node >= 0) {
+                    U4 a, b;
+                    if (w.node < TOP_NODES) { a = g_top[2 * w.node]; b = g_top[2 * w.node + 1]; }
+                    else {
+                        const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
+                        a = p[0]; b = p[1];
+                    }
+                    InteriorStep(bvh, w, st, a, b);
+                }
+            }
+            if (w.node != NODE_NONE) LeafStep<ANY>(bvh, w, st);
+        } while (__popcll(__ballot(w.node != NODE_NONE)) >= threshold);
+    }
+}
+
+__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_pl(WorkState ws, FastBVH bvh, int cur, int threshold, int *stackSpill) {
+    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    const RayQueueV q = ws.rq[cur];
+    RefillTrace<false>(
+        bvh, n, &ws.counters[(CNT_NEXT_CLOSEST) * CNT_STRIDE], threshold, st,
+        [&](int i, V3 *o, V3 *d, float *tMax) {
+            F4 o4 = q.o[i], d4 = q.d[i];
+            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
+        },
+        [&](int i, const RayWalk &w) { ws.hit[i] = F4{BitsToFloat((uint32_t)w.prim), w.b0, w.b1, w.b2}; });
+}
+// routes the hit records written by k_closest_pl: EnqueueWorkAfterMiss / EnqueueWorkAfterIntersection
+__global__ void __launch_bounds__(BLOCK) k_route_hits(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
+    for (int base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
+        const int i = base + threadIdx.x;
+        const bool valid = i < n;
+        F4 h{BitsToFloat(0xffffffffu), 0, 0, 0};
+        if (valid) h = ws.hit[i];
+        KAfterClosestHitBlock(sv, ws, cur, i, valid, (int)FloatToBits(h.x), h.y, h.z, h.w);
+    }
+}
+__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_pl(WorkState ws, FastBVH bvh, int threshold, int *stackSpill) {
+    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    RefillTrace<true>(
+        bvh, n, &ws.counters[(CNT_NEXT_SHADOW) * CNT_STRIDE], threshold, st,
+        [&](int i, V3 *o, V3 *d, float *tMax) {
+            F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
+            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
+        },
+        [&](int i, const RayWalk &w) { KRecordShadowRay(ws, i, w.prim >= 0); });
+}
+
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
@@ -631,6 +750,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         const int maxG = MAX_GRID * BLOCK / TBLOCK;  // stackSpill is sized for MAX_GRID * BLOCK threads
         ctx->persistentGrid = g > maxG ? maxG : (g < 1 ? 1 : g);
         if (getenv("WF_NO_FAST")) ctx->fastOk = false;
+        if (const char *v = getenv("WF_PL_THRESHOLD")) ctx->plThreshold = atoi(v);
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
@@ -721,7 +841,10 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     // otherwise the production traversal (wf_traverse.h)
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
-    else if (ctx->fastOk)
+    else if (ctx->fastOk && ctx->plThreshold > 0) {
+        LAUNCHT("Intersect closest", k_closest_pl, ctx->persistentGrid, ctx->ws, ctx->fast, depth & 1, depth == 0 ? 1 : ctx->plThreshold, ctx->stackSpill);
+        LAUNCH("Route hits", k_route_hits, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    } else if (ctx->fastOk)
         LAUNCHT("Intersect closest", k_closest_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
     else
         LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
@@ -765,6 +888,8 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    else if (ctx->fastOk && ctx->plThreshold > 0)
+        LAUNCHT("Intersect shadow", k_shadow_pl, ctx->persistentGrid, ctx->ws, ctx->fast, ctx->plThreshold, ctx->stackSpill);
     else if (ctx->fastOk)
         LAUNCHT("Intersect shadow", k_shadow_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else

@@ -43,9 +43,21 @@ struct alignas(16) LeafTri {
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 
 constexpr int NODE_NONE = (int)0x80000000;
-constexpr int TOP_NODES = 1024;  // QNodes cached in LDS per workgroup (32 KiB)
-constexpr int TBLOCK = 512;      // threads per workgroup of the traversal kernels
-constexpr int TSTACK = 16;       // LDS stack entries per lane (16 x 4 B x 512 = 32 KiB)
+#ifndef WF_TOP_NODES
+#define WF_TOP_NODES 512
+#endif
+#ifndef WF_TBLOCK
+#define WF_TBLOCK 256
+#endif
+#ifndef WF_TSTACK
+#define WF_TSTACK 12
+#endif
+#ifndef WF_TWAVES
+#define WF_TWAVES 6   // __launch_bounds__ second argument (minimum waves per SIMD) of the traversal kernels
+#endif
+constexpr int TOP_NODES = WF_TOP_NODES;  // QNodes cached in LDS per workgroup (32 B each)
+constexpr int TBLOCK = WF_TBLOCK;        // threads per workgroup of the traversal kernels
+constexpr int TSTACK = WF_TSTACK;        // LDS stack entries per lane (x 4 B x TBLOCK)
 
 struct FastBVH {
     const QNode *nodes;
