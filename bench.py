@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--samples-per-pass", type=int, default=0, help="sample indices carried per pass (0 = automatic, ~4 M rays in flight)")
     ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like"], default="killeroo-like",
                     help="killeroo-like = BASELINE configs[1] stand-in (default, the metric's config); sanmiguel-like = configs[2] stand-in")
     ap.add_argument("--meshes", type=int, default=1600, help="sanmiguel-like: number of 6272-triangle meshes (1600 = 10 M triangles)")
@@ -122,7 +123,7 @@ def main():
     scene_path = os.path.join(td, "killeroo-like.pbrt")
     make_scene(scene_path, spp_total, a.workload, a.meshes)
     scene = wfpt.Scene(path=scene_path, spp=spp_total)
-    scene.create_renderer(local_rank)
+    scene.create_renderer(local_rank, samples_per_pass=a.samples_per_pass)
     info = scene.info
 
     def barrier():
@@ -187,7 +188,7 @@ def main():
                                     "San Miguel 1080p (BASELINE.json configs[2]) on the sanmiguel-like stand-in: %d triangles, diffuse/coated "
                                     "diffuse/dielectric/conductor, sun + sky + 400 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
                                    % (info.n_triangles, info.max_depth),
-                       "resolution": [info.width, info.height], "spp": K, "partition": "sample-index round-robin x%d + RCCL film all-reduce" % world
+                       "resolution": [info.width, info.height], "spp": K, "samples_per_pass": scene.samples_per_pass, "partition": "sample-index round-robin x%d + RCCL film all-reduce" % world
                        if world > 1 else "single GPU"},
         }
         if not a.no_roofline and counters and counters["closest_rays"] > 0:

@@ -369,8 +369,15 @@ void *wf_stream(wf_ctx *ctx);                               /* hipStream_t as vo
 int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *desc);
 int wf_aggregate_bounds(wf_ctx *ctx, float out_bounds[6]);  /* WavefrontAggregate::Bounds */
 
-/* integrator.cpp:227-274 queue sizing + allocation; film pixels (film.h:302-307) */
-int wf_queues_alloc(wf_ctx *ctx, int max_queue_size);
+/* integrator.cpp:227-274 queue sizing + allocation; film pixels (film.h:302-307).
+   pixels_per_pass = the reference's maxQueueSize (width x scanlinesPerPass).  samples_per_pass = how many
+   sample indices of each pixel one pass carries (queue capacity = the product): 1 reproduces the
+   reference's wavefront size; larger values fill the 256 CUs with one launch per stage (the film result
+   is bit-identical for any value). */
+int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass);
+/* the following passes carry sample indices s, s + sample_step, ..., n_samples of them (s = the sample_index
+   argument of wf_gen_camera_rays / wf_gen_ray_samples / wf_render_pass) */
+int wf_set_pass_samples(wf_ctx *ctx, int sample_step, int n_samples);
 int wf_film_clear(wf_ctx *ctx);
 
 /* K1: "Reset ray queue"/"Reset queues before tracing rays"/"Reset shadowRayQueue" (integrator.cpp:357-397,581-585) */

@@ -163,6 +163,8 @@ int main(int argc, char **argv) {
     const int n = T.maxQueueSize;
     WorkState ws{};
     ws.maxQueueSize = n;
+    ws.pixelsPerPass = n;   // the reference's geometry: one sample index per pass
+    ws.samplesPerPass = 1;
     ws.filterWeight = Alloc<float>(n); ws.pPixel = Alloc<I2>(n);
     ws.lambda = Alloc<F4>(n); ws.lambdaPdf = Alloc<F4>(n); ws.L = Alloc<F4>(n); ws.cameraRayWeight = Alloc<F4>(n);
     ws.samples0 = Alloc<F4>(n); ws.samples1 = Alloc<F4>(n);
@@ -183,8 +185,8 @@ int main(int argc, char **argv) {
     if (sampleEnd < 0) sampleEnd = T.spp;
     for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep) {
         for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
-            ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0);
-            ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex); });
+            ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, 1);
+            ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex, sampleStep, 1); });
             ws.stats[0] += ws.counters[(CNT_RAY0) * CNT_STRIDE];
             const bool dumpNow = !dumpStages.empty() && sampleIndex == sampleBegin && y0 == F.pixel_min[1];
             if (dumpNow) {
@@ -203,7 +205,7 @@ int main(int argc, char **argv) {
                 for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.counters[(CNT_MAT0 + m) * CNT_STRIDE] = 0;
                 const int nRays = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
                 ws.stats[1 + depth] += nRays;
-                ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex); });
+                ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex, sampleStep); });
                 std::atomic<unsigned long long> nv{0}, nt{0};
                 ParallelFor(nRays, [&](int i) {
                     F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
@@ -259,7 +261,7 @@ int main(int argc, char **argv) {
                 ws.stats[65 + depth] += nShadow;
                 ws.counters[(CNT_SHADOW) * CNT_STRIDE] = 0;
             }
-            ParallelFor(n, [&](int i) { KUpdateFilm(sv, ws, i); });
+            ParallelFor(n, [&](int i) { KUpdateFilm(sv, ws, i, 1); });
         }
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -55,7 +55,11 @@ struct ShadowQueueV {
     F4 *Ld, *r_u, *r_l;
 };
 struct WorkState {
-    int maxQueueSize;
+    int maxQueueSize;      // queue capacity = pixelsPerPass * samplesPerPass
+    // MI355X-first wavefront sizing: a pass carries `samplesPerPass` sample indices of every pixel of the
+    // scanline band (the reference carries one, capped at 2^20 rays: integrator.cpp:227-236).  Item index
+    // i = s * pixelsPerPass + p: sample slot s, pixel p of the band.  samplesPerPass = 1 is the reference.
+    int pixelsPerPass, samplesPerPass;
     // PixelSampleState
     float *filterWeight;
     I2 *pPixel;
@@ -160,13 +164,30 @@ WF_HD void StoreCtx(const RayQueueV &q, int i, const LightCtx &ctx) {
     q.ctx2[i] = F4{ctx.n.z, ctx.ns.x, ctx.ns.y, ctx.ns.z};
 }
 
-// ---------------------------------------------------------------------------------------------
-// K2: GenerateCameraRays, wavefront/camera.cpp:35-79
-WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixelIndex, int y0, int sampleIndex) {
+// number of in-bounds pixels of the pass starting at scanline y0 (row-major band)
+WF_HD int KValidPixels(const SceneView &sv, const WorkState &ws, int y0) {
     const wf_film &F = sv.film;
     int xResolution = F.pixel_max[0] - F.pixel_min[0];
-    int px = F.pixel_min[0] + pixelIndex % xResolution;
-    int py = y0 + pixelIndex / xResolution;
+    int rows = F.pixel_max[1] - y0;
+    int maxRows = ws.pixelsPerPass / xResolution;
+    if (rows > maxRows) rows = maxRows;
+    if (rows < 0) rows = 0;
+    return rows * xResolution;
+}
+// camera rays of the pass: nSamples sample slots x the in-bounds pixels
+WF_HD int KCameraRayCount(const SceneView &sv, const WorkState &ws, int y0, int nSamples) { return KValidPixels(sv, ws, y0) * nSamples; }
+
+// ---------------------------------------------------------------------------------------------
+// K2: GenerateCameraRays, wavefront/camera.cpp:35-79
+WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixelIndex, int y0, int sampleBase, int sampleStep, int nSamples) {
+    // pixelIndex = item index: sample slot s = pixelIndex / pixelsPerPass, band pixel p = pixelIndex % pixelsPerPass
+    const wf_film &F = sv.film;
+    int xResolution = F.pixel_max[0] - F.pixel_min[0];
+    const int slot = pixelIndex / ws.pixelsPerPass, p = pixelIndex - slot * ws.pixelsPerPass;
+    const int sampleIndex = sampleBase + slot * sampleStep;
+    int px = F.pixel_min[0] + p % xResolution;
+    int py = y0 + p / xResolution;
+    if (slot >= nSamples) py = F.pixel_max[1];  // unused sample slot of a short last batch: mark out of bounds
     ws.pPixel[pixelIndex] = I2{px, py};
     if (!(px >= F.pixel_min[0] && px < F.pixel_max[0] && py >= F.pixel_min[1] && py < F.pixel_max[1])) return;
     ZSobol sampler(sv);
@@ -192,10 +213,10 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     ws.filterWeight[pixelIndex] = filterWeight;
     if (cr.valid) {
         // RayQueue::PushCameraRay, workitems.h:346-361.  Both projective cameras always produce a ray and
-        // the in-bounds pixels of a pass are exactly pixelIndex < rows*width, so the slot is the pixel index
-        // itself (queue in pixel order, no atomic); KCameraRayCount sets the queue size.
+        // the in-bounds pixels of a band are exactly p < rows*width, so the queue slot is analytic (pixel
+        // order within each sample slot, no atomic); KCameraRayCount sets the queue size.
         const RayQueueV &q = ws.rq[0];
-        int index = pixelIndex;
+        int index = slot * KValidPixels(sv, ws, y0) + p;
         q.o[index] = F4{cr.o.x, cr.o.y, cr.o.z, cr.time};
         q.d[index] = F4{cr.d.x, cr.d.y, cr.d.z, 1.f};
         q.beta[index] = F4{1, 1, 1, 1};
@@ -206,21 +227,11 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     } else ws.cameraRayWeight[pixelIndex] = F4{0, 0, 0, 0};
 }
 
-// number of camera rays of the pass starting at scanline y0 (the in-bounds pixels, row-major)
-WF_HD int KCameraRayCount(const SceneView &sv, const WorkState &ws, int y0) {
-    const wf_film &F = sv.film;
-    int xResolution = F.pixel_max[0] - F.pixel_min[0];
-    int rows = F.pixel_max[1] - y0;
-    int maxRows = ws.maxQueueSize / xResolution;
-    if (rows > maxRows) rows = maxRows;
-    if (rows < 0) rows = 0;
-    return rows * xResolution;
-}
-
 // K3: GenerateRaySamples, wavefront/samples.cpp:35-65 (no subsurface: dimension = 6 + 7*depth)
-WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur, int i, int sampleIndex) {
+WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur, int i, int sampleBase, int sampleStep) {
     I4 m = ws.rq[cur].meta[i];
     int pixelIndex = m.x, depth = m.y;
+    const int sampleIndex = sampleBase + (pixelIndex / ws.pixelsPerPass) * sampleStep;
     int dimension = 6 + 7 * depth;
     ZSobol sampler(sv);
     I2 pp = ws.pPixel[pixelIndex];
@@ -562,29 +573,34 @@ WF_HD void KRecordShadowRay(const WorkState &ws, int i, bool occluded) {
 }
 
 // K13: UpdateFilm (wavefront/film.cpp:14-38) -> RGBFilm::AddSample (film.h:239-255) -> PixelSensor::ToSensorRGB (film.h:95-101)
-WF_HD void KUpdateFilm(const SceneView &sv, const WorkState &ws, int pixelIndex) {
+// One thread per band pixel p; it adds the pass's sample slots in sample order (the order the reference's
+// successive passes would add them), so the double-precision sums are bit-identical for any samplesPerPass.
+WF_HD void KUpdateFilm(const SceneView &sv, const WorkState &ws, int p, int nSamples) {
     const wf_film &F = sv.film;
-    I2 pp = ws.pPixel[pixelIndex];
-    if (!(pp.x >= F.pixel_min[0] && pp.x < F.pixel_max[0] && pp.y >= F.pixel_min[1] && pp.y < F.pixel_max[1])) return;
-    S4 Lw = toS4(ws.L[pixelIndex]) * toS4(ws.cameraRayWeight[pixelIndex]);
-    Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    float filterWeight = ws.filterWeight[pixelIndex];
-    S4 L = SafeDiv(Lw, lambda.PDF());
-    float r = F.imaging_ratio * (DenseSample(sv, F.rbar_offset, lambda) * L).Average();
-    float g = F.imaging_ratio * (DenseSample(sv, F.gbar_offset, lambda) * L).Average();
-    float b = F.imaging_ratio * (DenseSample(sv, F.bbar_offset, lambda) * L).Average();
-    float m = fmax(fmax(r, g), b);
-    if (m > F.max_component_value) {
-        float s = F.max_component_value / m;
-        r *= s; g *= s; b *= s;
+    for (int slot = 0; slot < nSamples; ++slot) {
+        const int pixelIndex = slot * ws.pixelsPerPass + p;
+        I2 pp = ws.pPixel[pixelIndex];
+        if (!(pp.x >= F.pixel_min[0] && pp.x < F.pixel_max[0] && pp.y >= F.pixel_min[1] && pp.y < F.pixel_max[1])) return;
+        S4 Lw = toS4(ws.L[pixelIndex]) * toS4(ws.cameraRayWeight[pixelIndex]);
+        Wavelengths lambda = LoadLambda(ws, pixelIndex);
+        float filterWeight = ws.filterWeight[pixelIndex];
+        S4 L = SafeDiv(Lw, lambda.PDF());
+        float r = F.imaging_ratio * (DenseSample(sv, F.rbar_offset, lambda) * L).Average();
+        float g = F.imaging_ratio * (DenseSample(sv, F.gbar_offset, lambda) * L).Average();
+        float b = F.imaging_ratio * (DenseSample(sv, F.bbar_offset, lambda) * L).Average();
+        float m = fmax(fmax(r, g), b);
+        if (m > F.max_component_value) {
+            float sc = F.max_component_value / m;
+            r *= sc; g *= sc; b *= sc;
+        }
+        int width = F.pixel_max[0] - F.pixel_min[0];
+        size_t idx = (size_t)(pp.y - F.pixel_min[1]) * width + (pp.x - F.pixel_min[0]);
+        double *px = ws.film + 4 * idx;
+        px[0] += filterWeight * r;
+        px[1] += filterWeight * g;
+        px[2] += filterWeight * b;
+        px[3] += filterWeight;
     }
-    int width = F.pixel_max[0] - F.pixel_min[0];
-    size_t idx = (size_t)(pp.y - F.pixel_min[1]) * width + (pp.x - F.pixel_min[0]);
-    double *px = ws.film + 4 * idx;
-    px[0] += filterWeight * r;
-    px[1] += filterWeight * g;
-    px[2] += filterWeight * b;
-    px[3] += filterWeight;
 }
 
 }  // namespace wf

@@ -14,18 +14,34 @@ namespace wf {
 
 struct TriHit { float b0, b1, b2, t; };
 
-WF_HD bool IntersectTriangle(V3 ro, V3 rd, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
-    if (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0) return false;
-    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+// The per-ray part of IntersectTriangle (shapes.cpp:181-198): the permutation (a rotation chosen by the
+// largest |d| component) and the shear constants depend on the ray only, so the traversal kernels compute
+// them once per ray instead of once per triangle test.  Same operations, same values.
+struct RayShear {
+    int kz;
+    float Sx, Sy, Sz;
+};
+WF_HD V3 ShearRot(int kz, V3 v) { return kz == 0 ? V3{v.y, v.z, v.x} : (kz == 1 ? V3{v.z, v.x, v.y} : v); }
+WF_HD RayShear MakeRayShear(V3 rd) {
     // Permute(v, {kx, ky, kz}) with kx = (kz+1)%3, ky = (kx+1)%3 is one of three rotations; written as
     // selects so that nothing is a runtime-indexed array on the device
-    int kz = MaxComponentIndex(Abs(rd));
-    auto rot = [kz](V3 v) { return kz == 0 ? V3{v.y, v.z, v.x} : (kz == 1 ? V3{v.z, v.x, v.y} : v); };
-    V3 d = rot(rd);
-    p0t = rot(p0t);
-    p1t = rot(p1t);
-    p2t = rot(p2t);
-    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1 / d.z;
+    RayShear sh;
+    sh.kz = MaxComponentIndex(Abs(rd));
+    V3 d = ShearRot(sh.kz, rd);
+    sh.Sx = -d.x / d.z;
+    sh.Sy = -d.y / d.z;
+    sh.Sz = 1 / d.z;
+    return sh;
+}
+// The per-triangle part.  checkDegenerate = false when the caller knows the triangle is not degenerate
+// (the production BVH layout drops the test by flagging degenerate triangles at build time).
+WF_HD bool IntersectTriangleSheared(V3 ro, const RayShear &sh, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit, bool checkDegenerate = true) {
+    if (checkDegenerate && LengthSquared(Cross(p2 - p0, p1 - p0)) == 0) return false;
+    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
+    p0t = ShearRot(sh.kz, p0t);
+    p1t = ShearRot(sh.kz, p1t);
+    p2t = ShearRot(sh.kz, p2t);
+    const float Sx = sh.Sx, Sy = sh.Sy, Sz = sh.Sz;
     p0t.x += Sx * p0t.z;
     p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z;
@@ -70,6 +86,13 @@ WF_HD bool IntersectTriangle(V3 ro, V3 rd, float tMax, V3 p0, V3 p1, V3 p2, TriH
     if (t <= deltaT) return false;
     hit->b0 = b0; hit->b1 = b1; hit->b2 = b2; hit->t = t;
     return true;
+}
+// IntersectTriangle, shapes.cpp:168-269
+WF_HD bool IntersectTriangle(V3 ro, V3 rd, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
+    // (the degenerate-triangle test comes first in the reference; it does not depend on the ray)
+    if (LengthSquared(Cross(p2 - p0, p1 - p0)) == 0) return false;
+    RayShear sh = MakeRayShear(rd);
+    return IntersectTriangleSheared(ro, sh, tMax, p0, p1, p2, hit, false);
 }
 
 // Bounds3::IntersectP with precomputed invDir/dirIsNeg.  dirIsNeg travels as a 3-bit mask (bit a = ray

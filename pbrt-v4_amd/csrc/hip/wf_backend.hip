@@ -72,6 +72,7 @@ struct wf_ctx {
     struct Ev { std::string name; hipEvent_t a, b; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> eventPool;
+    int passStep = 1, passSamples = 1;  // wf_set_pass_samples: sample-index stride and sample slots used by the current pass
     bool countTraversal = false;
     int plThreshold = 0;         // WF_PL_THRESHOLD > 0: per-lane-refill traversal kernels (k_closest_pl / k_shadow_pl)
     bool traceLaunch = false;    // WF_TRACE_LAUNCH=1: print every launch and synchronise after it (debugging)
@@ -107,15 +108,15 @@ __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, in
     if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) ws.counters[(threadIdx.x) * CNT_STRIDE] = 0;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleIndex) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0);
+__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleBase, int sampleStep, int nSamples) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, nSamples);
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
-        KGenerateCameraRay(sv, ws, i, y0, sampleIndex);
+        KGenerateCameraRay(sv, ws, i, y0, sampleBase, sampleStep, nSamples);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleIndex) {
+__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleBase, int sampleStep) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleIndex);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleBase, sampleStep);
 }
 
 // LDS short stack with HBM spill: one column per lane ([entry][lane] so a wave's same-depth accesses hit
@@ -450,8 +451,8 @@ extern "C" {
 #define WF_DECL_MAT(n) void wf_launch_eval_material_##n(hipStream_t, int, const SceneView *, const WorkState *, int);
 WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7)
 }
-__global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws) {
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK) KUpdateFilm(sv, ws, i);
+__global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
+    for (int p = blockIdx.x * BLOCK + threadIdx.x; p < ws.pixelsPerPass; p += gridDim.x * BLOCK) KUpdateFilm(sv, ws, p, nSamples);
 }
 
 // stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
@@ -562,7 +563,10 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         LeafTri lt;
         lt.a = F4{p0[0], p0[1], p0[2], p1[0]};
         lt.b = F4{p1[1], p1[2], p2[0], p2[1]};
-        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), 0.f, 0.f};
+        // IntersectTriangle's first test (shapes.cpp:172-173), hoisted to build time
+        V3 q0{p0[0], p0[1], p0[2]}, q1{p1[0], p1[1], p1[2]}, q2{p2[0], p2[1], p2[2]};
+        bool degenerate = LengthSquared(Cross(q2 - q0, q1 - q0)) == 0;
+        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : 0.f, 0.f};
         (*tris)[k] = lt;
     }
     // quantisation grid over the root bounds; cell rounded up so that 65535 cells cover the extent
@@ -777,14 +781,21 @@ static int allocRayQueue(wf_ctx *c, RayQueueV *q, size_t n) {
     return 0;
 }
 
-int wf_queues_alloc(wf_ctx *ctx, int max_queue_size) {
+int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     if (ctx->queuesAllocated) return fail(-1, "queues already allocated");
-    if (max_queue_size <= 0) return fail(-1, "max_queue_size must be positive");
+    if (pixels_per_pass <= 0 || samples_per_pass <= 0) return fail(-1, "pixels_per_pass and samples_per_pass must be positive");
+    if ((long long)pixels_per_pass * samples_per_pass > (1ll << 30)) return fail(-1, "queue capacity %lld too large", (long long)pixels_per_pass * samples_per_pass);
+    if (pixels_per_pass % ctx->W != 0) return fail(-1, "pixels_per_pass must be a whole number of scanlines (width %d)", ctx->W);
     HIPCHK(hipSetDevice(ctx->device));
+    const int max_queue_size = pixels_per_pass * samples_per_pass;
     const size_t n = (size_t)max_queue_size;
     WorkState &ws = ctx->ws;
     ws.maxQueueSize = max_queue_size;
+    ws.pixelsPerPass = pixels_per_pass;
+    ws.samplesPerPass = samples_per_pass;
+    ctx->passSamples = 1;
+    ctx->passStep = 1;
     int e;
     if ((e = devAlloc(ctx, &ws.filterWeight, n)) || (e = devAlloc(ctx, &ws.pPixel, n)) || (e = devAlloc(ctx, &ws.lambda, n)) ||
         (e = devAlloc(ctx, &ws.lambdaPdf, n)) || (e = devAlloc(ctx, &ws.L, n)) || (e = devAlloc(ctx, &ws.cameraRayWeight, n)) ||
@@ -799,6 +810,17 @@ int wf_queues_alloc(wf_ctx *ctx, int max_queue_size) {
         return e;
     ctx->maxQueueSize = max_queue_size;
     ctx->queuesAllocated = true;
+    return 0;
+}
+
+// sample indices carried by the following passes: sample_index, sample_index + sample_step, ... (n_samples of
+// them, n_samples <= samples_per_pass of wf_queues_alloc)
+int wf_set_pass_samples(wf_ctx *ctx, int sample_step, int n_samples) {
+    if (int e = checkReady(ctx)) return e;
+    if (n_samples < 1 || n_samples > ctx->ws.samplesPerPass) return fail(-1, "n_samples %d outside 1..%d", n_samples, ctx->ws.samplesPerPass);
+    if (sample_step < 1) return fail(-1, "sample_step must be >= 1");
+    ctx->passStep = sample_step;
+    ctx->passSamples = n_samples;
     return 0;
 }
 
@@ -826,13 +848,13 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
 }
 int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index);
+    LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index, ctx->passStep, ctx->passSamples);
     LAUNCH("Update camera ray stats", k_reset, 1, ctx->ws, 0u, 0, CNT_RAY0);
     return 0;
 }
 int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, sample_index);
+    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, sample_index, ctx->passStep);
     return 0;
 }
 int wf_intersect_closest(wf_ctx *ctx, int depth) {
@@ -900,7 +922,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
 }
 int wf_update_film(wf_ctx *ctx) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Update film", k_update_film, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws);
+    LAUNCH("Update film", k_update_film, gridFor(ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, ctx->passSamples);
     return 0;
 }
 

@@ -38,7 +38,7 @@ struct alignas(16) QNode {
 struct alignas(16) LeafTri {
     F4 a;  // p0.xyz, p1.x
     F4 b;  // p1.yz, p2.xy
-    F4 c;  // p2.z, triangle id (int bits), -, -
+    F4 c;  // p2.z, triangle id (int bits), 1.0 if the triangle is degenerate (zero-length normal) else 0, -
 };
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 
@@ -67,7 +67,8 @@ struct FastBVH {
 };
 
 struct RayWalk {
-    V3 o, d, invDir;
+    V3 o, invDir;
+    RayShear sh;   // per-ray part of the triangle test (MakeRayShear)
     float tMax;
     int negMask;
     int node;  // current ref; NODE_NONE = finished
@@ -76,7 +77,8 @@ struct RayWalk {
 };
 
 __device__ inline void WalkInit(RayWalk &w, V3 o, V3 d, float tMax) {
-    w.o = o; w.d = d; w.tMax = tMax;
+    w.o = o; w.tMax = tMax;
+    w.sh = MakeRayShear(d);
     w.invDir = V3{1 / d.x, 1 / d.y, 1 / d.z};
     w.negMask = int(w.invDir.x < 0) | (int(w.invDir.y < 0) << 1) | (int(w.invDir.z < 0) << 2);
     w.node = 0;
@@ -136,7 +138,8 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st) {
         const LeafTri *lt = bvh.tris + first + i;
         const F4 ta = lt->a, tb = lt->b, tc = lt->c;
         TriHit h;
-        if (IntersectTriangle(w.o, w.d, w.tMax, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h)) {
+        if (tc.z == 0.f &&
+            IntersectTriangleSheared(w.o, w.sh, w.tMax, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
             w.prim = (int)FloatToBits(tc.y);
             w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;
             w.tMax = h.t;

@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 
 namespace wf {
@@ -20,10 +21,20 @@ static void Check(int rc, const char *what) {
     }
 }
 
-WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device) : T(tables) {
+WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPassArg) : T(tables) {
+    // Wavefront sizing.  The reference carries one sample index per pass (<= 2^20 rays, integrator.cpp:227-236).
+    // On a 256-CU part a 1 M-ray launch is two rounds of a latency-bound walk; the queues here carry several
+    // sample indices per pass (default: up to ~4 M rays in flight, ~2.3 GB of queues out of 288 GB).
+    samplesPerPass = samplesPerPassArg;
+    if (samplesPerPass <= 0) {
+        const char *env = getenv("WF_SAMPLES_PER_PASS");
+        if (env) samplesPerPass = atoi(env);
+    }
+    if (samplesPerPass <= 0) samplesPerPass = std::max(1, (4 << 20) / T.maxQueueSize);
+    samplesPerPass = std::min(samplesPerPass, std::max(1, T.spp));
     Check(wf_ctx_create(device, &ctx), "wf_ctx_create");
     Check(wf_scene_upload(ctx, &T.desc), "wf_scene_upload");
-    Check(wf_queues_alloc(ctx, T.maxQueueSize), "wf_queues_alloc");
+    Check(wf_queues_alloc(ctx, T.maxQueueSize, samplesPerPass), "wf_queues_alloc");
     Check(wf_film_clear(ctx), "wf_film_clear");
     Check(wf_sync(ctx), "wf_sync");
 }
@@ -44,7 +55,10 @@ double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep,
     const wf_film &F = T.desc.film;
     auto t0 = std::chrono::steady_clock::now();
     const int maxDepth = T.desc.max_depth;
-    for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep) {
+    for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep * samplesPerPass) {
+        // this batch of passes carries sampleIndex, sampleIndex + sampleStep, ... (at most samplesPerPass of them)
+        const int remaining = (sampleEnd - sampleIndex + sampleStep - 1) / sampleStep;
+        Check(wf_set_pass_samples(ctx, sampleStep, std::min(samplesPerPass, remaining)), "wf_set_pass_samples");
         for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
             if (fused) {
                 Check(wf_render_pass(ctx, y0, sampleIndex), "wf_render_pass");

@@ -9,7 +9,9 @@ class WavefrontRenderer {
   public:
     // uploads the scene tables to HIP device `device` and allocates the work queues
     // (WavefrontPathIntegrator ctor, wavefront/integrator.cpp:80-287)
-    WavefrontRenderer(const SceneTables &tables, int device);
+    // samplesPerPass <= 0: automatic (env WF_SAMPLES_PER_PASS, else ~4 M rays in flight)
+    WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPass = 0);
+    int SamplesPerPass() const { return samplesPerPass; }
     ~WavefrontRenderer();
     WavefrontRenderer(const WavefrontRenderer &) = delete;
     // returns wall seconds (Render(), integrator.cpp:308,483-487).  fused: one wf_render_pass call per
@@ -25,6 +27,7 @@ class WavefrontRenderer {
   private:
     const SceneTables &T;
     wf_ctx *ctx = nullptr;
+    int samplesPerPass = 1;
 };
 
 }  // namespace wf

@@ -72,11 +72,12 @@ int wfh_scene_info(wfh_scene *s, wfh_info *out) {
     return 0;
 }
 
-int wfh_renderer_create(wfh_scene *s, int device) {
+int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass) {
     if (!s) return -1;
-    s->renderer = std::make_unique<WavefrontRenderer>(s->T, device);
+    s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass);
     return 0;
 }
+int wfh_renderer_samples_per_pass(wfh_scene *s) { return (s && s->renderer) ? s->renderer->SamplesPerPass() : -1; }
 wf_ctx *wfh_renderer_ctx(wfh_scene *s) { return (s && s->renderer) ? s->renderer->Context() : nullptr; }
 
 double wfh_render(wfh_scene *s, int sample_begin, int sample_end, int sample_step, int fused) {

@@ -52,7 +52,7 @@ class ProfileEntry(C.Structure):
 # every symbol include/wf_abi.h and include/wf_host.h declare (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "wf_last_error", "wf_abi_version", "wf_ctx_create", "wf_ctx_destroy", "wf_sync", "wf_stream", "wf_scene_upload",
-    "wf_aggregate_bounds", "wf_queues_alloc", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
+    "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
     "wf_gen_camera_rays", "wf_gen_ray_samples", "wf_intersect_closest", "wf_handle_escaped", "wf_handle_emissive",
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
     "wf_film_device_ptr", "wf_film_upload", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "wfh_init", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
-    "wfh_renderer_create", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
+    "wfh_renderer_create", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
     "wfh_film_to_rgb", "wfh_write_image",
 ]
 
@@ -93,7 +93,8 @@ def libs():
     _host.wfh_scene_desc.restype = C.c_void_p
     _host.wfh_scene_desc.argtypes = [C.c_void_p]
     _host.wfh_scene_info.argtypes = [C.c_void_p, C.POINTER(Info)]
-    _host.wfh_renderer_create.argtypes = [C.c_void_p, C.c_int]
+    _host.wfh_renderer_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    _host.wfh_renderer_samples_per_pass.argtypes = [C.c_void_p]
     _host.wfh_renderer_ctx.restype = C.c_void_p
     _host.wfh_renderer_ctx.argtypes = [C.c_void_p]
     _host.wfh_render.restype = C.c_double
@@ -156,12 +157,14 @@ class Scene:
     def spp(self):
         return self.info.spp
 
-    def create_renderer(self, device=0):
-        """WavefrontPathIntegrator ctor: upload tables to HIP device `device`, allocate queues."""
+    def create_renderer(self, device=0, samples_per_pass=0):
+        """WavefrontPathIntegrator ctor: upload tables to HIP device `device`, allocate queues.
+        samples_per_pass: sample indices one pass carries (0 = automatic); the film is bit-identical for any value."""
         host, _ = libs()
-        if host.wfh_renderer_create(self.h, device) != 0:
+        if host.wfh_renderer_create(self.h, device, samples_per_pass) != 0:
             raise WfError("renderer creation failed")
         self._renderer = True
+        self.samples_per_pass = host.wfh_renderer_samples_per_pass(self.h)
         self.ctx = host.wfh_renderer_ctx(self.h)
         return self
 

@@ -222,3 +222,24 @@ def test_edge_cases(wfpt):
     assert s.image().max() == 0.0
     assert sum(s.stats()["indirect_rays"][1:]) == 0
     s.close()
+
+
+def test_samples_per_pass_invariance(wfpt):
+    """A pass may carry several sample indices (bigger wavefronts); the film sums must not depend on how
+    many: 8 spp rendered as 8 x 1, 3 + 3 + 2 and 1 x 8 sample slots give bit-identical double accumulators
+    and identical ray counts."""
+    films, stats = [], []
+    for spp_per_pass in (1, 3, 8):
+        s = wfpt.Scene(path=os.path.join(GOLDEN, "materials_lights.pbrt"), spp=8)
+        s.create_renderer(0, samples_per_pass=spp_per_pass)
+        assert s.samples_per_pass == spp_per_pass
+        s.render()
+        films.append(s.film().copy())
+        stats.append(s.stats())
+        s.close()
+    for f in films[1:]:
+        assert (f.view(np.uint64) == films[0].view(np.uint64)).all()
+    for st in stats[1:]:
+        assert st["camera_rays"] == stats[0]["camera_rays"]
+        assert st["indirect_rays"] == stats[0]["indirect_rays"]
+        assert st["shadow_rays"] == stats[0]["shadow_rays"]
