@@ -240,7 +240,7 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
             V3 o, d;
             float tMax;
             fetch(idx, &o, &d, &tMax);
-            WalkInit(w, o, d, tMax);
+            WalkInit(bvh, w, o, d, tMax);
             st.n = 0;
         }
         while (__any(w.node != NODE_NONE)) {
@@ -255,7 +255,7 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
                         const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
                         a = p[0]; b = p[1];
                     }
-                    InteriorStep(bvh, w, st, a, b);
+                    InteriorStep(w, st, a, b);
                 }
             }
             if (w.node != NODE_NONE) LeafStep<ANY>(bvh, w, st);
@@ -344,7 +344,7 @@ __device__ inline void RefillTrace(const FastBVH &bvh, int n, int32_t *cursor, i
             float dx = __shfl(pd.x, srcc), dy = __shfl(pd.y, srcc), dz = __shfl(pd.z, srcc);
             float tm = __shfl(ptmax, srcc);
             if (take) {
-                WalkInit(w, V3{ox, oy, oz}, V3{dx, dy, dz}, tm);
+                WalkInit(bvh, w, V3{ox, oy, oz}, V3{dx, dy, dz}, tm);
                 st.n = 0;
                 idx = pfBase + src;
                 need = false;
@@ -362,7 +362,7 @@ __device__ inline void RefillTrace(const FastBVH &bvh, int n, int32_t *cursor, i
                         const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
                         a = p[0]; b = p[1];
                     }
-                    InteriorStep(bvh, w, st, a, b);
+                    InteriorStep(w, st, a, b);
                 }
             }
             if (w.node != NODE_NONE) LeafStep<ANY>(bvh, w, st);
@@ -569,31 +569,41 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : 0.f, 0.f};
         (*tris)[k] = lt;
     }
-    // quantisation grid over the root bounds; cell rounded up so that 65535 cells cover the extent
+    // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
+    // it as a float: WalkInit folds base and cell into per-ray fma constants).  Every stored plane lies at least
+    // `margin` outside the float box it bounds; margin = 2^-20 of the largest coordinate magnitude, which covers the
+    // rounding of (base - o) and of the box's own float planes in the reference's slab test.
+    double margin[3];
     for (int a = 0; a < 3; ++a) {
-        out->base[a] = L[0].bmin[a];
-        double ext = (double)L[0].bmax[a] - (double)L[0].bmin[a];
-        float cell = (float)(ext / 65535.0);
+        double lo = L[0].bmin[a], hi = L[0].bmax[a];
+        double ext = hi - lo;
+        margin[a] = 0x1p-20 * (std::max(std::fabs(lo), std::fabs(hi)) + ext) + 1e-37;
+        float base = (float)(lo - 2 * margin[a]);
+        while ((double)base > lo - 2 * margin[a]) base = NextFloatDown(base);
+        float cell = (float)((hi + 2 * margin[a] - (double)base) / 65535.0);
         if (!(cell > 0)) cell = 1e-30f;
         cell = NextFloatUp(NextFloatUp(cell));
+        out->base[a] = base;
         out->cell[a] = cell;
     }
-    auto deq = [&](int q, int a) { return ::fmaf((float)q, out->cell[a], out->base[a]); };  // == the device's dequantisation
+    auto plane = [&](int q, int a) { return (double)out->base[a] + (double)q * (double)out->cell[a]; };
+    bool gridOk = true;
     auto qlo = [&](float v, int a) {
-        int q = (int)std::floor(((double)v - out->base[a]) / out->cell[a]);
+        double target = (double)v - margin[a];
+        int q = (int)std::floor((target - out->base[a]) / out->cell[a]);
         q = std::min(std::max(q, 0), 65535);
-        while (q > 0 && deq(q, a) > v) --q;
+        while (q > 0 && plane(q, a) > target) --q;
+        if (plane(q, a) > target) gridOk = false;
         return (uint32_t)q;
     };
     auto qhi = [&](float v, int a) {
-        int q = (int)std::ceil(((double)v - out->base[a]) / out->cell[a]);
+        double target = (double)v + margin[a];
+        int q = (int)std::ceil((target - out->base[a]) / out->cell[a]);
         q = std::min(std::max(q, 0), 65535);
-        while (q < 65535 && deq(q, a) < v) ++q;
+        while (q < 65535 && plane(q, a) < target) ++q;
+        if (plane(q, a) < target) gridOk = false;
         return (uint32_t)q;
     };
-    // conservative check at the grid's end (cell was rounded up twice)
-    for (int a = 0; a < 3; ++a)
-        if (deq(65535, a) < L[0].bmax[a]) return false;
     auto leafRef = [&](int i) { return (int)~(((unsigned)L[i].offset << 4) | (unsigned)(L[i].nprims - 1)); };
     // breadth-first numbering of the interior nodes
     std::vector<int> order;  // BFS list of linear indices of interior nodes
@@ -608,20 +618,16 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         }
     }
     auto packBox = [&](const wf_bvh_node &b, uint32_t q[6], int slot) {
-        uint32_t v[6] = {qlo(b.bmin[0], 0), qlo(b.bmin[1], 1), qlo(b.bmin[2], 2), qhi(b.bmax[0], 0), qhi(b.bmax[1], 1), qhi(b.bmax[2], 2)};
-        for (int k = 0; k < 6; ++k) {
-            int e = slot * 6 + k;  // element index among the 12 u16
-            if (e & 1) q[e >> 1] |= v[k] << 16;
-            else q[e >> 1] |= v[k];
-        }
+        for (int a = 0; a < 3; ++a) q[slot * 3 + a] = qlo(b.bmin[a], a) | (qhi(b.bmax[a], a) << 16);
     };
     if (order.empty()) {
-        // the whole scene is one leaf: a root node whose left child is that leaf and whose right child is absent
+        // the whole scene is one leaf: a root node whose two children are both that leaf (testing it twice
+        // changes neither the closest hit nor occlusion)
         QNode qn{};
         packBox(L[0], qn.q, 0);
         packBox(L[0], qn.q, 1);
         qn.left = leafRef(0);
-        qn.right = NODE_NONE;
+        qn.right = leafRef(0);
         nodes->assign(1, qn);
     } else {
         nodes->resize(order.size());
@@ -636,6 +642,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             (*nodes)[h] = qn;
         }
     }
+    if (!gridOk) return false;
     out->nNodes = (int)nodes->size();
     return true;
 }

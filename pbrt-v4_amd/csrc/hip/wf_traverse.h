@@ -32,8 +32,10 @@
 namespace wf {
 
 struct alignas(16) QNode {
-    uint32_t q[6];  // 12 x u16: L.min.xyz, L.max.xyz, R.min.xyz, R.max.xyz (two per dword, low half first)
-    int32_t left, right;  // >= 0: interior QNode index; < 0: leaf ~((first << 4) | (count - 1)); NODE_NONE: absent
+    // q[0..2]: left child x, y, z;  q[3..5]: right child x, y, z.  Each dword = min plane (low half) | max plane << 16
+    // on the 16-bit grid of FastBVH (plane = base + q * cell, with build-time outward margins)
+    uint32_t q[6];
+    int32_t left, right;  // >= 0: interior QNode index; < 0: leaf ~((first << 4) | (count - 1))
 };
 struct alignas(16) LeafTri {
     F4 a;  // p0.xyz, p1.x
@@ -63,69 +65,82 @@ struct FastBVH {
     const QNode *nodes;
     const LeafTri *tris;
     int nNodes;
-    float base[3], cell[3];  // dequantisation: v = fma(q, cell, base)
+    float base[3], cell[3];  // grid: plane(q) = base + q * cell (real arithmetic; the builder keeps a margin, see BuildFastBVH)
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct RayWalk {
-    V3 o, invDir;
+    V3 o;
     RayShear sh;   // per-ray part of the triangle test (MakeRayShear)
     float tMax;
-    int negMask;
+    // slab test in grid coordinates: entry t of an axis = fma(qNear, a, bn), exit t = fma(qFar, af, bf)
+    V3 a, bn, af, bf;
+    uint32_t selx, sely, selz;  // v_perm selectors: put the near plane in the low half, the far plane in the high half
     int node;  // current ref; NODE_NONE = finished
     int prim;
     float b0, b1, b2;
 };
 
-__device__ inline void WalkInit(RayWalk &w, V3 o, V3 d, float tMax) {
+// Per-ray constants of the box test.  Bounds3::IntersectP (util/vecmath.h:1574-1608) computes, per axis,
+// tNear = (pNear - o) * invDir and tFar = (pFar - o) * invDir * (1 + 2 gamma(3)).  With pNear = base + q * cell
+// that is q * (cell * invDir) + (base - o) * invDir: one fma per plane.  The evaluation error of that form is
+// bounded by a few ulps of (65535 |a| + |b|); SLACK times that bound is folded into the constants (subtracted on
+// the near side, added on the far side) so that the test passes whenever the reference's test on the exact
+// box would: a superset of visited nodes, while the hit itself is decided by the exact triangle test.
+__device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, float tMax) {
+    constexpr float SLACK = 0x1p-20f;            // 16 ulp
+    constexpr float G = 1 + 2 * gamma(3);        // the reference's tMax factor
+    constexpr float INV_MAX = 1e28f;             // |1/d| clamp: keeps every product finite (no 0 * inf NaNs)
     w.o = o; w.tMax = tMax;
     w.sh = MakeRayShear(d);
-    w.invDir = V3{1 / d.x, 1 / d.y, 1 / d.z};
-    w.negMask = int(w.invDir.x < 0) | (int(w.invDir.y < 0) << 1) | (int(w.invDir.z < 0) << 2);
+    const float dd[3] = {d.x, d.y, d.z}, oo[3] = {o.x, o.y, o.z};
+    float a[3], bn[3], af[3], bf[3];
+    uint32_t sel[3];
+    for (int k = 0; k < 3; ++k) {
+        float inv = 1 / dd[k];
+        if (!(fabsf(inv) <= INV_MAX)) inv = copysignf(INV_MAX, dd[k]);
+        const float ak = bvh.cell[k] * inv, bk = (bvh.base[k] - oo[k]) * inv;
+        const float delta = SLACK * fma(65535.f, fabsf(ak), fabsf(bk));
+        a[k] = ak; bn[k] = bk - delta;
+        af[k] = ak * G; bf[k] = fma(bk, G, delta * 1.001f);
+        sel[k] = (FloatToBits(dd[k]) >> 31) ? 0x01000302u : 0x03020100u;  // negative direction (incl. -0): swap halves
+    }
+    w.a = V3{a[0], a[1], a[2]}; w.bn = V3{bn[0], bn[1], bn[2]};
+    w.af = V3{af[0], af[1], af[2]}; w.bf = V3{bf[0], bf[1], bf[2]};
+    w.selx = sel[0]; w.sely = sel[1]; w.selz = sel[2];
     w.node = 0;
     w.prim = -1;
     w.b0 = w.b1 = w.b2 = 0;
 }
 
-// Bounds3::IntersectP (util/vecmath.h:1574-1608) that also reports the entry distance for child ordering
-__device__ inline bool SlabTestT(const float bmin[3], const float bmax[3], V3 o, float raytMax, V3 invDir, int negMask, float *tEntry) {
-    const bool n0 = negMask & 1, n1 = negMask & 2, n2 = negMask & 4;
-    float tMin = ((n0 ? bmax[0] : bmin[0]) - o.x) * invDir.x;
-    float tMax = ((n0 ? bmin[0] : bmax[0]) - o.x) * invDir.x;
-    float tyMin = ((n1 ? bmax[1] : bmin[1]) - o.y) * invDir.y;
-    float tyMax = ((n1 ? bmin[1] : bmax[1]) - o.y) * invDir.y;
-    tMax *= 1 + 2 * gamma(3);
-    tyMax *= 1 + 2 * gamma(3);
-    if (tMin > tyMax || tyMin > tMax) return false;
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
-    float tzMin = ((n2 ? bmax[2] : bmin[2]) - o.z) * invDir.z;
-    float tzMax = ((n2 ? bmin[2] : bmax[2]) - o.z) * invDir.z;
-    tzMax *= 1 + 2 * gamma(3);
-    if (tMin > tzMax || tzMin > tMax) return false;
-    if (tzMin > tMin) tMin = tzMin;
-    if (tzMax < tMax) tMax = tzMax;
-    *tEntry = tMin;
-    return (tMin < raytMax) && (tMax > 0);
-}
+__device__ inline float CvtLo(uint32_t v) { return (float)(v & 0xffffu); }
+__device__ inline float CvtHi(uint32_t v) { return (float)(v >> 16); }
 
-// Interior visit.  a, b = the node's two 16-byte halves (from LDS or global).  Precondition: w.node >= 0.
+// Interior visit: branch-free test of both children (packed left/right), nearest entry first.
+// a, b = the node's two 16-byte halves (from LDS or global).  Precondition: w.node >= 0.
 template <typename Stack>
-__device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, U4 a, U4 b) {
-    auto dq = [&](uint32_t word, int hi, int axis) { return fma((float)(hi ? (word >> 16) : (word & 0xffffu)), bvh.cell[axis], bvh.base[axis]); };
-    const float lmin[3] = {dq(a.x, 0, 0), dq(a.x, 1, 1), dq(a.y, 0, 2)};
-    const float lmax[3] = {dq(a.y, 1, 0), dq(a.z, 0, 1), dq(a.z, 1, 2)};
-    const float rmin[3] = {dq(a.w, 0, 0), dq(a.w, 1, 1), dq(b.x, 0, 2)};
-    const float rmax[3] = {dq(b.x, 1, 0), dq(b.y, 0, 1), dq(b.y, 1, 2)};
+__device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
+    // near plane -> low half, far plane -> high half of each dword
+    const uint32_t lx = __builtin_amdgcn_perm(a.x, a.x, w.selx), ly = __builtin_amdgcn_perm(a.y, a.y, w.sely), lz = __builtin_amdgcn_perm(a.z, a.z, w.selz);
+    const uint32_t rx = __builtin_amdgcn_perm(a.w, a.w, w.selx), ry = __builtin_amdgcn_perm(b.x, b.x, w.sely), rz = __builtin_amdgcn_perm(b.y, b.y, w.selz);
     const int left = (int)b.z, right = (int)b.w;
-    float tL = 0, tR = 0;
-    bool hitL = SlabTestT(lmin, lmax, w.o, w.tMax, w.invDir, w.negMask, &tL);
-    bool hitR = right != NODE_NONE && SlabTestT(rmin, rmax, w.o, w.tMax, w.invDir, w.negMask, &tR);
-    if (hitL && hitR) {
-        bool rightFirst = tR < tL;
+    const f2 nx = __builtin_elementwise_fma(f2{CvtLo(lx), CvtLo(rx)}, f2{w.a.x, w.a.x}, f2{w.bn.x, w.bn.x});
+    const f2 ny = __builtin_elementwise_fma(f2{CvtLo(ly), CvtLo(ry)}, f2{w.a.y, w.a.y}, f2{w.bn.y, w.bn.y});
+    const f2 nz = __builtin_elementwise_fma(f2{CvtLo(lz), CvtLo(rz)}, f2{w.a.z, w.a.z}, f2{w.bn.z, w.bn.z});
+    const f2 fx = __builtin_elementwise_fma(f2{CvtHi(lx), CvtHi(rx)}, f2{w.af.x, w.af.x}, f2{w.bf.x, w.bf.x});
+    const f2 fy = __builtin_elementwise_fma(f2{CvtHi(ly), CvtHi(ry)}, f2{w.af.y, w.af.y}, f2{w.bf.y, w.bf.y});
+    const f2 fz = __builtin_elementwise_fma(f2{CvtHi(lz), CvtHi(rz)}, f2{w.af.z, w.af.z}, f2{w.bf.z, w.bf.z});
+    // tMin < raytMax && tMax > 0 && tMin <= tMax, relaxed to max(tMin, 0) <= min(tMax, raytMax)
+    const float tL = __builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), nz.x), tR = __builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), nz.y);
+    const float eL = __builtin_fminf(__builtin_fminf(fx.x, fy.x), fz.x), eR = __builtin_fminf(__builtin_fminf(fx.y, fy.y), fz.y);
+    const bool hitL = __builtin_fmaxf(tL, 0.f) <= __builtin_fminf(eL, w.tMax);
+    const bool hitR = __builtin_fmaxf(tR, 0.f) <= __builtin_fminf(eR, w.tMax);
+    const bool rightFirst = tR < tL;
+    if (hitL & hitR) {
         st.push(rightFirst ? left : right);
         w.node = rightFirst ? right : left;
-    } else if (hitL) w.node = left;
-    else if (hitR) w.node = right;
+    } else if (hitL | hitR) w.node = hitL ? left : right;
     else w.node = st.empty() ? NODE_NONE : st.pop();
 }
 // Leaf: <= 16 triangle tests.  Precondition: w.node < 0 && w.node != NODE_NONE.  ANY: stop at the first hit.

@@ -5,5 +5,3 @@ for e in "$@"; do
   echo "== $e"
   env $e timeout 120 pbrt-v4_amd/_build/pbrt_amd --stats --outfile /tmp/k.pfm /tmp/k.pbrt 2>&1 | grep -E "Rendering|Intersect|Route"
 done
-echo "== pytest with WF_PL_THRESHOLD=32"
-WF_PL_THRESHOLD=32 timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3

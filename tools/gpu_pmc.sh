@@ -2,7 +2,7 @@
 # PMC counters for the traversal kernels on the killeroo-like scene (separate passes; --kernel-trace only)
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-python tools/make_scenes.py killeroo-like /tmp/k.pbrt --spp 4
+python tools/make_scenes.py killeroo-like /tmp/k.pbrt --spp ${SPP:-16}
 cd /tmp
 pass() {
   name=$1; shift
