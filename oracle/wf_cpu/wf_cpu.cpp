@@ -105,7 +105,7 @@ int main(int argc, char **argv) {
     ParseFiles({scenePath}, &opt, &parsed);
     SceneTables T;
     BuildSceneTables(parsed, opt, &T);
-    uint32_t sobol[104];
+    static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
     SceneView sv = MakeHostView(T.desc, sobol);
 

@@ -48,8 +48,33 @@ static void evalBxDF(const B &b, V3 wo, V3 wi, float uc, V2 u, float *w) {
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: wf_probe <golden_dir> <out_dir>\n"); return 1; }
     std::string gd = argv[1], od = argv[2];
-    uint32_t sobol[104];
+    static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
+    {
+        // the sampler's exact integer shortcuts against their defining expressions (util/lowdiscrepancy.h:165-180,
+        // samplers.h:331): every value of the reduced modulo's domain, random operands, and operands above 2^32
+        int bad = 0;
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+        for (long i = 0; i < 4000000; ++i) {
+            uint64_t hd = rnd() >> (i % 3 == 0 ? 20 : 32 + (i % 29));
+            uint32_t dm = 0x55555555u * (uint32_t)(i % 97);
+            int want = (int)((MixBits(hd ^ dm) >> 24) % 24);
+            if (ZSobol::PermutationIndex(hd, dm) != want) ++bad;
+        }
+        for (long i = 0; i < 2000000; ++i) {
+            uint64_t a = rnd() >> (i % 2 ? 32 : 12 + (i % 20));
+            for (int dim = 0; dim < 2; ++dim) {
+                uint32_t v = 0;
+                uint64_t t = a;
+                for (int c = dim * 52; t != 0; t >>= 1, c++)
+                    if (t & 1) v ^= sobol[c];
+                float want = fmin(v * 0x1p-32f, OneMinusEpsilon);
+                if (SobolSample(sobol, (int64_t)a, dim, WF_RAND_NONE, 0) != want) ++bad;
+            }
+        }
+        if (bad) { fprintf(stderr, "wf_probe: sampler identity check failed (%d mismatches)\n", bad); return 2; }
+    }
     auto sampler = [&](const char *name, int spp, int rx, int ry, int startDim, int nd) {
         std::vector<int32_t> in = readBin<int32_t>(gd + "/" + name + "_in.bin");
         int n = (int)in.size() / 3;

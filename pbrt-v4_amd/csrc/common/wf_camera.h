@@ -27,8 +27,15 @@ WF_HD uint32_t OwenScramble(uint32_t v, uint32_t seed) {
 }
 WF_HD float SobolSample(const uint32_t *sobol, int64_t a, int dimension, int randomize, uint32_t hash) {
     uint32_t v = 0;
-    for (int i = dimension * 52; a != 0; a >>= 1, i++)
-        if (a & 1) v ^= sobol[i];
+    if (((uint64_t)a >> 32) == 0) {
+        // the same XOR of columns, four index bytes at a time (tables: FillSobol2D)
+        const uint32_t *lut = sobol + WF_SOBOL_COLUMNS + dimension * 1024;
+        const uint32_t x = (uint32_t)a;
+        v = lut[x & 255u] ^ lut[256 + ((x >> 8) & 255u)] ^ lut[512 + ((x >> 16) & 255u)] ^ lut[768 + (x >> 24)];
+    } else {
+        for (int i = dimension * 52; a != 0; a >>= 1, i++)
+            if (a & 1) v ^= sobol[i];
+    }
     if (randomize == WF_RAND_PERMUTE_DIGITS) v = hash ^ v;
     else if (randomize == WF_RAND_FAST_OWEN) v = FastOwenScramble(v, hash);
     else if (randomize == WF_RAND_OWEN) v = OwenScramble(v, hash);
@@ -57,6 +64,28 @@ struct ZSobol {
             0xC6, 0x36, 0xD2, 0x72, 0x4E, 0x1E, 0x27, 0x87, 0x1B, 0x4B, 0x63, 0x93};
         return (perms[p] >> (2 * digit)) & 3;
     }
+    // (MixBits(higherDigits ^ dimMix) >> 24) % 24 (samplers.h:331).  The arithmetic is integer, so any exact
+    // rearrangement gives the reference's value; for operands below 2^32 (every image up to 65536^2 pixels at any
+    // practical spp) the first multiplication is 32 x 64 bit and the 40-bit modulo reduces through 2^32 = 2^16 =
+    // 2^8 = 1 (mod 3) to a 10-bit one — no 64-bit division on the device.
+    WF_HD static int PermutationIndex(uint64_t higherDigits, uint32_t dimMix) {
+        uint64_t v = higherDigits ^ dimMix;
+        if ((v >> 32) != 0) return (int)((MixBits(v) >> 24) % 24);
+        uint32_t x = (uint32_t)v;
+        x ^= x >> 31;
+        uint64_t m = (uint64_t)x * 0x7fb5d329728ea185ull;
+        m ^= m >> 27;
+        m *= 0x81dadef4bc2dd44dull;
+        m ^= m >> 33;
+        const uint64_t y = m >> 24;            // 40 bits
+        const uint32_t low3 = (uint32_t)y & 7u;
+        const uint64_t z = y >> 3;             // y % 24 = 8 * (z % 3) + low3
+        const uint32_t zl = (uint32_t)z, zh = (uint32_t)(z >> 32);
+        uint32_t s = (zl & 0xffffu) + (zl >> 16) + zh;  // = z (mod 3), < 2^17 + 32
+        s = (s & 0xffu) + (s >> 8);                     // < 2^8 + 2^9 + 1
+        const uint32_t q = (s * 43691u) >> 17;          // s / 3 for s < 2^16
+        return (int)((s - 3u * q) * 8u + low3);
+    }
     WF_HD uint64_t GetSampleIndex() const {
         uint64_t sampleIndex = 0;
         bool pow2Samples = log2spp & 1;
@@ -65,7 +94,7 @@ struct ZSobol {
             int digitShift = 2 * i - (pow2Samples ? 1 : 0);
             int digit = (int)((mortonIndex >> digitShift) & 3);
             uint64_t higherDigits = mortonIndex >> (digitShift + 2);
-            int p = (int)((MixBits(higherDigits ^ (0x55555555u * (uint32_t)dimension)) >> 24) % 24);
+            int p = PermutationIndex(higherDigits, 0x55555555u * (uint32_t)dimension);
             digit = Perm(p, digit);
             sampleIndex |= uint64_t(digit) << digitShift;
         }

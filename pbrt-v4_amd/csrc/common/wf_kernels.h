@@ -489,6 +489,9 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
         // Sample BSDF and enqueue indirect ray
         BSDFSample bs = bsdf.Sample_f(wo, s0.w, V2{s1.x, s1.y});
+#if defined(WF_EXP) && (WF_EXP & 2)
+        bs.valid = false;
+#endif
         if (bs.valid) {
             V3 wi = bs.wi;
             S4 beta = wbeta * bs.f * AbsDot(wi, ns) / bs.pdf;
@@ -517,6 +520,9 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
 
         // Sample light and enqueue shadow ray
         int flags = bsdf.Flags();
+#if defined(WF_EXP) && (WF_EXP & 1)
+        flags = 0;
+#endif
         if (IsNonSpecular(flags)) {
             LightCtx ctx{si.pi, si.n, ns};
             if (IsReflective(flags) && !IsTransmissive(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, wo));
@@ -525,7 +531,12 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
             if (lightId >= 0) {
                 const wf_light &light = sv.lights[lightId];
+#if defined(WF_EXP) && (WF_EXP & 4)
+                LightLiSample ls{};
+                ls.valid = true; ls.L = S4c(1.f); ls.pdf = 1.f; ls.wi = V3{s0.y, s0.z, 0.5f}; ls.pLightPi = ctx.pi; ls.pLightN = N3{0, 1, 0};
+#else
                 LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+#endif
                 if (ls.valid && ls.L && ls.pdf != 0) {
                     V3 wi = ls.wi;
                     S4 f = bsdf.f(wo, wi);

@@ -36,7 +36,7 @@ struct SceneView {
     wf_filter filter;
     const float *filterData;
     wf_sampler sampler;
-    const uint32_t *sobol;  // SobolMatrices32 rows for dimensions 0 and 1 (2 x 52)
+    const uint32_t *sobol;  // WF_SOBOL_WORDS: SobolMatrices32 columns of dimensions 0 and 1 (2 x 52), then their byte tables (FillSobol2D)
     // integrator
     int maxDepth, regularize, haveMedia;
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
@@ -47,7 +47,12 @@ struct SceneView {
 // identity matrix, dimension 1 the Pascal-triangle matrix v[i] = v[i-1] ^ (v[i-1] >> 1); both are padded
 // to SobolMatrixSize = 52 columns the way the reference table is (zeros, resp. the period-32 repeat).
 // The ZSobol sampler (samplers.h:261-291) only ever asks for these two dimensions.
-inline void FillSobol2D(uint32_t out[104]) {
+// Behind the 104 columns come the byte tables SobolSample uses for indices below 2^32: the sample value is
+// the XOR of the columns selected by the index bits (a GF(2) matrix-vector product), so it is also the XOR of four
+// 256-entry tables, one per index byte: lut[dim][k][b] = XOR of columns 8k+j over the set bits j of b.
+constexpr int WF_SOBOL_COLUMNS = 104;
+constexpr int WF_SOBOL_WORDS = WF_SOBOL_COLUMNS + 2 * 4 * 256;
+inline void FillSobol2D(uint32_t out[WF_SOBOL_WORDS]) {
     uint32_t v = 0x80000000u;
     uint32_t d1[32];
     for (int i = 0; i < 32; ++i) { d1[i] = v; v ^= v >> 1; }
@@ -55,6 +60,14 @@ inline void FillSobol2D(uint32_t out[104]) {
         out[i] = i < 32 ? (0x80000000u >> i) : 0u;
         out[52 + i] = d1[i & 31];
     }
+    for (int dim = 0; dim < 2; ++dim)
+        for (int k = 0; k < 4; ++k)
+            for (int b = 0; b < 256; ++b) {
+                uint32_t x = 0;
+                for (int j = 0; j < 8; ++j)
+                    if (b & (1 << j)) x ^= out[dim * 52 + 8 * k + j];
+                out[WF_SOBOL_COLUMNS + (dim * 4 + k) * 256 + b] = x;
+            }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -723,9 +723,9 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.filterData, d->filter_data, (size_t)d->n_filter_floats))) return e;
     sv.sampler = d->sampler;
     if (d->sampler.type != WF_SAMPLER_ZSOBOL) return fail(-1, "only the zsobol sampler is implemented by the HIP kernels");
-    uint32_t sobol[104];
+    static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
-    if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)104))) return e;
+    if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)WF_SOBOL_WORDS))) return e;
     sv.maxDepth = d->max_depth;
     sv.regularize = d->regularize;
     sv.haveMedia = d->have_media;

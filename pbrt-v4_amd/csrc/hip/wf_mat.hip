@@ -14,8 +14,11 @@ using namespace wf;
 
 constexpr int MBLOCK = 256;
 
+#ifndef WF_MAT_WAVES
+#define WF_MAT_WAVES 2
+#endif
 template <int MAT>
-__global__ void __launch_bounds__(MBLOCK) k_eval_material(const SceneView sv, WorkState ws, int cur) {
+__global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE];
     // block-uniform trip count: BlockAlloc inside the body synchronises the workgroup
     for (int base = blockIdx.x * MBLOCK; base < n; base += gridDim.x * MBLOCK) {

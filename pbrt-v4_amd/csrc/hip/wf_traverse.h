@@ -55,7 +55,7 @@ constexpr int NODE_NONE = (int)0x80000000;
 #define WF_TSTACK 12
 #endif
 #ifndef WF_TWAVES
-#define WF_TWAVES 6   // __launch_bounds__ second argument (minimum waves per SIMD) of the traversal kernels
+#define WF_TWAVES 5   // __launch_bounds__ second argument (minimum waves per SIMD) of the traversal kernels
 #endif
 constexpr int TOP_NODES = WF_TOP_NODES;  // QNodes cached in LDS per workgroup (32 B each)
 constexpr int TBLOCK = WF_TBLOCK;        // threads per workgroup of the traversal kernels
@@ -125,15 +125,18 @@ __device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
     const uint32_t lx = __builtin_amdgcn_perm(a.x, a.x, w.selx), ly = __builtin_amdgcn_perm(a.y, a.y, w.sely), lz = __builtin_amdgcn_perm(a.z, a.z, w.selz);
     const uint32_t rx = __builtin_amdgcn_perm(a.w, a.w, w.selx), ry = __builtin_amdgcn_perm(b.x, b.x, w.sely), rz = __builtin_amdgcn_perm(b.y, b.y, w.selz);
     const int left = (int)b.z, right = (int)b.w;
-    const f2 nx = __builtin_elementwise_fma(f2{CvtLo(lx), CvtLo(rx)}, f2{w.a.x, w.a.x}, f2{w.bn.x, w.bn.x});
-    const f2 ny = __builtin_elementwise_fma(f2{CvtLo(ly), CvtLo(ry)}, f2{w.a.y, w.a.y}, f2{w.bn.y, w.bn.y});
-    const f2 nz = __builtin_elementwise_fma(f2{CvtLo(lz), CvtLo(rz)}, f2{w.a.z, w.a.z}, f2{w.bn.z, w.bn.z});
-    const f2 fx = __builtin_elementwise_fma(f2{CvtHi(lx), CvtHi(rx)}, f2{w.af.x, w.af.x}, f2{w.bf.x, w.bf.x});
-    const f2 fy = __builtin_elementwise_fma(f2{CvtHi(ly), CvtHi(ry)}, f2{w.af.y, w.af.y}, f2{w.bf.y, w.bf.y});
-    const f2 fz = __builtin_elementwise_fma(f2{CvtHi(lz), CvtHi(rz)}, f2{w.af.z, w.af.z}, f2{w.bf.z, w.bf.z});
+    // one packed fma per child and axis: {entry, exit} = {qNear, qFar} * {a, af} + {bn, bf}
+    const f2 cx{w.a.x, w.af.x}, cy{w.a.y, w.af.y}, cz{w.a.z, w.af.z};
+    const f2 dx{w.bn.x, w.bf.x}, dy{w.bn.y, w.bf.y}, dz{w.bn.z, w.bf.z};
+    const f2 Lx = __builtin_elementwise_fma(f2{CvtLo(lx), CvtHi(lx)}, cx, dx);
+    const f2 Ly = __builtin_elementwise_fma(f2{CvtLo(ly), CvtHi(ly)}, cy, dy);
+    const f2 Lz = __builtin_elementwise_fma(f2{CvtLo(lz), CvtHi(lz)}, cz, dz);
+    const f2 Rx = __builtin_elementwise_fma(f2{CvtLo(rx), CvtHi(rx)}, cx, dx);
+    const f2 Ry = __builtin_elementwise_fma(f2{CvtLo(ry), CvtHi(ry)}, cy, dy);
+    const f2 Rz = __builtin_elementwise_fma(f2{CvtLo(rz), CvtHi(rz)}, cz, dz);
     // tMin < raytMax && tMax > 0 && tMin <= tMax, relaxed to max(tMin, 0) <= min(tMax, raytMax)
-    const float tL = __builtin_fmaxf(__builtin_fmaxf(nx.x, ny.x), nz.x), tR = __builtin_fmaxf(__builtin_fmaxf(nx.y, ny.y), nz.y);
-    const float eL = __builtin_fminf(__builtin_fminf(fx.x, fy.x), fz.x), eR = __builtin_fminf(__builtin_fminf(fx.y, fy.y), fz.y);
+    const float tL = __builtin_fmaxf(__builtin_fmaxf(Lx.x, Ly.x), Lz.x), tR = __builtin_fmaxf(__builtin_fmaxf(Rx.x, Ry.x), Rz.x);
+    const float eL = __builtin_fminf(__builtin_fminf(Lx.y, Ly.y), Lz.y), eR = __builtin_fminf(__builtin_fminf(Rx.y, Ry.y), Rz.y);
     const bool hitL = __builtin_fmaxf(tL, 0.f) <= __builtin_fminf(eL, w.tMax);
     const bool hitR = __builtin_fmaxf(tR, 0.f) <= __builtin_fminf(eR, w.tMax);
     const bool rightFirst = tR < tL;
