@@ -86,11 +86,11 @@ struct ZSobol {
         const uint32_t q = (s * 43691u) >> 17;          // s / 3 for s < 2^16
         return (int)((s - 3u * q) * 8u + low3);
     }
-    WF_HD uint64_t GetSampleIndex() const {
+    // Digits iHi .. iLo (inclusive) of the permuted index (the loop of samplers.h:324-337)
+    WF_HD uint64_t IndexDigits(int iHi, int iLo) const {
         uint64_t sampleIndex = 0;
-        bool pow2Samples = log2spp & 1;
-        int lastDigit = pow2Samples ? 1 : 0;
-        for (int i = nBase4Digits - 1; i >= lastDigit; --i) {
+        const bool pow2Samples = log2spp & 1;
+        for (int i = iHi; i >= iLo; --i) {
             int digitShift = 2 * i - (pow2Samples ? 1 : 0);
             int digit = (int)((mortonIndex >> digitShift) & 3);
             uint64_t higherDigits = mortonIndex >> (digitShift + 2);
@@ -98,11 +98,30 @@ struct ZSobol {
             digit = Perm(p, digit);
             sampleIndex |= uint64_t(digit) << digitShift;
         }
+        return sampleIndex;
+    }
+    // Digits whose value AND whose permutation depend on the pixel only (digitShift >= log2spp): the same for
+    // every sample index of the pixel, so the device computes them once per pixel, dimension and pass
+    // (KSampleTops) instead of once per ray.
+    WF_HD int SplitDigit() const { return (log2spp + 1) / 2; }
+    WF_HD uint64_t TopDigits() const { return IndexDigits(nBase4Digits - 1, SplitDigit()); }
+    WF_HD uint64_t LowDigits() const {
+        const bool pow2Samples = log2spp & 1;
+        uint64_t sampleIndex = IndexDigits(SplitDigit() - 1, pow2Samples ? 1 : 0);
         if (pow2Samples) {
             int digit = (int)(mortonIndex & 1);
             sampleIndex |= (uint64_t)(digit ^ (int)(MixBits((mortonIndex >> 1) ^ (0x55555555u * (uint32_t)dimension)) & 1));
         }
         return sampleIndex;
+    }
+    bool haveTop = false;
+    uint64_t top = 0;
+    // the next Get*() call uses `t` as its TopDigits() (t must be TopDigits() of this pixel at the current dimension)
+    WF_HD void SetTop(uint64_t t) { haveTop = true; top = t; }
+    WF_HD uint64_t GetSampleIndex() {
+        uint64_t t = haveTop ? top : TopDigits();
+        haveTop = false;
+        return t | LowDigits();
     }
     WF_HD float Get1D() {
         uint64_t sampleIndex = GetSampleIndex();

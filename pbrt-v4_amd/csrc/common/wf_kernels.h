@@ -31,9 +31,7 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_NEXT_CLOSEST = CNT_MAT0 + WF_MAT_NTYPES,  // ray cursors of the persistent traversal kernels
-    CNT_NEXT_SHADOW = CNT_NEXT_CLOSEST + 1,
-    CNT_COUNT = CNT_NEXT_SHADOW + 1
+    CNT_COUNT = CNT_MAT0 + WF_MAT_NTYPES
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
 // (~88 returning atomics/us on MI355X), and with adjacent ints every queue of a stage shared that budget
@@ -66,6 +64,9 @@ struct WorkState {
     F4 *lambda, *lambdaPdf, *L, *cameraRayWeight;
     F4 *samples0;  // direct.uc, direct.u.x, direct.u.y, indirect.uc
     F4 *samples1;  // indirect.u.x, indirect.u.y, indirect.rr, -
+    // ZSobol TopDigits() of every pixel of the band for the five dimensions one stage draws (dim0 + {0,1,3,4,6}),
+    // [5][pixelsPerPass]; refreshed by KSampleTops before the stage.  Null: not used (CPU checker, > 32-bit indices).
+    uint32_t *sampleTops;
     RayQueueV rq[2];
     F4 *hit;       // per ray slot of the current queue: triangle id (int bits), b0, b1, b2
     int32_t *escapedQ, *hitLightQ;
@@ -179,7 +180,24 @@ WF_HD int KCameraRayCount(const SceneView &sv, const WorkState &ws, int y0, int 
 
 // ---------------------------------------------------------------------------------------------
 // K2: GenerateCameraRays, wavefront/camera.cpp:35-79
-WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixelIndex, int y0, int sampleBase, int sampleStep, int nSamples) {
+// sampler dimension offsets drawn by one stage: camera rays use dims 0, 1(+2), 3, 4(+5) (samplers.h:796-814); ray
+// samples use dim0 + {0, 1(+2), 3, 4(+5), 6} (samples.cpp:39-58)
+WF_HD int SampleTopOffset(int k) { return k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 3 : (k == 3 ? 4 : 6))); }
+// TopDigits() of band pixel p for the five dimensions starting at dim0 -> ws.sampleTops
+WF_HD void KSampleTops(const SceneView &sv, const WorkState &ws, int item, int y0, int dim0) {
+    const wf_film &F = sv.film;
+    const int k = item / ws.pixelsPerPass, p = item - k * ws.pixelsPerPass;
+    int xResolution = F.pixel_max[0] - F.pixel_min[0];
+    int px = F.pixel_min[0] + p % xResolution;
+    int py = y0 + p / xResolution;
+    if (py >= F.pixel_max[1]) return;
+    ZSobol sampler(sv);
+    sampler.StartPixelSample(px, py, 0, dim0 + SampleTopOffset(k));
+    ws.sampleTops[item] = (uint32_t)sampler.TopDigits();
+}
+
+WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixelIndex, int y0, int sampleBase, int sampleStep, int nSamples,
+                              bool useTops = false) {
     // pixelIndex = item index: sample slot s = pixelIndex / pixelsPerPass, band pixel p = pixelIndex % pixelsPerPass
     const wf_film &F = sv.film;
     int xResolution = F.pixel_max[0] - F.pixel_min[0];
@@ -192,13 +210,19 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     if (!(px >= F.pixel_min[0] && px < F.pixel_max[0] && py >= F.pixel_min[1] && py < F.pixel_max[1])) return;
     ZSobol sampler(sv);
     sampler.StartPixelSample(px, py, sampleIndex, 0);
+    const uint32_t *tops = useTops ? ws.sampleTops + p : nullptr;
+    const int tstride = ws.pixelsPerPass;
+    if (useTops) sampler.SetTop(tops[0]);
     float lu = sampler.Get1D();
     if (sv.options.disable_wavelength_jitter) lu = 0.5f;
     Wavelengths lambda = SampleVisible(lu);
     // GetCameraSample, samplers.h:796-814
+    if (useTops) sampler.SetTop(tops[tstride]);
     FilterSampleR fs = FilterSample(sv, sampler.GetPixel2D());
     V2 pFilm{px + fs.p.x + 0.5f, py + fs.p.y + 0.5f};
+    if (useTops) sampler.SetTop(tops[2 * tstride]);
     float time = sampler.Get1D();
+    if (useTops) sampler.SetTop(tops[3 * tstride]);
     V2 pLens = sampler.Get2D();
     float filterWeight = fs.weight;
     if (sv.options.disable_pixel_jitter) {
@@ -228,18 +252,29 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
 }
 
 // K3: GenerateRaySamples, wavefront/samples.cpp:35-65 (no subsurface: dimension = 6 + 7*depth)
-WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur, int i, int sampleBase, int sampleStep) {
+// topsDepth >= 0: ws.sampleTops holds the tops of dimension 6 + 7 * topsDepth (rays at another depth — re-pushed
+// through interface materials — take the generic path)
+WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur, int i, int sampleBase, int sampleStep, int topsDepth = -1) {
     I4 m = ws.rq[cur].meta[i];
     int pixelIndex = m.x, depth = m.y;
-    const int sampleIndex = sampleBase + (pixelIndex / ws.pixelsPerPass) * sampleStep;
+    const int slot = pixelIndex / ws.pixelsPerPass;
+    const int sampleIndex = sampleBase + slot * sampleStep;
     int dimension = 6 + 7 * depth;
     ZSobol sampler(sv);
     I2 pp = ws.pPixel[pixelIndex];
     sampler.StartPixelSample(pp.x, pp.y, sampleIndex, dimension);
+    const bool useTops = depth == topsDepth;
+    const uint32_t *tops = useTops ? ws.sampleTops + (pixelIndex - slot * ws.pixelsPerPass) : nullptr;
+    const int tstride = ws.pixelsPerPass;
+    if (useTops) sampler.SetTop(tops[0]);
     float duc = sampler.Get1D();
+    if (useTops) sampler.SetTop(tops[tstride]);
     V2 du = sampler.Get2D();
+    if (useTops) sampler.SetTop(tops[2 * tstride]);
     float iuc = sampler.Get1D();
+    if (useTops) sampler.SetTop(tops[3 * tstride]);
     V2 iu = sampler.Get2D();
+    if (useTops) sampler.SetTop(tops[4 * tstride]);
     float rr = sampler.Get1D();
     ws.samples0[pixelIndex] = F4{duc, du.x, du.y, iuc};
     ws.samples1[pixelIndex] = F4{iu.x, iu.y, rr, 0.f};
@@ -339,6 +374,77 @@ WF_HD void KAfterClosestHitBlock(const SceneView &sv, const WorkState &ws, int c
         if (slot >= 0) ws.matQ[t][slot] = i;
     }
 }
+
+#if defined(__HIPCC__)
+// The routing of a whole workgroup's batch in ONE allocation round (two barriers instead of three per
+// destination queue).  `route` = the triangle's build-time routing code (LeafTri.c.w): material type |
+// emissive << 4 | interface << 5, so nothing is gathered per hit.  Destinations: 0 escaped, 1 emitter hit,
+// 2 re-pushed ray (interface material), 2 + t material type t.
+__device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, uint32_t route,
+                                      float b0, float b1, float b2) {
+    constexpr int NID = 3 + WF_MAT_NTYPES;
+    __shared__ int s_cnt[NID][16];
+    __shared__ int s_base[NID];
+    const bool found = valid && prim >= 0;
+    unsigned dest = 0;
+    if (valid && !found && sv.nInfiniteLights > 0) dest = 1u;
+    if (found) {
+        ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
+        if (route & 16u) dest |= 2u;
+        if ((route & 32u) && sv.haveMedia) dest |= 4u;
+        if (route & 15u) dest |= 4u << (route & 15u);
+    }
+    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? 4u : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2);
+    const unsigned lane = __lane_id();
+    const int wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    auto counterOf = [&](int id) {
+        int c = id == 0 ? CNT_ESCAPED : (id == 1 ? CNT_HITLIGHT : (id == 2 ? CNT_RAY0 + (cur ^ 1) : CNT_MAT0 + (id - 2)));
+        return &ws.counters[c * CNT_STRIDE];
+    };
+    for (unsigned m = active; m; m &= m - 1) {
+        const int id = __builtin_ctz(m);
+        const unsigned long long mask = __ballot((dest >> id) & 1u);
+        if (lane == 0) s_cnt[id][wave] = __popcll(mask);
+    }
+    __syncthreads();
+    if (threadIdx.x < NID && ((active >> threadIdx.x) & 1u)) {
+        int total = 0;
+        for (int w = 0; w < nWaves; ++w) total += s_cnt[threadIdx.x][w];
+        s_base[threadIdx.x] = total > 0 ? atomicAdd(counterOf(threadIdx.x), total) : 0;
+    }
+    __syncthreads();
+    for (unsigned m = active; m; m &= m - 1) {
+        const int id = __builtin_ctz(m);
+        const bool mine = (dest >> id) & 1u;
+        const unsigned long long mask = __ballot(mine);
+        if (!mine) continue;
+        int slot = s_base[id] + __popcll(mask & below);
+        for (int w = 0; w < wave; ++w) slot += s_cnt[id][w];
+        if (id == 0) ws.escapedQ[slot] = i;
+        else if (id == 1) ws.hitLightQ[slot] = i;
+        else if (id == 2) {
+            // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
+            const RayQueueV &q = ws.rq[cur];
+            const RayQueueV &nq = ws.rq[cur ^ 1];
+            SurfIntr si;
+            TriangleInteraction(sv, prim, b0, b1, b2, &si);
+            F4 o = q.o[i], d = q.d[i];
+            V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
+            nq.o[slot] = F4{no.x, no.y, no.z, o.w};
+            nq.d[slot] = d;
+            nq.beta[slot] = q.beta[i];
+            nq.r_u[slot] = q.r_u[i];
+            nq.r_l[slot] = q.r_l[i];
+            nq.ctx0[slot] = q.ctx0[i];
+            nq.ctx1[slot] = q.ctx1[i];
+            nq.ctx2[slot] = q.ctx2[i];
+            nq.meta[slot] = q.meta[i];
+        } else ws.matQ[id - 2][slot] = i;
+    }
+    __syncthreads();  // s_cnt / s_base are reused by the next batch
+}
+#endif
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537
 WF_HD void KHandleEscaped(const SceneView &sv, const WorkState &ws, int cur, int qi) {

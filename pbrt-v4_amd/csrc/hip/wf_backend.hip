@@ -16,6 +16,7 @@
 // fma calls of the restated arithmetic, as in the reference's CPU build).
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -72,9 +73,9 @@ struct wf_ctx {
     struct Ev { std::string name; hipEvent_t a, b; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> eventPool;
+    int passY0 = INT_MIN;        // first scanline of the band of the last wf_gen_camera_rays
     int passStep = 1, passSamples = 1;  // wf_set_pass_samples: sample-index stride and sample slots used by the current pass
     bool countTraversal = false;
-    int plThreshold = 0;         // WF_PL_THRESHOLD > 0: per-lane-refill traversal kernels (k_closest_pl / k_shadow_pl)
     bool traceLaunch = false;    // WF_TRACE_LAUNCH=1: print every launch and synchronise after it (debugging)
 };
 
@@ -108,15 +109,19 @@ __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, in
     if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) ws.counters[(threadIdx.x) * CNT_STRIDE] = 0;
 }
 
+__global__ void __launch_bounds__(BLOCK) k_sample_tops(const SceneView sv, WorkState ws, int y0, int dim0) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < 5 * ws.pixelsPerPass; i += gridDim.x * BLOCK) KSampleTops(sv, ws, i, y0, dim0);
+}
 __global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleBase, int sampleStep, int nSamples) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, nSamples);
+    const bool useTops = ws.sampleTops != nullptr;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
-        KGenerateCameraRay(sv, ws, i, y0, sampleBase, sampleStep, nSamples);
+        KGenerateCameraRay(sv, ws, i, y0, sampleBase, sampleStep, nSamples, useTops);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleBase, int sampleStep) {
+__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleBase, int sampleStep, int topsDepth) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleBase, sampleStep);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleBase, sampleStep, topsDepth);
 }
 
 // LDS short stack with HBM spill: one column per lane ([entry][lane] so a wave's same-depth accesses hit
@@ -235,6 +240,7 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
         RayWalk w;
         w.node = NODE_NONE;
         w.prim = -1;
+        w.route = 0;
         w.b0 = w.b1 = w.b2 = 0;
         if (valid) {
             V3 o, d;
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneV
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
         },
-        [&](int i, bool valid, const RayWalk &w) { KAfterClosestHitBlock(sv, ws, cur, i, valid, w.prim, w.b0, w.b1, w.b2); });
+        [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock(sv, ws, cur, i, valid, w.prim, w.route, w.b0, w.b1, w.b2); });
 }
 __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
@@ -289,124 +295,6 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneVi
         },
         [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
 }
-// ---- variant: persistent waves with PER-LANE refill from a register-resident prefetch batch ----
-// A wave keeps one prefetched ray per lane (64 consecutive queue entries, loaded with one atomic).  Lanes
-// whose ray has finished store its 16-byte result (fire and forget — the queue routing is a separate
-// streaming kernel, k_route_hits) and take the next unconsumed prefetched ray through ds_bpermute; the batch
-// is reloaded when it runs dry.  Refills happen when fewer than `threshold` lanes are still walking.
-template <bool ANY, typename Fetch, typename Store>
-__device__ inline void RefillTrace(const FastBVH &bvh, int n, int32_t *cursor, int threshold, LdsStackT &st, Fetch fetch, Store store) {
-    LoadTreeTop(bvh);
-    const unsigned lane = __lane_id();
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-    int pfUsed = 0, pfCount = 0;   // wave-uniform
-    bool more = true;              // wave-uniform: the cursor has not run past n
-    V3 po{0, 0, 0}, pd{0, 0, 1};
-    float ptmax = 0;
-    auto loadBatch = [&]() {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(cursor, 64);
-        base = __builtin_amdgcn_readfirstlane(base);
-        pfUsed = 0;
-        int c = n - base;
-        pfCount = c < 0 ? 0 : (c > 64 ? 64 : c);
-        if (base + 64 >= n) more = false;
-        if ((int)lane < pfCount) fetch(base + (int)lane, &po, &pd, &ptmax);
-        return base;
-    };
-    int pfBase = loadBatch();
-    RayWalk w;
-    w.node = NODE_NONE;
-    w.prim = -1;
-    w.b0 = w.b1 = w.b2 = 0;
-    int idx = -1;
-    while (true) {
-        if (w.node == NODE_NONE && idx >= 0) {
-            store(idx, w);
-            idx = -1;
-        }
-        bool need = idx < 0;
-        while (true) {
-            unsigned long long needMask = __ballot(need);
-            if (!needMask) break;
-            int avail = pfCount - pfUsed;
-            if (avail <= 0) {
-                if (!more) break;
-                pfBase = loadBatch();
-                avail = pfCount;
-                if (avail <= 0) break;
-            }
-            int rank = __popcll(needMask & ltMask);
-            int src = pfUsed + rank;
-            bool take = need && rank < avail;
-            int srcc = src < 63 ? src : 63;
-            float ox = __shfl(po.x, srcc), oy = __shfl(po.y, srcc), oz = __shfl(po.z, srcc);
-            float dx = __shfl(pd.x, srcc), dy = __shfl(pd.y, srcc), dz = __shfl(pd.z, srcc);
-            float tm = __shfl(ptmax, srcc);
-            if (take) {
-                WalkInit(bvh, w, V3{ox, oy, oz}, V3{dx, dy, dz}, tm);
-                st.n = 0;
-                idx = pfBase + src;
-                need = false;
-            }
-            int taken = __popcll(needMask);
-            pfUsed += taken < avail ? taken : avail;
-        }
-        if (!__any(w.node != NODE_NONE)) break;
-        do {
-            while (__any(w.node >= 0)) {
-                if (w.node >= 0) {
-                    U4 a, b;
-                    if (w.node < TOP_NODES) { a = g_top[2 * w.node]; b = g_top[2 * w.node + 1]; }
-                    else {
-                        const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
-                        a = p[0]; b = p[1];
-                    }
-                    InteriorStep(w, st, a, b);
-                }
-            }
-            if (w.node != NODE_NONE) LeafStep<ANY>(bvh, w, st);
-        } while (__popcll(__ballot(w.node != NODE_NONE)) >= threshold);
-    }
-}
-
-__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_pl(WorkState ws, FastBVH bvh, int cur, int threshold, int *stackSpill) {
-    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
-    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
-    const RayQueueV q = ws.rq[cur];
-    RefillTrace<false>(
-        bvh, n, &ws.counters[(CNT_NEXT_CLOSEST) * CNT_STRIDE], threshold, st,
-        [&](int i, V3 *o, V3 *d, float *tMax) {
-            F4 o4 = q.o[i], d4 = q.d[i];
-            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
-        },
-        [&](int i, const RayWalk &w) { ws.hit[i] = F4{BitsToFloat((uint32_t)w.prim), w.b0, w.b1, w.b2}; });
-}
-// routes the hit records written by k_closest_pl: EnqueueWorkAfterMiss / EnqueueWorkAfterIntersection
-__global__ void __launch_bounds__(BLOCK) k_route_hits(const SceneView sv, WorkState ws, int cur) {
-    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
-    for (int base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
-        const int i = base + threadIdx.x;
-        const bool valid = i < n;
-        F4 h{BitsToFloat(0xffffffffu), 0, 0, 0};
-        if (valid) h = ws.hit[i];
-        KAfterClosestHitBlock(sv, ws, cur, i, valid, (int)FloatToBits(h.x), h.y, h.z, h.w);
-    }
-}
-__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_pl(WorkState ws, FastBVH bvh, int threshold, int *stackSpill) {
-    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
-    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
-    RefillTrace<true>(
-        bvh, n, &ws.counters[(CNT_NEXT_SHADOW) * CNT_STRIDE], threshold, st,
-        [&](int i, V3 *o, V3 *d, float *tMax) {
-            F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
-            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
-        },
-        [&](int i, const RayWalk &w) { KRecordShadowRay(ws, i, w.prim >= 0); });
-}
-
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
@@ -566,7 +454,13 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         // IntersectTriangle's first test (shapes.cpp:172-173), hoisted to build time
         V3 q0{p0[0], p0[1], p0[2]}, q1{p1[0], p1[1], p1[2]}, q2{p2[0], p2[1], p2[2]};
         bool degenerate = LengthSquared(Cross(q2 - q0, q1 - q0)) == 0;
-        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : 0.f, 0.f};
+        // routing code of EnqueueWorkAfterIntersection (intersect.h:48-156), so that the traversal kernel needs no
+        // per-hit mesh / material gathers: material type | emissive << 4 | interface << 5
+        const wf_mesh &mesh = d->meshes[d->tri_mesh[t]];
+        uint32_t route = 0;
+        if (mesh.material >= 0) route = (uint32_t)d->materials[mesh.material].type | (mesh.first_light >= 0 ? 16u : 0u);
+        else route = 32u;
+        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : 0.f, BitsToFloat(route)};
         (*tris)[k] = lt;
     }
     // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
@@ -761,7 +655,6 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         const int maxG = MAX_GRID * BLOCK / TBLOCK;  // stackSpill is sized for MAX_GRID * BLOCK threads
         ctx->persistentGrid = g > maxG ? maxG : (g < 1 ? 1 : g);
         if (getenv("WF_NO_FAST")) ctx->fastOk = false;
-        if (const char *v = getenv("WF_PL_THRESHOLD")) ctx->plThreshold = atoi(v);
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
@@ -808,6 +701,10 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
         (e = devAlloc(ctx, &ws.lambdaPdf, n)) || (e = devAlloc(ctx, &ws.L, n)) || (e = devAlloc(ctx, &ws.cameraRayWeight, n)) ||
         (e = devAlloc(ctx, &ws.samples0, n)) || (e = devAlloc(ctx, &ws.samples1, n)))
         return e;
+    // pixel-only sample-index digits (wf_camera.h TopDigits): usable while the permuted index fits 32 bits
+    ws.sampleTops = nullptr;
+    if (2 * ctx->svHost.sampler.nBase4Digits <= 32 && !getenv("WF_NO_SAMPLE_TOPS"))
+        if ((e = devAlloc(ctx, &ws.sampleTops, (size_t)5 * pixels_per_pass))) return e;
     if ((e = allocRayQueue(ctx, &ws.rq[0], n)) || (e = allocRayQueue(ctx, &ws.rq[1], n))) return e;
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
@@ -847,7 +744,7 @@ int wf_reset_ray_queue(wf_ctx *ctx, int which) {
 int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     const int cur = depth & 1;
-    unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT) | (1u << CNT_NEXT_CLOSEST);
+    unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + depth, CNT_RAY0 + cur);
@@ -855,13 +752,20 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
 }
 int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
     if (int e = checkReady(ctx)) return e;
+    ctx->passY0 = y0;
+    if (ctx->ws.sampleTops) LAUNCH("Sampler index prefixes", k_sample_tops, gridFor(5 * ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, y0, 0);
     LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index, ctx->passStep, ctx->passSamples);
     LAUNCH("Update camera ray stats", k_reset, 1, ctx->ws, 0u, 0, CNT_RAY0);
     return 0;
 }
 int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, sample_index, ctx->passStep);
+    // the pixel-only digits of the sample-index permutation, once per pixel and dimension instead of once per ray
+    // (needs the band of the pass: the y0 of the last wf_gen_camera_rays)
+    const bool tops = ctx->ws.sampleTops != nullptr && ctx->passY0 != INT_MIN;
+    if (tops) LAUNCH("Sampler index prefixes", k_sample_tops, gridFor(5 * ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, ctx->passY0, 6 + 7 * depth);
+    LAUNCH("Generate ray samples - ZSobolSampler", k_gen_ray_samples, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, sample_index, ctx->passStep,
+           tops ? depth : -1);
     return 0;
 }
 int wf_intersect_closest(wf_ctx *ctx, int depth) {
@@ -870,10 +774,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     // otherwise the production traversal (wf_traverse.h)
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
-    else if (ctx->fastOk && ctx->plThreshold > 0) {
-        LAUNCHT("Intersect closest", k_closest_pl, ctx->persistentGrid, ctx->ws, ctx->fast, depth & 1, depth == 0 ? 1 : ctx->plThreshold, ctx->stackSpill);
-        LAUNCH("Route hits", k_route_hits, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
-    } else if (ctx->fastOk)
+    else if (ctx->fastOk)
         LAUNCHT("Intersect closest", k_closest_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
     else
         LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
@@ -917,14 +818,12 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
-    else if (ctx->fastOk && ctx->plThreshold > 0)
-        LAUNCHT("Intersect shadow", k_shadow_pl, ctx->persistentGrid, ctx->ws, ctx->fast, ctx->plThreshold, ctx->stackSpill);
     else if (ctx->fastOk)
         LAUNCHT("Intersect shadow", k_shadow_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
-    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW) | (1u << CNT_NEXT_SHADOW), 65 + depth, CNT_SHADOW);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + depth, CNT_SHADOW);
     return 0;
 }
 int wf_update_film(wf_ctx *ctx) {

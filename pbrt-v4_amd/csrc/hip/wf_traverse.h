@@ -40,7 +40,7 @@ struct alignas(16) QNode {
 struct alignas(16) LeafTri {
     F4 a;  // p0.xyz, p1.x
     F4 b;  // p1.yz, p2.xy
-    F4 c;  // p2.z, triangle id (int bits), 1.0 if the triangle is degenerate (zero-length normal) else 0, -
+    F4 c;  // p2.z, triangle id (int bits), 1.0 if the triangle is degenerate (zero-length normal) else 0, routing code (int bits)
 };
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 
@@ -79,6 +79,7 @@ struct RayWalk {
     uint32_t selx, sely, selz;  // v_perm selectors: put the near plane in the low half, the far plane in the high half
     int node;  // current ref; NODE_NONE = finished
     int prim;
+    uint32_t route;  // routing code of the hit triangle (LeafTri.c.w)
     float b0, b1, b2;
 };
 
@@ -111,6 +112,7 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     w.selx = sel[0]; w.sely = sel[1]; w.selz = sel[2];
     w.node = 0;
     w.prim = -1;
+    w.route = 0;
     w.b0 = w.b1 = w.b2 = 0;
 }
 
@@ -159,6 +161,7 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st) {
         if (tc.z == 0.f &&
             IntersectTriangleSheared(w.o, w.sh, w.tMax, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
             w.prim = (int)FloatToBits(tc.y);
+            w.route = FloatToBits(tc.w);
             w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;
             w.tMax = h.t;
             if (ANY) { done = true; break; }
