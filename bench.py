@@ -205,9 +205,16 @@ def main():
                 avg_ms = ms.value / launches
                 bytes_per_launch = bytes_per_ray * rays_closest / launches
                 gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                # measured HBM bytes per launch: PMC passes cannot run inside this process; the committed rocprofv3
+                # FETCH_SIZE/WRITE_SIZE summary of the same kernel on the same workload (profiles/pmc_traffic.json,
+                # bytes per ray, corrected as MI355X_MICROARCH.md prescribes) scaled to this run's rays per launch
+                traffic = None
+                tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if a.workload == "killeroo-like" and os.path.exists(tp):
+                    traffic = json.load(open(tp))["hbm_bytes_per_ray"] * rays_closest / launches
                 out["roofline"] = {
-                    "bound": "hbm", "kernel": "Intersect closest (k_intersect_closest)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                    "bound": "hbm", "kernel": "Intersect closest (k_closest_fast)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
                     "nodes_per_ray": counters["closest_nodes"] / counters["closest_rays"],
                     "tris_per_ray": counters["closest_tris"] / counters["closest_rays"],

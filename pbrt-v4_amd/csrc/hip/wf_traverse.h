@@ -5,25 +5,26 @@
 // -> P); it stays as the *counting* variant, because SURVEY.md §8(d) defines the roofline's algorithmic
 // bytes on exactly those visit counts.  The kernels that render use the layout and loop below instead.
 //
-// What bounds traversal on MI355X (profiles/r01_*pmc*): not HBM and not VALU (10 % busy) but the per-CU
-// vector L1 (TCP): every lane of a wave gathers its own node, the TCP retires about one tag lookup per
-// clock, and it is ~87 % busy.  So the design minimises L1 lookups per ray:
+// What bounds traversal on MI355X (profiles/r01_*pmc*): not HBM.  With launches of millions of rays the walk is
+// bounded by VALU issue (56-75 % busy at ~30 % active lanes) and by the latency of the dependent node fetches, so
+// the design minimises instructions and fetches per visited node:
 //
-//  * QNode (32 B, two dwordx4): an interior node carries BOTH children's bounds, quantised to 16 bits per
-//    plane on a global grid over the scene bounds, rounded outwards.  One fetch feeds two slab tests;
-//    half the bytes (and lookups) of two float boxes.  Outward rounding keeps results exact: the slab
-//    test (same formula as Bounds3::IntersectP) on a superset box passes whenever the reference's test on
-//    the exact box passes, and WHICH triangle is hit is decided only by the (exact, float) triangle test.
-//  * the top TOP_NODES nodes of the tree (breadth-first numbering, ~10 levels) are copied into LDS by each
-//    workgroup at kernel start: most of a ray's interior visits are served by ds_read_b128 (LDS has
-//    128 B/clk/CU to spare) and never touch the TCP.
+//  * QNode (32 B, two dwordx4): an interior node carries BOTH children's bounds, quantised to 16 bits per plane on
+//    a global grid over the scene bounds, with build-time outward margins.  One fetch feeds two slab tests.
+//  * the slab test runs in grid coordinates: WalkInit folds the grid (base, cell), the ray (o, 1/d), the
+//    reference's (1 + 2 gamma(3)) factor and an evaluation-error slack into per-ray constants, so a plane costs one
+//    v_cvt (SDWA half-word select) and half a v_pk_fma; near/far planes are swapped per ray with v_perm; min/max
+//    are v_max3/v_min3.  No branches inside the step.  The test is a superset of Bounds3::IntersectP on the exact
+//    box (it passes whenever the reference's test passes); WHICH triangle is hit is decided only by the exact,
+//    float triangle test, so results are the reference's.
+//  * the top TOP_NODES nodes of the tree (breadth-first numbering, ~9 levels) are copied into LDS by each
+//    workgroup at kernel start: most of a ray's interior visits are served by ds_read_b128.
 //  * LeafTri (48 B, three dwordx4): the three vertices of each triangle in BVH leaf order — the
-//    "3 indices + 3 Point3f" of the §8(d) formula as one contiguous record, no index chase.
+//    "3 indices + 3 Point3f" of the §8(d) formula as one contiguous record, no index chase — plus the triangle's
+//    routing code (material type / emissive / interface), so the end-of-batch routing gathers nothing.
 //  * children are visited nearest-entry first; the node stack lives in LDS, one column per lane.
-//  * persistent waves ("while-while"): a wave pulls 64 consecutive rays with one atomic, all lanes descend
-//    interior nodes until every lane sits at a leaf, leaves are processed together, results are written
-//    together when the whole wave is done (whole-wave refill measured faster than per-lane refill: mixing
-//    rays destroys the little coherence consecutive queue entries have).
+//  * "while-while": all lanes of a wave descend interior nodes until every lane sits at a leaf, leaves are
+//    processed together, a workgroup finishes a batch of TBLOCK rays together (block-aggregated queue pushes).
 //
 // Exact ties in t between two triangles are the one case where visiting order can pick the other triangle
 // (same t): tests/test_gpu_parity.py allows a different triangle id only at bit-equal t.
@@ -148,7 +149,7 @@ __device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
     } else if (hitL | hitR) w.node = hitL ? left : right;
     else w.node = st.empty() ? NODE_NONE : st.pop();
 }
-// Leaf: <= 16 triangle tests.  Precondition: w.node < 0 && w.node != NODE_NONE.  ANY: stop at the first hit.
+// Leaf: <= 16 triangle tests.  ANY: stop at the first hit.  Precondition: w.node < 0 && w.node != NODE_NONE.
 template <bool ANY, typename Stack>
 __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st) {
     unsigned ref = ~(unsigned)w.node;
