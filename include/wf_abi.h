@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 1
+#define WF_ABI_VERSION 2
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -44,6 +44,23 @@ typedef struct wf_transform {    /* util/transform.h:Transform — m and its inv
     float m[4][4];
     float mInv[4][4];
 } wf_transform;
+
+/* Medium (media.h:226-352): HomogeneousMedium and GridMedium ("uniformgrid"), both with the Henyey-Greenstein
+ * phase function.  Spectra are DenselySampledSpectrum tables (471 floats each in spectrum_data), already
+ * multiplied by the medium's "scale" / Le scale as the reference's constructors do (media.h:233-241). */
+enum wf_medium_type { WF_MEDIUM_HOMOGENEOUS = 0, WF_MEDIUM_GRID = 1 };
+typedef struct wf_medium {
+    int32_t type;
+    int32_t sigma_a_offset, sigma_s_offset, le_offset;   /* offsets into spectrum_data */
+    float g;
+    int32_t is_emissive;
+    /* GridMedium only */
+    float bounds[6];                 /* medium-space box p0, p1 */
+    wf_transform render_from_medium;
+    int32_t nx, ny, nz, density_offset;                 /* SampledGrid<Float> density, offsets into medium_data */
+    int32_t le_nx, le_ny, le_nz, le_scale_offset;       /* SampledGrid<Float> LeScale (already times 1/photometric(Le)) */
+    int32_t maj_res[3], maj_offset;                     /* MajorantGrid 16^3 (media.h:105-133) */
+} wf_medium;
 
 /* Spectrum (util/spectrum.h:48-67 TaggedPointer family) flattened to a 32-byte descriptor.
  * Sample values live in wf_scene_desc::spectrum_data (float pool). */
@@ -289,6 +306,10 @@ typedef struct wf_scene_desc {
     int32_t regularize;
     int32_t have_media;
     wf_options options;
+    /* participating media (media.h): ids referenced by wf_mesh.medium_inside/outside, wf_camera.medium */
+    int32_t n_media, n_medium_floats;
+    const struct wf_medium *media;
+    const float *medium_data;    /* density / Lescale / majorant grids */
 } wf_scene_desc;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -389,6 +410,9 @@ int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index);
 int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index);
 /* K4: WavefrontAggregate::IntersectClosest (integrator.h:37-43) */
 int wf_intersect_closest(wf_ctx *ctx, int depth);
+/* K5 + K6: SampleMediumInteraction (wavefront/media.cpp:22-257) then SampleMediumScattering<HGPhaseFunction>
+   (:259-352) — delta tracking through the medium of every ray with ray.medium set; no-op without media */
+int wf_medium_sample(wf_ctx *ctx, int depth);
 /* K7/K8: HandleEscapedRays / HandleEmissiveIntersection (integrator.cpp:495-573) */
 int wf_handle_escaped(wf_ctx *ctx, int depth);
 int wf_handle_emissive(wf_ctx *ctx, int depth);
@@ -396,6 +420,9 @@ int wf_handle_emissive(wf_ctx *ctx, int depth);
 int wf_eval_material(wf_ctx *ctx, int material_type, int depth);
 /* K10: WavefrontAggregate::IntersectShadow (integrator.h:45-46) + RecordShadowRayResult */
 int wf_intersect_shadow(wf_ctx *ctx, int depth);
+/* K11: WavefrontAggregate::IntersectShadowTr (integrator.h:48-49; TraceTransmittance, intersect.h:165-274): the
+   shadow-ray stage of scenes with media (ratio tracking through interface surfaces) */
+int wf_intersect_shadow_tr(wf_ctx *ctx, int depth);
 /* K13: UpdateFilm (wavefront/film.cpp:14-38) */
 int wf_update_film(wf_ctx *ctx);
 

@@ -65,6 +65,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     for (int i = 0; i < 6; ++i) sv.allLightBounds[i] = d.all_light_bounds[i];
     sv.camera = d.camera; sv.film = d.film; sv.filter = d.filter; sv.filterData = d.filter_data; sv.sampler = d.sampler;
     sv.sobol = sobol;
+    sv.media = d.media; sv.mediumData = d.medium_data;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;
     sv.matTypeMask = 0;
     for (int i = 0; i < d.n_materials; ++i) sv.matTypeMask |= 1 << d.materials[i].type;
@@ -173,6 +174,10 @@ int main(int argc, char **argv) {
     ws.escapedQ = Alloc<int32_t>(n); ws.hitLightQ = Alloc<int32_t>(n);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.matQ[m] = Alloc<int32_t>(T.materialTypePresent[m] ? n : 1);
     ws.sq.o = Alloc<F4>(n); ws.sq.d = Alloc<F4>(n); ws.sq.Ld = Alloc<F4>(n); ws.sq.r_u = Alloc<F4>(n); ws.sq.r_l = Alloc<F4>(n);
+    if (sv.haveMedia) {
+        ws.hitT = Alloc<float>(n); ws.mediumSampleQ = Alloc<int32_t>(n); ws.mediumScatterQ = Alloc<int32_t>(n);
+        ws.scatterP = Alloc<F4>(n); ws.sq.medium = Alloc<int32_t>(n);
+    }
     ws.counters = Alloc<int32_t>(CNT_COUNT * CNT_STRIDE);
     const wf_film &F = T.desc.film;
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
@@ -203,6 +208,7 @@ int main(int argc, char **argv) {
                 ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE] = 0;
                 ws.counters[(CNT_ESCAPED) * CNT_STRIDE] = ws.counters[(CNT_HITLIGHT) * CNT_STRIDE] = 0;
                 for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.counters[(CNT_MAT0 + m) * CNT_STRIDE] = 0;
+                ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE] = ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE] = 0;
                 const int nRays = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
                 ws.stats[1 + depth] += nRays;
                 ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex, sampleStep); });
@@ -213,7 +219,7 @@ int main(int argc, char **argv) {
                     ClosestHit ch;
                     bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
                     nv += ch.nodesVisited; nt += ch.trisTested;
-                    KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.b0, ch.h.b1, ch.h.b2);
+                    KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
                 });
                 nodesVisited += nv; trisTested += nt;
                 if (dumpNow && depth == 0) {
@@ -241,6 +247,12 @@ int main(int argc, char **argv) {
                     }
                     fclose(f);
                 }
+                if (sv.haveMedia) {
+                    // SampleMediumInteraction, integrator.cpp:416 (K5, then K6 unless this is the last depth)
+                    ParallelFor(ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE], [&](int i) { KSampleMediumInteraction(sv, ws, cur, i); });
+                    if (depth != maxDepth)
+                        ParallelFor(ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE], [&](int i) { KSampleMediumScattering(sv, ws, cur, i); });
+                }
                 ParallelFor(ws.counters[(CNT_ESCAPED) * CNT_STRIDE], [&](int i) { KHandleEscaped(sv, ws, cur, i); });
                 ParallelFor(ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
                 if (depth == maxDepth) break;
@@ -252,6 +264,17 @@ int main(int argc, char **argv) {
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_DIFFUSE>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_CONDUCTOR>(sv, ws, cur, i, true); });
                 const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+                if (sv.haveMedia)
+                    ParallelFor(nShadow, [&](int i) {
+                        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, float *b0, float *b1, float *b2) {
+                            ArrayStack st;
+                            ClosestHit ch;
+                            bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+                            if (found) { *prim = ch.prim; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+                            return found;
+                        });
+                    });
+                else
                 ParallelFor(nShadow, [&](int i) {
                     F4 o = ws.sq.o[i], d = ws.sq.d[i];
                     ArrayStack st;

@@ -20,6 +20,7 @@
 #include "wf_bxdf.h"
 #include "wf_camera.h"
 #include "wf_lights.h"
+#include "wf_media.h"
 
 namespace wf {
 
@@ -31,7 +32,8 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_COUNT = CNT_MAT0 + WF_MAT_NTYPES
+    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER,
+    CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
 // (~88 returning atomics/us on MI355X), and with adjacent ints every queue of a stage shared that budget
@@ -51,6 +53,7 @@ struct ShadowQueueV {
     F4 *o;     // o.xyz, tMax
     F4 *d;     // d.xyz, pixelIndex (int bits)
     F4 *Ld, *r_u, *r_l;
+    int32_t *medium;  // ray.medium (allocated when the scene has media)
 };
 struct WorkState {
     int maxQueueSize;      // queue capacity = pixelsPerPass * samplesPerPass
@@ -69,7 +72,12 @@ struct WorkState {
     uint32_t *sampleTops;
     RayQueueV rq[2];
     F4 *hit;       // per ray slot of the current queue: triangle id (int bits), b0, b1, b2
+    float *hitT;   // tHit of the closest hit (only with media: MediumSampleWorkItem.tMax, workitems.h:219-250)
     int32_t *escapedQ, *hitLightQ;
+    // MediumSampleQueue / MediumScatterQueue (workitems.h:219-262) as index queues over the current ray queue: the
+    // items' payload is the ray slot itself (+ hit / hitT), beta, r_u, r_l are updated in place in the ray queue
+    int32_t *mediumSampleQ, *mediumScatterQ;
+    F4 *scatterP;  // per ray slot: scattering point p.xyz, HG g
     int32_t *matQ[WF_MAT_NTYPES];
     ShadowQueueV sq;
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
@@ -284,16 +292,15 @@ WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur
 // K4 tail: EnqueueWorkAfterMiss / EnqueueWorkAfterIntersection (wavefront/intersect.h:16-29,48-156) for
 // surfaces without media.  `next` = index of the queue that receives rays re-spawned through "interface"
 // surfaces.
-WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, float b0, float b1, float b2) {
-    if (!found) {
-        if (sv.nInfiniteLights > 0) {
-            int slot = QueueAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE]);
-            ws.escapedQ[slot] = i;
-        }
-        return;
-    }
-    uint32_t primBits = (uint32_t)prim;
-    ws.hit[i] = F4{BitsToFloat(primBits), b0, b1, b2};
+// GetMedium(w) of a surface interaction (interaction.h:117-121, 218-229): the primitive's MediumInterface when it
+// is a medium transition, else the medium of the ray that found the surface
+WF_HD int SurfaceMedium(const wf_mesh &mesh, N3 n, V3 w, int rayMedium) {
+    if (mesh.medium_inside != mesh.medium_outside) return Dot(w, n) > 0 ? mesh.medium_outside : mesh.medium_inside;
+    return rayMedium;
+}
+// routing of a surface hit whose record is already in ws.hit[i] (beta, r_u, r_l are read from the ray slot by the
+// consumers): interface re-push / area light / material queue
+WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, int i, int prim, float b0, float b1, float b2) {
     const wf_mesh mesh = sv.meshes[sv.triMesh[prim]];
     if (mesh.material < 0) {
         // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
@@ -313,7 +320,9 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
         nq.ctx0[slot] = q.ctx0[i];
         nq.ctx1[slot] = q.ctx1[i];
         nq.ctx2[slot] = q.ctx2[i];
-        nq.meta[slot] = q.meta[i];
+        I4 m = q.meta[i];
+        m.w = SurfaceMedium(mesh, si.n, rd, m.w);
+        nq.meta[slot] = m;
         return;
     }
     if (mesh.first_light >= 0) {
@@ -324,82 +333,59 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
     int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + mtype) * CNT_STRIDE]);
     ws.matQ[mtype][slot] = i;
 }
-
-// The same routing with block-aggregated pushes (BlockAlloc): every thread of the workgroup calls it once
-// per batch, `valid` = the thread has a ray.  Used by the production traversal kernel, whose workgroup
-// finishes a batch of rays together.
-WF_HD void KAfterClosestHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, float b0, float b1, float b2) {
-    const bool found = valid && prim >= 0;
-    if (sv.nInfiniteLights > 0) {
-        int slot = BlockAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE], valid && !found);
-        if (slot >= 0) ws.escapedQ[slot] = i;
+WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, float tHit, float b0, float b1, float b2) {
+    if (sv.haveMedia && ws.rq[cur].meta[i].w >= 0) {
+        // ray.medium set: the medium is sampled first, up to the surface or to infinity (intersect.h:16-29,53-88)
+        ws.hit[i] = F4{BitsToFloat((uint32_t)(found ? prim : -1)), b0, b1, b2};
+        ws.hitT[i] = found ? tHit : WF_INFINITY;
+        int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE]);
+        ws.mediumSampleQ[slot] = i;
+        return;
     }
-    int material = -1, firstLight = -1, mtype = -1;
-    if (found) {
-        ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
-        const wf_mesh &mesh = sv.meshes[sv.triMesh[prim]];
-        material = mesh.material;
-        firstLight = mesh.first_light;
-        if (material >= 0) mtype = sv.materials[material].type;
-    }
-    if (sv.haveMedia) {
-        // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
-        const bool isInterface = found && material < 0;
-        int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], isInterface);
-        if (isInterface) {
-            const RayQueueV &q = ws.rq[cur];
-            const RayQueueV &nq = ws.rq[cur ^ 1];
-            SurfIntr si;
-            TriangleInteraction(sv, prim, b0, b1, b2, &si);
-            F4 o = q.o[i], d = q.d[i];
-            V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
-            nq.o[slot] = F4{no.x, no.y, no.z, o.w};
-            nq.d[slot] = d;
-            nq.beta[slot] = q.beta[i];
-            nq.r_u[slot] = q.r_u[i];
-            nq.r_l[slot] = q.r_l[i];
-            nq.ctx0[slot] = q.ctx0[i];
-            nq.ctx1[slot] = q.ctx1[i];
-            nq.ctx2[slot] = q.ctx2[i];
-            nq.meta[slot] = q.meta[i];
+    if (!found) {
+        if (sv.nInfiniteLights > 0) {
+            int slot = QueueAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE]);
+            ws.escapedQ[slot] = i;
         }
+        return;
     }
-    {
-        int slot = BlockAlloc(&ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], found && material >= 0 && firstLight >= 0);
-        if (slot >= 0) ws.hitLightQ[slot] = i;
-    }
-    for (int t = 1; t < WF_MAT_NTYPES; ++t) {
-        if (!((sv.matTypeMask >> t) & 1)) continue;
-        int slot = BlockAlloc(&ws.counters[(CNT_MAT0 + t) * CNT_STRIDE], mtype == t);
-        if (slot >= 0) ws.matQ[t][slot] = i;
-    }
+    ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
+    RouteSurfaceHit(sv, ws, cur, i, prim, b0, b1, b2);
 }
 
 #if defined(__HIPCC__)
 // The routing of a whole workgroup's batch in ONE allocation round (two barriers instead of three per
 // destination queue).  `route` = the triangle's build-time routing code (LeafTri.c.w): material type |
 // emissive << 4 | interface << 5, so nothing is gathered per hit.  Destinations: 0 escaped, 1 emitter hit,
-// 2 re-pushed ray (interface material), 2 + t material type t.
+// 2 re-pushed ray (interface material), 2 + t material type t, MS medium sample (rays travelling in a medium).
 __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, uint32_t route,
-                                      float b0, float b1, float b2) {
-    constexpr int NID = 3 + WF_MAT_NTYPES;
+                                      float tHit, float b0, float b1, float b2) {
+    constexpr int MS = 2 + WF_MAT_NTYPES;
+    constexpr int NID = MS + 1;
     __shared__ int s_cnt[NID][16];
     __shared__ int s_base[NID];
     const bool found = valid && prim >= 0;
     unsigned dest = 0;
-    if (valid && !found && sv.nInfiniteLights > 0) dest = 1u;
-    if (found) {
-        ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
-        if (route & 16u) dest |= 2u;
-        if ((route & 32u) && sv.haveMedia) dest |= 4u;
-        if (route & 15u) dest |= 4u << (route & 15u);
+    const bool inMedium = sv.haveMedia && valid && ws.rq[cur].meta[i].w >= 0;
+    if (inMedium) {
+        ws.hit[i] = F4{BitsToFloat((uint32_t)(found ? prim : -1)), b0, b1, b2};
+        ws.hitT[i] = found ? tHit : WF_INFINITY;
+        dest = 1u << MS;
+    } else {
+        if (valid && !found && sv.nInfiniteLights > 0) dest = 1u;
+        if (found) {
+            ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
+            if (route & 16u) dest |= 2u;
+            if ((route & 32u) && sv.haveMedia) dest |= 4u;
+            if (route & 15u) dest |= 4u << (route & 15u);
+        }
     }
-    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? 4u : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2);
+    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? (4u | (1u << MS)) : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2);
     const unsigned lane = __lane_id();
     const int wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     auto counterOf = [&](int id) {
-        int c = id == 0 ? CNT_ESCAPED : (id == 1 ? CNT_HITLIGHT : (id == 2 ? CNT_RAY0 + (cur ^ 1) : CNT_MAT0 + (id - 2)));
+        int c = id == 0 ? CNT_ESCAPED : (id == 1 ? CNT_HITLIGHT : (id == 2 ? CNT_RAY0 + (cur ^ 1) : (id == MS ? CNT_MEDIUM_SAMPLE : CNT_MAT0 + (id - 2))));
         return &ws.counters[c * CNT_STRIDE];
     };
     for (unsigned m = active; m; m &= m - 1) {
@@ -439,12 +425,224 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             nq.ctx0[slot] = q.ctx0[i];
             nq.ctx1[slot] = q.ctx1[i];
             nq.ctx2[slot] = q.ctx2[i];
-            nq.meta[slot] = q.meta[i];
-        } else ws.matQ[id - 2][slot] = i;
+            I4 m = q.meta[i];
+            m.w = SurfaceMedium(sv.meshes[sv.triMesh[prim]], si.n, V3{d.x, d.y, d.z}, m.w);
+            nq.meta[slot] = m;
+        } else if (id == MS) ws.mediumSampleQ[slot] = i;
+        else ws.matQ[id - 2][slot] = i;
     }
     __syncthreads();  // s_cnt / s_base are reused by the next batch
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// K5: SampleMediumInteraction, wavefront/media.cpp:22-257.  The MediumSampleWorkItem is the ray slot i of the
+// current queue + its hit record; beta / r_u / r_l are written back into the slot, so the consumers that follow
+// (escaped, emitter hit, material evaluation, medium scattering) see the medium-attenuated values.
+WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    const int i = ws.mediumSampleQ[qi];
+    const RayQueueV &q = ws.rq[cur];
+    F4 o4 = q.o[i], d4 = q.d[i];
+    I4 meta = q.meta[i];
+    const int pixelIndex = meta.x, depth = meta.y, medium = meta.w;
+    V3 ro{o4.x, o4.y, o4.z}, rd{d4.x, d4.y, d4.z};
+    F4 h = ws.hit[i];
+    const int prim = (int)FloatToBits(h.x);
+    const float tMax = ws.hitT[i];
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]), r_l = toS4(q.r_l[i]);
+    S4 L = S4c(0.f);
+    RNG rng(Hash3f1(ro, tMax), Hash3f(rd));
+    bool scattered = false;
+    float uDist = rng.UniformFloat();
+    float uMode = rng.UniformFloat();
+    S4 T_maj = SampleT_maj(sv, medium, ro, rd, tMax, uDist, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
+        // emission, scaled by sigma_a / sigma_maj at every event (media.cpp:72-83)
+        if (depth < sv.maxDepth && mp.Le) {
+            float pr = sigma_maj[0] * T_maj[0];
+            S4 r_e = r_u * sigma_maj * T_maj / pr;
+            if (r_e) L = L + beta * mp.sigma_a * T_maj * mp.Le / (pr * r_e.Average());
+        }
+        float pAbsorb = mp.sigma_a[0] / sigma_maj[0];
+        float pScatter = mp.sigma_s[0] / sigma_maj[0];
+        float pNull = fmax(0.f, 1 - pAbsorb - pScatter);
+        const float w3[3] = {pAbsorb, pScatter, pNull};
+        int mode = SampleDiscreteN(w3, 3, uMode);
+        if (mode == 0) {
+            beta = S4c(0.f);
+            return false;
+        } else if (mode == 1) {
+            float pr = T_maj[0] * mp.sigma_s[0];
+            beta = beta * (T_maj * mp.sigma_s / pr);
+            r_u = r_u * (T_maj * mp.sigma_s / pr);
+            if (beta && r_u) {
+                // MediumScatterWorkItem push (media.cpp:104-113)
+                q.beta[i] = toF4(beta);
+                q.r_u[i] = toF4(r_u);
+                ws.scatterP[i] = F4{p.x, p.y, p.z, mp.g};
+                int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE]);
+                ws.mediumScatterQ[slot] = i;
+            }
+            scattered = true;
+            return false;
+        } else {
+            S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
+            float pr = T_maj[0] * sigma_n[0];
+            beta = beta * (T_maj * sigma_n / pr);
+            if (pr == 0) beta = S4c(0.f);
+            r_u = r_u * (T_maj * sigma_n / pr);
+            r_l = r_l * (T_maj * sigma_maj / pr);
+            uMode = rng.UniformFloat();
+            return bool(beta) && bool(r_u);
+        }
+    });
+    if (!scattered && beta) {
+        beta = beta * (T_maj / T_maj[0]);
+        r_u = r_u * (T_maj / T_maj[0]);
+        r_l = r_l * (T_maj / T_maj[0]);
+    }
+    if (L) ws.L[pixelIndex] = toF4(toS4(ws.L[pixelIndex]) + L);
+    if (scattered || !beta || !r_u || depth == sv.maxDepth) return;
+    // the ray reached the surface (or left the scene): route it as EnqueueWorkAfterIntersection would have
+    q.beta[i] = toF4(beta);
+    q.r_u[i] = toF4(r_u);
+    q.r_l[i] = toF4(r_l);
+    if (IsInf(tMax)) {
+        if (sv.nInfiniteLights > 0) {
+            int slot = QueueAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE]);
+            ws.escapedQ[slot] = i;
+        }
+        return;
+    }
+    RouteSurfaceHit(sv, ws, cur, i, prim, h.y, h.z, h.w);
+}
+
+// K6: SampleMediumScattering<HGPhaseFunction>, wavefront/media.cpp:259-352
+WF_HD void KSampleMediumScattering(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    const int i = ws.mediumScatterQ[qi];
+    const RayQueueV &q = ws.rq[cur];
+    const RayQueueV &nq = ws.rq[cur ^ 1];
+    F4 o4 = q.o[i], d4 = q.d[i], sp = ws.scatterP[i];
+    I4 meta = q.meta[i];
+    const int pixelIndex = meta.x, depth = meta.y, medium = meta.w;
+    const float time = o4.w, etaScale = d4.w, g = sp.w;
+    const V3 p{sp.x, sp.y, sp.z};
+    const V3 wo{-d4.x, -d4.y, -d4.z};
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    const S4 wbeta = toS4(q.beta[i]), wr_u = toS4(q.r_u[i]);
+    F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
+    LightCtx ctx{MakeP3i(p), N3{0, 0, 0}, N3{0, 0, 0}};
+    // direct lighting
+    float lightPMF = 0;
+    int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
+    if (lightId >= 0) {
+        const wf_light &light = sv.lights[lightId];
+        LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+        if (ls.valid && ls.L && ls.pdf > 0) {
+            V3 wi = ls.wi;
+            S4 beta = wbeta * HenyeyGreenstein(Dot(wo, wi), g);
+            float lightPDF = ls.pdf * lightPMF;
+            float phasePDF = IsDeltaLight(light.type) ? 0.f : HenyeyGreenstein(Dot(wo, wi), g);
+            S4 r_u = wr_u * phasePDF;
+            S4 r_l = wr_u * lightPDF;
+            S4 Ld = beta * ls.L;
+            V3 sd = ls.pLightPi.mid() - p;
+            int slot = QueueAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE]);
+            ws.sq.o[slot] = F4{p.x, p.y, p.z, 1 - ShadowEpsilon};
+            ws.sq.d[slot] = F4{sd.x, sd.y, sd.z, BitsToFloat((uint32_t)pixelIndex)};
+            ws.sq.Ld[slot] = toF4(Ld);
+            ws.sq.r_u[slot] = toF4(r_u);
+            ws.sq.r_l[slot] = toF4(r_l);
+            ws.sq.medium[slot] = medium;
+        }
+    }
+    // indirect lighting
+    float pdf = 0;
+    V3 wi = SampleHenyeyGreenstein(wo, g, V2{s1.x, s1.y}, &pdf);
+    if (pdf == 0) return;
+    S4 beta = wbeta * pdf / pdf;  // phaseSample->p == phaseSample->pdf
+    S4 r_u = wr_u;
+    S4 r_l = wr_u / pdf;
+    S4 rrBeta = beta * etaScale / r_u.Average();
+    if (rrBeta.MaxComponentValue() < 1 && depth >= 1) {
+        float qq = fmax(0.f, 1 - rrBeta.MaxComponentValue());
+        if (s1.z < qq) return;
+        beta = beta / (1 - qq);
+    }
+    int slot = QueueAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
+    nq.o[slot] = F4{p.x, p.y, p.z, time};
+    nq.d[slot] = F4{wi.x, wi.y, wi.z, etaScale};
+    nq.beta[slot] = toF4(beta);
+    nq.r_u[slot] = toF4(r_u);
+    nq.r_l[slot] = toF4(r_l);
+    StoreCtx(nq, slot, ctx);
+    nq.meta[slot] = I4{pixelIndex, depth + 1, RAYFLAG_ANY_NONSPECULAR, medium};
+}
+
+// K11: TraceTransmittance, wavefront/intersect.h:165-274 (the shadow-ray stage when the scene has media).
+// trace(o, d, tMax, &prim, &b0, &b1, &b2) -> closest hit?
+template <typename Trace>
+WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, Trace trace) {
+    F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
+    const int pixelIndex = (int)FloatToBits(d4.w);
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    S4 Ld = toS4(ws.sq.Ld[i]);
+    const S4 sr_u = toS4(ws.sq.r_u[i]), sr_l = toS4(ws.sq.r_l[i]);
+    V3 ro{o4.x, o4.y, o4.z}, rd{d4.x, d4.y, d4.z};
+    float tMax = o4.w;
+    int medium = ws.sq.medium[i];
+    const V3 pLight = ro + rd * tMax;
+    RNG rng(Hash3f(ro), Hash3f(rd));
+    S4 T_ray = S4c(1.f), r_u = S4c(1.f), r_l = S4c(1.f);
+    while (!(rd.x == 0 && rd.y == 0 && rd.z == 0)) {
+        int prim = -1;
+        float b0 = 0, b1 = 0, b2 = 0;
+        bool hit = trace(ro, rd, tMax, &prim, &b0, &b1, &b2);
+        SurfIntr si;
+        bool opaque = false;
+        if (hit) {
+            TriangleInteraction(sv, prim, b0, b1, b2, &si);
+            opaque = sv.meshes[si.mesh].material >= 0;
+        }
+        if (opaque) {
+            T_ray = S4c(0.f);
+            break;
+        }
+        if (medium >= 0) {
+            float tEnd = !hit ? tMax : (Distance(ro, si.pi.mid()) / Length(rd));
+            float u0 = rng.UniformFloat();
+            S4 T_maj = SampleT_maj(sv, medium, ro, rd, tEnd, u0, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
+                S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
+                // ratio tracking: only null scattering is evaluated
+                float pr = T_maj[0] * sigma_maj[0];
+                T_ray = T_ray * (T_maj * sigma_n / pr);
+                r_l = r_l * (T_maj * sigma_maj / pr);
+                r_u = r_u * (T_maj * sigma_n / pr);
+                S4 Tr = T_ray / (r_l + r_u).Average();
+                if (Tr.MaxComponentValue() < 0.05f) {
+                    float qq = 0.75f;
+                    if (rng.UniformFloat() < qq) T_ray = S4c(0.f);
+                    else T_ray = T_ray / (1 - qq);
+                }
+                if (!T_ray) return false;
+                return true;
+            });
+            T_ray = T_ray * (T_maj / T_maj[0]);
+            r_l = r_l * (T_maj / T_maj[0]);
+            r_u = r_u * (T_maj / T_maj[0]);
+        }
+        if (!hit || !T_ray) break;
+        // ray = si->intr.SpawnRayTo(pLight): interaction.h:103-107
+        RayOD nr = SpawnRayTo(si.pi, si.n, pLight);
+        medium = SurfaceMedium(sv.meshes[si.mesh], si.n, nr.d, medium);
+        ro = nr.o;
+        rd = nr.d;  // (tMax stays sr.tMax, intersect.h:176,185)
+    }
+    if (T_ray) {
+        Ld = Ld * (T_ray / (sr_u * r_u + sr_l * r_l).Average());
+        ws.L[pixelIndex] = toF4(toS4(ws.L[pixelIndex]) + Ld);
+    }
+}
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537
 WF_HD void KHandleEscaped(const SceneView &sv, const WorkState &ws, int cur, int qi) {
@@ -494,7 +692,10 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     int lightId = mesh.first_light + (prim - mesh.first_tri);
     const wf_light &light = sv.lights[lightId];
     F4 d4 = q.d[i];
-    V3 wo = Normalize(V3{-d4.x, -d4.y, -d4.z});  // intr.wo is normalised by the Interaction ctor (interaction.h:40-43)
+    // intr.wo is normalised by the Interaction ctor (interaction.h:40-43); items that went through the medium
+    // stage carry -ray.d as it is (media.cpp:206-208)
+    V3 wo{-d4.x, -d4.y, -d4.z};
+    if (!(sv.haveMedia && m.w >= 0)) wo = Normalize(wo);
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
     S4 Le = AreaLightL(sv, light, si.n, wo, lambda);
     if (!Le) return;
@@ -559,7 +760,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
     V3 ro{0, 0, 0}, rwi{0, 0, 0};
     S4 rbeta = S4c(0.f), rr_u = S4c(0.f), rr_l = S4c(0.f);
     float retaScale = 0, time = 0;
-    int rflags = 0, rmedium = -1, pixelIndex = 0, depth = 0;
+    int rflags = 0, rmedium = -1, smedium = -1, pixelIndex = 0, depth = 0;
     LightCtx rctx{};
     // shadow-ray payload
     RayOD sr{V3{0, 0, 0}, V3{0, 0, 0}};
@@ -579,8 +780,10 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         F4 o4 = q.o[i], d4 = q.d[i];
         time = o4.w;
         float etaScale0 = d4.w;
-        // intr.wo: the Interaction constructor normalises it (interaction.h:40-43), also for unit-length ray.d
-        V3 wo = Normalize(V3{-d4.x, -d4.y, -d4.z});
+        // intr.wo: the Interaction constructor normalises it (interaction.h:40-43), also for unit-length ray.d;
+        // items enqueued by the medium stage carry -ray.d as it is (media.cpp:240)
+        V3 wo{-d4.x, -d4.y, -d4.z};
+        if (!(sv.haveMedia && meta.w >= 0)) wo = Normalize(wo);
         // (texture-filtering differentials, surfscatter.cpp:75-104, only feed image textures; the textures
         // evaluated here are position-independent)
         N3 ns = si.ns;
@@ -616,7 +819,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                 pushRay = true;
                 ro = OffsetRayOrigin(si.pi, si.n, wi);
                 rwi = wi;
-                if (sv.haveMedia) rmedium = Dot(wi, si.n) > 0 ? mesh.medium_outside : mesh.medium_inside;
+                if (sv.haveMedia) rmedium = SurfaceMedium(mesh, si.n, wi, meta.w);
                 bool anyNonSpecularBounces = !bs.IsSpecularS() || anyNonSpecularBounces0;
                 rctx = LightCtx{si.pi, si.n, ns};
                 rbeta = beta; rr_u = r_u; rr_l = r_l; retaScale = etaScale;
@@ -654,6 +857,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                         sr_l = wr_u * lightPDF;
                         sLd = beta * ls.L;
                         sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
+                        if (sv.haveMedia) smedium = SurfaceMedium(mesh, si.n, sr.d, meta.w);
                         pushShadow = true;
                     }
                 }
@@ -677,6 +881,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         ws.sq.Ld[slot] = toF4(sLd);
         ws.sq.r_u[slot] = toF4(sr_u);
         ws.sq.r_l[slot] = toF4(sr_l);
+        if (sv.haveMedia) ws.sq.medium[slot] = smedium;
     }
 }
 

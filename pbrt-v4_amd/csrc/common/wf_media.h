@@ -1,0 +1,268 @@
+// wf_media.h — participating media on the hot path: HomogeneousMedium / GridMedium majorant iteration,
+// SampleT_maj (delta tracking driver), point sampling of the medium properties.  Restates media.h:40-352,
+// 724-800 and util/containers.h:765-850 operation for operation (host branches; FastExp is the polynomial
+// of util/math.h:450-474, not an intrinsic).
+#pragma once
+
+#include "wf_camera.h"
+
+namespace wf {
+
+// Hash(Point3f, Float) / Hash(Vector3f) as used for the medium RNGs (wavefront/media.cpp:44, intersect.h:170)
+WF_HD uint64_t Hash3f1(V3 p, float t) {
+    uint32_t w[4] = {FloatToBits(p.x), FloatToBits(p.y), FloatToBits(p.z), FloatToBits(t)};
+    return HashWords(w, 4);
+}
+constexpr float WF_FLT_MAX = 3.402823466e+38f;
+
+// general SampleDiscrete (util/sampling.h:79-113), weights in a small array
+WF_HD int SampleDiscreteN(const float *weights, int n, float u) {
+    float sumWeights = 0;
+    for (int i = 0; i < n; ++i) sumWeights += weights[i];
+    float up = u * sumWeights;
+    if (up == sumWeights) up = NextFloatDown(up);
+    int offset = 0;
+    float sum = 0;
+    while (sum + weights[offset] <= up) sum += weights[offset++];
+    return offset;
+}
+
+struct MediumProps {  // MediumProperties, media.h:71-76 (phase = HG with parameter g)
+    S4 sigma_a, sigma_s, Le;
+    float g;
+};
+struct MajorantSeg { float tMin, tMax; S4 sigma_maj; };  // RayMajorantSegment, base/medium.h
+
+// SampledGrid<Float>::Lookup (util/containers.h:797-826)
+WF_HD float GridLookupI(const float *v, int nx, int ny, int nz, int x, int y, int z) {
+    if (!(x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz)) return 0.f;
+    return v[((size_t)z * ny + y) * nx + x];
+}
+WF_HD float GridLookup(const float *v, int nx, int ny, int nz, V3 p) {
+    V3 ps{p.x * nx - .5f, p.y * ny - .5f, p.z * nz - .5f};
+    int ix = (int)floor(ps.x), iy = (int)floor(ps.y), iz = (int)floor(ps.z);
+    V3 d{ps.x - (float)ix, ps.y - (float)iy, ps.z - (float)iz};
+    float d00 = Lerp(d.x, GridLookupI(v, nx, ny, nz, ix, iy, iz), GridLookupI(v, nx, ny, nz, ix + 1, iy, iz));
+    float d10 = Lerp(d.x, GridLookupI(v, nx, ny, nz, ix, iy + 1, iz), GridLookupI(v, nx, ny, nz, ix + 1, iy + 1, iz));
+    float d01 = Lerp(d.x, GridLookupI(v, nx, ny, nz, ix, iy, iz + 1), GridLookupI(v, nx, ny, nz, ix + 1, iy, iz + 1));
+    float d11 = Lerp(d.x, GridLookupI(v, nx, ny, nz, ix, iy + 1, iz + 1), GridLookupI(v, nx, ny, nz, ix + 1, iy + 1, iz + 1));
+    return Lerp(d.z, Lerp(d.y, d00, d10), Lerp(d.y, d01, d11));
+}
+// Bounds3::Offset (util/vecmath.h)
+WF_HD V3 BoundsOffset(const float b[6], V3 p) {
+    V3 o{p.x - b[0], p.y - b[1], p.z - b[2]};
+    if (b[3] > b[0]) o.x /= b[3] - b[0];
+    if (b[4] > b[1]) o.y /= b[4] - b[1];
+    if (b[5] > b[2]) o.z /= b[5] - b[2];
+    return o;
+}
+// Bounds3::IntersectP(o, d, tMax, &t0, &t1), util/vecmath.h:1545-1572
+WF_HD bool BoundsIntersectT(const float b[6], V3 o, V3 d, float tMax, float *hitt0, float *hitt1) {
+    float t0 = 0, t1 = tMax;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1 / dd[i];
+        float tNear = (b[i] - oo[i]) * invRayDir;
+        float tFar = (b[3 + i] - oo[i]) * invRayDir;
+        if (tNear > tFar) { float t = tNear; tNear = tFar; tFar = t; }
+        tFar *= 1 + 2 * gamma(3);
+        t0 = tNear > t0 ? tNear : t0;
+        t1 = tFar < t1 ? tFar : t1;
+        if (t0 > t1) return false;
+    }
+    *hitt0 = t0;
+    *hitt1 = t1;
+    return true;
+}
+// Transform::ApplyInverse(Point3f) (util/transform.h:387-399) and (Ray, tMax) (:350-364 with the Point3fi
+// form of util/transform.cpp for an exact point)
+WF_HD V3 XfInvPoint(const wf_transform &t, V3 p) {
+    const float (*m)[4] = t.mInv;
+    float x = p.x, y = p.y, z = p.z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    float wp = (m[3][0] * x + m[3][1] * y) + (m[3][2] * z + m[3][3]);
+    if (wp == 1) return V3{xp, yp, zp};
+    return V3{xp, yp, zp} / wp;
+}
+WF_HD void XfInvRay(const wf_transform &t, V3 *o, V3 *d, float *tMax) {
+    const float (*m)[4] = t.mInv;
+    float x = o->x, y = o->y, z = o->z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    V3 pe;
+    pe.x = gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z));
+    pe.y = gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z));
+    pe.z = gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z));
+    P3i oi = MakeP3i(V3{xp, yp, zp}, pe);  // affine transforms only (wp == 1)
+    V3 dd = XfVector(t.mInv, *d);
+    float lengthSquared = LengthSquared(dd);
+    if (lengthSquared > 0) {
+        float dt = Dot(Abs(dd), oi.err()) / lengthSquared;
+        V3 off = dd * dt;
+        o->x = IntervalAddMid(oi.lo.x, oi.hi.x, off.x);
+        o->y = IntervalAddMid(oi.lo.y, oi.hi.y, off.y);
+        o->z = IntervalAddMid(oi.lo.z, oi.hi.z, off.z);
+        *tMax -= dt;
+    } else *o = oi.mid();
+    *d = dd;
+}
+
+// Medium::SamplePoint: HomogeneousMedium media.h:247-252, GridMedium media.h:283-317
+WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, V3 p, const Wavelengths &lambda) {
+    MediumProps mp;
+    mp.g = M.g;
+    mp.sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
+    mp.sigma_s = DenseSample(sv, M.sigma_s_offset, lambda);
+    if (M.type == WF_MEDIUM_HOMOGENEOUS) {
+        mp.Le = DenseSample(sv, M.le_offset, lambda);
+        return mp;
+    }
+    p = XfInvPoint(M.render_from_medium, p);
+    p = BoundsOffset(M.bounds, p);
+    float d = GridLookup(sv.mediumData + M.density_offset, M.nx, M.ny, M.nz, p);
+    mp.sigma_a = mp.sigma_a * d;
+    mp.sigma_s = mp.sigma_s * d;
+    mp.Le = S4c(0.f);
+    if (M.is_emissive) {
+        float scale = GridLookup(sv.mediumData + M.le_scale_offset, M.le_nx, M.le_ny, M.le_nz, p);
+        if (scale > 0) mp.Le = scale * DenseSample(sv, M.le_offset, lambda);
+    }
+    return mp;
+}
+
+// HomogeneousMajorantIterator (media.h:79-102) and DDAMajorantIterator (media.h:136-214) behind one interface
+struct MajorantIter {
+    // homogeneous
+    bool homogeneous, called;
+    MajorantSeg seg;
+    // DDA
+    S4 sigma_t;
+    float tMin, tMax;
+    const float *voxels;
+    int res[3];
+    float nextCrossingT[3], deltaT[3];
+    int step[3], voxelLimit[3], voxel[3];
+
+    WF_HD bool Next(MajorantSeg *out) {
+        if (homogeneous) {
+            if (called) return false;
+            called = true;
+            *out = seg;
+            return true;
+        }
+        if (tMin >= tMax) return false;
+        int bits = ((nextCrossingT[0] < nextCrossingT[1]) << 2) + ((nextCrossingT[0] < nextCrossingT[2]) << 1) +
+                   ((nextCrossingT[1] < nextCrossingT[2]));
+        // cmpToAxis = {2, 1, 2, 1, 2, 2, 0, 0}
+        int stepAxis = (bits == 6 || bits == 7) ? 0 : ((bits == 1 || bits == 3) ? 1 : 2);
+        float nct = stepAxis == 0 ? nextCrossingT[0] : (stepAxis == 1 ? nextCrossingT[1] : nextCrossingT[2]);
+        float tVoxelExit = fmin(tMax, nct);
+        S4 sigma_maj = sigma_t * voxels[voxel[0] + res[0] * (voxel[1] + res[1] * voxel[2])];
+        *out = MajorantSeg{tMin, tVoxelExit, sigma_maj};
+        tMin = tVoxelExit;
+        if (nct > tMax) tMin = tMax;
+        for (int a = 0; a < 3; ++a)
+            if (a == stepAxis) {
+                voxel[a] += step[a];
+                if (voxel[a] == voxelLimit[a]) tMin = tMax;
+                nextCrossingT[a] += deltaT[a];
+            }
+        return true;
+    }
+};
+
+// Medium::SampleRay for a ray with unit-length direction (SampleT_maj normalises first)
+WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, V3 o, V3 d, float raytMax, const Wavelengths &lambda) {
+    MajorantIter it;
+    S4 sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
+    S4 sigma_s = DenseSample(sv, M.sigma_s_offset, lambda);
+    if (M.type == WF_MEDIUM_HOMOGENEOUS) {
+        it.homogeneous = true;
+        it.called = false;
+        it.seg = MajorantSeg{0, raytMax, sigma_a + sigma_s};
+        return it;
+    }
+    it.homogeneous = false;
+    it.called = true;
+    it.tMin = WF_INFINITY;   // default-constructed DDA iterator: Next() returns nothing
+    it.tMax = -WF_INFINITY;
+    XfInvRay(M.render_from_medium, &o, &d, &raytMax);
+    float tMin, tMax;
+    if (!BoundsIntersectT(M.bounds, o, d, raytMax, &tMin, &tMax)) return it;
+    it.sigma_t = sigma_a + sigma_s;
+    it.tMin = tMin;
+    it.tMax = tMax;
+    it.voxels = sv.mediumData + M.maj_offset;
+    for (int a = 0; a < 3; ++a) it.res[a] = M.maj_res[a];
+    // DDAMajorantIterator ctor, media.h:141-178
+    const float diag[3] = {M.bounds[3] - M.bounds[0], M.bounds[4] - M.bounds[1], M.bounds[5] - M.bounds[2]};
+    V3 og = BoundsOffset(M.bounds, o);
+    float rd[3] = {d.x / diag[0], d.y / diag[1], d.z / diag[2]};
+    // rayGrid(tMin) = o + d * t
+    const float gi[3] = {og.x + rd[0] * tMin, og.y + rd[1] * tMin, og.z + rd[2] * tMin};
+    for (int a = 0; a < 3; ++a) {
+        it.voxel[a] = (int)Clamp(gi[a] * it.res[a], 0.f, (float)(it.res[a] - 1));
+        it.deltaT[a] = 1 / (abs(rd[a]) * it.res[a]);
+        if (rd[a] == -0.f) rd[a] = 0.f;
+        if (rd[a] >= 0) {
+            float nextVoxelPos = float(it.voxel[a] + 1) / it.res[a];
+            it.nextCrossingT[a] = tMin + (nextVoxelPos - gi[a]) / rd[a];
+            it.step[a] = 1;
+            it.voxelLimit[a] = it.res[a];
+        } else {
+            float nextVoxelPos = float(it.voxel[a]) / it.res[a];
+            it.nextCrossingT[a] = tMin + (nextVoxelPos - gi[a]) / rd[a];
+            it.step[a] = -1;
+            it.voxelLimit[a] = -1;
+        }
+    }
+    return it;
+}
+
+// SampleT_maj, media.h:724-800.  callback(p, mp, sigma_maj, T_maj) -> continue?
+template <typename F>
+WF_HD S4 SampleT_maj(const SceneView &sv, int mediumId, V3 o, V3 d, float tMax, float u, RNG &rng, const Wavelengths &lambda, F callback) {
+    const wf_medium &M = sv.media[mediumId];
+    tMax *= Length(d);
+    d = Normalize(d);
+    MajorantIter iter = MediumSampleRay(sv, M, o, d, tMax, lambda);
+    S4 T_maj = S4c(1.f);
+    bool done = false;
+    while (!done) {
+        MajorantSeg seg;
+        if (!iter.Next(&seg)) return T_maj;
+        if (seg.sigma_maj[0] == 0) {
+            float dt = seg.tMax - seg.tMin;
+            if (IsInf(dt)) dt = WF_FLT_MAX;
+            T_maj = T_maj * FastExp(-dt * seg.sigma_maj);
+            continue;
+        }
+        float tMin = seg.tMin;
+        while (true) {
+            float t = tMin + SampleExponential(u, seg.sigma_maj[0]);
+            u = rng.UniformFloat();
+            if (t < seg.tMax) {
+                T_maj = T_maj * FastExp(-(t - tMin) * seg.sigma_maj);
+                V3 p = o + d * t;
+                MediumProps mp = MediumSamplePoint(sv, M, p, lambda);
+                if (!callback(p, mp, seg.sigma_maj, T_maj)) {
+                    done = true;
+                    break;
+                }
+                T_maj = S4c(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (IsInf(dt)) dt = WF_FLT_MAX;
+                T_maj = T_maj * FastExp(-dt * seg.sigma_maj);
+                break;
+            }
+        }
+    }
+    return S4c(1.f);
+}
+
+}  // namespace wf

@@ -30,6 +30,9 @@ struct SceneView {
     const wf_transform *lightXforms;
     int nLights, nInfiniteLights, nLightBvhNodes, lightSampler;
     float allLightBounds[6];
+    // participating media
+    const wf_medium *media;
+    const float *mediumData;
     // camera / film / filter / sampler
     wf_camera camera;
     wf_film film;

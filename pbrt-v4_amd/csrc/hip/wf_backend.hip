@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv,
         ClosestHit ch;
         st.n = 0;
         bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
-        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.b0, ch.h.b1, ch.h.b2);
+        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
         if (COUNT) { nv += ch.nodesVisited; nt += ch.trisTested; nh += found; nr += 1; }
     }
     if (COUNT) {
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneV
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
         },
-        [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock(sv, ws, cur, i, valid, w.prim, w.route, w.b0, w.b1, w.b2); });
+        [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock(sv, ws, cur, i, valid, w.prim, w.route, w.tMax, w.b0, w.b1, w.b2); });
 }
 __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
@@ -326,6 +326,29 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(FastBVH bvh, int n, c
             *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
         },
         [&](int i, bool valid, const RayWalk &w) { if (valid) occluded[i] = w.prim >= 0; });
+}
+
+// K5 / K6 / K11: participating media (wf_media.h, wf_kernels.h)
+__global__ void __launch_bounds__(BLOCK) k_medium_sample(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction(sv, ws, cur, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_medium_scatter(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumScattering(sv, ws, cur, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkState ws, int *stackSpill) {
+    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride)
+        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, float *b0, float *b1, float *b2) {
+            ClosestHit ch;
+            st.n = 0;
+            bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+            if (found) { *prim = ch.prim; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+            return found;
+        });
 }
 
 __global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView sv, WorkState ws, int cur) {
@@ -608,6 +631,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.infiniteLights, d->infinite_lights, (size_t)d->n_infinite_lights))) return e;
     if ((e = devUpload(ctx, &sv.lightBvh, d->light_bvh_nodes, (size_t)d->n_light_bvh_nodes))) return e;
     if ((e = devUpload(ctx, &sv.lightXforms, d->light_transforms, (size_t)d->n_light_transforms))) return e;
+    if ((e = devUpload(ctx, &sv.media, d->media, (size_t)d->n_media))) return e;
+    if ((e = devUpload(ctx, &sv.mediumData, d->medium_data, (size_t)d->n_medium_floats))) return e;
     sv.nLights = d->n_lights;
     sv.nInfiniteLights = d->n_infinite_lights;
     sv.nLightBvhNodes = d->n_light_bvh_nodes;
@@ -708,6 +733,11 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if (2 * ctx->svHost.sampler.nBase4Digits <= 32 && !getenv("WF_NO_SAMPLE_TOPS"))
         if ((e = devAlloc(ctx, &ws.sampleTops, (size_t)5 * pixels_per_pass))) return e;
     if ((e = allocRayQueue(ctx, &ws.rq[0], n)) || (e = allocRayQueue(ctx, &ws.rq[1], n))) return e;
+    if (ctx->svHost.haveMedia) {
+        if ((e = devAlloc(ctx, &ws.hitT, n)) || (e = devAlloc(ctx, &ws.mediumSampleQ, n)) || (e = devAlloc(ctx, &ws.mediumScatterQ, n)) ||
+            (e = devAlloc(ctx, &ws.scatterP, n)) || (e = devAlloc(ctx, &ws.sq.medium, n)))
+            return e;
+    }
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
         if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
@@ -748,6 +778,7 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     const int cur = depth & 1;
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
+    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + depth, CNT_RAY0 + cur);
     return 0;
@@ -780,6 +811,23 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
         LAUNCHT("Intersect closest", k_closest_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
     else
         LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
+    return 0;
+}
+// SampleMediumInteraction (wavefront/media.cpp:22-257): K5, then K6 for the Henyey-Greenstein phase function
+int wf_medium_sample(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (!ctx->svHost.haveMedia) return 0;
+    LAUNCH("Sample medium interaction", k_medium_sample, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    if (depth == ctx->maxDepth) return 0;
+    LAUNCH("Sample direct/indirect - Henyey-Greenstein", k_medium_scatter, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    return 0;
+}
+// TraceShadowRays with media: IntersectShadowTr (wavefront/aggregate.cpp:70-88, intersect.h:165-274)
+int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
+    LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + depth, CNT_SHADOW);
     return 0;
 }
 int wf_handle_escaped(wf_ctx *ctx, int depth) {
@@ -844,13 +892,14 @@ int wf_render_pass(wf_ctx *ctx, int y0, int sample_index) {
         if ((e = wf_reset_stage_queues(ctx, depth))) return e;
         if ((e = wf_gen_ray_samples(ctx, depth, sample_index))) return e;
         if ((e = wf_intersect_closest(ctx, depth))) return e;
+        if ((e = wf_medium_sample(ctx, depth))) return e;
         if ((e = wf_handle_escaped(ctx, depth))) return e;
         if ((e = wf_handle_emissive(ctx, depth))) return e;
         if (depth == ctx->maxDepth) break;
         for (int m = 0; m < WF_MAT_NTYPES; ++m)
             if (ctx->matPresent[m] && m != WF_MAT_INTERFACE)
                 if ((e = wf_eval_material(ctx, m, depth))) return e;
-        if ((e = wf_intersect_shadow(ctx, depth))) return e;
+        if ((e = ctx->svHost.haveMedia ? wf_intersect_shadow_tr(ctx, depth) : wf_intersect_shadow(ctx, depth))) return e;
     }
     return wf_update_film(ctx);
 }

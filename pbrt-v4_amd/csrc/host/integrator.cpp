@@ -72,13 +72,16 @@ double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep,
                 Check(wf_reset_stage_queues(ctx, wavefrontDepth), "wf_reset_stage_queues");
                 Check(wf_gen_ray_samples(ctx, wavefrontDepth, sampleIndex), "wf_gen_ray_samples");
                 Check(wf_intersect_closest(ctx, wavefrontDepth), "wf_intersect_closest");
+                if (T.desc.have_media) Check(wf_medium_sample(ctx, wavefrontDepth), "wf_medium_sample");  // integrator.cpp:416
                 Check(wf_handle_escaped(ctx, wavefrontDepth), "wf_handle_escaped");
                 Check(wf_handle_emissive(ctx, wavefrontDepth), "wf_handle_emissive");
                 if (wavefrontDepth == maxDepth) break;
                 for (int m = 0; m < WF_MAT_NTYPES; ++m)
                     if (T.materialTypePresent[m] && m != WF_MAT_INTERFACE)
                         Check(wf_eval_material(ctx, m, wavefrontDepth), "wf_eval_material");
-                Check(wf_intersect_shadow(ctx, wavefrontDepth), "wf_intersect_shadow");
+                // TraceShadowRays, integrator.cpp:575-586
+                if (T.desc.have_media) Check(wf_intersect_shadow_tr(ctx, wavefrontDepth), "wf_intersect_shadow_tr");
+                else Check(wf_intersect_shadow(ctx, wavefrontDepth), "wf_intersect_shadow");
             }
             Check(wf_update_film(ctx), "wf_update_film");
         }

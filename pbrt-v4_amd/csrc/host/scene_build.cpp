@@ -42,6 +42,8 @@ void SceneTables::Finalize() {
     desc.n_light_transforms = (int)lightTransforms.size(); desc.light_transforms = lightTransforms.data();
     desc.power_alias = powerAlias.data();
     desc.n_filter_floats = (int)filterData.size(); desc.filter_data = filterData.data();
+    desc.n_media = (int)media.size(); desc.media = media.data();
+    desc.n_medium_floats = (int)mediumData.size(); desc.medium_data = mediumData.data();
 }
 
 namespace {
@@ -427,6 +429,102 @@ void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTable
     ps.ReportUnused("Sampler");
 }
 
+// Medium::Create (media.cpp:667-689): HomogeneousMedium::Create (:201-234) and GridMedium::Create (:283-360) with the
+// constructors' precomputation (spectra densely sampled and pre-scaled, 16^3 majorant grid, media.cpp:238-272)
+static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::string, int> *ids) {
+    for (const auto &nm : scene.media) {
+        const Entity &e = nm.second;
+        const ParamSet &ps = e.params;
+        if (ids->count(nm.first)) Die(e.loc, nm.first + ": named medium redefined.");
+        wf_medium M{};
+        auto dense = [&](const SpectrumH &s, float scale) {
+            SpectrumP d = MakeDense(s);
+            d->Scale(scale);
+            return T->pool.AddDense(*d);
+        };
+        M.g = ps.GetOneFloat("g", 0.f);
+        float sigmaScale = ps.GetOneFloat("scale", 1.f);
+        if (!ps.GetOneString("preset", "").empty()) Die(e.loc, "medium \"preset\" tables are not supported by this build yet");
+        SpectrumP sig_a = ps.GetOneSpectrum("sigma_a", nullptr, SpectrumType::Unbounded);
+        if (!sig_a) sig_a = MakeConstant(1.f);
+        SpectrumP sig_s = ps.GetOneSpectrum("sigma_s", nullptr, SpectrumType::Unbounded);
+        if (!sig_s) sig_s = MakeConstant(1.f);
+        M.sigma_a_offset = dense(*sig_a, sigmaScale);
+        M.sigma_s_offset = dense(*sig_s, sigmaScale);
+        SpectrumP Le = ps.GetOneSpectrum("Le", nullptr, SpectrumType::Illuminant);
+        if (e.name == "homogeneous") {
+            M.type = WF_MEDIUM_HOMOGENEOUS;
+            float LeScale = ps.GetOneFloat("Lescale", 1.f);
+            if (!Le || Le->MaxValue() == 0) Le = MakeConstant(0.f);
+            else LeScale /= SpectrumToPhotometric(*Le);
+            SpectrumP d = MakeDense(*Le);
+            d->Scale(LeScale);
+            M.is_emissive = d->MaxValue() > 0;
+            M.le_offset = T->pool.AddDense(*d);
+        } else if (e.name == "uniformgrid") {
+            M.type = WF_MEDIUM_GRID;
+            std::vector<float> density = ps.GetFloatArray("density");
+            if (density.empty()) Die(e.loc, "No \"density\" value provided for grid medium.");
+            if (!ps.GetFloatArray("temperature").empty()) Die(e.loc, "grid medium \"temperature\" is not supported by this build yet");
+            M.nx = ps.GetOneInt("nx", 1); M.ny = ps.GetOneInt("ny", 1); M.nz = ps.GetOneInt("nz", 1);
+            if ((long long)density.size() != (long long)M.nx * M.ny * M.nz)
+                Die(e.loc, "Grid medium has " + std::to_string(density.size()) + " density values; expected nx*ny*nz = " + std::to_string((long long)M.nx * M.ny * M.nz));
+            float LeNorm = 1;
+            if (!Le || Le->MaxValue() == 0) Le = MakeConstant(0.f);
+            else LeNorm = 1 / SpectrumToPhotometric(*Le);
+            SpectrumP d = MakeDense(*Le);
+            M.is_emissive = d->MaxValue() > 0;
+            M.le_offset = T->pool.AddDense(*d);
+            std::vector<float> LeScale = ps.GetFloatArray("Lescale");
+            M.le_scale_offset = (int)T->mediumData.size();
+            if (LeScale.empty()) {
+                M.le_nx = M.le_ny = M.le_nz = 1;
+                T->mediumData.push_back(LeNorm);
+            } else {
+                if (LeScale.size() != density.size()) Die(e.loc, "\"Lescale\" must have nx*ny*nz values");
+                M.le_nx = M.nx; M.le_ny = M.ny; M.le_nz = M.nz;
+                for (float v : LeScale) T->mediumData.push_back(v * LeNorm);
+            }
+            V3 p0 = ps.GetOnePoint3f("p0", V3{0, 0, 0}), p1 = ps.GetOnePoint3f("p1", V3{1, 1, 1});
+            // Bounds3f(p0, p1): componentwise min / max
+            for (int c = 0; c < 3; ++c) { M.bounds[c] = std::min(p0[c], p1[c]); M.bounds[3 + c] = std::max(p0[c], p1[c]); }
+            M.render_from_medium = scene.mediaTransforms.at(nm.first).abi();
+            M.density_offset = (int)T->mediumData.size();
+            T->mediumData.insert(T->mediumData.end(), density.begin(), density.end());
+            // majorant grid: SampledGrid::MaxValue over each voxel's bounds (util/containers.h:828-845)
+            M.maj_res[0] = M.maj_res[1] = M.maj_res[2] = 16;
+            M.maj_offset = (int)T->mediumData.size();
+            const int nx = M.nx, ny = M.ny, nz = M.nz;
+            auto lookup = [&](int x, int y, int z) -> float {
+                if (!(x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz)) return 0.f;
+                return density[((size_t)z * ny + y) * nx + x];
+            };
+            for (int z = 0; z < 16; ++z)
+                for (int y = 0; y < 16; ++y)
+                    for (int x = 0; x < 16; ++x) {
+                        // MajorantGrid::VoxelBounds (media.h:124-128)
+                        float b0[3] = {float(x) / 16, float(y) / 16, float(z) / 16};
+                        float b1[3] = {float(x + 1) / 16, float(y + 1) / 16, float(z + 1) / 16};
+                        float ps0[3] = {b0[0] * nx - .5f, b0[1] * ny - .5f, b0[2] * nz - .5f};
+                        float ps1[3] = {b1[0] * nx - .5f, b1[1] * ny - .5f, b1[2] * nz - .5f};
+                        int lo[3], hi[3];
+                        const int n3[3] = {nx, ny, nz};
+                        for (int c = 0; c < 3; ++c) {
+                            lo[c] = std::max((int)std::floor(ps0[c]), 0);
+                            hi[c] = std::min((int)std::floor(ps1[c]) + 1, n3[c] - 1);
+                        }
+                        float mx = lookup(lo[0], lo[1], lo[2]);
+                        for (int zz = lo[2]; zz <= hi[2]; ++zz)
+                            for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                                for (int xx = lo[0]; xx <= hi[0]; ++xx) mx = std::max(mx, lookup(xx, yy, zz));
+                        T->mediumData.push_back(mx);
+                    }
+        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid)");
+        (*ids)[nm.first] = (int)T->media.size();
+        T->media.push_back(M);
+    }
+}
+
 void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, SceneTables *T) {
     const ParamSet &ps = scene.camera.params;
     wf_camera &C = T->desc.camera;
@@ -637,7 +735,16 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     T->desc.max_depth = ip.GetOneInt("maxdepth", 5);
     std::string lightSamplerName = ip.GetOneString("lightsampler", "bvh");
 
-    if (!scene.media.empty()) Die(scene.media[0].second.loc, "participating media are not supported by this build yet");
+    // media (scene.cpp CreateMedia -> Medium::Create, media.cpp:667-689)
+    std::map<std::string, int> mediumIds;
+    BuildMedia(scene, T, &mediumIds);
+    auto mediumId = [&](const std::string &name, const std::string &loc) {
+        if (name.empty()) return -1;
+        auto it = mediumIds.find(name);
+        if (it == mediumIds.end()) Die(loc, name + ": medium is not defined.");
+        return it->second;
+    };
+    T->desc.camera.medium = mediumId(scene.cameraMedium, scene.camera.loc);
 
     // textures and materials (scene.cpp:1110-1171)
     TexBuilder tb;
@@ -653,6 +760,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     // with renderFromInstance applied) — see DESIGN.md "Instancing".
     struct PendingAreaLight { int mesh; int lightEntity; Transform renderFromObject; };
     std::vector<PendingAreaLight> pendingArea;
+    bool anyMediumInterface = false;
     auto addShape = [&](const ShapeEntity &sh, const Transform *extra) {
         MeshSource src;
         if (!LoadShapeGeometry(sh, scene.baseDir, &src)) return;
@@ -696,8 +804,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         std::string alphaTex = sh.params.GetTexture("alpha");
         float alpha = sh.params.GetOneFloat("alpha", 1.f);
         if (!alphaTex.empty() || alpha < 1.f) Die(sh.loc, "alpha textures are not supported by this build yet");
-        mesh.medium_inside = mesh.medium_outside = -1;
-        if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) Die(sh.loc, "MediumInterface is not supported by this build yet");
+        mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
+        mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
+        if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;
         T->meshes.push_back(mesh);
         if (sh.lightIndex >= 0 && !extra) {
             if (mesh.material < 0) fprintf(stderr, "Warning: %s: Ignoring area light specification for shape with \"interface\" material.\n", sh.loc.c_str());
@@ -919,8 +1028,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         BuildLightBVH(bvhLights, allLightBounds, &T->lightBvh, &T->lights);
     }
     for (int c = 0; c < 3; ++c) { T->desc.all_light_bounds[c] = allLightBounds.pMin[c]; T->desc.all_light_bounds[3 + c] = allLightBounds.pMax[c]; }
-    T->desc.have_media = 0;
-    for (const wf_mesh &m : T->meshes) if (m.material < 0) T->desc.have_media = 1;  // interface material (integrator.cpp:52)
+    // "haveMedia" (integrator.cpp:91-111,51): a shape names a medium, or an "interface" material is present
+    T->desc.have_media = anyMediumInterface ? 1 : 0;
+    for (const wf_mesh &m : T->meshes) if (m.material < 0) T->desc.have_media = 1;
 
     // wavefront pass geometry (integrator.cpp:227-236)
     {

@@ -114,7 +114,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights"])
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "media_box"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
     s = wfpt.Scene(path=path, spp=4)
@@ -122,14 +122,20 @@ def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     img, cpu, j = _render_both(s, path, 4, tmp_path)
     # integer work: identical ray counts stage by stage
     assert s.stats()["camera_rays"] == j["camera_rays"]
-    assert s.total_rays() == j["rays"]
+    if name != "media_box":
+        assert s.total_rays() == j["rays"]
+    else:
+        assert abs(s.total_rays() - j["rays"]) <= 0.01 * j["rays"]
     ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))  # the reference's own CPU wavefront render
     assert (cpu.view(np.uint32) == ref.view(np.uint32)).all()  # the port IS the reference, bit for bit
     # layered (coated*) BxDFs seed their random walk from a hash of wo/wi: a 1-ulp difference in a bounce
     # direction (device sin/cos vs glibc) re-rolls the whole walk for that sample, so that scene gets a
     # larger outlier allowance and a statistical mean check
-    frac_allowed = 0.03 if name == "materials_lights" else FRAC_OUTLIERS
-    mean_tol = 3e-3 if name == "materials_lights" else 2e-4
+    # (media_box: the medium random walks are seeded from a hash of the ray origin / direction / tHit,
+    # media.cpp:44 — the same amplification)
+    statistical = name in ("materials_lights", "media_box")
+    frac_allowed = {"materials_lights": 0.03, "media_box": 0.10}.get(name, FRAC_OUTLIERS)
+    mean_tol = 3e-3 if statistical else 2e-4
     for other in (cpu, ref):
         rel = image_error(img, other)
         print(name, "frac over tol", (rel > REL_TOL).mean(), "max rel", rel.max(), "means", img.mean(), other.mean())

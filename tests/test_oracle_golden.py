@@ -40,11 +40,12 @@ def test_triangle_golden_covers_hits_misses_edges():
     assert np.allclose(b.sum(axis=1), 1, atol=1e-5)
 
 
-@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("blobs_small", 4), ("materials_lights", 4)])
+@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("blobs_small", 4), ("materials_lights", 4), ("media_box", 4)])
 def test_cpu_checker_image_matches_reference_wavefront(built, tmp_path, scene, spp):
     """Whole path, sample-aligned: oracle/wf_cpu vs the reference's CPU WavefrontPathIntegrator
     (pbrt --wavefront) on the same .pbrt, same seed: BIT-IDENTICAL images — every material (incl. the
-    hash-seeded layered BxDFs) and every light type implemented (materials_lights scene)."""
+    hash-seeded layered BxDFs) and every light type implemented (materials_lights scene), and participating media
+    (media_box: homogeneous emissive fog, a rotated grid medium, interface surfaces, glass and metal inside the fog)."""
     ref = read_pfm(os.path.join(GOLDEN, scene + "_ref.pfm"))
     out = str(tmp_path / "cpu.pfm")
     run_wf_cpu(os.path.join(GOLDEN, scene + ".pbrt"), out, spp)

@@ -14,10 +14,12 @@ sys.path.insert(0, "tools")
 import make_scenes
 make_scenes.killeroo_like("tests/golden/blobs_small.pbrt", (96, 54), 4, rings=14, segs=20)
 make_scenes.materials_lights("tests/golden/materials_lights.pbrt", (96, 54), 4)
+make_scenes.media_box("tests/golden/media_box.pbrt", (64, 64), 4)
 PY
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_ref.pfm $G/cornell64.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_small_ref.pfm $G/blobs_small.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_ref.pfm $G/materials_lights.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_box_ref.pfm $G/media_box.pbrt
 # the named physical oracle (not sample-aligned): VolPathIntegrator at high spp, for mean comparisons
 oracle/_ref/pbrt_ref --quiet --seed 0 --spp 256 --outfile $G/cornell64_volpath256.pfm $G/cornell64.pbrt
 ls -la $G
