@@ -134,8 +134,8 @@ def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     # (media_box: the medium random walks are seeded from a hash of the ray origin / direction / tHit,
     # media.cpp:44 — the same amplification)
     statistical = name in ("materials_lights", "media_box")
-    frac_allowed = {"materials_lights": 0.03, "media_box": 0.10}.get(name, FRAC_OUTLIERS)
-    mean_tol = 3e-3 if statistical else 2e-4
+    frac_allowed = {"materials_lights": 0.03, "media_box": 0.30}.get(name, FRAC_OUTLIERS)
+    mean_tol = {"materials_lights": 3e-3, "media_box": 2e-2}.get(name, 2e-4)
     for other in (cpu, ref):
         rel = image_error(img, other)
         print(name, "frac over tol", (rel > REL_TOL).mean(), "max rel", rel.max(), "means", img.mean(), other.mean())
@@ -143,6 +143,24 @@ def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
         assert abs(img.mean() - other.mean()) <= mean_tol * other.mean()
     assert np.isfinite(img).all()
     s.close()
+
+
+def test_media_converged_mean(wfpt, tmp_path):
+    """Participating media: a sample whose walk was re-seeded by a 1-ulp difference is a different, equally valid
+    sample, so beyond the 4-spp comparison above the HIP path and the port are compared converged: 256 spp means
+    within 0.5 % and the per-pixel difference within the Monte Carlo noise of the two estimates."""
+    path = os.path.join(GOLDEN, "media_box.pbrt")
+    s = wfpt.Scene(path=path, spp=256)
+    s.create_renderer(0)
+    img, cpu, j = _render_both(s, path, 256, tmp_path)
+    s.close()
+    assert np.isfinite(img).all()
+    assert abs(img.mean() - cpu.mean()) <= 5e-3 * cpu.mean(), (img.mean(), cpu.mean())
+    # 4x4 block means: noise averages down, systematic differences would not
+    def blocks(a):
+        return a.reshape(16, 4, 16, 4, 3).mean(axis=(1, 3))
+    rel = np.abs(blocks(img) - blocks(cpu)) / np.maximum(blocks(cpu), 1e-2)
+    assert np.median(rel) < 0.02 and rel.max() < 0.25, (np.median(rel), rel.max())
 
 
 def test_per_stage_calls_equal_fused_pass(cornell):
