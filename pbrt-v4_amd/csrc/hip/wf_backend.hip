@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(BLOCK) k_medium_scatter(const SceneView sv, Wo
     const int n = ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumScattering(sv, ws, cur, i);
 }
+// reference-order variant (no production BVH, or WF_NO_FAST)
 __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkState ws, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
@@ -348,6 +349,33 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
             bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
             if (found) { *prim = ch.prim; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
             return found;
+        });
+}
+// production layout, one independent walk per lane (a transmittance ray alternates between tracing and
+// ratio tracking, so there is no batch to share)
+__global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{stackSpill + gtid, stride, 0};
+    LoadTreeTop(bvh);
+    for (int i = gtid; i < n; i += stride)
+        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, float *b0, float *b1, float *b2) {
+            RayWalk w;
+            WalkInit(bvh, w, o, d, tMax);
+            st.n = 0;
+            while (w.node != NODE_NONE) {
+                if (w.node >= 0) {
+                    U4 a, b;
+                    if (w.node < TOP_NODES) { a = g_top[2 * w.node]; b = g_top[2 * w.node + 1]; }
+                    else {
+                        const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
+                        a = p[0]; b = p[1];
+                    }
+                    InteriorStep(w, st, a, b);
+                } else LeafStep<false>(bvh, w, st);
+            }
+            if (w.prim >= 0) { *prim = w.prim; *b0 = w.b0; *b1 = w.b1; *b2 = w.b2; }
+            return w.prim >= 0;
         });
 }
 
@@ -826,7 +854,10 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
 int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
-    LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    if (ctx->fastOk && !ctx->countTraversal)
+        LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+    else
+        LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + depth, CNT_SHADOW);
     return 0;
 }
