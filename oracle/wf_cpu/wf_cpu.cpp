@@ -65,6 +65,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     for (int i = 0; i < 6; ++i) sv.allLightBounds[i] = d.all_light_bounds[i];
     sv.camera = d.camera; sv.film = d.film; sv.filter = d.filter; sv.filterData = d.filter_data; sv.sampler = d.sampler;
     sv.sobol = sobol;
+    sv.powerAlias = d.power_alias;
     sv.media = d.media; sv.mediumData = d.medium_data;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;
     sv.matTypeMask = 0;

@@ -166,6 +166,21 @@ WF_HD int LightSamplerSample(const SceneView &sv, const LightCtx &ctx, float u, 
         *pmfOut = 1.f / sv.nLights;
         return lightIndex;
     }
+    if (sv.lightSampler == WF_LS_POWER) {
+        // PowerLightSampler::Sample (lightsamplers.h:69-75) = AliasTable::Sample (util/sampling.cpp:88-113)
+        if (sv.nLights == 0) return -1;
+        int offset = (int)(u * sv.nLights);
+        if (offset > sv.nLights - 1) offset = sv.nLights - 1;
+        float up = fmin(u * sv.nLights - offset, OneMinusEpsilon);
+        const float *bin = sv.powerAlias + 3 * offset;
+        if (up < bin[0]) {
+            *pmfOut = bin[1];
+            return offset;
+        }
+        int alias = (int)FloatToBits(bin[2]);
+        *pmfOut = sv.powerAlias[3 * alias + 1];
+        return alias;
+    }
     // BVHLightSampler::Sample, lightsamplers.h:266-320
     int nInf = sv.nInfiniteLights;
     bool nodesEmpty = sv.nLightBvhNodes == 0;
@@ -208,6 +223,7 @@ WF_HD int LightSamplerSample(const SceneView &sv, const LightCtx &ctx, float u, 
 // LightSampler::PMF(ctx, light)
 WF_HD float LightSamplerPMF(const SceneView &sv, const LightCtx &ctx, int lightId) {
     if (sv.lightSampler == WF_LS_UNIFORM) return sv.nLights == 0 ? 0.f : 1.f / sv.nLights;
+    if (sv.lightSampler == WF_LS_POWER) return sv.nLights == 0 ? 0.f : sv.powerAlias[3 * lightId + 1];  // lightsamplers.h:78-82
     // BVHLightSampler::PMF, lightsamplers.h:323-358
     const wf_light &l = sv.lights[lightId];
     int nInf = sv.nInfiniteLights;

@@ -29,6 +29,7 @@ struct SceneView {
     const wf_light_bvh_node *lightBvh;
     const wf_transform *lightXforms;
     int nLights, nInfiniteLights, nLightBvhNodes, lightSampler;
+    const float *powerAlias;  // PowerLightSampler's AliasTable bins: nLights x {q, p, alias (int bits)}
     float allLightBounds[6];
     // participating media
     const wf_medium *media;

@@ -659,6 +659,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.infiniteLights, d->infinite_lights, (size_t)d->n_infinite_lights))) return e;
     if ((e = devUpload(ctx, &sv.lightBvh, d->light_bvh_nodes, (size_t)d->n_light_bvh_nodes))) return e;
     if ((e = devUpload(ctx, &sv.lightXforms, d->light_transforms, (size_t)d->n_light_transforms))) return e;
+    if ((e = devUpload(ctx, &sv.powerAlias, d->power_alias, d->light_sampler == WF_LS_POWER ? (size_t)3 * d->n_lights : (size_t)0))) return e;
     if ((e = devUpload(ctx, &sv.media, d->media, (size_t)d->n_media))) return e;
     if ((e = devUpload(ctx, &sv.mediumData, d->medium_data, (size_t)d->n_medium_floats))) return e;
     sv.nLights = d->n_lights;

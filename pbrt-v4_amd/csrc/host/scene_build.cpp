@@ -525,6 +525,71 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
     }
 }
 
+// PowerLightSampler ctor (lightsamplers.cpp:64-86): Light::Phi at SampleVisible(0.5) / pdf, averaged, then the
+// AliasTable construction of util/sampling.cpp:34-86 (same work-list order, so the same bins)
+static void BuildPowerAlias(SceneTables *T) {
+    const size_t n = T->lights.size();
+    T->powerAlias.assign(3 * n, 0.f);
+    if (n == 0) return;
+    Wavelengths lambda = SampleVisible(0.5f);
+    std::vector<float> lightPower;
+    for (const wf_light &l : T->lights) {
+        S4 Ls = S4c(0.f);
+        for (int i = 0; i < 4; ++i) {
+            int o = (int)std::lround(lambda.lambda[i]) - WF_LAMBDA_MIN;
+            Ls[i] = (o < 0 || o >= WF_NDENSE) ? 0.f : T->pool.data[l.spectrum_offset + o];
+        }
+        S4 phi = S4c(0.f);
+        switch (l.type) {
+        case WF_LIGHT_POINT: phi = 4 * Pi * l.scale * Ls; break;                              // lights.cpp:164-166
+        case WF_LIGHT_SPOT:                                                                   // lights.cpp:1365-1368
+            phi = l.scale * Ls * 2 * Pi * ((1 - l.cosFalloffStart) + (l.cosFalloffStart - l.cosFalloffEnd) / 2);
+            break;
+        case WF_LIGHT_DISTANT: phi = l.scale * Ls * Pi * Sqr(l.sceneRadius); break;           // lights.cpp:216-218
+        case WF_LIGHT_DIFFUSE_AREA:                                                           // lights.cpp:769-786
+            phi = Pi * ((l.flags & WF_LIGHTFLAG_TWOSIDED) ? 2 : 1) * l.area * (Ls * l.scale);
+            break;
+        case WF_LIGHT_UNIFORM_INFINITE: phi = 4 * Pi * Pi * Sqr(l.sceneRadius) * l.scale * Ls; break;  // lights.cpp:974-976
+        default: break;
+        }
+        lightPower.push_back(SafeDiv(phi, lambda.PDF()).Average());
+    }
+    float total = 0.f;
+    for (float v : lightPower) total += v;  // std::accumulate(..., 0.f)
+    if (total == 0.f) std::fill(lightPower.begin(), lightPower.end(), 1.f);
+    // AliasTable::AliasTable: the sum is accumulated in double (std::accumulate(..., 0.)) and stored as Float
+    double dsum = 0.;
+    for (float v : lightPower) dsum += v;
+    const float sum = (float)dsum;
+    struct Bin { float q = 0, p = 0; int alias = 0; };
+    std::vector<Bin> bins(n);
+    for (size_t i = 0; i < n; ++i) bins[i].p = lightPower[i] / sum;
+    struct Outcome { float pHat; size_t index; };
+    std::vector<Outcome> under, over;
+    for (size_t i = 0; i < n; ++i) {
+        float pHat = bins[i].p * n;
+        if (pHat < 1) under.push_back(Outcome{pHat, i});
+        else over.push_back(Outcome{pHat, i});
+    }
+    while (!under.empty() && !over.empty()) {
+        Outcome un = under.back(), ov = over.back();
+        under.pop_back();
+        over.pop_back();
+        bins[un.index].q = un.pHat;
+        bins[un.index].alias = (int)ov.index;
+        float pExcess = un.pHat + ov.pHat - 1;
+        if (pExcess < 1) under.push_back(Outcome{pExcess, ov.index});
+        else over.push_back(Outcome{pExcess, ov.index});
+    }
+    while (!over.empty()) { Outcome ov = over.back(); over.pop_back(); bins[ov.index].q = 1; bins[ov.index].alias = -1; }
+    while (!under.empty()) { Outcome un = under.back(); under.pop_back(); bins[un.index].q = 1; bins[un.index].alias = -1; }
+    for (size_t i = 0; i < n; ++i) {
+        T->powerAlias[3 * i] = bins[i].q;
+        T->powerAlias[3 * i + 1] = bins[i].p;
+        T->powerAlias[3 * i + 2] = BitsToFloat((uint32_t)bins[i].alias);
+    }
+}
+
 void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, SceneTables *T) {
     const ParamSet &ps = scene.camera.params;
     wf_camera &C = T->desc.camera;
@@ -1021,7 +1086,10 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         T->desc.light_sampler = WF_LS_BVH;
         // lights without Bounds() (distant, infinite) are the BVH sampler's "infiniteLights" — already listed
         BuildLightBVH(bvhLights, allLightBounds, &T->lightBvh, &T->lights);
-    } else if (lightSamplerName == "power") Die(scene.integrator.loc, "the \"power\" light sampler is not supported by this build yet");
+    } else if (lightSamplerName == "power") {
+        T->desc.light_sampler = WF_LS_POWER;
+        BuildPowerAlias(T);
+    }
     else {
         fprintf(stderr, "Warning: Light sample distribution type \"%s\" unknown. Using \"bvh\".\n", lightSamplerName.c_str());
         T->desc.light_sampler = WF_LS_BVH;

@@ -20,6 +20,9 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_small_ref.pfm $G/blobs_small.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_ref.pfm $G/materials_lights.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_box_ref.pfm $G/media_box.pbrt
+# the same lights through the PowerLightSampler (alias table)
+sed 's/Integrator "volpath"/Integrator "volpath" "string lightsampler" [ "power" ]/' $G/materials_lights.pbrt > $G/materials_lights_power.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_power_ref.pfm $G/materials_lights_power.pbrt
 # the named physical oracle (not sample-aligned): VolPathIntegrator at high spp, for mean comparisons
 oracle/_ref/pbrt_ref --quiet --seed 0 --spp 256 --outfile $G/cornell64_volpath256.pfm $G/cornell64.pbrt
 ls -la $G
