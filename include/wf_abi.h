@@ -168,10 +168,26 @@ typedef struct wf_light {
     float sceneCenter[3];        /* DISTANT / infinite: set by Preprocess (lights.h:243,546) */
     float sceneRadius;
     int32_t xform;               /* index into light_transforms (SPOT / IMAGE_INFINITE), or -1 */
-    int32_t image;               /* IMAGE_INFINITE image table id */
+    int32_t image;               /* IMAGE_INFINITE: index into image_lights */
     int32_t pad[2];
 } wf_light;
 #define WF_LIGHTFLAG_TWOSIDED 1
+
+/* PiecewiseConstant2D over [0,1]^2 (util/sampling.h:698-790): per row func[nx] + cdf[nx+1], row integrals,
+ * marginal func[ny] + cdf[ny+1]; offsets into wf_scene_desc::table_data */
+typedef struct wf_pc2d {
+    int32_t nx, ny;
+    int32_t cond_func_offset, cond_cdf_offset, cond_int_offset;
+    int32_t marg_func_offset, marg_cdf_offset;
+    float marg_int;
+} wf_pc2d;
+/* ImageInfiniteLight (lights.h:566-662): square equal-area (octahedral) RGB float image + its sampling
+ * distribution and the MIS-compensated one (lights.cpp:1009-1040) */
+typedef struct wf_image_light {
+    int32_t res;                 /* image is res x res */
+    int32_t pixel_offset;        /* res*res*3 floats (RGB interleaved, row 0 first) in table_data */
+    wf_pc2d distribution, compensated;
+} wf_image_light;
 
 /* Light BVH node, 32 bytes, same content as LightBVHNode/CompactLightBounds (lightsamplers.h:101-257) */
 typedef struct wf_light_bvh_node {
@@ -306,6 +322,13 @@ typedef struct wf_scene_desc {
     int32_t regularize;
     int32_t have_media;
     wf_options options;
+    /* image infinite lights + the RGB -> spectrum table of their colour space (util/color.h:368-395; sRGB) */
+    int32_t n_image_lights, n_table_floats;
+    const wf_image_light *image_lights;
+    const float *table_data;
+    const float *rgb2spec_coeffs;        /* [3][64][64][64][3] or null when no image light needs it */
+    float rgb2spec_znodes[64];
+    int32_t cs_illuminant_offset;        /* dense illuminant of that colour space in spectrum_data */
     /* participating media (media.h): ids referenced by wf_mesh.medium_inside/outside, wf_camera.medium */
     int32_t n_media, n_medium_floats;
     const struct wf_medium *media;

@@ -44,6 +44,79 @@ WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, N3 n, V3 w, const Wa
     return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ImageInfiniteLight (lights.h:566-662, lights.cpp:1042-1052)
+// PiecewiseConstant2D::Sample / PDF (util/sampling.h:760-780) over [0,1]^2
+WF_HD V2 PC2DSample(const float *D, const wf_pc2d &t, V2 u, float *pdf) {
+    float pdf1, pdf0;
+    int iv, iu;
+    float d1 = PC1DSample(D + t.marg_func_offset, D + t.marg_cdf_offset, t.ny, t.marg_int, 0.f, 1.f, u.y, &pdf1, &iv);
+    float d0 = PC1DSample(D + t.cond_func_offset + (size_t)iv * t.nx, D + t.cond_cdf_offset + (size_t)iv * (t.nx + 1), t.nx,
+                          D[t.cond_int_offset + iv], 0.f, 1.f, u.x, &pdf0, &iu);
+    *pdf = pdf0 * pdf1;
+    return V2{d0, d1};
+}
+WF_HD float PC2DPDF(const float *D, const wf_pc2d &t, V2 p) {
+    // domain.Offset(p) with domain [0,1]^2: (p - 0) / (1 - 0)
+    V2 o{(p.x - 0.f) / (1.f - 0.f), (p.y - 0.f) / (1.f - 0.f)};
+    int iu = Clamp((int)(o.x * t.nx), 0, t.nx - 1);
+    int iv = Clamp((int)(o.y * t.ny), 0, t.ny - 1);
+    return D[t.cond_func_offset + (size_t)iv * t.nx + iu] / t.marg_int;
+}
+// RGBToSpectrumTable::operator() (util/color.cpp:31-68) on the device copy of the table
+WF_HD void RGBToSpectrumCoeffs(const SceneView &sv, const float rgb[3], float c[3]) {
+    constexpr int res = 64;
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) {
+        c[0] = 0; c[1] = 0;
+        c[2] = (rgb[0] - .5f) / sqrt(rgb[0] * (1 - rgb[0]));
+        return;
+    }
+    int maxc = (rgb[0] > rgb[1]) ? ((rgb[0] > rgb[2]) ? 0 : 2) : ((rgb[1] > rgb[2]) ? 1 : 2);
+    float z = maxc == 0 ? rgb[0] : (maxc == 1 ? rgb[1] : rgb[2]);
+    float cx = maxc == 0 ? rgb[1] : (maxc == 1 ? rgb[2] : rgb[0]);  // rgb[(maxc + 1) % 3]
+    float cy = maxc == 0 ? rgb[2] : (maxc == 1 ? rgb[0] : rgb[1]);  // rgb[(maxc + 2) % 3]
+    float x = cx * (res - 1) / z;
+    float y = cy * (res - 1) / z;
+    int xi = (int)x < res - 2 ? (int)x : res - 2, yi = (int)y < res - 2 ? (int)y : res - 2;
+    int zi = FindInterval(res, [&](int i) { return sv.rgb2specZNodes[i] < z; });
+    float dx = x - xi, dy = y - yi, dz = (z - sv.rgb2specZNodes[zi]) / (sv.rgb2specZNodes[zi + 1] - sv.rgb2specZNodes[zi]);
+    for (int i = 0; i < 3; ++i) {
+        auto co = [&](int ddx, int ddy, int ddz) {
+            return sv.rgb2specCoeffs[((((size_t)maxc * res + (zi + ddz)) * res + (yi + ddy)) * res + (xi + ddx)) * 3 + i];
+        };
+        c[i] = Lerp(dz, Lerp(dy, Lerp(dx, co(0, 0, 0), co(1, 0, 0)), Lerp(dx, co(0, 1, 0), co(1, 1, 0))),
+                    Lerp(dy, Lerp(dx, co(0, 0, 1), co(1, 0, 1)), Lerp(dx, co(0, 1, 1), co(1, 1, 1))));
+    }
+}
+// ImageInfiniteLight::ImageLe (lights.h:640-647): nearest texel with octahedral wrap (util/image.h:96-125,352-356),
+// RGBIlluminantSpectrum of the clamped RGB (util/spectrum.cpp:235-246, util/spectrum.h:606-626)
+WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavelengths &lambda) {
+    const wf_image_light &im = sv.imageLights[l.image];
+    const int res = im.res;
+    int px = (int)(uv.x * res), py = (int)(uv.y * res);
+    if (px < 0) { px = -px; py = res - 1 - py; }
+    else if (px >= res) { px = 2 * res - 1 - px; py = res - 1 - py; }
+    if (py < 0) { px = res - 1 - px; py = -py; }
+    else if (py >= res) { px = res - 1 - px; py = 2 * res - 1 - py; }
+    if (res == 1) { px = 0; py = 0; }
+    const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
+    float rgb[3] = {fmax(0.f, texel[0]), fmax(0.f, texel[1]), fmax(0.f, texel[2])};
+    float m = fmax(fmax(rgb[0], rgb[1]), rgb[2]);
+    float scale = 2 * m;
+    float in[3] = {0, 0, 0};
+    if (scale) { in[0] = rgb[0] / scale; in[1] = rgb[1] / scale; in[2] = rgb[2] / scale; }
+    float c[3];
+    RGBToSpectrumCoeffs(sv, in, c);
+    S4 s;
+    for (int i = 0; i < 4; ++i) s[i] = scale * SigmoidPoly(lambda.lambda[i], c[0], c[1], c[2]);
+    S4 spec = s * DenseSample(sv, sv.csIlluminantOffset, lambda);
+    return l.scale * spec;
+}
+WF_HD V3 XfApply3(const float m[4][4], V3 v) {
+    return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
+              m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
+}
+
 WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V2 u,
                                   const Wavelengths &lambda, bool allowIncompletePDF) {
     LightLiSample ls{};
@@ -95,6 +168,19 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
         ls.pLightPi = MakeP3i(ctx.p() + wi * (2 * l.sceneRadius)); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
         return ls;
     }
+    case WF_LIGHT_IMAGE_INFINITE: {
+        // lights.h:606-633
+        const wf_image_light &im = sv.imageLights[l.image];
+        float mapPDF = 0;
+        V2 uv = PC2DSample(sv.tableData, allowIncompletePDF ? im.compensated : im.distribution, u, &mapPDF);
+        if (mapPDF == 0) return ls;
+        V3 wLight = EqualAreaSquareToSphere(uv);
+        V3 wi = XfApply3(sv.lightXforms[l.xform].m, wLight);
+        ls.L = ImageLightLe(sv, l, uv, lambda);
+        ls.wi = wi; ls.pdf = mapPDF / (4 * Pi);
+        ls.pLightPi = MakeP3i(ctx.p() + wi * (2 * l.sceneRadius)); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
     default: return ls;
     }
 }
@@ -103,12 +189,24 @@ WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &
     switch (l.type) {
     case WF_LIGHT_DIFFUSE_AREA: return TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
     case WF_LIGHT_UNIFORM_INFINITE: return allowIncompletePDF ? 0.f : Inv4Pi;
+    case WF_LIGHT_IMAGE_INFINITE: {
+        // lights.cpp:1042-1052
+        const wf_image_light &im = sv.imageLights[l.image];
+        V3 wLight = XfApply3(sv.lightXforms[l.xform].mInv, wi);
+        V2 uv = EqualAreaSphereToSquare(wLight);
+        return PC2DPDF(sv.tableData, allowIncompletePDF ? im.compensated : im.distribution, uv) / (4 * Pi);
+    }
     default: return 0.f;
     }
 }
 // Light::Le for infinite lights (lights.h:172-174 for the others)
 WF_HD S4 LightLe(const SceneView &sv, const wf_light &l, V3 rayd, const Wavelengths &lambda) {
     if (l.type == WF_LIGHT_UNIFORM_INFINITE) return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+    if (l.type == WF_LIGHT_IMAGE_INFINITE) {
+        // lights.h:597-601
+        V3 wLight = Normalize(XfApply3(sv.lightXforms[l.xform].mInv, rayd));
+        return ImageLightLe(sv, l, EqualAreaSphereToSquare(wLight), lambda);
+    }
     return S4c(0.f);
 }
 

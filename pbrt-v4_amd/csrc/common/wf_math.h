@@ -265,6 +265,46 @@ WF_HD float SphericalTriangleArea(V3 a, V3 b, V3 c) {
     return abs(2 * atan2(Dot(a, Cross(b, c)), 1 + Dot(a, b) + Dot(a, c) + Dot(b, c)));
 }
 
+// EqualAreaSquareToSphere / EqualAreaSphereToSquare, util/math.cpp:23-44,47-94
+WF_HD V3 EqualAreaSquareToSphere(V2 p) {
+    float u = 2 * p.x - 1, v = 2 * p.y - 1;
+    float up = abs(u), vp = abs(v);
+    float signedDistance = 1 - (up + vp);
+    float d = abs(signedDistance);
+    float r = 1 - d;
+    float phi = (r == 0 ? 1 : (vp - up) / r + 1) * Pi / 4;
+    float z = copysign(1 - Sqr(r), signedDistance);
+    float cosPhi = copysign(cos(phi), u);
+    float sinPhi = copysign(sin(phi), v);
+    return V3{cosPhi * r * SafeSqrt(2 - Sqr(r)), sinPhi * r * SafeSqrt(2 - Sqr(r)), z};
+}
+WF_HD V2 EqualAreaSphereToSquare(V3 d) {
+    float x = abs(d.x), y = abs(d.y), z = abs(d.z);
+    float r = SafeSqrt(1 - z);
+    float a = fmax(x, y), b = fmin(x, y);
+    b = a == 0 ? 0 : b / a;
+    const float t1 = 0.406758566246788489601959989e-5f;
+    const float t2 = 0.636226545274016134946890922156f;
+    const float t3 = 0.61572017898280213493197203466e-2f;
+    const float t4 = -0.247333733281268944196501420480f;
+    const float t5 = 0.881770664775316294736387951347e-1f;
+    const float t6 = 0.419038818029165735901852432784e-1f;
+    const float t7 = -0.251390972343483509333252996350e-1f;
+    // EvaluatePolynomial(b, t1..t7) = fma(b, EvaluatePolynomial(b, t2..t7), t1)  (util/math.h:329-337)
+    float phi = fma(b, fma(b, fma(b, fma(b, fma(b, fma(b, t7, t6), t5), t4), t3), t2), t1);
+    if (x < y) phi = 1 - phi;
+    float v = phi * r;
+    float u = r - v;
+    if (d.z < 0) {
+        float t = u; u = v; v = t;
+        u = 1 - u;
+        v = 1 - v;
+    }
+    u = copysign(u, d.x);
+    v = copysign(v, d.y);
+    return V2{0.5f * (u + 1), 0.5f * (v + 1)};
+}
+
 // Frame (util/vecmath.h:1847-1927)
 struct Frame {
     V3 x, y, z;

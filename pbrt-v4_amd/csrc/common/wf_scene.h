@@ -31,6 +31,12 @@ struct SceneView {
     int nLights, nInfiniteLights, nLightBvhNodes, lightSampler;
     const float *powerAlias;  // PowerLightSampler's AliasTable bins: nLights x {q, p, alias (int bits)}
     float allLightBounds[6];
+    // image infinite lights
+    const wf_image_light *imageLights;
+    const float *tableData;
+    const float *rgb2specCoeffs;
+    float rgb2specZNodes[64];
+    int csIlluminantOffset;
     // participating media
     const wf_medium *media;
     const float *mediumData;

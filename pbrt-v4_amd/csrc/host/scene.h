@@ -123,6 +123,8 @@ struct SceneTables {
     std::vector<wf_light_bvh_node> lightBvh;
     std::vector<wf_transform> lightTransforms;
     std::vector<float> filterData, powerAlias;
+    std::vector<wf_image_light> imageLights;
+    std::vector<float> tableData;
     std::vector<wf_medium> media;
     std::vector<float> mediumData;
     std::string imageFile;

@@ -42,6 +42,8 @@ void SceneTables::Finalize() {
     desc.n_light_transforms = (int)lightTransforms.size(); desc.light_transforms = lightTransforms.data();
     desc.power_alias = powerAlias.data();
     desc.n_filter_floats = (int)filterData.size(); desc.filter_data = filterData.data();
+    desc.n_image_lights = (int)imageLights.size(); desc.image_lights = imageLights.data();
+    desc.n_table_floats = (int)tableData.size(); desc.table_data = tableData.data();
     desc.n_media = (int)media.size(); desc.media = media.data();
     desc.n_medium_floats = (int)mediumData.size(); desc.medium_data = mediumData.data();
 }
@@ -550,6 +552,22 @@ static void BuildPowerAlias(SceneTables *T) {
             phi = Pi * ((l.flags & WF_LIGHTFLAG_TWOSIDED) ? 2 : 1) * l.area * (Ls * l.scale);
             break;
         case WF_LIGHT_UNIFORM_INFINITE: phi = 4 * Pi * Pi * Sqr(l.sceneRadius) * l.scale * Ls; break;  // lights.cpp:974-976
+        case WF_LIGHT_IMAGE_INFINITE: {                                                       // lights.cpp:1054-1072
+            const wf_image_light &im = T->imageLights[l.image];
+            const ColorSpace *ics = SpectralData::Get().sRGB();
+            S4 sumL = S4c(0.f);
+            for (int v = 0; v < im.res; ++v)
+                for (int u = 0; u < im.res; ++u) {
+                    const float *px = &T->tableData[im.pixel_offset + 3 * ((size_t)v * im.res + u)];
+                    float rgb[3] = {std::max(0.f, px[0]), std::max(0.f, px[1]), std::max(0.f, px[2])};
+                    SpectrumP sp = ics->Illuminant(rgb);
+                    S4 s;
+                    for (int i = 0; i < 4; ++i) s[i] = sp->scale * SigmoidPoly(lambda.lambda[i], sp->c0, sp->c1, sp->c2);
+                    sumL = sumL + s * Ls;  // Ls = the colour space's illuminant at lambda
+                }
+            phi = 4 * Pi * Pi * Sqr(l.sceneRadius) * l.scale * sumL / (float)(im.res * im.res);
+            break;
+        }
         default: break;
         }
         lightPower.push_back(SafeDiv(phi, lambda.PDF()).Average());
@@ -1042,10 +1060,99 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         } else if (le.name == "infinite") {
             std::vector<V3> portal = ps.GetPoint3fArray("portal");
             std::string filename = ps.GetOneString("filename", "");
-            if (!portal.empty() || !filename.empty()) Die(le.loc, "image / portal infinite lights are not supported by this build yet");
+            if (!portal.empty()) Die(le.loc, "portal infinite lights are not supported by this build yet");
             SpectrumP L = ps.GetOneSpectrum("L", nullptr, SpectrumType::Illuminant);
             float scale = ps.GetOneFloat("scale", 1);
             float E_v = ps.GetOneFloat("illuminance", -1);
+            if (!filename.empty()) {
+                // ImageInfiniteLight (lights.cpp:1567-1672, ctor :1001-1040)
+                if (L) Die(le.loc, "Can't specify both emission \"L\" and \"filename\" with ImageInfiniteLight");
+                if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
+                std::vector<float> rgb;
+                int w = 0, h = 0;
+                if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
+                    Die(le.loc, filename + ": unable to read image (this build reads RGB .pfm environment maps)");
+                for (float v : rgb) {
+                    if (std::isinf(v)) Die(le.loc, filename + ": image has infinite pixel values and so is not suitable as a light.");
+                    if (std::isnan(v)) Die(le.loc, filename + ": image has not-a-number pixel values and so is not suitable as a light.");
+                }
+                if (w != h) Die(le.loc, filename + ": image resolution is non-square. It's unlikely this is an equal area environment map.");
+                const ColorSpace *ics = sd.sRGB();  // PFM carries no colour space: ImageMetadata::GetColorSpace() -> sRGB
+                scale /= SpectrumToPhotometric(*ics->illuminant);
+                if (E_v > 0) {
+                    // upper-hemisphere illuminance of the map (lights.cpp:1620-1648)
+                    float illuminance = 0;
+                    float lum[3];
+                    for (int c = 0; c < 3; ++c) lum[c] = ics->XYZFromRGB.m[1][c];  // RGBColorSpace::LuminanceVector
+                    for (int y = 0; y < h; ++y) {
+                        float v = (float(y) + 0.5f) / float(h);
+                        for (int x = 0; x < w; ++x) {
+                            float u = (x + 0.5f) / w;
+                            V3 wv = EqualAreaSquareToSphere(V2{u, v});
+                            if (wv.z <= 0) continue;
+                            const float *px = &rgb[3 * ((size_t)y * w + x)];
+                            for (int c = 0; c < 3; ++c) illuminance += px[c] * lum[c] * wv.z;  // ... * CosTheta(w)
+                        }
+                    }
+                    illuminance *= 2 * Pi / (w * h);
+                    scale *= E_v / illuminance;
+                }
+                wf_image_light im{};
+                im.res = w;
+                im.pixel_offset = (int)T->tableData.size();
+                T->tableData.insert(T->tableData.end(), rgb.begin(), rgb.end());
+                // Image::GetSamplingDistribution (util/image.h:449-470): channel average per pixel
+                std::vector<float> d((size_t)w * h);
+                for (size_t i = 0; i < d.size(); ++i) {
+                    float sum = 0;
+                    for (int c = 0; c < 3; ++c) sum += rgb[3 * i + c];
+                    d[i] = sum / 3;
+                }
+                auto pc2d = [&](const std::vector<float> &f) {
+                    wf_pc2d t{};
+                    t.nx = w; t.ny = h;
+                    std::vector<float> condFunc, condCdf, condInt(h), mFunc, mCdf;
+                    for (int v = 0; v < h; ++v) {
+                        std::vector<float> fn, cdf;
+                        float fi;
+                        BuildPC1D(&f[(size_t)v * w], w, 0.f, 1.f, &fn, &cdf, &fi);
+                        condFunc.insert(condFunc.end(), fn.begin(), fn.end());
+                        condCdf.insert(condCdf.end(), cdf.begin(), cdf.end());
+                        condInt[v] = fi;
+                    }
+                    BuildPC1D(condInt.data(), h, 0.f, 1.f, &mFunc, &mCdf, &t.marg_int);
+                    std::vector<float> &D = T->tableData;
+                    t.cond_func_offset = (int)D.size(); D.insert(D.end(), condFunc.begin(), condFunc.end());
+                    t.cond_cdf_offset = (int)D.size(); D.insert(D.end(), condCdf.begin(), condCdf.end());
+                    t.cond_int_offset = (int)D.size(); D.insert(D.end(), condInt.begin(), condInt.end());
+                    t.marg_func_offset = (int)D.size(); D.insert(D.end(), mFunc.begin(), mFunc.end());
+                    t.marg_cdf_offset = (int)D.size(); D.insert(D.end(), mCdf.begin(), mCdf.end());
+                    return t;
+                };
+                im.distribution = pc2d(d);
+                // compensated distribution (lights.cpp:1031-1039)
+                double acc = 0.;
+                for (float v : d) acc += v;
+                float average = (float)(acc / d.size());
+                bool allZero = true;
+                for (float &v : d) { v = std::max(v - average, 0.f); if (v != 0) allZero = false; }
+                if (allZero) std::fill(d.begin(), d.end(), 1.f);
+                im.compensated = pc2d(d);
+                l.type = WF_LIGHT_IMAGE_INFINITE; l.scale = scale; l.spectrum_offset = T->pool.AddDense(*ics->illuminant);
+                l.image = (int)T->imageLights.size();
+                T->imageLights.push_back(im);
+                l.xform = (int)T->lightTransforms.size();
+                T->lightTransforms.push_back(le.renderFromLight.abi());
+                l.infinite_index = (int)T->infiniteLights.size();
+                T->infiniteLights.push_back(lightId);
+                T->lights.push_back(l);
+                // the device-side RGB -> spectrum table of the image's colour space
+                T->desc.rgb2spec_coeffs = ics->table->coeffs.data();
+                for (int i = 0; i < 64; ++i) T->desc.rgb2spec_znodes[i] = ics->table->zNodes[i];
+                T->desc.cs_illuminant_offset = l.spectrum_offset;
+                ps.ReportUnused("LightSource");
+                continue;
+            }
             if (!L) L = cs->illuminant;
             scale /= SpectrumToPhotometric(*L);
             if (E_v > 0) { float k_e = Pi; scale *= E_v / k_e; }
