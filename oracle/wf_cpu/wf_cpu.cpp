@@ -76,9 +76,171 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     return sv;
 }
 
+
+// ---- design study (not a checker): lane utilisation of wave-synchronous traversal schemes ---------------------
+// Walks each ray of a queue the way the production kernel does (pair nodes: both children tested at the parent,
+// nearest first) and records its event string: 0 = interior step, k > 0 = leaf with k triangle tests.  Then, for
+// groups of 64 consecutive queue entries (= one wave), counts the instruction cost of: "while-while" (all lanes
+// descend until each sits at a leaf, then leaves together), "unified" (every iteration each lane does one interior
+// step or one triangle test) and the ideal (no divergence).
+static float SlabEntry(const float bmin[3], const float bmax[3], V3 o, float raytMax, V3 invDir, int negMask, bool *hit) {
+    const bool n0 = negMask & 1, n1 = negMask & 2, n2 = negMask & 4;
+    float tMin = ((n0 ? bmax[0] : bmin[0]) - o.x) * invDir.x, tMax = ((n0 ? bmin[0] : bmax[0]) - o.x) * invDir.x;
+    float tyMin = ((n1 ? bmax[1] : bmin[1]) - o.y) * invDir.y, tyMax = ((n1 ? bmin[1] : bmax[1]) - o.y) * invDir.y;
+    float tzMin = ((n2 ? bmax[2] : bmin[2]) - o.z) * invDir.z, tzMax = ((n2 ? bmin[2] : bmax[2]) - o.z) * invDir.z;
+    tMin = std::max(tMin, std::max(tyMin, tzMin));
+    tMax = std::min(tMax, std::min(tyMax, tzMax)) * (1 + 2 * gamma(3));
+    *hit = tMin <= tMax && tMin < raytMax && tMax > 0;
+    return tMin;
+}
+static void RayEvents(const SceneView &sv, V3 o, V3 d, float tMax, std::vector<uint8_t> *ev) {
+    ev->clear();
+    V3 invDir{1 / d.x, 1 / d.y, 1 / d.z};
+    int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
+    int stack[128], sp = 0;
+    int node = 0;
+    if (sv.bvhNodes[0].nprims > 0) return;
+    while (true) {
+        const wf_bvh_node &n = sv.bvhNodes[node];
+        if (n.nprims == 0) {
+            ev->push_back(0);
+            int c[2] = {node + 1, (int)n.offset};
+            bool h[2];
+            float t[2];
+            for (int k = 0; k < 2; ++k) t[k] = SlabEntry(sv.bvhNodes[c[k]].bmin, sv.bvhNodes[c[k]].bmax, o, tMax, invDir, negMask, &h[k]);
+            if (h[0] && h[1]) {
+                int nearC = t[1] < t[0] ? 1 : 0;
+                stack[sp++] = c[nearC ^ 1];
+                node = c[nearC];
+                continue;
+            } else if (h[0]) { node = c[0]; continue; }
+            else if (h[1]) { node = c[1]; continue; }
+        } else {
+            ev->push_back((uint8_t)n.nprims);
+            for (int i = 0; i < n.nprims; ++i) {
+                int tri = sv.bvhPrims[n.offset + i];
+                V3 p0, p1, p2;
+                TriVerts(sv, tri, &p0, &p1, &p2);
+                TriHit hh;
+                if (IntersectTriangle(o, d, tMax, p0, p1, p2, &hh)) tMax = hh.t;
+            }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+}
+
+// streaming scheme: a wave owns a run of queue entries; finished lanes are refilled when >= R are idle; an iteration
+// runs the leaf step when >= LT lanes wait at a leaf (or nobody is interior), else the interior step
+static double SimulateStream(const std::vector<std::vector<uint8_t>> &rays, int R, int LT, double *itersOut) {
+    const double CI = 60, CT = 130, CR = 160;
+    size_t next = 0;
+    struct Lane { const std::vector<uint8_t> *ev = nullptr; size_t pos = 0; };
+    Lane lane[64];
+    double cost = 0, iters = 0;
+    while (true) {
+        int idle = 0;
+        for (auto &L : lane) if (!L.ev || L.pos >= L.ev->size()) ++idle;
+        if (idle >= R && next < rays.size()) {
+            for (auto &L : lane)
+                if ((!L.ev || L.pos >= L.ev->size()) && next < rays.size()) { L.ev = &rays[next++]; L.pos = 0; }
+            cost += CR;
+            continue;
+        }
+        int nI = 0, nL = 0, maxk = 0;
+        for (auto &L : lane) if (L.ev && L.pos < L.ev->size()) { if ((*L.ev)[L.pos] == 0) ++nI; else { ++nL; maxk = std::max(maxk, (int)(*L.ev)[L.pos]); } }
+        if (nI == 0 && nL == 0) { if (next >= rays.size()) break; else continue; }
+        iters += 1;
+        if (nL >= LT || nI == 0) {
+            for (auto &L : lane) if (L.ev && L.pos < L.ev->size() && (*L.ev)[L.pos] != 0) ++L.pos;
+            cost += maxk * CT;
+        } else {
+            for (auto &L : lane) if (L.ev && L.pos < L.ev->size() && (*L.ev)[L.pos] == 0) ++L.pos;
+            cost += CI;
+        }
+    }
+    *itersOut = iters;
+    return cost;
+}
+static uint64_t EncodeMorton3(uint32_t x, uint32_t y, uint32_t z) {
+    auto spread = [](uint64_t v) { uint64_t r = 0; for (int b = 0; b < 10; ++b) r |= ((v >> b) & 1ull) << (3 * b); return r; };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+struct WaveSim { double ww = 0, unified = 0, ideal = 0, spec = 0; double wwI = 0, wwT = 0, sumI = 0, sumT = 0; long waves = 0; };
+static void SimulateWave(const std::vector<std::vector<uint8_t>> &ev, int lanes, WaveSim *S) {
+    const double CI = 60, CT = 130;
+    // ideal
+    double sI = 0, sT = 0;
+    for (int l = 0; l < lanes; ++l) for (uint8_t e : ev[l]) { if (e == 0) sI += 1; else sT += e; }
+    S->sumI += sI; S->sumT += sT;
+    S->ideal += (sI * CI + sT * CT) / 64.0;
+    // while-while
+    {
+        std::vector<size_t> pos(lanes, 0);
+        while (true) {
+            int A = 0;
+            bool any = false;
+            for (int l = 0; l < lanes; ++l) {
+                int run = 0;
+                while (pos[l] < ev[l].size() && ev[l][pos[l]] == 0) { ++pos[l]; ++run; }
+                A = std::max(A, run);
+                if (pos[l] < ev[l].size()) any = true;
+            }
+            S->ww += A * CI; S->wwI += A;
+            if (!any) break;
+            int B = 0;
+            for (int l = 0; l < lanes; ++l) if (pos[l] < ev[l].size()) { B = std::max(B, (int)ev[l][pos[l]]); ++pos[l]; }
+            S->ww += B * CT; S->wwT += B;
+        }
+    }
+    // unified: per iteration each lane consumes one unit
+    {
+        std::vector<size_t> pos(lanes, 0);
+        std::vector<int> rem(lanes, 0);
+        while (true) {
+            bool anyI = false, anyT = false;
+            for (int l = 0; l < lanes; ++l) {
+                if (rem[l] > 0) { --rem[l]; anyT = true; continue; }
+                if (pos[l] >= ev[l].size()) continue;
+                uint8_t e = ev[l][pos[l]++];
+                if (e == 0) anyI = true;
+                else { rem[l] = e - 1; anyT = true; }
+            }
+            if (!anyI && !anyT) break;
+            S->unified += (anyI ? CI : 0) + (anyT ? CT : 0);
+        }
+    }
+    // speculative while-while: a lane parks its first leaf and keeps descending until its second leaf
+    {
+        std::vector<size_t> pos(lanes, 0);
+        std::vector<int> pend(lanes, 0);
+        while (true) {
+            int A = 0;
+            for (int l = 0; l < lanes; ++l) {
+                int run = 0;
+                while (pos[l] < ev[l].size()) {
+                    uint8_t e = ev[l][pos[l]];
+                    if (e == 0) { ++pos[l]; ++run; }
+                    else if (pend[l] == 0) { pend[l] = e; ++pos[l]; }
+                    else break;
+                }
+                A = std::max(A, run);
+            }
+            S->spec += A * CI;
+            int B = 0;
+            bool any = false;
+            for (int l = 0; l < lanes; ++l) { B = std::max(B, pend[l]); pend[l] = 0; if (pos[l] < ev[l].size()) any = true; }
+            S->spec += B * CT;
+            if (!any && B == 0) break;
+        }
+    }
+    S->waves++;
+}
+
 int main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
+    bool simulateWaves = false;
     int sampleBegin = 0, sampleEnd = -1, sampleStep = 1, probeStartDim = 0, probeNDims = 0;
     gThreads = std::max(1u, std::thread::hardware_concurrency());
     for (int i = 1; i < argc; ++i) {
@@ -93,6 +255,7 @@ int main(int argc, char **argv) {
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
         else if (a == "--dump-stages") dumpStages = next();
+        else if (a == "--simulate-waves") simulateWaves = true;
         else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
         else if (a == "--sampler-probe") { probeIn = next(); probeOut = next(); probeStartDim = atoi(next().c_str()); probeNDims = atoi(next().c_str()); }
         else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
@@ -216,6 +379,72 @@ int main(int argc, char **argv) {
                 const int nRays = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
                 ws.stats[1 + depth] += nRays;
                 ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex, sampleStep); });
+                if (simulateWaves && nRays > 0) {
+                    WaveSim S;
+                    std::vector<std::vector<uint8_t>> ev(64);
+                    for (int base = 0; base < nRays; base += 64 * 16) {  // every 16th wave
+                        int lanes = std::min(64, nRays - base);
+                        for (int l = 0; l < lanes; ++l) {
+                            F4 o = ws.rq[cur].o[base + l], d = ws.rq[cur].d[base + l];
+                            RayEvents(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, &ev[l]);
+                        }
+                        for (int l = lanes; l < 64; ++l) ev[l].clear();
+                        SimulateWave(ev, 64, &S);
+                    }
+                    {
+                        // one wave's share of the queue (~1700 consecutive rays) under the streaming scheme
+                        std::vector<std::vector<uint8_t>> run;
+                        int cnt = std::min(nRays, 1700);
+                        run.resize(cnt);
+                        for (int l = 0; l < cnt; ++l) {
+                            F4 o = ws.rq[cur].o[nRays / 3 + l < nRays ? nRays / 3 + l : l], d = ws.rq[cur].d[nRays / 3 + l < nRays ? nRays / 3 + l : l];
+                            RayEvents(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, &run[l]);
+                        }
+                        for (int R : {4, 8, 16})
+                            for (int LT : {8, 16, 24, 32}) {
+                                double it;
+                                double c = SimulateStream(run, R, LT, &it);
+                                fprintf(stderr, "  stream R=%d LT=%d: cost per 64 rays %.0f (iterations %.1f)\n", R, LT, c / cnt * 64, it / cnt * 64);
+                            }
+                    }
+                    {
+                        // the same queue sorted by (direction octant, Morton code of the origin cell): what a ray-binning
+                        // pass before the launch would give the fixed-batch kernel
+                        std::vector<std::pair<uint64_t, int>> keys(nRays);
+                        const float *sb = T.desc.scene_bounds;
+                        for (int i = 0; i < nRays; ++i) {
+                            F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+                            uint32_t oct = (d.x < 0) | ((d.y < 0) << 1) | ((d.z < 0) << 2);
+                            auto cell = [&](float v, int a) { float t = (v - sb[a]) / (sb[3 + a] - sb[a]); int c = (int)(t * 1024); return (uint32_t)std::min(std::max(c, 0), 1023); };
+                            uint64_t m = EncodeMorton3(cell(o.x, 0), cell(o.y, 1), cell(o.z, 2));
+                            for (int variant = 0; variant < 1; ++variant) keys[i] = {((uint64_t)oct << 40) | m, i};
+                        }
+                        std::sort(keys.begin(), keys.end());
+                        for (int mode = 0; mode < 2; ++mode) {
+                            if (mode == 1) {  // origin cell major, octant minor
+                                for (auto &k : keys) k.first = ((k.first & ((1ull << 40) - 1)) >> 9 << 3) | (k.first >> 40);
+                                std::sort(keys.begin(), keys.end());
+                            }
+                            WaveSim S2;
+                            std::vector<std::vector<uint8_t>> ev2(64);
+                            for (int base = 0; base < nRays; base += 64 * 16) {
+                                int lanes = std::min(64, nRays - base);
+                                for (int l = 0; l < lanes; ++l) {
+                                    int i = keys[base + l].second;
+                                    F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+                                    RayEvents(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, &ev2[l]);
+                                }
+                                for (int l = lanes; l < 64; ++l) ev2[l].clear();
+                                SimulateWave(ev2, 64, &S2);
+                            }
+                            fprintf(stderr, "  sorted (%s): while-while %.0f (I iters %.1f, T iters %.1f) util %.2f\n", mode == 0 ? "octant, origin" : "origin cell/8, octant",
+                                    S2.ww / S2.waves, S2.wwI / S2.waves, S2.wwT / S2.waves, S2.ideal / S2.ww);
+                        }
+                    }
+                    fprintf(stderr, "sim depth %d: waves %ld  per wave: ideal %.0f  while-while %.0f (I iters %.1f, T iters %.1f)  unified %.0f  speculative %.0f  | per ray: interior %.1f tris %.1f | util ww %.2f\n",
+                            depth, S.waves, S.ideal / S.waves, S.ww / S.waves, S.wwI / S.waves, S.wwT / S.waves, S.unified / S.waves, S.spec / S.waves,
+                            S.sumI / S.waves / 64, S.sumT / S.waves / 64, S.ideal / S.ww);
+                }
                 std::atomic<unsigned long long> nv{0}, nt{0};
                 ParallelFor(nRays, [&](int i) {
                     F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];

@@ -249,8 +249,11 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
             WalkInit(bvh, w, o, d, tMax);
             st.n = 0;
         }
-        // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower here; and
-        // per-lane refill of finished lanes from a prefetched batch — no gain once the launches are large.)
+        // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
+        // per-lane refill ("streaming": idle lanes take the next rays of the wave's run, leaf / interior step chosen per
+        // iteration) — 28 % fewer VALU instructions at 53 % instead of 31 % active lanes, but 5x the vector-L1 line
+        // accesses (7.2e8 vs 1.45e8 per 8.5 M-ray launch): lanes at unrelated depths of the tree no longer share
+        // cache lines, and the walk becomes L1-bound: 33 ms vs 27 ms per 16 spp.  DESIGN.md §4.)
         while (__any(w.node != NODE_NONE)) {
             while (__any(w.node >= 0)) {
                 if (w.node >= 0) {
@@ -297,6 +300,7 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneVi
         },
         [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
 }
+
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};

@@ -18,7 +18,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0][-40:]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
 for k in agg:
-    if "closest" in k or "shadow" in k:
+    if "closest" in k or "shadow" in k or "route" in k:
         print(k, len(cnt[k]), {c: "%.4g" % (v / len(cnt[k])) for c, v in agg[k].items()})
 PY
 }
