@@ -50,6 +50,8 @@ def make_scene(path, spp, workload="killeroo-like", meshes=1600):
     import make_scenes
     if workload == "sanmiguel-like":
         make_scenes.sanmiguel_like(path, (W, H), spp, n_meshes=meshes)
+    elif workload == "cloud-like":
+        make_scenes.cloud_like(path, (W, H), spp)
     else:
         make_scenes.killeroo_like(path, (W, H), spp)
 
@@ -94,7 +96,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="sample indices carried per pass (0 = automatic, ~16 M rays in flight)")
-    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like"], default="killeroo-like",
+    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like"], default="killeroo-like",
                     help="killeroo-like = BASELINE configs[1] stand-in (default, the metric's config); sanmiguel-like = configs[2] stand-in")
     ap.add_argument("--meshes", type=int, default=1600, help="sanmiguel-like: number of 6272-triangle meshes (1600 = 10 M triangles)")
     a = ap.parse_args()
@@ -185,6 +187,9 @@ def main():
             "config": {"workload": ("killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
                                     "diffuse + dielectric, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
                                     if a.workload == "killeroo-like" else
+                                    "Disney cloud 1080p (BASELINE.json configs[3]) on the cloud-like stand-in (64^3 uniformgrid medium, g = 0.877, "
+                                    "%d triangles, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
+                                    if a.workload == "cloud-like" else
                                     "San Miguel 1080p (BASELINE.json configs[2]) on the sanmiguel-like stand-in: %d triangles, diffuse/coated "
                                     "diffuse/dielectric/conductor, sun + sky + 400 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
                                    % (info.n_triangles, info.max_depth),

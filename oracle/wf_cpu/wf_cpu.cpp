@@ -441,6 +441,45 @@ int main(int argc, char **argv) {
                                     S2.ww / S2.waves, S2.wwI / S2.waves, S2.wwT / S2.waves, S2.ideal / S2.ww);
                         }
                     }
+                    {
+                        // capped batches with continuation: a lane that has done K interior steps is suspended (state to a
+                        // continuation queue); suspended rays are walked later, 64 at a time, again capped
+                        for (int K : {16, 24, 32, 48}) {
+                            std::vector<std::vector<uint8_t>> cur_, nextq;
+                            for (int base = 0; base < nRays; base += 64 * 16)
+                                for (int l = 0; l < std::min(64, nRays - base); ++l) {
+                                    F4 o = ws.rq[cur].o[base + l], d = ws.rq[cur].d[base + l];
+                                    std::vector<uint8_t> e;
+                                    RayEvents(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, &e);
+                                    cur_.push_back(std::move(e));
+                                }
+                            const double nTotal = cur_.size();
+                            double cost = 0;
+                            int rounds = 0;
+                            while (!cur_.empty() && rounds < 12) {
+                                nextq.clear();
+                                for (size_t base = 0; base < cur_.size(); base += 64) {
+                                    std::vector<std::vector<uint8_t>> ev3(64);
+                                    for (size_t l = 0; l < 64 && base + l < cur_.size(); ++l) {
+                                        auto &e = cur_[base + l];
+                                        int nI = 0;
+                                        size_t cut = e.size();
+                                        for (size_t k = 0; k < e.size(); ++k)
+                                            if (e[k] == 0 && ++nI > K) { cut = k; break; }
+                                        ev3[l].assign(e.begin(), e.begin() + cut);
+                                        if (cut < e.size()) nextq.emplace_back(e.begin() + cut, e.end());
+                                    }
+                                    WaveSim S3;
+                                    SimulateWave(ev3, 64, &S3);
+                                    cost += S3.ww + (rounds > 0 ? 200 : 0);   // + restore cost
+                                }
+                                cost += nextq.size() * 200.0 / 64;   // suspend cost
+                                cur_.swap(nextq);
+                                ++rounds;
+                            }
+                            fprintf(stderr, "  capped K=%d: cost per 64 rays %.0f (%d rounds)\n", K, cost / nTotal * 64, rounds);
+                        }
+                    }
                     fprintf(stderr, "sim depth %d: waves %ld  per wave: ideal %.0f  while-while %.0f (I iters %.1f, T iters %.1f)  unified %.0f  speculative %.0f  | per ray: interior %.1f tris %.1f | util ww %.2f\n",
                             depth, S.waves, S.ideal / S.waves, S.ww / S.waves, S.wwI / S.waves, S.wwT / S.waves, S.unified / S.waves, S.spec / S.waves,
                             S.sumI / S.waves / 64, S.sumT / S.waves / 64, S.ideal / S.ww);

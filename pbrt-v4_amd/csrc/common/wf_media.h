@@ -110,14 +110,24 @@ WF_HD void XfInvRay(const wf_transform &t, V3 *o, V3 *d, float *tMax) {
     *d = dd;
 }
 
-// Medium::SamplePoint: HomogeneousMedium media.h:247-252, GridMedium media.h:283-317
-WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, V3 p, const Wavelengths &lambda) {
+// Medium::SamplePoint: HomogeneousMedium media.h:247-252, GridMedium media.h:283-317.  The spectra sampled at the
+// ray's wavelengths (sigma_a_spec.Sample(lambda) ...) do not depend on the point: MediumAtLambda holds them once per
+// ray instead of once per tracking event (same values).
+struct MediumAtLambda { S4 sigma_a, sigma_s, Le; };
+WF_HD MediumAtLambda MediumSpectra(const SceneView &sv, const wf_medium &M, const Wavelengths &lambda) {
+    MediumAtLambda ml;
+    ml.sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
+    ml.sigma_s = DenseSample(sv, M.sigma_s_offset, lambda);
+    ml.Le = (M.type == WF_MEDIUM_HOMOGENEOUS || M.is_emissive) ? DenseSample(sv, M.le_offset, lambda) : S4c(0.f);
+    return ml;
+}
+WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, const MediumAtLambda &ml, V3 p) {
     MediumProps mp;
     mp.g = M.g;
-    mp.sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
-    mp.sigma_s = DenseSample(sv, M.sigma_s_offset, lambda);
+    mp.sigma_a = ml.sigma_a;
+    mp.sigma_s = ml.sigma_s;
     if (M.type == WF_MEDIUM_HOMOGENEOUS) {
-        mp.Le = DenseSample(sv, M.le_offset, lambda);
+        mp.Le = ml.Le;
         return mp;
     }
     p = XfInvPoint(M.render_from_medium, p);
@@ -128,7 +138,7 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, V3 
     mp.Le = S4c(0.f);
     if (M.is_emissive) {
         float scale = GridLookup(sv.mediumData + M.le_scale_offset, M.le_nx, M.le_ny, M.le_nz, p);
-        if (scale > 0) mp.Le = scale * DenseSample(sv, M.le_offset, lambda);
+        if (scale > 0) mp.Le = scale * ml.Le;
     }
     return mp;
 }
@@ -175,10 +185,10 @@ struct MajorantIter {
 };
 
 // Medium::SampleRay for a ray with unit-length direction (SampleT_maj normalises first)
-WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, V3 o, V3 d, float raytMax, const Wavelengths &lambda) {
+WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, const MediumAtLambda &ml, V3 o, V3 d, float raytMax) {
     MajorantIter it;
-    S4 sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
-    S4 sigma_s = DenseSample(sv, M.sigma_s_offset, lambda);
+    S4 sigma_a = ml.sigma_a;
+    S4 sigma_s = ml.sigma_s;
     if (M.type == WF_MEDIUM_HOMOGENEOUS) {
         it.homogeneous = true;
         it.called = false;
@@ -228,7 +238,8 @@ WF_HD S4 SampleT_maj(const SceneView &sv, int mediumId, V3 o, V3 d, float tMax, 
     const wf_medium &M = sv.media[mediumId];
     tMax *= Length(d);
     d = Normalize(d);
-    MajorantIter iter = MediumSampleRay(sv, M, o, d, tMax, lambda);
+    const MediumAtLambda ml = MediumSpectra(sv, M, lambda);
+    MajorantIter iter = MediumSampleRay(sv, M, ml, o, d, tMax);
     S4 T_maj = S4c(1.f);
     bool done = false;
     while (!done) {
@@ -247,7 +258,7 @@ WF_HD S4 SampleT_maj(const SceneView &sv, int mediumId, V3 o, V3 d, float tMax, 
             if (t < seg.tMax) {
                 T_maj = T_maj * FastExp(-(t - tMin) * seg.sigma_maj);
                 V3 p = o + d * t;
-                MediumProps mp = MediumSamplePoint(sv, M, p, lambda);
+                MediumProps mp = MediumSamplePoint(sv, M, ml, p);
                 if (!callback(p, mp, seg.sigma_maj, T_maj)) {
                     done = true;
                     break;
