@@ -265,7 +265,7 @@ typedef struct wf_film {
     float outputRGBFromSensorRGB[3][3];
 } wf_film;
 
-enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1 };
+enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1, WF_SAMPLER_STRATIFIED = 2, WF_SAMPLER_PADDED_SOBOL = 3 };
 enum wf_randomize { WF_RAND_NONE = 0, WF_RAND_PERMUTE_DIGITS = 1, WF_RAND_FAST_OWEN = 2, WF_RAND_OWEN = 3 };
 typedef struct wf_sampler {
     int32_t type;
@@ -273,6 +273,7 @@ typedef struct wf_sampler {
     int32_t seed;
     int32_t randomize;
     int32_t log2spp, nBase4Digits;        /* ZSobol (samplers.h:228-240) */
+    int32_t x_samples, y_samples, jitter; /* Stratified (samplers.h:503-575) */
 } wf_sampler;
 
 enum wf_light_sampler_type { WF_LS_UNIFORM = 0, WF_LS_POWER = 1, WF_LS_BVH = 2 };

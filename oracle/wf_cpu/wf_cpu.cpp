@@ -290,7 +290,7 @@ int main(int argc, char **argv) {
         fclose(f);
         std::vector<float> out((size_t)n * probeNDims);
         for (int i = 0; i < n; ++i) {
-            ZSobol s(sv);
+            PixelSampler s(sv);
             s.StartPixelSample(in[3 * i], in[3 * i + 1], in[3 * i + 2], probeStartDim);
             for (int d = 0; d < probeNDims; ++d) out[(size_t)i * probeNDims + d] = s.Get1D();
         }

@@ -140,6 +140,67 @@ struct ZSobol {
     WF_HD V2 GetPixel2D() { return Get2D(); }
 };
 
+// The sampler of the scene behind the Sampler interface the stages use (base/sampler.h:40-64): ZSobol (above),
+// IndependentSampler (samplers.h:442-482), StratifiedSampler (:503-575), PaddedSobolSampler (:130-222).
+struct PixelSampler {
+    ZSobol z;
+    int type, spp, seed, randomize, xs, ys, jitter;
+    const uint32_t *sobol;
+    RNG rng;
+    int px = 0, py = 0, sampleIndex = 0, dimension = 0;
+
+    WF_HD PixelSampler(const SceneView &sv)
+        : z(sv), type(sv.sampler.type), spp(sv.sampler.spp), seed(sv.sampler.seed), randomize(sv.sampler.randomize),
+          xs(sv.sampler.x_samples), ys(sv.sampler.y_samples), jitter(sv.sampler.jitter), sobol(sv.sobol) {}
+    WF_HD static uint64_t HashPixelSeed(int x, int y, int sd) { uint32_t w[3] = {(uint32_t)x, (uint32_t)y, (uint32_t)sd}; return HashWords(w, 3); }
+    WF_HD static uint64_t HashPixelDimSeed(int x, int y, int dim, int sd) {
+        uint32_t w[4] = {(uint32_t)x, (uint32_t)y, (uint32_t)dim, (uint32_t)sd};
+        return HashWords(w, 4);
+    }
+    WF_HD void StartPixelSample(int x, int y, int index, int dim) {
+        if (type == WF_SAMPLER_ZSOBOL) { z.StartPixelSample(x, y, index, dim); return; }
+        px = x; py = y; sampleIndex = index; dimension = dim;
+        if (type != WF_SAMPLER_PADDED_SOBOL) {
+            rng.SetSequence(HashPixelSeed(x, y, seed));
+            rng.Advance(index * 65536ull + dim);
+        }
+    }
+    WF_HD void SetTop(uint64_t t) { z.SetTop(t); }
+    WF_HD float PaddedDim(int dim, uint32_t a, uint32_t hash) const { return SobolSample(sobol, (int64_t)a, dim, randomize, hash); }
+    WF_HD float Get1D() {
+        if (type == WF_SAMPLER_ZSOBOL) return z.Get1D();
+        if (type == WF_SAMPLER_INDEPENDENT) return rng.UniformFloat();
+        uint64_t hash = HashPixelDimSeed(px, py, dimension, seed);
+        if (type == WF_SAMPLER_STRATIFIED) {
+            int n = xs * ys;
+            int stratum = PermutationElement((uint32_t)sampleIndex, (uint32_t)n, (uint32_t)hash);
+            ++dimension;
+            float delta = jitter ? rng.UniformFloat() : 0.5f;
+            return (stratum + delta) / n;
+        }
+        int index = PermutationElement((uint32_t)sampleIndex, (uint32_t)spp, (uint32_t)hash);
+        dimension++;
+        return PaddedDim(0, (uint32_t)index, (uint32_t)(hash >> 32));
+    }
+    WF_HD V2 Get2D() {
+        if (type == WF_SAMPLER_ZSOBOL) return z.Get2D();
+        if (type == WF_SAMPLER_INDEPENDENT) { float a = rng.UniformFloat(); float b = rng.UniformFloat(); return V2{a, b}; }
+        uint64_t hash = HashPixelDimSeed(px, py, dimension, seed);
+        if (type == WF_SAMPLER_STRATIFIED) {
+            int stratum = PermutationElement((uint32_t)sampleIndex, (uint32_t)(xs * ys), (uint32_t)hash);
+            dimension += 2;
+            int x = stratum % xs, y = stratum / xs;
+            float dx = jitter ? rng.UniformFloat() : 0.5f;
+            float dy = jitter ? rng.UniformFloat() : 0.5f;
+            return V2{(x + dx) / xs, (y + dy) / ys};
+        }
+        int index = PermutationElement((uint32_t)sampleIndex, (uint32_t)spp, (uint32_t)hash);
+        dimension += 2;
+        return V2{PaddedDim(0, (uint32_t)index, (uint32_t)hash), PaddedDim(1, (uint32_t)index, (uint32_t)(hash >> 32))};
+    }
+    WF_HD V2 GetPixel2D() { return Get2D(); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Filter::Sample (filters.h): box/triangle analytic, the others through FilterSampler (filters.h:26-45)
 // = PiecewiseConstant2D::Sample (util/sampling.h:760-770) over PiecewiseConstant1D::Sample (:657-675).

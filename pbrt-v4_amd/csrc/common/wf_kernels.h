@@ -216,7 +216,7 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     if (slot >= nSamples) py = F.pixel_max[1];  // unused sample slot of a short last batch: mark out of bounds
     ws.pPixel[pixelIndex] = I2{px, py};
     if (!(px >= F.pixel_min[0] && px < F.pixel_max[0] && py >= F.pixel_min[1] && py < F.pixel_max[1])) return;
-    ZSobol sampler(sv);
+    PixelSampler sampler(sv);
     sampler.StartPixelSample(px, py, sampleIndex, 0);
     const uint32_t *tops = useTops ? ws.sampleTops + p : nullptr;
     const int tstride = ws.pixelsPerPass;
@@ -268,7 +268,7 @@ WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur
     const int slot = pixelIndex / ws.pixelsPerPass;
     const int sampleIndex = sampleBase + slot * sampleStep;
     int dimension = 6 + 7 * depth;
-    ZSobol sampler(sv);
+    PixelSampler sampler(sv);
     I2 pp = ws.pPixel[pixelIndex];
     sampler.StartPixelSample(pp.x, pp.y, sampleIndex, dimension);
     const bool useTops = depth == topsDepth;

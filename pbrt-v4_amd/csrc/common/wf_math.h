@@ -483,6 +483,36 @@ WF_HD uint64_t MixBits(uint64_t v) {
     v ^= (v >> 33);
     return v;
 }
+// util/math.h:727-755
+WF_HD int PermutationElement(uint32_t i, uint32_t l, uint32_t p) {
+    uint32_t w = l - 1;
+    w |= w >> 1;
+    w |= w >> 2;
+    w |= w >> 4;
+    w |= w >> 8;
+    w |= w >> 16;
+    do {
+        i ^= p;
+        i *= 0xe170893d;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8;
+        i *= 0x0929eb3f;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1;
+        i *= 1 | p >> 27;
+        i *= 0x6935fa69;
+        i ^= (i & w) >> 11;
+        i *= 0x74dcb303;
+        i ^= (i & w) >> 2;
+        i *= 0x9e501cc3;
+        i ^= (i & w) >> 2;
+        i *= 0xc860a3df;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (int)((i + p) % l);
+}
 WF_HD float HashToFloat(uint64_t h) { return uint32_t(h) * 0x1p-32f; }
 
 // PCG32 (util/rng.h:22-172)
@@ -490,6 +520,22 @@ struct RNG {
     uint64_t state, inc;
     WF_HD RNG() : state(0x853c49e6748fea9bULL), inc(0xda3e39cb94b95bdbULL) {}
     WF_HD RNG(uint64_t seqIndex, uint64_t offset) { SetSequence(seqIndex, offset); }
+    WF_HD void SetSequence(uint64_t sequenceIndex) { SetSequence(sequenceIndex, MixBits(sequenceIndex)); }  // util/rng.h:43-45
+    // util/rng.h:137-150
+    WF_HD void Advance(int64_t idelta) {
+        uint64_t curMult = 0x5851f42d4c957f2dULL, curPlus = inc, accMult = 1u;
+        uint64_t accPlus = 0u, delta = (uint64_t)idelta;
+        while (delta > 0) {
+            if (delta & 1) {
+                accMult *= curMult;
+                accPlus = accPlus * curMult + curPlus;
+            }
+            curPlus = (curMult + 1) * curPlus;
+            curMult *= curMult;
+            delta /= 2;
+        }
+        state = accMult * state + accPlus;
+    }
     WF_HD void SetSequence(uint64_t sequenceIndex, uint64_t seed) {
         state = 0u;
         inc = (sequenceIndex << 1u) | 1u;

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_any(const SceneView sv, int n, 
 }
 __global__ void __launch_bounds__(BLOCK) k_sampler_probe(const SceneView sv, int n, const int32_t *px, const int32_t *py, const int32_t *si, int startDim, int ndims, float *out) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        ZSobol s(sv);
+        PixelSampler s(sv);
         s.StartPixelSample(px[i], py[i], si[i], startDim);
         for (int d = 0; d < ndims; ++d) out[(size_t)i * ndims + d] = s.Get1D();
     }
@@ -681,7 +681,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.filter = d->filter;
     if ((e = devUpload(ctx, &sv.filterData, d->filter_data, (size_t)d->n_filter_floats))) return e;
     sv.sampler = d->sampler;
-    if (d->sampler.type != WF_SAMPLER_ZSOBOL) return fail(-1, "only the zsobol sampler is implemented by the HIP kernels");
+    if (d->sampler.type < WF_SAMPLER_ZSOBOL || d->sampler.type > WF_SAMPLER_PADDED_SOBOL) return fail(-1, "unknown sampler type %d", d->sampler.type);
     static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
     if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)WF_SOBOL_WORDS))) return e;
@@ -768,7 +768,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
         return e;
     // pixel-only sample-index digits (wf_camera.h TopDigits): usable while the permuted index fits 32 bits
     ws.sampleTops = nullptr;
-    if (2 * ctx->svHost.sampler.nBase4Digits <= 32 && !getenv("WF_NO_SAMPLE_TOPS"))
+    if (ctx->svHost.sampler.type == WF_SAMPLER_ZSOBOL && 2 * ctx->svHost.sampler.nBase4Digits <= 32 && !getenv("WF_NO_SAMPLE_TOPS"))
         if ((e = devAlloc(ctx, &ws.sampleTops, (size_t)5 * pixels_per_pass))) return e;
     if ((e = allocRayQueue(ctx, &ws.rq[0], n)) || (e = allocRayQueue(ctx, &ws.rq[1], n))) return e;
     if (ctx->svHost.haveMedia) {

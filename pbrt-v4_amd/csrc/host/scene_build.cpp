@@ -424,9 +424,36 @@ void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTable
         S.nBase4Digits = Log2Int((uint32_t)res) + log4spp;
         S.spp = 1 << S.log2spp;
     } else if (scene.sampler.name == "independent") {
+        // samplers.cpp IndependentSampler::Create: default 4 samples
         S.type = WF_SAMPLER_INDEPENDENT;
+        S.spp = ps.GetOneInt("pixelsamples", 4);
+        if (opt.pixelSamples > 0) S.spp = opt.pixelSamples;
+    } else if (scene.sampler.name == "stratified") {
+        // StratifiedSampler::Create
+        S.type = WF_SAMPLER_STRATIFIED;
+        S.jitter = ps.GetOneBool("jitter", true);
+        int xs = ps.GetOneInt("xsamples", 4), ys = ps.GetOneInt("ysamples", 4);
+        if (opt.pixelSamples > 0) {
+            int n = opt.pixelSamples;
+            int div = (int)std::sqrt((double)n);
+            while (n % div) --div;
+            xs = n / div;
+            ys = n / xs;
+        }
+        S.x_samples = xs; S.y_samples = ys;
+        S.spp = xs * ys;
+    } else if (scene.sampler.name == "paddedsobol") {
+        // PaddedSobolSampler::Create
+        S.type = WF_SAMPLER_PADDED_SOBOL;
+        std::string s = ps.GetOneString("randomization", "fastowen");
+        if (s == "none") S.randomize = WF_RAND_NONE;
+        else if (s == "permutedigits") S.randomize = WF_RAND_PERMUTE_DIGITS;
+        else if (s == "fastowen") S.randomize = WF_RAND_FAST_OWEN;
+        else if (s == "owen") S.randomize = WF_RAND_OWEN;
+        else Die(scene.sampler.loc, s + ": unknown randomization strategy given to PaddedSobolSampler");
+        if (nsamp & (nsamp - 1)) fprintf(stderr, "Warning: Sobol samplers with non power-of-two sample counts (%d) are suboptimal.\n", nsamp);
         S.spp = nsamp;
-    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, independent)");
+    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, independent, stratified, paddedsobol)");
     T->spp = S.spp;
     ps.ReportUnused("Sampler");
 }

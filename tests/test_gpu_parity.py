@@ -107,19 +107,21 @@ def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
 
 def _render_both(scene, path, spp, tmp_path):
     scene.clear_film()
-    scene.render(0, spp, 1)
+    scene.render(0, spp if spp else scene.spp, 1)
     img = scene.image()
     out = str(tmp_path / "cpu.pfm")
     j = run_wf_cpu(path, out, spp)
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "envmap"])
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "envmap",
+                                  "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
-    s = wfpt.Scene(path=path, spp=4)
+    spp = 0 if name.startswith("cornell64_") else 4   # the sampler scenes keep their samplers' default sample counts
+    s = wfpt.Scene(path=path, spp=spp)
     s.create_renderer(0)
-    img, cpu, j = _render_both(s, path, 4, tmp_path)
+    img, cpu, j = _render_both(s, path, spp, tmp_path)
     # integer work: identical ray counts stage by stage
     assert s.stats()["camera_rays"] == j["camera_rays"]
     if name in ("media_box", "envmap"):
