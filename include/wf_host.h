@@ -33,7 +33,7 @@ void wfh_scene_free(wfh_scene *s);
 const wf_scene_desc *wfh_scene_desc(wfh_scene *s);
 int wfh_scene_info(wfh_scene *s, wfh_info *out);
 /* WavefrontPathIntegrator ctor on HIP device `device`.  samples_per_pass: sample indices carried by one pass
-   (see wf_queues_alloc); <= 0 = automatic (~16 M rays in flight, capped at spp; env WF_SAMPLES_PER_PASS) */
+   (see wf_queues_alloc); <= 0 = automatic (~64 M rays in flight, capped at spp; env WF_SAMPLES_PER_PASS) */
 int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass);
 int wfh_renderer_samples_per_pass(wfh_scene *s);
 wf_ctx *wfh_renderer_ctx(wfh_scene *s);

@@ -9,7 +9,7 @@ class WavefrontRenderer {
   public:
     // uploads the scene tables to HIP device `device` and allocates the work queues
     // (WavefrontPathIntegrator ctor, wavefront/integrator.cpp:80-287)
-    // samplesPerPass <= 0: automatic (env WF_SAMPLES_PER_PASS, else ~16 M rays in flight)
+    // samplesPerPass <= 0: automatic (env WF_SAMPLES_PER_PASS, else ~64 M rays in flight)
     WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPass = 0);
     int SamplesPerPass() const { return samplesPerPass; }
     ~WavefrontRenderer();

@@ -12,12 +12,12 @@ python tools/make_scenes.py killeroo-like /tmp/k.pbrt --spp 16
 timeout 120 pbrt-v4_amd/_build/pbrt_amd --stats --outfile /tmp/k.pfm /tmp/k.pbrt > gpurun_out/killeroo_stats.txt 2>&1
 grep -E "Rendering|launches|Total" gpurun_out/killeroo_stats.txt
 if [ "${BIG:-1}" = "1" ]; then
-  timeout 900 python bench.py --workload sanmiguel-like --meshes ${MESHES:-1600} --steps 8 --warmup 1 --cpu-spp 0 2>gpurun_out/bench_sm_err.txt | tee gpurun_out/bench_sanmiguel.json
+  timeout 900 python bench.py --workload sanmiguel-like --meshes ${MESHES:-1600} --steps 16 --warmup 1 --cpu-spp 0 2>gpurun_out/bench_sm_err.txt | tee gpurun_out/bench_sanmiguel.json
   tail -3 gpurun_out/bench_sm_err.txt
 fi
 if [ "${PROF:-1}" = "1" ]; then
   rm -rf /tmp/prof
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 1 --cpu-spp 0 > $GRAFT_REPO_ROOT/gpurun_out/bench_prof.json 2> /tmp/rocprof_err.txt)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps ${STEPS:-64} --warmup 2 --cpu-spp 0 > $GRAFT_REPO_ROOT/gpurun_out/bench_prof.json 2> /tmp/rocprof_err.txt)
   for f in $(find /tmp/prof -name "*kernel_stats.csv"); do cp $f gpurun_out/rocprof_kernel_stats.csv; done
   head -16 gpurun_out/rocprof_kernel_stats.csv
   python tools/make_scenes.py killeroo-like /tmp/k4.pbrt --spp 4
