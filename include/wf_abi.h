@@ -92,7 +92,9 @@ enum wf_texture_type {
     WF_TEX_FLOAT_MIX = 4,          /* lerp(amount tex2, tex0, tex1) */
     WF_TEX_SPECTRUM_MIX = 5,
     WF_TEX_FLOAT_IMAGE = 6,        /* image id in i0, mapping in map */
-    WF_TEX_SPECTRUM_IMAGE = 7
+    WF_TEX_SPECTRUM_IMAGE = 7,
+    WF_TEX_FLOAT_CHECKERBOARD = 8,     /* 2D checkerboard over the UVMapping in map[0..3]; tex0 = "tex1", tex1 = "tex2" (textures.h:352-420) */
+    WF_TEX_SPECTRUM_CHECKERBOARD = 9
 };
 typedef struct wf_texture {
     int32_t type;

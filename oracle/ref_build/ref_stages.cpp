@@ -2,7 +2,7 @@
 // Runs the reference's CPU WavefrontPathIntegrator stage by stage for sample index 0 of the first pass and
 // dumps the queues after "Generate camera rays" and after IntersectClosest at depth 0, so that the restated
 // stages can be compared item by item (tools/compare_stages.py).  Private members are reached with the
-// test-only `#define private public` below; nothing in the reference is modified.
+// test-only `#define private public` / `protected public` below; nothing in the reference is modified.
 //   ref_stages scene.pbrt outdir
 #include <algorithm>
 #include <cstdio>
@@ -35,6 +35,7 @@
 #define private public
 #define protected public
 #include <pbrt/pbrt.h>
+#include <pbrt/cameras.h>
 #include <pbrt/wavefront/integrator.h>
 #undef private
 #undef protected
@@ -55,6 +56,24 @@ static void dumpMat(FILE *f, MaterialEvalQueue *mq, int tag) {
                          w.n.x, w.n.y, w.n.z, w.ns.x, w.ns.y, w.ns.z, w.dpdus.x, w.dpdus.y, w.dpdus.z, w.wo.x, w.wo.y, w.wo.z, w.uv[0], w.uv[1],
                          w.dpdu.x, w.dpdu.y, w.dpdu.z, w.dpdv.x, w.dpdv.y, w.dpdv.z};
         fwrite(rec, 4, 28, f);
+    }
+}
+
+template <typename M>
+static void dumpDiffs(FILE *f, MaterialEvalQueue *mq, WavefrontPathIntegrator *in) {
+    auto q = mq->Get<MaterialEvalWorkItem<M>>();
+    for (int i = 0; i < q->Size(); ++i) {
+        MaterialEvalWorkItem<M> w = (*q)[i];
+        Vector3f dpdx, dpdy;
+        in->camera.Approximate_dp_dxy(Point3f(w.pi), w.n, w.time, in->samplesPerPixel, &dpdx, &dpdy);
+        const CameraBase *cb = (const CameraBase *)in->camera.ptr();
+        Point3f pc = cb->CameraFromRender(Point3f(w.pi), w.time);
+        Normal3f nc = cb->CameraFromRender(w.n, w.time);
+        Transform dz = RotateFromTo(Normalize(Vector3f(pc)), Vector3f(0, 0, 1));
+        Point3f pd = dz(pc);
+        Normal3f nd = dz(nc);
+        float rec[19] = {(float)w.pixelIndex, dpdx.x, dpdx.y, dpdx.z, dpdy.x, dpdy.y, dpdy.z, pc.x, pc.y, pc.z, nc.x, nc.y, nc.z, pd.x, pd.y, pd.z, nd.x, nd.y, nd.z};
+        fwrite(rec, 4, 19, f);
     }
 }
 
@@ -101,6 +120,27 @@ int main(int argc, char **argv) {
             dumpMat<DielectricMaterial>(f, in->basicEvalMaterialQueue, 3);
             dumpMat<CoatedDiffuseMaterial>(f, in->basicEvalMaterialQueue, 6);
             dumpMat<CoatedConductorMaterial>(f, in->basicEvalMaterialQueue, 7);
+            fclose(f);
+        }
+        {
+            {
+                const CameraBase *cb = (const CameraBase *)in->camera.ptr();
+                FILE *g = fopen((dir + "/camera_diffs.bin").c_str(), "wb");
+                float rec[12] = {cb->minPosDifferentialX.x, cb->minPosDifferentialX.y, cb->minPosDifferentialX.z,
+                                 cb->minPosDifferentialY.x, cb->minPosDifferentialY.y, cb->minPosDifferentialY.z,
+                                 cb->minDirDifferentialX.x, cb->minDirDifferentialX.y, cb->minDirDifferentialX.z,
+                                 cb->minDirDifferentialY.x, cb->minDirDifferentialY.y, cb->minDirDifferentialY.z};
+                fwrite(rec, 4, 12, g);
+                const Transform &rfc = cb->cameraTransform.renderFromCamera.startTransform;
+                for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float v = rfc.GetMatrix()[i][j]; fwrite(&v, 4, 1, g); }
+                for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float v = rfc.GetInverseMatrix()[i][j]; fwrite(&v, 4, 1, g); }
+                fclose(g);
+            }
+            FILE *f = fopen((dir + "/mat_diffs.bin").c_str(), "wb");
+            for (MaterialEvalQueue *mq : {in->basicEvalMaterialQueue, in->universalEvalMaterialQueue}) {
+                dumpDiffs<DiffuseMaterial>(f, mq, in);
+                dumpDiffs<ConductorMaterial>(f, mq, in);
+            }
             fclose(f);
         }
         {

@@ -71,6 +71,11 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.csIlluminantOffset = d.cs_illuminant_offset;
     sv.media = d.media; sv.mediumData = d.medium_data;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;
+    sv.texNeedsFootprint = 0;
+    for (int i = 0; i < d.n_textures; ++i)
+        if (d.textures[i].type >= WF_TEX_FLOAT_IMAGE) sv.texNeedsFootprint = 1;
+    for (int i = 0; i < d.n_materials; ++i)
+        if (d.materials[i].displacement >= 0) sv.texNeedsFootprint = 1;
     sv.matTypeMask = 0;
     for (int i = 0; i < d.n_materials; ++i) sv.matTypeMask |= 1 << d.materials[i].type;
     return sv;
@@ -508,6 +513,34 @@ int main(int argc, char **argv) {
                                              si.n.x, si.n.y, si.n.z, si.ns.x, si.ns.y, si.ns.z, si.dpdus.x, si.dpdus.y, si.dpdus.z, wo_.x, wo_.y, wo_.z,
                                              si.uv.x, si.uv.y, si.dpdu.x, si.dpdu.y, si.dpdu.z, si.dpdv.x, si.dpdv.y, si.dpdv.z};
                             fwrite(rec, 4, 28, f);
+                        }
+                    fclose(f);
+                    {
+                        FILE *g = fopen((dumpStages + "/camera_diffs.bin").c_str(), "wb");
+                        const wf_camera &C = sv.camera;
+                        fwrite(C.minPosDifferentialX, 4, 3, g); fwrite(C.minPosDifferentialY, 4, 3, g);
+                        fwrite(C.minDirDifferentialX, 4, 3, g); fwrite(C.minDirDifferentialY, 4, 3, g);
+                        fwrite(C.renderFromCamera.m, 4, 16, g); fwrite(C.renderFromCamera.mInv, 4, 16, g);
+                        fclose(g);
+                    }
+                    f = fopen((dumpStages + "/mat_diffs.bin").c_str(), "wb");
+                    for (int m = 1; m <= 2; ++m)
+                        for (int k = 0; k < ws.counters[(CNT_MAT0 + m) * CNT_STRIDE]; ++k) {
+                            int i = ws.matQ[m][k];
+                            F4 h = ws.hit[i];
+                            SurfIntr si;
+                            TriangleInteraction(sv, (int)FloatToBits(h.x), h.y, h.z, h.w, &si);
+                            V3 dpdx, dpdy;
+                            ApproximateDpDxy(sv, si.pi.mid(), si.n, &dpdx, &dpdy);
+                            float rec[7] = {(float)ws.rq[cur].meta[i].x, dpdx.x, dpdx.y, dpdx.z, dpdy.x, dpdy.y, dpdy.z};
+                            fwrite(rec, 4, 7, f);
+                            if (getenv("WF_DEBUG_PIXEL") && ws.rq[cur].meta[i].x == atoi(getenv("WF_DEBUG_PIXEL"))) {
+                                V3 pc = XfInvPointM(sv.camera.renderFromCamera.mInv, si.pi.mid());
+                                const float (*mm)[4] = sv.camera.renderFromCamera.m;
+                                N3 n = si.n;
+                                N3 nc{mm[0][0] * n.x + mm[1][0] * n.y + mm[2][0] * n.z, mm[0][1] * n.x + mm[1][1] * n.y + mm[2][1] * n.z, mm[0][2] * n.x + mm[1][2] * n.y + mm[2][2] * n.z};
+                                fprintf(stderr, "dbg pc %.9g %.9g %.9g nc %.9g %.9g %.9g p %.9g %.9g %.9g\n", pc.x, pc.y, pc.z, nc.x, nc.y, nc.z, si.pi.mid().x, si.pi.mid().y, si.pi.mid().z);
+                            }
                         }
                     fclose(f);
                     f = fopen((dumpStages + "/samples.bin").c_str(), "wb");

@@ -757,15 +757,15 @@ struct BSDF {
 // Material::GetBxDF for constant/scale/mix textures (BasicTextureEvaluator)
 WF_HD S4 ClampS01(S4 s) { return ClampS(s, 0.f, 1.f); }
 
-WF_HD DiffuseBxDF GetDiffuseBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD DiffuseBxDF GetDiffuseBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.h:465-469
-    S4 r = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda));
+    S4 r = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda, tc));
     return DiffuseBxDF{r};
 }
-WF_HD DiffuseTransmissionBxDF GetDiffuseTransmissionBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD DiffuseTransmissionBxDF GetDiffuseTransmissionBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.h:815-821
-    S4 r = ClampS01(m.scale * EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda));
-    S4 t = ClampS01(m.scale * EvalSpectrumTexture(sv, m.tex[WF_MT_TRANSMITTANCE], lambda));
+    S4 r = ClampS01(m.scale * EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda, tc));
+    S4 t = ClampS01(m.scale * EvalSpectrumTexture(sv, m.tex[WF_MT_TRANSMITTANCE], lambda, tc));
     return DiffuseTransmissionBxDF{r, t};
 }
 WF_HD float SampledEta(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
@@ -775,87 +775,87 @@ WF_HD float SampledEta(const SceneView &sv, const wf_material &m, Wavelengths &l
     if (sampledEta == 0) sampledEta = 1;
     return sampledEta;
 }
-WF_HD DielectricBxDF GetDielectricBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD DielectricBxDF GetDielectricBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.h:182-203
     float sampledEta = SampledEta(sv, m, lambda);
-    float urough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH]), vrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH]);
+    float urough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH], tc), vrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH], tc);
     if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
         urough = TrowbridgeReitz::RoughnessToAlpha(urough);
         vrough = TrowbridgeReitz::RoughnessToAlpha(vrough);
     }
     return DielectricBxDF{sampledEta, TrowbridgeReitz(urough, vrough)};
 }
-WF_HD ThinDielectricBxDF GetThinDielectricBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD ThinDielectricBxDF GetThinDielectricBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.h:226-240
     return ThinDielectricBxDF{SampledEta(sv, m, lambda)};
 }
-WF_HD ConductorBxDF GetConductorBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD ConductorBxDF GetConductorBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.h:491-511
-    float uRough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH]), vRough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH]);
+    float uRough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH], tc), vRough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH], tc);
     if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
         uRough = TrowbridgeReitz::RoughnessToAlpha(uRough);
         vRough = TrowbridgeReitz::RoughnessToAlpha(vRough);
     }
     S4 etas, ks;
     if (!(m.flags & WF_MATFLAG_CONDUCTOR_REFLECTANCE)) {
-        etas = EvalSpectrumTexture(sv, m.tex[WF_MT_ETA], lambda);
-        ks = EvalSpectrumTexture(sv, m.tex[WF_MT_K], lambda);
+        etas = EvalSpectrumTexture(sv, m.tex[WF_MT_ETA], lambda, tc);
+        ks = EvalSpectrumTexture(sv, m.tex[WF_MT_K], lambda, tc);
     } else {
-        S4 r = ClampS(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda), 0.f, .9999f);
+        S4 r = ClampS(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda, tc), 0.f, .9999f);
         etas = S4c(1.f);
         ks = 2 * Sqrt(r) / Sqrt(ClampZero(S4c(1.f) - r));
     }
     return ConductorBxDF{TrowbridgeReitz(uRough, vRough), etas, ks};
 }
 
-WF_HD CoatedDiffuseBxDF GetCoatedDiffuseBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD CoatedDiffuseBxDF GetCoatedDiffuseBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.cpp:255-284
-    S4 r = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda));
-    float urough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH]);
-    float vrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH]);
+    S4 r = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda, tc));
+    float urough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH], tc);
+    float vrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH], tc);
     if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
         urough = TrowbridgeReitz::RoughnessToAlpha(urough);
         vrough = TrowbridgeReitz::RoughnessToAlpha(vrough);
     }
     TrowbridgeReitz distrib(urough, vrough);
-    float thick = EvalFloatTexture(sv, m.tex[WF_MT_THICKNESS]);
+    float thick = EvalFloatTexture(sv, m.tex[WF_MT_THICKNESS], tc);
     float sampledEta = SampledEta(sv, m, lambda);
-    S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda));
-    float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G]), -1.f, 1.f);
+    S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda, tc));
+    float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G], tc), -1.f, 1.f);
     return CoatedDiffuseBxDF{DielectricBxDF{sampledEta, distrib}, DiffuseBxDF{r}, fmax(thick, 1.17549435e-38f), gg, a, m.maxdepth, m.nsamples,
                              sv.options.seed};
 }
-WF_HD CoatedConductorBxDF GetCoatedConductorBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda) {
+WF_HD CoatedConductorBxDF GetCoatedConductorBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.cpp:346-392
-    float iurough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH]);
-    float ivrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH]);
+    float iurough = EvalFloatTexture(sv, m.tex[WF_MT_UROUGH], tc);
+    float ivrough = EvalFloatTexture(sv, m.tex[WF_MT_VROUGH], tc);
     if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
         iurough = TrowbridgeReitz::RoughnessToAlpha(iurough);
         ivrough = TrowbridgeReitz::RoughnessToAlpha(ivrough);
     }
     TrowbridgeReitz interfaceDistrib(iurough, ivrough);
-    float thick = EvalFloatTexture(sv, m.tex[WF_MT_THICKNESS]);
+    float thick = EvalFloatTexture(sv, m.tex[WF_MT_THICKNESS], tc);
     float ieta = SampledEta(sv, m, lambda);
     S4 ce, ck;
     if (!(m.flags & WF_MATFLAG_CONDUCTOR_REFLECTANCE)) {
-        ce = EvalSpectrumTexture(sv, m.tex[WF_MT_COND_ETA], lambda);
-        ck = EvalSpectrumTexture(sv, m.tex[WF_MT_COND_K], lambda);
+        ce = EvalSpectrumTexture(sv, m.tex[WF_MT_COND_ETA], lambda, tc);
+        ck = EvalSpectrumTexture(sv, m.tex[WF_MT_COND_K], lambda, tc);
     } else {
-        S4 r = ClampS(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda), 0.f, .9999f);
+        S4 r = ClampS(EvalSpectrumTexture(sv, m.tex[WF_MT_REFLECTANCE], lambda, tc), 0.f, .9999f);
         ce = S4c(1.f);
         ck = 2 * Sqrt(r) / Sqrt(ClampZero(S4c(1.f) - r));
     }
     ce = ce / ieta;
     ck = ck / ieta;
-    float curough = EvalFloatTexture(sv, m.tex[WF_MT_COND_UROUGH]);
-    float cvrough = EvalFloatTexture(sv, m.tex[WF_MT_COND_VROUGH]);
+    float curough = EvalFloatTexture(sv, m.tex[WF_MT_COND_UROUGH], tc);
+    float cvrough = EvalFloatTexture(sv, m.tex[WF_MT_COND_VROUGH], tc);
     if (m.flags & WF_MATFLAG_REMAP_ROUGHNESS) {
         curough = TrowbridgeReitz::RoughnessToAlpha(curough);
         cvrough = TrowbridgeReitz::RoughnessToAlpha(cvrough);
     }
     TrowbridgeReitz conductorDistrib(curough, cvrough);
-    S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda));
-    float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G]), -1.f, 1.f);
+    S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda, tc));
+    float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G], tc), -1.f, 1.f);
     return CoatedConductorBxDF{DielectricBxDF{ieta, interfaceDistrib}, ConductorBxDF{conductorDistrib, ce, ck}, fmax(thick, 1.17549435e-38f), gg, a,
                                m.maxdepth, m.nsamples, sv.options.seed};
 }

@@ -257,6 +257,16 @@ WF_HD V3 XfPoint(const float m[4][4], V3 p) {
     if (wp == 1) return V3{xp, yp, zp};
     return V3{xp, yp, zp} / wp;
 }
+// Transform::ApplyInverse(Point3f), util/transform.h:386-398 (mInv passed in)
+WF_HD V3 XfInvPointM(const float mi[4][4], V3 p) {
+    float x = p.x, y = p.y, z = p.z;
+    float xp = (mi[0][0] * x + mi[0][1] * y) + (mi[0][2] * z + mi[0][3]);
+    float yp = (mi[1][0] * x + mi[1][1] * y) + (mi[1][2] * z + mi[1][3]);
+    float zp = (mi[2][0] * x + mi[2][1] * y) + (mi[2][2] * z + mi[2][3]);
+    float wp = (mi[3][0] * x + mi[3][1] * y) + (mi[3][2] * z + mi[3][3]);
+    if (wp == 1) return V3{xp, yp, zp};
+    return V3{xp, yp, zp} / wp;
+}
 WF_HD V3 XfVector(const float m[4][4], V3 v) {
     return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
               m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
@@ -294,6 +304,55 @@ WF_HD void XfRay(const float m[4][4], V3 *o, V3 *d) {
         o->z = IntervalAddMid(oi.lo.z, oi.hi.z, off.z);
     } else *o = oi.mid();
     *d = dd;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CameraBase::Approximate_dp_dxy (cameras.h:155-183) with RotateFromTo (util/transform.h:249-270): the texture
+// footprint of a surface point, from the camera's minimum ray differentials (FindMinimumDifferentials,
+// cameras.cpp:153-203, evaluated on the host)
+WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy) {
+    const wf_camera &C = sv.camera;
+    V3 pCamera = XfInvPointM(C.renderFromCamera.mInv, p);  // CameraFromRender(p, time)
+    // RotateFromTo(Normalize(pCamera), (0, 0, 1))
+    V3 from = Normalize(pCamera), to{0, 0, 1};
+    V3 refl;
+    if (abs(from.x) < 0.72f && abs(to.x) < 0.72f) refl = V3{1, 0, 0};
+    else if (abs(from.y) < 0.72f && abs(to.y) < 0.72f) refl = V3{0, 1, 0};
+    else refl = V3{0, 0, 1};
+    V3 u = refl - from, v = refl - to;
+    const float uu[3] = {u.x, u.y, u.z}, vv[3] = {v.x, v.y, v.z};
+    float r[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r[i][j] = ((i == j) ? 1 : 0) - 2 / Dot(u, u) * uu[i] * uu[j] - 2 / Dot(v, v) * vv[i] * vv[j] +
+                      4 * Dot(u, v) / (Dot(u, u) * Dot(v, v)) * vv[i] * uu[j];
+    auto fwdPoint = [&](V3 q) {  // Transform::operator()(Point3f): the fourth row and column are (0, 0, 0, 1)
+        return V3{r[0][0] * q.x + r[0][1] * q.y + r[0][2] * q.z + 0.f, r[1][0] * q.x + r[1][1] * q.y + r[1][2] * q.z + 0.f,
+                  r[2][0] * q.x + r[2][1] * q.y + r[2][2] * q.z + 0.f};
+    };
+    V3 pDownZ = fwdPoint(pCamera);
+    // CameraFromRender(n, time) = renderFromCamera.ApplyInverse(Normal3f): m transposed (util/transform.h:409-415)
+    const float (*m)[4] = C.renderFromCamera.m;
+    N3 nCam{m[0][0] * n.x + m[1][0] * n.y + m[2][0] * n.z, m[0][1] * n.x + m[1][1] * n.y + m[2][1] * n.z,
+            m[0][2] * n.x + m[1][2] * n.y + m[2][2] * n.z};
+    // DownZFromCamera(Normal3f): mInv transposed = r (mInv = Transpose(r))
+    N3 nDownZ{r[0][0] * nCam.x + r[0][1] * nCam.y + r[0][2] * nCam.z, r[1][0] * nCam.x + r[1][1] * nCam.y + r[1][2] * nCam.z,
+              r[2][0] * nCam.x + r[2][1] * nCam.y + r[2][2] * nCam.z};
+    float d = nDownZ.z * pDownZ.z;
+    V3 xo = V3{0, 0, 0} + V3{C.minPosDifferentialX[0], C.minPosDifferentialX[1], C.minPosDifferentialX[2]};
+    V3 xd = V3{0, 0, 1} + V3{C.minDirDifferentialX[0], C.minDirDifferentialX[1], C.minDirDifferentialX[2]};
+    float tx = -(Dot(nDownZ, xo) - d) / Dot(nDownZ, xd);
+    V3 yo = V3{0, 0, 0} + V3{C.minPosDifferentialY[0], C.minPosDifferentialY[1], C.minPosDifferentialY[2]};
+    V3 yd = V3{0, 0, 1} + V3{C.minDirDifferentialY[0], C.minDirDifferentialY[1], C.minDirDifferentialY[2]};
+    float ty = -(Dot(nDownZ, yo) - d) / Dot(nDownZ, yd);
+    V3 px = xo + xd * tx, py = yo + yd * ty;
+    float sppScale = sv.options.disable_pixel_jitter ? 1.f : fmax(.125f, 1 / sqrt((float)sv.sampler.spp));
+    auto invVec = [&](V3 q) {  // DownZFromCamera.ApplyInverse(Vector3f): mInv * q = r^T q
+        return V3{r[0][0] * q.x + r[1][0] * q.y + r[2][0] * q.z, r[0][1] * q.x + r[1][1] * q.y + r[2][1] * q.z,
+                  r[0][2] * q.x + r[1][2] * q.y + r[2][2] * q.z};
+    };
+    *dpdx = sppScale * XfVector(C.renderFromCamera.m, invVec(px - pDownZ));
+    *dpdy = sppScale * XfVector(C.renderFromCamera.m, invVec(py - pDownZ));
 }
 
 // ---------------------------------------------------------------------------------------------

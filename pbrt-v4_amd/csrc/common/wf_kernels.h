@@ -720,35 +720,38 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
 template <int MAT> struct MatBxDF;
 template <> struct MatBxDF<WF_MAT_DIFFUSE> {
     using T = DiffuseBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDiffuseBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetDiffuseBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_CONDUCTOR> {
     using T = ConductorBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetConductorBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetConductorBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_DIELECTRIC> {
     using T = DielectricBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDielectricBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetDielectricBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_THIN_DIELECTRIC> {
     using T = ThinDielectricBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetThinDielectricBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetThinDielectricBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_DIFFUSE_TRANSMISSION> {
     using T = DiffuseTransmissionBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetDiffuseTransmissionBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetDiffuseTransmissionBxDF(sv, m, l, tc); }
 };
 
 template <> struct MatBxDF<WF_MAT_COATED_DIFFUSE> {
     using T = CoatedDiffuseBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetCoatedDiffuseBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetCoatedDiffuseBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_COATED_CONDUCTOR> {
     using T = CoatedConductorBxDF;
-    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l) { return GetCoatedConductorBxDF(sv, m, l); }
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetCoatedConductorBxDF(sv, m, l, tc); }
 };
 
-template <int MAT>
+// TEXCTX = false: the scene has neither footprint-dependent textures nor displacement, so the differentials and
+// the bump-mapping block (whose only consumers those are) are compiled out — a separate kernel variant, because
+// their registers cost the common case ~25 % (35 spilled VGPRs in the diffuse kernel).
+template <int MAT, bool TEXCTX = true>
 WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid) {
     // `valid` = this thread has an item.  The two queue pushes go through BlockAlloc, which every thread of
     // the workgroup must reach: control flow below is flattened into the flags pushRay / pushShadow.
@@ -784,12 +787,52 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         // items enqueued by the medium stage carry -ray.d as it is (media.cpp:240)
         V3 wo{-d4.x, -d4.y, -d4.z};
         if (!(sv.haveMedia && meta.w >= 0)) wo = Normalize(wo);
-        // (texture-filtering differentials, surfscatter.cpp:75-104, only feed image textures; the textures
-        // evaluated here are position-independent)
+        // differentials of position and (u, v) at the intersection (surfscatter.cpp:73-104)
+        TexCtx tc;
+        tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
+        if constexpr (TEXCTX)
+        if (!sv.options.disable_texture_filtering) {
+            // movingFromCamera is the identity transform
+            ApproximateDpDxy(sv, tc.p, si.n, &tc.dpdx, &tc.dpdy);
+            V3 dpdu = si.dpdu, dpdv = si.dpdv;
+            float ata00 = Dot(dpdu, dpdu), ata01 = Dot(dpdu, dpdv), ata11 = Dot(dpdv, dpdv);
+            float invDet = 1 / DifferenceOfProducts(ata00, ata11, ata01, ata01);
+            invDet = IsFinite(invDet) ? invDet : 0.f;
+            float atb0x = Dot(dpdu, tc.dpdx), atb1x = Dot(dpdv, tc.dpdx);
+            float atb0y = Dot(dpdu, tc.dpdy), atb1y = Dot(dpdv, tc.dpdy);
+            float dudx = DifferenceOfProducts(ata11, atb0x, ata01, atb1x) * invDet;
+            float dvdx = DifferenceOfProducts(ata00, atb1x, ata01, atb0x) * invDet;
+            float dudy = DifferenceOfProducts(ata11, atb0y, ata01, atb1y) * invDet;
+            float dvdy = DifferenceOfProducts(ata00, atb1y, ata01, atb0y) * invDet;
+            tc.dudx = IsFinite(dudx) ? Clamp(dudx, -1e8f, 1e8f) : 0.f;
+            tc.dvdx = IsFinite(dvdx) ? Clamp(dvdx, -1e8f, 1e8f) : 0.f;
+            tc.dudy = IsFinite(dudy) ? Clamp(dudy, -1e8f, 1e8f) : 0.f;
+            tc.dvdy = IsFinite(dvdy) ? Clamp(dvdy, -1e8f, 1e8f) : 0.f;
+        }
         N3 ns = si.ns;
         V3 dpdus = si.dpdus;
+        if constexpr (TEXCTX)
+        if (mat.displacement >= 0) {
+            // BumpMap (materials.h:109-138) and the shading frame rebuilt from it (surfscatter.cpp:120-130)
+            TexCtx sh = tc;
+            float du = .5f * (abs(tc.dudx) + abs(tc.dudy));
+            if (du == 0) du = .0005f;
+            sh.p = tc.p + du * si.dpdus;
+            sh.uv = V2{tc.uv.x + du, tc.uv.y + 0.f};
+            float uDisplace = EvalFloatTexture(sv, mat.displacement, sh);
+            float dv = .5f * (abs(tc.dvdx) + abs(tc.dvdy));
+            if (dv == 0) dv = .0005f;
+            sh.p = tc.p + dv * si.dpdvs;
+            sh.uv = V2{tc.uv.x + 0.f, tc.uv.y + dv};
+            float vDisplace = EvalFloatTexture(sv, mat.displacement, sh);
+            float displace = EvalFloatTexture(sv, mat.displacement, tc);
+            dpdus = si.dpdus + (uDisplace - displace) / du * toV(si.ns) + displace * toV(si.dndus);
+            V3 dpdvs = si.dpdvs + (vDisplace - displace) / dv * toV(si.ns) + displace * toV(si.dndvs);
+            ns = toN(Normalize(Cross(dpdus, dpdvs)));
+            ns = FaceForward(ns, si.n);
+        }
         Wavelengths lambda = LoadLambda(ws, pixelIndex);
-        BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda);
+        BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda, tc);
         BSDF<BxDF> bsdf(ns, dpdus, bxdf);
         if (lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
         if (sv.regularize && anyNonSpecularBounces0) bsdf.Regularize();

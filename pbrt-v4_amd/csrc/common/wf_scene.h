@@ -50,6 +50,8 @@ struct SceneView {
     // integrator
     int maxDepth, regularize, haveMedia;
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
+    int texNeedsFootprint;  // some texture's value depends on the TextureEvalContext (checkerboard, image) or some material
+                            // is bump-mapped: selects the material-kernel variant that computes the differentials
     wf_options options;
 };
 
@@ -149,58 +151,90 @@ WF_HD float SpectrumEval(const SceneView &sv, int id, float lambda) {
 WF_HD bool SpectrumIsConstant(const SceneView &sv, int id) { return sv.spectra[id].type == WF_SPEC_CONSTANT; }
 
 // ---------------------------------------------------------------------------------------------
-// BasicTextureEvaluator over the flattened texture nodes (textures.h:1092-1137): constant, scale, mix.
-// The node tree is walked with a compile-time depth bound (WF_TEX_MAX_DEPTH, enforced by the host
-// builder) so the device code has no recursion and inlines completely.  Image textures arrive with the
+// Texture evaluation over the flattened texture nodes (textures.h:1092-1155): constant, scale, mix, 2D checkerboard.
+// The nesting depth is bounded by WF_TEX_MAX_DEPTH (enforced by the host builder).  Image textures arrive with the
 // image-texture row of SURVEY.md §8(f).
-#define WF_TEX_MAX_DEPTH 3
+// TextureEvalContext (textures.h:33-61)
+struct TexCtx {
+    V3 p{0, 0, 0}, dpdx{0, 0, 0}, dpdy{0, 0, 0};
+    N3 n{0, 0, 0};
+    V2 uv{0, 0};
+    float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
+};
+// Checkerboard() for a 2D UVMapping (textures.cpp:183-207, textures.h:86-106)
+WF_HD float Checkerboard2D(const wf_texture &t, const TexCtx &c) {
+    const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
+    float dsdx = su * c.dudx, dsdy = su * c.dudy;
+    float dtdx = sv_ * c.dvdx, dtdy = sv_ * c.dvdy;
+    float s = su * c.uv.x + du, tt = sv_ * c.uv.y + dv;
+    auto d = [](float x) {
+        float y = x / 2 - floor(x / 2) - 0.5f;
+        return x / 2 + y * (1 - 2 * abs(y));
+    };
+    auto bf = [&](float x, float r) -> float {
+        if (floor(x - r) == floor(x + r)) return (float)(1 - 2 * ((int)floor(x) & 1));
+        return (d(x + r) - 2 * d(x) + d(x - r)) / Sqr(r);
+    };
+    float ds = fmax(abs(dsdx), abs(dsdy));
+    float dt = fmax(abs(dtdx), abs(dtdy));
+    ds *= 1.5f;
+    dt *= 1.5f;
+    return 0.5f - bf(s, ds) * bf(tt, dt) / 2;
+}
+// FloatTexture::Evaluate / SpectrumTexture::Evaluate over the flattened texture graph.  The reference recurses through
+// tagged pointers; the device code has no recursion: the walk is a template over the remaining depth, fully inlined.
+// With three interior node types the inlined code grows ~7x per level, so the bound is two interior levels above the
+// constants (e.g. mix(checkerboard(c, c), scale(c, c))); the host builder rejects deeper graphs.  (An explicit stack
+// machine was tried: it compiles in seconds for any depth but its indexed stack arrays live in scratch and the
+// material kernels then spill ~470 VGPRs: 22 -> 71 ms for the diffuse kernel.)
+#define WF_TEX_MAX_DEPTH 2
 template <int D>
-WF_HD float EvalFloatTextureD(const SceneView &sv, int id) {
+WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
     if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
     if constexpr (D > 0) {
         if (t.type == WF_TEX_FLOAT_SCALE) {
             // FloatScaledTexture::Evaluate, textures.h:1039-1044
-            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1);
+            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
             if (sc == 0) return 0;
-            return EvalFloatTextureD<D - 1>(sv, t.tex0) * sc;
+            return EvalFloatTextureD<D - 1>(sv, t.tex0, tc) * sc;
         }
-        if (t.type == WF_TEX_FLOAT_MIX) {
-            // FloatMixTexture::Evaluate, textures.h:810-818
-            float amt = EvalFloatTextureD<D - 1>(sv, t.tex2);
-            float t1 = 0, t2 = 0;
-            if (amt != 1) t1 = EvalFloatTextureD<D - 1>(sv, t.tex0);
-            if (amt != 0) t2 = EvalFloatTextureD<D - 1>(sv, t.tex1);
-            return (1 - amt) * t1 + amt * t2;
+        if (t.type == WF_TEX_FLOAT_MIX || t.type == WF_TEX_FLOAT_CHECKERBOARD) {
+            // FloatMixTexture::Evaluate (textures.h:810-818), FloatCheckerboardTexture::Evaluate (:370-378)
+            float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(t, tc);
+            float t0 = 0, t1 = 0;
+            if (w != 1) t0 = EvalFloatTextureD<D - 1>(sv, t.tex0, tc);
+            if (w != 0) t1 = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
+            return (1 - w) * t0 + w * t1;
         }
     }
     return 0.f;
 }
-WF_HD float EvalFloatTexture(const SceneView &sv, int id) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(sv, id); }
+WF_HD float EvalFloatTexture(const SceneView &sv, int id, const TexCtx &tc) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(sv, id, tc); }
 template <int D>
-WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda) {
+WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
     if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
     if constexpr (D > 0) {
         if (t.type == WF_TEX_SPECTRUM_SCALE) {
             // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
-            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1);
+            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
             if (sc == 0) return S4c(0.f);
-            return EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda) * sc;
+            return EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc) * sc;
         }
-        if (t.type == WF_TEX_SPECTRUM_MIX) {
-            // SpectrumMixTexture::Evaluate, textures.h:840-850
-            float amt = EvalFloatTextureD<D - 1>(sv, t.tex2);
-            S4 t1 = S4c(0.f), t2 = S4c(0.f);
-            if (amt != 1) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda);
-            if (amt != 0) t2 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda);
-            return (1 - amt) * t1 + amt * t2;
+        if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD) {
+            // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413)
+            float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(t, tc);
+            S4 t0 = S4c(0.f), t1 = S4c(0.f);
+            if (w != 1) t0 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc);
+            if (w != 0) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda, tc);
+            return (1 - w) * t0 + w * t1;
         }
     }
     return S4c(0.f);
 }
-WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda) {
-    return EvalSpectrumTextureD<WF_TEX_MAX_DEPTH>(sv, id, lambda);
+WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
+    return EvalSpectrumTextureD<WF_TEX_MAX_DEPTH>(sv, id, lambda, tc);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -685,6 +685,11 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
     if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)WF_SOBOL_WORDS))) return e;
+    sv.texNeedsFootprint = 0;
+    for (int i = 0; i < d->n_textures; ++i)
+        if (d->textures[i].type >= WF_TEX_FLOAT_IMAGE) sv.texNeedsFootprint = 1;
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].displacement >= 0) sv.texNeedsFootprint = 1;
     sv.maxDepth = d->max_depth;
     sv.regularize = d->regularize;
     sv.haveMedia = d->have_media;

@@ -46,11 +46,18 @@ struct Mat4 {
     bool eq(const Mat4 &o) const { for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (m[i][j] != o.m[i][j]) return false; return true; }
 };
 inline Mat4 Transpose(const Mat4 &a) { Mat4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = a.m[j][i]; return r; }
+// SquareMatrix<4> product as Transform::operator* (util/transform.cpp:141-143) evaluates it: the generic FMA
+// accumulation of util/math.h:1497-1508.  (math.h:1475-1484 also specialises the 4x4 product with the compensated
+// InnerProduct, but the out-of-line Transform::operator* of the reference build does not use it: the translation
+// column of renderFromCamera's inverse shows the FMA rounding — checked with a harness against libpbrt_ref.a.)
 inline Mat4 operator*(const Mat4 &a, const Mat4 &b) {
     Mat4 r;
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            r.m[i][j] = InnerProduct(a.m[i][0], b.m[0][j], a.m[i][1], b.m[1][j], a.m[i][2], b.m[2][j], a.m[i][3], b.m[3][j]);
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0;
+            for (int k = 0; k < 4; ++k) acc = fma(a.m[i][k], b.m[k][j], acc);
+            r.m[i][j] = acc;
+        }
     return r;
 }
 inline Mat3 operator*(const Mat3 &a, const Mat3 &b) {

@@ -9,6 +9,7 @@
 //   lights.cpp:120-166,684-941,1345-1380       light parameter handling, scale normalisation, Bounds()
 //   util/mesh.cpp:25-75, shapes.cpp:283-307,368-438  triangle meshes (vertices transformed to render space)
 #include "scene.h"
+#include "../common/wf_camera.h"
 
 #include <algorithm>
 #include <cmath>
@@ -56,7 +57,16 @@ struct TexBuilder {
     std::map<std::string, int> floatTextures, spectrumTexturesAlbedo, spectrumTexturesUnbounded, spectrumTexturesIllum;
     const ParsedScene *scene;
 
-    int AddTex(const wf_texture &t) { T->textures.push_back(t); return (int)T->textures.size() - 1; }
+    std::vector<int> texDepth;  // nesting depth of every texture node: the device walks the graph with a WF_TEX_MAX_DEPTH stack
+    int AddTex(const wf_texture &t) {
+        int d = 1;
+        for (int c : {t.tex0, t.tex1, t.tex2})
+            if (c >= 0) d = std::max(d, 1 + texDepth[c]);
+        if (d > WF_TEX_MAX_DEPTH + 1) Die("", "texture graph nested deeper than " + std::to_string(WF_TEX_MAX_DEPTH + 1) + " levels");
+        texDepth.push_back(d);
+        T->textures.push_back(t);
+        return (int)T->textures.size() - 1;
+    }
     int FloatConst(float v) {
         wf_texture t{};
         t.type = WF_TEX_FLOAT_CONSTANT; t.f0 = v; t.spectrum = t.tex0 = t.tex1 = t.tex2 = -1;
@@ -112,6 +122,16 @@ struct TexBuilder {
         return t >= 0 ? t : SpectrumConst(def);
     }
 
+    // TextureMapping2D::Create (textures.cpp:49-73) for the 2D checkerboard: UVMapping(su, sv, du, dv)
+    void CheckerMapping(const TextureEntity &te, wf_texture *t) {
+        const ParamSet &ps = te.params;
+        if (ps.GetOneInt("dimension", 2) != 2) Die(te.loc, "3D checkerboard textures are not supported by this build");
+        if (ps.GetOneString("mapping", "uv") != "uv") Die(te.loc, "only the \"uv\" texture mapping is supported by this build");
+        t->map[0] = ps.GetOneFloat("uscale", 1.f);
+        t->map[1] = ps.GetOneFloat("vscale", 1.f);
+        t->map[2] = ps.GetOneFloat("udelta", 0.f);
+        t->map[3] = ps.GetOneFloat("vdelta", 0.f);
+    }
     void CreateNamedTextures() {
         for (const TextureEntity &te : scene->textures) {
             const ParamSet &ps = te.params;
@@ -128,6 +148,12 @@ struct TexBuilder {
                     t.tex0 = GetFloatTexture(ps, "tex1", 0.f);
                     t.tex1 = GetFloatTexture(ps, "tex2", 1.f);
                     t.tex2 = GetFloatTexture(ps, "amount", 0.5f);
+                } else if (te.name == "checkerboard") {
+                    // FloatCheckerboardTexture::Create (textures.cpp:219-241)
+                    CheckerMapping(te, &t);
+                    t.type = WF_TEX_FLOAT_CHECKERBOARD;
+                    t.tex0 = GetFloatTexture(ps, "tex1", 1.f);
+                    t.tex1 = GetFloatTexture(ps, "tex2", 0.f);
                 } else Die(te.loc, te.name + ": float texture type not supported by this build");
                 if (floatTextures.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
                 floatTextures[te.texName] = AddTex(t);
@@ -149,6 +175,12 @@ struct TexBuilder {
                         t.tex0 = GetSpectrumTexture(ps, "tex1", *MakeConstant(0.f), st);
                         t.tex1 = GetSpectrumTexture(ps, "tex2", *MakeConstant(1.f), st);
                         t.tex2 = GetFloatTexture(ps, "amount", 0.5f);
+                    } else if (te.name == "checkerboard") {
+                        // SpectrumCheckerboardTexture::Create (textures.cpp:250-278)
+                        CheckerMapping(te, &t);
+                        t.type = WF_TEX_SPECTRUM_CHECKERBOARD;
+                        t.tex0 = GetSpectrumTexture(ps, "tex1", *MakeConstant(1.f), st);
+                        t.tex1 = GetSpectrumTexture(ps, "tex2", *MakeConstant(0.f), st);
                     } else Die(te.loc, te.name + ": spectrum texture type not supported by this build");
                     auto &m = SpecMap(st);
                     if (st == SpectrumType::Albedo && m.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
@@ -174,7 +206,6 @@ struct TexBuilder {
         m.displacement = GetFloatTextureOrNull(ps, "displacement");
         m.normalmap = -1;
         if (!ps.GetOneString("normalmap", "").empty()) Die(e.loc, "normalmap is not supported by this build");
-        if (m.displacement >= 0) Die(e.loc, "displacement (bump mapping) is not supported by this build");
         const std::string &name = e.name;
         auto roughness = [&](const char *u, const char *v, const char *r, int us, int vs) {
             int ur = GetFloatTextureOrNull(ps, u), vr = GetFloatTextureOrNull(ps, v);
@@ -681,6 +712,59 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
         for (int i = 0; i < 3; ++i) { C.minPosDifferentialX[i] = dx[i]; C.minPosDifferentialY[i] = dy[i]; }
     }
     for (int i = 0; i < 3; ++i) { C.dxCamera[i] = dx[i]; C.dyCamera[i] = dy[i]; }
+    if (C.type == WF_CAMERA_PERSPECTIVE) {
+        // CameraBase::FindMinimumDifferentials (cameras.cpp:153-203) over PerspectiveCamera::GenerateRayDifferential
+        // (cameras.cpp:429-478) with pLens = (0.5, 0.5), time = 0.5
+        const float INF = std::numeric_limits<float>::infinity();
+        V3 minPosX{INF, INF, INF}, minPosY = minPosX, minDirX = minPosX, minDirY = minPosX;
+        const int n = 512;
+        for (int i = 0; i < n; ++i) {
+            float fx = float(i) / (n - 1) * F.full_res[0], fy = float(i) / (n - 1) * F.full_res[1];
+            V3 pCamera = XfPoint(C.cameraFromRaster.m, V3{fx, fy, 0});
+            V3 o{0, 0, 0}, d = Normalize(pCamera);
+            V3 rxo, ryo, rxd, ryd;
+            if (lensradius > 0) {
+                V2 pLens{0, 0};  // lensRadius * SampleUniformDiskConcentric((0.5, 0.5)) = (0, 0)
+                float ft = focaldistance / d.z;
+                V3 pFocus = o + d * ft;
+                o = V3{pLens.x, pLens.y, 0};
+                d = Normalize(pFocus - o);
+                V3 ddx = Normalize(pCamera + dx);
+                ft = focaldistance / ddx.z;
+                pFocus = V3{0, 0, 0} + (ft * ddx);
+                rxo = V3{pLens.x, pLens.y, 0};
+                rxd = Normalize(pFocus - rxo);
+                V3 ddy = Normalize(pCamera + dy);
+                ft = focaldistance / ddy.z;
+                pFocus = V3{0, 0, 0} + (ft * ddy);
+                ryo = V3{pLens.x, pLens.y, 0};
+                ryd = Normalize(pFocus - ryo);
+            } else {
+                rxo = ryo = o;
+                rxd = Normalize(pCamera + dx);
+                ryd = Normalize(pCamera + dy);
+            }
+            // RenderFromCamera(RayDifferential), util/transform.h:350-360
+            V3 ro = o, rd = d;
+            XfRay(C.renderFromCamera.m, &ro, &rd);
+            rxo = XfPoint(C.renderFromCamera.m, rxo); ryo = XfPoint(C.renderFromCamera.m, ryo);
+            rxd = XfVector(C.renderFromCamera.m, rxd); ryd = XfVector(C.renderFromCamera.m, ryd);
+            V3 dox = XfVector(C.renderFromCamera.mInv, rxo - ro);
+            if (Length(dox) < Length(minPosX)) minPosX = dox;
+            V3 doy = XfVector(C.renderFromCamera.mInv, ryo - ro);
+            if (Length(doy) < Length(minPosY)) minPosY = doy;
+            rd = Normalize(rd); rxd = Normalize(rxd); ryd = Normalize(ryd);
+            Frame f = Frame::FromZ(rd);
+            V3 df = f.ToLocal(rd);
+            V3 dxf = Normalize(f.ToLocal(rxd)), dyf = Normalize(f.ToLocal(ryd));
+            if (Length(dxf - df) < Length(minDirX)) minDirX = dxf - df;
+            if (Length(dyf - df) < Length(minDirY)) minDirY = dyf - df;
+        }
+        for (int k = 0; k < 3; ++k) {
+            C.minPosDifferentialX[k] = minPosX[k]; C.minPosDifferentialY[k] = minPosY[k];
+            C.minDirDifferentialX[k] = minDirX[k]; C.minDirDifferentialY[k] = minDirY[k];
+        }
+    }
     ps.ReportUnused("Camera");
 }
 
