@@ -100,8 +100,8 @@ typedef struct wf_texture {
     int32_t type;
     int32_t spectrum;            /* index into spectra, or -1 */
     int32_t tex0, tex1, tex2;    /* child texture ids, or -1 */
-    int32_t i0;                  /* image id / spectrum type for image textures */
-    float f0, f1;                /* constant value / scale, invert flag etc. */
+    int32_t i0;                  /* IMAGE: index into tex_images (SPECTRUM_IMAGE: `spectrum` holds the SpectrumType 0 albedo / 1 unbounded / 2 illuminant) */
+    float f0, f1;                /* constant value; IMAGE: scale, invert flag */
     float map[8];                /* UVMapping: su, sv, du, dv (textures.h:76-104) */
 } wf_texture;
 
@@ -190,6 +190,17 @@ typedef struct wf_image_light {
     int32_t pixel_offset;        /* res*res*3 floats (RGB interleaved, row 0 first) in table_data */
     wf_pc2d distribution, compensated;
 } wf_image_light;
+
+/* MIPMap of an image texture (util/mipmap.h:49-92): float pyramid levels (Image::GeneratePyramid,
+ * util/image.cpp) stored one after the other in table_data, level 0 first, rows top to bottom, channels interleaved */
+enum wf_wrap_mode { WF_WRAP_BLACK = 0, WF_WRAP_CLAMP = 1, WF_WRAP_REPEAT = 2, WF_WRAP_OCTAHEDRAL = 3 };
+enum wf_mip_filter { WF_MIP_POINT = 0, WF_MIP_BILINEAR = 1, WF_MIP_TRILINEAR = 2 };
+typedef struct wf_tex_image {
+    int32_t res[2];
+    int32_t n_levels, n_channels;   /* 1 or 3 channels */
+    int32_t wrap, filter;
+    int32_t level_offset[20];       /* float offsets of the levels in table_data */
+} wf_tex_image;
 
 /* Light BVH node, 32 bytes, same content as LightBVHNode/CompactLightBounds (lightsamplers.h:101-257) */
 typedef struct wf_light_bvh_node {
@@ -328,6 +339,8 @@ typedef struct wf_scene_desc {
     /* image infinite lights + the RGB -> spectrum table of their colour space (util/color.h:368-395; sRGB) */
     int32_t n_image_lights, n_table_floats;
     const wf_image_light *image_lights;
+    int32_t n_tex_images;
+    const wf_tex_image *tex_images;  /* wf_texture.i0 of the IMAGE texture types */
     const float *table_data;
     const float *rgb2spec_coeffs;        /* [3][64][64][64][3] or null when no image light needs it */
     float rgb2spec_znodes[64];

@@ -66,8 +66,9 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.camera = d.camera; sv.film = d.film; sv.filter = d.filter; sv.filterData = d.filter_data; sv.sampler = d.sampler;
     sv.sobol = sobol;
     sv.powerAlias = d.power_alias;
+    sv.texImages = d.tex_images;
     sv.imageLights = d.image_lights; sv.tableData = d.table_data; sv.rgb2specCoeffs = d.rgb2spec_coeffs;
-    for (int i = 0; i < 64; ++i) sv.rgb2specZNodes[i] = d.rgb2spec_znodes[i];
+    sv.rgb2specZNodes = d.rgb2spec_znodes;
     sv.csIlluminantOffset = d.cs_illuminant_offset;
     sv.media = d.media; sv.mediumData = d.medium_data;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;

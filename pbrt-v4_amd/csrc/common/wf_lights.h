@@ -63,31 +63,6 @@ WF_HD float PC2DPDF(const float *D, const wf_pc2d &t, V2 p) {
     int iv = Clamp((int)(o.y * t.ny), 0, t.ny - 1);
     return D[t.cond_func_offset + (size_t)iv * t.nx + iu] / t.marg_int;
 }
-// RGBToSpectrumTable::operator() (util/color.cpp:31-68) on the device copy of the table
-WF_HD void RGBToSpectrumCoeffs(const SceneView &sv, const float rgb[3], float c[3]) {
-    constexpr int res = 64;
-    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) {
-        c[0] = 0; c[1] = 0;
-        c[2] = (rgb[0] - .5f) / sqrt(rgb[0] * (1 - rgb[0]));
-        return;
-    }
-    int maxc = (rgb[0] > rgb[1]) ? ((rgb[0] > rgb[2]) ? 0 : 2) : ((rgb[1] > rgb[2]) ? 1 : 2);
-    float z = maxc == 0 ? rgb[0] : (maxc == 1 ? rgb[1] : rgb[2]);
-    float cx = maxc == 0 ? rgb[1] : (maxc == 1 ? rgb[2] : rgb[0]);  // rgb[(maxc + 1) % 3]
-    float cy = maxc == 0 ? rgb[2] : (maxc == 1 ? rgb[0] : rgb[1]);  // rgb[(maxc + 2) % 3]
-    float x = cx * (res - 1) / z;
-    float y = cy * (res - 1) / z;
-    int xi = (int)x < res - 2 ? (int)x : res - 2, yi = (int)y < res - 2 ? (int)y : res - 2;
-    int zi = FindInterval(res, [&](int i) { return sv.rgb2specZNodes[i] < z; });
-    float dx = x - xi, dy = y - yi, dz = (z - sv.rgb2specZNodes[zi]) / (sv.rgb2specZNodes[zi + 1] - sv.rgb2specZNodes[zi]);
-    for (int i = 0; i < 3; ++i) {
-        auto co = [&](int ddx, int ddy, int ddz) {
-            return sv.rgb2specCoeffs[((((size_t)maxc * res + (zi + ddz)) * res + (yi + ddy)) * res + (xi + ddx)) * 3 + i];
-        };
-        c[i] = Lerp(dz, Lerp(dy, Lerp(dx, co(0, 0, 0), co(1, 0, 0)), Lerp(dx, co(0, 1, 0), co(1, 1, 0))),
-                    Lerp(dy, Lerp(dx, co(0, 0, 1), co(1, 0, 1)), Lerp(dx, co(0, 1, 1), co(1, 1, 1))));
-    }
-}
 // ImageInfiniteLight::ImageLe (lights.h:640-647): nearest texel with octahedral wrap (util/image.h:96-125,352-356),
 // RGBIlluminantSpectrum of the clamped RGB (util/spectrum.cpp:235-246, util/spectrum.h:606-626)
 WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavelengths &lambda) {

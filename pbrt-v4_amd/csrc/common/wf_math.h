@@ -22,8 +22,13 @@
 // always_inline: a kernel must never fall back to real calls (the by-value scene struct would be spilled to
 // scratch and the callee would run on a private stack)
 #define WF_HD __host__ __device__ inline __attribute__((always_inline))
+// the few deliberately out-of-line device functions (image-texture filtering): leaf functions whose arguments are
+// plain pointers and scalars, so nothing of the by-value scene struct is forced into memory.  Inlining them at every
+// node of the texture-graph template multiplies the material kernels' code by ~100 (40-minute compiles).
+#define WF_NI __host__ __device__ inline __attribute__((noinline))
 #else
 #define WF_HD inline
+#define WF_NI inline
 #endif
 
 namespace wf {

@@ -33,9 +33,10 @@ struct SceneView {
     float allLightBounds[6];
     // image infinite lights
     const wf_image_light *imageLights;
+    const wf_tex_image *texImages;
     const float *tableData;
     const float *rgb2specCoeffs;
-    float rgb2specZNodes[64];
+    const float *rgb2specZNodes;  // [64]
     int csIlluminantOffset;
     // participating media
     const wf_medium *media;
@@ -181,6 +182,179 @@ WF_HD float Checkerboard2D(const wf_texture &t, const TexCtx &c) {
     dt *= 1.5f;
     return 0.5f - bf(s, ds) * bf(tt, dt) / 2;
 }
+// ---------------------------------------------------------------------------------------------
+// Image textures: MIPMap::Filter for the point / bilinear / trilinear filters (util/mipmap.cpp:228-262), Image::
+// BilerpChannel / GetChannel with wrap modes (util/image.h:96-147,265-292), RGB -> spectrum (util/spectrum.cpp:218-246)
+// RGBToSpectrumTable::operator() (util/color.cpp:31-68) on the device copy of the table
+WF_NI void RGBToSpectrumCoeffsP(const float *coeffs, const float *zNodes, float r, float g, float b, float *c0, float *c1, float *c2) {
+    constexpr int res = 64;
+    const float rgb[3] = {r, g, b};
+    float c[3];
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) {
+        *c0 = 0; *c1 = 0;
+        *c2 = (rgb[0] - .5f) / sqrt(rgb[0] * (1 - rgb[0]));
+        return;
+    }
+    int maxc = (rgb[0] > rgb[1]) ? ((rgb[0] > rgb[2]) ? 0 : 2) : ((rgb[1] > rgb[2]) ? 1 : 2);
+    float z = maxc == 0 ? rgb[0] : (maxc == 1 ? rgb[1] : rgb[2]);
+    float cx = maxc == 0 ? rgb[1] : (maxc == 1 ? rgb[2] : rgb[0]);  // rgb[(maxc + 1) % 3]
+    float cy = maxc == 0 ? rgb[2] : (maxc == 1 ? rgb[0] : rgb[1]);  // rgb[(maxc + 2) % 3]
+    float x = cx * (res - 1) / z;
+    float y = cy * (res - 1) / z;
+    int xi = (int)x < res - 2 ? (int)x : res - 2, yi = (int)y < res - 2 ? (int)y : res - 2;
+    int zi = FindInterval(res, [&](int i) { return zNodes[i] < z; });
+    float dx = x - xi, dy = y - yi, dz = (z - zNodes[zi]) / (zNodes[zi + 1] - zNodes[zi]);
+    for (int i = 0; i < 3; ++i) {
+        auto co = [&](int ddx, int ddy, int ddz) {
+            return coeffs[((((size_t)maxc * res + (zi + ddz)) * res + (yi + ddy)) * res + (xi + ddx)) * 3 + i];
+        };
+        c[i] = Lerp(dz, Lerp(dy, Lerp(dx, co(0, 0, 0), co(1, 0, 0)), Lerp(dx, co(0, 1, 0), co(1, 1, 0))),
+                    Lerp(dy, Lerp(dx, co(0, 0, 1), co(1, 0, 1)), Lerp(dx, co(0, 1, 1), co(1, 1, 1))));
+    }
+    *c0 = c[0]; *c1 = c[1]; *c2 = c[2];
+}
+WF_HD void RGBToSpectrumCoeffs(const SceneView &sv, const float rgb[3], float c[3]) {
+    RGBToSpectrumCoeffsP(sv.rgb2specCoeffs, sv.rgb2specZNodes, rgb[0], rgb[1], rgb[2], &c[0], &c[1], &c[2]);
+}
+WF_HD int ModI(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }  // util/math.h:251-254
+WF_HD float ImageTexel(const float *table, const wf_tex_image &im, int level, int x, int y, int c) {
+    const int rx = im.res[0] >> level > 0 ? im.res[0] >> level : 1, ry = im.res[1] >> level > 0 ? im.res[1] >> level : 1;
+    // RemapPixelCoords (util/image.h:96-147)
+    if (im.wrap == WF_WRAP_OCTAHEDRAL) {
+        if (x < 0) { x = -x; y = ry - 1 - y; }
+        else if (x >= rx) { x = 2 * rx - 1 - x; y = ry - 1 - y; }
+        if (y < 0) { x = rx - 1 - x; y = -y; }
+        else if (y >= ry) { x = rx - 1 - x; y = 2 * ry - 1 - y; }
+        if (rx == 1) x = 0;
+        if (ry == 1) y = 0;
+    } else {
+        if (!(x >= 0 && x < rx)) {
+            if (im.wrap == WF_WRAP_REPEAT) x = ModI(x, rx);
+            else if (im.wrap == WF_WRAP_CLAMP) x = Clamp(x, 0, rx - 1);
+            else return 0.f;
+        }
+        if (!(y >= 0 && y < ry)) {
+            if (im.wrap == WF_WRAP_REPEAT) y = ModI(y, ry);
+            else if (im.wrap == WF_WRAP_CLAMP) y = Clamp(y, 0, ry - 1);
+            else return 0.f;
+        }
+    }
+    return table[im.level_offset[level] + ((size_t)y * rx + x) * im.n_channels + c];
+}
+WF_HD float ImageBilerpChannel(const float *table, const wf_tex_image &im, int level, V2 p, int c) {
+    const int rx = im.res[0] >> level > 0 ? im.res[0] >> level : 1, ry = im.res[1] >> level > 0 ? im.res[1] >> level : 1;
+    float x = p.x * rx - 0.5f, y = p.y * ry - 0.5f;
+    int xi = (int)floor(x), yi = (int)floor(y);
+    float dx = x - xi, dy = y - yi;
+    float v0 = ImageTexel(table, im, level, xi, yi, c), v1 = ImageTexel(table, im, level, xi + 1, yi, c);
+    float v2 = ImageTexel(table, im, level, xi, yi + 1, c), v3 = ImageTexel(table, im, level, xi + 1, yi + 1, c);
+    return ((1 - dx) * (1 - dy) * v0 + dx * (1 - dy) * v1 + (1 - dx) * dy * v2 + dx * dy * v3);
+}
+struct RGB3 { float r, g, b; };
+// MIPMap::Texel<RGB> / Bilerp<RGB> (util/mipmap.cpp:214-226,286-298), Texel<Float> / Bilerp<Float> (:208-212,395-409)
+WF_HD RGB3 MIPTexelRGB(const float *table, const wf_tex_image &im, int level, int x, int y) {
+    if (im.n_channels == 3) return RGB3{ImageTexel(table, im, level, x, y, 0), ImageTexel(table, im, level, x, y, 1), ImageTexel(table, im, level, x, y, 2)};
+    float v = ImageTexel(table, im, level, x, y, 0);
+    return RGB3{v, v, v};
+}
+WF_HD RGB3 MIPBilerpRGB(const float *table, const wf_tex_image &im, int level, V2 st) {
+    if (im.n_channels == 3) return RGB3{ImageBilerpChannel(table, im, level, st, 0), ImageBilerpChannel(table, im, level, st, 1), ImageBilerpChannel(table, im, level, st, 2)};
+    float v = ImageBilerpChannel(table, im, level, st, 0);
+    return RGB3{v, v, v};
+}
+WF_HD float MIPBilerpFloat(const float *table, const wf_tex_image &im, int level, V2 st) {
+    if (im.n_channels == 1) return ImageBilerpChannel(table, im, level, st, 0);
+    float sum = 0;
+    for (int c = 0; c < 3; ++c) sum += ImageBilerpChannel(table, im, level, st, c);
+    return sum / 3;
+}
+// the level choice of the non-EWA filters; returns false when the filter is wider than the image (top level texel)
+WF_HD bool MIPLevel(const wf_tex_image &im, float dsdx, float dtdx, float dsdy, float dtdy, float *level, int *iLevel) {
+    float width = 2 * fmax(fmax(abs(dsdx), abs(dtdx)), fmax(abs(dsdy), abs(dtdy)));
+    const int nLevels = im.n_levels;
+    *level = nLevels - 1 + log(fmax(width, 1e-8f)) * 1.442695040888963387004650940071f;
+    if (*level >= nLevels - 1) return false;
+    int il = (int)floor(*level);
+    *iLevel = il > 0 ? il : 0;
+    return true;
+}
+WF_NI void MIPFilterRGBP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy, float *r, float *g, float *b) {
+    const wf_tex_image im = *imp;
+    const V2 st{s_, t_};
+    RGB3 o = [&]() -> RGB3 {
+    float level;
+    int iLevel;
+    if (!MIPLevel(im, dsdx, dtdx, dsdy, dtdy, &level, &iLevel)) return MIPTexelRGB(table, im, im.n_levels - 1, 0, 0);
+    if (im.filter == WF_MIP_POINT) {
+        const int rx = im.res[0] >> iLevel > 0 ? im.res[0] >> iLevel : 1, ry = im.res[1] >> iLevel > 0 ? im.res[1] >> iLevel : 1;
+        return MIPTexelRGB(table, im, iLevel, (int)roundf(st.x * rx - 0.5f), (int)roundf(st.y * ry - 0.5f));
+    }
+    if (im.filter == WF_MIP_BILINEAR || iLevel == 0) return MIPBilerpRGB(table, im, iLevel, st);
+    RGB3 a = MIPBilerpRGB(table, im, iLevel, st), bb = MIPBilerpRGB(table, im, iLevel + 1, st);
+    float t = level - iLevel;
+    return RGB3{Lerp(t, a.r, bb.r), Lerp(t, a.g, bb.g), Lerp(t, a.b, bb.b)};
+    }();
+    *r = o.r; *g = o.g; *b = o.b;
+}
+WF_HD RGB3 MIPFilterRGB(const SceneView &sv, int image, V2 st, float dsdx, float dtdx, float dsdy, float dtdy) {
+    RGB3 o;
+    MIPFilterRGBP(sv.tableData, sv.texImages + image, st.x, st.y, dsdx, dtdx, dsdy, dtdy, &o.r, &o.g, &o.b);
+    return o;
+}
+WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy) {
+    const wf_tex_image im = *imp;
+    const V2 st{s_, t_};
+    float level;
+    int iLevel;
+    if (!MIPLevel(im, dsdx, dtdx, dsdy, dtdy, &level, &iLevel)) return ImageTexel(table, im, im.n_levels - 1, 0, 0, 0);
+    if (im.filter == WF_MIP_POINT) {
+        const int rx = im.res[0] >> iLevel > 0 ? im.res[0] >> iLevel : 1, ry = im.res[1] >> iLevel > 0 ? im.res[1] >> iLevel : 1;
+        return ImageTexel(table, im, iLevel, (int)roundf(st.x * rx - 0.5f), (int)roundf(st.y * ry - 0.5f), 0);
+    }
+    if (im.filter == WF_MIP_BILINEAR || iLevel == 0) return MIPBilerpFloat(table, im, iLevel, st);
+    return Lerp(level - iLevel, MIPBilerpFloat(table, im, iLevel, st), MIPBilerpFloat(table, im, iLevel + 1, st));
+}
+WF_HD float MIPFilterFloat(const SceneView &sv, int image, V2 st, float dsdx, float dtdx, float dsdy, float dtdy) {
+    return MIPFilterFloatP(sv.tableData, sv.texImages + image, st.x, st.y, dsdx, dtdx, dsdy, dtdy);
+}
+// FloatImageTexture::Evaluate (textures.h:579-591), SpectrumImageTexture::Evaluate (textures.cpp:300-328)
+WF_HD float EvalFloatImageTexture(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+    const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
+    float dsdx = su * c.dudx, dsdy = su * c.dudy, dtdx = sv_ * c.dvdx, dtdy = sv_ * c.dvdy;
+    V2 st{su * c.uv.x + du, sv_ * c.uv.y + dv};
+    st.y = 1 - st.y;
+    float v = t.f0 * MIPFilterFloat(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
+    return t.f1 != 0 ? fmax(0.f, 1 - v) : v;
+}
+WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &c) {
+    const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
+    float dsdx = su * c.dudx, dsdy = su * c.dudy, dtdx = sv_ * c.dvdx, dtdy = sv_ * c.dvdy;
+    V2 st{su * c.uv.x + du, sv_ * c.uv.y + dv};
+    st.y = 1 - st.y;
+    RGB3 f = MIPFilterRGB(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
+    float rgb[3] = {t.f0 * f.r, t.f0 * f.g, t.f0 * f.b};
+    if (t.f1 != 0) { rgb[0] = 1 - rgb[0]; rgb[1] = 1 - rgb[1]; rgb[2] = 1 - rgb[2]; }
+    for (int k = 0; k < 3; ++k) rgb[k] = fmax(0.f, rgb[k]);
+    float cf[3];
+    S4 s;
+    if (t.spectrum == 0) {
+        // RGBAlbedoSpectrum(cs, Clamp(rgb, 0, 1))
+        float in[3] = {Clamp(rgb[0], 0.f, 1.f), Clamp(rgb[1], 0.f, 1.f), Clamp(rgb[2], 0.f, 1.f)};
+        RGBToSpectrumCoeffs(sv, in, cf);
+        for (int i = 0; i < 4; ++i) s[i] = SigmoidPoly(lambda.lambda[i], cf[0], cf[1], cf[2]);
+        return s;
+    }
+    // RGBUnboundedSpectrum / RGBIlluminantSpectrum: scale = 2 max(rgb), rsp = coeffs(rgb / scale)
+    float m = fmax(fmax(rgb[0], rgb[1]), rgb[2]);
+    float scale = 2 * m;
+    float in[3] = {0, 0, 0};
+    if (scale) { in[0] = rgb[0] / scale; in[1] = rgb[1] / scale; in[2] = rgb[2] / scale; }
+    RGBToSpectrumCoeffs(sv, in, cf);
+    for (int i = 0; i < 4; ++i) s[i] = scale * SigmoidPoly(lambda.lambda[i], cf[0], cf[1], cf[2]);
+    if (t.spectrum == 2) return s * DenseSample(sv, sv.csIlluminantOffset, lambda);
+    return s;
+}
+
 // FloatTexture::Evaluate / SpectrumTexture::Evaluate over the flattened texture graph.  The reference recurses through
 // tagged pointers; the device code has no recursion: the walk is a template over the remaining depth, fully inlined.
 // With three interior node types the inlined code grows ~7x per level, so the bound is two interior levels above the
@@ -192,6 +366,7 @@ template <int D>
 WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
     if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
+    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture(sv, t, tc);
     if constexpr (D > 0) {
         if (t.type == WF_TEX_FLOAT_SCALE) {
             // FloatScaledTexture::Evaluate, textures.h:1039-1044
@@ -215,6 +390,7 @@ template <int D>
 WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
     if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
+    if (t.type == WF_TEX_SPECTRUM_IMAGE) return EvalSpectrumImageTexture(sv, t, lambda, tc);
     if constexpr (D > 0) {
         if (t.type == WF_TEX_SPECTRUM_SCALE) {
             // SpectrumScaledTexture::Evaluate, textures.h:1059-1064

@@ -665,9 +665,10 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.lightXforms, d->light_transforms, (size_t)d->n_light_transforms))) return e;
     if ((e = devUpload(ctx, &sv.powerAlias, d->power_alias, d->light_sampler == WF_LS_POWER ? (size_t)3 * d->n_lights : (size_t)0))) return e;
     if ((e = devUpload(ctx, &sv.imageLights, d->image_lights, (size_t)d->n_image_lights))) return e;
+    if ((e = devUpload(ctx, &sv.texImages, d->tex_images, (size_t)d->n_tex_images))) return e;
     if ((e = devUpload(ctx, &sv.tableData, d->table_data, (size_t)d->n_table_floats))) return e;
     if ((e = devUpload(ctx, &sv.rgb2specCoeffs, d->rgb2spec_coeffs, d->rgb2spec_coeffs ? (size_t)3 * 64 * 64 * 64 * 3 : (size_t)0))) return e;
-    for (int i = 0; i < 64; ++i) sv.rgb2specZNodes[i] = d->rgb2spec_znodes[i];
+    if ((e = devUpload(ctx, &sv.rgb2specZNodes, d->rgb2spec_znodes, (size_t)64))) return e;
     sv.csIlluminantOffset = d->cs_illuminant_offset;
     if ((e = devUpload(ctx, &sv.media, d->media, (size_t)d->n_media))) return e;
     if ((e = devUpload(ctx, &sv.mediumData, d->medium_data, (size_t)d->n_medium_floats))) return e;

@@ -124,6 +124,7 @@ struct SceneTables {
     std::vector<wf_transform> lightTransforms;
     std::vector<float> filterData, powerAlias;
     std::vector<wf_image_light> imageLights;
+    std::vector<wf_tex_image> texImages;
     std::vector<float> tableData;
     std::vector<wf_medium> media;
     std::vector<float> mediumData;

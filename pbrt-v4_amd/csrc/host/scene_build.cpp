@@ -44,6 +44,7 @@ void SceneTables::Finalize() {
     desc.power_alias = powerAlias.data();
     desc.n_filter_floats = (int)filterData.size(); desc.filter_data = filterData.data();
     desc.n_image_lights = (int)imageLights.size(); desc.image_lights = imageLights.data();
+    desc.n_tex_images = (int)texImages.size(); desc.tex_images = texImages.data();
     desc.n_table_floats = (int)tableData.size(); desc.table_data = tableData.data();
     desc.n_media = (int)media.size(); desc.media = media.data();
     desc.n_medium_floats = (int)mediumData.size(); desc.medium_data = mediumData.data();
@@ -132,6 +133,68 @@ struct TexBuilder {
         t->map[2] = ps.GetOneFloat("udelta", 0.f);
         t->map[3] = ps.GetOneFloat("vdelta", 0.f);
     }
+    // ImageTextureBase ctor + MIPMap::CreateFromFile + Image::GeneratePyramid (textures.h:528-550, util/mipmap.cpp:163-206,
+    // util/image.cpp GeneratePyramid) for float .pfm images with power-of-two resolution
+    std::map<std::string, int> imageCache;
+    int LoadTexImage(const TextureEntity &te, wf_texture *t) {
+        const ParamSet &ps = te.params;
+        if (ps.GetOneString("mapping", "uv") != "uv") Die(te.loc, "only the \"uv\" texture mapping is supported by this build");
+        t->map[0] = ps.GetOneFloat("uscale", 1.f); t->map[1] = ps.GetOneFloat("vscale", 1.f);
+        t->map[2] = ps.GetOneFloat("udelta", 0.f); t->map[3] = ps.GetOneFloat("vdelta", 0.f);
+        ps.GetOneFloat("maxanisotropy", 8.f);
+        std::string filter = ps.GetOneString("filter", "bilinear"), wrap = ps.GetOneString("wrap", "repeat");
+        int ff = filter == "point" ? WF_MIP_POINT : filter == "bilinear" ? WF_MIP_BILINEAR : filter == "trilinear" ? WF_MIP_TRILINEAR : -1;
+        if (ff < 0) Die(te.loc, filter + ": only the point, bilinear and trilinear texture filters are supported by this build");
+        int wm = wrap == "clamp" ? WF_WRAP_CLAMP : wrap == "repeat" ? WF_WRAP_REPEAT : wrap == "black" ? WF_WRAP_BLACK : wrap == "octahedralsphere" ? WF_WRAP_OCTAHEDRAL : -1;
+        if (wm < 0) Die(te.loc, wrap + ": wrap mode unknown");
+        t->f0 = ps.GetOneFloat("scale", 1.f);
+        t->f1 = ps.GetOneBool("invert", false) ? 1.f : 0.f;
+        std::string filename = ps.GetOneString("filename", "");
+        ps.GetOneString("encoding", "linear");
+        if (filename.empty()) Die(te.loc, "imagemap texture without a filename");
+        if (filename[0] != '/') filename = scene->baseDir + "/" + filename;
+        std::string key = filename + "|" + filter + "|" + wrap;
+        auto it = imageCache.find(key);
+        if (it != imageCache.end()) return it->second;
+        std::vector<float> rgb;
+        int w = 0, h = 0;
+        if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
+            Die(te.loc, filename + ": unable to read image (this build reads .pfm textures)");
+        if ((w & (w - 1)) || (h & (h - 1))) Die(te.loc, filename + ": texture resolution must be a power of two in this build (no resampling)");
+        bool grey = false;
+        { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); } }
+        wf_tex_image im{};
+        im.res[0] = w; im.res[1] = h; im.n_channels = grey ? 1 : 3; im.wrap = wm; im.filter = ff;
+        const int nc = im.n_channels;
+        std::vector<float> level((size_t)w * h * nc);
+        for (size_t i = 0; i < (size_t)w * h; ++i)
+            for (int c = 0; c < nc; ++c) level[i * nc + c] = rgb[i * 3 + c];
+        int lw = w, lh = h;
+        im.n_levels = 1 + (31 - __builtin_clz((unsigned)std::max(w, h)));
+        if (im.n_levels > 20) Die(te.loc, "texture too large");
+        for (int l = 0; l < im.n_levels; ++l) {
+            im.level_offset[l] = (int)T->tableData.size();
+            T->tableData.insert(T->tableData.end(), level.begin(), level.end());
+            if (l == im.n_levels - 1) break;
+            int nw = std::max(1, lw / 2), nh = std::max(1, lh / 2);
+            std::vector<float> next((size_t)nw * nh * nc);
+            int d1 = nc, d2 = nc * lw, d3 = nc * (lw + 1);
+            if (lw == 1) { d1 = 0; d3 -= nc; }
+            if (lh == 1) { d2 = 0; d3 -= nc * lw; }
+            for (int y = 0; y < nh; ++y) {
+                size_t src = (size_t)(2 * y) * lw * nc, dst = (size_t)y * nw * nc;
+                for (int x = 0; x < nw; ++x, src += nc)
+                    for (int c = 0; c < nc; ++c, ++src, ++dst)
+                        next[dst] = (level[src] + level[src + d1] + level[src + d2] + level[src + d3]) / 4;
+            }
+            level.swap(next);
+            lw = nw; lh = nh;
+        }
+        int id = (int)T->texImages.size();
+        T->texImages.push_back(im);
+        imageCache[key] = id;
+        return id;
+    }
     void CreateNamedTextures() {
         for (const TextureEntity &te : scene->textures) {
             const ParamSet &ps = te.params;
@@ -148,6 +211,10 @@ struct TexBuilder {
                     t.tex0 = GetFloatTexture(ps, "tex1", 0.f);
                     t.tex1 = GetFloatTexture(ps, "tex2", 1.f);
                     t.tex2 = GetFloatTexture(ps, "amount", 0.5f);
+                } else if (te.name == "imagemap") {
+                    // FloatImageTexture::Create (textures.cpp:335-370)
+                    t.type = WF_TEX_FLOAT_IMAGE;
+                    t.i0 = LoadTexImage(te, &t);
                 } else if (te.name == "checkerboard") {
                     // FloatCheckerboardTexture::Create (textures.cpp:219-241)
                     CheckerMapping(te, &t);
@@ -175,6 +242,15 @@ struct TexBuilder {
                         t.tex0 = GetSpectrumTexture(ps, "tex1", *MakeConstant(0.f), st);
                         t.tex1 = GetSpectrumTexture(ps, "tex2", *MakeConstant(1.f), st);
                         t.tex2 = GetFloatTexture(ps, "amount", 0.5f);
+                    } else if (te.name == "imagemap") {
+                        // SpectrumImageTexture::Create (textures.cpp:372-407); the PFM carries no colour space -> sRGB
+                        t.type = WF_TEX_SPECTRUM_IMAGE;
+                        t.i0 = LoadTexImage(te, &t);
+                        t.spectrum = st == SpectrumType::Albedo ? 0 : (st == SpectrumType::Unbounded ? 1 : 2);
+                        const ColorSpace *ics = SpectralData::Get().sRGB();
+                        T->desc.rgb2spec_coeffs = ics->table->coeffs.data();
+                        for (int i = 0; i < 64; ++i) T->desc.rgb2spec_znodes[i] = ics->table->zNodes[i];
+                        T->desc.cs_illuminant_offset = T->pool.AddDense(*ics->illuminant);
                     } else if (te.name == "checkerboard") {
                         // SpectrumCheckerboardTexture::Create (textures.cpp:250-278)
                         CheckerMapping(te, &t);

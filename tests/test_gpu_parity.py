@@ -114,7 +114,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "envmap", "textures_bump",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "envmap", "textures_bump", "image_textures",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")

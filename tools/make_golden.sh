@@ -17,6 +17,7 @@ make_scenes.materials_lights("tests/golden/materials_lights.pbrt", (96, 54), 4)
 make_scenes.media_box("tests/golden/media_box.pbrt", (64, 64), 4)
 make_scenes.envmap_scene("tests/golden/envmap.pbrt", (64, 64), 4)
 make_scenes.textures_bump("tests/golden/textures_bump.pbrt", (64, 64), 4)
+make_scenes.image_textures("tests/golden/image_textures.pbrt", (64, 64), 4)
 PY
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_ref.pfm $G/cornell64.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_small_ref.pfm $G/blobs_small.pbrt
@@ -24,6 +25,7 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_box_ref.pfm $G/media_box.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/envmap_ref.pfm $G/envmap.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_bump_ref.pfm $G/textures_bump.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/image_textures_ref.pfm $G/image_textures.pbrt
 # the same lights through the PowerLightSampler (alias table)
 sed 's/Integrator "volpath"/Integrator "volpath" "string lightsampler" [ "power" ]/' $G/materials_lights.pbrt > $G/materials_lights_power.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_power_ref.pfm $G/materials_lights_power.pbrt
