@@ -116,7 +116,8 @@ enum wf_material_type {
     WF_MAT_DIFFUSE_TRANSMISSION = 5, /* materials.h:672-720 */
     WF_MAT_COATED_DIFFUSE = 6,       /* materials.h:551-608 */
     WF_MAT_COATED_CONDUCTOR = 7,     /* materials.h:611-669 */
-    WF_MAT_NTYPES = 8
+    WF_MAT_NTYPES = 8,               /* the types above have an evaluation queue + kernel each */
+    WF_MAT_MIX = 8                   /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
 };
 /* tex[] slots */
 #define WF_MT_REFLECTANCE 0   /* diffuse / conductor(reflectance) / difftrans / coated diffuse */
@@ -128,6 +129,7 @@ enum wf_material_type {
 #define WF_MT_THICKNESS 5     /* coated */
 #define WF_MT_G 6             /* coated */
 #define WF_MT_ALBEDO 7        /* coated */
+#define WF_MT_AMOUNT 0        /* mix */
 #define WF_MT_NTEX 12
 /* coated conductor: interface roughness in UROUGH/VROUGH, conductor in slots 8..11 */
 #define WF_MT_COND_UROUGH 8
@@ -143,6 +145,7 @@ typedef struct wf_material {
     float scale;                 /* difftrans scale */
     int32_t displacement;        /* float texture id or -1 */
     int32_t normalmap;           /* image id or -1 */
+    int32_t mix[2];              /* WF_MAT_MIX: the two material ids; the "amount" float texture is tex[WF_MT_AMOUNT] */
 } wf_material;
 #define WF_MATFLAG_REMAP_ROUGHNESS 1
 #define WF_MATFLAG_CONDUCTOR_REFLECTANCE 2

@@ -73,12 +73,19 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.media = d.media; sv.mediumData = d.medium_data;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;
     sv.texNeedsFootprint = 0;
+    sv.haveAlpha = 0;
+    for (int i = 0; i < d.n_meshes; ++i)
+        if (d.meshes[i].alpha_tex >= 0) sv.haveAlpha = 1;
     for (int i = 0; i < d.n_textures; ++i)
         if (d.textures[i].type >= WF_TEX_FLOAT_IMAGE) sv.texNeedsFootprint = 1;
     for (int i = 0; i < d.n_materials; ++i)
-        if (d.materials[i].displacement >= 0) sv.texNeedsFootprint = 1;
+        if (d.materials[i].displacement >= 0 || d.materials[i].normalmap >= 0) sv.texNeedsFootprint = 1;
     sv.matTypeMask = 0;
-    for (int i = 0; i < d.n_materials; ++i) sv.matTypeMask |= 1 << d.materials[i].type;
+    sv.haveMix = 0;
+    for (int i = 0; i < d.n_materials; ++i) {
+        if (d.materials[i].type == WF_MAT_MIX) sv.haveMix = 1;
+        else sv.matTypeMask |= 1 << d.materials[i].type;
+    }
     return sv;
 }
 
@@ -344,6 +351,7 @@ int main(int argc, char **argv) {
     ws.samples0 = Alloc<F4>(n); ws.samples1 = Alloc<F4>(n);
     AllocRayQueue(&ws.rq[0], n); AllocRayQueue(&ws.rq[1], n);
     ws.hit = Alloc<F4>(n);
+    if (sv.haveMix) ws.mixMat = Alloc<int32_t>(n);
     ws.escapedQ = Alloc<int32_t>(n); ws.hitLightQ = Alloc<int32_t>(n);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.matQ[m] = Alloc<int32_t>(T.materialTypePresent[m] ? n : 1);
     ws.sq.o = Alloc<F4>(n); ws.sq.d = Alloc<F4>(n); ws.sq.Ld = Alloc<F4>(n); ws.sq.r_u = Alloc<F4>(n); ws.sq.r_l = Alloc<F4>(n);

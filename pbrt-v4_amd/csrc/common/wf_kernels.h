@@ -78,6 +78,7 @@ struct WorkState {
     // items' payload is the ray slot itself (+ hit / hitT), beta, r_u, r_l are updated in place in the ray queue
     int32_t *mediumSampleQ, *mediumScatterQ;
     F4 *scatterP;  // per ray slot: scattering point p.xyz, HG g
+    int32_t *mixMat;  // per ray slot: the material id a MixMaterial hit resolved to (allocated when sv.haveMix)
     int32_t *matQ[WF_MAT_NTYPES];
     ShadowQueueV sq;
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
@@ -298,6 +299,32 @@ WF_HD int SurfaceMedium(const wf_mesh &mesh, N3 n, V3 w, int rayMedium) {
     if (mesh.medium_inside != mesh.medium_outside) return Dot(w, n) > 0 ? mesh.medium_outside : mesh.medium_inside;
     return rayMedium;
 }
+// The MixMaterial resolve loop of EnqueueWorkAfterIntersection (intersect.h:92-97) + MixMaterial::ChooseMaterial
+// (materials.h:284-294).  The reference hashes (p, wo, the two Material tagged POINTERS): its choice depends on heap
+// addresses and differs from run to run, so this is the one place where parity with it is statistical by construction;
+// here the two material ids take the pointers' place.
+WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, float b0, float b1, float b2, V3 wo) {
+    if (sv.materials[matId].type != WF_MAT_MIX) return matId;
+    SurfIntr si;
+    TriangleInteraction(sv, prim, b0, b1, b2, &si);
+    TexCtx tc;
+    tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
+    while (sv.materials[matId].type == WF_MAT_MIX) {
+        const wf_material &m = sv.materials[matId];
+        float amt = EvalFloatTexture(sv, m.tex[WF_MT_AMOUNT], tc);
+        int pick;
+        if (amt <= 0) pick = 0;
+        else if (amt >= 1) pick = 1;
+        else {
+            uint32_t w[8] = {FloatToBits(tc.p.x), FloatToBits(tc.p.y), FloatToBits(tc.p.z), FloatToBits(wo.x), FloatToBits(wo.y), FloatToBits(wo.z),
+                             (uint32_t)m.mix[0], (uint32_t)m.mix[1]};
+            float u = HashToFloat(HashWords(w, 8));
+            pick = (amt < u) ? 0 : 1;
+        }
+        matId = m.mix[pick];
+    }
+    return matId;
+}
 // routing of a surface hit whose record is already in ws.hit[i] (beta, r_u, r_l are read from the ray slot by the
 // consumers): interface re-push / area light / material queue
 WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, int i, int prim, float b0, float b1, float b2) {
@@ -329,7 +356,13 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
         int slot = QueueAlloc(&ws.counters[(CNT_HITLIGHT) * CNT_STRIDE]);
         ws.hitLightQ[slot] = i;
     }
-    int mtype = sv.materials[mesh.material].type;
+    int matId = mesh.material;
+    if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) {
+        F4 d = ws.rq[cur].d[i];
+        matId = ResolveMix(sv, matId, prim, b0, b1, b2, V3{-d.x, -d.y, -d.z});
+        ws.mixMat[i] = matId;
+    }
+    int mtype = sv.materials[matId].type;
     int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + mtype) * CNT_STRIDE]);
     ws.matQ[mtype][slot] = i;
 }
@@ -377,7 +410,14 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
             if (route & 16u) dest |= 2u;
             if ((route & 32u) && sv.haveMedia) dest |= 4u;
-            if (route & 15u) dest |= 4u << (route & 15u);
+            unsigned mtype = route & 15u;
+            if (mtype == WF_MAT_MIX) {
+                F4 d = ws.rq[cur].d[i];
+                int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, b0, b1, b2, V3{-d.x, -d.y, -d.z});
+                ws.mixMat[i] = matId;
+                mtype = (unsigned)sv.materials[matId].type;
+            }
+            if (mtype) dest |= 4u << mtype;
         }
     }
     const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? (4u | (1u << MS)) : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2);
@@ -779,7 +819,9 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         SurfIntr si;
         TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
         const wf_mesh &mesh = sv.meshes[si.mesh];
-        const wf_material &mat = sv.materials[mesh.material];
+        int matId = mesh.material;
+        if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) matId = ws.mixMat[i];
+        const wf_material &mat = sv.materials[matId];
         F4 o4 = q.o[i], d4 = q.d[i];
         time = o4.w;
         float etaScale0 = d4.w;
@@ -811,8 +853,20 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         }
         N3 ns = si.ns;
         V3 dpdus = si.dpdus;
-        if constexpr (TEXCTX)
-        if (mat.displacement >= 0) {
+        if constexpr (TEXCTX) {
+        if (mat.normalmap >= 0) {
+            // NormalMap (materials.h:86-106) and the shading frame rebuilt from it (surfscatter.cpp:111-118)
+            V3 nm;
+            NormalMapTexelP(sv.tableData, sv.texImages + mat.normalmap, tc.uv.x, tc.uv.y, &nm.x, &nm.y, &nm.z);
+            nm = Normalize(nm);
+            Frame frame = Frame::FromXZ(Normalize(si.dpdus), toV(si.ns));
+            nm = frame.FromLocal(nm);
+            float ulen = Length(si.dpdus), vlen = Length(si.dpdvs);
+            dpdus = Normalize(GramSchmidt(si.dpdus, nm)) * ulen;
+            V3 dpdvs = Normalize(Cross(nm, dpdus)) * vlen;
+            ns = toN(Normalize(Cross(dpdus, dpdvs)));
+            ns = FaceForward(ns, si.n);
+        } else if (mat.displacement >= 0) {
             // BumpMap (materials.h:109-138) and the shading frame rebuilt from it (surfscatter.cpp:120-130)
             TexCtx sh = tc;
             float du = .5f * (abs(tc.dudx) + abs(tc.dudy));
@@ -830,6 +884,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             V3 dpdvs = si.dpdvs + (vDisplace - displace) / dv * toV(si.ns) + displace * toV(si.dndvs);
             ns = toN(Normalize(Cross(dpdus, dpdvs)));
             ns = FaceForward(ns, si.n);
+        }
         }
         Wavelengths lambda = LoadLambda(ws, pixelIndex);
         BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda, tc);

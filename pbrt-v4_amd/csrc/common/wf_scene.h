@@ -52,7 +52,9 @@ struct SceneView {
     int maxDepth, regularize, haveMedia;
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
     int texNeedsFootprint;  // some texture's value depends on the TextureEvalContext (checkerboard, image) or some material
-                            // is bump-mapped: selects the material-kernel variant that computes the differentials
+                            // is bump- or normal-mapped: selects the material-kernel variant that computes the differentials
+    int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
+    int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
     wf_options options;
 };
 
@@ -267,6 +269,14 @@ WF_HD float MIPBilerpFloat(const float *table, const wf_tex_image &im, int level
     float sum = 0;
     for (int c = 0; c < 3; ++c) sum += ImageBilerpChannel(table, im, level, st, c);
     return sum / 3;
+}
+// the texel triple NormalMap() reads (materials.h:86-95): Image::BilerpChannel of channels 0..2 at (u, 1-v), repeat wrap
+WF_NI void NormalMapTexelP(const float *table, const wf_tex_image *imp, float u, float v, float *x, float *y, float *z) {
+    const wf_tex_image im = *imp;
+    const V2 uv{u, 1 - v};
+    *x = 2 * ImageBilerpChannel(table, im, 0, uv, 0) - 1;
+    *y = 2 * ImageBilerpChannel(table, im, 0, uv, 1) - 1;
+    *z = 2 * ImageBilerpChannel(table, im, 0, uv, 2) - 1;
 }
 // the level choice of the non-EWA filters; returns false when the filter is wider than the image (top level texel)
 WF_HD bool MIPLevel(const wf_tex_image &im, float dsdx, float dtdx, float dsdy, float dtdy, float *level, int *iLevel) {

@@ -122,6 +122,24 @@ WF_HD void TriVerts(const SceneView &sv, int tri, V3 *p0, V3 *p1, V3 *p2) {
     *p0 = LoadP(sv, v[0]); *p1 = LoadP(sv, v[1]); *p2 = LoadP(sv, v[2]);
 }
 
+// GeometricPrimitive::Intersect's stochastic alpha test (cpu/primitive.cpp:57-72; IntersectP goes through Intersect,
+// :79-84).  A triangle cannot be hit again by the ray respawned behind it, so a failed test simply drops the hit.
+// The texture sees TextureEvalContext(SurfaceInteraction) with all differentials zero (interaction.h: set only by
+// ComputeDifferentials, which this path never calls).
+WF_HD bool AlphaTestPasses(const SceneView &sv, int tri, float b0, float b1, float b2, V3 o, V3 d) {
+    const wf_mesh &mesh = sv.meshes[sv.triMesh[tri]];
+    if (mesh.alpha_tex < 0) return true;
+    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
+    if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+    TexCtx tc;
+    tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
+    float a = EvalFloatTexture(sv, mesh.alpha_tex, tc);
+    if (!(a < 1)) return true;
+    float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(o, d));
+    return !(u > a);
+}
+
 // Reference-order BVH walk.  Stack is any type with push(int)/pop()/empty(); the HIP kernels pass an
 // LDS-backed short stack (csrc/hip/wf_traverse.hip), the CPU checker a plain array.
 struct ClosestHit { int prim; TriHit h; int nodesVisited, trisTested; };
@@ -145,7 +163,7 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
                     ++out->trisTested;
-                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) {
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h) && (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d))) {
                         out->prim = tri;
                         out->h = h;
                         tMax = h.t;
@@ -188,7 +206,7 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
                     ++nt;
-                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) found = true;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h) && (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d))) found = true;
                 }
                 if (found || stack.empty()) break;
                 currentNodeIndex = stack.pop();

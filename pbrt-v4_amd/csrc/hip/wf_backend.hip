@@ -231,8 +231,8 @@ __device__ inline void LoadTreeTop(const FastBVH &bvh) {
 // atomic).  Waves walk independently ("while-while": all lanes descend interior nodes until every one of
 // them sits at a leaf or is done, then the leaves are processed together); `finish` runs once per batch for
 // the whole workgroup, so its queue pushes are block-aggregated (BlockAlloc).
-template <bool ANY, typename Fetch, typename Finish>
-__device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
+template <bool ANY, bool ALPHA, typename Fetch, typename Finish>
+__device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
     LoadTreeTop(bvh);
     for (int base = blockIdx.x * TBLOCK; base < n; base += gridDim.x * TBLOCK) {
         const int idx = base + threadIdx.x;
@@ -242,8 +242,8 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
         w.prim = -1;
         w.route = 0;
         w.b0 = w.b1 = w.b2 = 0;
+        V3 o{0, 0, 0}, d{0, 0, 0};
         if (valid) {
-            V3 o, d;
             float tMax;
             fetch(idx, &o, &d, &tMax);
             WalkInit(bvh, w, o, d, tMax);
@@ -269,31 +269,37 @@ __device__ inline void BatchTrace(const FastBVH &bvh, int n, LdsStackT &st, Fetc
                     InteriorStep(w, st, a, b);
                 }
             }
-            if (w.node != NODE_NONE) LeafStep<ANY>(bvh, w, st);
+            if (w.node != NODE_NONE) {
+                if constexpr (ALPHA)
+                    LeafStep<ANY, true>(bvh, w, st, [&](int prim, float b0, float b1, float b2) { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); });
+                else LeafStep<ANY>(bvh, w, st);
+            }
         }
         finish(idx, valid, w);
     }
 }
 
+template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
     const RayQueueV q = ws.rq[cur];
-    BatchTrace<false>(
-        bvh, n, st,
+    BatchTrace<false, ALPHA>(
+        sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
         },
         [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock(sv, ws, cur, i, valid, w.prim, w.route, w.tMax, w.b0, w.b1, w.b2); });
 }
+template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true>(
-        bvh, n, st,
+    BatchTrace<true, ALPHA>(
+        sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
@@ -304,8 +310,8 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneVi
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<false>(
-        bvh, n, st,
+    BatchTrace<false, false>(
+        SceneView{}, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
             *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
@@ -323,8 +329,8 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int 
 __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true>(
-        bvh, n, st,
+    BatchTrace<true, false>(
+        SceneView{}, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
             *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
@@ -357,6 +363,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
 }
 // production layout, one independent walk per lane (a transmittance ray alternates between tracing and
 // ratio tracking, so there is no batch to share)
+template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
@@ -376,7 +383,9 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
                         a = p[0]; b = p[1];
                     }
                     InteriorStep(w, st, a, b);
-                } else LeafStep<false>(bvh, w, st);
+                } else if constexpr (ALPHA)
+                    LeafStep<false, true>(bvh, w, st, [&](int pr, float c0, float c1, float c2) { return AlphaTestPasses(sv, pr, c0, c1, c2, o, d); });
+                else LeafStep<false>(bvh, w, st);
             }
             if (w.prim >= 0) { *prim = w.prim; *b0 = w.b0; *b1 = w.b1; *b2 = w.b2; }
             return w.prim >= 0;
@@ -517,7 +526,8 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         uint32_t route = 0;
         if (mesh.material >= 0) route = (uint32_t)d->materials[mesh.material].type | (mesh.first_light >= 0 ? 16u : 0u);
         else route = 32u;
-        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : 0.f, BitsToFloat(route)};
+        // c.z: 0 = test, 1 = degenerate (never hit), 2 = test, then the mesh's alpha texture decides (ALPHA kernel variants)
+        lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : mesh.alpha_tex >= 0 ? 2.f : 0.f, BitsToFloat(route)};
         (*tris)[k] = lt;
     }
     // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
@@ -687,18 +697,29 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     FillSobol2D(sobol);
     if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)WF_SOBOL_WORDS))) return e;
     sv.texNeedsFootprint = 0;
+    sv.haveAlpha = 0;
+    for (int i = 0; i < d->n_meshes; ++i)
+        if (d->meshes[i].alpha_tex >= 0) sv.haveAlpha = 1;
     for (int i = 0; i < d->n_textures; ++i)
         if (d->textures[i].type >= WF_TEX_FLOAT_IMAGE) sv.texNeedsFootprint = 1;
     for (int i = 0; i < d->n_materials; ++i)
-        if (d->materials[i].displacement >= 0) sv.texNeedsFootprint = 1;
+        if (d->materials[i].displacement >= 0 || d->materials[i].normalmap >= 0) sv.texNeedsFootprint = 1;
     sv.maxDepth = d->max_depth;
     sv.regularize = d->regularize;
     sv.haveMedia = d->have_media;
     sv.options = d->options;
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ctx->matPresent[m] = false;
     sv.matTypeMask = 0;
+    sv.haveMix = 0;
     for (int i = 0; i < d->n_materials; ++i) {
         int t = d->materials[i].type;
+        if (t == WF_MAT_MIX) {
+            const int32_t *mx = d->materials[i].mix;
+            if (mx[0] < 0 || mx[0] >= d->n_materials || mx[1] < 0 || mx[1] >= d->n_materials || mx[0] >= i || mx[1] >= i)
+                return fail(-1, "mix material %d must name two earlier materials", i);
+            sv.haveMix = 1;
+            continue;
+        }
         if (t < 0 || t >= WF_MAT_NTYPES) return fail(-1, "material %d has unknown type %d", i, t);
         ctx->matPresent[t] = true;
         sv.matTypeMask |= 1 << t;
@@ -718,7 +739,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
         int perCU = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_closest_fast, TBLOCK, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_closest_fast<false>, TBLOCK, 0));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
         int g = std::max(1, perCU) * prop.multiProcessorCount;
@@ -782,6 +803,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
             (e = devAlloc(ctx, &ws.scatterP, n)) || (e = devAlloc(ctx, &ws.sq.medium, n)))
             return e;
     }
+    if (ctx->svHost.haveMix && (e = devAlloc(ctx, &ws.mixMat, n))) return e;
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
         if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
@@ -852,7 +874,8 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     else if (ctx->fastOk)
-        LAUNCHT("Intersect closest", k_closest_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
     else
         LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     return 0;
@@ -871,7 +894,8 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
     if (ctx->fastOk && !ctx->countTraversal)
-        LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + depth, CNT_SHADOW);
@@ -916,7 +940,8 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     else if (ctx->fastOk)
-        LAUNCHT("Intersect shadow", k_shadow_fast, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        else LAUNCHT("Intersect shadow", k_shadow_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)

@@ -150,8 +150,11 @@ __device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
     else w.node = st.empty() ? NODE_NONE : st.pop();
 }
 // Leaf: <= 16 triangle tests.  ANY: stop at the first hit.  Precondition: w.node < 0 && w.node != NODE_NONE.
-template <bool ANY, typename Stack>
-__device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st) {
+// accept(prim, b0, b1, b2): the alpha test of triangles marked c.z == 2 (ALPHA variants only; other variants
+// never see the mark).
+struct AcceptAll { __device__ bool operator()(int, float, float, float) const { return true; } };
+template <bool ANY, bool ALPHA = false, typename Stack, typename Accept = AcceptAll>
+__device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, Accept accept = Accept()) {
     unsigned ref = ~(unsigned)w.node;
     int first = (int)(ref >> 4), count = (int)(ref & 15u) + 1;
     bool done = false;
@@ -159,8 +162,10 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st) {
         const LeafTri *lt = bvh.tris + first + i;
         const F4 ta = lt->a, tb = lt->b, tc = lt->c;
         TriHit h;
-        if (tc.z == 0.f &&
+        if ((ALPHA ? tc.z != 1.f : tc.z == 0.f) &&
             IntersectTriangleSheared(w.o, w.sh, w.tMax, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
+            if constexpr (ALPHA)
+                if (tc.z == 2.f && !accept((int)FloatToBits(tc.y), h.b0, h.b1, h.b2)) continue;
             w.prim = (int)FloatToBits(tc.y);
             w.route = FloatToBits(tc.w);
             w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;

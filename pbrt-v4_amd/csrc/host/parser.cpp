@@ -65,6 +65,11 @@ std::string ParamSet::GetOneString(const std::string &name, const std::string &d
         }
     return def;
 }
+std::vector<std::string> ParamSet::GetStringArray(const std::string &name) const {
+    for (const Param &p : params)
+        if (p.name == name && p.type == "string") { p.lookedUp = true; return p.strings; }
+    return {};
+}
 std::vector<float> ParamSet::GetFloatArray(const std::string &name) const {
     for (const Param &p : params)
         if (p.name == name && p.type == "float") { p.lookedUp = true; return p.floats; }

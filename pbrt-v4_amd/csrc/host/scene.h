@@ -35,6 +35,7 @@ class ParamSet {
     bool GetOneBool(const std::string &name, bool def) const;
     std::string GetOneString(const std::string &name, const std::string &def) const;
     std::vector<float> GetFloatArray(const std::string &name) const;
+    std::vector<std::string> GetStringArray(const std::string &name) const;
     std::vector<int> GetIntArray(const std::string &name) const;
     std::vector<V3> GetPoint3fArray(const std::string &name) const;   // also vector3/normal
     std::vector<V2> GetPoint2fArray(const std::string &name) const;

@@ -136,6 +136,7 @@ struct TexBuilder {
     // ImageTextureBase ctor + MIPMap::CreateFromFile + Image::GeneratePyramid (textures.h:528-550, util/mipmap.cpp:163-206,
     // util/image.cpp GeneratePyramid) for float .pfm images with power-of-two resolution
     std::map<std::string, int> imageCache;
+    std::map<std::string, int> namedMaterialIds;  // in definition order: a "mix" material names earlier ones
     int LoadTexImage(const TextureEntity &te, wf_texture *t) {
         const ParamSet &ps = te.params;
         if (ps.GetOneString("mapping", "uv") != "uv") Die(te.loc, "only the \"uv\" texture mapping is supported by this build");
@@ -190,6 +191,29 @@ struct TexBuilder {
             level.swap(next);
             lw = nw; lh = nh;
         }
+        int id = (int)T->texImages.size();
+        T->texImages.push_back(im);
+        imageCache[key] = id;
+        return id;
+    }
+    // BasicScene::GetNormalMap (scene.cpp:885-910): the RGB channels of the image, read bilinearly at level 0 with
+    // repeat wrap by NormalMap(); .pfm only in this build
+    int LoadNormalMap(std::string filename, const std::string &loc) {
+        if (filename.empty()) return -1;
+        if (filename[0] != '/') filename = scene->baseDir + "/" + filename;
+        std::string key = filename + "|normalmap";
+        auto it = imageCache.find(key);
+        if (it != imageCache.end()) return it->second;
+        std::vector<float> rgb;
+        int w = 0, h = 0;
+        if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
+            Die(loc, filename + ": unable to read normal map (this build reads .pfm images)");
+        { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { bool grey = fread(m, 1, 2, f) == 2 && m[1] == 'f'; fclose(f);
+          if (grey) Die(loc, filename + ": normal map image must contain R, G, and B channels"); } }
+        wf_tex_image im{};
+        im.res[0] = w; im.res[1] = h; im.n_channels = 3; im.wrap = WF_WRAP_REPEAT; im.filter = WF_MIP_BILINEAR; im.n_levels = 1;
+        im.level_offset[0] = (int)T->tableData.size();
+        T->tableData.insert(T->tableData.end(), rgb.begin(), rgb.end());
         int id = (int)T->texImages.size();
         T->texImages.push_back(im);
         imageCache[key] = id;
@@ -280,8 +304,7 @@ struct TexBuilder {
         for (int &t : m.tex) t = -1;
         m.eta_spectrum = -1;
         m.displacement = GetFloatTextureOrNull(ps, "displacement");
-        m.normalmap = -1;
-        if (!ps.GetOneString("normalmap", "").empty()) Die(e.loc, "normalmap is not supported by this build");
+        m.normalmap = LoadNormalMap(ps.GetOneString("normalmap", ""), e.loc);
         const std::string &name = e.name;
         auto roughness = [&](const char *u, const char *v, const char *r, int us, int vs) {
             int ur = GetFloatTextureOrNull(ps, u), vr = GetFloatTextureOrNull(ps, v);
@@ -346,6 +369,21 @@ struct TexBuilder {
             if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
         } else if (name == "interface" || name == "none" || name.empty()) {
             m.type = WF_MAT_INTERFACE;
+        } else if (name == "mix") {
+            // Material::Create "mix" (materials.cpp:664-681) + MixMaterial::Create (:105-125)
+            m.type = WF_MAT_MIX;
+            std::vector<std::string> names = ps.GetStringArray("materials");
+            if (names.size() != 2) Die(e.loc, "Must provide two values for \"string materials\" for mix material.");
+            for (int i = 0; i < 2; ++i) {
+                auto it = namedMaterialIds.find(names[i]);
+                if (it == namedMaterialIds.end()) Die(e.loc, names[i] + ": named material not found.");
+                if (T->materials[it->second].type == WF_MAT_INTERFACE)
+                    Die(e.loc, names[i] + ": an \"interface\" material cannot be used as an element of the \"mix\" material.");
+                m.mix[i] = it->second;
+            }
+            m.tex[WF_MT_AMOUNT] = GetFloatTexture(ps, "amount", 0.5f);
+            T->materials.push_back(m);
+            return (int)T->materials.size() - 1;
         } else Die(e.loc, name + ": material type not supported by this build");
         T->materialTypePresent[m.type] = true;
         T->materials.push_back(m);
@@ -1021,7 +1059,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     tb.T = T;
     tb.scene = &scene;
     tb.CreateNamedTextures();
-    std::map<std::string, int> namedMaterialIds;
+    std::map<std::string, int> &namedMaterialIds = tb.namedMaterialIds;
     for (const auto &nm : scene.namedMaterials) namedMaterialIds[nm.first] = tb.CreateMaterial(nm.second);
     std::vector<int> materialIds;
     for (const Entity &m : scene.materials) materialIds.push_back(tb.CreateMaterial(m));
@@ -1071,9 +1109,10 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (T->materials[mesh.material].type == WF_MAT_INTERFACE) mesh.material = -1;
         mesh.first_light = -1;
         mesh.alpha_tex = -1;
-        std::string alphaTex = sh.params.GetTexture("alpha");
-        float alpha = sh.params.GetOneFloat("alpha", 1.f);
-        if (!alphaTex.empty() || alpha < 1.f) Die(sh.loc, "alpha textures are not supported by this build yet");
+        // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
+        if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
+        else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
+        if (mesh.alpha_tex >= 0 && sh.lightIndex >= 0) Die(sh.loc, "alpha-masked area lights are not supported by this build yet");
         mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
         mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
         if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;

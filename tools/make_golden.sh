@@ -18,6 +18,8 @@ make_scenes.media_box("tests/golden/media_box.pbrt", (64, 64), 4)
 make_scenes.envmap_scene("tests/golden/envmap.pbrt", (64, 64), 4)
 make_scenes.textures_bump("tests/golden/textures_bump.pbrt", (64, 64), 4)
 make_scenes.image_textures("tests/golden/image_textures.pbrt", (64, 64), 4)
+make_scenes.alpha_normalmap("tests/golden/alpha_normalmap.pbrt", (64, 64), 4)
+make_scenes.mix_materials("tests/golden/mix_materials.pbrt", (64, 64), 64)
 PY
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_ref.pfm $G/cornell64.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_small_ref.pfm $G/blobs_small.pbrt
@@ -26,6 +28,9 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_box
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/envmap_ref.pfm $G/envmap.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_bump_ref.pfm $G/textures_bump.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/image_textures_ref.pfm $G/image_textures.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/alpha_normalmap_ref.pfm $G/alpha_normalmap.pbrt
+# MixMaterial: the reference's choice hashes heap pointers -> statistical comparison only (64 spp, block means)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/mix_materials_ref.pfm $G/mix_materials.pbrt
 # the same lights through the PowerLightSampler (alias table)
 sed 's/Integrator "volpath"/Integrator "volpath" "string lightsampler" [ "power" ]/' $G/materials_lights.pbrt > $G/materials_lights_power.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_power_ref.pfm $G/materials_lights_power.pbrt
