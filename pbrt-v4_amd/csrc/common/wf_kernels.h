@@ -32,7 +32,7 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER,
+    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX,
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -79,6 +79,7 @@ struct WorkState {
     int32_t *mediumSampleQ, *mediumScatterQ;
     F4 *scatterP;  // per ray slot: scattering point p.xyz, HG g
     int32_t *mixMat;  // per ray slot: the material id a MixMaterial hit resolved to (allocated when sv.haveMix)
+    int32_t *mixQ;    // HIP traversal kernel only: hits on a MixMaterial, resolved by the kernel that follows it
     int32_t *matQ[WF_MAT_NTYPES];
     ShadowQueueV sq;
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
@@ -386,6 +387,17 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
     RouteSurfaceHit(sv, ws, cur, i, prim, b0, b1, b2);
 }
 
+// the follow-up of the HIP traversal kernel for hits on a MixMaterial (ws.mixQ): resolve, then the material queue
+WF_HD void KResolveMix(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    const int i = ws.mixQ[qi];
+    F4 h = ws.hit[i], d = ws.rq[cur].d[i];
+    int prim = (int)FloatToBits(h.x);
+    int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, h.y, h.z, h.w, V3{-d.x, -d.y, -d.z});
+    ws.mixMat[i] = matId;
+    int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + sv.materials[matId].type) * CNT_STRIDE]);
+    ws.matQ[sv.materials[matId].type][slot] = i;
+}
+
 #if defined(__HIPCC__)
 // The routing of a whole workgroup's batch in ONE allocation round (two barriers instead of three per
 // destination queue).  `route` = the triangle's build-time routing code (LeafTri.c.w): material type |
@@ -394,7 +406,8 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
 __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, uint32_t route,
                                       float tHit, float b0, float b1, float b2) {
     constexpr int MS = 2 + WF_MAT_NTYPES;
-    constexpr int NID = MS + 1;
+    constexpr int MIXQ = MS + 1;
+    constexpr int NID = MIXQ + 1;
     __shared__ int s_cnt[NID][16];
     __shared__ int s_base[NID];
     const bool found = valid && prim >= 0;
@@ -410,22 +423,19 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
             if (route & 16u) dest |= 2u;
             if ((route & 32u) && sv.haveMedia) dest |= 4u;
-            unsigned mtype = route & 15u;
-            if (mtype == WF_MAT_MIX) {
-                F4 d = ws.rq[cur].d[i];
-                int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, b0, b1, b2, V3{-d.x, -d.y, -d.z});
-                ws.mixMat[i] = matId;
-                mtype = (unsigned)sv.materials[matId].type;
-            }
-            if (mtype) dest |= 4u << mtype;
+            // a MixMaterial hit goes to its own queue; KResolveMix turns it into a material-queue entry (keeps the
+            // texture evaluation out of the traversal kernel's register budget)
+            if ((route & 15u) == WF_MAT_MIX) dest |= 1u << MIXQ;
+            else if (route & 15u) dest |= 4u << (route & 15u);
         }
     }
-    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? (4u | (1u << MS)) : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2);
+    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? (4u | (1u << MS)) : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2) |
+                            (sv.haveMix ? 1u << MIXQ : 0u);
     const unsigned lane = __lane_id();
     const int wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     auto counterOf = [&](int id) {
-        int c = id == 0 ? CNT_ESCAPED : (id == 1 ? CNT_HITLIGHT : (id == 2 ? CNT_RAY0 + (cur ^ 1) : (id == MS ? CNT_MEDIUM_SAMPLE : CNT_MAT0 + (id - 2))));
+        int c = id == 0 ? CNT_ESCAPED : (id == 1 ? CNT_HITLIGHT : (id == 2 ? CNT_RAY0 + (cur ^ 1) : (id == MS ? CNT_MEDIUM_SAMPLE : (id == MIXQ ? CNT_MIX : CNT_MAT0 + (id - 2)))));
         return &ws.counters[c * CNT_STRIDE];
     };
     for (unsigned m = active; m; m &= m - 1) {
@@ -469,6 +479,7 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             m.w = SurfaceMedium(sv.meshes[sv.triMesh[prim]], si.n, V3{d.x, d.y, d.z}, m.w);
             nq.meta[slot] = m;
         } else if (id == MS) ws.mediumSampleQ[slot] = i;
+        else if (id == MIXQ) ws.mixQ[slot] = i;
         else ws.matQ[id - 2][slot] = i;
     }
     __syncthreads();  // s_cnt / s_base are reused by the next batch

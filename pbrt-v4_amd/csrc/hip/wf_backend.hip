@@ -338,6 +338,10 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(FastBVH bvh, int n, c
         [&](int i, bool valid, const RayWalk &w) { if (valid) occluded[i] = w.prim >= 0; });
 }
 
+__global__ void __launch_bounds__(BLOCK) k_resolve_mix(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_MIX) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KResolveMix(sv, ws, cur, i);
+}
 // K5 / K6 / K11: participating media (wf_media.h, wf_kernels.h)
 __global__ void __launch_bounds__(BLOCK) k_medium_sample(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE];
@@ -803,7 +807,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
             (e = devAlloc(ctx, &ws.scatterP, n)) || (e = devAlloc(ctx, &ws.sq.medium, n)))
             return e;
     }
-    if (ctx->svHost.haveMix && (e = devAlloc(ctx, &ws.mixMat, n))) return e;
+    if (ctx->svHost.haveMix && ((e = devAlloc(ctx, &ws.mixMat, n)) || (e = devAlloc(ctx, &ws.mixQ, n)))) return e;
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
         if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
@@ -844,7 +848,7 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     const int cur = depth & 1;
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
-    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER);
+    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + depth, CNT_RAY0 + cur);
     return 0;
@@ -873,10 +877,11 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     // otherwise the production traversal (wf_traverse.h)
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
-    else if (ctx->fastOk)
+    else if (ctx->fastOk) {
         if (ctx->svHost.haveAlpha) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
-    else
+        if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    } else
         LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     return 0;
 }
