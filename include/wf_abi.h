@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 2
+#define WF_ABI_VERSION 3
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -164,7 +164,7 @@ typedef struct wf_light {
     int32_t flags;               /* bit0 twoSided (area), bit1 delta-position via zero alpha */
     int32_t spectrum_offset;     /* DenselySampledSpectrum (471 floats) in spectrum_data */
     float scale;
-    int32_t tri;                 /* DIFFUSE_AREA: global triangle id */
+    int32_t tri;                 /* DIFFUSE_AREA: global primitive id (triangle, or n_triangles + sphere index) */
     float area;                  /* DIFFUSE_AREA: shape.Area() */
     int32_t bit_trail;           /* BVH light sampler: lightToBitTrail value, -1 if not in light BVH */
     int32_t infinite_index;      /* index in infinite_lights, or -1 */
@@ -242,6 +242,16 @@ typedef struct wf_mesh {
 #define WF_MESH_HAS_UV 2
 #define WF_MESH_FLIP_NORMAL 4    /* reverseOrientation ^ transformSwapsHandedness */
 #define WF_MESH_HAS_MEDIUM_INTERFACE 8
+#define WF_MESH_REVERSE_ORIENTATION 16  /* the shape's own reverseOrientation (Sphere::Sample flips by it alone, shapes.h:274) */
+
+/* Sphere (shapes.h:107-383), kept in object space like the reference's: primitive id n_triangles + index.  Its
+ * material / area light / media / orientation live in a wf_mesh entry with ntris = 0 and first_tri = that id. */
+typedef struct wf_sphere {
+    float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;
+    int32_t mesh;
+    int32_t pad;
+    wf_transform render_from_object;   /* m = renderFromObject, mInv = objectFromRender */
+} wf_sphere;
 
 enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1 };
 typedef struct wf_camera {
@@ -307,10 +317,10 @@ typedef struct wf_scene_desc {
     const float *N;              /* [n_vertices][3] (zero for meshes without normals) */
     const float *UV;             /* [n_vertices][2] */
     const int32_t *tri_indices;  /* [n_triangles][3] global vertex ids */
-    const int32_t *tri_mesh;     /* [n_triangles] mesh id */
+    const int32_t *tri_mesh;     /* [n_triangles + n_spheres] mesh id of every primitive */
     const wf_mesh *meshes;
     const wf_bvh_node *bvh_nodes;
-    const int32_t *bvh_prims;    /* [n_triangles] triangle ids in BVH leaf order */
+    const int32_t *bvh_prims;    /* [n_triangles + n_spheres] primitive ids in BVH leaf order */
     float scene_bounds[6];
     /* shading */
     int32_t n_spectra, n_spectrum_floats, n_textures, n_materials;
@@ -352,6 +362,9 @@ typedef struct wf_scene_desc {
     int32_t n_media, n_medium_floats;
     const struct wf_medium *media;
     const float *medium_data;    /* density / Lescale / majorant grids */
+    /* quadrics */
+    int32_t n_spheres, pad_spheres;
+    const wf_sphere *spheres;
 } wf_scene_desc;
 
 /* ------------------------------------------------------------------------------------------- */

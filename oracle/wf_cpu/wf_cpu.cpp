@@ -81,6 +81,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     for (int i = 0; i < d.n_materials; ++i)
         if (d.materials[i].displacement >= 0 || d.materials[i].normalmap >= 0) sv.texNeedsFootprint = 1;
     sv.matTypeMask = 0;
+    sv.spheres = d.spheres; sv.nSpheres = d.n_spheres;
     sv.haveMix = 0;
     for (int i = 0; i < d.n_materials; ++i) {
         if (d.materials[i].type == WF_MAT_MIX) sv.haveMix = 1;

@@ -432,9 +432,6 @@ WF_HD float HenyeyGreenstein(float cosTheta, float g) {
     float denom = 1 + Sqr(g) + 2 * g * cosTheta;
     return Inv4Pi * (1 - Sqr(g)) / (denom * SafeSqrt(denom));
 }
-WF_HD V3 SphericalDirection(float sinTheta, float cosTheta, float phi) {
-    return V3{Clamp(sinTheta, -1.f, 1.f) * cos(phi), Clamp(sinTheta, -1.f, 1.f) * sin(phi), Clamp(cosTheta, -1.f, 1.f)};
-}
 WF_HD V3 SampleHenyeyGreenstein(V3 wo, float g, V2 u, float *pdf) {
     g = ClampG(g);
     float cosTheta;

@@ -307,7 +307,7 @@ WF_HD int SurfaceMedium(const wf_mesh &mesh, N3 n, V3 w, int rayMedium) {
 WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, float b0, float b1, float b2, V3 wo) {
     if (sv.materials[matId].type != WF_MAT_MIX) return matId;
     SurfIntr si;
-    TriangleInteraction(sv, prim, b0, b1, b2, &si);
+    HitInteraction(sv, prim, b0, b1, b2, &si);
     TexCtx tc;
     tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
     while (sv.materials[matId].type == WF_MAT_MIX) {
@@ -335,7 +335,7 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
         const RayQueueV &q = ws.rq[cur];
         const RayQueueV &nq = ws.rq[cur ^ 1];
         SurfIntr si;
-        TriangleInteraction(sv, prim, b0, b1, b2, &si);
+        HitInteraction(sv, prim, b0, b1, b2, &si);
         F4 o = q.o[i], d = q.d[i];
         V3 rd{d.x, d.y, d.z};
         V3 no = OffsetRayOrigin(si.pi, si.n, rd);
@@ -464,7 +464,7 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             const RayQueueV &q = ws.rq[cur];
             const RayQueueV &nq = ws.rq[cur ^ 1];
             SurfIntr si;
-            TriangleInteraction(sv, prim, b0, b1, b2, &si);
+            HitInteraction(sv, prim, b0, b1, b2, &si);
             F4 o = q.o[i], d = q.d[i];
             V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
             nq.o[slot] = F4{no.x, no.y, no.z, o.w};
@@ -652,7 +652,7 @@ WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, 
         SurfIntr si;
         bool opaque = false;
         if (hit) {
-            TriangleInteraction(sv, prim, b0, b1, b2, &si);
+            HitInteraction(sv, prim, b0, b1, b2, &si);
             opaque = sv.meshes[si.mesh].material >= 0;
         }
         if (opaque) {
@@ -738,7 +738,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     F4 h = ws.hit[i];
     int prim = (int)FloatToBits(h.x);
     SurfIntr si;
-    TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
+    HitInteraction(sv, prim, h.y, h.z, h.w, &si);
     const wf_mesh &mesh = sv.meshes[si.mesh];
     int lightId = mesh.first_light + (prim - mesh.first_tri);
     const wf_light &light = sv.lights[lightId];
@@ -746,7 +746,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     // intr.wo is normalised by the Interaction ctor (interaction.h:40-43); items that went through the medium
     // stage carry -ray.d as it is (media.cpp:206-208)
     V3 wo{-d4.x, -d4.y, -d4.z};
-    if (!(sv.haveMedia && m.w >= 0)) wo = Normalize(wo);
+    if (!(sv.haveMedia && m.w >= 0)) wo = IntrWo(sv, prim, wo);
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
     S4 Le = AreaLightL(sv, light, si.n, wo, lambda);
     if (!Le) return;
@@ -828,7 +828,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         F4 h = ws.hit[i];
         int prim = (int)FloatToBits(h.x);
         SurfIntr si;
-        TriangleInteraction(sv, prim, h.y, h.z, h.w, &si);
+        HitInteraction(sv, prim, h.y, h.z, h.w, &si);
         const wf_mesh &mesh = sv.meshes[si.mesh];
         int matId = mesh.material;
         if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) matId = ws.mixMat[i];
@@ -839,7 +839,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         // intr.wo: the Interaction constructor normalises it (interaction.h:40-43), also for unit-length ray.d;
         // items enqueued by the medium stage carry -ray.d as it is (media.cpp:240)
         V3 wo{-d4.x, -d4.y, -d4.z};
-        if (!(sv.haveMedia && meta.w >= 0)) wo = Normalize(wo);
+        if (!(sv.haveMedia && meta.w >= 0)) wo = IntrWo(sv, prim, wo);
         // differentials of position and (u, v) at the intersection (surfscatter.cpp:73-104)
         TexCtx tc;
         tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;

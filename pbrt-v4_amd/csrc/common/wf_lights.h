@@ -31,12 +31,6 @@ WF_HD float SmoothStep(float x, float a, float b) {
     float t = Clamp((x - a) / (b - a), 0.f, 1.f);
     return t * t * (3 - 2 * t);
 }
-WF_HD V3 SampleUniformSphere(V2 u) {
-    float z = 1 - 2 * u.x;
-    float r = SafeSqrt(1 - Sqr(z));
-    float phi = 2 * Pi * u.y;
-    return {r * cos(phi), r * sin(phi), z};
-}
 
 // DiffuseAreaLight::L, lights.h:441-463 (no alpha, no image)
 WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, N3 n, V3 w, const Wavelengths &lambda) {
@@ -98,7 +92,7 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
     ls.valid = false;
     switch (l.type) {
     case WF_LIGHT_DIFFUSE_AREA: {
-        ShapeSampleR ss = TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
+        ShapeSampleR ss = l.tri >= sv.nTriangles ? SphereSample(sv, l.tri, ctx.pi, ctx.n, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
         if (!ss.valid || ss.pdf == 0 || LengthSquared(ss.pi.mid() - ctx.p()) == 0) return ls;
         V3 wi = Normalize(ss.pi.mid() - ctx.p());
         S4 Le = AreaLightL(sv, l, ss.n, -wi, lambda);
@@ -162,7 +156,8 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
 
 WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V3 wi, bool allowIncompletePDF) {
     switch (l.type) {
-    case WF_LIGHT_DIFFUSE_AREA: return TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
+    case WF_LIGHT_DIFFUSE_AREA:
+        return l.tri >= sv.nTriangles ? SpherePDF(sv, l.tri, ctx.pi, ctx.n, wi) : TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
     case WF_LIGHT_UNIFORM_INFINITE: return allowIncompletePDF ? 0.f : Inv4Pi;
     case WF_LIGHT_IMAGE_INFINITE: {
         // lights.cpp:1042-1052

@@ -341,6 +341,64 @@ WF_HD P3i MakeP3i(V3 p, V3 e) {
 }
 WF_HD P3i MakeP3i(V3 p) { return P3i{p, p}; }
 
+WF_HD V3 SampleUniformSphere(V2 u) {
+    float z = 1 - 2 * u.x;
+    float r = SafeSqrt(1 - Sqr(z));
+    float phi = 2 * Pi * u.y;
+    return {r * cos(phi), r * sin(phi), z};
+}
+WF_HD V3 SphericalDirection(float sinTheta, float cosTheta, float phi) {
+    return V3{Clamp(sinTheta, -1.f, 1.f) * cos(phi), Clamp(sinTheta, -1.f, 1.f) * sin(phi), Clamp(cosTheta, -1.f, 1.f)};
+}
+
+// Interval (util/math.h:818-1130) with the HOST rounding branch of util/float.h:204-305 (NextFloatUp/Down of the
+// rounded-to-nearest result) on both sides, so the quadric tests decide exactly as the reference's CPU build does.
+struct Ivl {
+    float lo, hi;
+    WF_HD Ivl() : lo(0), hi(0) {}
+    WF_HD explicit Ivl(float v) : lo(v), hi(v) {}
+    WF_HD Ivl(float a, float b) : lo(b < a ? b : a), hi(a < b ? b : a) {}  // std::min / std::max of the two
+    WF_HD static Ivl FromValueAndError(float v, float e) {
+        Ivl i;
+        IntervalFromValueAndError(v, e, &i.lo, &i.hi);
+        return i;
+    }
+    WF_HD float mid() const { return (lo + hi) / 2; }
+    WF_HD bool contains0() const { return 0 >= lo && 0 <= hi; }
+    WF_HD bool operator==(Ivl o) const { return lo == o.lo && hi == o.hi; }
+    WF_HD Ivl operator-() const { return Ivl(-hi, -lo); }
+    WF_HD Ivl operator+(Ivl i) const { return Ivl(NextFloatDown(lo + i.lo), NextFloatUp(hi + i.hi)); }
+    WF_HD Ivl operator-(Ivl i) const { return Ivl(NextFloatDown(lo + -i.hi), NextFloatUp(hi + -i.lo)); }
+    WF_HD static float Min4(float a, float b, float c, float d) { float m = a; if (b < m) m = b; if (c < m) m = c; if (d < m) m = d; return m; }
+    WF_HD static float Max4(float a, float b, float c, float d) { float m = a; if (m < b) m = b; if (m < c) m = c; if (m < d) m = d; return m; }
+    WF_HD Ivl operator*(Ivl i) const {
+        float p0 = lo * i.lo, p1 = hi * i.lo, p2 = lo * i.hi, p3 = hi * i.hi;
+        return Ivl(Min4(NextFloatDown(p0), NextFloatDown(p1), NextFloatDown(p2), NextFloatDown(p3)),
+                   Max4(NextFloatUp(p0), NextFloatUp(p1), NextFloatUp(p2), NextFloatUp(p3)));
+    }
+    WF_HD Ivl operator/(Ivl i) const {
+        if (i.contains0()) return Ivl(-WF_INFINITY, WF_INFINITY);
+        float q0 = lo / i.lo, q1 = hi / i.lo, q2 = lo / i.hi, q3 = hi / i.hi;
+        return Ivl(Min4(NextFloatDown(q0), NextFloatDown(q1), NextFloatDown(q2), NextFloatDown(q3)),
+                   Max4(NextFloatUp(q0), NextFloatUp(q1), NextFloatUp(q2), NextFloatUp(q3)));
+    }
+};
+WF_HD Ivl operator*(float f, Ivl i) {
+    if (f > 0) return Ivl(NextFloatDown(f * i.lo), NextFloatUp(f * i.hi));
+    return Ivl(NextFloatDown(f * i.hi), NextFloatUp(f * i.lo));
+}
+WF_HD Ivl Sqr(Ivl i) {
+    float alow = abs(i.lo), ahigh = abs(i.hi);
+    if (alow > ahigh) { float t = alow; alow = ahigh; ahigh = t; }
+    if (i.contains0()) return Ivl(0, NextFloatUp(ahigh * ahigh));
+    return Ivl(NextFloatDown(alow * alow), NextFloatUp(ahigh * ahigh));
+}
+WF_HD Ivl Sqrt(Ivl i) {
+    float l = NextFloatDown(sqrt(i.lo));
+    return Ivl(0 < l ? l : 0.f, NextFloatUp(sqrt(i.hi)));  // SqrtRoundDown clamps at 0 (std::max<Float>(0, .))
+}
+struct Ivl3 { Ivl x, y, z; };
+
 // ray.h:75-113
 WF_HD V3 OffsetRayOrigin(const P3i &pi, N3 n, V3 w) {
     float d = Dot(Abs(n), pi.err());

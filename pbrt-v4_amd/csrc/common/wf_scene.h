@@ -53,6 +53,8 @@ struct SceneView {
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
     int texNeedsFootprint;  // some texture's value depends on the TextureEvalContext (checkerboard, image) or some material
                             // is bump- or normal-mapped: selects the material-kernel variant that computes the differentials
+    const wf_sphere *spheres;
+    int nSpheres;
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
     int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
     wf_options options;

@@ -122,6 +122,117 @@ WF_HD void TriVerts(const SceneView &sv, int tri, V3 *p0, V3 *p1, V3 *p2) {
     *p0 = LoadP(sv, v[0]); *p1 = LoadP(sv, v[1]); *p2 = LoadP(sv, v[2]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sphere (shapes.h:107-383).  The quadric test runs in object space on intervals, as the reference's.
+// Transform::operator()(Point3fi) for an exact point and Transform::operator()(Vector3fi) for an exact vector
+// (util/transform.h:133-176, 272-306); affine transforms only (w' == 1, checked at load).
+WF_HD Ivl3 XfPointExactI(const float m[4][4], V3 p) {
+    float x = p.x, y = p.y, z = p.z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    float ex = gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z) + abs(m[0][3]));
+    float ey = gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z) + abs(m[1][3]));
+    float ez = gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z) + abs(m[2][3]));
+    return Ivl3{Ivl::FromValueAndError(xp, ex), Ivl::FromValueAndError(yp, ey), Ivl::FromValueAndError(zp, ez)};
+}
+WF_HD Ivl3 XfVectorExactI(const float m[4][4], V3 v) {
+    float x = v.x, y = v.y, z = v.z;
+    float ex = gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z));
+    float ey = gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z));
+    float ez = gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z));
+    float xp = m[0][0] * x + m[0][1] * y + m[0][2] * z;
+    float yp = m[1][0] * x + m[1][1] * y + m[1][2] * z;
+    float zp = m[2][0] * x + m[2][1] * y + m[2][2] * z;
+    return Ivl3{Ivl::FromValueAndError(xp, ex), Ivl::FromValueAndError(yp, ey), Ivl::FromValueAndError(zp, ez)};
+}
+// Transform::operator()(Point3fi) for a point with error bounds (util/transform.h:152-170)
+WF_HD P3i XfPointI(const float m[4][4], V3 pIn, V3 eIn) {
+    // Point3fi(p, e) first: the transform then sees the interval's midpoint and half width, not p and e themselves
+    const P3i in = MakeP3i(pIn, eIn);
+    if (in.exact()) {
+        Ivl3 r = XfPointExactI(m, pIn);
+        return P3i{V3{r.x.lo, r.y.lo, r.z.lo}, V3{r.x.hi, r.y.hi, r.z.hi}};
+    }
+    const V3 p = in.mid(), e = in.err();
+    float x = p.x, y = p.y, z = p.z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    V3 pe;
+    pe.x = (gamma(3) + 1) * (abs(m[0][0]) * e.x + abs(m[0][1]) * e.y + abs(m[0][2]) * e.z) +
+           gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z) + abs(m[0][3]));
+    pe.y = (gamma(3) + 1) * (abs(m[1][0]) * e.x + abs(m[1][1]) * e.y + abs(m[1][2]) * e.z) +
+           gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z) + abs(m[1][3]));
+    pe.z = (gamma(3) + 1) * (abs(m[2][0]) * e.x + abs(m[2][1]) * e.y + abs(m[2][2]) * e.z) +
+           gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z) + abs(m[2][3]));
+    return MakeP3i(V3{xp, yp, zp}, pe);
+}
+WF_HD V3 XfPoint3(const float m[4][4], V3 p) {  // Transform::operator()(Point3f), affine
+    return V3{m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3], m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3],
+              m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3]};
+}
+WF_HD V3 XfVector3(const float m[4][4], V3 v) {
+    return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
+              m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
+}
+WF_HD N3 XfNormal3(const float mInv[4][4], N3 n) {
+    return N3{mInv[0][0] * n.x + mInv[1][0] * n.y + mInv[2][0] * n.z, mInv[0][1] * n.x + mInv[1][1] * n.y + mInv[2][1] * n.z,
+              mInv[0][2] * n.x + mInv[1][2] * n.y + mInv[2][2] * n.z};
+}
+
+struct QuadricHit { float tHit; V3 pObj; float phi; };
+// Sphere::BasicIntersect, shapes.h:147-233
+WF_HD bool SphereBasicIntersect(const wf_sphere &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    const float radius = s.radius;
+    Ivl3 oi = XfPointExactI(s.render_from_object.mInv, ro);
+    Ivl3 di = XfVectorExactI(s.render_from_object.mInv, rd);
+    Ivl a = Sqr(di.x) + Sqr(di.y) + Sqr(di.z);
+    Ivl b = 2.f * (di.x * oi.x + di.y * oi.y + di.z * oi.z);
+    Ivl c = Sqr(oi.x) + Sqr(oi.y) + Sqr(oi.z) - Sqr(Ivl(radius));
+    Ivl k = b / (2.f * a);
+    Ivl vx = oi.x - k * di.x, vy = oi.y - k * di.y, vz = oi.z - k * di.z;
+    Ivl length = Sqrt(Sqr(vx) + Sqr(vy) + Sqr(vz));
+    Ivl discrim = 4.f * a * (Ivl(radius) + length) * (Ivl(radius) - length);
+    if (discrim.lo < 0) return false;
+    Ivl rootDiscrim = Sqrt(discrim);
+    Ivl q;
+    if (b.mid() < 0) q = -.5f * (b - rootDiscrim);
+    else q = -.5f * (b + rootDiscrim);
+    Ivl t0 = q / a;
+    Ivl t1 = c / q;
+    if (t0.lo > t1.lo) { Ivl t = t0; t0 = t1; t1 = t; }
+    if (t0.hi > tMax || t1.lo <= 0) return false;
+    Ivl tShapeHit = t0;
+    if (tShapeHit.lo <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit.hi > tMax) return false;
+    }
+    const V3 om{oi.x.mid(), oi.y.mid(), oi.z.mid()}, dm{di.x.mid(), di.y.mid(), di.z.mid()};
+    V3 pHit;
+    float phi;
+    auto hitPoint = [&]() {
+        pHit = om + tShapeHit.mid() * dm;
+        pHit = pHit * (radius / Length(pHit));
+        if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+        phi = atan2(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * Pi;
+    };
+    hitPoint();
+    auto clipped = [&]() { return (s.z_min > -radius && pHit.z < s.z_min) || (s.z_max < radius && pHit.z > s.z_max) || phi > s.phi_max; };
+    if (clipped()) {
+        if (tShapeHit == t1) return false;
+        if (t1.hi > tMax) return false;
+        tShapeHit = t1;
+        hitPoint();
+        if (clipped()) return false;
+    }
+    out->tHit = tShapeHit.mid();
+    out->pObj = pHit;
+    out->phi = phi;
+    return true;
+}
+
 // GeometricPrimitive::Intersect's stochastic alpha test (cpu/primitive.cpp:57-72; IntersectP goes through Intersect,
 // :79-84).  A triangle cannot be hit again by the ray respawned behind it, so a failed test simply drops the hit.
 // The texture sees TextureEvalContext(SurfaceInteraction) with all differentials zero (interaction.h: set only by
@@ -159,10 +270,20 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
             if (node->nprims > 0) {
                 for (int i = 0; i < node->nprims; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
+                    ++out->trisTested;
+                    if (tri >= sv.nTriangles) {
+                        // a sphere: the hit record carries pObj in place of the barycentrics
+                        QuadricHit qh;
+                        if (SphereBasicIntersect(sv.spheres[tri - sv.nTriangles], o, d, tMax, &qh)) {
+                            out->prim = tri;
+                            out->h.t = qh.tHit; out->h.b0 = qh.pObj.x; out->h.b1 = qh.pObj.y; out->h.b2 = qh.pObj.z;
+                            tMax = qh.tHit;
+                        }
+                        continue;
+                    }
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
-                    ++out->trisTested;
                     if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h) && (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d))) {
                         out->prim = tri;
                         out->h = h;
@@ -202,10 +323,15 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
             if (node->nprims > 0) {
                 for (int i = 0; i < node->nprims && !found; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
+                    ++nt;
+                    if (tri >= sv.nTriangles) {
+                        QuadricHit qh;
+                        if (SphereBasicIntersect(sv.spheres[tri - sv.nTriangles], o, d, tMax, &qh)) found = true;
+                        continue;
+                    }
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
-                    ++nt;
                     if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h) && (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d))) found = true;
                 }
                 if (found || stack.empty()) break;
@@ -458,6 +584,165 @@ WF_HD float TrianglePDF(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxN,
         pdf *= BilinearPDF(u, w);
     }
     return pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sphere::InteractionFromIntersection (shapes.h:241-289) + the SurfaceInteraction ctor (interaction.h:164-183) +
+// Transform::operator()(SurfaceInteraction) (util/transform.cpp:229-261)
+WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *si) {
+    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
+    const wf_mesh &mesh = sv.meshes[s.mesh];
+    const float radius = s.radius, phiMax = s.phi_max, thetaZMin = s.theta_z_min, thetaZMax = s.theta_z_max;
+    float phi = atan2(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * Pi;
+    float u = phi / phiMax;
+    float cosTheta = pHit.z / radius;
+    float theta = SafeACos(cosTheta);
+    float v = (theta - thetaZMin) / (thetaZMax - thetaZMin);
+    float zRadius = sqrt(Sqr(pHit.x) + Sqr(pHit.y));
+    float cosPhi = pHit.x / zRadius, sinPhi = pHit.y / zRadius;
+    V3 dpdu{-phiMax * pHit.y, phiMax * pHit.x, 0};
+    float sinTheta = SafeSqrt(1 - Sqr(cosTheta));
+    V3 dpdv = (thetaZMax - thetaZMin) * V3{pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinTheta};
+    V3 d2Pduu = -phiMax * phiMax * V3{pHit.x, pHit.y, 0};
+    V3 d2Pduv = (thetaZMax - thetaZMin) * pHit.z * phiMax * V3{-sinPhi, cosPhi, 0.f};
+    V3 d2Pdvv = -Sqr(thetaZMax - thetaZMin) * V3{pHit.x, pHit.y, pHit.z};
+    float E = Dot(dpdu, dpdu), F = Dot(dpdu, dpdv), G = Dot(dpdv, dpdv);
+    V3 n = Normalize(Cross(dpdu, dpdv));
+    float e = Dot(n, d2Pduu), f = Dot(n, d2Pduv), g = Dot(n, d2Pdvv);
+    float EGF2 = DifferenceOfProducts(E, G, F, F);
+    float invEGF2 = (EGF2 == 0) ? 0.f : 1 / EGF2;
+    N3 dndu = toN((f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv);
+    N3 dndv = toN((g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv);
+    V3 pError = gamma(5) * Abs(pHit);
+    bool flipNormal = (mesh.flags & WF_MESH_FLIP_NORMAL) != 0;
+    N3 nObj = toN(n);
+    if (flipNormal) nObj = -nObj;
+    const float(*m)[4] = s.render_from_object.m;
+    const float(*mi)[4] = s.render_from_object.mInv;
+    si->pi = XfPointI(m, pHit, pError);
+    si->n = Normalize(XfNormal3(mi, nObj));
+    si->uv = V2{u, v};
+    si->dpdu = XfVector3(m, dpdu);
+    si->dpdv = XfVector3(m, dpdv);
+    si->dndu = XfNormal3(mi, dndu);
+    si->dndv = XfNormal3(mi, dndv);
+    si->ns = FaceForward(Normalize(XfNormal3(mi, nObj)), si->n);
+    si->dpdus = si->dpdu;
+    si->dpdvs = si->dpdv;
+    si->dndus = si->dndu;
+    si->dndvs = si->dndv;
+    si->mesh = s.mesh;
+}
+// intr.wo: the Interaction ctor normalises -ray.d (interaction.h:40-43); a quadric builds its interaction in object
+// space and transforms it back, so its wo is normalised there and again after the transform (shapes.h:286-288,
+// util/transform.cpp:235)
+WF_HD V3 IntrWo(const SceneView &sv, int prim, V3 minusD) {
+    if (prim < sv.nTriangles) return Normalize(minusD);
+    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
+    return Normalize(XfVector3(s.render_from_object.m, Normalize(XfVector3(s.render_from_object.mInv, minusD))));
+}
+// the SurfaceInteraction of a hit record (prim, three floats): barycentrics for a triangle, pObj for a sphere
+WF_HD void HitInteraction(const SceneView &sv, int prim, float b0, float b1, float b2, SurfIntr *si) {
+    if (prim >= sv.nTriangles) SphereInteraction(sv, prim, V3{b0, b1, b2}, si);
+    else TriangleInteraction(sv, prim, b0, b1, b2, si);
+}
+
+// Sphere::Sample(Point2f u), shapes.cpp:38-58
+WF_HD ShapeSampleR SphereSampleArea(const SceneView &sv, const wf_sphere &s, V2 u) {
+    const wf_mesh &mesh = sv.meshes[s.mesh];
+    ShapeSampleR r;
+    V3 pObj = s.radius * SampleUniformSphere(u);
+    pObj = pObj * (s.radius / Length(pObj));
+    V3 pObjError = gamma(5) * Abs(pObj);
+    N3 n = Normalize(XfNormal3(s.render_from_object.mInv, N3{pObj.x, pObj.y, pObj.z}));
+    if (mesh.flags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
+    float theta = SafeACos(pObj.z / s.radius);
+    float phi = atan2(pObj.y, pObj.x);
+    if (phi < 0) phi += 2 * Pi;
+    r.uv = V2{phi / s.phi_max, (theta - s.theta_z_min) / (s.theta_z_max - s.theta_z_min)};
+    r.pi = XfPointI(s.render_from_object.m, pObj, pObjError);
+    r.n = n;
+    r.pdf = 1 / (s.phi_max * s.radius * (s.z_max - s.z_min));
+    r.valid = true;
+    return r;
+}
+// Sphere::Sample(const ShapeSampleContext &, Point2f), shapes.h:300-372
+WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V2 u) {
+    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
+    const wf_mesh &mesh = sv.meshes[s.mesh];
+    const float radius = s.radius;
+    ShapeSampleR r;
+    r.valid = false;
+    r.pdf = 0;
+    V3 pCenter = XfPoint3(s.render_from_object.m, V3{0, 0, 0});
+    V3 rp = ctxPi.mid();
+    V3 pOrigin = OffsetRayOrigin(ctxPi, ctxN, pCenter - rp);
+    if (DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
+        r = SphereSampleArea(sv, s, u);
+        r.valid = false;
+        V3 wi = r.pi.mid() - rp;
+        if (LengthSquared(wi) == 0) return r;
+        wi = Normalize(wi);
+        r.pdf /= AbsDot(r.n, -wi) / DistanceSquared(rp, r.pi.mid());
+        if (IsInf(r.pdf)) return r;
+        r.valid = true;
+        return r;
+    }
+    float sinThetaMax = radius / Distance(rp, pCenter);
+    float sin2ThetaMax = Sqr(sinThetaMax);
+    float cosThetaMax = SafeSqrt(1 - sin2ThetaMax);
+    float oneMinusCosThetaMax = 1 - cosThetaMax;
+    float cosTheta = (cosThetaMax - 1) * u.x + 1;
+    float sin2Theta = 1 - Sqr(cosTheta);
+    if (sin2ThetaMax < 0.00068523f /* sin^2(1.5 deg) */) {
+        sin2Theta = sin2ThetaMax * u.x;
+        cosTheta = sqrt(1 - sin2Theta);
+        oneMinusCosThetaMax = sin2ThetaMax / 2;
+    }
+    float cosAlpha = sin2Theta / sinThetaMax + cosTheta * SafeSqrt(1 - sin2Theta / Sqr(sinThetaMax));
+    float sinAlpha = SafeSqrt(1 - Sqr(cosAlpha));
+    float phi = u.y * 2 * Pi;
+    V3 w = SphericalDirection(sinAlpha, cosAlpha, phi);
+    Frame samplingFrame = Frame::FromZ(Normalize(pCenter - rp));
+    N3 n = toN(samplingFrame.FromLocal(-w));
+    V3 p = pCenter + radius * V3{n.x, n.y, n.z};
+    if (mesh.flags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
+    V3 pError = gamma(5) * Abs(p);
+    V3 pObj = XfPoint3(s.render_from_object.mInv, p);
+    float theta = SafeACos(pObj.z / radius);
+    float spherePhi = atan2(pObj.y, pObj.x);
+    if (spherePhi < 0) spherePhi += 2 * Pi;
+    r.uv = V2{spherePhi / s.phi_max, (theta - s.theta_z_min) / (s.theta_z_max - s.theta_z_min)};
+    r.pi = MakeP3i(p, pError);
+    r.n = n;
+    r.pdf = 1 / (2 * Pi * oneMinusCosThetaMax);
+    r.valid = true;
+    return r;
+}
+// Sphere::PDF(const ShapeSampleContext &, Vector3f wi), shapes.h:374-405
+WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V3 wi) {
+    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
+    const float radius = s.radius;
+    V3 pCenter = XfPoint3(s.render_from_object.m, V3{0, 0, 0});
+    V3 rp = ctxPi.mid();
+    V3 pOrigin = OffsetRayOrigin(ctxPi, ctxN, pCenter - rp);
+    if (DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
+        V3 o = OffsetRayOrigin(ctxPi, ctxN, wi);
+        QuadricHit qh;
+        if (!SphereBasicIntersect(s, o, wi, WF_INFINITY, &qh)) return 0;
+        SurfIntr si;
+        SphereInteraction(sv, prim, qh.pObj, &si);
+        float area = s.phi_max * radius * (s.z_max - s.z_min);
+        float pdf = (1 / area) / (AbsDot(si.n, -wi) / DistanceSquared(rp, si.pi.mid()));
+        if (IsInf(pdf)) pdf = 0;
+        return pdf;
+    }
+    float sin2ThetaMax = radius * radius / DistanceSquared(rp, pCenter);
+    float cosThetaMax = SafeSqrt(1 - sin2ThetaMax);
+    float oneMinusCosThetaMax = 1 - cosThetaMax;
+    if (sin2ThetaMax < 0.00068523f /* sin^2(1.5 deg) */) oneMinusCosThetaMax = sin2ThetaMax / 2;
+    return 1 / (2 * Pi * oneMinusCosThetaMax);
 }
 
 }  // namespace wf

@@ -231,6 +231,13 @@ __device__ inline void LoadTreeTop(const FastBVH &bvh) {
 // atomic).  Waves walk independently ("while-while": all lanes descend interior nodes until every one of
 // them sits at a leaf or is done, then the leaves are processed together); `finish` runs once per batch for
 // the whole workgroup, so its queue pushes are block-aggregated (BlockAlloc).
+// what the general-primitive traversal variants call back into (wf_traverse.h LeafStep): the alpha test and the spheres
+struct GeneralPrims {
+    const SceneView &sv;
+    V3 o, d;
+    __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
+    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return SphereBasicIntersect(sv.spheres[prim - sv.nTriangles], o, d, tMax, qh); }
+};
 template <bool ANY, bool ALPHA, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
     LoadTreeTop(bvh);
@@ -270,8 +277,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                 }
             }
             if (w.node != NODE_NONE) {
-                if constexpr (ALPHA)
-                    LeafStep<ANY, true>(bvh, w, st, [&](int prim, float b0, float b1, float b2) { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); });
+                if constexpr (ALPHA) LeafStep<ANY, true>(bvh, w, st, GeneralPrims{sv, o, d});
                 else LeafStep<ANY>(bvh, w, st);
             }
         }
@@ -387,8 +393,7 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
                         a = p[0]; b = p[1];
                     }
                     InteriorStep(w, st, a, b);
-                } else if constexpr (ALPHA)
-                    LeafStep<false, true>(bvh, w, st, [&](int pr, float c0, float c1, float c2) { return AlphaTestPasses(sv, pr, c0, c1, c2, o, d); });
+                } else if constexpr (ALPHA) LeafStep<false, true>(bvh, w, st, GeneralPrims{sv, o, d});
                 else LeafStep<false>(bvh, w, st);
             }
             if (w.prim >= 0) { *prim = w.prim; *b0 = w.b0; *b1 = w.b1; *b2 = w.b2; }
@@ -510,12 +515,24 @@ static int checkReady(wf_ctx *ctx) {
 static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, FastBVH *out) {
     const wf_bvh_node *L = d->bvh_nodes;
     const int n = d->n_bvh_nodes;
-    if (n == 0 || (size_t)d->n_triangles >= (1u << 27)) return false;
+    const int nPrims = d->n_triangles + d->n_spheres;
+    if (n == 0 || (size_t)nPrims >= (1u << 27)) return false;
     for (int i = 0; i < n; ++i)
         if (L[i].nprims > 16) return false;
-    tris->resize((size_t)d->n_triangles);
-    for (int k = 0; k < d->n_triangles; ++k) {
+    tris->resize((size_t)nPrims);
+    for (int k = 0; k < nPrims; ++k) {
         int t = d->bvh_prims[k];
+        if (t >= d->n_triangles) {
+            // a sphere: c.z == 3, tested by the general-primitive kernel variants from wf_sphere (object space)
+            const wf_mesh &mesh = d->meshes[d->tri_mesh[t]];
+            uint32_t route = mesh.material >= 0 ? (uint32_t)d->materials[mesh.material].type | (mesh.first_light >= 0 ? 16u : 0u) : 32u;
+            LeafTri lt;
+            lt.a = F4{0, 0, 0, 0};
+            lt.b = F4{0, 0, 0, 0};
+            lt.c = F4{0, BitsToFloat((uint32_t)t), 3.f, BitsToFloat(route)};
+            (*tris)[k] = lt;
+            continue;
+        }
         const int32_t *v = d->tri_indices + 3 * (size_t)t;
         const float *p0 = d->P + 3 * (size_t)v[0], *p1 = d->P + 3 * (size_t)v[1], *p2 = d->P + 3 * (size_t)v[2];
         LeafTri lt;
@@ -663,10 +680,12 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.N, d->N, (size_t)3 * d->n_vertices))) return e;
     if ((e = devUpload(ctx, &sv.UV, d->UV, (size_t)2 * d->n_vertices))) return e;
     if ((e = devUpload(ctx, &sv.triIndices, d->tri_indices, (size_t)3 * d->n_triangles))) return e;
-    if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles))) return e;
+    if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles + d->n_spheres))) return e;
+    if ((e = devUpload(ctx, &sv.spheres, d->spheres, (size_t)d->n_spheres))) return e;
+    sv.nSpheres = d->n_spheres;
     if ((e = devUpload(ctx, &sv.meshes, d->meshes, (size_t)d->n_meshes))) return e;
     if ((e = devUpload(ctx, &sv.bvhNodes, d->bvh_nodes, (size_t)d->n_bvh_nodes))) return e;
-    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles))) return e;
+    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles + d->n_spheres))) return e;
     sv.nTriangles = d->n_triangles;
     sv.nBvhNodes = d->n_bvh_nodes;
     if ((e = devUpload(ctx, &sv.spectra, d->spectra, (size_t)d->n_spectra))) return e;
@@ -878,7 +897,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     else if (ctx->fastOk) {
-        if (ctx->svHost.haveAlpha) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nSpheres > 0) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
@@ -899,7 +918,7 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
     if (ctx->fastOk && !ctx->countTraversal)
-        if (ctx->svHost.haveAlpha) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nSpheres > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
@@ -945,7 +964,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     else if (ctx->fastOk)
-        if (ctx->svHost.haveAlpha) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nSpheres > 0) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
         else LAUNCHT("Intersect shadow", k_shadow_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);

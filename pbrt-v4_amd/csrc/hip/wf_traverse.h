@@ -150,11 +150,15 @@ __device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
     else w.node = st.empty() ? NODE_NONE : st.pop();
 }
 // Leaf: <= 16 triangle tests.  ANY: stop at the first hit.  Precondition: w.node < 0 && w.node != NODE_NONE.
-// accept(prim, b0, b1, b2): the alpha test of triangles marked c.z == 2 (ALPHA variants only; other variants
-// never see the mark).
-struct AcceptAll { __device__ bool operator()(int, float, float, float) const { return true; } };
-template <bool ANY, bool ALPHA = false, typename Stack, typename Accept = AcceptAll>
-__device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, Accept accept = Accept()) {
+// The general-primitive variants (ALPHA): leaf entries marked c.z == 2 are triangles whose mesh carries an alpha
+// texture (ex.accept(prim, b0, b1, b2) decides), entries marked c.z == 3 are spheres (ex.sphere(prim, tMax, &hit);
+// the hit's pObj travels in b0..b2).  Scenes without either use the plain variants, which never see the marks.
+struct NoExtra {
+    __device__ bool accept(int, float, float, float) const { return true; }
+    __device__ bool sphere(int, float, QuadricHit *) const { return false; }
+};
+template <bool ANY, bool ALPHA = false, typename Stack, typename Extra = NoExtra>
+__device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const Extra &ex = Extra()) {
     unsigned ref = ~(unsigned)w.node;
     int first = (int)(ref >> 4), count = (int)(ref & 15u) + 1;
     bool done = false;
@@ -162,10 +166,22 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, Accep
         const LeafTri *lt = bvh.tris + first + i;
         const F4 ta = lt->a, tb = lt->b, tc = lt->c;
         TriHit h;
+        if constexpr (ALPHA)
+            if (tc.z == 3.f) {
+                QuadricHit qh;
+                if (ex.sphere((int)FloatToBits(tc.y), w.tMax, &qh)) {
+                    w.prim = (int)FloatToBits(tc.y);
+                    w.route = FloatToBits(tc.w);
+                    w.b0 = qh.pObj.x; w.b1 = qh.pObj.y; w.b2 = qh.pObj.z;
+                    w.tMax = qh.tHit;
+                    if (ANY) { done = true; break; }
+                }
+                continue;
+            }
         if ((ALPHA ? tc.z != 1.f : tc.z == 0.f) &&
             IntersectTriangleSheared(w.o, w.sh, w.tMax, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
             if constexpr (ALPHA)
-                if (tc.z == 2.f && !accept((int)FloatToBits(tc.y), h.b0, h.b1, h.b2)) continue;
+                if (tc.z == 2.f && !ex.accept((int)FloatToBits(tc.y), h.b0, h.b1, h.b2)) continue;
             w.prim = (int)FloatToBits(tc.y);
             w.route = FloatToBits(tc.w);
             w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;

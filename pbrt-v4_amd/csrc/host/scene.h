@@ -116,6 +116,7 @@ struct SceneTables {
     std::vector<float> P, N, UV;
     std::vector<int32_t> triIndices, triMesh, bvhPrims, infiniteLights;
     std::vector<wf_mesh> meshes;
+    std::vector<wf_sphere> spheres;
     std::vector<wf_bvh_node> bvhNodes;
     SpectrumPool pool;
     std::vector<wf_texture> textures;
@@ -141,8 +142,10 @@ struct SceneTables {
 void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *out);
 
 // geometry BVH (bvh_build.cpp): SAH build restating BVHAggregate (cpu/aggregates.cpp:140-387,505-521)
-void BuildBVH(const std::vector<float> &P, const std::vector<int32_t> &triIndices, int maxPrimsInNode,
-              std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims);
+// extraPrims: non-triangle primitives as (number of triangles created before it, render-space bounds), in creation
+// order; extra primitive k gets primitive id nTris + k and enters the build where the reference's shape list has it
+void BuildBVH(const std::vector<float> &P, const std::vector<int32_t> &triIndices, const std::vector<std::pair<int, B3>> &extraPrims,
+              int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims);
 // light BVH (lightbvh_build.cpp): BVHLightSampler ctor (lightsamplers.cpp:105-232)
 struct LightBoundsH {
     B3 bounds;

@@ -33,6 +33,7 @@ void SceneTables::Finalize() {
     desc.P = P.data(); desc.N = N.data(); desc.UV = UV.data();
     desc.tri_indices = triIndices.data(); desc.tri_mesh = triMesh.data();
     desc.meshes = meshes.data(); desc.bvh_nodes = bvhNodes.data(); desc.bvh_prims = bvhPrims.data();
+    desc.n_spheres = (int)spheres.size(); desc.spheres = spheres.data();
     desc.n_spectra = (int)pool.spectra.size(); desc.n_spectrum_floats = (int)pool.data.size();
     desc.spectra = pool.spectra.data(); desc.spectrum_data = pool.data.data();
     desc.n_textures = (int)textures.size(); desc.textures = textures.data();
@@ -1069,7 +1070,72 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     struct PendingAreaLight { int mesh; int lightEntity; Transform renderFromObject; };
     std::vector<PendingAreaLight> pendingArea;
     bool anyMediumInterface = false;
+    // the part of a shape that is not geometry: material, alpha, media, area light (scene.cpp:1395-1440)
+    auto commitMesh = [&](wf_mesh &mesh, int meshId, const ShapeEntity &sh, const Transform &rfo, bool instanced) {
+        if (!sh.materialName.empty()) {
+            auto it = namedMaterialIds.find(sh.materialName);
+            if (it == namedMaterialIds.end()) Die(sh.loc, sh.materialName + ": no named material defined.");
+            mesh.material = it->second;
+        } else mesh.material = materialIds.at(sh.materialIndex);
+        if (T->materials[mesh.material].type == WF_MAT_INTERFACE) mesh.material = -1;
+        mesh.first_light = -1;
+        mesh.alpha_tex = -1;
+        // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
+        if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
+        else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
+        if (mesh.alpha_tex >= 0 && sh.lightIndex >= 0) Die(sh.loc, "alpha-masked area lights are not supported by this build yet");
+        if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres are not supported by this build yet");
+        mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
+        mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
+        if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;
+        T->meshes.push_back(mesh);
+        if (sh.lightIndex >= 0 && !instanced) {
+            if (mesh.material < 0) fprintf(stderr, "Warning: %s: Ignoring area light specification for shape with \"interface\" material.\n", sh.loc.c_str());
+            else pendingArea.push_back({meshId, sh.lightIndex, rfo});
+        }
+        sh.params.ReportUnused("Shape");
+    };
+    struct PendingSphere { wf_sphere s; int orderPos; B3 bounds; };
+    std::vector<PendingSphere> spheres;
+    std::map<int, int> sphereOfMesh;
     auto addShape = [&](const ShapeEntity &sh, const Transform *extra) {
+        if (sh.name == "sphere") {
+            // Sphere::Create + ctor (shapes.cpp:71-81, shapes.h:117-129); kept in object space like the reference's
+            if (extra) Die(sh.loc, "spheres inside object instances are not supported by this build yet");
+            const Transform &rfo = sh.renderFromObject;
+            const ParamSet &ps = sh.params;
+            float radius = ps.GetOneFloat("radius", 1.f);
+            float zmin = ps.GetOneFloat("zmin", -radius), zmax = ps.GetOneFloat("zmax", radius), phimax = ps.GetOneFloat("phimax", 360.f);
+            auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
+            PendingSphere p{};
+            p.s.radius = radius;
+            p.s.z_min = clampf(std::min(zmin, zmax), -radius, radius);
+            p.s.z_max = clampf(std::max(zmin, zmax), -radius, radius);
+            p.s.theta_z_min = std::acos(clampf(std::min(zmin, zmax) / radius, -1, 1));
+            p.s.theta_z_max = std::acos(clampf(std::max(zmin, zmax) / radius, -1, 1));
+            p.s.phi_max = Radians(clampf(phimax, 0, 360));
+            p.s.render_from_object = rfo.abi();
+            for (int j = 0; j < 3; ++j)
+                if (rfo.m.m[3][j] != 0 || rfo.m.m[3][3] != 1) Die(sh.loc, "sphere: only affine transformations are supported");
+            // Sphere::Bounds (shapes.cpp:33-36) through Transform::operator()(Bounds3f) (util/transform.cpp:134-139)
+            V3 lo{-radius, -radius, p.s.z_min}, hi{radius, radius, p.s.z_max};
+            for (int c = 0; c < 8; ++c) p.bounds = Union(p.bounds, rfo.Point(V3{(c & 1) ? hi.x : lo.x, (c & 2) ? hi.y : lo.y, (c & 4) ? hi.z : lo.z}));
+            p.orderPos = (int)T->triIndices.size() / 3;
+            wf_mesh mesh{};
+            mesh.first_tri = -1;  // set to the sphere's primitive id once the triangle count is known
+            mesh.ntris = 0;
+            mesh.first_vertex = (int)T->P.size() / 3;
+            mesh.nverts = 0;
+            mesh.flags = 0;
+            if (sh.reverseOrientation ^ rfo.SwapsHandedness()) mesh.flags |= WF_MESH_FLIP_NORMAL;
+            if (sh.reverseOrientation) mesh.flags |= WF_MESH_REVERSE_ORIENTATION;
+            int meshId = (int)T->meshes.size();
+            p.s.mesh = meshId;
+            sphereOfMesh[meshId] = (int)spheres.size();
+            spheres.push_back(p);
+            commitMesh(mesh, meshId, sh, rfo, false);
+            return;
+        }
         MeshSource src;
         if (!LoadShapeGeometry(sh, scene.baseDir, &src)) return;
         Transform rfo = sh.renderFromObject;
@@ -1100,28 +1166,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         int meshId = (int)T->meshes.size();
         for (int vi : src.indices) T->triIndices.push_back(mesh.first_vertex + vi);
         for (int i = 0; i < mesh.ntris; ++i) T->triMesh.push_back(meshId);
-        // material
-        if (!sh.materialName.empty()) {
-            auto it = namedMaterialIds.find(sh.materialName);
-            if (it == namedMaterialIds.end()) Die(sh.loc, sh.materialName + ": no named material defined.");
-            mesh.material = it->second;
-        } else mesh.material = materialIds.at(sh.materialIndex);
-        if (T->materials[mesh.material].type == WF_MAT_INTERFACE) mesh.material = -1;
-        mesh.first_light = -1;
-        mesh.alpha_tex = -1;
-        // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
-        if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
-        else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
-        if (mesh.alpha_tex >= 0 && sh.lightIndex >= 0) Die(sh.loc, "alpha-masked area lights are not supported by this build yet");
-        mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
-        mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
-        if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;
-        T->meshes.push_back(mesh);
-        if (sh.lightIndex >= 0 && !extra) {
-            if (mesh.material < 0) fprintf(stderr, "Warning: %s: Ignoring area light specification for shape with \"interface\" material.\n", sh.loc.c_str());
-            else pendingArea.push_back({meshId, sh.lightIndex, rfo});
-        }
-        sh.params.ReportUnused("Shape");
+        commitMesh(mesh, meshId, sh, rfo, extra != nullptr);
     };
     for (const ShapeEntity &sh : scene.shapes) addShape(sh, nullptr);
     for (const InstanceUse &u : scene.instances) {
@@ -1129,7 +1174,16 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (it == scene.instanceDefinitions.end()) Die("", u.name + ": object instance not defined");
         for (const ShapeEntity &sh : it->second.shapes) addShape(sh, &u.renderFromInstance);
     }
-    if (T->triIndices.empty()) Die("", "scene has no geometry");
+    if (T->triIndices.empty() && spheres.empty()) Die("", "scene has no geometry");
+    // spheres: primitive ids follow the triangles'
+    {
+        const int nTris = (int)T->triIndices.size() / 3;
+        for (size_t i = 0; i < spheres.size(); ++i) {
+            T->meshes[spheres[i].s.mesh].first_tri = nTris + (int)i;
+            T->triMesh.push_back(spheres[i].s.mesh);
+            T->spheres.push_back(spheres[i].s);
+        }
+    }
 
     // ---- lights: area lights first (scene.cpp:1290-1340), then the others ----
     auto triVerts = [&](int tri, V3 *p0, V3 *p1, V3 *p2) {
@@ -1159,6 +1213,35 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         mesh.first_light = (int)T->lights.size();
         int specOff = T->pool.AddDense(*L);
         float LemitMax = MakeDense(*L)->MaxValue();
+        if (auto sit = sphereOfMesh.find(pa.mesh); sit != sphereOfMesh.end()) {
+            const PendingSphere &sp = spheres[sit->second];
+            float area = sp.s.phi_max * sp.s.radius * (sp.s.z_max - sp.s.z_min);  // Sphere::Area (shapes.h:292)
+            float sc = scale;
+            if (phi_v > 0) {
+                float k_e = 1;
+                k_e *= (twoSided ? 2 : 1) * area * Pi;
+                sc *= phi_v / k_e;
+            }
+            wf_light l{};
+            l.type = WF_LIGHT_DIFFUSE_AREA;
+            l.flags = twoSided ? WF_LIGHTFLAG_TWOSIDED : 0;
+            l.spectrum_offset = specOff;
+            l.scale = sc;
+            l.tri = mesh.first_tri;
+            l.area = area;
+            l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = -1;
+            int lightId = (int)T->lights.size();
+            T->lights.push_back(l);
+            // DiffuseAreaLight::Bounds (lights.cpp:788-806) with Sphere::NormalBounds = DirectionCone::EntireSphere()
+            LightBoundsH lb;
+            lb.bounds = sp.bounds;
+            lb.w = Normalize(V3{0, 0, 1});
+            lb.phi = LemitMax * (sc * area * Pi);
+            lb.cosTheta_o = -1.f;
+            lb.cosTheta_e = std::cos(Pi / 2);
+            lb.twoSided = twoSided;
+            addLightBounds(lightId, lb);
+        }
         for (int t = 0; t < mesh.ntris; ++t) {
             int tri = mesh.first_tri + t;
             V3 p0, p1, p2;
@@ -1396,7 +1479,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     std::string split = scene.accelerator.params.GetOneString("splitmethod", "sah");
     if (split != "sah") fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str());
     int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
-    BuildBVH(T->P, T->triIndices, maxPrims, &T->bvhNodes, &T->bvhPrims);
+    std::vector<std::pair<int, B3>> spherePrims;
+    for (const PendingSphere &sp : spheres) spherePrims.emplace_back(sp.orderPos, sp.bounds);
+    BuildBVH(T->P, T->triIndices, spherePrims, maxPrims, &T->bvhNodes, &T->bvhPrims);
     B3 sceneBounds;
     for (int c = 0; c < 3; ++c) { sceneBounds.pMin[c] = T->bvhNodes[0].bmin[c]; sceneBounds.pMax[c] = T->bvhNodes[0].bmax[c]; }
     for (int c = 0; c < 3; ++c) { T->desc.scene_bounds[c] = sceneBounds.pMin[c]; T->desc.scene_bounds[3 + c] = sceneBounds.pMax[c]; }
