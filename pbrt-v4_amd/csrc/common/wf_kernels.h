@@ -403,6 +403,9 @@ WF_HD void KResolveMix(const SceneView &sv, const WorkState &ws, int cur, int qi
 // destination queue).  `route` = the triangle's build-time routing code (LeafTri.c.w): material type |
 // emissive << 4 | interface << 5, so nothing is gathered per hit.  Destinations: 0 escaped, 1 emitter hit,
 // 2 re-pushed ray (interface material), 2 + t material type t, MS medium sample (rays travelling in a medium).
+// GENERAL: the scene has non-triangle primitives (the plain traversal variant must not even link the quadric code:
+// an out-of-line callee's register count becomes the kernel's and costs it a wave of occupancy).
+template <bool GENERAL>
 __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, uint32_t route,
                                       float tHit, float b0, float b1, float b2) {
     constexpr int MS = 2 + WF_MAT_NTYPES;
@@ -464,7 +467,8 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             const RayQueueV &q = ws.rq[cur];
             const RayQueueV &nq = ws.rq[cur ^ 1];
             SurfIntr si;
-            HitInteraction(sv, prim, b0, b1, b2, &si);
+            if constexpr (GENERAL) HitInteraction(sv, prim, b0, b1, b2, &si);
+            else TriangleInteraction(sv, prim, b0, b1, b2, &si);
             F4 o = q.o[i], d = q.d[i];
             V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
             nq.o[slot] = F4{no.x, no.y, no.z, o.w};

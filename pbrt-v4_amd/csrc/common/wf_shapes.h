@@ -589,9 +589,11 @@ WF_HD float TrianglePDF(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxN,
 // ---------------------------------------------------------------------------------------------
 // Sphere::InteractionFromIntersection (shapes.h:241-289) + the SurfaceInteraction ctor (interaction.h:164-183) +
 // Transform::operator()(SurfaceInteraction) (util/transform.cpp:229-261)
-WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *si) {
-    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
-    const wf_mesh &mesh = sv.meshes[s.mesh];
+// (out of line, pointer / scalar arguments only: the quadric code stays out of the material and traversal kernels'
+// register budgets, which scenes without spheres would otherwise pay for)
+WF_NI void SphereInteractionP(const wf_sphere *sp, int meshFlags, float px, float py, float pz, SurfIntr *si) {
+    const wf_sphere s = *sp;
+    const V3 pHit{px, py, pz};
     const float radius = s.radius, phiMax = s.phi_max, thetaZMin = s.theta_z_min, thetaZMax = s.theta_z_max;
     float phi = atan2(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * Pi;
@@ -615,7 +617,7 @@ WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *s
     N3 dndu = toN((f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv);
     N3 dndv = toN((g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv);
     V3 pError = gamma(5) * Abs(pHit);
-    bool flipNormal = (mesh.flags & WF_MESH_FLIP_NORMAL) != 0;
+    bool flipNormal = (meshFlags & WF_MESH_FLIP_NORMAL) != 0;
     N3 nObj = toN(n);
     if (flipNormal) nObj = -nObj;
     const float(*m)[4] = s.render_from_object.m;
@@ -634,13 +636,24 @@ WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *s
     si->dndvs = si->dndv;
     si->mesh = s.mesh;
 }
+WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *si) {
+    const wf_sphere *s = sv.spheres + (prim - sv.nTriangles);
+    SurfIntr tmp;  // the out-of-line call's result lives in memory; *si stays in registers
+    SphereInteractionP(s, sv.meshes[s->mesh].flags, pHit.x, pHit.y, pHit.z, &tmp);
+    *si = tmp;
+}
 // intr.wo: the Interaction ctor normalises -ray.d (interaction.h:40-43); a quadric builds its interaction in object
 // space and transforms it back, so its wo is normalised there and again after the transform (shapes.h:286-288,
 // util/transform.cpp:235)
+WF_NI void SphereWoP(const wf_sphere *s, float x, float y, float z, float *ox, float *oy, float *oz) {
+    V3 w = Normalize(XfVector3(s->render_from_object.m, Normalize(XfVector3(s->render_from_object.mInv, V3{x, y, z}))));
+    *ox = w.x; *oy = w.y; *oz = w.z;
+}
 WF_HD V3 IntrWo(const SceneView &sv, int prim, V3 minusD) {
     if (prim < sv.nTriangles) return Normalize(minusD);
-    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
-    return Normalize(XfVector3(s.render_from_object.m, Normalize(XfVector3(s.render_from_object.mInv, minusD))));
+    V3 w;
+    SphereWoP(sv.spheres + (prim - sv.nTriangles), minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
+    return w;
 }
 // the SurfaceInteraction of a hit record (prim, three floats): barycentrics for a triangle, pObj for a sphere
 WF_HD void HitInteraction(const SceneView &sv, int prim, float b0, float b1, float b2, SurfIntr *si) {
@@ -649,14 +662,13 @@ WF_HD void HitInteraction(const SceneView &sv, int prim, float b0, float b1, flo
 }
 
 // Sphere::Sample(Point2f u), shapes.cpp:38-58
-WF_HD ShapeSampleR SphereSampleArea(const SceneView &sv, const wf_sphere &s, V2 u) {
-    const wf_mesh &mesh = sv.meshes[s.mesh];
+WF_HD ShapeSampleR SphereSampleArea(const wf_sphere &s, int meshFlags, V2 u) {
     ShapeSampleR r;
     V3 pObj = s.radius * SampleUniformSphere(u);
     pObj = pObj * (s.radius / Length(pObj));
     V3 pObjError = gamma(5) * Abs(pObj);
     N3 n = Normalize(XfNormal3(s.render_from_object.mInv, N3{pObj.x, pObj.y, pObj.z}));
-    if (mesh.flags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
+    if (meshFlags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
     float theta = SafeACos(pObj.z / s.radius);
     float phi = atan2(pObj.y, pObj.x);
     if (phi < 0) phi += 2 * Pi;
@@ -668,26 +680,28 @@ WF_HD ShapeSampleR SphereSampleArea(const SceneView &sv, const wf_sphere &s, V2 
     return r;
 }
 // Sphere::Sample(const ShapeSampleContext &, Point2f), shapes.h:300-372
-WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V2 u) {
-    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
-    const wf_mesh &mesh = sv.meshes[s.mesh];
+WF_NI void SphereSampleP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float ux, float uy, ShapeSampleR *out) {
+    const wf_sphere s = *sp;
+    const P3i ctxPi = *ctxPiP;
+    const N3 ctxN{nx, ny, nz};
+    const V2 u{ux, uy};
     const float radius = s.radius;
-    ShapeSampleR r;
+    ShapeSampleR &r = *out;
     r.valid = false;
     r.pdf = 0;
     V3 pCenter = XfPoint3(s.render_from_object.m, V3{0, 0, 0});
     V3 rp = ctxPi.mid();
     V3 pOrigin = OffsetRayOrigin(ctxPi, ctxN, pCenter - rp);
     if (DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
-        r = SphereSampleArea(sv, s, u);
+        r = SphereSampleArea(s, meshFlags, u);
         r.valid = false;
         V3 wi = r.pi.mid() - rp;
-        if (LengthSquared(wi) == 0) return r;
+        if (LengthSquared(wi) == 0) return;
         wi = Normalize(wi);
         r.pdf /= AbsDot(r.n, -wi) / DistanceSquared(rp, r.pi.mid());
-        if (IsInf(r.pdf)) return r;
+        if (IsInf(r.pdf)) return;
         r.valid = true;
-        return r;
+        return;
     }
     float sinThetaMax = radius / Distance(rp, pCenter);
     float sin2ThetaMax = Sqr(sinThetaMax);
@@ -707,7 +721,7 @@ WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi,
     Frame samplingFrame = Frame::FromZ(Normalize(pCenter - rp));
     N3 n = toN(samplingFrame.FromLocal(-w));
     V3 p = pCenter + radius * V3{n.x, n.y, n.z};
-    if (mesh.flags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
+    if (meshFlags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
     V3 pError = gamma(5) * Abs(p);
     V3 pObj = XfPoint3(s.render_from_object.mInv, p);
     float theta = SafeACos(pObj.z / radius);
@@ -718,11 +732,20 @@ WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi,
     r.n = n;
     r.pdf = 1 / (2 * Pi * oneMinusCosThetaMax);
     r.valid = true;
+}
+WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V2 u) {
+    const wf_sphere *s = sv.spheres + (prim - sv.nTriangles);
+    const P3i pi = ctxPi;
+    ShapeSampleR r;
+    SphereSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, u.x, u.y, &r);
     return r;
 }
 // Sphere::PDF(const ShapeSampleContext &, Vector3f wi), shapes.h:374-405
-WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V3 wi) {
-    const wf_sphere &s = sv.spheres[prim - sv.nTriangles];
+WF_NI float SpherePDFP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float wx, float wy, float wz) {
+    const wf_sphere s = *sp;
+    const P3i ctxPi = *ctxPiP;
+    const N3 ctxN{nx, ny, nz};
+    const V3 wi{wx, wy, wz};
     const float radius = s.radius;
     V3 pCenter = XfPoint3(s.render_from_object.m, V3{0, 0, 0});
     V3 rp = ctxPi.mid();
@@ -732,7 +755,7 @@ WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, 
         QuadricHit qh;
         if (!SphereBasicIntersect(s, o, wi, WF_INFINITY, &qh)) return 0;
         SurfIntr si;
-        SphereInteraction(sv, prim, qh.pObj, &si);
+        SphereInteractionP(sp, meshFlags, qh.pObj.x, qh.pObj.y, qh.pObj.z, &si);
         float area = s.phi_max * radius * (s.z_max - s.z_min);
         float pdf = (1 / area) / (AbsDot(si.n, -wi) / DistanceSquared(rp, si.pi.mid()));
         if (IsInf(pdf)) pdf = 0;
@@ -743,6 +766,11 @@ WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, 
     float oneMinusCosThetaMax = 1 - cosThetaMax;
     if (sin2ThetaMax < 0.00068523f /* sin^2(1.5 deg) */) oneMinusCosThetaMax = sin2ThetaMax / 2;
     return 1 / (2 * Pi * oneMinusCosThetaMax);
+}
+WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V3 wi) {
+    const wf_sphere *s = sv.spheres + (prim - sv.nTriangles);
+    const P3i pi = ctxPi;
+    return SpherePDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, wi.x, wi.y, wi.z);
 }
 
 }  // namespace wf

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneV
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
         },
-        [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock(sv, ws, cur, i, valid, w.prim, w.route, w.tMax, w.b0, w.b1, w.b2); });
+        [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock<ALPHA>(sv, ws, cur, i, valid, w.prim, w.route, w.tMax, w.b0, w.b1, w.b2); });
 }
 template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
