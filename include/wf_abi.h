@@ -291,7 +291,8 @@ typedef struct wf_film {
     float outputRGBFromSensorRGB[3][3];
 } wf_film;
 
-enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1, WF_SAMPLER_STRATIFIED = 2, WF_SAMPLER_PADDED_SOBOL = 3 };
+enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1, WF_SAMPLER_STRATIFIED = 2, WF_SAMPLER_PADDED_SOBOL = 3,
+                       WF_SAMPLER_HALTON = 4 };
 enum wf_randomize { WF_RAND_NONE = 0, WF_RAND_PERMUTE_DIGITS = 1, WF_RAND_FAST_OWEN = 2, WF_RAND_OWEN = 3 };
 typedef struct wf_sampler {
     int32_t type;
@@ -300,6 +301,7 @@ typedef struct wf_sampler {
     int32_t randomize;
     int32_t log2spp, nBase4Digits;        /* ZSobol (samplers.h:228-240) */
     int32_t x_samples, y_samples, jitter; /* Stratified (samplers.h:503-575) */
+    int32_t halton_base_scales[2], halton_base_exponents[2], halton_mult_inverse[2]; /* Halton (samplers.cpp:32-52) */
 } wf_sampler;
 
 enum wf_light_sampler_type { WF_LS_UNIFORM = 0, WF_LS_POWER = 1, WF_LS_BVH = 2 };
@@ -362,6 +364,11 @@ typedef struct wf_scene_desc {
     int32_t n_media, n_medium_floats;
     const struct wf_medium *media;
     const float *medium_data;    /* density / Lescale / majorant grids */
+    /* HaltonSampler tables (util/primes.h, util/lowdiscrepancy.h:26-62): null unless the sampler is WF_SAMPLER_HALTON */
+    const int32_t *halton_primes;        /* [1000] */
+    const int32_t *halton_perm_offsets;  /* [1000] start of dimension d's nDigits x base digit permutations */
+    const uint16_t *halton_perms;
+    int64_t n_halton_perms;
     /* quadrics */
     int32_t n_spheres, pad_spheres;
     const wf_sphere *spheres;

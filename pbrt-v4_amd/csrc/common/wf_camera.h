@@ -142,16 +142,84 @@ struct ZSobol {
 
 // The sampler of the scene behind the Sampler interface the stages use (base/sampler.h:40-64): ZSobol (above),
 // IndependentSampler (samplers.h:442-482), StratifiedSampler (:503-575), PaddedSobolSampler (:130-222).
+// RadicalInverse / ScrambledRadicalInverse / OwenScrambledRadicalInverse, util/lowdiscrepancy.h:86-159
+WF_HD float RadicalInverseBase(unsigned base, uint64_t a) {
+    uint64_t limit = ~0ull / base - base;
+    float invBase = (float)1 / (float)base, invBaseM = 1;
+    uint64_t reversedDigits = 0;
+    while (a && reversedDigits < limit) {
+        uint64_t next = a / base;
+        uint64_t digit = a - next * base;
+        reversedDigits = reversedDigits * base + digit;
+        invBaseM *= invBase;
+        a = next;
+    }
+    return fmin(reversedDigits * invBaseM, OneMinusEpsilon);
+}
+WF_HD float ScrambledRadicalInverseBase(unsigned base, uint64_t a, const uint16_t *perm) {
+    uint64_t limit = ~0ull / base - base;
+    float invBase = (float)1 / (float)base, invBaseM = 1;
+    uint64_t reversedDigits = 0;
+    int digitIndex = 0;
+    while (1 - (base - 1) * invBaseM < 1 && reversedDigits < limit) {
+        uint64_t next = a / base;
+        int digitValue = (int)(a - next * base);
+        reversedDigits = reversedDigits * base + perm[digitIndex * base + digitValue];
+        invBaseM *= invBase;
+        ++digitIndex;
+        a = next;
+    }
+    return fmin(invBaseM * reversedDigits, OneMinusEpsilon);
+}
+WF_HD float OwenScrambledRadicalInverseBase(unsigned base, uint64_t a, uint32_t hash) {
+    uint64_t limit = ~0ull / base - base;
+    float invBase = (float)1 / (float)base, invBaseM = 1;
+    uint64_t reversedDigits = 0;
+    while (1 - invBaseM < 1 && reversedDigits < limit) {
+        uint64_t next = a / base;
+        int digitValue = (int)(a - next * base);
+        uint32_t digitHash = (uint32_t)MixBits(hash ^ reversedDigits);
+        digitValue = PermutationElement((uint32_t)digitValue, base, digitHash);
+        reversedDigits = reversedDigits * base + digitValue;
+        invBaseM *= invBase;
+        a = next;
+    }
+    return fmin(invBaseM * reversedDigits, OneMinusEpsilon);
+}
+WF_HD uint64_t InverseRadicalInverse(uint64_t inverse, int base, int nDigits) {
+    uint64_t index = 0;
+    for (int i = 0; i < nDigits; ++i) {
+        uint64_t digit = inverse % base;
+        inverse /= base;
+        index = index * base + digit;
+    }
+    return index;
+}
+
 struct PixelSampler {
     ZSobol z;
     int type, spp, seed, randomize, xs, ys, jitter;
     const uint32_t *sobol;
     RNG rng;
     int px = 0, py = 0, sampleIndex = 0, dimension = 0;
+    // HaltonSampler (samplers.h:33-141)
+    int hbs0, hbs1, hbe0, hbe1, hmi0, hmi1;  // baseScales, baseExponents, multInverse
+    const int32_t *primes, *permOffsets;
+    const uint16_t *perms;
+    int64_t haltonIndex = 0;
 
     WF_HD PixelSampler(const SceneView &sv)
         : z(sv), type(sv.sampler.type), spp(sv.sampler.spp), seed(sv.sampler.seed), randomize(sv.sampler.randomize),
-          xs(sv.sampler.x_samples), ys(sv.sampler.y_samples), jitter(sv.sampler.jitter), sobol(sv.sobol) {}
+          xs(sv.sampler.x_samples), ys(sv.sampler.y_samples), jitter(sv.sampler.jitter), sobol(sv.sobol),
+          hbs0(sv.sampler.halton_base_scales[0]), hbs1(sv.sampler.halton_base_scales[1]), hbe0(sv.sampler.halton_base_exponents[0]),
+          hbe1(sv.sampler.halton_base_exponents[1]), hmi0(sv.sampler.halton_mult_inverse[0]), hmi1(sv.sampler.halton_mult_inverse[1]),
+          primes(sv.haltonPrimes), permOffsets(sv.haltonPermOffsets), perms(sv.haltonPerms) {}
+    WF_HD float HaltonDimension(int dim) const {
+        unsigned base = (unsigned)primes[dim];
+        if (randomize == WF_RAND_NONE) return RadicalInverseBase(base, (uint64_t)haltonIndex);
+        if (randomize == WF_RAND_PERMUTE_DIGITS) return ScrambledRadicalInverseBase(base, (uint64_t)haltonIndex, perms + permOffsets[dim]);
+        return OwenScrambledRadicalInverseBase(base, (uint64_t)haltonIndex, (uint32_t)MixBits(1 + ((uint64_t)dim << 4)));
+    }
     WF_HD static uint64_t HashPixelSeed(int x, int y, int sd) { uint32_t w[3] = {(uint32_t)x, (uint32_t)y, (uint32_t)sd}; return HashWords(w, 3); }
     WF_HD static uint64_t HashPixelDimSeed(int x, int y, int dim, int sd) {
         uint32_t w[4] = {(uint32_t)x, (uint32_t)y, (uint32_t)dim, (uint32_t)sd};
@@ -159,6 +227,23 @@ struct PixelSampler {
     }
     WF_HD void StartPixelSample(int x, int y, int index, int dim) {
         if (type == WF_SAMPLER_ZSOBOL) { z.StartPixelSample(x, y, index, dim); return; }
+        if (type == WF_SAMPLER_HALTON) {
+            // samplers.h:53-71
+            haltonIndex = 0;
+            int sampleStride = hbs0 * hbs1;
+            if (sampleStride > 1) {
+                auto Mod = [](int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; };
+                int pm[2] = {Mod(x, 128), Mod(y, 128)};
+                for (int i = 0; i < 2; ++i) {
+                    uint64_t dimOffset = InverseRadicalInverse((uint64_t)pm[i], i == 0 ? 2 : 3, i == 0 ? hbe0 : hbe1);
+                    haltonIndex += (int64_t)(dimOffset * (uint64_t)(sampleStride / (i == 0 ? hbs0 : hbs1)) * (uint64_t)(i == 0 ? hmi0 : hmi1));
+                }
+                haltonIndex %= sampleStride;
+            }
+            haltonIndex += index * sampleStride;
+            dimension = dim > 2 ? dim : 2;
+            return;
+        }
         px = x; py = y; sampleIndex = index; dimension = dim;
         if (type != WF_SAMPLER_PADDED_SOBOL) {
             rng.SetSequence(HashPixelSeed(x, y, seed));
@@ -169,6 +254,10 @@ struct PixelSampler {
     WF_HD float PaddedDim(int dim, uint32_t a, uint32_t hash) const { return SobolSample(sobol, (int64_t)a, dim, randomize, hash); }
     WF_HD float Get1D() {
         if (type == WF_SAMPLER_ZSOBOL) return z.Get1D();
+        if (type == WF_SAMPLER_HALTON) {
+            if (dimension >= 1000) dimension = 2;
+            return HaltonDimension(dimension++);
+        }
         if (type == WF_SAMPLER_INDEPENDENT) return rng.UniformFloat();
         uint64_t hash = HashPixelDimSeed(px, py, dimension, seed);
         if (type == WF_SAMPLER_STRATIFIED) {
@@ -184,6 +273,13 @@ struct PixelSampler {
     }
     WF_HD V2 Get2D() {
         if (type == WF_SAMPLER_ZSOBOL) return z.Get2D();
+        if (type == WF_SAMPLER_HALTON) {
+            if (dimension + 1 >= 1000) dimension = 2;
+            int dim = dimension;
+            dimension += 2;
+            float a = HaltonDimension(dim), b = HaltonDimension(dim + 1);
+            return V2{a, b};
+        }
         if (type == WF_SAMPLER_INDEPENDENT) { float a = rng.UniformFloat(); float b = rng.UniformFloat(); return V2{a, b}; }
         uint64_t hash = HashPixelDimSeed(px, py, dimension, seed);
         if (type == WF_SAMPLER_STRATIFIED) {
@@ -198,7 +294,11 @@ struct PixelSampler {
         dimension += 2;
         return V2{PaddedDim(0, (uint32_t)index, (uint32_t)hash), PaddedDim(1, (uint32_t)index, (uint32_t)(hash >> 32))};
     }
-    WF_HD V2 GetPixel2D() { return Get2D(); }
+    WF_HD V2 GetPixel2D() {
+        if (type == WF_SAMPLER_HALTON)
+            return V2{RadicalInverseBase(2, (uint64_t)(haltonIndex >> hbe0)), RadicalInverseBase(3, (uint64_t)(haltonIndex / hbs1))};
+        return Get2D();
+    }
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -53,6 +53,8 @@ struct SceneView {
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
     int texNeedsFootprint;  // some texture's value depends on the TextureEvalContext (checkerboard, image) or some material
                             // is bump- or normal-mapped: selects the material-kernel variant that computes the differentials
+    const int32_t *haltonPrimes, *haltonPermOffsets;
+    const uint16_t *haltonPerms;
     const wf_sphere *spheres;
     int nSpheres;
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat

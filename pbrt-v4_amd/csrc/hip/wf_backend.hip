@@ -682,6 +682,9 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.triIndices, d->tri_indices, (size_t)3 * d->n_triangles))) return e;
     if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles + d->n_spheres))) return e;
     if ((e = devUpload(ctx, &sv.spheres, d->spheres, (size_t)d->n_spheres))) return e;
+    if ((e = devUpload(ctx, &sv.haltonPrimes, d->halton_primes, d->halton_primes ? (size_t)1000 : (size_t)0))) return e;
+    if ((e = devUpload(ctx, &sv.haltonPermOffsets, d->halton_perm_offsets, d->halton_perm_offsets ? (size_t)1000 : (size_t)0))) return e;
+    if ((e = devUpload(ctx, &sv.haltonPerms, d->halton_perms, (size_t)d->n_halton_perms))) return e;
     sv.nSpheres = d->n_spheres;
     if ((e = devUpload(ctx, &sv.meshes, d->meshes, (size_t)d->n_meshes))) return e;
     if ((e = devUpload(ctx, &sv.bvhNodes, d->bvh_nodes, (size_t)d->n_bvh_nodes))) return e;

@@ -117,6 +117,8 @@ struct SceneTables {
     std::vector<int32_t> triIndices, triMesh, bvhPrims, infiniteLights;
     std::vector<wf_mesh> meshes;
     std::vector<wf_sphere> spheres;
+    std::vector<int32_t> haltonPrimes, haltonPermOffsets;
+    std::vector<uint16_t> haltonPerms;
     std::vector<wf_bvh_node> bvhNodes;
     SpectrumPool pool;
     std::vector<wf_texture> textures;

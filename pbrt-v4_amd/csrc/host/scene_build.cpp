@@ -34,6 +34,10 @@ void SceneTables::Finalize() {
     desc.tri_indices = triIndices.data(); desc.tri_mesh = triMesh.data();
     desc.meshes = meshes.data(); desc.bvh_nodes = bvhNodes.data(); desc.bvh_prims = bvhPrims.data();
     desc.n_spheres = (int)spheres.size(); desc.spheres = spheres.data();
+    desc.halton_primes = haltonPrimes.empty() ? nullptr : haltonPrimes.data();
+    desc.halton_perm_offsets = haltonPermOffsets.empty() ? nullptr : haltonPermOffsets.data();
+    desc.halton_perms = haltonPerms.empty() ? nullptr : haltonPerms.data();
+    desc.n_halton_perms = (int64_t)haltonPerms.size();
     desc.n_spectra = (int)pool.spectra.size(); desc.n_spectrum_floats = (int)pool.data.size();
     desc.spectra = pool.spectra.data(); desc.spectrum_data = pool.data.data();
     desc.n_textures = (int)textures.size(); desc.textures = textures.data();
@@ -599,7 +603,55 @@ void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTable
         else Die(scene.sampler.loc, s + ": unknown randomization strategy given to PaddedSobolSampler");
         if (nsamp & (nsamp - 1)) fprintf(stderr, "Warning: Sobol samplers with non power-of-two sample counts (%d) are suboptimal.\n", nsamp);
         S.spp = nsamp;
-    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, independent, stratified, paddedsobol)");
+    } else if (scene.sampler.name == "halton") {
+        // HaltonSampler::Create + ctor (samplers.cpp:32-52,67-92)
+        S.type = WF_SAMPLER_HALTON;
+        std::string s = ps.GetOneString("randomization", "permutedigits");
+        if (s == "none") S.randomize = WF_RAND_NONE;
+        else if (s == "permutedigits") S.randomize = WF_RAND_PERMUTE_DIGITS;
+        else if (s == "fastowen") Die(scene.sampler.loc, "\"fastowen\" randomization not supported by Halton sampler.");
+        else if (s == "owen") S.randomize = WF_RAND_OWEN;
+        else Die(scene.sampler.loc, s + ": unknown randomization strategy given to HaltonSampler");
+        S.spp = nsamp;
+        for (int i = 0; i < 2; ++i) {
+            int base = (i == 0) ? 2 : 3, scale = 1, exp = 0;
+            while (scale < std::min(T->desc.film.full_res[i], 128)) { scale *= base; ++exp; }
+            S.halton_base_scales[i] = scale;
+            S.halton_base_exponents[i] = exp;
+        }
+        // multiplicativeInverse via the extended GCD (samplers.h:100-116)
+        struct G { static void gcd(uint64_t a, uint64_t b, int64_t *x, int64_t *y) {
+            if (b == 0) { *x = 1; *y = 0; return; }
+            int64_t d = a / b, xp, yp;
+            gcd(b, a % b, &xp, &yp);
+            *x = yp; *y = xp - (d * yp);
+        } };
+        auto multInv = [](int64_t a, int64_t n) { int64_t x, y; G::gcd(a, n, &x, &y); int64_t r = x - (x / n) * n; return (int)(r < 0 ? r + n : r); };
+        S.halton_mult_inverse[0] = multInv(S.halton_base_scales[1], S.halton_base_scales[0]);
+        S.halton_mult_inverse[1] = multInv(S.halton_base_scales[0], S.halton_base_scales[1]);
+        // Primes[1000] (util/primes.cpp) by sieve; DigitPermutation per prime (util/lowdiscrepancy.h:30-48)
+        std::vector<char> composite(7920, 0);
+        for (int i = 2; i < 7920 && (int)T->haltonPrimes.size() < 1000; ++i) {
+            if (composite[i]) continue;
+            T->haltonPrimes.push_back(i);
+            for (int j = 2 * i; j < 7920; j += i) composite[j] = 1;
+        }
+        T->haltonPermOffsets.assign(1000, 0);
+        if (S.randomize == WF_RAND_PERMUTE_DIGITS)
+            for (int d = 0; d < 1000; ++d) {
+                const int base = T->haltonPrimes[d];
+                int nDigits = 0;
+                float invBase = (float)1 / (float)base, invBaseM = 1;
+                while (1 - (base - 1) * invBaseM < 1) { ++nDigits; invBaseM *= invBase; }
+                T->haltonPermOffsets[d] = (int32_t)T->haltonPerms.size();
+                for (int digitIndex = 0; digitIndex < nDigits; ++digitIndex) {
+                    uint32_t w[3] = {(uint32_t)base, (uint32_t)digitIndex, (uint32_t)S.seed};
+                    uint64_t dseed = HashWords(w, 3);
+                    for (int digitValue = 0; digitValue < base; ++digitValue)
+                        T->haltonPerms.push_back((uint16_t)PermutationElement((uint32_t)digitValue, (uint32_t)base, (uint32_t)dseed));
+                }
+            }
+    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, independent, stratified, paddedsobol, halton)");
     T->spp = S.spp;
     ps.ReportUnused("Sampler");
 }

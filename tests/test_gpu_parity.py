@@ -115,7 +115,7 @@ def _render_both(scene, path, spp, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "envmap", "textures_bump", "image_textures", "alpha_normalmap", "spheres",
-                                  "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol"])
+                                  "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
     spp = 0 if name.startswith("cornell64_") else 4   # the sampler scenes keep their samplers' default sample counts

@@ -36,8 +36,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/mix_materials_ref
 # the same lights through the PowerLightSampler (alias table)
 sed 's/Integrator "volpath"/Integrator "volpath" "string lightsampler" [ "power" ]/' $G/materials_lights.pbrt > $G/materials_lights_power.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_power_ref.pfm $G/materials_lights_power.pbrt
-# the other pixel samplers on the Cornell box (scene defaults: independent 4 spp, stratified 4x4, paddedsobol 16)
-for smp in independent stratified paddedsobol; do
+# the other pixel samplers on the Cornell box (scene defaults: independent 4 spp, stratified 4x4, paddedsobol 16, halton 16)
+for smp in independent stratified paddedsobol halton; do
   sed "s/^Sampler \"zsobol\".*/Sampler \"$smp\"/" $G/cornell64.pbrt > $G/cornell64_$smp.pbrt
   oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/cornell64_${smp}_ref.pfm $G/cornell64_$smp.pbrt
 done
