@@ -244,14 +244,18 @@ typedef struct wf_mesh {
 #define WF_MESH_HAS_MEDIUM_INTERFACE 8
 #define WF_MESH_REVERSE_ORIENTATION 16  /* the shape's own reverseOrientation (Sphere::Sample flips by it alone, shapes.h:274) */
 
-/* Sphere (shapes.h:107-383), kept in object space like the reference's: primitive id n_triangles + index.  Its
- * material / area light / media / orientation live in a wf_mesh entry with ntris = 0 and first_tri = that id. */
-typedef struct wf_sphere {
-    float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;
+/* Sphere, Disk, Cylinder (shapes.h:107-383, 385-540, 543-748), kept in object space like the reference's: primitive
+ * id n_triangles + index.  Material / area light / media / orientation live in a wf_mesh entry with ntris = 0 and
+ * first_tri = that id. */
+enum wf_quadric_type { WF_QUADRIC_SPHERE = 0, WF_QUADRIC_DISK = 1, WF_QUADRIC_CYLINDER = 2 };
+typedef struct wf_quadric {
+    float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;  /* disk: z_min = z_max = height */
     int32_t mesh;
-    int32_t pad;
+    int32_t type;                      /* wf_quadric_type */
+    float inner_radius;                /* disk */
+    float pad[3];
     wf_transform render_from_object;   /* m = renderFromObject, mInv = objectFromRender */
-} wf_sphere;
+} wf_quadric;
 
 enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1 };
 typedef struct wf_camera {
@@ -319,10 +323,10 @@ typedef struct wf_scene_desc {
     const float *N;              /* [n_vertices][3] (zero for meshes without normals) */
     const float *UV;             /* [n_vertices][2] */
     const int32_t *tri_indices;  /* [n_triangles][3] global vertex ids */
-    const int32_t *tri_mesh;     /* [n_triangles + n_spheres] mesh id of every primitive */
+    const int32_t *tri_mesh;     /* [n_triangles + n_quadrics] mesh id of every primitive */
     const wf_mesh *meshes;
     const wf_bvh_node *bvh_nodes;
-    const int32_t *bvh_prims;    /* [n_triangles + n_spheres] primitive ids in BVH leaf order */
+    const int32_t *bvh_prims;    /* [n_triangles + n_quadrics] primitive ids in BVH leaf order */
     float scene_bounds[6];
     /* shading */
     int32_t n_spectra, n_spectrum_floats, n_textures, n_materials;
@@ -370,8 +374,8 @@ typedef struct wf_scene_desc {
     const uint16_t *halton_perms;
     int64_t n_halton_perms;
     /* quadrics */
-    int32_t n_spheres, pad_spheres;
-    const wf_sphere *spheres;
+    int32_t n_quadrics, pad_quadrics;
+    const wf_quadric *quadrics;
 } wf_scene_desc;
 
 /* ------------------------------------------------------------------------------------------- */

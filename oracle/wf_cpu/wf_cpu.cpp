@@ -81,7 +81,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     for (int i = 0; i < d.n_materials; ++i)
         if (d.materials[i].displacement >= 0 || d.materials[i].normalmap >= 0) sv.texNeedsFootprint = 1;
     sv.matTypeMask = 0;
-    sv.spheres = d.spheres; sv.nSpheres = d.n_spheres;
+    sv.quadrics = d.quadrics; sv.nQuadrics = d.n_quadrics;
     sv.haltonPrimes = d.halton_primes; sv.haltonPermOffsets = d.halton_perm_offsets; sv.haltonPerms = d.halton_perms;
     sv.haveMix = 0;
     for (int i = 0; i < d.n_materials; ++i) {

@@ -55,8 +55,8 @@ struct SceneView {
                             // is bump- or normal-mapped: selects the material-kernel variant that computes the differentials
     const int32_t *haltonPrimes, *haltonPermOffsets;
     const uint16_t *haltonPerms;
-    const wf_sphere *spheres;
-    int nSpheres;
+    const wf_quadric *quadrics;
+    int nQuadrics;
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
     int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
     wf_options options;

@@ -183,7 +183,7 @@ WF_HD N3 XfNormal3(const float mInv[4][4], N3 n) {
 
 struct QuadricHit { float tHit; V3 pObj; float phi; };
 // Sphere::BasicIntersect, shapes.h:147-233
-WF_HD bool SphereBasicIntersect(const wf_sphere &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+WF_HD bool SphereBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
     const float radius = s.radius;
     Ivl3 oi = XfPointExactI(s.render_from_object.mInv, ro);
     Ivl3 di = XfVectorExactI(s.render_from_object.mInv, rd);
@@ -233,6 +233,86 @@ WF_HD bool SphereBasicIntersect(const wf_sphere &s, V3 ro, V3 rd, float tMax, Qu
     return true;
 }
 
+// Disk::BasicIntersect, shapes.h:427-452
+WF_HD bool DiskBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    Ivl3 oi = XfPointExactI(s.render_from_object.mInv, ro);
+    Ivl3 di = XfVectorExactI(s.render_from_object.mInv, rd);
+    if (di.z.mid() == 0) return false;
+    float tShapeHit = (s.z_min - oi.z.mid()) / di.z.mid();
+    if (tShapeHit <= 0 || tShapeHit >= tMax) return false;
+    V3 pHit = V3{oi.x.mid(), oi.y.mid(), oi.z.mid()} + tShapeHit * V3{di.x.mid(), di.y.mid(), di.z.mid()};
+    float dist2 = Sqr(pHit.x) + Sqr(pHit.y);
+    if (dist2 > Sqr(s.radius) || dist2 < Sqr(s.inner_radius)) return false;
+    float phi = atan2(pHit.y, pHit.x);
+    if (phi < 0) phi += 2 * Pi;
+    if (phi > s.phi_max) return false;
+    out->tHit = tShapeHit;
+    out->pObj = pHit;
+    out->phi = phi;
+    return true;
+}
+// Cylinder::BasicIntersect, shapes.h:575-654
+WF_HD bool CylinderBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    const float radius = s.radius;
+    Ivl3 oi = XfPointExactI(s.render_from_object.mInv, ro);
+    Ivl3 di = XfVectorExactI(s.render_from_object.mInv, rd);
+    Ivl a = Sqr(di.x) + Sqr(di.y);
+    Ivl b = 2.f * (di.x * oi.x + di.y * oi.y);
+    Ivl c = Sqr(oi.x) + Sqr(oi.y) - Sqr(Ivl(radius));
+    Ivl f = b / (2.f * a);
+    Ivl vx = oi.x - f * di.x, vy = oi.y - f * di.y;
+    Ivl length = Sqrt(Sqr(vx) + Sqr(vy));
+    Ivl discrim = 4.f * a * (Ivl(radius) + length) * (Ivl(radius) - length);
+    if (discrim.lo < 0) return false;
+    Ivl rootDiscrim = Sqrt(discrim);
+    Ivl q;
+    if (b.mid() < 0) q = -.5f * (b - rootDiscrim);
+    else q = -.5f * (b + rootDiscrim);
+    Ivl t0 = q / a;
+    Ivl t1 = c / q;
+    if (t0.lo > t1.lo) { Ivl t = t0; t0 = t1; t1 = t; }
+    if (t0.hi > tMax || t1.lo <= 0) return false;
+    Ivl tShapeHit = t0;
+    if (tShapeHit.lo <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit.hi > tMax) return false;
+    }
+    const V3 om{oi.x.mid(), oi.y.mid(), oi.z.mid()}, dm{di.x.mid(), di.y.mid(), di.z.mid()};
+    V3 pHit;
+    float phi;
+    auto hitPoint = [&]() {
+        pHit = om + tShapeHit.mid() * dm;
+        float hitRad = sqrt(Sqr(pHit.x) + Sqr(pHit.y));
+        pHit.x *= radius / hitRad;
+        pHit.y *= radius / hitRad;
+        phi = atan2(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * Pi;
+    };
+    hitPoint();
+    auto clipped = [&]() { return pHit.z < s.z_min || pHit.z > s.z_max || phi > s.phi_max; };
+    if (clipped()) {
+        if (tShapeHit == t1) return false;
+        tShapeHit = t1;
+        if (t1.hi > tMax) return false;
+        hitPoint();
+        if (clipped()) return false;
+    }
+    out->tHit = tShapeHit.mid();
+    out->pObj = pHit;
+    out->phi = phi;
+    return true;
+}
+WF_HD bool QuadricBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    if (s.type == WF_QUADRIC_DISK) return DiskBasicIntersect(s, ro, rd, tMax, out);
+    if (s.type == WF_QUADRIC_CYLINDER) return CylinderBasicIntersect(s, ro, rd, tMax, out);
+    return SphereBasicIntersect(s, ro, rd, tMax, out);
+}
+WF_HD float QuadricArea(const wf_quadric &s) {
+    if (s.type == WF_QUADRIC_DISK) return s.phi_max * 0.5f * (Sqr(s.radius) - Sqr(s.inner_radius));  // shapes.h:407
+    if (s.type == WF_QUADRIC_CYLINDER) return (s.z_max - s.z_min) * s.radius * s.phi_max;             // shapes.h:559
+    return s.phi_max * s.radius * (s.z_max - s.z_min);                                                // shapes.h:292
+}
+
 // GeometricPrimitive::Intersect's stochastic alpha test (cpu/primitive.cpp:57-72; IntersectP goes through Intersect,
 // :79-84).  A triangle cannot be hit again by the ray respawned behind it, so a failed test simply drops the hit.
 // The texture sees TextureEvalContext(SurfaceInteraction) with all differentials zero (interaction.h: set only by
@@ -274,7 +354,7 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
                     if (tri >= sv.nTriangles) {
                         // a sphere: the hit record carries pObj in place of the barycentrics
                         QuadricHit qh;
-                        if (SphereBasicIntersect(sv.spheres[tri - sv.nTriangles], o, d, tMax, &qh)) {
+                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) {
                             out->prim = tri;
                             out->h.t = qh.tHit; out->h.b0 = qh.pObj.x; out->h.b1 = qh.pObj.y; out->h.b2 = qh.pObj.z;
                             tMax = qh.tHit;
@@ -326,7 +406,7 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
                     ++nt;
                     if (tri >= sv.nTriangles) {
                         QuadricHit qh;
-                        if (SphereBasicIntersect(sv.spheres[tri - sv.nTriangles], o, d, tMax, &qh)) found = true;
+                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) found = true;
                         continue;
                     }
                     V3 p0, p1, p2;
@@ -591,12 +671,58 @@ WF_HD float TrianglePDF(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxN,
 // Transform::operator()(SurfaceInteraction) (util/transform.cpp:229-261)
 // (out of line, pointer / scalar arguments only: the quadric code stays out of the material and traversal kernels'
 // register budgets, which scenes without spheres would otherwise pay for)
-WF_NI void SphereInteractionP(const wf_sphere *sp, int meshFlags, float px, float py, float pz, SurfIntr *si) {
-    const wf_sphere s = *sp;
-    const V3 pHit{px, py, pz};
+WF_NI void SphereInteractionP(const wf_quadric *sp, int meshFlags, float px, float py, float pz, SurfIntr *si) {
+    const wf_quadric s = *sp;
+    V3 pHit{px, py, pz};
     const float radius = s.radius, phiMax = s.phi_max, thetaZMin = s.theta_z_min, thetaZMax = s.theta_z_max;
     float phi = atan2(pHit.y, pHit.x);
     if (phi < 0) phi += 2 * Pi;
+    const bool flipN = (meshFlags & WF_MESH_FLIP_NORMAL) != 0;
+    if (s.type != WF_QUADRIC_SPHERE) {
+        float u = phi / phiMax, v;
+        V3 dpdu{-phiMax * pHit.y, phiMax * pHit.x, 0}, dpdv, pError;
+        N3 dndu{0, 0, 0}, dndv{0, 0, 0};
+        if (s.type == WF_QUADRIC_DISK) {
+            // Disk::InteractionFromIntersection, shapes.h:455-482
+            float rHit = sqrt(Sqr(pHit.x) + Sqr(pHit.y));
+            v = (radius - rHit) / (radius - s.inner_radius);
+            dpdv = V3{pHit.x, pHit.y, 0} * (s.inner_radius - radius) / rHit;
+            pHit.z = s.z_min;
+            pError = V3{0, 0, 0};
+        } else {
+            // Cylinder::InteractionFromIntersection, shapes.h:662-698
+            v = (pHit.z - s.z_min) / (s.z_max - s.z_min);
+            dpdv = V3{0, 0, s.z_max - s.z_min};
+            V3 d2Pduu = -phiMax * phiMax * V3{pHit.x, pHit.y, 0};
+            V3 d2Pduv{0, 0, 0}, d2Pdvv{0, 0, 0};
+            float E = Dot(dpdu, dpdu), F = Dot(dpdu, dpdv), G = Dot(dpdv, dpdv);
+            V3 nn = Normalize(Cross(dpdu, dpdv));
+            float e = Dot(nn, d2Pduu), f = Dot(nn, d2Pduv), g = Dot(nn, d2Pdvv);
+            float EGF2 = DifferenceOfProducts(E, G, F, F);
+            float invEGF2 = (EGF2 == 0) ? 0.f : 1 / EGF2;
+            dndu = toN((f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv);
+            dndv = toN((g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv);
+            pError = gamma(3) * Abs(V3{pHit.x, pHit.y, 0});
+        }
+        N3 nObj = toN(Normalize(Cross(dpdu, dpdv)));
+        if (flipN) nObj = -nObj;
+        const float(*m)[4] = s.render_from_object.m;
+        const float(*mi)[4] = s.render_from_object.mInv;
+        si->pi = XfPointI(m, pHit, pError);
+        si->n = Normalize(XfNormal3(mi, nObj));
+        si->uv = V2{u, v};
+        si->dpdu = XfVector3(m, dpdu);
+        si->dpdv = XfVector3(m, dpdv);
+        si->dndu = XfNormal3(mi, dndu);
+        si->dndv = XfNormal3(mi, dndv);
+        si->ns = FaceForward(Normalize(XfNormal3(mi, nObj)), si->n);
+        si->dpdus = si->dpdu;
+        si->dpdvs = si->dpdv;
+        si->dndus = si->dndu;
+        si->dndvs = si->dndv;
+        si->mesh = s.mesh;
+        return;
+    }
     float u = phi / phiMax;
     float cosTheta = pHit.z / radius;
     float theta = SafeACos(cosTheta);
@@ -637,7 +763,7 @@ WF_NI void SphereInteractionP(const wf_sphere *sp, int meshFlags, float px, floa
     si->mesh = s.mesh;
 }
 WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *si) {
-    const wf_sphere *s = sv.spheres + (prim - sv.nTriangles);
+    const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     SurfIntr tmp;  // the out-of-line call's result lives in memory; *si stays in registers
     SphereInteractionP(s, sv.meshes[s->mesh].flags, pHit.x, pHit.y, pHit.z, &tmp);
     *si = tmp;
@@ -645,14 +771,14 @@ WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *s
 // intr.wo: the Interaction ctor normalises -ray.d (interaction.h:40-43); a quadric builds its interaction in object
 // space and transforms it back, so its wo is normalised there and again after the transform (shapes.h:286-288,
 // util/transform.cpp:235)
-WF_NI void SphereWoP(const wf_sphere *s, float x, float y, float z, float *ox, float *oy, float *oz) {
+WF_NI void SphereWoP(const wf_quadric *s, float x, float y, float z, float *ox, float *oy, float *oz) {
     V3 w = Normalize(XfVector3(s->render_from_object.m, Normalize(XfVector3(s->render_from_object.mInv, V3{x, y, z}))));
     *ox = w.x; *oy = w.y; *oz = w.z;
 }
 WF_HD V3 IntrWo(const SceneView &sv, int prim, V3 minusD) {
     if (prim < sv.nTriangles) return Normalize(minusD);
     V3 w;
-    SphereWoP(sv.spheres + (prim - sv.nTriangles), minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
+    SphereWoP(sv.quadrics + (prim - sv.nTriangles), minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
     return w;
 }
 // the SurfaceInteraction of a hit record (prim, three floats): barycentrics for a triangle, pObj for a sphere
@@ -662,8 +788,42 @@ WF_HD void HitInteraction(const SceneView &sv, int prim, float b0, float b1, flo
 }
 
 // Sphere::Sample(Point2f u), shapes.cpp:38-58
-WF_HD ShapeSampleR SphereSampleArea(const wf_sphere &s, int meshFlags, V2 u) {
+WF_HD ShapeSampleR SphereSampleArea(const wf_quadric &s, int meshFlags, V2 u) {
     ShapeSampleR r;
+    if (s.type == WF_QUADRIC_DISK) {
+        // Disk::Sample(Point2f), shapes.h:490-505
+        V2 pd = SampleUniformDiskConcentric(u);
+        V3 pObj{pd.x * s.radius, pd.y * s.radius, s.z_min};
+        r.pi = XfPointI(s.render_from_object.m, pObj, V3{0, 0, 0});
+        N3 n = Normalize(XfNormal3(s.render_from_object.mInv, N3{0, 0, 1}));
+        if (meshFlags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
+        float phi = atan2(pd.y, pd.x);
+        if (phi < 0) phi += 2 * Pi;
+        float radiusSample = sqrt(Sqr(pObj.x) + Sqr(pObj.y));
+        r.uv = V2{phi / s.phi_max, (s.radius - radiusSample) / (s.radius - s.inner_radius)};
+        r.n = n;
+        r.pdf = 1 / QuadricArea(s);
+        r.valid = true;
+        return r;
+    }
+    if (s.type == WF_QUADRIC_CYLINDER) {
+        // Cylinder::Sample(Point2f), shapes.h:701-717
+        float z = Lerp(u.x, s.z_min, s.z_max);
+        float phi = u.y * s.phi_max;
+        V3 pObj{s.radius * cos(phi), s.radius * sin(phi), z};
+        float hitRad = sqrt(Sqr(pObj.x) + Sqr(pObj.y));
+        pObj.x *= s.radius / hitRad;
+        pObj.y *= s.radius / hitRad;
+        V3 pObjError = gamma(3) * Abs(V3{pObj.x, pObj.y, 0});
+        r.pi = XfPointI(s.render_from_object.m, pObj, pObjError);
+        N3 n = Normalize(XfNormal3(s.render_from_object.mInv, N3{pObj.x, pObj.y, 0}));
+        if (meshFlags & WF_MESH_REVERSE_ORIENTATION) n = n * -1.f;
+        r.uv = V2{phi / s.phi_max, (pObj.z - s.z_min) / (s.z_max - s.z_min)};
+        r.n = n;
+        r.pdf = 1 / QuadricArea(s);
+        r.valid = true;
+        return r;
+    }
     V3 pObj = s.radius * SampleUniformSphere(u);
     pObj = pObj * (s.radius / Length(pObj));
     V3 pObjError = gamma(5) * Abs(pObj);
@@ -675,13 +835,13 @@ WF_HD ShapeSampleR SphereSampleArea(const wf_sphere &s, int meshFlags, V2 u) {
     r.uv = V2{phi / s.phi_max, (theta - s.theta_z_min) / (s.theta_z_max - s.theta_z_min)};
     r.pi = XfPointI(s.render_from_object.m, pObj, pObjError);
     r.n = n;
-    r.pdf = 1 / (s.phi_max * s.radius * (s.z_max - s.z_min));
+    r.pdf = 1 / QuadricArea(s);
     r.valid = true;
     return r;
 }
 // Sphere::Sample(const ShapeSampleContext &, Point2f), shapes.h:300-372
-WF_NI void SphereSampleP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float ux, float uy, ShapeSampleR *out) {
-    const wf_sphere s = *sp;
+WF_NI void SphereSampleP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float ux, float uy, ShapeSampleR *out) {
+    const wf_quadric s = *sp;
     const P3i ctxPi = *ctxPiP;
     const N3 ctxN{nx, ny, nz};
     const V2 u{ux, uy};
@@ -692,7 +852,8 @@ WF_NI void SphereSampleP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, 
     V3 pCenter = XfPoint3(s.render_from_object.m, V3{0, 0, 0});
     V3 rp = ctxPi.mid();
     V3 pOrigin = OffsetRayOrigin(ctxPi, ctxN, pCenter - rp);
-    if (DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
+    // Disk / Cylinder::Sample(ctx, u) (shapes.h:511-526, 723-738) are the area-sampling branch taken unconditionally
+    if (s.type != WF_QUADRIC_SPHERE || DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
         r = SphereSampleArea(s, meshFlags, u);
         r.valid = false;
         V3 wi = r.pi.mid() - rp;
@@ -734,15 +895,15 @@ WF_NI void SphereSampleP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, 
     r.valid = true;
 }
 WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V2 u) {
-    const wf_sphere *s = sv.spheres + (prim - sv.nTriangles);
+    const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
     ShapeSampleR r;
     SphereSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, u.x, u.y, &r);
     return r;
 }
 // Sphere::PDF(const ShapeSampleContext &, Vector3f wi), shapes.h:374-405
-WF_NI float SpherePDFP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float wx, float wy, float wz) {
-    const wf_sphere s = *sp;
+WF_NI float SpherePDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float wx, float wy, float wz) {
+    const wf_quadric s = *sp;
     const P3i ctxPi = *ctxPiP;
     const N3 ctxN{nx, ny, nz};
     const V3 wi{wx, wy, wz};
@@ -750,13 +911,13 @@ WF_NI float SpherePDFP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, fl
     V3 pCenter = XfPoint3(s.render_from_object.m, V3{0, 0, 0});
     V3 rp = ctxPi.mid();
     V3 pOrigin = OffsetRayOrigin(ctxPi, ctxN, pCenter - rp);
-    if (DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
+    if (s.type != WF_QUADRIC_SPHERE || DistanceSquared(pOrigin, pCenter) <= Sqr(radius)) {
         V3 o = OffsetRayOrigin(ctxPi, ctxN, wi);
         QuadricHit qh;
-        if (!SphereBasicIntersect(s, o, wi, WF_INFINITY, &qh)) return 0;
+        if (!QuadricBasicIntersect(s, o, wi, WF_INFINITY, &qh)) return 0;
         SurfIntr si;
         SphereInteractionP(sp, meshFlags, qh.pObj.x, qh.pObj.y, qh.pObj.z, &si);
-        float area = s.phi_max * radius * (s.z_max - s.z_min);
+        float area = QuadricArea(s);
         float pdf = (1 / area) / (AbsDot(si.n, -wi) / DistanceSquared(rp, si.pi.mid()));
         if (IsInf(pdf)) pdf = 0;
         return pdf;
@@ -768,7 +929,7 @@ WF_NI float SpherePDFP(const wf_sphere *sp, int meshFlags, const P3i *ctxPiP, fl
     return 1 / (2 * Pi * oneMinusCosThetaMax);
 }
 WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V3 wi) {
-    const wf_sphere *s = sv.spheres + (prim - sv.nTriangles);
+    const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
     return SpherePDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, wi.x, wi.y, wi.z);
 }

@@ -236,7 +236,7 @@ struct GeneralPrims {
     const SceneView &sv;
     V3 o, d;
     __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
-    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return SphereBasicIntersect(sv.spheres[prim - sv.nTriangles], o, d, tMax, qh); }
+    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], o, d, tMax, qh); }
 };
 template <bool ANY, bool ALPHA, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
@@ -515,7 +515,7 @@ static int checkReady(wf_ctx *ctx) {
 static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, FastBVH *out) {
     const wf_bvh_node *L = d->bvh_nodes;
     const int n = d->n_bvh_nodes;
-    const int nPrims = d->n_triangles + d->n_spheres;
+    const int nPrims = d->n_triangles + d->n_quadrics;
     if (n == 0 || (size_t)nPrims >= (1u << 27)) return false;
     for (int i = 0; i < n; ++i)
         if (L[i].nprims > 16) return false;
@@ -523,7 +523,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     for (int k = 0; k < nPrims; ++k) {
         int t = d->bvh_prims[k];
         if (t >= d->n_triangles) {
-            // a sphere: c.z == 3, tested by the general-primitive kernel variants from wf_sphere (object space)
+            // a sphere: c.z == 3, tested by the general-primitive kernel variants from wf_quadric (object space)
             const wf_mesh &mesh = d->meshes[d->tri_mesh[t]];
             uint32_t route = mesh.material >= 0 ? (uint32_t)d->materials[mesh.material].type | (mesh.first_light >= 0 ? 16u : 0u) : 32u;
             LeafTri lt;
@@ -680,15 +680,15 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.N, d->N, (size_t)3 * d->n_vertices))) return e;
     if ((e = devUpload(ctx, &sv.UV, d->UV, (size_t)2 * d->n_vertices))) return e;
     if ((e = devUpload(ctx, &sv.triIndices, d->tri_indices, (size_t)3 * d->n_triangles))) return e;
-    if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles + d->n_spheres))) return e;
-    if ((e = devUpload(ctx, &sv.spheres, d->spheres, (size_t)d->n_spheres))) return e;
+    if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles + d->n_quadrics))) return e;
+    if ((e = devUpload(ctx, &sv.quadrics, d->quadrics, (size_t)d->n_quadrics))) return e;
     if ((e = devUpload(ctx, &sv.haltonPrimes, d->halton_primes, d->halton_primes ? (size_t)1000 : (size_t)0))) return e;
     if ((e = devUpload(ctx, &sv.haltonPermOffsets, d->halton_perm_offsets, d->halton_perm_offsets ? (size_t)1000 : (size_t)0))) return e;
     if ((e = devUpload(ctx, &sv.haltonPerms, d->halton_perms, (size_t)d->n_halton_perms))) return e;
-    sv.nSpheres = d->n_spheres;
+    sv.nQuadrics = d->n_quadrics;
     if ((e = devUpload(ctx, &sv.meshes, d->meshes, (size_t)d->n_meshes))) return e;
     if ((e = devUpload(ctx, &sv.bvhNodes, d->bvh_nodes, (size_t)d->n_bvh_nodes))) return e;
-    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles + d->n_spheres))) return e;
+    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles + d->n_quadrics))) return e;
     sv.nTriangles = d->n_triangles;
     sv.nBvhNodes = d->n_bvh_nodes;
     if ((e = devUpload(ctx, &sv.spectra, d->spectra, (size_t)d->n_spectra))) return e;
@@ -718,7 +718,9 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.filter = d->filter;
     if ((e = devUpload(ctx, &sv.filterData, d->filter_data, (size_t)d->n_filter_floats))) return e;
     sv.sampler = d->sampler;
-    if (d->sampler.type < WF_SAMPLER_ZSOBOL || d->sampler.type > WF_SAMPLER_PADDED_SOBOL) return fail(-1, "unknown sampler type %d", d->sampler.type);
+    if (d->sampler.type < WF_SAMPLER_ZSOBOL || d->sampler.type > WF_SAMPLER_HALTON) return fail(-1, "unknown sampler type %d", d->sampler.type);
+    if (d->sampler.type == WF_SAMPLER_HALTON && (!d->halton_primes || (d->sampler.randomize == WF_RAND_PERMUTE_DIGITS && (!d->halton_perm_offsets || !d->halton_perms))))
+        return fail(-1, "Halton sampler without its prime / digit-permutation tables");
     static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
     if ((e = devUpload(ctx, &sv.sobol, sobol, (size_t)WF_SOBOL_WORDS))) return e;
@@ -900,7 +902,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     else if (ctx->fastOk) {
-        if (ctx->svHost.haveAlpha || ctx->svHost.nSpheres > 0) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
@@ -921,7 +923,7 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
     if (ctx->fastOk && !ctx->countTraversal)
-        if (ctx->svHost.haveAlpha || ctx->svHost.nSpheres > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
@@ -967,7 +969,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     else if (ctx->fastOk)
-        if (ctx->svHost.haveAlpha || ctx->svHost.nSpheres > 0) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
         else LAUNCHT("Intersect shadow", k_shadow_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);

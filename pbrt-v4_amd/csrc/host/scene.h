@@ -116,7 +116,7 @@ struct SceneTables {
     std::vector<float> P, N, UV;
     std::vector<int32_t> triIndices, triMesh, bvhPrims, infiniteLights;
     std::vector<wf_mesh> meshes;
-    std::vector<wf_sphere> spheres;
+    std::vector<wf_quadric> quadrics;
     std::vector<int32_t> haltonPrimes, haltonPermOffsets;
     std::vector<uint16_t> haltonPerms;
     std::vector<wf_bvh_node> bvhNodes;

@@ -10,6 +10,7 @@
 //   util/mesh.cpp:25-75, shapes.cpp:283-307,368-438  triangle meshes (vertices transformed to render space)
 #include "scene.h"
 #include "../common/wf_camera.h"
+#include "../common/wf_shapes.h"
 
 #include <algorithm>
 #include <cmath>
@@ -33,7 +34,7 @@ void SceneTables::Finalize() {
     desc.P = P.data(); desc.N = N.data(); desc.UV = UV.data();
     desc.tri_indices = triIndices.data(); desc.tri_mesh = triMesh.data();
     desc.meshes = meshes.data(); desc.bvh_nodes = bvhNodes.data(); desc.bvh_prims = bvhPrims.data();
-    desc.n_spheres = (int)spheres.size(); desc.spheres = spheres.data();
+    desc.n_quadrics = (int)quadrics.size(); desc.quadrics = quadrics.data();
     desc.halton_primes = haltonPrimes.empty() ? nullptr : haltonPrimes.data();
     desc.halton_perm_offsets = haltonPermOffsets.empty() ? nullptr : haltonPermOffsets.data();
     desc.halton_perms = haltonPerms.empty() ? nullptr : haltonPerms.data();
@@ -1147,24 +1148,38 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         }
         sh.params.ReportUnused("Shape");
     };
-    struct PendingSphere { wf_sphere s; int orderPos; B3 bounds; };
+    struct PendingSphere { wf_quadric s; int orderPos; B3 bounds; };
     std::vector<PendingSphere> spheres;
     std::map<int, int> sphereOfMesh;
     auto addShape = [&](const ShapeEntity &sh, const Transform *extra) {
-        if (sh.name == "sphere") {
-            // Sphere::Create + ctor (shapes.cpp:71-81, shapes.h:117-129); kept in object space like the reference's
-            if (extra) Die(sh.loc, "spheres inside object instances are not supported by this build yet");
+        if (sh.name == "sphere" || sh.name == "disk" || sh.name == "cylinder") {
+            // Sphere / Disk / Cylinder::Create + ctors (shapes.cpp:71-81,106-115,132-142; shapes.h:117-129,387-398,737-748);
+            // kept in object space like the reference's
+            if (extra) Die(sh.loc, "quadrics inside object instances are not supported by this build yet");
             const Transform &rfo = sh.renderFromObject;
             const ParamSet &ps = sh.params;
             float radius = ps.GetOneFloat("radius", 1.f);
-            float zmin = ps.GetOneFloat("zmin", -radius), zmax = ps.GetOneFloat("zmax", radius), phimax = ps.GetOneFloat("phimax", 360.f);
             auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };
             PendingSphere p{};
             p.s.radius = radius;
-            p.s.z_min = clampf(std::min(zmin, zmax), -radius, radius);
-            p.s.z_max = clampf(std::max(zmin, zmax), -radius, radius);
-            p.s.theta_z_min = std::acos(clampf(std::min(zmin, zmax) / radius, -1, 1));
-            p.s.theta_z_max = std::acos(clampf(std::max(zmin, zmax) / radius, -1, 1));
+            if (sh.name == "sphere") {
+                p.s.type = WF_QUADRIC_SPHERE;
+                float zmin = ps.GetOneFloat("zmin", -radius), zmax = ps.GetOneFloat("zmax", radius);
+                p.s.z_min = clampf(std::min(zmin, zmax), -radius, radius);
+                p.s.z_max = clampf(std::max(zmin, zmax), -radius, radius);
+                p.s.theta_z_min = std::acos(clampf(std::min(zmin, zmax) / radius, -1, 1));
+                p.s.theta_z_max = std::acos(clampf(std::max(zmin, zmax) / radius, -1, 1));
+            } else if (sh.name == "disk") {
+                p.s.type = WF_QUADRIC_DISK;
+                p.s.z_min = p.s.z_max = ps.GetOneFloat("height", 0.f);
+                p.s.inner_radius = ps.GetOneFloat("innerradius", 0.f);
+            } else {
+                p.s.type = WF_QUADRIC_CYLINDER;
+                float zmin = ps.GetOneFloat("zmin", -1.f), zmax = ps.GetOneFloat("zmax", 1.f);
+                p.s.z_min = std::min(zmin, zmax);
+                p.s.z_max = std::max(zmin, zmax);
+            }
+            float phimax = ps.GetOneFloat("phimax", 360.f);
             p.s.phi_max = Radians(clampf(phimax, 0, 360));
             p.s.render_from_object = rfo.abi();
             for (int j = 0; j < 3; ++j)
@@ -1233,7 +1248,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         for (size_t i = 0; i < spheres.size(); ++i) {
             T->meshes[spheres[i].s.mesh].first_tri = nTris + (int)i;
             T->triMesh.push_back(spheres[i].s.mesh);
-            T->spheres.push_back(spheres[i].s);
+            T->quadrics.push_back(spheres[i].s);
         }
     }
 
@@ -1267,7 +1282,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         float LemitMax = MakeDense(*L)->MaxValue();
         if (auto sit = sphereOfMesh.find(pa.mesh); sit != sphereOfMesh.end()) {
             const PendingSphere &sp = spheres[sit->second];
-            float area = sp.s.phi_max * sp.s.radius * (sp.s.z_max - sp.s.z_min);  // Sphere::Area (shapes.h:292)
+            float area = QuadricArea(sp.s);  // Sphere / Disk / Cylinder::Area (shapes.h:292,407,559)
             float sc = scale;
             if (phi_v > 0) {
                 float k_e = 1;
@@ -1290,6 +1305,13 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             lb.w = Normalize(V3{0, 0, 1});
             lb.phi = LemitMax * (sc * area * Pi);
             lb.cosTheta_o = -1.f;
+            if (sp.s.type == WF_QUADRIC_DISK) {
+                // Disk::NormalBounds (shapes.cpp:89-94): DirectionCone(Vector3f(n)) normalizes, the LightBounds ctor again
+                N3 n = pa.renderFromObject.Normal(N3{0, 0, 1});
+                if (T->meshes[sp.s.mesh].flags & WF_MESH_REVERSE_ORIENTATION) n = -n;
+                lb.w = Normalize(Normalize(toV(n)));
+                lb.cosTheta_o = 1.f;
+            }
             lb.cosTheta_e = std::cos(Pi / 2);
             lb.twoSided = twoSided;
             addLightBounds(lightId, lb);

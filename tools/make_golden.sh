@@ -21,6 +21,7 @@ make_scenes.image_textures("tests/golden/image_textures.pbrt", (64, 64), 4)
 make_scenes.alpha_normalmap("tests/golden/alpha_normalmap.pbrt", (64, 64), 4)
 make_scenes.mix_materials("tests/golden/mix_materials.pbrt", (64, 64), 64)
 make_scenes.spheres("tests/golden/spheres.pbrt", (64, 64), 4)
+make_scenes.quadrics("tests/golden/quadrics.pbrt", (64, 64), 4)
 PY
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_ref.pfm $G/cornell64.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_small_ref.pfm $G/blobs_small.pbrt
@@ -31,6 +32,7 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/image_textures_ref.pfm $G/image_textures.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/alpha_normalmap_ref.pfm $G/alpha_normalmap.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spheres_ref.pfm $G/spheres.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_ref.pfm $G/quadrics.pbrt
 # MixMaterial: the reference's choice hashes heap pointers -> statistical comparison only (64 spp, block means)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/mix_materials_ref.pfm $G/mix_materials.pbrt
 # the same lights through the PowerLightSampler (alias table)
