@@ -157,7 +157,9 @@ enum wf_light_type {
     WF_LIGHT_SPOT = 2,
     WF_LIGHT_DIFFUSE_AREA = 3,
     WF_LIGHT_UNIFORM_INFINITE = 4,
-    WF_LIGHT_IMAGE_INFINITE = 5
+    WF_LIGHT_IMAGE_INFINITE = 5,
+    WF_LIGHT_PROJECTION = 7,          /* lights.h:280-350: xform = renderFromLight * Scale(1,-1,1), xform2 = screenFromLight, image = RGB wf_tex_image */
+    WF_LIGHT_GONIOMETRIC = 6          /* lights.h:353-404: xform = renderFromLight * swapYZ, image = one-channel wf_tex_image, area = mean texel */
 };
 typedef struct wf_light {
     int32_t type;
@@ -173,8 +175,10 @@ typedef struct wf_light {
     float sceneCenter[3];        /* DISTANT / infinite: set by Preprocess (lights.h:243,546) */
     float sceneRadius;
     int32_t xform;               /* index into light_transforms (SPOT / IMAGE_INFINITE), or -1 */
-    int32_t image;               /* IMAGE_INFINITE: index into image_lights */
-    int32_t pad[2];
+    int32_t image;               /* IMAGE_INFINITE: index into image_lights; GONIOMETRIC / PROJECTION: index into tex_images */
+    int32_t xform2;              /* PROJECTION: screenFromLight in light_transforms */
+    int32_t pad;
+    float screen_bounds[4];      /* PROJECTION: screenBounds pMin.xy, pMax.xy */
 } wf_light;
 #define WF_LIGHTFLAG_TWOSIDED 1
 
@@ -257,7 +261,7 @@ typedef struct wf_quadric {
     wf_transform render_from_object;   /* m = renderFromObject, mInv = objectFromRender */
 } wf_quadric;
 
-enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1 };
+enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1, WF_CAMERA_SPHERICAL = 2 };
 typedef struct wf_camera {
     int32_t type;
     wf_transform cameraFromRaster;      /* cameras.h:ProjectiveCamera */
@@ -268,6 +272,7 @@ typedef struct wf_camera {
     float minPosDifferentialX[3], minPosDifferentialY[3];
     float minDirDifferentialX[3], minDirDifferentialY[3];
     int32_t medium;
+    int32_t spherical_mapping;          /* SphericalCamera (cameras.h:370-420): 0 equal-area, 1 equirectangular */
 } wf_camera;
 
 enum wf_filter_type { WF_FILTER_BOX = 0, WF_FILTER_GAUSSIAN = 1, WF_FILTER_MITCHELL = 2,

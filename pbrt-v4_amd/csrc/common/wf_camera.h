@@ -462,6 +462,29 @@ WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy)
 struct CameraRayR { V3 o, d; float time; bool valid; };
 WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSample, V2 pLens) {
     const wf_camera &C = sv.camera;
+    if (C.type == WF_CAMERA_SPHERICAL) {
+        // SphericalCamera::GenerateRay, cameras.cpp:610-630
+        V2 uv{pFilm.x / sv.film.full_res[0], pFilm.y / sv.film.full_res[1]};
+        V3 dir;
+        if (C.spherical_mapping == 1) {
+            float theta = Pi * uv.y, phi = 2 * Pi * uv.x;
+            dir = SphericalDirection(sin(theta), cos(theta), phi);
+        } else {
+            // WrapEqualAreaSquare, util/math.cpp:363-379
+            if (uv.x < 0) { uv.x = -uv.x; uv.y = 1 - uv.y; }
+            else if (uv.x > 1) { uv.x = 2 - uv.x; uv.y = 1 - uv.y; }
+            if (uv.y < 0) { uv.x = 1 - uv.x; uv.y = -uv.y; }
+            else if (uv.y > 1) { uv.x = 1 - uv.x; uv.y = 2 - uv.y; }
+            dir = EqualAreaSquareToSphere(uv);
+        }
+        { float t = dir.y; dir.y = dir.z; dir.z = t; }
+        V3 so{0, 0, 0};
+        float stime = Lerp(timeSample, C.shutterOpen, C.shutterClose);
+        XfRay(C.renderFromCamera.m, &so, &dir);
+        const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+        XfRay(I, &so, &dir);
+        return {so, dir, stime, true};
+    }
     V3 pCamera = XfPoint(C.cameraFromRaster.m, V3{pFilm.x, pFilm.y, 0});
     V3 o, d;
     if (C.type == WF_CAMERA_PERSPECTIVE) {

@@ -24,7 +24,9 @@ struct LightLiSample {
     bool valid;
 };
 
-WF_HD bool IsDeltaLight(int type) { return type == WF_LIGHT_POINT || type == WF_LIGHT_SPOT || type == WF_LIGHT_DISTANT; }
+WF_HD bool IsDeltaLight(int type) {
+    return type == WF_LIGHT_POINT || type == WF_LIGHT_SPOT || type == WF_LIGHT_DISTANT || type == WF_LIGHT_GONIOMETRIC || type == WF_LIGHT_PROJECTION;
+}
 
 WF_HD float SmoothStep(float x, float a, float b) {
     if (a == b) return (x < a) ? 0 : 1;
@@ -59,6 +61,19 @@ WF_HD float PC2DPDF(const float *D, const wf_pc2d &t, V2 p) {
 }
 // ImageInfiniteLight::ImageLe (lights.h:640-647): nearest texel with octahedral wrap (util/image.h:96-125,352-356),
 // RGBIlluminantSpectrum of the clamped RGB (util/spectrum.cpp:235-246, util/spectrum.h:606-626)
+// RGBIlluminantSpectrum(cs, ClampZero(rgb)).Sample(lambda) (util/spectrum.cpp:2674-2680, spectrum.h:620-640)
+WF_HD S4 RGBIlluminantSample(const SceneView &sv, float r, float g, float b, const Wavelengths &lambda) {
+    float rgb[3] = {fmax(0.f, r), fmax(0.f, g), fmax(0.f, b)};
+    float m = fmax(fmax(rgb[0], rgb[1]), rgb[2]);
+    float scale = 2 * m;
+    float in[3] = {0, 0, 0};
+    if (scale) { in[0] = rgb[0] / scale; in[1] = rgb[1] / scale; in[2] = rgb[2] / scale; }
+    float c[3];
+    RGBToSpectrumCoeffs(sv, in, c);
+    S4 s;
+    for (int i = 0; i < 4; ++i) s[i] = scale * SigmoidPoly(lambda.lambda[i], c[0], c[1], c[2]);
+    return s * DenseSample(sv, sv.csIlluminantOffset, lambda);
+}
 WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavelengths &lambda) {
     const wf_image_light &im = sv.imageLights[l.image];
     const int res = im.res;
@@ -69,17 +84,7 @@ WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavel
     else if (py >= res) { px = res - 1 - px; py = 2 * res - 1 - py; }
     if (res == 1) { px = 0; py = 0; }
     const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
-    float rgb[3] = {fmax(0.f, texel[0]), fmax(0.f, texel[1]), fmax(0.f, texel[2])};
-    float m = fmax(fmax(rgb[0], rgb[1]), rgb[2]);
-    float scale = 2 * m;
-    float in[3] = {0, 0, 0};
-    if (scale) { in[0] = rgb[0] / scale; in[1] = rgb[1] / scale; in[2] = rgb[2] / scale; }
-    float c[3];
-    RGBToSpectrumCoeffs(sv, in, c);
-    S4 s;
-    for (int i = 0; i < 4; ++i) s[i] = scale * SigmoidPoly(lambda.lambda[i], c[0], c[1], c[2]);
-    S4 spec = s * DenseSample(sv, sv.csIlluminantOffset, lambda);
-    return l.scale * spec;
+    return l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda);
 }
 WF_HD V3 XfApply3(const float m[4][4], V3 v) {
     return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
@@ -118,6 +123,42 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
         V3 wLight = Normalize(wl);
         S4 I = SmoothStep(wLight.z, l.cosFalloffEnd, l.cosFalloffStart) * l.scale * DenseSample(sv, l.spectrum_offset, lambda);
         S4 Li = I / DistanceSquared(p, ctx.p());
+        if (!Li) return ls;
+        ls.L = Li; ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(p); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
+    case WF_LIGHT_GONIOMETRIC: {
+        // GoniometricLight::SampleLi / I (lights.cpp:538-547, lights.h:393-396): Image::LookupNearestChannel, clamp wrap
+        V3 p{l.pos[0], l.pos[1], l.pos[2]};
+        V3 wi = Normalize(p - ctx.p());
+        V3 w = XfApply3(sv.lightXforms[l.xform].mInv, -wi);
+        V2 uv = EqualAreaSphereToSquare(w);
+        const wf_tex_image &im = sv.texImages[l.image];
+        int x = (int)(uv.x * im.res[0]), y = (int)(uv.y * im.res[1]);
+        x = x < 0 ? 0 : (x > im.res[0] - 1 ? im.res[0] - 1 : x);
+        y = y < 0 ? 0 : (y > im.res[1] - 1 ? im.res[1] - 1 : y);
+        S4 I = l.scale * DenseSample(sv, l.spectrum_offset, lambda) * sv.tableData[im.level_offset[0] + (size_t)y * im.res[0] + x];
+        ls.L = I / DistanceSquared(p, ctx.p());
+        ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(p); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+        return ls;
+    }
+    case WF_LIGHT_PROJECTION: {
+        // ProjectionLight::SampleLi / I (lights.cpp:324-360)
+        V3 p{l.pos[0], l.pos[1], l.pos[2]};
+        V3 wi = Normalize(p - ctx.p());
+        V3 wl = XfApply3(sv.lightXforms[l.xform].mInv, -wi);
+        if (wl.z < 1e-3f) return ls;
+        V3 ps = XfPoint(sv.lightXforms[l.xform2].m, wl);
+        if (!(ps.x >= l.screen_bounds[0] && ps.x <= l.screen_bounds[2] && ps.y >= l.screen_bounds[1] && ps.y <= l.screen_bounds[3])) return ls;
+        V2 uv{ps.x - l.screen_bounds[0], ps.y - l.screen_bounds[1]};
+        if (l.screen_bounds[2] > l.screen_bounds[0]) uv.x /= l.screen_bounds[2] - l.screen_bounds[0];
+        if (l.screen_bounds[3] > l.screen_bounds[1]) uv.y /= l.screen_bounds[3] - l.screen_bounds[1];
+        const wf_tex_image &im = sv.texImages[l.image];
+        int x = (int)(uv.x * im.res[0]), y = (int)(uv.y * im.res[1]);
+        x = x < 0 ? 0 : (x > im.res[0] - 1 ? im.res[0] - 1 : x);
+        y = y < 0 ? 0 : (y > im.res[1] - 1 ? im.res[1] - 1 : y);
+        const float *texel = sv.tableData + im.level_offset[0] + 3 * ((size_t)y * im.res[0] + x);
+        S4 Li = l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda) / DistanceSquared(p, ctx.p());
         if (!Li) return ls;
         ls.L = Li; ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(p); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
         return ls;

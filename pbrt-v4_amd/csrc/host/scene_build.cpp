@@ -774,6 +774,38 @@ static void BuildPowerAlias(SceneTables *T) {
             phi = l.scale * Ls * 2 * Pi * ((1 - l.cosFalloffStart) + (l.cosFalloffStart - l.cosFalloffEnd) / 2);
             break;
         case WF_LIGHT_DISTANT: phi = l.scale * Ls * Pi * Sqr(l.sceneRadius); break;           // lights.cpp:216-218
+        case WF_LIGHT_PROJECTION: {                                                           // lights.cpp:362-382
+            const wf_tex_image &im = T->texImages[l.image];
+            const ColorSpace *ics = SpectralData::Get().sRGB();
+            Mat4 lm, lmi;
+            std::memcpy(lm.m, T->lightTransforms[l.xform2].mInv, sizeof(lm.m));
+            std::memcpy(lmi.m, T->lightTransforms[l.xform2].m, sizeof(lmi.m));
+            Transform lightFromScreen(lm, lmi);
+            S4 sum = S4c(0.f);
+            const int w = im.res[0], h = im.res[1];
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    float tx = (x + 0.5f) / w, ty = (y + 0.5f) / h;
+                    V2 p2{(1 - tx) * l.screen_bounds[0] + tx * l.screen_bounds[2], (1 - ty) * l.screen_bounds[1] + ty * l.screen_bounds[3]};
+                    V3 wv = Normalize(lightFromScreen.Point(V3{p2.x, p2.y, 0}));
+                    float dwdA = wv.z * wv.z * wv.z;
+                    const float *px = &T->tableData[im.level_offset[0] + 3 * ((size_t)y * w + x)];
+                    float rgb[3] = {std::max(0.f, px[0]), std::max(0.f, px[1]), std::max(0.f, px[2])};
+                    SpectrumP sp = ics->Illuminant(rgb);
+                    S4 s;
+                    for (int i = 0; i < 4; ++i) s[i] = sp->scale * SigmoidPoly(lambda.lambda[i], sp->c0, sp->c1, sp->c2);
+                    sum = sum + (s * Ls) * dwdA;  // Ls = the colour space's illuminant at lambda
+                }
+            phi = l.scale * l.area * sum / (float)(w * h);
+            break;
+        }
+        case WF_LIGHT_GONIOMETRIC: {                                                          // lights.cpp:554-561
+            const wf_tex_image &im = T->texImages[l.image];
+            float sumY = 0;
+            for (size_t i = 0; i < (size_t)im.res[0] * im.res[1]; ++i) sumY += T->tableData[im.level_offset[0] + i];
+            phi = l.scale * Ls * 4 * Pi * sumY / (float)(im.res[0] * im.res[1]);
+            break;
+        }
         case WF_LIGHT_DIFFUSE_AREA:                                                           // lights.cpp:769-786
             phi = Pi * ((l.flags & WF_LIGHTFLAG_TWOSIDED) ? 2 : 1) * l.area * (Ls * l.scale);
             break;
@@ -860,7 +892,16 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
     } else if (scene.camera.name == "orthographic") {
         C.type = WF_CAMERA_ORTHOGRAPHIC;
         screenFromCamera = Orthographic(0, 1);
-    } else Die(scene.camera.loc, scene.camera.name + ": camera type not supported by this build (perspective, orthographic)");
+    } else if (scene.camera.name == "spherical") {
+        // SphericalCamera::Create (cameras.cpp:632-690): lens and screen window parameters are read and ignored
+        C.type = WF_CAMERA_SPHERICAL;
+        std::string m = ps.GetOneString("mapping", "equalarea");
+        if (m == "equalarea") C.spherical_mapping = 0;
+        else if (m == "equirectangular") C.spherical_mapping = 1;
+        else Die(scene.camera.loc, m + ": unknown mapping for spherical camera. (Must be \"equalarea\" or \"equirectangular\".)");
+        screenFromCamera = Orthographic(0, 1);  // unused by the spherical camera
+        lensradius = 0;
+    } else Die(scene.camera.loc, scene.camera.name + ": camera type not supported by this build (perspective, orthographic, spherical)");
     // ProjectiveCamera (cameras.h:243-263)
     Transform NDCFromScreen = Scale(1 / (sMaxX - sMinX), 1 / (sMaxY - sMinY), 1) * Translate(V3{-sMinX, -sMaxY, 0});
     Transform rasterFromNDC = Scale((float)F.full_res[0], -(float)F.full_res[1], 1);
@@ -880,6 +921,40 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
         for (int i = 0; i < 3; ++i) { C.minPosDifferentialX[i] = dx[i]; C.minPosDifferentialY[i] = dy[i]; }
     }
     for (int i = 0; i < 3; ++i) { C.dxCamera[i] = dx[i]; C.dyCamera[i] = dy[i]; }
+    if (C.type == WF_CAMERA_SPHERICAL) {
+        // CameraBase::FindMinimumDifferentials (cameras.cpp:153-203) over the generic CameraBase::GenerateRayDifferential
+        // (cameras.cpp:116-152: finite differences of GenerateRay at +-0.05 pixel)
+        const float INF = std::numeric_limits<float>::infinity();
+        V3 minPosX{INF, INF, INF}, minPosY = minPosX, minDirX = minPosX, minDirY = minPosX;
+        SceneView tmp{};
+        tmp.camera = C;
+        tmp.film = F;
+        const int n = 512;
+        for (int i = 0; i < n; ++i) {
+            V2 pFilm{float(i) / (n - 1) * F.full_res[0], float(i) / (n - 1) * F.full_res[1]};
+            CameraRayR cr = GenerateCameraRay(tmp, pFilm, 0.5f, V2{0.5f, 0.5f});
+            const float eps = .05f;  // GenerateRay never fails for this camera, so the first eps is taken
+            CameraRayR rx = GenerateCameraRay(tmp, V2{pFilm.x + eps, pFilm.y}, 0.5f, V2{0.5f, 0.5f});
+            CameraRayR ry = GenerateCameraRay(tmp, V2{pFilm.x, pFilm.y + eps}, 0.5f, V2{0.5f, 0.5f});
+            V3 rxo = cr.o + (rx.o - cr.o) / eps, rxd = cr.d + (rx.d - cr.d) / eps;
+            V3 ryo = cr.o + (ry.o - cr.o) / eps, ryd = cr.d + (ry.d - cr.d) / eps;
+            V3 dox = XfVector(C.renderFromCamera.mInv, rxo - cr.o);
+            if (Length(dox) < Length(minPosX)) minPosX = dox;
+            V3 doy = XfVector(C.renderFromCamera.mInv, ryo - cr.o);
+            if (Length(doy) < Length(minPosY)) minPosY = doy;
+            V3 rd = Normalize(cr.d);
+            rxd = Normalize(rxd); ryd = Normalize(ryd);
+            Frame f = Frame::FromZ(rd);
+            V3 df = f.ToLocal(rd);
+            V3 dxf = Normalize(f.ToLocal(rxd)), dyf = Normalize(f.ToLocal(ryd));
+            if (Length(dxf - df) < Length(minDirX)) minDirX = dxf - df;
+            if (Length(dyf - df) < Length(minDirY)) minDirY = dyf - df;
+        }
+        for (int k = 0; k < 3; ++k) {
+            C.minPosDifferentialX[k] = minPosX[k]; C.minPosDifferentialY[k] = minPosY[k];
+            C.minDirDifferentialX[k] = minDirX[k]; C.minDirDifferentialY[k] = minDirY[k];
+        }
+    }
     if (C.type == WF_CAMERA_PERSPECTIVE) {
         // CameraBase::FindMinimumDifferentials (cameras.cpp:153-203) over PerspectiveCamera::GenerateRayDifferential
         // (cameras.cpp:429-478) with pLens = (0.5, 0.5), time = 0.5
@@ -1420,6 +1495,123 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             float cosTheta_e = std::cos(std::acos(l.cosFalloffEnd) - std::acos(l.cosFalloffStart));
             if (cosTheta_e == 1 && l.cosFalloffEnd != l.cosFalloffStart) cosTheta_e = 0.999f;
             lb.cosTheta_o = l.cosFalloffStart; lb.cosTheta_e = cosTheta_e; lb.twoSided = false;
+            addLightBounds(lightId, lb);
+        } else if (le.name == "projection") {
+            // ProjectionLight::Create + ctor + Bounds (lights.cpp:448-518, 287-321, 384-399); .pfm only in this build
+            float sc = ps.GetOneFloat("scale", 1);
+            float power = ps.GetOneFloat("power", -1);
+            float fov = ps.GetOneFloat("fov", 90.f);
+            std::string filename = ps.GetOneString("filename", "");
+            if (filename.empty()) Die(le.loc, "Must provide \"filename\" to \"projection\" light source");
+            if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
+            std::vector<float> rgb;
+            int w = 0, h = 0;
+            if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
+                Die(le.loc, filename + ": unable to read image (this build reads .pfm images)");
+            { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; bool grey = false; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); }
+              if (grey) Die(le.loc, "Image provided to \"projection\" light must have R, G, and B channels."); }
+            for (float v : rgb) if (!std::isfinite(v)) Die(le.loc, filename + ": image has infinite or not-a-number pixel values and so is not suitable as a light.");
+            const ColorSpace *ics = SpectralData::Get().sRGB();
+            wf_tex_image im{};
+            im.res[0] = w; im.res[1] = h; im.n_levels = 1; im.n_channels = 3; im.wrap = WF_WRAP_CLAMP; im.filter = WF_MIP_POINT;
+            im.level_offset[0] = (int)T->tableData.size();
+            T->tableData.insert(T->tableData.end(), rgb.begin(), rgb.end());
+            l.image = (int)T->texImages.size();
+            T->texImages.push_back(im);
+            sc /= SpectrumToPhotometric(*ics->illuminant);
+            const float hither = 1e-3f;
+            float aspect = float(w) / float(h);
+            float sb[4];
+            if (aspect > 1) { sb[0] = -aspect; sb[1] = -1; sb[2] = aspect; sb[3] = 1; }
+            else { sb[0] = -1; sb[1] = -1 / aspect; sb[2] = 1; sb[3] = 1 / aspect; }
+            Transform screenFromLight = Perspective(fov, hither, 1e30f);
+            Transform lightFromScreen = Inverse(screenFromLight);
+            float opposite = std::tan(Radians(fov) / 2);
+            float A = 4 * Sqr(opposite) * (aspect > 1 ? aspect : (1 / aspect));
+            auto screenLerp = [&](float tx, float ty) { return V2{(1 - tx) * sb[0] + tx * sb[2], (1 - ty) * sb[1] + ty * sb[3]}; };
+            if (power > 0) {
+                float sum = 0;
+                float lum[3];
+                for (int c = 0; c < 3; ++c) lum[c] = ics->XYZFromRGB.m[1][c];  // RGBColorSpace::LuminanceVector
+                for (int y = 0; y < h; ++y)
+                    for (int x = 0; x < w; ++x) {
+                        V2 p2 = screenLerp((x + .5f) / w, (y + .5f) / h);
+                        V3 wv = Normalize(lightFromScreen.Point(V3{p2.x, p2.y, 0}));
+                        float dwdA = wv.z * wv.z * wv.z;
+                        for (int c = 0; c < 3; ++c) sum += rgb[3 * ((size_t)y * w + x) + c] * lum[c] * dwdA;
+                    }
+                sc *= power / (A * sum / (w * h));
+            }
+            Transform rfl = le.renderFromLight * Scale(1, -1, 1);
+            l.type = WF_LIGHT_PROJECTION; l.scale = sc; l.spectrum_offset = T->pool.AddDense(*ics->illuminant);
+            l.area = A;
+            for (int k = 0; k < 4; ++k) l.screen_bounds[k] = sb[k];
+            // the device-side RGB -> spectrum table of the image's colour space
+            T->desc.rgb2spec_coeffs = ics->table->coeffs.data();
+            for (int i = 0; i < 64; ++i) T->desc.rgb2spec_znodes[i] = ics->table->zNodes[i];
+            T->desc.cs_illuminant_offset = l.spectrum_offset;
+            V3 p = rfl.Point(V3{0, 0, 0});
+            l.pos[0] = p.x; l.pos[1] = p.y; l.pos[2] = p.z;
+            l.xform = (int)T->lightTransforms.size();
+            T->lightTransforms.push_back(rfl.abi());
+            l.xform2 = (int)T->lightTransforms.size();
+            T->lightTransforms.push_back(screenFromLight.abi());
+            T->lights.push_back(l);
+            float sumMax = 0;
+            for (size_t i = 0; i < (size_t)w * h; ++i) sumMax += std::max(std::max(rgb[3 * i], rgb[3 * i + 1]), rgb[3 * i + 2]);
+            LightBoundsH lb;
+            lb.bounds.pMin = lb.bounds.pMax = p;
+            lb.w = Normalize(Normalize(rfl.Vector(V3{0, 0, 1})));
+            lb.phi = sc * sumMax / (w * h);
+            V3 wCorner = Normalize(lightFromScreen.Point(V3{sb[2], sb[3], 0}));
+            lb.cosTheta_o = std::cos(0.f); lb.cosTheta_e = wCorner.z; lb.twoSided = false;
+            addLightBounds(lightId, lb);
+        } else if (le.name == "goniometric") {
+            // GoniometricLight::Create + ctor + Bounds (lights.cpp:603-682, 521-536, 563-575); .pfm only in this build
+            SpectrumP I = ps.GetOneSpectrum("I", cs->illuminant, SpectrumType::Illuminant);
+            float sc = ps.GetOneFloat("scale", 1);
+            std::string filename = ps.GetOneString("filename", "");
+            if (filename.empty()) Die(le.loc, "goniometric light without a \"filename\" is not supported by this build");
+            if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
+            std::vector<float> rgb;
+            int w = 0, h = 0;
+            if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
+                Die(le.loc, filename + ": unable to read image (this build reads .pfm images)");
+            if (w != h) Die(le.loc, filename + ": image resolution is non-square. It's unlikely this is an equal-area environment map.");
+            bool grey = false;
+            { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); } }
+            wf_tex_image im{};
+            im.res[0] = w; im.res[1] = h; im.n_levels = 1; im.n_channels = 1; im.wrap = WF_WRAP_CLAMP; im.filter = WF_MIP_POINT;
+            im.level_offset[0] = (int)T->tableData.size();
+            float sumY = 0;
+            for (size_t i = 0; i < (size_t)w * h; ++i) {
+                float v = grey ? rgb[3 * i] : (rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3;  // ImageChannelValues::Average
+                if (!std::isfinite(v)) Die(le.loc, filename + ": image has infinite or not-a-number pixel values and so is not suitable as a light.");
+                T->tableData.push_back(v);
+                sumY += v;
+            }
+            l.image = (int)T->texImages.size();
+            T->texImages.push_back(im);
+            sc /= SpectrumToPhotometric(*I);
+            float phi_v = ps.GetOneFloat("power", -1);
+            if (phi_v > 0) {
+                float k_e = 4 * Pi * sumY / (w * h);
+                sc *= phi_v / k_e;
+            }
+            Transform swapYZ(M4(1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1));
+            Transform rfl = le.renderFromLight * swapYZ;
+            l.type = WF_LIGHT_GONIOMETRIC; l.scale = sc; l.spectrum_offset = T->pool.AddDense(*I);
+            l.area = sumY / (w * h);  // mean texel, for Phi (lights.cpp:554-561)
+            V3 p = rfl.Point(V3{0, 0, 0});
+            l.pos[0] = p.x; l.pos[1] = p.y; l.pos[2] = p.z;
+            l.xform = (int)T->lightTransforms.size();
+            T->lightTransforms.push_back(rfl.abi());
+            T->lights.push_back(l);
+            LightBoundsH lb;
+            lb.bounds.pMin = lb.bounds.pMax = p;
+            lb.w = Normalize(V3{0, 0, 1});
+            lb.phi = sc * MakeDense(*I)->MaxValue() * 4 * Pi * sumY / (w * h);
+            lb.cosTheta_o = std::cos(Pi); lb.cosTheta_e = std::cos(Pi / 2); lb.twoSided = false;
             addLightBounds(lightId, lb);
         } else if (le.name == "distant") {
             SpectrumP L = ps.GetOneSpectrum("L", cs->illuminant, SpectrumType::Illuminant);

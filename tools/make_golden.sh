@@ -35,6 +35,11 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spheres_r
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_ref.pfm $G/quadrics.pbrt
 # MixMaterial: the reference's choice hashes heap pointers -> statistical comparison only (64 spp, block means)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/mix_materials_ref.pfm $G/mix_materials.pbrt
+# the textures scene through the spherical camera (equirectangular mapping)
+sed 's/^Camera "perspective".*/Camera "spherical" "string mapping" "equirectangular"/; s/textures_bump.pfm/spherical_camera.pfm/' $G/textures_bump.pbrt > $G/spherical_camera.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spherical_camera_ref.pfm $G/spherical_camera.pbrt
+# goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
 sed 's/Integrator "volpath"/Integrator "volpath" "string lightsampler" [ "power" ]/' $G/materials_lights.pbrt > $G/materials_lights_power.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_power_ref.pfm $G/materials_lights_power.pbrt
