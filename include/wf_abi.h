@@ -48,7 +48,7 @@ typedef struct wf_transform {    /* util/transform.h:Transform — m and its inv
 /* Medium (media.h:226-352): HomogeneousMedium and GridMedium ("uniformgrid"), both with the Henyey-Greenstein
  * phase function.  Spectra are DenselySampledSpectrum tables (471 floats each in spectrum_data), already
  * multiplied by the medium's "scale" / Le scale as the reference's constructors do (media.h:233-241). */
-enum wf_medium_type { WF_MEDIUM_HOMOGENEOUS = 0, WF_MEDIUM_GRID = 1 };
+enum wf_medium_type { WF_MEDIUM_HOMOGENEOUS = 0, WF_MEDIUM_GRID = 1, WF_MEDIUM_RGB_GRID = 2 };
 typedef struct wf_medium {
     int32_t type;
     int32_t sigma_a_offset, sigma_s_offset, le_offset;   /* offsets into spectrum_data */
@@ -60,6 +60,10 @@ typedef struct wf_medium {
     int32_t nx, ny, nz, density_offset;                 /* SampledGrid<Float> density, offsets into medium_data */
     int32_t le_nx, le_ny, le_nz, le_scale_offset;       /* SampledGrid<Float> LeScale (already times 1/photometric(Le)) */
     int32_t maj_res[3], maj_offset;                     /* MajorantGrid 16^3 (media.h:105-133) */
+    /* RGBGridMedium (media.h:355-430): SampledGrid<RGBUnboundedSpectrum> sigma_a / sigma_s and SampledGrid<RGBIlluminantSpectrum>
+     * Le as {c0, c1, c2, scale} per cell in medium_data (-1 = grid absent); le_offset = the colour space's dense illuminant */
+    int32_t rgb_a_offset, rgb_s_offset, rgb_le_offset;
+    float sigma_scale, le_scale;
 } wf_medium;
 
 /* Spectrum (util/spectrum.h:48-67 TaggedPointer family) flattened to a 32-byte descriptor.

@@ -113,12 +113,32 @@ WF_HD void XfInvRay(const wf_transform &t, V3 *o, V3 *d, float *tMax) {
 // Medium::SamplePoint: HomogeneousMedium media.h:247-252, GridMedium media.h:283-317.  The spectra sampled at the
 // ray's wavelengths (sigma_a_spec.Sample(lambda) ...) do not depend on the point: MediumAtLambda holds them once per
 // ray instead of once per tracking event (same values).
-struct MediumAtLambda { S4 sigma_a, sigma_s, Le; };
+struct MediumAtLambda { S4 sigma_a, sigma_s, Le, lam; };
+// SampledGrid<RGB*Spectrum>::Lookup(p, convert) (util/containers.h:790-826): trilinear interpolation of the CONVERTED cells
+WF_HD S4 RGBGridCell(const float *v, int nx, int ny, int nz, int x, int y, int z, const S4 &lam) {
+    if (!(x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz)) return S4c(0.f);
+    const float *c = v + 4 * (((size_t)z * ny + y) * nx + x);
+    S4 s;
+    for (int i = 0; i < 4; ++i) s[i] = c[3] * SigmoidPoly(lam[i], c[0], c[1], c[2]);
+    return s;
+}
+WF_HD S4 LerpS(float t, const S4 &a, const S4 &b) { return (1 - t) * a + t * b; }
+WF_HD S4 RGBGridLookup(const float *v, int nx, int ny, int nz, V3 p, const S4 &lam) {
+    V3 ps{p.x * nx - .5f, p.y * ny - .5f, p.z * nz - .5f};
+    int ix = (int)floor(ps.x), iy = (int)floor(ps.y), iz = (int)floor(ps.z);
+    V3 d{ps.x - (float)ix, ps.y - (float)iy, ps.z - (float)iz};
+    S4 d00 = LerpS(d.x, RGBGridCell(v, nx, ny, nz, ix, iy, iz, lam), RGBGridCell(v, nx, ny, nz, ix + 1, iy, iz, lam));
+    S4 d10 = LerpS(d.x, RGBGridCell(v, nx, ny, nz, ix, iy + 1, iz, lam), RGBGridCell(v, nx, ny, nz, ix + 1, iy + 1, iz, lam));
+    S4 d01 = LerpS(d.x, RGBGridCell(v, nx, ny, nz, ix, iy, iz + 1, lam), RGBGridCell(v, nx, ny, nz, ix + 1, iy, iz + 1, lam));
+    S4 d11 = LerpS(d.x, RGBGridCell(v, nx, ny, nz, ix, iy + 1, iz + 1, lam), RGBGridCell(v, nx, ny, nz, ix + 1, iy + 1, iz + 1, lam));
+    return LerpS(d.z, LerpS(d.y, d00, d10), LerpS(d.y, d01, d11));
+}
 WF_HD MediumAtLambda MediumSpectra(const SceneView &sv, const wf_medium &M, const Wavelengths &lambda) {
     MediumAtLambda ml;
     ml.sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
     ml.sigma_s = DenseSample(sv, M.sigma_s_offset, lambda);
     ml.Le = (M.type == WF_MEDIUM_HOMOGENEOUS || M.is_emissive) ? DenseSample(sv, M.le_offset, lambda) : S4c(0.f);
+    for (int i = 0; i < 4; ++i) ml.lam[i] = lambda.lambda[i];
     return ml;
 }
 WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, const MediumAtLambda &ml, V3 p) {
@@ -132,6 +152,27 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
     }
     p = XfInvPoint(M.render_from_medium, p);
     p = BoundsOffset(M.bounds, p);
+    if (M.type == WF_MEDIUM_RGB_GRID) {
+        // RGBGridMedium::SamplePoint, media.h:377-401 (ml.Le = the colour space's illuminant at lambda)
+        mp.sigma_a = M.sigma_scale * (M.rgb_a_offset >= 0 ? RGBGridLookup(sv.mediumData + M.rgb_a_offset, M.nx, M.ny, M.nz, p, ml.lam) : S4c(1.f));
+        mp.sigma_s = M.sigma_scale * (M.rgb_s_offset >= 0 ? RGBGridLookup(sv.mediumData + M.rgb_s_offset, M.nx, M.ny, M.nz, p, ml.lam) : S4c(1.f));
+        mp.Le = S4c(0.f);
+        if (M.is_emissive) {
+            // the RGBIlluminantSpectrum cells: scale * sigmoid, times the illuminant, interpolated after conversion
+            const float *v = sv.mediumData + M.rgb_le_offset;
+            const int nx = M.nx, ny = M.ny, nz = M.nz;
+            V3 ps{p.x * nx - .5f, p.y * ny - .5f, p.z * nz - .5f};
+            int ix = (int)floor(ps.x), iy = (int)floor(ps.y), iz = (int)floor(ps.z);
+            V3 d{ps.x - (float)ix, ps.y - (float)iy, ps.z - (float)iz};
+            auto cell = [&](int x, int y, int z) { return RGBGridCell(v, nx, ny, nz, x, y, z, ml.lam) * ml.Le; };
+            S4 d00 = LerpS(d.x, cell(ix, iy, iz), cell(ix + 1, iy, iz));
+            S4 d10 = LerpS(d.x, cell(ix, iy + 1, iz), cell(ix + 1, iy + 1, iz));
+            S4 d01 = LerpS(d.x, cell(ix, iy, iz + 1), cell(ix + 1, iy, iz + 1));
+            S4 d11 = LerpS(d.x, cell(ix, iy + 1, iz + 1), cell(ix + 1, iy + 1, iz + 1));
+            mp.Le = M.le_scale * LerpS(d.z, LerpS(d.y, d00, d10), LerpS(d.y, d01, d11));
+        }
+        return mp;
+    }
     float d = GridLookup(sv.mediumData + M.density_offset, M.nx, M.ny, M.nz, p);
     mp.sigma_a = mp.sigma_a * d;
     mp.sigma_s = mp.sigma_s * d;
@@ -202,7 +243,7 @@ WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, cons
     XfInvRay(M.render_from_medium, &o, &d, &raytMax);
     float tMin, tMax;
     if (!BoundsIntersectT(M.bounds, o, d, raytMax, &tMin, &tMax)) return it;
-    it.sigma_t = sigma_a + sigma_s;
+    it.sigma_t = M.type == WF_MEDIUM_RGB_GRID ? S4c(1.f) : sigma_a + sigma_s;  // RGBGridMedium::SampleRay: sigma_t(1), media.h:413
     it.tMin = tMin;
     it.tMax = tMax;
     it.voxels = sv.mediumData + M.maj_offset;

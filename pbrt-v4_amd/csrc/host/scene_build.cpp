@@ -673,13 +673,14 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
         M.g = ps.GetOneFloat("g", 0.f);
         float sigmaScale = ps.GetOneFloat("scale", 1.f);
         if (!ps.GetOneString("preset", "").empty()) Die(e.loc, "medium \"preset\" tables are not supported by this build yet");
-        SpectrumP sig_a = ps.GetOneSpectrum("sigma_a", nullptr, SpectrumType::Unbounded);
+        const bool rgbGrid = e.name == "rgbgrid";  // its sigma_a / sigma_s / Le are per-cell RGB arrays
+        SpectrumP sig_a = rgbGrid ? nullptr : ps.GetOneSpectrum("sigma_a", nullptr, SpectrumType::Unbounded);
         if (!sig_a) sig_a = MakeConstant(1.f);
-        SpectrumP sig_s = ps.GetOneSpectrum("sigma_s", nullptr, SpectrumType::Unbounded);
+        SpectrumP sig_s = rgbGrid ? nullptr : ps.GetOneSpectrum("sigma_s", nullptr, SpectrumType::Unbounded);
         if (!sig_s) sig_s = MakeConstant(1.f);
         M.sigma_a_offset = dense(*sig_a, sigmaScale);
         M.sigma_s_offset = dense(*sig_s, sigmaScale);
-        SpectrumP Le = ps.GetOneSpectrum("Le", nullptr, SpectrumType::Illuminant);
+        SpectrumP Le = rgbGrid ? nullptr : ps.GetOneSpectrum("Le", nullptr, SpectrumType::Illuminant);
         if (e.name == "homogeneous") {
             M.type = WF_MEDIUM_HOMOGENEOUS;
             float LeScale = ps.GetOneFloat("Lescale", 1.f);
@@ -747,7 +748,77 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
                                 for (int xx = lo[0]; xx <= hi[0]; ++xx) mx = std::max(mx, lookup(xx, yy, zz));
                         T->mediumData.push_back(mx);
                     }
-        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid)");
+        } else if (e.name == "rgbgrid") {
+            // RGBGridMedium::Create + ctor (media.cpp:380-456, 339-378)
+            M.type = WF_MEDIUM_RGB_GRID;
+            std::vector<V3> a = ps.GetTuple3Array("sigma_a", "rgb"), s = ps.GetTuple3Array("sigma_s", "rgb"), le = ps.GetTuple3Array("Le", "rgb");
+            if (a.empty() && s.empty()) Die(e.loc, "RGB grid requires \"sigma_a\" and/or \"sigma_s\" parameter values.");
+            size_t nDensity = !a.empty() ? a.size() : s.size();
+            if (!a.empty() && !s.empty() && a.size() != s.size()) Die(e.loc, "Different number of samples provided for \"sigma_a\" and \"sigma_s\".");
+            if (!le.empty() && a.empty()) Die(e.loc, "RGB grid requires \"sigma_a\" if \"Le\" value provided.");
+            if (!le.empty() && nDensity != le.size()) Die(e.loc, "Wrong number of values for the \"Le\" parameter.");
+            M.nx = ps.GetOneInt("nx", 1); M.ny = ps.GetOneInt("ny", 1); M.nz = ps.GetOneInt("nz", 1);
+            if ((long long)nDensity != (long long)M.nx * M.ny * M.nz) Die(e.loc, "RGB grid medium has " + std::to_string(nDensity) + " density values; expected nx*ny*nz");
+            const ColorSpace *cs = ps.colorSpace;
+            // the cells as {c0, c1, c2, scale}; RGBSigmoidPolynomial::MaxValue (util/color.h:348-355) for the majorants
+            auto polyMax = [](float c0, float c1, float c2) {
+                float result = std::max(SigmoidPoly(360.f, c0, c1, c2), SigmoidPoly(830.f, c0, c1, c2));
+                float lambda = -c1 / (2 * c0);
+                if (lambda >= 360 && lambda <= 830) result = std::max(result, SigmoidPoly(lambda, c0, c1, c2));
+                return result;
+            };
+            std::vector<float> maxA, maxS;
+            auto pushGrid = [&](const std::vector<V3> &rgbs, bool illuminant, std::vector<float> *maxv) {
+                int off = (int)T->mediumData.size();
+                for (const V3 &c : rgbs) {
+                    float rgb[3] = {c.x, c.y, c.z};
+                    SpectrumP sp = illuminant ? cs->Illuminant(rgb) : cs->Unbounded(rgb);
+                    T->mediumData.push_back(sp->c0); T->mediumData.push_back(sp->c1); T->mediumData.push_back(sp->c2); T->mediumData.push_back(sp->scale);
+                    if (maxv) maxv->push_back(sp->scale * polyMax(sp->c0, sp->c1, sp->c2));
+                }
+                return off;
+            };
+            M.rgb_a_offset = a.empty() ? -1 : pushGrid(a, false, &maxA);
+            M.rgb_s_offset = s.empty() ? -1 : pushGrid(s, false, &maxS);
+            M.rgb_le_offset = le.empty() ? -1 : pushGrid(le, true, nullptr);
+            V3 p0 = ps.GetOnePoint3f("p0", V3{0, 0, 0}), p1 = ps.GetOnePoint3f("p1", V3{1, 1, 1});
+            for (int c = 0; c < 3; ++c) { M.bounds[c] = std::min(p0[c], p1[c]); M.bounds[3 + c] = std::max(p0[c], p1[c]); }
+            M.le_scale = ps.GetOneFloat("Lescale", 1.f);
+            M.g = ps.GetOneFloat("g", 0.f);
+            M.sigma_scale = ps.GetOneFloat("scale", 1.f);
+            M.is_emissive = !le.empty() && M.le_scale > 0;
+            M.le_offset = T->pool.AddDense(*cs->illuminant);
+            M.sigma_a_offset = M.sigma_s_offset = M.le_offset;  // unused by this medium type
+            M.render_from_medium = scene.mediaTransforms.at(nm.first).abi();
+            M.maj_res[0] = M.maj_res[1] = M.maj_res[2] = 16;
+            M.maj_offset = (int)T->mediumData.size();
+            const int nx = M.nx, ny = M.ny, nz = M.nz;
+            auto gridMax = [&](const std::vector<float> &v, const int lo[3], const int hi[3]) {
+                auto lookup = [&](int x, int y, int z) -> float {
+                    if (!(x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz)) return 0.f;
+                    return v[((size_t)z * ny + y) * nx + x];
+                };
+                float mx = lookup(lo[0], lo[1], lo[2]);
+                for (int zz = lo[2]; zz <= hi[2]; ++zz)
+                    for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                        for (int xx = lo[0]; xx <= hi[0]; ++xx) mx = std::max(mx, lookup(xx, yy, zz));
+                return mx;
+            };
+            for (int z = 0; z < 16; ++z)
+                for (int y = 0; y < 16; ++y)
+                    for (int x = 0; x < 16; ++x) {
+                        float b0[3] = {float(x) / 16, float(y) / 16, float(z) / 16};
+                        float b1[3] = {float(x + 1) / 16, float(y + 1) / 16, float(z + 1) / 16};
+                        int lo[3], hi[3];
+                        const int n3[3] = {nx, ny, nz};
+                        for (int c = 0; c < 3; ++c) {
+                            lo[c] = std::max((int)std::floor(b0[c] * n3[c] - .5f), 0);
+                            hi[c] = std::min((int)std::floor(b1[c] * n3[c] - .5f) + 1, n3[c] - 1);
+                        }
+                        float maxSigma_t = (a.empty() ? 1 : gridMax(maxA, lo, hi)) + (s.empty() ? 1 : gridMax(maxS, lo, hi));
+                        T->mediumData.push_back(M.sigma_scale * maxSigma_t);
+                    }
+        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid, rgbgrid)");
         (*ids)[nm.first] = (int)T->media.size();
         T->media.push_back(M);
     }

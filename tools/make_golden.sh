@@ -38,6 +38,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/mix_materials_ref
 # the textures scene through the spherical camera (equirectangular mapping)
 sed 's/^Camera "perspective".*/Camera "spherical" "string mapping" "equirectangular"/; s/textures_bump.pfm/spherical_camera.pfm/' $G/textures_bump.pbrt > $G/spherical_camera.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spherical_camera_ref.pfm $G/spherical_camera.pbrt
+# RGBGridMedium: hand-written scene tests/golden/rgbgrid_medium.pbrt (6x5x4 cells, absorbing + scattering + emitting)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rgbgrid_medium_ref.pfm $G/rgbgrid_medium.pbrt
 # goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
