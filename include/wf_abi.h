@@ -64,6 +64,9 @@ typedef struct wf_medium {
      * Le as {c0, c1, c2, scale} per cell in medium_data (-1 = grid absent); le_offset = the colour space's dense illuminant */
     int32_t rgb_a_offset, rgb_s_offset, rgb_le_offset;
     float sigma_scale, le_scale;
+    /* GridMedium "temperature" (media.h:305-318): SampledGrid<Float> of nx*ny*nz kelvins in medium_data, or -1 */
+    int32_t temperature_offset;
+    float temperature_shift, temperature_scale;
 } wf_medium;
 
 /* Spectrum (util/spectrum.h:48-67 TaggedPointer family) flattened to a 32-byte descriptor.

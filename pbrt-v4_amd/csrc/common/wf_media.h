@@ -179,7 +179,20 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
     mp.Le = S4c(0.f);
     if (M.is_emissive) {
         float scale = GridLookup(sv.mediumData + M.le_scale_offset, M.le_nx, M.le_ny, M.le_nz, p);
-        if (scale > 0) mp.Le = scale * ml.Le;
+        if (scale > 0) {
+            if (M.temperature_offset >= 0) {
+                // blackbody emission from the temperature grid (media.h:305-318, util/spectrum.h:486-520)
+                float temp = GridLookup(sv.mediumData + M.temperature_offset, M.nx, M.ny, M.nz, p);
+                temp = (temp - M.temperature_shift) * M.temperature_scale;
+                if (temp > 100.f) {
+                    float lambdaMax = 2.8977721e-3f / temp;
+                    float norm = 1 / Blackbody(lambdaMax * 1e9f, temp);
+                    S4 bb;
+                    for (int i = 0; i < 4; ++i) bb[i] = Blackbody(ml.lam[i], temp) * norm;
+                    mp.Le = scale * bb;
+                }
+            } else mp.Le = scale * ml.Le;
+        }
     }
     return mp;
 }

@@ -665,6 +665,7 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
         const ParamSet &ps = e.params;
         if (ids->count(nm.first)) Die(e.loc, nm.first + ": named medium redefined.");
         wf_medium M{};
+        M.temperature_offset = -1;
         auto dense = [&](const SpectrumH &s, float scale) {
             SpectrumP d = MakeDense(s);
             d->Scale(scale);
@@ -694,7 +695,9 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
             M.type = WF_MEDIUM_GRID;
             std::vector<float> density = ps.GetFloatArray("density");
             if (density.empty()) Die(e.loc, "No \"density\" value provided for grid medium.");
-            if (!ps.GetFloatArray("temperature").empty()) Die(e.loc, "grid medium \"temperature\" is not supported by this build yet");
+            std::vector<float> temperature = ps.GetFloatArray("temperature");
+            if (!temperature.empty() && temperature.size() != density.size()) Die(e.loc, "Different number of samples provided for \"density\" and \"temperature\".");
+            if (Le && !temperature.empty()) Die(e.loc, "Both \"Le\" and \"temperature\" values were provided.");
             M.nx = ps.GetOneInt("nx", 1); M.ny = ps.GetOneInt("ny", 1); M.nz = ps.GetOneInt("nz", 1);
             if ((long long)density.size() != (long long)M.nx * M.ny * M.nz)
                 Die(e.loc, "Grid medium has " + std::to_string(density.size()) + " density values; expected nx*ny*nz = " + std::to_string((long long)M.nx * M.ny * M.nz));
@@ -702,8 +705,15 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
             if (!Le || Le->MaxValue() == 0) Le = MakeConstant(0.f);
             else LeNorm = 1 / SpectrumToPhotometric(*Le);
             SpectrumP d = MakeDense(*Le);
-            M.is_emissive = d->MaxValue() > 0;
+            M.is_emissive = !temperature.empty() ? 1 : d->MaxValue() > 0;  // media.cpp:238
             M.le_offset = T->pool.AddDense(*d);
+            M.temperature_offset = -1;
+            if (!temperature.empty()) {
+                M.temperature_offset = (int)T->mediumData.size();
+                T->mediumData.insert(T->mediumData.end(), temperature.begin(), temperature.end());
+            }
+            M.temperature_shift = ps.GetOneFloat("temperatureoffset", ps.GetOneFloat("temperaturecutoff", 0.f));
+            M.temperature_scale = ps.GetOneFloat("temperaturescale", 1.f);
             std::vector<float> LeScale = ps.GetFloatArray("Lescale");
             M.le_scale_offset = (int)T->mediumData.size();
             if (LeScale.empty()) {

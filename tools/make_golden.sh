@@ -40,6 +40,8 @@ sed 's/^Camera "perspective".*/Camera "spherical" "string mapping" "equirectangu
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spherical_camera_ref.pfm $G/spherical_camera.pbrt
 # RGBGridMedium: hand-written scene tests/golden/rgbgrid_medium.pbrt (6x5x4 cells, absorbing + scattering + emitting)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rgbgrid_medium_ref.pfm $G/rgbgrid_medium.pbrt
+# GridMedium with a temperature grid (blackbody emission): hand-written scene tests/golden/tempgrid_medium.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/tempgrid_medium_ref.pfm $G/tempgrid_medium.pbrt
 # goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
