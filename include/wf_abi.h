@@ -109,8 +109,11 @@ typedef struct wf_texture {
     int32_t tex0, tex1, tex2;    /* child texture ids, or -1 */
     int32_t i0;                  /* IMAGE: index into tex_images (SPECTRUM_IMAGE: `spectrum` holds the SpectrumType 0 albedo / 1 unbounded / 2 illuminant) */
     float f0, f1;                /* constant value; IMAGE: scale, invert flag */
-    float map[8];                /* UVMapping: su, sv, du, dv (textures.h:76-104) */
+    float map[12];               /* UVMapping: su, sv, du, dv (textures.h:76-104); PlanarMapping: ds, dt in [2..3], vs in [4..6], vt in [7..9] */
+    int32_t mapping;             /* wf_tex_mapping */
+    int32_t xform;               /* spherical / cylindrical / planar: renderFromTexture in light_transforms (textureFromRender = its inverse) */
 } wf_texture;
+enum wf_tex_mapping { WF_TEXMAP_UV = 0, WF_TEXMAP_SPHERICAL = 1, WF_TEXMAP_CYLINDRICAL = 2, WF_TEXMAP_PLANAR = 3 };
 
 /* Materials (materials.h).  tex[] holds texture ids; meaning per type is listed in DESIGN.md and
  * mirrored by the WF_MT_* index constants below. */

@@ -865,6 +865,10 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             tc.dvdx = IsFinite(dvdx) ? Clamp(dvdx, -1e8f, 1e8f) : 0.f;
             tc.dudy = IsFinite(dudy) ? Clamp(dudy, -1e8f, 1e8f) : 0.f;
             tc.dvdy = IsFinite(dvdy) ? Clamp(dvdy, -1e8f, 1e8f) : 0.f;
+            // MaterialEvalWorkItem::GetMaterialEvalContext / GetNormalBumpEvalContext (wavefront/workitems.h:268-302) hand
+            // the (u, v) differentials to the textures but leave ctx.dpdx / dpdy at their zero defaults: in the wavefront
+            // path the spherical / cylindrical / planar mappings therefore see a zero footprint.  Reproduced as is.
+            tc.dpdx = tc.dpdy = V3{0, 0, 0};
         }
         N3 ns = si.ns;
         V3 dpdus = si.dpdus;

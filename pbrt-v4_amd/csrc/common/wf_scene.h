@@ -168,12 +168,59 @@ struct TexCtx {
     V2 uv{0, 0};
     float dudx = 0, dudy = 0, dvdx = 0, dvdy = 0;
 };
-// Checkerboard() for a 2D UVMapping (textures.cpp:183-207, textures.h:86-106)
-WF_HD float Checkerboard2D(const wf_texture &t, const TexCtx &c) {
-    const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
-    float dsdx = su * c.dudx, dsdy = su * c.dudy;
-    float dtdx = sv_ * c.dvdx, dtdy = sv_ * c.dvdy;
-    float s = su * c.uv.x + du, tt = sv_ * c.uv.y + dv;
+// TextureMapping2D::Map: UVMapping, SphericalMapping, CylindricalMapping, PlanarMapping (textures.h:76-225)
+struct TexCoord2 { V2 st; float dsdx, dsdy, dtdx, dtdy; };
+WF_HD TexCoord2 TexMap2D(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+    TexCoord2 r;
+    if (t.mapping == WF_TEXMAP_UV) {
+        const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
+        r.dsdx = su * c.dudx; r.dsdy = su * c.dudy;
+        r.dtdx = sv_ * c.dvdx; r.dtdy = sv_ * c.dvdy;
+        r.st = V2{su * c.uv.x + du, sv_ * c.uv.y + dv};
+        return r;
+    }
+    const float(*m)[4] = sv.lightXforms[t.xform].mInv;  // textureFromRender
+    auto xfP = [&](V3 p) {
+        float xp = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
+        float yp = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
+        float zp = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
+        float wp = m[3][0] * p.x + m[3][1] * p.y + m[3][2] * p.z + m[3][3];
+        return wp == 1 ? V3{xp, yp, zp} : V3{xp, yp, zp} / wp;
+    };
+    auto xfV = [&](V3 v) {
+        return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
+                  m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
+    };
+    V3 pt = xfP(c.p);
+    V3 dpdx = xfV(c.dpdx), dpdy = xfV(c.dpdy);
+    if (t.mapping == WF_TEXMAP_PLANAR) {
+        V3 vs{t.map[4], t.map[5], t.map[6]}, vt{t.map[7], t.map[8], t.map[9]};
+        r.dsdx = Dot(vs, dpdx); r.dsdy = Dot(vs, dpdy);
+        r.dtdx = Dot(vt, dpdx); r.dtdy = Dot(vt, dpdy);
+        r.st = V2{t.map[2] + Dot(pt, vs), t.map[3] + Dot(pt, vt)};
+        return r;
+    }
+    float x2y2 = Sqr(pt.x) + Sqr(pt.y);
+    V3 dsdp = V3{-pt.y, pt.x, 0} / (2 * Pi * x2y2), dtdp;
+    if (t.mapping == WF_TEXMAP_SPHERICAL) {
+        float sqrtx2y2 = sqrt(x2y2);
+        dtdp = 1 / (Pi * (x2y2 + Sqr(pt.z))) * V3{pt.x * pt.z / sqrtx2y2, pt.y * pt.z / sqrtx2y2, -sqrtx2y2};
+        V3 vec = Normalize(pt);
+        float phi = atan2(vec.y, vec.x);
+        r.st = V2{SafeACos(vec.z) * InvPi, (phi < 0 ? phi + 2 * Pi : phi) * Inv2Pi};
+    } else {
+        dtdp = V3{0, 0, 1};
+        r.st = V2{(Pi + atan2(pt.y, pt.x)) * Inv2Pi, pt.z};
+    }
+    r.dsdx = Dot(dsdp, dpdx); r.dsdy = Dot(dsdp, dpdy);
+    r.dtdx = Dot(dtdp, dpdx); r.dtdy = Dot(dtdp, dpdy);
+    return r;
+}
+// Checkerboard() for a 2D mapping (textures.cpp:183-207)
+WF_HD float Checkerboard2D(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+    TexCoord2 tcd = TexMap2D(sv, t, c);
+    float dsdx = tcd.dsdx, dsdy = tcd.dsdy, dtdx = tcd.dtdx, dtdy = tcd.dtdy;
+    float s = tcd.st.x, tt = tcd.st.y;
     auto d = [](float x) {
         float y = x / 2 - floor(x / 2) - 0.5f;
         return x / 2 + y * (1 - 2 * abs(y));
@@ -333,17 +380,17 @@ WF_HD float MIPFilterFloat(const SceneView &sv, int image, V2 st, float dsdx, fl
 }
 // FloatImageTexture::Evaluate (textures.h:579-591), SpectrumImageTexture::Evaluate (textures.cpp:300-328)
 WF_HD float EvalFloatImageTexture(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
-    const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
-    float dsdx = su * c.dudx, dsdy = su * c.dudy, dtdx = sv_ * c.dvdx, dtdy = sv_ * c.dvdy;
-    V2 st{su * c.uv.x + du, sv_ * c.uv.y + dv};
+    TexCoord2 tcd = TexMap2D(sv, t, c);
+    float dsdx = tcd.dsdx, dsdy = tcd.dsdy, dtdx = tcd.dtdx, dtdy = tcd.dtdy;
+    V2 st = tcd.st;
     st.y = 1 - st.y;
     float v = t.f0 * MIPFilterFloat(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
     return t.f1 != 0 ? fmax(0.f, 1 - v) : v;
 }
 WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &c) {
-    const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
-    float dsdx = su * c.dudx, dsdy = su * c.dudy, dtdx = sv_ * c.dvdx, dtdy = sv_ * c.dvdy;
-    V2 st{su * c.uv.x + du, sv_ * c.uv.y + dv};
+    TexCoord2 tcd = TexMap2D(sv, t, c);
+    float dsdx = tcd.dsdx, dsdy = tcd.dsdy, dtdx = tcd.dtdx, dtdy = tcd.dtdy;
+    V2 st = tcd.st;
     st.y = 1 - st.y;
     RGB3 f = MIPFilterRGB(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
     float rgb[3] = {t.f0 * f.r, t.f0 * f.g, t.f0 * f.b};
@@ -390,7 +437,7 @@ WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
         }
         if (t.type == WF_TEX_FLOAT_MIX || t.type == WF_TEX_FLOAT_CHECKERBOARD) {
             // FloatMixTexture::Evaluate (textures.h:810-818), FloatCheckerboardTexture::Evaluate (:370-378)
-            float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(t, tc);
+            float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(sv, t, tc);
             float t0 = 0, t1 = 0;
             if (w != 1) t0 = EvalFloatTextureD<D - 1>(sv, t.tex0, tc);
             if (w != 0) t1 = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
@@ -414,7 +461,7 @@ WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &la
         }
         if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD) {
             // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413)
-            float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(t, tc);
+            float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(sv, t, tc);
             S4 t0 = S4c(0.f), t1 = S4c(0.f);
             if (w != 1) t0 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc);
             if (w != 0) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda, tc);

@@ -325,6 +325,7 @@ WF_HD bool AlphaTestPasses(const SceneView &sv, int tri, float b0, float b1, flo
     if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
     TexCtx tc;
     tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
+    tc.p = b0 * LoadP(sv, v[0]) + b1 * LoadP(sv, v[1]) + b2 * LoadP(sv, v[2]);  // intr.p() for the non-uv mappings (shapes.h:900)
     float a = EvalFloatTexture(sv, mesh.alpha_tex, tc);
     if (!(a < 1)) return true;
     float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(o, d));

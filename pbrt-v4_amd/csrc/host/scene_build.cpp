@@ -130,14 +130,35 @@ struct TexBuilder {
     }
 
     // TextureMapping2D::Create (textures.cpp:49-73) for the 2D checkerboard: UVMapping(su, sv, du, dv)
-    void CheckerMapping(const TextureEntity &te, wf_texture *t) {
+    // TextureMapping2D::Create (textures.cpp:49-73)
+    void SetMapping2D(const TextureEntity &te, wf_texture *t) {
         const ParamSet &ps = te.params;
-        if (ps.GetOneInt("dimension", 2) != 2) Die(te.loc, "3D checkerboard textures are not supported by this build");
-        if (ps.GetOneString("mapping", "uv") != "uv") Die(te.loc, "only the \"uv\" texture mapping is supported by this build");
-        t->map[0] = ps.GetOneFloat("uscale", 1.f);
-        t->map[1] = ps.GetOneFloat("vscale", 1.f);
-        t->map[2] = ps.GetOneFloat("udelta", 0.f);
-        t->map[3] = ps.GetOneFloat("vdelta", 0.f);
+        std::string type = ps.GetOneString("mapping", "uv");
+        t->xform = -1;
+        if (type == "uv") {
+            t->mapping = WF_TEXMAP_UV;
+            t->map[0] = ps.GetOneFloat("uscale", 1.f);
+            t->map[1] = ps.GetOneFloat("vscale", 1.f);
+            t->map[2] = ps.GetOneFloat("udelta", 0.f);
+            t->map[3] = ps.GetOneFloat("vdelta", 0.f);
+            return;
+        }
+        if (type == "spherical") t->mapping = WF_TEXMAP_SPHERICAL;
+        else if (type == "cylindrical") t->mapping = WF_TEXMAP_CYLINDRICAL;
+        else if (type == "planar") {
+            t->mapping = WF_TEXMAP_PLANAR;
+            V3 v1 = ps.GetOneVector3f("v1", V3{1, 0, 0}), v2 = ps.GetOneVector3f("v2", V3{0, 1, 0});
+            t->map[2] = ps.GetOneFloat("udelta", 0.f);
+            t->map[3] = ps.GetOneFloat("vdelta", 0.f);
+            t->map[4] = v1.x; t->map[5] = v1.y; t->map[6] = v1.z;
+            t->map[7] = v2.x; t->map[8] = v2.y; t->map[9] = v2.z;
+        } else Die(te.loc, "2D texture mapping \"" + type + "\" unknown");
+        t->xform = (int)T->lightTransforms.size();
+        T->lightTransforms.push_back(te.renderFromTexture.abi());
+    }
+    void CheckerMapping(const TextureEntity &te, wf_texture *t) {
+        if (te.params.GetOneInt("dimension", 2) != 2) Die(te.loc, "3D checkerboard textures are not supported by this build");
+        SetMapping2D(te, t);
     }
     // ImageTextureBase ctor + MIPMap::CreateFromFile + Image::GeneratePyramid (textures.h:528-550, util/mipmap.cpp:163-206,
     // util/image.cpp GeneratePyramid) for float .pfm images with power-of-two resolution
@@ -145,9 +166,7 @@ struct TexBuilder {
     std::map<std::string, int> namedMaterialIds;  // in definition order: a "mix" material names earlier ones
     int LoadTexImage(const TextureEntity &te, wf_texture *t) {
         const ParamSet &ps = te.params;
-        if (ps.GetOneString("mapping", "uv") != "uv") Die(te.loc, "only the \"uv\" texture mapping is supported by this build");
-        t->map[0] = ps.GetOneFloat("uscale", 1.f); t->map[1] = ps.GetOneFloat("vscale", 1.f);
-        t->map[2] = ps.GetOneFloat("udelta", 0.f); t->map[3] = ps.GetOneFloat("vdelta", 0.f);
+        SetMapping2D(te, t);
         ps.GetOneFloat("maxanisotropy", 8.f);
         std::string filter = ps.GetOneString("filter", "bilinear"), wrap = ps.GetOneString("wrap", "repeat");
         int ff = filter == "point" ? WF_MIP_POINT : filter == "bilinear" ? WF_MIP_BILINEAR : filter == "trilinear" ? WF_MIP_TRILINEAR : -1;

@@ -42,6 +42,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spherical
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rgbgrid_medium_ref.pfm $G/rgbgrid_medium.pbrt
 # GridMedium with a temperature grid (blackbody emission): hand-written scene tests/golden/tempgrid_medium.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/tempgrid_medium_ref.pfm $G/tempgrid_medium.pbrt
+# spherical / cylindrical / planar texture mappings (checkerboard, imagemap, alpha): hand-written tests/golden/texture_mappings.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/texture_mappings_ref.pfm $G/texture_mappings.pbrt
 # goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
