@@ -101,7 +101,11 @@ enum wf_texture_type {
     WF_TEX_FLOAT_IMAGE = 6,        /* image id in i0, mapping in map */
     WF_TEX_SPECTRUM_IMAGE = 7,
     WF_TEX_FLOAT_CHECKERBOARD = 8,     /* 2D checkerboard over the UVMapping in map[0..3]; tex0 = "tex1", tex1 = "tex2" (textures.h:352-420) */
-    WF_TEX_SPECTRUM_CHECKERBOARD = 9
+    WF_TEX_SPECTRUM_CHECKERBOARD = 9,
+    WF_TEX_FLOAT_BILERP = 10,          /* textures.h:300-330: v00 = f0, v01 = f1, v10 = map[10], v11 = map[11] over the 2D mapping */
+    WF_TEX_SPECTRUM_BILERP = 11,       /* spectra ids: v00 = spectrum, v10 = tex0, v01 = tex1, v11 = tex2 */
+    WF_TEX_FLOAT_DIRECTIONMIX = 12,    /* textures.h:830-860: dir (render space, normalized) in map[4..6]; tex0 = "tex2", tex1 = "tex1" */
+    WF_TEX_SPECTRUM_DIRECTIONMIX = 13
 };
 typedef struct wf_texture {
     int32_t type;

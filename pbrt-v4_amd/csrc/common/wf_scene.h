@@ -428,6 +428,12 @@ WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
     if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
     if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture(sv, t, tc);
+    if (t.type == WF_TEX_FLOAT_BILERP) {
+        // FloatBilerpTexture::Evaluate, textures.h:314-318
+        TexCoord2 c = TexMap2D(sv, t, tc);
+        const float v00 = t.f0, v01 = t.f1, v10 = t.map[10], v11 = t.map[11];
+        return (1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11;
+    }
     if constexpr (D > 0) {
         if (t.type == WF_TEX_FLOAT_SCALE) {
             // FloatScaledTexture::Evaluate, textures.h:1039-1044
@@ -435,9 +441,11 @@ WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
             if (sc == 0) return 0;
             return EvalFloatTextureD<D - 1>(sv, t.tex0, tc) * sc;
         }
-        if (t.type == WF_TEX_FLOAT_MIX || t.type == WF_TEX_FLOAT_CHECKERBOARD) {
-            // FloatMixTexture::Evaluate (textures.h:810-818), FloatCheckerboardTexture::Evaluate (:370-378)
-            float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(sv, t, tc);
+        if (t.type == WF_TEX_FLOAT_MIX || t.type == WF_TEX_FLOAT_CHECKERBOARD || t.type == WF_TEX_FLOAT_DIRECTIONMIX) {
+            // FloatMixTexture::Evaluate (textures.h:810-818), FloatCheckerboardTexture::Evaluate (:370-378),
+            // FloatDirectionMixTexture::Evaluate (:839-847: amt * tex1 + (1 - amt) * tex2 = this form with tex0 = "tex2")
+            float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc)
+                      : t.type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : Checkerboard2D(sv, t, tc);
             float t0 = 0, t1 = 0;
             if (w != 1) t0 = EvalFloatTextureD<D - 1>(sv, t.tex0, tc);
             if (w != 0) t1 = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
@@ -452,6 +460,13 @@ WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &la
     const wf_texture t = sv.textures[id];
     if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
     if (t.type == WF_TEX_SPECTRUM_IMAGE) return EvalSpectrumImageTexture(sv, t, lambda, tc);
+    if (t.type == WF_TEX_SPECTRUM_BILERP) {
+        // SpectrumBilerpTexture::Evaluate (textures.h:340-344) through Bilerp(p, {v00, v10, v01, v11}) (util/math.h)
+        TexCoord2 c = TexMap2D(sv, t, tc);
+        S4 v00 = SpectrumSample(sv, t.spectrum, lambda), v10 = SpectrumSample(sv, t.tex0, lambda);
+        S4 v01 = SpectrumSample(sv, t.tex1, lambda), v11 = SpectrumSample(sv, t.tex2, lambda);
+        return ((1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11);
+    }
     if constexpr (D > 0) {
         if (t.type == WF_TEX_SPECTRUM_SCALE) {
             // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
@@ -459,9 +474,11 @@ WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &la
             if (sc == 0) return S4c(0.f);
             return EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc) * sc;
         }
-        if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD) {
-            // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413)
-            float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc) : Checkerboard2D(sv, t, tc);
+        if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD || t.type == WF_TEX_SPECTRUM_DIRECTIONMIX) {
+            // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413),
+            // SpectrumDirectionMixTexture::Evaluate (:880-890)
+            float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc)
+                      : t.type == WF_TEX_SPECTRUM_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : Checkerboard2D(sv, t, tc);
             S4 t0 = S4c(0.f), t1 = S4c(0.f);
             if (w != 1) t0 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc);
             if (w != 0) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda, tc);

@@ -67,8 +67,9 @@ struct TexBuilder {
     std::vector<int> texDepth;  // nesting depth of every texture node: the device walks the graph with a WF_TEX_MAX_DEPTH stack
     int AddTex(const wf_texture &t) {
         int d = 1;
-        for (int c : {t.tex0, t.tex1, t.tex2})
-            if (c >= 0) d = std::max(d, 1 + texDepth[c]);
+        if (t.type != WF_TEX_SPECTRUM_BILERP)  // (its tex0..2 hold spectrum ids, not child textures)
+            for (int c : {t.tex0, t.tex1, t.tex2})
+                if (c >= 0) d = std::max(d, 1 + texDepth[c]);
         if (d > WF_TEX_MAX_DEPTH + 1) Die("", "texture graph nested deeper than " + std::to_string(WF_TEX_MAX_DEPTH + 1) + " levels");
         texDepth.push_back(d);
         T->textures.push_back(t);
@@ -270,6 +271,19 @@ struct TexBuilder {
                     t.type = WF_TEX_FLOAT_CHECKERBOARD;
                     t.tex0 = GetFloatTexture(ps, "tex1", 1.f);
                     t.tex1 = GetFloatTexture(ps, "tex2", 0.f);
+                } else if (te.name == "bilerp") {
+                    // FloatBilerpTexture::Create (textures.cpp:141-151)
+                    SetMapping2D(te, &t);
+                    t.type = WF_TEX_FLOAT_BILERP;
+                    t.f0 = ps.GetOneFloat("v00", 0.f); t.f1 = ps.GetOneFloat("v01", 1.f);
+                    t.map[10] = ps.GetOneFloat("v10", 0.f); t.map[11] = ps.GetOneFloat("v11", 1.f);
+                } else if (te.name == "directionmix") {
+                    // FloatDirectionMixTexture::Create (textures.cpp:563-571); stored as a mix with weight |n . dir|
+                    t.type = WF_TEX_FLOAT_DIRECTIONMIX;
+                    V3 dir = Normalize(te.renderFromTexture.Vector(ps.GetOneVector3f("dir", V3{0, 1, 0})));
+                    t.map[4] = dir.x; t.map[5] = dir.y; t.map[6] = dir.z;
+                    t.tex1 = GetFloatTexture(ps, "tex1", 0.f);
+                    t.tex0 = GetFloatTexture(ps, "tex2", 1.f);
                 } else Die(te.loc, te.name + ": float texture type not supported by this build");
                 if (floatTextures.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
                 floatTextures[te.texName] = AddTex(t);
@@ -306,6 +320,22 @@ struct TexBuilder {
                         t.type = WF_TEX_SPECTRUM_CHECKERBOARD;
                         t.tex0 = GetSpectrumTexture(ps, "tex1", *MakeConstant(1.f), st);
                         t.tex1 = GetSpectrumTexture(ps, "tex2", *MakeConstant(0.f), st);
+                    } else if (te.name == "bilerp") {
+                        // SpectrumBilerpTexture::Create (textures.cpp:159-174)
+                        SetMapping2D(te, &t);
+                        t.type = WF_TEX_SPECTRUM_BILERP;
+                        SpectrumP zero = MakeConstant(0.f), one = MakeConstant(1.f);
+                        t.spectrum = T->pool.Add(*ps.GetOneSpectrum("v00", zero, st));
+                        t.tex1 = T->pool.Add(*ps.GetOneSpectrum("v01", one, st));
+                        t.tex0 = T->pool.Add(*ps.GetOneSpectrum("v10", zero, st));
+                        t.tex2 = T->pool.Add(*ps.GetOneSpectrum("v11", one, st));
+                    } else if (te.name == "directionmix") {
+                        // SpectrumDirectionMixTexture::Create (textures.cpp:573-583)
+                        t.type = WF_TEX_SPECTRUM_DIRECTIONMIX;
+                        V3 dir = Normalize(te.renderFromTexture.Vector(ps.GetOneVector3f("dir", V3{0, 1, 0})));
+                        t.map[4] = dir.x; t.map[5] = dir.y; t.map[6] = dir.z;
+                        t.tex1 = GetSpectrumTexture(ps, "tex1", *MakeConstant(0.f), st);
+                        t.tex0 = GetSpectrumTexture(ps, "tex2", *MakeConstant(1.f), st);
                     } else Die(te.loc, te.name + ": spectrum texture type not supported by this build");
                     auto &m = SpecMap(st);
                     if (st == SpectrumType::Albedo && m.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
