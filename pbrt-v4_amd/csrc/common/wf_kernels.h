@@ -752,7 +752,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     V3 wo{-d4.x, -d4.y, -d4.z};
     if (!(sv.haveMedia && m.w >= 0)) wo = IntrWo(sv, prim, wo);
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    S4 Le = AreaLightL(sv, light, si.n, wo, lambda);
+    S4 Le = AreaLightL(sv, light, si.n, si.uv, wo, lambda);
     if (!Le) return;
     S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]);
     S4 L;

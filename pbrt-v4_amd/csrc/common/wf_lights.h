@@ -34,11 +34,6 @@ WF_HD float SmoothStep(float x, float a, float b) {
     return t * t * (3 - 2 * t);
 }
 
-// DiffuseAreaLight::L, lights.h:441-463 (no alpha, no image)
-WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, N3 n, V3 w, const Wavelengths &lambda) {
-    if (!(l.flags & WF_LIGHTFLAG_TWOSIDED) && Dot(n, w) < 0) return S4c(0.f);
-    return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
-}
 
 // ---------------------------------------------------------------------------------------------
 // ImageInfiniteLight (lights.h:566-662, lights.cpp:1042-1052)
@@ -86,6 +81,18 @@ WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavel
     const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
     return l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda);
 }
+// DiffuseAreaLight::L, lights.h:441-463 (no alpha); with an image: Image::BilerpChannel at (u, 1 - v), clamp wrap
+WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, N3 n, V2 uv, V3 w, const Wavelengths &lambda) {
+    if (!(l.flags & WF_LIGHTFLAG_TWOSIDED) && Dot(n, w) < 0) return S4c(0.f);
+    if (l.image >= 0) {
+        const wf_tex_image im = sv.texImages[l.image];
+        V2 st{uv.x, 1 - uv.y};
+        float r = ImageBilerpChannel(sv.tableData, im, 0, st, 0), g = ImageBilerpChannel(sv.tableData, im, 0, st, 1);
+        float b = ImageBilerpChannel(sv.tableData, im, 0, st, 2);
+        return l.scale * RGBIlluminantSample(sv, r, g, b, lambda);
+    }
+    return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
+}
 WF_HD V3 XfApply3(const float m[4][4], V3 v) {
     return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
               m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
@@ -100,7 +107,7 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
         ShapeSampleR ss = l.tri >= sv.nTriangles ? SphereSample(sv, l.tri, ctx.pi, ctx.n, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
         if (!ss.valid || ss.pdf == 0 || LengthSquared(ss.pi.mid() - ctx.p()) == 0) return ls;
         V3 wi = Normalize(ss.pi.mid() - ctx.p());
-        S4 Le = AreaLightL(sv, l, ss.n, -wi, lambda);
+        S4 Le = AreaLightL(sv, l, ss.n, ss.uv, -wi, lambda);
         if (!Le) return ls;
         ls.L = Le; ls.wi = wi; ls.pdf = ss.pdf; ls.pLightPi = ss.pi; ls.pLightN = ss.n; ls.valid = true;
         return ls;

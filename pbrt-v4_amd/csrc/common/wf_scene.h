@@ -170,16 +170,13 @@ struct TexCtx {
 };
 // TextureMapping2D::Map: UVMapping, SphericalMapping, CylindricalMapping, PlanarMapping (textures.h:76-225)
 struct TexCoord2 { V2 st; float dsdx, dsdy, dtdx, dtdy; };
-WF_HD TexCoord2 TexMap2D(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+// the non-uv mappings, out of line (pointer arguments only): inlined at every leaf of the texture-graph template they
+// doubled the material kernels' compile time
+WF_NI void TexMap2DP(const wf_transform *xf, const wf_texture *tp, const TexCtx *cp, TexCoord2 *out) {
+    const wf_texture &t = *tp;
+    const TexCtx &c = *cp;
     TexCoord2 r;
-    if (t.mapping == WF_TEXMAP_UV) {
-        const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
-        r.dsdx = su * c.dudx; r.dsdy = su * c.dudy;
-        r.dtdx = sv_ * c.dvdx; r.dtdy = sv_ * c.dvdy;
-        r.st = V2{su * c.uv.x + du, sv_ * c.uv.y + dv};
-        return r;
-    }
-    const float(*m)[4] = sv.lightXforms[t.xform].mInv;  // textureFromRender
+    const float(*m)[4] = xf->mInv;  // textureFromRender
     auto xfP = [&](V3 p) {
         float xp = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
         float yp = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
@@ -198,7 +195,8 @@ WF_HD TexCoord2 TexMap2D(const SceneView &sv, const wf_texture &t, const TexCtx 
         r.dsdx = Dot(vs, dpdx); r.dsdy = Dot(vs, dpdy);
         r.dtdx = Dot(vt, dpdx); r.dtdy = Dot(vt, dpdy);
         r.st = V2{t.map[2] + Dot(pt, vs), t.map[3] + Dot(pt, vt)};
-        return r;
+        *out = r;
+        return;
     }
     float x2y2 = Sqr(pt.x) + Sqr(pt.y);
     V3 dsdp = V3{-pt.y, pt.x, 0} / (2 * Pi * x2y2), dtdp;
@@ -214,6 +212,20 @@ WF_HD TexCoord2 TexMap2D(const SceneView &sv, const wf_texture &t, const TexCtx 
     }
     r.dsdx = Dot(dsdp, dpdx); r.dsdy = Dot(dsdp, dpdy);
     r.dtdx = Dot(dtdp, dpdx); r.dtdy = Dot(dtdp, dpdy);
+    *out = r;
+}
+WF_HD TexCoord2 TexMap2D(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+    TexCoord2 r;
+    if (t.mapping == WF_TEXMAP_UV) {
+        const float su = t.map[0], sv_ = t.map[1], du = t.map[2], dv = t.map[3];
+        r.dsdx = su * c.dudx; r.dsdy = su * c.dudy;
+        r.dtdx = sv_ * c.dvdx; r.dtdy = sv_ * c.dvdy;
+        r.st = V2{su * c.uv.x + du, sv_ * c.uv.y + dv};
+        return r;
+    }
+    const wf_texture tt = t;
+    const TexCtx cc = c;
+    TexMap2DP(sv.lightXforms + t.xform, &tt, &cc, &r);
     return r;
 }
 // Checkerboard() for a 2D mapping (textures.cpp:183-207)

@@ -937,6 +937,22 @@ static void BuildPowerAlias(SceneTables *T) {
             break;
         }
         case WF_LIGHT_DIFFUSE_AREA:                                                           // lights.cpp:769-786
+            if (l.image >= 0) {
+                const wf_tex_image &im = T->texImages[l.image];
+                const ColorSpace *ics = SpectralData::Get().sRGB();
+                S4 Lsum = S4c(0.f);
+                for (size_t i = 0; i < (size_t)im.res[0] * im.res[1]; ++i) {
+                    const float *px = &T->tableData[im.level_offset[0] + 3 * i];
+                    float rgb[3] = {std::max(0.f, px[0]), std::max(0.f, px[1]), std::max(0.f, px[2])};
+                    SpectrumP sp = ics->Illuminant(rgb);
+                    S4 s;
+                    for (int k = 0; k < 4; ++k) s[k] = sp->scale * SigmoidPoly(lambda.lambda[k], sp->c0, sp->c1, sp->c2);
+                    Lsum = Lsum + s * Ls;  // Ls = the colour space's illuminant at lambda
+                }
+                Lsum = Lsum * (l.scale / (im.res[0] * im.res[1]));
+                phi = Pi * ((l.flags & WF_LIGHTFLAG_TWOSIDED) ? 2 : 1) * l.area * Lsum;
+                break;
+            }
             phi = Pi * ((l.flags & WF_LIGHTFLAG_TWOSIDED) ? 2 : 1) * l.area * (Ls * l.scale);
             break;
         case WF_LIGHT_UNIFORM_INFINITE: phi = 4 * Pi * Pi * Sqr(l.sceneRadius) * l.scale * Ls; break;  // lights.cpp:974-976
@@ -1477,20 +1493,50 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         SpectrumP L = ps.GetOneSpectrum("L", nullptr, SpectrumType::Illuminant);
         float scale = ps.GetOneFloat("scale", 1);
         bool twoSided = ps.GetOneBool("twosided", false);
-        if (!ps.GetOneString("filename", "").empty()) Die(al.loc, "image-textured area lights are not supported by this build");
+        // DiffuseAreaLight::Create with "filename" (lights.cpp:884-910): an RGB image in the (u, v) square; .pfm -> sRGB
+        int lightImage = -1;
+        float imageLumAvg = 1, imageChannelAvg = 0;
+        std::string filename = ps.GetOneString("filename", "");
+        if (!filename.empty()) {
+            if (L) Die(al.loc, "Both \"L\" and \"filename\" specified for DiffuseAreaLight.");
+            if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
+            std::vector<float> rgb;
+            int w = 0, h = 0;
+            if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
+                Die(al.loc, filename + ": unable to read image (this build reads .pfm images)");
+            { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; bool grey = false; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); }
+              if (grey) Die(al.loc, filename + ": Image provided to \"diffuse\" area light must have R, G, and B channels."); }
+            for (float v : rgb) if (!std::isfinite(v)) Die(al.loc, filename + ": image has infinite or not-a-number pixel values and so is not suitable as a light.");
+            const ColorSpace *ics = SpectralData::Get().sRGB();
+            wf_tex_image im{};
+            im.res[0] = w; im.res[1] = h; im.n_levels = 1; im.n_channels = 3; im.wrap = WF_WRAP_CLAMP; im.filter = WF_MIP_BILINEAR;
+            im.level_offset[0] = (int)T->tableData.size();
+            T->tableData.insert(T->tableData.end(), rgb.begin(), rgb.end());
+            lightImage = (int)T->texImages.size();
+            T->texImages.push_back(im);
+            float k_e = 0, sum = 0;
+            for (size_t i = 0; i < (size_t)w * h; ++i)
+                for (int c = 0; c < 3; ++c) { k_e += rgb[3 * i + c] * ics->XYZFromRGB.m[1][c]; sum += rgb[3 * i + c]; }
+            imageLumAvg = k_e / (w * h);           // lights.cpp:917-925
+            imageChannelAvg = sum / (3 * w * h);   // DiffuseAreaLight::Bounds, lights.cpp:792-799
+            L = ics->illuminant;
+            T->desc.rgb2spec_coeffs = ics->table->coeffs.data();
+            for (int i = 0; i < 64; ++i) T->desc.rgb2spec_znodes[i] = ics->table->zNodes[i];
+        }
         if (!L) L = cs->illuminant;
         scale /= SpectrumToPhotometric(*L);
         float phi_v = ps.GetOneFloat("power", -1.0f);
         wf_mesh &mesh = T->meshes[pa.mesh];
         mesh.first_light = (int)T->lights.size();
         int specOff = T->pool.AddDense(*L);
-        float LemitMax = MakeDense(*L)->MaxValue();
+        float LemitMax = lightImage >= 0 ? imageChannelAvg : MakeDense(*L)->MaxValue();  // Bounds(): image average or Lemit max
+        if (lightImage >= 0) T->desc.cs_illuminant_offset = specOff;
         if (auto sit = sphereOfMesh.find(pa.mesh); sit != sphereOfMesh.end()) {
             const PendingSphere &sp = spheres[sit->second];
             float area = QuadricArea(sp.s);  // Sphere / Disk / Cylinder::Area (shapes.h:292,407,559)
             float sc = scale;
             if (phi_v > 0) {
-                float k_e = 1;
+                float k_e = lightImage >= 0 ? imageLumAvg : 1.f;
                 k_e *= (twoSided ? 2 : 1) * area * Pi;
                 sc *= phi_v / k_e;
             }
@@ -1501,7 +1547,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             l.scale = sc;
             l.tri = mesh.first_tri;
             l.area = area;
-            l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = -1;
+            l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = lightImage;
             int lightId = (int)T->lights.size();
             T->lights.push_back(l);
             // DiffuseAreaLight::Bounds (lights.cpp:788-806) with Sphere::NormalBounds = DirectionCone::EntireSphere()
@@ -1528,7 +1574,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             float area = 0.5f * Length(Cross(p1 - p0, p2 - p0));  // Triangle::Area (shapes.h:852-858)
             float sc = scale;
             if (phi_v > 0) {
-                float k_e = 1;
+                float k_e = lightImage >= 0 ? imageLumAvg : 1.f;
                 k_e *= (twoSided ? 2 : 1) * area * Pi;
                 sc *= phi_v / k_e;
             }
@@ -1539,7 +1585,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             l.scale = sc;
             l.tri = tri;
             l.area = area;
-            l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = -1;
+            l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = lightImage;
             int lightId = (int)T->lights.size();
             T->lights.push_back(l);
             // DiffuseAreaLight::Bounds (lights.cpp:788-806) + Triangle::NormalBounds (shapes.cpp:292-307)
