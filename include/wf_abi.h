@@ -538,6 +538,11 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
 /* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample */
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index,
                      int start_dim, int ndims, float *out);
+/* Elementary-function probe for parity tests: out[i] = f(in[i]) evaluated on the device with the kernels' own
+   routines (csrc/common/wf_libm.h, the restatement of the glibc 2.35 float libm the reference is linked against).
+   fn: 0 sin, 1 cos, 2 exp, 3 log, 4 atan, 5 asin, 6 acos, 7 cosh, 8 atanh, 9 atan2 (in = n (y, x) pairs).
+   Needs a context only (no scene). */
+int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out);
 /* debug/parity access to queues: downloads the named SoA member */
 int wf_queue_size(wf_ctx *ctx, const char *queue, int *size);
 int wf_queue_download(wf_ctx *ctx, const char *queue, const char *member, void *dst, uint64_t nbytes);

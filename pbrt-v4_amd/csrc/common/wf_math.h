@@ -30,6 +30,7 @@
 #define WF_HD inline
 #define WF_NI inline
 #endif
+#include "wf_libm.h"
 
 namespace wf {
 
@@ -91,9 +92,10 @@ WF_HD float NextFloatDown(float v) {
 
 // ---------------------------------------------------------------------------------------------
 // elementary functions.  fma/sqrt/div are IEEE-exact on both sides.  For the transcendental
-// functions the host uses libm's float routines (as the reference does); the device evaluates the
-// double-precision routine and rounds once, which reproduces a correctly rounded float result and
-// therefore agrees with glibc's (almost always correctly rounded) sinf/cosf/expf/logf/powf.
+// functions the host uses libm's float routines (as the reference does); the device evaluates
+// wf_libm.h, the operation-for-operation restatement of this image's glibc 2.35 float routines
+// (bit-identical to the live libm on all 2^32 arguments: oracle/wf_cpu/libm_check.cpp), so that the
+// device and the reference agree to the last bit, not "almost always".
 WF_HD float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
 WF_HD float sqrt(float x) { return ::sqrtf(x); }
 WF_HD float abs(float x) { return ::fabsf(x); }
@@ -103,30 +105,27 @@ WF_HD float copysign(float a, float b) { return ::copysignf(a, b); }
 WF_HD float fmin(float a, float b) { return b < a ? b : a; }  // std::min semantics
 WF_HD float fmax(float a, float b) { return a < b ? b : a; }  // std::max semantics
 #if defined(__HIP_DEVICE_COMPILE__)
-WF_HD float sin(float x) { return (float)::sin((double)x); }
-WF_HD float cos(float x) { return (float)::cos((double)x); }
-WF_HD float tan(float x) { return (float)::tan((double)x); }
-WF_HD float asin(float x) { return (float)::asin((double)x); }
-WF_HD float acos(float x) { return (float)::acos((double)x); }
-WF_HD float atan(float x) { return (float)::atan((double)x); }
-WF_HD float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
-WF_HD float exp(float x) { return (float)::exp((double)x); }
-WF_HD float log(float x) { return (float)::log((double)x); }
-WF_HD float pow(float x, float y) { return (float)::pow((double)x, (double)y); }
-WF_HD float cosh(float x) { return (float)::cosh((double)x); }
-WF_HD float atanh(float x) { return (float)::atanh((double)x); }
+WF_HD float sin(float x) { return glibc235::sinf(x); }
+WF_HD float cos(float x) { return glibc235::cosf(x); }
+WF_HD float asin(float x) { return glibc235::asinf(x); }
+WF_HD float acos(float x) { return glibc235::acosf(x); }
+WF_HD float atan(float x) { return glibc235::atanf(x); }
+WF_HD float atan2(float y, float x) { return glibc235::atan2f(y, x); }
+WF_HD float exp(float x) { return glibc235::expf(x); }
+WF_HD float log(float x) { return glibc235::logf(x); }
+WF_HD float cosh(float x) { return glibc235::coshf(x); }
+WF_HD float atanh(float x) { return glibc235::atanhf(x); }
+// tan / pow have no call site in the device path (host-side scene set-up only)
 WF_HD long lround(float x) { return (long)::roundf(x); }
 #else
 WF_HD float sin(float x) { return std::sin(x); }
 WF_HD float cos(float x) { return std::cos(x); }
-WF_HD float tan(float x) { return std::tan(x); }
 WF_HD float asin(float x) { return std::asin(x); }
 WF_HD float acos(float x) { return std::acos(x); }
 WF_HD float atan(float x) { return std::atan(x); }
 WF_HD float atan2(float y, float x) { return std::atan2(y, x); }
 WF_HD float exp(float x) { return std::exp(x); }
 WF_HD float log(float x) { return std::log(x); }
-WF_HD float pow(float x, float y) { return std::pow(x, y); }
 WF_HD float cosh(float x) { return std::cosh(x); }
 WF_HD float atanh(float x) { return std::atanh(x); }
 WF_HD long lround(float x) { return std::lround(x); }

@@ -1186,6 +1186,44 @@ int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, c
     return 0;
 }
 
+__global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    if (fn == 9) r = wf::atan2(in[2 * i], in[2 * i + 1]);
+    else {
+        float x = in[i];
+        switch (fn) {
+        case 0: r = wf::sin(x); break;
+        case 1: r = wf::cos(x); break;
+        case 2: r = wf::exp(x); break;
+        case 3: r = wf::log(x); break;
+        case 4: r = wf::atan(x); break;
+        case 5: r = wf::asin(x); break;
+        case 6: r = wf::acos(x); break;
+        case 7: r = wf::cosh(x); break;
+        default: r = wf::atanh(x); break;
+        }
+    }
+    out[i] = r;
+}
+int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out) {
+    if (!ctx) return fail(-1, "null context");
+    if (fn < 0 || fn > 9) return fail(-1, "wf_libm_probe: unknown function %d", fn);
+    if (n <= 0) return 0;
+    size_t nin = (size_t)n * (fn == 9 ? 2 : 1);
+    float *din = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&din, nin * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)n * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(din, in, nin * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH("libm probe", k_libm_probe, gridFor(n), fn, n, din, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(din));
+    HIPCHK(hipFree(dout));
+    return 0;
+}
+
 int wf_queue_size(wf_ctx *ctx, const char *queue, int *size) {
     if (int e = checkReady(ctx)) return e;
     static const std::map<std::string, int> idx = {{"ray0", CNT_RAY0}, {"ray1", CNT_RAY1}, {"escaped", CNT_ESCAPED}, {"hitlight", CNT_HITLIGHT},

@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
     "wf_film_device_ptr", "wf_film_upload", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
-    "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_queue_size", "wf_queue_download",
+    "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_queue_size", "wf_queue_download",
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms",
 ]
 HOST_SYMBOLS = [
@@ -116,6 +116,7 @@ def libs():
     _hip.wf_trace_closest_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _hip.wf_trace_any_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _hip.wf_sampler_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    _hip.wf_libm_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _hip.wf_kernel_time_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _hip.wf_aggregate_bounds.argtypes = [C.c_void_p, C.c_void_p]
     _hip.wf_render_pass.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -256,6 +257,17 @@ class Scene:
         out = np.empty((px.shape[0], ndims), dtype=np.float32)
         _check(hip.wf_sampler_probe(self.ctx, px.shape[0], px.ctypes.data, py.ctypes.data, si.ctypes.data, start_dim, ndims, out.ctypes.data),
                "wf_sampler_probe")
+        return out
+
+    LIBM_FNS = ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2")
+
+    def libm_probe(self, fn, x):
+        """Device evaluation of the kernels' elementary function `fn` over float32 array x ((n, 2) (y, x) pairs for atan2)."""
+        _, hip = libs()
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        out = np.empty(n, dtype=np.float32)
+        _check(hip.wf_libm_probe(self.ctx, self.LIBM_FNS.index(fn), n, x.ctypes.data, out.ctypes.data), "wf_libm_probe")
         return out
 
     def enable_profile(self, on=True):

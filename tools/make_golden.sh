@@ -61,3 +61,4 @@ done
 # the named physical oracle (not sample-aligned): VolPathIntegrator at high spp, for mean comparisons
 oracle/_ref/pbrt_ref --quiet --seed 0 --spp 256 --outfile $G/cornell64_volpath256.pfm $G/cornell64.pbrt
 ls -la $G
+python3 tools/make_libm_golden.py
