@@ -611,8 +611,12 @@ int main(int argc, char **argv) {
     if (!opt.quiet)
         fprintf(stderr, "wf_cpu: %dx%d %d spp, %d threads: %.3f s, %.3f Msamples/s, %.3f Mray/s (nodes %llu tris %llu)\n", W, H, T.spp,
                 gThreads, secs, (double)W * H * T.spp / secs / 1e6, rays / secs / 1e6, nodesVisited, trisTested);
-    printf("{\"seconds\": %.6f, \"width\": %d, \"height\": %d, \"spp\": %d, \"threads\": %d, \"rays\": %llu, \"camera_rays\": %llu}\n", secs, W, H,
+    printf("{\"seconds\": %.6f, \"width\": %d, \"height\": %d, \"spp\": %d, \"threads\": %d, \"rays\": %llu, \"camera_rays\": %llu, \"indirect_rays\": [", secs, W, H,
            T.spp, gThreads, rays, ws.stats[0]);
+    for (int d = 0; d < 64; ++d) printf("%s%llu", d ? ", " : "", ws.stats[1 + d]);
+    printf("], \"shadow_rays\": [");
+    for (int d = 0; d < 64; ++d) printf("%s%llu", d ? ", " : "", ws.stats[65 + d]);
+    printf("]}\n");
 
     if (!dumpFilm.empty()) {
         FILE *f = fopen(dumpFilm.c_str(), "wb");

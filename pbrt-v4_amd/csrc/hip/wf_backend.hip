@@ -248,6 +248,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
         w.node = NODE_NONE;
         w.prim = -1;
         w.route = 0;
+        w.tMax = 0;
         w.b0 = w.b1 = w.b2 = 0;
         V3 o{0, 0, 0}, d{0, 0, 0};
         if (valid) {
@@ -273,7 +274,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                         const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
                         a = p[0]; b = p[1];
                     }
-                    InteriorStep(w, st, a, b);
+                    InteriorStep<!ANY>(bvh, w, st, a, b);
                 }
             }
             if (w.node != NODE_NONE) {
@@ -297,7 +298,26 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneV
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
         },
-        [&](int i, bool valid, const RayWalk &w) { KRouteHitBlock<ALPHA>(sv, ws, cur, i, valid, w.prim, w.route, w.tMax, w.b0, w.b1, w.b2); });
+        [&](int i, bool valid, const RayWalk &w) {
+            // near-tie seen (wf_traverse.h): the reference-order walk decides (k_closest_retrace)
+            const bool amb = valid && WalkAmbiguous(w);
+            if (amb) ws.retraceQ[atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1)] = i;
+            KRouteHitBlock<ALPHA>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2);
+        });
+}
+// the rays k_closest_fast marked as near-ties, in the reference's own traversal order (rare: coplanar overlapping geometry)
+__global__ void __launch_bounds__(BLOCK) k_closest_retrace(const SceneView sv, WorkState ws, int cur, int *stackSpill) {
+    const int n = ws.counters[(CNT_RETRACE) * CNT_STRIDE];
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int qi = gtid; qi < n; qi += stride) {
+        const int i = ws.retraceQ[qi];
+        F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+        ClosestHit ch;
+        st.n = 0;
+        bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
+        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
+    }
 }
 template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
@@ -327,8 +347,8 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int 
             wf_hit_record h;
             bool found = w.prim >= 0;
             h.prim = w.prim;
-            h.t = found ? w.tMax : 0; h.b0 = w.b0; h.b1 = w.b1; h.b2 = w.b2;
-            h.nodes_visited = 0; h.tris_tested = 0; h.pad = 0;
+            h.t = found ? WalkT(w) : 0; h.b0 = w.b0; h.b1 = w.b1; h.b2 = w.b2;
+            h.nodes_visited = 0; h.tris_tested = 0; h.pad = WalkAmbiguous(w) ? 1 : 0;
             out[i] = h;
         });
 }
@@ -392,9 +412,16 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
                         const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
                         a = p[0]; b = p[1];
                     }
-                    InteriorStep(w, st, a, b);
+                    InteriorStep(bvh, w, st, a, b);
                 } else if constexpr (ALPHA) LeafStep<false, true>(bvh, w, st, GeneralPrims{sv, o, d});
                 else LeafStep<false>(bvh, w, st);
+            }
+            if (WalkAmbiguous(w)) {  // near-tie (wf_traverse.h): the reference-order walk decides
+                ClosestHit ch;
+                st.n = 0;
+                bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+                if (found) { *prim = ch.prim; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+                return found;
             }
             if (w.prim >= 0) { *prim = w.prim; *b0 = w.b0; *b1 = w.b1; *b2 = w.b2; }
             return w.prim >= 0;
@@ -419,10 +446,12 @@ __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkS
 }
 
 // stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
-__global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
+// onlyMarked: the re-trace pass after k_trace_closest_fast — only the records it marked as near-ties (pad == 1)
+__global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int n, const float *rays, wf_hit_record *out, int *stackSpill, int onlyMarked) {
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride) {
+        if (onlyMarked && out[i].pad != 1) continue;
         const float *r = rays + (size_t)7 * i;
         ClosestHit ch;
         st.n = 0;
@@ -430,7 +459,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int
         wf_hit_record h;
         h.prim = found ? ch.prim : -1;
         h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;
-        h.nodes_visited = ch.nodesVisited; h.tris_tested = ch.trisTested; h.pad = 0;
+        h.nodes_visited = onlyMarked ? 0 : ch.nodesVisited; h.tris_tested = onlyMarked ? 0 : ch.trisTested; h.pad = onlyMarked ? 2 : 0;
         out[i] = h;
     }
 }
@@ -503,6 +532,10 @@ struct Prof {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(TBLOCK), 0, ctx->stream, __VA_ARGS__); \
     } while (0)
 
+// wf_render_stats carries 64 per-depth slots (indirect_rays[64], shadow_rays[64]); deeper bounces (volumetric scenes
+// set maxdepth 100 and more) accumulate in the last slot instead of running past the array
+static int statDepth(int depth) { return depth < 63 ? depth : 63; }
+
 static int checkReady(wf_ctx *ctx) {
     if (!ctx) return fail(-1, "null context");
     if (!ctx->sceneLoaded) return fail(-1, "no scene uploaded");
@@ -567,6 +600,11 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         cell = NextFloatUp(NextFloatUp(cell));
         out->base[a] = base;
         out->cell[a] = cell;
+    }
+    {
+        double ext = 0;
+        for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
+        out->absBand = (float)(0x1p-16 * ext);
     }
     auto plane = [&](int q, int a) { return (double)out->base[a] + (double)q * (double)out->cell[a]; };
     bool gridOk = true;
@@ -832,7 +870,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
             return e;
     }
     if (ctx->svHost.haveMix && ((e = devAlloc(ctx, &ws.mixMat, n)) || (e = devAlloc(ctx, &ws.mixQ, n)))) return e;
-    if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n))) return e;
+    if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n)) || (e = devAlloc(ctx, &ws.retraceQ, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
         if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
     if ((e = devAlloc(ctx, &ws.sq.o, n)) || (e = devAlloc(ctx, &ws.sq.d, n)) || (e = devAlloc(ctx, &ws.sq.Ld, n)) ||
@@ -872,9 +910,9 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     const int cur = depth & 1;
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
-    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX);
+    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
-    LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + depth, CNT_RAY0 + cur);
+    LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + statDepth(depth), CNT_RAY0 + cur);
     return 0;
 }
 int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
@@ -904,6 +942,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     else if (ctx->fastOk) {
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
         LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
@@ -927,7 +966,7 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
         LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
-    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + depth, CNT_SHADOW);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
     return 0;
 }
 int wf_handle_escaped(wf_ctx *ctx, int depth) {
@@ -974,7 +1013,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
-    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + depth, CNT_SHADOW);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
     return 0;
 }
 int wf_update_film(wf_ctx *ctx) {
@@ -1132,9 +1171,10 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     HIPCHK(hipMalloc((void **)&dh, (size_t)n * sizeof(wf_hit_record)));
     HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (count_visits || !ctx->fastOk) {
-        LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill);
+        LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 0);
     } else {
         LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
+        LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 1);
     }
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1187,8 +1227,7 @@ int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, c
 }
 
 __global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float r;
     if (fn == 9) r = wf::atan2(in[2 * i], in[2 * i + 1]);
     else {
@@ -1206,6 +1245,7 @@ __global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
         }
     }
     out[i] = r;
+    }
 }
 int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out) {
     if (!ctx) return fail(-1, "null context");
@@ -1227,7 +1267,7 @@ int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out) {
 int wf_queue_size(wf_ctx *ctx, const char *queue, int *size) {
     if (int e = checkReady(ctx)) return e;
     static const std::map<std::string, int> idx = {{"ray0", CNT_RAY0}, {"ray1", CNT_RAY1}, {"escaped", CNT_ESCAPED}, {"hitlight", CNT_HITLIGHT},
-                                                   {"shadow", CNT_SHADOW}, {"mat_diffuse", CNT_MAT0 + WF_MAT_DIFFUSE},
+                                                   {"shadow", CNT_SHADOW}, {"retrace", CNT_RETRACE}, {"mat_diffuse", CNT_MAT0 + WF_MAT_DIFFUSE},
                                                    {"mat_conductor", CNT_MAT0 + WF_MAT_CONDUCTOR}, {"mat_dielectric", CNT_MAT0 + WF_MAT_DIELECTRIC},
                                                    {"mat_thindielectric", CNT_MAT0 + WF_MAT_THIN_DIELECTRIC},
                                                    {"mat_diffusetransmission", CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION},

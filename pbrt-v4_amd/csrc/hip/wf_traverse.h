@@ -26,8 +26,20 @@
 //  * "while-while": all lanes of a wave descend interior nodes until every lane sits at a leaf, leaves are
 //    processed together, a workgroup finishes a batch of TBLOCK rays together (block-aggregated queue pushes).
 //
-// Exact ties in t between two triangles are the one case where visiting order can pick the other triangle
-// (same t): tests/test_gpu_parity.py allows a different triangle id only at bit-equal t.
+// Near-ties in t (coplanar overlapping geometry, e.g. a glass box standing on the floor seen from inside) are the one
+// case where the visiting order decides the result: IntersectTriangle (shapes.cpp:234-237) accepts a triangle while
+// tScaled <= fl(tMax * det), so among candidates whose t agree to ~3 * 2^-24 the reference keeps the LAST one its own
+// depth-first order accepts.  This walk visits nearest-entry first, so it cannot know; instead it tests and prunes
+// against tMax * (1 + 2^-16) + 2^-16 of the scene extent (one fma), and a candidate that lands inside that band of the
+// current best marks the ray (sign bit of RayWalk::tMax).  Marked rays are re-traced by the reference-order walk
+// (k_closest_retrace / BVHIntersectClosest).  The band has to cover more than the acceptance test's own rounding: the
+// computed t of two coplanar triangles differ by their evaluation errors (absolute: a few ulps of the vertex
+// coordinates, not of t), and the reference prunes subtrees with the EXACT tMax against box entries that carry errors
+// of the same size — a flat leaf box coplanar with the current hit is skipped or not by a hair.  2^-16 = 256 ulps of
+// the larger of t and the scene extent; measured differences on coplanar geometry are ~1 ulp of the coordinates.
+// (Measured and dropped: deciding marks by the triangles' own deltaT bounds of shapes.cpp:252-266 in a slow branch —
+// sound by pbrt's error analysis, but deltaT grows as distance^2 / triangle size, which forces a 2^-8 pruning band:
+// +24 % closest-hit time on the bench scene.)
 #pragma once
 
 namespace wf {
@@ -67,14 +79,16 @@ struct FastBVH {
     const LeafTri *tris;
     int nNodes;
     float base[3], cell[3];  // grid: plane(q) = base + q * cell (real arithmetic; the builder keeps a margin, see BuildFastBVH)
+    float absBand;           // 2^-16 x the scene extent: absolute part of the near-tie band
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+
 struct RayWalk {
     V3 o;
     RayShear sh;   // per-ray part of the triangle test (MakeRayShear)
-    float tMax;
+    float tMax;    // |tMax| = nearest hit so far; sign bit set = a near-tie was seen (see above): re-trace in reference order
     // slab test in grid coordinates: entry t of an axis = fma(qNear, a, bn), exit t = fma(qFar, af, bf)
     V3 a, bn, af, bf;
     uint32_t selx, sely, selz;  // v_perm selectors: put the near plane in the low half, the far plane in the high half
@@ -117,13 +131,36 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     w.b0 = w.b1 = w.b2 = 0;
 }
 
+__device__ inline bool WalkAmbiguous(const RayWalk &w) { return (FloatToBits(w.tMax) >> 31) != 0; }
+__device__ inline float WalkT(const RayWalk &w) { return __builtin_fabsf(w.tMax); }
+constexpr float TIE_BAND = 1 + 0x1p-16f;
+#ifndef WF_TIE
+#define WF_TIE 1   // 0: timing experiments only — no near-tie handling (round-1 behaviour: the visiting order decides ties)
+#endif
+#if WF_TIE
+__device__ inline float WalkBound(const FastBVH &bvh, float t) { return fma(t, TIE_BAND, bvh.absBand); }
+#else
+__device__ inline float WalkBound(const FastBVH &, float t) { return t; }
+#endif
+// a candidate hit at t: clearly nearer -> new best (an older mark is dropped: those candidates lie beyond);
+// within the band of the best -> keep the nearer one, mark the ray
+__device__ inline bool WalkAccept(const FastBVH &bvh, RayWalk &w, float t) {
+    const float cur = __builtin_fabsf(w.tMax);
+    if (!WF_TIE || WalkBound(bvh, t) < cur) { w.tMax = t; return true; }
+    const bool nearer = t < cur;
+    w.tMax = -(nearer ? t : cur);
+    return nearer;
+}
+
 __device__ inline float CvtLo(uint32_t v) { return (float)(v & 0xffffu); }
 __device__ inline float CvtHi(uint32_t v) { return (float)(v >> 16); }
 
 // Interior visit: branch-free test of both children (packed left/right), nearest entry first.
 // a, b = the node's two 16-byte halves (from LDS or global).  Precondition: w.node >= 0.
-template <typename Stack>
-__device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
+// RELAX: prune against the near-tie band (closest hit); any-hit walks prune against the exact tMax (their result
+// does not depend on the visiting order)
+template <bool RELAX = true, typename Stack>
+__device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, U4 a, U4 b) {
     // near plane -> low half, far plane -> high half of each dword
     const uint32_t lx = __builtin_amdgcn_perm(a.x, a.x, w.selx), ly = __builtin_amdgcn_perm(a.y, a.y, w.sely), lz = __builtin_amdgcn_perm(a.z, a.z, w.selz);
     const uint32_t rx = __builtin_amdgcn_perm(a.w, a.w, w.selx), ry = __builtin_amdgcn_perm(b.x, b.x, w.sely), rz = __builtin_amdgcn_perm(b.y, b.y, w.selz);
@@ -140,8 +177,9 @@ __device__ inline void InteriorStep(RayWalk &w, Stack &st, U4 a, U4 b) {
     // tMin < raytMax && tMax > 0 && tMin <= tMax, relaxed to max(tMin, 0) <= min(tMax, raytMax)
     const float tL = __builtin_fmaxf(__builtin_fmaxf(Lx.x, Ly.x), Lz.x), tR = __builtin_fmaxf(__builtin_fmaxf(Rx.x, Ry.x), Rz.x);
     const float eL = __builtin_fminf(__builtin_fminf(Lx.y, Ly.y), Lz.y), eR = __builtin_fminf(__builtin_fminf(Rx.y, Ry.y), Rz.y);
-    const bool hitL = __builtin_fmaxf(tL, 0.f) <= __builtin_fminf(eL, w.tMax);
-    const bool hitR = __builtin_fmaxf(tR, 0.f) <= __builtin_fminf(eR, w.tMax);
+    const float tPrune = RELAX ? WalkBound(bvh, __builtin_fabsf(w.tMax)) : w.tMax;
+    const bool hitL = __builtin_fmaxf(tL, 0.f) <= __builtin_fminf(eL, tPrune);
+    const bool hitR = __builtin_fmaxf(tR, 0.f) <= __builtin_fminf(eR, tPrune);
     const bool rightFirst = tR < tL;
     if (hitL & hitR) {
         st.push(rightFirst ? left : right);
@@ -166,27 +204,31 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
         const LeafTri *lt = bvh.tris + first + i;
         const F4 ta = lt->a, tb = lt->b, tc = lt->c;
         TriHit h;
+        // closest hit: test against the relaxed bound so that near-ties are seen (WalkAccept sorts them out)
+        const float tTest = ANY ? w.tMax : WalkBound(bvh, __builtin_fabsf(w.tMax));
         if constexpr (ALPHA)
             if (tc.z == 3.f) {
                 QuadricHit qh;
-                if (ex.sphere((int)FloatToBits(tc.y), w.tMax, &qh)) {
-                    w.prim = (int)FloatToBits(tc.y);
-                    w.route = FloatToBits(tc.w);
-                    w.b0 = qh.pObj.x; w.b1 = qh.pObj.y; w.b2 = qh.pObj.z;
-                    w.tMax = qh.tHit;
-                    if (ANY) { done = true; break; }
+                if (ex.sphere((int)FloatToBits(tc.y), ANY ? w.tMax : __builtin_fabsf(w.tMax), &qh)) {
+                    if (ANY) { w.prim = (int)FloatToBits(tc.y); w.tMax = qh.tHit; done = true; break; }
+                    if (WalkAccept(bvh, w, qh.tHit)) {
+                        w.prim = (int)FloatToBits(tc.y);
+                        w.route = FloatToBits(tc.w);
+                        w.b0 = qh.pObj.x; w.b1 = qh.pObj.y; w.b2 = qh.pObj.z;
+                    }
                 }
                 continue;
             }
         if ((ALPHA ? tc.z != 1.f : tc.z == 0.f) &&
-            IntersectTriangleSheared(w.o, w.sh, w.tMax, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
+            IntersectTriangleSheared(w.o, w.sh, tTest, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
             if constexpr (ALPHA)
                 if (tc.z == 2.f && !ex.accept((int)FloatToBits(tc.y), h.b0, h.b1, h.b2)) continue;
-            w.prim = (int)FloatToBits(tc.y);
-            w.route = FloatToBits(tc.w);
-            w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;
-            w.tMax = h.t;
-            if (ANY) { done = true; break; }
+            if (ANY) { w.prim = (int)FloatToBits(tc.y); w.tMax = h.t; done = true; break; }
+            if (WalkAccept(bvh, w, h.t)) {
+                w.prim = (int)FloatToBits(tc.y);
+                w.route = FloatToBits(tc.w);
+                w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;
+            }
         }
     }
     w.node = (done || st.empty()) ? NODE_NONE : st.pop();
