@@ -1196,7 +1196,7 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
 }
 
 // Minimal PLY reader (ascii + binary_little_endian; vertex x,y,z[,nx,ny,nz][,u,v|s,t], face vertex_indices
-// with triangles or quads split as (0,1,2),(0,2,3) — TriQuadMesh::ReadPLY + ConvertToOnlyTriangles, util/mesh.cpp:158-420)
+// with triangle faces — TriQuadMesh::ReadPLY, util/mesh.cpp:158-420; quad faces are bilinear patches in the reference: refused)
 bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
     std::ifstream in(fn, std::ios::binary);
     if (!in) { *err = "unable to open PLY file"; return false; }
@@ -1260,7 +1260,6 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
                     else if (p.name == "v" || p.name == "t" || p.name == "texture_v" || p.name == "texture_t") out->uv[i].y = v;
                 }
         } else if (e.name == "face") {
-            std::vector<int> quads;
             for (long i = 0; i < e.count; ++i)
                 for (const Prop &p : e.props) {
                     if (!p.list) { readNum(p.type); continue; }
@@ -1269,14 +1268,14 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
                     for (int k = 0; k < n; ++k) idx[k] = (int)readNum(p.type);
                     if (p.name != "vertex_indices" && p.name != "vertex_index") continue;
                     if (n == 3) out->indices.insert(out->indices.end(), idx.begin(), idx.end());
-                    else if (n == 4) quads.insert(quads.end(), idx.begin(), idx.end());
-                    else { *err = "only triangles and quads are supported"; return false; }
+                    else if (n == 4) {
+                        // the reference turns the quad faces of a plymesh into BilinearPatch shapes (shapes.cpp:1465-1472, face
+                        // order 0,1,3,2 of util/mesh.cpp:302-305), not into triangle pairs: splitting them here would render a
+                        // different surface.  Bilinear patches are not built yet -> refuse, do not approximate.
+                        *err = "quad faces (bilinear patches in pbrt-v4) are not supported by this build";
+                        return false;
+                    } else { *err = "only triangle faces are supported (the reference accepts triangles and quads)"; return false; }
                 }
-            // ConvertToOnlyTriangles (util/mesh.cpp:407-428): quads appended after the triangles as (0,1,3),(0,3,2)
-            for (size_t q = 0; q + 3 < quads.size(); q += 4) {
-                out->indices.push_back(quads[q]); out->indices.push_back(quads[q + 1]); out->indices.push_back(quads[q + 3]);
-                out->indices.push_back(quads[q]); out->indices.push_back(quads[q + 3]); out->indices.push_back(quads[q + 2]);
-            }
         } else {
             for (long i = 0; i < e.count; ++i)
                 for (const Prop &p : e.props) {
