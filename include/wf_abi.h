@@ -275,6 +275,25 @@ typedef struct wf_quadric {
     wf_transform render_from_object;   /* m = renderFromObject, mInv = objectFromRender */
 } wf_quadric;
 
+/* Object instances (ObjectBegin / ObjectInstance): the reference wraps an instance definition's own BVHAggregate
+ * (built with maxPrimsInNode = 1, scene.cpp:1539-1543) in a TransformedPrimitive (cpu/primitive.h:83-118,
+ * cpu/primitive.cpp:112-130) that enters the top-level BVH with the transformed bounds.  Here: the definition's
+ * triangles live in the global vertex / triangle tables in the definition's own render space, its BVH nodes follow
+ * the top-level ones in bvh_nodes (child and primitive offsets absolute), and an instance is the primitive
+ * n_triangles + n_quadrics + its index.  Area lights inside definitions are not supported by the reference either. */
+typedef struct wf_instance {
+    wf_transform render_from_instance;  /* TransformedPrimitive::renderFromPrimitive: m and mInv */
+    int32_t def;                        /* index into instance_defs */
+    int32_t pad[3];
+} wf_instance;
+typedef struct wf_instance_def {
+    int32_t bvh_root;                   /* root of the definition's BVH in bvh_nodes */
+    int32_t n_nodes;
+    int32_t first_prim, n_prims;        /* its range of bvh_prims */
+    float bounds[6];                    /* BVHAggregate::Bounds() = root bounds */
+    int32_t pad[2];
+} wf_instance_def;
+
 enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1, WF_CAMERA_SPHERICAL = 2 };
 typedef struct wf_camera {
     int32_t type;
@@ -395,6 +414,10 @@ typedef struct wf_scene_desc {
     /* quadrics */
     int32_t n_quadrics, pad_quadrics;
     const wf_quadric *quadrics;
+    /* object instances: the top-level BVH is bvh_nodes[0 .. n_top_bvh_nodes), over bvh_prims[0 .. n_top_prims) */
+    int32_t n_instances, n_instance_defs, n_top_bvh_nodes, n_top_prims;
+    const wf_instance *instances;
+    const wf_instance_def *instance_defs;
 } wf_scene_desc;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -437,10 +460,10 @@ typedef struct wf_ray_queue {
 
 /* Result of IntersectClosest per ray, used by parity tests and by the counting variant. */
 typedef struct wf_hit_record {
-    int32_t prim;                /* global triangle id or -1 */
+    int32_t prim;                /* global triangle id (or n_triangles + quadric index), -1 = no hit */
     float t, b0, b1, b2;
     int32_t nodes_visited, tris_tested;
-    int32_t pad;
+    int32_t instance;            /* index of the object instance the hit primitive was reached through, -1 = top level */
 } wf_hit_record;
 
 typedef struct wf_ctx wf_ctx;    /* opaque: device, stream, uploaded scene, queues, film */

@@ -15,6 +15,8 @@
 #include <pbrt/util/sampling.h>
 #include <pbrt/util/scattering.h>
 #include <pbrt/util/spectrum.h>
+#include <pbrt/util/transform.h>
+#include <pbrt/interaction.h>
 
 #include <cstdio>
 #include <string>
@@ -212,6 +214,56 @@ int main(int argc, char **argv) {
         }
         writeBin(dir + "/scalar_in.bin", in.data(), in.size() * 4);
         writeBin(dir + "/scalar_out.bin", out.data(), out.size() * 4);
+    }
+    // ---- instance: what TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125) does to a ray and to the interaction.
+    //      in (32 floats): translate[3], rotate angle + axis[3], scale[3], ray o[3] d[3] tMax, interaction p[3] pError[3]
+    //      n[3] dpdu[3] wo[3];   out (60): m[16], mInv[16], ApplyInverse(ray): o[3] d[3] tMax, transformed interaction:
+    //      pi lo[3] hi[3], n[3], dpdu[3], shading.n[3] (FaceForward applied), wo[3]
+    {
+        const int n = 2048, wi = 32, wo_ = 60;
+        Lcg g(7);
+        std::vector<float> in((size_t)n * wi), out((size_t)n * wo_);
+        for (int i = 0; i < n; ++i) {
+            float *r = &in[(size_t)i * wi], *w = &out[(size_t)i * wo_];
+            for (int k = 0; k < 3; ++k) r[k] = g.range(-5, 5);
+            r[3] = g.range(-180, 180);
+            for (int k = 0; k < 3; ++k) r[4 + k] = g.range(-1, 1);
+            for (int k = 0; k < 3; ++k) r[7 + k] = (i % 5 == 0 ? -1.f : 1.f) * g.range(0.3f, 2.5f);
+            if (i % 7 == 0) { r[3] = 0; r[7] = r[8] = r[9] = 1; }  // pure translation
+            for (int k = 0; k < 3; ++k) r[10 + k] = g.range(-8, 8);
+            Vector3f d = Normalize(Vector3f(g.range(-1, 1), g.range(-1, 1), g.range(-1, 1)));
+            r[13] = d.x; r[14] = d.y; r[15] = d.z;
+            r[16] = (i % 3 == 0) ? Infinity : g.range(0.1f, 20);
+            for (int k = 0; k < 3; ++k) r[17 + k] = g.range(-3, 3);
+            for (int k = 0; k < 3; ++k) r[20 + k] = (i % 4 == 0) ? 0.f : g.range(0, 1e-5f);
+            Vector3f nn = Normalize(Vector3f(g.range(-1, 1), g.range(-1, 1), g.range(-1, 1)));
+            r[23] = nn.x; r[24] = nn.y; r[25] = nn.z;
+            for (int k = 0; k < 3; ++k) r[26 + k] = g.range(-2, 2);
+            Vector3f wv = Normalize(Vector3f(g.range(-1, 1), g.range(-1, 1), g.range(-1, 1)));
+            r[29] = wv.x; r[30] = wv.y; r[31] = wv.z;
+            Transform t = Translate(Vector3f(r[0], r[1], r[2])) * Rotate(r[3], Vector3f(r[4], r[5], r[6])) * Scale(r[7], r[8], r[9]);
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) { w[4 * a + b] = t.GetMatrix()[a][b]; w[16 + 4 * a + b] = t.GetInverseMatrix()[a][b]; }
+            Float tMax = r[16];
+            Ray ray = t.ApplyInverse(Ray(Point3f(r[10], r[11], r[12]), Vector3f(r[13], r[14], r[15])), &tMax);
+            w[32] = ray.o.x; w[33] = ray.o.y; w[34] = ray.o.z; w[35] = ray.d.x; w[36] = ray.d.y; w[37] = ray.d.z; w[38] = tMax;
+            Point3fi pi(Point3f(r[17], r[18], r[19]), Vector3f(r[20], r[21], r[22]));
+            Normal3f ng(r[23], r[24], r[25]);
+            Vector3f dpdu(r[26], r[27], r[28]), dpdv = Cross(Vector3f(ng), dpdu);
+            SurfaceInteraction si(pi, Point2f(0.25f, 0.5f), Vector3f(r[29], r[30], r[31]), dpdu, dpdv, Normal3f(0, 0, 0), Normal3f(0, 0, 0), 0.f, false);
+            si.n = ng;
+            si.shading.n = -ng;  // so that the FaceForward at the end of the transform acts
+            SurfaceInteraction ts = t(si);
+            w[39] = ts.pi.x.LowerBound(); w[40] = ts.pi.y.LowerBound(); w[41] = ts.pi.z.LowerBound();
+            w[42] = ts.pi.x.UpperBound(); w[43] = ts.pi.y.UpperBound(); w[44] = ts.pi.z.UpperBound();
+            w[45] = ts.n.x; w[46] = ts.n.y; w[47] = ts.n.z;
+            w[48] = ts.dpdu.x; w[49] = ts.dpdu.y; w[50] = ts.dpdu.z;
+            w[51] = ts.shading.n.x; w[52] = ts.shading.n.y; w[53] = ts.shading.n.z;
+            w[54] = ts.wo.x; w[55] = ts.wo.y; w[56] = ts.wo.z;
+            w[57] = w[58] = w[59] = 0;
+        }
+        writeBin(dir + "/instance_in.bin", in.data(), in.size() * 4);
+        writeBin(dir + "/instance_out.bin", out.data(), out.size() * 4);
     }
     return 0;
 }

@@ -88,6 +88,17 @@ int main(int argc, char **argv) {
         BasicScene scene;
         BasicSceneBuilder builder(&scene);
         ParseFiles(&builder, {std::string(argv[1])});
+        {   // object instances as the parser recorded them: m and mInv of renderFromInstance, 32 floats each
+            FILE *f = fopen((std::string(argv[2]) + "/instances.bin").c_str(), "wb");
+            for (const auto &inst : scene.instances)
+                if (inst.renderFromInstance) {
+                    float rec[32];
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b) { rec[4 * a + b] = inst.renderFromInstance->GetMatrix()[a][b]; rec[16 + 4 * a + b] = inst.renderFromInstance->GetInverseMatrix()[a][b]; }
+                    fwrite(rec, 4, 32, f);
+                }
+            fclose(f);
+        }
         WavefrontPathIntegrator *in = new WavefrontPathIntegrator(pstd::pmr::get_default_resource(), scene);
         std::string dir = argv[2];
         Bounds2i pb = in->film.PixelBounds();

@@ -170,5 +170,39 @@ int main(int argc, char **argv) {
         }
         writeBin(od + "/scalar_out.bin", out.data(), out.size() * 4);
     }
+    {   // instance: the ray and interaction transforms of TransformedPrimitive::Intersect.  The matrices are taken from the
+        // reference's output (they are the host parser's job, checked by the instances golden scene); everything else is
+        // recomputed with InstanceRay / XfP3i / InstanceInteractionP / InstanceWoP
+        std::vector<float> in = readBin<float>(gd + "/instance_in.bin"), ref = readBin<float>(gd + "/instance_out.bin");
+        const int wi = 32, wo_ = 60, n = (int)in.size() / wi;
+        std::vector<float> out((size_t)n * wo_);
+        for (int i = 0; i < n; ++i) {
+            const float *r = &in[(size_t)i * wi], *rf = &ref[(size_t)i * wo_];
+            float *w = &out[(size_t)i * wo_];
+            wf_instance inst{};
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) { inst.render_from_instance.m[a][b] = rf[4 * a + b]; inst.render_from_instance.mInv[a][b] = rf[16 + 4 * a + b]; }
+            for (int k = 0; k < 32; ++k) w[k] = rf[k];
+            float tMax = r[16];
+            V3 o, d;
+            InstanceRay(inst, V3{r[10], r[11], r[12]}, V3{r[13], r[14], r[15]}, &tMax, &o, &d);
+            w[32] = o.x; w[33] = o.y; w[34] = o.z; w[35] = d.x; w[36] = d.y; w[37] = d.z; w[38] = tMax;
+            SurfIntr si{};
+            si.pi = MakeP3i(V3{r[17], r[18], r[19]}, V3{r[20], r[21], r[22]});
+            si.n = N3{r[23], r[24], r[25]};
+            si.ns = -si.n;
+            si.dpdu = V3{r[26], r[27], r[28]};
+            InstanceInteractionP(&inst, &si);
+            w[39] = si.pi.lo.x; w[40] = si.pi.lo.y; w[41] = si.pi.lo.z; w[42] = si.pi.hi.x; w[43] = si.pi.hi.y; w[44] = si.pi.hi.z;
+            w[45] = si.n.x; w[46] = si.n.y; w[47] = si.n.z;
+            w[48] = si.dpdu.x; w[49] = si.dpdu.y; w[50] = si.dpdu.z;
+            w[51] = si.ns.x; w[52] = si.ns.y; w[53] = si.ns.z;
+            // ts.wo = Normalize(t(si.wo)), si.wo = Normalize(wo) from the Interaction ctor
+            V3 wv = Normalize(XfVector3(inst.render_from_instance.m, Normalize(V3{r[29], r[30], r[31]})));
+            w[54] = wv.x; w[55] = wv.y; w[56] = wv.z;
+            w[57] = w[58] = w[59] = 0;
+        }
+        writeBin(od + "/instance_out.bin", out.data(), out.size() * 4);
+    }
     return 0;
 }

@@ -72,6 +72,7 @@ struct WorkState {
     uint32_t *sampleTops;
     RayQueueV rq[2];
     F4 *hit;       // per ray slot of the current queue: triangle id (int bits), b0, b1, b2
+    int32_t *hitInst;  // per ray slot: object instance of the hit (-1 = top level); allocated when the scene has instances
     float *hitT;   // tHit of the closest hit (only with media: MediumSampleWorkItem.tMax, workitems.h:219-250)
     int32_t *escapedQ, *hitLightQ;
     // MediumSampleQueue / MediumScatterQueue (workitems.h:219-262) as index queues over the current ray queue: the
@@ -305,10 +306,11 @@ WF_HD int SurfaceMedium(const wf_mesh &mesh, N3 n, V3 w, int rayMedium) {
 // (materials.h:284-294).  The reference hashes (p, wo, the two Material tagged POINTERS): its choice depends on heap
 // addresses and differs from run to run, so this is the one place where parity with it is statistical by construction;
 // here the two material ids take the pointers' place.
-WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, float b0, float b1, float b2, V3 wo) {
+WF_HD int HitInst(const SceneView &sv, const WorkState &ws, int i) { return sv.nInstances > 0 ? ws.hitInst[i] : -1; }
+WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, int inst, float b0, float b1, float b2, V3 wo) {
     if (sv.materials[matId].type != WF_MAT_MIX) return matId;
     SurfIntr si;
-    HitInteraction(sv, prim, b0, b1, b2, &si);
+    HitInteraction(sv, prim, inst, b0, b1, b2, &si);
     TexCtx tc;
     tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
     while (sv.materials[matId].type == WF_MAT_MIX) {
@@ -329,14 +331,14 @@ WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, float b0, float b
 }
 // routing of a surface hit whose record is already in ws.hit[i] (beta, r_u, r_l are read from the ray slot by the
 // consumers): interface re-push / area light / material queue
-WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, int i, int prim, float b0, float b1, float b2) {
+WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, int i, int prim, int inst, float b0, float b1, float b2) {
     const wf_mesh mesh = sv.meshes[sv.triMesh[prim]];
     if (mesh.material < 0) {
         // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
         const RayQueueV &q = ws.rq[cur];
         const RayQueueV &nq = ws.rq[cur ^ 1];
         SurfIntr si;
-        HitInteraction(sv, prim, b0, b1, b2, &si);
+        HitInteraction(sv, prim, inst, b0, b1, b2, &si);
         F4 o = q.o[i], d = q.d[i];
         V3 rd{d.x, d.y, d.z};
         V3 no = OffsetRayOrigin(si.pi, si.n, rd);
@@ -361,14 +363,15 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
     int matId = mesh.material;
     if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) {
         F4 d = ws.rq[cur].d[i];
-        matId = ResolveMix(sv, matId, prim, b0, b1, b2, V3{-d.x, -d.y, -d.z});
+        matId = ResolveMix(sv, matId, prim, inst, b0, b1, b2, V3{-d.x, -d.y, -d.z});
         ws.mixMat[i] = matId;
     }
     int mtype = sv.materials[matId].type;
     int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + mtype) * CNT_STRIDE]);
     ws.matQ[mtype][slot] = i;
 }
-WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, float tHit, float b0, float b1, float b2) {
+WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, int inst, float tHit, float b0, float b1, float b2) {
+    if (sv.nInstances > 0) ws.hitInst[i] = found ? inst : -1;
     if (sv.haveMedia && ws.rq[cur].meta[i].w >= 0) {
         // ray.medium set: the medium is sampled first, up to the surface or to infinity (intersect.h:16-29,53-88)
         ws.hit[i] = F4{BitsToFloat((uint32_t)(found ? prim : -1)), b0, b1, b2};
@@ -385,7 +388,7 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
         return;
     }
     ws.hit[i] = F4{BitsToFloat((uint32_t)prim), b0, b1, b2};
-    RouteSurfaceHit(sv, ws, cur, i, prim, b0, b1, b2);
+    RouteSurfaceHit(sv, ws, cur, i, prim, inst, b0, b1, b2);
 }
 
 // the follow-up of the HIP traversal kernel for hits on a MixMaterial (ws.mixQ): resolve, then the material queue
@@ -393,7 +396,8 @@ WF_HD void KResolveMix(const SceneView &sv, const WorkState &ws, int cur, int qi
     const int i = ws.mixQ[qi];
     F4 h = ws.hit[i], d = ws.rq[cur].d[i];
     int prim = (int)FloatToBits(h.x);
-    int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, h.y, h.z, h.w, V3{-d.x, -d.y, -d.z});
+    const int inst = HitInst(sv, ws, i);
+    int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, inst, h.y, h.z, h.w, V3{-d.x, -d.y, -d.z});
     ws.mixMat[i] = matId;
     int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + sv.materials[matId].type) * CNT_STRIDE]);
     ws.matQ[sv.materials[matId].type][slot] = i;
@@ -408,13 +412,14 @@ WF_HD void KResolveMix(const SceneView &sv, const WorkState &ws, int cur, int qi
 // an out-of-line callee's register count becomes the kernel's and costs it a wave of occupancy).
 template <bool GENERAL>
 __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, int cur, int i, bool valid, int prim, uint32_t route,
-                                      float tHit, float b0, float b1, float b2) {
+                                      float tHit, float b0, float b1, float b2, int inst = -1) {
     constexpr int MS = 2 + WF_MAT_NTYPES;
     constexpr int MIXQ = MS + 1;
     constexpr int NID = MIXQ + 1;
     __shared__ int s_cnt[NID][16];
     __shared__ int s_base[NID];
     const bool found = valid && prim >= 0;
+    if (valid && sv.nInstances > 0) ws.hitInst[i] = found ? inst : -1;
     unsigned dest = 0;
     const bool inMedium = sv.haveMedia && valid && ws.rq[cur].meta[i].w >= 0;
     if (inMedium) {
@@ -468,7 +473,7 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             const RayQueueV &q = ws.rq[cur];
             const RayQueueV &nq = ws.rq[cur ^ 1];
             SurfIntr si;
-            if constexpr (GENERAL) HitInteraction(sv, prim, b0, b1, b2, &si);
+            if constexpr (GENERAL) HitInteraction(sv, prim, inst, b0, b1, b2, &si);
             else TriangleInteraction(sv, prim, b0, b1, b2, &si);
             F4 o = q.o[i], d = q.d[i];
             V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
@@ -570,7 +575,7 @@ WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, in
         }
         return;
     }
-    RouteSurfaceHit(sv, ws, cur, i, prim, h.y, h.z, h.w);
+    RouteSurfaceHit(sv, ws, cur, i, prim, HitInst(sv, ws, i), h.y, h.z, h.w);
 }
 
 // K6: SampleMediumScattering<HGPhaseFunction>, wavefront/media.cpp:259-352
@@ -651,13 +656,13 @@ WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, 
     RNG rng(Hash3f(ro), Hash3f(rd));
     S4 T_ray = S4c(1.f), r_u = S4c(1.f), r_l = S4c(1.f);
     while (!(rd.x == 0 && rd.y == 0 && rd.z == 0)) {
-        int prim = -1;
+        int prim = -1, inst = -1;
         float b0 = 0, b1 = 0, b2 = 0;
-        bool hit = trace(ro, rd, tMax, &prim, &b0, &b1, &b2);
+        bool hit = trace(ro, rd, tMax, &prim, &inst, &b0, &b1, &b2);
         SurfIntr si;
         bool opaque = false;
         if (hit) {
-            HitInteraction(sv, prim, b0, b1, b2, &si);
+            HitInteraction(sv, prim, inst, b0, b1, b2, &si);
             opaque = sv.meshes[si.mesh].material >= 0;
         }
         if (opaque) {
@@ -743,7 +748,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     F4 h = ws.hit[i];
     int prim = (int)FloatToBits(h.x);
     SurfIntr si;
-    HitInteraction(sv, prim, h.y, h.z, h.w, &si);
+    HitInteraction(sv, prim, -1, h.y, h.z, h.w, &si);  // emitters are top-level primitives (no area lights inside object instances)
     const wf_mesh &mesh = sv.meshes[si.mesh];
     int lightId = mesh.first_light + (prim - mesh.first_tri);
     const wf_light &light = sv.lights[lightId];
@@ -751,7 +756,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     // intr.wo is normalised by the Interaction ctor (interaction.h:40-43); items that went through the medium
     // stage carry -ray.d as it is (media.cpp:206-208)
     V3 wo{-d4.x, -d4.y, -d4.z};
-    if (!(sv.haveMedia && m.w >= 0)) wo = IntrWo(sv, prim, wo);
+    if (!(sv.haveMedia && m.w >= 0)) wo = IntrWo(sv, prim, -1, wo);
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
     S4 Le = AreaLightL(sv, light, si.n, si.uv, wo, lambda);
     if (!Le) return;
@@ -832,8 +837,9 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         bool anyNonSpecularBounces0 = meta.z & RAYFLAG_ANY_NONSPECULAR;
         F4 h = ws.hit[i];
         int prim = (int)FloatToBits(h.x);
+        const int inst = HitInst(sv, ws, i);
         SurfIntr si;
-        HitInteraction(sv, prim, h.y, h.z, h.w, &si);
+        HitInteraction(sv, prim, inst, h.y, h.z, h.w, &si);
         const wf_mesh &mesh = sv.meshes[si.mesh];
         int matId = mesh.material;
         if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) matId = ws.mixMat[i];
@@ -844,7 +850,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         // intr.wo: the Interaction constructor normalises it (interaction.h:40-43), also for unit-length ray.d;
         // items enqueued by the medium stage carry -ray.d as it is (media.cpp:240)
         V3 wo{-d4.x, -d4.y, -d4.z};
-        if (!(sv.haveMedia && meta.w >= 0)) wo = IntrWo(sv, prim, wo);
+        if (!(sv.haveMedia && meta.w >= 0)) wo = IntrWo(sv, prim, inst, wo);
         // differentials of position and (u, v) at the intersection (surfscatter.cpp:73-104)
         TexCtx tc;
         tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;

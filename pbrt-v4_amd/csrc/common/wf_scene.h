@@ -57,6 +57,10 @@ struct SceneView {
     const uint16_t *haltonPerms;
     const wf_quadric *quadrics;
     int nQuadrics;
+    // object instances (include/wf_abi.h wf_instance): primitive id nTriangles + nQuadrics + instance index
+    const wf_instance *instances;
+    const wf_instance_def *instanceDefs;
+    int nInstances;
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
     int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
     wf_options options;

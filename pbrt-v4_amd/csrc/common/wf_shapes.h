@@ -126,6 +126,14 @@ WF_HD void TriVerts(const SceneView &sv, int tri, V3 *p0, V3 *p1, V3 *p2) {
 // Sphere (shapes.h:107-383).  The quadric test runs in object space on intervals, as the reference's.
 // Transform::operator()(Point3fi) for an exact point and Transform::operator()(Vector3fi) for an exact vector
 // (util/transform.h:133-176, 272-306); affine transforms only (w' == 1, checked at load).
+// Interval / Float (util/math.h:1027-1035) and the homogeneous divide the reference applies whenever w' != 1: the
+// numerically inverted matrix of a composite transform can carry 0.99999994 in its last element
+WF_HD Ivl DivF(Ivl i, float f) {
+    if (f == 0) return Ivl(-WF_INFINITY, WF_INFINITY);
+    if (f > 0) return Ivl(NextFloatDown(i.lo / f), NextFloatUp(i.hi / f));
+    return Ivl(NextFloatDown(i.hi / f), NextFloatUp(i.lo / f));
+}
+WF_HD float XfW(const float m[4][4], V3 p) { return (m[3][0] * p.x + m[3][1] * p.y) + (m[3][2] * p.z + m[3][3]); }
 WF_HD Ivl3 XfPointExactI(const float m[4][4], V3 p) {
     float x = p.x, y = p.y, z = p.z;
     float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
@@ -134,7 +142,10 @@ WF_HD Ivl3 XfPointExactI(const float m[4][4], V3 p) {
     float ex = gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z) + abs(m[0][3]));
     float ey = gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z) + abs(m[1][3]));
     float ez = gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z) + abs(m[2][3]));
-    return Ivl3{Ivl::FromValueAndError(xp, ex), Ivl::FromValueAndError(yp, ey), Ivl::FromValueAndError(zp, ez)};
+    Ivl3 r{Ivl::FromValueAndError(xp, ex), Ivl::FromValueAndError(yp, ey), Ivl::FromValueAndError(zp, ez)};
+    const float wp = XfW(m, p);
+    if (wp != 1) { r.x = DivF(r.x, wp); r.y = DivF(r.y, wp); r.z = DivF(r.z, wp); }
+    return r;
 }
 WF_HD Ivl3 XfVectorExactI(const float m[4][4], V3 v) {
     float x = v.x, y = v.y, z = v.z;
@@ -166,7 +177,13 @@ WF_HD P3i XfPointI(const float m[4][4], V3 pIn, V3 eIn) {
            gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z) + abs(m[1][3]));
     pe.z = (gamma(3) + 1) * (abs(m[2][0]) * e.x + abs(m[2][1]) * e.y + abs(m[2][2]) * e.z) +
            gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z) + abs(m[2][3]));
-    return MakeP3i(V3{xp, yp, zp}, pe);
+    P3i r = MakeP3i(V3{xp, yp, zp}, pe);
+    const float wp = XfW(m, p);
+    if (wp != 1) {
+        Ivl rx = DivF(Ivl(r.lo.x, r.hi.x), wp), ry = DivF(Ivl(r.lo.y, r.hi.y), wp), rz = DivF(Ivl(r.lo.z, r.hi.z), wp);
+        r = P3i{V3{rx.lo, ry.lo, rz.lo}, V3{rx.hi, ry.hi, rz.hi}};
+    }
+    return r;
 }
 WF_HD V3 XfPoint3(const float m[4][4], V3 p) {  // Transform::operator()(Point3f), affine
     return V3{m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3], m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3],
@@ -332,13 +349,135 @@ WF_HD bool AlphaTestPasses(const SceneView &sv, int tri, float b0, float b1, flo
     return !(u > a);
 }
 
+struct ClosestHit { int prim; TriHit h; int nodesVisited, trisTested; int inst; };
+
+// TransformedPrimitive::Intersect / IntersectP (cpu/primitive.cpp:112-130): the ray in the instance's space,
+// Transform::ApplyInverse(Ray, &tMax) (util/transform.h:416-429) over ApplyInverse(Point3fi) for an exact point
+// (util/transform.cpp:263-306: no translation term in the exact case) and ApplyInverse(Vector3f).
+WF_HD void InstanceRay(const wf_instance &in, V3 o, V3 d, float *tMax, V3 *oOut, V3 *dOut) {
+    const float(*mi)[4] = in.render_from_instance.mInv;
+    const float x = o.x, y = o.y, z = o.z;
+    const float xp = (mi[0][0] * x + mi[0][1] * y) + (mi[0][2] * z + mi[0][3]);
+    const float yp = (mi[1][0] * x + mi[1][1] * y) + (mi[1][2] * z + mi[1][3]);
+    const float zp = (mi[2][0] * x + mi[2][1] * y) + (mi[2][2] * z + mi[2][3]);
+    const float ex = gamma(3) * (abs(mi[0][0] * x) + abs(mi[0][1] * y) + abs(mi[0][2] * z));
+    const float ey = gamma(3) * (abs(mi[1][0] * x) + abs(mi[1][1] * y) + abs(mi[1][2] * z));
+    const float ez = gamma(3) * (abs(mi[2][0] * x) + abs(mi[2][1] * y) + abs(mi[2][2] * z));
+    Ivl ox = Ivl::FromValueAndError(xp, ex), oy = Ivl::FromValueAndError(yp, ey), oz = Ivl::FromValueAndError(zp, ez);
+    const float wp = XfW(mi, o);
+    if (wp != 1) { ox = DivF(ox, wp); oy = DivF(oy, wp); oz = DivF(oz, wp); }
+    const V3 dd = XfVector3(mi, d);
+    const float lengthSquared = LengthSquared(dd);
+    if (lengthSquared > 0) {
+        const V3 oError{(ox.hi - ox.lo) / 2, (oy.hi - oy.lo) / 2, (oz.hi - oz.lo) / 2};
+        const float dt = Dot(Abs(dd), oError) / lengthSquared;
+        const V3 off = dd * dt;
+        ox = ox + Ivl(off.x); oy = oy + Ivl(off.y); oz = oz + Ivl(off.z);
+        *tMax -= dt;
+    }
+    *oOut = V3{ox.mid(), oy.mid(), oz.mid()};
+    *dOut = dd;
+}
+
+// BVHAggregate::Intersect / IntersectP of an instance definition's own BVH (triangles only), on the shared stack above
+// its current top.  tMax is updated in place; returns whether a hit was recorded.
+template <typename Stack>
+WF_HD bool BVHIntersectClosestDef(const SceneView &sv, int root, V3 o, V3 d, float *tMaxIO, Stack &stack, ClosestHit *out) {
+    float tMax = *tMaxIO;
+    bool hitAny = false;
+    const int base = stack.n;
+    V3 invDir{1 / d.x, 1 / d.y, 1 / d.z};
+    int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
+    int currentNodeIndex = root;
+    while (true) {
+        ++out->nodesVisited;
+        const wf_bvh_node *node = &sv.bvhNodes[currentNodeIndex];
+        if (BoxIntersectP(node->bmin, node->bmax, o, tMax, invDir, negMask)) {
+            if (node->nprims > 0) {
+                for (int i = 0; i < node->nprims; ++i) {
+                    int tri = sv.bvhPrims[node->offset + i];
+                    ++out->trisTested;
+                    V3 p0, p1, p2;
+                    TriVerts(sv, tri, &p0, &p1, &p2);
+                    TriHit h;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) {
+                        if (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d)) {
+                            out->prim = tri;
+                            out->h = h;
+                            tMax = h.t;
+                            hitAny = true;
+                        } else ++out->trisTested;  // the reference re-intersects the primitive with the respawned ray (cpu/primitive.cpp:62-70): one more test, never a hit
+                    }
+                }
+                if (stack.n == base) break;
+                currentNodeIndex = stack.pop();
+            } else {
+                if ((negMask >> node->axis) & 1) {
+                    stack.push(currentNodeIndex + 1);
+                    currentNodeIndex = node->offset;
+                } else {
+                    stack.push(node->offset);
+                    currentNodeIndex = currentNodeIndex + 1;
+                }
+            }
+        } else {
+            if (stack.n == base) break;
+            currentNodeIndex = stack.pop();
+        }
+    }
+    *tMaxIO = tMax;
+    return hitAny;
+}
+template <typename Stack>
+WF_HD bool BVHIntersectAnyDef(const SceneView &sv, int root, V3 o, V3 d, float tMax, Stack &stack, int *nv, int *nt) {
+    const int base = stack.n;
+    V3 invDir{1.f / d.x, 1.f / d.y, 1.f / d.z};
+    int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
+    int currentNodeIndex = root;
+    bool found = false;
+    while (true) {
+        ++*nv;
+        const wf_bvh_node *node = &sv.bvhNodes[currentNodeIndex];
+        if (BoxIntersectP(node->bmin, node->bmax, o, tMax, invDir, negMask)) {
+            if (node->nprims > 0) {
+                for (int i = 0; i < node->nprims && !found; ++i) {
+                    int tri = sv.bvhPrims[node->offset + i];
+                    ++*nt;
+                    V3 p0, p1, p2;
+                    TriVerts(sv, tri, &p0, &p1, &p2);
+                    TriHit h;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) {
+                        if (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d)) found = true;
+                        else ++*nt;
+                    }
+                }
+                if (found || stack.n == base) break;
+                currentNodeIndex = stack.pop();
+            } else {
+                if ((negMask >> node->axis) & 1) {
+                    stack.push(currentNodeIndex + 1);
+                    currentNodeIndex = node->offset;
+                } else {
+                    stack.push(node->offset);
+                    currentNodeIndex = currentNodeIndex + 1;
+                }
+            }
+        } else {
+            if (stack.n == base) break;
+            currentNodeIndex = stack.pop();
+        }
+    }
+    stack.n = base;  // an early out leaves the definition's entries behind
+    return found;
+}
+
 // Reference-order BVH walk.  Stack is any type with push(int)/pop()/empty(); the HIP kernels pass an
 // LDS-backed short stack (csrc/hip/wf_traverse.hip), the CPU checker a plain array.
-struct ClosestHit { int prim; TriHit h; int nodesVisited, trisTested; };
 
 template <typename Stack>
 WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, ClosestHit *out) {
     out->prim = -1;
+    out->inst = -1;
     out->nodesVisited = 0;
     out->trisTested = 0;
     V3 invDir{1 / d.x, 1 / d.y, 1 / d.z};
@@ -351,12 +490,27 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
             if (node->nprims > 0) {
                 for (int i = 0; i < node->nprims; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
+                    if (tri >= sv.nTriangles + sv.nQuadrics) {
+                        // an object instance: TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125).  tHit stays the
+                        // instance ray's parameter (the reference does not add the origin shift dt back either).
+                        const int inst = tri - sv.nTriangles - sv.nQuadrics;
+                        const wf_instance &in = sv.instances[inst];
+                        float tI = tMax;
+                        V3 oI, dI;
+                        InstanceRay(in, o, d, &tI, &oI, &dI);
+                        if (BVHIntersectClosestDef(sv, sv.instanceDefs[in.def].bvh_root, oI, dI, &tI, stack, out)) {
+                            out->inst = inst;
+                            tMax = tI;
+                        }
+                        continue;
+                    }
                     ++out->trisTested;
                     if (tri >= sv.nTriangles) {
                         // a sphere: the hit record carries pObj in place of the barycentrics
                         QuadricHit qh;
                         if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) {
                             out->prim = tri;
+                            out->inst = -1;
                             out->h.t = qh.tHit; out->h.b0 = qh.pObj.x; out->h.b1 = qh.pObj.y; out->h.b2 = qh.pObj.z;
                             tMax = qh.tHit;
                         }
@@ -365,10 +519,13 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
-                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h) && (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d))) {
-                        out->prim = tri;
-                        out->h = h;
-                        tMax = h.t;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) {
+                        if (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d)) {
+                            out->prim = tri;
+                            out->inst = -1;
+                            out->h = h;
+                            tMax = h.t;
+                        } else ++out->trisTested;  // see BVHIntersectClosestDef
                     }
                 }
                 if (stack.empty()) break;
@@ -404,6 +561,14 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
             if (node->nprims > 0) {
                 for (int i = 0; i < node->nprims && !found; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
+                    if (tri >= sv.nTriangles + sv.nQuadrics) {
+                        const wf_instance &in = sv.instances[tri - sv.nTriangles - sv.nQuadrics];
+                        float tI = tMax;
+                        V3 oI, dI;
+                        InstanceRay(in, o, d, &tI, &oI, &dI);
+                        if (BVHIntersectAnyDef(sv, sv.instanceDefs[in.def].bvh_root, oI, dI, tI, stack, &nv, &nt)) found = true;
+                        continue;
+                    }
                     ++nt;
                     if (tri >= sv.nTriangles) {
                         QuadricHit qh;
@@ -413,7 +578,10 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
-                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h) && (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d))) found = true;
+                    if (IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) {
+                        if (!sv.haveAlpha || AlphaTestPasses(sv, tri, h.b0, h.b1, h.b2, o, d)) found = true;
+                        else ++nt;
+                    }
                 }
                 if (found || stack.empty()) break;
                 currentNodeIndex = stack.pop();
@@ -437,7 +605,7 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
 }
 
 struct ArrayStack {  // int nodesToVisit[64], cpu/aggregates.cpp:538
-    int s[64];
+    int s[128];  // the top-level walk's entries + an instance definition's on top of them
     int n = 0;
     WF_HD void push(int v) { s[n++] = v; }
     WF_HD int pop() { return s[--n]; }
@@ -649,6 +817,9 @@ WF_HD float TrianglePDF(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxN,
         // ctx.SpawnRay(wi) (shapes.h:63-90), Triangle::Intersect with tMax = Infinity
         V3 o = OffsetRayOrigin(ctxPi, ctxN, wi);
         TriHit h;
+#if defined(WF_COUNT_TRI_TESTS) && !defined(__HIP_DEVICE_COMPILE__)
+        WF_COUNT_TRI_TESTS;  // the CPU checker's statistics: this is one of the reference's "Ray-Triangle intersection tests"
+#endif
         if (!IntersectTriangle(o, wi, WF_INFINITY, p0, p1, p2, &h)) return 0;
         SurfIntr si;
         TriangleInteraction(sv, tri, h.b0, h.b1, h.b2, &si);
@@ -776,16 +947,82 @@ WF_NI void SphereWoP(const wf_quadric *s, float x, float y, float z, float *ox, 
     V3 w = Normalize(XfVector3(s->render_from_object.m, Normalize(XfVector3(s->render_from_object.mInv, V3{x, y, z}))));
     *ox = w.x; *oy = w.y; *oz = w.z;
 }
-WF_HD V3 IntrWo(const SceneView &sv, int prim, V3 minusD) {
+// Transform::operator()(Point3fi) (util/transform.h:152-170) for an interval point
+WF_HD P3i XfP3i(const float m[4][4], const P3i &in) {
+    if (in.exact()) {
+        Ivl3 r = XfPointExactI(m, in.mid());
+        return P3i{V3{r.x.lo, r.y.lo, r.z.lo}, V3{r.x.hi, r.y.hi, r.z.hi}};
+    }
+    const V3 p = in.mid(), e = in.err();
+    float x = p.x, y = p.y, z = p.z;
+    float xp = (m[0][0] * x + m[0][1] * y) + (m[0][2] * z + m[0][3]);
+    float yp = (m[1][0] * x + m[1][1] * y) + (m[1][2] * z + m[1][3]);
+    float zp = (m[2][0] * x + m[2][1] * y) + (m[2][2] * z + m[2][3]);
+    V3 pe;
+    pe.x = (gamma(3) + 1) * (abs(m[0][0]) * e.x + abs(m[0][1]) * e.y + abs(m[0][2]) * e.z) +
+           gamma(3) * (abs(m[0][0] * x) + abs(m[0][1] * y) + abs(m[0][2] * z) + abs(m[0][3]));
+    pe.y = (gamma(3) + 1) * (abs(m[1][0]) * e.x + abs(m[1][1]) * e.y + abs(m[1][2]) * e.z) +
+           gamma(3) * (abs(m[1][0] * x) + abs(m[1][1] * y) + abs(m[1][2] * z) + abs(m[1][3]));
+    pe.z = (gamma(3) + 1) * (abs(m[2][0]) * e.x + abs(m[2][1]) * e.y + abs(m[2][2]) * e.z) +
+           gamma(3) * (abs(m[2][0] * x) + abs(m[2][1] * y) + abs(m[2][2] * z) + abs(m[2][3]));
+    P3i r = MakeP3i(V3{xp, yp, zp}, pe);
+    const float wp = XfW(m, p);
+    if (wp != 1) {
+        Ivl rx = DivF(Ivl(r.lo.x, r.hi.x), wp), ry = DivF(Ivl(r.lo.y, r.hi.y), wp), rz = DivF(Ivl(r.lo.z, r.hi.z), wp);
+        r = P3i{V3{rx.lo, ry.lo, rz.lo}, V3{rx.hi, ry.hi, rz.hi}};
+    }
+    return r;
+}
+// Transform::operator()(SurfaceInteraction) (util/transform.cpp:229-261): what TransformedPrimitive::Intersect applies to
+// the interaction found in the instance's space.  Out of line: pointer arguments only (see WF_NI).
+WF_NI void InstanceInteractionP(const wf_instance *in, SurfIntr *si) {
+    const float(*m)[4] = in->render_from_instance.m;
+    const float(*mi)[4] = in->render_from_instance.mInv;
+    SurfIntr r;
+    r.pi = XfP3i(m, si->pi);
+    r.n = Normalize(XfNormal3(mi, si->n));
+    r.uv = si->uv;
+    r.dpdu = XfVector3(m, si->dpdu);
+    r.dpdv = XfVector3(m, si->dpdv);
+    r.dndu = XfNormal3(mi, si->dndu);
+    r.dndv = XfNormal3(mi, si->dndv);
+    r.ns = Normalize(XfNormal3(mi, si->ns));
+    r.dpdus = XfVector3(m, si->dpdus);
+    r.dpdvs = XfVector3(m, si->dpdvs);
+    r.dndus = XfNormal3(mi, si->dndus);
+    r.dndvs = XfNormal3(mi, si->dndvs);
+    r.ns = FaceForward(r.ns, r.n);
+    r.mesh = si->mesh;
+    *si = r;
+}
+WF_NI void InstanceWoP(const wf_instance *in, float x, float y, float z, float *ox, float *oy, float *oz) {
+    // the instance-space interaction's wo = Normalize(-ApplyInverse(ray.d)) (interaction.h:40-43), transformed back and
+    // normalised again (util/transform.cpp:235)
+    V3 w = Normalize(XfVector3(in->render_from_instance.m, Normalize(XfVector3(in->render_from_instance.mInv, V3{x, y, z}))));
+    *ox = w.x; *oy = w.y; *oz = w.z;
+}
+WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
+    if (inst >= 0) {
+        V3 w;
+        InstanceWoP(sv.instances + inst, minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
+        return w;
+    }
     if (prim < sv.nTriangles) return Normalize(minusD);
     V3 w;
     SphereWoP(sv.quadrics + (prim - sv.nTriangles), minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
     return w;
 }
 // the SurfaceInteraction of a hit record (prim, three floats): barycentrics for a triangle, pObj for a sphere
-WF_HD void HitInteraction(const SceneView &sv, int prim, float b0, float b1, float b2, SurfIntr *si) {
+// inst >= 0: the primitive was reached through that object instance — the interaction is built in the definition's
+// space and transformed (TransformedPrimitive::Intersect)
+WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si) {
     if (prim >= sv.nTriangles) SphereInteraction(sv, prim, V3{b0, b1, b2}, si);
     else TriangleInteraction(sv, prim, b0, b1, b2, si);
+    if (inst >= 0) {
+        SurfIntr tmp = *si;
+        InstanceInteractionP(sv.instances + inst, &tmp);
+        *si = tmp;
+    }
 }
 
 // Sphere::Sample(Point2f u), shapes.cpp:38-58

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv,
         ClosestHit ch;
         st.n = 0;
         bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
-        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
+        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.inst, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
         if (COUNT) { nv += ch.nodesVisited; nt += ch.trisTested; nh += found; nr += 1; }
     }
     if (COUNT) {
@@ -238,7 +238,7 @@ struct GeneralPrims {
     __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
     __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], o, d, tMax, qh); }
 };
-template <bool ANY, bool ALPHA, typename Fetch, typename Finish>
+template <bool ANY, bool ALPHA, bool INST = false, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
     LoadTreeTop(bvh);
     for (int base = blockIdx.x * TBLOCK; base < n; base += gridDim.x * TBLOCK) {
@@ -250,6 +250,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
         w.route = 0;
         w.tMax = 0;
         w.b0 = w.b1 = w.b2 = 0;
+        w.inst = w.curInst = -1;
         V3 o{0, 0, 0}, d{0, 0, 0};
         if (valid) {
             float tMax;
@@ -257,6 +258,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
             WalkInit(bvh, w, o, d, tMax);
             st.n = 0;
         }
+        V3 dCur = d;  // the ray direction in the space being walked (render space, or an instance's)
         // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
         // per-lane refill ("streaming": idle lanes take the next rays of the wave's run, leaf / interior step chosen per
         // iteration) — 28 % fewer VALU instructions at 53 % instead of 31 % active lanes, but 5x the vector-L1 line
@@ -278,7 +280,14 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                 }
             }
             if (w.node != NODE_NONE) {
-                if constexpr (ALPHA) LeafStep<ANY, true>(bvh, w, st, GeneralPrims{sv, o, d});
+                if constexpr (INST) {
+                    // object instances travel through the stack as leaf references (wf_traverse.h)
+                    if (w.node == NODE_EXIT) { ExitInstance(bvh, w, st, o, d, &dCur); continue; }
+                    const int first = (int)((~(unsigned)w.node) >> 4);
+                    if (first >= INST_FIRST) { EnterInstance(bvh, w, st, o, d, first - INST_FIRST, &dCur); continue; }
+                    if constexpr (ALPHA) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims{sv, w.o, dCur});
+                    else LeafStep<ANY, false, true>(bvh, w, st);
+                } else if constexpr (ALPHA) LeafStep<ANY, true>(bvh, w, st, GeneralPrims{sv, o, d});
                 else LeafStep<ANY>(bvh, w, st);
             }
         }
@@ -286,13 +295,13 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
     }
 }
 
-template <bool ALPHA>
-__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
+template <bool ALPHA, bool INST = false>
+__global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
     const RayQueueV q = ws.rq[cur];
-    BatchTrace<false, ALPHA>(
+    BatchTrace<false, ALPHA, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = q.o[i], d4 = q.d[i];
@@ -302,7 +311,7 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_closest_fast(const SceneV
             // near-tie seen (wf_traverse.h): the reference-order walk decides (k_closest_retrace)
             const bool amb = valid && WalkAmbiguous(w);
             if (amb) ws.retraceQ[atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1)] = i;
-            KRouteHitBlock<ALPHA>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2);
+            KRouteHitBlock<ALPHA || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
         });
 }
 // the rays k_closest_fast marked as near-ties, in the reference's own traversal order (rare: coplanar overlapping geometry)
@@ -316,15 +325,15 @@ __global__ void __launch_bounds__(BLOCK) k_closest_retrace(const SceneView sv, W
         ClosestHit ch;
         st.n = 0;
         bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
-        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
+        KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.inst, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
     }
 }
-template <bool ALPHA>
-__global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+template <bool ALPHA, bool INST = false>
+__global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true, ALPHA>(
+    BatchTrace<true, ALPHA, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
@@ -333,10 +342,11 @@ __global__ void __launch_bounds__(TBLOCK, WF_TWAVES) k_shadow_fast(const SceneVi
         [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
 }
 
+template <bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<false, false>(
+    BatchTrace<false, false, INST>(
         SceneView{}, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
@@ -348,14 +358,16 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int 
             bool found = w.prim >= 0;
             h.prim = w.prim;
             h.t = found ? WalkT(w) : 0; h.b0 = w.b0; h.b1 = w.b1; h.b2 = w.b2;
-            h.nodes_visited = 0; h.tris_tested = 0; h.pad = WalkAmbiguous(w) ? 1 : 0;
+            h.nodes_visited = WalkAmbiguous(w) ? -1 : 0;  // -1: near-tie, re-traced in reference order by the pass that follows
+            h.tris_tested = 0; h.instance = (INST && found) ? w.inst : -1;
             out[i] = h;
         });
 }
+template <bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true, false>(
+    BatchTrace<true, false, INST>(
         SceneView{}, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
@@ -383,11 +395,11 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride)
-        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, float *b0, float *b1, float *b2) {
+        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
             ClosestHit ch;
             st.n = 0;
             bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
-            if (found) { *prim = ch.prim; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+            if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
             return found;
         });
 }
@@ -400,7 +412,7 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
     LdsStackT st{stackSpill + gtid, stride, 0};
     LoadTreeTop(bvh);
     for (int i = gtid; i < n; i += stride)
-        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, float *b0, float *b1, float *b2) {
+        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
             RayWalk w;
             WalkInit(bvh, w, o, d, tMax);
             st.n = 0;
@@ -420,7 +432,7 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
                 ClosestHit ch;
                 st.n = 0;
                 bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
-                if (found) { *prim = ch.prim; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+                if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
                 return found;
             }
             if (w.prim >= 0) { *prim = w.prim; *b0 = w.b0; *b1 = w.b1; *b2 = w.b2; }
@@ -438,7 +450,8 @@ __global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, W
 }
 // the material kernels live in wf_mat.hip (one translation unit per material type)
 extern "C" {
-#define WF_DECL_MAT(n) void wf_launch_eval_material_##n(hipStream_t, int, const SceneView *, const WorkState *, int);
+#define WF_DECL_MAT(n) void wf_launch_eval_material_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
+                       void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int);
 WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7)
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
@@ -446,12 +459,12 @@ __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkS
 }
 
 // stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
-// onlyMarked: the re-trace pass after k_trace_closest_fast — only the records it marked as near-ties (pad == 1)
+// onlyMarked: the re-trace pass after k_trace_closest_fast — only the records it marked as near-ties (nodes_visited == -1)
 __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int n, const float *rays, wf_hit_record *out, int *stackSpill, int onlyMarked) {
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride) {
-        if (onlyMarked && out[i].pad != 1) continue;
+        if (onlyMarked && out[i].nodes_visited != -1) continue;
         const float *r = rays + (size_t)7 * i;
         ClosestHit ch;
         st.n = 0;
@@ -459,7 +472,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int
         wf_hit_record h;
         h.prim = found ? ch.prim : -1;
         h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;
-        h.nodes_visited = onlyMarked ? 0 : ch.nodesVisited; h.tris_tested = onlyMarked ? 0 : ch.trisTested; h.pad = onlyMarked ? 2 : 0;
+        h.nodes_visited = onlyMarked ? 0 : ch.nodesVisited; h.tris_tested = onlyMarked ? 0 : ch.trisTested; h.instance = found ? ch.inst : -1;
         out[i] = h;
     }
 }
@@ -543,18 +556,29 @@ static int checkReady(wf_ctx *ctx) {
     return 0;
 }
 
-// Reference LinearBVHNode array (depth-first: left child = i + 1, right child = offset) -> QNode (breadth-first
-// numbering, quantised child boxes) + LeafTri (vertices in leaf order).  See wf_traverse.h.
-static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, FastBVH *out) {
+// Reference LinearBVHNode arrays (depth-first: left child = i + 1, right child = offset) -> QNode (breadth-first
+// numbering per tree, quantised child boxes on the tree's own grid) + LeafTri (vertices in leaf order).  The top-level
+// tree comes first; every instance definition's tree follows with its own grid (FastDef).  See wf_traverse.h.
+static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, std::vector<FastDef> *defs, FastBVH *out) {
     const wf_bvh_node *L = d->bvh_nodes;
     const int n = d->n_bvh_nodes;
-    const int nPrims = d->n_triangles + d->n_quadrics;
-    if (n == 0 || (size_t)nPrims >= (1u << 27)) return false;
+    const int nGeom = d->n_triangles + d->n_quadrics;
+    const int nPrims = nGeom + d->n_instances;  // entries of bvh_prims: every triangle / quadric once, every instance once
+    if (n == 0 || (size_t)nPrims >= (size_t)INST_FIRST || d->n_instances >= INST_FIRST) return false;
     for (int i = 0; i < n; ++i)
         if (L[i].nprims > 16) return false;
     tris->resize((size_t)nPrims);
     for (int k = 0; k < nPrims; ++k) {
         int t = d->bvh_prims[k];
+        if (t >= nGeom) {
+            // an object instance: c.z == 4, entered by the INST kernel variants
+            LeafTri lt;
+            lt.a = F4{0, 0, 0, 0};
+            lt.b = F4{0, 0, 0, 0};
+            lt.c = F4{0, BitsToFloat((uint32_t)(t - nGeom)), 4.f, BitsToFloat(0u)};
+            (*tris)[k] = lt;
+            continue;
+        }
         if (t >= d->n_triangles) {
             // a sphere: c.z == 3, tested by the general-primitive kernel variants from wf_quadric (object space)
             const wf_mesh &mesh = d->meshes[d->tri_mesh[t]];
@@ -584,73 +608,71 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         lt.c = F4{p2[2], BitsToFloat((uint32_t)t), degenerate ? 1.f : mesh.alpha_tex >= 0 ? 2.f : 0.f, BitsToFloat(route)};
         (*tris)[k] = lt;
     }
-    // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
-    // it as a float: WalkInit folds base and cell into per-ray fma constants).  Every stored plane lies at least
-    // `margin` outside the float box it bounds; margin = 2^-20 of the largest coordinate magnitude, which covers the
-    // rounding of (base - o) and of the box's own float planes in the reference's slab test.
-    double margin[3];
-    for (int a = 0; a < 3; ++a) {
-        double lo = L[0].bmin[a], hi = L[0].bmax[a];
-        double ext = hi - lo;
-        margin[a] = 0x1p-20 * (std::max(std::fabs(lo), std::fabs(hi)) + ext) + 1e-37;
-        float base = (float)(lo - 2 * margin[a]);
-        while ((double)base > lo - 2 * margin[a]) base = NextFloatDown(base);
-        float cell = (float)((hi + 2 * margin[a] - (double)base) / 65535.0);
-        if (!(cell > 0)) cell = 1e-30f;
-        cell = NextFloatUp(NextFloatUp(cell));
-        out->base[a] = base;
-        out->cell[a] = cell;
-    }
-    {
-        double ext = 0;
-        for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
-        out->absBand = (float)(0x1p-16 * ext);
-    }
-    auto plane = [&](int q, int a) { return (double)out->base[a] + (double)q * (double)out->cell[a]; };
+    nodes->clear();
     bool gridOk = true;
-    auto qlo = [&](float v, int a) {
-        double target = (double)v - margin[a];
-        int q = (int)std::floor((target - out->base[a]) / out->cell[a]);
-        q = std::min(std::max(q, 0), 65535);
-        while (q > 0 && plane(q, a) > target) --q;
-        if (plane(q, a) > target) gridOk = false;
-        return (uint32_t)q;
-    };
-    auto qhi = [&](float v, int a) {
-        double target = (double)v + margin[a];
-        int q = (int)std::ceil((target - out->base[a]) / out->cell[a]);
-        q = std::min(std::max(q, 0), 65535);
-        while (q < 65535 && plane(q, a) < target) ++q;
-        if (plane(q, a) < target) gridOk = false;
-        return (uint32_t)q;
-    };
-    auto leafRef = [&](int i) { return (int)~(((unsigned)L[i].offset << 4) | (unsigned)(L[i].nprims - 1)); };
-    // breadth-first numbering of the interior nodes
-    std::vector<int> order;  // BFS list of linear indices of interior nodes
     std::vector<int> bfsIndex(n, -1);
-    if (L[0].nprims == 0) {
-        order.push_back(0);
-        bfsIndex[0] = 0;
+    // one tree: linear nodes [root, ...) reachable from root; grid written to base / cell; returns the root's QNode index
+    auto buildTree = [&](int root, float baseOut[3], float cellOut[3]) -> int {
+        // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
+        // it as a float: WalkSetRay folds base and cell into per-ray fma constants).  Every stored plane lies at least
+        // `margin` outside the float box it bounds; margin = 2^-20 of the largest coordinate magnitude, which covers the
+        // rounding of (base - o) and of the box's own float planes in the reference's slab test.
+        double margin[3];
+        for (int a = 0; a < 3; ++a) {
+            double lo = L[root].bmin[a], hi = L[root].bmax[a];
+            double ext = hi - lo;
+            margin[a] = 0x1p-20 * (std::max(std::fabs(lo), std::fabs(hi)) + ext) + 1e-37;
+            float base = (float)(lo - 2 * margin[a]);
+            while ((double)base > lo - 2 * margin[a]) base = NextFloatDown(base);
+            float cell = (float)((hi + 2 * margin[a] - (double)base) / 65535.0);
+            if (!(cell > 0)) cell = 1e-30f;
+            cell = NextFloatUp(NextFloatUp(cell));
+            baseOut[a] = base;
+            cellOut[a] = cell;
+        }
+        auto plane = [&](int q, int a) { return (double)baseOut[a] + (double)q * (double)cellOut[a]; };
+        auto qlo = [&](float v, int a) {
+            double target = (double)v - margin[a];
+            int q = (int)std::floor((target - baseOut[a]) / cellOut[a]);
+            q = std::min(std::max(q, 0), 65535);
+            while (q > 0 && plane(q, a) > target) --q;
+            if (plane(q, a) > target) gridOk = false;
+            return (uint32_t)q;
+        };
+        auto qhi = [&](float v, int a) {
+            double target = (double)v + margin[a];
+            int q = (int)std::ceil((target - baseOut[a]) / cellOut[a]);
+            q = std::min(std::max(q, 0), 65535);
+            while (q < 65535 && plane(q, a) < target) ++q;
+            if (plane(q, a) < target) gridOk = false;
+            return (uint32_t)q;
+        };
+        auto leafRef = [&](int i) { return (int)~(((unsigned)L[i].offset << 4) | (unsigned)(L[i].nprims - 1)); };
+        auto packBox = [&](const wf_bvh_node &b, uint32_t q[6], int slot) {
+            for (int a = 0; a < 3; ++a) q[slot * 3 + a] = qlo(b.bmin[a], a) | (qhi(b.bmax[a], a) << 16);
+        };
+        const int qBase = (int)nodes->size();
+        if (L[root].nprims > 0) {
+            // the whole tree is one leaf: a root node whose two children are both that leaf (testing it twice
+            // changes neither the closest hit nor occlusion)
+            QNode qn{};
+            packBox(L[root], qn.q, 0);
+            packBox(L[root], qn.q, 1);
+            qn.left = leafRef(root);
+            qn.right = leafRef(root);
+            nodes->push_back(qn);
+            return qBase;
+        }
+        // breadth-first numbering of the interior nodes
+        std::vector<int> order;
+        order.push_back(root);
+        bfsIndex[root] = qBase;
         for (size_t h = 0; h < order.size(); ++h) {
             int i = order[h];
             for (int c : {i + 1, (int)L[i].offset})
-                if (L[c].nprims == 0) { bfsIndex[c] = (int)order.size(); order.push_back(c); }
+                if (L[c].nprims == 0) { bfsIndex[c] = qBase + (int)order.size(); order.push_back(c); }
         }
-    }
-    auto packBox = [&](const wf_bvh_node &b, uint32_t q[6], int slot) {
-        for (int a = 0; a < 3; ++a) q[slot * 3 + a] = qlo(b.bmin[a], a) | (qhi(b.bmax[a], a) << 16);
-    };
-    if (order.empty()) {
-        // the whole scene is one leaf: a root node whose two children are both that leaf (testing it twice
-        // changes neither the closest hit nor occlusion)
-        QNode qn{};
-        packBox(L[0], qn.q, 0);
-        packBox(L[0], qn.q, 1);
-        qn.left = leafRef(0);
-        qn.right = leafRef(0);
-        nodes->assign(1, qn);
-    } else {
-        nodes->resize(order.size());
+        nodes->resize((size_t)qBase + order.size());
         for (size_t h = 0; h < order.size(); ++h) {
             int i = order[h];
             int l = i + 1, r = L[i].offset;
@@ -659,8 +681,21 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             packBox(L[r], qn.q, 1);
             qn.left = L[l].nprims == 0 ? bfsIndex[l] : leafRef(l);
             qn.right = L[r].nprims == 0 ? bfsIndex[r] : leafRef(r);
-            (*nodes)[h] = qn;
+            (*nodes)[(size_t)qBase + h] = qn;
         }
+        return qBase;
+    };
+    buildTree(0, out->base, out->cell);
+    {
+        double ext = 0;
+        for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
+        out->absBand = (float)(0x1p-16 * ext);
+    }
+    defs->clear();
+    for (int k = 0; k < d->n_instance_defs; ++k) {
+        FastDef fd{};
+        fd.root = d->instance_defs[k].bvh_root >= 0 ? buildTree(d->instance_defs[k].bvh_root, fd.base, fd.cell) : 0;
+        defs->push_back(fd);
     }
     if (!gridOk) return false;
     out->nNodes = (int)nodes->size();
@@ -726,7 +761,10 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.nQuadrics = d->n_quadrics;
     if ((e = devUpload(ctx, &sv.meshes, d->meshes, (size_t)d->n_meshes))) return e;
     if ((e = devUpload(ctx, &sv.bvhNodes, d->bvh_nodes, (size_t)d->n_bvh_nodes))) return e;
-    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles + d->n_quadrics))) return e;
+    if ((e = devUpload(ctx, &sv.bvhPrims, d->bvh_prims, (size_t)d->n_triangles + d->n_quadrics + d->n_instances))) return e;
+    if ((e = devUpload(ctx, &sv.instances, d->instances, (size_t)d->n_instances))) return e;
+    if ((e = devUpload(ctx, &sv.instanceDefs, d->instance_defs, (size_t)d->n_instance_defs))) return e;
+    sv.nInstances = d->n_instances;
     sv.nTriangles = d->n_triangles;
     sv.nBvhNodes = d->n_bvh_nodes;
     if ((e = devUpload(ctx, &sv.spectra, d->spectra, (size_t)d->n_spectra))) return e;
@@ -798,10 +836,13 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     {
         std::vector<QNode> qn;
         std::vector<LeafTri> lt;
-        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &ctx->fast);
+        std::vector<FastDef> fdefs;
+        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &ctx->fast);
         if (ctx->fastOk) {
             if ((e = devUpload(ctx, &ctx->fast.nodes, qn.data(), qn.size()))) return e;
             if ((e = devUpload(ctx, &ctx->fast.tris, lt.data(), lt.size()))) return e;
+            if ((e = devUpload(ctx, &ctx->fast.defs, fdefs.data(), fdefs.size()))) return e;
+            ctx->fast.instances = ctx->svHost.instances;
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
         int perCU = 0;
@@ -871,6 +912,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     }
     if (ctx->svHost.haveMix && ((e = devAlloc(ctx, &ws.mixMat, n)) || (e = devAlloc(ctx, &ws.mixQ, n)))) return e;
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n)) || (e = devAlloc(ctx, &ws.retraceQ, n))) return e;
+    if (ctx->svHost.nInstances > 0 && (e = devAlloc(ctx, &ws.hitInst, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
         if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
     if ((e = devAlloc(ctx, &ws.sq.o, n)) || (e = devAlloc(ctx, &ws.sq.d, n)) || (e = devAlloc(ctx, &ws.sq.Ld, n)) ||
@@ -940,7 +982,11 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     else if (ctx->fastOk) {
-        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        const bool general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
+        if (ctx->svHost.nInstances > 0) {
+            if (general) LAUNCHT("Intersect closest", (k_closest_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+            else LAUNCHT("Intersect closest", (k_closest_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        } else if (general) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
@@ -961,7 +1007,7 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
 int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
-    if (ctx->fastOk && !ctx->countTraversal)
+    if (ctx->fastOk && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the transmittance walk has no two-level variant yet)
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     else
@@ -991,14 +1037,15 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
     {
         Prof prof_(ctx, names[material_type]);
+        const bool tex = ctx->svHost.texNeedsFootprint != 0;
         switch (material_type) {
-        case 1: wf_launch_eval_material_1(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 2: wf_launch_eval_material_2(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 3: wf_launch_eval_material_3(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 4: wf_launch_eval_material_4(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 5: wf_launch_eval_material_5(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 6: wf_launch_eval_material_6(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 7: wf_launch_eval_material_7(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 1: (tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 2: (tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 3: (tex ? wf_launch_eval_material_3_1 : wf_launch_eval_material_3_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 4: (tex ? wf_launch_eval_material_4_1 : wf_launch_eval_material_4_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 5: (tex ? wf_launch_eval_material_5_1 : wf_launch_eval_material_5_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 6: (tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 7: (tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         }
     }
     return 0;
@@ -1007,10 +1054,14 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
-    else if (ctx->fastOk)
-        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+    else if (ctx->fastOk) {
+        const bool general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
+        if (ctx->svHost.nInstances > 0) {
+            if (general) LAUNCHT("Intersect shadow", (k_shadow_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+            else LAUNCHT("Intersect shadow", (k_shadow_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        } else if (general) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
         else LAUNCHT("Intersect shadow", k_shadow_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
-    else
+    } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
@@ -1173,7 +1224,8 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     if (count_visits || !ctx->fastOk) {
         LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 0);
     } else {
-        LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
+        if (ctx->svHost.nInstances > 0) LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast<true>, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
+        else LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast<false>, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
         LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 1);
     }
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
@@ -1198,7 +1250,8 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     if (nodes_visited || tris_tested || !ctx->fastOk) {
         LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svHost, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
     } else {
-        LAUNCHT("trace any fast (host rays)", k_trace_any_fast, ctx->persistentGrid, ctx->fast, n, dr, dres, ctx->stackSpill);
+        if (ctx->svHost.nInstances > 0) LAUNCHT("trace any fast (host rays)", k_trace_any_fast<true>, ctx->persistentGrid, ctx->fast, n, dr, dres, ctx->stackSpill);
+        else LAUNCHT("trace any fast (host rays)", k_trace_any_fast<false>, ctx->persistentGrid, ctx->fast, n, dr, dres, ctx->stackSpill);
     }
     HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,4 +1,5 @@
-// wf_mat.hip — one translation unit per material type (compiled with -DWF_MAT_INSTANCE=<wf_material_type>):
+// wf_mat.hip — one translation unit per material type and texture-context variant (compiled with
+// -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_TEXCTX=<0|1>):
 // the K9 kernel "<Material> + BxDF eval" (EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>,
 // wavefront/surfscatter.cpp:57-328) and its launcher.  Split from wf_backend.hip so that the seven material
 // kernels compile in parallel (the layered ones take minutes).
@@ -8,8 +9,8 @@
 
 using namespace wf;
 
-#ifndef WF_MAT_INSTANCE
-#error "compile with -DWF_MAT_INSTANCE=<wf_material_type>"
+#if !defined(WF_MAT_INSTANCE) || !defined(WF_MAT_TEXCTX)
+#error "compile with -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_TEXCTX=<0|1>"
 #endif
 
 constexpr int MBLOCK = 256;
@@ -27,10 +28,9 @@ __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const Sc
     }
 }
 
-#define WF_CAT2(a, b) a##b
-#define WF_CAT(a, b) WF_CAT2(a, b)
-extern "C" void WF_CAT(wf_launch_eval_material_, WF_MAT_INSTANCE)(hipStream_t stream, int grid, const SceneView *sv, const WorkState *ws, int cur) {
-    // sv->texNeedsFootprint: some texture depends on the footprint, or some material has a displacement texture
-    if (sv->texNeedsFootprint) hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, true>), dim3(grid), dim3(MBLOCK), 0, stream, *sv, *ws, cur);
-    else hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, false>), dim3(grid), dim3(MBLOCK), 0, stream, *sv, *ws, cur);
+#define WF_CAT3_(a, b, c, d) a##b##c##d
+#define WF_CAT3(a, b, c, d) WF_CAT3_(a, b, c, d)
+// WF_MAT_TEXCTX = 1: some texture depends on the footprint, or some material has a displacement texture / normal map
+extern "C" void WF_CAT3(wf_launch_eval_material_, WF_MAT_INSTANCE, _, WF_MAT_TEXCTX)(hipStream_t stream, int grid, const SceneView *sv, const WorkState *ws, int cur) {
+    hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, WF_MAT_TEXCTX != 0>), dim3(grid), dim3(MBLOCK), 0, stream, *sv, *ws, cur);
 }

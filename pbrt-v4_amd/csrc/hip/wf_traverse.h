@@ -40,6 +40,12 @@
 // (Measured and dropped: deciding marks by the triangles' own deltaT bounds of shapes.cpp:252-266 in a slow branch —
 // sound by pbrt's error analysis, but deltaT grows as distance^2 / triangle size, which forces a 2^-8 pruning band:
 // +24 % closest-hit time on the bench scene.)
+//
+// Object instances (two-level BVH): an instance definition's tree lives in the same QNode / LeafTri arrays with its own
+// quantisation grid (FastDef); a top-level leaf entry marked c.z == 4 is an instance.  The walk pushes it as a leaf
+// reference with first >= INST_FIRST, and when that reference is popped it switches the lane to the instance's space
+// (InstanceRay = the reference's Transform::ApplyInverse(Ray, &tMax), per-ray constants recomputed for the definition's
+// grid), with the world tMax and a NODE_EXIT marker underneath on the stack; popping the marker switches back.
 #pragma once
 
 namespace wf {
@@ -80,7 +86,16 @@ struct FastBVH {
     int nNodes;
     float base[3], cell[3];  // grid: plane(q) = base + q * cell (real arithmetic; the builder keeps a margin, see BuildFastBVH)
     float absBand;           // 2^-16 x the scene extent: absolute part of the near-tie band
+    const struct FastDef *defs;       // per instance definition (scenes with object instances)
+    const wf_instance *instances;
 };
+struct FastDef {
+    int root;                // QNode index of the definition's root
+    float base[3], cell[3];  // its quantisation grid
+    int pad;
+};
+constexpr int INST_FIRST = 1 << 26;          // leaf references with first >= INST_FIRST: object instance (first - INST_FIRST)
+constexpr int NODE_EXIT = (int)0x80000001;   // stack marker: leave the instance (the world tMax is the entry below it)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -96,6 +111,8 @@ struct RayWalk {
     int prim;
     uint32_t route;  // routing code of the hit triangle (LeafTri.c.w)
     float b0, b1, b2;
+    int inst;        // instance the hit primitive was reached through (-1: top level); only the INST kernel variants use it
+    int curInst;     // instance whose definition is being walked (-1: top level)
 };
 
 // Per-ray constants of the box test.  Bounds3::IntersectP (util/vecmath.h:1574-1608) computes, per axis,
@@ -104,11 +121,12 @@ struct RayWalk {
 // bounded by a few ulps of (65535 |a| + |b|); SLACK times that bound is folded into the constants (subtracted on
 // the near side, added on the far side) so that the test passes whenever the reference's test on the exact
 // box would: a superset of visited nodes, while the hit itself is decided by the exact triangle test.
-__device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, float tMax) {
+// the ray-dependent part: origin, shear, slab constants on the grid (base, cell)
+__device__ inline void WalkSetRay(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
     constexpr float SLACK = 0x1p-20f;            // 16 ulp
     constexpr float G = 1 + 2 * gamma(3);        // the reference's tMax factor
     constexpr float INV_MAX = 1e28f;             // |1/d| clamp: keeps every product finite (no 0 * inf NaNs)
-    w.o = o; w.tMax = tMax;
+    w.o = o;
     w.sh = MakeRayShear(d);
     const float dd[3] = {d.x, d.y, d.z}, oo[3] = {o.x, o.y, o.z};
     float a[3], bn[3], af[3], bf[3];
@@ -116,7 +134,7 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     for (int k = 0; k < 3; ++k) {
         float inv = 1 / dd[k];
         if (!(fabsf(inv) <= INV_MAX)) inv = copysignf(INV_MAX, dd[k]);
-        const float ak = bvh.cell[k] * inv, bk = (bvh.base[k] - oo[k]) * inv;
+        const float ak = cell[k] * inv, bk = (base[k] - oo[k]) * inv;
         const float delta = SLACK * fma(65535.f, fabsf(ak), fabsf(bk));
         a[k] = ak; bn[k] = bk - delta;
         af[k] = ak * G; bf[k] = fma(bk, G, delta * 1.001f);
@@ -125,10 +143,45 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     w.a = V3{a[0], a[1], a[2]}; w.bn = V3{bn[0], bn[1], bn[2]};
     w.af = V3{af[0], af[1], af[2]}; w.bf = V3{bf[0], bf[1], bf[2]};
     w.selx = sel[0]; w.sely = sel[1]; w.selz = sel[2];
+}
+__device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, float tMax) {
+    WalkSetRay(bvh.base, bvh.cell, w, o, d);
+    w.tMax = tMax;
     w.node = 0;
     w.prim = -1;
     w.route = 0;
     w.b0 = w.b1 = w.b2 = 0;
+    w.inst = -1;
+    w.curInst = -1;
+}
+// Switch the lane into / out of an object instance (see the header comment).  oW, dW: the ray in render space.
+template <typename Stack>
+__device__ inline void EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int inst, V3 *dCur) {
+    const wf_instance &in = bvh.instances[inst];
+    float tI = __builtin_fabsf(w.tMax);
+    V3 oI, dI;
+    InstanceRay(in, oW, dW, &tI, &oI, &dI);
+    st.push((int)FloatToBits(w.tMax));
+    st.push(NODE_EXIT);
+    const FastDef fd = bvh.defs[in.def];
+    WalkSetRay(fd.base, fd.cell, w, oI, dI);
+    w.tMax = (FloatToBits(w.tMax) >> 31) ? -tI : tI;
+    w.curInst = inst;
+    w.node = fd.root;
+    *dCur = dI;
+}
+template <typename Stack>
+__device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, V3 *dCur) {
+    const float saved = BitsToFloat((uint32_t)st.pop());
+    // a hit found inside: its t (the instance ray's parameter) becomes the world tMax as it is, like the reference's
+    // si->tHit (cpu/primitive.cpp:112-125); otherwise the world tMax is restored.  Near-tie marks are kept either way.
+    const float tW = (w.inst == w.curInst) ? __builtin_fabsf(w.tMax) : __builtin_fabsf(saved);
+    const bool mark = ((FloatToBits(w.tMax) | FloatToBits(saved)) >> 31) != 0;
+    WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
+    w.tMax = mark ? -tW : tW;
+    w.curInst = -1;
+    w.node = st.empty() ? NODE_NONE : st.pop();
+    *dCur = dW;
 }
 
 __device__ inline bool WalkAmbiguous(const RayWalk &w) { return (FloatToBits(w.tMax) >> 31) != 0; }
@@ -195,7 +248,7 @@ struct NoExtra {
     __device__ bool accept(int, float, float, float) const { return true; }
     __device__ bool sphere(int, float, QuadricHit *) const { return false; }
 };
-template <bool ANY, bool ALPHA = false, typename Stack, typename Extra = NoExtra>
+template <bool ANY, bool ALPHA = false, bool INST = false, typename Stack, typename Extra = NoExtra>
 __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const Extra &ex = Extra()) {
     unsigned ref = ~(unsigned)w.node;
     int first = (int)(ref >> 4), count = (int)(ref & 15u) + 1;
@@ -204,6 +257,11 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
         const LeafTri *lt = bvh.tris + first + i;
         const F4 ta = lt->a, tb = lt->b, tc = lt->c;
         TriHit h;
+        if constexpr (INST)
+            if (tc.z == 4.f) {  // an object instance: visited through the stack (the main loop enters it when it is popped)
+                st.push((int)~(((unsigned)INST_FIRST + FloatToBits(tc.y)) << 4));
+                continue;
+            }
         // closest hit: test against the relaxed bound so that near-ties are seen (WalkAccept sorts them out)
         const float tTest = ANY ? w.tMax : WalkBound(bvh, __builtin_fabsf(w.tMax));
         if constexpr (ALPHA)
@@ -213,6 +271,7 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
                     if (ANY) { w.prim = (int)FloatToBits(tc.y); w.tMax = qh.tHit; done = true; break; }
                     if (WalkAccept(bvh, w, qh.tHit)) {
                         w.prim = (int)FloatToBits(tc.y);
+                        w.inst = w.curInst;
                         w.route = FloatToBits(tc.w);
                         w.b0 = qh.pObj.x; w.b1 = qh.pObj.y; w.b2 = qh.pObj.z;
                     }
@@ -226,6 +285,7 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
             if (ANY) { w.prim = (int)FloatToBits(tc.y); w.tMax = h.t; done = true; break; }
             if (WalkAccept(bvh, w, h.t)) {
                 w.prim = (int)FloatToBits(tc.y);
+                w.inst = w.curInst;
                 w.route = FloatToBits(tc.w);
                 w.b0 = h.b0; w.b1 = h.b1; w.b2 = h.b2;
             }

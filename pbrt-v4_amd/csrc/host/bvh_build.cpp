@@ -120,48 +120,36 @@ struct Builder {
 
 }  // namespace
 
-void BuildBVH(const std::vector<float> &P, const std::vector<int32_t> &triIndices, const std::vector<std::pair<int, B3>> &extraPrims,
-              int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims) {
-    int nTris = (int)triIndices.size() / 3;
-    const int nAll = nTris + (int)extraPrims.size();
-    nodes->clear();
-    orderedPrims->clear();
-    if (nAll == 0) return;
-    std::vector<BVHPrim> prims;
-    prims.reserve(nAll);
-    size_t nextExtra = 0;
-    auto flushExtras = [&](int trisSoFar) {
-        while (nextExtra < extraPrims.size() && extraPrims[nextExtra].first <= trisSoFar) {
-            BVHPrim e;
-            e.index = nTris + (int)nextExtra;
-            e.bounds = extraPrims[nextExtra].second;
-            prims.push_back(e);
-            ++nextExtra;
-        }
-    };
-    for (int i = 0; i < nTris; ++i) {
-        flushExtras(i);
-        auto vtx = [&](int k) { int v = triIndices[3 * i + k]; return V3{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
-        // Triangle::Bounds (shapes.cpp:283-290): Union(Bounds3f(p0, p1), p2)
-        V3 p0 = vtx(0), p1 = vtx(1), p2 = vtx(2);
-        B3 b;
-        b.pMin = {fmin(p0.x, p1.x), fmin(p0.y, p1.y), fmin(p0.z, p1.z)};
-        b.pMax = {fmax(p0.x, p1.x), fmax(p0.y, p1.y), fmax(p0.z, p1.z)};
-        BVHPrim tp;
-        tp.index = i;
-        tp.bounds = Union(b, p2);
-        prims.push_back(tp);
-    }
-    flushExtras(nTris);
+B3 TriangleBounds(const std::vector<float> &P, const std::vector<int32_t> &triIndices, int i) {
+    auto vtx = [&](int k) { int v = triIndices[3 * (size_t)i + k]; return V3{P[3 * (size_t)v], P[3 * (size_t)v + 1], P[3 * (size_t)v + 2]}; };
+    // Triangle::Bounds (shapes.cpp:283-290): Union(Bounds3f(p0, p1), p2)
+    V3 p0 = vtx(0), p1 = vtx(1), p2 = vtx(2);
+    B3 b;
+    b.pMin = {fmin(p0.x, p1.x), fmin(p0.y, p1.y), fmin(p0.z, p1.z)};
+    b.pMax = {fmax(p0.x, p1.x), fmax(p0.y, p1.y), fmax(p0.z, p1.z)};
+    return Union(b, p2);
+}
+
+int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims) {
+    const int nAll = (int)primsIn.size();
+    if (nAll == 0) return -1;
+    std::vector<BVHPrim> prims(nAll);
+    for (int i = 0; i < nAll; ++i) { prims[i].index = primsIn[i].first; prims[i].bounds = primsIn[i].second; }
+    const int nodeBase = (int)nodes->size(), primBase = (int)orderedPrims->size();
+    std::vector<int32_t> ordered;
+    ordered.reserve(nAll);
     Builder bld;
     bld.maxPrimsInNode = std::min(255, maxPrimsInNode);
     bld.pool.resize(2 * (size_t)nAll);
-    bld.ordered = orderedPrims;
-    orderedPrims->reserve(nAll);
+    bld.ordered = &ordered;
     BuildNode *root = bld.Build(prims.data(), nAll);
-    nodes->assign(bld.totalNodes, wf_bvh_node{});
+    std::vector<wf_bvh_node> local(bld.totalNodes, wf_bvh_node{});
     int offset = 0;
-    bld.Flatten(root, nodes, &offset);
+    bld.Flatten(root, &local, &offset);
+    for (wf_bvh_node &n : local) n.offset += n.nprims > 0 ? primBase : nodeBase;  // leaf: primitivesOffset, interior: secondChildOffset
+    nodes->insert(nodes->end(), local.begin(), local.end());
+    orderedPrims->insert(orderedPrims->end(), ordered.begin(), ordered.end());
+    return nodeBase;
 }
 
 }  // namespace wf

@@ -117,6 +117,9 @@ struct SceneTables {
     std::vector<int32_t> triIndices, triMesh, bvhPrims, infiniteLights;
     std::vector<wf_mesh> meshes;
     std::vector<wf_quadric> quadrics;
+    std::vector<wf_instance> instances;
+    std::vector<wf_instance_def> instanceDefs;
+    int nTopBvhNodes = 0, nTopPrims = 0;
     std::vector<int32_t> haltonPrimes, haltonPermOffsets;
     std::vector<uint16_t> haltonPerms;
     std::vector<wf_bvh_node> bvhNodes;
@@ -144,10 +147,11 @@ struct SceneTables {
 void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *out);
 
 // geometry BVH (bvh_build.cpp): SAH build restating BVHAggregate (cpu/aggregates.cpp:140-387,505-521)
-// extraPrims: non-triangle primitives as (number of triangles created before it, render-space bounds), in creation
-// order; extra primitive k gets primitive id nTris + k and enters the build where the reference's shape list has it
-void BuildBVH(const std::vector<float> &P, const std::vector<int32_t> &triIndices, const std::vector<std::pair<int, B3>> &extraPrims,
-              int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims);
+// prims: the primitives in the reference's creation order as (primitive id, render-space bounds).  Nodes and ordered
+// primitive ids are APPENDED to *nodes / *orderedPrims (child and primitive offsets absolute); returns the root index.
+int BuildBVH(const std::vector<std::pair<int, B3>> &prims, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims);
+// Triangle::Bounds (shapes.cpp:283-290) of global triangle i
+B3 TriangleBounds(const std::vector<float> &P, const std::vector<int32_t> &triIndices, int i);
 // light BVH (lightbvh_build.cpp): BVHLightSampler ctor (lightsamplers.cpp:105-232)
 struct LightBoundsH {
     B3 bounds;

@@ -35,6 +35,9 @@ void SceneTables::Finalize() {
     desc.tri_indices = triIndices.data(); desc.tri_mesh = triMesh.data();
     desc.meshes = meshes.data(); desc.bvh_nodes = bvhNodes.data(); desc.bvh_prims = bvhPrims.data();
     desc.n_quadrics = (int)quadrics.size(); desc.quadrics = quadrics.data();
+    desc.n_instances = (int)instances.size(); desc.instances = instances.data();
+    desc.n_instance_defs = (int)instanceDefs.size(); desc.instance_defs = instanceDefs.data();
+    desc.n_top_bvh_nodes = nTopBvhNodes; desc.n_top_prims = nTopPrims;
     desc.halton_primes = haltonPrimes.empty() ? nullptr : haltonPrimes.data();
     desc.halton_perm_offsets = haltonPermOffsets.empty() ? nullptr : haltonPermOffsets.data();
     desc.halton_perms = haltonPerms.empty() ? nullptr : haltonPerms.data();
@@ -1368,14 +1371,19 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         }
         sh.params.ReportUnused("Shape");
     };
-    struct PendingSphere { wf_quadric s; int orderPos; B3 bounds; };
+    struct PendingSphere { wf_quadric s; B3 bounds; };
     std::vector<PendingSphere> spheres;
     std::map<int, int> sphereOfMesh;
-    auto addShape = [&](const ShapeEntity &sh, const Transform *extra) {
+    // the primitive lists in the reference's creation order (scene.cpp:1386-1470): (primitive id, bounds).  Quadric ids
+    // are patched once the triangle count is known (they follow ALL triangles): stored as -1 - quadric index meanwhile.
+    typedef std::vector<std::pair<int, B3>> PrimList;
+    PrimList topPrims;
+    auto addShape = [&](const ShapeEntity &sh, PrimList *prims, bool inDefinition) {
+        const Transform *extra = nullptr;
         if (sh.name == "sphere" || sh.name == "disk" || sh.name == "cylinder") {
             // Sphere / Disk / Cylinder::Create + ctors (shapes.cpp:71-81,106-115,132-142; shapes.h:117-129,387-398,737-748);
             // kept in object space like the reference's
-            if (extra) Die(sh.loc, "quadrics inside object instances are not supported by this build yet");
+            if (inDefinition) Die(sh.loc, "quadrics inside object instances are not supported by this build yet");
             const Transform &rfo = sh.renderFromObject;
             const ParamSet &ps = sh.params;
             float radius = ps.GetOneFloat("radius", 1.f);
@@ -1407,7 +1415,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             // Sphere::Bounds (shapes.cpp:33-36) through Transform::operator()(Bounds3f) (util/transform.cpp:134-139)
             V3 lo{-radius, -radius, p.s.z_min}, hi{radius, radius, p.s.z_max};
             for (int c = 0; c < 8; ++c) p.bounds = Union(p.bounds, rfo.Point(V3{(c & 1) ? hi.x : lo.x, (c & 2) ? hi.y : lo.y, (c & 4) ? hi.z : lo.z}));
-            p.orderPos = (int)T->triIndices.size() / 3;
+            prims->emplace_back(-1 - (int)spheres.size(), p.bounds);
             wf_mesh mesh{};
             mesh.first_tri = -1;  // set to the sphere's primitive id once the triangle count is known
             mesh.ntris = 0;
@@ -1452,14 +1460,27 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         }
         int meshId = (int)T->meshes.size();
         for (int vi : src.indices) T->triIndices.push_back(mesh.first_vertex + vi);
-        for (int i = 0; i < mesh.ntris; ++i) T->triMesh.push_back(meshId);
-        commitMesh(mesh, meshId, sh, rfo, extra != nullptr);
+        for (int i = 0; i < mesh.ntris; ++i) {
+            T->triMesh.push_back(meshId);
+            prims->emplace_back(mesh.first_tri + i, TriangleBounds(T->P, T->triIndices, mesh.first_tri + i));
+        }
+        commitMesh(mesh, meshId, sh, rfo, inDefinition);
     };
-    for (const ShapeEntity &sh : scene.shapes) addShape(sh, nullptr);
+    for (const ShapeEntity &sh : scene.shapes) addShape(sh, &topPrims, false);
+    // instance definitions (scene.cpp:1522-1557): the shapes stay in the definition's own render space, each definition
+    // gets its own BVH; only definitions that are used are built
+    std::map<std::string, int> defIndex;
+    std::vector<PrimList> defPrims;
     for (const InstanceUse &u : scene.instances) {
         auto it = scene.instanceDefinitions.find(u.name);
         if (it == scene.instanceDefinitions.end()) Die("", u.name + ": object instance not defined");
-        for (const ShapeEntity &sh : it->second.shapes) addShape(sh, &u.renderFromInstance);
+        if (defIndex.count(u.name)) continue;
+        defIndex[u.name] = (int)defPrims.size();
+        defPrims.emplace_back();
+        for (const ShapeEntity &sh : it->second.shapes) {
+            if (sh.lightIndex >= 0) fprintf(stderr, "Warning: %s: Area lights not supported with object instancing\n", sh.loc.c_str());
+            addShape(sh, &defPrims.back(), true);
+        }
     }
     if (T->triIndices.empty() && spheres.empty()) Die("", "scene has no geometry");
     // spheres: primitive ids follow the triangles'
@@ -1470,6 +1491,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             T->triMesh.push_back(spheres[i].s.mesh);
             T->quadrics.push_back(spheres[i].s);
         }
+        for (auto &pr : topPrims) if (pr.first < 0) pr.first = nTris + (-1 - pr.first);
     }
 
     // ---- lights: area lights first (scene.cpp:1290-1340), then the others ----
@@ -1920,9 +1942,48 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     std::string split = scene.accelerator.params.GetOneString("splitmethod", "sah");
     if (split != "sah") fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str());
     int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
-    std::vector<std::pair<int, B3>> spherePrims;
-    for (const PendingSphere &sp : spheres) spherePrims.emplace_back(sp.orderPos, sp.bounds);
-    BuildBVH(T->P, T->triIndices, spherePrims, maxPrims, &T->bvhNodes, &T->bvhPrims);
+    {
+        // instance definitions first (their bounds enter the top-level build): BVHAggregate(prims) with the constructor's
+        // default maxPrimsInNode = 1 (scene.cpp:1539-1543, cpu/aggregates.h:34)
+        std::vector<wf_bvh_node> defNodes;
+        std::vector<int32_t> defOrdered;
+        T->instanceDefs.resize(defPrims.size());
+        for (size_t d = 0; d < defPrims.size(); ++d) {
+            wf_instance_def &def = T->instanceDefs[d];
+            def = wf_instance_def{};
+            def.first_prim = (int)defOrdered.size();
+            def.n_prims = (int)defPrims[d].size();
+            def.bvh_root = BuildBVH(defPrims[d], 1, &defNodes, &defOrdered);
+            def.n_nodes = (int)defNodes.size() - (def.bvh_root < 0 ? (int)defNodes.size() : def.bvh_root);
+            if (def.bvh_root >= 0)
+                for (int c = 0; c < 3; ++c) { def.bounds[c] = defNodes[def.bvh_root].bmin[c]; def.bounds[3 + c] = defNodes[def.bvh_root].bmax[c]; }
+        }
+        // the instances (scene.cpp:1560-1577): TransformedPrimitive(definition, renderFromInstance), after the shapes
+        const int nTrisAll = (int)T->triIndices.size() / 3, nQuads = (int)T->quadrics.size();
+        for (const InstanceUse &u : scene.instances) {
+            const int d = defIndex.at(u.name);
+            if (T->instanceDefs[d].bvh_root < 0) continue;  // empty instance
+            wf_instance in{};
+            in.render_from_instance = u.renderFromInstance.abi();
+            for (int j = 0; j < 3; ++j)
+                if (u.renderFromInstance.m.m[3][j] != 0 || u.renderFromInstance.m.m[3][3] != 1) Die("", u.name + ": only affine instance transformations are supported");
+            in.def = d;
+            // TransformedPrimitive::Bounds = (*renderFromPrimitive)(primitive.Bounds()): the 8 corners (util/transform.cpp:134-139)
+            const float *b = T->instanceDefs[d].bounds;
+            B3 wb;
+            for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}));
+            topPrims.emplace_back(nTrisAll + nQuads + (int)T->instances.size(), wb);
+            T->instances.push_back(in);
+        }
+        BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims);
+        T->nTopBvhNodes = (int)T->bvhNodes.size();
+        T->nTopPrims = (int)T->bvhPrims.size();
+        const int nodeShift = T->nTopBvhNodes, primShift = T->nTopPrims;
+        for (wf_bvh_node &n : defNodes) n.offset += n.nprims > 0 ? primShift : nodeShift;
+        for (wf_instance_def &def : T->instanceDefs) { if (def.bvh_root >= 0) def.bvh_root += nodeShift; def.first_prim += primShift; }
+        T->bvhNodes.insert(T->bvhNodes.end(), defNodes.begin(), defNodes.end());
+        T->bvhPrims.insert(T->bvhPrims.end(), defOrdered.begin(), defOrdered.end());
+    }
     B3 sceneBounds;
     for (int c = 0; c < 3; ++c) { sceneBounds.pMin[c] = T->bvhNodes[0].bmin[c]; sceneBounds.pMax[c] = T->bvhNodes[0].bmax[c]; }
     for (int c = 0; c < 3; ++c) { T->desc.scene_bounds[c] = sceneBounds.pMin[c]; T->desc.scene_bounds[3 + c] = sceneBounds.pMax[c]; }

@@ -36,7 +36,7 @@ class RenderStats(C.Structure):
 
 class HitRecord(C.Structure):
     _fields_ = [("prim", C.c_int32), ("t", C.c_float), ("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float),
-                ("nodes_visited", C.c_int32), ("tris_tested", C.c_int32), ("pad", C.c_int32)]
+                ("nodes_visited", C.c_int32), ("tris_tested", C.c_int32), ("instance", C.c_int32)]
 
 
 class TraversalCounters(C.Structure):
@@ -226,7 +226,7 @@ class Scene:
         out = (HitRecord * n)()
         _check(hip.wf_trace_closest_host(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, out, 1 if reference_order else 0), "wf_trace_closest_host")
         return np.frombuffer(out, dtype=np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
-                                                  ("nodes_visited", "<i4"), ("tris_tested", "<i4"), ("pad", "<i4")])).copy()
+                                                  ("nodes_visited", "<i4"), ("tris_tested", "<i4"), ("instance", "<i4")])).copy()
 
     def bounds(self):
         """WavefrontAggregate::Bounds() in rendering space: (pMin[3], pMax[3])"""

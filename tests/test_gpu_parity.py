@@ -65,7 +65,7 @@ def _random_rays(n, bounds_lo, bounds_hi, seed):
     return o, d.astype(np.float32), tmax
 
 
-@pytest.mark.parametrize("scene_name", ["cornell64", "blobs_small"])
+@pytest.mark.parametrize("scene_name", ["cornell64", "blobs_small", "instances"])
 def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
     """k_intersect_closest's traversal (LDS stack) vs the oracle's BVHAggregate::Intersect restatement: same
     triangle, same t and barycentrics (bit-exact), same number of nodes visited and triangles tested."""
@@ -82,8 +82,10 @@ def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
     subprocess.run([WF_CPU, "--quiet", "--trace", str(tmp_path / "rays.bin"), str(tmp_path / "hits.bin"), path], check=True)
     ref = np.fromfile(tmp_path / "hits.bin", dtype=got.dtype)
     assert 0.3 < (ref["prim"] >= 0).mean() < 1.0
-    for f in ("prim", "nodes_visited", "tris_tested"):
+    for f in ("prim", "instance", "nodes_visited", "tris_tested"):
         assert (got[f] == ref[f]).all(), f
+    if scene_name == "instances":
+        assert (ref["instance"] >= 0).mean() > 0.02  # rays do reach geometry inside object instances
     for f in ("t", "b0", "b1", "b2"):
         assert (got[f].view(np.uint32) == ref[f].view(np.uint32)).all(), f
     # any-hit agrees with closest-hit about occlusion
@@ -92,7 +94,7 @@ def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
     # the production traversal (persistent waves over QNode/LeafTri, wf_traverse.h) returns the same hits: same
     # triangle, same t and barycentrics bit for bit — near-ties in t included (re-traced in reference order)
     fast = s.trace_closest(o, d, tmax, reference_order=False)
-    assert (fast["prim"] == ref["prim"]).all()
+    assert (fast["prim"] == ref["prim"]).all() and (fast["instance"] == ref["instance"]).all()
     for f in ("t", "b0", "b1", "b2"):
         assert (fast[f].view(np.uint32) == ref[f].view(np.uint32)).all(), f
     occ_fast, _, _ = s.trace_any(o, d, tmax, reference_order=False)
@@ -109,7 +111,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")

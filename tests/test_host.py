@@ -85,3 +85,47 @@ def test_film_to_rgb_matches_getpixelrgb(wfpt):
     # sRGB output space: X=Y=Z=0.5 maps to a slightly pink-ish white; luminance row sums to ~0.5
     assert 0.3 < rgb[1, 1].mean() < 0.7
     s.close()
+
+
+# ---- the BVH and its visit counts against the reference's own statistics ----------------------
+def _bvh_stat_scenes(tmp_path):
+    import make_scenes
+    from conftest import GOLDEN
+    out = [(n, os.path.join(GOLDEN, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap")]
+    k = str(tmp_path / "killeroo_like_240.pbrt")
+    make_scenes.killeroo_like(k, (240, 135), 1)
+    out.append(("killeroo_like_240x135_1spp", k, 1))
+    s = str(tmp_path / "sanmiguel_like_small.pbrt")
+    make_scenes.sanmiguel_like(s, (240, 135), 1, n_meshes=100, n_defs=10, tex_res=64, sky_res=64)
+    out.append(("sanmiguel_like_100meshes_240x135_1spp", s, 1))
+    return out
+
+
+def test_bvh_and_visit_counts_equal_the_references(built, tmp_path):
+    """tests/golden/bvh_stats.json holds what `pbrt --wavefront --stats` reports for its BVHAggregate (interior / leaf
+    nodes, primitives in leaves — over the top-level tree and every instance definition's — and the render's total
+    "Nodes visited" and ray-triangle tests, closest-hit + shadow).  The restated SAH builder and the reference-order walk
+    must reproduce every number EXACTLY: the N_nodes / N_tris behind bench.py's roofline are the reference's."""
+    import json
+    from conftest import GOLDEN, run_wf_cpu
+    golden = json.load(open(os.path.join(GOLDEN, "bvh_stats.json")))
+    keys = ("bvh_interior_nodes", "bvh_leaf_nodes", "bvh_leaf_prims", "bvh_nodes_visited", "tri_tests")
+    for name, path, spp in _bvh_stat_scenes(tmp_path):
+        j = run_wf_cpu(path, str(tmp_path / "o.pfm"), spp)
+        got = {k: j[k] for k in keys}
+        want = {k: golden[name][k] for k in keys}
+        assert got == want, (name, got, want)
+
+
+def test_bvh_stats_golden_is_the_live_references(tmp_path):
+    """where the shimmed reference build is present (this container): the golden IS what it prints today"""
+    import json
+    from conftest import GOLDEN, ROOT
+    ref = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/pbrt_ref not built (no /root/reference)")
+    import make_bvh_stats_golden as mk
+    golden = json.load(open(os.path.join(GOLDEN, "bvh_stats.json")))
+    for name in ("blobs_small", "instances"):
+        live = mk.ref_stats(os.path.join(GOLDEN, name + ".pbrt"), 4)
+        assert all(live[k] == golden[name][k] for k in live), (name, live, golden[name])

@@ -48,6 +48,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/texture_m
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_extra_ref.pfm $G/textures_extra.pbrt
 # image-textured diffuse area lights (triangles and a sphere): hand-written tests/golden/arealight_image.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_image_ref.pfm $G/arealight_image.pbrt
+# object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
 # goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
