@@ -3,12 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): BASELINE.json configs[1], "killeroo-simple 1080p 64spp on 1xMI355X", on its
-synthetic stand-in (tools/make_scenes.py killeroo-like: ~30k triangles, diffuse + smooth dielectric, two
-quad area lights, closed room; the pbrt-v4-scenes asset is not available offline).  A *step* is one pass
-of the hot path over one batch: one sample index over the whole 1920x1080 image (both 540-scanline
-wavefront passes, wavefront/integrator.cpp:336-442) = 2 073 600 pixel samples.  The default K = 64 steps is
-the configuration's full 64 spp.
+Workload (config.workload): BASELINE.json configs[2], "San Miguel 1080p 256spp on 1xMI355X" — the configuration the
+north_star's target is quoted on — on its synthetic stand-in at the SURVEY.md 8(d) specification (tools/make_scenes.py
+sanmiguel-like: 2000 meshes x 5000 triangles = 10 M unique triangles, three decades of sizes, 60 % of the meshes in 200
+object-instance definitions instanced 1..50x (two-level BVH), 10 % alpha-cut, 1k^2 image textures on the diffuse 40 %,
+coated diffuse / dielectric / conductor, a sun + a 2k^2 equal-area image sky + 500 emitters; the pbrt-v4-scenes asset is
+not available offline).  A *step* is one pass of the hot path over one batch: one sample index over the whole 1920x1080
+image (both 540-scanline wavefront passes, wavefront/integrator.cpp:336-442) = 2 073 600 pixel samples; 256 steps are the
+configuration's 256 spp (throughput does not depend on K: every step repeats the same passes on new sample indices).
+--workload killeroo-like selects configs[1] (round 1's default), cloud-like configs[3].
 
 N > 1 (launched by torch.distributed.run, one process per GPU): the scene is replicated, rank r renders
 the step indices r, r+N, ... (identical per-pixel sample sets to the 1-GPU render because the sampler is
@@ -45,11 +48,11 @@ def load_pkg():
     return m
 
 
-def make_scene(path, spp, workload="killeroo-like", meshes=1600):
+def make_scene(path, spp, workload="sanmiguel-like", meshes=2000):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_scenes
     if workload == "sanmiguel-like":
-        make_scenes.sanmiguel_like(path, (W, H), spp, n_meshes=meshes)
+        return make_scenes.sanmiguel_like(path, (W, H), spp, n_meshes=meshes, n_defs=max(1, meshes // 10))
     elif workload == "cloud-like":
         make_scenes.cloud_like(path, (W, H), spp)
     else:
@@ -96,9 +99,10 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="sample indices carried per pass (0 = automatic, ~64 M rays in flight)")
-    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like"], default="killeroo-like",
-                    help="killeroo-like = BASELINE configs[1] stand-in (default, the metric's config); sanmiguel-like = configs[2] stand-in")
-    ap.add_argument("--meshes", type=int, default=1600, help="sanmiguel-like: number of 6272-triangle meshes (1600 = 10 M triangles)")
+    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like"], default="sanmiguel-like",
+                    help="sanmiguel-like = BASELINE configs[2] stand-in at the SURVEY 8(d) spec (default: the north_star target config); "
+                         "killeroo-like = configs[1] stand-in; cloud-like = configs[3] stand-in")
+    ap.add_argument("--meshes", type=int, default=2000, help="sanmiguel-like: number of 5000-triangle meshes (2000 = 10 M unique triangles)")
     a = ap.parse_args()
 
     import torch
@@ -121,11 +125,30 @@ def main():
     spp_total = 1
     while spp_total < max(K, Wm):
         spp_total *= 2
-    td = tempfile.mkdtemp(prefix="wfbench_")
-    scene_path = os.path.join(td, "killeroo-like.pbrt")
-    make_scene(scene_path, spp_total, a.workload, a.meshes)
-    scene = wfpt.Scene(path=scene_path, spp=spp_total)
-    scene.create_renderer(local_rank, samples_per_pass=a.samples_per_pass)
+    # the generated scene files are kept per box under /tmp (keyed by the generator's source and parameters): the driver's
+    # N = 1, 2, 4, 8 runs and the N ranks of one run share them; rank 0 generates, the others wait for its marker file
+    import hashlib
+    gen_src = open(os.path.join(ROOT, "tools", "make_scenes.py"), "rb").read()
+    key = hashlib.sha1(gen_src + ("%s %d %d" % (a.workload, a.meshes, spp_total)).encode()).hexdigest()[:16]
+    td = os.path.join(tempfile.gettempdir(), "wfbench_%s_%s" % (a.workload, key))
+    scene_path = os.path.join(td, a.workload + ".pbrt")
+    marker = os.path.join(td, "_complete")
+    t_gen0 = time.perf_counter()
+    if not os.path.exists(marker):
+        if rank == 0:
+            os.makedirs(td, exist_ok=True)
+            make_scene(scene_path, spp_total, a.workload, a.meshes)
+            open(marker, "w").write("ok\n")
+        else:
+            while not os.path.exists(marker):
+                time.sleep(0.5)
+    t_gen = time.perf_counter() - t_gen0
+    t_load0 = time.perf_counter()
+    scene = wfpt.Scene(path=scene_path, spp=spp_total)         # parse + flat tables + host SAH BVH builds
+    t_parse = time.perf_counter() - t_load0
+    scene.create_renderer(local_rank, samples_per_pass=a.samples_per_pass)   # upload + production BVH layout + queues
+    torch.cuda.synchronize()
+    t_upload = time.perf_counter() - t_load0 - t_parse
     info = scene.info
 
     def barrier():
@@ -184,14 +207,17 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "mray_per_s": total_rays / T / 1e6,
+            "load_s": {"generate_scene_files": round(t_gen, 2), "parse_and_host_bvh_build": round(t_parse, 2), "upload_and_device_layout": round(t_upload, 2)},
             "config": {"workload": ("killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
                                     "diffuse + dielectric, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
                                     if a.workload == "killeroo-like" else
                                     "Disney cloud 1080p (BASELINE.json configs[3]) on the cloud-like stand-in (64^3 uniformgrid medium, g = 0.877, "
                                     "%d triangles, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
                                     if a.workload == "cloud-like" else
-                                    "San Miguel 1080p (BASELINE.json configs[2]) on the sanmiguel-like stand-in: %d triangles, diffuse/coated "
-                                    "diffuse/dielectric/conductor, sun + sky + 400 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
+                                    "San Miguel 1080p 256spp (BASELINE.json configs[2]) on the sanmiguel-like stand-in at the SURVEY 8(d) spec: %d unique "
+                                    "triangles in " + str(a.meshes) + " meshes, 60 %% of them in " + str(max(1, a.meshes // 10)) + " object-instance definitions "
+                                    "(two-level BVH), 10 %% alpha-cut, 1k^2 image textures, diffuse / coated diffuse / dielectric / conductor, sun + 2k^2 image "
+                                    "sky + 500 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
                                    % (info.n_triangles, info.max_depth),
                        "resolution": [info.width, info.height], "spp": K, "samples_per_pass": scene.samples_per_pass, "partition": "sample-index round-robin x%d + RCCL film all-reduce" % world
                        if world > 1 else "single GPU"},
@@ -215,11 +241,19 @@ def main():
                 # bytes per ray, corrected as MI355X_MICROARCH.md prescribes) scaled to this run's rays per launch
                 traffic = None
                 tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if a.workload == "killeroo-like" and os.path.exists(tp):
-                    traffic = json.load(open(tp))["hbm_bytes_per_ray"] * rays_closest / launches
+                if os.path.exists(tp):
+                    pj = json.load(open(tp))
+                    per_ray = pj.get(a.workload, {}).get("hbm_bytes_per_ray") if isinstance(pj.get(a.workload), dict) else (pj.get("hbm_bytes_per_ray") if a.workload == "killeroo-like" else None)
+                    if per_ray:
+                        traffic = per_ray * rays_closest / launches
                 out["roofline"] = {
                     "bound": "hbm", "kernel": "Intersect closest (k_closest_fast)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    # the same algorithmic rate against the L2 ceiling (34.5 TB/s aggregate), and the measured HBM rate of the kernel
+                    "l2_frac": gbs / 34500.0,
+                    "traffic_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                    "traffic_frac_of_hbm_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
                     "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
                     "nodes_per_ray": counters["closest_nodes"] / counters["closest_rays"],
                     "tris_per_ray": counters["closest_tris"] / counters["closest_rays"],

@@ -342,12 +342,13 @@ __global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_shadow_fast(co
         [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
 }
 
-template <bool INST>
-__global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
+// GENERAL: the scene has alpha-tested triangles or quadrics (the variant the render uses then)
+template <bool INST, bool GENERAL>
+__global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<false, false, INST>(
-        SceneView{}, bvh, n, st,
+    BatchTrace<false, GENERAL, INST>(
+        sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
             *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
@@ -363,12 +364,12 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(FastBVH bvh, int 
             out[i] = h;
         });
 }
-template <bool INST>
-__global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
+template <bool INST, bool GENERAL>
+__global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true, false, INST>(
-        SceneView{}, bvh, n, st,
+    BatchTrace<true, GENERAL, INST>(
+        sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
             *o = V3{r[0], r[1], r[2]}; *d = V3{r[3], r[4], r[5]}; *tMax = r[6];
@@ -611,6 +612,19 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     nodes->clear();
     bool gridOk = true;
     std::vector<int> bfsIndex(n, -1);
+    // Subtree collapse: the production tree need not mirror the reference's leaves — a reference subtree holding at most
+    // `collapse` primitives (contiguous in bvh_prims: leaf order is depth-first) becomes ONE leaf here.  The walk then tests
+    // a superset of the triangles the reference tests, which changes no result (the exact triangle test decides, near-ties
+    // are re-traced in reference order) and removes the bottom levels of dependent node fetches: instance definitions are
+    // built with one primitive per leaf (maxPrimsInNode = 1, scene.cpp:1539).
+    int collapse = 4;
+    if (const char *e = getenv("WF_LEAF_COLLAPSE")) collapse = std::min(16, std::max(1, atoi(e)));
+    std::vector<int> subFirst(n), subCount(n);
+    for (int i = n - 1; i >= 0; --i) {
+        if (L[i].nprims > 0) { subFirst[i] = L[i].offset; subCount[i] = L[i].nprims; }
+        else { subFirst[i] = subFirst[i + 1]; subCount[i] = subCount[i + 1] + subCount[L[i].offset]; }
+    }
+    auto leafLike = [&](int i) { return L[i].nprims > 0 || subCount[i] <= collapse; };
     // one tree: linear nodes [root, ...) reachable from root; grid written to base / cell; returns the root's QNode index
     auto buildTree = [&](int root, float baseOut[3], float cellOut[3]) -> int {
         // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
@@ -647,12 +661,12 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             if (plane(q, a) < target) gridOk = false;
             return (uint32_t)q;
         };
-        auto leafRef = [&](int i) { return (int)~(((unsigned)L[i].offset << 4) | (unsigned)(L[i].nprims - 1)); };
+        auto leafRef = [&](int i) { return (int)~(((unsigned)subFirst[i] << 4) | (unsigned)(subCount[i] - 1)); };
         auto packBox = [&](const wf_bvh_node &b, uint32_t q[6], int slot) {
             for (int a = 0; a < 3; ++a) q[slot * 3 + a] = qlo(b.bmin[a], a) | (qhi(b.bmax[a], a) << 16);
         };
         const int qBase = (int)nodes->size();
-        if (L[root].nprims > 0) {
+        if (leafLike(root)) {
             // the whole tree is one leaf: a root node whose two children are both that leaf (testing it twice
             // changes neither the closest hit nor occlusion)
             QNode qn{};
@@ -670,7 +684,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         for (size_t h = 0; h < order.size(); ++h) {
             int i = order[h];
             for (int c : {i + 1, (int)L[i].offset})
-                if (L[c].nprims == 0) { bfsIndex[c] = qBase + (int)order.size(); order.push_back(c); }
+                if (!leafLike(c)) { bfsIndex[c] = qBase + (int)order.size(); order.push_back(c); }
         }
         nodes->resize((size_t)qBase + order.size());
         for (size_t h = 0; h < order.size(); ++h) {
@@ -679,8 +693,8 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             QNode qn{};
             packBox(L[l], qn.q, 0);
             packBox(L[r], qn.q, 1);
-            qn.left = L[l].nprims == 0 ? bfsIndex[l] : leafRef(l);
-            qn.right = L[r].nprims == 0 ? bfsIndex[r] : leafRef(r);
+            qn.left = !leafLike(l) ? bfsIndex[l] : leafRef(l);
+            qn.right = !leafLike(r) ? bfsIndex[r] : leafRef(r);
             (*nodes)[(size_t)qBase + h] = qn;
         }
         return qBase;
@@ -689,7 +703,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     {
         double ext = 0;
         for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
-        out->absBand = (float)(0x1p-16 * ext);
+        out->absBand = (float)(0x1p-20 * ext);
     }
     defs->clear();
     for (int k = 0; k < d->n_instance_defs; ++k) {
@@ -1224,8 +1238,11 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     if (count_visits || !ctx->fastOk) {
         LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 0);
     } else {
-        if (ctx->svHost.nInstances > 0) LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast<true>, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
-        else LAUNCHT("trace closest fast (host rays)", k_trace_closest_fast<false>, ctx->persistentGrid, ctx->fast, n, dr, dh, ctx->stackSpill);
+        const bool inst = ctx->svHost.nInstances > 0, general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
+        if (inst && general) LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
+        else if (inst) LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<true, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
+        else if (general) LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
+        else LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<false, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
         LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 1);
     }
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
@@ -1250,8 +1267,11 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     if (nodes_visited || tris_tested || !ctx->fastOk) {
         LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svHost, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
     } else {
-        if (ctx->svHost.nInstances > 0) LAUNCHT("trace any fast (host rays)", k_trace_any_fast<true>, ctx->persistentGrid, ctx->fast, n, dr, dres, ctx->stackSpill);
-        else LAUNCHT("trace any fast (host rays)", k_trace_any_fast<false>, ctx->persistentGrid, ctx->fast, n, dr, dres, ctx->stackSpill);
+        const bool inst = ctx->svHost.nInstances > 0, general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
+        if (inst && general) LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
+        else if (inst) LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<true, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
+        else if (general) LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
+        else LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<false, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
     }
     HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -30,13 +30,16 @@
 // case where the visiting order decides the result: IntersectTriangle (shapes.cpp:234-237) accepts a triangle while
 // tScaled <= fl(tMax * det), so among candidates whose t agree to ~3 * 2^-24 the reference keeps the LAST one its own
 // depth-first order accepts.  This walk visits nearest-entry first, so it cannot know; instead it tests and prunes
-// against tMax * (1 + 2^-16) + 2^-16 of the scene extent (one fma), and a candidate that lands inside that band of the
+// against tMax * (1 + 2^-20) + 2^-20 of the scene extent (one fma), and a candidate that lands inside that band of the
 // current best marks the ray (sign bit of RayWalk::tMax).  Marked rays are re-traced by the reference-order walk
 // (k_closest_retrace / BVHIntersectClosest).  The band has to cover more than the acceptance test's own rounding: the
 // computed t of two coplanar triangles differ by their evaluation errors (absolute: a few ulps of the vertex
 // coordinates, not of t), and the reference prunes subtrees with the EXACT tMax against box entries that carry errors
-// of the same size — a flat leaf box coplanar with the current hit is skipped or not by a hair.  2^-16 = 256 ulps of
-// the larger of t and the scene extent; measured differences on coplanar geometry are ~1 ulp of the coordinates.
+// of the same size — a flat leaf box coplanar with the current hit is skipped or not by a hair.  Size of the band: inside a
+// triangle t = sum b_i z_i with b_i in [0, 1], so its rounding error is a few ulps of max |z_i|, the sheared depth of the
+// farthest vertex, which is at most sqrt(3) x (scene extent + |o|) for any triangle; 2^-20 = 16 ulps of t plus 16 ulps of the
+// scene extent covers that with a margin (measured on the coplanar floor / glass-box golden: ~1e-5 at extent 16).  A wider band
+// only re-traces more rays (2^-16 re-traced 1 ray in 40 on the 100-unit san-miguel-like scene: every blob resting on the ground).
 // (Measured and dropped: deciding marks by the triangles' own deltaT bounds of shapes.cpp:252-266 in a slow branch —
 // sound by pbrt's error analysis, but deltaT grows as distance^2 / triangle size, which forces a 2^-8 pruning band:
 // +24 % closest-hit time on the bench scene.)
@@ -85,7 +88,7 @@ struct FastBVH {
     const LeafTri *tris;
     int nNodes;
     float base[3], cell[3];  // grid: plane(q) = base + q * cell (real arithmetic; the builder keeps a margin, see BuildFastBVH)
-    float absBand;           // 2^-16 x the scene extent: absolute part of the near-tie band
+    float absBand;           // 2^-20 x the scene extent: absolute part of the near-tie band
     const struct FastDef *defs;       // per instance definition (scenes with object instances)
     const wf_instance *instances;
 };
@@ -186,7 +189,7 @@ __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V
 
 __device__ inline bool WalkAmbiguous(const RayWalk &w) { return (FloatToBits(w.tMax) >> 31) != 0; }
 __device__ inline float WalkT(const RayWalk &w) { return __builtin_fabsf(w.tMax); }
-constexpr float TIE_BAND = 1 + 0x1p-16f;
+constexpr float TIE_BAND = 1 + 0x1p-20f;
 #ifndef WF_TIE
 #define WF_TIE 1   // 0: timing experiments only — no near-tie handling (round-1 behaviour: the visiting order decides ties)
 #endif

@@ -65,7 +65,7 @@ def _random_rays(n, bounds_lo, bounds_hi, seed):
     return o, d.astype(np.float32), tmax
 
 
-@pytest.mark.parametrize("scene_name", ["cornell64", "blobs_small", "instances"])
+@pytest.mark.parametrize("scene_name", ["cornell64", "blobs_small", "instances", "alpha_normalmap", "spheres"])
 def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
     """k_intersect_closest's traversal (LDS stack) vs the oracle's BVHAggregate::Intersect restatement: same
     triangle, same t and barycentrics (bit-exact), same number of nodes visited and triangles tested."""
@@ -81,7 +81,7 @@ def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
     rays.tofile(tmp_path / "rays.bin")
     subprocess.run([WF_CPU, "--quiet", "--trace", str(tmp_path / "rays.bin"), str(tmp_path / "hits.bin"), path], check=True)
     ref = np.fromfile(tmp_path / "hits.bin", dtype=got.dtype)
-    assert 0.3 < (ref["prim"] >= 0).mean() < 1.0
+    assert (0.3 if scene_name in ("cornell64", "blobs_small") else 0.1) < (ref["prim"] >= 0).mean() < 1.0
     for f in ("prim", "instance", "nodes_visited", "tris_tested"):
         assert (got[f] == ref[f]).all(), f
     if scene_name == "instances":
