@@ -15,6 +15,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the only fused operations are the explicit
 // fma calls of the restated arithmetic, as in the reference's CPU build).
 #include <hip/hip_runtime.h>
+#include <array>
 
 #include <climits>
 #include <cstdarg>
@@ -56,11 +57,13 @@ struct wf_ctx {
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     SceneView svHost{};          // device pointers inside; passed to every kernel by value (kernarg)
+    const SceneView *svDev = nullptr;  // the same struct in device memory, for the out-of-line callbacks of the traversal kernels
     WorkState ws{};
     int maxQueueSize = 0;
     int *stackSpill = nullptr;   // [STACK_MAX-STACK_LDS][MAX_GRID*BLOCK]
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
+    int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels
     int32_t *probeCursor = nullptr;
     bool matPresent[WF_MAT_NTYPES] = {};
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, 
 
 // ---- production traversal: persistent waves over QNode/LeafTri with the tree top in LDS (wf_traverse.h) ----
 __shared__ int g_tstack[TSTACK * TBLOCK];
-__shared__ U4 g_top[2 * TOP_NODES];
+__shared__ U4 g_top[QNODE_U4 * TOP_NODES];
 // the HBM spill path of the stack is out of line so that the compiler cannot merge it with the LDS path
 // into a pointer select (which turns every pop into a flat load)
 __device__ __attribute__((noinline)) int SpillRead(const int *p) { return *p; }
@@ -222,9 +225,16 @@ struct LdsStackT {
 
 __device__ inline void LoadTreeTop(const FastBVH &bvh) {
     const U4 *src = reinterpret_cast<const U4 *>(bvh.nodes);
-    const int n = 2 * (bvh.nNodes < TOP_NODES ? bvh.nNodes : TOP_NODES);
+    const int n = QNODE_U4 * (bvh.nNodes < TOP_NODES ? bvh.nNodes : TOP_NODES);
     for (int i = threadIdx.x; i < n; i += TBLOCK) g_top[i] = src[i];
     __syncthreads();
+}
+// a node's 16-byte words: tree top from LDS, the rest from global memory.  (Measured: splitting the two fetch paths
+// into separate loops so that each is a pure ds_read / global_load costs more in extra wave serialisation than the
+// merged flat load does: 0.57 ms vs 0.45 ms per launch.)
+__device__ inline void FetchNode(const FastBVH &bvh, int node, U4 *n) {
+    const U4 *p = node < TOP_NODES ? g_top + QNODE_U4 * node : reinterpret_cast<const U4 *>(bvh.nodes + node);
+    for (int k = 0; k < QNODE_U4; ++k) n[k] = p[k];
 }
 
 // One batch of TBLOCK rays per workgroup iteration: ray index = thread index within the batch (no cursor
@@ -232,13 +242,57 @@ __device__ inline void LoadTreeTop(const FastBVH &bvh) {
 // them sits at a leaf or is done, then the leaves are processed together); `finish` runs once per batch for
 // the whole workgroup, so its queue pushes are block-aggregated (BlockAlloc).
 // what the general-primitive traversal variants call back into (wf_traverse.h LeafStep): the alpha test and the spheres
+// The general-primitive work of the traversal kernels comes in two strengths (template parameter GEN of the kernels):
+//   GEN = 1  "simple alpha": every alpha texture of the scene is a constant, an image map or a bilerp (no texture graph:
+//            EvalFloatTextureD<0>) and there are no quadrics.  The test is a real call into a small out-of-line function
+//            that reads the device-resident SceneView: the walk keeps its registers, the call is paid only when an
+//            alpha-tested triangle is actually hit.  (Foliage cut-outs are image maps: this is the san-miguel case.)
+//   GEN = 2  anything else (texture graphs as alpha, spheres / disks / cylinders): evaluated inline as before — an
+//            out-of-line callee for the full texture graph needs 194 VGPRs, which would become the kernel's own count.
+// The ray is NOT kept in registers for either: the origin of the space being walked is w.o, the direction is re-fetched
+// from the queue (and taken into the instance's space) when such a primitive is hit.
+__device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp, int tri, float b0, float b1, float b2, float ox, float oy, float oz,
+                                                            float dx, float dy, float dz) {
+    // AlphaTestPasses (common/wf_shapes.h) with the depth-0 texture evaluator
+    const SceneView &sv = *svp;
+    const wf_mesh &mesh = sv.meshes[sv.triMesh[tri]];
+    if (mesh.alpha_tex < 0) return true;
+    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
+    if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+    TexCtx tc;
+    tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
+    tc.p = b0 * LoadP(sv, v[0]) + b1 * LoadP(sv, v[1]) + b2 * LoadP(sv, v[2]);
+    float a = EvalFloatTextureD<0>(sv, mesh.alpha_tex, tc);
+    if (!(a < 1)) return true;
+    float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(V3{ox, oy, oz}, V3{dx, dy, dz}));
+    return !(u > a);
+}
+template <typename Fetch, int GEN>
 struct GeneralPrims {
     const SceneView &sv;
-    V3 o, d;
-    __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
-    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], o, d, tMax, qh); }
+    const FastBVH &bvh;
+    const RayWalk &w;
+    const Fetch &fetch;
+    int idx;
+    __device__ V3 dir() const {
+        V3 o, d;
+        float t;
+        fetch(idx, &o, &d, &t);
+        if (w.curInst >= 0) d = XfVector3(bvh.instances[w.curInst].render_from_instance.mInv, d);  // = InstanceRay's direction
+        return d;
+    }
+    __device__ bool accept(int prim, float b0, float b1, float b2) const {
+        const V3 d = dir();
+        if constexpr (GEN == 1) return AlphaTestSimpleP(bvh.sv, prim, b0, b1, b2, w.o.x, w.o.y, w.o.z, d.x, d.y, d.z);
+        else return AlphaTestPasses(sv, prim, b0, b1, b2, w.o, d);
+    }
+    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const {
+        if constexpr (GEN == 1) return false;
+        else return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], w.o, dir(), tMax, qh);
+    }
 };
-template <bool ANY, bool ALPHA, bool INST = false, typename Fetch, typename Finish>
+template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
     LoadTreeTop(bvh);
     for (int base = blockIdx.x * TBLOCK; base < n; base += gridDim.x * TBLOCK) {
@@ -251,14 +305,13 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
         w.tMax = 0;
         w.b0 = w.b1 = w.b2 = 0;
         w.inst = w.curInst = -1;
-        V3 o{0, 0, 0}, d{0, 0, 0};
         if (valid) {
+            V3 o, d;
             float tMax;
             fetch(idx, &o, &d, &tMax);
             WalkInit(bvh, w, o, d, tMax);
             st.n = 0;
         }
-        V3 dCur = d;  // the ray direction in the space being walked (render space, or an instance's)
         // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
         // per-lane refill ("streaming": idle lanes take the next rays of the wave's run, leaf / interior step chosen per
         // iteration) — 28 % fewer VALU instructions at 53 % instead of 31 % active lanes, but 5x the vector-L1 line
@@ -267,27 +320,27 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
         while (__any(w.node != NODE_NONE)) {
             while (__any(w.node >= 0)) {
                 if (w.node >= 0) {
-                    // tree top from LDS, the rest from global memory.  (Measured: splitting the two fetch paths
-                    // into separate loops so that each is a pure ds_read / global_load costs more in extra wave
-                    // serialisation than the merged flat load does: 0.57 ms vs 0.45 ms per launch.)
-                    U4 a, b;
-                    if (w.node < TOP_NODES) { a = g_top[2 * w.node]; b = g_top[2 * w.node + 1]; }
-                    else {
-                        const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
-                        a = p[0]; b = p[1];
-                    }
-                    InteriorStep<!ANY>(bvh, w, st, a, b);
+                    U4 nd[QNODE_U4];
+                    FetchNode(bvh, w.node, nd);
+                    InteriorStep<!ANY>(bvh, w, st, nd);
                 }
             }
             if (w.node != NODE_NONE) {
                 if constexpr (INST) {
                     // object instances travel through the stack as leaf references (wf_traverse.h)
-                    if (w.node == NODE_EXIT) { ExitInstance(bvh, w, st, o, d, &dCur); continue; }
+                    // (the render-space ray is re-fetched from the queue on these rare transitions instead of living in registers)
                     const int first = (int)((~(unsigned)w.node) >> 4);
-                    if (first >= INST_FIRST) { EnterInstance(bvh, w, st, o, d, first - INST_FIRST, &dCur); continue; }
-                    if constexpr (ALPHA) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims{sv, w.o, dCur});
+                    if (w.node == NODE_EXIT || first >= INST_FIRST) {
+                        V3 o, d;
+                        float t0;
+                        fetch(idx, &o, &d, &t0);
+                        if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
+                        else EnterInstance(bvh, w, st, o, d, first - INST_FIRST);
+                        continue;
+                    }
+                    if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
                     else LeafStep<ANY, false, true>(bvh, w, st);
-                } else if constexpr (ALPHA) LeafStep<ANY, true>(bvh, w, st, GeneralPrims{sv, o, d});
+                } else if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
                 else LeafStep<ANY>(bvh, w, st);
             }
         }
@@ -295,13 +348,13 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
     }
 }
 
-template <bool ALPHA, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
+template <int GEN, bool INST = false>
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
     const RayQueueV q = ws.rq[cur];
-    BatchTrace<false, ALPHA, INST>(
+    BatchTrace<false, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = q.o[i], d4 = q.d[i];
@@ -310,8 +363,11 @@ __global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_closest_fast(c
         [&](int i, bool valid, const RayWalk &w) {
             // near-tie seen (wf_traverse.h): the reference-order walk decides (k_closest_retrace)
             const bool amb = valid && WalkAmbiguous(w);
-            if (amb) ws.retraceQ[atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1)] = i;
-            KRouteHitBlock<ALPHA || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
+            if (amb) {
+                ws.retraceQ[atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1)] = i;
+                ws.hit[i] = F4{0, 2 * WalkBound(bvh, WalkT(w)) - WalkT(w), 0, 0};  // the re-trace's starting bound, see k_closest_retrace
+            }
+            KRouteHitBlock<(GEN > 1) || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
         });
 }
 // the rays k_closest_fast marked as near-ties, in the reference's own traversal order (rare: coplanar overlapping geometry)
@@ -324,16 +380,20 @@ __global__ void __launch_bounds__(BLOCK) k_closest_retrace(const SceneView sv, W
         F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
         ClosestHit ch;
         st.n = 0;
-        bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
+        // The walk starts from tMax = t* + twice the near-tie band instead of infinity (t* = the production walk's hit): every
+        // candidate that can end up as the reference's hit lies inside the band around t*, a candidate beyond the starting
+        // bound could only have been a temporary hit that the band's members replace — the result is the reference's, and
+        // the walk visits a fraction of the nodes (the latency of this launch is one ray's dependent chain).
+        bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, ws.hit[i].y, st, &ch);
         KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.inst, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
     }
 }
-template <bool ALPHA, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+template <int GEN, bool INST = false>
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true, ALPHA, INST>(
+    BatchTrace<true, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
@@ -343,11 +403,11 @@ __global__ void __launch_bounds__(TBLOCK, INST ? 4 : WF_TWAVES) k_shadow_fast(co
 }
 
 // GENERAL: the scene has alpha-tested triangles or quadrics (the variant the render uses then)
-template <bool INST, bool GENERAL>
+template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<false, GENERAL, INST>(
+    BatchTrace<false, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
@@ -364,11 +424,11 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView s
             out[i] = h;
         });
 }
-template <bool INST, bool GENERAL>
+template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
-    BatchTrace<true, GENERAL, INST>(
+    BatchTrace<true, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
@@ -406,6 +466,12 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
 }
 // production layout, one independent walk per lane (a transmittance ray alternates between tracing and
 // ratio tracking, so there is no batch to share)
+struct TrPrims {  // the same callbacks for the transmittance walk, whose ray is a local of its loop
+    const SceneView &sv;
+    V3 o, d;
+    __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
+    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], o, d, tMax, qh); }
+};
 template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
@@ -419,14 +485,10 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
             st.n = 0;
             while (w.node != NODE_NONE) {
                 if (w.node >= 0) {
-                    U4 a, b;
-                    if (w.node < TOP_NODES) { a = g_top[2 * w.node]; b = g_top[2 * w.node + 1]; }
-                    else {
-                        const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + w.node);
-                        a = p[0]; b = p[1];
-                    }
-                    InteriorStep(bvh, w, st, a, b);
-                } else if constexpr (ALPHA) LeafStep<false, true>(bvh, w, st, GeneralPrims{sv, o, d});
+                    U4 nd[QNODE_U4];
+                    FetchNode(bvh, w.node, nd);
+                    InteriorStep(bvh, w, st, nd);
+                } else if constexpr (ALPHA) LeafStep<false, true>(bvh, w, st, TrPrims{sv, o, d});
                 else LeafStep<false>(bvh, w, st);
             }
             if (WalkAmbiguous(w)) {  // near-tie (wf_traverse.h): the reference-order walk decides
@@ -540,6 +602,16 @@ struct Prof {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, __VA_ARGS__);  \
     } while (0)
 
+// launch KERNEL<GEN, INST> (or <INST, GEN> for the host-ray probes: ORDER = 1) for the context's scene
+#define LAUNCHT_VARIANT(name, KERNEL, ORDER, ...)                                                              \
+    do {                                                                                                       \
+        const int gen_ = ctx->genMode;                                                                         \
+        const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
+        if (ORDER == 0) {                                                                                      \
+            if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); } \
+            else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); } \
+        }                                                                                                      \
+    } while (0)
 #define LAUNCHT(name, kernel, grid, ...)                                                   \
     do {                                                                                   \
         Prof prof_(ctx, name);                                                             \
@@ -617,7 +689,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     // a superset of the triangles the reference tests, which changes no result (the exact triangle test decides, near-ties
     // are re-traced in reference order) and removes the bottom levels of dependent node fetches: instance definitions are
     // built with one primitive per leaf (maxPrimsInNode = 1, scene.cpp:1539).
-    int collapse = 4;
+    int collapse = 1;
     if (const char *e = getenv("WF_LEAF_COLLAPSE")) collapse = std::min(16, std::max(1, atoi(e)));
     std::vector<int> subFirst(n), subCount(n);
     for (int i = n - 1; i >= 0; --i) {
@@ -666,6 +738,58 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             for (int a = 0; a < 3; ++a) q[slot * 3 + a] = qlo(b.bmin[a], a) | (qhi(b.bmax[a], a) << 16);
         };
         const int qBase = (int)nodes->size();
+#if WF_BVH4
+        auto emptyBox = [&](uint32_t q[12], int slot) { for (int a = 0; a < 3; ++a) q[slot * 3 + a] = 0x0000ffffu; };
+        auto area = [&](int i) {
+            double dx = (double)L[i].bmax[0] - L[i].bmin[0], dy = (double)L[i].bmax[1] - L[i].bmin[1], dz = (double)L[i].bmax[2] - L[i].bmin[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        auto packBox4 = [&](const wf_bvh_node &b, uint32_t q[12], int slot) {
+            for (int a = 0; a < 3; ++a) q[slot * 3 + a] = qlo(b.bmin[a], a) | (qhi(b.bmax[a], a) << 16);
+        };
+        if (leafLike(root)) {
+            QNode qn{};
+            packBox4(L[root], qn.q, 0);
+            qn.child[0] = leafRef(root);
+            for (int c = 1; c < 4; ++c) { emptyBox(qn.q, c); qn.child[c] = NODE_NONE; }
+            nodes->push_back(qn);
+            return qBase;
+        }
+        // four-way collapse of the binary tree: a node's children are its two binary children, the largest interior ones
+        // replaced by their own children until there are four (or only leaves are left); breadth-first numbering
+        std::vector<int> order;
+        order.push_back(root);
+        bfsIndex[root] = qBase;
+        std::vector<std::array<int, 4>> kidsOf;
+        for (size_t h = 0; h < order.size(); ++h) {
+            int i = order[h];
+            std::array<int, 4> kids = {i + 1, (int)L[i].offset, -1, -1};
+            int nk = 2;
+            while (nk < 4) {
+                int best = -1;
+                for (int k = 0; k < nk; ++k)
+                    if (!leafLike(kids[k]) && (best < 0 || area(kids[k]) > area(kids[best]))) best = k;
+                if (best < 0) break;
+                int c = kids[best];
+                kids[best] = c + 1;
+                kids[nk++] = L[c].offset;
+            }
+            for (int k = 0; k < nk; ++k)
+                if (!leafLike(kids[k])) { bfsIndex[kids[k]] = qBase + (int)order.size(); order.push_back(kids[k]); }
+            kidsOf.push_back(kids);
+        }
+        nodes->resize((size_t)qBase + order.size());
+        for (size_t h = 0; h < order.size(); ++h) {
+            QNode qn{};
+            for (int c = 0; c < 4; ++c) {
+                int k = kidsOf[h][c];
+                if (k < 0) { emptyBox(qn.q, c); qn.child[c] = NODE_NONE; continue; }
+                packBox4(L[k], qn.q, c);
+                qn.child[c] = !leafLike(k) ? bfsIndex[k] : leafRef(k);
+            }
+            (*nodes)[(size_t)qBase + h] = qn;
+        }
+#else
         if (leafLike(root)) {
             // the whole tree is one leaf: a root node whose two children are both that leaf (testing it twice
             // changes neither the closest hit nor occlusion)
@@ -697,6 +821,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             qn.right = !leafLike(r) ? bfsIndex[r] : leafRef(r);
             (*nodes)[(size_t)qBase + h] = qn;
         }
+#endif
         return qBase;
     };
     buildTree(0, out->base, out->cell);
@@ -850,6 +975,16 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     {
         std::vector<QNode> qn;
         std::vector<LeafTri> lt;
+        {
+            ctx->genMode = 0;
+            if (d->n_quadrics > 0) ctx->genMode = 2;
+            for (int i = 0; i < d->n_meshes && ctx->genMode < 2; ++i)
+                if (d->meshes[i].alpha_tex >= 0) {
+                    const int tt = d->textures[d->meshes[i].alpha_tex].type;
+                    ctx->genMode = std::max(ctx->genMode, (tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) ? 1 : 2);
+                }
+            if (getenv("WF_GEN_MODE")) ctx->genMode = std::max(ctx->genMode, atoi(getenv("WF_GEN_MODE")));  // timing experiments: force the general variant
+        }
         std::vector<FastDef> fdefs;
         ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &ctx->fast);
         if (ctx->fastOk) {
@@ -860,7 +995,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
         int perCU = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_closest_fast<false>, TBLOCK, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_closest_fast<0, false>, TBLOCK, 0));
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
         int g = std::max(1, perCU) * prop.multiProcessorCount;
@@ -874,6 +1009,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)129))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.trav, (size_t)8))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT * CNT_STRIDE))) return e;
+    if ((e = devUpload(ctx, &ctx->svDev, &ctx->svHost, (size_t)1))) return e;
+    ctx->fast.sv = ctx->svDev;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sv / sobol live on the host stack
     ctx->sceneLoaded = true;
     return 0;
@@ -996,12 +1133,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     else if (ctx->fastOk) {
-        const bool general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
-        if (ctx->svHost.nInstances > 0) {
-            if (general) LAUNCHT("Intersect closest", (k_closest_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
-            else LAUNCHT("Intersect closest", (k_closest_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
-        } else if (general) LAUNCHT("Intersect closest", k_closest_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
-        else LAUNCHT("Intersect closest", k_closest_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
@@ -1069,12 +1201,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     else if (ctx->fastOk) {
-        const bool general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
-        if (ctx->svHost.nInstances > 0) {
-            if (general) LAUNCHT("Intersect shadow", (k_shadow_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
-            else LAUNCHT("Intersect shadow", (k_shadow_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
-        } else if (general) LAUNCHT("Intersect shadow", k_shadow_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
-        else LAUNCHT("Intersect shadow", k_shadow_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
@@ -1238,11 +1365,7 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     if (count_visits || !ctx->fastOk) {
         LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 0);
     } else {
-        const bool inst = ctx->svHost.nInstances > 0, general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
-        if (inst && general) LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
-        else if (inst) LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<true, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
-        else if (general) LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
-        else LAUNCHT("trace closest fast (host rays)", (k_trace_closest_fast<false, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
+        LAUNCHT_VARIANT("trace closest fast (host rays)", k_trace_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
         LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 1);
     }
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
@@ -1267,11 +1390,7 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     if (nodes_visited || tris_tested || !ctx->fastOk) {
         LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svHost, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
     } else {
-        const bool inst = ctx->svHost.nInstances > 0, general = ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0;
-        if (inst && general) LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<true, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
-        else if (inst) LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<true, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
-        else if (general) LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
-        else LAUNCHT("trace any fast (host rays)", (k_trace_any_fast<false, false>), ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
+        LAUNCHT_VARIANT("trace any fast (host rays)", k_trace_any_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
     }
     HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-BUILD = os.path.join(HERE, "_build")
+BUILD = os.environ.get("WF_BUILD_DIR") or os.path.join(HERE, "_build")  # WF_BUILD_DIR: timing / validation of variant builds (pbrt-v4_amd/_exp*)
 DATA = os.path.join(HERE, "data")
 
 

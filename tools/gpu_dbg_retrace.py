@@ -4,8 +4,12 @@ sys.path.insert(0, "tests"); sys.path.insert(0, "tools")
 from conftest import load_pkg
 import make_scenes
 wfpt = load_pkg(); host, hip = wfpt.libs()
-make_scenes.killeroo_like("/tmp/k.pbrt", (1920, 1080), 16)
-s = wfpt.Scene(path="/tmp/k.pbrt", spp=16); s.create_renderer(0)
+if len(sys.argv) > 1:
+    scene_path = sys.argv[1]
+else:
+    make_scenes.killeroo_like("/tmp/k.pbrt", (1920, 1080), 16)
+    scene_path = "/tmp/k.pbrt"
+s = wfpt.Scene(path=scene_path, spp=16); s.create_renderer(0)
 ctx = s.ctx
 for f in ("wf_reset_ray_queue", "wf_gen_camera_rays", "wf_reset_stage_queues", "wf_gen_ray_samples", "wf_intersect_closest", "wf_eval_material", "wf_intersect_shadow", "wf_handle_escaped", "wf_handle_emissive"):
     getattr(hip, f).argtypes = [C.c_void_p] + [C.c_int] * (2 if f in ("wf_gen_camera_rays", "wf_gen_ray_samples", "wf_eval_material") else 1)
@@ -20,6 +24,6 @@ for depth in range(0, 4):
     hip.wf_intersect_closest(ctx, depth)
     print("depth", depth, "rays", qs("ray%d" % (depth & 1)), "retrace", qs("retrace"))
     hip.wf_handle_escaped(ctx, depth); hip.wf_handle_emissive(ctx, depth)
-    for m in (1, 3):
+    for m in (1, 2, 3, 6):
         hip.wf_eval_material(ctx, m, depth)
     hip.wf_intersect_shadow(ctx, depth)
