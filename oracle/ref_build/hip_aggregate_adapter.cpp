@@ -1,0 +1,246 @@
+// oracle/ref_build/hip_aggregate_adapter.cpp — TEST INFRASTRUCTURE (ours), and the compiled form of INTEGRATION.md §2:
+// the binding a pbrt-v4 maintainer would add to put the MI355X traversal under the reference's own
+// WavefrontPathIntegrator.  `class HipAggregate` implements the reference's `WavefrontAggregate` interface
+// (wavefront/integrator.h:32-54) on top of the C ABI of libwfhip.so / libwfhost.so (include/wf_abi.h, include/wf_host.h):
+//
+//   IntersectClosest  rays of the RayQueue -> wf_trace_closest_host (production two-level walk + near-tie re-trace)
+//                     -> per hit the reference's own Triangle::InteractionFromIntersection + SetIntersectionProperties
+//                     -> the reference's own EnqueueWorkAfterIntersection / EnqueueWorkAfterMiss (wavefront/intersect.h)
+//   IntersectShadow   shadow rays -> wf_trace_any_host -> the reference's RecordShadowRayResult
+//   Bounds            wf_aggregate_bounds
+//   IntersectShadowTr / IntersectOneRandom: forwarded to the reference's CPUAggregate (media / subsurface scenes)
+//
+// Everything else — camera rays, samplers, materials, lights, film — stays the reference's CPU code, so the image must be
+// the one `pbrt --wavefront` writes, bit for bit (tests/test_gpu_parity.py::test_reference_integrator_over_hip_aggregate).
+// Scope: triangle meshes without alpha textures, no object instances (the primitive id -> reference primitive map below
+// covers top-level triangles).  Links the shimmed reference build (libpbrt_ref.a); nothing of the reference is modified —
+// private members are reached with the test-only `#define private public`.
+//   pbrt_hipagg [--spp N] [--outfile out.pfm] scene.pbrt
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <future>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <set>
+#include <shared_mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <typeindex>
+#include <typeinfo>
+#include <unordered_map>
+#include <variant>
+#include <vector>
+
+#define private public
+#define protected public
+#include <pbrt/pbrt.h>
+#include <pbrt/cameras.h>
+#include <pbrt/cpu/aggregates.h>
+#include <pbrt/cpu/primitive.h>
+#include <pbrt/shapes.h>
+#include <pbrt/wavefront/aggregate.h>
+#include <pbrt/wavefront/integrator.h>
+#undef private
+#undef protected
+#include <pbrt/film.h>
+#include <pbrt/options.h>
+#include <pbrt/parser.h>
+#include <pbrt/scene.h>
+#include <pbrt/util/image.h>
+#include <pbrt/util/parallel.h>
+#include <pbrt/wavefront/intersect.h>
+
+#include "../../include/wf_host.h"
+
+using namespace pbrt;
+
+class HipAggregate : public WavefrontAggregate {
+  public:
+    HipAggregate(CPUAggregate *cpu, wf_ctx *ctx, const wf_scene_desc *desc) : cpu(cpu), ctx(ctx) {
+        // primitive id (global triangle id of the flat tables) -> the reference's primitive.  The reference registers its meshes
+        // in whatever order its parallel shape creation finishes, so meshes are matched by content: triangle count + the bytes
+        // of their render-space vertex positions (both sides apply the same transform arithmetic: bit-identical).
+        const int nTriangles = desc->n_triangles;
+        prims.assign(nTriangles, Primitive());
+        auto key = [](int ntris, const float *p, int nverts) {
+            uint64_t h = 1469598103934665603ull ^ (uint64_t)ntris;
+            for (size_t i = 0; i < (size_t)nverts * 3; ++i) {
+                float f = p[i] + 0.0f;  // -0 and +0 are the same position
+                uint32_t u;
+                std::memcpy(&u, &f, 4);
+                h = (h ^ u) * 1099511628211ull;
+            }
+            return h;
+        };
+        // (the reference creates the shapes of emitters twice — once for the lights, scene.cpp:1290-1340, once for the
+        // primitives — so a reference mesh may repeat; identical meshes on our side are handed out in turn)
+        std::map<uint64_t, std::pair<std::vector<int>, size_t>> ours;  // key -> first global triangle ids, next to hand out
+        for (int m = 0; m < desc->n_meshes; ++m)
+            if (desc->meshes[m].ntris > 0) ours[key(desc->meshes[m].ntris, desc->P + 3 * (size_t)desc->meshes[m].first_vertex, desc->meshes[m].nverts)].first.push_back(desc->meshes[m].first_tri);
+        std::vector<int> firstTri(Triangle::allMeshes->size(), -1);
+        for (size_t m = 0; m < Triangle::allMeshes->size(); ++m) {
+            const TriangleMesh *tm = (*Triangle::allMeshes)[m];
+            std::vector<float> P(3 * (size_t)tm->nVertices);
+            for (int v = 0; v < tm->nVertices; ++v) { P[3 * v] = tm->p[v].x; P[3 * v + 1] = tm->p[v].y; P[3 * v + 2] = tm->p[v].z; }
+            auto it = ours.find(key(tm->nTriangles, P.data(), tm->nVertices));
+            if (it == ours.end()) ErrorExit("pbrt_hipagg: a reference mesh (%d triangles) has no counterpart in the flat tables", tm->nTriangles);
+            firstTri[m] = it->second.first[it->second.second++ % it->second.first.size()];
+        }
+        std::function<void(Primitive)> visit = [&](Primitive p) {
+            if (!p) return;
+            if (p.Is<BVHAggregate>()) {
+                for (Primitive q : p.Cast<BVHAggregate>()->primitives) visit(q);
+                return;
+            }
+            Shape shape;
+            if (p.Is<SimplePrimitive>()) shape = p.Cast<SimplePrimitive>()->shape;
+            else if (p.Is<GeometricPrimitive>()) {
+                shape = p.Cast<GeometricPrimitive>()->shape;
+                if (p.Cast<GeometricPrimitive>()->alpha) ErrorExit("pbrt_hipagg: alpha textures are outside this adapter's scope");
+            } else ErrorExit("pbrt_hipagg: object instances / animated primitives are outside this adapter's scope");
+            if (!shape.Is<Triangle>()) ErrorExit("pbrt_hipagg: only triangle meshes are inside this adapter's scope");
+            const Triangle *t = shape.Cast<Triangle>();
+            int id = firstTri[t->meshIndex] + t->triIndex;
+            CHECK(id >= 0 && id < nTriangles);
+            prims[id] = p;
+        };
+        visit(cpu->aggregate);
+        // identical meshes (same geometry, possibly different materials) may have been handed out in a different order than
+        // the primitives were created in: every triangle must still have found exactly one primitive
+        for (const Primitive &p : prims)
+            if (!p) ErrorExit("pbrt_hipagg: ambiguous mesh matching (identical meshes with different roles)");
+    }
+
+    Bounds3f Bounds() const override {
+        float b[6];
+        if (wf_aggregate_bounds(ctx, b) != 0) ErrorExit("wf_aggregate_bounds: %s", wf_last_error());
+        return Bounds3f(Point3f(b[0], b[1], b[2]), Point3f(b[3], b[4], b[5]));
+    }
+
+    void IntersectClosest(int maxRays, const RayQueue *rayQueue, EscapedRayQueue *escapedRayQueue, HitAreaLightQueue *hitAreaLightQueue,
+                          MaterialEvalQueue *basicEvalMaterialQueue, MaterialEvalQueue *universalEvalMaterialQueue,
+                          MediumSampleQueue *mediumSampleQueue, RayQueue *nextRayQueue) const override {
+        const int n = rayQueue->Size();
+        if (n == 0) return;
+        std::vector<float> o(3 * (size_t)n), d(3 * (size_t)n), tmax(n, Infinity);
+        for (int i = 0; i < n; ++i) {
+            const RayWorkItem r = (*rayQueue)[i];
+            o[3 * i] = r.ray.o.x; o[3 * i + 1] = r.ray.o.y; o[3 * i + 2] = r.ray.o.z;
+            d[3 * i] = r.ray.d.x; d[3 * i + 1] = r.ray.d.y; d[3 * i + 2] = r.ray.d.z;
+        }
+        std::vector<wf_hit_record> hits(n);
+        // count_visits = 0: the production traversal (wf_traverse.h); near-ties are re-traced in the reference's order
+        if (wf_trace_closest_host(ctx, n, o.data(), d.data(), tmax.data(), hits.data(), 0) != 0) ErrorExit("wf_trace_closest_host: %s", wf_last_error());
+        ParallelFor(0, n, [&](int64_t index) {
+            const RayWorkItem r = (*rayQueue)[index];
+            const wf_hit_record &h = hits[index];
+            if (h.prim < 0) {
+                EnqueueWorkAfterMiss(r, mediumSampleQueue, escapedRayQueue);
+                return;
+            }
+            // what Triangle::Intersect + GeometricPrimitive / SimplePrimitive::Intersect build from the hit
+            Primitive p = prims[h.prim];
+            const Triangle *tri = (p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->shape : p.Cast<GeometricPrimitive>()->shape).Cast<Triangle>();
+            TriangleIntersection ti{h.b0, h.b1, h.b2, h.t};
+            SurfaceInteraction intr = Triangle::InteractionFromIntersection(tri->GetMesh(), tri->triIndex, ti, r.ray.time, -r.ray.d);
+            if (p.Is<SimplePrimitive>()) intr.SetIntersectionProperties(p.Cast<SimplePrimitive>()->material, nullptr, nullptr, r.ray.medium);
+            else {
+                const GeometricPrimitive *g = p.Cast<GeometricPrimitive>();
+                intr.SetIntersectionProperties(g->material, g->areaLight, &g->mediumInterface, r.ray.medium);
+            }
+            EnqueueWorkAfterIntersection(r, r.ray.medium, h.t, intr, mediumSampleQueue, nextRayQueue, hitAreaLightQueue, basicEvalMaterialQueue,
+                                         universalEvalMaterialQueue);
+        });
+    }
+
+    void IntersectShadow(int maxRays, ShadowRayQueue *shadowRayQueue, SOA<PixelSampleState> *pixelSampleState) const override {
+        const int n = shadowRayQueue->Size();
+        if (n == 0) return;
+        std::vector<float> o(3 * (size_t)n), d(3 * (size_t)n), tmax(n);
+        for (int i = 0; i < n; ++i) {
+            const ShadowRayWorkItem w = (*shadowRayQueue)[i];
+            o[3 * i] = w.ray.o.x; o[3 * i + 1] = w.ray.o.y; o[3 * i + 2] = w.ray.o.z;
+            d[3 * i] = w.ray.d.x; d[3 * i + 1] = w.ray.d.y; d[3 * i + 2] = w.ray.d.z;
+            tmax[i] = w.tMax;
+        }
+        std::vector<int32_t> occluded(n);
+        if (wf_trace_any_host(ctx, n, o.data(), d.data(), tmax.data(), occluded.data(), nullptr, nullptr) != 0) ErrorExit("wf_trace_any_host: %s", wf_last_error());
+        ParallelFor(0, n, [&](int64_t index) { RecordShadowRayResult((*shadowRayQueue)[index], pixelSampleState, occluded[index] != 0); });
+    }
+
+    void IntersectShadowTr(int maxRays, ShadowRayQueue *q, SOA<PixelSampleState> *ps) const override { cpu->IntersectShadowTr(maxRays, q, ps); }
+    void IntersectOneRandom(int maxRays, SubsurfaceScatterQueue *q) const override { cpu->IntersectOneRandom(maxRays, q); }
+
+  private:
+    CPUAggregate *cpu;
+    wf_ctx *ctx;
+    std::vector<Primitive> prims;
+};
+
+int main(int argc, char **argv) {
+    std::string scenePath, outfile, dataDir;
+    int spp = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--spp" && i + 1 < argc) spp = atoi(argv[++i]);
+        else if (a == "--outfile" && i + 1 < argc) outfile = argv[++i];
+        else if (a == "--datadir" && i + 1 < argc) dataDir = argv[++i];
+        else scenePath = a;
+    }
+    if (scenePath.empty()) { fprintf(stderr, "usage: pbrt_hipagg [--spp N] [--outfile out.pfm] [--datadir DIR] scene.pbrt\n"); return 1; }
+    if (dataDir.empty()) {
+        std::string self = argv[0];
+        size_t p = self.rfind('/');
+        dataDir = (p == std::string::npos ? std::string(".") : self.substr(0, p)) + "/../../pbrt-v4_amd/data";
+    }
+    // the HIP side: the same scene file through libwfhost's loader, uploaded to device 0
+    if (wfh_init(dataDir.c_str()) != 0) { fprintf(stderr, "wfh_init failed\n"); return 1; }
+    wfh_scene *hs = wfh_scene_load(scenePath.c_str(), spp, 0);
+    const bool dryRun = getenv("WF_ADAPTER_DRYRUN") != nullptr;  // mesh matching only (no GPU): debugging aid
+    if (!hs || (!dryRun && wfh_renderer_create(hs, 0, 1) != 0)) { fprintf(stderr, "libwfhost: could not load / upload the scene: %s\n", wf_last_error()); return 1; }
+    wfh_info info;
+    wfh_scene_info(hs, &info);
+
+    PBRTOptions opt;
+    opt.wavefront = true;
+    opt.quiet = true;
+    opt.seed = 0;
+    if (spp > 0) opt.pixelSamples = spp;
+    if (!outfile.empty()) opt.imageFile = outfile;
+    InitPBRT(opt);
+    {
+        BasicScene scene;
+        BasicSceneBuilder builder(&scene);
+        ParseFiles(&builder, {scenePath});
+        WavefrontPathIntegrator *in = new WavefrontPathIntegrator(pstd::pmr::get_default_resource(), scene);
+        CPUAggregate *cpu = dynamic_cast<CPUAggregate *>(in->aggregate);
+        CHECK(cpu);
+        if (dryRun) {
+            const wf_scene_desc *dd = wfh_scene_desc(hs);
+            for (int m = 0; m < dd->n_meshes; ++m) { const float *P = dd->P + 3 * (size_t)dd->meshes[m].first_vertex; fprintf(stderr, "ours mesh %d ntris %d nverts %d p0 %a %a %a\n", m, dd->meshes[m].ntris, dd->meshes[m].nverts, P[0], P[1], P[2]); }
+            for (size_t m = 0; m < Triangle::allMeshes->size(); ++m) { const TriangleMesh *tm = (*Triangle::allMeshes)[m]; fprintf(stderr, "ref mesh %zu ntris %d nverts %d p0 %a %a %a\n", m, tm->nTriangles, tm->nVertices, tm->p[0].x, tm->p[0].y, tm->p[0].z); }
+        }
+        in->aggregate = new HipAggregate(cpu, dryRun ? nullptr : wfh_renderer_ctx(hs), wfh_scene_desc(hs));
+        if (dryRun) { printf("dry run: meshes matched\n"); return 0; }
+        Float seconds = in->Render();
+        ImageMetadata metadata;
+        in->camera.InitMetadata(&metadata);
+        metadata.renderTimeSeconds = seconds;
+        metadata.samplesPerPixel = in->sampler.SamplesPerPixel();
+        in->film.WriteImage(metadata);
+        printf("{\"adapter\": \"HipAggregate\", \"seconds\": %.3f, \"triangles\": %d}\n", (double)seconds, info.n_triangles);
+    }
+    CleanupPBRT();
+    return 0;
+}

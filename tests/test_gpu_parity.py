@@ -308,3 +308,21 @@ def test_samples_per_pass_invariance(wfpt):
         assert st["camera_rays"] == stats[0]["camera_rays"]
         assert st["indirect_rays"] == stats[0]["indirect_rays"]
         assert st["shadow_rays"] == stats[0]["shadow_rays"]
+
+
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights"])
+def test_reference_integrator_over_hip_aggregate(tmp_path, name):
+    """The drop-in boundary, compiled and run: oracle/_ref/pbrt_hipagg is the REFERENCE's own WavefrontPathIntegrator (its
+    CPU camera / sampler / material / light / film code, linked from the unmodified sources) with its WavefrontAggregate
+    replaced by oracle/ref_build/hip_aggregate_adapter.cpp's HipAggregate, which answers IntersectClosest / IntersectShadow
+    through the C ABI of libwfhip.so (production traversal on the GPU) and feeds the hits to the reference's own
+    EnqueueWorkAfterIntersection.  The image must be the one `pbrt --wavefront` wrote: bit for bit."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "pbrt_hipagg")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/pbrt_hipagg not built (needs /root/reference at build time)")
+    out = str(tmp_path / "agg.pfm")
+    subprocess.run([exe, "--spp", "4", "--outfile", out, os.path.join(GOLDEN, name + ".pbrt")], check=True, cwd=str(tmp_path))
+    img = read_pfm(out)
+    ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))
+    assert img.shape == ref.shape
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()

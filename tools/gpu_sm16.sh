@@ -7,5 +7,5 @@ mkdir -p $d
 for b in pbrt-v4_amd/_build pbrt-v4_amd/_exp*; do
   [ -x $b/pbrt_amd ] || continue
   echo "== $b"
-  timeout 600 $b/pbrt_amd --stats --spp 16 --outfile /tmp/sm.pfm $d/sm.pbrt 2>&1 | grep -E "Rendering|${GREP:-Intersect|Total GPU}"
+  timeout 150 $b/pbrt_amd --stats --spp 16 --outfile /tmp/sm.pfm $d/sm.pbrt 2>&1 | grep -E "Rendering|${GREP:-Intersect|Total GPU}"
 done
