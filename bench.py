@@ -13,10 +13,11 @@ image (both 540-scanline wavefront passes, wavefront/integrator.cpp:336-442) = 2
 configuration's 256 spp (throughput does not depend on K: every step repeats the same passes on new sample indices).
 --workload killeroo-like selects configs[1] (round 1's default), cloud-like configs[3].
 
-N > 1 (launched by torch.distributed.run, one process per GPU): the scene is replicated, rank r renders
-the step indices r, r+N, ... (identical per-pixel sample sets to the 1-GPU render because the sampler is
-keyed on (pixel, sampleIndex, dimension)), and the double-precision film accumulators are summed with one
-RCCL all-reduce inside the timed region.  Total work is fixed as N grows: "scaling": "strong".
+N > 1 (launched by torch.distributed.run, one process per GPU): the scene is replicated (built once: the first rank to
+arrive writes the table cache, the others load it), the IMAGE is partitioned — rank r renders the interleaved 16-line
+strips r, r+N, ... for every step (pbrt-v4_amd/multigpu.py, wf_set_strips) — and the double-precision film accumulators
+go to rank 0 with one RCCL reduce inside the timed region (disjoint strips: a gather, bit-identical to the 1-GPU film).
+Total work is fixed as N grows: "scaling": "strong".  --partition samples selects the sample-index partition instead.
 
 The JSON line also carries
   roofline      achieved algorithmic GB/s of the dominant kernel ("Intersect closest") vs the 8 TB/s HBM peak:
@@ -102,6 +103,7 @@ def main():
     ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like"], default="sanmiguel-like",
                     help="sanmiguel-like = BASELINE configs[2] stand-in at the SURVEY 8(d) spec (default: the north_star target config); "
                          "killeroo-like = configs[1] stand-in; cloud-like = configs[3] stand-in")
+    ap.add_argument("--partition", choices=["strips", "samples"], default="strips", help="N > 1: interleaved scanline strips (default) or sample indices")
     ap.add_argument("--meshes", type=int, default=2000, help="sanmiguel-like: number of 5000-triangle meshes (2000 = 10 M unique triangles)")
     a = ap.parse_args()
 
@@ -121,6 +123,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     wfpt = load_pkg()
+    spec = importlib.util.spec_from_file_location("multigpu", os.path.join(ROOT, "pbrt-v4_amd", "multigpu.py"))
+    multigpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(multigpu)
     K, Wm = a.steps, a.warmup
     spp_total = 1
     while spp_total < max(K, Wm):
@@ -143,9 +148,15 @@ def main():
             while not os.path.exists(marker):
                 time.sleep(0.5)
     t_gen = time.perf_counter() - t_gen0
+    # the built scene tables are shared through the on-disk cache (WF_TABLE_CACHE): rank 0 builds and writes, the others load
+    os.environ.setdefault("WF_TABLE_CACHE", td)
+    if dist is not None and rank != 0:
+        dist.barrier()
     t_load0 = time.perf_counter()
-    scene = wfpt.Scene(path=scene_path, spp=spp_total)         # parse + flat tables + host SAH BVH builds
+    scene = wfpt.Scene(path=scene_path, spp=spp_total)         # parse + flat tables + host SAH BVH builds (or the cache)
     t_parse = time.perf_counter() - t_load0
+    if dist is not None and rank == 0:
+        dist.barrier()
     scene.create_renderer(local_rank, samples_per_pass=a.samples_per_pass)   # upload + production BVH layout + queues
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t_load0 - t_parse
@@ -176,11 +187,12 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    # timed region: K steps = sample indices 0 .. K-1, dealt round-robin to the ranks
-    scene.render(rank, K, world)
+    # timed region: K steps = sample indices 0 .. K-1 of this rank's part of the image (or this rank's sample indices), then the
+    # film reduce to rank 0
+    multigpu.render_partition(scene, rank, world, 0, K, a.partition)
     if dist is not None:
         scene.film_to_tensor(film_t)
-        dist.all_reduce(film_t)
+        multigpu.reduce_film(film_t, dist, 0)
     barrier()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
@@ -219,7 +231,7 @@ def main():
                                     "(two-level BVH), 10 %% alpha-cut, 1k^2 image textures, diffuse / coated diffuse / dielectric / conductor, sun + 2k^2 image "
                                     "sky + 500 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
                                    % (info.n_triangles, info.max_depth),
-                       "resolution": [info.width, info.height], "spp": K, "samples_per_pass": scene.samples_per_pass, "partition": "sample-index round-robin x%d + RCCL film all-reduce" % world
+                       "resolution": [info.width, info.height], "spp": K, "samples_per_pass": scene.samples_per_pass, "partition": (("interleaved 16-line scanline strips x%d" if a.partition == "strips" else "sample-index round-robin x%d") % world) + " + RCCL film reduce to rank 0"
                        if world > 1 else "single GPU"},
         }
         if not a.no_roofline and counters and counters["closest_rays"] > 0:

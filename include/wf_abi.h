@@ -538,6 +538,13 @@ int wf_update_film(wf_ctx *ctx);
    integrator.cpp:357-434, enqueued without host synchronisation. */
 int wf_render_pass(wf_ctx *ctx, int y0, int sample_index);
 
+/* Image partition for multi-GPU rendering (the north_star's "image tiled across the GPUs"): this context renders the
+   scanline strips rank, rank + count, rank + 2 count, ... of `height` lines each (interleaved: sky and foliage are dealt evenly).
+   wf_render_pass's y0 then counts LOCAL lines (pixel_min.y + first local line of the band); *local_rows = lines owned.  Every
+   context keeps a full-size film whose foreign lines stay zero, so summing the films (one reduce to rank 0) is a gather and the
+   result is bit-identical to a single-context render.  count = 1 restores the whole image. */
+int wf_set_strips(wf_ctx *ctx, int rank, int count, int height, int *local_rows);
+
 /* results */
 int wf_film_download(wf_ctx *ctx, double *rgb_sum_weight /* [H][W][4] */);
 int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes); /* for the RCCL film reduce */

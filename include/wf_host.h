@@ -37,6 +37,8 @@ int wfh_scene_info(wfh_scene *s, wfh_info *out);
 int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass);
 int wfh_renderer_samples_per_pass(wfh_scene *s);
 wf_ctx *wfh_renderer_ctx(wfh_scene *s);
+/* multi-GPU image partition (wf_set_strips): this renderer owns the scanline strips rank, rank + count, ... of `height` lines */
+int wfh_renderer_set_strips(wfh_scene *s, int rank, int count, int height);
 /* Render(): sample indices begin, begin+step, ... < end; returns wall seconds (negative on error) */
 double wfh_render(wfh_scene *s, int sample_begin, int sample_end, int sample_step, int fused);
 int wfh_clear_film(wfh_scene *s);

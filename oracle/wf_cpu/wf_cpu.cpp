@@ -262,6 +262,7 @@ int main(int argc, char **argv) {
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
     bool simulateWaves = false;
     int sampleBegin = 0, sampleEnd = -1, sampleStep = 1, probeStartDim = 0, probeNDims = 0;
+    int stripRank = 0, stripCount = 1, stripHeight = 16;
     gThreads = std::max(1u, std::thread::hardware_concurrency());
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -276,6 +277,7 @@ int main(int argc, char **argv) {
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
         else if (a == "--dump-stages") dumpStages = next();
         else if (a == "--simulate-waves") simulateWaves = true;
+        else if (a == "--strips") { stripRank = atoi(next().c_str()); stripCount = atoi(next().c_str()); stripHeight = atoi(next().c_str()); }
         else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
         else if (a == "--sampler-probe") { probeIn = next(); probeOut = next(); probeStartDim = atoi(next().c_str()); probeNDims = atoi(next().c_str()); }
         else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
@@ -296,6 +298,7 @@ int main(int argc, char **argv) {
     static uint32_t sobol[WF_SOBOL_WORDS];
     FillSobol2D(sobol);
     SceneView sv = MakeHostView(T.desc, sobol);
+    sv.self = &sv;
 
     // sampler probe: in = n x {px, py, sampleIndex} int32 -> out = n x ndims floats (Get1D from startDim)
     if (!probeIn.empty()) {
@@ -353,6 +356,9 @@ int main(int argc, char **argv) {
     ws.maxQueueSize = n;
     ws.pixelsPerPass = n;   // the reference's geometry: one sample index per pass
     ws.samplesPerPass = 1;
+    // --strips rank count height: the multi-GPU image partition (wf_set_strips): only the owned scanline strips are rendered
+    ws.stripRank = stripRank; ws.stripCount = stripCount; ws.stripHeight = stripHeight; ws.localRows = 0;
+    for (int y = 0; y < T.desc.film.pixel_max[1] - T.desc.film.pixel_min[1]; ++y) ws.localRows += stripCount <= 1 || (y / stripHeight) % stripCount == stripRank;
     ws.filterWeight = Alloc<float>(n); ws.pPixel = Alloc<I2>(n);
     ws.lambda = Alloc<F4>(n); ws.lambdaPdf = Alloc<F4>(n); ws.L = Alloc<F4>(n); ws.cameraRayWeight = Alloc<F4>(n);
     ws.samples0 = Alloc<F4>(n); ws.samples1 = Alloc<F4>(n);
@@ -379,7 +385,7 @@ int main(int argc, char **argv) {
     const int maxDepth = T.desc.max_depth;
     if (sampleEnd < 0) sampleEnd = T.spp;
     for (int sampleIndex = sampleBegin; sampleIndex < sampleEnd; sampleIndex += sampleStep) {
-        for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
+        for (int y0 = F.pixel_min[1]; y0 < F.pixel_min[1] + ws.localRows; y0 += T.scanlinesPerPass) {
             ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, 1);
             ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex, sampleStep, 1); });
             ws.stats[0] += ws.counters[(CNT_RAY0) * CNT_STRIDE];

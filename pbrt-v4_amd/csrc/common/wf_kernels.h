@@ -61,6 +61,10 @@ struct WorkState {
     // scanline band (the reference carries one, capped at 2^20 rays: integrator.cpp:227-236).  Item index
     // i = s * pixelsPerPass + p: sample slot s, pixel p of the band.  samplesPerPass = 1 is the reference.
     int pixelsPerPass, samplesPerPass;
+    // image partition for multi-GPU rendering (interleaved strips): this context owns the scanline strips
+    // stripRank, stripRank + stripCount, ... of stripHeight lines each — localRows lines in all; a pass covers a band of
+    // LOCAL rows.  stripCount = 1: the whole image (local row = image row).
+    int stripRank, stripCount, stripHeight, localRows;
     // PixelSampleState
     float *filterWeight;
     I2 *pPixel;
@@ -177,11 +181,18 @@ WF_HD void StoreCtx(const RayQueueV &q, int i, const LightCtx &ctx) {
     q.ctx2[i] = F4{ctx.n.z, ctx.ns.x, ctx.ns.y, ctx.ns.z};
 }
 
-// number of in-bounds pixels of the pass starting at scanline y0 (row-major band)
+// image scanline of local row y0 + r of this context's partition (y0 = pixel_min.y + first local row of the band)
+WF_HD int BandScanline(const SceneView &sv, const WorkState &ws, int y0, int r) {
+    if (ws.stripCount <= 1) return y0 + r;
+    const int l = (y0 - sv.film.pixel_min[1]) + r;
+    if (l >= ws.localRows) return sv.film.pixel_max[1];  // past the last owned line
+    return sv.film.pixel_min[1] + (l / ws.stripHeight * ws.stripCount + ws.stripRank) * ws.stripHeight + l % ws.stripHeight;
+}
+// number of in-bounds pixels of the pass starting at (local) scanline y0 (row-major band)
 WF_HD int KValidPixels(const SceneView &sv, const WorkState &ws, int y0) {
     const wf_film &F = sv.film;
     int xResolution = F.pixel_max[0] - F.pixel_min[0];
-    int rows = F.pixel_max[1] - y0;
+    int rows = (ws.stripCount <= 1 ? F.pixel_max[1] : F.pixel_min[1] + ws.localRows) - y0;
     int maxRows = ws.pixelsPerPass / xResolution;
     if (rows > maxRows) rows = maxRows;
     if (rows < 0) rows = 0;
@@ -201,7 +212,7 @@ WF_HD void KSampleTops(const SceneView &sv, const WorkState &ws, int item, int y
     const int k = item / ws.pixelsPerPass, p = item - k * ws.pixelsPerPass;
     int xResolution = F.pixel_max[0] - F.pixel_min[0];
     int px = F.pixel_min[0] + p % xResolution;
-    int py = y0 + p / xResolution;
+    int py = BandScanline(sv, ws, y0, p / xResolution);
     if (py >= F.pixel_max[1]) return;
     ZSobol sampler(sv);
     sampler.StartPixelSample(px, py, 0, dim0 + SampleTopOffset(k));
@@ -216,7 +227,7 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     const int slot = pixelIndex / ws.pixelsPerPass, p = pixelIndex - slot * ws.pixelsPerPass;
     const int sampleIndex = sampleBase + slot * sampleStep;
     int px = F.pixel_min[0] + p % xResolution;
-    int py = y0 + p / xResolution;
+    int py = BandScanline(sv, ws, y0, p / xResolution);
     if (slot >= nSamples) py = F.pixel_max[1];  // unused sample slot of a short last batch: mark out of bounds
     ws.pPixel[pixelIndex] = I2{px, py};
     if (!(px >= F.pixel_min[0] && px < F.pixel_max[0] && py >= F.pixel_min[1] && py < F.pixel_max[1])) return;

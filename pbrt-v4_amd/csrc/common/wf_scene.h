@@ -64,6 +64,9 @@ struct SceneView {
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
     int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
     wf_options options;
+    // this struct in memory the kernels can read (device memory on the GPU, the object itself on the host): what the few
+    // out-of-line device functions take instead of the by-value kernel argument (whose address must never be taken)
+    const SceneView *self;
 };
 
 // SobolMatrices32 dimensions 0 and 1 (util/sobolmatrices.cpp:40-58).  Dimension 0 is the van der Corput
@@ -438,7 +441,9 @@ WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, cons
 // constants (e.g. mix(checkerboard(c, c), scale(c, c))); the host builder rejects deeper graphs.  (An explicit stack
 // machine was tried: it compiles in seconds for any depth but its indexed stack arrays live in scratch and the
 // material kernels then spill ~470 VGPRs: 22 -> 71 ms for the diffuse kernel.)
+#ifndef WF_TEX_MAX_DEPTH
 #define WF_TEX_MAX_DEPTH 2
+#endif
 template <int D>
 WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
@@ -470,7 +475,17 @@ WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
     }
     return 0.f;
 }
-WF_HD float EvalFloatTexture(const SceneView &sv, int id, const TexCtx &tc) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(sv, id, tc); }
+// Texture GRAPHS (scale / mix / checkerboard / directionmix over other textures) are evaluated out of line, through the
+// memory-resident SceneView: inlined at every material parameter, the depth-bounded recursion was 80 % of the material
+// kernels' code (683 KB -> 137 KB for the diffuse kernel, minutes -> seconds of compile time) for a path that scenes whose
+// parameters are constants or image maps never take.  A root that is a constant, an image map or a bilerp stays inline.
+WF_NI float EvalFloatTextureGraphP(const SceneView *svp, int id, const TexCtx *tc) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(*svp, id, *tc); }
+WF_HD float EvalFloatTexture(const SceneView &sv, int id, const TexCtx &tc) {
+    const int type = sv.textures[id].type;
+    if (type == WF_TEX_FLOAT_CONSTANT || type == WF_TEX_FLOAT_IMAGE || type == WF_TEX_FLOAT_BILERP) return EvalFloatTextureD<0>(sv, id, tc);
+    TexCtx tmp = tc;
+    return EvalFloatTextureGraphP(sv.self, id, &tmp);
+}
 template <int D>
 WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
@@ -503,8 +518,17 @@ WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &la
     }
     return S4c(0.f);
 }
+WF_NI void EvalSpectrumTextureGraphP(const SceneView *svp, int id, const Wavelengths *lambda, const TexCtx *tc, S4 *out) {
+    *out = EvalSpectrumTextureD<WF_TEX_MAX_DEPTH>(*svp, id, *lambda, *tc);
+}
 WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
-    return EvalSpectrumTextureD<WF_TEX_MAX_DEPTH>(sv, id, lambda, tc);
+    const int type = sv.textures[id].type;
+    if (type == WF_TEX_SPECTRUM_CONSTANT || type == WF_TEX_SPECTRUM_IMAGE || type == WF_TEX_SPECTRUM_BILERP) return EvalSpectrumTextureD<0>(sv, id, lambda, tc);
+    TexCtx tmp = tc;
+    Wavelengths l = lambda;
+    S4 r;
+    EvalSpectrumTextureGraphP(sv.self, id, &l, &tmp, &r);
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------

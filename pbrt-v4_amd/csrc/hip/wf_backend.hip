@@ -1009,7 +1009,13 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)129))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.trav, (size_t)8))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT * CNT_STRIDE))) return e;
-    if ((e = devUpload(ctx, &ctx->svDev, &ctx->svHost, (size_t)1))) return e;
+    {
+        SceneView *dev = nullptr;
+        if ((e = devAlloc(ctx, &dev, (size_t)1))) return e;
+        ctx->svHost.self = dev;  // the device copy points at itself: the address the out-of-line device functions are given
+        HIPCHK(hipMemcpyAsync(dev, &ctx->svHost, sizeof(SceneView), hipMemcpyHostToDevice, ctx->stream));
+        ctx->svDev = dev;
+    }
     ctx->fast.sv = ctx->svDev;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sv / sobol live on the host stack
     ctx->sceneLoaded = true;
@@ -1044,6 +1050,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     ws.maxQueueSize = max_queue_size;
     ws.pixelsPerPass = pixels_per_pass;
     ws.samplesPerPass = samples_per_pass;
+    if (ws.stripCount < 1) { ws.stripRank = 0; ws.stripCount = 1; ws.stripHeight = 1; ws.localRows = ctx->H; }
     ctx->passSamples = 1;
     ctx->passStep = 1;
     int e;
@@ -1082,6 +1089,16 @@ int wf_set_pass_samples(wf_ctx *ctx, int sample_step, int n_samples) {
     if (sample_step < 1) return fail(-1, "sample_step must be >= 1");
     ctx->passStep = sample_step;
     ctx->passSamples = n_samples;
+    return 0;
+}
+
+int wf_set_strips(wf_ctx *ctx, int rank, int count, int height, int *local_rows) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (count < 1 || rank < 0 || rank >= count || height < 1) return fail(-1, "wf_set_strips: rank %d of %d, height %d", rank, count, height);
+    int rows = 0;
+    for (int y = 0; y < ctx->H; ++y) rows += (y / height) % count == rank;
+    ctx->ws.stripRank = rank; ctx->ws.stripCount = count; ctx->ws.stripHeight = height; ctx->ws.localRows = count > 1 ? rows : ctx->H;
+    if (local_rows) *local_rows = ctx->ws.localRows;
     return 0;
 }
 

@@ -37,10 +37,16 @@ WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device, int 
     Check(wf_queues_alloc(ctx, T.maxQueueSize, samplesPerPass), "wf_queues_alloc");
     Check(wf_film_clear(ctx), "wf_film_clear");
     Check(wf_sync(ctx), "wf_sync");
+    localRows = T.desc.film.pixel_max[1] - T.desc.film.pixel_min[1];
 }
 
 WavefrontRenderer::~WavefrontRenderer() {
     if (ctx) wf_ctx_destroy(ctx);
+}
+
+// the image partition of multi-GPU rendering: this renderer owns the strips rank, rank + count, ... (wf_set_strips)
+void WavefrontRenderer::SetStrips(int rank, int count, int height) {
+    Check(wf_set_strips(ctx, rank, count, height, &localRows), "wf_set_strips");
 }
 
 void WavefrontRenderer::ClearFilm() {
@@ -59,7 +65,7 @@ double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep,
         // this batch of passes carries sampleIndex, sampleIndex + sampleStep, ... (at most samplesPerPass of them)
         const int remaining = (sampleEnd - sampleIndex + sampleStep - 1) / sampleStep;
         Check(wf_set_pass_samples(ctx, sampleStep, std::min(samplesPerPass, remaining)), "wf_set_pass_samples");
-        for (int y0 = F.pixel_min[1]; y0 < F.pixel_max[1]; y0 += T.scanlinesPerPass) {
+        for (int y0 = F.pixel_min[1]; y0 < F.pixel_min[1] + localRows; y0 += T.scanlinesPerPass) {
             if (fused) {
                 Check(wf_render_pass(ctx, y0, sampleIndex), "wf_render_pass");
                 continue;

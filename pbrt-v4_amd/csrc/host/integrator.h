@@ -17,6 +17,8 @@ class WavefrontRenderer {
     // returns wall seconds (Render(), integrator.cpp:308,483-487).  fused: one wf_render_pass call per
     // pass instead of one C-ABI call per stage (same launches, fewer boundary crossings)
     double Render(int sampleBegin, int sampleEnd, int sampleStep, bool fused = true);
+    // multi-GPU image partition: own the scanline strips rank, rank + count, ... of `height` lines (count = 1: whole image)
+    void SetStrips(int rank, int count, int height);
     void ClearFilm();
     void DownloadFilm(double *dst /* [H][W][4] */);
     void UploadFilm(const double *src);
@@ -28,6 +30,7 @@ class WavefrontRenderer {
     const SceneTables &T;
     wf_ctx *ctx = nullptr;
     int samplesPerPass = 1;
+    int localRows = 0;  // scanlines this renderer owns (set by the ctor = image height, or by SetStrips)
 };
 
 }  // namespace wf

@@ -142,6 +142,10 @@ struct SceneTables {
     int scanlinesPerPass = 0, maxQueueSize = 0, nPasses = 0;
     bool materialTypePresent[WF_MAT_NTYPES] = {};
     void Finalize();  // fills desc pointers/counters from the vectors
+    // on-disk cache of the built tables: one flat file, every array verbatim.  Load() returns false when the
+    // file is missing, truncated or from another ABI / build of the table builder.
+    bool Save(const std::string &path) const;
+    bool Load(const std::string &path);
 };
 
 void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *out);

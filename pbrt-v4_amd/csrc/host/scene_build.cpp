@@ -9,6 +9,7 @@
 //   lights.cpp:120-166,684-941,1345-1380       light parameter handling, scale normalisation, Bounds()
 //   util/mesh.cpp:25-75, shapes.cpp:283-307,368-438  triangle meshes (vertices transformed to render space)
 #include "scene.h"
+#include <unistd.h>
 #include "../common/wf_camera.h"
 #include "../common/wf_shapes.h"
 
@@ -57,6 +58,67 @@ void SceneTables::Finalize() {
     desc.n_table_floats = (int)tableData.size(); desc.table_data = tableData.data();
     desc.n_media = (int)media.size(); desc.media = media.data();
     desc.n_medium_floats = (int)mediumData.size(); desc.medium_data = mediumData.data();
+}
+
+// ---- on-disk cache of the built tables -------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kTablesMagic = 0x3230424154465755ull;  // "UWFTAB02"
+template <typename V> void putVec(FILE *f, const V &v) {
+    uint64_t n = v.size();
+    fwrite(&n, 8, 1, f);
+    if (n) fwrite(v.data(), sizeof(v[0]), n, f);
+}
+template <typename V> bool getVec(FILE *f, V &v) {
+    uint64_t n = 0;
+    if (fread(&n, 8, 1, f) != 1 || n > (1ull << 36)) return false;
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(v[0]), n, f) == n;
+}
+}  // namespace
+bool SceneTables::Save(const std::string &path) const {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    uint64_t hdr[4] = {kTablesMagic, (uint64_t)WF_ABI_VERSION, sizeof(wf_scene_desc), sizeof(SceneTables)};
+    fwrite(hdr, 8, 4, f);
+    fwrite(&desc, sizeof(desc), 1, f);
+    putVec(f, P); putVec(f, N); putVec(f, UV); putVec(f, triIndices); putVec(f, triMesh); putVec(f, bvhPrims); putVec(f, infiniteLights);
+    putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
+    putVec(f, haltonPerms); putVec(f, bvhNodes); putVec(f, pool.spectra); putVec(f, pool.data); putVec(f, textures); putVec(f, materials);
+    putVec(f, lights); putVec(f, lightBvh); putVec(f, lightTransforms); putVec(f, filterData); putVec(f, powerAlias); putVec(f, imageLights);
+    putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile);
+    int32_t sc[8] = {nTopBvhNodes, nTopPrims, saveFP16 ? 1 : 0, spp, scanlinesPerPass, maxQueueSize, nPasses, desc.rgb2spec_coeffs ? 1 : 0};
+    fwrite(sc, 4, 8, f);
+    fwrite(materialTypePresent, sizeof(materialTypePresent), 1, f);
+    uint64_t end = kTablesMagic;
+    fwrite(&end, 8, 1, f);
+    bool ok = fflush(f) == 0;
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { remove(tmp.c_str()); return false; }  // atomic: readers never see a partial file
+    return true;
+}
+bool SceneTables::Load(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t hdr[4];
+    bool ok = fread(hdr, 8, 4, f) == 4 && hdr[0] == kTablesMagic && hdr[1] == (uint64_t)WF_ABI_VERSION && hdr[2] == sizeof(wf_scene_desc) && hdr[3] == sizeof(SceneTables);
+    ok = ok && fread(&desc, sizeof(desc), 1, f) == 1;
+    ok = ok && getVec(f, P) && getVec(f, N) && getVec(f, UV) && getVec(f, triIndices) && getVec(f, triMesh) && getVec(f, bvhPrims) && getVec(f, infiniteLights) &&
+         getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
+         getVec(f, haltonPerms) && getVec(f, bvhNodes) && getVec(f, pool.spectra) && getVec(f, pool.data) && getVec(f, textures) && getVec(f, materials) &&
+         getVec(f, lights) && getVec(f, lightBvh) && getVec(f, lightTransforms) && getVec(f, filterData) && getVec(f, powerAlias) && getVec(f, imageLights) &&
+         getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile);
+    int32_t sc[8];
+    ok = ok && fread(sc, 4, 8, f) == 8 && fread(materialTypePresent, sizeof(materialTypePresent), 1, f) == 1;
+    uint64_t end = 0;
+    ok = ok && fread(&end, 8, 1, f) == 1 && end == kTablesMagic;
+    fclose(f);
+    if (!ok) return false;
+    nTopBvhNodes = sc[0]; nTopPrims = sc[1]; saveFP16 = sc[2] != 0; spp = sc[3]; scanlinesPerPass = sc[4]; maxQueueSize = sc[5]; nPasses = sc[6];
+    Finalize();
+    // the one pointer that does not point into this object: the sRGB RGB -> spectrum coefficient table (process-wide)
+    desc.rgb2spec_coeffs = sc[7] ? SpectralData::Get().sRGB()->table->coeffs.data() : nullptr;
+    return true;
 }
 
 namespace {

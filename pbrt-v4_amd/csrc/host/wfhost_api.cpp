@@ -5,6 +5,7 @@
 #include "../../../include/wf_host.h"
 
 #include <cstring>
+#include <sys/stat.h>
 #include <memory>
 #include <string>
 
@@ -36,8 +37,25 @@ wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed) {
     s->opt.pixelSamples = spp_override;
     s->opt.seed = seed;
     s->opt.quiet = true;
+    // WF_TABLE_CACHE=<dir>: the built tables are kept on disk, keyed by the scene file (path, size, mtime), spp and seed — the
+    // N ranks of a multi-GPU job and repeated runs on one box then build the 10 M-triangle BVHs once (first come builds and
+    // writes, atomically; the others load).  The scene's PLY / image files are assumed to change together with the .pbrt.
+    std::string cacheFile;
+    if (const char *dir = getenv("WF_TABLE_CACHE")) {
+        struct stat st;
+        if (*dir && stat(path, &st) == 0) {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull; };
+            mix(path, strlen(path)); mix(&st.st_size, sizeof(st.st_size)); mix(&st.st_mtime, sizeof(st.st_mtime)); mix(&spp_override, 4); mix(&seed, 4);
+            char name[64];
+            snprintf(name, sizeof(name), "/tables_%016llx.wftab", (unsigned long long)h);
+            cacheFile = std::string(dir) + name;
+            if (s->T.Load(cacheFile)) return s;
+        }
+    }
     ParseFiles({path}, &s->opt, &s->parsed);
     BuildSceneTables(s->parsed, s->opt, &s->T);
+    if (!cacheFile.empty() && !s->T.Save(cacheFile)) fprintf(stderr, "Warning: could not write the scene-table cache %s\n", cacheFile.c_str());
     return s;
 }
 wfh_scene *wfh_scene_load_string(const char *text, int spp_override, int seed) {
@@ -75,6 +93,11 @@ int wfh_scene_info(wfh_scene *s, wfh_info *out) {
 int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass) {
     if (!s) return -1;
     s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass);
+    return 0;
+}
+int wfh_renderer_set_strips(wfh_scene *s, int rank, int count, int height) {
+    if (!s || !s->renderer) return -1;
+    s->renderer->SetStrips(rank, count, height);
     return 0;
 }
 int wfh_renderer_samples_per_pass(wfh_scene *s) { return (s && s->renderer) ? s->renderer->SamplesPerPass() : -1; }

@@ -52,7 +52,7 @@ class ProfileEntry(C.Structure):
 # every symbol include/wf_abi.h and include/wf_host.h declare (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "wf_last_error", "wf_abi_version", "wf_ctx_create", "wf_ctx_destroy", "wf_sync", "wf_stream", "wf_scene_upload",
-    "wf_medium_sample", "wf_intersect_shadow_tr", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
+    "wf_medium_sample", "wf_intersect_shadow_tr", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_set_strips", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
     "wf_gen_camera_rays", "wf_gen_ray_samples", "wf_intersect_closest", "wf_handle_escaped", "wf_handle_emissive",
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
     "wf_film_device_ptr", "wf_film_upload", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "wfh_init", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
-    "wfh_renderer_create", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
+    "wfh_renderer_create", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
     "wfh_film_to_rgb", "wfh_write_image",
 ]
 
@@ -95,6 +95,7 @@ def libs():
     _host.wfh_scene_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     _host.wfh_renderer_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _host.wfh_renderer_samples_per_pass.argtypes = [C.c_void_p]
+    _host.wfh_renderer_set_strips.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     _host.wfh_renderer_ctx.restype = C.c_void_p
     _host.wfh_renderer_ctx.argtypes = [C.c_void_p]
     _host.wfh_render.restype = C.c_double
@@ -168,6 +169,12 @@ class Scene:
         self.samples_per_pass = host.wfh_renderer_samples_per_pass(self.h)
         self.ctx = host.wfh_renderer_ctx(self.h)
         return self
+
+    def set_strips(self, rank, count, height=16):
+        """multi-GPU image partition (wf_set_strips): this renderer owns the scanline strips rank, rank + count, ..."""
+        host, _ = libs()
+        if host.wfh_renderer_set_strips(self.h, rank, count, height) != 0:
+            raise WfError("set_strips failed")
 
     def render(self, sample_begin=0, sample_end=None, sample_step=1, fused=True):
         """Render(): returns wall seconds."""

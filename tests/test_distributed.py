@@ -1,6 +1,9 @@
-"""N > 1 path on CPU: two gloo ranks render disjoint sample-index subsets with the CPU checker, the
-double-precision film accumulators are all-reduced (as bench.py does with RCCL) and must reproduce the
-single-process film.  world_size = 2, 127.0.0.1 rendezvous."""
+"""N > 1 path on CPU (world_size = 2, gloo, 127.0.0.1 rendezvous).  The product's partition / reduce module
+(pbrt-v4_amd/multigpu.py) runs as it does under bench.py --gpus N; the per-rank rendering — which needs a GPU in the product —
+is stood in for by the CPU checker, which takes the same partition parameters as wf_set_strips (`--strips rank count height`).
+Checked: the strips the kernels' BandScanline assigns to a rank are exactly multigpu.strip_rows(), the ranks' strips are
+disjoint and cover the image, and the film reduced to rank 0 is BIT-IDENTICAL to the single-process film (strip partition);
+the sample-index partition agrees to double rounding."""
 import os
 import socket
 import subprocess
@@ -12,22 +15,37 @@ import numpy as np
 from conftest import GOLDEN, ROOT, WF_CPU
 
 WORKER = textwrap.dedent("""
-    import os, subprocess, sys
+    import importlib.util, os, subprocess, sys
     import numpy as np
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo")
-    wf_cpu, scene, outdir = sys.argv[1:4]
-    spp = 4
-    film_path = os.path.join(outdir, "film_%d.bin" % rank)
-    # rank r renders sample indices r, r + world, ... (same partition as bench.py --gpus N)
-    subprocess.run([wf_cpu, "--quiet", "--spp", str(spp), "--nthreads", "2", "--samples", str(rank), str(spp), str(world),
-                    "--dump-film", film_path, "--outfile", os.path.join(outdir, "img_%d.pfm" % rank), scene], check=True, stdout=subprocess.DEVNULL)
-    film = torch.from_numpy(np.fromfile(film_path, dtype=np.float64))
-    dist.all_reduce(film)
+    root, wf_cpu, scene, outdir, partition = sys.argv[1:6]
+    spec = importlib.util.spec_from_file_location("multigpu", os.path.join(root, "pbrt-v4_amd", "multigpu.py"))
+    multigpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(multigpu)
+    spp, H, W = 4, 64, 96
+
+    class CheckerScene:   # the two calls render_partition makes, answered by the CPU checker
+        def set_strips(self, r, n, h):
+            self.strips = (r, n, h)
+        def render(self, begin, end, step):
+            film_path = os.path.join(outdir, "film_%s_%d.bin" % (partition, rank))
+            subprocess.run([wf_cpu, "--quiet", "--spp", str(spp), "--nthreads", "2", "--samples", str(begin), str(end), str(step),
+                            "--strips"] + [str(v) for v in self.strips] +
+                           ["--dump-film", film_path, "--outfile", os.path.join(outdir, "img_%d.pfm" % rank), scene], check=True, stdout=subprocess.DEVNULL)
+            self.film = torch.from_numpy(np.fromfile(film_path, dtype=np.float64).reshape(H, W, 4))
+            return 0.0
+
+    s = CheckerScene()
+    multigpu.render_partition(s, rank, world, 0, spp, partition)
+    if partition == "strips":
+        owned = np.where(s.film[..., 3].numpy().sum(axis=1) > 0)[0]
+        assert (owned == multigpu.strip_rows(rank, world, H)).all(), (rank, owned)
+    film = multigpu.reduce_film(s.film, dist, 0)
     if rank == 0:
-        film.numpy().tofile(os.path.join(outdir, "film_sum.bin"))
+        film.numpy().tofile(os.path.join(outdir, "film_%s_sum.bin" % partition))
     dist.barrier()
     dist.destroy_process_group()
 """)
@@ -41,19 +59,40 @@ def free_port():
     return p
 
 
-def test_sample_partition_film_reduce_gloo(built, tmp_path):
-    scene = os.path.join(GOLDEN, "cornell64.pbrt")
+def _run(tmp_path, partition, scene):
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), str(worker), WF_CPU, scene, str(tmp_path)]
+           "--master-port", str(free_port()), str(worker), ROOT, WF_CPU, scene, str(tmp_path), partition]
     subprocess.run(cmd, check=True, timeout=600, cwd=ROOT)
     single = tmp_path / "film_single.bin"
     subprocess.run([WF_CPU, "--quiet", "--spp", "4", "--dump-film", str(single), "--outfile", str(tmp_path / "s.pfm"), scene], check=True,
                    stdout=subprocess.DEVNULL)
-    a = np.fromfile(tmp_path / "film_sum.bin", dtype=np.float64)
-    b = np.fromfile(single, dtype=np.float64)
-    assert a.shape == b.shape == (64 * 64 * 4,)
+    return np.fromfile(tmp_path / ("film_%s_sum.bin" % partition), dtype=np.float64), np.fromfile(single, dtype=np.float64)
+
+
+def test_strip_rows_partition_the_image():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("multigpu", os.path.join(ROOT, "pbrt-v4_amd", "multigpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for H in (64, 1080, 2160, 45):
+        for world in (1, 2, 3, 8):
+            rows = [m.strip_rows(r, world, H) for r in range(world)]
+            allrows = np.sort(np.concatenate(rows))
+            assert (allrows == np.arange(H)).all()
+            assert max(len(r) for r in rows) - min(len(r) for r in rows) <= m.STRIP_HEIGHT
+
+
+def test_strip_partition_film_reduce_gloo(built, tmp_path):
+    a, b = _run(tmp_path, "strips", os.path.join(GOLDEN, "instances.pbrt"))
+    assert a.shape == b.shape == (64 * 96 * 4,)
+    assert (a.view(np.uint64) == b.view(np.uint64)).all()   # disjoint strips: the reduce is a gather
+    assert (a.reshape(-1, 4)[:, 3] > 0).all()
+
+
+def test_sample_partition_film_reduce_gloo(built, tmp_path):
+    a, b = _run(tmp_path, "samples", os.path.join(GOLDEN, "instances.pbrt"))
     # identical sample sets; only the order of the double-precision additions differs
     assert np.allclose(a, b, rtol=1e-12, atol=0)
     assert (a.reshape(-1, 4)[:, 3] > 0).all()

@@ -326,3 +326,40 @@ def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))
     assert img.shape == ref.shape
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()
+
+
+def test_strip_partition_two_contexts_bit_identical(wfpt, tmp_path, monkeypatch):
+    """The multi-GPU image partition on one device: two contexts own the interleaved 16-line strips 0, 2, ... and 1, 3, ...
+    (wf_set_strips through pbrt-v4_amd/multigpu.py); each renders all sample indices of its lines; the SUM of the two films —
+    what the RCCL reduce to rank 0 computes — is BIT-IDENTICAL to the single-context film, and the lines a context wrote are
+    exactly multigpu.strip_rows().  The second context loads the scene from the table cache the first one wrote."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("multigpu", os.path.join(ROOT, "pbrt-v4_amd", "multigpu.py"))
+    multigpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(multigpu)
+    monkeypatch.setenv("WF_TABLE_CACHE", str(tmp_path))
+    path = os.path.join(GOLDEN, "materials_lights.pbrt")
+    full = wfpt.Scene(path=path, spp=4)
+    full.create_renderer(0)
+    full.render()
+    want = full.film()
+    full.close()
+    total = np.zeros_like(want)
+    for rank in range(2):
+        s = wfpt.Scene(path=path, spp=4)
+        s.create_renderer(0)
+        multigpu.render_partition(s, rank, 2, 0, 4, "strips")
+        f = s.film()
+        owned = np.where(f[..., 3].sum(axis=1) > 0)[0]
+        assert (owned == multigpu.strip_rows(rank, 2, f.shape[0])).all()
+        total += f
+        s.close()
+    assert (total.view(np.uint64) == want.view(np.uint64)).all()
+    # and back to the whole image on the same context
+    s = wfpt.Scene(path=path, spp=4)
+    s.create_renderer(0)
+    s.set_strips(1, 2)
+    s.set_strips(0, 1)
+    s.render()
+    assert (s.film().view(np.uint64) == want.view(np.uint64)).all()
+    s.close()

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN, ROOT
 
@@ -129,3 +130,29 @@ def test_bvh_stats_golden_is_the_live_references(tmp_path):
     for name in ("blobs_small", "instances"):
         live = mk.ref_stats(os.path.join(GOLDEN, name + ".pbrt"), 4)
         assert all(live[k] == golden[name][k] for k in live), (name, live, golden[name])
+
+
+def test_scene_table_cache_round_trip(wfpt, tmp_path, monkeypatch):
+    """WF_TABLE_CACHE: the second load of a scene comes from the on-disk table file and is the same
+    scene — every geometry / BVH array byte for byte, same counts (instances scene: two-level BVH, textures, alpha)."""
+    path = os.path.join(GOLDEN, "instances.pbrt")
+    monkeypatch.setenv("WF_TABLE_CACHE", str(tmp_path))
+    a = wfpt.Scene(path=path, spp=4)
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".wftab")]
+    assert len(files) == 1
+    mtime = os.path.getmtime(os.path.join(tmp_path, files[0]))
+    b = wfpt.Scene(path=path, spp=4)   # served by the cache
+    assert os.path.getmtime(os.path.join(tmp_path, files[0])) == mtime and len(os.listdir(tmp_path)) == 1
+    c = wfpt.Scene(path=path, spp=8)   # another key
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".wftab")]) == 2
+    ha, hb = desc_fields(wfpt, a), desc_fields(wfpt, b)
+    for f in ("abi_version", "n_vertices", "n_triangles", "n_meshes", "n_bvh_nodes"):
+        assert getattr(ha, f) == getattr(hb, f)
+    def arr(h, field, n, ctype):
+        return np.ctypeslib.as_array((ctype * n).from_address(getattr(h, field))).copy()
+    for field, n, ct in (("P", 3 * ha.n_vertices, C.c_float), ("N", 3 * ha.n_vertices, C.c_float), ("UV", 2 * ha.n_vertices, C.c_float),
+                         ("tri_indices", 3 * ha.n_triangles, C.c_int32), ("bvh_nodes", 8 * ha.n_bvh_nodes, C.c_uint32)):
+        assert (arr(ha, field, n, ct).view(np.uint32) == arr(hb, field, n, ct).view(np.uint32)).all(), field
+    for f in ("width", "height", "spp", "max_queue_size", "n_passes", "scanlines_per_pass", "n_triangles", "n_bvh_nodes", "n_lights", "max_depth"):
+        assert getattr(a.info, f) == getattr(b.info, f)
+    a.close(); b.close(); c.close()

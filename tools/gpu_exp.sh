@@ -6,7 +6,7 @@ python tools/make_scenes.py killeroo-like /tmp/k.pbrt --spp 16
 for rep in 1 2; do
 for d in pbrt-v4_amd/_build pbrt-v4_amd/_exp*; do
   echo "== $d"
-  timeout 120 $d/pbrt_amd --stats --outfile /tmp/k.pfm /tmp/k.pbrt 2>&1 | grep -E "Rendering|${GREP:-Intersect}"
+  timeout 100 $d/pbrt_amd --stats --outfile /tmp/k.pfm /tmp/k.pbrt 2>&1 | grep -E "Rendering|${GREP:-Intersect}"
   [ -n "$SM" ] && timeout 300 $d/pbrt_amd --stats --outfile /tmp/sm.pfm /tmp/sm.pbrt 2>&1 | grep -E "Rendering|${GREP:-Intersect}"
 done
 done
