@@ -65,6 +65,17 @@ struct wf_ctx {
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels
+    // ray-coherence pass (SortRayQueue): bit 0 sorts the ray queue before the closest-hit launch of depth >= 1, bit 1 the shadow queue
+    int raySort = 0;
+    int sortMin = 4096;
+    int sortOriginBits = 6, sortDirBits = 4;  // per axis of the origin grid / per axis of the octahedral direction map
+    float sceneMin[3] = {0, 0, 0}, sceneMax[3] = {0, 0, 0};  // bounds of the top-level BVH
+    float sortBase[3] = {0, 0, 0}, sortScale[3] = {0, 0, 0};
+    uint32_t *sortKeys[2] = {nullptr, nullptr}, *sortVals[2] = {nullptr, nullptr};
+    void *sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+    RayQueueV rqTmp{};
+    ShadowQueueV sqTmp{};
     int32_t *probeCursor = nullptr;
     bool matPresent[WF_MAT_NTYPES] = {};
     int W = 0, H = 0;
@@ -370,6 +381,74 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_c
             KRouteHitBlock<(GEN > 1) || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
         });
 }
+// ---- ray-coherence pass -----------------------------------------------------------------------------------------
+// Rays past the first bounce arrive in the order the material kernels pushed them: neighbouring lanes start anywhere in the scene and
+// point anywhere, a wavefront's 64 walks share neither nodes nor length.  Before such a queue is traced it is SORTED by a key made of
+// the cell of the ray's origin (Morton order of a 2^b grid over the scene bounds) and its direction (Morton order of the octahedral
+// map), and the queue is permuted physically — one gather per ray, after which the traversal and every later stage of the depth
+// read coalesced again.  Results do not depend on the order of a queue (each item owns its pixel-sample slot), only the time does.
+extern "C" int wf_sort_pairs_u32(hipStream_t stream, void *temp, size_t *tempBytes, const uint32_t *keysIn, uint32_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                 unsigned n, unsigned endBit);
+__device__ inline uint32_t Part1By2(uint32_t x) {  // 10 bits -> every third bit
+    x &= 0x3ff;
+    x = (x ^ (x << 16)) & 0xff0000ff;
+    x = (x ^ (x << 8)) & 0x0300f00f;
+    x = (x ^ (x << 4)) & 0x030c30c3;
+    x = (x ^ (x << 2)) & 0x09249249;
+    return x;
+}
+__device__ inline uint32_t Part1By1(uint32_t x) {  // 16 bits -> every second bit
+    x &= 0xffff;
+    x = (x ^ (x << 8)) & 0x00ff00ff;
+    x = (x ^ (x << 4)) & 0x0f0f0f0f;
+    x = (x ^ (x << 2)) & 0x33333333;
+    x = (x ^ (x << 1)) & 0x55555555;
+    return x;
+}
+struct SortGrid { float base[3], scale[3]; int obits, dbits; };
+__device__ inline uint32_t RaySortKey(const SortGrid &g, F4 o, F4 d) {
+    const int oMax = (1 << g.obits) - 1;
+    int cx = min(max((int)((o.x - g.base[0]) * g.scale[0]), 0), oMax);
+    int cy = min(max((int)((o.y - g.base[1]) * g.scale[1]), 0), oMax);
+    int cz = min(max((int)((o.z - g.base[2]) * g.scale[2]), 0), oMax);
+    uint32_t key = Part1By2(cx) | (Part1By2(cy) << 1) | (Part1By2(cz) << 2);
+    if (g.dbits > 0) {
+        // octahedral map of the direction to [0, 1)^2
+        float inv = 1.f / (fabsf(d.x) + fabsf(d.y) + fabsf(d.z));
+        float u = d.x * inv, v = d.y * inv;
+        if (d.z < 0) {
+            float tu = (1 - fabsf(v)) * (u >= 0 ? 1.f : -1.f), tv = (1 - fabsf(u)) * (v >= 0 ? 1.f : -1.f);
+            u = tu; v = tv;
+        }
+        const int dMax = (1 << g.dbits) - 1;
+        int du = min(max((int)((u * .5f + .5f) * (dMax + 1)), 0), dMax), dv = min(max((int)((v * .5f + .5f) * (dMax + 1)), 0), dMax);
+        key = (key << (2 * g.dbits)) | Part1By1(du) | (Part1By1(dv) << 1);
+    }
+    return key;
+}
+__global__ void __launch_bounds__(BLOCK) k_ray_sort_keys(const F4 *o, const F4 *d, int n, SortGrid g, uint32_t *keys, uint32_t *vals) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        keys[i] = RaySortKey(g, o[i], d[i]);
+        vals[i] = (uint32_t)i;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_permute_rays(RayQueueV src, RayQueueV dst, const uint32_t *perm, int n) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t j = perm[i];
+        F4 a = src.o[j], b = src.d[j], c = src.beta[j], e = src.r_u[j], f = src.r_l[j], g = src.ctx0[j], h = src.ctx1[j], k = src.ctx2[j];
+        I4 m = src.meta[j];
+        dst.o[i] = a; dst.d[i] = b; dst.beta[i] = c; dst.r_u[i] = e; dst.r_l[i] = f; dst.ctx0[i] = g; dst.ctx1[i] = h; dst.ctx2[i] = k; dst.meta[i] = m;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_permute_shadow(ShadowQueueV src, ShadowQueueV dst, const uint32_t *perm, int n) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t j = perm[i];
+        F4 a = src.o[j], b = src.d[j], c = src.Ld[j], e = src.r_u[j], f = src.r_l[j];
+        dst.o[i] = a; dst.d[i] = b; dst.Ld[i] = c; dst.r_u[i] = e; dst.r_l[i] = f;
+        if (src.medium) dst.medium[i] = src.medium[j];
+    }
+}
+
 // the rays k_closest_fast marked as near-ties, in the reference's own traversal order (rare: coplanar overlapping geometry)
 __global__ void __launch_bounds__(BLOCK) k_closest_retrace(const SceneView sv, WorkState ws, int cur, int *stackSpill) {
     const int n = ws.counters[(CNT_RETRACE) * CNT_STRIDE];
@@ -987,6 +1066,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         }
         std::vector<FastDef> fdefs;
         ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &ctx->fast);
+        if (d->n_bvh_nodes > 0)
+            for (int a = 0; a < 3; ++a) { ctx->sceneMin[a] = d->bvh_nodes[0].bmin[a]; ctx->sceneMax[a] = d->bvh_nodes[0].bmax[a]; }
         if (ctx->fastOk) {
             if ((e = devUpload(ctx, &ctx->fast.nodes, qn.data(), qn.size()))) return e;
             if ((e = devUpload(ctx, &ctx->fast.tris, lt.data(), lt.size()))) return e;
@@ -1076,6 +1157,34 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if ((e = devAlloc(ctx, &ws.sq.o, n)) || (e = devAlloc(ctx, &ws.sq.d, n)) || (e = devAlloc(ctx, &ws.sq.Ld, n)) ||
         (e = devAlloc(ctx, &ws.sq.r_u, n)) || (e = devAlloc(ctx, &ws.sq.r_l, n)))
         return e;
+    ctx->raySort = getenv("WF_RAY_SORT") ? atoi(getenv("WF_RAY_SORT")) : 0;
+    if (!ctx->fastOk) ctx->raySort = 0;
+    if (ctx->raySort) {
+        if (getenv("WF_SORT_MIN")) ctx->sortMin = atoi(getenv("WF_SORT_MIN"));
+        if (getenv("WF_SORT_OBITS")) ctx->sortOriginBits = std::min(std::max(atoi(getenv("WF_SORT_OBITS")), 1), 10);
+        if (getenv("WF_SORT_DBITS")) ctx->sortDirBits = std::min(std::max(atoi(getenv("WF_SORT_DBITS")), 0), (32 - 3 * ctx->sortOriginBits) / 2);
+        for (int k = 0; k < 2; ++k)
+            if ((e = devAlloc(ctx, &ctx->sortKeys[k], n)) || (e = devAlloc(ctx, &ctx->sortVals[k], n))) return e;
+        size_t bytes = 0;
+        if (wf_sort_pairs_u32(ctx->stream, nullptr, &bytes, ctx->sortKeys[0], ctx->sortKeys[1], ctx->sortVals[0], ctx->sortVals[1], (unsigned)n, 32u) != 0)
+            return fail(-1, "ray sort: scratch size query failed");
+        unsigned char *tmp = nullptr;
+        if ((e = devAlloc(ctx, &tmp, bytes))) return e;
+        ctx->sortTemp = tmp; ctx->sortTempBytes = bytes;
+        if ((ctx->raySort & 1) && (e = allocRayQueue(ctx, &ctx->rqTmp, n))) return e;
+        if (ctx->raySort & 2) {
+            if ((e = devAlloc(ctx, &ctx->sqTmp.o, n)) || (e = devAlloc(ctx, &ctx->sqTmp.d, n)) || (e = devAlloc(ctx, &ctx->sqTmp.Ld, n)) ||
+                (e = devAlloc(ctx, &ctx->sqTmp.r_u, n)) || (e = devAlloc(ctx, &ctx->sqTmp.r_l, n)))
+                return e;
+            if (ctx->svHost.haveMedia && (e = devAlloc(ctx, &ctx->sqTmp.medium, n))) return e;
+        }
+        const float cells = (float)(1 << ctx->sortOriginBits);
+        for (int a = 0; a < 3; ++a) {
+            float ext = ctx->sceneMax[a] - ctx->sceneMin[a];
+            ctx->sortBase[a] = ctx->sceneMin[a];
+            ctx->sortScale[a] = ext > 0 ? cells / ext : 0.f;
+        }
+    }
     ctx->maxQueueSize = max_queue_size;
     ctx->queuesAllocated = true;
     return 0;
@@ -1143,6 +1252,34 @@ int wf_gen_ray_samples(wf_ctx *ctx, int depth, int sample_index) {
            tops ? depth : -1);
     return 0;
 }
+// ray-coherence pass: sort + physically permute the ray queue `cur` (shadow = false) or the shadow queue (see k_ray_sort_keys)
+static int SortQueue(wf_ctx *ctx, bool shadow, int cur) {
+    WorkState &ws = ctx->ws;
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, &ws.counters[(shadow ? CNT_SHADOW : CNT_RAY0 + cur) * CNT_STRIDE], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n < ctx->sortMin) return 0;  // (a launch this small is latency, not throughput)
+    SortGrid g;
+    for (int a = 0; a < 3; ++a) { g.base[a] = ctx->sortBase[a]; g.scale[a] = ctx->sortScale[a]; }
+    g.obits = ctx->sortOriginBits; g.dbits = ctx->sortDirBits;
+    const F4 *o = shadow ? ws.sq.o : ws.rq[cur].o, *d = shadow ? ws.sq.d : ws.rq[cur].d;
+    {
+        Prof prof_(ctx, shadow ? "Sort shadow rays" : "Sort rays");
+        hipLaunchKernelGGL(k_ray_sort_keys, dim3(gridFor(n)), dim3(BLOCK), 0, ctx->stream, o, d, n, g, ctx->sortKeys[0], ctx->sortVals[0]);
+        size_t bytes = ctx->sortTempBytes;
+        if (wf_sort_pairs_u32(ctx->stream, ctx->sortTemp, &bytes, ctx->sortKeys[0], ctx->sortKeys[1], ctx->sortVals[0], ctx->sortVals[1], (unsigned)n,
+                              (unsigned)(3 * g.obits + 2 * g.dbits)) != 0)
+            return fail(-1, "ray sort failed");
+        if (shadow) {
+            hipLaunchKernelGGL(k_permute_shadow, dim3(gridFor(n)), dim3(BLOCK), 0, ctx->stream, ws.sq, ctx->sqTmp, ctx->sortVals[1], n);
+            std::swap(ws.sq, ctx->sqTmp);
+        } else {
+            hipLaunchKernelGGL(k_permute_rays, dim3(gridFor(n)), dim3(BLOCK), 0, ctx->stream, ws.rq[cur], ctx->rqTmp, ctx->sortVals[1], n);
+            std::swap(ws.rq[cur], ctx->rqTmp);
+        }
+    }
+    return 0;
+}
 int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     // counting on: the reference-order walk (its visit counts define the algorithmic bytes);
@@ -1150,6 +1287,8 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
     else if (ctx->fastOk) {
+        if ((ctx->raySort & 1) && depth >= 1)
+            if (int e = SortQueue(ctx, false, depth & 1)) return e;
         LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
@@ -1218,6 +1357,8 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (ctx->countTraversal)
         LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     else if (ctx->fastOk) {
+        if ((ctx->raySort & 2) && (depth >= 1 || (ctx->raySort & 4)))
+            if (int e = SortQueue(ctx, true, 0)) return e;
         LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
     } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);

@@ -9,8 +9,9 @@
 // bounded by VALU issue (56-75 % busy at ~30 % active lanes) and by the latency of the dependent node fetches, so
 // the design minimises instructions and fetches per visited node:
 //
-//  * QNode (32 B, two dwordx4): an interior node carries BOTH children's bounds, quantised to 16 bits per plane on
-//    a global grid over the scene bounds, with build-time outward margins.  One fetch feeds two slab tests.
+//  * QNode (64 B, four dwordx4; WF_BVH4): an interior node carries FOUR children's bounds (the reference's binary tree with every
+//    second level collapsed), quantised to 16 bits per plane on the tree's grid, with build-time outward margins.  One fetch
+//    feeds four slab tests and halves the dependent fetches per ray (the two-child 32-byte layout of round 1 remains as WF_BVH4=0).
 //  * the slab test runs in grid coordinates: WalkInit folds the grid (base, cell), the ray (o, 1/d), the
 //    reference's (1 + 2 gamma(3)) factor and an evaluation-error slack into per-ray constants, so a plane costs one
 //    v_cvt (SDWA half-word select) and half a v_pk_fma; near/far planes are swapped per ray with v_perm; min/max
@@ -97,7 +98,7 @@ constexpr int NODE_NONE = (int)0x80000000;
 #ifndef WF_TWAVES_INST
 #define WF_TWAVES_INST 4   // the same for the two-level (object instance) variants, which carry the render-space ray as well
 #endif
-constexpr int TOP_NODES = WF_TOP_NODES;  // QNodes cached in LDS per workgroup (32 B each)
+constexpr int TOP_NODES = WF_TOP_NODES;  // QNodes cached in LDS per workgroup
 constexpr int TBLOCK = WF_TBLOCK;        // threads per workgroup of the traversal kernels
 constexpr int TSTACK = WF_TSTACK;        // LDS stack entries per lane (x 4 B x TBLOCK)
 
