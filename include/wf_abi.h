@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 3
+#define WF_ABI_VERSION 4
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -130,8 +130,9 @@ enum wf_material_type {
     WF_MAT_DIFFUSE_TRANSMISSION = 5, /* materials.h:672-720 */
     WF_MAT_COATED_DIFFUSE = 6,       /* materials.h:551-608 */
     WF_MAT_COATED_CONDUCTOR = 7,     /* materials.h:611-669 */
-    WF_MAT_NTYPES = 8,               /* the types above have an evaluation queue + kernel each */
-    WF_MAT_MIX = 8                   /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
+    WF_MAT_SUBSURFACE = 8,           /* materials.h:696-790: dielectric boundary + TabulatedBSSRDF (K12, wf_sample_subsurface) */
+    WF_MAT_NTYPES = 9,               /* the types above have an evaluation queue + kernel each */
+    WF_MAT_MIX = 9                   /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
 };
 /* tex[] slots */
 #define WF_MT_REFLECTANCE 0   /* diffuse / conductor(reflectance) / difftrans / coated diffuse */
@@ -144,6 +145,9 @@ enum wf_material_type {
 #define WF_MT_G 6             /* coated */
 #define WF_MT_ALBEDO 7        /* coated */
 #define WF_MT_AMOUNT 0        /* mix */
+#define WF_MT_MFP 1           /* subsurface: mean free path (with WF_MT_REFLECTANCE), when sigma_a / sigma_s are not given */
+#define WF_MT_SIGMA_A 5       /* subsurface (WF_MATFLAG_SSS_COEFFICIENTS) */
+#define WF_MT_SIGMA_S 6
 #define WF_MT_NTEX 12
 /* coated conductor: interface roughness in UROUGH/VROUGH, conductor in slots 8..11 */
 #define WF_MT_COND_UROUGH 8
@@ -160,9 +164,13 @@ typedef struct wf_material {
     int32_t displacement;        /* float texture id or -1 */
     int32_t normalmap;           /* image id or -1 */
     int32_t mix[2];              /* WF_MAT_MIX: the two material ids; the "amount" float texture is tex[WF_MT_AMOUNT] */
+    float sss_eta;               /* WF_MAT_SUBSURFACE: the scalar eta of SubsurfaceMaterial (materials.h:786) */
+    int32_t sss_table;           /* offset into table_data of the material's BSSRDFTable (100 albedo x 64 radius samples, bssrdf.h:73-96):
+                                    rhoSamples[100] radiusSamples[64] profile[6400] rhoEff[100] profileCDF[6400]; "scale" is `scale` above */
 } wf_material;
 #define WF_MATFLAG_REMAP_ROUGHNESS 1
 #define WF_MATFLAG_CONDUCTOR_REFLECTANCE 2
+#define WF_MATFLAG_SSS_COEFFICIENTS 4   /* subsurface: sigma_a / sigma_s textures given (else reflectance + mfp) */
 
 /* Lights (lights.h). */
 enum wf_light_type {
@@ -531,6 +539,16 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth);
 /* K11: WavefrontAggregate::IntersectShadowTr (integrator.h:48-49; TraceTransmittance, intersect.h:165-274): the
    shadow-ray stage of scenes with media (ratio tracking through interface surfaces) */
 int wf_intersect_shadow_tr(wf_ctx *ctx, int depth);
+/* K12: SampleSubsurface (wavefront/subsurface.cpp:18-203), in its three launches; no-ops without a subsurface material.
+   wf_subsurface_probe      "Get BSSRDF and enqueue probe ray": SubsurfaceMaterial::GetBSSRDF + TabulatedBSSRDF::SampleSp
+   wf_intersect_one_random  WavefrontAggregate::IntersectOneRandom (integrator.h:51-52; wavefront/aggregate.cpp:90-115): every
+                            intersection of the probe segment with a surface of the SAME material, one of them kept by weighted
+                            reservoir sampling seeded with Hash(p0, p1)
+   wf_subsurface_scatter    "Handle out-scattering after SSS": ProbeIntersectionToSample, then the indirect ray and the light
+                            sample at the exit point; the caller traces the shadow rays (wf_intersect_shadow / _tr) afterwards */
+int wf_subsurface_probe(wf_ctx *ctx, int depth);
+int wf_intersect_one_random(wf_ctx *ctx);
+int wf_subsurface_scatter(wf_ctx *ctx, int depth);
 /* K13: UpdateFilm (wavefront/film.cpp:14-38) */
 int wf_update_film(wf_ctx *ctx);
 

@@ -89,8 +89,10 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.instances = d.instances; sv.instanceDefs = d.instance_defs; sv.nInstances = d.n_instances;
     sv.haltonPrimes = d.halton_primes; sv.haltonPermOffsets = d.halton_perm_offsets; sv.haltonPerms = d.halton_perms;
     sv.haveMix = 0;
+    sv.haveSubsurface = 0;
     for (int i = 0; i < d.n_materials; ++i) {
         if (d.materials[i].type == WF_MAT_MIX) sv.haveMix = 1;
+        if (d.materials[i].type == WF_MAT_SUBSURFACE) sv.haveSubsurface = 1;
         else sv.matTypeMask |= 1 << d.materials[i].type;
     }
     return sv;
@@ -366,6 +368,7 @@ int main(int argc, char **argv) {
     ws.hit = Alloc<F4>(n);
     if (sv.nInstances > 0) ws.hitInst = Alloc<int32_t>(n);
     if (sv.haveMix) ws.mixMat = Alloc<int32_t>(n);
+    if (sv.haveSubsurface) { ws.samples2 = Alloc<F4>(n); ws.bssrdfQ = Alloc<BssrdfItem>(n); ws.sssQ = Alloc<SubsurfaceItem>(n); }
     ws.escapedQ = Alloc<int32_t>(n); ws.hitLightQ = Alloc<int32_t>(n);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.matQ[m] = Alloc<int32_t>(T.materialTypePresent[m] ? n : 1);
     ws.sq.o = Alloc<F4>(n); ws.sq.d = Alloc<F4>(n); ws.sq.Ld = Alloc<F4>(n); ws.sq.r_u = Alloc<F4>(n); ws.sq.r_l = Alloc<F4>(n);
@@ -378,7 +381,7 @@ int main(int argc, char **argv) {
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
     ws.film = Alloc<double>((size_t)W * H * 4);
     ws.stats = Alloc<unsigned long long>(129);
-    unsigned long long nodesVisited = 0, trisTested = 0;
+    unsigned long long nodesVisited = 0, trisTested = 0, sssProbes = 0, sssExits = 0;
     std::atomic<unsigned long long> shadowNodes{0}, shadowTris{0};
 
     auto t0 = std::chrono::steady_clock::now();
@@ -410,6 +413,7 @@ int main(int argc, char **argv) {
                 ws.counters[(CNT_ESCAPED) * CNT_STRIDE] = ws.counters[(CNT_HITLIGHT) * CNT_STRIDE] = 0;
                 for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.counters[(CNT_MAT0 + m) * CNT_STRIDE] = 0;
                 ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE] = ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE] = 0;
+                ws.counters[(CNT_BSSRDF) * CNT_STRIDE] = ws.counters[(CNT_SSS) * CNT_STRIDE] = 0;
                 const int nRays = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
                 ws.stats[1 + depth] += nRays;
                 ParallelFor(nRays, [&](int i) { KGenerateRaySamples(sv, ws, cur, i, sampleIndex, sampleStep); });
@@ -608,28 +612,41 @@ int main(int argc, char **argv) {
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_DIFFUSE>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_CONDUCTOR>(sv, ws, cur, i, true); });
-                const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
-                if (sv.haveMedia)
-                    ParallelFor(nShadow, [&](int i) {
-                        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
-                            ArrayStack st;
-                            ClosestHit ch;
-                            bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
-                            if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
-                            return found;
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_SUBSURFACE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_SUBSURFACE>(sv, ws, cur, i, true); });
+                auto traceShadowRays = [&]() {  // TraceShadowRays, integrator.cpp:575-586
+                    const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+                    if (sv.haveMedia)
+                        ParallelFor(nShadow, [&](int i) {
+                            KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
+                                ArrayStack st;
+                                ClosestHit ch;
+                                bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+                                if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+                                return found;
+                            });
                         });
+                    else
+                    ParallelFor(nShadow, [&](int i) {
+                        F4 o = ws.sq.o[i], d = ws.sq.d[i];
+                        ArrayStack st;
+                        int v = 0, t = 0;
+                        bool occluded = BVHIntersectAny(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t);
+                        shadowNodes += (unsigned long long)v; shadowTris += (unsigned long long)t;
+                        KRecordShadowRay(ws, i, occluded);
                     });
-                else
-                ParallelFor(nShadow, [&](int i) {
-                    F4 o = ws.sq.o[i], d = ws.sq.d[i];
-                    ArrayStack st;
-                    int v = 0, t = 0;
-                    bool occluded = BVHIntersectAny(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t);
-                    shadowNodes += (unsigned long long)v; shadowTris += (unsigned long long)t;
-                    KRecordShadowRay(ws, i, occluded);
-                });
-                ws.stats[65 + depth] += nShadow;
-                ws.counters[(CNT_SHADOW) * CNT_STRIDE] = 0;
+                    ws.stats[65 + depth] += nShadow;
+                    ws.counters[(CNT_SHADOW) * CNT_STRIDE] = 0;
+                };
+                traceShadowRays();
+                if (sv.haveSubsurface) {
+                    // SampleSubsurface, integrator.cpp:431 -> wavefront/subsurface.cpp:18-203
+                    ParallelFor(ws.counters[(CNT_BSSRDF) * CNT_STRIDE], [&](int i) { KSubsurfaceProbe(sv, ws, i); });
+                    ParallelFor(ws.counters[(CNT_SSS) * CNT_STRIDE], [&](int i) { ArrayStack st; KIntersectOneRandom(sv, ws, i, st); });
+                    ParallelFor(ws.counters[(CNT_SSS) * CNT_STRIDE], [&](int i) { KSubsurfaceScatter(sv, ws, cur, i); });
+                    sssProbes += ws.counters[(CNT_SSS) * CNT_STRIDE];
+                    for (int i = 0; i < ws.counters[(CNT_SSS) * CNT_STRIDE]; ++i) sssExits += ws.sssQ[i].reservoirPDF != 0;
+                    traceShadowRays();
+                }
             }
             ParallelFor(n, [&](int i) { KUpdateFilm(sv, ws, i, 1); });
         }
@@ -650,7 +667,8 @@ int main(int argc, char **argv) {
         for (int k = 0; k < T.desc.n_bvh_nodes; ++k) {
             if (T.desc.bvh_nodes[k].nprims > 0) { ++leaf; leafPrims += T.desc.bvh_nodes[k].nprims; } else ++interior;
         }
-        printf("], \"bvh_interior_nodes\": %llu, \"bvh_leaf_nodes\": %llu, \"bvh_leaf_prims\": %llu, \"bvh_nodes_visited\": %llu, \"tri_tests\": %llu, \"closest_nodes_visited\": %llu, \"closest_tri_tests\": %llu",
+        printf("], \"subsurface_probes\": %llu, \"subsurface_exits\": %llu", sssProbes, sssExits);
+        printf(", \"bvh_interior_nodes\": %llu, \"bvh_leaf_nodes\": %llu, \"bvh_leaf_prims\": %llu, \"bvh_nodes_visited\": %llu, \"tri_tests\": %llu, \"closest_nodes_visited\": %llu, \"closest_tri_tests\": %llu",
                interior, leaf, leafPrims, nodesVisited + shadowNodes.load(), trisTested + shadowTris.load() + g_pdfTriTests.load(), nodesVisited, trisTested);
         printf(", \"shadow_rays\": [");
     }

@@ -21,6 +21,7 @@
 #include "wf_camera.h"
 #include "wf_lights.h"
 #include "wf_media.h"
+#include "wf_bssrdf.h"
 
 namespace wf {
 
@@ -32,7 +33,7 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE,
+    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS,
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -55,6 +56,29 @@ struct ShadowQueueV {
     F4 *Ld, *r_u, *r_l;
     int32_t *medium;  // ray.medium (allocated when the scene has media)
 };
+// K12 work items (workitems.h:175-216), array of structures: subsurface scattering is a side path
+struct BssrdfItem {
+    F4 beta, r_u;
+    V3 p; float etaScale;
+    V3 wo; int depth;
+    N3 n; int pixelIndex;
+    N3 ns; int material;
+    V3 dpdus; int mediumInside;
+    V2 uv; int mediumOutside; int pad;
+};
+struct SubsurfaceItem {
+    V3 p0, p1;
+    int depth, material;
+    TabulatedBSSRDF bssrdf;
+    F4 beta, r_u;
+    float reservoirPDF;
+    P3i pi;             // ssi (bssrdf.h:32-66)
+    N3 n, ns;
+    V3 dpdu, dpdv, dpdus, dpdvs;
+    int mediumInside, mediumOutside;
+    float etaScale;
+    int pixelIndex;
+};
 struct WorkState {
     int maxQueueSize;      // queue capacity = pixelsPerPass * samplesPerPass
     // MI355X-first wavefront sizing: a pass carries `samplesPerPass` sample indices of every pixel of the
@@ -71,6 +95,7 @@ struct WorkState {
     F4 *lambda, *lambdaPdf, *L, *cameraRayWeight;
     F4 *samples0;  // direct.uc, direct.u.x, direct.u.y, indirect.uc
     F4 *samples1;  // indirect.u.x, indirect.u.y, indirect.rr, -
+    F4 *samples2;  // subsurface.uc, subsurface.u.x, subsurface.u.y, - (allocated when the scene has a subsurface material)
     // ZSobol TopDigits() of every pixel of the band for the five dimensions one stage draws (dim0 + {0,1,3,4,6}),
     // [5][pixelsPerPass]; refreshed by KSampleTops before the stage.  Null: not used (CPU checker, > 32-bit indices).
     uint32_t *sampleTops;
@@ -87,6 +112,8 @@ struct WorkState {
     int32_t *mixQ;    // HIP traversal kernel only: hits on a MixMaterial, resolved by the kernel that follows it
     int32_t *retraceQ;  // HIP traversal kernel only: rays whose closest hit was a near-tie (wf_traverse.h), re-traced in reference order
     int32_t *matQ[WF_MAT_NTYPES];
+    struct BssrdfItem *bssrdfQ;       // GetBSSRDFAndProbeRayQueue / SubsurfaceScatterQueue (K12; allocated when sv.haveSubsurface)
+    struct SubsurfaceItem *sssQ;
     ShadowQueueV sq;
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
     double *film;                   // [pixels][4]: rgbSum[3], weightSum (film.h:302-307)
@@ -283,6 +310,7 @@ WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur
     const int slot = pixelIndex / ws.pixelsPerPass;
     const int sampleIndex = sampleBase + slot * sampleStep;
     int dimension = 6 + 7 * depth;
+    if (sv.haveSubsurface) dimension += 3 * depth;  // samples.cpp:40-41
     PixelSampler sampler(sv);
     I2 pp = ws.pPixel[pixelIndex];
     sampler.StartPixelSample(pp.x, pp.y, sampleIndex, dimension);
@@ -301,6 +329,11 @@ WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur
     float rr = sampler.Get1D();
     ws.samples0[pixelIndex] = F4{duc, du.x, du.y, iuc};
     ws.samples1[pixelIndex] = F4{iu.x, iu.y, rr, 0.f};
+    if (sv.haveSubsurface) {  // samples.cpp:57-61 (never with sample tops: the host turns them off)
+        float suc = sampler.Get1D();
+        V2 su = sampler.Get2D();
+        ws.samples2[pixelIndex] = F4{suc, su.x, su.y, 0.f};
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -449,7 +482,7 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             else if (route & 15u) dest |= 4u << (route & 15u);
         }
     }
-    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? (4u | (1u << MS)) : 0u) | (((unsigned)sv.matTypeMask & 0xfeu) << 2) |
+    const unsigned active = (sv.nInfiniteLights > 0 ? 1u : 0u) | 2u | (sv.haveMedia ? (4u | (1u << MS)) : 0u) | (((unsigned)sv.matTypeMask & ((1u << WF_MAT_NTYPES) - 2u)) << 2) |
                             (sv.haveMix ? 1u << MIXQ : 0u);
     const unsigned lane = __lane_id();
     const int wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
@@ -811,6 +844,10 @@ template <> struct MatBxDF<WF_MAT_DIFFUSE_TRANSMISSION> {
     WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetDiffuseTransmissionBxDF(sv, m, l, tc); }
 };
 
+template <> struct MatBxDF<WF_MAT_SUBSURFACE> {
+    using T = DielectricBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetSubsurfaceBxDF(sv, m, l, tc); }
+};
 template <> struct MatBxDF<WF_MAT_COATED_DIFFUSE> {
     using T = CoatedDiffuseBxDF;
     WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetCoatedDiffuseBxDF(sv, m, l, tc); }
@@ -950,6 +987,17 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                 if (s1.z < qq) beta = S4c(0.f);
                 else beta = beta / (1 - qq);
             }
+            if (MAT == WF_MAT_SUBSURFACE && beta && bs.IsTransmission()) {
+                // the path enters the medium: K12 takes over (surfscatter.cpp:226-231)
+                BssrdfItem b;
+                b.beta = toF4(beta); b.r_u = toF4(r_u);
+                b.p = tc.p; b.etaScale = etaScale; b.wo = wo; b.depth = depth; b.n = si.n; b.pixelIndex = pixelIndex; b.ns = ns; b.material = matId;
+                b.dpdus = dpdus; b.uv = tc.uv;
+                const bool transition = mesh.medium_inside != mesh.medium_outside;
+                b.mediumInside = transition ? mesh.medium_inside : meta.w;
+                b.mediumOutside = transition ? mesh.medium_outside : meta.w;
+                ws.bssrdfQ[QueueAlloc(&ws.counters[(CNT_BSSRDF) * CNT_STRIDE])] = b;
+            } else
             if (beta) {
                 pushRay = true;
                 ro = OffsetRayOrigin(si.pi, si.n, wi);
@@ -1017,6 +1065,133 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         ws.sq.r_u[slot] = toF4(sr_u);
         ws.sq.r_l[slot] = toF4(sr_l);
         if (sv.haveMedia) ws.sq.medium[slot] = smedium;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K12: WavefrontPathIntegrator::SampleSubsurface (wavefront/subsurface.cpp:18-203)
+// "Get BSSRDF and enqueue probe ray" (:25-45)
+WF_HD void KSubsurfaceProbe(const SceneView &sv, const WorkState &ws, int i) {
+    const BssrdfItem w = ws.bssrdfQ[i];
+    const wf_material &mat = sv.materials[w.material];
+    TexCtx tc{};  // GetBSSRDFAndProbeRayWorkItem::GetMaterialEvalContext (workitems.h:176-186): p, n, ns, dpdus, wo, uv only
+    tc.p = w.p; tc.n = w.n; tc.uv = w.uv;
+    Wavelengths lambda = LoadLambda(ws, w.pixelIndex);
+    TabulatedBSSRDF bssrdf = GetBSSRDF(sv, mat, lambda, tc, w.ns, w.wo);
+    F4 s2 = ws.samples2[w.pixelIndex];
+    V3 p0, p1;
+    if (!bssrdf.SampleSp(s2.x, V2{s2.y, s2.z}, &p0, &p1)) return;
+    SubsurfaceItem o{};
+    o.p0 = p0; o.p1 = p1; o.depth = w.depth; o.material = w.material; o.bssrdf = bssrdf; o.beta = w.beta; o.r_u = w.r_u;
+    o.mediumInside = w.mediumInside; o.mediumOutside = w.mediumOutside; o.etaScale = w.etaScale; o.pixelIndex = w.pixelIndex;
+    ws.sssQ[QueueAlloc(&ws.counters[(CNT_SSS) * CNT_STRIDE])] = o;
+}
+// WavefrontAggregate::IntersectOneRandom (CPUAggregate: wavefront/aggregate.cpp:90-115; OptiX: gpu/optix/optix.cu:474-573)
+template <typename Stack>
+WF_HD void KIntersectOneRandom(const SceneView &sv, const WorkState &ws, int i, Stack &st) {
+    SubsurfaceItem &w = ws.sssQ[i];
+    RNG rng;
+    rng.SetSequence(Hash6f(w.p0, w.p1));   // WeightedReservoirSampler(seed) -> RNG(seed)
+    float weightSum = 0, reservoirWeight = 0;
+    P3i basePi = MakeP3i(w.p0);
+    N3 baseN{0, 0, 0};
+    while (true) {
+        RayOD r = SpawnRayTo(basePi, baseN, w.p1);
+        if (r.d.x == 0 && r.d.y == 0 && r.d.z == 0) break;
+        ClosestHit ch;
+        st.n = 0;
+        if (!BVHIntersectClosest(sv, r.o, r.d, 1.f, st, &ch)) break;
+        SurfIntr si;
+        HitInteraction(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si);
+        basePi = si.pi; baseN = si.n;
+        if (sv.meshes[si.mesh].material == w.material) {
+            // wrs.Add(SubsurfaceInteraction(si->intr), 1.f)  (util/sampling.h:535-546)
+            weightSum += 1.f;
+            float p = 1.f / weightSum;
+            if (rng.UniformFloat() < p) {
+                w.pi = si.pi; w.n = si.n; w.ns = si.ns; w.dpdu = si.dpdu; w.dpdv = si.dpdv; w.dpdus = si.dpdus; w.dpdvs = si.dpdvs;
+                reservoirWeight = 1.f;
+            }
+        }
+    }
+    w.reservoirPDF = weightSum > 0 ? reservoirWeight / weightSum : 0.f;
+}
+// "Handle out-scattering after SSS" (:49-199)
+WF_HD void KSubsurfaceScatter(const SceneView &sv, const WorkState &ws, int cur, int i) {
+    const SubsurfaceItem &w = ws.sssQ[i];
+    if (w.reservoirPDF == 0) return;
+    const RayQueueV &nq = ws.rq[cur ^ 1];
+    // TabulatedBSSRDF::ProbeIntersectionToSample (bssrdf.h:258-264)
+    NormalizedFresnelBxDF bxdf{w.bssrdf.eta};
+    V3 wo = toV(w.ns);
+    BSDF<NormalizedFresnelBxDF> bsdf(w.ns, w.dpdus, bxdf);
+    S4 Sp = w.bssrdf.Sp(w.pi.mid()), pdf = w.bssrdf.PDF_Sp(w.pi.mid(), w.n);
+    if (!Sp || !pdf) return;
+    float pr = w.reservoirPDF * pdf[0];
+    S4 betap = toS4(w.beta) * Sp / pr;
+    S4 r_u = toS4(w.r_u) * pdf / pdf[0];
+    Wavelengths lambda = LoadLambda(ws, w.pixelIndex);
+    F4 s0 = ws.samples0[w.pixelIndex], s1 = ws.samples1[w.pixelIndex];
+    const float time = 0;  // "TODO: pipe through" (subsurface.cpp:74)
+    // Indirect
+    {
+        BSDFSample bs = bsdf.Sample_f(wo, s0.w, V2{s1.x, s1.y});
+        if (bs.valid) {
+            V3 wi = bs.wi;
+            S4 beta = betap * bs.f * AbsDot(wi, w.ns) / bs.pdf;
+            S4 indir_r_u = r_u, r_l;
+            if (bs.pdfIsProportional) r_l = r_u / bsdf.PDF(wo, bs.wi);
+            else r_l = r_u / bs.pdf;
+            float etaScale = w.etaScale;
+            if (bs.IsTransmission()) etaScale *= Sqr(bs.eta);
+            S4 rrBeta = beta * etaScale / indir_r_u.Average();
+            if (rrBeta.MaxComponentValue() < 1 && w.depth > 1) {
+                float q = fmax(0.f, 1 - rrBeta.MaxComponentValue());
+                if (s1.z < q) beta = S4c(0.f);
+                else beta = beta / (1 - q);
+            }
+            if (beta) {
+                V3 ro = OffsetRayOrigin(w.pi, w.n, wi);
+                int medium = -1;
+                if (sv.haveMedia) medium = Dot(wi, w.n) > 0 ? w.mediumOutside : w.mediumInside;
+                int slot = QueueAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
+                nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
+                nq.d[slot] = F4{wi.x, wi.y, wi.z, etaScale};
+                nq.beta[slot] = toF4(beta);
+                nq.r_u[slot] = toF4(indir_r_u);
+                nq.r_l[slot] = toF4(r_l);
+                StoreCtx(nq, slot, LightCtx{w.pi, w.n, w.ns});
+                // anyNonSpecularBounces = true (subsurface.cpp:127)
+                nq.meta[slot] = I4{w.pixelIndex, w.depth + 1, (bs.IsSpecularS() ? RAYFLAG_SPECULAR_BOUNCE : 0) | RAYFLAG_ANY_NONSPECULAR, medium};
+            }
+        }
+    }
+    // Direct lighting
+    if (IsNonSpecular(bsdf.Flags())) {
+        LightCtx ctx{w.pi, w.n, w.ns};
+        float lightPMF = 0;
+        int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
+        if (lightId < 0) return;
+        const wf_light &light = sv.lights[lightId];
+        LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+        if (!ls.valid || !ls.L || ls.pdf == 0) return;
+        V3 wi = ls.wi;
+        S4 f = bsdf.f(wo, wi);
+        if (!f) return;
+        S4 beta = betap * f * AbsDot(wi, w.ns);
+        float lightPDF = ls.pdf * lightPMF;
+        float bsdfPDF = IsDeltaLight(light.type) ? 0.f : bsdf.PDF(wo, wi);
+        S4 r_l = r_u * lightPDF;
+        r_u = r_u * bsdfPDF;
+        S4 Ld = beta * ls.L;
+        RayOD sr = SpawnRayTo(w.pi, w.n, ls.pLightPi, ls.pLightN);
+        int slot = QueueAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE]);
+        ws.sq.o[slot] = F4{sr.o.x, sr.o.y, sr.o.z, 1 - ShadowEpsilon};
+        ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)w.pixelIndex)};
+        ws.sq.Ld[slot] = toF4(Ld);
+        ws.sq.r_u[slot] = toF4(r_u);
+        ws.sq.r_l[slot] = toF4(r_l);
+        if (sv.haveMedia) ws.sq.medium[slot] = Dot(sr.d, w.n) > 0 ? w.mediumOutside : w.mediumInside;
     }
 }
 

@@ -61,6 +61,7 @@ struct SceneView {
     const wf_instance *instances;
     const wf_instance_def *instanceDefs;
     int nInstances;
+    int haveSubsurface;     // some material is a SubsurfaceMaterial: K12 runs, and every depth draws 3 more sample dimensions
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
     int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
     wf_options options;

@@ -467,6 +467,21 @@ __global__ void __launch_bounds__(BLOCK) k_closest_retrace(const SceneView sv, W
         KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.inst, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
     }
 }
+// K12 (wavefront/subsurface.cpp): probe segment, one random intersection of it with the same material, out-scattering
+__global__ void __launch_bounds__(BLOCK) k_subsurface_probe(const SceneView sv, WorkState ws) {
+    const int n = ws.counters[(CNT_BSSRDF) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceProbe(sv, ws, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_intersect_one_random(const SceneView sv, WorkState ws, int *stackSpill) {
+    const int n = ws.counters[(CNT_SSS) * CNT_STRIDE];
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride) KIntersectOneRandom(sv, ws, i, st);
+}
+__global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_SSS) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
+}
 template <int GEN, bool INST = false>
 __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
@@ -594,7 +609,7 @@ __global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, W
 extern "C" {
 #define WF_DECL_MAT(n) void wf_launch_eval_material_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
                        void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int);
-WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7)
+WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8)
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
     for (int p = blockIdx.x * BLOCK + threadIdx.x; p < ws.pixelsPerPass; p += gridDim.x * BLOCK) KUpdateFilm(sv, ws, p, nSamples);
@@ -1033,6 +1048,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ctx->matPresent[m] = false;
     sv.matTypeMask = 0;
     sv.haveMix = 0;
+    sv.haveSubsurface = 0;
     for (int i = 0; i < d->n_materials; ++i) {
         int t = d->materials[i].type;
         if (t == WF_MAT_MIX) {
@@ -1045,6 +1061,11 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         if (t < 0 || t >= WF_MAT_NTYPES) return fail(-1, "material %d has unknown type %d", i, t);
         ctx->matPresent[t] = true;
         sv.matTypeMask |= 1 << t;
+        if (t == WF_MAT_SUBSURFACE) {
+            sv.haveSubsurface = 1;
+            if (d->materials[i].sss_table < 0 || (size_t)d->materials[i].sss_table + BSSRDF_TABLE_FLOATS > (size_t)d->n_table_floats)
+                return fail(-1, "subsurface material %d: BSSRDF table outside table_data", i);
+        }
     }
     ctx->W = d->film.pixel_max[0] - d->film.pixel_min[0];
     ctx->H = d->film.pixel_max[1] - d->film.pixel_min[1];
@@ -1141,7 +1162,8 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
         return e;
     // pixel-only sample-index digits (wf_camera.h TopDigits): usable while the permuted index fits 32 bits
     ws.sampleTops = nullptr;
-    if (ctx->svHost.sampler.type == WF_SAMPLER_ZSOBOL && 2 * ctx->svHost.sampler.nBase4Digits <= 32 && !getenv("WF_NO_SAMPLE_TOPS"))
+    if (ctx->svHost.sampler.type == WF_SAMPLER_ZSOBOL && 2 * ctx->svHost.sampler.nBase4Digits <= 32 && !getenv("WF_NO_SAMPLE_TOPS") &&
+        !ctx->svHost.haveSubsurface)  // (K12 scenes draw 10 dimensions per depth, not 7)
         if ((e = devAlloc(ctx, &ws.sampleTops, (size_t)5 * pixels_per_pass))) return e;
     if ((e = allocRayQueue(ctx, &ws.rq[0], n)) || (e = allocRayQueue(ctx, &ws.rq[1], n))) return e;
     if (ctx->svHost.haveMedia) {
@@ -1150,6 +1172,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
             return e;
     }
     if (ctx->svHost.haveMix && ((e = devAlloc(ctx, &ws.mixMat, n)) || (e = devAlloc(ctx, &ws.mixQ, n)))) return e;
+    if (ctx->svHost.haveSubsurface && ((e = devAlloc(ctx, &ws.samples2, n)) || (e = devAlloc(ctx, &ws.bssrdfQ, n)) || (e = devAlloc(ctx, &ws.sssQ, n)))) return e;
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n)) || (e = devAlloc(ctx, &ws.retraceQ, n))) return e;
     if (ctx->svHost.nInstances > 0 && (e = devAlloc(ctx, &ws.hitInst, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
@@ -1229,7 +1252,7 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     const int cur = depth & 1;
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
-    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE);
+    mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE) | (1u << CNT_BSSRDF) | (1u << CNT_SSS);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + statDepth(depth), CNT_RAY0 + cur);
     return 0;
@@ -1334,7 +1357,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     static const char *names[WF_MAT_NTYPES] = {"", "DiffuseMaterial + BxDF eval (Basic tex)", "ConductorMaterial + BxDF eval (Basic tex)",
                                                "DielectricMaterial + BxDF eval (Basic tex)", "ThinDielectricMaterial + BxDF eval (Basic tex)",
                                                "DiffuseTransmissionMaterial + BxDF eval (Basic tex)", "CoatedDiffuseMaterial + BxDF eval (Basic tex)",
-                                               "CoatedConductorMaterial + BxDF eval (Basic tex)"};
+                                               "CoatedConductorMaterial + BxDF eval (Basic tex)", "SubsurfaceMaterial + BxDF eval (Basic tex)"};
     if (material_type == WF_MAT_INTERFACE) return 0;
     if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
     {
@@ -1348,6 +1371,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
         case 5: (tex ? wf_launch_eval_material_5_1 : wf_launch_eval_material_5_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 6: (tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 7: (tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 8: (tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         }
     }
     return 0;
@@ -1364,6 +1388,27 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
+    return 0;
+}
+// K12: SampleSubsurface (wavefront/subsurface.cpp:18-203) in its three launches
+int wf_subsurface_probe(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (!ctx->svHost.haveSubsurface) return 0;
+    (void)depth;
+    LAUNCH("Get BSSRDF and enqueue probe ray", k_subsurface_probe, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws);
+    return 0;
+}
+int wf_intersect_one_random(wf_ctx *ctx) {
+    if (int e = checkReady(ctx)) return e;
+    if (!ctx->svHost.haveSubsurface) return 0;
+    // reference-order walk (the chain of probe hits is a dependent sequence per item; the subsurface path is a side path)
+    LAUNCH("Intersect one random (subsurface probe)", k_intersect_one_random, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    return 0;
+}
+int wf_subsurface_scatter(wf_ctx *ctx, int depth) {
+    if (int e = checkReady(ctx)) return e;
+    if (!ctx->svHost.haveSubsurface) return 0;
+    LAUNCH("Handle out-scattering after SSS", k_subsurface_scatter, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
 }
 int wf_update_film(wf_ctx *ctx) {
@@ -1390,6 +1435,10 @@ int wf_render_pass(wf_ctx *ctx, int y0, int sample_index) {
             if (ctx->matPresent[m] && m != WF_MAT_INTERFACE)
                 if ((e = wf_eval_material(ctx, m, depth))) return e;
         if ((e = ctx->svHost.haveMedia ? wf_intersect_shadow_tr(ctx, depth) : wf_intersect_shadow(ctx, depth))) return e;
+        if (ctx->svHost.haveSubsurface) {  // SampleSubsurface (integrator.cpp:431) ends with its own TraceShadowRays
+            if ((e = wf_subsurface_probe(ctx, depth)) || (e = wf_intersect_one_random(ctx)) || (e = wf_subsurface_scatter(ctx, depth))) return e;
+            if ((e = ctx->svHost.haveMedia ? wf_intersect_shadow_tr(ctx, depth) : wf_intersect_shadow(ctx, depth))) return e;
+        }
     }
     return wf_update_film(ctx);
 }

@@ -88,6 +88,14 @@ double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep,
                 // TraceShadowRays, integrator.cpp:575-586
                 if (T.desc.have_media) Check(wf_intersect_shadow_tr(ctx, wavefrontDepth), "wf_intersect_shadow_tr");
                 else Check(wf_intersect_shadow(ctx, wavefrontDepth), "wf_intersect_shadow");
+                // SampleSubsurface, integrator.cpp:431 -> wavefront/subsurface.cpp:18-203 (ends with its own TraceShadowRays)
+                if (T.materialTypePresent[WF_MAT_SUBSURFACE]) {
+                    Check(wf_subsurface_probe(ctx, wavefrontDepth), "wf_subsurface_probe");
+                    Check(wf_intersect_one_random(ctx), "wf_intersect_one_random");
+                    Check(wf_subsurface_scatter(ctx, wavefrontDepth), "wf_subsurface_scatter");
+                    if (T.desc.have_media) Check(wf_intersect_shadow_tr(ctx, wavefrontDepth), "wf_intersect_shadow_tr");
+                    else Check(wf_intersect_shadow(ctx, wavefrontDepth), "wf_intersect_shadow");
+                }
             }
             Check(wf_update_film(ctx), "wf_update_film");
         }

@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include "../common/wf_camera.h"
 #include "../common/wf_shapes.h"
+#include "../common/wf_bssrdf.h"
 
 #include <algorithm>
 #include <cmath>
@@ -487,6 +488,37 @@ struct TexBuilder {
             m.tex[WF_MT_G] = GetFloatTexture(ps, "g", 0.f);
             m.tex[WF_MT_ALBEDO] = GetSpectrumTexture(ps, "albedo", *MakeConstant(0.f), SpectrumType::Albedo);
             if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
+        } else if (name == "subsurface") {
+            // SubsurfaceMaterial::Create (materials.cpp:498-567)
+            m.type = WF_MAT_SUBSURFACE;
+            float g = ps.GetOneFloat("g", 0.f);
+            if (!ps.GetOneString("name", "").empty())
+                Die(e.loc, "subsurface: named scattering coefficients (a data table of the reference's source tree) are not supported by this build");
+            int sigma_a = GetSpectrumTextureOrNull(ps, "sigma_a", SpectrumType::Unbounded), sigma_s = GetSpectrumTextureOrNull(ps, "sigma_s", SpectrumType::Unbounded);
+            if (sigma_a >= 0 && sigma_s < 0) Die(e.loc, "Provided \"sigma_a\" parameter without \"sigma_s\".");
+            if (sigma_s >= 0 && sigma_a < 0) Die(e.loc, "Provided \"sigma_s\" parameter without \"sigma_a\".");
+            if (sigma_a < 0) {
+                int refl = GetSpectrumTextureOrNull(ps, "reflectance", SpectrumType::Albedo);
+                if (refl >= 0) {
+                    m.tex[WF_MT_REFLECTANCE] = refl;
+                    m.tex[WF_MT_MFP] = GetSpectrumTexture(ps, "mfp", *MakeConstant(1.f), SpectrumType::Unbounded);
+                } else {
+                    // RGBUnboundedSpectrum(*RGBColorSpace::sRGB, ...) whatever the scene's colour space is
+                    const float a[3] = {.0011f, .0024f, .014f}, sc[3] = {2.55f, 3.21f, 3.77f};
+                    sigma_a = SpectrumConst(*SpectralData::Get().sRGB()->Unbounded(a));
+                    sigma_s = SpectrumConst(*SpectralData::Get().sRGB()->Unbounded(sc));
+                }
+            }
+            if (sigma_a >= 0) { m.tex[WF_MT_SIGMA_A] = sigma_a; m.tex[WF_MT_SIGMA_S] = sigma_s; m.flags |= WF_MATFLAG_SSS_COEFFICIENTS; }
+            m.scale = ps.GetOneFloat("scale", 1.f);
+            m.sss_eta = ps.GetOneFloat("eta", 1.33f);
+            roughness("uroughness", "vroughness", "roughness", WF_MT_UROUGH, WF_MT_VROUGH);
+            if (ps.GetOneBool("remaproughness", true)) m.flags |= WF_MATFLAG_REMAP_ROUGHNESS;
+            // the material's BSSRDFTable (materials.h:719-720)
+            std::vector<float> table(wf::BSSRDF_TABLE_FLOATS);
+            wf::ComputeBeamDiffusionBSSRDF(g, m.sss_eta, table.data());
+            m.sss_table = (int)T->tableData.size();
+            T->tableData.insert(T->tableData.end(), table.begin(), table.end());
         } else if (name == "interface" || name == "none" || name.empty()) {
             m.type = WF_MAT_INTERFACE;
         } else if (name == "mix") {

@@ -50,6 +50,9 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_image_ref.pfm $G/arealight_image.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
+# K12 subsurface scattering: the two blobs of blobs_small as SubsurfaceMaterials (reflectance + mfp; default coefficients with scale and g)
+sed 's/^MakeNamedMaterial "blobA".*/MakeNamedMaterial "blobA" "string type" [ "subsurface" ] "rgb reflectance" [ 0.8 0.5 0.35 ] "rgb mfp" [ 0.25 0.12 0.06 ] "float eta" [ 1.4 ] "float roughness" [ 0.15 ]/; s/^MakeNamedMaterial "blobB".*/MakeNamedMaterial "blobB" "string type" [ "subsurface" ] "float scale" [ 4 ] "float g" [ 0.3 ]/; s/killeroo-like.pfm/subsurface.pfm/' $G/blobs_small.pbrt > $G/subsurface.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/subsurface_ref.pfm $G/subsurface.pbrt
 # goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
