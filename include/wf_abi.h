@@ -583,6 +583,10 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
                           wf_hit_record *out, int count_visits);
 int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax,
                       int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested);
+/* WavefrontAggregate::IntersectOneRandom (integrator.h:51-52) on caller-supplied probe segments p0 -> p1 (3 floats each): out[i] =
+   the hit of a surface whose material id is material[i], chosen by the reference's weighted reservoir sampling (seed Hash(p0, p1))
+   among all such hits along the segment, reservoir_pdf[i] its sample probability (0 and prim = -1: none) */
+int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p1, const int32_t *material, wf_hit_record *out, float *reservoir_pdf);
 /* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample */
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index,
                      int start_dim, int ndims, float *out);

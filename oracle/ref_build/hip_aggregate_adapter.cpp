@@ -8,7 +8,8 @@
 //                     -> the reference's own EnqueueWorkAfterIntersection / EnqueueWorkAfterMiss (wavefront/intersect.h)
 //   IntersectShadow   shadow rays -> wf_trace_any_host -> the reference's RecordShadowRayResult
 //   Bounds            wf_aggregate_bounds
-//   IntersectShadowTr / IntersectOneRandom: forwarded to the reference's CPUAggregate (media / subsurface scenes)
+//   IntersectOneRandom  probe segments -> wf_trace_one_random_host (reservoir over the hits of the item's material) -> SubsurfaceInteraction
+//   IntersectShadowTr: forwarded to the reference's CPUAggregate (scenes with media)
 //
 // Everything else — camera rays, samplers, materials, lights, film — stays the reference's CPU code, so the image must be
 // the one `pbrt --wavefront` writes, bit for bit (tests/test_gpu_parity.py::test_reference_integrator_over_hip_aggregate).
@@ -114,6 +115,8 @@ class HipAggregate : public WavefrontAggregate {
             int id = firstTri[t->meshIndex] + t->triIndex;
             CHECK(id >= 0 && id < nTriangles);
             prims[id] = p;
+            Material mat = p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->material : p.Cast<GeometricPrimitive>()->material;
+            materialIds[mat.ptr()] = desc->meshes[desc->tri_mesh[id]].material;
         };
         visit(cpu->aggregate);
         // identical meshes (same geometry, possibly different materials) may have been handed out in a different order than
@@ -180,12 +183,42 @@ class HipAggregate : public WavefrontAggregate {
     }
 
     void IntersectShadowTr(int maxRays, ShadowRayQueue *q, SOA<PixelSampleState> *ps) const override { cpu->IntersectShadowTr(maxRays, q, ps); }
-    void IntersectOneRandom(int maxRays, SubsurfaceScatterQueue *q) const override { cpu->IntersectOneRandom(maxRays, q); }
+    // wavefront/aggregate.cpp:90-115: the probe segment's hits with the item's own material, one kept by weighted reservoir sampling
+    void IntersectOneRandom(int maxRays, SubsurfaceScatterQueue *q) const override {
+        const int n = q->Size();
+        if (n == 0) return;
+        std::vector<float> p0(3 * (size_t)n), p1(3 * (size_t)n), pdf(n);
+        std::vector<int32_t> material(n);
+        for (int i = 0; i < n; ++i) {
+            const SubsurfaceScatterWorkItem &w = (*q)[i];
+            p0[3 * i] = w.p0.x; p0[3 * i + 1] = w.p0.y; p0[3 * i + 2] = w.p0.z;
+            p1[3 * i] = w.p1.x; p1[3 * i + 1] = w.p1.y; p1[3 * i + 2] = w.p1.z;
+            auto it = materialIds.find(w.material.ptr());
+            if (it == materialIds.end()) ErrorExit("pbrt_hipagg: a subsurface work item's material has no counterpart in the flat tables");
+            material[i] = it->second;
+        }
+        std::vector<wf_hit_record> hits(n);
+        if (wf_trace_one_random_host(ctx, n, p0.data(), p1.data(), material.data(), hits.data(), pdf.data()) != 0)
+            ErrorExit("wf_trace_one_random_host: %s", wf_last_error());
+        ParallelFor(0, n, [&](int64_t index) {
+            const wf_hit_record &h = hits[index];
+            q->reservoirPDF[index] = h.prim < 0 ? 0.f : pdf[index];
+            if (h.prim < 0) return;
+            Primitive p = prims[h.prim];
+            const Triangle *tri = (p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->shape : p.Cast<GeometricPrimitive>()->shape).Cast<Triangle>();
+            TriangleIntersection ti{h.b0, h.b1, h.b2, h.t};
+            const SubsurfaceScatterWorkItem &w = (*q)[index];
+            // (SubsurfaceInteraction keeps pi, n, dpdu, dpdv and the shading frame: none of them depends on wo)
+            SurfaceInteraction intr = Triangle::InteractionFromIntersection(tri->GetMesh(), tri->triIndex, ti, 0.f, Normalize(w.p0 - w.p1));
+            q->ssi[index] = SubsurfaceInteraction(intr);
+        });
+    }
 
   private:
     CPUAggregate *cpu;
     wf_ctx *ctx;
     std::vector<Primitive> prims;
+    std::map<const void *, int32_t> materialIds;   // the reference's Material (tagged pointer payload) -> material id of the flat tables
 };
 
 int main(int argc, char **argv) {

@@ -1087,16 +1087,16 @@ WF_HD void KSubsurfaceProbe(const SceneView &sv, const WorkState &ws, int i) {
     ws.sssQ[QueueAlloc(&ws.counters[(CNT_SSS) * CNT_STRIDE])] = o;
 }
 // WavefrontAggregate::IntersectOneRandom (CPUAggregate: wavefront/aggregate.cpp:90-115; OptiX: gpu/optix/optix.cu:474-573)
+// returns the reservoir's sample probability (0: the segment meets no surface of `material`) and the kept hit
 template <typename Stack>
-WF_HD void KIntersectOneRandom(const SceneView &sv, const WorkState &ws, int i, Stack &st) {
-    SubsurfaceItem &w = ws.sssQ[i];
+WF_HD float IntersectOneRandom(const SceneView &sv, V3 p0, V3 p1, int material, Stack &st, ClosestHit *kept, SurfIntr *keptSi) {
     RNG rng;
-    rng.SetSequence(Hash6f(w.p0, w.p1));   // WeightedReservoirSampler(seed) -> RNG(seed)
+    rng.SetSequence(Hash6f(p0, p1));   // WeightedReservoirSampler(seed) -> RNG(seed)
     float weightSum = 0, reservoirWeight = 0;
-    P3i basePi = MakeP3i(w.p0);
+    P3i basePi = MakeP3i(p0);          // Interaction base(w.p0, 0.f, Medium()): exact point, zero normal
     N3 baseN{0, 0, 0};
     while (true) {
-        RayOD r = SpawnRayTo(basePi, baseN, w.p1);
+        RayOD r = SpawnRayTo(basePi, baseN, p1);
         if (r.d.x == 0 && r.d.y == 0 && r.d.z == 0) break;
         ClosestHit ch;
         st.n = 0;
@@ -1104,17 +1104,25 @@ WF_HD void KIntersectOneRandom(const SceneView &sv, const WorkState &ws, int i, 
         SurfIntr si;
         HitInteraction(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si);
         basePi = si.pi; baseN = si.n;
-        if (sv.meshes[si.mesh].material == w.material) {
+        if (sv.meshes[si.mesh].material == material) {
             // wrs.Add(SubsurfaceInteraction(si->intr), 1.f)  (util/sampling.h:535-546)
             weightSum += 1.f;
             float p = 1.f / weightSum;
             if (rng.UniformFloat() < p) {
-                w.pi = si.pi; w.n = si.n; w.ns = si.ns; w.dpdu = si.dpdu; w.dpdv = si.dpdv; w.dpdus = si.dpdus; w.dpdvs = si.dpdvs;
+                *kept = ch; *keptSi = si;
                 reservoirWeight = 1.f;
             }
         }
     }
-    w.reservoirPDF = weightSum > 0 ? reservoirWeight / weightSum : 0.f;
+    return weightSum > 0 ? reservoirWeight / weightSum : 0.f;
+}
+template <typename Stack>
+WF_HD void KIntersectOneRandom(const SceneView &sv, const WorkState &ws, int i, Stack &st) {
+    SubsurfaceItem &w = ws.sssQ[i];
+    ClosestHit ch;
+    SurfIntr si;
+    w.reservoirPDF = IntersectOneRandom(sv, w.p0, w.p1, w.material, st, &ch, &si);
+    if (w.reservoirPDF != 0) { w.pi = si.pi; w.n = si.n; w.ns = si.ns; w.dpdu = si.dpdu; w.dpdv = si.dpdv; w.dpdus = si.dpdus; w.dpdvs = si.dpdvs; }
 }
 // "Handle out-scattering after SSS" (:49-199)
 WF_HD void KSubsurfaceScatter(const SceneView &sv, const WorkState &ws, int cur, int i) {

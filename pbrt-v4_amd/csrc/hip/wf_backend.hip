@@ -478,6 +478,23 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_one_random(const SceneView 
     LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride) KIntersectOneRandom(sv, ws, i, st);
 }
+// IntersectOneRandom on caller-supplied probe segments (the boundary adapter's path): segs = p0.xyz p1.xyz per item
+__global__ void __launch_bounds__(BLOCK) k_trace_one_random(const SceneView sv, int n, const float *segs, const int32_t *material, wf_hit_record *out, float *pdf,
+                                                            int *stackSpill) {
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride) {
+        const float *s = segs + (size_t)6 * i;
+        ClosestHit ch;
+        SurfIntr si;
+        float p = IntersectOneRandom(sv, V3{s[0], s[1], s[2]}, V3{s[3], s[4], s[5]}, material[i], st, &ch, &si);
+        wf_hit_record h{};
+        h.prim = p != 0 ? ch.prim : -1;
+        if (p != 0) { h.t = ch.h.t; h.b0 = ch.h.b0; h.b1 = ch.h.b1; h.b2 = ch.h.b2; h.instance = ch.inst; } else h.instance = -1;
+        out[i] = h;
+        pdf[i] = p;
+    }
+}
 __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_SSS) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
@@ -1579,6 +1596,28 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(dr));
     HIPCHK(hipFree(dh));
+    return 0;
+}
+int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p1, const int32_t *material, wf_hit_record *out, float *reservoir_pdf) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (n <= 0) return 0;
+    std::vector<float> segs((size_t)n * 6);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { segs[(size_t)i * 6 + k] = p0[3 * i + k]; segs[(size_t)i * 6 + 3 + k] = p1[3 * i + k]; }
+    float *ds = nullptr, *dp = nullptr;
+    int32_t *dm = nullptr;
+    wf_hit_record *dh = nullptr;
+    HIPCHK(hipMalloc((void **)&ds, segs.size() * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&dm, (size_t)n * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **)&dh, (size_t)n * sizeof(wf_hit_record)));
+    HIPCHK(hipMalloc((void **)&dp, (size_t)n * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(ds, segs.data(), segs.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dm, material, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH("intersect one random (host segments)", k_trace_one_random, gridFor(n), ctx->svHost, n, ds, dm, dh, dp, ctx->stackSpill);
+    HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(reservoir_pdf, dp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(ds)); HIPCHK(hipFree(dm)); HIPCHK(hipFree(dh)); HIPCHK(hipFree(dp));
     return 0;
 }
 int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested) {

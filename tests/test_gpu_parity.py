@@ -310,12 +310,12 @@ def test_samples_per_pass_invariance(wfpt):
         assert st["shadow_rays"] == stats[0]["shadow_rays"]
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights"])
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "subsurface"])
 def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     """The drop-in boundary, compiled and run: oracle/_ref/pbrt_hipagg is the REFERENCE's own WavefrontPathIntegrator (its
     CPU camera / sampler / material / light / film code, linked from the unmodified sources) with its WavefrontAggregate
-    replaced by oracle/ref_build/hip_aggregate_adapter.cpp's HipAggregate, which answers IntersectClosest / IntersectShadow
-    through the C ABI of libwfhip.so (production traversal on the GPU) and feeds the hits to the reference's own
+    replaced by oracle/ref_build/hip_aggregate_adapter.cpp's HipAggregate, which answers IntersectClosest / IntersectShadow /
+    IntersectOneRandom (the `subsurface` scene) through the C ABI of libwfhip.so (production traversal on the GPU) and feeds the hits to the reference's own
     EnqueueWorkAfterIntersection.  The image must be the one `pbrt --wavefront` wrote: bit for bit."""
     exe = os.path.join(ROOT, "oracle", "_ref", "pbrt_hipagg")
     if not os.path.exists(exe):
