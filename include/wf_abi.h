@@ -587,6 +587,11 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
    the hit of a surface whose material id is material[i], chosen by the reference's weighted reservoir sampling (seed Hash(p0, p1))
    among all such hits along the segment, reservoir_pdf[i] its sample probability (0 and prim = -1: none) */
 int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p1, const int32_t *material, wf_hit_record *out, float *reservoir_pdf);
+/* Device part of the HLBVH build (cpu/aggregates.cpp:394-411): Morton codes (10 bits per axis of each centroid's
+   offset inside `bounds` = min.xyz max.xyz) and their stable radix sort.  codes[i] / order[i] = code and input position of the i-th
+   primitive in Morton order; the host builder emits the treelets and the SAH upper tree from them.  Needs no context; non-zero
+   when no device is visible. */
+int wf_morton_sort(int n, const float *centroids, const float bounds[6], uint32_t *codes, uint32_t *order);
 /* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample */
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index,
                      int start_dim, int ndims, float *out);

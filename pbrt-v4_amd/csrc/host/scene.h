@@ -153,7 +153,12 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
 // geometry BVH (bvh_build.cpp): SAH build restating BVHAggregate (cpu/aggregates.cpp:140-387,505-521)
 // prims: the primitives in the reference's creation order as (primitive id, render-space bounds).  Nodes and ordered
 // primitive ids are APPENDED to *nodes / *orderedPrims (child and primitive offsets absolute); returns the root index.
-int BuildBVH(const std::vector<std::pair<int, B3>> &prims, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims);
+// splitMethod: 0 = "sah" (cpu/aggregates.cpp:198-387), 1 = "hlbvh" (:389-503, 626-722)
+int BuildBVH(const std::vector<std::pair<int, B3>> &prims, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims, int splitMethod = 0);
+// Morton codes (10 bits per axis of the centroids' offsets in `bounds`) + stable sort, on the device: order[i] = input position of the
+// i-th primitive in Morton order, codes[i] its code.  Non-zero return: not available (the host path is used).
+typedef int (*MortonSortFn)(int n, const float *centroids, const float bounds[6], uint32_t *codes, uint32_t *order);
+void SetMortonSort(MortonSortFn fn);
 // Triangle::Bounds (shapes.cpp:283-290) of global triangle i
 B3 TriangleBounds(const std::vector<float> &P, const std::vector<int32_t> &triIndices, int i);
 // light BVH (lightbvh_build.cpp): BVHLightSampler ctor (lightsamplers.cpp:105-232)

@@ -15,6 +15,7 @@
 #include "../common/wf_bssrdf.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -1391,6 +1392,15 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
 void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
     const SpectralData &sd = SpectralData::Get();
     (void)sd;
+    // WF_LOAD_TIMING=1: where the load time goes (stderr)
+    const bool timing = getenv("WF_LOAD_TIMING") != nullptr;
+    auto tPhase = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[load] %-44s %7.3f s\n", what, std::chrono::duration<double>(now - tPhase).count());
+        tPhase = now;
+    };
     // rendering space: camera-world (cameras.cpp:35-41)
     V3 pCamera = scene.worldFromCamera.Point(V3{0, 0, 0});
     Transform worldFromRender = Translate(pCamera);
@@ -2031,10 +2041,12 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     }
     if (T->lights.empty()) Die("", "No light sources specified");
 
+    tick("textures, materials, shapes (PLY), lights");
     // ---- acceleration structure (scene.cpp:1575-1591, cpu/aggregates.cpp:725-744) ----
     if (scene.accelerator.name != "bvh") fprintf(stderr, "Warning: accelerator \"%s\" is replaced by the BVH\n", scene.accelerator.name.c_str());
     std::string split = scene.accelerator.params.GetOneString("splitmethod", "sah");
-    if (split != "sah") fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str());
+    if (getenv("WF_BVH_SPLIT")) split = getenv("WF_BVH_SPLIT");   // load-time experiments: build the top-level tree with the other method
+    if (split != "sah" && split != "hlbvh") { fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str()); split = "sah"; }
     int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
     {
         // instance definitions first (their bounds enter the top-level build): BVHAggregate(prims) with the constructor's
@@ -2052,6 +2064,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             if (def.bvh_root >= 0)
                 for (int c = 0; c < 3; ++c) { def.bounds[c] = defNodes[def.bvh_root].bmin[c]; def.bounds[3 + c] = defNodes[def.bvh_root].bmax[c]; }
         }
+        tick("instance-definition BVHs (SAH)");
         // the instances (scene.cpp:1560-1577): TransformedPrimitive(definition, renderFromInstance), after the shapes
         const int nTrisAll = (int)T->triIndices.size() / 3, nQuads = (int)T->quadrics.size();
         for (const InstanceUse &u : scene.instances) {
@@ -2069,7 +2082,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             topPrims.emplace_back(nTrisAll + nQuads + (int)T->instances.size(), wb);
             T->instances.push_back(in);
         }
-        BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims);
+        BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims, split == "hlbvh" ? 1 : 0);
+        tick(split == "hlbvh" ? "top-level BVH (HLBVH)" : "top-level BVH (SAH)");
         T->nTopBvhNodes = (int)T->bvhNodes.size();
         T->nTopPrims = (int)T->bvhPrims.size();
         const int nodeShift = T->nTopBvhNodes, primShift = T->nTopPrims;
@@ -2126,6 +2140,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     }
     ip.ReportUnused("Integrator");
     T->Finalize();
+    tick("light sampler, finalisation");
 }
 
 }  // namespace wf

@@ -27,6 +27,7 @@ int wfh_init(const char *data_dir) {
     std::string d = data_dir ? data_dir : "";
     if (d.empty()) return -1;
     SpectralData::Init(d, d + "/cache");
+    SetMortonSort(&wf_morton_sort);  // the HLBVH build's Morton sort runs on the GPU when one is visible (WF_HOST_MORTON_SORT=1: never)
     g_init = true;
     return 0;
 }
@@ -47,6 +48,7 @@ wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed) {
             uint64_t h = 1469598103934665603ull;
             auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull; };
             mix(path, strlen(path)); mix(&st.st_size, sizeof(st.st_size)); mix(&st.st_mtime, sizeof(st.st_mtime)); mix(&spp_override, 4); mix(&seed, 4);
+            if (const char *sp = getenv("WF_BVH_SPLIT")) mix(sp, strlen(sp));
             char name[64];
             snprintf(name, sizeof(name), "/tables_%016llx.wftab", (unsigned long long)h);
             cacheFile = std::string(dir) + name;

@@ -4,6 +4,7 @@ must be bit-exact; radiance is float32 and is compared within the stated toleran
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -111,7 +112,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
@@ -363,3 +364,43 @@ def test_strip_partition_two_contexts_bit_identical(wfpt, tmp_path, monkeypatch)
     s.render()
     assert (s.film().view(np.uint64) == want.view(np.uint64)).all()
     s.close()
+
+
+def test_device_morton_sort_builds_the_same_hlbvh(wfpt, tmp_path, monkeypatch):
+    """HLBVH build (cpu/aggregates.cpp:389-503, `splitmethod "hlbvh"`): with a GPU visible the Morton codes and their stable radix
+    sort come from wf_morton_sort (csrc/hip/wf_sort.hip); the tree must be the one the host sort gives, node for node."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_scenes
+    path = str(tmp_path / "k.pbrt")
+    make_scenes.killeroo_like(path, (96, 54), 1)
+    text = open(path).read().replace("WorldBegin", 'Accelerator "bvh" "string splitmethod" "hlbvh"\nWorldBegin', 1)
+    from test_host import desc_fields
+    def nodes(scene):
+        h = desc_fields(wfpt, scene)
+        return (np.ctypeslib.as_array((C.c_uint32 * (8 * h.n_bvh_nodes)).from_address(h.bvh_nodes)).copy(),
+                np.ctypeslib.as_array((C.c_int32 * h.n_triangles).from_address(h.bvh_prims)).copy())
+    a = wfpt.Scene(text=text, spp=1)
+    monkeypatch.setenv("WF_HOST_MORTON_SORT", "1")
+    b = wfpt.Scene(text=text, spp=1)
+    na, pa = nodes(a); nb, pb = nodes(b)
+    assert a.info.n_triangles > 4096 and na.shape == nb.shape and (na == nb).all() and (pa == pb).all()
+    # and the sort itself against numpy on random centroids
+    _, hip = wfpt.libs()
+    n = 200000
+    rng = np.random.default_rng(5)
+    c = rng.random((n, 3), dtype=np.float32) * np.float32(7) - np.float32(3)
+    bounds = np.concatenate([c.min(axis=0), c.max(axis=0)]).astype(np.float32)
+    codes = np.zeros(n, np.uint32); order = np.zeros(n, np.uint32)
+    hip.wf_morton_sort.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert hip.wf_morton_sort(n, c.ctypes.data, bounds.ctypes.data, codes.ctypes.data, order.ctypes.data) == 0
+    o = (c - bounds[:3]) / (bounds[3:] - bounds[:3]) * np.float32(1024)
+    q = np.minimum(o.astype(np.uint32), 1023).astype(np.uint64)
+    def spread(x):
+        r = np.zeros_like(x)
+        for bit in range(10): r |= ((x >> bit) & 1) << (3 * bit)
+        return r
+    want = (spread(q[:, 2]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 0])
+    perm = np.argsort(want, kind="stable")
+    assert (order == perm).all() and (codes == want[perm]).all()
+    a.close(); b.close()

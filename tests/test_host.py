@@ -92,7 +92,7 @@ def test_film_to_rgb_matches_getpixelrgb(wfpt):
 def _bvh_stat_scenes(tmp_path):
     import make_scenes
     from conftest import GOLDEN
-    out = [(n, os.path.join(GOLDEN, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap")]
+    out = [(n, os.path.join(GOLDEN, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap", "blobs_hlbvh")]
     k = str(tmp_path / "killeroo_like_240.pbrt")
     make_scenes.killeroo_like(k, (240, 135), 1)
     out.append(("killeroo_like_240x135_1spp", k, 1))
@@ -127,7 +127,7 @@ def test_bvh_stats_golden_is_the_live_references(tmp_path):
         pytest.skip("oracle/_ref/pbrt_ref not built (no /root/reference)")
     import make_bvh_stats_golden as mk
     golden = json.load(open(os.path.join(GOLDEN, "bvh_stats.json")))
-    for name in ("blobs_small", "instances"):
+    for name in ("blobs_small", "instances", "blobs_hlbvh"):
         live = mk.ref_stats(os.path.join(GOLDEN, name + ".pbrt"), 4)
         assert all(live[k] == golden[name][k] for k in live), (name, live, golden[name])
 

@@ -28,7 +28,7 @@ def ref_stats(path, spp):
 
 
 def scenes(td):
-    out = [(n, os.path.join(G, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap")]
+    out = [(n, os.path.join(G, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap", "blobs_hlbvh")]
     k = os.path.join(td, "killeroo_like_240.pbrt")
     make_scenes.killeroo_like(k, (240, 135), 1)
     out.append(("killeroo_like_240x135_1spp", k, 1))

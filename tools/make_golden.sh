@@ -50,6 +50,9 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_image_ref.pfm $G/arealight_image.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
+# the reference's other BVH builder: blobs_small with `splitmethod "hlbvh"` (cpu/aggregates.cpp:389-503, 626-722)
+sed 's/^WorldBegin/Accelerator "bvh" "string splitmethod" "hlbvh"\nWorldBegin/; s/killeroo-like.pfm/blobs_hlbvh.pfm/' $G/blobs_small.pbrt > $G/blobs_hlbvh.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/blobs_hlbvh_ref.pfm $G/blobs_hlbvh.pbrt
 # K12 subsurface scattering: the two blobs of blobs_small as SubsurfaceMaterials (reflectance + mfp; default coefficients with scale and g)
 sed 's/^MakeNamedMaterial "blobA".*/MakeNamedMaterial "blobA" "string type" [ "subsurface" ] "rgb reflectance" [ 0.8 0.5 0.35 ] "rgb mfp" [ 0.25 0.12 0.06 ] "float eta" [ 1.4 ] "float roughness" [ 0.15 ]/; s/^MakeNamedMaterial "blobB".*/MakeNamedMaterial "blobB" "string type" [ "subsurface" ] "float scale" [ 4 ] "float g" [ 0.3 ]/; s/killeroo-like.pfm/subsurface.pfm/' $G/blobs_small.pbrt > $G/subsurface.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/subsurface_ref.pfm $G/subsurface.pbrt
