@@ -1321,51 +1321,92 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
         } else if (kw == "end_header") break;
     }
     if (fmt == BBE) { *err = "big-endian PLY is not supported"; return false; }
-    auto typeSize = [](const std::string &t) {
-        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
-        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
-        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
-        return 8;
+    // the body in one read; property types and roles resolved once per element (a 10 M-triangle scene reads ~60 M numbers)
+    std::vector<char> body;
+    {
+        std::streampos at = in.tellg();
+        in.seekg(0, std::ios::end);
+        std::streampos endPos = in.tellg();
+        in.seekg(at);
+        body.resize((size_t)(endPos - at));
+        in.read(body.data(), (std::streamsize)body.size());
+    }
+    const char *cur = body.data(), *const bodyEnd = body.data() + body.size();
+    enum Ty { I8, U8, I16, U16, I32, U32, F32, F64 };
+    auto typeOf = [](const std::string &t) {
+        if (t == "char" || t == "int8") return I8;
+        if (t == "uchar" || t == "uint8") return U8;
+        if (t == "short" || t == "int16") return I16;
+        if (t == "ushort" || t == "uint16") return U16;
+        if (t == "int" || t == "int32") return I32;
+        if (t == "uint" || t == "uint32") return U32;
+        if (t == "float" || t == "float32") return F32;
+        return F64;
     };
-    auto readNum = [&](const std::string &t) -> double {
-        if (fmt == ASCII) { double v; in >> v; return v; }
-        char buf[8];
-        int n = typeSize(t);
-        in.read(buf, n);
-        if (t == "char" || t == "int8") return *(int8_t *)buf;
-        if (t == "uchar" || t == "uint8") return *(uint8_t *)buf;
-        if (t == "short" || t == "int16") { int16_t v; memcpy(&v, buf, 2); return v; }
-        if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, buf, 2); return v; }
-        if (t == "int" || t == "int32") { int32_t v; memcpy(&v, buf, 4); return v; }
-        if (t == "uint" || t == "uint32") { uint32_t v; memcpy(&v, buf, 4); return v; }
-        if (t == "float" || t == "float32") { float v; memcpy(&v, buf, 4); return v; }
-        double v; memcpy(&v, buf, 8); return v;
+    bool truncated = false;
+    auto readNum = [&](Ty t) -> double {
+        if (fmt == ASCII) {
+            while (cur < bodyEnd && isspace((unsigned char)*cur)) ++cur;
+            if (cur >= bodyEnd) { truncated = true; return 0; }
+            char *e = nullptr;
+            double v = strtod(cur, &e);
+            if (e == cur) { truncated = true; return 0; }
+            cur = e;
+            return v;
+        }
+        static const int size[8] = {1, 1, 2, 2, 4, 4, 4, 8};
+        if (cur + size[t] > bodyEnd) { truncated = true; return 0; }
+        const char *b = cur;
+        cur += size[t];
+        switch (t) {
+        case I8: return *(const int8_t *)b;
+        case U8: return *(const uint8_t *)b;
+        case I16: { int16_t v; memcpy(&v, b, 2); return v; }
+        case U16: { uint16_t v; memcpy(&v, b, 2); return v; }
+        case I32: { int32_t v; memcpy(&v, b, 4); return v; }
+        case U32: { uint32_t v; memcpy(&v, b, 4); return v; }
+        case F32: { float v; memcpy(&v, b, 4); return v; }
+        default: { double v; memcpy(&v, b, 8); return v; }
+        }
     };
     for (const Elem &e : elems) {
+        struct P2 { Ty type, countType; bool list; int role; };  // role: 0..2 position, 3..5 normal, 6 / 7 uv, 8 vertex indices, -1 skipped
+        std::vector<P2> props;
+        for (const Prop &p : e.props) {
+            P2 q{typeOf(p.type), typeOf(p.countType), p.list, -1};
+            if (e.name == "vertex") {
+                if (p.name == "x") q.role = 0; else if (p.name == "y") q.role = 1; else if (p.name == "z") q.role = 2;
+                else if (p.name == "nx") q.role = 3; else if (p.name == "ny") q.role = 4; else if (p.name == "nz") q.role = 5;
+                else if (p.name == "u" || p.name == "s" || p.name == "texture_u" || p.name == "texture_s") q.role = 6;
+                else if (p.name == "v" || p.name == "t" || p.name == "texture_v" || p.name == "texture_t") q.role = 7;
+            } else if (e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index")) q.role = 8;
+            props.push_back(q);
+        }
         if (e.name == "vertex") {
             bool hasN = false, hasUV = false;
-            for (const Prop &p : e.props) { if (p.name == "nx") hasN = true; if (p.name == "u" || p.name == "s" || p.name == "texture_u" || p.name == "texture_s") hasUV = true; }
+            for (const P2 &p : props) { if (p.role == 3) hasN = true; if (p.role == 6) hasUV = true; }
             out->P.resize(e.count);
             if (hasN) out->N.resize(e.count);
             if (hasUV) out->uv.resize(e.count);
-            for (long i = 0; i < e.count; ++i)
-                for (const Prop &p : e.props) {
+            for (long i = 0; i < e.count && !truncated; ++i)
+                for (const P2 &p : props) {
                     if (p.list) { int n = (int)readNum(p.countType); for (int k = 0; k < n; ++k) readNum(p.type); continue; }
                     float v = (float)readNum(p.type);
-                    if (p.name == "x") out->P[i].x = v; else if (p.name == "y") out->P[i].y = v; else if (p.name == "z") out->P[i].z = v;
-                    else if (p.name == "nx") out->N[i].x = v; else if (p.name == "ny") out->N[i].y = v; else if (p.name == "nz") out->N[i].z = v;
-                    else if (p.name == "u" || p.name == "s" || p.name == "texture_u" || p.name == "texture_s") out->uv[i].x = v;
-                    else if (p.name == "v" || p.name == "t" || p.name == "texture_v" || p.name == "texture_t") out->uv[i].y = v;
+                    switch (p.role) {
+                    case 0: out->P[i].x = v; break; case 1: out->P[i].y = v; break; case 2: out->P[i].z = v; break;
+                    case 3: out->N[i].x = v; break; case 4: out->N[i].y = v; break; case 5: out->N[i].z = v; break;
+                    case 6: out->uv[i].x = v; break; case 7: if (hasUV) out->uv[i].y = v; break;
+                    default: break;
+                    }
                 }
         } else if (e.name == "face") {
-            for (long i = 0; i < e.count; ++i)
-                for (const Prop &p : e.props) {
+            out->indices.reserve(out->indices.size() + 3 * (size_t)e.count);
+            for (long i = 0; i < e.count && !truncated; ++i)
+                for (const P2 &p : props) {
                     if (!p.list) { readNum(p.type); continue; }
                     int n = (int)readNum(p.countType);
-                    std::vector<int> idx(n);
-                    for (int k = 0; k < n; ++k) idx[k] = (int)readNum(p.type);
-                    if (p.name != "vertex_indices" && p.name != "vertex_index") continue;
-                    if (n == 3) out->indices.insert(out->indices.end(), idx.begin(), idx.end());
+                    if (p.role != 8) { for (int k = 0; k < n; ++k) readNum(p.type); continue; }
+                    if (n == 3) { for (int k = 0; k < 3; ++k) out->indices.push_back((int)readNum(p.type)); }
                     else if (n == 4) {
                         // the reference turns the quad faces of a plymesh into BilinearPatch shapes (shapes.cpp:1465-1472, face
                         // order 0,1,3,2 of util/mesh.cpp:302-305), not into triangle pairs: splitting them here would render a
@@ -1375,13 +1416,14 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
                     } else { *err = "only triangle faces are supported (the reference accepts triangles and quads)"; return false; }
                 }
         } else {
-            for (long i = 0; i < e.count; ++i)
-                for (const Prop &p : e.props) {
+            for (long i = 0; i < e.count && !truncated; ++i)
+                for (const P2 &p : props) {
                     if (p.list) { int n = (int)readNum(p.countType); for (int k = 0; k < n; ++k) readNum(p.type); }
                     else readNum(p.type);
                 }
         }
     }
+    if (truncated) { *err = "unexpected end of PLY data"; return false; }
     for (int vi : out->indices) if (vi < 0 || vi >= (int)out->P.size()) { *err = "vertex index out of bounds"; return false; }
     return true;
 }
