@@ -48,7 +48,8 @@ typedef struct wf_transform {    /* util/transform.h:Transform — m and its inv
 /* Medium (media.h:226-352): HomogeneousMedium and GridMedium ("uniformgrid"), both with the Henyey-Greenstein
  * phase function.  Spectra are DenselySampledSpectrum tables (471 floats each in spectrum_data), already
  * multiplied by the medium's "scale" / Le scale as the reference's constructors do (media.h:233-241). */
-enum wf_medium_type { WF_MEDIUM_HOMOGENEOUS = 0, WF_MEDIUM_GRID = 1, WF_MEDIUM_RGB_GRID = 2 };
+enum wf_medium_type { WF_MEDIUM_HOMOGENEOUS = 0, WF_MEDIUM_GRID = 1, WF_MEDIUM_RGB_GRID = 2,
+                      WF_MEDIUM_CLOUD = 3 /* media.h:430-525: procedural density from Perlin noise inside `bounds`, one homogeneous majorant */ };
 typedef struct wf_medium {
     int32_t type;
     int32_t sigma_a_offset, sigma_s_offset, le_offset;   /* offsets into spectrum_data */
@@ -67,6 +68,8 @@ typedef struct wf_medium {
     /* GridMedium "temperature" (media.h:305-318): SampledGrid<Float> of nx*ny*nz kelvins in medium_data, or -1 */
     int32_t temperature_offset;
     float temperature_shift, temperature_scale;
+    /* CloudMedium */
+    float cloud_density, cloud_wispiness, cloud_frequency;
 } wf_medium;
 
 /* Spectrum (util/spectrum.h:48-67 TaggedPointer family) flattened to a 32-byte descriptor.
@@ -105,7 +108,16 @@ enum wf_texture_type {
     WF_TEX_FLOAT_BILERP = 10,          /* textures.h:300-330: v00 = f0, v01 = f1, v10 = map[10], v11 = map[11] over the 2D mapping */
     WF_TEX_SPECTRUM_BILERP = 11,       /* spectra ids: v00 = spectrum, v10 = tex0, v01 = tex1, v11 = tex2 */
     WF_TEX_FLOAT_DIRECTIONMIX = 12,    /* textures.h:830-860: dir (render space, normalized) in map[4..6]; tex0 = "tex2", tex1 = "tex1" */
-    WF_TEX_SPECTRUM_DIRECTIONMIX = 13
+    WF_TEX_SPECTRUM_DIRECTIONMIX = 13,
+    /* the procedural textures of the reference's "universal" evaluator (textures.h:427-502,775-800,1079-1122; util/noise.cpp).
+       3D mapping = PointTransformMapping: textureFromRender = inverse of light_transforms[xform] */
+    WF_TEX_FLOAT_FBM = 14,             /* i0 = octaves, f0 = omega ("roughness") */
+    WF_TEX_FLOAT_WRINKLED = 15,        /* Turbulence: i0 = octaves, f0 = omega */
+    WF_TEX_FLOAT_WINDY = 16,
+    WF_TEX_SPECTRUM_MARBLE = 17,       /* i0 = octaves, f0 = omega, f1 = scale, map[10] = variation; RGBAlbedoSpectrum in sRGB */
+    WF_TEX_FLOAT_DOTS = 18,            /* 2D mapping in map; tex0 = evaluated outside the dots, tex1 = inside (see scene_build.cpp for which
+                                          parameter that is in the reference) */
+    WF_TEX_SPECTRUM_DOTS = 19
 };
 typedef struct wf_texture {
     int32_t type;
@@ -117,7 +129,8 @@ typedef struct wf_texture {
     int32_t mapping;             /* wf_tex_mapping */
     int32_t xform;               /* spherical / cylindrical / planar: renderFromTexture in light_transforms (textureFromRender = its inverse) */
 } wf_texture;
-enum wf_tex_mapping { WF_TEXMAP_UV = 0, WF_TEXMAP_SPHERICAL = 1, WF_TEXMAP_CYLINDRICAL = 2, WF_TEXMAP_PLANAR = 3 };
+enum wf_tex_mapping { WF_TEXMAP_UV = 0, WF_TEXMAP_SPHERICAL = 1, WF_TEXMAP_CYLINDRICAL = 2, WF_TEXMAP_PLANAR = 3,
+                      WF_TEXMAP_POINT3D = 4 /* checkerboard "dimension" 3: PointTransformMapping through xform */ };
 
 /* Materials (materials.h).  tex[] holds texture ids; meaning per type is listed in DESIGN.md and
  * mirrored by the WF_MT_* index constants below. */
@@ -407,6 +420,7 @@ typedef struct wf_scene_desc {
     int32_t n_tex_images;
     const wf_tex_image *tex_images;  /* wf_texture.i0 of the IMAGE texture types */
     const float *table_data;
+    const int32_t *noise_perm;           /* [512] Perlin permutation (util/noise.cpp:19-56), or null when no texture / medium uses noise */
     const float *rgb2spec_coeffs;        /* [3][64][64][64][3] or null when no image light needs it */
     float rgb2spec_znodes[64];
     int32_t cs_illuminant_offset;        /* dense illuminant of that colour space in spectrum_data */

@@ -73,6 +73,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.texImages = d.tex_images;
     sv.imageLights = d.image_lights; sv.tableData = d.table_data; sv.rgb2specCoeffs = d.rgb2spec_coeffs;
     sv.rgb2specZNodes = d.rgb2spec_znodes;
+    sv.noisePerm = d.noise_perm;
     sv.csIlluminantOffset = d.cs_illuminant_offset;
     sv.media = d.media; sv.mediumData = d.medium_data;
     sv.maxDepth = d.max_depth; sv.regularize = d.regularize; sv.haveMedia = d.have_media; sv.options = d.options;

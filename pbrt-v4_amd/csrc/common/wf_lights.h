@@ -28,11 +28,7 @@ WF_HD bool IsDeltaLight(int type) {
     return type == WF_LIGHT_POINT || type == WF_LIGHT_SPOT || type == WF_LIGHT_DISTANT || type == WF_LIGHT_GONIOMETRIC || type == WF_LIGHT_PROJECTION;
 }
 
-WF_HD float SmoothStep(float x, float a, float b) {
-    if (a == b) return (x < a) ? 0 : 1;
-    float t = Clamp((x - a) / (b - a), 0.f, 1.f);
-    return t * t * (3 - 2 * t);
-}
+// (SmoothStep: wf_noise.h)
 
 
 // ---------------------------------------------------------------------------------------------

@@ -151,6 +151,38 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
         return mp;
     }
     p = XfInvPoint(M.render_from_medium, p);
+    if (M.type == WF_MEDIUM_CLOUD) {
+        // CloudMedium::SamplePoint + Density (media.h:464-471, 493-517)
+        const int32_t *perm = sv.noisePerm;
+        V3 pp = M.cloud_frequency * p;
+        if (M.cloud_wispiness > 0) {
+            float vomega = 0.05f * M.cloud_wispiness, vlambda = 10.f;
+            for (int i = 0; i < 2; ++i) {
+                // DNoise (util/noise.cpp:110-116)
+                V3 q = vlambda * pp;
+                const float delta = .01f;
+                float n = Noise3(perm, q);
+                V3 nd{Noise3(perm, q + V3{delta, 0, 0}), Noise3(perm, q + V3{0, delta, 0}), Noise3(perm, q + V3{0, 0, delta})};
+                pp = pp + vomega * ((nd - V3{n, n, n}) / delta);
+                vomega *= 0.5f;
+                vlambda *= 1.99f;
+            }
+        }
+        float d = 0;
+        float omega = 0.5f, lambda = 1.f;
+        for (int i = 0; i < 5; ++i) {
+            d += omega * Noise3(perm, lambda * pp);
+            omega *= 0.5f;
+            lambda *= 1.99f;
+        }
+        d = Clamp((1 - p.y) * 4.5f * M.cloud_density * d, 0.f, 1.f);
+        d += 2 * fmax(0.f, 0.5f - p.y);
+        d = Clamp(d, 0.f, 1.f);
+        mp.sigma_a = d * ml.sigma_a;
+        mp.sigma_s = d * ml.sigma_s;
+        mp.Le = S4c(0.f);
+        return mp;
+    }
     p = BoundsOffset(M.bounds, p);
     if (M.type == WF_MEDIUM_RGB_GRID) {
         // RGBGridMedium::SamplePoint, media.h:377-401 (ml.Le = the colour space's illuminant at lambda)
@@ -255,6 +287,13 @@ WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, cons
     it.tMax = -WF_INFINITY;
     XfInvRay(M.render_from_medium, &o, &d, &raytMax);
     float tMin, tMax;
+    if (M.type == WF_MEDIUM_CLOUD) {
+        // CloudMedium::SampleRay (media.h:474-488): one HomogeneousMajorantIterator over the box overlap (none: the default iterator)
+        it.homogeneous = true;
+        it.called = !BoundsIntersectT(M.bounds, o, d, raytMax, &tMin, &tMax);
+        if (!it.called) it.seg = MajorantSeg{tMin, tMax, sigma_a + sigma_s};
+        return it;
+    }
     if (!BoundsIntersectT(M.bounds, o, d, raytMax, &tMin, &tMax)) return it;
     it.sigma_t = M.type == WF_MEDIUM_RGB_GRID ? S4c(1.f) : sigma_a + sigma_s;  // RGBGridMedium::SampleRay: sigma_t(1), media.h:413
     it.tMin = tMin;

@@ -6,6 +6,7 @@
 #pragma once
 
 #include "wf_math.h"
+#include "wf_noise.h"
 #include "../../../include/wf_abi.h"
 
 namespace wf {
@@ -37,6 +38,7 @@ struct SceneView {
     const float *tableData;
     const float *rgb2specCoeffs;
     const float *rgb2specZNodes;  // [64]
+    const int32_t *noisePerm;     // [512] Perlin permutation (procedural textures, cloud medium), or null
     int csIlluminantOffset;
     // participating media
     const wf_medium *media;
@@ -436,6 +438,98 @@ WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, cons
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The procedural textures (the reference evaluates them through its UniversalTextureEvaluator): fbm, wrinkled, windy
+// (textures.h:480-502,1079-1122), marble (textures.cpp:480-503), dots (textures.h:427-478 + InsidePolkaDot, textures.cpp:288-303),
+// 3D checkerboard (textures.cpp:208-216).  Out of line: leaves of the texture graph that production scenes rarely have.
+// TexCoord3D of PointTransformMapping::Map (textures.h:238-241): textureFromRender applied to p, dpdx, dpdy
+struct TexCoord3 { V3 p, dpdx, dpdy; };
+WF_HD TexCoord3 TexMap3D(const wf_transform *xf, const TexCtx &c) {
+    const float(*m)[4] = xf->mInv;
+    auto xfP = [&](V3 p) {
+        float xp = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
+        float yp = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
+        float zp = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
+        float wp = m[3][0] * p.x + m[3][1] * p.y + m[3][2] * p.z + m[3][3];
+        return wp == 1 ? V3{xp, yp, zp} : V3{xp, yp, zp} / wp;
+    };
+    auto xfV = [&](V3 v) {
+        return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z, m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
+    };
+    return TexCoord3{xfP(c.p), xfV(c.dpdx), xfV(c.dpdy)};
+}
+WF_NI float NoiseFloatTextureP(const int32_t *perm, const wf_transform *xf, const wf_texture *tp, const TexCtx *cp) {
+    const wf_texture &t = *tp;
+    TexCoord3 c = TexMap3D(xf, *cp);
+    if (t.type == WF_TEX_FLOAT_FBM) return FBm(perm, c.p, c.dpdx, c.dpdy, t.f0, t.i0);
+    if (t.type == WF_TEX_FLOAT_WRINKLED) return Turbulence(perm, c.p, c.dpdx, c.dpdy, t.f0, t.i0);
+    // WindyTexture::Evaluate
+    float windStrength = FBm(perm, .1f * c.p, .1f * c.dpdx, .1f * c.dpdy, .5f, 3);
+    float waveHeight = FBm(perm, c.p, c.dpdx, c.dpdy, .5f, 6);
+    return abs(windStrength) * waveHeight;
+}
+WF_NI void MarbleTextureP(const int32_t *perm, const wf_transform *xf, const wf_texture *tp, const TexCtx *cp, const float *coeffs, const float *zNodes,
+                          const float *lambda, float *out) {
+    const wf_texture &t = *tp;
+    TexCoord3 c = TexMap3D(xf, *cp);
+    const float scale = t.f1, variation = t.map[10];
+    c.p = c.p * scale;
+    float marble = c.p.y + variation * FBm(perm, c.p, scale * c.dpdx, scale * c.dpdy, t.f0, t.i0);
+    float tt = .5f + .5f * sin(marble);
+    const float colors[9][3] = {{.58f, .58f, .6f}, {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.5f, .5f, .5f}, {.6f, .59f, .58f},
+                                {.58f, .58f, .6f}, {.58f, .58f, .6f}, {.2f, .2f, .33f}, {.58f, .58f, .6f}};
+    const int nSeg = 9 - 3;
+    int first = (int)floor(tt * nSeg);
+    if (first > nSeg - 1) first = nSeg - 1;
+    tt = tt * nSeg - first;
+    float rgb[3];
+    for (int k = 0; k < 3; ++k) {
+        // EvaluateCubicBezier = BlossomCubicBezier(cp, u, u, u) (util/splines.h:17-28)
+        float a0 = Lerp(tt, colors[first][k], colors[first + 1][k]), a1 = Lerp(tt, colors[first + 1][k], colors[first + 2][k]), a2 = Lerp(tt, colors[first + 2][k], colors[first + 3][k]);
+        float b0 = Lerp(tt, a0, a1), b1 = Lerp(tt, a1, a2);
+        rgb[k] = 1.5f * Lerp(tt, b0, b1);
+    }
+    float c0, c1, c2;
+    RGBToSpectrumCoeffsP(coeffs, zNodes, rgb[0], rgb[1], rgb[2], &c0, &c1, &c2);   // RGBAlbedoSpectrum(*RGBColorSpace::sRGB, rgb)
+    for (int i = 0; i < 4; ++i) out[i] = SigmoidPoly(lambda[i], c0, c1, c2);
+}
+WF_NI bool InsidePolkaDotP(const int32_t *perm, float s, float t) {
+    int sCell = (int)floor(s + .5f), tCell = (int)floor(t + .5f);
+    if (Noise(perm, sCell + .5f, tCell + .5f) > 0) {
+        float radius = .35f;
+        float maxShift = 0.5f - radius;
+        float sCenter = sCell + maxShift * Noise(perm, sCell + 1.5f, tCell + 2.8f);
+        float tCenter = tCell + maxShift * Noise(perm, sCell + 4.5f, tCell + 9.8f);
+        float ds = s - sCenter, dt = t - tCenter;
+        if (Sqr(ds) + Sqr(dt) < Sqr(radius)) return true;
+    }
+    return false;
+}
+// Checkerboard() for the 3D mapping (textures.cpp:208-216)
+WF_NI float Checkerboard3DP(const wf_transform *xf, const TexCtx *cp) {
+    TexCoord3 c = TexMap3D(xf, *cp);
+    auto d = [](float x) {
+        float y = x / 2 - floor(x / 2) - 0.5f;
+        return x / 2 + y * (1 - 2 * abs(y));
+    };
+    auto bf = [&](float x, float r) -> float {
+        if (floor(x - r) == floor(x + r)) return (float)(1 - 2 * ((int)floor(x) & 1));
+        return (d(x + r) - 2 * d(x) + d(x - r)) / Sqr(r);
+    };
+    float dx = 1.5f * fmax(abs(c.dpdx.x), abs(c.dpdy.x));
+    float dy = 1.5f * fmax(abs(c.dpdx.y), abs(c.dpdy.y));
+    float dz = 1.5f * fmax(abs(c.dpdx.z), abs(c.dpdy.z));
+    return 0.5f - 0.5f * bf(c.p.x, dx) * bf(c.p.y, dy) * bf(c.p.z, dz);
+}
+WF_HD float CheckerboardWeight(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+    if (t.mapping == WF_TEXMAP_POINT3D) { TexCtx cc = c; return Checkerboard3DP(sv.lightXforms + t.xform, &cc); }
+    return Checkerboard2D(sv, t, c);
+}
+WF_HD bool InsidePolkaDot(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
+    TexCoord2 st = TexMap2D(sv, t, c);
+    return InsidePolkaDotP(sv.noisePerm, st.st.x, st.st.y);
+}
+
 // FloatTexture::Evaluate / SpectrumTexture::Evaluate over the flattened texture graph.  The reference recurses through
 // tagged pointers; the device code has no recursion: the walk is a template over the remaining depth, fully inlined.
 // With three interior node types the inlined code grows ~7x per level, so the bound is two interior levels above the
@@ -445,18 +539,28 @@ WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, cons
 #ifndef WF_TEX_MAX_DEPTH
 #define WF_TEX_MAX_DEPTH 2
 #endif
+// the three texture types a production scene's parameters usually are: what the material kernels and the traversal kernels' alpha test
+// evaluate inline
+WF_HD float EvalFloatTextureSimple(const SceneView &sv, const wf_texture &t, const TexCtx &tc) {
+    if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
+    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture(sv, t, tc);
+    // FloatBilerpTexture::Evaluate, textures.h:314-318
+    TexCoord2 c = TexMap2D(sv, t, tc);
+    const float v00 = t.f0, v01 = t.f1, v10 = t.map[10], v11 = t.map[11];
+    return (1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11;
+}
+WF_HD bool IsSimpleFloatTexture(int type) { return type == WF_TEX_FLOAT_CONSTANT || type == WF_TEX_FLOAT_IMAGE || type == WF_TEX_FLOAT_BILERP; }
 template <int D>
 WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
-    if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
-    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture(sv, t, tc);
-    if (t.type == WF_TEX_FLOAT_BILERP) {
-        // FloatBilerpTexture::Evaluate, textures.h:314-318
-        TexCoord2 c = TexMap2D(sv, t, tc);
-        const float v00 = t.f0, v01 = t.f1, v10 = t.map[10], v11 = t.map[11];
-        return (1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11;
+    if (IsSimpleFloatTexture(t.type)) return EvalFloatTextureSimple(sv, t, tc);
+    if (t.type == WF_TEX_FLOAT_FBM || t.type == WF_TEX_FLOAT_WRINKLED || t.type == WF_TEX_FLOAT_WINDY) {
+        TexCtx cc = tc;
+        wf_texture tt = t;
+        return NoiseFloatTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc);
     }
     if constexpr (D > 0) {
+        if (t.type == WF_TEX_FLOAT_DOTS) return EvalFloatTextureD<D - 1>(sv, InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0, tc);
         if (t.type == WF_TEX_FLOAT_SCALE) {
             // FloatScaledTexture::Evaluate, textures.h:1039-1044
             float sc = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
@@ -467,7 +571,7 @@ WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
             // FloatMixTexture::Evaluate (textures.h:810-818), FloatCheckerboardTexture::Evaluate (:370-378),
             // FloatDirectionMixTexture::Evaluate (:839-847: amt * tex1 + (1 - amt) * tex2 = this form with tex0 = "tex2")
             float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc)
-                      : t.type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : Checkerboard2D(sv, t, tc);
+                      : t.type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
             float t0 = 0, t1 = 0;
             if (w != 1) t0 = EvalFloatTextureD<D - 1>(sv, t.tex0, tc);
             if (w != 0) t1 = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
@@ -483,23 +587,33 @@ WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
 WF_NI float EvalFloatTextureGraphP(const SceneView *svp, int id, const TexCtx *tc) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(*svp, id, *tc); }
 WF_HD float EvalFloatTexture(const SceneView &sv, int id, const TexCtx &tc) {
     const int type = sv.textures[id].type;
-    if (type == WF_TEX_FLOAT_CONSTANT || type == WF_TEX_FLOAT_IMAGE || type == WF_TEX_FLOAT_BILERP) return EvalFloatTextureD<0>(sv, id, tc);
+    if (IsSimpleFloatTexture(type)) return EvalFloatTextureSimple(sv, sv.textures[id], tc);
     TexCtx tmp = tc;
     return EvalFloatTextureGraphP(sv.self, id, &tmp);
 }
+WF_HD S4 EvalSpectrumTextureSimple(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &tc) {
+    if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
+    if (t.type == WF_TEX_SPECTRUM_IMAGE) return EvalSpectrumImageTexture(sv, t, lambda, tc);
+    // SpectrumBilerpTexture::Evaluate (textures.h:340-344) through Bilerp(p, {v00, v10, v01, v11}) (util/math.h)
+    TexCoord2 c = TexMap2D(sv, t, tc);
+    S4 v00 = SpectrumSample(sv, t.spectrum, lambda), v10 = SpectrumSample(sv, t.tex0, lambda);
+    S4 v01 = SpectrumSample(sv, t.tex1, lambda), v11 = SpectrumSample(sv, t.tex2, lambda);
+    return ((1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11);
+}
+WF_HD bool IsSimpleSpectrumTexture(int type) { return type == WF_TEX_SPECTRUM_CONSTANT || type == WF_TEX_SPECTRUM_IMAGE || type == WF_TEX_SPECTRUM_BILERP; }
 template <int D>
 WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const wf_texture t = sv.textures[id];
-    if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
-    if (t.type == WF_TEX_SPECTRUM_IMAGE) return EvalSpectrumImageTexture(sv, t, lambda, tc);
-    if (t.type == WF_TEX_SPECTRUM_BILERP) {
-        // SpectrumBilerpTexture::Evaluate (textures.h:340-344) through Bilerp(p, {v00, v10, v01, v11}) (util/math.h)
-        TexCoord2 c = TexMap2D(sv, t, tc);
-        S4 v00 = SpectrumSample(sv, t.spectrum, lambda), v10 = SpectrumSample(sv, t.tex0, lambda);
-        S4 v01 = SpectrumSample(sv, t.tex1, lambda), v11 = SpectrumSample(sv, t.tex2, lambda);
-        return ((1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11);
+    if (IsSimpleSpectrumTexture(t.type)) return EvalSpectrumTextureSimple(sv, t, lambda, tc);
+    if (t.type == WF_TEX_SPECTRUM_MARBLE) {
+        TexCtx cc = tc;
+        wf_texture tt = t;
+        S4 r;
+        MarbleTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc, sv.rgb2specCoeffs, sv.rgb2specZNodes, lambda.lambda, r.v);
+        return r;
     }
     if constexpr (D > 0) {
+        if (t.type == WF_TEX_SPECTRUM_DOTS) return EvalSpectrumTextureD<D - 1>(sv, InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0, lambda, tc);
         if (t.type == WF_TEX_SPECTRUM_SCALE) {
             // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
             float sc = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
@@ -510,7 +624,7 @@ WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &la
             // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413),
             // SpectrumDirectionMixTexture::Evaluate (:880-890)
             float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc)
-                      : t.type == WF_TEX_SPECTRUM_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : Checkerboard2D(sv, t, tc);
+                      : t.type == WF_TEX_SPECTRUM_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
             S4 t0 = S4c(0.f), t1 = S4c(0.f);
             if (w != 1) t0 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc);
             if (w != 0) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda, tc);
@@ -524,7 +638,7 @@ WF_NI void EvalSpectrumTextureGraphP(const SceneView *svp, int id, const Wavelen
 }
 WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const int type = sv.textures[id].type;
-    if (type == WF_TEX_SPECTRUM_CONSTANT || type == WF_TEX_SPECTRUM_IMAGE || type == WF_TEX_SPECTRUM_BILERP) return EvalSpectrumTextureD<0>(sv, id, lambda, tc);
+    if (IsSimpleSpectrumTexture(type)) return EvalSpectrumTextureSimple(sv, sv.textures[id], lambda, tc);
     TexCtx tmp = tc;
     Wavelengths l = lambda;
     S4 r;

@@ -255,7 +255,7 @@ __device__ inline void FetchNode(const FastBVH &bvh, int node, U4 *n) {
 // what the general-primitive traversal variants call back into (wf_traverse.h LeafStep): the alpha test and the spheres
 // The general-primitive work of the traversal kernels comes in two strengths (template parameter GEN of the kernels):
 //   GEN = 1  "simple alpha": every alpha texture of the scene is a constant, an image map or a bilerp (no texture graph:
-//            EvalFloatTextureD<0>) and there are no quadrics.  The test is a real call into a small out-of-line function
+//            EvalFloatTextureSimple) and there are no quadrics.  The test is a real call into a small out-of-line function
 //            that reads the device-resident SceneView: the walk keeps its registers, the call is paid only when an
 //            alpha-tested triangle is actually hit.  (Foliage cut-outs are image maps: this is the san-miguel case.)
 //   GEN = 2  anything else (texture graphs as alpha, spheres / disks / cylinders): evaluated inline as before — an
@@ -274,7 +274,7 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
     TexCtx tc;
     tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
     tc.p = b0 * LoadP(sv, v[0]) + b1 * LoadP(sv, v[1]) + b2 * LoadP(sv, v[2]);
-    float a = EvalFloatTextureD<0>(sv, mesh.alpha_tex, tc);
+    float a = EvalFloatTextureSimple(sv, sv.textures[mesh.alpha_tex], tc);
     if (!(a < 1)) return true;
     float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(V3{ox, oy, oz}, V3{dx, dy, dz}));
     return !(u > a);
@@ -1031,6 +1031,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.tableData, d->table_data, (size_t)d->n_table_floats))) return e;
     if ((e = devUpload(ctx, &sv.rgb2specCoeffs, d->rgb2spec_coeffs, d->rgb2spec_coeffs ? (size_t)3 * 64 * 64 * 64 * 3 : (size_t)0))) return e;
     if ((e = devUpload(ctx, &sv.rgb2specZNodes, d->rgb2spec_znodes, (size_t)64))) return e;
+    if ((e = devUpload(ctx, &sv.noisePerm, d->noise_perm, d->noise_perm ? (size_t)512 : (size_t)0))) return e;
     sv.csIlluminantOffset = d->cs_illuminant_offset;
     if ((e = devUpload(ctx, &sv.media, d->media, (size_t)d->n_media))) return e;
     if ((e = devUpload(ctx, &sv.mediumData, d->medium_data, (size_t)d->n_medium_floats))) return e;

@@ -141,6 +141,7 @@ struct SceneTables {
     // wavefront geometry (integrator.cpp:227-236)
     int scanlinesPerPass = 0, maxQueueSize = 0, nPasses = 0;
     bool materialTypePresent[WF_MAT_NTYPES] = {};
+    std::vector<int32_t> noisePerm;  // the Perlin permutation (data/noise_perm.txt) when a texture or medium uses noise
     void Finalize();  // fills desc pointers/counters from the vectors
     // on-disk cache of the built tables: one flat file, every array verbatim.  Load() returns false when the
     // file is missing, truncated or from another ABI / build of the table builder.

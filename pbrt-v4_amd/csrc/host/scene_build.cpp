@@ -58,6 +58,7 @@ void SceneTables::Finalize() {
     desc.n_image_lights = (int)imageLights.size(); desc.image_lights = imageLights.data();
     desc.n_tex_images = (int)texImages.size(); desc.tex_images = texImages.data();
     desc.n_table_floats = (int)tableData.size(); desc.table_data = tableData.data();
+    desc.noise_perm = noisePerm.empty() ? nullptr : noisePerm.data();
     desc.n_media = (int)media.size(); desc.media = media.data();
     desc.n_medium_floats = (int)mediumData.size(); desc.medium_data = mediumData.data();
 }
@@ -88,7 +89,7 @@ bool SceneTables::Save(const std::string &path) const {
     putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
     putVec(f, haltonPerms); putVec(f, bvhNodes); putVec(f, pool.spectra); putVec(f, pool.data); putVec(f, textures); putVec(f, materials);
     putVec(f, lights); putVec(f, lightBvh); putVec(f, lightTransforms); putVec(f, filterData); putVec(f, powerAlias); putVec(f, imageLights);
-    putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile);
+    putVec(f, noisePerm); putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile);
     int32_t sc[8] = {nTopBvhNodes, nTopPrims, saveFP16 ? 1 : 0, spp, scanlinesPerPass, maxQueueSize, nPasses, desc.rgb2spec_coeffs ? 1 : 0};
     fwrite(sc, 4, 8, f);
     fwrite(materialTypePresent, sizeof(materialTypePresent), 1, f);
@@ -109,7 +110,7 @@ bool SceneTables::Load(const std::string &path) {
          getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
          getVec(f, haltonPerms) && getVec(f, bvhNodes) && getVec(f, pool.spectra) && getVec(f, pool.data) && getVec(f, textures) && getVec(f, materials) &&
          getVec(f, lights) && getVec(f, lightBvh) && getVec(f, lightTransforms) && getVec(f, filterData) && getVec(f, powerAlias) && getVec(f, imageLights) &&
-         getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile);
+         getVec(f, noisePerm) && getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile);
     int32_t sc[8];
     ok = ok && fread(sc, 4, 8, f) == 8 && fread(materialTypePresent, sizeof(materialTypePresent), 1, f) == 1;
     uint64_t end = 0;
@@ -126,6 +127,20 @@ bool SceneTables::Load(const std::string &path) {
 namespace {
 
 // ---- textures & materials ---------------------------------------------------------------------------
+// the Perlin permutation of util/noise.cpp (data/noise_perm.txt, written by tools/extract_noise_perm.py)
+static void LoadNoisePerm(SceneTables *T) {
+    if (!T->noisePerm.empty()) return;
+    std::ifstream f(SpectralData::Get().DataDir() + "/noise_perm.txt");
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        int v;
+        while (ls >> v) T->noisePerm.push_back(v);
+    }
+    if (T->noisePerm.size() != 512) Die("", "data/noise_perm.txt: expected the 512-entry Perlin permutation (tools/extract_noise_perm.py)");
+}
+
 struct TexBuilder {
     SceneTables *T;
     std::map<std::string, int> floatTextures, spectrumTexturesAlbedo, spectrumTexturesUnbounded, spectrumTexturesIllum;
@@ -224,9 +239,24 @@ struct TexBuilder {
         t->xform = (int)T->lightTransforms.size();
         T->lightTransforms.push_back(te.renderFromTexture.abi());
     }
+    // TextureMapping3D::Create (textures.cpp:75-79): PointTransformMapping(Inverse(renderFromTexture))
+    void SetMapping3D(const TextureEntity &te, wf_texture *t) {
+        t->mapping = WF_TEXMAP_POINT3D;
+        t->xform = (int)T->lightTransforms.size();
+        T->lightTransforms.push_back(te.renderFromTexture.abi());
+    }
+    void NeedNoise() { LoadNoisePerm(T); }
+    void NeedSRGBTable() {
+        if (T->desc.rgb2spec_coeffs) return;
+        const ColorSpace *cs = SpectralData::Get().sRGB();
+        T->desc.rgb2spec_coeffs = cs->table->coeffs.data();
+        for (int i = 0; i < 64; ++i) T->desc.rgb2spec_znodes[i] = cs->table->zNodes[i];
+    }
     void CheckerMapping(const TextureEntity &te, wf_texture *t) {
-        if (te.params.GetOneInt("dimension", 2) != 2) Die(te.loc, "3D checkerboard textures are not supported by this build");
-        SetMapping2D(te, t);
+        int dim = te.params.GetOneInt("dimension", 2);
+        if (dim != 2 && dim != 3) Die(te.loc, std::to_string(dim) + " dimensional checkerboard texture not supported");
+        if (dim == 2) SetMapping2D(te, t);
+        else SetMapping3D(te, t);
     }
     // ImageTextureBase ctor + MIPMap::CreateFromFile + Image::GeneratePyramid (textures.h:528-550, util/mipmap.cpp:163-206,
     // util/image.cpp GeneratePyramid) for float .pfm images with power-of-two resolution
@@ -351,6 +381,25 @@ struct TexBuilder {
                     t.map[4] = dir.x; t.map[5] = dir.y; t.map[6] = dir.z;
                     t.tex1 = GetFloatTexture(ps, "tex1", 0.f);
                     t.tex0 = GetFloatTexture(ps, "tex2", 1.f);
+                } else if (te.name == "fbm" || te.name == "wrinkled") {
+                    // FBmTexture::Create / WrinkledTexture::Create (textures.cpp:343-351, 980-988)
+                    NeedNoise();
+                    SetMapping3D(te, &t);
+                    t.type = te.name == "fbm" ? WF_TEX_FLOAT_FBM : WF_TEX_FLOAT_WRINKLED;
+                    t.i0 = ps.GetOneInt("octaves", 8);
+                    t.f0 = ps.GetOneFloat("roughness", .5f);
+                } else if (te.name == "windy") {
+                    NeedNoise();
+                    SetMapping3D(te, &t);
+                    t.type = WF_TEX_FLOAT_WINDY;
+                } else if (te.name == "dots") {
+                    // FloatDotsTexture::Create (textures.cpp:305-315) hands ("inside", "outside") to a constructor declared
+                    // (mapping, outsideDot, insideDot) (textures.h:429-431): inside a dot the reference evaluates the "outside" parameter
+                    NeedNoise();
+                    SetMapping2D(te, &t);
+                    t.type = WF_TEX_FLOAT_DOTS;
+                    t.tex0 = GetFloatTexture(ps, "inside", 1.f);
+                    t.tex1 = GetFloatTexture(ps, "outside", 0.f);
                 } else Die(te.loc, te.name + ": float texture type not supported by this build");
                 if (floatTextures.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
                 floatTextures[te.texName] = AddTex(t);
@@ -403,6 +452,23 @@ struct TexBuilder {
                         t.map[4] = dir.x; t.map[5] = dir.y; t.map[6] = dir.z;
                         t.tex1 = GetSpectrumTexture(ps, "tex1", *MakeConstant(0.f), st);
                         t.tex0 = GetSpectrumTexture(ps, "tex2", *MakeConstant(1.f), st);
+                    } else if (te.name == "marble") {
+                        // MarbleTexture::Create (textures.cpp:511-520); the same texture for every SpectrumType
+                        NeedNoise();
+                        NeedSRGBTable();
+                        SetMapping3D(te, &t);
+                        t.type = WF_TEX_SPECTRUM_MARBLE;
+                        t.i0 = ps.GetOneInt("octaves", 8);
+                        t.f0 = ps.GetOneFloat("roughness", .5f);
+                        t.f1 = ps.GetOneFloat("scale", 1.f);
+                        t.map[10] = ps.GetOneFloat("variation", .2f);
+                    } else if (te.name == "dots") {
+                        // SpectrumDotsTexture::Create (textures.cpp:322-334): same argument swap as the float variant
+                        NeedNoise();
+                        SetMapping2D(te, &t);
+                        t.type = WF_TEX_SPECTRUM_DOTS;
+                        t.tex0 = GetSpectrumTexture(ps, "inside", *MakeConstant(1.f), st);
+                        t.tex1 = GetSpectrumTexture(ps, "outside", *MakeConstant(0.f), st);
                     } else Die(te.loc, te.name + ": spectrum texture type not supported by this build");
                     auto &m = SpecMap(st);
                     if (st == SpectrumType::Albedo && m.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
@@ -975,7 +1041,21 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
                         float maxSigma_t = (a.empty() ? 1 : gridMax(maxA, lo, hi)) + (s.empty() ? 1 : gridMax(maxS, lo, hi));
                         T->mediumData.push_back(M.sigma_scale * maxSigma_t);
                     }
-        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid, rgbgrid)");
+        } else if (e.name == "cloud") {
+            // CloudMedium::Create (media.cpp:462-484): no "scale", no emission
+            M.type = WF_MEDIUM_CLOUD;
+            M.sigma_a_offset = dense(*sig_a, 1.f);
+            M.sigma_s_offset = dense(*sig_s, 1.f);
+            M.le_offset = M.sigma_a_offset;
+            M.cloud_density = ps.GetOneFloat("density", 1.f);
+            M.cloud_wispiness = ps.GetOneFloat("wispiness", 1.f);
+            M.cloud_frequency = ps.GetOneFloat("frequency", 5.f);
+            V3 p0 = ps.GetOnePoint3f("p0", V3{0, 0, 0}), p1 = ps.GetOnePoint3f("p1", V3{1, 1, 1});
+            // Bounds3f(p0, p1): componentwise min / max
+            for (int c = 0; c < 3; ++c) { M.bounds[c] = std::min(p0[c], p1[c]); M.bounds[3 + c] = std::max(p0[c], p1[c]); }
+            M.render_from_medium = scene.mediaTransforms.at(nm.first).abi();
+            LoadNoisePerm(T);
+        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid, rgbgrid, cloud)");
         (*ids)[nm.first] = (int)T->media.size();
         T->media.push_back(M);
     }
