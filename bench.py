@@ -54,6 +54,8 @@ def make_scene(path, spp, workload="sanmiguel-like", meshes=2000):
     import make_scenes
     if workload == "sanmiguel-like":
         return make_scenes.sanmiguel_like(path, (W, H), spp, n_meshes=meshes, n_defs=max(1, meshes // 10))
+    elif workload == "tm-like":
+        return make_scenes.tm_like(path, (W, H), spp)
     elif workload == "cloud-like":
         make_scenes.cloud_like(path, (W, H), spp)
     else:
@@ -100,12 +102,15 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="sample indices carried per pass (0 = automatic, ~64 M rays in flight)")
-    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like"], default="sanmiguel-like",
+    ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like", "tm-like"], default="sanmiguel-like",
                     help="sanmiguel-like = BASELINE configs[2] stand-in at the SURVEY 8(d) spec (default: the north_star target config); "
-                         "killeroo-like = configs[1] stand-in; cloud-like = configs[3] stand-in")
+                         "killeroo-like = configs[1] stand-in; cloud-like = configs[3] stand-in; tm-like = configs[4] stand-in (3840x2160, maxdepth 50)")
     ap.add_argument("--partition", choices=["strips", "samples"], default="strips", help="N > 1: interleaved scanline strips (default) or sample indices")
     ap.add_argument("--meshes", type=int, default=2000, help="sanmiguel-like: number of 5000-triangle meshes (2000 = 10 M unique triangles)")
     a = ap.parse_args()
+    global W, H
+    if a.workload == "tm-like":
+        W, H = 3840, 2160
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,7 +211,7 @@ def main():
     if rank == 0:
         samples = float(info.width) * info.height * K
         out = {
-            "metric": "Msamples/sec (whole node), 1920x1080 at fixed spp",
+            "metric": "Msamples/sec (whole node), %dx%d at fixed spp" % (W, H),
             "value": samples / T / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -220,7 +225,11 @@ def main():
             "data": "synthetic",
             "mray_per_s": total_rays / T / 1e6,
             "load_s": {"generate_scene_files": round(t_gen, 2), "parse_and_host_bvh_build": round(t_parse, 2), "upload_and_device_layout": round(t_upload, 2)},
-            "config": {"workload": ("killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
+            "config": {"workload": ("Transparent Machines 4K 1024spp (BASELINE.json configs[4]) on the tm-like stand-in (SURVEY 8(d) row 5: nested dielectric shells "
+                                    "eta 1.3-1.7, a quarter of them rough, coated-conductor frames, 2000 small area lights, image infinite light): %d triangles, "
+                                    "maxdepth %d, zsobol; step = 1 sample index x 3840x2160"
+                                    if a.workload == "tm-like" else
+                                    "killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
                                     "diffuse + dielectric, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
                                     if a.workload == "killeroo-like" else
                                     "Disney cloud 1080p (BASELINE.json configs[3]) on the cloud-like stand-in (64^3 uniformgrid medium, g = 0.877, "
