@@ -33,7 +33,7 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS,
+    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS, CNT_CURSOR,
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -110,6 +110,7 @@ struct WorkState {
     F4 *scatterP;  // per ray slot: scattering point p.xyz, HG g
     int32_t *mixMat;  // per ray slot: the material id a MixMaterial hit resolved to (allocated when sv.haveMix)
     int32_t *mixQ;    // HIP traversal kernel only: hits on a MixMaterial, resolved by the kernel that follows it
+    uint32_t *routeCode;  // HIP traversal kernel only (split routing): per ray slot, the hit primitive's routing code | ROUTE_SKIP
     int32_t *retraceQ;  // HIP traversal kernel only: rays whose closest hit was a near-tie (wf_traverse.h), re-traced in reference order
     int32_t *matQ[WF_MAT_NTYPES];
     struct BssrdfItem *bssrdfQ;       // GetBSSRDFAndProbeRayQueue / SubsurfaceScatterQueue (K12; allocated when sv.haveSubsurface)

@@ -67,6 +67,10 @@ struct wf_ctx {
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels
     // ray-coherence pass (SortRayQueue): bit 0 sorts the ray queue before the closest-hit launch of depth >= 1, bit 1 the shadow queue
     int raySort = 0;
+    int cursorChunk = 2;         // 64-ray batches a wave takes per cursor fetch (WF_CURSOR_CHUNK): 1 is best on the 10 M-triangle scene
+                                 // (-3 %), but on a 30 k-triangle scene one fetch per 64 rays is 83 atomics/us on one counter: the kernel's bound
+    int splitRoute = 2;          // WF_SPLIT_ROUTE: 0 = the closest-hit walk routes its hits per workgroup (KRouteHitBlock inside the walk);
+                                 // 1 = walk without the workgroup barrier + k_route_hits; 2 (default) = 1 + waves draw their rays from a shared cursor
     int sortMin = 4096;
     int sortOriginBits = 6, sortDirBits = 4;  // per axis of the origin grid / per axis of the octahedral direction map
     float sceneMin[3] = {0, 0, 0}, sceneMax[3] = {0, 0, 0};  // bounds of the top-level BVH
@@ -304,10 +308,30 @@ struct GeneralPrims {
     }
 };
 template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
-__device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish) {
+__device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
     LoadTreeTop(bvh);
-    for (int base = blockIdx.x * TBLOCK; base < n; base += gridDim.x * TBLOCK) {
-        const int idx = base + threadIdx.x;
+    // cursor != nullptr (only when `finish` has no workgroup barrier): every wave takes its next `chunk` x 64 rays from a shared
+    // cursor, so a wave with short walks serves more of the queue and the launch ends without a tail of waves that drew long ones
+    // (one returning atomic per chunk x 64 rays: a counter sustains ~88 of them per microsecond)
+    // (a queue shorter than two rounds of the resident grid is dealt statically: every wave starts at once, no atomics)
+    if (n < 2 * (int)gridDim.x * TBLOCK) cursor = nullptr;
+    int chunkBase = 0, chunkSub = chunk;
+    for (int base = blockIdx.x * TBLOCK; true; base += gridDim.x * TBLOCK) {
+        int idx;
+        if (cursor) {
+            if (chunkSub == chunk) {
+                int b = 0;
+                if ((threadIdx.x & 63) == 0) b = atomicAdd(cursor, 64 * chunk);
+                chunkBase = __shfl(b, 0);
+                chunkSub = 0;
+            }
+            if (chunkBase + chunkSub * 64 >= n) break;
+            idx = chunkBase + chunkSub * 64 + (threadIdx.x & 63);
+            ++chunkSub;
+        } else {
+            if (base >= n) break;
+            idx = base + threadIdx.x;
+        }
         const bool valid = idx < n;
         RayWalk w;
         w.node = NODE_NONE;
@@ -359,8 +383,13 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
     }
 }
 
-template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill) {
+// SPLIT = false: a workgroup routes its 256 hits together at the end of every batch (KRouteHitBlock: one atomic per destination queue
+// per workgroup) — its four waves wait for the slowest walk of the 256.  SPLIT = true: the walk only records the hit (ws.hit, hitInst,
+// hitT, routeCode) and k_route_hits pushes the queue entries afterwards in one streaming pass; waves never meet, so a wave whose 64
+// walks are done moves on to its next 64 rays while the others still walk.
+constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes this ray
+template <int GEN, bool INST = false, bool SPLIT = false>
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
@@ -378,8 +407,42 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_c
                 ws.retraceQ[atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1)] = i;
                 ws.hit[i] = F4{0, 2 * WalkBound(bvh, WalkT(w)) - WalkT(w), 0, 0};  // the re-trace's starting bound, see k_closest_retrace
             }
+            if constexpr (SPLIT) {
+                if (!valid) return;
+                ws.routeCode[i] = amb ? ROUTE_SKIP : (uint32_t)w.route;
+                if (amb) return;
+                ws.hit[i] = F4{BitsToFloat((uint32_t)w.prim), w.b0, w.b1, w.b2};
+                if (INST) ws.hitInst[i] = w.prim >= 0 ? w.inst : -1;
+                if (sv.haveMedia) ws.hitT[i] = w.prim >= 0 ? WalkT(w) : WF_INFINITY;
+            } else
             KRouteHitBlock<(GEN > 1) || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
-        });
+        }, SPLIT ? cursor : nullptr, chunk);
+}
+// the routing pass of the SPLIT traversal: EnqueueWorkAfterIntersection / Miss for every ray of the queue (block-aggregated pushes)
+// (1024 threads per workgroup: one returning atomic per destination queue per 1024 rays — a queue counter sustains ~88 of them per
+// microsecond, which at 256 rays per workgroup was the whole cost of this pass)
+constexpr int RBLOCK = 1024;
+template <bool GENERAL>
+__global__ void __launch_bounds__(RBLOCK) k_route_hits(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
+    for (int base = blockIdx.x * RBLOCK; base < n; base += gridDim.x * RBLOCK) {
+        const int i = base + threadIdx.x;
+        bool valid = i < n;
+        uint32_t route = 0;
+        F4 h{0, 0, 0, 0};
+        int inst = -1;
+        float tHit = 0;
+        if (valid) {
+            route = ws.routeCode[i];
+            if (route & ROUTE_SKIP) valid = false;
+            else {
+                h = ws.hit[i];
+                if (sv.nInstances > 0) inst = ws.hitInst[i];
+                if (sv.haveMedia) tHit = ws.hitT[i];
+            }
+        }
+        KRouteHitBlock<GENERAL>(sv, ws, cur, i, valid, (int)FloatToBits(h.x), route, tHit, h.y, h.z, h.w, inst);
+    }
 }
 // ---- ray-coherence pass -----------------------------------------------------------------------------------------
 // Rays past the first bounce arrive in the order the material kernels pushed them: neighbouring lanes start anywhere in the scene and
@@ -500,7 +563,7 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
 }
 template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};
@@ -510,7 +573,7 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_s
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
         },
-        [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); });
+        [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); }, cursor, chunk);
 }
 
 // GENERAL: the scene has alpha-tested triangles or quadrics (the variant the render uses then)
@@ -722,6 +785,14 @@ struct Prof {
             if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); } \
             else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); } \
         }                                                                                                      \
+    } while (0)
+// the closest-hit walk with the routing split off (ctx->splitRoute)
+#define LAUNCHT_CLOSEST_SPLIT(name, ...)                                                                       \
+    do {                                                                                                       \
+        const int gen_ = ctx->genMode;                                                                         \
+        const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
+        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); } \
+        else { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, false, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, false, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<2, false, true>), __VA_ARGS__); } \
     } while (0)
 #define LAUNCHT(name, kernel, grid, ...)                                                   \
     do {                                                                                   \
@@ -1198,6 +1269,9 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if ((e = devAlloc(ctx, &ws.sq.o, n)) || (e = devAlloc(ctx, &ws.sq.d, n)) || (e = devAlloc(ctx, &ws.sq.Ld, n)) ||
         (e = devAlloc(ctx, &ws.sq.r_u, n)) || (e = devAlloc(ctx, &ws.sq.r_l, n)))
         return e;
+    ctx->splitRoute = getenv("WF_SPLIT_ROUTE") ? atoi(getenv("WF_SPLIT_ROUTE")) : 2;
+    if (getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = std::max(1, atoi(getenv("WF_CURSOR_CHUNK")));
+    if (ctx->splitRoute && (e = devAlloc(ctx, &ws.routeCode, n))) return e;
     ctx->raySort = getenv("WF_RAY_SORT") ? atoi(getenv("WF_RAY_SORT")) : 0;
     if (!ctx->fastOk) ctx->raySort = 0;
     if (ctx->raySort) {
@@ -1330,6 +1404,20 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     else if (ctx->fastOk) {
         if ((ctx->raySort & 1) && depth >= 1)
             if (int e = SortQueue(ctx, false, depth & 1)) return e;
+        if (ctx->splitRoute) {
+            int *cursor = nullptr;
+            if (ctx->splitRoute > 1) {
+                cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
+                HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+            }
+            LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill, cursor, ctx->cursorChunk);
+            {
+                Prof prof_(ctx, "Route hits");
+                const int g = std::min(MAX_GRID, std::max(1, (ctx->maxQueueSize + RBLOCK - 1) / RBLOCK));
+                if (ctx->genMode > 1 || ctx->svHost.nInstances > 0) hipLaunchKernelGGL(k_route_hits<true>, dim3(g), dim3(RBLOCK), 0, ctx->stream, ctx->svHost, ctx->ws, depth & 1);
+                else hipLaunchKernelGGL(k_route_hits<false>, dim3(g), dim3(RBLOCK), 0, ctx->stream, ctx->svHost, ctx->ws, depth & 1);
+            }
+        } else
         LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
@@ -1401,7 +1489,12 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     else if (ctx->fastOk) {
         if ((ctx->raySort & 2) && (depth >= 1 || (ctx->raySort & 4)))
             if (int e = SortQueue(ctx, true, 0)) return e;
-        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        int *cursor = nullptr;
+        if (ctx->splitRoute > 1) {
+            cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
+            HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+        }
+        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill, cursor, ctx->cursorChunk);
     } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
