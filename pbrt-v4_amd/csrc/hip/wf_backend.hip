@@ -64,7 +64,9 @@ struct wf_ctx {
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything (see GeneralPrims)
-    int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels
+    int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
+    int persistentGridShadow = 1024;
+    static bool splitRouteWanted() { return !getenv("WF_SPLIT_ROUTE") || atoi(getenv("WF_SPLIT_ROUTE")) != 0; }
     // ray-coherence pass (SortRayQueue): bit 0 sorts the ray queue before the closest-hit launch of depth >= 1, bit 1 the shadow queue
     int raySort = 0;
     int cursorChunk = 2;         // 64-ray batches a wave takes per cursor fetch (WF_CURSOR_CHUNK): 1 is best on the 10 M-triangle scene
@@ -1185,14 +1187,30 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             ctx->fast.instances = ctx->svHost.instances;
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
-        int perCU = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_closest_fast<0, false>, TBLOCK, 0));
+        // resident workgroups of the traversal kernel variants this scene launches (closest-hit and shadow differ in registers)
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-        int g = std::max(1, perCU) * prop.multiProcessorCount;
-        if (const char *m = getenv("WF_PGRID_MULT")) g = (int)(g * atof(m));
         const int maxG = MAX_GRID * BLOCK / TBLOCK;  // stackSpill is sized for MAX_GRID * BLOCK threads
-        ctx->persistentGrid = g > maxG ? maxG : (g < 1 ? 1 : g);
+        auto residentGrid = [&](const void *kernel, int *out) {
+            int perCU = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, TBLOCK, 0));
+            int g = std::max(1, perCU) * prop.multiProcessorCount;
+            if (const char *m = getenv("WF_PGRID_MULT")) g = (int)(g * atof(m));
+            *out = g > maxG ? maxG : (g < 1 ? 1 : g);
+            return 0;
+        };
+        {
+            const int gen = ctx->genMode;
+            const bool inst = ctx->svHost.nInstances > 0, split = ctx->splitRouteWanted();
+            const void *kc, *ks;
+#define WF_PICK(K, ...) (inst ? (gen == 0 ? (const void *)K<0, true __VA_ARGS__> : gen == 1 ? (const void *)K<1, true __VA_ARGS__> : (const void *)K<2, true __VA_ARGS__>) \
+                              : (gen == 0 ? (const void *)K<0, false __VA_ARGS__> : gen == 1 ? (const void *)K<1, false __VA_ARGS__> : (const void *)K<2, false __VA_ARGS__>))
+            if (split) kc = WF_PICK(k_closest_fast, , true);
+            else kc = WF_PICK(k_closest_fast, , false);
+            ks = WF_PICK(k_shadow_fast);
+#undef WF_PICK
+            if ((e = residentGrid(kc, &ctx->persistentGrid)) || (e = residentGrid(ks, &ctx->persistentGridShadow))) return e;
+        }
         if (getenv("WF_NO_FAST")) ctx->fastOk = false;
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
     }
@@ -1494,7 +1512,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
             cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
             HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
         }
-        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill, cursor, ctx->cursorChunk);
+        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill, cursor, ctx->cursorChunk);
     } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
