@@ -355,7 +355,7 @@ typedef struct wf_film {
 } wf_film;
 
 enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1, WF_SAMPLER_STRATIFIED = 2, WF_SAMPLER_PADDED_SOBOL = 3,
-                       WF_SAMPLER_HALTON = 4 };
+                       WF_SAMPLER_HALTON = 4, WF_SAMPLER_SOBOL = 5 /* samplers.h:479-565: needs wf_scene_desc.sobol_matrices */ };
 enum wf_randomize { WF_RAND_NONE = 0, WF_RAND_PERMUTE_DIGITS = 1, WF_RAND_FAST_OWEN = 2, WF_RAND_OWEN = 3 };
 typedef struct wf_sampler {
     int32_t type;
@@ -365,6 +365,7 @@ typedef struct wf_sampler {
     int32_t log2spp, nBase4Digits;        /* ZSobol (samplers.h:228-240) */
     int32_t x_samples, y_samples, jitter; /* Stratified (samplers.h:503-575) */
     int32_t halton_base_scales[2], halton_base_exponents[2], halton_mult_inverse[2]; /* Halton (samplers.cpp:32-52) */
+    int32_t sobol_scale;                  /* SobolSampler: RoundUpPow2(max(full resolution)) (samplers.h:489) */
 } wf_sampler;
 
 enum wf_light_sampler_type { WF_LS_UNIFORM = 0, WF_LS_POWER = 1, WF_LS_BVH = 2 };
@@ -429,6 +430,10 @@ typedef struct wf_scene_desc {
     const struct wf_medium *media;
     const float *medium_data;    /* density / Lescale / majorant grids */
     /* HaltonSampler tables (util/primes.h, util/lowdiscrepancy.h:26-62): null unless the sampler is WF_SAMPLER_HALTON */
+    /* SobolSampler tables (util/sobolmatrices.cpp; data/sobol_matrices.bin): null unless the sampler is WF_SAMPLER_SOBOL */
+    const uint32_t *sobol_matrices;      /* SobolMatrices32 [1024][52] */
+    const uint64_t *vdc_sobol;           /* VdCSobolMatrices [25][52] */
+    const uint64_t *vdc_sobol_inv;       /* VdCSobolMatricesInv [26][52] */
     const int32_t *halton_primes;        /* [1000] */
     const int32_t *halton_perm_offsets;  /* [1000] start of dimension d's nDigits x base digit permutations */
     const uint16_t *halton_perms;

@@ -88,6 +88,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.matTypeMask = 0;
     sv.quadrics = d.quadrics; sv.nQuadrics = d.n_quadrics;
     sv.instances = d.instances; sv.instanceDefs = d.instance_defs; sv.nInstances = d.n_instances;
+    sv.sobolMatrices = d.sobol_matrices; sv.vdcSobol = d.vdc_sobol; sv.vdcSobolInv = d.vdc_sobol_inv;
     sv.haltonPrimes = d.halton_primes; sv.haltonPermOffsets = d.halton_perm_offsets; sv.haltonPerms = d.halton_perms;
     sv.haveMix = 0;
     sv.haveSubsurface = 0;

@@ -207,13 +207,33 @@ struct PixelSampler {
     const int32_t *primes, *permOffsets;
     const uint16_t *perms;
     int64_t haltonIndex = 0;
+    // SobolSampler (samplers.h:479-565)
+    const uint32_t *sobolM;
+    const uint64_t *vdc, *vdcInv;
+    int sobolScale;
+    int64_t sobolIndex = 0;
 
     WF_HD PixelSampler(const SceneView &sv)
         : z(sv), type(sv.sampler.type), spp(sv.sampler.spp), seed(sv.sampler.seed), randomize(sv.sampler.randomize),
           xs(sv.sampler.x_samples), ys(sv.sampler.y_samples), jitter(sv.sampler.jitter), sobol(sv.sobol),
           hbs0(sv.sampler.halton_base_scales[0]), hbs1(sv.sampler.halton_base_scales[1]), hbe0(sv.sampler.halton_base_exponents[0]),
           hbe1(sv.sampler.halton_base_exponents[1]), hmi0(sv.sampler.halton_mult_inverse[0]), hmi1(sv.sampler.halton_mult_inverse[1]),
-          primes(sv.haltonPrimes), permOffsets(sv.haltonPermOffsets), perms(sv.haltonPerms) {}
+          primes(sv.haltonPrimes), permOffsets(sv.haltonPermOffsets), perms(sv.haltonPerms), sobolM(sv.sobolMatrices), vdc(sv.vdcSobol),
+          vdcInv(sv.vdcSobolInv), sobolScale(sv.sampler.sobol_scale) {}
+    // SobolSample over the full table (util/lowdiscrepancy.h:167-181) + SobolSampler::SampleDimension (samplers.h:544-557)
+    WF_HD float SobolDimension(int dim) const {
+        uint32_t v = 0;
+        int64_t a = sobolIndex;
+        for (int i = dim * 52; a != 0; a >>= 1, i++)
+            if (a & 1) v ^= sobolM[i];
+        if (randomize != WF_RAND_NONE) {
+            uint32_t hash = (uint32_t)Hash2i(dim, seed);
+            if (randomize == WF_RAND_PERMUTE_DIGITS) v = hash ^ v;
+            else if (randomize == WF_RAND_FAST_OWEN) v = FastOwenScramble(v, hash);
+            else v = OwenScramble(v, hash);
+        }
+        return fmin(v * 0x1p-32f, OneMinusEpsilon);
+    }
     WF_HD float HaltonDimension(int dim) const {
         unsigned base = (unsigned)primes[dim];
         if (randomize == WF_RAND_NONE) return RadicalInverseBase(base, (uint64_t)haltonIndex);
@@ -245,6 +265,24 @@ struct PixelSampler {
             return;
         }
         px = x; py = y; sampleIndex = index; dimension = dim;
+        if (type == WF_SAMPLER_SOBOL) {
+            // samplers.h:502-506 + SobolIntervalToIndex (util/lowdiscrepancy.h:266-286)
+            dimension = dim > 2 ? dim : 2;
+            uint32_t m = 0;
+            while ((1 << (m + 1)) <= sobolScale) ++m;  // Log2Int(scale)
+            uint64_t frame = (uint64_t)index;
+            if (m == 0) { sobolIndex = (int64_t)frame; return; }
+            const uint32_t m2 = m << 1;
+            uint64_t idx = frame << m2;
+            uint64_t delta = 0;
+            for (int c = 0; frame; frame >>= 1, ++c)
+                if (frame & 1) delta ^= vdc[(m - 1) * 52 + c];
+            uint64_t b = ((((uint64_t)((uint32_t)x)) << m) | ((uint32_t)y)) ^ delta;
+            for (int c = 0; b; b >>= 1, ++c)
+                if (b & 1) idx ^= vdcInv[(m - 1) * 52 + c];
+            sobolIndex = (int64_t)idx;
+            return;
+        }
         if (type != WF_SAMPLER_PADDED_SOBOL) {
             rng.SetSequence(HashPixelSeed(x, y, seed));
             rng.Advance(index * 65536ull + dim);
@@ -257,6 +295,10 @@ struct PixelSampler {
         if (type == WF_SAMPLER_HALTON) {
             if (dimension >= 1000) dimension = 2;
             return HaltonDimension(dimension++);
+        }
+        if (type == WF_SAMPLER_SOBOL) {
+            if (dimension >= 1024) dimension = 2;
+            return SobolDimension(dimension++);
         }
         if (type == WF_SAMPLER_INDEPENDENT) return rng.UniformFloat();
         uint64_t hash = HashPixelDimSeed(px, py, dimension, seed);
@@ -280,6 +322,12 @@ struct PixelSampler {
             float a = HaltonDimension(dim), b = HaltonDimension(dim + 1);
             return V2{a, b};
         }
+        if (type == WF_SAMPLER_SOBOL) {
+            if (dimension + 1 >= 1024) dimension = 2;
+            float a = SobolDimension(dimension), b = SobolDimension(dimension + 1);
+            dimension += 2;
+            return V2{a, b};
+        }
         if (type == WF_SAMPLER_INDEPENDENT) { float a = rng.UniformFloat(); float b = rng.UniformFloat(); return V2{a, b}; }
         uint64_t hash = HashPixelDimSeed(px, py, dimension, seed);
         if (type == WF_SAMPLER_STRATIFIED) {
@@ -297,6 +345,14 @@ struct PixelSampler {
     WF_HD V2 GetPixel2D() {
         if (type == WF_SAMPLER_HALTON)
             return V2{RadicalInverseBase(2, (uint64_t)(haltonIndex >> hbe0)), RadicalInverseBase(3, (uint64_t)(haltonIndex / hbs1))};
+        if (type == WF_SAMPLER_SOBOL) {
+            // samplers.h:525-536: dimensions 0 and 1 unscrambled, remapped to the pixel
+            const int keep = randomize;
+            randomize = WF_RAND_NONE;
+            float u0 = SobolDimension(0), u1 = SobolDimension(1);
+            randomize = keep;
+            return V2{Clamp(u0 * sobolScale - px, 0.f, OneMinusEpsilon), Clamp(u1 * sobolScale - py, 0.f, OneMinusEpsilon)};
+        }
         return Get2D();
     }
 };

@@ -55,6 +55,8 @@ struct SceneView {
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
     int texNeedsFootprint;  // some texture's value depends on the TextureEvalContext (checkerboard, image) or some material
                             // is bump- or normal-mapped: selects the material-kernel variant that computes the differentials
+    const uint32_t *sobolMatrices;   // SobolSampler: SobolMatrices32 [1024][52]
+    const uint64_t *vdcSobol, *vdcSobolInv;
     const int32_t *haltonPrimes, *haltonPermOffsets;
     const uint16_t *haltonPerms;
     const wf_quadric *quadrics;

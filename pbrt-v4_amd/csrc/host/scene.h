@@ -120,6 +120,8 @@ struct SceneTables {
     std::vector<wf_instance> instances;
     std::vector<wf_instance_def> instanceDefs;
     int nTopBvhNodes = 0, nTopPrims = 0;
+    std::vector<uint32_t> sobolMatrices;       // data/sobol_matrices.bin when the sampler is "sobol"
+    std::vector<uint64_t> vdcSobol, vdcSobolInv;
     std::vector<int32_t> haltonPrimes, haltonPermOffsets;
     std::vector<uint16_t> haltonPerms;
     std::vector<wf_bvh_node> bvhNodes;

@@ -41,6 +41,9 @@ void SceneTables::Finalize() {
     desc.n_instances = (int)instances.size(); desc.instances = instances.data();
     desc.n_instance_defs = (int)instanceDefs.size(); desc.instance_defs = instanceDefs.data();
     desc.n_top_bvh_nodes = nTopBvhNodes; desc.n_top_prims = nTopPrims;
+    desc.sobol_matrices = sobolMatrices.empty() ? nullptr : sobolMatrices.data();
+    desc.vdc_sobol = vdcSobol.empty() ? nullptr : vdcSobol.data();
+    desc.vdc_sobol_inv = vdcSobolInv.empty() ? nullptr : vdcSobolInv.data();
     desc.halton_primes = haltonPrimes.empty() ? nullptr : haltonPrimes.data();
     desc.halton_perm_offsets = haltonPermOffsets.empty() ? nullptr : haltonPermOffsets.data();
     desc.halton_perms = haltonPerms.empty() ? nullptr : haltonPerms.data();
@@ -86,7 +89,7 @@ bool SceneTables::Save(const std::string &path) const {
     fwrite(hdr, 8, 4, f);
     fwrite(&desc, sizeof(desc), 1, f);
     putVec(f, P); putVec(f, N); putVec(f, UV); putVec(f, triIndices); putVec(f, triMesh); putVec(f, bvhPrims); putVec(f, infiniteLights);
-    putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
+    putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, sobolMatrices); putVec(f, vdcSobol); putVec(f, vdcSobolInv); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
     putVec(f, haltonPerms); putVec(f, bvhNodes); putVec(f, pool.spectra); putVec(f, pool.data); putVec(f, textures); putVec(f, materials);
     putVec(f, lights); putVec(f, lightBvh); putVec(f, lightTransforms); putVec(f, filterData); putVec(f, powerAlias); putVec(f, imageLights);
     putVec(f, noisePerm); putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile);
@@ -107,7 +110,7 @@ bool SceneTables::Load(const std::string &path) {
     bool ok = fread(hdr, 8, 4, f) == 4 && hdr[0] == kTablesMagic && hdr[1] == (uint64_t)WF_ABI_VERSION && hdr[2] == sizeof(wf_scene_desc) && hdr[3] == sizeof(SceneTables);
     ok = ok && fread(&desc, sizeof(desc), 1, f) == 1;
     ok = ok && getVec(f, P) && getVec(f, N) && getVec(f, UV) && getVec(f, triIndices) && getVec(f, triMesh) && getVec(f, bvhPrims) && getVec(f, infiniteLights) &&
-         getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
+         getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, sobolMatrices) && getVec(f, vdcSobol) && getVec(f, vdcSobolInv) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
          getVec(f, haltonPerms) && getVec(f, bvhNodes) && getVec(f, pool.spectra) && getVec(f, pool.data) && getVec(f, textures) && getVec(f, materials) &&
          getVec(f, lights) && getVec(f, lightBvh) && getVec(f, lightTransforms) && getVec(f, filterData) && getVec(f, powerAlias) && getVec(f, imageLights) &&
          getVec(f, noisePerm) && getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile);
@@ -817,6 +820,34 @@ void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTable
         else Die(scene.sampler.loc, s + ": unknown randomization strategy given to PaddedSobolSampler");
         if (nsamp & (nsamp - 1)) fprintf(stderr, "Warning: Sobol samplers with non power-of-two sample counts (%d) are suboptimal.\n", nsamp);
         S.spp = nsamp;
+    } else if (scene.sampler.name == "sobol") {
+        // SobolSampler::Create + ctor (samplers.cpp:258-283, samplers.h:482-490)
+        S.type = WF_SAMPLER_SOBOL;
+        std::string s = ps.GetOneString("randomization", "fastowen");
+        if (s == "none") S.randomize = WF_RAND_NONE;
+        else if (s == "permutedigits") S.randomize = WF_RAND_PERMUTE_DIGITS;
+        else if (s == "fastowen") S.randomize = WF_RAND_FAST_OWEN;
+        else if (s == "owen") S.randomize = WF_RAND_OWEN;
+        else Die(scene.sampler.loc, s + ": unknown randomization strategy given to SobolSampler");
+        if (nsamp & (nsamp - 1)) fprintf(stderr, "Warning: Non power-of-two sample count %d will perform suboptimally with the SobolSampler.\n", nsamp);
+        S.spp = nsamp;
+        {
+            const ParamSet &fp = scene.film.params;
+            int rx = fp.GetOneInt("xresolution", 1280), ry = fp.GetOneInt("yresolution", 720);
+            int sc = 1;
+            while (sc < std::max(rx, ry)) sc *= 2;  // RoundUpPow2
+            S.sobol_scale = sc;
+        }
+        std::ifstream f(SpectralData::Get().DataDir() + "/sobol_matrices.bin", std::ios::binary);
+        uint32_t hdr[5] = {};
+        f.read((char *)hdr, sizeof(hdr));
+        if (!f || memcmp(hdr, "SOBM", 4) != 0 || hdr[1] != 1024 || hdr[2] != 52 || hdr[3] != 25 || hdr[4] != 26)
+            Die(scene.sampler.loc, "data/sobol_matrices.bin is missing or malformed (tools/extract_sobol_matrices.py)");
+        T->sobolMatrices.resize(1024 * 52); T->vdcSobol.resize(25 * 52); T->vdcSobolInv.resize(26 * 52);
+        f.read((char *)T->sobolMatrices.data(), T->sobolMatrices.size() * 4);
+        f.read((char *)T->vdcSobol.data(), T->vdcSobol.size() * 8);
+        f.read((char *)T->vdcSobolInv.data(), T->vdcSobolInv.size() * 8);
+        if (!f) Die(scene.sampler.loc, "data/sobol_matrices.bin is truncated");
     } else if (scene.sampler.name == "halton") {
         // HaltonSampler::Create + ctor (samplers.cpp:32-52,67-92)
         S.type = WF_SAMPLER_HALTON;
@@ -865,7 +896,7 @@ void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTable
                         T->haltonPerms.push_back((uint16_t)PermutationElement((uint32_t)digitValue, (uint32_t)base, (uint32_t)dseed));
                 }
             }
-    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, independent, stratified, paddedsobol, halton)");
+    } else Die(scene.sampler.loc, scene.sampler.name + ": sampler type not supported by this build (zsobol, sobol, independent, stratified, paddedsobol, halton)");
     T->spp = S.spp;
     ps.ReportUnused("Sampler");
 }

@@ -65,11 +65,13 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_ex
 # the same lights through the PowerLightSampler (alias table)
 sed 's/Integrator "volpath"/Integrator "volpath" "string lightsampler" [ "power" ]/' $G/materials_lights.pbrt > $G/materials_lights_power.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/materials_lights_power_ref.pfm $G/materials_lights_power.pbrt
-# the other pixel samplers on the Cornell box (scene defaults: independent 4 spp, stratified 4x4, paddedsobol 16, halton 16)
-for smp in independent stratified paddedsobol halton; do
+# the other pixel samplers on the Cornell box (scene defaults: independent 4 spp, stratified 4x4, paddedsobol 16, halton 16, sobol 16)
+for smp in independent stratified paddedsobol halton sobol; do
   sed "s/^Sampler \"zsobol\".*/Sampler \"$smp\"/" $G/cornell64.pbrt > $G/cornell64_$smp.pbrt
   oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/cornell64_${smp}_ref.pfm $G/cornell64_$smp.pbrt
 done
+sed 's/^Sampler "zsobol".*/Sampler "sobol" "string randomization" "owen" "integer pixelsamples" 8/' $G/cornell64.pbrt > $G/cornell64_sobol_owen.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/cornell64_sobol_owen_ref.pfm $G/cornell64_sobol_owen.pbrt
 # the named physical oracle (not sample-aligned): VolPathIntegrator at high spp, for mean comparisons
 oracle/_ref/pbrt_ref --quiet --seed 0 --spp 256 --outfile $G/cornell64_volpath256.pfm $G/cornell64.pbrt
 ls -la $G
