@@ -60,7 +60,7 @@ struct wf_ctx {
     const SceneView *svDev = nullptr;  // the same struct in device memory, for the out-of-line callbacks of the traversal kernels
     WorkState ws{};
     int maxQueueSize = 0;
-    int *stackSpill = nullptr;   // [STACK_MAX-STACK_LDS][MAX_GRID*BLOCK]
+    int *stackSpill = nullptr;   // [rows][MAX_GRID*BLOCK], rows from the trees' depths (wf_scene_upload)
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything (see GeneralPrims)
@@ -1167,7 +1167,29 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     ctx->H = d->film.pixel_max[1] - d->film.pixel_min[1];
     ctx->maxDepth = d->max_depth;
     for (int i = 0; i < 6; ++i) ctx->sceneBounds[i] = d->scene_bounds[i];
-    if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)(STACK_MAX - STACK_LDS) * MAX_GRID * BLOCK))) return e;
+    {
+        // traversal stacks: LDS entries per lane + rows of `stackSpill` behind them.  The rows are sized from the trees' depths: the
+        // reference-order walk pushes one sibling per level (top-level tree, then an instance definition's on top), the four-wide
+        // production walk up to three per level of its collapsed tree, plus the instance markers
+        auto treeDepth = [&](int root) {
+            int best = 0;
+            if (root < 0 || root >= d->n_bvh_nodes) return best;
+            std::vector<std::pair<int, int>> st{{root, 1}};
+            while (!st.empty()) {
+                auto [i, dep] = st.back();
+                st.pop_back();
+                best = std::max(best, dep);
+                if (d->bvh_nodes[i].nprims == 0) { st.push_back({i + 1, dep + 1}); st.push_back({d->bvh_nodes[i].offset, dep + 1}); }
+            }
+            return best;
+        };
+        int depthTop = d->n_bvh_nodes > 0 ? treeDepth(0) : 0, depthDef = 0;
+        for (int k = 0; k < d->n_instance_defs; ++k) depthDef = std::max(depthDef, treeDepth(d->instance_defs[k].bvh_root));
+        const int needRef = depthTop + depthDef + 4, needFast = 3 * ((depthTop + 1) / 2 + 1) + 3 * ((depthDef + 1) / 2 + 1) + 4;
+        const int rows = std::max(std::max(needRef - STACK_LDS, needFast - TSTACK), STACK_MAX - STACK_LDS);
+        if (rows > 2048) return fail(-1, "BVH too deep for the traversal stacks (depth %d + %d)", depthTop, depthDef);
+        if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)rows * MAX_GRID * BLOCK))) return e;
+    }
     {
         std::vector<QNode> qn;
         std::vector<LeafTri> lt;

@@ -1,7 +1,7 @@
 // parser.cpp — .pbrt (v4 syntax) tokenizer + directive interpreter.  Restates the behaviour of
 // src/pbrt/parser.cpp (tokenizer :140-330, parameter lists :434-600, directives :600-1000) and the
 // graphics-state bookkeeping of BasicSceneBuilder (src/pbrt/scene.cpp:80-620) for the static
-// (non-animated) subset: the CTM is a single transform, ActiveTransform/TransformTimes are accepted
+// (non-animated) subset: ActiveTransform is tracked (start- and end-time CTM); creating something where the two differ is refused; TransformTimes are accepted
 // and ignored.
 #include "scene.h"
 
@@ -270,7 +270,9 @@ static int ParseIntTok(const std::string &t, const std::string &loc) {
 
 // ---- graphics state & interpreter --------------------------------------------------------------------
 struct GraphicsState {
-    Transform ctm;
+    Transform ctm;       // the start-time CTM: what a static render uses
+    Transform ctmEnd;    // the end-time CTM (ActiveTransform EndTime); they must agree wherever something is created
+    int activeBits = 3;  // ActiveTransform: 1 StartTime, 2 EndTime, 3 All
     bool reverseOrientation = false;
     int currentMaterialIndex = 0;
     std::string currentMaterialName;
@@ -299,6 +301,13 @@ struct Interpreter {
         ps.params = std::move(params);
         for (const Param &a : attrs) ps.params.push_back(a);  // lower precedence: looked up after explicit ones
         return ps;
+    }
+    // a static render uses the start-time transformation; something created under two different CTMs is animated (AnimatedTransform /
+    // AnimatedPrimitive in the reference): refused, not rendered in the wrong place
+    void RequireStaticCTM(const std::string &loc) const {
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                if (gs.ctm.m.m[i][j] != gs.ctmEnd.m.m[i][j]) Fatal(loc, "animated transformations (ActiveTransform StartTime / EndTime with different CTMs) are not supported by this build");
     }
     Transform RenderFromObject() const { return Transform((renderFromWorld * gs.ctm).m); }
 
@@ -381,7 +390,12 @@ struct Interpreter {
                 else Fatal(loc, "Unknown attribute target \"%s\".", target.c_str());
                 for (Param &p : ps) { p.lookedUp = true; dst->push_back(p); }
             } else if (tok == "ActiveTransform") {
-                nextRequired("ActiveTransform argument");
+                // BasicSceneBuilder::ActiveTransform{All,StartTime,EndTime} (scene.cpp): which of the two CTMs the following transforms change
+                std::string a = nextRequired("ActiveTransform argument");
+                if (a == "StartTime") gs.activeBits = 1;
+                else if (a == "EndTime") gs.activeBits = 2;
+                else if (a == "All") gs.activeBits = 3;
+                else Fatal(loc, "Unknown ActiveTransform \"%s\".", a.c_str());
             } else if (tok == "TransformTimes") { nextFloat(); nextFloat(); }
             else if (tok == "AreaLightSource") {
                 gs.areaLightName = nextString();
@@ -396,12 +410,13 @@ struct Interpreter {
                 Mat4 mm;
                 for (int i = 0; i < 16; ++i) mm.m[i / 4][i % 4] = m[i];
                 Transform t = TransposeT(Transform(mm));
-                gs.ctm = (tok == "Transform") ? t : gs.ctm * t;
+                if (gs.activeBits & 1) gs.ctm = (tok == "Transform") ? t : gs.ctm * t;
+                if (gs.activeBits & 2) gs.ctmEnd = (tok == "Transform") ? t : gs.ctmEnd * t;
             } else if (tok == "CoordinateSystem") namedCoordinateSystems[nextString()] = gs.ctm;
             else if (tok == "CoordSysTransform") {
                 std::string n = nextString();
                 auto it = namedCoordinateSystems.find(n);
-                if (it != namedCoordinateSystems.end()) gs.ctm = it->second;
+                if (it != namedCoordinateSystems.end()) { if (gs.activeBits & 1) gs.ctm = it->second; if (gs.activeBits & 2) gs.ctmEnd = it->second; }
                 else fprintf(stderr, "Warning: %s: Couldn't find named coordinate system \"%s\"\n", loc.c_str(), n.c_str());
             } else if (tok == "ColorSpace") {
                 std::string n = nextString();
@@ -410,6 +425,7 @@ struct Interpreter {
                 gs.colorSpace = cs;
             } else if (tok == "Camera") {
                 basicParamDirective(&scene->camera);
+                RequireStaticCTM(loc);
                 scene->cameraFromWorld = gs.ctm;
                 scene->worldFromCamera = Inverse(gs.ctm);
                 namedCoordinateSystems["camera"] = Inverse(gs.ctm);
@@ -431,17 +447,18 @@ struct Interpreter {
                 sub.text = ss.str();
                 sub.filename = fn;
                 Run(sub);
-            } else if (tok == "Identity") gs.ctm = Transform();
+            } else if (tok == "Identity") { if (gs.activeBits & 1) gs.ctm = Transform(); if (gs.activeBits & 2) gs.ctmEnd = Transform(); }
             else if (tok == "LightSource") {
                 LightEntity e;
                 basicParamDirective(&e, gs.lightAttributes);
+                RequireStaticCTM(loc);
                 e.renderFromLight = RenderFromObject();
                 e.medium = gs.currentOutsideMedium;
                 scene->lights.push_back(std::move(e));
             } else if (tok == "LookAt") {
                 float v[9];
                 for (float &f : v) f = nextFloat();
-                gs.ctm = gs.ctm * LookAt(V3{v[0], v[1], v[2]}, V3{v[3], v[4], v[5]}, V3{v[6], v[7], v[8]});
+                { Transform t = LookAt(V3{v[0], v[1], v[2]}, V3{v[3], v[4], v[5]}, V3{v[6], v[7], v[8]}); if (gs.activeBits & 1) gs.ctm = gs.ctm * t; if (gs.activeBits & 2) gs.ctmEnd = gs.ctmEnd * t; }
             } else if (tok == "MakeNamedMaterial") {
                 Entity e;
                 std::string name = nextString();
@@ -495,6 +512,7 @@ struct Interpreter {
                 InstanceUse u;
                 u.name = name;
                 // scene.cpp:398-430: renderFromInstance = RenderFromObject() * worldFromRender
+                RequireStaticCTM(loc);
                 u.renderFromInstance = RenderFromObject() * Inverse(renderFromWorld);
                 scene->instances.push_back(u);
             } else if (tok == "Option") {
@@ -510,11 +528,11 @@ struct Interpreter {
             else if (tok == "ReverseOrientation") gs.reverseOrientation = !gs.reverseOrientation;
             else if (tok == "Rotate") {
                 float a = nextFloat(), x = nextFloat(), y = nextFloat(), z = nextFloat();
-                gs.ctm = gs.ctm * Rotate(a, V3{x, y, z});
+                { Transform t = Rotate(a, V3{x, y, z}); if (gs.activeBits & 1) gs.ctm = gs.ctm * t; if (gs.activeBits & 2) gs.ctmEnd = gs.ctmEnd * t; }
             } else if (tok == "Sampler") basicParamDirective(&scene->sampler);
             else if (tok == "Scale") {
                 float x = nextFloat(), y = nextFloat(), z = nextFloat();
-                gs.ctm = gs.ctm * Scale(x, y, z);
+                { Transform t = Scale(x, y, z); if (gs.activeBits & 1) gs.ctm = gs.ctm * t; if (gs.activeBits & 2) gs.ctmEnd = gs.ctmEnd * t; }
             } else if (tok == "Shape") {
                 ShapeEntity e;
                 basicParamDirective(&e, gs.shapeAttributes);
@@ -527,6 +545,7 @@ struct Interpreter {
                     e.lightIndex = (int)scene->areaLights.size() - 1;
                     if (activeInstance) fprintf(stderr, "Warning: %s: Area lights not supported with object instancing\n", loc.c_str());
                 }
+                RequireStaticCTM(loc);
                 e.renderFromObject = RenderFromObject();
                 e.reverseOrientation = gs.reverseOrientation;
                 e.materialIndex = gs.currentMaterialIndex;
@@ -547,10 +566,11 @@ struct Interpreter {
                 scene->textures.push_back(std::move(e));
             } else if (tok == "Translate") {
                 float x = nextFloat(), y = nextFloat(), z = nextFloat();
-                gs.ctm = gs.ctm * Translate(V3{x, y, z});
+                { Transform t = Translate(V3{x, y, z}); if (gs.activeBits & 1) gs.ctm = gs.ctm * t; if (gs.activeBits & 2) gs.ctmEnd = gs.ctmEnd * t; }
             } else if (tok == "WorldBegin") {
                 inWorld = true;
-                gs.ctm = Transform();
+                gs.ctm = gs.ctmEnd = Transform();
+                gs.activeBits = 3;
                 namedCoordinateSystems["world"] = gs.ctm;
             } else if (tok == "WorldEnd") {
             } else Fatal(loc, "%s: unknown directive", tok.c_str());
