@@ -25,6 +25,8 @@ typedef struct wfh_info {
 /* InitPBRT's table setup (pbrt.cpp:100-110): spectral tables + RGB->spectrum tables (generated on first
    use and cached under <data_dir>/cache) */
 int wfh_init(const char *data_dir);
+/* the message of the last scene or back-end error on this thread (entry points return NULL / -1; nothing in the library exits the process) */
+const char *wfh_last_error(void);
 /* ParseFiles + BasicScene::Create* for the supported subset; spp_override <= 0 keeps the file's value
    (--spp); seed as --seed.  Parse errors exit the process with a message, as the reference does. */
 wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed);

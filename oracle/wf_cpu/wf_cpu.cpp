@@ -261,7 +261,16 @@ static void SimulateWave(const std::vector<std::vector<uint8_t>> &ev, int lanes,
     S->waves++;
 }
 
+static int Main(int argc, char **argv);
 int main(int argc, char **argv) {
+    try {
+        return Main(argc, argv);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
+static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
     bool simulateWaves = false;

@@ -16,8 +16,7 @@ namespace wf {
 static void Check(int rc, const char *what) {
     if (rc != 0) {
         // CUDA_CHECK -> LOG_FATAL in the reference (gpu/util.h:35-49)
-        fprintf(stderr, "Fatal: %s failed: %s\n", what, wf_last_error());
-        abort();
+        throw SceneError(std::string("Fatal: ") + what + " failed: " + wf_last_error());
     }
 }
 

@@ -26,7 +26,16 @@ static void usage() {
             "  --quiet, --gpu, --wavefront (accepted)\n");
 }
 
+static int Main(int argc, char **argv);
 int main(int argc, char **argv) {
+    try {
+        return Main(argc, argv);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
+static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dataDir;
     int device = 0;

@@ -16,11 +16,10 @@ namespace wf {
 [[noreturn]] static void Fatal(const std::string &loc, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    fprintf(stderr, "Error: %s: ", loc.c_str());
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    char buf[2048];
+    vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    exit(1);
+    throw SceneError("Error: " + loc + ": " + buf);
 }
 
 // ---- ParamSet --------------------------------------------------------------------------------------

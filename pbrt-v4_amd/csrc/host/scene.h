@@ -11,7 +11,14 @@
 #include <string>
 #include <vector>
 
+#include <stdexcept>
+
 namespace wf {
+
+// Scene errors (the reference's ErrorExit) and back-end failures (its CUDA_CHECK -> LOG_FATAL) are thrown; the extern "C" entry points
+// of libwfhost.so catch them and return an error (wfh_last_error), the command-line programs print them and exit
+struct SceneError : std::runtime_error { using std::runtime_error::runtime_error; };
+
 
 // ---- parameters (paramdict.h) ---------------------------------------------------------------------
 struct Param {

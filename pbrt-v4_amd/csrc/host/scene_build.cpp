@@ -24,8 +24,7 @@
 namespace wf {
 
 [[noreturn]] static void Die(const std::string &loc, const std::string &msg) {
-    fprintf(stderr, "Error: %s: %s\n", loc.c_str(), msg.c_str());
-    exit(1);
+    throw SceneError("Error: " + loc + ": " + msg);
 }
 
 void SceneTables::Finalize() {

@@ -20,6 +20,19 @@ struct wfh_scene {
 
 static bool g_init = false;
 
+static thread_local std::string g_lastError;
+// run f(); a thrown SceneError becomes the return value `bad` + wfh_last_error()
+template <typename R, typename F>
+static R Guard(R bad, F f) {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        g_lastError = e.what();
+        fprintf(stderr, "%s\n", e.what());
+        return bad;
+    }
+}
+
 extern "C" {
 
 int wfh_init(const char *data_dir) {
@@ -32,7 +45,13 @@ int wfh_init(const char *data_dir) {
     return 0;
 }
 
+const char *wfh_last_error(void) { return g_lastError.c_str(); }
+
+static wfh_scene *SceneLoadImpl(const char *path, int spp_override, int seed);
 wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed) {
+    return Guard<wfh_scene *>(nullptr, [&] { return SceneLoadImpl(path, spp_override, seed); });
+}
+static wfh_scene *SceneLoadImpl(const char *path, int spp_override, int seed) {
     if (!g_init || !path) return nullptr;
     auto *s = new wfh_scene();
     s->opt.pixelSamples = spp_override;
@@ -62,13 +81,15 @@ wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed) {
 }
 wfh_scene *wfh_scene_load_string(const char *text, int spp_override, int seed) {
     if (!g_init || !text) return nullptr;
-    auto *s = new wfh_scene();
-    s->opt.pixelSamples = spp_override;
-    s->opt.seed = seed;
-    s->opt.quiet = true;
-    ParseString(text, &s->opt, &s->parsed);
-    BuildSceneTables(s->parsed, s->opt, &s->T);
-    return s;
+    return Guard<wfh_scene *>(nullptr, [&] {
+        std::unique_ptr<wfh_scene> s(new wfh_scene());
+        s->opt.pixelSamples = spp_override;
+        s->opt.seed = seed;
+        s->opt.quiet = true;
+        ParseString(text, &s->opt, &s->parsed);
+        BuildSceneTables(s->parsed, s->opt, &s->T);
+        return s.release();
+    });
 }
 void wfh_scene_free(wfh_scene *s) { delete s; }
 
@@ -94,30 +115,26 @@ int wfh_scene_info(wfh_scene *s, wfh_info *out) {
 
 int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass) {
     if (!s) return -1;
-    s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass);
-    return 0;
+    return Guard<int>(-1, [&] { s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass); return 0; });
 }
 int wfh_renderer_set_strips(wfh_scene *s, int rank, int count, int height) {
     if (!s || !s->renderer) return -1;
-    s->renderer->SetStrips(rank, count, height);
-    return 0;
+    return Guard<int>(-1, [&] { s->renderer->SetStrips(rank, count, height); return 0; });
 }
 int wfh_renderer_samples_per_pass(wfh_scene *s) { return (s && s->renderer) ? s->renderer->SamplesPerPass() : -1; }
 wf_ctx *wfh_renderer_ctx(wfh_scene *s) { return (s && s->renderer) ? s->renderer->Context() : nullptr; }
 
 double wfh_render(wfh_scene *s, int sample_begin, int sample_end, int sample_step, int fused) {
     if (!s || !s->renderer) return -1.0;
-    return s->renderer->Render(sample_begin, sample_end, sample_step, fused != 0);
+    return Guard<double>(-1.0, [&] { return s->renderer->Render(sample_begin, sample_end, sample_step, fused != 0); });
 }
 int wfh_clear_film(wfh_scene *s) {
     if (!s || !s->renderer) return -1;
-    s->renderer->ClearFilm();
-    return 0;
+    return Guard<int>(-1, [&] { s->renderer->ClearFilm(); return 0; });
 }
 int wfh_download_film(wfh_scene *s, double *dst) {
     if (!s || !s->renderer) return -1;
-    s->renderer->DownloadFilm(dst);
-    return 0;
+    return Guard<int>(-1, [&] { s->renderer->DownloadFilm(dst); return 0; });
 }
 int wfh_stats(wfh_scene *s, wf_render_stats *out) {
     if (!s || !s->renderer) return -1;

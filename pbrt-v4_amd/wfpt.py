@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms",
 ]
 HOST_SYMBOLS = [
-    "wfh_init", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
+    "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
     "wfh_renderer_create", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
     "wfh_film_to_rgb", "wfh_write_image",
 ]
@@ -142,7 +142,8 @@ class Scene:
         else:
             self.h = host.wfh_scene_load_string(text.encode(), spp, seed)
         if not self.h:
-            raise WfError("scene load failed")
+            host.wfh_last_error.restype = C.c_char_p
+            raise WfError("scene load failed: " + (host.wfh_last_error() or b"").decode(errors="replace"))
         self.info = Info()
         host.wfh_scene_info(self.h, C.byref(self.info))
         self._renderer = False

@@ -156,3 +156,18 @@ def test_scene_table_cache_round_trip(wfpt, tmp_path, monkeypatch):
     for f in ("width", "height", "spp", "max_queue_size", "n_passes", "scanlines_per_pass", "n_triangles", "n_bvh_nodes", "n_lights", "max_depth"):
         assert getattr(a.info, f) == getattr(b.info, f)
     a.close(); b.close(); c.close()
+
+
+def test_scene_errors_are_returned_not_fatal(wfpt):
+    """ErrorExit of the reference = an error RETURN of the C API here: a bad scene raises in the caller (message from
+    wfh_last_error) and the process — pytest, bench.py, a host application — lives on."""
+    with pytest.raises(wfpt.WfError) as e:
+        wfpt.Scene(text='Film "rgb"\nWorldBegin\nShape "bogus"\n', spp=1)
+    assert "bogus" in str(e.value) and "not supported" in str(e.value)
+    base = open(os.path.join(GOLDEN, "cornell64.pbrt")).read()
+    with pytest.raises(wfpt.WfError) as e:   # animated transformation: refused, not rendered in the wrong place
+        wfpt.Scene(text=base.replace("WorldBegin", "WorldBegin\nActiveTransform EndTime\nTranslate 1 0 0\nActiveTransform All", 1), spp=1)
+    assert "animated" in str(e.value)
+    s = wfpt.Scene(text=base, spp=1)   # and the library is still usable
+    assert s.info.n_triangles > 0
+    s.close()
