@@ -144,8 +144,9 @@ enum wf_material_type {
     WF_MAT_COATED_DIFFUSE = 6,       /* materials.h:551-608 */
     WF_MAT_COATED_CONDUCTOR = 7,     /* materials.h:611-669 */
     WF_MAT_SUBSURFACE = 8,           /* materials.h:696-790: dielectric boundary + TabulatedBSSRDF (K12, wf_sample_subsurface) */
-    WF_MAT_NTYPES = 9,               /* the types above have an evaluation queue + kernel each */
-    WF_MAT_MIX = 9                   /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
+    WF_MAT_HAIR = 9,                 /* materials.h:353-427: HairBxDF (bxdfs.h:921-1019); h = -1 + 2 v */
+    WF_MAT_NTYPES = 10,              /* the types above have an evaluation queue + kernel each */
+    WF_MAT_MIX = 10                  /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
 };
 /* tex[] slots */
 #define WF_MT_REFLECTANCE 0   /* diffuse / conductor(reflectance) / difftrans / coated diffuse */
@@ -161,6 +162,13 @@ enum wf_material_type {
 #define WF_MT_MFP 1           /* subsurface: mean free path (with WF_MT_REFLECTANCE), when sigma_a / sigma_s are not given */
 #define WF_MT_SIGMA_A 5       /* subsurface (WF_MATFLAG_SSS_COEFFICIENTS) */
 #define WF_MT_SIGMA_S 6
+/* hair: sigma_a = WF_MT_SIGMA_A (spectrum) or colour = WF_MT_REFLECTANCE (spectrum) or the two melanin concentrations */
+#define WF_MT_HAIR_ETA 1      /* float textures */
+#define WF_MT_HAIR_ALPHA 2
+#define WF_MT_HAIR_BETA_M 3
+#define WF_MT_HAIR_BETA_N 4
+#define WF_MT_HAIR_EUMELANIN 8
+#define WF_MT_HAIR_PHEOMELANIN 9
 #define WF_MT_NTEX 12
 /* coated conductor: interface roughness in UROUGH/VROUGH, conductor in slots 8..11 */
 #define WF_MT_COND_UROUGH 8

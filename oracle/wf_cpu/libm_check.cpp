@@ -25,11 +25,13 @@ static float r_atan(float x) { return atanf(x); }
 static float r_asin(float x) { return asinf(x); }
 static float r_acos(float x) { return acosf(x); }
 static float r_cosh(float x) { return coshf(x); }
+static float r_sinh(float x) { return sinhf(x); }
+static float r_expm1(float x) { return expm1f(x); }
 static float r_atanh(float x) { return atanhf(x); }
 static const Fn fns[] = {
     {"sin", glibc235::sinf, r_sin},     {"cos", glibc235::cosf, r_cos},     {"exp", glibc235::expf, r_exp},
     {"log", glibc235::logf, r_log},     {"atan", glibc235::atanf, r_atan},  {"asin", glibc235::asinf, r_asin},
-    {"acos", glibc235::acosf, r_acos},  {"cosh", glibc235::coshf, r_cosh},  {"atanh", glibc235::atanhf, r_atanh},
+    {"acos", glibc235::acosf, r_acos},  {"cosh", glibc235::coshf, r_cosh}, {"sinh", glibc235::sinhf, r_sinh}, {"expm1", glibc235::expm1f, r_expm1},  {"atanh", glibc235::atanhf, r_atanh},
 };
 static inline bool same(float a, float b) {
     if (a != a && b != b) return true;

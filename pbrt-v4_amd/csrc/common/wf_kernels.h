@@ -22,6 +22,7 @@
 #include "wf_lights.h"
 #include "wf_media.h"
 #include "wf_bssrdf.h"
+#include "wf_hair.h"
 
 namespace wf {
 
@@ -848,6 +849,10 @@ template <> struct MatBxDF<WF_MAT_DIFFUSE_TRANSMISSION> {
 template <> struct MatBxDF<WF_MAT_SUBSURFACE> {
     using T = DielectricBxDF;
     WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetSubsurfaceBxDF(sv, m, l, tc); }
+};
+template <> struct MatBxDF<WF_MAT_HAIR> {
+    using T = HairBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetHairBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_COATED_DIFFUSE> {
     using T = CoatedDiffuseBxDF;

@@ -465,6 +465,89 @@ WFLM_HD float coshf(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// sinhf (e_sinhf.c) over the full expm1f (s_expm1f.c) and expf
+WFLM_HD float expm1f(float x) {
+    const float o_threshold = asfloat(0x42b17180u), ln2_hi = asfloat(0x3f317180u), ln2_lo = asfloat(0x3717f7d1u), invln2 = asfloat(0x3fb8aa3bu);
+    const float Q1 = asfloat(0xbd088889u), Q2 = asfloat(0x3ad00d01u), Q3 = asfloat(0xb8a670cdu), Q4 = asfloat(0x36867e54u),
+                Q5 = asfloat(0xb457edbbu);
+    float y, hi, lo, c = 0, t, e, hxs, hfx, r1;
+    int32_t k;
+    uint32_t hx = asuint(x);
+    const uint32_t xsb = hx & 0x80000000u;
+    hx &= 0x7fffffffu;
+    if (hx >= 0x4195b844u) {        // |x| >= 27 ln2
+        if (hx >= 0x42b17218u) {    // |x| >= 88.72...
+            if (hx > 0x7f800000u) return x + x;
+            if (hx == 0x7f800000u) return xsb == 0 ? x : -1.0f;
+            if (x > o_threshold) return asfloat(0x7f800000u);  // huge * huge
+        }
+        if (xsb != 0) return 1.0e-30f - 1.0f;  // x < -27 ln2
+    }
+    if (hx > 0x3eb17218u) {         // |x| > 0.5 ln2
+        if (hx < 0x3f851592u) {     // |x| < 1.5 ln2
+            if (xsb == 0) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
+            else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
+        } else {
+            k = (int32_t)(invln2 * x + (xsb == 0 ? 0.5f : -0.5f));
+            t = (float)k;
+            hi = x - t * ln2_hi;
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000u) {  // |x| < 2^-25
+        return x;
+    } else k = 0;
+    hfx = 0.5f * x;
+    hxs = x * hfx;
+    r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    t = 3.0f - r1 * hfx;
+    e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = (x * (e - c) - c);
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) {
+        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+        return 1.0f + 2.0f * (x - e);
+    }
+    if (k <= -2 || k > 56) {
+        y = 1.0f - (e - x);
+        y = asfloat((uint32_t)((int32_t)asuint(y) + (k << 23)));
+        return y - 1.0f;
+    }
+    if (k < 23) {
+        t = asfloat((uint32_t)(0x3f800000 - (0x1000000 >> k)));  // 1 - 2^-k
+        y = t - (e - x);
+        y = asfloat((uint32_t)((int32_t)asuint(y) + (k << 23)));
+    } else {
+        t = asfloat((uint32_t)((0x7f - k) << 23));  // 2^-k
+        y = x - (e + t);
+        y += 1.0f;
+        y = asfloat((uint32_t)((int32_t)asuint(y) + (k << 23)));
+    }
+    return y;
+}
+WFLM_HD float sinhf(float x) {
+    const int32_t jx = (int32_t)asuint(x), ix = jx & 0x7fffffff;
+    if (ix >= 0x7f800000) return x + x;
+    float h = jx < 0 ? -0.5f : 0.5f;
+    if (ix < 0x41b00000) {  // |x| < 22
+        if (ix < 0x31800000) return x;  // |x| < 2^-28
+        float t = expm1f(ffabs(x));
+        if (ix < 0x3f800000) return h * (2.0f * t - t * t / (t + 1.0f));
+        return h * (t + t / (t + 1.0f));
+    }
+    if (ix <= 0x42b1717f) return h * expf(ffabs(x));
+    if (ix <= 0x42b2d4fc) {
+        float w = expf(0.5f * ffabs(x));
+        float t = h * w;
+        return t * w;
+    }
+    return x * 1.0e37f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // atanhf (e_atanhf.c) over log1pf (s_log1pf.c)
 WFLM_HD float log1pf(float x) {
     const float ln2_hi = asfloat(0x3f317180u), ln2_lo = asfloat(0x3717f7d1u);

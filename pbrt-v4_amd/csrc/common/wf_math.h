@@ -114,6 +114,7 @@ WF_HD float atan2(float y, float x) { return glibc235::atan2f(y, x); }
 WF_HD float exp(float x) { return glibc235::expf(x); }
 WF_HD float log(float x) { return glibc235::logf(x); }
 WF_HD float cosh(float x) { return glibc235::coshf(x); }
+WF_HD float sinh(float x) { return glibc235::sinhf(x); }
 WF_HD float atanh(float x) { return glibc235::atanhf(x); }
 // tan / pow have no call site in the device path (host-side scene set-up only)
 WF_HD long lround(float x) { return (long)::roundf(x); }
@@ -127,6 +128,7 @@ WF_HD float atan2(float y, float x) { return std::atan2(y, x); }
 WF_HD float exp(float x) { return std::exp(x); }
 WF_HD float log(float x) { return std::log(x); }
 WF_HD float cosh(float x) { return std::cosh(x); }
+WF_HD float sinh(float x) { return std::sinh(x); }
 WF_HD float atanh(float x) { return std::atanh(x); }
 WF_HD long lround(float x) { return std::lround(x); }
 #endif

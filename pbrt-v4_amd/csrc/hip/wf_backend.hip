@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, W
 extern "C" {
 #define WF_DECL_MAT(n) void wf_launch_eval_material_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
                        void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int);
-WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8)
+WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8) WF_DECL_MAT(9)
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
     for (int p = blockIdx.x * BLOCK + threadIdx.x; p < ws.pixelsPerPass; p += gridDim.x * BLOCK) KUpdateFilm(sv, ws, p, nSamples);
@@ -1123,7 +1123,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.filter = d->filter;
     if ((e = devUpload(ctx, &sv.filterData, d->filter_data, (size_t)d->n_filter_floats))) return e;
     sv.sampler = d->sampler;
-    if (d->sampler.type < WF_SAMPLER_ZSOBOL || d->sampler.type > WF_SAMPLER_HALTON) return fail(-1, "unknown sampler type %d", d->sampler.type);
+    if (d->sampler.type < WF_SAMPLER_ZSOBOL || d->sampler.type > WF_SAMPLER_SOBOL) return fail(-1, "unknown sampler type %d", d->sampler.type);
     if (d->sampler.type == WF_SAMPLER_HALTON && (!d->halton_primes || (d->sampler.randomize == WF_RAND_PERMUTE_DIGITS && (!d->halton_perm_offsets || !d->halton_perms))))
         return fail(-1, "Halton sampler without its prime / digit-permutation tables");
     static uint32_t sobol[WF_SOBOL_WORDS];
@@ -1511,7 +1511,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     static const char *names[WF_MAT_NTYPES] = {"", "DiffuseMaterial + BxDF eval (Basic tex)", "ConductorMaterial + BxDF eval (Basic tex)",
                                                "DielectricMaterial + BxDF eval (Basic tex)", "ThinDielectricMaterial + BxDF eval (Basic tex)",
                                                "DiffuseTransmissionMaterial + BxDF eval (Basic tex)", "CoatedDiffuseMaterial + BxDF eval (Basic tex)",
-                                               "CoatedConductorMaterial + BxDF eval (Basic tex)", "SubsurfaceMaterial + BxDF eval (Basic tex)"};
+                                               "CoatedConductorMaterial + BxDF eval (Basic tex)", "SubsurfaceMaterial + BxDF eval (Basic tex)", "HairMaterial + BxDF eval (Basic tex)"};
     if (material_type == WF_MAT_INTERFACE) return 0;
     if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
     {
@@ -1526,6 +1526,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
         case 6: (tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 7: (tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 8: (tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 9: (tex ? wf_launch_eval_material_9_1 : wf_launch_eval_material_9_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         }
     }
     return 0;
@@ -1821,6 +1822,7 @@ __global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
         case 5: r = wf::asin(x); break;
         case 6: r = wf::acos(x); break;
         case 7: r = wf::cosh(x); break;
+        case 10: r = wf::sinh(x); break;
         default: r = wf::atanh(x); break;
         }
     }
@@ -1829,7 +1831,7 @@ __global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
 }
 int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out) {
     if (!ctx) return fail(-1, "null context");
-    if (fn < 0 || fn > 9) return fail(-1, "wf_libm_probe: unknown function %d", fn);
+    if (fn < 0 || fn > 10) return fail(-1, "wf_libm_probe: unknown function %d", fn);
     if (n <= 0) return 0;
     size_t nin = (size_t)n * (fn == 9 ? 2 : 1);
     float *din = nullptr, *dout = nullptr;

@@ -588,6 +588,28 @@ struct TexBuilder {
             wf::ComputeBeamDiffusionBSSRDF(g, m.sss_eta, table.data());
             m.sss_table = (int)T->tableData.size();
             T->tableData.insert(T->tableData.end(), table.begin(), table.end());
+        } else if (name == "hair") {
+            // HairMaterial::Create (materials.cpp:135-184)
+            m.type = WF_MAT_HAIR;
+            int sigma_a = GetSpectrumTextureOrNull(ps, "sigma_a", SpectrumType::Unbounded);
+            int refl = GetSpectrumTextureOrNull(ps, "reflectance", SpectrumType::Albedo);
+            if (refl < 0) refl = GetSpectrumTextureOrNull(ps, "color", SpectrumType::Albedo);
+            int eu = GetFloatTextureOrNull(ps, "eumelanin"), ph = GetFloatTextureOrNull(ps, "pheomelanin");
+            if (sigma_a >= 0) { refl = eu = ph = -1; }
+            else if (refl >= 0) { eu = ph = -1; }
+            else if (eu < 0 && ph < 0) {
+                // default: brown-ish hair, RGBUnboundedSpectrum(SigmaAFromConcentration(1.3, 0)) in sRGB
+                const float rgb[3] = {1.3f * 0.419f + 0.f * 0.187f, 1.3f * 0.697f + 0.f * 0.4f, 1.3f * 1.37f + 0.f * 1.05f};
+                sigma_a = SpectrumConst(*SpectralData::Get().sRGB()->Unbounded(rgb));
+            }
+            m.tex[WF_MT_SIGMA_A] = sigma_a; m.tex[WF_MT_REFLECTANCE] = refl;
+            m.tex[WF_MT_HAIR_EUMELANIN] = eu; m.tex[WF_MT_HAIR_PHEOMELANIN] = ph;
+            if (eu >= 0 || ph >= 0) NeedSRGBTable();
+            m.tex[WF_MT_HAIR_ETA] = GetFloatTexture(ps, "eta", 1.55f);
+            m.tex[WF_MT_HAIR_BETA_M] = GetFloatTexture(ps, "beta_m", 0.3f);
+            m.tex[WF_MT_HAIR_BETA_N] = GetFloatTexture(ps, "beta_n", 0.3f);
+            m.tex[WF_MT_HAIR_ALPHA] = GetFloatTexture(ps, "alpha", 2.f);
+            m.displacement = -1; m.normalmap = -1;   // GetDisplacement() / GetNormalMap() return null
         } else if (name == "interface" || name == "none" || name.empty()) {
             m.type = WF_MAT_INTERFACE;
         } else if (name == "mix") {
