@@ -294,7 +294,11 @@ typedef struct wf_mesh {
 /* Sphere, Disk, Cylinder (shapes.h:107-383, 385-540, 543-748), kept in object space like the reference's: primitive
  * id n_triangles + index.  Material / area light / media / orientation live in a wf_mesh entry with ntris = 0 and
  * first_tri = that id. */
-enum wf_quadric_type { WF_QUADRIC_SPHERE = 0, WF_QUADRIC_DISK = 1, WF_QUADRIC_CYLINDER = 2 };
+enum wf_quadric_type { WF_QUADRIC_SPHERE = 0, WF_QUADRIC_DISK = 1, WF_QUADRIC_CYLINDER = 2,
+                       /* BilinearPatch (shapes.h:1279-1510): a primitive of the same id range, in RENDER space.  The record's
+                          render_from_object storage holds the patch instead of a transformation: m = p00 p10 p01 p11 (12 floats, then
+                          uv00.st uv10.st), mInv = n00 n10 n01 n11 (12 floats, then uv01.st uv11.st); pad[0] bit 0: has normals, bit 1: has uv */
+                       WF_QUADRIC_BILINEAR = 3 };
 typedef struct wf_quadric {
     float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;  /* disk: z_min = z_max = height */
     int32_t mesh;

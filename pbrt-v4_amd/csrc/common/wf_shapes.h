@@ -319,7 +319,98 @@ WF_HD bool CylinderBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax,
     out->phi = phi;
     return true;
 }
+// ---------------------------------------------------------------------------------------------
+// BilinearPatch (shapes.h:1279-1510) as a wf_quadric of type WF_QUADRIC_BILINEAR (payload layout: include/wf_abi.h)
+struct BlpData { V3 p00, p10, p01, p11; N3 n00, n10, n01, n11; V2 uv00, uv10, uv01, uv11; bool hasN, hasUV; };
+WF_HD BlpData LoadBlp(const wf_quadric &s) {
+    const float *a = &s.render_from_object.m[0][0], *b = &s.render_from_object.mInv[0][0];
+    BlpData d;
+    d.p00 = V3{a[0], a[1], a[2]}; d.p10 = V3{a[3], a[4], a[5]}; d.p01 = V3{a[6], a[7], a[8]}; d.p11 = V3{a[9], a[10], a[11]};
+    d.uv00 = V2{a[12], a[13]}; d.uv10 = V2{a[14], a[15]};
+    d.n00 = N3{b[0], b[1], b[2]}; d.n10 = N3{b[3], b[4], b[5]}; d.n01 = N3{b[6], b[7], b[8]}; d.n11 = N3{b[9], b[10], b[11]};
+    d.uv01 = V2{b[12], b[13]}; d.uv11 = V2{b[14], b[15]};
+    const int flags = (int)s.pad[0];
+    d.hasN = flags & 1; d.hasUV = flags & 2;
+    return d;
+}
+// util/math.h:613-636
+WF_HD bool QuadraticF(float a, float b, float c, float *t0, float *t1) {
+    if (a == 0) {
+        if (b == 0) return false;
+        *t0 = *t1 = -c / b;
+        return true;
+    }
+    float discrim = DifferenceOfProducts(b, b, 4 * a, c);
+    if (discrim < 0) return false;
+    float rootDiscrim = sqrt(discrim);
+    float q = -0.5f * (b + copysignf(rootDiscrim, b));
+    *t0 = q / a;
+    *t1 = c / q;
+    if (*t0 > *t1) { float t = *t0; *t0 = *t1; *t1 = t; }
+    return true;
+}
+// Determinant(SquareMatrix<3>) (util/math.h:1419-1425), rows given
+WF_HD float Det3(float m00, float m01, float m02, float m10, float m11, float m12, float m20, float m21, float m22) {
+    float minor12 = DifferenceOfProducts(m11, m22, m12, m21);
+    float minor02 = DifferenceOfProducts(m10, m22, m12, m20);
+    float minor01 = DifferenceOfProducts(m10, m21, m11, m20);
+    return fmaf(m02, minor01, DifferenceOfProducts(m00, minor12, m01, minor02));
+}
+WF_HD V3 LerpV(float t, V3 a, V3 b) { return (1 - t) * a + t * b; }
+WF_HD float MaxAbsComp(V3 v) { return fmax(fmax(abs(v.x), abs(v.y)), abs(v.z)); }
+// IntersectBilinearPatch (shapes.h:1279-1347): (u, v, t) of the hit
+WF_HD bool IntersectBilinearPatch(V3 ro, V3 rd, float tMax, V3 p00, V3 p10, V3 p01, V3 p11, float *uOut, float *vOut, float *tOut) {
+    float a = Dot(Cross(p10 - p00, p01 - p11), rd);
+    float c = Dot(Cross(p00 - ro, rd), p01 - p00);
+    float b = Dot(Cross(p10 - ro, rd), p11 - p10) - (a + c);
+    float u1, u2;
+    if (!QuadraticF(a, b, c, &u1, &u2)) return false;
+    float eps = gamma(30) * (MaxAbsComp(ro) + MaxAbsComp(rd) + MaxAbsComp(p00) + MaxAbsComp(p10) + MaxAbsComp(p01) + MaxAbsComp(p11));
+    float t = tMax, u = 0, v = 0;
+    if (0 <= u1 && u1 <= 1) {
+        V3 uo = LerpV(u1, p00, p10);
+        V3 ud = LerpV(u1, p01, p11) - uo;
+        V3 deltao = uo - ro;
+        V3 perp = Cross(rd, ud);
+        float p2 = LengthSquared(perp);
+        float v1 = Det3(deltao.x, rd.x, perp.x, deltao.y, rd.y, perp.y, deltao.z, rd.z, perp.z);
+        float t1 = Det3(deltao.x, ud.x, perp.x, deltao.y, ud.y, perp.y, deltao.z, ud.z, perp.z);
+        if (t1 > p2 * eps && 0 <= v1 && v1 <= p2) {
+            u = u1;
+            v = v1 / p2;
+            t = t1 / p2;
+        }
+    }
+    if (0 <= u2 && u2 <= 1 && u2 != u1) {
+        V3 uo = LerpV(u2, p00, p10);
+        V3 ud = LerpV(u2, p01, p11) - uo;
+        V3 deltao = uo - ro;
+        V3 perp = Cross(rd, ud);
+        float p2 = LengthSquared(perp);
+        float v2 = Det3(deltao.x, rd.x, perp.x, deltao.y, rd.y, perp.y, deltao.z, rd.z, perp.z);
+        float t2 = Det3(deltao.x, ud.x, perp.x, deltao.y, ud.y, perp.y, deltao.z, ud.z, perp.z);
+        t2 /= p2;
+        if (0 <= v2 && v2 <= p2 && t > t2 && t2 > eps) {
+            t = t2;
+            u = u2;
+            v = v2 / p2;
+        }
+    }
+    if (t >= tMax) return false;
+    *uOut = u; *vOut = v; *tOut = t;
+    return true;
+}
+WF_HD bool BilinearBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    const float *a = &s.render_from_object.m[0][0];
+    float u, v, t;
+    if (!IntersectBilinearPatch(ro, rd, tMax, V3{a[0], a[1], a[2]}, V3{a[3], a[4], a[5]}, V3{a[6], a[7], a[8]}, V3{a[9], a[10], a[11]}, &u, &v, &t)) return false;
+    out->tHit = t;
+    out->pObj = V3{u, v, 0.f};   // the hit record's three floats: (u, v) of the patch
+    out->phi = 0;
+    return true;
+}
 WF_HD bool QuadricBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    if (s.type == WF_QUADRIC_BILINEAR) return BilinearBasicIntersect(s, ro, rd, tMax, out);
     if (s.type == WF_QUADRIC_DISK) return DiskBasicIntersect(s, ro, rd, tMax, out);
     if (s.type == WF_QUADRIC_CYLINDER) return CylinderBasicIntersect(s, ro, rd, tMax, out);
     return SphereBasicIntersect(s, ro, rd, tMax, out);
@@ -934,9 +1025,95 @@ WF_NI void SphereInteractionP(const wf_quadric *sp, int meshFlags, float px, flo
     si->dndvs = si->dndv;
     si->mesh = s.mesh;
 }
+// BilinearPatch::InteractionFromIntersection (shapes.h:1396-1497).  Out of line: pointer arguments only.
+WF_NI void BilinearInteractionP(const wf_quadric *sp, int meshFlags, float u, float v, SurfIntr *si) {
+    const BlpData d = LoadBlp(*sp);
+    const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+    V3 p = LerpV(u, LerpV(v, p00, p01), LerpV(v, p10, p11));
+    V3 dpdu = LerpV(v, p10, p11) - LerpV(v, p00, p01);
+    V3 dpdv = LerpV(u, p01, p11) - LerpV(u, p00, p10);
+    V2 st{u, v};
+    float duds = 1, dudt = 0, dvds = 0, dvdt = 1;
+    auto lerp2 = [](float t, V2 a, V2 b) { return V2{(1 - t) * a.x + t * b.x, (1 - t) * a.y + t * b.y}; };
+    if (d.hasUV) {
+        st = lerp2(u, lerp2(v, d.uv00, d.uv01), lerp2(v, d.uv10, d.uv11));
+        V2 e0 = lerp2(v, d.uv10, d.uv11), e1 = lerp2(v, d.uv00, d.uv01), f0 = lerp2(u, d.uv01, d.uv11), f1 = lerp2(u, d.uv00, d.uv10);
+        V2 dstdu{e0.x - e1.x, e0.y - e1.y}, dstdv{f0.x - f1.x, f0.y - f1.y};
+        duds = abs(dstdu.x) < 1e-8f ? 0 : 1 / dstdu.x;
+        dvds = abs(dstdv.x) < 1e-8f ? 0 : 1 / dstdv.x;
+        dudt = abs(dstdu.y) < 1e-8f ? 0 : 1 / dstdu.y;
+        dvdt = abs(dstdv.y) < 1e-8f ? 0 : 1 / dstdv.y;
+        V3 dpds = dpdu * duds + dpdv * dvds;
+        V3 dpdt = dpdu * dudt + dpdv * dvdt;
+        V3 cr = Cross(dpds, dpdt);
+        if (cr.x != 0 || cr.y != 0 || cr.z != 0) {
+            if (Dot(Cross(dpdu, dpdv), cr) < 0) dpdt = -dpdt;
+            dpdu = dpds;
+            dpdv = dpdt;
+        }
+    }
+    V3 d2Pduu{0, 0, 0}, d2Pdvv{0, 0, 0};
+    V3 d2Pduv = (p00 - p01) + (p11 - p10);
+    float E = Dot(dpdu, dpdu), F = Dot(dpdu, dpdv), G = Dot(dpdv, dpdv);
+    V3 n = Normalize(Cross(dpdu, dpdv));
+    float e = Dot(n, d2Pduu), f = Dot(n, d2Pduv), g = Dot(n, d2Pdvv);
+    float EGF2 = DifferenceOfProducts(E, G, F, F);
+    float invEGF2 = (EGF2 == 0) ? 0.f : 1 / EGF2;
+    N3 dndu = toN((f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv);
+    N3 dndv = toN((g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv);
+    N3 dnds = dndu * duds + dndv * dvds;
+    N3 dndt = dndu * dudt + dndv * dvdt;
+    dndu = dnds;
+    dndv = dndt;
+    V3 pAbsSum = Abs(p00) + Abs(p01) + Abs(p10) + Abs(p11);
+    V3 pError = gamma(6) * pAbsSum;
+    // SurfaceInteraction ctor (interaction.h:140-162)
+    si->pi = MakeP3i(p, pError);
+    si->uv = st;
+    si->dpdu = dpdu; si->dpdv = dpdv; si->dndu = dndu; si->dndv = dndv;
+    N3 ng = toN(Normalize(Cross(dpdu, dpdv)));
+    N3 ns = ng;
+    if (meshFlags & WF_MESH_FLIP_NORMAL) { ng = -ng; ns = -ns; }
+    si->n = ng; si->ns = ns;
+    si->dpdus = dpdu; si->dpdvs = dpdv; si->dndus = dndu; si->dndvs = dndv;
+    si->mesh = sp->mesh;
+    if (d.hasN) {
+        auto lerpN = [](float t, N3 a, N3 b) { return (1 - t) * a + t * b; };
+        N3 nsI = lerpN(u, lerpN(v, d.n00, d.n01), lerpN(v, d.n10, d.n11));
+        if (LengthSquared(nsI) > 0) {
+            nsI = Normalize(nsI);
+            N3 dnduS = lerpN(v, d.n10, d.n11) - lerpN(v, d.n00, d.n01);
+            N3 dndvS = lerpN(u, d.n01, d.n11) - lerpN(u, d.n00, d.n10);
+            N3 dndsS = dnduS * duds + dndvS * dvds;
+            N3 dndtS = dnduS * dudt + dndvS * dvdt;
+            // RotateFromTo(Normalize(isect.n), ns) (util/transform.h:249-270) applied to dpdu, dpdv
+            V3 from = Normalize(toV(si->n)), to = toV(nsI);
+            V3 refl;
+            if (abs(from.x) < 0.72f && abs(to.x) < 0.72f) refl = V3{1, 0, 0};
+            else if (abs(from.y) < 0.72f && abs(to.y) < 0.72f) refl = V3{0, 1, 0};
+            else refl = V3{0, 0, 1};
+            V3 uu = refl - from, vv = refl - to;
+            float r[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    r[i][j] = ((i == j) ? 1 : 0) - 2 / Dot(uu, uu) * uu[i] * uu[j] - 2 / Dot(vv, vv) * vv[i] * vv[j] + 4 * Dot(uu, vv) / (Dot(uu, uu) * Dot(vv, vv)) * vv[i] * uu[j];
+            auto rot = [&](V3 w) { return V3{r[0][0] * w.x + r[0][1] * w.y + r[0][2] * w.z, r[1][0] * w.x + r[1][1] * w.y + r[1][2] * w.z, r[2][0] * w.x + r[2][1] * w.y + r[2][2] * w.z}; };
+            // SetShadingGeometry(ns, r(dpdu), r(dpdv), dndu, dndv, true) (interaction.h:186-200)
+            si->ns = nsI;
+            si->n = FaceForward(si->n, si->ns);
+            si->dpdus = rot(dpdu);
+            si->dpdvs = rot(dpdv);
+            si->dndus = dndsS;
+            si->dndvs = dndtS;
+        }
+    }
+}
+
 WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *si) {
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     SurfIntr tmp;  // the out-of-line call's result lives in memory; *si stays in registers
+    if (s->type == WF_QUADRIC_BILINEAR) BilinearInteractionP(s, sv.meshes[s->mesh].flags, pHit.x, pHit.y, &tmp);
+    else
     SphereInteractionP(s, sv.meshes[s->mesh].flags, pHit.x, pHit.y, pHit.z, &tmp);
     *si = tmp;
 }
@@ -944,6 +1121,11 @@ WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *s
 // space and transforms it back, so its wo is normalised there and again after the transform (shapes.h:286-288,
 // util/transform.cpp:235)
 WF_NI void SphereWoP(const wf_quadric *s, float x, float y, float z, float *ox, float *oy, float *oz) {
+    if (s->type == WF_QUADRIC_BILINEAR) {  // built in render space like a triangle's: normalised once
+        V3 w = Normalize(V3{x, y, z});
+        *ox = w.x; *oy = w.y; *oz = w.z;
+        return;
+    }
     V3 w = Normalize(XfVector3(s->render_from_object.m, Normalize(XfVector3(s->render_from_object.mInv, V3{x, y, z}))));
     *ox = w.x; *oy = w.y; *oz = w.z;
 }

@@ -1390,6 +1390,7 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
 // ---- shapes -----------------------------------------------------------------------------------------
 struct MeshSource {
     std::vector<int> indices;
+    std::vector<int> quads;  // bilinear patches: p00 p10 p01 p11 per patch (a PLY quad face f0 f1 f2 f3 is stored f0 f1 f3 f2, util/mesh.cpp:302-305)
     std::vector<V3> P, N;
     std::vector<V2> uv;
 };
@@ -1422,7 +1423,25 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         if (!ps.GetTexture("displacement").empty()) Die(sh.loc, "plymesh displacement is not supported by this build");
         return true;
     }
-    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh)");
+    if (sh.name == "bilinearmesh") {
+        // BilinearPatch::CreateMesh (shapes.cpp:910-1010)
+        m->quads = ps.GetIntArray("indices");
+        m->P = ps.GetPoint3fArray("P");
+        m->uv = ps.GetPoint2fArray("uv");
+        m->N = ps.GetTuple3Array("N", "normal");
+        if (m->N.empty()) m->N = ps.GetTuple3Array("N", "normal3");
+        if (m->quads.empty()) {
+            if (m->P.size() == 4) m->quads = {0, 1, 2, 3};
+            else { fprintf(stderr, "Error: %s: Vertex indices \"indices\" must be provided with bilinear patch mesh shape.\n", sh.loc.c_str()); return false; }
+        } else while (m->quads.size() % 4) m->quads.pop_back();
+        if (m->P.empty()) { fprintf(stderr, "Error: %s: Vertex positions \"P\" must be provided with bilinear patch mesh shape.\n", sh.loc.c_str()); return false; }
+        if (!m->uv.empty() && m->uv.size() != m->P.size()) m->uv.clear();
+        if (!m->N.empty() && m->N.size() != m->P.size()) m->N.clear();
+        for (int vi : m->quads) if (vi < 0 || vi >= (int)m->P.size()) { fprintf(stderr, "Error: %s: Bilinear patch mesh has out of-bounds vertex index %d\n", sh.loc.c_str(), vi); return false; }
+        if (!ps.GetOneString("emissionfilename", "").empty()) Die(sh.loc, "bilinearmesh \"emissionfilename\" is not supported by this build");
+        return true;
+    }
+    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh, bilinearmesh, sphere, disk, cylinder)");
 }
 
 // Minimal PLY reader (ascii + binary_little_endian; vertex x,y,z[,nx,ny,nz][,u,v|s,t], face vertex_indices
@@ -1540,11 +1559,10 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
                     if (p.role != 8) { for (int k = 0; k < n; ++k) readNum(p.type); continue; }
                     if (n == 3) { for (int k = 0; k < 3; ++k) out->indices.push_back((int)readNum(p.type)); }
                     else if (n == 4) {
-                        // the reference turns the quad faces of a plymesh into BilinearPatch shapes (shapes.cpp:1465-1472, face
-                        // order 0,1,3,2 of util/mesh.cpp:302-305), not into triangle pairs: splitting them here would render a
-                        // different surface.  Bilinear patches are not built yet -> refuse, do not approximate.
-                        *err = "quad faces (bilinear patches in pbrt-v4) are not supported by this build";
-                        return false;
+                        // quad faces become BilinearPatch shapes (shapes.cpp:1465-1472); face order 0, 1, 3, 2 (util/mesh.cpp:302-305)
+                        int q[4];
+                        for (int k = 0; k < 4; ++k) q[k] = (int)readNum(p.type);
+                        out->quads.push_back(q[0]); out->quads.push_back(q[1]); out->quads.push_back(q[3]); out->quads.push_back(q[2]);
                     } else { *err = "only triangle faces are supported (the reference accepts triangles and quads)"; return false; }
                 }
         } else {
@@ -1557,6 +1575,7 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
     }
     if (truncated) { *err = "unexpected end of PLY data"; return false; }
     for (int vi : out->indices) if (vi < 0 || vi >= (int)out->P.size()) { *err = "vertex index out of bounds"; return false; }
+    for (int vi : out->quads) if (vi < 0 || vi >= (int)out->P.size()) { *err = "vertex index out of bounds"; return false; }
     return true;
 }
 
@@ -1638,7 +1657,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
         else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
         if (mesh.alpha_tex >= 0 && sh.lightIndex >= 0) Die(sh.loc, "alpha-masked area lights are not supported by this build yet");
-        if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres are not supported by this build yet");
+        if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres and bilinear patches are not supported by this build yet");
         mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
         mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
         if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;
@@ -1742,6 +1761,39 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             T->triMesh.push_back(meshId);
             prims->emplace_back(mesh.first_tri + i, TriangleBounds(T->P, T->triIndices, mesh.first_tri + i));
         }
+        if (!src.quads.empty()) {
+            // BilinearPatchMesh + BilinearPatch::CreatePatches (util/mesh.cpp:183-230, shapes.cpp:1040-1060): after the shape's triangles,
+            // in render space, sharing the shape's wf_mesh (material, media, orientation)
+            if (inDefinition) Die(sh.loc, "bilinear patches inside object instances are not supported by this build yet");
+            if (sh.lightIndex >= 0) Die(sh.loc, "emissive bilinear patches are not supported by this build yet");
+            if (!sh.params.GetTexture("alpha").empty() || sh.params.GetOneFloat("alpha", 1.f) < 1.f) Die(sh.loc, "alpha on bilinear patches is not supported by this build yet");
+            if (mesh.ntris == 0) mesh.first_tri = -1;  // set to the first patch's primitive id once the triangle count is known
+            const size_t v0 = (size_t)mesh.first_vertex;
+            auto P3 = [&](int vi) { return V3{T->P[3 * (v0 + vi)], T->P[3 * (v0 + vi) + 1], T->P[3 * (v0 + vi) + 2]}; };
+            auto N3f = [&](int vi) { return V3{T->N[3 * (v0 + vi)], T->N[3 * (v0 + vi) + 1], T->N[3 * (v0 + vi) + 2]}; };
+            auto UV2 = [&](int vi) { return V2{T->UV[2 * (v0 + vi)], T->UV[2 * (v0 + vi) + 1]}; };
+            for (size_t q = 0; q + 3 < src.quads.size(); q += 4) {
+                PendingSphere p{};
+                p.s.type = WF_QUADRIC_BILINEAR;
+                p.s.mesh = meshId;
+                p.s.pad[0] = (float)((src.N.empty() ? 0 : 1) | (src.uv.empty() ? 0 : 2));
+                float *a = &p.s.render_from_object.m[0][0], *b = &p.s.render_from_object.mInv[0][0];
+                const int *vi = &src.quads[q];
+                for (int k = 0; k < 4; ++k) {
+                    V3 pk = P3(vi[k]), nk = N3f(vi[k]);
+                    a[3 * k] = pk.x; a[3 * k + 1] = pk.y; a[3 * k + 2] = pk.z;
+                    b[3 * k] = nk.x; b[3 * k + 1] = nk.y; b[3 * k + 2] = nk.z;
+                }
+                V2 u00 = UV2(vi[0]), u10 = UV2(vi[1]), u01 = UV2(vi[2]), u11 = UV2(vi[3]);
+                a[12] = u00.x; a[13] = u00.y; a[14] = u10.x; a[15] = u10.y;
+                b[12] = u01.x; b[13] = u01.y; b[14] = u11.x; b[15] = u11.y;
+                // BilinearPatch::Bounds (shapes.cpp:1070-1078)
+                V3 p00 = P3(vi[0]), p10 = P3(vi[1]), p01 = P3(vi[2]), p11 = P3(vi[3]);
+                p.bounds = Union(Union(Union(B3(), p00), p01), Union(Union(B3(), p10), p11));
+                prims->emplace_back(-1 - (int)spheres.size(), p.bounds);
+                spheres.push_back(p);
+            }
+        }
         commitMesh(mesh, meshId, sh, rfo, inDefinition);
     };
     for (const ShapeEntity &sh : scene.shapes) addShape(sh, &topPrims, false);
@@ -1765,7 +1817,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     {
         const int nTris = (int)T->triIndices.size() / 3;
         for (size_t i = 0; i < spheres.size(); ++i) {
-            T->meshes[spheres[i].s.mesh].first_tri = nTris + (int)i;
+            wf_mesh &qm = T->meshes[spheres[i].s.mesh];
+            if (spheres[i].s.type != WF_QUADRIC_BILINEAR) qm.first_tri = nTris + (int)i;
+            else if (qm.ntris == 0 && qm.first_tri < 0) qm.first_tri = nTris + (int)i;  // a patch mesh: its first patch
             T->triMesh.push_back(spheres[i].s.mesh);
             T->quadrics.push_back(spheres[i].s);
         }
