@@ -100,7 +100,7 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
     ls.valid = false;
     switch (l.type) {
     case WF_LIGHT_DIFFUSE_AREA: {
-        ShapeSampleR ss = l.tri >= sv.nTriangles ? SphereSample(sv, l.tri, ctx.pi, ctx.n, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
+        ShapeSampleR ss = l.tri >= sv.nTriangles ? SphereSample(sv, l.tri, ctx.pi, ctx.n, ctx.ns, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
         if (!ss.valid || ss.pdf == 0 || LengthSquared(ss.pi.mid() - ctx.p()) == 0) return ls;
         V3 wi = Normalize(ss.pi.mid() - ctx.p());
         S4 Le = AreaLightL(sv, l, ss.n, ss.uv, -wi, lambda);
@@ -201,7 +201,7 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
 WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V3 wi, bool allowIncompletePDF) {
     switch (l.type) {
     case WF_LIGHT_DIFFUSE_AREA:
-        return l.tri >= sv.nTriangles ? SpherePDF(sv, l.tri, ctx.pi, ctx.n, wi) : TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
+        return l.tri >= sv.nTriangles ? SpherePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi) : TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
     case WF_LIGHT_UNIFORM_INFINITE: return allowIncompletePDF ? 0.f : Inv4Pi;
     case WF_LIGHT_IMAGE_INFINITE: {
         // lights.cpp:1042-1052

@@ -1314,10 +1314,274 @@ WF_NI void SphereSampleP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP,
     r.pdf = 1 / (2 * Pi * oneMinusCosThetaMax);
     r.valid = true;
 }
-WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V2 u) {
+
+// ---------------------------------------------------------------------------------------------
+// BilinearPatch as an emitter: Sample / PDF (shapes.cpp:1155-1368), SampleSphericalRectangle / InvertSphericalRectangleSample
+// (util/sampling.cpp:163-330), SphericalQuadArea (util/vecmath.h:1646-1664), InvertBilinear (util/vecmath.h:623-660).
+// The patch's area (radius field) and its IsRectangle() verdict (pad[0] bit 2) are computed at load (scene_build.cpp).
+WF_HD float SphericalQuadArea(V3 a, V3 b, V3 c, V3 d) {
+    V3 axb = Cross(a, b), bxc = Cross(b, c);
+    V3 cxd = Cross(c, d), dxa = Cross(d, a);
+    if (LengthSquared(axb) == 0 || LengthSquared(bxc) == 0 || LengthSquared(cxd) == 0 || LengthSquared(dxa) == 0) return 0;
+    axb = Normalize(axb); bxc = Normalize(bxc); cxd = Normalize(cxd); dxa = Normalize(dxa);
+    float alpha = AngleBetween(dxa, -axb);
+    float beta = AngleBetween(axb, -bxc);
+    float gam = AngleBetween(bxc, -cxd);
+    float delta = AngleBetween(cxd, -dxa);
+    return abs(alpha + beta + gam + delta - 2 * Pi);
+}
+struct SphRect { V3 rx, ry, rz; float x0, y0, z0, x1, y1, g0, g1, g2, g3, b0, b1; };
+WF_HD SphRect SphRectInit(V3 pRef, V3 s, V3 ex, V3 ey, float exl, float eyl) {
+    SphRect q;
+    q.rx = ex / exl; q.ry = ey / eyl; q.rz = Cross(q.rx, q.ry);  // Frame::FromXY
+    V3 dd = s - pRef;
+    V3 dLocal{Dot(dd, q.rx), Dot(dd, q.ry), Dot(dd, q.rz)};
+    q.z0 = dLocal.z;
+    if (q.z0 > 0) { q.rz = -q.rz; q.z0 *= -1; }
+    q.x0 = dLocal.x; q.y0 = dLocal.y;
+    q.x1 = q.x0 + exl; q.y1 = q.y0 + eyl;
+    V3 v00{q.x0, q.y0, q.z0}, v01{q.x0, q.y1, q.z0}, v10{q.x1, q.y0, q.z0}, v11{q.x1, q.y1, q.z0};
+    V3 n0 = Normalize(Cross(v00, v10)), n1 = Normalize(Cross(v10, v11));
+    V3 n2 = Normalize(Cross(v11, v01)), n3 = Normalize(Cross(v01, v00));
+    q.g0 = AngleBetween(-n0, n1); q.g1 = AngleBetween(-n1, n2);
+    q.g2 = AngleBetween(-n2, n3); q.g3 = AngleBetween(-n3, n0);
+    q.b0 = n0.z; q.b1 = n2.z;
+    return q;
+}
+WF_HD V3 SampleSphericalRectangle(V3 pRef, V3 s, V3 ex, V3 ey, V2 u, float *pdf) {
+    float exl = Length(ex), eyl = Length(ey);
+    SphRect q = SphRectInit(pRef, s, ex, ey, exl, eyl);
+    float solidAngle = q.g0 + q.g1 + q.g2 + q.g3 - 2 * Pi;
+    if (solidAngle <= 0) { *pdf = 0; return s + u.x * ex + u.y * ey; }
+    *pdf = fmax(0.f, 1 / solidAngle);
+    if ((double)solidAngle < 1e-3) return s + u.x * ex + u.y * ey;
+    float au = u.x * (q.g0 + q.g1 - 2 * Pi) + (u.x - 1) * (q.g2 + q.g3);
+    float fu = (cos(au) * q.b0 - q.b1) / sin(au);
+    float cu = copysign(1 / sqrt(Sqr(fu) + Sqr(q.b0)), fu);
+    cu = Clamp(cu, -OneMinusEpsilon, OneMinusEpsilon);
+    float xu = -(cu * q.z0) / SafeSqrt(1 - Sqr(cu));
+    xu = Clamp(xu, q.x0, q.x1);
+    float dd = sqrt(Sqr(xu) + Sqr(q.z0));
+    float h0 = q.y0 / sqrt(Sqr(dd) + Sqr(q.y0));
+    float h1 = q.y1 / sqrt(Sqr(dd) + Sqr(q.y1));
+    float hv = h0 + u.y * (h1 - h0), hvsq = Sqr(hv);
+    float yv = (hvsq < 1 - 1e-6f) ? (hv * dd) / sqrt(1 - hvsq) : q.y1;
+    return pRef + (xu * q.rx + yv * q.ry + q.z0 * q.rz);
+}
+WF_HD V2 InvertSphericalRectangleSample(V3 pRef, V3 s, V3 ex, V3 ey, V3 pRect) {
+    float exl = Length(ex), eyl = Length(ey);
+    SphRect q = SphRectInit(pRef, s, ex, ey, exl, eyl);
+    const float z0 = q.z0, x0 = q.x0, y0 = q.y0, x1 = q.x1, y1 = q.y1;
+    float z0sq = Sqr(z0), y0sq = Sqr(y0), y1sq = Sqr(y1);
+    float b0 = q.b0, b1 = q.b1, b0sq = Sqr(b0);
+    float solidAngle = (float)((double)q.g0 + (double)q.g1 + (double)q.g2 + (double)q.g3 - 2. * (double)Pi);
+    if ((double)solidAngle < 1e-3) {
+        V3 pq = pRect - s;
+        return V2{Dot(pq, ex) / LengthSquared(ex), Dot(pq, ey) / LengthSquared(ey)};
+    }
+    V3 vv = pRect - pRef;
+    V3 v{Dot(vv, q.rx), Dot(vv, q.ry), Dot(vv, q.rz)};
+    float xu = v.x, yv = v.y;
+    xu = Clamp(xu, x0, x1);
+    if (xu == 0) xu = 1e-10f;
+    float invcusq = 1 + z0sq / Sqr(xu);
+    float fusq = invcusq - b0sq;
+    float fu = copysign(sqrt(fusq), xu);
+    float sq = SafeSqrt(DifferenceOfProducts(b0, b0, b1, b1) + fusq);
+    float au = atan2(-(b1 * fu) - copysign(b0 * sq, fu * b0), b0 * b1 - sq * abs(fu));
+    if (au > 0) au -= 2 * Pi;
+    if (fu == 0) au = Pi;
+    float u0 = (au + q.g2 + q.g3) / solidAngle;
+    float ddsq = Sqr(xu) + z0sq;
+    float h0 = y0 / sqrt(ddsq + y0sq);
+    float h1 = y1 / sqrt(ddsq + y1sq);
+    float yvsq = Sqr(yv);
+    float u1[2] = {(DifferenceOfProducts(h0, h0, h0, h1) - abs(h0 - h1) * sqrt(yvsq * (ddsq + yvsq)) / (ddsq + yvsq)) / Sqr(h0 - h1),
+                   (DifferenceOfProducts(h0, h0, h0, h1) + abs(h0 - h1) * sqrt(yvsq * (ddsq + yvsq)) / (ddsq + yvsq)) / Sqr(h0 - h1)};
+    // TODO: yuck is there a better way to figure out which is the right solution?
+    float hv[2] = {Lerp(u1[0], h0, h1), Lerp(u1[1], h0, h1)};
+    float hvsq[2] = {Sqr(hv[0]), Sqr(hv[1])};
+    float yz[2] = {(hv[0] * sqrt(ddsq)) / sqrt(1 - hvsq[0]), (hv[1] * sqrt(ddsq)) / sqrt(1 - hvsq[1])};
+    V2 u = (abs(yz[0] - yv) < abs(yz[1] - yv)) ? V2{Clamp(u0, 0.f, 1.f), u1[0]} : V2{Clamp(u0, 0.f, 1.f), u1[1]};
+    return u;
+}
+WF_HD V2 InvertBilinear(V2 p, V2 v0, V2 v1, V2 v2, V2 v3) {
+    V2 a = v0, b = v1, c = v3, d = v2;
+    V2 e{b.x - a.x, b.y - a.y}, f{d.x - a.x, d.y - a.y}, g{(a.x - b.x) + (c.x - d.x), (a.y - b.y) + (c.y - d.y)}, h{p.x - a.x, p.y - a.y};
+    auto cross2d = [](V2 a, V2 b) { return DifferenceOfProducts(a.x, b.y, a.y, b.x); };
+    float k2 = cross2d(g, f);
+    float k1 = cross2d(e, f) + cross2d(h, g);
+    float k0 = cross2d(h, e);
+    if (abs(k2) < 0.001f) {
+        if (abs(e.x * k1 - g.x * k0) < 1e-5f) return V2{(h.y * k1 + f.y * k0) / (e.y * k1 - g.y * k0), -k0 / k1};
+        else return V2{(h.x * k1 + f.x * k0) / (e.x * k1 - g.x * k0), -k0 / k1};
+    }
+    float v0q, v1q;
+    if (!QuadraticF(k2, k1, k0, &v0q, &v1q)) return V2{0, 0};
+    float u = (h.x - f.x * v0q) / (e.x + g.x * v0q);
+    if (u < 0 || u > 1 || v0q < 0 || v0q > 1) return V2{(h.x - f.x * v1q) / (e.x + g.x * v1q), v1q};
+    return V2{u, v0q};
+}
+// BilinearPatch::IsRectangle (shapes.h:1512-1533) and the area of the constructor (shapes.cpp:1036-1067); evaluated at load
+WF_HD bool BlpIsRectangle(const BlpData &d) {
+    const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+    auto eq = [](V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+    if (eq(p00, p01) || eq(p01, p11) || eq(p11, p10) || eq(p10, p00)) return false;
+    N3 n = toN(Normalize(Cross(p10 - p00, p01 - p00)));
+    if (AbsDot(toN(Normalize(p11 - p00)), n) > 1e-5f) return false;
+    V3 pCenter = (p00 + p01 + p10 + p11) / 4;
+    float d2[4] = {DistanceSquared(p00, pCenter), DistanceSquared(p01, pCenter), DistanceSquared(p10, pCenter), DistanceSquared(p11, pCenter)};
+    for (int i = 1; i < 4; ++i)
+        if (abs(d2[i] - d2[0]) / d2[0] > 1e-4f) return false;
+    return true;
+}
+WF_HD float BlpArea(const BlpData &d, bool rectangle) {
+    const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+    if (rectangle) return Distance(p00, p01) * Distance(p00, p10);
+    constexpr int na = 3;
+    V3 p[na + 1][na + 1];
+    for (int i = 0; i <= na; ++i) {
+        float u = float(i) / float(na);
+        for (int j = 0; j <= na; ++j) {
+            float v = float(j) / float(na);
+            p[i][j] = LerpV(u, LerpV(v, p00, p01), LerpV(v, p10, p11));
+        }
+    }
+    float area = 0;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < na; ++j) area += 0.5f * Length(Cross(p[i + 1][j + 1] - p[i][j], p[i + 1][j] - p[i][j + 1]));
+    return area;
+}
+WF_HD N3 BlpSampleNormal(const BlpData &d, int meshFlags, V3 dpdu, V3 dpdv, float u, float v) {
+    N3 n = toN(Normalize(Cross(dpdu, dpdv)));
+    if (d.hasN) {
+        auto lerpN = [](float t, N3 a, N3 b) { return (1 - t) * a + t * b; };
+        N3 ns = lerpN(u, lerpN(v, d.n00, d.n01), lerpN(v, d.n10, d.n11));
+        n = FaceForward(n, ns);
+    } else if (meshFlags & WF_MESH_FLIP_NORMAL) n = -n;
+    return n;
+}
+WF_HD V2 BlpST(const BlpData &d, float u, float v) {
+    if (!d.hasUV) return V2{u, v};
+    auto lerp2 = [](float t, V2 a, V2 b) { return V2{(1 - t) * a.x + t * b.x, (1 - t) * a.y + t * b.y}; };
+    return lerp2(u, lerp2(v, d.uv00, d.uv01), lerp2(v, d.uv10, d.uv11));
+}
+// BilinearPatch::Sample(Point2f u) (shapes.cpp:1155-1215)
+WF_HD ShapeSampleR BlpSampleArea(const BlpData &d, int meshFlags, bool rectangle, V2 u) {
+    ShapeSampleR r;
+    r.valid = false;
+    const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+    float pdf = 1;
+    V2 uv;
+    if (!rectangle) {
+        const float w[4] = {Length(Cross(p10 - p00, p01 - p00)), Length(Cross(p10 - p00, p11 - p10)), Length(Cross(p01 - p00, p11 - p01)), Length(Cross(p11 - p10, p11 - p01))};
+        uv = SampleBilinear(u, w);
+        pdf = BilinearPDF(uv, w);
+    } else uv = u;
+    V3 pu0 = LerpV(uv.y, p00, p01), pu1 = LerpV(uv.y, p10, p11);
+    V3 p = LerpV(uv.x, pu0, pu1);
+    V3 dpdu = pu1 - pu0;
+    V3 dpdv = LerpV(uv.x, p01, p11) - LerpV(uv.x, p00, p10);
+    if (LengthSquared(dpdu) == 0 || LengthSquared(dpdv) == 0) return r;
+    V3 pAbsSum = Abs(p00) + Abs(p01) + Abs(p10) + Abs(p11);
+    r.pi = MakeP3i(p, gamma(6) * pAbsSum);
+    r.n = BlpSampleNormal(d, meshFlags, dpdu, dpdv, uv.x, uv.y);
+    r.uv = BlpST(d, uv.x, uv.y);
+    r.pdf = pdf / Length(Cross(dpdu, dpdv));
+    r.valid = true;
+    return r;
+}
+// BilinearPatch::Sample(const ShapeSampleContext &, Point2f) (shapes.cpp:1252-1327).  Out of line: pointer arguments only.
+WF_NI void BilinearSampleP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nsx, float nsy, float nsz, float ux, float uy, ShapeSampleR *out) {
+    const BlpData d = LoadBlp(*sp);
+    const bool rectangle = ((int)sp->pad[0] & 4) != 0;
+    const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+    const V3 ctxP = ctxPiP->mid();
+    const N3 ctxNs{nsx, nsy, nsz};
+    V2 u{ux, uy};
+    V3 v00 = Normalize(p00 - ctxP), v10 = Normalize(p10 - ctxP);
+    V3 v01 = Normalize(p01 - ctxP), v11 = Normalize(p11 - ctxP);
+    if (!rectangle || SphericalQuadArea(v00, v10, v11, v01) <= 1e-4f) {
+        ShapeSampleR ss = BlpSampleArea(d, meshFlags, rectangle, u);
+        ss.valid = ss.valid;
+        if (ss.valid) {
+            V3 wi = ss.pi.mid() - ctxP;
+            if (LengthSquared(wi) == 0) ss.valid = false;
+            else {
+                wi = Normalize(wi);
+                ss.pdf /= AbsDot(ss.n, -wi) / DistanceSquared(ctxP, ss.pi.mid());
+                if (IsInf(ss.pdf)) ss.valid = false;
+            }
+        }
+        *out = ss;
+        return;
+    }
+    float pdf = 1;
+    if (ctxNs.x != 0 || ctxNs.y != 0 || ctxNs.z != 0) {
+        const float w[4] = {fmax(0.01f, AbsDot(toN(v00), ctxNs)), fmax(0.01f, AbsDot(toN(v10), ctxNs)), fmax(0.01f, AbsDot(toN(v01), ctxNs)), fmax(0.01f, AbsDot(toN(v11), ctxNs))};
+        u = SampleBilinear(u, w);
+        pdf *= BilinearPDF(u, w);
+    }
+    V3 eu = p10 - p00, ev = p01 - p00;
+    float quadPDF;
+    V3 p = SampleSphericalRectangle(ctxP, p00, eu, ev, u, &quadPDF);
+    pdf *= quadPDF;
+    V2 uv{Dot(p - p00, eu) / DistanceSquared(p10, p00), Dot(p - p00, ev) / DistanceSquared(p01, p00)};
+    ShapeSampleR r;
+    r.pi = MakeP3i(p);
+    r.n = BlpSampleNormal(d, meshFlags, eu, ev, uv.x, uv.y);
+    r.uv = BlpST(d, uv.x, uv.y);
+    r.pdf = pdf;
+    r.valid = true;
+    *out = r;
+}
+// BilinearPatch::PDF(const ShapeSampleContext &, Vector3f wi) (shapes.cpp:1329-1368) over PDF(const Interaction &) (:1217-1250)
+WF_NI float BilinearPDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float nsx, float nsy, float nsz, float wx, float wy, float wz) {
+    const BlpData d = LoadBlp(*sp);
+    const bool rectangle = ((int)sp->pad[0] & 4) != 0;
+    const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+    const P3i ctxPi = *ctxPiP;
+    const V3 ctxP = ctxPi.mid();
+    const N3 ctxN{nx, ny, nz}, ctxNs{nsx, nsy, nsz};
+    const V3 wi{wx, wy, wz};
+    V3 o = OffsetRayOrigin(ctxPi, ctxN, wi);
+    float hu, hv, ht;
+    if (!IntersectBilinearPatch(o, wi, WF_INFINITY, p00, p10, p01, p11, &hu, &hv, &ht)) return 0;
+    SurfIntr si;
+    BilinearInteractionP(sp, meshFlags, hu, hv, &si);
+    const V3 pHit = si.pi.mid();
+    V3 v00 = Normalize(p00 - ctxP), v10 = Normalize(p10 - ctxP);
+    V3 v01 = Normalize(p01 - ctxP), v11 = Normalize(p11 - ctxP);
+    if (!rectangle || SphericalQuadArea(v00, v10, v11, v01) <= 1e-4f) {
+        // PDF(isect->intr): parametric (u, v) back from the interaction's (s, t)
+        V2 uv = si.uv;
+        if (d.hasUV) uv = InvertBilinear(uv, d.uv00, d.uv10, d.uv01, d.uv11);
+        float pdfA;
+        if (!rectangle) {
+            const float w[4] = {Length(Cross(p10 - p00, p01 - p00)), Length(Cross(p10 - p00, p11 - p10)), Length(Cross(p01 - p00, p11 - p01)), Length(Cross(p11 - p10, p11 - p01))};
+            pdfA = BilinearPDF(uv, w);
+        } else pdfA = 1;
+        V3 pu0 = LerpV(uv.y, p00, p01), pu1 = LerpV(uv.y, p10, p11);
+        V3 dpdu = pu1 - pu0;
+        V3 dpdv = LerpV(uv.x, p01, p11) - LerpV(uv.x, p00, p10);
+        pdfA = pdfA / Length(Cross(dpdu, dpdv));
+        float pdf = pdfA * (DistanceSquared(ctxP, pHit) / AbsDot(si.n, -wi));
+        return IsInf(pdf) ? 0.f : pdf;
+    }
+    float pdf = 1 / SphericalQuadArea(v00, v10, v11, v01);
+    if (ctxNs.x != 0 || ctxNs.y != 0 || ctxNs.z != 0) {
+        const float w[4] = {fmax(0.01f, AbsDot(toN(v00), ctxNs)), fmax(0.01f, AbsDot(toN(v10), ctxNs)), fmax(0.01f, AbsDot(toN(v01), ctxNs)), fmax(0.01f, AbsDot(toN(v11), ctxNs))};
+        V2 u = InvertSphericalRectangleSample(ctxP, p00, p10 - p00, p01 - p00, pHit);
+        return BilinearPDF(u, w) * pdf;
+    }
+    return pdf;
+}
+
+WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, N3 ctxNs, V2 u) {
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
     ShapeSampleR r;
+    if (s->type == WF_QUADRIC_BILINEAR) { BilinearSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxNs.x, ctxNs.y, ctxNs.z, u.x, u.y, &r); return r; }
     SphereSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, u.x, u.y, &r);
     return r;
 }
@@ -1348,9 +1612,10 @@ WF_NI float SpherePDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, f
     if (sin2ThetaMax < 0.00068523f /* sin^2(1.5 deg) */) oneMinusCosThetaMax = sin2ThetaMax / 2;
     return 1 / (2 * Pi * oneMinusCosThetaMax);
 }
-WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, V3 wi) {
+WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, N3 ctxNs, V3 wi) {
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
+    if (s->type == WF_QUADRIC_BILINEAR) return BilinearPDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, ctxNs.x, ctxNs.y, ctxNs.z, wi.x, wi.y, wi.z);
     return SpherePDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, wi.x, wi.y, wi.z);
 }
 

@@ -1671,6 +1671,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     struct PendingSphere { wf_quadric s; B3 bounds; };
     std::vector<PendingSphere> spheres;
     std::map<int, int> sphereOfMesh;
+    std::map<int, std::vector<int>> patchesOfMesh;  // mesh id -> its bilinear patches (indices into spheres)
     // the primitive lists in the reference's creation order (scene.cpp:1386-1470): (primitive id, bounds).  Quadric ids
     // are patched once the triangle count is known (they follow ALL triangles): stored as -1 - quadric index meanwhile.
     typedef std::vector<std::pair<int, B3>> PrimList;
@@ -1765,7 +1766,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             // BilinearPatchMesh + BilinearPatch::CreatePatches (util/mesh.cpp:183-230, shapes.cpp:1040-1060): after the shape's triangles,
             // in render space, sharing the shape's wf_mesh (material, media, orientation)
             if (inDefinition) Die(sh.loc, "bilinear patches inside object instances are not supported by this build yet");
-            if (sh.lightIndex >= 0) Die(sh.loc, "emissive bilinear patches are not supported by this build yet");
+            if (sh.lightIndex >= 0 && mesh.ntris > 0) Die(sh.loc, "an emissive plymesh with both triangle and quad faces is not supported by this build yet");
             if (!sh.params.GetTexture("alpha").empty() || sh.params.GetOneFloat("alpha", 1.f) < 1.f) Die(sh.loc, "alpha on bilinear patches is not supported by this build yet");
             if (mesh.ntris == 0) mesh.first_tri = -1;  // set to the first patch's primitive id once the triangle count is known
             const size_t v0 = (size_t)mesh.first_vertex;
@@ -1790,7 +1791,13 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
                 // BilinearPatch::Bounds (shapes.cpp:1070-1078)
                 V3 p00 = P3(vi[0]), p10 = P3(vi[1]), p01 = P3(vi[2]), p11 = P3(vi[3]);
                 p.bounds = Union(Union(Union(B3(), p00), p01), Union(Union(B3(), p10), p11));
+                // BilinearPatch ctor (shapes.cpp:1036-1067): IsRectangle() and the area, kept in the record (flag bit 2, radius field)
+                const BlpData bd = LoadBlp(p.s);
+                const bool rect = BlpIsRectangle(bd);
+                if (rect) p.s.pad[0] = (float)((int)p.s.pad[0] | 4);
+                p.s.radius = BlpArea(bd, rect);
                 prims->emplace_back(-1 - (int)spheres.size(), p.bounds);
+                patchesOfMesh[meshId].push_back((int)spheres.size());
                 spheres.push_back(p);
             }
         }
@@ -1962,6 +1969,73 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             lb.cosTheta_e = std::cos(Pi / 2);
             lb.twoSided = twoSided;
             addLightBounds(lightId, lb);
+        }
+        if (auto pit = patchesOfMesh.find(pa.mesh); pit != patchesOfMesh.end()) {
+            // one DiffuseAreaLight per bilinear patch (scene.cpp:1290-1340), in patch order; hits find theirs as
+            // first_light + (primitive id - first_tri)
+            const int nTris = (int)T->triIndices.size() / 3;
+            for (int si : pit->second) {
+                const PendingSphere &sp = spheres[si];
+                const BlpData d = LoadBlp(sp.s);
+                float area = sp.s.radius;
+                float sc = scale;
+                if (phi_v > 0) {
+                    float k_e = lightImage >= 0 ? imageLumAvg : 1.f;
+                    k_e *= (twoSided ? 2 : 1) * area * Pi;
+                    sc *= phi_v / k_e;
+                }
+                wf_light l{};
+                l.type = WF_LIGHT_DIFFUSE_AREA;
+                l.flags = twoSided ? WF_LIGHTFLAG_TWOSIDED : 0;
+                l.spectrum_offset = specOff;
+                l.scale = sc;
+                l.tri = nTris + si;
+                l.area = area;
+                l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = lightImage;
+                int lightId = (int)T->lights.size();
+                T->lights.push_back(l);
+                // DiffuseAreaLight::Bounds (lights.cpp:788-806) + BilinearPatch::NormalBounds (shapes.cpp:1080-1126)
+                const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
+                auto eq = [](V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+                const bool flip = (mesh.flags & WF_MESH_FLIP_NORMAL) != 0;
+                V3 w;
+                float cosTheta;
+                if (eq(p00, p10) || eq(p10, p11) || eq(p11, p01) || eq(p01, p00)) {
+                    V3 dpdu = LerpV(0.5f, p10, p11) - LerpV(0.5f, p00, p01);
+                    V3 dpdv = LerpV(0.5f, p01, p11) - LerpV(0.5f, p00, p10);
+                    V3 n = Normalize(Cross(dpdu, dpdv));
+                    if (d.hasN) {
+                        N3 ns = (d.n00 + d.n10 + d.n01 + d.n11) / 4;
+                        n = toV(FaceForward(toN(n), ns));
+                    } else if (flip) n = -n;
+                    w = Normalize(n);
+                    cosTheta = 1;
+                } else {
+                    V3 n00 = Normalize(Cross(p10 - p00, p01 - p00));
+                    if (d.hasN) n00 = toV(FaceForward(toN(n00), d.n00));
+                    else if (flip) n00 = -n00;
+                    V3 n10 = Normalize(Cross(p11 - p10, p00 - p10));
+                    V3 n01 = Normalize(Cross(p00 - p01, p11 - p01));
+                    V3 n11 = Normalize(Cross(p01 - p11, p10 - p11));
+                    if (d.hasN) {
+                        n10 = toV(FaceForward(toN(n10), d.n10));
+                        n01 = toV(FaceForward(toN(n01), d.n01));
+                        n11 = toV(FaceForward(toN(n11), d.n11));
+                    } else if (flip) { n10 = -n10; n01 = -n01; n11 = -n11; }
+                    V3 n = Normalize(n00 + n10 + n01 + n11);
+                    float ct = std::min(std::min(Dot(n, n00), Dot(n, n01)), std::min(Dot(n, n10), Dot(n, n11)));
+                    w = Normalize(n);   // DirectionCone(w, cosTheta) normalises
+                    cosTheta = ct < -1 ? -1 : (ct > 1 ? 1 : ct);
+                }
+                LightBoundsH lb;
+                lb.bounds = sp.bounds;
+                lb.w = Normalize(w);    // and the LightBounds ctor again
+                lb.phi = LemitMax * (sc * area * Pi);
+                lb.cosTheta_o = cosTheta;
+                lb.cosTheta_e = std::cos(Pi / 2);
+                lb.twoSided = twoSided;
+                addLightBounds(lightId, lb);
+            }
         }
         ps.ReportUnused("AreaLightSource");
     }
