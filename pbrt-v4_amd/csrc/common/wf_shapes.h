@@ -488,6 +488,17 @@ WF_HD bool BVHIntersectClosestDef(const SceneView &sv, int root, V3 o, V3 d, flo
                 for (int i = 0; i < node->nprims; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
                     ++out->trisTested;
+                    if (tri >= sv.nTriangles) {
+                        // a quadric or bilinear patch of the definition, in the definition's space
+                        QuadricHit qh;
+                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) {
+                            out->prim = tri;
+                            out->h.t = qh.tHit; out->h.b0 = qh.pObj.x; out->h.b1 = qh.pObj.y; out->h.b2 = qh.pObj.z;
+                            tMax = qh.tHit;
+                            hitAny = true;
+                        }
+                        continue;
+                    }
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
@@ -534,6 +545,11 @@ WF_HD bool BVHIntersectAnyDef(const SceneView &sv, int root, V3 o, V3 d, float t
                 for (int i = 0; i < node->nprims && !found; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
                     ++*nt;
+                    if (tri >= sv.nTriangles) {
+                        QuadricHit qh;
+                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) found = true;
+                        continue;
+                    }
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
@@ -1186,6 +1202,14 @@ WF_NI void InstanceWoP(const wf_instance *in, float x, float y, float z, float *
 WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
     if (inst >= 0) {
         V3 w;
+        if (prim >= sv.nTriangles) {
+            // a quadric inside an instance: built in object space from the instance-space ray (normalised there and after the transform
+            // back to instance space), then taken to render space by the instance transform (normalised again)
+            const wf_instance *in = sv.instances + inst;
+            V3 vI = XfVector3(in->render_from_instance.mInv, minusD);
+            SphereWoP(sv.quadrics + (prim - sv.nTriangles), vI.x, vI.y, vI.z, &w.x, &w.y, &w.z);
+            return Normalize(XfVector3(in->render_from_instance.m, w));
+        }
         InstanceWoP(sv.instances + inst, minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
         return w;
     }

@@ -1681,7 +1681,6 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (sh.name == "sphere" || sh.name == "disk" || sh.name == "cylinder") {
             // Sphere / Disk / Cylinder::Create + ctors (shapes.cpp:71-81,106-115,132-142; shapes.h:117-129,387-398,737-748);
             // kept in object space like the reference's
-            if (inDefinition) Die(sh.loc, "quadrics inside object instances are not supported by this build yet");
             const Transform &rfo = sh.renderFromObject;
             const ParamSet &ps = sh.params;
             float radius = ps.GetOneFloat("radius", 1.f);
@@ -1765,7 +1764,6 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (!src.quads.empty()) {
             // BilinearPatchMesh + BilinearPatch::CreatePatches (util/mesh.cpp:183-230, shapes.cpp:1040-1060): after the shape's triangles,
             // in render space, sharing the shape's wf_mesh (material, media, orientation)
-            if (inDefinition) Die(sh.loc, "bilinear patches inside object instances are not supported by this build yet");
             if (sh.lightIndex >= 0 && mesh.ntris > 0) Die(sh.loc, "an emissive plymesh with both triangle and quad faces is not supported by this build yet");
             if (!sh.params.GetTexture("alpha").empty() || sh.params.GetOneFloat("alpha", 1.f) < 1.f) Die(sh.loc, "alpha on bilinear patches is not supported by this build yet");
             if (mesh.ntris == 0) mesh.first_tri = -1;  // set to the first patch's primitive id once the triangle count is known
@@ -1831,6 +1829,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             T->quadrics.push_back(spheres[i].s);
         }
         for (auto &pr : topPrims) if (pr.first < 0) pr.first = nTris + (-1 - pr.first);
+        for (PrimList &dl : defPrims)
+            for (auto &pr : dl) if (pr.first < 0) pr.first = nTris + (-1 - pr.first);
     }
 
     // ---- lights: area lights first (scene.cpp:1290-1340), then the others ----

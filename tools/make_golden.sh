@@ -62,6 +62,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/hair_ref.
 # BilinearPatch shapes (bilinearmesh + a plymesh with quad faces): hand-written tests/golden/bilinear.pbrt + bilinear_quads.ply
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/bilinear_ref.pfm $G/bilinear.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/bilinear_lights_ref.pfm $G/bilinear_lights.pbrt
+# quadrics and bilinear patches inside object-instance definitions: hand-written tests/golden/instances_quadrics.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_quadrics_ref.pfm $G/instances_quadrics.pbrt
 # K12 subsurface scattering: the two blobs of blobs_small as SubsurfaceMaterials (reflectance + mfp; default coefficients with scale and g)
 sed 's/^MakeNamedMaterial "blobA".*/MakeNamedMaterial "blobA" "string type" [ "subsurface" ] "rgb reflectance" [ 0.8 0.5 0.35 ] "rgb mfp" [ 0.25 0.12 0.06 ] "float eta" [ 1.4 ] "float roughness" [ 0.15 ]/; s/^MakeNamedMaterial "blobB".*/MakeNamedMaterial "blobB" "string type" [ "subsurface" ] "float scale" [ 4 ] "float g" [ 0.3 ]/; s/killeroo-like.pfm/subsurface.pfm/' $G/blobs_small.pbrt > $G/subsurface.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/subsurface_ref.pfm $G/subsurface.pbrt
