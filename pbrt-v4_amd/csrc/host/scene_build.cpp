@@ -129,6 +129,24 @@ bool SceneTables::Load(const std::string &path) {
 namespace {
 
 // ---- textures & materials ---------------------------------------------------------------------------
+// GetMediumScatteringProperties (media.cpp:79-150) over data/medium_presets.txt (tools/extract_medium_presets.py): RGBUnboundedSpectrum in sRGB
+static bool MediumPreset(const std::string &name, SpectrumP *sigma_a, SpectrumP *sigma_s) {
+    std::ifstream f(SpectralData::Get().DataDir() + "/medium_presets.txt");
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        size_t b1 = line.find(" | "), b2 = line.find(" | ", b1 == std::string::npos ? 0 : b1 + 3);
+        if (b1 == std::string::npos || b2 == std::string::npos || line.substr(0, b1) != name) continue;
+        double s[3], a[3];
+        if (sscanf(line.c_str() + b1 + 3, "%lf %lf %lf", &s[0], &s[1], &s[2]) != 3 || sscanf(line.c_str() + b2 + 3, "%lf %lf %lf", &a[0], &a[1], &a[2]) != 3) continue;
+        const float sf[3] = {(float)s[0], (float)s[1], (float)s[2]}, af[3] = {(float)a[0], (float)a[1], (float)a[2]};  // RGB(double, double, double)
+        *sigma_a = SpectralData::Get().sRGB()->Unbounded(af);
+        *sigma_s = SpectralData::Get().sRGB()->Unbounded(sf);
+        return true;
+    }
+    return false;
+}
+
 // the Perlin permutation of util/noise.cpp (data/noise_perm.txt, written by tools/extract_noise_perm.py)
 static void LoadNoisePerm(SceneTables *T) {
     if (!T->noisePerm.empty()) return;
@@ -561,9 +579,18 @@ struct TexBuilder {
             // SubsurfaceMaterial::Create (materials.cpp:498-567)
             m.type = WF_MAT_SUBSURFACE;
             float g = ps.GetOneFloat("g", 0.f);
-            if (!ps.GetOneString("name", "").empty())
-                Die(e.loc, "subsurface: named scattering coefficients (a data table of the reference's source tree) are not supported by this build");
-            int sigma_a = GetSpectrumTextureOrNull(ps, "sigma_a", SpectrumType::Unbounded), sigma_s = GetSpectrumTextureOrNull(ps, "sigma_s", SpectrumType::Unbounded);
+            int sigma_a = -1, sigma_s = -1;
+            if (std::string pname = ps.GetOneString("name", ""); !pname.empty()) {
+                // 1. by name: the measured coefficients are reduced scattering coefficients, so g is forced to 0
+                SpectrumP pa, psc;
+                if (!MediumPreset(pname, &pa, &psc)) Die(e.loc, pname + ": named medium not found.");
+                g = 0;
+                sigma_a = SpectrumConst(*pa);
+                sigma_s = SpectrumConst(*psc);
+            } else {
+                sigma_a = GetSpectrumTextureOrNull(ps, "sigma_a", SpectrumType::Unbounded);
+                sigma_s = GetSpectrumTextureOrNull(ps, "sigma_s", SpectrumType::Unbounded);
+            }
             if (sigma_a >= 0 && sigma_s < 0) Die(e.loc, "Provided \"sigma_a\" parameter without \"sigma_s\".");
             if (sigma_s >= 0 && sigma_a < 0) Die(e.loc, "Provided \"sigma_s\" parameter without \"sigma_a\".");
             if (sigma_a < 0) {
@@ -938,11 +965,14 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
         };
         M.g = ps.GetOneFloat("g", 0.f);
         float sigmaScale = ps.GetOneFloat("scale", 1.f);
-        if (!ps.GetOneString("preset", "").empty()) Die(e.loc, "medium \"preset\" tables are not supported by this build yet");
         const bool rgbGrid = e.name == "rgbgrid";  // its sigma_a / sigma_s / Le are per-cell RGB arrays
-        SpectrumP sig_a = rgbGrid ? nullptr : ps.GetOneSpectrum("sigma_a", nullptr, SpectrumType::Unbounded);
+        SpectrumP sig_a, sig_s;
+        if (e.name == "homogeneous")   // HomogeneousMedium::Create (media.cpp:169-186): the only medium with presets
+            if (std::string preset = ps.GetOneString("preset", ""); !preset.empty() && !MediumPreset(preset, &sig_a, &sig_s))
+                fprintf(stderr, "Warning: %s: Material preset \"%s\" not found.\n", e.loc.c_str(), preset.c_str());
+        if (!sig_a) sig_a = rgbGrid ? nullptr : ps.GetOneSpectrum("sigma_a", nullptr, SpectrumType::Unbounded);
         if (!sig_a) sig_a = MakeConstant(1.f);
-        SpectrumP sig_s = rgbGrid ? nullptr : ps.GetOneSpectrum("sigma_s", nullptr, SpectrumType::Unbounded);
+        if (!sig_s) sig_s = rgbGrid ? nullptr : ps.GetOneSpectrum("sigma_s", nullptr, SpectrumType::Unbounded);
         if (!sig_s) sig_s = MakeConstant(1.f);
         M.sigma_a_offset = dense(*sig_a, sigmaScale);
         M.sigma_s_offset = dense(*sig_s, sigmaScale);

@@ -64,9 +64,14 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/bilinear_
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/bilinear_lights_ref.pfm $G/bilinear_lights.pbrt
 # quadrics and bilinear patches inside object-instance definitions: hand-written tests/golden/instances_quadrics.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_quadrics_ref.pfm $G/instances_quadrics.pbrt
+# named scattering coefficients: the fog of media_box by preset, a blob of the subsurface scene by name
+sed 's/^MakeNamedMedium "fog".*/MakeNamedMedium "fog" "string type" [ "homogeneous" ] "string preset" "Skimmilk" "float scale" [ 0.25 ] "float g" [ 0.3 ]/; s/media_box.pfm/media_preset.pfm/' $G/media_box.pbrt > $G/media_preset.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_preset_ref.pfm $G/media_preset.pbrt
 # K12 subsurface scattering: the two blobs of blobs_small as SubsurfaceMaterials (reflectance + mfp; default coefficients with scale and g)
 sed 's/^MakeNamedMaterial "blobA".*/MakeNamedMaterial "blobA" "string type" [ "subsurface" ] "rgb reflectance" [ 0.8 0.5 0.35 ] "rgb mfp" [ 0.25 0.12 0.06 ] "float eta" [ 1.4 ] "float roughness" [ 0.15 ]/; s/^MakeNamedMaterial "blobB".*/MakeNamedMaterial "blobB" "string type" [ "subsurface" ] "float scale" [ 4 ] "float g" [ 0.3 ]/; s/killeroo-like.pfm/subsurface.pfm/' $G/blobs_small.pbrt > $G/subsurface.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/subsurface_ref.pfm $G/subsurface.pbrt
+sed 's/^MakeNamedMaterial "blobB".*/MakeNamedMaterial "blobB" "string type" [ "subsurface" ] "string name" "Skin1" "float scale" [ 6 ] "float g" [ 0.5 ]/; s/subsurface.pfm/subsurface_named.pfm/' $G/subsurface.pbrt > $G/subsurface_named.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/subsurface_named_ref.pfm $G/subsurface_named.pbrt
 # goniometric + projection lights: hand-written scene tests/golden/lights_extra.pbrt (uses sky.pfm and wood.pfm)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/lights_extra_ref.pfm $G/lights_extra.pbrt
 # the same lights through the PowerLightSampler (alias table)
