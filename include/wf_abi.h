@@ -220,10 +220,11 @@ typedef struct wf_light {
     int32_t xform;               /* index into light_transforms (SPOT / IMAGE_INFINITE), or -1 */
     int32_t image;               /* IMAGE_INFINITE: index into image_lights; GONIOMETRIC / PROJECTION: index into tex_images */
     int32_t xform2;              /* PROJECTION: screenFromLight in light_transforms */
-    int32_t pad;
+    int32_t alpha_tex_plus1;     /* DIFFUSE_AREA: 1 + the float texture id of the emitter's alpha mask, 0 = none */
     float screen_bounds[4];      /* PROJECTION: screenBounds pMin.xy, pMax.xy */
 } wf_light;
 #define WF_LIGHTFLAG_TWOSIDED 1
+#define WF_LIGHTFLAG_DELTA_POSITION 2 /* an emitter whose alpha is the constant 0 (lights.cpp:690-706): never hit, sampled without MIS */
 
 /* PiecewiseConstant2D over [0,1]^2 (util/sampling.h:698-790): per row func[nx] + cdf[nx+1], row integrals,
  * marginal func[ny] + cdf[ny+1]; offsets into wf_scene_desc::table_data */

@@ -649,7 +649,7 @@ WF_HD void KSampleMediumScattering(const SceneView &sv, const WorkState &ws, int
             V3 wi = ls.wi;
             S4 beta = wbeta * HenyeyGreenstein(Dot(wo, wi), g);
             float lightPDF = ls.pdf * lightPMF;
-            float phasePDF = IsDeltaLight(light.type) ? 0.f : HenyeyGreenstein(Dot(wo, wi), g);
+            float phasePDF = IsDeltaLight(light) ? 0.f : HenyeyGreenstein(Dot(wo, wi), g);
             S4 r_u = wr_u * phasePDF;
             S4 r_l = wr_u * lightPDF;
             S4 Ld = beta * ls.L;
@@ -804,7 +804,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     V3 wo{-d4.x, -d4.y, -d4.z};
     if (!(sv.haveMedia && m.w >= 0)) wo = IntrWo(sv, prim, -1, wo);
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    S4 Le = AreaLightL(sv, light, si.n, si.uv, wo, lambda);
+    S4 Le = AreaLightL(sv, light, si.pi.mid(), si.n, si.uv, wo, lambda);
     if (!Le) return;
     S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]);
     S4 L;
@@ -1041,7 +1041,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                     if (f) {
                         S4 beta = wbeta * f * AbsDot(wi, ns);
                         float lightPDF = ls.pdf * lightPMF;
-                        float bsdfPDF = IsDeltaLight(light.type) ? 0.f : bsdf.PDF(wo, wi);
+                        float bsdfPDF = IsDeltaLight(light) ? 0.f : bsdf.PDF(wo, wi);
                         sr_u = wr_u * bsdfPDF;
                         sr_l = wr_u * lightPDF;
                         sLd = beta * ls.L;
@@ -1194,7 +1194,7 @@ WF_HD void KSubsurfaceScatter(const SceneView &sv, const WorkState &ws, int cur,
         if (!f) return;
         S4 beta = betap * f * AbsDot(wi, w.ns);
         float lightPDF = ls.pdf * lightPMF;
-        float bsdfPDF = IsDeltaLight(light.type) ? 0.f : bsdf.PDF(wo, wi);
+        float bsdfPDF = IsDeltaLight(light) ? 0.f : bsdf.PDF(wo, wi);
         S4 r_l = r_u * lightPDF;
         r_u = r_u * bsdfPDF;
         S4 Ld = beta * ls.L;

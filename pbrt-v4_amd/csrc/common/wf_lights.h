@@ -24,7 +24,9 @@ struct LightLiSample {
     bool valid;
 };
 
-WF_HD bool IsDeltaLight(int type) {
+WF_HD bool IsDeltaLight(const wf_light &l) {
+    const int type = l.type;
+    if (l.flags & WF_LIGHTFLAG_DELTA_POSITION) return true;
     return type == WF_LIGHT_POINT || type == WF_LIGHT_SPOT || type == WF_LIGHT_DISTANT || type == WF_LIGHT_GONIOMETRIC || type == WF_LIGHT_PROJECTION;
 }
 
@@ -77,9 +79,22 @@ WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavel
     const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
     return l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda);
 }
-// DiffuseAreaLight::L, lights.h:441-463 (no alpha); with an image: Image::BilerpChannel at (u, 1 - v), clamp wrap
-WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, N3 n, V2 uv, V3 w, const Wavelengths &lambda) {
+// DiffuseAreaLight::AlphaMasked (lights.h:486-496): the alpha texture sees TextureEvalContext(Interaction(p, uv));
+// a fractional alpha is resolved by HashFloat(p)
+WF_HD bool AreaLightAlphaMasked(const SceneView &sv, const wf_light &l, V3 p, V2 uv) {
+    if (l.alpha_tex_plus1 == 0) return false;
+    TexCtx tc;
+    tc.p = p;
+    tc.uv = uv;
+    float a = EvalFloatTexture(sv, l.alpha_tex_plus1 - 1, tc);
+    if (a >= 1) return false;
+    if (a <= 0) return true;
+    return HashToFloat(Hash3f(p)) > a;
+}
+// DiffuseAreaLight::L, lights.h:441-463; with an image: Image::BilerpChannel at (u, 1 - v), clamp wrap
+WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, V3 p, N3 n, V2 uv, V3 w, const Wavelengths &lambda) {
     if (!(l.flags & WF_LIGHTFLAG_TWOSIDED) && Dot(n, w) < 0) return S4c(0.f);
+    if (AreaLightAlphaMasked(sv, l, p, uv)) return S4c(0.f);
     if (l.image >= 0) {
         const wf_tex_image im = sv.texImages[l.image];
         V2 st{uv.x, 1 - uv.y};
@@ -103,7 +118,7 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
         ShapeSampleR ss = l.tri >= sv.nTriangles ? SphereSample(sv, l.tri, ctx.pi, ctx.n, ctx.ns, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
         if (!ss.valid || ss.pdf == 0 || LengthSquared(ss.pi.mid() - ctx.p()) == 0) return ls;
         V3 wi = Normalize(ss.pi.mid() - ctx.p());
-        S4 Le = AreaLightL(sv, l, ss.n, ss.uv, -wi, lambda);
+        S4 Le = AreaLightL(sv, l, ss.pi.mid(), ss.n, ss.uv, -wi, lambda);
         if (!Le) return ls;
         ls.L = Le; ls.wi = wi; ls.pdf = ss.pdf; ls.pLightPi = ss.pi; ls.pLightN = ss.n; ls.valid = true;
         return ls;

@@ -1686,7 +1686,6 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
         if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
         else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
-        if (mesh.alpha_tex >= 0 && sh.lightIndex >= 0) Die(sh.loc, "alpha-masked area lights are not supported by this build yet");
         if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres and bilinear patches are not supported by this build yet");
         mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
         mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
@@ -1918,6 +1917,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         float phi_v = ps.GetOneFloat("power", -1.0f);
         wf_mesh &mesh = T->meshes[pa.mesh];
         mesh.first_light = (int)T->lights.size();
+        // a constant-zero alpha makes the emitter a DeltaPosition light without an alpha texture (lights.cpp:690-709)
+        const bool alphaZero = mesh.alpha_tex >= 0 && T->textures[mesh.alpha_tex].type == WF_TEX_FLOAT_CONSTANT && T->textures[mesh.alpha_tex].f0 == 0;
         int specOff = T->pool.AddDense(*L);
         float LemitMax = lightImage >= 0 ? imageChannelAvg : MakeDense(*L)->MaxValue();  // Bounds(): image average or Lemit max
         if (lightImage >= 0) T->desc.cs_illuminant_offset = specOff;
@@ -1932,7 +1933,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             }
             wf_light l{};
             l.type = WF_LIGHT_DIFFUSE_AREA;
-            l.flags = twoSided ? WF_LIGHTFLAG_TWOSIDED : 0;
+            l.flags = (twoSided ? WF_LIGHTFLAG_TWOSIDED : 0) | (alphaZero ? WF_LIGHTFLAG_DELTA_POSITION : 0);
+            l.alpha_tex_plus1 = alphaZero ? 0 : mesh.alpha_tex + 1;
             l.spectrum_offset = specOff;
             l.scale = sc;
             l.tri = mesh.first_tri;
@@ -1970,7 +1972,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             }
             wf_light l{};
             l.type = WF_LIGHT_DIFFUSE_AREA;
-            l.flags = twoSided ? WF_LIGHTFLAG_TWOSIDED : 0;
+            l.flags = (twoSided ? WF_LIGHTFLAG_TWOSIDED : 0) | (alphaZero ? WF_LIGHTFLAG_DELTA_POSITION : 0);
+            l.alpha_tex_plus1 = alphaZero ? 0 : mesh.alpha_tex + 1;
             l.spectrum_offset = specOff;
             l.scale = sc;
             l.tri = tri;
@@ -2016,7 +2019,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
                 }
                 wf_light l{};
                 l.type = WF_LIGHT_DIFFUSE_AREA;
-                l.flags = twoSided ? WF_LIGHTFLAG_TWOSIDED : 0;
+                l.flags = (twoSided ? WF_LIGHTFLAG_TWOSIDED : 0) | (alphaZero ? WF_LIGHTFLAG_DELTA_POSITION : 0);
+            l.alpha_tex_plus1 = alphaZero ? 0 : mesh.alpha_tex + 1;
                 l.spectrum_offset = specOff;
                 l.scale = sc;
                 l.tri = nTris + si;

@@ -48,6 +48,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/texture_m
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_extra_ref.pfm $G/textures_extra.pbrt
 # image-textured diffuse area lights (triangles and a sphere): hand-written tests/golden/arealight_image.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_image_ref.pfm $G/arealight_image.pbrt
+# alpha-masked emitters (checkerboard cut-out, fractional alpha, the invisible alpha-0 DeltaPosition case): hand-written
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_alpha_ref.pfm $G/arealight_alpha.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
 # the reference's other BVH builder: blobs_small with `splitmethod "hlbvh"` (cpu/aggregates.cpp:389-503, 626-722)
