@@ -248,7 +248,7 @@ enum wf_wrap_mode { WF_WRAP_BLACK = 0, WF_WRAP_CLAMP = 1, WF_WRAP_REPEAT = 2, WF
 enum wf_mip_filter { WF_MIP_POINT = 0, WF_MIP_BILINEAR = 1, WF_MIP_TRILINEAR = 2 };
 typedef struct wf_tex_image {
     int32_t res[2];
-    int32_t n_levels, n_channels;   /* 1 or 3 channels */
+    int32_t n_levels, n_channels;   /* 1 (Y), 3 (R G B) or 4 (R G B A: float lookups return A, util/mipmap.cpp:403-405) */
     int32_t wrap, filter;
     int32_t level_offset[20];       /* float offsets of the levels in table_data */
 } wf_tex_image;

@@ -1,4 +1,7 @@
-// Build shim: lodepng declarations only; PNG I/O reports an error in the oracle build.
+// Build shim (test infrastructure): the part of the lodepng interface util/image.cpp calls, implemented in
+// shim_png.cpp on top of the system zlib (the vendored lodepng submodule is absent from /root/reference).
+// Decoding covers non-interlaced PNGs of every colour type at 8 and 16 bits (sub-byte grey / palette depths
+// are expanded to 8 bits); encoding writes 8-bit grey / RGB with filter 0.
 #pragma once
 #include <cstddef>
 #include <vector>
@@ -10,14 +13,13 @@ struct LodePNGInfo { LodePNGColorMode color; unsigned srgb_defined = 0; unsigned
 struct LodePNGState { LodePNGInfo info_png; LodePNGColorMode info_raw; };
 static inline void lodepng_state_init(LodePNGState *) {}
 static inline void lodepng_state_cleanup(LodePNGState *) {}
-static inline unsigned lodepng_inspect(unsigned *, unsigned *, LodePNGState *, const unsigned char *,
-                                       size_t) { return 1; }
-static inline const char *lodepng_error_text(unsigned) { return "PNG unavailable in oracle build"; }
-static inline unsigned lodepng_encode_memory(unsigned char **, size_t *, const unsigned char *,
-        unsigned, unsigned, LodePNGColorType, unsigned) { return 1; }
+unsigned lodepng_inspect(unsigned *w, unsigned *h, LodePNGState *state, const unsigned char *in, size_t insize);
+const char *lodepng_error_text(unsigned code);
+unsigned lodepng_encode_memory(unsigned char **out, size_t *outsize, const unsigned char *image, unsigned w,
+                               unsigned h, LodePNGColorType colortype, unsigned bitdepth);
 namespace lodepng {
-static inline unsigned decode(std::vector<unsigned char> &, unsigned &, unsigned &,
-        const unsigned char *, size_t, LodePNGColorType = LCT_RGBA, unsigned = 8) { return 1; }
-static inline unsigned decode(std::vector<unsigned char> &, unsigned &, unsigned &, LodePNGState &,
-        const unsigned char *, size_t) { return 1; }
+unsigned decode(std::vector<unsigned char> &out, unsigned &w, unsigned &h, const unsigned char *in,
+                size_t insize, LodePNGColorType colortype = LCT_RGBA, unsigned bitdepth = 8);
+unsigned decode(std::vector<unsigned char> &out, unsigned &w, unsigned &h, LodePNGState &state,
+                const unsigned char *in, size_t insize);
 }

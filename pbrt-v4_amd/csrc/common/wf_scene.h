@@ -330,17 +330,18 @@ WF_HD float ImageBilerpChannel(const float *table, const wf_tex_image &im, int l
 struct RGB3 { float r, g, b; };
 // MIPMap::Texel<RGB> / Bilerp<RGB> (util/mipmap.cpp:214-226,286-298), Texel<Float> / Bilerp<Float> (:208-212,395-409)
 WF_HD RGB3 MIPTexelRGB(const float *table, const wf_tex_image &im, int level, int x, int y) {
-    if (im.n_channels == 3) return RGB3{ImageTexel(table, im, level, x, y, 0), ImageTexel(table, im, level, x, y, 1), ImageTexel(table, im, level, x, y, 2)};
+    if (im.n_channels >= 3) return RGB3{ImageTexel(table, im, level, x, y, 0), ImageTexel(table, im, level, x, y, 1), ImageTexel(table, im, level, x, y, 2)};
     float v = ImageTexel(table, im, level, x, y, 0);
     return RGB3{v, v, v};
 }
 WF_HD RGB3 MIPBilerpRGB(const float *table, const wf_tex_image &im, int level, V2 st) {
-    if (im.n_channels == 3) return RGB3{ImageBilerpChannel(table, im, level, st, 0), ImageBilerpChannel(table, im, level, st, 1), ImageBilerpChannel(table, im, level, st, 2)};
+    if (im.n_channels >= 3) return RGB3{ImageBilerpChannel(table, im, level, st, 0), ImageBilerpChannel(table, im, level, st, 1), ImageBilerpChannel(table, im, level, st, 2)};
     float v = ImageBilerpChannel(table, im, level, st, 0);
     return RGB3{v, v, v};
 }
 WF_HD float MIPBilerpFloat(const float *table, const wf_tex_image &im, int level, V2 st) {
     if (im.n_channels == 1) return ImageBilerpChannel(table, im, level, st, 0);
+    if (im.n_channels == 4) return ImageBilerpChannel(table, im, level, st, 3);  // R G B A: the alpha channel
     float sum = 0;
     for (int c = 0; c < 3; ++c) sum += ImageBilerpChannel(table, im, level, st, c);
     return sum / 3;

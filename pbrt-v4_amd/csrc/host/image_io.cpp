@@ -2,10 +2,234 @@
 // scanlines, little-endian scale -1).  EXR is written uncompressed, 32-bit float, channels B,G,R.
 #include "scene.h"
 
+#include <zlib.h>
+
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 
 namespace wf {
+
+[[noreturn]] static void Die(const std::string &loc, const std::string &msg) { throw SceneError("Error: " + loc + (loc.empty() ? "" : ": ") + msg); }
+bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);
+
+// ---------------------------------------------------------------------------------------------------------------
+// ColorEncoding (util/color.h:402-477, util/color.cpp:183-279)
+static const float *SRGBToLinearLUT() {
+    static std::vector<float> lut;
+    if (lut.empty()) {
+        std::ifstream f(SpectralData::Get().DataDir() + "/srgb_to_linear_lut.txt");
+        std::string line;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream ls(line);
+            std::string tok;
+            while (ls >> tok) lut.push_back((float)strtod(tok.c_str(), nullptr));
+        }
+        if (lut.size() != 256) Die("", "data/srgb_to_linear_lut.txt: expected 256 entries (tools/extract_srgb_lut.py)");
+    }
+    return lut.data();
+}
+static float Poly(float, float c) { return c; }
+template <typename... A> static float Poly(float t, float c, A... rest) { return std::fma(t, Poly(t, rest...), c); }  // EvaluatePolynomial (util/math.h)
+// LinearToSRGB / LinearToSRGB8 (util/color.h:494-518)
+static float LinearToSRGB(float value) {
+    if (value <= 0.0031308f) return 12.92f * value;
+    float sqrtValue = std::sqrt(std::max(0.f, value));
+    float p = Poly(sqrtValue, -0.0016829072605308378f, 0.03453868659826638f, 0.7642611304733891f, 2.0041169284241644f,
+                   0.7551545191665577f, -0.016202083165206348f);
+    float q = Poly(sqrtValue, 4.178892964897981e-7f, -0.00004375359692957097f, 0.03467195408529984f, 0.6085338522168684f,
+                   1.8970238036421054f, 1.f);
+    return p / q * value;
+}
+// SRGBToLinear (util/color.h:520-531)
+static float SRGBToLinear(float value) {
+    if (value <= 0.04045f) return value * (1 / 12.92f);
+    float p = Poly(value, -0.0163933279112946f, -0.7386328024653209f, -11.199318357635072f, -47.46726633009393f, -36.04572663838034f);
+    float q = Poly(value, -0.004261480793199332f, -19.140923959601675f, -59.096406619244426f, -18.225745396846637f, 1.f);
+    return p / q * value;
+}
+ColorEnc ColorEnc::Parse(const std::string &name) {
+    ColorEnc e;
+    if (name == "linear") { e.kind = 0; return e; }
+    if (name == "sRGB") { e.kind = 1; return e; }
+    std::istringstream ss(name);
+    std::string a, b, c;
+    ss >> a >> b;
+    if (a != "gamma" || b.empty() || (ss >> c)) Die("", name + ": expected \"gamma <value>\" for color encoding");
+    e.kind = 2;
+    e.gamma = (float)atof(b.c_str());
+    if (e.gamma == 0) Die("", b + ": unable to parse gamma value");
+    return e;
+}
+float ColorEnc::ToLinear(uint8_t v) const {
+    if (kind == 0) return v / 255.f;
+    if (kind == 1) return SRGBToLinearLUT()[v];
+    return std::pow(float(v) / 255.f, gamma);   // GammaColorEncoding::applyLUT
+}
+uint8_t ColorEnc::FromLinear(float v) const {
+    auto clampf = [](float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); };
+    if (kind == 0) return uint8_t(clampf(v * 255.f + 0.5f, 0, 255));
+    if (kind == 1) {
+        if (v <= 0) return 0;
+        if (v >= 1) return 255;
+        return uint8_t(clampf(std::round(255.f * LinearToSRGB(v) + 0.f), 0, 255));
+    }
+    // GammaColorEncoding::FromLinear: a 1024-entry table of Clamp(255 pow(i / 1023, 1 / gamma) + .5, 0, 255) stored as floats
+    int i = (int)clampf(v * 1023.f, 0, 1023);
+    float t = clampf(255.f * std::pow(float(i) / 1023.f, 1.f / gamma) + .5f, 0, 255);
+    return uint8_t(t);
+}
+float ColorEnc::ToFloatLinear(float v) const { return kind == 0 ? v : kind == 1 ? SRGBToLinear(v) : std::pow(v, gamma); }
+
+float HostImage::Quantize(float v) const {
+    if (format == U256) return enc.ToLinear(enc.FromLinear(v));
+    if (format == Half) return RoundToHalf(v);
+    return v;
+}
+void HostImage::SelectChannels(int first, int count) {
+    if (first == 0 && count == nc) return;
+    const size_t n = (size_t)w * h;
+    if (format == U256) {
+        std::vector<uint8_t> o(n * count);
+        for (size_t i = 0; i < n; ++i) for (int c = 0; c < count; ++c) o[i * count + c] = p8[i * nc + first + c];
+        p8.swap(o);
+    } else {
+        std::vector<float> o(n * count);
+        for (size_t i = 0; i < n; ++i) for (int c = 0; c < count; ++c) o[i * count + c] = p32[i * nc + first + c];
+        p32.swap(o);
+    }
+    nc = count;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PNG: chunk walk, zlib inflate, scanline un-filtering (PNG specification 1.2, sections 5, 6, 9).  What the decoded
+// samples become follows ReadPNG (util/image.cpp:1260-1376): grey(+alpha) -> "Y", everything else -> R G B (A only for
+// colour type 6); 8 bits stay bytes with the encoding, 16 bits become halves of ToFloatLinear(v / 65535).
+namespace {
+struct PngFile {
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+};
+uint32_t BE32(const uint8_t *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+int PaethPredictor(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+}  // namespace
+static void ReadPNG(const std::string &path, const ColorEnc &encIn, HostImage *img) {
+    std::vector<uint8_t> file;
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) Die("", path + ": unable to open file");
+        fseek(f, 0, SEEK_END);
+        long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        file.resize(n > 0 ? n : 0);
+        if (n > 0 && fread(file.data(), 1, n, f) != (size_t)n) { fclose(f); Die("", path + ": read error"); }
+        fclose(f);
+    }
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (file.size() < 33 || memcmp(file.data(), sig, 8)) Die("", path + ": incorrect PNG signature, it's no PNG or corrupted");
+    PngFile png;
+    for (size_t pos = 8; pos + 12 <= file.size();) {
+        const uint32_t len = BE32(&file[pos]);
+        const uint8_t *type = &file[pos + 4], *data = &file[pos + 8];
+        if (pos + 12 + (size_t)len > file.size()) Die("", path + ": truncated PNG chunk");
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            png.w = BE32(data); png.h = BE32(data + 4); png.depth = data[8]; png.ctype = data[9]; png.interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) png.plte.assign(data, data + len);
+        else if (!memcmp(type, "IDAT", 4)) png.idat.insert(png.idat.end(), data, data + len);
+        else if (!memcmp(type, "IEND", 4)) break;
+        pos += 12 + (size_t)len;
+    }
+    const int ct = png.ctype;
+    const int srcNc = ct == 0 ? 1 : ct == 2 ? 3 : ct == 3 ? 1 : ct == 4 ? 2 : ct == 6 ? 4 : 0;
+    if (!png.w || !png.h || !srcNc || (png.depth != 1 && png.depth != 2 && png.depth != 4 && png.depth != 8 && png.depth != 16))
+        Die("", path + ": malformed PNG header");
+    if (png.interlace) Die("", path + ": interlaced PNG images are not supported by this build");
+    const size_t bpp = std::max<size_t>(1, (size_t)srcNc * png.depth / 8), stride = ((size_t)png.w * srcNc * png.depth + 7) / 8;
+    std::vector<uint8_t> raw((stride + 1) * png.h);
+    uLongf rawLen = raw.size();
+    if (uncompress(raw.data(), &rawLen, png.idat.data(), png.idat.size()) != Z_OK || rawLen != raw.size())
+        Die("", path + ": corrupt PNG image data");
+    // un-filter in place (the filter byte stays in front of each row)
+    for (uint32_t y = 0; y < png.h; ++y) {
+        uint8_t *row = &raw[(stride + 1) * y + 1];
+        const uint8_t *up = y ? row - (stride + 1) : nullptr;
+        const int ft = row[-1];
+        if (ft > 4) Die("", path + ": corrupt PNG filter type");
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? row[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+            int pred = 0;
+            switch (ft) {
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: pred = PaethPredictor(a, b, c); break;
+            }
+            row[i] = (uint8_t)(row[i] + pred);
+        }
+    }
+    const bool grey = ct == 0 || ct == 4, hasAlpha = ct == 6, wide = png.depth == 16;
+    const int nc = grey ? 1 : (hasAlpha ? 4 : 3);
+    img->w = (int)png.w; img->h = (int)png.h; img->nc = nc;
+    img->enc = encIn;
+    img->format = wide ? HostImage::Half : HostImage::U256;
+    const size_t npix = (size_t)png.w * png.h;
+    if (wide) img->p32.resize(npix * nc); else img->p8.resize(npix * nc);
+    // sample s of row y: 16-bit big-endian, a byte, or depth bits (MSB first) scaled to a byte (palette indices are not scaled)
+    auto sample = [&](uint32_t y, size_t s) -> unsigned {
+        const uint8_t *row = &raw[(stride + 1) * y + 1];
+        if (png.depth == 16) return (unsigned)row[2 * s] << 8 | row[2 * s + 1];
+        if (png.depth == 8) return row[s];
+        const size_t bit = s * png.depth;
+        unsigned v = (row[bit >> 3] >> (8 - png.depth - (bit & 7))) & ((1u << png.depth) - 1);
+        return ct == 3 ? v : v * 255u / ((1u << png.depth) - 1);
+    };
+    for (uint32_t y = 0; y < png.h; ++y)
+        for (uint32_t x = 0; x < png.w; ++x) {
+            unsigned v[4] = {0, 0, 0, 0};
+            if (ct == 3) {
+                const unsigned idx = sample(y, x);
+                if (3 * (size_t)idx + 2 >= png.plte.size()) Die("", path + ": PNG palette index out of range");
+                for (int c = 0; c < 3; ++c) v[c] = png.plte[3 * idx + c];
+            } else if (grey) v[0] = sample(y, (size_t)x * srcNc);
+            else for (int c = 0; c < nc; ++c) v[c] = sample(y, (size_t)x * srcNc + c);
+            const size_t o = ((size_t)y * png.w + x) * nc;
+            for (int c = 0; c < nc; ++c) {
+                if (wide) img->p32[o + c] = RoundToHalf(encIn.ToFloatLinear(v[c] / 65535.f));
+                else img->p8[o + c] = (uint8_t)v[c];
+            }
+        }
+}
+
+static void ReadPFMImage(const std::string &path, HostImage *img) {
+    std::vector<float> rgb;
+    int w = 0, h = 0;
+    if (!ReadPFM(path, &rgb, &w, &h)) Die("", path + ": unable to read PFM file");
+    bool grey = false;
+    { FILE *f = fopen(path.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); } }
+    img->format = HostImage::Float;
+    img->w = w; img->h = h; img->nc = grey ? 1 : 3;
+    img->p32.resize((size_t)w * h * img->nc);
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        for (int c = 0; c < img->nc; ++c) img->p32[i * img->nc + c] = rgb[i * 3 + c];
+}
+
+void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img) {
+    *img = HostImage();
+    const size_t dot = path.find_last_of('.');
+    std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+    for (char &c : ext) c = (char)tolower(c);
+    if (ext == "pfm") ReadPFMImage(path, img);
+    else if (ext == "png") ReadPNG(path, enc, img);
+    else Die("", path + ": no support for reading images with this extension (this build reads .pfm and .png)");
+}
 
 bool WritePFM(const std::string &path, const float *rgb, int w, int h) {
     FILE *f = fopen(path.c_str(), "wb");
@@ -73,7 +297,7 @@ static bool WriteEXR(const std::string &path, const float *rgb, int w, int h) {
 
 // float -> half -> float with round-to-nearest-even (util/float.h Half(float) ctor), what storing into a
 // PixelFormat::Half image and reading it back does (film.cpp:536, util/image.h)
-static float RoundToHalf(float f) {
+float RoundToHalf(float f) {
     uint32_t x;
     memcpy(&x, &f, 4);
     uint32_t sign = x & 0x80000000u, mag = x & 0x7fffffffu;

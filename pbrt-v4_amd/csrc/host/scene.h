@@ -183,6 +183,34 @@ struct LightBoundsH {
 void BuildLightBVH(const std::vector<std::pair<int, LightBoundsH>> &bvhLightsIn, const B3 &allLightBounds,
                    std::vector<wf_light_bvh_node> *nodes, std::vector<wf_light> *lights);
 
+// ColorEncoding (util/color.h:402-477): how 8-bit texels map to linear floats and back
+struct ColorEnc {
+    int kind = 1;     // 0 linear, 1 sRGB, 2 gamma
+    float gamma = 1;
+    static ColorEnc Linear() { ColorEnc e; e.kind = 0; return e; }
+    static ColorEnc Parse(const std::string &name);   // "linear" | "sRGB" | "gamma <value>" (ColorEncoding::Get)
+    std::string Key() const { return std::to_string(kind) + ":" + std::to_string(gamma); }
+    float ToLinear(uint8_t v) const;       // ColorEncoding::ToLinear
+    uint8_t FromLinear(float v) const;     // ColorEncoding::FromLinear
+    float ToFloatLinear(float v) const;    // ColorEncoding::ToFloatLinear (16-bit PNG samples)
+};
+// An image as Image::Read leaves it (util/image.h): 8-bit texels keep their bytes + encoding, 16-bit PNG samples are
+// stored rounded to half precision, .pfm is float.  Channels are Y | R G B | R G B A, rows top to bottom.
+struct HostImage {
+    enum Format { U256 = 0, Half = 1, Float = 2 };
+    int format = Float;
+    int w = 0, h = 0, nc = 0;
+    ColorEnc enc;
+    std::vector<uint8_t> p8;   // U256
+    std::vector<float> p32;    // Half (already rounded to half) and Float
+    float Get(size_t i) const { return format == U256 ? enc.ToLinear(p8[i]) : p32[i]; }   // Image::GetChannel's decode
+    float Quantize(float v) const;   // what SetChannel / CopyRectIn followed by GetChannel gives back for this format
+    void SelectChannels(int first, int count);   // Image::SelectChannels for a channel range
+};
+// Image::Read (util/image.cpp:1000-1040) for .pfm and .png; throws SceneError with the reference's wording
+void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img);
+float RoundToHalf(float f);
+
 // image output (image_io.cpp)
 bool WritePFM(const std::string &path, const float *rgb, int w, int h);
 bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);

@@ -27,6 +27,17 @@ namespace wf {
     throw SceneError("Error: " + loc + ": " + msg);
 }
 
+// Image::Read with the default encoding (8-bit PNG: sRGB) for the light sources: the pixels as Image::GetChannel returns
+// them, grey replicated to three channels; *nc is the file's channel count (1 Y, 3 R G B, 4 R G B A)
+static void ReadLightImage(const std::string &filename, const std::string &loc, std::vector<float> *rgb, int *w, int *h, int *nc) {
+    HostImage img;
+    try { ReadImage(filename, ColorEnc(), &img); } catch (const SceneError &e) { Die(loc, std::string(e.what()).substr(7)); }
+    *w = img.w; *h = img.h; *nc = img.nc;
+    rgb->resize((size_t)img.w * img.h * 3);
+    for (size_t i = 0; i < (size_t)img.w * img.h; ++i)
+        for (int c = 0; c < 3; ++c) (*rgb)[3 * i + c] = img.Get(i * img.nc + (img.nc >= 3 ? c : 0));
+}
+
 void SceneTables::Finalize() {
     desc.abi_version = WF_ABI_VERSION;
     desc.n_vertices = (int)P.size() / 3;
@@ -278,10 +289,61 @@ struct TexBuilder {
         if (dim == 2) SetMapping2D(te, t);
         else SetMapping3D(te, t);
     }
-    // ImageTextureBase ctor + MIPMap::CreateFromFile + Image::GeneratePyramid (textures.h:528-550, util/mipmap.cpp:163-206,
-    // util/image.cpp GeneratePyramid) for float .pfm images with power-of-two resolution
+    // ImageTextureBase ctor + MIPMap::CreateFromFile + Image::GeneratePyramid (textures.h:528-550, util/mipmap.cpp:163-206, 351-383,
+    // util/image.cpp:313-383).  The levels are uploaded as floats holding exactly what Image::GetChannel returns for the
+    // level's own storage format: an 8-bit image's levels are re-encoded to bytes (and a 16-bit one's to halves) after the
+    // float down-sampling, as CopyRectIn does, and decoded again here.
     std::map<std::string, int> imageCache;
     std::map<std::string, int> namedMaterialIds;  // in definition order: a "mix" material names earlier ones
+    // Image::ResampleWeights / FloatResizeUp (util/image.cpp:386-497): separable windowed-sinc up-sampling to the next
+    // power of two; the result per pixel does not depend on the reference's tiling
+    static void FloatResizeUp(const HostImage &img, int wm, int nw, int nh, std::vector<float> *out) {
+        struct RW { int first; float w[4]; };
+        auto weights = [](int oldRes, int newRes) {
+            std::vector<RW> wt(newRes);
+            const float filterRadius = 2, tau = 2;
+            auto sinc = [](float x) { x = Pi * x; return 1 - x * x == 1 ? 1.f : std::sin(x) / x; };   // SinXOverX (util/math.h)
+            for (int i = 0; i < newRes; ++i) {
+                float center = (i + .5f) * oldRes / newRes;
+                wt[i].first = (int)std::floor((center - filterRadius) + 0.5f);
+                for (int j = 0; j < 4; ++j) {
+                    float pos = wt[i].first + j + .5f, x = pos - center;
+                    wt[i].w[j] = std::abs(x) > filterRadius ? 0.f : sinc(x) * sinc(x / tau);
+                }
+                float invSumWts = 1 / (wt[i].w[0] + wt[i].w[1] + wt[i].w[2] + wt[i].w[3]);
+                for (int j = 0; j < 4; ++j) wt[i].w[j] *= invSumWts;
+            }
+            return wt;
+        };
+        const std::vector<RW> xw = weights(img.w, nw), yw = weights(img.h, nh);
+        const int nc = img.nc;
+        // CopyRectOut's lookups: RemapPixelCoords with the texture's wrap mode, 0 outside for "black"
+        auto fetch = [&](int x, int y, int c) -> float {
+            if (wm == WF_WRAP_OCTAHEDRAL) {
+                if (x < 0) { x = -x; y = img.h - 1 - y; } else if (x >= img.w) { x = 2 * img.w - 1 - x; y = img.h - 1 - y; }
+                if (y < 0) { x = img.w - 1 - x; y = -y; } else if (y >= img.h) { x = img.w - 1 - x; y = 2 * img.h - 1 - y; }
+                if (img.w == 1) x = 0;
+                if (img.h == 1) y = 0;
+            } else {
+                auto mod = [](int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; };
+                if (x < 0 || x >= img.w) { if (wm == WF_WRAP_REPEAT) x = mod(x, img.w); else if (wm == WF_WRAP_CLAMP) x = std::min(std::max(x, 0), img.w - 1); else return 0.f; }
+                if (y < 0 || y >= img.h) { if (wm == WF_WRAP_REPEAT) y = mod(y, img.h); else if (wm == WF_WRAP_CLAMP) y = std::min(std::max(y, 0), img.h - 1); else return 0.f; }
+            }
+            return img.Get(((size_t)y * img.w + x) * nc + c);
+        };
+        out->assign((size_t)nw * nh * nc, 0.f);
+        std::vector<float> xrow((size_t)4 * nc);
+        for (int y = 0; y < nh; ++y)
+            for (int x = 0; x < nw; ++x) {
+                const RW &rx = xw[x], &ry = yw[y];
+                for (int j = 0; j < 4; ++j)
+                    for (int c = 0; c < nc; ++c)
+                        xrow[(size_t)j * nc + c] = rx.w[0] * fetch(rx.first, ry.first + j, c) + rx.w[1] * fetch(rx.first + 1, ry.first + j, c) +
+                                                   rx.w[2] * fetch(rx.first + 2, ry.first + j, c) + rx.w[3] * fetch(rx.first + 3, ry.first + j, c);
+                for (int c = 0; c < nc; ++c)
+                    (*out)[((size_t)y * nw + x) * nc + c] = std::max(0.f, (ry.w[0] * xrow[c] + ry.w[1] * xrow[nc + c] + ry.w[2] * xrow[2 * nc + c] + ry.w[3] * xrow[3 * nc + c]));
+            }
+    }
     int LoadTexImage(const TextureEntity &te, wf_texture *t) {
         const ParamSet &ps = te.params;
         SetMapping2D(te, t);
@@ -294,31 +356,43 @@ struct TexBuilder {
         t->f0 = ps.GetOneFloat("scale", 1.f);
         t->f1 = ps.GetOneBool("invert", false) ? 1.f : 0.f;
         std::string filename = ps.GetOneString("filename", "");
-        ps.GetOneString("encoding", "linear");
         if (filename.empty()) Die(te.loc, "imagemap texture without a filename");
         if (filename[0] != '/') filename = scene->baseDir + "/" + filename;
-        std::string key = filename + "|" + filter + "|" + wrap;
+        // textures.cpp:436-438: 8-bit files default to sRGB, everything else to linear
+        const bool isPng = filename.size() > 4 && (filename.substr(filename.size() - 4) == ".png" || filename.substr(filename.size() - 4) == ".PNG");
+        const ColorEnc enc = ColorEnc::Parse(ps.GetOneString("encoding", isPng ? "sRGB" : "linear"));
+        std::string key = filename + "|" + filter + "|" + wrap + "|" + enc.Key();
         auto it = imageCache.find(key);
         if (it != imageCache.end()) return it->second;
-        std::vector<float> rgb;
-        int w = 0, h = 0;
-        if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
-            Die(te.loc, filename + ": unable to read image (this build reads .pfm textures)");
-        if ((w & (w - 1)) || (h & (h - 1))) Die(te.loc, filename + ": texture resolution must be a power of two in this build (no resampling)");
-        bool grey = false;
-        { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); } }
+        HostImage img;
+        try { ReadImage(filename, enc, &img); } catch (const SceneError &e) { Die(te.loc, std::string(e.what()).substr(7)); }
+        // MIPMap::CreateFromFile: R G B, plus A unless it is 1 everywhere
+        if (img.nc == 4) {
+            bool allOne = true;
+            for (size_t i = 0; i < (size_t)img.w * img.h && allOne; ++i) allOne = img.Get(i * 4 + 3) == 1;
+            if (allOne) img.SelectChannels(0, 3);
+        }
+        const int nc = img.nc;
+        int w = img.w, h = img.h;
+        std::vector<float> level;
+        if ((w & (w - 1)) || (h & (h - 1))) {
+            auto roundUpPow2 = [](int v) { int r = 1; while (r < v) r *= 2; return r; };
+            const int nw = roundUpPow2(w), nh = roundUpPow2(h);
+            FloatResizeUp(img, wm, nw, nh, &level);
+            w = nw; h = nh;
+        } else {
+            level.resize((size_t)w * h * nc);
+            for (size_t i = 0; i < level.size(); ++i) level[i] = img.Get(i);   // ConvertToFormat(Float)
+        }
         wf_tex_image im{};
-        im.res[0] = w; im.res[1] = h; im.n_channels = grey ? 1 : 3; im.wrap = wm; im.filter = ff;
-        const int nc = im.n_channels;
-        std::vector<float> level((size_t)w * h * nc);
-        for (size_t i = 0; i < (size_t)w * h; ++i)
-            for (int c = 0; c < nc; ++c) level[i * nc + c] = rgb[i * 3 + c];
+        im.res[0] = w; im.res[1] = h; im.n_channels = nc; im.wrap = wm; im.filter = ff;
         int lw = w, lh = h;
         im.n_levels = 1 + (31 - __builtin_clz((unsigned)std::max(w, h)));
         if (im.n_levels > 20) Die(te.loc, "texture too large");
         for (int l = 0; l < im.n_levels; ++l) {
             im.level_offset[l] = (int)T->tableData.size();
-            T->tableData.insert(T->tableData.end(), level.begin(), level.end());
+            if (img.format == HostImage::Float) T->tableData.insert(T->tableData.end(), level.begin(), level.end());
+            else for (float v : level) T->tableData.push_back(img.Quantize(v));   // CopyRectIn into the level's format, then GetChannel
             if (l == im.n_levels - 1) break;
             int nw = std::max(1, lw / 2), nh = std::max(1, lh / 2);
             std::vector<float> next((size_t)nw * nh * nc);
@@ -339,24 +413,22 @@ struct TexBuilder {
         imageCache[key] = id;
         return id;
     }
-    // BasicScene::GetNormalMap (scene.cpp:885-910): the RGB channels of the image, read bilinearly at level 0 with
-    // repeat wrap by NormalMap(); .pfm only in this build
+    // BasicScene::startLoadingNormalMaps (scene.cpp:885-910): Image::Read with the linear encoding, the R G B channels,
+    // read bilinearly at level 0 with repeat wrap by NormalMap()
     int LoadNormalMap(std::string filename, const std::string &loc) {
         if (filename.empty()) return -1;
         if (filename[0] != '/') filename = scene->baseDir + "/" + filename;
         std::string key = filename + "|normalmap";
         auto it = imageCache.find(key);
         if (it != imageCache.end()) return it->second;
-        std::vector<float> rgb;
-        int w = 0, h = 0;
-        if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
-            Die(loc, filename + ": unable to read normal map (this build reads .pfm images)");
-        { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { bool grey = fread(m, 1, 2, f) == 2 && m[1] == 'f'; fclose(f);
-          if (grey) Die(loc, filename + ": normal map image must contain R, G, and B channels"); } }
+        HostImage img;
+        try { ReadImage(filename, ColorEnc::Linear(), &img); } catch (const SceneError &e) { Die(loc, std::string(e.what()).substr(7)); }
+        if (img.nc < 3) Die(loc, filename + ": normal map image must contain R, G, and B channels");
+        img.SelectChannels(0, 3);
         wf_tex_image im{};
-        im.res[0] = w; im.res[1] = h; im.n_channels = 3; im.wrap = WF_WRAP_REPEAT; im.filter = WF_MIP_BILINEAR; im.n_levels = 1;
+        im.res[0] = img.w; im.res[1] = img.h; im.n_channels = 3; im.wrap = WF_WRAP_REPEAT; im.filter = WF_MIP_BILINEAR; im.n_levels = 1;
         im.level_offset[0] = (int)T->tableData.size();
-        T->tableData.insert(T->tableData.end(), rgb.begin(), rgb.end());
+        for (size_t i = 0; i < (size_t)img.w * img.h * 3; ++i) T->tableData.push_back(img.Get(i));
         int id = (int)T->texImages.size();
         T->texImages.push_back(im);
         imageCache[key] = id;
@@ -1891,10 +1963,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
             std::vector<float> rgb;
             int w = 0, h = 0;
-            if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
-                Die(al.loc, filename + ": unable to read image (this build reads .pfm images)");
-            { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; bool grey = false; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); }
-              if (grey) Die(al.loc, filename + ": Image provided to \"diffuse\" area light must have R, G, and B channels."); }
+            int fileNc = 0;
+            ReadLightImage(filename, al.loc, &rgb, &w, &h, &fileNc);
+            if (fileNc < 3) Die(al.loc, filename + ": Image provided to \"diffuse\" area light must have R, G, and B channels.");
             for (float v : rgb) if (!std::isfinite(v)) Die(al.loc, filename + ": image has infinite or not-a-number pixel values and so is not suitable as a light.");
             const ColorSpace *ics = SpectralData::Get().sRGB();
             wf_tex_image im{};
@@ -2143,10 +2214,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
             std::vector<float> rgb;
             int w = 0, h = 0;
-            if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
-                Die(le.loc, filename + ": unable to read image (this build reads .pfm images)");
-            { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; bool grey = false; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); }
-              if (grey) Die(le.loc, "Image provided to \"projection\" light must have R, G, and B channels."); }
+            int fileNc = 0;
+            ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc);
+            if (fileNc < 3) Die(le.loc, "Image provided to \"projection\" light must have R, G, and B channels.");
             for (float v : rgb) if (!std::isfinite(v)) Die(le.loc, filename + ": image has infinite or not-a-number pixel values and so is not suitable as a light.");
             const ColorSpace *ics = SpectralData::Get().sRGB();
             wf_tex_image im{};
@@ -2212,11 +2282,10 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
             std::vector<float> rgb;
             int w = 0, h = 0;
-            if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
-                Die(le.loc, filename + ": unable to read image (this build reads .pfm images)");
+            int fileNc = 0;
+            ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc);
             if (w != h) Die(le.loc, filename + ": image resolution is non-square. It's unlikely this is an equal-area environment map.");
-            bool grey = false;
-            { FILE *f = fopen(filename.c_str(), "rb"); char m[3] = {0, 0, 0}; if (f) { if (fread(m, 1, 2, f) == 2) grey = m[1] == 'f'; fclose(f); } }
+            const bool grey = fileNc == 1;
             wf_tex_image im{};
             im.res[0] = w; im.res[1] = h; im.n_levels = 1; im.n_channels = 1; im.wrap = WF_WRAP_CLAMP; im.filter = WF_MIP_POINT;
             im.level_offset[0] = (int)T->tableData.size();
@@ -2282,8 +2351,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
                 if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
                 std::vector<float> rgb;
                 int w = 0, h = 0;
-                if (filename.size() < 4 || filename.substr(filename.size() - 4) != ".pfm" || !ReadPFM(filename, &rgb, &w, &h))
-                    Die(le.loc, filename + ": unable to read image (this build reads RGB .pfm environment maps)");
+                int fileNc = 0;
+                ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc);
+                if (fileNc < 3) Die(le.loc, filename + ": image used for ImageInfiniteLight doesn't have R, G, B channels.");
                 for (float v : rgb) {
                     if (std::isinf(v)) Die(le.loc, filename + ": image has infinite pixel values and so is not suitable as a light.");
                     if (std::isnan(v)) Die(le.loc, filename + ": image has not-a-number pixel values and so is not suitable as a light.");

@@ -50,6 +50,10 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_image_ref.pfm $G/arealight_image.pbrt
 # alpha-masked emitters (checkerboard cut-out, fractional alpha, the invisible alpha-0 DeltaPosition case): hand-written
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_alpha_ref.pfm $G/arealight_alpha.pbrt
+# PNG image maps (every colour type / depth, sRGB / linear / gamma encodings, non-power-of-two resize, RGBA alpha, PNG normal
+# map and emitter image): fixtures from tools/make_png_fixtures.py, decoded in the reference build by oracle/ref_build/shim_png.cpp
+python3 tools/make_png_fixtures.py
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/png_textures_ref.pfm $G/png_textures.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
 # the reference's other BVH builder: blobs_small with `splitmethod "hlbvh"` (cpu/aggregates.cpp:389-503, 626-722)
