@@ -245,12 +245,14 @@ typedef struct wf_image_light {
 /* MIPMap of an image texture (util/mipmap.h:49-92): float pyramid levels (Image::GeneratePyramid,
  * util/image.cpp) stored one after the other in table_data, level 0 first, rows top to bottom, channels interleaved */
 enum wf_wrap_mode { WF_WRAP_BLACK = 0, WF_WRAP_CLAMP = 1, WF_WRAP_REPEAT = 2, WF_WRAP_OCTAHEDRAL = 3 };
-enum wf_mip_filter { WF_MIP_POINT = 0, WF_MIP_BILINEAR = 1, WF_MIP_TRILINEAR = 2 };
+enum wf_mip_filter { WF_MIP_POINT = 0, WF_MIP_BILINEAR = 1, WF_MIP_TRILINEAR = 2, WF_MIP_EWA = 3 };
 typedef struct wf_tex_image {
     int32_t res[2];
     int32_t n_levels, n_channels;   /* 1 (Y), 3 (R G B) or 4 (R G B A: float lookups return A, util/mipmap.cpp:403-405) */
     int32_t wrap, filter;
     int32_t level_offset[20];       /* float offsets of the levels in table_data */
+    int32_t ewa_lut_offset;         /* WF_MIP_EWA: the 128-entry Gaussian weight table (util/mipmap.cpp:59-191) in table_data */
+    float max_anisotropy;           /* WF_MIP_EWA: MIPMapFilterOptions::maxAnisotropy */
 } wf_tex_image;
 
 /* Light BVH node, 32 bytes, same content as LightBVHNode/CompactLightBounds (lightsamplers.h:101-257) */
@@ -299,7 +301,12 @@ enum wf_quadric_type { WF_QUADRIC_SPHERE = 0, WF_QUADRIC_DISK = 1, WF_QUADRIC_CY
                        /* BilinearPatch (shapes.h:1279-1510): a primitive of the same id range, in RENDER space.  The record's
                           render_from_object storage holds the patch instead of a transformation: m = p00 p10 p01 p11 (12 floats, then
                           uv00.st uv10.st), mInv = n00 n10 n01 n11 (12 floats, then uv01.st uv11.st); pad[0] bit 0: has normals, bit 1: has uv */
-                       WF_QUADRIC_BILINEAR = 3 };
+                       WF_QUADRIC_BILINEAR = 3,
+                       /* Curve (shapes.h:1200-1270): one u-range of a cubic Bezier curve.  radius = width[0], theta_z_min = width[1],
+                          z_min = uMin, z_max = uMax, theta_z_max = normalAngle, phi_max = invSinNormalAngle, inner_radius = curve type
+                          (0 flat, 1 cylinder, 2 ribbon), ext[0..11] = the object-space control points, ext[12..17] = the ribbon normals.
+                          Its hit record holds (u, v, tHit). */
+                       WF_QUADRIC_CURVE = 4 };
 typedef struct wf_quadric {
     float radius, z_min, z_max, theta_z_min, theta_z_max, phi_max;  /* disk: z_min = z_max = height */
     int32_t mesh;
@@ -307,6 +314,7 @@ typedef struct wf_quadric {
     float inner_radius;                /* disk */
     float pad[3];
     wf_transform render_from_object;   /* m = renderFromObject, mInv = objectFromRender */
+    float ext[20];                     /* WF_QUADRIC_CURVE: control points and ribbon normals */
 } wf_quadric;
 
 /* Object instances (ObjectBegin / ObjectInstance): the reference wraps an instance definition's own BVHAggregate

@@ -49,6 +49,10 @@ int wfh_stats(wfh_scene *s, wf_render_stats *out);
 /* RGBFilm::GetImage */
 int wfh_film_to_rgb(wfh_scene *s, const double *film, float *rgb /* [H][W][3] */);
 int wfh_write_image(const char *path, const float *rgb, int w, int h);
+/* Image::Read (util/image.cpp:877-921) for .pfm, .png and .exr: the linear pixel values Image::GetChannel returns, channels
+   Y | R G B | R G B A, rows top to bottom.  encoding: "sRGB", "linear" or "gamma <g>" for 8-bit files (NULL = sRGB).
+   Call with pixels = NULL to get the size; returns 0, or -1 with wfh_last_error(). format: 0 8-bit, 1 half, 2 float storage. */
+int wfh_read_image(const char *path, const char *encoding, int32_t *width, int32_t *height, int32_t *n_channels, int32_t *format, float *pixels);
 
 #ifdef __cplusplus
 }

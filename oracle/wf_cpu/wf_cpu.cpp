@@ -92,6 +92,8 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.haltonPrimes = d.halton_primes; sv.haltonPermOffsets = d.halton_perm_offsets; sv.haltonPerms = d.halton_perms;
     sv.haveMix = 0;
     sv.haveSubsurface = 0;
+    sv.haveCurves = 0;
+    for (int i = 0; i < d.n_quadrics; ++i) if (d.quadrics[i].type == WF_QUADRIC_CURVE) sv.haveCurves = 1;
     for (int i = 0; i < d.n_materials; ++i) {
         if (d.materials[i].type == WF_MAT_MIX) sv.haveMix = 1;
         if (d.materials[i].type == WF_MAT_SUBSURFACE) sv.haveSubsurface = 1;
@@ -560,9 +562,9 @@ static int Main(int argc, char **argv) {
                     for (int m = 1; m < WF_MAT_NTYPES; ++m)
                         for (int k = 0; k < ws.counters[(CNT_MAT0 + m) * CNT_STRIDE]; ++k) {
                             int i = ws.matQ[m][k];
-                            F4 h = ws.hit[i], d = ws.rq[cur].d[i];
+                            F4 h = ws.hit[i], d = ws.rq[cur].d[i], o = ws.rq[cur].o[i];
                             SurfIntr si;
-                            HitInteraction(sv, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, &si);
+                            HitInteraction(sv, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, &si, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z});
                             V3 wo_ = IntrWo(sv, (int)FloatToBits(h.x), HitInst(sv, ws, i), V3{-d.x, -d.y, -d.z});
                             float rec[28] = {(float)m, (float)ws.rq[cur].meta[i].x, si.pi.lo.x, si.pi.lo.y, si.pi.lo.z, si.pi.hi.x, si.pi.hi.y, si.pi.hi.z,
                                              si.n.x, si.n.y, si.n.z, si.ns.x, si.ns.y, si.ns.z, si.dpdus.x, si.dpdus.y, si.dpdus.z, wo_.x, wo_.y, wo_.z,
@@ -582,9 +584,9 @@ static int Main(int argc, char **argv) {
                     for (int m = 1; m <= 2; ++m)
                         for (int k = 0; k < ws.counters[(CNT_MAT0 + m) * CNT_STRIDE]; ++k) {
                             int i = ws.matQ[m][k];
-                            F4 h = ws.hit[i];
+                            F4 h = ws.hit[i], d = ws.rq[cur].d[i], o = ws.rq[cur].o[i];
                             SurfIntr si;
-                            HitInteraction(sv, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, &si);
+                            HitInteraction(sv, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, &si, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z});
                             V3 dpdx, dpdy;
                             ApproximateDpDxy(sv, si.pi.mid(), si.n, &dpdx, &dpdy);
                             float rec[7] = {(float)ws.rq[cur].meta[i].x, dpdx.x, dpdx.y, dpdx.z, dpdy.x, dpdy.y, dpdy.z};

@@ -353,10 +353,10 @@ WF_HD int SurfaceMedium(const wf_mesh &mesh, N3 n, V3 w, int rayMedium) {
 // addresses and differs from run to run, so this is the one place where parity with it is statistical by construction;
 // here the two material ids take the pointers' place.
 WF_HD int HitInst(const SceneView &sv, const WorkState &ws, int i) { return sv.nInstances > 0 ? ws.hitInst[i] : -1; }
-WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, int inst, float b0, float b1, float b2, V3 wo) {
+WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, int inst, float b0, float b1, float b2, V3 wo, V3 ro) {
     if (sv.materials[matId].type != WF_MAT_MIX) return matId;
     SurfIntr si;
-    HitInteraction(sv, prim, inst, b0, b1, b2, &si);
+    HitInteraction(sv, prim, inst, b0, b1, b2, &si, ro, -wo);
     TexCtx tc;
     tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
     while (sv.materials[matId].type == WF_MAT_MIX) {
@@ -384,9 +384,9 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
         const RayQueueV &q = ws.rq[cur];
         const RayQueueV &nq = ws.rq[cur ^ 1];
         SurfIntr si;
-        HitInteraction(sv, prim, inst, b0, b1, b2, &si);
         F4 o = q.o[i], d = q.d[i];
         V3 rd{d.x, d.y, d.z};
+        HitInteraction(sv, prim, inst, b0, b1, b2, &si, V3{o.x, o.y, o.z}, rd);
         V3 no = OffsetRayOrigin(si.pi, si.n, rd);
         int slot = QueueAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
         nq.o[slot] = F4{no.x, no.y, no.z, o.w};
@@ -408,8 +408,8 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
     }
     int matId = mesh.material;
     if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) {
-        F4 d = ws.rq[cur].d[i];
-        matId = ResolveMix(sv, matId, prim, inst, b0, b1, b2, V3{-d.x, -d.y, -d.z});
+        F4 d = ws.rq[cur].d[i], o = ws.rq[cur].o[i];
+        matId = ResolveMix(sv, matId, prim, inst, b0, b1, b2, V3{-d.x, -d.y, -d.z}, V3{o.x, o.y, o.z});
         ws.mixMat[i] = matId;
     }
     int mtype = sv.materials[matId].type;
@@ -440,10 +440,10 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
 // the follow-up of the HIP traversal kernel for hits on a MixMaterial (ws.mixQ): resolve, then the material queue
 WF_HD void KResolveMix(const SceneView &sv, const WorkState &ws, int cur, int qi) {
     const int i = ws.mixQ[qi];
-    F4 h = ws.hit[i], d = ws.rq[cur].d[i];
+    F4 h = ws.hit[i], d = ws.rq[cur].d[i], o = ws.rq[cur].o[i];
     int prim = (int)FloatToBits(h.x);
     const int inst = HitInst(sv, ws, i);
-    int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, inst, h.y, h.z, h.w, V3{-d.x, -d.y, -d.z});
+    int matId = ResolveMix(sv, sv.meshes[sv.triMesh[prim]].material, prim, inst, h.y, h.z, h.w, V3{-d.x, -d.y, -d.z}, V3{o.x, o.y, o.z});
     ws.mixMat[i] = matId;
     int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + sv.materials[matId].type) * CNT_STRIDE]);
     ws.matQ[sv.materials[matId].type][slot] = i;
@@ -519,9 +519,9 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
             const RayQueueV &q = ws.rq[cur];
             const RayQueueV &nq = ws.rq[cur ^ 1];
             SurfIntr si;
-            if constexpr (GENERAL) HitInteraction(sv, prim, inst, b0, b1, b2, &si);
-            else TriangleInteraction(sv, prim, b0, b1, b2, &si);
             F4 o = q.o[i], d = q.d[i];
+            if constexpr (GENERAL) HitInteraction(sv, prim, inst, b0, b1, b2, &si, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z});
+            else TriangleInteraction(sv, prim, b0, b1, b2, &si);
             V3 no = OffsetRayOrigin(si.pi, si.n, V3{d.x, d.y, d.z});
             nq.o[slot] = F4{no.x, no.y, no.z, o.w};
             nq.d[slot] = d;
@@ -708,7 +708,7 @@ WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, 
         SurfIntr si;
         bool opaque = false;
         if (hit) {
-            HitInteraction(sv, prim, inst, b0, b1, b2, &si);
+            HitInteraction(sv, prim, inst, b0, b1, b2, &si, ro, rd);
             opaque = sv.meshes[si.mesh].material >= 0;
         }
         if (opaque) {
@@ -794,7 +794,7 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     F4 h = ws.hit[i];
     int prim = (int)FloatToBits(h.x);
     SurfIntr si;
-    HitInteraction(sv, prim, -1, h.y, h.z, h.w, &si);  // emitters are top-level primitives (no area lights inside object instances)
+    HitInteraction(sv, prim, -1, h.y, h.z, h.w, &si, V3{0, 0, 0}, V3{0, 0, 0});  // emitters are top-level primitives (no area lights inside object instances), never curves
     const wf_mesh &mesh = sv.meshes[si.mesh];
     int lightId = mesh.first_light + (prim - mesh.first_tri);
     const wf_light &light = sv.lights[lightId];
@@ -893,7 +893,11 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         int prim = (int)FloatToBits(h.x);
         const int inst = HitInst(sv, ws, i);
         SurfIntr si;
-        HitInteraction(sv, prim, inst, h.y, h.z, h.w, &si);
+        {
+            V3 ro{0, 0, 0}, rd{0, 0, 0};   // only a curve's interaction needs the ray that found it
+            if (sv.haveCurves) { F4 o4 = q.o[i], d4 = q.d[i]; ro = V3{o4.x, o4.y, o4.z}; rd = V3{d4.x, d4.y, d4.z}; }
+            HitInteraction(sv, prim, inst, h.y, h.z, h.w, &si, ro, rd);
+        }
         const wf_mesh &mesh = sv.meshes[si.mesh];
         int matId = mesh.material;
         if (sv.haveMix && sv.materials[matId].type == WF_MAT_MIX) matId = ws.mixMat[i];
@@ -1108,7 +1112,7 @@ WF_HD float IntersectOneRandom(const SceneView &sv, V3 p0, V3 p1, int material, 
         st.n = 0;
         if (!BVHIntersectClosest(sv, r.o, r.d, 1.f, st, &ch)) break;
         SurfIntr si;
-        HitInteraction(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si);
+        HitInteraction(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si, r.o, r.d);
         basePi = si.pi; baseN = si.n;
         if (sv.meshes[si.mesh].material == material) {
             // wrs.Add(SubsurfaceInteraction(si->intr), 1.f)  (util/sampling.h:535-546)

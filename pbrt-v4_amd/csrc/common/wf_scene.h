@@ -65,6 +65,7 @@ struct SceneView {
     const wf_instance *instances;
     const wf_instance_def *instanceDefs;
     int nInstances;
+    int haveCurves;         // some primitive is a Curve segment: its interaction is rebuilt from the ray (HitInteraction)
     int haveSubsurface;     // some material is a SubsurfaceMaterial: K12 runs, and every depth draws 3 more sample dimensions
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat
     int haveAlpha;          // some mesh carries an alpha texture: selects the traversal-kernel variant with the alpha test
@@ -364,10 +365,72 @@ WF_HD bool MIPLevel(const wf_tex_image &im, float dsdx, float dtdx, float dsdy, 
     *iLevel = il > 0 ? il : 0;
     return true;
 }
+WF_HD float LengthSquared2(V2 v) { return Sqr(v.x) + Sqr(v.y); }
+// MIPMap::EWA (util/mipmap.cpp:300-349): the texels inside the unit ellipse of the two footprint axes, Gaussian weights
+// from the table.  FLOAT: Texel<Float> (channel 0 only, returned in .r)
+template <bool FLOAT>
+WF_HD RGB3 MIPEWA(const float *table, const wf_tex_image &im, int level, V2 st, V2 dst0, V2 dst1) {
+    if (level >= im.n_levels) return FLOAT ? RGB3{ImageTexel(table, im, im.n_levels - 1, 0, 0, 0), 0, 0} : MIPTexelRGB(table, im, im.n_levels - 1, 0, 0);
+    const int rx = im.res[0] >> level > 0 ? im.res[0] >> level : 1, ry = im.res[1] >> level > 0 ? im.res[1] >> level : 1;
+    st.x = st.x * rx - 0.5f;
+    st.y = st.y * ry - 0.5f;
+    dst0.x *= rx; dst0.y *= ry;
+    dst1.x *= rx; dst1.y *= ry;
+    float A = Sqr(dst0.y) + Sqr(dst1.y) + 1;
+    float B = -2 * (dst0.x * dst0.y + dst1.x * dst1.y);
+    float C = Sqr(dst0.x) + Sqr(dst1.x) + 1;
+    float invF = 1 / (A * C - Sqr(B) * 0.25f);
+    A *= invF; B *= invF; C *= invF;
+    float det = -Sqr(B) + 4 * A * C;
+    float invDet = 1 / det;
+    float uSqrt = SafeSqrt(det * C), vSqrt = SafeSqrt(A * det);
+    int s0 = (int)ceil(st.x - 2 * invDet * uSqrt), s1 = (int)floor(st.x + 2 * invDet * uSqrt);
+    int t0 = (int)ceil(st.y - 2 * invDet * vSqrt), t1 = (int)floor(st.y + 2 * invDet * vSqrt);
+    RGB3 sum{0, 0, 0};
+    float sumWts = 0;
+    const float *lut = table + im.ewa_lut_offset;
+    for (int it = t0; it <= t1; ++it) {
+        float tt = it - st.y;
+        for (int is = s0; is <= s1; ++is) {
+            float ss = is - st.x;
+            float r2 = A * Sqr(ss) + B * ss * tt + C * Sqr(tt);
+            if (r2 < 1) {
+                int index = (int)(r2 * 128);
+                if (index > 127) index = 127;
+                float weight = lut[index];
+                if (FLOAT) sum.r += weight * ImageTexel(table, im, level, is, it, 0);
+                else {
+                    RGB3 tx = MIPTexelRGB(table, im, level, is, it);
+                    sum.r += weight * tx.r; sum.g += weight * tx.g; sum.b += weight * tx.b;
+                }
+                sumWts += weight;
+            }
+        }
+    }
+    return RGB3{sum.r / sumWts, sum.g / sumWts, sum.b / sumWts};
+}
+// the EWA branch of MIPMap::Filter (util/mipmap.cpp:264-283)
+template <bool FLOAT>
+WF_HD RGB3 MIPFilterEWA(const float *table, const wf_tex_image &im, V2 st, V2 dst0, V2 dst1) {
+    if (LengthSquared2(dst0) < LengthSquared2(dst1)) { V2 t = dst0; dst0 = dst1; dst1 = t; }
+    float longerVecLength = sqrt(LengthSquared2(dst0)), shorterVecLength = sqrt(LengthSquared2(dst1));
+    if (shorterVecLength * im.max_anisotropy < longerVecLength && shorterVecLength > 0) {
+        float scale = longerVecLength / (shorterVecLength * im.max_anisotropy);
+        dst1.x *= scale; dst1.y *= scale;
+        shorterVecLength *= scale;
+    }
+    if (shorterVecLength == 0) return FLOAT ? RGB3{MIPBilerpFloat(table, im, 0, st), 0, 0} : MIPBilerpRGB(table, im, 0, st);
+    float lod = fmax(0.f, im.n_levels - 1 + Log2f(shorterVecLength));
+    int ilod = (int)floor(lod);
+    RGB3 a = MIPEWA<FLOAT>(table, im, ilod, st, dst0, dst1), b = MIPEWA<FLOAT>(table, im, ilod + 1, st, dst0, dst1);
+    float t = lod - ilod;
+    return RGB3{Lerp(t, a.r, b.r), FLOAT ? 0.f : Lerp(t, a.g, b.g), FLOAT ? 0.f : Lerp(t, a.b, b.b)};
+}
 WF_NI void MIPFilterRGBP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy, float *r, float *g, float *b) {
     const wf_tex_image im = *imp;
     const V2 st{s_, t_};
     RGB3 o = [&]() -> RGB3 {
+    if (im.filter == WF_MIP_EWA) return MIPFilterEWA<false>(table, im, st, V2{dsdx, dtdx}, V2{dsdy, dtdy});
     float level;
     int iLevel;
     if (!MIPLevel(im, dsdx, dtdx, dsdy, dtdy, &level, &iLevel)) return MIPTexelRGB(table, im, im.n_levels - 1, 0, 0);
@@ -390,6 +453,7 @@ WF_HD RGB3 MIPFilterRGB(const SceneView &sv, int image, V2 st, float dsdx, float
 WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy) {
     const wf_tex_image im = *imp;
     const V2 st{s_, t_};
+    if (im.filter == WF_MIP_EWA) return MIPFilterEWA<true>(table, im, st, V2{dsdx, dtdx}, V2{dsdy, dtdy}).r;
     float level;
     int iLevel;
     if (!MIPLevel(im, dsdx, dtdx, dsdy, dtdy, &level, &iLevel)) return ImageTexel(table, im, im.n_levels - 1, 0, 0, 0);

@@ -409,7 +409,262 @@ WF_HD bool BilinearBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax,
     out->phi = 0;
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Curve (shapes.h:1200-1270, shapes.cpp:519-733): one u-range [uMin, uMax] of a cubic Bezier curve with a width, tested by
+// recursive subdivision in a ray-aligned frame.  The record (wf_quadric, type WF_QUADRIC_CURVE) carries the CurveCommon:
+// radius = width[0], theta_z_min = width[1], z_min = uMin, z_max = uMax, theta_z_max = normalAngle, phi_max = invSinNormalAngle,
+// inner_radius = type (0 flat, 1 cylinder, 2 ribbon), ext[0..11] = cpObj, ext[12..17] = n[0], n[1]; render_from_object as usual.
+struct CFloatD { float v, err; };
+WF_HD CFloatD TwoProdD(float a, float b) { float ab = a * b; return {ab, fma(a, b, -ab)}; }
+WF_HD CFloatD TwoSumD(float a, float b) { float s = a + b, delta = s - a; return {s, (a - (s - delta)) + (b - delta)}; }
+WF_HD CFloatD IPD(float a, float b) { return TwoProdD(a, b); }
+template <typename... T>
+WF_HD CFloatD IPD(float a, float b, T... terms) {
+    CFloatD ab = TwoProdD(a, b);
+    CFloatD tp = IPD(terms...);
+    CFloatD sum = TwoSumD(ab.v, tp.v);
+    return {sum.v, ab.err + (tp.err + sum.err)};
+}
+template <typename... T>
+WF_HD float InnerProductD(T... terms) { CFloatD ip = IPD(terms...); return ip.v + ip.err; }   // util/math.h:594-610
+struct M44 { float m[4][4]; };
+// Inverse(SquareMatrix<4>) (util/math.h:1560-1632)
+WF_HD bool Inverse44(const M44 &a, M44 *out) {
+    const auto &m = a.m;
+    float s0 = DifferenceOfProducts(m[0][0], m[1][1], m[1][0], m[0][1]);
+    float s1 = DifferenceOfProducts(m[0][0], m[1][2], m[1][0], m[0][2]);
+    float s2 = DifferenceOfProducts(m[0][0], m[1][3], m[1][0], m[0][3]);
+    float s3 = DifferenceOfProducts(m[0][1], m[1][2], m[1][1], m[0][2]);
+    float s4 = DifferenceOfProducts(m[0][1], m[1][3], m[1][1], m[0][3]);
+    float s5 = DifferenceOfProducts(m[0][2], m[1][3], m[1][2], m[0][3]);
+    float c0 = DifferenceOfProducts(m[2][0], m[3][1], m[3][0], m[2][1]);
+    float c1 = DifferenceOfProducts(m[2][0], m[3][2], m[3][0], m[2][2]);
+    float c2 = DifferenceOfProducts(m[2][0], m[3][3], m[3][0], m[2][3]);
+    float c3 = DifferenceOfProducts(m[2][1], m[3][2], m[3][1], m[2][2]);
+    float c4 = DifferenceOfProducts(m[2][1], m[3][3], m[3][1], m[2][3]);
+    float c5 = DifferenceOfProducts(m[2][2], m[3][3], m[3][2], m[2][3]);
+    float determinant = InnerProductD(s0, c5, -s1, c4, s2, c3, s3, c2, s5, c0, -s4, c1);
+    if (determinant == 0) return false;
+    float s = 1 / determinant;
+    auto &r = out->m;
+    r[0][0] = s * InnerProductD(m[1][1], c5, m[1][3], c3, -m[1][2], c4);
+    r[0][1] = s * InnerProductD(-m[0][1], c5, m[0][2], c4, -m[0][3], c3);
+    r[0][2] = s * InnerProductD(m[3][1], s5, m[3][3], s3, -m[3][2], s4);
+    r[0][3] = s * InnerProductD(-m[2][1], s5, m[2][2], s4, -m[2][3], s3);
+    r[1][0] = s * InnerProductD(-m[1][0], c5, m[1][2], c2, -m[1][3], c1);
+    r[1][1] = s * InnerProductD(m[0][0], c5, m[0][3], c1, -m[0][2], c2);
+    r[1][2] = s * InnerProductD(-m[3][0], s5, m[3][2], s2, -m[3][3], s1);
+    r[1][3] = s * InnerProductD(m[2][0], s5, m[2][3], s1, -m[2][2], s2);
+    r[2][0] = s * InnerProductD(m[1][0], c4, m[1][3], c0, -m[1][1], c2);
+    r[2][1] = s * InnerProductD(-m[0][0], c4, m[0][1], c2, -m[0][3], c0);
+    r[2][2] = s * InnerProductD(m[3][0], s4, m[3][3], s0, -m[3][1], s2);
+    r[2][3] = s * InnerProductD(-m[2][0], s4, m[2][1], s2, -m[2][3], s0);
+    r[3][0] = s * InnerProductD(-m[1][0], c3, m[1][1], c1, -m[1][2], c0);
+    r[3][1] = s * InnerProductD(m[0][0], c3, m[0][2], c0, -m[0][1], c1);
+    r[3][2] = s * InnerProductD(-m[3][0], s3, m[3][1], s1, -m[3][2], s0);
+    r[3][3] = s * InnerProductD(m[2][0], s3, m[2][2], s0, -m[2][1], s1);
+    return true;
+}
+// LookAt (util/transform.cpp:81-113): returns cameraFromWorld (the numeric inverse) and worldFromCamera
+WF_HD bool LookAtD(V3 pos, V3 look, V3 up, M44 *cameraFromWorld, M44 *worldFromCamera) {
+    M44 w{};
+    w.m[0][3] = pos.x; w.m[1][3] = pos.y; w.m[2][3] = pos.z; w.m[3][3] = 1;
+    V3 dir = Normalize(look - pos);
+    V3 right = Normalize(Cross(Normalize(up), dir));
+    V3 newUp = Cross(dir, right);
+    w.m[0][0] = right.x; w.m[1][0] = right.y; w.m[2][0] = right.z; w.m[3][0] = 0;
+    w.m[0][1] = newUp.x; w.m[1][1] = newUp.y; w.m[2][1] = newUp.z; w.m[3][1] = 0;
+    w.m[0][2] = dir.x; w.m[1][2] = dir.y; w.m[2][2] = dir.z; w.m[3][2] = 0;
+    *worldFromCamera = w;
+    return Inverse44(w, cameraFromWorld);
+}
+// Transform::operator()(Point3f) with the homogeneous divide (util/transform.h:303-313)
+WF_HD V3 XfPointW(const float m[4][4], V3 p) {
+    float xp = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
+    float yp = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
+    float zp = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
+    float wp = m[3][0] * p.x + m[3][1] * p.y + m[3][2] * p.z + m[3][3];
+    if (wp == 1) return V3{xp, yp, zp};
+    return V3{xp, yp, zp} / wp;
+}
+// Transform::operator()(const Ray &, Float *tMax = nullptr) (util/transform.h:372-385) with the matrix m: the origin's
+// rounding-error bound is walked off along d; Curve::IntersectRay passes no tMax
+WF_HD void XfRayOffset(const float m[4][4], V3 o, V3 d, V3 *oOut, V3 *dOut) {
+    P3i oi = XfPointI(m, o, V3{0, 0, 0});
+    V3 dd = XfVector3(m, d);
+    Ivl ox(oi.lo.x, oi.hi.x), oy(oi.lo.y, oi.hi.y), oz(oi.lo.z, oi.hi.z);
+    const float lengthSquared = LengthSquared(dd);
+    if (lengthSquared > 0) {
+        const V3 oError{(ox.hi - ox.lo) / 2, (oy.hi - oy.lo) / 2, (oz.hi - oz.lo) / 2};
+        const float dt = Dot(Abs(dd), oError) / lengthSquared;
+        const V3 off = dd * dt;
+        ox = ox + Ivl(off.x); oy = oy + Ivl(off.y); oz = oz + Ivl(off.z);
+    }
+    *oOut = V3{ox.mid(), oy.mid(), oz.mid()};
+    *dOut = dd;
+}
+// util/splines.h:17-62
+WF_HD V3 BlossomCubicBezier(const V3 *p, float u0, float u1, float u2) {
+    V3 a[3] = {LerpV(u0, p[0], p[1]), LerpV(u0, p[1], p[2]), LerpV(u0, p[2], p[3])};
+    V3 b[2] = {LerpV(u1, a[0], a[1]), LerpV(u1, a[1], a[2])};
+    return LerpV(u2, b[0], b[1]);
+}
+WF_HD V3 EvaluateCubicBezierD(const V3 *cp, float u, V3 *deriv) {
+    V3 cp1[3] = {LerpV(u, cp[0], cp[1]), LerpV(u, cp[1], cp[2]), LerpV(u, cp[2], cp[3])};
+    V3 cp2[2] = {LerpV(u, cp1[0], cp1[1]), LerpV(u, cp1[1], cp1[2])};
+    if (deriv) {
+        if (LengthSquared(cp2[1] - cp2[0]) > 0) *deriv = 3 * (cp2[1] - cp2[0]);
+        else *deriv = cp[3] - cp[0];
+    }
+    return LerpV(u, cp2[0], cp2[1]);
+}
+WF_HD void CubicBezierControlPoints(const V3 *cp, float uMin, float uMax, V3 *out) {
+    out[0] = BlossomCubicBezier(cp, uMin, uMin, uMin);
+    out[1] = BlossomCubicBezier(cp, uMin, uMin, uMax);
+    out[2] = BlossomCubicBezier(cp, uMin, uMax, uMax);
+    out[3] = BlossomCubicBezier(cp, uMax, uMax, uMax);
+}
+WF_HD int Log2IntF(float v) {   // util/math.h:372-384
+    if (v < 1) return -Log2IntF(1 / v);
+    const uint32_t midsignif = 0x3504f3u;
+    const uint32_t bits = FloatToBits(v);
+    return ((int)(bits >> 23) - 127) + (((bits & ((1u << 23) - 1)) >= midsignif) ? 1 : 0);
+}
+struct CurveData { V3 cp[4]; float width0, width1, uMin, uMax, normalAngle, invSinNormalAngle; int type; N3 n0, n1; };
+WF_HD CurveData LoadCurve(const wf_quadric &s) {
+    CurveData c;
+    for (int i = 0; i < 4; ++i) c.cp[i] = V3{s.ext[3 * i], s.ext[3 * i + 1], s.ext[3 * i + 2]};
+    c.width0 = s.radius; c.width1 = s.theta_z_min; c.uMin = s.z_min; c.uMax = s.z_max;
+    c.normalAngle = s.theta_z_max; c.invSinNormalAngle = s.phi_max; c.type = (int)s.inner_radius;
+    c.n0 = N3{s.ext[12], s.ext[13], s.ext[14]}; c.n1 = N3{s.ext[15], s.ext[16], s.ext[17]};
+    return c;
+}
+// the ray-aligned frame of Curve::IntersectRay (shapes.cpp:560-571): object-space segment control points, LookAt(o, o + d, dx)
+WF_HD void CurveRayFrame(const CurveData &c, V3 o, V3 d, V3 *cpObj, M44 *rayFromObject, M44 *objectFromRay) {
+    CubicBezierControlPoints(c.cp, c.uMin, c.uMax, cpObj);
+    V3 dx = Cross(d, cpObj[3] - cpObj[0]);
+    if (LengthSquared(dx) == 0) { V3 dy; CoordinateSystem(d, &dx, &dy); }
+    LookAtD(o, o + d, dx, rayFromObject, objectFromRay);
+}
+// the ribbon normal at u (shapes.cpp:665-675)
+WF_HD N3 CurveRibbonNormal(const CurveData &c, float u) {
+    if (c.normalAngle == 0) return c.n0;
+    float sin0 = sin((1 - u) * c.normalAngle) * c.invSinNormalAngle;
+    float sin1 = sin(u * c.normalAngle) * c.invSinNormalAngle;
+    return sin0 * c.n0 + sin1 * c.n1;
+}
+WF_HD bool CurveBoundsOverlapRay(const V3 *cps, float maxWidth, float zMax) {
+    // Union(Bounds3f(cps[0], cps[1]), Bounds3f(cps[2], cps[3])) expanded by maxWidth / 2 against [0, 0, 0] - [0, 0, zMax]
+    const float e = 0.5f * maxWidth;
+    float lox = fmin(fmin(cps[0].x, cps[1].x), fmin(cps[2].x, cps[3].x)) - e, hix = fmax(fmax(cps[0].x, cps[1].x), fmax(cps[2].x, cps[3].x)) + e;
+    float loy = fmin(fmin(cps[0].y, cps[1].y), fmin(cps[2].y, cps[3].y)) - e, hiy = fmax(fmax(cps[0].y, cps[1].y), fmax(cps[2].y, cps[3].y)) + e;
+    float loz = fmin(fmin(cps[0].z, cps[1].z), fmin(cps[2].z, cps[3].z)) - e, hiz = fmax(fmax(cps[0].z, cps[1].z), fmax(cps[2].z, cps[3].z)) + e;
+    // Overlaps(rayBounds, curveBounds) (util/vecmath.h): pMax >= pMin && pMin <= pMax per axis; rayBounds = Bounds3f((0,0,0), (0,0,zMax))
+    const float rzlo = fmin(0.f, zMax), rzhi = fmax(0.f, zMax);
+    bool x = (0.f >= lox) && (0.f <= hix);
+    bool y = (0.f >= loy) && (0.f <= hiy);
+    bool z = (rzhi >= loz) && (rzlo <= hiz);
+    return x && y && z;
+}
+// Curve::IntersectRay + RecursiveIntersect (shapes.cpp:552-733), the recursion unrolled onto an explicit stack (both halves of a
+// split are bounds-tested before the first is descended, as the loop over seg does).  wantHit = 0 is IntersectP: the first leaf hit
+// returns.  Out of line, pointer arguments only: the traversal kernels keep their register budget.
+WF_NI bool CurveIntersectP(const wf_quadric *sp, float rox, float roy, float roz, float rdx, float rdy, float rdz, float tMax, int wantHit,
+                           float *uOut, float *vOut, float *tOut) {
+    const CurveData c = LoadCurve(*sp);
+    V3 o, d;
+    XfRayOffset(sp->render_from_object.mInv, V3{rox, roy, roz}, V3{rdx, rdy, rdz}, &o, &d);
+    V3 cpObj[4];
+    M44 rayFromObject, objectFromRay;
+    CurveRayFrame(c, o, d, cpObj, &rayFromObject, &objectFromRay);
+    struct Seg { V3 cp[4]; float u0, u1; int depth; };
+    Seg stack[12];
+    int sp_ = 0;
+    Seg root;
+    for (int i = 0; i < 4; ++i) root.cp[i] = XfPointW(rayFromObject.m, cpObj[i]);
+    const float rayLength = Length(d);
+    const float zMax = rayLength * tMax;
+    {
+        float maxWidth = fmax(Lerp(c.uMin, c.width0, c.width1), Lerp(c.uMax, c.width0, c.width1));
+        if (!CurveBoundsOverlapRay(root.cp, maxWidth, zMax)) return false;
+    }
+    float L0 = 0;
+    for (int i = 0; i < 2; ++i)
+        L0 = fmax(L0, fmax(fmax(abs(root.cp[i].x - 2 * root.cp[i + 1].x + root.cp[i + 2].x), abs(root.cp[i].y - 2 * root.cp[i + 1].y + root.cp[i + 2].y)),
+                           abs(root.cp[i].z - 2 * root.cp[i + 1].z + root.cp[i + 2].z)));
+    int maxDepth = 0;
+    if (L0 > 0) {
+        float eps = fmax(c.width0, c.width1) * .05f;
+        int r0 = Log2IntF(1.41421356237f * 6.f * L0 / (8.f * eps)) / 2;
+        maxDepth = Clamp(r0, 0, 10);
+    }
+    root.u0 = c.uMin; root.u1 = c.uMax; root.depth = maxDepth;
+    stack[sp_++] = root;
+    bool have = false;
+    float bestT = 0, bestU = 0, bestV = 0;
+    while (sp_ > 0) {
+        const Seg g = stack[--sp_];
+        if (g.depth > 0) {
+            // SubdivideCubicBezier (util/splines.h:45-54)
+            V3 sp7[7] = {g.cp[0], (g.cp[0] + g.cp[1]) / 2, (g.cp[0] + 2 * g.cp[1] + g.cp[2]) / 4, (g.cp[0] + 3 * g.cp[1] + 3 * g.cp[2] + g.cp[3]) / 8,
+                         (g.cp[1] + 2 * g.cp[2] + g.cp[3]) / 4, (g.cp[2] + g.cp[3]) / 2, g.cp[3]};
+            float u[3] = {g.u0, (g.u0 + g.u1) / 2, g.u1};
+            // second half first onto the stack: the first half is descended first
+            for (int seg = 1; seg >= 0; --seg) {
+                float maxWidth = fmax(Lerp(u[seg], c.width0, c.width1), Lerp(u[seg + 1], c.width0, c.width1));
+                if (!CurveBoundsOverlapRay(&sp7[3 * seg], maxWidth, zMax)) continue;
+                Seg n;
+                for (int i = 0; i < 4; ++i) n.cp[i] = sp7[3 * seg + i];
+                n.u0 = u[seg]; n.u1 = u[seg + 1]; n.depth = g.depth - 1;
+                stack[sp_++] = n;
+            }
+            continue;
+        }
+        const V3 *cp = g.cp;
+        float edge = (cp[1].y - cp[0].y) * -cp[0].y + cp[0].x * (cp[0].x - cp[1].x);
+        if (edge < 0) continue;
+        edge = (cp[2].y - cp[3].y) * -cp[3].y + cp[3].x * (cp[3].x - cp[2].x);
+        if (edge < 0) continue;
+        V2 segmentDir{cp[3].x - cp[0].x, cp[3].y - cp[0].y};
+        float denom = Sqr(segmentDir.x) + Sqr(segmentDir.y);
+        if (denom == 0) continue;
+        float w = SumOfProducts(-cp[0].x, segmentDir.x, -cp[0].y, segmentDir.y) / denom;   // Dot(Vector2f, Vector2f)
+        float u = Clamp(Lerp(w, g.u0, g.u1), g.u0, g.u1);
+        float hitWidth = Lerp(u, c.width0, c.width1);
+        if (c.type == 2) {
+            N3 nHit = CurveRibbonNormal(c, u);
+            hitWidth *= AbsDot(nHit, d) / rayLength;
+        }
+        V3 dpcdw;
+        V3 pc = EvaluateCubicBezierD(cp, Clamp(w, 0.f, 1.f), &dpcdw);
+        float ptCurveDist2 = Sqr(pc.x) + Sqr(pc.y);
+        if (ptCurveDist2 > Sqr(hitWidth) * 0.25f) continue;
+        if (pc.z < 0 || pc.z > zMax) continue;
+        if (!wantHit) return true;
+        float tHit = pc.z / rayLength;
+        if (have && tHit > bestT) continue;
+        float ptCurveDist = sqrt(ptCurveDist2);
+        float edgeFunc = dpcdw.x * -pc.y + pc.x * dpcdw.y;
+        float v = (edgeFunc > 0) ? 0.5f + ptCurveDist / hitWidth : 0.5f - ptCurveDist / hitWidth;
+        have = true; bestT = tHit; bestU = u; bestV = v;
+    }
+    if (have) { *uOut = bestU; *vOut = bestV; *tOut = bestT; }
+    return have;
+}
+WF_HD bool CurveBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    float u, v, t;
+    if (!CurveIntersectP(&s, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, tMax, 1, &u, &v, &t)) return false;
+    out->tHit = t;
+    out->pObj = V3{u, v, t};   // the hit record's three floats: (u, v) on the curve and the hit's parametric distance
+    out->phi = 0;
+    return true;
+}
+// CURVES = false: a caller that knows the scene has no curves leaves the curve code (and its register budget: a kernel is
+// allocated the maximum over its out-of-line callees) out
+template <bool CURVES = true>
 WF_HD bool QuadricBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, QuadricHit *out) {
+    if constexpr (CURVES) if (s.type == WF_QUADRIC_CURVE) return CurveBasicIntersect(s, ro, rd, tMax, out);
     if (s.type == WF_QUADRIC_BILINEAR) return BilinearBasicIntersect(s, ro, rd, tMax, out);
     if (s.type == WF_QUADRIC_DISK) return DiskBasicIntersect(s, ro, rd, tMax, out);
     if (s.type == WF_QUADRIC_CYLINDER) return CylinderBasicIntersect(s, ro, rd, tMax, out);
@@ -1125,6 +1380,65 @@ WF_NI void BilinearInteractionP(const wf_quadric *sp, int meshFlags, float u, fl
     }
 }
 
+
+// The SurfaceInteraction Curve::RecursiveIntersect builds at its accepted leaf (shapes.cpp:683-727), rebuilt from the hit
+// record (u, v, tHit) and the ray the primitive was intersected with (ro, rd: in the space the primitive lives in).
+WF_NI void CurveInteractionP(const wf_quadric *sp, int meshFlags, float u, float v, float tHit, float rox, float roy, float roz,
+                             float rdx, float rdy, float rdz, SurfIntr *si) {
+    const wf_quadric &s = *sp;
+    const CurveData c = LoadCurve(s);
+    V3 o, d;
+    XfRayOffset(s.render_from_object.mInv, V3{rox, roy, roz}, V3{rdx, rdy, rdz}, &o, &d);
+    const float rayLength = Length(d);
+    float hitWidth = Lerp(u, c.width0, c.width1);
+    N3 nHit{0, 0, 0};
+    if (c.type == 2) {
+        nHit = CurveRibbonNormal(c, u);
+        hitWidth *= AbsDot(nHit, d) / rayLength;
+    }
+    V3 dpdu, dpdv;
+    EvaluateCubicBezierD(c.cp, u, &dpdu);
+    if (c.type == 2) dpdv = Normalize(Cross(nHit, dpdu)) * hitWidth;
+    else {
+        V3 cpObj[4];
+        M44 rayFromObject, objectFromRay;
+        CurveRayFrame(c, o, d, cpObj, &rayFromObject, &objectFromRay);
+        V3 dpduPlane = XfVector3(rayFromObject.m, dpdu);   // objectFromRay.ApplyInverse(dpdu)
+        V3 dpdvPlane = Normalize(V3{-dpduPlane.y, dpduPlane.x, 0}) * hitWidth;
+        if (c.type == 1) {
+            // Rotate(-theta, dpduPlane) (util/transform.h:243-283) applied to a vector
+            float theta = Lerp(v, -90.f, 90.f);
+            float sinTheta = sin(Radians(-theta)), cosTheta = cos(Radians(-theta));
+            V3 a = Normalize(dpduPlane);
+            float m00 = a.x * a.x + (1 - a.x * a.x) * cosTheta, m01 = a.x * a.y * (1 - cosTheta) - a.z * sinTheta, m02 = a.x * a.z * (1 - cosTheta) + a.y * sinTheta;
+            float m10 = a.x * a.y * (1 - cosTheta) + a.z * sinTheta, m11 = a.y * a.y + (1 - a.y * a.y) * cosTheta, m12 = a.y * a.z * (1 - cosTheta) - a.x * sinTheta;
+            float m20 = a.x * a.z * (1 - cosTheta) - a.y * sinTheta, m21 = a.y * a.z * (1 - cosTheta) + a.x * sinTheta, m22 = a.z * a.z + (1 - a.z * a.z) * cosTheta;
+            V3 q = dpdvPlane;
+            dpdvPlane = V3{m00 * q.x + m01 * q.y + m02 * q.z, m10 * q.x + m11 * q.y + m12 * q.z, m20 * q.x + m21 * q.y + m22 * q.z};
+        }
+        dpdv = XfVector3(objectFromRay.m, dpdvPlane);
+    }
+    V3 pError{hitWidth, hitWidth, hitWidth};
+    V3 pHit = o + d * tHit;   // ray(tHit)
+    bool flipNormal = (meshFlags & WF_MESH_FLIP_NORMAL) != 0;
+    N3 nObj = toN(Normalize(Cross(dpdu, dpdv)));   // SurfaceInteraction ctor (interaction.h:142-160)
+    if (flipNormal) nObj = -nObj;
+    const float(*m)[4] = s.render_from_object.m;
+    const float(*mi)[4] = s.render_from_object.mInv;
+    si->pi = XfPointI(m, pHit, pError);
+    si->n = Normalize(XfNormal3(mi, nObj));
+    si->uv = V2{u, v};
+    si->dpdu = XfVector3(m, dpdu);
+    si->dpdv = XfVector3(m, dpdv);
+    si->dndu = XfNormal3(mi, N3{0, 0, 0});
+    si->dndv = XfNormal3(mi, N3{0, 0, 0});
+    si->ns = FaceForward(Normalize(XfNormal3(mi, nObj)), si->n);
+    si->dpdus = si->dpdu;
+    si->dpdvs = si->dpdv;
+    si->dndus = si->dndu;
+    si->dndvs = si->dndv;
+    si->mesh = s.mesh;
+}
 WF_HD void SphereInteraction(const SceneView &sv, int prim, V3 pHit, SurfIntr *si) {
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     SurfIntr tmp;  // the out-of-line call's result lives in memory; *si stays in registers
@@ -1221,8 +1535,16 @@ WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
 // the SurfaceInteraction of a hit record (prim, three floats): barycentrics for a triangle, pObj for a sphere
 // inst >= 0: the primitive was reached through that object instance — the interaction is built in the definition's
 // space and transformed (TransformedPrimitive::Intersect)
-WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si) {
-    if (prim >= sv.nTriangles) SphereInteraction(sv, prim, V3{b0, b1, b2}, si);
+WF_HD bool IsCurvePrim(const SceneView &sv, int prim) { return sv.haveCurves && prim >= sv.nTriangles && sv.quadrics[prim - sv.nTriangles].type == WF_QUADRIC_CURVE; }
+// ro, rd: the render-space ray that found the hit — only a curve's interaction depends on it (its frame is ray-aligned)
+WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si, V3 ro, V3 rd) {
+    if (IsCurvePrim(sv, prim)) {
+        if (inst >= 0) { float tm = WF_INFINITY; InstanceRay(sv.instances[inst], ro, rd, &tm, &ro, &rd); }
+        const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
+        SurfIntr tmp;
+        CurveInteractionP(s, sv.meshes[s->mesh].flags, b0, b1, b2, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, &tmp);
+        *si = tmp;
+    } else if (prim >= sv.nTriangles) SphereInteraction(sv, prim, V3{b0, b1, b2}, si);
     else TriangleInteraction(sv, prim, b0, b1, b2, si);
     if (inst >= 0) {
         SurfIntr tmp = *si;

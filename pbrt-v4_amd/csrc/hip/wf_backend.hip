@@ -63,7 +63,7 @@ struct wf_ctx {
     int *stackSpill = nullptr;   // [rows][MAX_GRID*BLOCK], rows from the trees' depths (wf_scene_upload)
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
-    int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything (see GeneralPrims)
+    int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
     int persistentGridShadow = 1024;
     static bool splitRouteWanted() { return !getenv("WF_SPLIT_ROUTE") || atoi(getenv("WF_SPLIT_ROUTE")) != 0; }
@@ -306,7 +306,7 @@ struct GeneralPrims {
     }
     __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const {
         if constexpr (GEN == 1) return false;
-        else return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], w.o, dir(), tMax, qh);
+        else return QuadricBasicIntersect<GEN == 3>(sv.quadrics[prim - sv.nTriangles], w.o, dir(), tMax, qh);
     }
 };
 template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
@@ -784,8 +784,8 @@ struct Prof {
         const int gen_ = ctx->genMode;                                                                         \
         const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
         if (ORDER == 0) {                                                                                      \
-            if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); } \
-            else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); } \
+            if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<3, true>), __VA_ARGS__); } \
+            else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<3, false>), __VA_ARGS__); } \
         }                                                                                                      \
     } while (0)
 // the closest-hit walk with the routing split off (ctx->splitRoute)
@@ -793,8 +793,8 @@ struct Prof {
     do {                                                                                                       \
         const int gen_ = ctx->genMode;                                                                         \
         const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
-        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); } \
-        else { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, false, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, false, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<2, false, true>), __VA_ARGS__); } \
+        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<3, true, true>), __VA_ARGS__); } \
+        else { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, false, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, false, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, false, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<3, false, true>), __VA_ARGS__); } \
     } while (0)
 #define LAUNCHT(name, kernel, grid, ...)                                                   \
     do {                                                                                   \
@@ -1145,6 +1145,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.matTypeMask = 0;
     sv.haveMix = 0;
     sv.haveSubsurface = 0;
+    sv.haveCurves = 0;
+    for (int i = 0; i < d->n_quadrics; ++i) if (d->quadrics[i].type == WF_QUADRIC_CURVE) sv.haveCurves = 1;
     for (int i = 0; i < d->n_materials; ++i) {
         int t = d->materials[i].type;
         if (t == WF_MAT_MIX) {
@@ -1195,7 +1197,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         std::vector<LeafTri> lt;
         {
             ctx->genMode = 0;
-            if (d->n_quadrics > 0) ctx->genMode = 2;
+            if (d->n_quadrics > 0) ctx->genMode = sv.haveCurves ? 3 : 2;
             for (int i = 0; i < d->n_meshes && ctx->genMode < 2; ++i)
                 if (d->meshes[i].alpha_tex >= 0) {
                     const int tt = d->textures[d->meshes[i].alpha_tex].type;
@@ -1233,8 +1235,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             const int gen = ctx->genMode;
             const bool inst = ctx->svHost.nInstances > 0, split = ctx->splitRouteWanted();
             const void *kc, *ks;
-#define WF_PICK(K, ...) (inst ? (gen == 0 ? (const void *)K<0, true __VA_ARGS__> : gen == 1 ? (const void *)K<1, true __VA_ARGS__> : (const void *)K<2, true __VA_ARGS__>) \
-                              : (gen == 0 ? (const void *)K<0, false __VA_ARGS__> : gen == 1 ? (const void *)K<1, false __VA_ARGS__> : (const void *)K<2, false __VA_ARGS__>))
+#define WF_PICK(K, ...) (inst ? (gen == 0 ? (const void *)K<0, true __VA_ARGS__> : gen == 1 ? (const void *)K<1, true __VA_ARGS__> : gen == 2 ? (const void *)K<2, true __VA_ARGS__> : (const void *)K<3, true __VA_ARGS__>) \
+                              : (gen == 0 ? (const void *)K<0, false __VA_ARGS__> : gen == 1 ? (const void *)K<1, false __VA_ARGS__> : gen == 2 ? (const void *)K<2, false __VA_ARGS__> : (const void *)K<3, false __VA_ARGS__>))
             if (split) kc = WF_PICK(k_closest_fast, , true);
             else kc = WF_PICK(k_closest_fast, , false);
             ks = WF_PICK(k_shadow_fast);

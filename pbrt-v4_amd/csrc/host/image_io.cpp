@@ -221,6 +221,162 @@ static void ReadPFMImage(const std::string &path, HostImage *img) {
         for (int c = 0; c < img->nc; ++c) img->p32[i * img->nc + c] = rgb[i * 3 + c];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// OpenEXR, single-part scan-line files (OpenEXR file layout: magic, version, attribute list, line-offset table, chunks;
+// compression NONE / RLE / ZIPS / ZIP — the zlib-based ones; PIZ, PXR24, B44 and DWA files are refused with a message).
+// What the pixels become follows ReadEXR (util/image.cpp:1055-1166): all channels of one type, half -> PixelFormat::Half,
+// float -> PixelFormat::Float; here the channels are put in the order Y | R G B | R G B A the image-map and light code selects.
+static float HalfBitsToFloat(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {  // subnormal half: man * 2^-24, exact in float
+            float v = (float)man * 5.9604644775390625e-08f;
+            memcpy(&bits, &v, 4);
+            bits |= sign;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+static void ReadEXR(const std::string &path, HostImage *img) {
+    std::vector<uint8_t> file;
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) Die("", "Unable to read image file \"" + path + "\": cannot open");
+        fseek(f, 0, SEEK_END);
+        long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        file.resize(n > 0 ? n : 0);
+        if (n > 0 && fread(file.data(), 1, n, f) != (size_t)n) { fclose(f); Die("", path + ": read error"); }
+        fclose(f);
+    }
+    auto fail = [&](const std::string &why) { Die("", "Unable to read image file \"" + path + "\": " + why); };
+    size_t pos = 0;
+    auto need = [&](size_t n) { if (pos + n > file.size()) fail("file is truncated"); };
+    auto rd32 = [&]() { need(4); uint32_t v; memcpy(&v, &file[pos], 4); pos += 4; return v; };
+    auto rdStr = [&]() { std::string r; while (true) { need(1); char c = (char)file[pos++]; if (!c) break; r.push_back(c); } return r; };
+    if (rd32() != 20000630u) fail("not an OpenEXR file");
+    const uint32_t version = rd32();
+    if (version & 0x200u) fail("tiled OpenEXR files are not supported by this build");
+    if (version & 0x1800u) fail("deep / multi-part OpenEXR files are not supported by this build");
+    struct Chan { std::string name; int type; };
+    std::vector<Chan> chans;
+    int compression = -1, dw[4] = {0, 0, -1, -1}, lineOrder = 0;
+    while (true) {
+        std::string name = rdStr();
+        if (name.empty()) break;
+        std::string type = rdStr();
+        const uint32_t size = rd32();
+        need(size);
+        const uint8_t *v = &file[pos];
+        if (name == "channels") {
+            size_t p = 0;
+            while (p < size && v[p]) {
+                Chan c;
+                while (v[p]) c.name.push_back((char)v[p++]);
+                ++p;
+                int32_t t; memcpy(&t, v + p, 4);
+                c.type = t;
+                int32_t xs, ys; memcpy(&xs, v + p + 8, 4); memcpy(&ys, v + p + 12, 4);
+                if (xs != 1 || ys != 1) fail("sub-sampled channels are not supported by this build");
+                p += 16;
+                chans.push_back(c);
+            }
+        } else if (name == "compression") compression = v[0];
+        else if (name == "dataWindow") memcpy(dw, v, 16);
+        else if (name == "lineOrder") lineOrder = v[0];
+        else if (name == "chromaticities" && size >= 32) {
+            // RGBColorSpace::Lookup (util/colorspace.cpp): this build's image maps are sRGB / Rec.709
+            float c[8]; memcpy(c, v, 32);
+            const float srgb[8] = {.64f, .33f, .3f, .6f, .15f, .06f, .3127f, .3290f};
+            for (int i = 0; i < 8; ++i) if (std::abs(c[i] - srgb[i]) > 1e-3f) fail("only sRGB / Rec.709 chromaticities are supported by this build");
+        }
+        pos += size;
+    }
+    (void)lineOrder;
+    const int w = dw[2] - dw[0] + 1, h = dw[3] - dw[1] + 1;
+    if (w <= 0 || h <= 0 || chans.empty()) fail("malformed header");
+    for (const Chan &c : chans) {
+        if (c.type != chans[0].type) fail("images with multiple channel types are not supported");
+        if (c.type != 1 && c.type != 2) fail("only half and float channels are supported");
+    }
+    const bool isHalf = chans[0].type == 1;
+    const int bytesPer = isHalf ? 2 : 4;
+    int linesPerChunk;
+    switch (compression) {
+    case 0: case 1: case 2: linesPerChunk = 1; break;   // NONE, RLE, ZIPS
+    case 3: linesPerChunk = 16; break;                   // ZIP
+    default: fail("compression method " + std::to_string(compression) + " (PIZ / PXR24 / B44 / DWA) is not supported by this build (NONE, RLE, ZIPS, ZIP are)"); return;
+    }
+    // destination channel of every file channel (the file stores them in alphabetical order)
+    auto find = [&](const char *n) { for (size_t i = 0; i < chans.size(); ++i) if (chans[i].name == n) return (int)i; return -1; };
+    int src[4] = {-1, -1, -1, -1}, nc;
+    if (find("R") >= 0 && find("G") >= 0 && find("B") >= 0) { src[0] = find("R"); src[1] = find("G"); src[2] = find("B"); src[3] = find("A"); nc = src[3] >= 0 ? 4 : 3; }
+    else if (chans.size() == 1) { src[0] = 0; nc = 1; }
+    else if (find("Y") >= 0) { src[0] = find("Y"); nc = 1; }
+    else { fail("image doesn't have R, G, and B channels"); return; }
+    img->format = isHalf ? HostImage::Half : HostImage::Float;
+    img->w = w; img->h = h; img->nc = nc;
+    img->p32.assign((size_t)w * h * nc, 0.f);
+    const int nChunks = (h + linesPerChunk - 1) / linesPerChunk;
+    const size_t tablePos = pos;
+    need((size_t)8 * nChunks);
+    const size_t lineBytes = (size_t)w * bytesPer * chans.size();
+    std::vector<uint8_t> raw, tmp;
+    for (int ck = 0; ck < nChunks; ++ck) {
+        uint64_t off; memcpy(&off, &file[tablePos + 8 * (size_t)ck], 8);
+        if (off + 8 > file.size()) fail("chunk offset out of range");
+        int32_t y0, dataSize;
+        memcpy(&y0, &file[off], 4); memcpy(&dataSize, &file[off + 4], 4);
+        if (dataSize < 0 || off + 8 + (size_t)dataSize > file.size()) fail("chunk size out of range");
+        const uint8_t *data = &file[off + 8];
+        const int nLines = std::min(linesPerChunk, dw[3] - y0 + 1);
+        if (y0 < dw[1] || nLines <= 0) fail("chunk outside the data window");
+        const size_t expect = lineBytes * nLines;
+        raw.resize(expect);
+        if ((size_t)dataSize == expect) memcpy(raw.data(), data, expect);   // stored uncompressed (also when compression did not help)
+        else if (compression == 0) fail("chunk size does not match the data window");
+        else {
+            tmp.resize(expect);
+            if (compression == 1) {
+                // RLE: a signed count byte; negative = that many literal bytes, otherwise count + 1 copies of the next byte
+                size_t o = 0, i = 0;
+                while (i < (size_t)dataSize) {
+                    int c = (int8_t)data[i++];
+                    if (c < 0) { size_t n = (size_t)-c; if (i + n > (size_t)dataSize || o + n > expect) fail("corrupt RLE data"); memcpy(&tmp[o], &data[i], n); o += n; i += n; }
+                    else { size_t n = (size_t)c + 1; if (i >= (size_t)dataSize || o + n > expect) fail("corrupt RLE data"); memset(&tmp[o], data[i++], n); o += n; }
+                }
+                if (o != expect) fail("corrupt RLE data");
+            } else {
+                uLongf outLen = expect;
+                if (uncompress(tmp.data(), &outLen, data, dataSize) != Z_OK || outLen != expect) fail("corrupt zip data");
+            }
+            // undo the byte predictor, then re-interleave the two halves
+            for (size_t i = 1; i < expect; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);
+            const size_t half = (expect + 1) / 2;
+            for (size_t i = 0; i < expect; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+        }
+        for (int l = 0; l < nLines; ++l) {
+            const int y = y0 - dw[1] + l;
+            const uint8_t *line = raw.data() + lineBytes * l;
+            for (int c = 0; c < nc; ++c) {
+                const uint8_t *cp = line + (size_t)src[c] * w * bytesPer;
+                for (int x = 0; x < w; ++x) {
+                    float v;
+                    if (isHalf) { uint16_t hb; memcpy(&hb, cp + 2 * (size_t)x, 2); v = HalfBitsToFloat(hb); }
+                    else memcpy(&v, cp + 4 * (size_t)x, 4);
+                    img->p32[((size_t)y * w + x) * nc + c] = v;
+                }
+            }
+        }
+    }
+}
+
 void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img) {
     *img = HostImage();
     const size_t dot = path.find_last_of('.');
@@ -228,7 +384,8 @@ void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img) {
     for (char &c : ext) c = (char)tolower(c);
     if (ext == "pfm") ReadPFMImage(path, img);
     else if (ext == "png") ReadPNG(path, enc, img);
-    else Die("", path + ": no support for reading images with this extension (this build reads .pfm and .png)");
+    else if (ext == "exr") ReadEXR(path, img);
+    else Die("", path + ": no support for reading images with this extension (this build reads .pfm, .png and .exr)");
 }
 
 bool WritePFM(const std::string &path, const float *rgb, int w, int h) {

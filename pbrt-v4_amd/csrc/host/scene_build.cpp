@@ -294,6 +294,7 @@ struct TexBuilder {
     // level's own storage format: an 8-bit image's levels are re-encoded to bytes (and a 16-bit one's to halves) after the
     // float down-sampling, as CopyRectIn does, and decoded again here.
     std::map<std::string, int> imageCache;
+    int ewaLutOffset = -1;
     std::map<std::string, int> namedMaterialIds;  // in definition order: a "mix" material names earlier ones
     // Image::ResampleWeights / FloatResizeUp (util/image.cpp:386-497): separable windowed-sinc up-sampling to the next
     // power of two; the result per pixel does not depend on the reference's tiling
@@ -347,10 +348,12 @@ struct TexBuilder {
     int LoadTexImage(const TextureEntity &te, wf_texture *t) {
         const ParamSet &ps = te.params;
         SetMapping2D(te, t);
-        ps.GetOneFloat("maxanisotropy", 8.f);
+        const float maxAniso = ps.GetOneFloat("maxanisotropy", 8.f);
         std::string filter = ps.GetOneString("filter", "bilinear"), wrap = ps.GetOneString("wrap", "repeat");
-        int ff = filter == "point" ? WF_MIP_POINT : filter == "bilinear" ? WF_MIP_BILINEAR : filter == "trilinear" ? WF_MIP_TRILINEAR : -1;
-        if (ff < 0) Die(te.loc, filter + ": only the point, bilinear and trilinear texture filters are supported by this build");
+        // ParseFilter (util/mipmap.cpp:27-41)
+        int ff = filter == "point" ? WF_MIP_POINT : filter == "bilinear" ? WF_MIP_BILINEAR : filter == "trilinear" ? WF_MIP_TRILINEAR :
+                 (filter == "ewa" || filter == "EWA") ? WF_MIP_EWA : -1;
+        if (ff < 0) Die(te.loc, filter + ": filter function unknown");
         int wm = wrap == "clamp" ? WF_WRAP_CLAMP : wrap == "repeat" ? WF_WRAP_REPEAT : wrap == "black" ? WF_WRAP_BLACK : wrap == "octahedralsphere" ? WF_WRAP_OCTAHEDRAL : -1;
         if (wm < 0) Die(te.loc, wrap + ": wrap mode unknown");
         t->f0 = ps.GetOneFloat("scale", 1.f);
@@ -361,7 +364,7 @@ struct TexBuilder {
         // textures.cpp:436-438: 8-bit files default to sRGB, everything else to linear
         const bool isPng = filename.size() > 4 && (filename.substr(filename.size() - 4) == ".png" || filename.substr(filename.size() - 4) == ".PNG");
         const ColorEnc enc = ColorEnc::Parse(ps.GetOneString("encoding", isPng ? "sRGB" : "linear"));
-        std::string key = filename + "|" + filter + "|" + wrap + "|" + enc.Key();
+        std::string key = filename + "|" + filter + "|" + wrap + "|" + enc.Key() + "|" + (ff == WF_MIP_EWA ? std::to_string(maxAniso) : "");
         auto it = imageCache.find(key);
         if (it != imageCache.end()) return it->second;
         HostImage img;
@@ -386,6 +389,18 @@ struct TexBuilder {
         }
         wf_tex_image im{};
         im.res[0] = w; im.res[1] = h; im.n_channels = nc; im.wrap = wm; im.filter = ff;
+        im.max_anisotropy = maxAniso;
+        if (ff == WF_MIP_EWA) {
+            // MIPFilterLUT (util/mipmap.cpp:45-191): the table's literals are exp(-2 r2) - exp(-2) in float, r2 = i / 127
+            if (ewaLutOffset < 0) {
+                ewaLutOffset = (int)T->tableData.size();
+                for (int i = 0; i < 128; ++i) {
+                    float alpha = 2, r2 = float(i) / float(127);
+                    T->tableData.push_back(std::exp(-alpha * r2) - std::exp(-alpha));
+                }
+            }
+            im.ewa_lut_offset = ewaLutOffset;
+        }
         int lw = w, lh = h;
         im.n_levels = 1 + (31 - __builtin_clz((unsigned)std::max(w, h)));
         if (im.n_levels > 20) Die(te.loc, "texture too large");
@@ -1543,7 +1558,7 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         if (!ps.GetOneString("emissionfilename", "").empty()) Die(sh.loc, "bilinearmesh \"emissionfilename\" is not supported by this build");
         return true;
     }
-    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh, bilinearmesh, sphere, disk, cylinder)");
+    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh, bilinearmesh, curve, sphere, disk, cylinder)");
 }
 
 // Minimal PLY reader (ascii + binary_little_endian; vertex x,y,z[,nx,ny,nz][,u,v|s,t], face vertex_indices
@@ -1758,7 +1773,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
         if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
         else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
-        if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres and bilinear patches are not supported by this build yet");
+        if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres, curves and bilinear patches are not supported by this build yet");
         mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
         mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
         if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;
@@ -1827,6 +1842,110 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             sphereOfMesh[meshId] = (int)spheres.size();
             spheres.push_back(p);
             commitMesh(mesh, meshId, sh, rfo, false);
+            return;
+        }
+        if (sh.name == "curve") {
+            // Curve::Create + CreateCurve + CurveCommon (shapes.cpp:761-900, 494-517, 458-481): every Bezier / b-spline segment becomes
+            // 2^splitdepth Curve primitives over sub-ranges of u, all sharing the shape's wf_mesh
+            const Transform &rfo = sh.renderFromObject;
+            const ParamSet &ps = sh.params;
+            float width = ps.GetOneFloat("width", 1.f);
+            float width0 = ps.GetOneFloat("width0", width), width1 = ps.GetOneFloat("width1", width);
+            int degree = ps.GetOneInt("degree", 3);
+            if (degree != 2 && degree != 3) Die(sh.loc, "Invalid degree " + std::to_string(degree) + ": only degree 2 and 3 curves are supported.");
+            std::string basis = ps.GetOneString("basis", "bezier");
+            if (basis != "bezier" && basis != "bspline") Die(sh.loc, "Invalid basis \"" + basis + "\": only \"bezier\" and \"bspline\" are supported.");
+            std::vector<V3> cp = ps.GetTuple3Array("P", "point3");
+            int nSegments;
+            if (basis == "bezier") {
+                if ((((int)cp.size() - 1 - degree) % degree) != 0 || (int)cp.size() < degree + 1)
+                    Die(sh.loc, "Invalid number of control points " + std::to_string(cp.size()) + " for the degree " + std::to_string(degree) + " Bezier basis.");
+                nSegments = ((int)cp.size() - 1) / degree;
+            } else {
+                if ((int)cp.size() < degree + 1) Die(sh.loc, "Invalid number of control points " + std::to_string(cp.size()) + " for the degree " + std::to_string(degree) + " b-spline basis.");
+                nSegments = (int)cp.size() - degree;
+            }
+            std::string curveType = ps.GetOneString("type", "flat");
+            int type = curveType == "flat" ? 0 : curveType == "cylinder" ? 1 : curveType == "ribbon" ? 2 : -1;
+            if (type < 0) { fprintf(stderr, "Error: %s: Unknown curve type \"%s\".  Using \"cylinder\".\n", sh.loc.c_str(), curveType.c_str()); type = 1; }
+            std::vector<V3> nrm = ps.GetTuple3Array("N", "normal");
+            if (!nrm.empty()) {
+                if (type != 2) { fprintf(stderr, "Warning: Curve normals are only used with \"ribbon\" type curves.\n"); nrm.clear(); }
+                else if ((int)nrm.size() != nSegments + 1) Die(sh.loc, "Invalid number of normals " + std::to_string(nrm.size()) + ": must provide " + std::to_string(nSegments + 1) + " normals for ribbon curves with " + std::to_string(nSegments) + " segments.");
+            } else if (type == 2) Die(sh.loc, "Must provide normals \"N\" at curve endpoints with ribbon curves.");
+            const int sd = ps.GetOneInt("splitdepth", 3);
+            for (int j = 0; j < 3; ++j)
+                if (rfo.m.m[3][j] != 0 || rfo.m.m[3][3] != 1) Die(sh.loc, "curve: only affine transformations are supported");
+            wf_mesh mesh{};
+            mesh.first_tri = -1;  // set to the first curve segment's primitive id once the triangle count is known
+            mesh.ntris = 0;
+            mesh.first_vertex = (int)T->P.size() / 3;
+            mesh.nverts = 0;
+            mesh.flags = 0;
+            if (sh.reverseOrientation ^ rfo.SwapsHandedness()) mesh.flags |= WF_MESH_FLIP_NORMAL;
+            if (sh.reverseOrientation) mesh.flags |= WF_MESH_REVERSE_ORIENTATION;
+            const int meshId = (int)T->meshes.size();
+            auto lerp3 = [](float t, V3 a, V3 b) { return (1 - t) * a + t * b; };
+            int cpOffset = 0;
+            for (int seg = 0; seg < nSegments; ++seg) {
+                V3 b[4];
+                const V3 *c = &cp[cpOffset];
+                if (basis == "bezier") {
+                    if (degree == 2) { b[0] = c[0]; b[1] = lerp3(2.f / 3.f, c[0], c[1]); b[2] = lerp3(1.f / 3.f, c[1], c[2]); b[3] = c[2]; }   // ElevateQuadraticBezierToCubic
+                    else for (int i = 0; i < 4; ++i) b[i] = c[i];
+                    cpOffset += degree;
+                } else {
+                    if (degree == 2) {
+                        // QuadraticBSplineToBezier, then elevated (util/splines.h:76-91)
+                        V3 q0 = lerp3(0.5f, c[0], c[1]), q1 = c[1], q2 = lerp3(0.5f, c[1], c[2]);
+                        b[0] = q0; b[1] = lerp3(2.f / 3.f, q0, q1); b[2] = lerp3(1.f / 3.f, q1, q2); b[3] = q2;
+                    } else {
+                        // CubicBSplineToBezier (util/splines.h:93-110)
+                        V3 p122 = lerp3(2.f / 3.f, c[0], c[1]), p223 = lerp3(1.f / 3.f, c[1], c[2]), p233 = lerp3(2.f / 3.f, c[1], c[2]), p334 = lerp3(1.f / 3.f, c[2], c[3]);
+                        b[0] = lerp3(0.5f, p122, p223); b[1] = p223; b[2] = p233; b[3] = lerp3(0.5f, p233, p334);
+                    }
+                    ++cpOffset;
+                }
+                const float w0 = Lerp(float(seg) / float(nSegments), width0, width1), w1 = Lerp(float(seg + 1) / float(nSegments), width0, width1);
+                PendingSphere proto{};
+                proto.s.type = WF_QUADRIC_CURVE;
+                proto.s.mesh = meshId;
+                proto.s.radius = w0;
+                proto.s.theta_z_min = w1;
+                proto.s.inner_radius = (float)type;
+                for (int i = 0; i < 4; ++i) { proto.s.ext[3 * i] = b[i].x; proto.s.ext[3 * i + 1] = b[i].y; proto.s.ext[3 * i + 2] = b[i].z; }
+                if (!nrm.empty()) {
+                    // CurveCommon ctor: normalised end normals, the angle between them and 1 / sin of it
+                    V3 n0 = Normalize(nrm[seg]), n1 = Normalize(nrm[seg + 1]);
+                    auto safeASin = [](float x) { return std::asin(x < -1 ? -1.f : (x > 1 ? 1.f : x)); };
+                    float normalAngle = Dot(n0, n1) < 0 ? Pi - 2 * safeASin(Length(n0 + n1) / 2) : 2 * safeASin(Length(n1 - n0) / 2);
+                    proto.s.theta_z_max = normalAngle;
+                    proto.s.phi_max = 1 / std::sin(normalAngle);
+                    proto.s.ext[12] = n0.x; proto.s.ext[13] = n0.y; proto.s.ext[14] = n0.z;
+                    proto.s.ext[15] = n1.x; proto.s.ext[16] = n1.y; proto.s.ext[17] = n1.z;
+                }
+                proto.s.render_from_object = rfo.abi();
+                const int nSplit = 1 << sd;
+                for (int i = 0; i < nSplit; ++i) {
+                    PendingSphere p = proto;
+                    const float uMin = i / (float)nSplit, uMax = (i + 1) / (float)nSplit;
+                    p.s.z_min = uMin; p.s.z_max = uMax;
+                    // Curve::Bounds (shapes.cpp:519-528): the control points of the u-range, expanded by half the larger width, transformed
+                    V3 cs[4];
+                    if (uMin == 0 && uMax == 1) for (int k = 0; k < 4; ++k) cs[k] = b[k];
+                    else CubicBezierControlPoints(b, uMin, uMax, cs);
+                    B3 ob;
+                    ob = Union(Union(Union(Union(ob, cs[0]), cs[1]), cs[2]), cs[3]);
+                    const float e = std::max(Lerp(uMin, w0, w1), Lerp(uMax, w0, w1)) * 0.5f;
+                    ob.pMin = ob.pMin - V3{e, e, e}; ob.pMax = ob.pMax + V3{e, e, e};
+                    for (int cnr = 0; cnr < 8; ++cnr)
+                        p.bounds = Union(p.bounds, rfo.Point(V3{(cnr & 1) ? ob.pMax.x : ob.pMin.x, (cnr & 2) ? ob.pMax.y : ob.pMin.y, (cnr & 4) ? ob.pMax.z : ob.pMin.z}));
+                    prims->emplace_back(-1 - (int)spheres.size(), p.bounds);
+                    spheres.push_back(p);
+                }
+            }
+            if (sh.lightIndex >= 0) Die(sh.loc, "curve: Curve::Sample is not implemented in the reference either: curves cannot be area lights");
+            commitMesh(mesh, meshId, sh, rfo, inDefinition);
             return;
         }
         MeshSource src;
@@ -1924,8 +2043,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         const int nTris = (int)T->triIndices.size() / 3;
         for (size_t i = 0; i < spheres.size(); ++i) {
             wf_mesh &qm = T->meshes[spheres[i].s.mesh];
-            if (spheres[i].s.type != WF_QUADRIC_BILINEAR) qm.first_tri = nTris + (int)i;
-            else if (qm.ntris == 0 && qm.first_tri < 0) qm.first_tri = nTris + (int)i;  // a patch mesh: its first patch
+            if (spheres[i].s.type != WF_QUADRIC_BILINEAR && spheres[i].s.type != WF_QUADRIC_CURVE) qm.first_tri = nTris + (int)i;
+            else if (qm.ntris == 0 && qm.first_tri < 0) qm.first_tri = nTris + (int)i;  // a patch or curve mesh: its first primitive
             T->triMesh.push_back(spheres[i].s.mesh);
             T->quadrics.push_back(spheres[i].s);
         }

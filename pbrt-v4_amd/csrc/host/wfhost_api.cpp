@@ -148,5 +148,18 @@ int wfh_film_to_rgb(wfh_scene *s, const double *film, float *rgb) {
     return 0;
 }
 int wfh_write_image(const char *path, const float *rgb, int w, int h) { return WriteImage(path, rgb, w, h) ? 0 : -1; }
+int wfh_read_image(const char *path, const char *encoding, int32_t *width, int32_t *height, int32_t *n_channels, int32_t *format, float *pixels) {
+    return Guard<int>(-1, [&] {
+        if (!g_init || !path) throw SceneError("wfh_read_image: library not initialised or no path");
+        HostImage img;
+        ReadImage(path, ColorEnc::Parse(encoding ? encoding : "sRGB"), &img);
+        if (width) *width = img.w;
+        if (height) *height = img.h;
+        if (n_channels) *n_channels = img.nc;
+        if (format) *format = img.format;
+        if (pixels) for (size_t i = 0; i < (size_t)img.w * img.h * img.nc; ++i) pixels[i] = img.Get(i);
+        return 0;
+    });
+}
 
 }  // extern "C"

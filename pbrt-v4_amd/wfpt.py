@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
     "wfh_renderer_create", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
-    "wfh_film_to_rgb", "wfh_write_image",
+    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image",
 ]
 
 _hip = None
@@ -85,6 +85,7 @@ def libs():
     _hip.wf_last_error.restype = C.c_char_p
     _hip.wf_stream.restype = C.c_void_p
     _hip.wf_stream.argtypes = [C.c_void_p]
+    _host.wfh_last_error.restype = C.c_char_p
     _host.wfh_scene_load.restype = C.c_void_p
     _host.wfh_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
     _host.wfh_scene_load_string.restype = C.c_void_p
@@ -105,6 +106,7 @@ def libs():
     _host.wfh_stats.argtypes = [C.c_void_p, C.POINTER(RenderStats)]
     _host.wfh_film_to_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _host.wfh_write_image.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    _host.wfh_read_image.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
     for name in ("wf_sync", "wf_film_clear", "wf_ctx_destroy"):
         getattr(_hip, name).argtypes = [C.c_void_p]
     _hip.wf_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -321,6 +323,19 @@ def write_pfm(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     if host.wfh_write_image(os.fsencode(path), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]) != 0:
         raise WfError("could not write %s" % path)
+
+
+def read_image(path, encoding=None):
+    """Image::Read through the host library (.pfm, .png, .exr): (float32 array [h][w][nc], storage format 0 8-bit / 1 half / 2 float)."""
+    host, _ = libs()
+    w, h, nc, fmt = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    enc = None if encoding is None else encoding.encode()
+    if host.wfh_read_image(os.fsencode(path), enc, C.byref(w), C.byref(h), C.byref(nc), C.byref(fmt), None) != 0:
+        raise WfError(host.wfh_last_error().decode())
+    px = np.empty((h.value, w.value, nc.value), np.float32)
+    if host.wfh_read_image(os.fsencode(path), enc, None, None, None, None, px.ctypes.data) != 0:
+        raise WfError(host.wfh_last_error().decode())
+    return px, fmt.value
 
 
 def read_pfm(path):

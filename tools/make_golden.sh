@@ -54,6 +54,10 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight
 # map and emitter image): fixtures from tools/make_png_fixtures.py, decoded in the reference build by oracle/ref_build/shim_png.cpp
 python3 tools/make_png_fixtures.py
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/png_textures_ref.pfm $G/png_textures.pbrt
+# EWA-filtered image maps (anisotropic footprints, the maxanisotropy clamp, float and RGB lookups): hand-written
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_ewa_ref.pfm $G/textures_ewa.pbrt
+# Curve shapes (flat / cylinder / ribbon, Bezier and b-spline of degree 2 and 3, hair strands, curves in object instances): hand-written
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/curves_ref.pfm $G/curves.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
 # the reference's other BVH builder: blobs_small with `splitmethod "hlbvh"` (cpu/aggregates.cpp:389-503, 626-722)
