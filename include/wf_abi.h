@@ -336,7 +336,7 @@ typedef struct wf_instance_def {
     int32_t pad[2];
 } wf_instance_def;
 
-enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1, WF_CAMERA_SPHERICAL = 2 };
+enum wf_camera_type { WF_CAMERA_PERSPECTIVE = 0, WF_CAMERA_ORTHOGRAPHIC = 1, WF_CAMERA_SPHERICAL = 2, WF_CAMERA_REALISTIC = 3 };
 typedef struct wf_camera {
     int32_t type;
     wf_transform cameraFromRaster;      /* cameras.h:ProjectiveCamera */
@@ -348,6 +348,12 @@ typedef struct wf_camera {
     float minDirDifferentialX[3], minDirDifferentialY[3];
     int32_t medium;
     int32_t spherical_mapping;          /* SphericalCamera (cameras.h:370-420): 0 equal-area, 1 equirectangular */
+    /* RealisticCamera (cameras.h:466-580): the lens prescription and the exit-pupil bounds computed at load, in table_data */
+    int32_t n_lens_elements, lens_offset;        /* n x {curvatureRadius, thickness, eta, apertureRadius} (metres), front element first */
+    int32_t n_exit_pupil_bounds, exit_pupil_offset; /* n x {pMin.x, pMin.y, pMax.x, pMax.y} by distance from the film centre */
+    float physical_extent[4];                    /* film rectangle pMin.xy, pMax.xy (metres) */
+    float film_diagonal;                         /* Film::Diagonal() (metres) */
+    int32_t aperture_image;                      /* index into tex_images (one channel, level 0) or -1: circular stop */
 } wf_camera;
 
 enum wf_filter_type { WF_FILTER_BOX = 0, WF_FILTER_GAUSSIAN = 1, WF_FILTER_MITCHELL = 2,

@@ -3,6 +3,8 @@
 #pragma once
 
 #include "wf_scene.h"
+#include "wf_bxdf.h"
+#include "wf_shapes.h"
 
 namespace wf {
 
@@ -511,13 +513,152 @@ WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy)
     *dpdy = sppScale * XfVector(C.renderFromCamera.m, invVec(py - pDownZ));
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RealisticCamera (cameras.h:466-580, cameras.cpp:695-951): rays traced from the film through the lens prescription
+struct LensElement { float curvatureRadius, thickness, eta, apertureRadius; };
+WF_HD LensElement LoadLensElement(const float *table, const wf_camera &C, int i) {
+    const float *e = table + C.lens_offset + 4 * i;
+    return LensElement{e[0], e[1], e[2], e[3]};
+}
+// RealisticCamera::IntersectSphericalElement (cameras.h:538-560)
+WF_HD bool IntersectSphericalElement(float radius, float zCenter, V3 ro, V3 rd, float *t, N3 *n) {
+    V3 o = ro - V3{0, 0, zCenter};
+    float A = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+    float B = 2 * (rd.x * o.x + rd.y * o.y + rd.z * o.z);
+    float C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    float t0, t1;
+    if (!QuadraticF(A, B, C, &t0, &t1)) return false;
+    bool useCloserT = (rd.z > 0) ^ (radius < 0);
+    *t = useCloserT ? fmin(t0, t1) : fmax(t0, t1);
+    if (*t < 0) return false;
+    V3 nv = o + *t * rd;
+    *n = FaceForward(Normalize(toN(nv)), -rd);
+    return true;
+}
+// RealisticCamera::TraceLensesFromFilm (cameras.cpp:749-813); returns the weight (0 = blocked)
+WF_HD float TraceLensesFromFilm(const SceneView &sv, const wf_camera &C, V3 co, V3 cd, V3 *oOut, V3 *dOut) {
+    const float *table = sv.tableData;
+    float elementZ = 0, weight = 1;
+    V3 ro{co.x, co.y, -co.z}, rd{cd.x, cd.y, -cd.z};
+    for (int i = C.n_lens_elements - 1; i >= 0; --i) {
+        const LensElement element = LoadLensElement(table, C, i);
+        elementZ -= element.thickness;
+        float t;
+        N3 n{0, 0, 0};
+        bool isStop = (element.curvatureRadius == 0);
+        if (isStop) {
+            t = (elementZ - ro.z) / rd.z;
+            if (t < 0) return 0;
+        } else {
+            float radius = element.curvatureRadius;
+            float zCenter = elementZ + element.curvatureRadius;
+            if (!IntersectSphericalElement(radius, zCenter, ro, rd, &t, &n)) return 0;
+        }
+        V3 pHit = ro + rd * t;
+        if (isStop && C.aperture_image >= 0) {
+            V2 uv{(pHit.x / element.apertureRadius + 1) / 2, (pHit.y / element.apertureRadius + 1) / 2};
+            weight = ImageBilerpChannel(table, sv.texImages[C.aperture_image], 0, uv, 0);   // WrapMode::Black
+            if (weight == 0) return 0;
+        } else {
+            if (Sqr(pHit.x) + Sqr(pHit.y) > Sqr(element.apertureRadius)) return 0;
+        }
+        ro = pHit;
+        if (!isStop) {
+            V3 w;
+            float eta_i = element.eta;
+            float eta_t = 1;
+            if (i > 0) { float e = table[C.lens_offset + 4 * (i - 1) + 2]; if (e != 0) eta_t = e; }
+            if (!Refract(Normalize(-rd), n, eta_t / eta_i, nullptr, &w)) return 0;
+            rd = w;
+        }
+    }
+    if (oOut) { *oOut = V3{ro.x, ro.y, -ro.z}; *dOut = V3{rd.x, rd.y, -rd.z}; }
+    return weight;
+}
+// RealisticCamera::TraceLensesFromScene (cameras.cpp:959-1007), used at load to focus the lens
+WF_HD float TraceLensesFromScene(const SceneView &sv, const wf_camera &C, V3 co, V3 cd, V3 *oOut, V3 *dOut) {
+    const float *table = sv.tableData;
+    float front = 0;
+    for (int i = 0; i < C.n_lens_elements; ++i) front += table[C.lens_offset + 4 * i + 1];
+    float elementZ = -front;
+    // LensFromCamera = Scale(1, 1, -1) applied to the ray: Transform::operator()(Ray) moves the origin along d by its rounding error bound
+    V3 ro, rd;
+    {
+        const float m[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, -1, 0}, {0, 0, 0, 1}};
+        XfRayOffset(m, co, cd, &ro, &rd);
+    }
+    for (int i = 0; i < C.n_lens_elements; ++i) {
+        const LensElement element = LoadLensElement(table, C, i);
+        float t;
+        N3 n{0, 0, 0};
+        bool isStop = (element.curvatureRadius == 0);
+        if (isStop) {
+            t = (elementZ - ro.z) / rd.z;
+            if (t < 0) return 0;
+        } else {
+            float radius = element.curvatureRadius;
+            float zCenter = elementZ + element.curvatureRadius;
+            if (!IntersectSphericalElement(radius, zCenter, ro, rd, &t, &n)) return 0;
+        }
+        V3 pHit = ro + rd * t;
+        float r2 = pHit.x * pHit.x + pHit.y * pHit.y;
+        if (r2 > element.apertureRadius * element.apertureRadius) return 0;
+        ro = pHit;
+        if (!isStop) {
+            V3 wt;
+            float eta_i = 1;
+            if (i > 0) { float e = table[C.lens_offset + 4 * (i - 1) + 2]; if (e != 0) eta_i = e; }
+            float eta_t = (element.eta != 0) ? element.eta : 1;
+            if (!Refract(Normalize(-rd), n, eta_t / eta_i, nullptr, &wt)) return 0;
+            rd = wt;
+        }
+        elementZ += element.thickness;
+    }
+    if (oOut) { *oOut = V3{ro.x, ro.y, -ro.z}; *dOut = V3{rd.x, rd.y, -rd.z}; }
+    return 1;
+}
 // ---------------------------------------------------------------------------------------------
 // GetCameraSample (samplers.h:796-814) + Perspective/OrthographicCamera::GenerateRay
 // (cameras.cpp:404-428, 283-307) + the identity "movingFromCamera" the wavefront loop applies
 // (wavefront/camera.cpp:64, integrator.cpp:364-368)
-struct CameraRayR { V3 o, d; float time; bool valid; };
-WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSample, V2 pLens) {
+struct CameraRayR { V3 o, d; float time; bool valid; float weight = 1; };
+// applyMoving: the identity "movingFromCamera" transform of the wavefront loop (it still walks the origin off its rounding-error
+// bound); Camera::GenerateRay itself, as FindMinimumDifferentials calls it at load, does not have it
+WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSample, V2 pLens, bool applyMoving = true) {
     const wf_camera &C = sv.camera;
+    if (C.type == WF_CAMERA_REALISTIC) {
+        // RealisticCamera::GenerateRay + SampleExitPupil (cameras.cpp:897-951)
+        V2 s{pFilm.x / sv.film.full_res[0], pFilm.y / sv.film.full_res[1]};
+        V2 pFilm2{(1 - s.x) * C.physical_extent[0] + s.x * C.physical_extent[2], (1 - s.y) * C.physical_extent[1] + s.y * C.physical_extent[3]};
+        V3 pF{-pFilm2.x, pFilm2.y, 0};
+        const float lensRearZ = sv.tableData[C.lens_offset + 4 * (C.n_lens_elements - 1) + 1];
+        float rFilm = sqrt(Sqr(pF.x) + Sqr(pF.y));
+        int rIndex = (int)(rFilm / (C.film_diagonal / 2) * C.n_exit_pupil_bounds);
+        rIndex = rIndex < C.n_exit_pupil_bounds - 1 ? rIndex : C.n_exit_pupil_bounds - 1;
+        const float *pb = sv.tableData + C.exit_pupil_offset + 4 * rIndex;
+        CameraRayR none{V3{0, 0, 0}, V3{0, 0, 0}, 0, false, 0};
+        if (pb[0] >= pb[2] || pb[1] >= pb[3]) return none;   // Bounds2::IsDegenerate
+        V2 pLensS{(1 - pLens.x) * pb[0] + pLens.x * pb[2], (1 - pLens.y) * pb[1] + pLens.y * pb[3]};
+        float pdf = 1 / ((pb[2] - pb[0]) * (pb[3] - pb[1]));
+        float sinTheta = (rFilm != 0) ? pF.y / rFilm : 0;
+        float cosTheta = (rFilm != 0) ? pF.x / rFilm : 1;
+        V3 pPupil{cosTheta * pLensS.x - sinTheta * pLensS.y, sinTheta * pLensS.x + cosTheta * pLensS.y, lensRearZ};
+        V3 fd = pPupil - pF;
+        V3 o, d;
+        float weight = TraceLensesFromFilm(sv, C, pF, fd, &o, &d);
+        if (weight == 0) return none;
+        float time = Lerp(timeSample, C.shutterOpen, C.shutterClose);
+        XfRay(C.renderFromCamera.m, &o, &d);
+        d = Normalize(d);
+        float cosT = Normalize(fd).z;
+        weight *= Sqr(Sqr(cosT)) / (pdf * Sqr(lensRearZ));
+        if (applyMoving) {
+            const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+            XfRay(I, &o, &d);
+        }
+        return {o, d, time, true, weight};
+    }
     if (C.type == WF_CAMERA_SPHERICAL) {
         // SphericalCamera::GenerateRay, cameras.cpp:610-630
         V2 uv{pFilm.x / sv.film.full_res[0], pFilm.y / sv.film.full_res[1]};

@@ -228,7 +228,8 @@ WF_HD int KValidPixels(const SceneView &sv, const WorkState &ws, int y0) {
     return rows * xResolution;
 }
 // camera rays of the pass: nSamples sample slots x the in-bounds pixels
-WF_HD int KCameraRayCount(const SceneView &sv, const WorkState &ws, int y0, int nSamples) { return KValidPixels(sv, ws, y0) * nSamples; }
+// (a realistic camera appends its rays one by one: 0 to start with)
+WF_HD int KCameraRayCount(const SceneView &sv, const WorkState &ws, int y0, int nSamples) { return sv.camera.type == WF_CAMERA_REALISTIC ? 0 : KValidPixels(sv, ws, y0) * nSamples; }
 
 // ---------------------------------------------------------------------------------------------
 // K2: GenerateCameraRays, wavefront/camera.cpp:35-79
@@ -291,15 +292,16 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
         // RayQueue::PushCameraRay, workitems.h:346-361.  Both projective cameras always produce a ray and
         // the in-bounds pixels of a band are exactly p < rows*width, so the queue slot is analytic (pixel
         // order within each sample slot, no atomic); KCameraRayCount sets the queue size.
+        // A realistic camera's rays can be blocked by the lens system: its rays are appended (the counter starts the pass at 0).
         const RayQueueV &q = ws.rq[0];
-        int index = slot * KValidPixels(sv, ws, y0) + p;
+        int index = sv.camera.type == WF_CAMERA_REALISTIC ? QueueAlloc(&ws.counters[(CNT_RAY0) * CNT_STRIDE]) : slot * KValidPixels(sv, ws, y0) + p;
         q.o[index] = F4{cr.o.x, cr.o.y, cr.o.z, cr.time};
         q.d[index] = F4{cr.d.x, cr.d.y, cr.d.z, 1.f};
         q.beta[index] = F4{1, 1, 1, 1};
         q.r_u[index] = F4{1, 1, 1, 1};
         q.r_l[index] = F4{1, 1, 1, 1};
         q.meta[index] = I4{pixelIndex, 0, 0, sv.camera.medium};
-        ws.cameraRayWeight[pixelIndex] = F4{1, 1, 1, 1};
+        ws.cameraRayWeight[pixelIndex] = F4{cr.weight, cr.weight, cr.weight, cr.weight};
     } else ws.cameraRayWeight[pixelIndex] = F4{0, 0, 0, 0};
 }
 

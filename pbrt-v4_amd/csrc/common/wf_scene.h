@@ -341,8 +341,9 @@ WF_HD RGB3 MIPBilerpRGB(const float *table, const wf_tex_image &im, int level, V
     return RGB3{v, v, v};
 }
 WF_HD float MIPBilerpFloat(const float *table, const wf_tex_image &im, int level, V2 st) {
-    if (im.n_channels == 1) return ImageBilerpChannel(table, im, level, st, 0);
-    if (im.n_channels == 4) return ImageBilerpChannel(table, im, level, st, 3);  // R G B A: the alpha channel
+    // one inlined lookup serves Y (channel 0) and R G B A (the alpha channel, 3): this function is instantiated three times in the
+    // out-of-line filter the traversal kernels' alpha test calls, and that callee's size and registers are paid at every call
+    if (im.n_channels != 3) return ImageBilerpChannel(table, im, level, st, im.n_channels == 4 ? 3 : 0);
     float sum = 0;
     for (int c = 0; c < 3; ++c) sum += ImageBilerpChannel(table, im, level, st, c);
     return sum / 3;
@@ -426,11 +427,22 @@ WF_HD RGB3 MIPFilterEWA(const float *table, const wf_tex_image &im, V2 st, V2 ds
     float t = lod - ilod;
     return RGB3{Lerp(t, a.r, b.r), FLOAT ? 0.f : Lerp(t, a.g, b.g), FLOAT ? 0.f : Lerp(t, a.b, b.b)};
 }
+// EWA lookups out of line on their own: the point / bilinear / trilinear functions below are called from the traversal kernels' alpha
+// test, and a callee's register use is paid at every call (callee-saved registers) whether the branch is taken or not
+WF_NI void MIPFilterEWARGBP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy, float *r, float *g, float *b) {
+    const wf_tex_image im = *imp;
+    RGB3 o = MIPFilterEWA<false>(table, im, V2{s_, t_}, V2{dsdx, dtdx}, V2{dsdy, dtdy});
+    *r = o.r; *g = o.g; *b = o.b;
+}
+WF_NI float MIPFilterEWAFloatP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy) {
+    const wf_tex_image im = *imp;
+    return MIPFilterEWA<true>(table, im, V2{s_, t_}, V2{dsdx, dtdx}, V2{dsdy, dtdy}).r;
+}
 WF_NI void MIPFilterRGBP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy, float *r, float *g, float *b) {
+    if (imp->filter == WF_MIP_EWA) { MIPFilterEWARGBP(table, imp, s_, t_, dsdx, dtdx, dsdy, dtdy, r, g, b); return; }
     const wf_tex_image im = *imp;
     const V2 st{s_, t_};
     RGB3 o = [&]() -> RGB3 {
-    if (im.filter == WF_MIP_EWA) return MIPFilterEWA<false>(table, im, st, V2{dsdx, dtdx}, V2{dsdy, dtdy});
     float level;
     int iLevel;
     if (!MIPLevel(im, dsdx, dtdx, dsdy, dtdy, &level, &iLevel)) return MIPTexelRGB(table, im, im.n_levels - 1, 0, 0);
@@ -453,7 +465,6 @@ WF_HD RGB3 MIPFilterRGB(const SceneView &sv, int image, V2 st, float dsdx, float
 WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy) {
     const wf_tex_image im = *imp;
     const V2 st{s_, t_};
-    if (im.filter == WF_MIP_EWA) return MIPFilterEWA<true>(table, im, st, V2{dsdx, dtdx}, V2{dsdy, dtdy}).r;
     float level;
     int iLevel;
     if (!MIPLevel(im, dsdx, dtdx, dsdy, dtdy, &level, &iLevel)) return ImageTexel(table, im, im.n_levels - 1, 0, 0, 0);
@@ -464,16 +475,22 @@ WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s
     if (im.filter == WF_MIP_BILINEAR || iLevel == 0) return MIPBilerpFloat(table, im, iLevel, st);
     return Lerp(level - iLevel, MIPBilerpFloat(table, im, iLevel, st), MIPBilerpFloat(table, im, iLevel + 1, st));
 }
+// EWA = false: the traversal kernels' inline alpha test (GEN = 1), which is only chosen for scenes whose alpha maps are not EWA-
+// filtered — a kernel's register allocation is the maximum over everything it can call, and the EWA loop must stay out of that
+template <bool EWA = true>
 WF_HD float MIPFilterFloat(const SceneView &sv, int image, V2 st, float dsdx, float dtdx, float dsdy, float dtdy) {
+    if constexpr (EWA)
+        if (sv.texImages[image].filter == WF_MIP_EWA) return MIPFilterEWAFloatP(sv.tableData, sv.texImages + image, st.x, st.y, dsdx, dtdx, dsdy, dtdy);
     return MIPFilterFloatP(sv.tableData, sv.texImages + image, st.x, st.y, dsdx, dtdx, dsdy, dtdy);
 }
 // FloatImageTexture::Evaluate (textures.h:579-591), SpectrumImageTexture::Evaluate (textures.cpp:300-328)
+template <bool EWA = true>
 WF_HD float EvalFloatImageTexture(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
     TexCoord2 tcd = TexMap2D(sv, t, c);
     float dsdx = tcd.dsdx, dsdy = tcd.dsdy, dtdx = tcd.dtdx, dtdy = tcd.dtdy;
     V2 st = tcd.st;
     st.y = 1 - st.y;
-    float v = t.f0 * MIPFilterFloat(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
+    float v = t.f0 * MIPFilterFloat<EWA>(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
     return t.f1 != 0 ? fmax(0.f, 1 - v) : v;
 }
 WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &c) {
@@ -608,9 +625,10 @@ WF_HD bool InsidePolkaDot(const SceneView &sv, const wf_texture &t, const TexCtx
 #endif
 // the three texture types a production scene's parameters usually are: what the material kernels and the traversal kernels' alpha test
 // evaluate inline
+template <bool EWA = true>
 WF_HD float EvalFloatTextureSimple(const SceneView &sv, const wf_texture &t, const TexCtx &tc) {
     if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
-    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture(sv, t, tc);
+    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture<EWA>(sv, t, tc);
     // FloatBilerpTexture::Evaluate, textures.h:314-318
     TexCoord2 c = TexMap2D(sv, t, tc);
     const float v00 = t.f0, v01 = t.f1, v10 = t.map[10], v11 = t.map[11];

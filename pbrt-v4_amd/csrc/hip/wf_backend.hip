@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(BLOCK) k_sample_tops(const SceneView sv, WorkS
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < 5 * ws.pixelsPerPass; i += gridDim.x * BLOCK) KSampleTops(sv, ws, i, y0, dim0);
 }
 __global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleBase, int sampleStep, int nSamples) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, nSamples);
+    if (sv.camera.type != WF_CAMERA_REALISTIC && blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, nSamples);
     const bool useTops = ws.sampleTops != nullptr;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
         KGenerateCameraRay(sv, ws, i, y0, sampleBase, sampleStep, nSamples, useTops);
@@ -280,7 +280,7 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
     TexCtx tc;
     tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
     tc.p = b0 * LoadP(sv, v[0]) + b1 * LoadP(sv, v[1]) + b2 * LoadP(sv, v[2]);
-    float a = EvalFloatTextureSimple(sv, sv.textures[mesh.alpha_tex], tc);
+    float a = EvalFloatTextureSimple<false>(sv, sv.textures[mesh.alpha_tex], tc);   // no EWA-filtered alpha maps under genMode 1
     if (!(a < 1)) return true;
     float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(V3{ox, oy, oz}, V3{dx, dy, dz}));
     return !(u > a);
@@ -1201,7 +1201,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             for (int i = 0; i < d->n_meshes && ctx->genMode < 2; ++i)
                 if (d->meshes[i].alpha_tex >= 0) {
                     const int tt = d->textures[d->meshes[i].alpha_tex].type;
-                    ctx->genMode = std::max(ctx->genMode, (tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) ? 1 : 2);
+                    const bool ewa = tt == WF_TEX_FLOAT_IMAGE && d->tex_images[d->textures[d->meshes[i].alpha_tex].i0].filter == WF_MIP_EWA;
+                    ctx->genMode = std::max(ctx->genMode, ((tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) && !ewa) ? 1 : 2);
                 }
             if (getenv("WF_GEN_MODE")) ctx->genMode = std::max(ctx->genMode, atoi(getenv("WF_GEN_MODE")));  // timing experiments: force the general variant
         }
@@ -1403,6 +1404,8 @@ int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
     if (int e = checkReady(ctx)) return e;
     ctx->passY0 = y0;
     if (ctx->ws.sampleTops) LAUNCH("Sampler index prefixes", k_sample_tops, gridFor(5 * ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, y0, 0);
+    if (ctx->svHost.camera.type == WF_CAMERA_REALISTIC)  // rays blocked by the lenses leave no queue entry: the kernel appends
+        LAUNCH("Reset ray queue", k_reset, 1, ctx->ws, 1u << CNT_RAY0, -1, 0);
     LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index, ctx->passStep, ctx->passSamples);
     LAUNCH("Update camera ray stats", k_reset, 1, ctx->ws, 0u, 0, CNT_RAY0);
     return 0;

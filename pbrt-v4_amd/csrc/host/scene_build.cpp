@@ -20,6 +20,8 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
+#include <atomic>
 
 namespace wf {
 
@@ -1377,6 +1379,243 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
     else { sMinX = -1.f; sMaxX = 1.f; sMinY = -1.f / frame; sMaxY = 1.f / frame; }
     std::vector<float> sw = ps.GetFloatArray("screenwindow");
     if (sw.size() == 4) { sMinX = sw[0]; sMaxX = sw[1]; sMinY = sw[2]; sMaxY = sw[3]; }
+    if (scene.camera.name == "realistic") {
+        // RealisticCamera::Create + ctor (cameras.cpp:1294-1446, 695-747): the lens prescription, the film's physical extent, the lens
+        // moved to focus (thick-lens approximation from two traced rays), 64 exit-pupil bounds from 2^20 traced rays each
+        C.type = WF_CAMERA_REALISTIC;
+        std::string lensFile = ps.GetOneString("lensfile", "");
+        float apertureDiameter = ps.GetOneFloat("aperturediameter", 1.0f);
+        const float focusDistance = ps.GetOneFloat("focusdistance", 10.0f);
+        if (lensFile.empty()) Die(scene.camera.loc, "No lens description file supplied!");
+        if (lensFile[0] != '/') lensFile = scene.baseDir + "/" + lensFile;
+        std::vector<float> lensParameters;
+        {
+            // ReadFloatFile (util/file.cpp:224-290): numbers separated by anything, '#' comments to the end of the line
+            std::ifstream f(lensFile);
+            if (!f) Die(scene.camera.loc, "Error reading lens specification file \"" + lensFile + "\".");
+            std::string line;
+            while (std::getline(f, line)) {
+                size_t h = line.find('#');
+                if (h != std::string::npos) line.resize(h);
+                const char *c = line.c_str();
+                while (*c) {
+                    if (isdigit((unsigned char)*c) || *c == '.' || *c == '-' || *c == '+') {
+                        char *end = nullptr;
+                        lensParameters.push_back(strtof(c, &end));
+                        if (end == c) Die(scene.camera.loc, lensFile + ": unable to parse float value");
+                        c = end;
+                    } else ++c;
+                }
+            }
+        }
+        if (lensParameters.empty()) Die(scene.camera.loc, "Error reading lens specification file \"" + lensFile + "\".");
+        if (lensParameters.size() % 4 != 0) Die(scene.camera.loc, lensFile + ": excess values in lens specification file; must be multiple-of-four values, read " + std::to_string(lensParameters.size()) + ".");
+        const std::string apertureName = ps.GetOneString("aperture", "");
+        C.aperture_image = -1;
+        if (!apertureName.empty()) {
+            const int builtinRes = 256;
+            int aw = builtinRes, ah = builtinRes;
+            std::vector<float> img((size_t)aw * ah, 0.f);
+            auto rasterize = [&](const std::vector<V2> &vert) {
+                for (int y = 0; y < ah; ++y)
+                    for (int x = 0; x < aw; ++x) {
+                        V2 pt{-1 + 2 * (x + 0.5f) / aw, -1 + 2 * (y + 0.5f) / ah};
+                        int windingNumber = 0;
+                        for (size_t i = 0; i < vert.size(); ++i) {
+                            size_t i1 = (i + 1) % vert.size();
+                            float e = (pt.x - vert[i].x) * (vert[i1].y - vert[i].y) - (pt.y - vert[i].y) * (vert[i1].x - vert[i].x);
+                            if (vert[i].y <= pt.y) { if (vert[i1].y > pt.y && e > 0) ++windingNumber; }
+                            else if (vert[i1].y <= pt.y && e < 0) --windingNumber;
+                        }
+                        img[(size_t)y * aw + x] = windingNumber == 0 ? 0.f : 1.f;
+                    }
+            };
+            if (apertureName == "gaussian") {
+                for (int y = 0; y < ah; ++y)
+                    for (int x = 0; x < aw; ++x) {
+                        V2 uv{-1 + 2 * (x + 0.5f) / aw, -1 + 2 * (y + 0.5f) / ah};
+                        float r2 = Sqr(uv.x) + Sqr(uv.y), sigma2 = 1;
+                        img[(size_t)y * aw + x] = std::max(0.f, std::exp(-r2 / sigma2) - std::exp(-1 / sigma2));
+                    }
+            } else if (apertureName == "square") {
+                for (int y = (int)(.25 * builtinRes); y < (int)(.75 * builtinRes); ++y)
+                    for (int x = (int)(.25 * builtinRes); x < (int)(.75 * builtinRes); ++x) img[(size_t)y * aw + x] = 4.f;
+            } else if (apertureName == "pentagon") {
+                float c1 = (std::sqrt(5.f) - 1) / 4, c2 = (std::sqrt(5.f) + 1) / 4;
+                float s1 = std::sqrt(10.f + 2.f * std::sqrt(5.f)) / 4, s2 = std::sqrt(10.f - 2.f * std::sqrt(5.f)) / 4;
+                std::vector<V2> vert = {V2{0, 1}, V2{s1, c1}, V2{s2, -c2}, V2{-s2, -c2}, V2{-s1, c1}};
+                for (V2 &v : vert) { v.x *= .8f; v.y *= .8f; }
+                rasterize(vert);
+            } else if (apertureName == "star") {
+                std::vector<V2> vert(10);
+                for (int i = 0; i < 10; ++i) {
+                    float r = (i & 1) ? 1.f : (std::cos(Radians(72.f)) / std::cos(Radians(36.f)));
+                    vert[i] = V2{r * std::cos(Pi * i / 5.f), r * std::sin(Pi * i / 5.f)};
+                }
+                std::reverse(vert.begin(), vert.end());
+                rasterize(vert);
+            } else {
+                std::string fn = apertureName[0] == '/' ? apertureName : scene.baseDir + "/" + apertureName;
+                HostImage hi;
+                try { ReadImage(fn, ColorEnc(), &hi); } catch (const SceneError &e) { Die(scene.camera.loc, std::string(e.what()).substr(7)); }
+                if (hi.nc == 2) Die(scene.camera.loc, fn + ": didn't find R, G, B channels to average for aperture image.");
+                aw = hi.w; ah = hi.h;
+                img.resize((size_t)aw * ah);
+                for (size_t i = 0; i < img.size(); ++i) {
+                    if (hi.nc == 1) img[i] = hi.Get(i);
+                    else img[i] = (hi.Get(i * hi.nc) + hi.Get(i * hi.nc + 1) + hi.Get(i * hi.nc + 2)) / 3;   // ImageChannelValues::Average
+                }
+            }
+            // FlipY, then normalised so that the brightness matches a circular aperture (cameras.cpp:1419-1435)
+            for (int y = 0; y < ah / 2; ++y)
+                for (int x = 0; x < aw; ++x) std::swap(img[(size_t)y * aw + x], img[(size_t)(ah - 1 - y) * aw + x]);
+            float sum = 0;
+            for (int y = 0; y < ah; ++y) for (int x = 0; x < aw; ++x) sum += img[(size_t)y * aw + x];
+            float avg = sum / (aw * ah);
+            float scale = (Pi / 4) / avg;
+            for (float &v : img) v = v * scale;
+            wf_tex_image im{};
+            im.res[0] = aw; im.res[1] = ah; im.n_levels = 1; im.n_channels = 1; im.wrap = WF_WRAP_BLACK; im.filter = WF_MIP_BILINEAR;
+            im.level_offset[0] = (int)T->tableData.size();
+            T->tableData.insert(T->tableData.end(), img.begin(), img.end());
+            C.aperture_image = (int)T->texImages.size();
+            T->texImages.push_back(im);
+        }
+        // film extent
+        const float diagonal = scene.film.params.GetOneFloat("diagonal", 35.f) * .001f;
+        C.film_diagonal = diagonal;
+        {
+            float aspect = (float)F.full_res[1] / (float)F.full_res[0];
+            float x = std::sqrt(Sqr(diagonal) / (1 + Sqr(aspect)));
+            float y = aspect * x;
+            C.physical_extent[0] = -x / 2; C.physical_extent[1] = -y / 2; C.physical_extent[2] = x / 2; C.physical_extent[3] = y / 2;
+        }
+        // element interfaces
+        const int nEl = (int)lensParameters.size() / 4;
+        C.n_lens_elements = nEl;
+        C.lens_offset = (int)T->tableData.size();
+        for (int i = 0; i < nEl; ++i) {
+            float curvatureRadius = lensParameters[4 * i] / 1000, thickness = lensParameters[4 * i + 1] / 1000;
+            float eta = lensParameters[4 * i + 2], apDiameter = lensParameters[4 * i + 3] / 1000;
+            if (curvatureRadius == 0) {
+                apertureDiameter /= 1000;
+                if (apertureDiameter > apDiameter) fprintf(stderr, "Warning: Aperture diameter %f is greater than maximum possible %f. Clamping it.\n", apertureDiameter, apDiameter);
+                else apDiameter = apertureDiameter;
+            }
+            T->tableData.push_back(curvatureRadius); T->tableData.push_back(thickness); T->tableData.push_back(eta); T->tableData.push_back(apDiameter / 2);
+        }
+        C.n_exit_pupil_bounds = 0;
+        C.exit_pupil_offset = 0;
+        SceneView tmp{};
+        auto view = [&]() -> const SceneView & { tmp.camera = C; tmp.film = F; tmp.tableData = T->tableData.data(); tmp.texImages = T->texImages.data(); return tmp; };
+        auto thicknessAt = [&](int i) -> float & { return T->tableData[C.lens_offset + 4 * i + 1]; };
+        // FocusThickLens / ComputeThickLensApproximation / ComputeCardinalPoints (cameras.cpp:815-859)
+        {
+            float pz[2], fz[2];
+            float x = .001f * diagonal;
+            float frontZ = 0;
+            for (int i = 0; i < nEl; ++i) frontZ += thicknessAt(i);
+            const float rearZ = thicknessAt(nEl - 1);
+            auto cardinal = [](V3 inO, V3 outO, V3 outD, float *pzv, float *fzv) {
+                float tf = -outO.x / outD.x;
+                *fzv = -(outO + outD * tf).z;
+                float tp = (inO.x - outO.x) / outD.x;
+                *pzv = -(outO + outD * tp).z;
+            };
+            V3 sO{x, 0, frontZ + 1}, sD{0, 0, -1}, fO, fD;
+            if (!TraceLensesFromScene(view(), C, sO, sD, &fO, &fD))
+                Die(scene.camera.loc, "Unable to trace ray from scene to film for thick lens approximation. Is aperture stop extremely small?");
+            cardinal(sO, fO, fD, &pz[0], &fz[0]);
+            V3 rO{x, 0, rearZ - 1}, rD{0, 0, 1}, oO, oD;
+            if (TraceLensesFromFilm(view(), C, rO, rD, &oO, &oD) == 0)
+                Die(scene.camera.loc, "Unable to trace ray from film to scene for thick lens approximation. Is aperture stop extremely small?");
+            cardinal(rO, oO, oD, &pz[1], &fz[1]);
+            float f = fz[0] - pz[0];
+            float z = -focusDistance;
+            float c = (pz[1] - z - pz[0]) * (pz[1] - z - 4 * f - pz[0]);
+            if (c <= 0) Die(scene.camera.loc, "Coefficient must be positive. It looks focusDistance is too short for a given lenses configuration");
+            float delta = (pz[1] - z + pz[0] - std::sqrt(c)) / 2;
+            thicknessAt(nEl - 1) = thicknessAt(nEl - 1) + delta;
+        }
+        // exit pupil bounds (cameras.cpp:861-895), one task per film-radius interval
+        {
+            const int nBounds = 64;
+            std::vector<float> bounds((size_t)4 * nBounds);
+            const SceneView &sv0 = view();
+            const float rearRadius = T->tableData[C.lens_offset + 4 * (nEl - 1) + 3], rearZ = thicknessAt(nEl - 1);
+            auto boundOne = [&](int i) {
+                float filmX0 = (float)i / nBounds * diagonal / 2, filmX1 = (float)(i + 1) / nBounds * diagonal / 2;
+                const float INF = std::numeric_limits<float>::max();
+                float b[4] = {INF, INF, -INF, -INF};   // Bounds2f(): max / lowest
+                const int nSamples = 1024 * 1024;
+                const float pr[4] = {-1.5f * rearRadius, -1.5f * rearRadius, 1.5f * rearRadius, 1.5f * rearRadius};
+                for (int k = 0; k < nSamples; ++k) {
+                    V3 pFilm{Lerp((k + 0.5f) / nSamples, filmX0, filmX1), 0, 0};
+                    float u0 = RadicalInverseBase(2, (uint64_t)k), u1 = RadicalInverseBase(3, (uint64_t)k);
+                    V3 pRear{Lerp(u0, pr[0], pr[2]), Lerp(u1, pr[1], pr[3]), rearZ};
+                    const bool inside = pRear.x >= b[0] && pRear.x <= b[2] && pRear.y >= b[1] && pRear.y <= b[3];
+                    if (!inside && TraceLensesFromFilm(sv0, C, pFilm, pRear - pFilm, nullptr, nullptr)) {
+                        b[0] = std::min(b[0], pRear.x); b[1] = std::min(b[1], pRear.y); b[2] = std::max(b[2], pRear.x); b[3] = std::max(b[3], pRear.y);
+                    }
+                }
+                if (!(b[0] >= b[2] || b[1] >= b[3])) {   // !IsDegenerate: expand for the sample spacing
+                    float ddx = pr[2] - pr[0], ddy = pr[3] - pr[1];
+                    float e = 2 * std::sqrt(ddx * ddx + ddy * ddy) / std::sqrt((float)nSamples);
+                    b[0] -= e; b[1] -= e; b[2] += e; b[3] += e;
+                }
+                for (int c = 0; c < 4; ++c) bounds[4 * i + c] = b[c];
+            };
+            unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> threads;
+            std::atomic<int> next{0};
+            for (unsigned t = 0; t < nt; ++t)
+                threads.emplace_back([&] { for (int i = next++; i < nBounds; i = next++) boundOne(i); });
+            for (auto &th : threads) th.join();
+            C.n_exit_pupil_bounds = nBounds;
+            C.exit_pupil_offset = (int)T->tableData.size();
+            T->tableData.insert(T->tableData.end(), bounds.begin(), bounds.end());
+        }
+        // CameraBase::FindMinimumDifferentials (cameras.cpp:153-203) over the generic CameraBase::GenerateRayDifferential (:116-152)
+        {
+            const float INF = std::numeric_limits<float>::infinity();
+            V3 minPosX{INF, INF, INF}, minPosY = minPosX, minDirX = minPosX, minDirY = minPosX;
+            const SceneView &sv0 = view();
+            const int n = 512;
+            for (int i = 0; i < n; ++i) {
+                V2 pFilm{float(i) / (n - 1) * F.full_res[0], float(i) / (n - 1) * F.full_res[1]};
+                CameraRayR cr = GenerateCameraRay(sv0, pFilm, 0.5f, V2{0.5f, 0.5f}, false);
+                if (!cr.valid) continue;
+                V3 rxo = cr.o, rxd = cr.d, ryo = cr.o, ryd = cr.d;   // RayDifferential(ray): differentials unset = the ray's own Point3f() / Vector3f()
+                rxo = ryo = V3{0, 0, 0}; rxd = ryd = V3{0, 0, 0};
+                for (float eps : {.05f, -.05f}) {
+                    CameraRayR rx = GenerateCameraRay(sv0, V2{pFilm.x + eps, pFilm.y}, 0.5f, V2{0.5f, 0.5f}, false);
+                    if (rx.valid) { rxo = cr.o + (rx.o - cr.o) / eps; rxd = cr.d + (rx.d - cr.d) / eps; break; }
+                }
+                for (float eps : {.05f, -.05f}) {
+                    CameraRayR ry = GenerateCameraRay(sv0, V2{pFilm.x, pFilm.y + eps}, 0.5f, V2{0.5f, 0.5f}, false);
+                    if (ry.valid) { ryo = cr.o + (ry.o - cr.o) / eps; ryd = cr.d + (ry.d - cr.d) / eps; break; }
+                }
+                V3 dox = XfVector(C.renderFromCamera.mInv, rxo - cr.o);
+                if (Length(dox) < Length(minPosX)) minPosX = dox;
+                V3 doy = XfVector(C.renderFromCamera.mInv, ryo - cr.o);
+                if (Length(doy) < Length(minPosY)) minPosY = doy;
+                V3 rd = Normalize(cr.d);
+                rxd = Normalize(rxd); ryd = Normalize(ryd);
+                Frame f = Frame::FromZ(rd);
+                V3 df = f.ToLocal(rd);
+                V3 dxf = Normalize(f.ToLocal(rxd)), dyf = Normalize(f.ToLocal(ryd));
+                if (Length(dxf - df) < Length(minDirX)) minDirX = dxf - df;
+                if (Length(dyf - df) < Length(minDirY)) minDirY = dyf - df;
+            }
+            for (int k = 0; k < 3; ++k) {
+                C.minPosDifferentialX[k] = minPosX[k]; C.minPosDifferentialY[k] = minPosY[k];
+                C.minDirDifferentialX[k] = minDirX[k]; C.minDirDifferentialY[k] = minDirY[k];
+            }
+        }
+        C.lensRadius = 0; C.focalDistance = 0;
+        ps.ReportUnused("Camera");
+        return;
+    }
     Transform screenFromCamera;
     if (scene.camera.name == "perspective") {
         C.type = WF_CAMERA_PERSPECTIVE;
@@ -1394,7 +1633,7 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
         else Die(scene.camera.loc, m + ": unknown mapping for spherical camera. (Must be \"equalarea\" or \"equirectangular\".)");
         screenFromCamera = Orthographic(0, 1);  // unused by the spherical camera
         lensradius = 0;
-    } else Die(scene.camera.loc, scene.camera.name + ": camera type not supported by this build (perspective, orthographic, spherical)");
+    } else Die(scene.camera.loc, scene.camera.name + ": camera type not supported by this build (perspective, orthographic, spherical, realistic)");
     // ProjectiveCamera (cameras.h:243-263)
     Transform NDCFromScreen = Scale(1 / (sMaxX - sMinX), 1 / (sMaxY - sMinY), 1) * Translate(V3{-sMinX, -sMaxY, 0});
     Transform rasterFromNDC = Scale((float)F.full_res[0], -(float)F.full_res[1], 1);

@@ -58,6 +58,9 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/png_textu
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_ewa_ref.pfm $G/textures_ewa.pbrt
 # Curve shapes (flat / cylinder / ribbon, Bezier and b-spline of degree 2 and 3, hair strands, curves in object instances): hand-written
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/curves_ref.pfm $G/curves.pbrt
+# RealisticCamera (tests/golden/dgauss50.dat: lens focusing, exit-pupil bounds, vignetting weights; the second with the built-in star aperture image)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/realistic_camera_ref.pfm $G/realistic_camera.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/realistic_camera_star_ref.pfm $G/realistic_camera_star.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
 # the reference's other BVH builder: blobs_small with `splitmethod "hlbvh"` (cpu/aggregates.cpp:389-503, 626-722)
