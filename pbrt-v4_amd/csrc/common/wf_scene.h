@@ -477,20 +477,31 @@ WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s
 }
 // EWA = false: the traversal kernels' inline alpha test (GEN = 1), which is only chosen for scenes whose alpha maps are not EWA-
 // filtered — a kernel's register allocation is the maximum over everything it can call, and the EWA loop must stay out of that
-template <bool EWA = true>
+// The lookup of a texture evaluated without a footprint (all differentials zero: the alpha test of the traversal kernels, whose
+// TextureEvalContext comes from an interaction nobody called ComputeDifferentials on).  MIPMap::Filter's level is then
+// nLevels - 1 + log2(1e-8) < 0 for any pyramid, so point filtering reads a level-0 texel and bilinear / trilinear both return
+// Bilerp(0, st): the same arithmetic as MIPFilterFloatP on these inputs, in a callee a tenth of its size.
+WF_NI float MIPFilterFloatZeroP(const float *table, const wf_tex_image *imp, float s_, float t_) {
+    const wf_tex_image im = *imp;
+    if (im.filter == WF_MIP_POINT) return ImageTexel(table, im, 0, (int)roundf(s_ * im.res[0] - 0.5f), (int)roundf(t_ * im.res[1] - 0.5f), 0);
+    return MIPBilerpFloat(table, im, 0, V2{s_, t_});
+}
+// EWA = false, ZERO = true: see above
+template <bool EWA = true, bool ZERO = false>
 WF_HD float MIPFilterFloat(const SceneView &sv, int image, V2 st, float dsdx, float dtdx, float dsdy, float dtdy) {
+    if constexpr (ZERO) return MIPFilterFloatZeroP(sv.tableData, sv.texImages + image, st.x, st.y);
     if constexpr (EWA)
         if (sv.texImages[image].filter == WF_MIP_EWA) return MIPFilterEWAFloatP(sv.tableData, sv.texImages + image, st.x, st.y, dsdx, dtdx, dsdy, dtdy);
     return MIPFilterFloatP(sv.tableData, sv.texImages + image, st.x, st.y, dsdx, dtdx, dsdy, dtdy);
 }
 // FloatImageTexture::Evaluate (textures.h:579-591), SpectrumImageTexture::Evaluate (textures.cpp:300-328)
-template <bool EWA = true>
+template <bool EWA = true, bool ZERO = false>
 WF_HD float EvalFloatImageTexture(const SceneView &sv, const wf_texture &t, const TexCtx &c) {
     TexCoord2 tcd = TexMap2D(sv, t, c);
     float dsdx = tcd.dsdx, dsdy = tcd.dsdy, dtdx = tcd.dtdx, dtdy = tcd.dtdy;
     V2 st = tcd.st;
     st.y = 1 - st.y;
-    float v = t.f0 * MIPFilterFloat<EWA>(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
+    float v = t.f0 * MIPFilterFloat<EWA, ZERO>(sv, t.i0, st, dsdx, dtdx, dsdy, dtdy);
     return t.f1 != 0 ? fmax(0.f, 1 - v) : v;
 }
 WF_HD S4 EvalSpectrumImageTexture(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &c) {
@@ -625,10 +636,10 @@ WF_HD bool InsidePolkaDot(const SceneView &sv, const wf_texture &t, const TexCtx
 #endif
 // the three texture types a production scene's parameters usually are: what the material kernels and the traversal kernels' alpha test
 // evaluate inline
-template <bool EWA = true>
+template <bool EWA = true, bool ZERO = false>
 WF_HD float EvalFloatTextureSimple(const SceneView &sv, const wf_texture &t, const TexCtx &tc) {
     if (t.type == WF_TEX_FLOAT_CONSTANT) return t.f0;
-    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture<EWA>(sv, t, tc);
+    if (t.type == WF_TEX_FLOAT_IMAGE) return EvalFloatImageTexture<EWA, ZERO>(sv, t, tc);
     // FloatBilerpTexture::Evaluate, textures.h:314-318
     TexCoord2 c = TexMap2D(sv, t, tc);
     const float v00 = t.f0, v01 = t.f1, v10 = t.map[10], v11 = t.map[11];

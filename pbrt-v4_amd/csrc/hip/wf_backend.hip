@@ -260,8 +260,8 @@ __device__ inline void FetchNode(const FastBVH &bvh, int node, U4 *n) {
 // the whole workgroup, so its queue pushes are block-aggregated (BlockAlloc).
 // what the general-primitive traversal variants call back into (wf_traverse.h LeafStep): the alpha test and the spheres
 // The general-primitive work of the traversal kernels comes in two strengths (template parameter GEN of the kernels):
-//   GEN = 1  "simple alpha": every alpha texture of the scene is a constant, an image map or a bilerp (no texture graph:
-//            EvalFloatTextureSimple) and there are no quadrics.  The test is a real call into a small out-of-line function
+//   GEN = 1  "simple alpha": every alpha texture of the scene is a constant, a uv-mapped image map (not EWA-filtered) or a bilerp
+//            (no texture graph: EvalFloatTextureSimple) and there are no quadrics.  The test is a real call into a small out-of-line function
 //            that reads the device-resident SceneView: the walk keeps its registers, the call is paid only when an
 //            alpha-tested triangle is actually hit.  (Foliage cut-outs are image maps: this is the san-miguel case.)
 //   GEN = 2  anything else (texture graphs as alpha, spheres / disks / cylinders): evaluated inline as before — an
@@ -270,17 +270,30 @@ __device__ inline void FetchNode(const FastBVH &bvh, int node, U4 *n) {
 // from the queue (and taken into the instance's space) when such a primitive is hit.
 __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp, int tri, float b0, float b1, float b2, float ox, float oy, float oz,
                                                             float dx, float dy, float dz) {
-    // AlphaTestPasses (common/wf_shapes.h) with the depth-0 texture evaluator
+    // AlphaTestPasses (common/wf_shapes.h) for the alpha textures genMode 1 admits: a constant, or a uv-mapped bilerp / image map
+    // looked up without a footprint.  The same arithmetic as EvalFloatTextureSimple on those inputs (UVMapping::Map, textures.h:76-98;
+    // FloatImageTexture::Evaluate, FloatBilerpTexture::Evaluate), without the interaction point the other mappings need and without
+    // the calls into the general filter: the test runs for every candidate hit of a cut-out triangle.
     const SceneView &sv = *svp;
     const wf_mesh &mesh = sv.meshes[sv.triMesh[tri]];
     if (mesh.alpha_tex < 0) return true;
-    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
-    V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
-    if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
-    TexCtx tc;
-    tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
-    tc.p = b0 * LoadP(sv, v[0]) + b1 * LoadP(sv, v[1]) + b2 * LoadP(sv, v[2]);
-    float a = EvalFloatTextureSimple<false>(sv, sv.textures[mesh.alpha_tex], tc);   // no EWA-filtered alpha maps under genMode 1
+    const wf_texture &t = sv.textures[mesh.alpha_tex];
+    float a;
+    if (t.type == WF_TEX_FLOAT_CONSTANT) a = t.f0;
+    else {
+        const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+        V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
+        if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+        const V2 uv{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
+        const V2 st{t.map[0] * uv.x + t.map[2], t.map[1] * uv.y + t.map[3]};
+        if (t.type == WF_TEX_FLOAT_IMAGE) {
+            const float val = t.f0 * MIPFilterFloatZeroP(sv.tableData, sv.texImages + t.i0, st.x, 1 - st.y);
+            a = t.f1 != 0 ? fmax(0.f, 1 - val) : val;
+        } else {
+            const float v00 = t.f0, v01 = t.f1, v10 = t.map[10], v11 = t.map[11];
+            a = (1 - st.x) * (1 - st.y) * v00 + st.x * (1 - st.y) * v10 + (1 - st.x) * st.y * v01 + st.x * st.y * v11;
+        }
+    }
     if (!(a < 1)) return true;
     float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(V3{ox, oy, oz}, V3{dx, dy, dz}));
     return !(u > a);
@@ -1201,8 +1214,10 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             for (int i = 0; i < d->n_meshes && ctx->genMode < 2; ++i)
                 if (d->meshes[i].alpha_tex >= 0) {
                     const int tt = d->textures[d->meshes[i].alpha_tex].type;
-                    const bool ewa = tt == WF_TEX_FLOAT_IMAGE && d->tex_images[d->textures[d->meshes[i].alpha_tex].i0].filter == WF_MIP_EWA;
-                    ctx->genMode = std::max(ctx->genMode, ((tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) && !ewa) ? 1 : 2);
+                    // the inline test looks an image map up without a footprint (MIPFilterFloatZeroP): uv-mapped, not EWA-filtered
+                    const wf_texture &at = d->textures[d->meshes[i].alpha_tex];
+                    const bool lean = tt == WF_TEX_FLOAT_CONSTANT || (at.mapping == WF_TEXMAP_UV && (tt != WF_TEX_FLOAT_IMAGE || d->tex_images[at.i0].filter != WF_MIP_EWA));
+                    ctx->genMode = std::max(ctx->genMode, ((tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) && lean) ? 1 : 2);
                 }
             if (getenv("WF_GEN_MODE")) ctx->genMode = std::max(ctx->genMode, atoi(getenv("WF_GEN_MODE")));  // timing experiments: force the general variant
         }
