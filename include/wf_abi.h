@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 4
+#define WF_ABI_VERSION 5
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830

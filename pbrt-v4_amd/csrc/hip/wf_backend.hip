@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
 }
 template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{stackSpill + gtid, stride, 0};

@@ -98,6 +98,9 @@ constexpr int NODE_NONE = (int)0x80000000;
 #ifndef WF_TWAVES_INST
 #define WF_TWAVES_INST 4   // the same for the two-level (object instance) variants, which carry the render-space ray as well
 #endif
+#ifndef WF_TWAVES_INST_SHADOW
+#define WF_TWAVES_INST_SHADOW 5   // the any-hit walk keeps no hit record: it fits 5 waves (96 VGPRs) two-level as well, -3 % (27.2 vs 28.1 ms)
+#endif
 constexpr int TOP_NODES = WF_TOP_NODES;  // QNodes cached in LDS per workgroup
 constexpr int TBLOCK = WF_TBLOCK;        // threads per workgroup of the traversal kernels
 constexpr int TSTACK = WF_TSTACK;        // LDS stack entries per lane (x 4 B x TBLOCK)
