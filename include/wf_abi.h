@@ -202,6 +202,7 @@ enum wf_light_type {
     WF_LIGHT_UNIFORM_INFINITE = 4,
     WF_LIGHT_IMAGE_INFINITE = 5,
     WF_LIGHT_PROJECTION = 7,          /* lights.h:280-350: xform = renderFromLight * Scale(1,-1,1), xform2 = screenFromLight, image = RGB wf_tex_image */
+    WF_LIGHT_PORTAL_INFINITE = 8,     /* lights.h:631-731 PortalImageInfiniteLight: image = index into image_lights (portal fields) */
     WF_LIGHT_GONIOMETRIC = 6          /* lights.h:353-404: xform = renderFromLight * swapYZ, image = one-channel wf_tex_image, area = mean texel */
 };
 typedef struct wf_light {
@@ -240,6 +241,13 @@ typedef struct wf_image_light {
     int32_t res;                 /* image is res x res */
     int32_t pixel_offset;        /* res*res*3 floats (RGB interleaved, row 0 first) in table_data */
     wf_pc2d distribution, compensated;
+    /* PortalImageInfiniteLight (lights.h:631-731): pixel_offset holds the image rectified to the portal's (alpha, beta) parametrisation */
+    int32_t is_portal;
+    int32_t func_offset;         /* res*res floats: the sampling function (WindowedPiecewiseConstant2D::func, util/sampling.h:895-990) */
+    int32_t sat_offset;          /* res*res doubles (two float slots each, even offset): its summed-area table (util/sampling.h:830-892) */
+    int32_t pad;
+    float portal[4][3];          /* the portal quadrilateral in render space */
+    float portal_frame[3][3];    /* Frame::FromXY(p03, p01): x, y, z */
 } wf_image_light;
 
 /* MIPMap of an image texture (util/mipmap.h:49-92): float pyramid levels (Image::GeneratePyramid,

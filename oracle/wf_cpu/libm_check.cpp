@@ -28,10 +28,11 @@ static float r_cosh(float x) { return coshf(x); }
 static float r_sinh(float x) { return sinhf(x); }
 static float r_expm1(float x) { return expm1f(x); }
 static float r_atanh(float x) { return atanhf(x); }
+static float r_tan(float x) { return tanf(x); }
 static const Fn fns[] = {
     {"sin", glibc235::sinf, r_sin},     {"cos", glibc235::cosf, r_cos},     {"exp", glibc235::expf, r_exp},
     {"log", glibc235::logf, r_log},     {"atan", glibc235::atanf, r_atan},  {"asin", glibc235::asinf, r_asin},
-    {"acos", glibc235::acosf, r_acos},  {"cosh", glibc235::coshf, r_cosh}, {"sinh", glibc235::sinhf, r_sinh}, {"expm1", glibc235::expm1f, r_expm1},  {"atanh", glibc235::atanhf, r_atanh},
+    {"acos", glibc235::acosf, r_acos},  {"cosh", glibc235::coshf, r_cosh}, {"sinh", glibc235::sinhf, r_sinh}, {"expm1", glibc235::expm1f, r_expm1},  {"atanh", glibc235::atanhf, r_atanh}, {"tan", glibc235::tanf, r_tan},
 };
 static inline bool same(float a, float b) {
     if (a != a && b != b) return true;

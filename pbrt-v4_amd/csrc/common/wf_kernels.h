@@ -761,14 +761,14 @@ WF_HD void KHandleEscaped(const SceneView &sv, const WorkState &ws, int cur, int
     int pixelIndex = m.x, depth = m.y;
     bool specularBounce = m.z & RAYFLAG_SPECULAR_BOUNCE;
     Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    F4 d4 = q.d[i];
-    V3 rayd{d4.x, d4.y, d4.z};
+    F4 d4 = q.d[i], o4 = q.o[i];
+    V3 rayd{d4.x, d4.y, d4.z}, rayo{o4.x, o4.y, o4.z};
     S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]), r_l0 = toS4(q.r_l[i]);
     S4 L = S4c(0.f);
     for (int k = 0; k < sv.nInfiniteLights; ++k) {
         int lightId = sv.infiniteLights[k];
         const wf_light &light = sv.lights[lightId];
-        S4 Le = LightLe(sv, light, rayd, lambda);
+        S4 Le = LightLe(sv, light, rayo, rayd, lambda);
         if (Le) {
             if (depth == 0 || specularBounce) {
                 L = L + beta * Le / r_u.Average();
@@ -868,8 +868,12 @@ template <> struct MatBxDF<WF_MAT_COATED_CONDUCTOR> {
 // TEXCTX = false: the scene has neither footprint-dependent textures nor displacement, so the differentials and
 // the bump-mapping block (whose only consumers those are) are compiled out — a separate kernel variant, because
 // their registers cost the common case ~25 % (35 spilled VGPRs in the diffuse kernel).
-template <int MAT, bool TEXCTX = true>
+// VARIANT 2 = 1 + the rarely used light types (portal infinite lights): their out-of-line samplers cost the material kernels 4-6 % by being
+// reachable at all (call-site spills), so scenes without them run variants that cannot reach them.
+template <int MAT, int VARIANT = 2>
 WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid) {
+    constexpr bool TEXCTX = VARIANT != 0;
+    constexpr bool RARE_LIGHTS = VARIANT == 2;
     // `valid` = this thread has an item.  The two queue pushes go through BlockAlloc, which every thread of
     // the workgroup must reach: control flow below is flattened into the flags pushRay / pushShadow.
     using BxDF = typename MatBxDF<MAT>::T;
@@ -1039,7 +1043,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                 LightLiSample ls{};
                 ls.valid = true; ls.L = S4c(1.f); ls.pdf = 1.f; ls.wi = V3{s0.y, s0.z, 0.5f}; ls.pLightPi = ctx.pi; ls.pLightN = N3{0, 1, 0};
 #else
-                LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+                LightLiSample ls = LightSampleLi<RARE_LIGHTS>(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
 #endif
                 if (ls.valid && ls.L && ls.pdf != 0) {
                     V3 wi = ls.wi;

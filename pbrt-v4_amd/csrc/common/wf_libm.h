@@ -630,4 +630,71 @@ WFLM_HD float atanhf(float x) {
     return asfloat((asuint(t) & 0x7fffffffu) | (asuint(x) & 0x80000000u));
 }
 
+// tanf: sysdeps/ieee754/flt-32/s_tanf.c of glibc 2.35 — the argument reduction of sincosf (reduce_fast / reduce_large above, here
+// without fused multiply-add: tanf has no FMA variant in 2.35), the double remainder split into a float head and tail — over fdlibm's
+// k_tanf.c kernel.  Verified against the live libm on all 2^32 arguments (oracle/wf_cpu/libm_check.cpp).
+WFLM_HD float kernel_tanf(float x, float y, int iy) {
+    const float one = 1.0f, pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f, T4 = 8.8632395491e-03f,
+                T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f, T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f,
+                T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f, T12 = 2.5907305826e-05f;
+    float z, r, v, w, s;
+    const int32_t hx = (int32_t)asuint(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {  // |x| < 2^-13
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return one / ffabs(x);
+            else if (iy == 1) return x;
+            else return -1 / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) {  // |x| >= 0.6744
+        if (hx < 0) { x = -x; y = -y; }
+        z = pio4 - x;
+        w = pio4lo - y;
+        x = z + w;
+        y = 0.0f;
+        if (ffabs(x) < 0x1p-13f) return (1 - ((hx >> 30) & 2)) * iy * (1.0f - 2 * iy * x);
+    }
+    z = x * x;
+    w = z * z;
+    r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    // -1 / (x + r), accurately
+    float a, t;
+    z = asfloat(asuint(w) & 0xfffff000u);
+    v = r - (z - x);
+    t = a = -1.0f / w;
+    t = asfloat(asuint(t) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+WFLM_HD float tanf(float x) {
+    const int32_t hx = (int32_t)asuint(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) return kernel_tanf(x, 0.0f, 1);   // |x| ~< pi/4
+    if (ix > 0x7f7fffff) return x - x;                      // tan(Inf or NaN) is NaN
+    double xd = x;
+    int n;
+    if (abstop12(x) <= 0x42e) {  // |x| < 120: reduce_fast, multiply and subtract rounded separately
+        double r = xd * 0x1.45f306dc9c883p+23;
+        n = ((int32_t)r + 0x800000) >> 24;
+        xd = xd - (double)n * 0x1.921fb54442d18p+0;
+    } else {
+        xd = reduce_large(asuint(x), &n);
+        if (hx < 0) xd = -xd;
+    }
+    const float y0 = (float)xd, y1 = (float)(xd - (double)y0);
+    return kernel_tanf(y0, y1, 1 - ((2 * n) & 2));   // 1: n even, -1: n odd
+}
+
 }  // namespace glibc235

@@ -104,11 +104,167 @@ WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, V3 p, N3 n, V2 uv, V
     }
     return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
 }
+
+// ---------------------------------------------------------------------------------------------
+// PortalImageInfiniteLight (lights.h:631-731, lights.cpp:1109-1336): an environment map seen through a rectangular portal,
+// re-parametrised so that the portal bounds an axis-aligned rectangle of the image for every reference point, sampled through a
+// summed-area table (WindowedPiecewiseConstant2D, util/sampling.h:830-990)
+struct B2 { V2 pMin, pMax; };
+WF_HD Frame PortalFrame(const wf_image_light &im) {
+    Frame f;
+    f.x = V3{im.portal_frame[0][0], im.portal_frame[0][1], im.portal_frame[0][2]};
+    f.y = V3{im.portal_frame[1][0], im.portal_frame[1][1], im.portal_frame[1][2]};
+    f.z = V3{im.portal_frame[2][0], im.portal_frame[2][1], im.portal_frame[2][2]};
+    return f;
+}
+WF_HD bool PortalImageFromRender(const wf_image_light &im, V3 wRender, V2 *uv, float *duv_dw) {
+    V3 w = PortalFrame(im).ToLocal(wRender);
+    if (w.z <= 0) return false;
+    if (duv_dw) *duv_dw = Sqr(Pi) * (1 - Sqr(w.x)) * (1 - Sqr(w.y)) / w.z;
+    float alpha = atan2(w.x, w.z), beta = atan2(w.y, w.z);
+    *uv = V2{Clamp((alpha + Pi / 2) / Pi, 0.f, 1.f), Clamp((beta + Pi / 2) / Pi, 0.f, 1.f)};
+    return true;
+}
+WF_HD V3 PortalRenderFromImage(const wf_image_light &im, V2 uv, float *duv_dw) {
+    float alpha = -Pi / 2 + uv.x * Pi, beta = -Pi / 2 + uv.y * Pi;
+    float x = tan(alpha), y = tan(beta);
+    V3 w = Normalize(V3{x, y, 1});
+    if (duv_dw) *duv_dw = Sqr(Pi) * (1 - Sqr(w.x)) * (1 - Sqr(w.y)) / w.z;
+    return PortalFrame(im).FromLocal(w);
+}
+WF_HD bool PortalImageBounds(const wf_image_light &im, V3 p, B2 *b) {
+    V3 c0{im.portal[0][0], im.portal[0][1], im.portal[0][2]}, c2{im.portal[2][0], im.portal[2][1], im.portal[2][2]};
+    V2 p0, p1;
+    if (!PortalImageFromRender(im, Normalize(c0 - p), &p0, nullptr)) return false;
+    if (!PortalImageFromRender(im, Normalize(c2 - p), &p1, nullptr)) return false;
+    b->pMin = V2{fmin(p0.x, p1.x), fmin(p0.y, p1.y)};
+    b->pMax = V2{fmax(p0.x, p1.x), fmax(p0.y, p1.y)};
+    return true;
+}
+WF_HD float SATLookupInt(const double *sum, int n, int x, int y) {
+    if (x == 0 || y == 0) return 0;
+    x = x - 1 < n - 1 ? x - 1 : n - 1;
+    y = y - 1 < n - 1 ? y - 1 : n - 1;
+    return (float)sum[(size_t)y * n + x];
+}
+WF_HD float SATLookup(const double *sum, int n, float x, float y) {
+    x *= n; y *= n;
+    int x0 = (int)x, y0 = (int)y;
+    float v00 = SATLookupInt(sum, n, x0, y0), v10 = SATLookupInt(sum, n, x0 + 1, y0);
+    float v01 = SATLookupInt(sum, n, x0, y0 + 1), v11 = SATLookupInt(sum, n, x0 + 1, y0 + 1);
+    float dx = x - int(x), dy = y - int(y);
+    return (1 - dx) * (1 - dy) * v00 + (1 - dx) * dy * v01 + dx * (1 - dy) * v10 + dx * dy * v11;
+}
+WF_HD float SATIntegral(const double *sum, int n, const B2 &e) {
+    double s = (((double)SATLookup(sum, n, e.pMax.x, e.pMax.y) - (double)SATLookup(sum, n, e.pMin.x, e.pMax.y)) +
+                ((double)SATLookup(sum, n, e.pMin.x, e.pMin.y) - (double)SATLookup(sum, n, e.pMax.x, e.pMin.y)));
+    float r = (float)(s / (n * n));
+    return r > 0 ? r : 0.f;
+}
+WF_HD float WindowedEval(const float *func, int n, V2 p) {
+    int px = (int)(p.x * n), py = (int)(p.y * n);
+    px = px < n - 1 ? px : n - 1;
+    py = py < n - 1 ? py : n - 1;
+    return func[(size_t)py * n + px];
+}
+// WindowedPiecewiseConstant2D::Sample / SampleBisection (util/sampling.h:903-975)
+WF_HD bool WindowedSample(const float *func, const double *sum, int n, V2 u, const B2 &b, V2 *pOut, float *pdf) {
+    const float bInt = SATIntegral(sum, n, b);
+    if (bInt == 0) return false;
+    V2 p;
+    {
+        auto Px = [&](float x) { B2 bx = b; bx.pMax.x = x; return SATIntegral(sum, n, bx) / bInt; };
+        float lo = b.pMin.x, hi = b.pMax.x;
+        while (ceil(n * hi) - floor(n * lo) > 1) {
+            float mid = (lo + hi) / 2;
+            if (Px(mid) > u.x) hi = mid; else lo = mid;
+        }
+        float t = (u.x - Px(lo)) / (Px(hi) - Px(lo));
+        p.x = Clamp(Lerp(t, lo, hi), lo, hi);
+    }
+    B2 bCond{V2{floor(p.x * n) / n, b.pMin.y}, V2{ceil(p.x * n) / n, b.pMax.y}};
+    if (bCond.pMin.x == bCond.pMax.x) bCond.pMax.x += 1.f / n;
+    const float condIntegral = SATIntegral(sum, n, bCond);
+    if (condIntegral == 0) return false;
+    {
+        auto Py = [&](float y) { B2 by = bCond; by.pMax.y = y; return SATIntegral(sum, n, by) / condIntegral; };
+        float lo = b.pMin.y, hi = b.pMax.y;
+        while (ceil(n * hi) - floor(n * lo) > 1) {
+            float mid = (lo + hi) / 2;
+            if (Py(mid) > u.y) hi = mid; else lo = mid;
+        }
+        float t = (u.y - Py(lo)) / (Py(hi) - Py(lo));
+        p.y = Clamp(Lerp(t, lo, hi), lo, hi);
+    }
+    *pdf = WindowedEval(func, n, p) / bInt;
+    *pOut = p;
+    return true;
+}
+// PortalImageInfiniteLight::ImageLookup (lights.cpp:1217-1224): Image::LookupNearestChannel, clamp wrap
+WF_HD S4 PortalImageLookup(const SceneView &sv, float scale, const wf_image_light &im, V2 uv, const Wavelengths &lambda) {
+    const int res = im.res;
+    int px = (int)(uv.x * res), py = (int)(uv.y * res);
+    px = px < 0 ? 0 : (px > res - 1 ? res - 1 : px);
+    py = py < 0 ? 0 : (py > res - 1 ? res - 1 : py);
+    const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
+    return scale * RGBIlluminantSample(sv, fmax(0.f, texel[0]), fmax(0.f, texel[1]), fmax(0.f, texel[2]), lambda);
+}
+// out of line: the sampling loops are long and only scenes with a portal light reach them
+// (the light's fields come by value: a pointer to the caller's wf_light would pin its copy in scratch)
+WF_NI void PortalSampleLiP(const SceneView *svp, int image, float scale, float sceneRadius, float px, float py, float pz, float u0, float u1,
+                           const Wavelengths *lambda, LightLiSample *out) {
+    const SceneView &sv = *svp;
+    const wf_image_light &im = sv.imageLights[image];
+    LightLiSample ls{};
+    ls.valid = false;
+    *out = ls;
+    const V3 p{px, py, pz};
+    B2 b;
+    if (!PortalImageBounds(im, p, &b)) return;
+    const float *func = sv.tableData + im.func_offset;
+    const double *sum = (const double *)(sv.tableData + im.sat_offset);
+    float mapPDF;
+    V2 uv;
+    if (!WindowedSample(func, sum, im.res, V2{u0, u1}, b, &uv, &mapPDF)) return;
+    float duv_dw;
+    V3 wi = PortalRenderFromImage(im, uv, &duv_dw);
+    if (duv_dw == 0) return;
+    ls.L = PortalImageLookup(sv, scale, im, uv, *lambda);
+    ls.wi = wi; ls.pdf = mapPDF / duv_dw;
+    ls.pLightPi = MakeP3i(p + wi * (2 * sceneRadius)); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
+    *out = ls;
+}
+WF_NI float PortalPDFLiP(const SceneView *svp, int image, float px, float py, float pz, float wx, float wy, float wz) {
+    const SceneView &sv = *svp;
+    const wf_image_light &im = sv.imageLights[image];
+    float duv_dw;
+    V2 uv;
+    if (!PortalImageFromRender(im, V3{wx, wy, wz}, &uv, &duv_dw) || duv_dw == 0) return 0;
+    B2 b;
+    if (!PortalImageBounds(im, V3{px, py, pz}, &b)) return 0;
+    const double *sum = (const double *)(sv.tableData + im.sat_offset);
+    float funcInt = SATIntegral(sum, im.res, b);
+    if (funcInt == 0) return 0;
+    return WindowedEval(sv.tableData + im.func_offset, im.res, uv) / funcInt / duv_dw;
+}
+// PortalImageInfiniteLight::Le (lights.cpp:1208-1215)
+WF_NI void PortalLeP(const SceneView *svp, int image, float scale, float ox, float oy, float oz, float dx, float dy, float dz, const Wavelengths *lambda, S4 *out) {
+    const SceneView &sv = *svp;
+    const wf_image_light &im = sv.imageLights[image];
+    *out = S4c(0.f);
+    V2 uv;
+    B2 b;
+    if (!PortalImageFromRender(im, Normalize(V3{dx, dy, dz}), &uv, nullptr)) return;
+    if (!PortalImageBounds(im, V3{ox, oy, oz}, &b)) return;
+    if (!(uv.x >= b.pMin.x && uv.x <= b.pMax.x && uv.y >= b.pMin.y && uv.y <= b.pMax.y)) return;   // Inside(Point2f, Bounds2f)
+    *out = PortalImageLookup(sv, scale, im, uv, *lambda);
+}
 WF_HD V3 XfApply3(const float m[4][4], V3 v) {
     return V3{m[0][0] * v.x + m[0][1] * v.y + m[0][2] * v.z, m[1][0] * v.x + m[1][1] * v.y + m[1][2] * v.z,
               m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z};
 }
 
+template <bool RARE = true>
 WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V2 u,
                                   const Wavelengths &lambda, bool allowIncompletePDF) {
     LightLiSample ls{};
@@ -209,6 +365,14 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
         ls.pLightPi = MakeP3i(ctx.p() + wi * (2 * l.sceneRadius)); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
         return ls;
     }
+    case WF_LIGHT_PORTAL_INFINITE: if constexpr (RARE) {
+        // locals for everything whose address the out-of-line callee gets: `ls` and `lambda` themselves stay in registers on the other paths
+        const V3 p = ctx.p();
+        const Wavelengths lam = lambda;
+        LightLiSample tmp;
+        PortalSampleLiP(sv.self, l.image, l.scale, l.sceneRadius, p.x, p.y, p.z, u.x, u.y, &lam, &tmp);
+        return tmp;
+    } else return ls;
     default: return ls;
     }
 }
@@ -225,11 +389,21 @@ WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &
         V2 uv = EqualAreaSphereToSquare(wLight);
         return PC2DPDF(sv.tableData, allowIncompletePDF ? im.compensated : im.distribution, uv) / (4 * Pi);
     }
+    case WF_LIGHT_PORTAL_INFINITE: {
+        const V3 p = ctx.p();
+        return PortalPDFLiP(sv.self, l.image, p.x, p.y, p.z, wi.x, wi.y, wi.z);
+    }
     default: return 0.f;
     }
 }
 // Light::Le for infinite lights (lights.h:172-174 for the others)
-WF_HD S4 LightLe(const SceneView &sv, const wf_light &l, V3 rayd, const Wavelengths &lambda) {
+WF_HD S4 LightLe(const SceneView &sv, const wf_light &l, V3 rayo, V3 rayd, const Wavelengths &lambda) {
+    if (l.type == WF_LIGHT_PORTAL_INFINITE) {
+        S4 Le;
+        const Wavelengths lam = lambda;
+        PortalLeP(sv.self, l.image, l.scale, rayo.x, rayo.y, rayo.z, rayd.x, rayd.y, rayd.z, &lam, &Le);
+        return Le;
+    }
     if (l.type == WF_LIGHT_UNIFORM_INFINITE) return l.scale * DenseSample(sv, l.spectrum_offset, lambda);
     if (l.type == WF_LIGHT_IMAGE_INFINITE) {
         // lights.h:597-601

@@ -116,7 +116,8 @@ WF_HD float log(float x) { return glibc235::logf(x); }
 WF_HD float cosh(float x) { return glibc235::coshf(x); }
 WF_HD float sinh(float x) { return glibc235::sinhf(x); }
 WF_HD float atanh(float x) { return glibc235::atanhf(x); }
-// tan / pow have no call site in the device path (host-side scene set-up only)
+WF_HD float tan(float x) { return glibc235::tanf(x); }
+// pow has no call site in the device path (host-side scene set-up only)
 WF_HD long lround(float x) { return (long)::roundf(x); }
 #else
 WF_HD float sin(float x) { return std::sin(x); }
@@ -130,6 +131,7 @@ WF_HD float log(float x) { return std::log(x); }
 WF_HD float cosh(float x) { return std::cosh(x); }
 WF_HD float sinh(float x) { return std::sinh(x); }
 WF_HD float atanh(float x) { return std::atanh(x); }
+WF_HD float tan(float x) { return std::tan(x); }
 WF_HD long lround(float x) { return std::lround(x); }
 #endif
 

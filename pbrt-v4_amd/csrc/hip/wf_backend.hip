@@ -63,6 +63,7 @@ struct wf_ctx {
     int *stackSpill = nullptr;   // [rows][MAX_GRID*BLOCK], rows from the trees' depths (wf_scene_upload)
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
+    bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
     int persistentGridShadow = 1024;
@@ -703,7 +704,8 @@ __global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, W
 // the material kernels live in wf_mat.hip (one translation unit per material type)
 extern "C" {
 #define WF_DECL_MAT(n) void wf_launch_eval_material_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
-                       void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int);
+                       void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int); \
+                       void wf_launch_eval_material_##n##_2(hipStream_t, int, const SceneView *, const WorkState *, int);
 WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8) WF_DECL_MAT(9)
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
@@ -1158,6 +1160,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.matTypeMask = 0;
     sv.haveMix = 0;
     sv.haveSubsurface = 0;
+    ctx->rareLights = false;
+    for (int i = 0; i < d->n_lights; ++i) if (d->lights[i].type == WF_LIGHT_PORTAL_INFINITE) ctx->rareLights = true;
     sv.haveCurves = 0;
     for (int i = 0; i < d->n_quadrics; ++i) if (d->quadrics[i].type == WF_QUADRIC_CURVE) sv.haveCurves = 1;
     for (int i = 0; i < d->n_materials; ++i) {
@@ -1537,16 +1541,17 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     {
         Prof prof_(ctx, names[material_type]);
         const bool tex = ctx->svHost.texNeedsFootprint != 0;
+        const bool rare = ctx->rareLights;   // a portal infinite light: the variant whose light sampling can reach it
         switch (material_type) {
-        case 1: (tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 2: (tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 3: (tex ? wf_launch_eval_material_3_1 : wf_launch_eval_material_3_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 4: (tex ? wf_launch_eval_material_4_1 : wf_launch_eval_material_4_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 5: (tex ? wf_launch_eval_material_5_1 : wf_launch_eval_material_5_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 6: (tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 7: (tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 8: (tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 9: (tex ? wf_launch_eval_material_9_1 : wf_launch_eval_material_9_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 1: (rare ? wf_launch_eval_material_1_2 : tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 2: (rare ? wf_launch_eval_material_2_2 : tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 3: (rare ? wf_launch_eval_material_3_2 : tex ? wf_launch_eval_material_3_1 : wf_launch_eval_material_3_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 4: (rare ? wf_launch_eval_material_4_2 : tex ? wf_launch_eval_material_4_1 : wf_launch_eval_material_4_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 5: (rare ? wf_launch_eval_material_5_2 : tex ? wf_launch_eval_material_5_1 : wf_launch_eval_material_5_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 6: (rare ? wf_launch_eval_material_6_2 : tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 7: (rare ? wf_launch_eval_material_7_2 : tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 8: (rare ? wf_launch_eval_material_8_2 : tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 9: (rare ? wf_launch_eval_material_9_2 : tex ? wf_launch_eval_material_9_1 : wf_launch_eval_material_9_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         }
     }
     return 0;
@@ -1843,6 +1848,7 @@ __global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
         case 6: r = wf::acos(x); break;
         case 7: r = wf::cosh(x); break;
         case 10: r = wf::sinh(x); break;
+        case 11: r = wf::tan(x); break;
         default: r = wf::atanh(x); break;
         }
     }
@@ -1851,7 +1857,7 @@ __global__ void k_libm_probe(int fn, int n, const float *in, float *out) {
 }
 int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out) {
     if (!ctx) return fail(-1, "null context");
-    if (fn < 0 || fn > 10) return fail(-1, "wf_libm_probe: unknown function %d", fn);
+    if (fn < 0 || fn > 11) return fail(-1, "wf_libm_probe: unknown function %d", fn);
     if (n <= 0) return 0;
     size_t nin = (size_t)n * (fn == 9 ? 2 : 1);
     float *din = nullptr, *dout = nullptr;

@@ -1,5 +1,5 @@
 // wf_mat.hip — one translation unit per material type and texture-context variant (compiled with
-// -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_TEXCTX=<0|1>):
+// -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_TEXCTX=<0|1|2>):
 // the K9 kernel "<Material> + BxDF eval" (EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>,
 // wavefront/surfscatter.cpp:57-328) and its launcher.  Split from wf_backend.hip so that the seven material
 // kernels compile in parallel (the layered ones take minutes).
@@ -10,7 +10,7 @@
 using namespace wf;
 
 #if !defined(WF_MAT_INSTANCE) || !defined(WF_MAT_TEXCTX)
-#error "compile with -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_TEXCTX=<0|1>"
+#error "compile with -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_TEXCTX=<0|1|2>"
 #endif
 
 constexpr int MBLOCK = 256;
@@ -18,7 +18,7 @@ constexpr int MBLOCK = 256;
 #ifndef WF_MAT_WAVES
 #define WF_MAT_WAVES 2
 #endif
-template <int MAT, bool TEXCTX>
+template <int MAT, int TEXCTX>
 __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE];
     // block-uniform trip count: BlockAlloc inside the body synchronises the workgroup
@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const Sc
 
 #define WF_CAT3_(a, b, c, d) a##b##c##d
 #define WF_CAT3(a, b, c, d) WF_CAT3_(a, b, c, d)
-// WF_MAT_TEXCTX = 1: some texture depends on the footprint, or some material has a displacement texture / normal map
+// WF_MAT_TEXCTX = 1: some texture depends on the footprint, or some material has a displacement texture / normal map;
+// 2: the same plus the rarely used light types (KEvalMaterial)
 extern "C" void WF_CAT3(wf_launch_eval_material_, WF_MAT_INSTANCE, _, WF_MAT_TEXCTX)(hipStream_t stream, int grid, const SceneView *sv, const WorkState *ws, int cur) {
-    hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, WF_MAT_TEXCTX != 0>), dim3(grid), dim3(MBLOCK), 0, stream, *sv, *ws, cur);
+    hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, WF_MAT_TEXCTX>), dim3(grid), dim3(MBLOCK), 0, stream, *sv, *ws, cur);
 }

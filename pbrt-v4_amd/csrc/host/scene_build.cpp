@@ -13,6 +13,7 @@
 #include "../common/wf_camera.h"
 #include "../common/wf_shapes.h"
 #include "../common/wf_bssrdf.h"
+#include "../common/wf_lights.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1305,6 +1306,27 @@ static void BuildPowerAlias(SceneTables *T) {
             phi = Pi * ((l.flags & WF_LIGHTFLAG_TWOSIDED) ? 2 : 1) * l.area * (Ls * l.scale);
             break;
         case WF_LIGHT_UNIFORM_INFINITE: phi = 4 * Pi * Pi * Sqr(l.sceneRadius) * l.scale * Ls; break;  // lights.cpp:974-976
+        case WF_LIGHT_PORTAL_INFINITE: {                                                      // lights.cpp:1183-1206
+            const wf_image_light &im = T->imageLights[l.image];
+            const ColorSpace *ics = SpectralData::Get().sRGB();
+            S4 sumL = S4c(0.f);
+            for (int y = 0; y < im.res; ++y)
+                for (int x = 0; x < im.res; ++x) {
+                    const float *px = &T->tableData[im.pixel_offset + 3 * ((size_t)y * im.res + x)];
+                    float rgb[3] = {std::max(0.f, px[0]), std::max(0.f, px[1]), std::max(0.f, px[2])};
+                    V2 st{(x + 0.5f) / im.res, (y + 0.5f) / im.res};
+                    float duv_dw;
+                    (void)PortalRenderFromImage(im, st, &duv_dw);
+                    SpectrumP sp = ics->Illuminant(rgb);
+                    S4 s;
+                    for (int i = 0; i < 4; ++i) s[i] = sp->scale * SigmoidPoly(lambda.lambda[i], sp->c0, sp->c1, sp->c2);
+                    sumL = sumL + (s * Ls) / duv_dw;
+                }
+            V3 c0{im.portal[0][0], im.portal[0][1], im.portal[0][2]}, c1{im.portal[1][0], im.portal[1][1], im.portal[1][2]}, c3{im.portal[3][0], im.portal[3][1], im.portal[3][2]};
+            float area = Length(c1 - c0) * Length(c3 - c0);
+            phi = l.scale * area * sumL / (float)(im.res * im.res);
+            break;
+        }
         case WF_LIGHT_IMAGE_INFINITE: {                                                       // lights.cpp:1054-1072
             const wf_image_light &im = T->imageLights[l.image];
             const ColorSpace *ics = SpectralData::Get().sRGB();
@@ -2699,7 +2721,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         } else if (le.name == "infinite") {
             std::vector<V3> portal = ps.GetPoint3fArray("portal");
             std::string filename = ps.GetOneString("filename", "");
-            if (!portal.empty()) Die(le.loc, "portal infinite lights are not supported by this build yet");
+            if (!portal.empty() && filename.empty()) Die(le.loc, "a portal with a uniform \"L\" (no \"filename\") is not supported by this build yet");
             SpectrumP L = ps.GetOneSpectrum("L", nullptr, SpectrumType::Illuminant);
             float scale = ps.GetOneFloat("scale", 1);
             float E_v = ps.GetOneFloat("illuminance", -1);
@@ -2736,6 +2758,72 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
                     }
                     illuminance *= 2 * Pi / (w * h);
                     scale *= E_v / illuminance;
+                }
+                if (!portal.empty()) {
+                    // PortalImageInfiniteLight ctor (lights.cpp:1109-1181): the portal in render space, its frame, the environment map
+                    // resampled into the portal's (alpha, beta) parametrisation, the sampling function and its summed-area table
+                    if (portal.size() != 4) Die(le.loc, "Expected 4 vertices for infinite light portal but given " + std::to_string(portal.size()));
+                    wf_image_light im{};
+                    im.is_portal = 1;
+                    im.res = w;
+                    V3 P[4];
+                    for (int i = 0; i < 4; ++i) {
+                        P[i] = renderFromWorld.Point(portal[i]);   // cameraTransform.RenderFromWorld(p): the portal is given in world space
+                        im.portal[i][0] = P[i].x; im.portal[i][1] = P[i].y; im.portal[i][2] = P[i].z;
+                    }
+                    V3 p01 = Normalize(P[1] - P[0]), p12 = Normalize(P[2] - P[1]), p32 = Normalize(P[2] - P[3]), p03 = Normalize(P[3] - P[0]);
+                    if (std::abs(Dot(p01, p32) - 1) > .001 || std::abs(Dot(p12, p03) - 1) > .001 || std::abs(Dot(p01, p12)) > .001 ||
+                        std::abs(Dot(p12, p32)) > .001 || std::abs(Dot(p32, p03)) > .001 || std::abs(Dot(p03, p01)) > .001)
+                        fprintf(stderr, "Error: %s: Infinite light portal isn't a planar quadrilateral\n", le.loc.c_str());
+                    V3 fz = Cross(p03, p01);   // Frame::FromXY(p03, p01)
+                    for (int k = 0; k < 3; ++k) { im.portal_frame[0][k] = p03[k]; im.portal_frame[1][k] = p01[k]; im.portal_frame[2][k] = fz[k]; }
+                    wf_tex_image src{};
+                    src.res[0] = w; src.res[1] = h; src.n_levels = 1; src.n_channels = 3; src.wrap = WF_WRAP_OCTAHEDRAL; src.filter = WF_MIP_BILINEAR;
+                    std::vector<float> rect((size_t)3 * w * h), dfun((size_t)w * h);
+                    for (int y = 0; y < h; ++y)
+                        for (int x = 0; x < w; ++x) {
+                            V2 uv{(x + 0.5f) / w, (y + 0.5f) / h};
+                            float duv_dw;
+                            V3 wr = PortalRenderFromImage(im, uv, &duv_dw);
+                            V3 wl = Normalize(XfVector3(le.renderFromLight.mInv.m, wr));   // renderFromLight.ApplyInverse(w)
+                            V2 uvEqui = EqualAreaSphereToSquare(wl);
+                            float sum = 0;
+                            for (int c = 0; c < 3; ++c) {
+                                float v = ImageBilerpChannel(rgb.data(), src, 0, uvEqui, c);
+                                rect[3 * ((size_t)y * w + x) + c] = v;
+                                sum += v;
+                            }
+                            dfun[(size_t)y * w + x] = (sum / 3) * duv_dw;   // GetSamplingDistribution: channel average x Jacobian at the pixel centre
+                        }
+                    // SummedAreaTable (util/sampling.h:834-848), double sums of the float function
+                    std::vector<double> sat((size_t)w * h);
+                    auto S = [&](int x, int y) -> double & { return sat[(size_t)y * w + x]; };
+                    auto F = [&](int x, int y) { return dfun[(size_t)y * w + x]; };
+                    S(0, 0) = F(0, 0);
+                    for (int x = 1; x < w; ++x) S(x, 0) = F(x, 0) + S(x - 1, 0);
+                    for (int y = 1; y < h; ++y) S(0, y) = F(0, y) + S(0, y - 1);
+                    for (int y = 1; y < h; ++y)
+                        for (int x = 1; x < w; ++x) S(x, y) = (F(x, y) + S(x - 1, y) + S(x, y - 1) - S(x - 1, y - 1));
+                    im.pixel_offset = (int)T->tableData.size();
+                    T->tableData.insert(T->tableData.end(), rect.begin(), rect.end());
+                    im.func_offset = (int)T->tableData.size();
+                    T->tableData.insert(T->tableData.end(), dfun.begin(), dfun.end());
+                    if (T->tableData.size() & 1) T->tableData.push_back(0.f);   // doubles: 8-byte aligned
+                    im.sat_offset = (int)T->tableData.size();
+                    T->tableData.resize(T->tableData.size() + 2 * sat.size());
+                    std::memcpy(&T->tableData[im.sat_offset], sat.data(), sat.size() * sizeof(double));
+                    l.type = WF_LIGHT_PORTAL_INFINITE; l.scale = scale; l.spectrum_offset = T->pool.AddDense(*ics->illuminant);
+                    l.image = (int)T->imageLights.size();
+                    T->imageLights.push_back(im);
+                    l.xform = -1;
+                    l.infinite_index = (int)T->infiniteLights.size();
+                    T->infiniteLights.push_back(lightId);
+                    T->lights.push_back(l);
+                    T->desc.rgb2spec_coeffs = ics->table->coeffs.data();
+                    for (int i = 0; i < 64; ++i) T->desc.rgb2spec_znodes[i] = ics->table->zNodes[i];
+                    T->desc.cs_illuminant_offset = l.spectrum_offset;
+                    ps.ReportUnused("LightSource");
+                    continue;
                 }
                 wf_image_light im{};
                 im.res = w;
@@ -2865,7 +2953,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         V3 center = (sceneBounds.pMin + sceneBounds.pMax) / 2;
         float radius = Inside(center, sceneBounds) ? Distance(center, sceneBounds.pMax) : 0;
         for (wf_light &l : T->lights)
-            if (l.type == WF_LIGHT_DISTANT || l.type == WF_LIGHT_UNIFORM_INFINITE || l.type == WF_LIGHT_IMAGE_INFINITE) {
+            if (l.type == WF_LIGHT_DISTANT || l.type == WF_LIGHT_UNIFORM_INFINITE || l.type == WF_LIGHT_IMAGE_INFINITE || l.type == WF_LIGHT_PORTAL_INFINITE) {
                 l.sceneCenter[0] = center.x; l.sceneCenter[1] = center.y; l.sceneCenter[2] = center.z;
                 l.sceneRadius = radius;
             }

@@ -269,7 +269,7 @@ class Scene:
                "wf_sampler_probe")
         return out
 
-    LIBM_FNS = ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2", "sinh")
+    LIBM_FNS = ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2", "sinh", "tan")
 
     def libm_probe(self, fn, x):
         """Device evaluation of the kernels' elementary function `fn` over float32 array x ((n, 2) (y, x) pairs for atan2)."""

@@ -12,7 +12,7 @@ import pytest
 from conftest import GOLDEN, ROOT
 
 CHECK = os.path.join(ROOT, "oracle", "_build", "libm_check")
-FNS = ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2", "sinh")
+FNS = ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2", "sinh", "tan")
 
 
 def _eval(mode, fn, x):

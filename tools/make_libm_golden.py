@@ -33,10 +33,11 @@ EDGES = {
     "acos": [0x3f800000, 0x3f000000, 0x32800000],
     "cosh": [0x41b00000, 0x3eb17218, 0x24000000, 0x42b1717f, 0x42b2d4fc, 0x33000000],
     "atanh": [0x3f000000, 0x31800000, 0x3f800000, 0x3ed413d7, 0x3e95f61f],
+    "tan": [0x3f490fda, 0x3f490fdb, 0x3fc90fdb, 0x3fc90fda, 0x39000000, 0x3f2ca140, 0x42f00000, 0x4016cbe4, 0x5f000000, 0x7f000000, 0x40490fdb],
     "sinh": [0x41b00000, 0x31800000, 0x3f800000, 0x42b1717f, 0x42b2d4fc, 0x3eb17218, 0x3f851592, 0x4195b844, 0x33000000],
 }
 RANGE = {"sin": (-8, 8), "cos": (-8, 8), "exp": (-90, 90), "log": (0, 100), "atan": (-20, 20), "asin": (-1, 1), "acos": (-1, 1),
-         "cosh": (-3, 3), "atanh": (-1, 1), "sinh": (-12, 12)}
+         "cosh": (-3, 3), "atanh": (-1, 1), "sinh": (-12, 12), "tan": (-1.6, 1.6)}
 
 def inputs(fn, rng):
     if fn == "atan2":
@@ -61,7 +62,7 @@ def inputs(fn, rng):
 
 def main():
     rng = np.random.default_rng(2035)
-    for fn in ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2", "sinh"):
+    for fn in ("sin", "cos", "exp", "log", "atan", "asin", "acos", "cosh", "atanh", "atan2", "sinh", "tan"):
         x = inputs(fn, rng)
         out = subprocess.run([CHECK, "eval", fn], input=x.tobytes(), capture_output=True, check=True).stdout
         y = np.frombuffer(out, dtype=np.float32)
