@@ -10,6 +10,7 @@
 //   util/mesh.cpp:25-75, shapes.cpp:283-307,368-438  triangle meshes (vertices transformed to render space)
 #include "scene.h"
 #include <unistd.h>
+#include <zlib.h>
 #include "../common/wf_camera.h"
 #include "../common/wf_shapes.h"
 #include "../common/wf_bssrdf.h"
@@ -1825,8 +1826,34 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
 // Minimal PLY reader (ascii + binary_little_endian; vertex x,y,z[,nx,ny,nz][,u,v|s,t], face vertex_indices
 // with triangle faces — TriQuadMesh::ReadPLY, util/mesh.cpp:158-420; quad faces are bilinear patches in the reference: refused)
 bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
-    std::ifstream in(fn, std::ios::binary);
-    if (!in) { *err = "unable to open PLY file"; return false; }
+    // the whole file in memory; "*.gz" through zlib, as the reference's rply does (ext/rply/rply.cpp:382-393)
+    std::string content;
+    {
+        const size_t L = fn.size();
+        const bool gz = L > 3 && fn[L - 3] == '.' && tolower((unsigned char)fn[L - 2]) == 'g' && tolower((unsigned char)fn[L - 1]) == 'z';
+        if (gz) {
+            gzFile g = gzopen(fn.c_str(), "rb");
+            if (!g) { *err = "unable to open PLY file"; return false; }
+            char buf[1 << 16];
+            int n;
+            while ((n = gzread(g, buf, sizeof(buf))) > 0) content.append(buf, (size_t)n);
+            gzclose(g);
+            if (n < 0) { *err = "error reading gzipped PLY file"; return false; }
+        } else {
+            std::ifstream f(fn, std::ios::binary);
+            if (!f) { *err = "unable to open PLY file"; return false; }
+            f.seekg(0, std::ios::end);
+            content.resize((size_t)f.tellg());
+            f.seekg(0);
+            f.read(&content[0], (std::streamsize)content.size());
+        }
+    }
+    // only the header goes through a stream (the body of a large mesh is hundreds of megabytes)
+    size_t headerEnd = content.find("end_header");
+    if (headerEnd != std::string::npos) headerEnd = content.find('\n', headerEnd);
+    if (headerEnd == std::string::npos) { *err = "not a PLY file"; return false; }
+    ++headerEnd;
+    std::istringstream in(content.substr(0, headerEnd));
     std::string line;
     std::getline(in, line);
     if (line.substr(0, 3) != "ply") { *err = "not a PLY file"; return false; }
@@ -1851,16 +1878,7 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
     }
     if (fmt == BBE) { *err = "big-endian PLY is not supported"; return false; }
     // the body in one read; property types and roles resolved once per element (a 10 M-triangle scene reads ~60 M numbers)
-    std::vector<char> body;
-    {
-        std::streampos at = in.tellg();
-        in.seekg(0, std::ios::end);
-        std::streampos endPos = in.tellg();
-        in.seekg(at);
-        body.resize((size_t)(endPos - at));
-        in.read(body.data(), (std::streamsize)body.size());
-    }
-    const char *cur = body.data(), *const bodyEnd = body.data() + body.size();
+    const char *cur = content.data() + headerEnd, *const bodyEnd = content.data() + content.size();
     enum Ty { I8, U8, I16, U16, I32, U32, F32, F64 };
     auto typeOf = [](const std::string &t) {
         if (t == "char" || t == "int8") return I8;
@@ -2721,18 +2739,26 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         } else if (le.name == "infinite") {
             std::vector<V3> portal = ps.GetPoint3fArray("portal");
             std::string filename = ps.GetOneString("filename", "");
-            if (!portal.empty() && filename.empty()) Die(le.loc, "a portal with a uniform \"L\" (no \"filename\") is not supported by this build yet");
             SpectrumP L = ps.GetOneSpectrum("L", nullptr, SpectrumType::Illuminant);
             float scale = ps.GetOneFloat("scale", 1);
             float E_v = ps.GetOneFloat("illuminance", -1);
-            if (!filename.empty()) {
+            if (!filename.empty() || (L && !portal.empty())) {
                 // ImageInfiniteLight (lights.cpp:1567-1672, ctor :1001-1040)
-                if (L) Die(le.loc, "Can't specify both emission \"L\" and \"filename\" with ImageInfiniteLight");
-                if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
+                if (L && !filename.empty()) Die(le.loc, "Can't specify both emission \"L\" and \"filename\" with ImageInfiniteLight");
                 std::vector<float> rgb;
                 int w = 0, h = 0;
                 int fileNc = 0;
-                ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc);
+                if (filename.empty()) {
+                    // "L" with a portal (lights.cpp:1569-1590): a 1 x 1 image holding L converted to sRGB
+                    float xyz[3], c[3];
+                    SpectrumToXYZ(*L, xyz);
+                    Mul3(sd.sRGB()->RGBFromXYZ, xyz, c);   // RGBColorSpace::ToRGB
+                    rgb = {c[0], c[1], c[2]};
+                    w = h = 1; fileNc = 3;
+                } else {
+                    if (filename[0] != '/') filename = scene.baseDir + "/" + filename;
+                    ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc);
+                }
                 if (fileNc < 3) Die(le.loc, filename + ": image used for ImageInfiniteLight doesn't have R, G, B channels.");
                 for (float v : rgb) {
                     if (std::isinf(v)) Die(le.loc, filename + ": image has infinite pixel values and so is not suitable as a light.");
