@@ -63,6 +63,10 @@ struct wf_ctx {
     int *stackSpill = nullptr;   // [rows][MAX_GRID*BLOCK], rows from the trees' depths (wf_scene_upload)
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
+    hipStream_t stream2 = nullptr;   // the near-tie re-trace runs here, beside the routing pass and the next stage's sample generation
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool retracePending = false, deferJoin = false;
+    int overlapRetrace = 1;      // WF_OVERLAP_RETRACE=0: everything on one stream
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
@@ -1055,6 +1059,10 @@ int wf_ctx_create(int device, wf_ctx **out) {
     wf_ctx *c = new wf_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    if (const char *e = getenv("WF_OVERLAP_RETRACE")) c->overlapRetrace = atoi(e);
     c->traceLaunch = getenv("WF_TRACE_LAUNCH") != nullptr;
     *out = c;
     return 0;
@@ -1467,6 +1475,12 @@ static int SortQueue(wf_ctx *ctx, bool shadow, int cur) {
     }
     return 0;
 }
+static int JoinRetrace(wf_ctx *ctx) {
+    if (!ctx->retracePending) return 0;
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+    ctx->retracePending = false;
+    return 0;
+}
 int wf_intersect_closest(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     // counting on: the reference-order walk (its visit counts define the algorithmic bytes);
@@ -1483,6 +1497,17 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
                 HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
             }
             LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill, cursor, ctx->cursorChunk);
+            // The near-tie re-trace is a handful of long single walks (1-2 ms of latency on 128 workgroups): it runs on a second stream
+            // beside the routing pass (and, in the fused pass, the next sample-generation launch) — they touch disjoint rays and share
+            // only the queue counters, through atomics — and the main stream waits for it before anything consumes the queues.
+            const bool overlap = ctx->overlapRetrace && ctx->profile != 1 && !ctx->traceLaunch;   // (the full per-stage profile times every launch on the main stream)
+            if (overlap) {
+                HIPCHK(hipEventRecord(ctx->evFork, ctx->stream));
+                HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+                hipLaunchKernelGGL(k_closest_retrace, dim3(128), dim3(BLOCK), 0, ctx->stream2, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);   // (nothing that runs beside it walks a tree: the spill rows are its own)
+                HIPCHK(hipEventRecord(ctx->evJoin, ctx->stream2));
+                ctx->retracePending = true;
+            }
             {
                 Prof prof_(ctx, "Route hits");
                 const int g = std::min(MAX_GRID, std::max(1, (ctx->maxQueueSize + RBLOCK - 1) / RBLOCK));
@@ -1491,6 +1516,10 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
             }
         } else
         LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        if (ctx->retracePending) {
+            if (ctx->deferJoin) return 0;   // the fused pass joins after its sample-generation launch (JoinRetrace)
+            if (int e = JoinRetrace(ctx)) return e;
+        } else
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
@@ -1610,8 +1639,13 @@ int wf_render_pass(wf_ctx *ctx, int y0, int sample_index) {
     if ((e = wf_gen_camera_rays(ctx, y0, sample_index))) return e;
     for (int depth = 0; true; ++depth) {
         if ((e = wf_reset_stage_queues(ctx, depth))) return e;
+        // (GenerateRaySamples does not depend on the intersections: it is issued after the closest-hit launch so that it runs beside
+        // the re-trace; the per-stage entry points keep the reference's order)
+        ctx->deferJoin = ctx->overlapRetrace && ctx->fastOk && ctx->splitRoute && !ctx->countTraversal && !ctx->svHost.haveMix;
+        if ((e = wf_intersect_closest(ctx, depth))) { ctx->deferJoin = false; return e; }
+        ctx->deferJoin = false;
         if ((e = wf_gen_ray_samples(ctx, depth, sample_index))) return e;
-        if ((e = wf_intersect_closest(ctx, depth))) return e;
+        if ((e = JoinRetrace(ctx))) return e;
         if ((e = wf_medium_sample(ctx, depth))) return e;
         if ((e = wf_handle_escaped(ctx, depth))) return e;
         if ((e = wf_handle_emissive(ctx, depth))) return e;

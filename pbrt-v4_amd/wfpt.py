@@ -282,7 +282,7 @@ class Scene:
 
     def enable_profile(self, on=True):
         _, hip = libs()
-        _check(hip.wf_profile_enable(self.ctx, 1 if on else 0), "wf_profile_enable")
+        _check(hip.wf_profile_enable(self.ctx, int(on)), "wf_profile_enable")   # 0 off, 1 every launch, 2 the Intersect* launches only
 
     def profile_report(self):
         _, hip = libs()
