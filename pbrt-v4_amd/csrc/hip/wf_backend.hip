@@ -1076,6 +1076,9 @@ int wf_ctx_destroy(wf_ctx *ctx) {
     for (auto &e : ctx->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : ctx->eventPool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
     delete ctx;
     return 0;
 }

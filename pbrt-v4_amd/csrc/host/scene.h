@@ -211,6 +211,10 @@ struct HostImage {
 void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img);
 float RoundToHalf(float f);
 
+// Shape "loopsubdiv" (loopsubdiv.cpp): the limit-surface triangle mesh of a control mesh, in object space
+void LoopSubdivide(int nLevels, const std::vector<int> &vertexIndices, const std::vector<V3> &P, std::vector<int> *outIndices,
+                   std::vector<V3> *outP, std::vector<V3> *outN);
+
 // image output (image_io.cpp)
 bool WritePFM(const std::string &path, const float *rgb, int w, int h);
 bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);

@@ -1794,6 +1794,17 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         for (int vi : m->indices) if (vi < 0 || vi >= (int)m->P.size()) { fprintf(stderr, "Error: %s: trianglemesh has out of-bounds vertex index %d\n", sh.loc.c_str(), vi); return false; }
         if (!ps.GetTuple3Array("S", "vector3").empty()) fprintf(stderr, "Warning: %s: \"S\" tangents are ignored by this build\n", sh.loc.c_str());
         return true;
+    } else if (sh.name == "loopsubdiv") {
+        // shapes.cpp:1473-1490
+        const int nLevels = ps.GetOneInt("levels", 3);
+        std::vector<int> vertexIndices = ps.GetIntArray("indices");
+        if (vertexIndices.empty()) Die(sh.loc, "Vertex indices \"indices\" not provided for LoopSubdiv shape.");
+        std::vector<V3> P = ps.GetPoint3fArray("P");
+        if (P.empty()) Die(sh.loc, "Vertex positions \"P\" not provided for LoopSubdiv shape.");
+        for (int vi : vertexIndices) if (vi < 0 || vi >= (int)P.size()) Die(sh.loc, "loopsubdiv has out of-bounds vertex index " + std::to_string(vi));
+        ps.GetOneString("scheme", "loop");
+        LoopSubdivide(nLevels, vertexIndices, P, &m->indices, &m->P, &m->N);
+        return true;
     } else if (sh.name == "plymesh") {
         std::string fn = ps.GetOneString("filename", "");
         if (!fn.empty() && fn[0] != '/') fn = baseDir + "/" + fn;
@@ -1820,7 +1831,7 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         if (!ps.GetOneString("emissionfilename", "").empty()) Die(sh.loc, "bilinearmesh \"emissionfilename\" is not supported by this build");
         return true;
     }
-    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh, bilinearmesh, curve, sphere, disk, cylinder)");
+    Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh, loopsubdiv, bilinearmesh, curve, sphere, disk, cylinder)");
 }
 
 // Minimal PLY reader (ascii + binary_little_endian; vertex x,y,z[,nx,ny,nz][,u,v|s,t], face vertex_indices
