@@ -60,11 +60,17 @@ inline Mat4 operator*(const Mat4 &a, const Mat4 &b) {
         }
     return r;
 }
+// SquareMatrix<3> product: like the 4x4 one above, what the reference build evaluates for `m1 * m2` is the generic FMA accumulation
+// (util/math.h:1497-1508), not the InnerProduct specialisation — pinned by the whitebalance golden (cornell64_wb), whose sensor
+// matrix is a product of three 3x3 matrices
 inline Mat3 operator*(const Mat3 &a, const Mat3 &b) {
     Mat3 r;
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            r.m[i][j] = InnerProduct(a.m[i][0], b.m[0][j], a.m[i][1], b.m[1][j], a.m[i][2], b.m[2][j]);
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0;
+            for (int k = 0; k < 3; ++k) acc = fma(a.m[i][k], b.m[k][j], acc);
+            r.m[i][j] = acc;
+        }
     return r;
 }
 inline float Determinant(const Mat3 &a) {

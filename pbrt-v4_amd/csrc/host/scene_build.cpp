@@ -870,7 +870,32 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
     const SpectralData &sd = SpectralData::Get();
     const ColorSpace *cs = scene.filmColorSpace;
     Mat3 XYZFromSensorRGB = Mat3::Identity();
-    if (whiteBalanceTemp != 0) Die(scene.film.loc, "whitebalance is not supported by this build");
+    if (whiteBalanceTemp != 0) {
+        // PixelSensor ctor for the XYZ matching functions (film.h:78-90): XYZFromSensorRGB = WhiteBalance(xy of the D illuminant of
+        // that temperature, the output colour space's white), the Bradford transform of util/color.h:541-560
+        SpectrumP dIllum = DaylightD(whiteBalanceTemp);
+        float xyz[3];
+        SpectrumToXYZ(*dIllum, xyz);
+        const float srcWhite[2] = {xyz[0] / (xyz[0] + xyz[1] + xyz[2]), xyz[1] / (xyz[0] + xyz[1] + xyz[2])};
+        const float dstWhite[2] = {cs->w[0], cs->w[1]};
+        auto FromxyY = [](const float xy[2], float out[3]) {
+            const float Y = 1;
+            if (xy[1] == 0) { out[0] = out[1] = out[2] = 0; return; }
+            out[0] = xy[0] * Y / xy[1]; out[1] = Y; out[2] = (1 - xy[0] - xy[1]) * Y / xy[1];
+        };
+        Mat3 LMSFromXYZ, XYZFromLMS;
+        const double a[9] = {0.8951, 0.2664, -0.1614, -0.7502, 1.7135, 0.0367, 0.0389, -0.0685, 1.0296};
+        const double b[9] = {0.986993, -0.147054, 0.159963, 0.432305, 0.51836, 0.0492912, -0.00852866, 0.0400428, 0.968487};
+        for (int i = 0; i < 9; ++i) { LMSFromXYZ.m[i / 3][i % 3] = (float)a[i]; XYZFromLMS.m[i / 3][i % 3] = (float)b[i]; }
+        float srcXYZ[3], dstXYZ[3], srcLMS[3], dstLMS[3];
+        FromxyY(srcWhite, srcXYZ);
+        FromxyY(dstWhite, dstXYZ);
+        Mul3(LMSFromXYZ, srcXYZ, srcLMS);
+        Mul3(LMSFromXYZ, dstXYZ, dstLMS);
+        Mat3 LMScorrect{};
+        for (int i = 0; i < 3; ++i) LMScorrect.m[i][i] = dstLMS[i] / srcLMS[i];
+        XYZFromSensorRGB = XYZFromLMS * LMScorrect * LMSFromXYZ;
+    }
     F.rbar_offset = T->pool.AddDense(*sd.X);
     F.gbar_offset = T->pool.AddDense(*sd.Y);
     F.bbar_offset = T->pool.AddDense(*sd.Z);
