@@ -92,6 +92,8 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.haltonPrimes = d.halton_primes; sv.haltonPermOffsets = d.halton_perm_offsets; sv.haltonPerms = d.halton_perms;
     sv.haveMix = 0;
     sv.haveSubsurface = 0;
+    sv.haveQuadricAlpha = 0;
+    for (int i = 0; i < d.n_quadrics; ++i) if (d.meshes[d.quadrics[i].mesh].alpha_tex >= 0) sv.haveQuadricAlpha = 1;
     sv.haveCurves = 0;
     for (int i = 0; i < d.n_quadrics; ++i) if (d.quadrics[i].type == WF_QUADRIC_CURVE) sv.haveCurves = 1;
     for (int i = 0; i < d.n_materials; ++i) {

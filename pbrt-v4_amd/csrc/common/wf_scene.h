@@ -65,6 +65,7 @@ struct SceneView {
     const wf_instance *instances;
     const wf_instance_def *instanceDefs;
     int nInstances;
+    int haveQuadricAlpha;   // some sphere / disk / cylinder / patch has an alpha texture (QuadricAlphaIntersectP)
     int haveCurves;         // some primitive is a Curve segment: its interaction is rebuilt from the ray (HitInteraction)
     int haveSubsurface;     // some material is a SubsurfaceMaterial: K12 runs, and every depth draws 3 more sample dimensions
     int haveMix;            // some material is a MixMaterial: hits on it store their resolved material id in ws.mixMat

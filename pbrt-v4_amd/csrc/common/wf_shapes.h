@@ -670,6 +670,23 @@ WF_HD bool QuadricBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax, 
     if (s.type == WF_QUADRIC_CYLINDER) return CylinderBasicIntersect(s, ro, rd, tMax, out);
     return SphereBasicIntersect(s, ro, rd, tMax, out);
 }
+// GeometricPrimitive::Intersect for a quadric / patch with an alpha texture (cpu/primitive.cpp:50-78), defined below
+WF_NI bool QuadricAlphaIntersectP(const SceneView *svp, int prim, float ox, float oy, float oz, float dx, float dy, float dz, float tMax,
+                                  float *tHit, float *px, float *py, float *pz);
+// the primitive `prim` (>= nTriangles) against the ray: the shape test, then the alpha test of its GeometricPrimitive when it has one
+// (RARE = false: a traversal kernel for scenes without curves and without alpha on quadrics — the two out-of-line callees stay out of its budget)
+template <bool RARE = true>
+WF_HD bool QuadricIntersect(const SceneView &sv, int prim, V3 o, V3 d, float tMax, QuadricHit *qh) {
+    constexpr bool CURVES = RARE;
+    const wf_quadric &s = sv.quadrics[prim - sv.nTriangles];
+    if (RARE && sv.haveQuadricAlpha && sv.meshes[s.mesh].alpha_tex >= 0) {
+        float t, x, y, z;
+        if (!QuadricAlphaIntersectP(sv.self, prim, o.x, o.y, o.z, d.x, d.y, d.z, tMax, &t, &x, &y, &z)) return false;
+        qh->tHit = t; qh->pObj = V3{x, y, z}; qh->phi = 0;
+        return true;
+    }
+    return QuadricBasicIntersect<CURVES>(s, o, d, tMax, qh);
+}
 WF_HD float QuadricArea(const wf_quadric &s) {
     if (s.type == WF_QUADRIC_DISK) return s.phi_max * 0.5f * (Sqr(s.radius) - Sqr(s.inner_radius));  // shapes.h:407
     if (s.type == WF_QUADRIC_CYLINDER) return (s.z_max - s.z_min) * s.radius * s.phi_max;             // shapes.h:559
@@ -746,7 +763,7 @@ WF_HD bool BVHIntersectClosestDef(const SceneView &sv, int root, V3 o, V3 d, flo
                     if (tri >= sv.nTriangles) {
                         // a quadric or bilinear patch of the definition, in the definition's space
                         QuadricHit qh;
-                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) {
+                        if (QuadricIntersect(sv, tri, o, d, tMax, &qh)) {
                             out->prim = tri;
                             out->h.t = qh.tHit; out->h.b0 = qh.pObj.x; out->h.b1 = qh.pObj.y; out->h.b2 = qh.pObj.z;
                             tMax = qh.tHit;
@@ -802,7 +819,7 @@ WF_HD bool BVHIntersectAnyDef(const SceneView &sv, int root, V3 o, V3 d, float t
                     ++*nt;
                     if (tri >= sv.nTriangles) {
                         QuadricHit qh;
-                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) found = true;
+                        if (QuadricIntersect(sv, tri, o, d, tMax, &qh)) found = true;
                         continue;
                     }
                     V3 p0, p1, p2;
@@ -870,7 +887,7 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
                     if (tri >= sv.nTriangles) {
                         // a sphere: the hit record carries pObj in place of the barycentrics
                         QuadricHit qh;
-                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) {
+                        if (QuadricIntersect(sv, tri, o, d, tMax, &qh)) {
                             out->prim = tri;
                             out->inst = -1;
                             out->h.t = qh.tHit; out->h.b0 = qh.pObj.x; out->h.b1 = qh.pObj.y; out->h.b2 = qh.pObj.z;
@@ -934,7 +951,7 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
                     ++nt;
                     if (tri >= sv.nTriangles) {
                         QuadricHit qh;
-                        if (QuadricBasicIntersect(sv.quadrics[tri - sv.nTriangles], o, d, tMax, &qh)) found = true;
+                        if (QuadricIntersect(sv, tri, o, d, tMax, &qh)) found = true;
                         continue;
                     }
                     V3 p0, p1, p2;
@@ -1551,6 +1568,43 @@ WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, flo
         InstanceInteractionP(sv.instances + inst, &tmp);
         *si = tmp;
     }
+}
+
+// GeometricPrimitive::Intersect (cpu/primitive.cpp:50-78) for a sphere / disk / cylinder / bilinear patch with an alpha texture: a hit
+// that fails the (stochastic) alpha test is skipped by re-intersecting the same shape with the ray respawned behind it; the
+// parametric distances add up innermost first, as the recursion returns.  (A triangle cannot be hit twice: AlphaTestPasses.)
+WF_NI bool QuadricAlphaIntersectP(const SceneView *svp, int prim, float ox, float oy, float oz, float dx, float dy, float dz, float tMax,
+                                  float *tHit, float *px, float *py, float *pz) {
+    const SceneView &sv = *svp;
+    const wf_quadric &s = sv.quadrics[prim - sv.nTriangles];
+    const int alphaTex = sv.meshes[s.mesh].alpha_tex;
+    V3 o{ox, oy, oz};
+    const V3 d{dx, dy, dz};
+    constexpr int MAXN = 16;
+    float ts[MAXN];
+    int n = 0;
+    QuadricHit h;
+    while (true) {
+        if (!QuadricBasicIntersect<false>(s, o, d, tMax, &h)) return false;
+        SurfIntr si;
+        SphereInteraction(sv, prim, h.pObj, &si);
+        TexCtx tc;
+        tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
+        const float a = EvalFloatTexture(sv, alphaTex, tc);
+        bool accept = true;
+        if (a < 1) {
+            const float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(o, d));
+            if (u > a) accept = false;
+        }
+        if (accept || n == MAXN - 1) break;
+        ts[n++] = h.tHit;
+        o = OffsetRayOrigin(si.pi, si.n, d);   // si->intr.SpawnRay(r.d)
+        tMax = tMax - h.tHit;
+    }
+    float t = h.tHit;
+    for (int i = n - 1; i >= 0; --i) t += ts[i];   // siNext->tHit += si->tHit, innermost first
+    *tHit = t; *px = h.pObj.x; *py = h.pObj.y; *pz = h.pObj.z;
+    return true;
 }
 
 // Sphere::Sample(Point2f u), shapes.cpp:38-58

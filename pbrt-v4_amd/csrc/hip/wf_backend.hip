@@ -68,7 +68,7 @@ struct wf_ctx {
     bool retracePending = false, deferJoin = false;
     int overlapRetrace = 1;      // WF_OVERLAP_RETRACE=0: everything on one stream
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
-    int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves, 3 anything (see GeneralPrims)
+    int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves and alpha on quadrics, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
     int persistentGridShadow = 1024;
     static bool splitRouteWanted() { return !getenv("WF_SPLIT_ROUTE") || atoi(getenv("WF_SPLIT_ROUTE")) != 0; }
@@ -324,7 +324,7 @@ struct GeneralPrims {
     }
     __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const {
         if constexpr (GEN == 1) return false;
-        else return QuadricBasicIntersect<GEN == 3>(sv.quadrics[prim - sv.nTriangles], w.o, dir(), tMax, qh);
+        else return QuadricIntersect<GEN == 3>(sv, prim, w.o, dir(), tMax, qh);
     }
 };
 template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
@@ -664,7 +664,7 @@ struct TrPrims {  // the same callbacks for the transmittance walk, whose ray is
     const SceneView &sv;
     V3 o, d;
     __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
-    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricBasicIntersect(sv.quadrics[prim - sv.nTriangles], o, d, tMax, qh); }
+    __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricIntersect(sv, prim, o, d, tMax, qh); }
 };
 template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
@@ -1173,6 +1173,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.haveSubsurface = 0;
     ctx->rareLights = false;
     for (int i = 0; i < d->n_lights; ++i) if (d->lights[i].type == WF_LIGHT_PORTAL_INFINITE) ctx->rareLights = true;
+    sv.haveQuadricAlpha = 0;
+    for (int i = 0; i < d->n_quadrics; ++i) if (d->meshes[d->quadrics[i].mesh].alpha_tex >= 0) sv.haveQuadricAlpha = 1;
     sv.haveCurves = 0;
     for (int i = 0; i < d->n_quadrics; ++i) if (d->quadrics[i].type == WF_QUADRIC_CURVE) sv.haveCurves = 1;
     for (int i = 0; i < d->n_materials; ++i) {
@@ -1225,7 +1227,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         std::vector<LeafTri> lt;
         {
             ctx->genMode = 0;
-            if (d->n_quadrics > 0) ctx->genMode = sv.haveCurves ? 3 : 2;
+            if (d->n_quadrics > 0) ctx->genMode = (sv.haveCurves || sv.haveQuadricAlpha) ? 3 : 2;
             for (int i = 0; i < d->n_meshes && ctx->genMode < 2; ++i)
                 if (d->meshes[i].alpha_tex >= 0) {
                     const int tt = d->textures[d->meshes[i].alpha_tex].type;

@@ -15,8 +15,15 @@ using namespace wf;
 
 constexpr int MBLOCK = 256;
 
+// minimum waves per SIMD (the register budget: 2 -> 256 VGPRs, 3 -> 168).  Measured per material on the spec scene, 2 vs 3 waves: diffuse
+// 24.1 -> 22.7 ms per 16 spp, conductor 6.27 -> 6.40, coated diffuse 17.4 -> 20.2 (its stochastic walks spill): only the diffuse kernel
+// takes the third wave.
 #ifndef WF_MAT_WAVES
+#if WF_MAT_INSTANCE == 1
+#define WF_MAT_WAVES 3
+#else
 #define WF_MAT_WAVES 2
+#endif
 #endif
 template <int MAT, int TEXCTX>
 __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const SceneView sv, WorkState ws, int cur) {

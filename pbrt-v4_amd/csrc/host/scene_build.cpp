@@ -2088,7 +2088,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
         if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
         else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
-        if (mesh.alpha_tex >= 0 && mesh.ntris == 0) Die(sh.loc, "alpha textures on spheres, curves and bilinear patches are not supported by this build yet");
+        if (mesh.alpha_tex >= 0 && sh.name == "curve") Die(sh.loc, "alpha textures on curves are not supported by this build yet");
         mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
         mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
         if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;
@@ -2300,7 +2300,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             // BilinearPatchMesh + BilinearPatch::CreatePatches (util/mesh.cpp:183-230, shapes.cpp:1040-1060): after the shape's triangles,
             // in render space, sharing the shape's wf_mesh (material, media, orientation)
             if (sh.lightIndex >= 0 && mesh.ntris > 0) Die(sh.loc, "an emissive plymesh with both triangle and quad faces is not supported by this build yet");
-            if (!sh.params.GetTexture("alpha").empty() || sh.params.GetOneFloat("alpha", 1.f) < 1.f) Die(sh.loc, "alpha on bilinear patches is not supported by this build yet");
+            if (mesh.ntris > 0 && (!sh.params.GetTexture("alpha").empty() || sh.params.GetOneFloat("alpha", 1.f) < 1.f))
+                Die(sh.loc, "alpha on a plymesh with both triangle and quad faces is not supported by this build yet");
             if (mesh.ntris == 0) mesh.first_tri = -1;  // set to the first patch's primitive id once the triangle count is known
             const size_t v0 = (size_t)mesh.first_vertex;
             auto P3 = [&](int vi) { return V3{T->P[3 * (v0 + vi)], T->P[3 * (v0 + vi) + 1], T->P[3 * (v0 + vi) + 2]}; };

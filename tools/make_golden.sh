@@ -69,6 +69,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/portal_un
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/loopsubdiv_ref.pfm $G/loopsubdiv.pbrt
 # film "whitebalance" + "iso" (the cornell64 scene with a 4200 K sensor illuminant): sed of cornell64.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_wb_ref.pfm $G/cornell64_wb.pbrt
+# alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/instances_ref.pfm $G/instances.pbrt
 # the reference's other BVH builder: blobs_small with `splitmethod "hlbvh"` (cpu/aggregates.cpp:389-503, 626-722)
