@@ -61,7 +61,7 @@ inline Mat4 operator*(const Mat4 &a, const Mat4 &b) {
     return r;
 }
 // SquareMatrix<3> product: like the 4x4 one above, what the reference build evaluates for `m1 * m2` is the generic FMA accumulation
-// (util/math.h:1497-1508), not the InnerProduct specialisation — pinned by the whitebalance golden (cornell64_wb), whose sensor
+// (util/math.h:1497-1508), not the InnerProduct specialisation — pinned by the whitebalance golden (film_whitebalance), whose sensor
 // matrix is a product of three 3x3 matrices
 inline Mat3 operator*(const Mat3 &a, const Mat3 &b) {
     Mat3 r;

@@ -67,8 +67,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/portal_li
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/portal_uniform_ref.pfm $G/portal_uniform.pbrt
 # Shape "loopsubdiv" (closed, open and valence-3 control meshes; limit positions and normals): hand-written
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/loopsubdiv_ref.pfm $G/loopsubdiv.pbrt
-# film "whitebalance" + "iso" (the cornell64 scene with a 4200 K sensor illuminant): sed of cornell64.pbrt
-oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/cornell64_wb_ref.pfm $G/cornell64_wb.pbrt
+# film "whitebalance" + "iso" (the cornell64 scene with a 4200 K sensor illuminant): film_whitebalance.pbrt is a sed of cornell64.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_whitebalance_ref.pfm $G/film_whitebalance.pbrt
 # alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # object instancing (two definitions, five instances incl. a mirroring one): hand-written tests/golden/instances.pbrt
