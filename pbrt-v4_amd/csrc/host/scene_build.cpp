@@ -33,8 +33,9 @@ namespace wf {
 
 // Image::Read with the default encoding (8-bit PNG: sRGB) for the light sources: the pixels as Image::GetChannel returns
 // them, grey replicated to three channels; *nc is the file's channel count (1 Y, 3 R G B, 4 R G B A)
-static void ReadLightImage(const std::string &filename, const std::string &loc, std::vector<float> *rgb, int *w, int *h, int *nc) {
-    HostImage img;
+static void ReadLightImage(const std::string &filename, const std::string &loc, std::vector<float> *rgb, int *w, int *h, int *nc, HostImage *raw = nullptr) {
+    HostImage localImg;
+    HostImage &img = raw ? *raw : localImg;
     try { ReadImage(filename, ColorEnc(), &img); } catch (const SceneError &e) { Die(loc, std::string(e.what()).substr(7)); }
     *w = img.w; *h = img.h; *nc = img.nc;
     rgb->resize((size_t)img.w * img.h * 3);
@@ -2718,7 +2719,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             std::vector<float> rgb;
             int w = 0, h = 0;
             int fileNc = 0;
-            ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc);
+            HostImage rawImg;
+            ReadLightImage(filename, le.loc, &rgb, &w, &h, &fileNc, &rawImg);
             if (w != h) Die(le.loc, filename + ": image resolution is non-square. It's unlikely this is an equal-area environment map.");
             const bool grey = fileNc == 1;
             wf_tex_image im{};
@@ -2726,7 +2728,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             im.level_offset[0] = (int)T->tableData.size();
             float sumY = 0;
             for (size_t i = 0; i < (size_t)w * h; ++i) {
-                float v = grey ? rgb[3 * i] : (rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3;  // ImageChannelValues::Average
+                // R G B files: a "Y" image of the file's own pixel format holds the channel average (lights.cpp:648-657), so an 8-bit or
+                // half file's average is re-quantised by SetChannel
+                float v = grey ? rgb[3 * i] : rawImg.Quantize((0.f + rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3);
                 if (!std::isfinite(v)) Die(le.loc, filename + ": image has infinite or not-a-number pixel values and so is not suitable as a light.");
                 T->tableData.push_back(v);
                 sumY += v;
