@@ -1913,7 +1913,6 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
             elems.back().props.push_back(p);
         } else if (kw == "end_header") break;
     }
-    if (fmt == BBE) { *err = "big-endian PLY is not supported"; return false; }
     // the body in one read; property types and roles resolved once per element (a 10 M-triangle scene reads ~60 M numbers)
     const char *cur = content.data() + headerEnd, *const bodyEnd = content.data() + content.size();
     enum Ty { I8, U8, I16, U16, I32, U32, F32, F64 };
@@ -1942,6 +1941,11 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
         if (cur + size[t] > bodyEnd) { truncated = true; return 0; }
         const char *b = cur;
         cur += size[t];
+        char swapped[8];
+        if (fmt == BBE && size[t] > 1) {   // binary_big_endian: reverse the bytes of every value
+            for (int k = 0; k < size[t]; ++k) swapped[k] = b[size[t] - 1 - k];
+            b = swapped;
+        }
         switch (t) {
         case I8: return *(const int8_t *)b;
         case U8: return *(const uint8_t *)b;

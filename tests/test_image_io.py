@@ -205,3 +205,34 @@ def test_scene_with_exr_environment_map_renders_like_the_pfm_one(wfpt, tmp_path)
     run_wf_cpu(str(tmp_path / "envmap_exr.pbrt"), out, 4)
     ref = read_pfm(os.path.join(GOLDEN, "envmap_ref.pfm"))
     assert (read_pfm(out).view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_ply_ascii_little_big_endian_and_gzip_load_the_same_mesh(wfpt, tmp_path):
+    """One mesh written as ASCII, binary little-endian, binary big-endian and gzipped PLY: the CPU checker's renders of the four
+    scenes are bit-identical (the readers feed the same vertex and index arrays to the scene tables)."""
+    import gzip
+    from conftest import read_pfm, run_wf_cpu
+    rng = np.random.default_rng(5)
+    n = 6
+    P = (rng.random((n * n, 3)).astype(np.float32) * 0.1 + np.stack(np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n)), -1).reshape(-1, 2).astype(np.float32) @ np.array([[1, 0, 0], [0, 1, 0]], np.float32)).astype(np.float32)
+    F = [(r * n + c, r * n + c + 1, (r + 1) * n + c) for r in range(n - 1) for c in range(n - 1)] + [(r * n + c + 1, (r + 1) * n + c + 1, (r + 1) * n + c) for r in range(n - 1) for c in range(n - 1)]
+    hdr = "ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+    def binary(end):
+        return (hdr % ("binary_%s_endian" % ("little" if end == "<" else "big"), len(P), len(F))).encode() + \
+            b"".join(struct.pack(end + "3f", *p) for p in P) + b"".join(struct.pack(end + "B3i", 3, *f) for f in F)
+    files = {"a.ply": (hdr % ("ascii", len(P), len(F))).encode() + "".join("%.9g %.9g %.9g\n" % tuple(p) for p in P).encode() + "".join("3 %d %d %d\n" % f for f in F).encode(),
+             "l.ply": binary("<"), "b.ply": binary(">"), "g.ply.gz": gzip.compress(binary("<"))}
+    imgs = []
+    for name, data in files.items():
+        open(tmp_path / name, "wb").write(data)
+        scene = ('LookAt 0 0 4  0 0 0  0 1 0\nCamera "perspective" "float fov" 40\nSampler "independent" "integer pixelsamples" 2\n'
+                 'Film "rgb" "integer xresolution" 32 "integer yresolution" 32 "string filename" "o.pfm"\nWorldBegin\n'
+                 'LightSource "distant" "point3 from" [1 2 4] "point3 to" [0 0 0] "rgb L" [3 3 3]\n'
+                 'Material "diffuse" "rgb reflectance" [0.6 0.5 0.4]\nShape "plymesh" "string filename" "%s"\n' % name)
+        open(tmp_path / (name + ".pbrt"), "w").write(scene)
+        out = str(tmp_path / (name + ".pfm"))
+        run_wf_cpu(str(tmp_path / (name + ".pbrt")), out, 2)
+        imgs.append(read_pfm(out))
+    assert imgs[0].max() > 0
+    for im in imgs[1:]:
+        assert (im.view(np.uint32) == imgs[0].view(np.uint32)).all()
