@@ -626,7 +626,8 @@ int wf_film_copy_from_device(wf_ctx *ctx, const void *src_device);
 int wf_stats_download(wf_ctx *ctx, wf_render_stats *out);
 int wf_profile_report(wf_ctx *ctx, wf_kernel_profile_entry *entries, int max_entries, int *n_out);
 /* per-launch hipEvent pairs on the context's stream (gpu/util.cpp:136-209): 0 off, 1 every launch,
-   2 only the traversal kernels ("Intersect closest" / "Intersect shadow") */
+   2 only the launches of the traversal stages ("Intersect closest", "Route hits", "Intersect closest: near-tie re-trace",
+   "Intersect shadow") */
 int wf_profile_enable(wf_ctx *ctx, int enabled);
 /* sum of the recorded durations of the named kernel since the last wf_profile_report */
 int wf_kernel_time_ms(wf_ctx *ctx, const char *name, double *total_ms, int *launches);
@@ -664,6 +665,11 @@ typedef struct wf_traversal_counters {
 } wf_traversal_counters;
 int wf_counters_enable(wf_ctx *ctx, int enabled);
 int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out);
+/* which rare paths of the production traversal ran since the last reset (the parity tests assert that a big-tree scene takes them):
+   out[0] node-stack entries that left the LDS ring for the lane's HBM column, out[1] != 0: a push ran past the HBM column (the
+   entry was dropped; wf_sync returns an error as well), out[2] near-tie rays re-walked in reference order inside the walk kernel,
+   out[3] != 0: a launch dealt its rays through the shared cursor.  reset != 0 zeroes the words after reading. */
+int wf_debug_counters(wf_ctx *ctx, uint64_t out[4], int reset);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,8 @@ constexpr int STACK_LDS = 24;   // LDS stack entries per lane: 24 x 4 B x 256 la
 constexpr int STACK_MAX = 64;   // nodesToVisit[64], cpu/aggregates.cpp:538
 constexpr int MAX_GRID = 256 * 8;  // 256 CUs x up to 8 resident 256-thread workgroups
 
+struct SpillArea { int *base; int rows; int *dbg; };   // the context's stackSpill rows + the debug words (kernel argument of the production traversal)
+
 struct wf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -61,6 +63,9 @@ struct wf_ctx {
     WorkState ws{};
     int maxQueueSize = 0;
     int *stackSpill = nullptr;   // [rows][MAX_GRID*BLOCK], rows from the trees' depths (wf_scene_upload)
+    int spillRows = 0;
+    int *dbgWords = nullptr;     // [4] spilled stack entries, stack-overflow flag, inline near-tie re-traces, cursor path taken (wf_debug_counters)
+    SpillArea spillArea() const { return SpillArea{stackSpill, spillRows, dbgWords}; }
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
     hipStream_t stream2 = nullptr;   // the near-tie re-trace runs here, beside the routing pass and the next stage's sample generation
@@ -227,19 +232,38 @@ __shared__ U4 g_top[QNODE_U4 * TOP_NODES];
 // into a pointer select (which turns every pop into a flat load)
 __device__ __attribute__((noinline)) int SpillRead(const int *p) { return *p; }
 __device__ __attribute__((noinline)) void SpillWrite(int *p, int v) { *p = v; }
+// The node stack of the production walk: a ring of TSTACK entries per lane in LDS holding the NEWEST entries; when it is full the
+// OLDEST entry moves to the lane's HBM column (round 3).  Until round 2 the entries above TSTACK went to HBM instead: a walk deep in
+// a two-level tree (20-30 entries) then paid an HBM store and an HBM load on nearly every push / pop — rocprofv3 WRITE_SIZE showed
+// 230 B per closest-hit ray and 394 B per shadow ray for kernels whose results are 28 B and 16 B.  With the bottom of the stack
+// spilled, an entry crosses the LDS / HBM boundary at most once in each direction, and the entries that do are the ones pushed near
+// the root, which are popped last.
+// dbg (null = off): [0] += entries spilled, [1] |= 1 when a push would have run past the lane's spill rows (the entry is dropped and
+// wf_sync reports the overflow: ADVICE r2, "the traversal spill stack can overflow on unbalanced trees").
 struct LdsStackT {
     int *spill;   // &stackSpill[global thread], stride = total threads
     int spillStride;
-    int n;
+    int n;        // entries on the stack
+    int lo;       // entries [0, lo) are in the HBM column, [lo, n) in the LDS ring (n - lo <= TSTACK)
+    int rows;     // capacity of the HBM column
+    int *dbg;
+    static constexpr int MASK = TSTACK - 1;
+    static_assert((TSTACK & (TSTACK - 1)) == 0, "WF_TSTACK must be a power of two (ring indexing)");
+    __device__ void reset() { n = 0; lo = 0; }
     __device__ void push(int v) {
-        if (__builtin_expect(n < TSTACK, 1)) g_tstack[n * TBLOCK + threadIdx.x] = v;
-        else SpillWrite(&spill[(size_t)(n - TSTACK) * spillStride], v);
+        if (__builtin_expect(n - lo == TSTACK, 0)) {
+            if (__builtin_expect(lo >= rows, 0)) { if (dbg) atomicOr(dbg + 1, 1); return; }
+            SpillWrite(&spill[(size_t)lo * spillStride], g_tstack[(lo & MASK) * TBLOCK + threadIdx.x]);
+            if (dbg) atomicAdd(dbg, 1);
+            ++lo;
+        }
+        g_tstack[(n & MASK) * TBLOCK + threadIdx.x] = v;
         ++n;
     }
     __device__ int pop() {
         --n;
-        int v = g_tstack[(n < TSTACK ? n : 0) * TBLOCK + threadIdx.x];  // always a ds_read
-        if (__builtin_expect(n >= TSTACK, 0)) v = SpillRead(&spill[(size_t)(n - TSTACK) * spillStride]);
+        int v = g_tstack[(n & MASK) * TBLOCK + threadIdx.x];  // always a ds_read
+        if (__builtin_expect(n < lo, 0)) { lo = n; v = SpillRead(&spill[(size_t)n * spillStride]); }
         return v;
     }
     __device__ bool empty() const { return n == 0; }
@@ -327,6 +351,95 @@ struct GeneralPrims {
         else return QuadricIntersect<GEN == 3>(sv, prim, w.o, dir(), tMax, qh);
     }
 };
+// ---- near-tie resolution inside the production walk (round 3) -------------------------------------------------------------------
+// A ray the production walk marked as a near-tie (wf_traverse.h) is walked once more in the REFERENCE's order — BVHAggregate::Intersect
+// over the reference-layout 32-byte nodes (cpu/aggregates.cpp:529-579), the exact Bounds3::IntersectP, the reference's accept rule —
+// starting from tMax = t* + twice the band instead of infinity (see k_closest_retrace).  Until round 2 this was a separate launch whose
+// duration was the latency of its longest single walk on a 388-VGPR kernel (1.5-3 ms per depth on the 10 M-triangle scene: a tenth
+// of the closest-hit stage); now the lane does it itself at the end of its batch, in this out-of-line function — triangles, simple
+// alpha cut-outs and object instances only (the GEN <= 1 kernels; scenes with quadrics / curves / texture-graph alpha keep the second
+// launch), so that it fits the walk's own register budget.  Cost: the few waves that hold a marked lane run one short walk at 1/64
+// lane utilisation (a marked ray's bound is tight: it descends to its hit and little else).
+struct RefHit { int prim, inst; float t, b0, b1, b2; uint32_t route; };
+template <int GEN, bool TOP>
+__device__ inline __attribute__((always_inline)) bool RefOrderTree(const SceneView *svp, int root, V3 o, V3 d, float *tMaxIO, LdsStackT &st, RefHit *out) {
+    const SceneView &sv = *svp;
+    float tMax = *tMaxIO;
+    bool hitAny = false;
+    const int base = st.n;
+    const V3 invDir{1 / d.x, 1 / d.y, 1 / d.z};
+    const int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
+    const RayShear sh = MakeRayShear(d);
+    int cur = root;
+    while (true) {
+        const wf_bvh_node *node = &sv.bvhNodes[cur];
+        if (BoxIntersectP(node->bmin, node->bmax, o, tMax, invDir, negMask)) {
+            if (node->nprims > 0) {
+                for (int i = 0; i < node->nprims; ++i) {
+                    const int tri = sv.bvhPrims[node->offset + i];
+                    if constexpr (TOP) {
+                        if (tri >= sv.nTriangles + sv.nQuadrics) {  // TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125)
+                            const int inst = tri - sv.nTriangles - sv.nQuadrics;
+                            const wf_instance &in = sv.instances[inst];
+                            float tI = tMax;
+                            V3 oI, dI;
+                            InstanceRay(in, o, d, &tI, &oI, &dI);
+                            if (RefOrderTree<GEN, false>(svp, sv.instanceDefs[in.def].bvh_root, oI, dI, &tI, st, out)) {
+                                out->inst = inst;
+                                tMax = tI;
+                                hitAny = true;
+                            }
+                            continue;
+                        }
+                    }
+                    V3 p0, p1, p2;
+                    TriVerts(sv, tri, &p0, &p1, &p2);
+                    TriHit h;
+                    if (IntersectTriangleSheared(o, sh, tMax, p0, p1, p2, &h, true)) {
+                        if (GEN == 0 || AlphaTestSimpleP(svp, tri, h.b0, h.b1, h.b2, o.x, o.y, o.z, d.x, d.y, d.z)) {
+                            out->prim = tri;
+                            if (TOP) out->inst = -1;
+                            out->t = h.t; out->b0 = h.b0; out->b1 = h.b1; out->b2 = h.b2;
+                            tMax = h.t;
+                            hitAny = true;
+                        }
+                    }
+                }
+                if (st.n == base) break;
+                cur = st.pop();
+            } else if ((negMask >> node->axis) & 1) {
+                st.push(cur + 1);
+                cur = node->offset;
+            } else {
+                st.push(node->offset);
+                cur = cur + 1;
+            }
+        } else {
+            if (st.n == base) break;
+            cur = st.pop();
+        }
+    }
+    *tMaxIO = tMax;
+    return hitAny;
+}
+template <int GEN>
+__device__ inline __attribute__((always_inline)) RefHit RetraceRefOrder(const SceneView *svp, float ox, float oy, float oz, float dx, float dy, float dz, float tBound,
+                                                           int *spill, int spillStride, int rows, int *dbg) {
+    LdsStackT st{spill, spillStride, 0, 0, rows, dbg};
+    RefHit out{-1, -1, 0, 0, 0, 0, 0};
+    float tMax = tBound;
+    RefOrderTree<GEN, true>(svp, 0, V3{ox, oy, oz}, V3{dx, dy, dz}, &tMax, st, &out);
+    if (out.prim >= 0) {
+        // the routing code BuildFastBVH stores per LeafTri (EnqueueWorkAfterIntersection, intersect.h:48-156)
+        const wf_mesh &mesh = svp->meshes[svp->triMesh[out.prim]];
+        out.route = mesh.material >= 0 ? (uint32_t)svp->materials[mesh.material].type | (mesh.first_light >= 0 ? 16u : 0u) : 32u;
+    }
+    if (dbg) atomicAdd(dbg + 2, 1);
+    return out;
+}
+// which kernel variants resolve their near-ties themselves
+constexpr bool RetraceInline(int gen) { return gen <= 1; }
+
 template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
     LoadTreeTop(bvh);
@@ -335,6 +448,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
     // (one returning atomic per chunk x 64 rays: a counter sustains ~88 of them per microsecond)
     // (a queue shorter than two rounds of the resident grid is dealt statically: every wave starts at once, no atomics)
     if (n < 2 * (int)gridDim.x * TBLOCK) cursor = nullptr;
+    if (cursor && st.dbg && threadIdx.x == 0 && blockIdx.x == 0) atomicOr(st.dbg + 3, 1);
     int chunkBase = 0, chunkSub = chunk;
     for (int base = blockIdx.x * TBLOCK; true; base += gridDim.x * TBLOCK) {
         int idx;
@@ -365,7 +479,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
             float tMax;
             fetch(idx, &o, &d, &tMax);
             WalkInit(bvh, w, o, d, tMax);
-            st.n = 0;
+            st.reset();
         }
         // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
         // per-lane refill ("streaming": idle lanes take the next rays of the wave's run, leaf / interior step chosen per
@@ -399,6 +513,17 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                 else LeafStep<ANY>(bvh, w, st);
             }
         }
+        if constexpr (!ANY && RetraceInline(GEN)) {
+            if (valid && WalkAmbiguous(w)) {
+                V3 o, d;
+                float t0;
+                fetch(idx, &o, &d, &t0);
+                const float tB = __builtin_fminf(2 * WalkBound(bvh, WalkT(w)) - WalkT(w), t0);
+                const RefHit rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+                w.prim = rh.prim; w.inst = rh.inst; w.route = rh.route;
+                w.tMax = rh.t; w.b0 = rh.b0; w.b1 = rh.b1; w.b2 = rh.b2;
+            }
+        }
         finish(idx, valid, w);
     }
 }
@@ -409,10 +534,10 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
 // walks are done moves on to its next 64 rays while the others still walk.
 constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes this ray
 template <int GEN, bool INST = false, bool SPLIT = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, int *stackSpill, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     const RayQueueV q = ws.rq[cur];
     BatchTrace<false, GEN, INST>(
         sv, bvh, n, st,
@@ -583,10 +708,10 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
 }
 template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     BatchTrace<true, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
@@ -598,9 +723,9 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST_SHADOW : WF_TWAV
 
 // GENERAL: the scene has alpha-tested triangles or quadrics (the variant the render uses then)
 template <int GEN, bool INST>
-__global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, wf_hit_record *out, int *stackSpill) {
+__global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, wf_hit_record *out, SpillArea sp) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     BatchTrace<false, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
@@ -619,9 +744,9 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView s
         });
 }
 template <int GEN, bool INST>
-__global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, int32_t *occluded, int *stackSpill) {
+__global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, int32_t *occluded, SpillArea sp) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     BatchTrace<true, GEN, INST>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
@@ -667,16 +792,16 @@ struct TrPrims {  // the same callbacks for the transmittance walk, whose ray is
     __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricIntersect(sv, prim, o, d, tMax, qh); }
 };
 template <bool ALPHA>
-__global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, int *stackSpill) {
+__global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{stackSpill + gtid, stride, 0};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     LoadTreeTop(bvh);
     for (int i = gtid; i < n; i += stride)
         KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
             RayWalk w;
             WalkInit(bvh, w, o, d, tMax);
-            st.n = 0;
+            st.reset();
             while (w.node != NODE_NONE) {
                 if (w.node >= 0) {
                     U4 nd[QNODE_U4];
@@ -687,7 +812,7 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
             }
             if (WalkAmbiguous(w)) {  // near-tie (wf_traverse.h): the reference-order walk decides
                 ClosestHit ch;
-                st.n = 0;
+                st.reset();
                 bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
                 if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
                 return found;
@@ -769,7 +894,7 @@ struct Prof {
     bool on;
     Prof(wf_ctx *c, const char *name) : c(c), name(name) {
         if (c->traceLaunch) { fprintf(stderr, "[wf] launch %s\n", name); fflush(stderr); }
-        on = c->profile == 1 || (c->profile == 2 && strncmp(name, "Intersect", 9) == 0);
+        on = c->profile == 1 || (c->profile == 2 && (strncmp(name, "Intersect", 9) == 0 || strcmp(name, "Route hits") == 0));
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -835,7 +960,8 @@ static int checkReady(wf_ctx *ctx) {
 // Reference LinearBVHNode arrays (depth-first: left child = i + 1, right child = offset) -> QNode (breadth-first
 // numbering per tree, quantised child boxes on the tree's own grid) + LeafTri (vertices in leaf order).  The top-level
 // tree comes first; every instance definition's tree follows with its own grid (FastDef).  See wf_traverse.h.
-static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, std::vector<FastDef> *defs, FastBVH *out) {
+struct FastDepths { int top = 0, def = 0, maxLeafInstances = 0; };   // levels of the four-wide trees (top level / deepest definition), most instances in one leaf
+static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, std::vector<FastDef> *defs, FastBVH *out, FastDepths *depths) {
     const wf_bvh_node *L = d->bvh_nodes;
     const int n = d->n_bvh_nodes;
     const int nGeom = d->n_triangles + d->n_quadrics;
@@ -901,7 +1027,9 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     }
     auto leafLike = [&](int i) { return L[i].nprims > 0 || subCount[i] <= collapse; };
     // one tree: linear nodes [root, ...) reachable from root; grid written to base / cell; returns the root's QNode index
+    int lastTreeDepth = 0;   // levels of the four-wide tree buildTree made last (a single leaf-like root: 1)
     auto buildTree = [&](int root, float baseOut[3], float cellOut[3]) -> int {
+        lastTreeDepth = 1;
         // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
         // it as a float: WalkSetRay folds base and cell into per-ray fma constants).  Every stored plane lies at least
         // `margin` outside the float box it bounds; margin = 2^-20 of the largest coordinate magnitude, which covers the
@@ -964,8 +1092,10 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         order.push_back(root);
         bfsIndex[root] = qBase;
         std::vector<std::array<int, 4>> kidsOf;
+        std::vector<int> level{1};
         for (size_t h = 0; h < order.size(); ++h) {
             int i = order[h];
+            lastTreeDepth = std::max(lastTreeDepth, level[h] + 1);   // + 1: the leaves hanging off this node
             std::array<int, 4> kids = {i + 1, (int)L[i].offset, -1, -1};
             int nk = 2;
             while (nk < 4) {
@@ -978,7 +1108,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
                 kids[nk++] = L[c].offset;
             }
             for (int k = 0; k < nk; ++k)
-                if (!leafLike(kids[k])) { bfsIndex[kids[k]] = qBase + (int)order.size(); order.push_back(kids[k]); }
+                if (!leafLike(kids[k])) { bfsIndex[kids[k]] = qBase + (int)order.size(); order.push_back(kids[k]); level.push_back(level[h] + 1); }
             kidsOf.push_back(kids);
         }
         nodes->resize((size_t)qBase + order.size());
@@ -1004,6 +1134,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             nodes->push_back(qn);
             return qBase;
         }
+        lastTreeDepth = 64;   // (two-wide legacy layout: the reference's own bound, nodesToVisit[64])
         // breadth-first numbering of the interior nodes
         std::vector<int> order;
         order.push_back(root);
@@ -1028,6 +1159,13 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         return qBase;
     };
     buildTree(0, out->base, out->cell);
+    depths->top = lastTreeDepth;
+    for (int i = 0; i < n; ++i)
+        if (leafLike(i)) {
+            int ni = 0;
+            for (int k = 0; k < subCount[i]; ++k) ni += d->bvh_prims[subFirst[i] + k] >= nGeom;
+            depths->maxLeafInstances = std::max(depths->maxLeafInstances, ni);
+        }
     {
         double ext = 0;
         for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
@@ -1037,6 +1175,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     for (int k = 0; k < d->n_instance_defs; ++k) {
         FastDef fd{};
         fd.root = d->instance_defs[k].bvh_root >= 0 ? buildTree(d->instance_defs[k].bvh_root, fd.base, fd.cell) : 0;
+        if (d->instance_defs[k].bvh_root >= 0) depths->def = std::max(depths->def, lastTreeDepth);
         defs->push_back(fd);
     }
     if (!gridOk) return false;
@@ -1087,6 +1226,20 @@ int wf_sync(wf_ctx *ctx) {
     if (!ctx) return fail(-1, "null context");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
+    if (ctx->dbgWords) {
+        int overflow = 0;
+        HIPCHK(hipMemcpy(&overflow, ctx->dbgWords + 1, sizeof(int), hipMemcpyDeviceToHost));
+        if (overflow) return fail(-1, "traversal stack overflow: a walk needed more than %d + %d node-stack entries (results are incomplete)", TSTACK, ctx->spillRows);
+    }
+    return 0;
+}
+int wf_debug_counters(wf_ctx *ctx, uint64_t out[4], int reset) {
+    if (!ctx || !ctx->sceneLoaded || !out) return fail(-1, "wf_debug_counters: no scene uploaded");
+    int h[4] = {0, 0, 0, 0};
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(h, ctx->dbgWords, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = (uint64_t)(unsigned)h[i];
+    if (reset) HIPCHK(hipMemset(ctx->dbgWords, 0, sizeof(h)));
     return 0;
 }
 void *wf_stream(wf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -1200,29 +1353,6 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     ctx->maxDepth = d->max_depth;
     for (int i = 0; i < 6; ++i) ctx->sceneBounds[i] = d->scene_bounds[i];
     {
-        // traversal stacks: LDS entries per lane + rows of `stackSpill` behind them.  The rows are sized from the trees' depths: the
-        // reference-order walk pushes one sibling per level (top-level tree, then an instance definition's on top), the four-wide
-        // production walk up to three per level of its collapsed tree, plus the instance markers
-        auto treeDepth = [&](int root) {
-            int best = 0;
-            if (root < 0 || root >= d->n_bvh_nodes) return best;
-            std::vector<std::pair<int, int>> st{{root, 1}};
-            while (!st.empty()) {
-                auto [i, dep] = st.back();
-                st.pop_back();
-                best = std::max(best, dep);
-                if (d->bvh_nodes[i].nprims == 0) { st.push_back({i + 1, dep + 1}); st.push_back({d->bvh_nodes[i].offset, dep + 1}); }
-            }
-            return best;
-        };
-        int depthTop = d->n_bvh_nodes > 0 ? treeDepth(0) : 0, depthDef = 0;
-        for (int k = 0; k < d->n_instance_defs; ++k) depthDef = std::max(depthDef, treeDepth(d->instance_defs[k].bvh_root));
-        const int needRef = depthTop + depthDef + 4, needFast = 3 * ((depthTop + 1) / 2 + 1) + 3 * ((depthDef + 1) / 2 + 1) + 4;
-        const int rows = std::max(std::max(needRef - STACK_LDS, needFast - TSTACK), STACK_MAX - STACK_LDS);
-        if (rows > 2048) return fail(-1, "BVH too deep for the traversal stacks (depth %d + %d)", depthTop, depthDef);
-        if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)rows * MAX_GRID * BLOCK))) return e;
-    }
-    {
         std::vector<QNode> qn;
         std::vector<LeafTri> lt;
         {
@@ -1239,7 +1369,36 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if (getenv("WF_GEN_MODE")) ctx->genMode = std::max(ctx->genMode, atoi(getenv("WF_GEN_MODE")));  // timing experiments: force the general variant
         }
         std::vector<FastDef> fdefs;
-        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &ctx->fast);
+        FastDepths fdep;
+        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &ctx->fast, &fdep);
+        {
+            // traversal stacks: LDS entries per lane + rows of `stackSpill` behind them, sized from the trees' ACTUAL depths: the
+            // reference-order walk pushes one sibling per level of the reference's binary trees (top level, then an instance
+            // definition's on top); the four-wide production walk up to three per level of ITS collapsed trees (BuildFastBVH records
+            // their depths: the greedy largest-area collapse does not halve the depth of an unbalanced tree), one entry per instance
+            // of a leaf, and the two instance markers.  A push past the rows is dropped and flagged (LdsStackT, wf_sync).
+            auto treeDepth = [&](int root) {
+                int best = 0;
+                if (root < 0 || root >= d->n_bvh_nodes) return best;
+                std::vector<std::pair<int, int>> st{{root, 1}};
+                while (!st.empty()) {
+                    auto [i, dep] = st.back();
+                    st.pop_back();
+                    best = std::max(best, dep);
+                    if (d->bvh_nodes[i].nprims == 0) { st.push_back({i + 1, dep + 1}); st.push_back({d->bvh_nodes[i].offset, dep + 1}); }
+                }
+                return best;
+            };
+            int depthTop = d->n_bvh_nodes > 0 ? treeDepth(0) : 0, depthDef = 0;
+            for (int k = 0; k < d->n_instance_defs; ++k) depthDef = std::max(depthDef, treeDepth(d->instance_defs[k].bvh_root));
+            const int needRef = depthTop + depthDef + 4;
+            const int needFast = 3 * fdep.top + fdep.maxLeafInstances + 3 * fdep.def + 6;
+            const int rows = std::max(std::max(needRef - std::min(STACK_LDS, TSTACK), needFast - TSTACK), STACK_MAX - std::min(STACK_LDS, TSTACK));
+            if (rows > 2048) return fail(-1, "BVH too deep for the traversal stacks (depth %d + %d)", depthTop, depthDef);
+            if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)rows * MAX_GRID * BLOCK))) return e;
+            ctx->spillRows = rows;
+            if ((e = devAlloc(ctx, &ctx->dbgWords, (size_t)4))) return e;
+        }
         if (d->n_bvh_nodes > 0)
             for (int a = 0; a < 3; ++a) { ctx->sceneMin[a] = d->bvh_nodes[0].bmin[a]; ctx->sceneMax[a] = d->bvh_nodes[0].bmax[a]; }
         if (ctx->fastOk) {
@@ -1501,11 +1660,12 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
                 cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
                 HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
             }
-            LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill, cursor, ctx->cursorChunk);
-            // The near-tie re-trace is a handful of long single walks (1-2 ms of latency on 128 workgroups): it runs on a second stream
-            // beside the routing pass (and, in the fused pass, the next sample-generation launch) — they touch disjoint rays and share
-            // only the queue counters, through atomics — and the main stream waits for it before anything consumes the queues.
-            const bool overlap = ctx->overlapRetrace && ctx->profile != 1 && !ctx->traceLaunch;   // (the full per-stage profile times every launch on the main stream)
+            LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk);
+            // The near-tie re-trace of the scenes whose walk does not resolve its ties itself (genMode >= 2: quadrics, curves, texture-graph
+            // alpha; RetraceInline) is a handful of long single walks: it runs on a second stream beside the routing pass (and, in the
+            // fused pass, the next sample-generation launch) — they touch disjoint rays and share only the queue counters, through
+            // atomics — and the main stream waits for it before anything consumes the queues.
+            const bool overlap = !RetraceInline(ctx->genMode) && ctx->overlapRetrace && ctx->profile != 1 && !ctx->traceLaunch;   // (the full per-stage profile times every launch on the main stream)
             if (overlap) {
                 HIPCHK(hipEventRecord(ctx->evFork, ctx->stream));
                 HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
@@ -1520,11 +1680,11 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
                 else hipLaunchKernelGGL(k_route_hits<false>, dim3(g), dim3(RBLOCK), 0, ctx->stream, ctx->svHost, ctx->ws, depth & 1);
             }
         } else
-        LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->stackSpill);
+        LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea());
         if (ctx->retracePending) {
             if (ctx->deferJoin) return 0;   // the fused pass joins after its sample-generation launch (JoinRetrace)
             if (int e = JoinRetrace(ctx)) return e;
-        } else
+        } else if (!RetraceInline(ctx->genMode))
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
@@ -1545,8 +1705,8 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
     if (ctx->fastOk && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the transmittance walk has no two-level variant yet)
-        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
-        else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill);
+        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
+        else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
     else
         LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
@@ -1602,7 +1762,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
             cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
             HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
         }
-        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->stackSpill, cursor, ctx->cursorChunk);
+        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk);
     } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
@@ -1796,7 +1956,7 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     if (count_visits || !ctx->fastOk) {
         LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 0);
     } else {
-        LAUNCHT_VARIANT("trace closest fast (host rays)", k_trace_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->stackSpill);
+        LAUNCHT_VARIANT("trace closest fast (host rays)", k_trace_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->spillArea());
         LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 1);
     }
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
@@ -1843,7 +2003,7 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     if (nodes_visited || tris_tested || !ctx->fastOk) {
         LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svHost, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
     } else {
-        LAUNCHT_VARIANT("trace any fast (host rays)", k_trace_any_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->stackSpill);
+        LAUNCHT_VARIANT("trace any fast (host rays)", k_trace_any_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->spillArea());
     }
     HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -90,7 +90,7 @@ constexpr int NODE_NONE = (int)0x80000000;
 #define WF_TBLOCK 256
 #endif
 #ifndef WF_TSTACK
-#define WF_TSTACK 12
+#define WF_TSTACK 16   // a power of two: the LDS part of the stack is a ring (LdsStackT)
 #endif
 #ifndef WF_TWAVES
 #define WF_TWAVES 5   // __launch_bounds__ second argument (minimum waves per SIMD) of the traversal kernels

@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "wf_film_device_ptr", "wf_film_upload", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_queue_size", "wf_queue_download",
-    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms",
+    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",
 ]
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
@@ -301,6 +301,15 @@ class Scene:
         c = TraversalCounters()
         _check(hip.wf_counters_download(self.ctx, C.byref(c)), "wf_counters_download")
         return {n: int(getattr(c, n)) for n, _ in TraversalCounters._fields_}
+
+    def debug_counters(self, reset=True):
+        """rare-path counters of the production traversal (wf_debug_counters): spilled stack entries, overflow flag,
+        inline near-tie re-traces, cursor path taken"""
+        _, hip = libs()
+        out = (C.c_uint64 * 4)()
+        hip.wf_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        _check(hip.wf_debug_counters(self.ctx, out, 1 if reset else 0), "wf_debug_counters")
+        return {"spilled_entries": int(out[0]), "overflow": int(out[1]), "inline_retraces": int(out[2]), "cursor": int(out[3])}
 
     def film_to_tensor(self, tensor):
         """device-to-device copy of the film accumulators into a torch CUDA float64 tensor (for the RCCL reduce)"""

@@ -67,3 +67,14 @@ def image_error(a, b, floor=1e-2):
     """relative error per value, relative to max(|b|, floor)"""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
     return d / np.maximum(np.abs(b), floor)
+
+
+def bench_small_scene(name, tmp_dir):
+    """Regenerate a downscaled benchmark stand-in (tools/make_scenes.py bench_small: the generators of bench.py's workloads with
+    fewer meshes) into tmp_dir and check the tree against the hash recorded when its golden render was made."""
+    import json
+    import make_scenes
+    path = make_scenes.bench_small(name, str(tmp_dir))
+    want = json.load(open(os.path.join(GOLDEN, "bench_small_hashes.json")))[name]
+    assert make_scenes.tree_hash(str(tmp_dir)) == want, "the generator of %s drifted from the one its golden was rendered from" % name
+    return path, make_scenes.BENCH_SMALL[name]["spp"]

@@ -56,6 +56,21 @@ def test_cpu_checker_image_matches_reference_wavefront(built, tmp_path, scene, s
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()
 
 
+@pytest.mark.parametrize("name", ["sanmiguel_like_small", "tm_like_small", "cloud_like_small"])
+def test_cpu_checker_matches_reference_on_benchmark_standins(built, tmp_path, name):
+    """The BENCHMARKED workloads (bench.py: san-miguel-like = 500 k triangles in a two-level BVH with alpha cut-outs, image
+    textures, sky + sun + emitters; tm-like = nested dielectric shells at maxdepth 50; cloud-like = a grid medium at
+    maxdepth 20), downscaled: the port is bit-identical to `pbrt --wavefront` on them too."""
+    from conftest import bench_small_scene
+    path, spp = bench_small_scene(name, tmp_path / "scene")
+    ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))
+    out = str(tmp_path / "cpu.pfm")
+    run_wf_cpu(path, out, spp)
+    img = read_pfm(out)
+    assert img.shape == ref.shape
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()
+
+
 def test_mix_material_matches_reference_statistically(built, tmp_path):
     """MixMaterial::ChooseMaterial hashes the two materials' tagged POINTERS (materials.h:292): the reference's own
     choice changes with heap layout, so there is no sample-aligned comparison.  64 spp, 8x8-pixel block means of the

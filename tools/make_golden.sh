@@ -113,3 +113,19 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --outfile $G/cornell64_sobol_o
 oracle/_ref/pbrt_ref --quiet --seed 0 --spp 256 --outfile $G/cornell64_volpath256.pfm $G/cornell64.pbrt
 ls -la $G
 python3 tools/make_libm_golden.py
+# downscaled versions of the BENCHMARKED stand-ins (BASELINE configs[2], [4], [3]): the scene trees are regenerated by the tests
+# (tools/make_scenes.py bench_small, deterministic) — only the reference's render and the tree hashes are committed
+python3 - <<'PY'
+import json, subprocess, sys, tempfile, os, shutil
+sys.path.insert(0, "tools")
+import make_scenes
+hashes = {}
+for name, cfg in make_scenes.BENCH_SMALL.items():
+    td = tempfile.mkdtemp()
+    path = make_scenes.bench_small(name, td)
+    hashes[name] = make_scenes.tree_hash(td)
+    subprocess.run(["oracle/_ref/pbrt_ref", "--wavefront", "--quiet", "--seed", "0", "--spp", str(cfg["spp"]), "--outfile",
+                    os.path.abspath("tests/golden/%s_ref.pfm" % name), path], check=True)
+    shutil.rmtree(td)
+json.dump(hashes, open("tests/golden/bench_small_hashes.json", "w"), indent=1)
+PY
