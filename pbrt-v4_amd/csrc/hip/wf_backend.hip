@@ -228,6 +228,15 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, 
 // ---- production traversal: persistent waves over QNode/LeafTri with the tree top in LDS (wf_traverse.h) ----
 __shared__ int g_tstack[TSTACK * TBLOCK];
 __shared__ U4 g_top[QNODE_U4 * TOP_NODES];
+// the render-space ray of every lane (o.xyz, d.xyz), for the instance transitions and the alpha test of the two-level / general
+// variants: re-reading it from the queue (round 2) put an L2 round trip in front of every transition — eight per ray on the spec scene
+__shared__ float g_ray[6 * TBLOCK];
+__device__ inline void StoreWorldRay(V3 o, V3 d) {
+    g_ray[0 * TBLOCK + threadIdx.x] = o.x; g_ray[1 * TBLOCK + threadIdx.x] = o.y; g_ray[2 * TBLOCK + threadIdx.x] = o.z;
+    g_ray[3 * TBLOCK + threadIdx.x] = d.x; g_ray[4 * TBLOCK + threadIdx.x] = d.y; g_ray[5 * TBLOCK + threadIdx.x] = d.z;
+}
+__device__ inline V3 WorldRayO() { return V3{g_ray[0 * TBLOCK + threadIdx.x], g_ray[1 * TBLOCK + threadIdx.x], g_ray[2 * TBLOCK + threadIdx.x]}; }
+__device__ inline V3 WorldRayD() { return V3{g_ray[3 * TBLOCK + threadIdx.x], g_ray[4 * TBLOCK + threadIdx.x], g_ray[5 * TBLOCK + threadIdx.x]}; }
 // the HBM spill path of the stack is out of line so that the compiler cannot merge it with the LDS path
 // into a pointer select (which turns every pop into a flat load)
 __device__ __attribute__((noinline)) int SpillRead(const int *p) { return *p; }
@@ -335,9 +344,7 @@ struct GeneralPrims {
     const Fetch &fetch;
     int idx;
     __device__ V3 dir() const {
-        V3 o, d;
-        float t;
-        fetch(idx, &o, &d, &t);
+        V3 d = WorldRayD();
         if (w.curInst >= 0) d = XfVector3(bvh.instances[w.curInst].render_from_instance.mInv, d);  // = InstanceRay's direction
         return d;
     }
@@ -479,6 +486,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
             float tMax;
             fetch(idx, &o, &d, &tMax);
             WalkInit(bvh, w, o, d, tMax);
+            if constexpr (INST || GEN > 0) StoreWorldRay(o, d);
             st.reset();
         }
         // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
@@ -500,9 +508,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                     // (the render-space ray is re-fetched from the queue on these rare transitions instead of living in registers)
                     const int first = (int)((~(unsigned)w.node) >> 4);
                     if (w.node == NODE_EXIT || first >= INST_FIRST) {
-                        V3 o, d;
-                        float t0;
-                        fetch(idx, &o, &d, &t0);
+                        const V3 o = WorldRayO(), d = WorldRayD();
                         if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
                         else EnterInstance(bvh, w, st, o, d, first - INST_FIRST);
                         continue;
@@ -528,18 +534,141 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
     }
 }
 
+// ---- the same walk with wave-level replacement of finished rays (round 3) ---------------------------------------------------------
+// BatchTrace keeps a wave on its 64 rays until the LAST of them is done: on the 10 M-triangle scene the SQ counters showed 24 % of
+// the lanes active over a wave's lifetime — walk lengths within a wave differ by an order of magnitude.  Here a wave whose active
+// lanes drop to WF_REFILL_AT or fewer retires its finished lanes (`finish` is a per-lane store in every caller that uses this
+// variant: no workgroup barrier) and deals them the next rays of the wave's private run of the queue (runs of chunk x 64 rays, taken
+// from the shared cursor with one returning atomic each, or dealt statically when the queue is short).  Between refills the loop is
+// the same "while-while" as before, so the lanes of one refill — neighbours in the queue — descend the top of the tree together
+// (LDS-cached nodes), which is what the continuous per-lane refill measured in round 2 lost (5x the L1 line accesses).
+#ifndef WF_REFILL_AT
+#define WF_REFILL_AT 40
+#endif
+template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
+__device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
+    LoadTreeTop(bvh);
+    if (n < 2 * (int)gridDim.x * TBLOCK) cursor = nullptr;
+    if (cursor && st.dbg && threadIdx.x == 0 && blockIdx.x == 0) atomicOr(st.dbg + 3, 1);
+    const int lane = threadIdx.x & 63;
+    const int waveId = (blockIdx.x * TBLOCK + threadIdx.x) >> 6, nWaves = (gridDim.x * TBLOCK) >> 6;
+    const int runRays = cursor ? 64 * chunk : 64;
+    int next = 0, end = 0, staticJ = 0;   // the wave's private run [next, end) of ray indices (uniform)
+    bool exhausted = false;
+    int idx = -1;
+    RayWalk w;
+    w.node = NODE_NONE;
+    w.prim = -1;
+    w.route = 0;
+    w.tMax = 0;
+    w.b0 = w.b1 = w.b2 = 0;
+    w.inst = w.curInst = -1;
+    auto retire = [&]() {
+        if constexpr (!ANY && RetraceInline(GEN)) {
+            if (WalkAmbiguous(w)) {
+                V3 o, d;
+                float t0;
+                fetch(idx, &o, &d, &t0);
+                const float tB = __builtin_fminf(2 * WalkBound(bvh, WalkT(w)) - WalkT(w), t0);
+                const RefHit rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+                w.prim = rh.prim; w.inst = rh.inst; w.route = rh.route;
+                w.tMax = rh.t; w.b0 = rh.b0; w.b1 = rh.b1; w.b2 = rh.b2;
+            }
+        }
+        finish(idx, true, w);
+        idx = -1;
+    };
+    while (true) {
+        const unsigned long long act = __ballot(w.node != NODE_NONE);
+        const int nAct = __popcll(act);
+        if (nAct <= WF_REFILL_AT && !exhausted) {
+            const bool idle = w.node == NODE_NONE;
+            if (idle && idx >= 0) retire();
+            const int need = 64 - nAct;
+            const int rank = __popcll(~act & ((1ull << lane) - 1ull));
+            int served = 0;
+            while (served < need) {
+                if (next >= end) {
+                    int b;
+                    if (cursor) {
+                        b = 0;
+                        if (lane == 0) b = atomicAdd(cursor, runRays);
+                        b = __builtin_amdgcn_readfirstlane(b);
+                    } else {
+                        b = (staticJ * nWaves + waveId) * 64;
+                        ++staticJ;
+                    }
+                    next = b;
+                    end = b + runRays < n ? b + runRays : n;
+                    if (next >= n) { exhausted = true; break; }
+                }
+                const int take = need - served < end - next ? need - served : end - next;
+                if (idle && rank >= served && rank < served + take) idx = next + (rank - served);
+                next += take;
+                served += take;
+            }
+            if (idle && idx >= 0) {
+                V3 o, d;
+                float tMax;
+                fetch(idx, &o, &d, &tMax);
+                WalkInit(bvh, w, o, d, tMax);
+                if constexpr (INST || GEN > 0) StoreWorldRay(o, d);
+                st.reset();
+            }
+            if (exhausted && !__any(w.node != NODE_NONE)) break;
+        } else if (nAct == 0) break;
+        while (__any(w.node >= 0)) {
+            if (w.node >= 0) {
+                U4 nd[QNODE_U4];
+                FetchNode(bvh, w.node, nd);
+                InteriorStep<!ANY>(bvh, w, st, nd);
+            }
+        }
+        if (w.node != NODE_NONE) {
+            if constexpr (INST) {
+                const int first = (int)((~(unsigned)w.node) >> 4);
+                if (w.node == NODE_EXIT || first >= INST_FIRST) {
+                    const V3 o = WorldRayO(), d = WorldRayD();
+                    if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
+                    else EnterInstance(bvh, w, st, o, d, first - INST_FIRST);
+                    continue;
+                }
+                if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
+                else LeafStep<ANY, false, true>(bvh, w, st);
+            } else if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
+            else LeafStep<ANY>(bvh, w, st);
+        }
+    }
+    if (idx >= 0) retire();   // the rays still held when the queue ran out
+}
+// Measured on the spec scene (16 spp, same box; gpurun_out/r3b_ab_sm16.txt): the any-hit walk gains (30.1 -> 25.2 ms at a threshold of
+// 40 lanes, 26.2 at 24, 27.5 at 12), the closest-hit walk loses (58.3 -> 65.7 / 74.9 / 72.2 ms: it carries the hit record and the
+// near-tie code through the refill, 400 B of scratch instead of 304) — so only the any-hit kernels use it by default.
+#ifndef WF_REFILL_SHADOW
+#define WF_REFILL_SHADOW 1
+#endif
+#ifndef WF_REFILL_CLOSEST
+#define WF_REFILL_CLOSEST 0
+#endif
+// PERLANE: `finish` has no workgroup barrier (every caller but the workgroup-routed closest-hit variant, SPLIT = false)
+template <bool ANY, int GEN, bool INST, bool PERLANE, typename Fetch, typename Finish>
+__device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
+    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW : WF_REFILL_CLOSEST)) BatchTraceRefill<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
+    else BatchTrace<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
+}
+
 // SPLIT = false: a workgroup routes its 256 hits together at the end of every batch (KRouteHitBlock: one atomic per destination queue
 // per workgroup) — its four waves wait for the slowest walk of the 256.  SPLIT = true: the walk only records the hit (ws.hit, hitInst,
 // hitT, routeCode) and k_route_hits pushes the queue entries afterwards in one streaming pass; waves never meet, so a wave whose 64
 // walks are done moves on to its next 64 rays while the others still walk.
 constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes this ray
 template <int GEN, bool INST = false, bool SPLIT = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     const RayQueueV q = ws.rq[cur];
-    BatchTrace<false, GEN, INST>(
+    TraceQueue<false, GEN, INST, SPLIT>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = q.o[i], d4 = q.d[i];
@@ -712,7 +841,7 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST_SHADOW : WF_TWAV
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
-    BatchTrace<true, GEN, INST>(
+    TraceQueue<true, GEN, INST, true>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
@@ -726,7 +855,7 @@ template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, wf_hit_record *out, SpillArea sp) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
-    BatchTrace<false, GEN, INST>(
+    TraceQueue<false, GEN, INST, true>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;
@@ -747,7 +876,7 @@ template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, int32_t *occluded, SpillArea sp) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
-    BatchTrace<true, GEN, INST>(
+    TraceQueue<true, GEN, INST, true>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             const float *r = rays + (size_t)7 * i;

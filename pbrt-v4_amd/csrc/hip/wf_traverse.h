@@ -84,7 +84,7 @@ struct alignas(16) U4 { uint32_t x, y, z, w; };
 
 constexpr int NODE_NONE = (int)0x80000000;
 #ifndef WF_TOP_NODES
-#define WF_TOP_NODES (WF_BVH4 ? 256 : 512)
+#define WF_TOP_NODES (WF_BVH4 ? 128 : 512)   // 128 x 64 B = 8 KiB: with the 16 KiB stack ring five 256-thread workgroups fit a CU's 160 KiB (256 nodes: four; any-hit -9 %)
 #endif
 #ifndef WF_TBLOCK
 #define WF_TBLOCK 256
@@ -94,6 +94,9 @@ constexpr int NODE_NONE = (int)0x80000000;
 #endif
 #ifndef WF_TWAVES
 #define WF_TWAVES 5   // __launch_bounds__ second argument (minimum waves per SIMD) of the traversal kernels
+#endif
+#ifndef WF_TWAVES_CLOSEST
+#define WF_TWAVES_CLOSEST WF_TWAVES   // the one-level closest-hit walk (it carries the hit record and the near-tie code)
 #endif
 #ifndef WF_TWAVES_INST
 #define WF_TWAVES_INST 4   // the same for the two-level (object instance) variants, which carry the render-space ray as well
@@ -181,19 +184,67 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     w.curInst = -1;
 }
 // Switch the lane into / out of an object instance (see the header comment).  oW, dW: the ray in render space.
+// Returns false when the instance is skipped.  (Round 3) The top-level leaf that holds an instance only says that the ray meets the
+// instance's RENDER-space box; clusters of rotated instances overlap heavily, so most entries ended at the definition's root node —
+// after the reference's full ray transform (interval arithmetic), two WalkSetRay (six divisions), two stack markers and a node fetch.
+// A cheap, conservative test comes first: the ray is taken into the instance's space with plain fmas and tested against the
+// definition's root box (its quantisation grid, which already lies outside the float box) widened by 2^-13 of the magnitudes
+// involved — three orders of magnitude more than the differences between this transform and Transform::ApplyInverse(Ray)
+// (a few ulps of the coordinates plus the interval-width shift of the origin, util/transform.h:416-429).  The reference's own
+// root test (Bounds3::IntersectP on the exact box with the exactly transformed ray) cannot pass where this one fails, so skipping
+// changes no result.  Non-affine matrices (bottom row not 0 0 0 1) are never skipped.
+#ifndef WF_INST_PRETEST
+#define WF_INST_PRETEST 0   // measured on the spec scene (gpurun_out/r3e_ab_sm16.txt): closest 56.8 vs 56.5 ms, any-hit 22.9 vs 21.7 ms per 16 spp with / without — the entries it saves are too few to pay for the test; off
+#endif
+__device__ inline float WalkBound(const FastBVH &bvh, float t);
+__device__ inline bool InstancePretestMiss(const wf_instance &in, const FastDef &fd, V3 o, V3 d, float tBound) {
+    const float(*mi)[4] = in.render_from_instance.mInv;
+    if (mi[3][0] != 0 || mi[3][1] != 0 || mi[3][2] != 0 || mi[3][3] != 1) return false;
+    const float oI[3] = {fma(mi[0][0], o.x, fma(mi[0][1], o.y, fma(mi[0][2], o.z, mi[0][3]))),
+                         fma(mi[1][0], o.x, fma(mi[1][1], o.y, fma(mi[1][2], o.z, mi[1][3]))),
+                         fma(mi[2][0], o.x, fma(mi[2][1], o.y, fma(mi[2][2], o.z, mi[2][3])))};
+    const float dI[3] = {fma(mi[0][0], d.x, fma(mi[0][1], d.y, mi[0][2] * d.z)), fma(mi[1][0], d.x, fma(mi[1][1], d.y, mi[1][2] * d.z)),
+                         fma(mi[2][0], d.x, fma(mi[2][1], d.y, mi[2][2] * d.z))};
+    float t0 = 0, t1 = tBound * (1 + 0x1p-13f);
+    for (int k = 0; k < 3; ++k) {
+        const float lo = fd.base[k], hi = fma(65535.f, fd.cell[k], fd.base[k]);
+        const float pad = 0x1p-13f * (__builtin_fabsf(lo) + __builtin_fabsf(hi) + __builtin_fabsf(oI[k]) + (hi - lo));
+        const float a = (lo - pad) - oI[k], b = (hi + pad) - oI[k];   // the origin relative to the widened slab
+        if (__builtin_fabsf(dI[k]) < 1e-30f) {          // parallel to the slab: inside or outside for good
+            if (a > 0 || b < 0) return true;
+            continue;
+        }
+        const float inv = __builtin_amdgcn_rcpf(dI[k]);
+        float tn = a * inv, tf = b * inv;
+        if (tn > tf) { const float x = tn; tn = tf; tf = x; }
+        // rcp and the products are good to a few ulps: widen the interval relatively and absolutely before intersecting
+        tn -= 0x1p-13f * __builtin_fabsf(tn);
+        tf += 0x1p-13f * __builtin_fabsf(tf);
+        t0 = __builtin_fmaxf(t0, tn);
+        t1 = __builtin_fminf(t1, tf);
+    }
+    return !(t0 <= t1);   // (NaNs never skip)
+}
 template <typename Stack>
-__device__ inline void EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int inst) {
+__device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int inst) {
     const wf_instance &in = bvh.instances[inst];
+    const FastDef fd = bvh.defs[in.def];
+#if WF_INST_PRETEST
+    if (InstancePretestMiss(in, fd, oW, dW, WalkBound(bvh, __builtin_fabsf(w.tMax)))) {
+        w.node = st.empty() ? NODE_NONE : st.pop();
+        return false;
+    }
+#endif
     float tI = __builtin_fabsf(w.tMax);
     V3 oI, dI;
     InstanceRay(in, oW, dW, &tI, &oI, &dI);
     st.push((int)FloatToBits(w.tMax));
     st.push(NODE_EXIT);
-    const FastDef fd = bvh.defs[in.def];
     WalkSetRay(fd.base, fd.cell, w, oI, dI);
     w.tMax = (FloatToBits(w.tMax) >> 31) ? -tI : tI;
     w.curInst = inst;
     w.node = fd.root;
+    return true;
 }
 template <typename Stack>
 __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW) {

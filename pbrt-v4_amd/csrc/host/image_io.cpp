@@ -149,8 +149,8 @@ static void ReadPNG(const std::string &path, const ColorEnc &encIn, HostImage *i
     }
     const int ct = png.ctype;
     const int srcNc = ct == 0 ? 1 : ct == 2 ? 3 : ct == 3 ? 1 : ct == 4 ? 2 : ct == 6 ? 4 : 0;
-    if (!png.w || !png.h || !srcNc || (png.depth != 1 && png.depth != 2 && png.depth != 4 && png.depth != 8 && png.depth != 16))
-        Die("", path + ": malformed PNG header");
+    if (!png.w || !png.h || png.w > 65536u || png.h > 65536u || !srcNc || (png.depth != 1 && png.depth != 2 && png.depth != 4 && png.depth != 8 && png.depth != 16))
+        Die("", path + ": malformed PNG header (dimensions / colour type / bit depth)");
     if (png.interlace) Die("", path + ": interlaced PNG images are not supported by this build");
     const size_t bpp = std::max<size_t>(1, (size_t)srcNc * png.depth / 8), stride = ((size_t)png.w * srcNc * png.depth + 7) / 8;
     std::vector<uint8_t> raw((stride + 1) * png.h);
@@ -257,7 +257,7 @@ static void ReadEXR(const std::string &path, HostImage *img) {
     }
     auto fail = [&](const std::string &why) { Die("", "Unable to read image file \"" + path + "\": " + why); };
     size_t pos = 0;
-    auto need = [&](size_t n) { if (pos + n > file.size()) fail("file is truncated"); };
+    auto need = [&](size_t n) { if (pos > file.size() || n > file.size() - pos) fail("file is truncated"); };
     auto rd32 = [&]() { need(4); uint32_t v; memcpy(&v, &file[pos], 4); pos += 4; return v; };
     auto rdStr = [&]() { std::string r; while (true) { need(1); char c = (char)file[pos++]; if (!c) break; r.push_back(c); } return r; };
     if (rd32() != 20000630u) fail("not an OpenEXR file");
@@ -278,8 +278,9 @@ static void ReadEXR(const std::string &path, HostImage *img) {
             size_t p = 0;
             while (p < size && v[p]) {
                 Chan c;
-                while (v[p]) c.name.push_back((char)v[p++]);
+                while (p < size && v[p]) c.name.push_back((char)v[p++]);
                 ++p;
+                if (p > size || size - p < 16) fail("malformed channel list");
                 int32_t t; memcpy(&t, v + p, 4);
                 c.type = t;
                 int32_t xs, ys; memcpy(&xs, v + p + 8, 4); memcpy(&ys, v + p + 12, 4);
@@ -287,9 +288,9 @@ static void ReadEXR(const std::string &path, HostImage *img) {
                 p += 16;
                 chans.push_back(c);
             }
-        } else if (name == "compression") compression = v[0];
-        else if (name == "dataWindow") memcpy(dw, v, 16);
-        else if (name == "lineOrder") lineOrder = v[0];
+        } else if (name == "compression") { if (size != 1) fail("malformed compression attribute"); compression = v[0]; }
+        else if (name == "dataWindow") { if (size != 16) fail("malformed dataWindow attribute"); memcpy(dw, v, 16); }
+        else if (name == "lineOrder") { if (size != 1) fail("malformed lineOrder attribute"); lineOrder = v[0]; }
         else if (name == "chromaticities" && size >= 32) {
             // RGBColorSpace::Lookup (util/colorspace.cpp): this build's image maps are sRGB / Rec.709
             float c[8]; memcpy(c, v, 32);
@@ -299,8 +300,9 @@ static void ReadEXR(const std::string &path, HostImage *img) {
         pos += size;
     }
     (void)lineOrder;
-    const int w = dw[2] - dw[0] + 1, h = dw[3] - dw[1] + 1;
-    if (w <= 0 || h <= 0 || chans.empty()) fail("malformed header");
+    const long long wl = (long long)dw[2] - dw[0] + 1, hl = (long long)dw[3] - dw[1] + 1;
+    if (wl <= 0 || hl <= 0 || wl > 65536 || hl > 65536 || chans.empty() || chans.size() > 64) fail("malformed header (data window / channel list)");
+    const int w = (int)wl, h = (int)hl;
     for (const Chan &c : chans) {
         if (c.type != chans[0].type) fail("images with multiple channel types are not supported");
         if (c.type != 1 && c.type != 2) fail("only half and float channels are supported");
@@ -330,13 +332,13 @@ static void ReadEXR(const std::string &path, HostImage *img) {
     std::vector<uint8_t> raw, tmp;
     for (int ck = 0; ck < nChunks; ++ck) {
         uint64_t off; memcpy(&off, &file[tablePos + 8 * (size_t)ck], 8);
-        if (off + 8 > file.size()) fail("chunk offset out of range");
+        if (off > file.size() || file.size() - off < 8) fail("chunk offset out of range");
         int32_t y0, dataSize;
         memcpy(&y0, &file[off], 4); memcpy(&dataSize, &file[off + 4], 4);
-        if (dataSize < 0 || off + 8 + (size_t)dataSize > file.size()) fail("chunk size out of range");
+        if (dataSize < 0 || (size_t)dataSize > file.size() - off - 8) fail("chunk size out of range");
         const uint8_t *data = &file[off + 8];
+        if (y0 < dw[1] || y0 > dw[3]) fail("chunk outside the data window");
         const int nLines = std::min(linesPerChunk, dw[3] - y0 + 1);
-        if (y0 < dw[1] || nLines <= 0) fail("chunk outside the data window");
         const size_t expect = lineBytes * nLines;
         raw.resize(expect);
         if ((size_t)dataSize == expect) memcpy(raw.data(), data, expect);   // stored uncompressed (also when compression did not help)

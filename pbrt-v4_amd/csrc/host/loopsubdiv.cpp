@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <map>
+#include <string>
 #include <utility>
 
 namespace wf {
@@ -89,16 +90,24 @@ void LoopSubdivide(int nLevels, const std::vector<int> &vertexIndices, const std
     for (size_t i = 0; i < nFaces; ++i)
         for (int j = 0; j < 3; ++j) {
             const int v = vertexIndices[3 * i + j];
+            if (v < 0 || (size_t)v >= P.size()) throw SceneError("Error: loopsubdiv: vertex index out of range");
             m.F[i].v[j] = v;
             m.V[v].startFace = (int)i;
         }
+    // (the reference dereferences a null startFace for a control vertex that no face uses, and links only the first two faces of an
+    // edge: both are input errors here, reported instead of crashing the embedding process)
+    for (size_t i = 0; i < P.size(); ++i)
+        if (m.V[i].startFace < 0) throw SceneError("Error: loopsubdiv: control vertex " + std::to_string(i) + " is not used by any face");
     // neighbour pointers: an edge is remembered until its second face arrives
     {
         struct Half { int f, edgeNum; };
         std::map<EdgeKey, Half> edges;
+        std::map<EdgeKey, int> uses;
         for (size_t i = 0; i < nFaces; ++i)
             for (int edgeNum = 0; edgeNum < 3; ++edgeNum) {
                 const EdgeKey e = Edge(m.F[i].v[edgeNum], m.F[i].v[NEXT(edgeNum)]);
+                if (e.first == e.second) throw SceneError("Error: loopsubdiv: degenerate face (repeated vertex)");
+                if (++uses[e] > 2) throw SceneError("Error: loopsubdiv: non-manifold control mesh (an edge is shared by more than two faces)");
                 auto it = edges.find(e);
                 if (it == edges.end()) edges[e] = Half{(int)i, edgeNum};
                 else {

@@ -1903,8 +1903,16 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
         std::istringstream ls(line);
         std::string kw;
         ls >> kw;
-        if (kw == "format") { std::string f; ls >> f; fmt = f == "ascii" ? ASCII : (f == "binary_little_endian" ? BLE : BBE); }
-        else if (kw == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+        if (kw == "format") {
+            std::string f; ls >> f;
+            if (f == "ascii") fmt = ASCII; else if (f == "binary_little_endian") fmt = BLE; else if (f == "binary_big_endian") fmt = BBE;
+            else { *err = "unknown PLY format \"" + f + "\""; return false; }
+        }
+        else if (kw == "element") {
+            Elem e; ls >> e.name >> e.count;
+            if (!ls || e.count < 0 || e.count > (1l << 31)) { *err = "malformed PLY element count"; return false; }
+            elems.push_back(e);
+        }
         else if (kw == "property") {
             Prop p; std::string t; ls >> t;
             if (t == "list") { p.list = true; ls >> p.countType >> p.type >> p.name; }
@@ -1972,7 +1980,11 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
         }
         if (e.name == "vertex") {
             bool hasN = false, hasUV = false;
-            for (const P2 &p : props) { if (p.role == 3) hasN = true; if (p.role == 6) hasUV = true; }
+            // normals need nx, ny and nz, texture coordinates u and v: a partial set is ignored, never written through an empty vector
+            bool r[8] = {};
+            for (const P2 &p : props) if (p.role >= 0 && p.role < 8) r[p.role] = true;
+            hasN = r[3] && r[4] && r[5];
+            hasUV = r[6] && r[7];
             out->P.resize(e.count);
             if (hasN) out->N.resize(e.count);
             if (hasUV) out->uv.resize(e.count);
@@ -1982,8 +1994,8 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
                     float v = (float)readNum(p.type);
                     switch (p.role) {
                     case 0: out->P[i].x = v; break; case 1: out->P[i].y = v; break; case 2: out->P[i].z = v; break;
-                    case 3: out->N[i].x = v; break; case 4: out->N[i].y = v; break; case 5: out->N[i].z = v; break;
-                    case 6: out->uv[i].x = v; break; case 7: if (hasUV) out->uv[i].y = v; break;
+                    case 3: if (hasN) out->N[i].x = v; break; case 4: if (hasN) out->N[i].y = v; break; case 5: if (hasN) out->N[i].z = v; break;
+                    case 6: if (hasUV) out->uv[i].x = v; break; case 7: if (hasUV) out->uv[i].y = v; break;
                     default: break;
                     }
                 }
@@ -2000,7 +2012,7 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
                         int q[4];
                         for (int k = 0; k < 4; ++k) q[k] = (int)readNum(p.type);
                         out->quads.push_back(q[0]); out->quads.push_back(q[1]); out->quads.push_back(q[3]); out->quads.push_back(q[2]);
-                    } else { *err = "only triangle faces are supported (the reference accepts triangles and quads)"; return false; }
+                    } else { *err = "only triangle and quad faces are supported (as in the reference, util/mesh.cpp:290-310)"; return false; }
                 }
         } else {
             for (long i = 0; i < e.count && !truncated; ++i)

@@ -4,6 +4,7 @@
 #include "integrator.h"
 #include "../../../include/wf_host.h"
 
+#include <dlfcn.h>
 #include <cstring>
 #include <sys/stat.h>
 #include <memory>
@@ -53,7 +54,7 @@ wfh_scene *wfh_scene_load(const char *path, int spp_override, int seed) {
 }
 static wfh_scene *SceneLoadImpl(const char *path, int spp_override, int seed) {
     if (!g_init || !path) return nullptr;
-    auto *s = new wfh_scene();
+    std::unique_ptr<wfh_scene> s(new wfh_scene());   // (ParseFiles / BuildSceneTables throw SceneError)
     s->opt.pixelSamples = spp_override;
     s->opt.seed = seed;
     s->opt.quiet = true;
@@ -68,16 +69,23 @@ static wfh_scene *SceneLoadImpl(const char *path, int spp_override, int seed) {
             auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull; };
             mix(path, strlen(path)); mix(&st.st_size, sizeof(st.st_size)); mix(&st.st_mtime, sizeof(st.st_mtime)); mix(&spp_override, 4); mix(&seed, 4);
             if (const char *sp = getenv("WF_BVH_SPLIT")) mix(sp, strlen(sp));
+            // the library that builds the tables is part of the key (its file's size and modification time): a rebuilt table
+            // builder / BVH builder never loads tables an older build wrote, even when no struct size changed
+            Dl_info di;
+            struct stat lst;
+            if (dladdr((const void *)&wfh_last_error, &di) && di.dli_fname && stat(di.dli_fname, &lst) == 0) {
+                mix(&lst.st_size, sizeof(lst.st_size)); mix(&lst.st_mtime, sizeof(lst.st_mtime));
+            }
             char name[64];
             snprintf(name, sizeof(name), "/tables_%016llx.wftab", (unsigned long long)h);
             cacheFile = std::string(dir) + name;
-            if (s->T.Load(cacheFile)) return s;
+            if (s->T.Load(cacheFile)) return s.release();
         }
     }
     ParseFiles({path}, &s->opt, &s->parsed);
     BuildSceneTables(s->parsed, s->opt, &s->T);
     if (!cacheFile.empty() && !s->T.Save(cacheFile)) fprintf(stderr, "Warning: could not write the scene-table cache %s\n", cacheFile.c_str());
-    return s;
+    return s.release();
 }
 wfh_scene *wfh_scene_load_string(const char *text, int spp_override, int seed) {
     if (!g_init || !text) return nullptr;
