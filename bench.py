@@ -176,7 +176,10 @@ def main():
     t_parse = time.perf_counter() - t_load0
     if dist is not None and rank == 0:
         dist.barrier()
-    scene.create_renderer(local_rank, samples_per_pass=a.samples_per_pass)   # upload + production BVH layout + queues
+    # upload + production BVH layout + queues.  A rank of a strip partition sizes its queues for ITS rows: a pass then carries `world`
+    # times the sample indices of 1/world of the pixels — launches as large as a single GPU's, as far as K allows
+    scene.create_renderer(local_rank, samples_per_pass=a.samples_per_pass,
+                          strips=(rank, world, multigpu.STRIP_HEIGHT) if (world > 1 and a.partition == "strips") else None)
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t_load0 - t_parse
     info = scene.info

@@ -41,6 +41,10 @@ int wfh_renderer_samples_per_pass(wfh_scene *s);
 wf_ctx *wfh_renderer_ctx(wfh_scene *s);
 /* multi-GPU image partition (wf_set_strips): this renderer owns the scanline strips rank, rank + count, ... of `height` lines */
 int wfh_renderer_set_strips(wfh_scene *s, int rank, int count, int height);
+/* the same constructor for one rank of a multi-GPU job: the partition is known before the queues are allocated, so they are sized
+   for the rank's own rows and a pass carries `count` times the sample indices (launches as large as a single GPU's, as far as the
+   render has that many sample indices: 1080p on 8 GPUs fills ~64 M rays per pass from 242 sample indices on) */
+int wfh_renderer_create_strips(wfh_scene *s, int device, int samples_per_pass, int rank, int count, int height);
 /* Render(): sample indices begin, begin+step, ... < end; returns wall seconds (negative on error) */
 double wfh_render(wfh_scene *s, int sample_begin, int sample_end, int sample_step, int fused);
 int wfh_clear_film(wfh_scene *s);

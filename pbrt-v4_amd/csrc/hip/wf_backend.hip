@@ -358,6 +358,42 @@ struct GeneralPrims {
         else return QuadricIntersect<GEN == 3>(sv, prim, w.o, dir(), tMax, qh);
     }
 };
+// The part of a "while-while" iteration that follows the interior descent: every lane sits at a leaf run, at an instance transition
+// (an instance entry popped from the stack, or the NODE_EXIT marker) or is done.  Leaves are processed first; the transitions —
+// ~400 instructions each (the reference's interval-arithmetic ray transform, two WalkSetRay with three IEEE divisions each), eight
+// per ray on the spec scene, about half of the walk's VALU work — are PARKED until WF_TRANS_BATCH lanes of the wave wait for one, or
+// until no lane has anything else to do: a parked lane loses nothing (its wave-mates' steps would have been issued with its lane
+// masked anyway), and the expensive code then runs with several times the lanes.  (0: run every transition in the iteration it is
+// popped in, as in round 2.)
+#ifndef WF_TRANS_BATCH
+#define WF_TRANS_BATCH 6   // spec scene, 16 spp, same box (gpurun_out/r3f_ab_sm16.txt): closest / any-hit 60.1 / 22.0 ms at 0, 56.5 / 20.2 at 6, 58.4 / 20.5 at 12, 62.4 / 21.1 at 24
+#endif
+__device__ inline bool AtTransition(int node) { return node < 0 && node != NODE_NONE && (node == NODE_EXIT || (int)((~(unsigned)node) >> 4) >= INST_FIRST); }
+template <bool ANY, int GEN, bool INST, typename Fetch>
+__device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWalk &w, LdsStackT &st, const Fetch &fetch, int idx) {
+    if constexpr (INST) {
+        bool tr = AtTransition(w.node);
+        if (w.node != NODE_NONE && !tr) {
+            if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
+            else LeafStep<ANY, false, true>(bvh, w, st);
+        }
+        if constexpr (WF_TRANS_BATCH > 0) {
+            tr = AtTransition(w.node);
+            const int nT = __popcll(__ballot(tr));
+            if (nT == 0) return;
+            if (nT < WF_TRANS_BATCH && __any(w.node != NODE_NONE && !tr)) return;   // parked: the others still have nodes and leaves to visit
+        }
+        if (tr) {
+            const V3 o = WorldRayO(), d = WorldRayD();
+            if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
+            else EnterInstance(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST);
+        }
+    } else if (w.node != NODE_NONE) {
+        if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
+        else LeafStep<ANY>(bvh, w, st);
+    }
+}
+
 // ---- near-tie resolution inside the production walk (round 3) -------------------------------------------------------------------
 // A ray the production walk marked as a near-tie (wf_traverse.h) is walked once more in the REFERENCE's order — BVHAggregate::Intersect
 // over the reference-layout 32-byte nodes (cpu/aggregates.cpp:529-579), the exact Bounds3::IntersectP, the reference's accept rule —
@@ -502,22 +538,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                     InteriorStep<!ANY>(bvh, w, st, nd);
                 }
             }
-            if (w.node != NODE_NONE) {
-                if constexpr (INST) {
-                    // object instances travel through the stack as leaf references (wf_traverse.h)
-                    // (the render-space ray is re-fetched from the queue on these rare transitions instead of living in registers)
-                    const int first = (int)((~(unsigned)w.node) >> 4);
-                    if (w.node == NODE_EXIT || first >= INST_FIRST) {
-                        const V3 o = WorldRayO(), d = WorldRayD();
-                        if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
-                        else EnterInstance(bvh, w, st, o, d, first - INST_FIRST);
-                        continue;
-                    }
-                    if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
-                    else LeafStep<ANY, false, true>(bvh, w, st);
-                } else if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
-                else LeafStep<ANY>(bvh, w, st);
-            }
+            LeafPhase<ANY, GEN, INST>(sv, bvh, w, st, fetch, idx);
         }
         if constexpr (!ANY && RetraceInline(GEN)) {
             if (valid && WalkAmbiguous(w)) {
@@ -624,20 +645,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
                 InteriorStep<!ANY>(bvh, w, st, nd);
             }
         }
-        if (w.node != NODE_NONE) {
-            if constexpr (INST) {
-                const int first = (int)((~(unsigned)w.node) >> 4);
-                if (w.node == NODE_EXIT || first >= INST_FIRST) {
-                    const V3 o = WorldRayO(), d = WorldRayD();
-                    if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
-                    else EnterInstance(bvh, w, st, o, d, first - INST_FIRST);
-                    continue;
-                }
-                if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
-                else LeafStep<ANY, false, true>(bvh, w, st);
-            } else if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
-            else LeafStep<ANY>(bvh, w, st);
-        }
+        LeafPhase<ANY, GEN, INST>(sv, bvh, w, st, fetch, idx);
     }
     if (idx >= 0) retire();   // the rays still held when the queue ran out
 }

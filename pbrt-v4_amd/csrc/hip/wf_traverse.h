@@ -151,6 +151,9 @@ struct RayWalk {
 // the near side, added on the far side) so that the test passes whenever the reference's test on the exact
 // box would: a superset of visited nodes, while the hit itself is decided by the exact triangle test.
 // the ray-dependent part: origin, shear, slab constants on the grid (base, cell)
+#ifndef WF_SLAB_RCP
+#define WF_SLAB_RCP 1
+#endif
 __device__ inline void WalkSetRay(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
     constexpr float SLACK = 0x1p-20f;            // 16 ulp
     constexpr float G = 1 + 2 * gamma(3);        // the reference's tMax factor
@@ -161,7 +164,9 @@ __device__ inline void WalkSetRay(const float base[3], const float cell[3], RayW
     float a[3], bn[3], af[3], bf[3];
     uint32_t sel[3];
     for (int k = 0; k < 3; ++k) {
-        float inv = 1 / dd[k];
+        // v_rcp_f32 (1 ulp) instead of the IEEE division (ten instructions): the constants feed the conservative slab test only, and
+        // the 16-ulp SLACK below covers one more ulp in a and b (the exact triangle test keeps its IEEE divisions, MakeRayShear)
+        float inv = WF_SLAB_RCP ? __builtin_amdgcn_rcpf(dd[k]) : 1 / dd[k];
         if (!(fabsf(inv) <= INV_MAX)) inv = copysignf(INV_MAX, dd[k]);
         const float ak = cell[k] * inv, bk = (base[k] - oo[k]) * inv;
         const float delta = SLACK * fma(65535.f, fabsf(ak), fabsf(bk));

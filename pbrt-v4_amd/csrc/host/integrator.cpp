@@ -20,23 +20,29 @@ static void Check(int rc, const char *what) {
     }
 }
 
-WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPassArg) : T(tables) {
+WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPassArg, int stripRank, int stripCount, int stripHeight) : T(tables) {
     // Wavefront sizing.  The reference carries one sample index per pass (<= 2^20 rays, integrator.cpp:227-236).
     // On a 256-CU part a 1 M-ray launch is two rounds of a latency-bound walk; the queues here carry several
     // sample indices per pass (default: up to ~64 M rays in flight, ~35 GB of queues out of 288 GB; measured at 1080p: 16 -> 437, 32 -> 458, 64 -> 472 Msamples/s).
+    // A rank of a multi-GPU job owns 1/N of the scanlines: its pass covers its own rows only and carries N times the sample
+    // indices instead, so its launches stay as large as a single GPU's (as far as the render has that many sample indices).
+    const int W = T.desc.film.pixel_max[0] - T.desc.film.pixel_min[0];
+    Check(wf_ctx_create(device, &ctx), "wf_ctx_create");
+    Check(wf_scene_upload(ctx, &T.desc), "wf_scene_upload");
+    localRows = T.desc.film.pixel_max[1] - T.desc.film.pixel_min[1];
+    if (stripCount > 1) Check(wf_set_strips(ctx, stripRank, stripCount, stripHeight, &localRows), "wf_set_strips");
+    rowsPerPass = std::max(1, std::min(T.scanlinesPerPass, localRows));
+    const int pixelsPerPass = W * rowsPerPass;
     samplesPerPass = samplesPerPassArg;
     if (samplesPerPass <= 0) {
         const char *env = getenv("WF_SAMPLES_PER_PASS");
         if (env) samplesPerPass = atoi(env);
     }
-    if (samplesPerPass <= 0) samplesPerPass = std::max(1, (64 << 20) / T.maxQueueSize);
+    if (samplesPerPass <= 0) samplesPerPass = std::max(1, (64 << 20) / pixelsPerPass);
     samplesPerPass = std::min(samplesPerPass, std::max(1, T.spp));
-    Check(wf_ctx_create(device, &ctx), "wf_ctx_create");
-    Check(wf_scene_upload(ctx, &T.desc), "wf_scene_upload");
-    Check(wf_queues_alloc(ctx, T.maxQueueSize, samplesPerPass), "wf_queues_alloc");
+    Check(wf_queues_alloc(ctx, pixelsPerPass, samplesPerPass), "wf_queues_alloc");
     Check(wf_film_clear(ctx), "wf_film_clear");
     Check(wf_sync(ctx), "wf_sync");
-    localRows = T.desc.film.pixel_max[1] - T.desc.film.pixel_min[1];
 }
 
 WavefrontRenderer::~WavefrontRenderer() {
@@ -46,6 +52,7 @@ WavefrontRenderer::~WavefrontRenderer() {
 // the image partition of multi-GPU rendering: this renderer owns the strips rank, rank + count, ... (wf_set_strips)
 void WavefrontRenderer::SetStrips(int rank, int count, int height) {
     Check(wf_set_strips(ctx, rank, count, height, &localRows), "wf_set_strips");
+    // (the queues keep the size they were allocated with: a partition set after construction runs in passes of at most that many rows)
 }
 
 void WavefrontRenderer::ClearFilm() {
@@ -64,7 +71,7 @@ double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep,
         // this batch of passes carries sampleIndex, sampleIndex + sampleStep, ... (at most samplesPerPass of them)
         const int remaining = (sampleEnd - sampleIndex + sampleStep - 1) / sampleStep;
         Check(wf_set_pass_samples(ctx, sampleStep, std::min(samplesPerPass, remaining)), "wf_set_pass_samples");
-        for (int y0 = F.pixel_min[1]; y0 < F.pixel_min[1] + localRows; y0 += T.scanlinesPerPass) {
+        for (int y0 = F.pixel_min[1]; y0 < F.pixel_min[1] + localRows; y0 += rowsPerPass) {
             if (fused) {
                 Check(wf_render_pass(ctx, y0, sampleIndex), "wf_render_pass");
                 continue;

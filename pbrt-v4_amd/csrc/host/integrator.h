@@ -10,7 +10,10 @@ class WavefrontRenderer {
     // uploads the scene tables to HIP device `device` and allocates the work queues
     // (WavefrontPathIntegrator ctor, wavefront/integrator.cpp:80-287)
     // samplesPerPass <= 0: automatic (env WF_SAMPLES_PER_PASS, else ~64 M rays in flight)
-    WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPass = 0);
+    // stripCount > 1: the renderer is one of stripCount ranks of a multi-GPU job and owns the scanline strips stripRank,
+    // stripRank + stripCount, ... from the start: its queues are sized for ITS rows, so that a pass of a rank carries as many
+    // rays as a pass of a single GPU does (more sample indices of fewer pixels; bounded by the number of sample indices rendered)
+    WavefrontRenderer(const SceneTables &tables, int device, int samplesPerPass = 0, int stripRank = 0, int stripCount = 1, int stripHeight = 16);
     int SamplesPerPass() const { return samplesPerPass; }
     ~WavefrontRenderer();
     WavefrontRenderer(const WavefrontRenderer &) = delete;
@@ -31,6 +34,7 @@ class WavefrontRenderer {
     wf_ctx *ctx = nullptr;
     int samplesPerPass = 1;
     int localRows = 0;  // scanlines this renderer owns (set by the ctor = image height, or by SetStrips)
+    int rowsPerPass = 0;   // local rows one pass covers (the queues hold rowsPerPass x width x samplesPerPass items)
 };
 
 }  // namespace wf

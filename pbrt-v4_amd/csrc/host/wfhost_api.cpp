@@ -125,6 +125,10 @@ int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass) {
     if (!s) return -1;
     return Guard<int>(-1, [&] { s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass); return 0; });
 }
+int wfh_renderer_create_strips(wfh_scene *s, int device, int samples_per_pass, int rank, int count, int height) {
+    if (!s) return -1;
+    return Guard<int>(-1, [&] { s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass, rank, count, height); return 0; });
+}
 int wfh_renderer_set_strips(wfh_scene *s, int rank, int count, int height) {
     if (!s || !s->renderer) return -1;
     return Guard<int>(-1, [&] { s->renderer->SetStrips(rank, count, height); return 0; });

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
-    "wfh_renderer_create", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
+    "wfh_renderer_create", "wfh_renderer_create_strips", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
     "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image",
 ]
 
@@ -95,6 +95,7 @@ def libs():
     _host.wfh_scene_desc.argtypes = [C.c_void_p]
     _host.wfh_scene_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     _host.wfh_renderer_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    _host.wfh_renderer_create_strips.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     _host.wfh_renderer_samples_per_pass.argtypes = [C.c_void_p]
     _host.wfh_renderer_set_strips.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     _host.wfh_renderer_ctx.restype = C.c_void_p
@@ -162,12 +163,18 @@ class Scene:
     def spp(self):
         return self.info.spp
 
-    def create_renderer(self, device=0, samples_per_pass=0):
+    def create_renderer(self, device=0, samples_per_pass=0, strips=None):
         """WavefrontPathIntegrator ctor: upload tables to HIP device `device`, allocate queues.
-        samples_per_pass: sample indices one pass carries (0 = automatic); the film is bit-identical for any value."""
+        samples_per_pass: sample indices one pass carries (0 = automatic); the film is bit-identical for any value.
+        strips = (rank, count[, height]): this renderer is one rank of a multi-GPU image partition from the start — its queues are
+        sized for its own rows (wfh_renderer_create_strips)."""
         host, _ = libs()
-        if host.wfh_renderer_create(self.h, device, samples_per_pass) != 0:
-            raise WfError("renderer creation failed")
+        if strips is not None and strips[1] > 1:
+            rc = host.wfh_renderer_create_strips(self.h, device, samples_per_pass, strips[0], strips[1], strips[2] if len(strips) > 2 else 16)
+        else:
+            rc = host.wfh_renderer_create(self.h, device, samples_per_pass)
+        if rc != 0:
+            raise WfError("renderer creation failed: " + (host.wfh_last_error() or b"").decode(errors="replace"))
         self._renderer = True
         self.samples_per_pass = host.wfh_renderer_samples_per_pass(self.h)
         self.ctx = host.wfh_renderer_ctx(self.h)
