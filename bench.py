@@ -64,7 +64,7 @@ def make_scene(path, spp, workload="sanmiguel-like", meshes=2000):
     elif workload == "tm-like":
         return make_scenes.tm_like(path, (W, H), spp)
     elif workload == "cloud-like":
-        make_scenes.cloud_like(path, (W, H), spp)
+        make_scenes.cloud_like(path, (W, H), spp, n=512)   # a 512^3 density grid
     else:
         make_scenes.killeroo_like(path, (W, H), spp)
 
@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="time EVERY launch of the timed region with HIP events and add the per-stage totals "
+                    "(\"stage_ms\") to the JSON line; the near-tie re-trace of general-primitive scenes then runs on the main stream (no overlap)")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="sample indices carried per pass (0 = automatic, ~64 M rays in flight)")
     ap.add_argument("--workload", choices=["killeroo-like", "sanmiguel-like", "cloud-like", "tm-like"], default="sanmiguel-like",
                     help="sanmiguel-like = BASELINE configs[2] stand-in at the SURVEY 8(d) spec (default: the north_star target config); "
@@ -208,7 +210,7 @@ def main():
         film_t.zero_()
     rays_before = scene.total_rays()
     stats_before = scene.stats()
-    scene.enable_profile(0 if a.no_roofline else 2)
+    scene.enable_profile(1 if a.breakdown else (0 if a.no_roofline else 2))
 
     barrier()
     t0 = time.perf_counter()
@@ -252,7 +254,7 @@ def main():
                                     "killeroo-simple 1080p 64spp (BASELINE.json configs[1]) on the killeroo-like stand-in: %d triangles, "
                                     "diffuse + dielectric, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
                                     if a.workload == "killeroo-like" else
-                                    "Disney cloud 1080p (BASELINE.json configs[3]) on the cloud-like stand-in (64^3 uniformgrid medium, g = 0.877, "
+                                    "Disney cloud 1080p 128spp (BASELINE.json configs[3]) on the cloud-like stand-in at the SURVEY 8(d) spec (512^3 fBm density grid, uniformgrid medium, g = 0.877, sigma_s = 12, inside an interface box, distant light + uniform sky): "
                                     "%d triangles, maxdepth %d, zsobol; step = 1 sample index x 1920x1080"
                                     if a.workload == "cloud-like" else
                                     "San Miguel 1080p 256spp (BASELINE.json configs[2]) on the sanmiguel-like stand-in at the SURVEY 8(d) spec: %d unique "
@@ -327,6 +329,8 @@ def main():
                     "mray_per_s": rays_shadow / (sh_ms * 1e-3) / 1e6,
                     "closest_mray_per_s": (rays_closest / (walk_ms * 1e-3) / 1e6) if walk_ms > 0 else None,
                 }
+        if a.breakdown:
+            out["stage_ms"] = {e["name"]: {"launches": e["launches"], "total_ms": round(e["total_ms"], 3)} for e in scene.profile_report()}
         parity_fail = None
         if world == 1 and a.cpu_spp > 0:
             out["cpu_baseline"], ref_img = cpu_baseline(scene_path, a.cpu_spp, wfpt.read_pfm)
