@@ -201,9 +201,11 @@ def main():
         scene.render(0, Wm, 1)
         counters = scene.counters()
         scene.enable_counters(False)
-        # ... and one untimed step through the PRODUCTION kernels (the counting pass above runs the reference-order variants): their
-        # code objects, the rocPRIM / RCCL state and the queue pages are touched before the timed region, not inside it
-        multigpu.render_partition(scene, rank, world, 0, 1, a.partition)
+        # ... and one untimed run of the SAME K steps through the PRODUCTION kernels (the counting pass above runs the reference-order
+        # variants): code objects, scratch, RCCL state and queue pages are touched before the timed region, not inside it — and every
+        # production launch of the process has the timed region's size, so that a rocprofv3 --stats average of this command agrees
+        # with roofline.avg_launch_ms
+        multigpu.render_partition(scene, rank, world, 0, K, a.partition)
     scene.clear_film()
     if dist is not None:
         dist.all_reduce(film_t)  # warm the communicator

@@ -34,7 +34,7 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
-    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS, CNT_CURSOR,
+    CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS, CNT_CURSOR, CNT_TR0, CNT_TR1,
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -117,6 +117,11 @@ struct WorkState {
     struct BssrdfItem *bssrdfQ;       // GetBSSRDFAndProbeRayQueue / SubsurfaceScatterQueue (K12; allocated when sv.haveSubsurface)
     struct SubsurfaceItem *sssQ;
     ShadowQueueV sq;
+    // the transmittance wavefront (HIP back end, scenes with media): per shadow ray the state of TraceTransmittance between segments —
+    // current origin / direction (+ medium id in trD.w), T_ray, r_u, r_l, the PCG32 state — and two index queues of the live rays
+    F4 *trO, *trD, *trT, *trRu, *trRl;
+    I4 *trRng;
+    int32_t *trQ[2];
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
     double *film;                   // [pixels][4]: rgbSum[3], weightSum (film.h:302-307)
     unsigned long long *stats;      // cameraRays, indirect[64], shadow[64]
@@ -689,68 +694,117 @@ WF_HD void KSampleMediumScattering(const SceneView &sv, const WorkState &ws, int
 }
 
 // K11: TraceTransmittance, wavefront/intersect.h:165-274 (the shadow-ray stage when the scene has media).
-// trace(o, d, tMax, &prim, &b0, &b1, &b2) -> closest hit?
-template <typename Trace>
-WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, Trace trace) {
+// The reference's per-ray loop — trace to the next surface, stop at an opaque one, ratio-track the medium along the segment, respawn
+// behind an interface — is written as three pieces over an explicit state, so that it can run either as one loop per lane
+// (KTraceTransmittance: the CPU checker, the reference-order device kernels) or as a wavefront of its own (round 3: TrBegin, then per
+// segment the production closest-hit walk over the live shadow rays + TrSegment, state in HBM between the launches: the walk runs at
+// its own occupancy instead of inside a 428-register loop).
+struct TrState {
+    V3 ro, rd;
+    int medium;
+    S4 T_ray, r_u, r_l;
+    RNG rng;
+};
+WF_HD void TrBegin(const WorkState &ws, int i, TrState *st) {
     F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
-    const int pixelIndex = (int)FloatToBits(d4.w);
-    Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    S4 Ld = toS4(ws.sq.Ld[i]);
-    const S4 sr_u = toS4(ws.sq.r_u[i]), sr_l = toS4(ws.sq.r_l[i]);
-    V3 ro{o4.x, o4.y, o4.z}, rd{d4.x, d4.y, d4.z};
-    float tMax = o4.w;
-    int medium = ws.sq.medium[i];
-    const V3 pLight = ro + rd * tMax;
-    RNG rng(Hash3f(ro), Hash3f(rd));
-    S4 T_ray = S4c(1.f), r_u = S4c(1.f), r_l = S4c(1.f);
-    while (!(rd.x == 0 && rd.y == 0 && rd.z == 0)) {
-        int prim = -1, inst = -1;
-        float b0 = 0, b1 = 0, b2 = 0;
-        bool hit = trace(ro, rd, tMax, &prim, &inst, &b0, &b1, &b2);
-        SurfIntr si;
-        bool opaque = false;
-        if (hit) {
-            HitInteraction(sv, prim, inst, b0, b1, b2, &si, ro, rd);
-            opaque = sv.meshes[si.mesh].material >= 0;
-        }
-        if (opaque) {
-            T_ray = S4c(0.f);
-            break;
-        }
-        if (medium >= 0) {
-            float tEnd = !hit ? tMax : (Distance(ro, si.pi.mid()) / Length(rd));
-            float u0 = rng.UniformFloat();
-            S4 T_maj = SampleT_maj(sv, medium, ro, rd, tEnd, u0, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
-                S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
-                // ratio tracking: only null scattering is evaluated
-                float pr = T_maj[0] * sigma_maj[0];
-                T_ray = T_ray * (T_maj * sigma_n / pr);
-                r_l = r_l * (T_maj * sigma_maj / pr);
-                r_u = r_u * (T_maj * sigma_n / pr);
-                S4 Tr = T_ray / (r_l + r_u).Average();
-                if (Tr.MaxComponentValue() < 0.05f) {
-                    float qq = 0.75f;
-                    if (rng.UniformFloat() < qq) T_ray = S4c(0.f);
-                    else T_ray = T_ray / (1 - qq);
-                }
-                if (!T_ray) return false;
-                return true;
-            });
-            T_ray = T_ray * (T_maj / T_maj[0]);
-            r_l = r_l * (T_maj / T_maj[0]);
-            r_u = r_u * (T_maj / T_maj[0]);
-        }
-        if (!hit || !T_ray) break;
-        // ray = si->intr.SpawnRayTo(pLight): interaction.h:103-107
-        RayOD nr = SpawnRayTo(si.pi, si.n, pLight);
-        medium = SurfaceMedium(sv.meshes[si.mesh], si.n, nr.d, medium);
-        ro = nr.o;
-        rd = nr.d;  // (tMax stays sr.tMax, intersect.h:176,185)
+    st->ro = V3{o4.x, o4.y, o4.z};
+    st->rd = V3{d4.x, d4.y, d4.z};
+    st->medium = ws.sq.medium[i];
+    st->rng = RNG(Hash3f(st->ro), Hash3f(st->rd));
+    st->T_ray = S4c(1.f); st->r_u = S4c(1.f); st->r_l = S4c(1.f);
+}
+// one turn of the loop body after the closest hit of (ro, rd, tMax) is known; returns whether the ray goes on (a new segment in st)
+WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *st, bool hit, int prim, int inst, float b0, float b1, float b2) {
+    F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
+    const float tMax = o4.w;
+    const V3 pLight = V3{o4.x, o4.y, o4.z} + V3{d4.x, d4.y, d4.z} * tMax;
+    SurfIntr si;
+    bool opaque = false;
+    if (hit) {
+        HitInteraction(sv, prim, inst, b0, b1, b2, &si, st->ro, st->rd);
+        opaque = sv.meshes[si.mesh].material >= 0;
     }
-    if (T_ray) {
-        Ld = Ld * (T_ray / (sr_u * r_u + sr_l * r_l).Average());
+    if (opaque) {
+        st->T_ray = S4c(0.f);
+        return false;
+    }
+    if (st->medium >= 0) {
+        const int pixelIndex = (int)FloatToBits(d4.w);
+        Wavelengths lambda = LoadLambda(ws, pixelIndex);
+        float tEnd = !hit ? tMax : (Distance(st->ro, si.pi.mid()) / Length(st->rd));
+        float u0 = st->rng.UniformFloat();
+        S4 &T_ray = st->T_ray, &r_u = st->r_u, &r_l = st->r_l;
+        RNG &rng = st->rng;
+        S4 T_maj = SampleT_maj(sv, st->medium, st->ro, st->rd, tEnd, u0, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
+            S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
+            // ratio tracking: only null scattering is evaluated
+            float pr = T_maj[0] * sigma_maj[0];
+            T_ray = T_ray * (T_maj * sigma_n / pr);
+            r_l = r_l * (T_maj * sigma_maj / pr);
+            r_u = r_u * (T_maj * sigma_n / pr);
+            S4 Tr = T_ray / (r_l + r_u).Average();
+            if (Tr.MaxComponentValue() < 0.05f) {
+                float qq = 0.75f;
+                if (rng.UniformFloat() < qq) T_ray = S4c(0.f);
+                else T_ray = T_ray / (1 - qq);
+            }
+            if (!T_ray) return false;
+            return true;
+        });
+        T_ray = T_ray * (T_maj / T_maj[0]);
+        r_l = r_l * (T_maj / T_maj[0]);
+        r_u = r_u * (T_maj / T_maj[0]);
+    }
+    if (!hit || !st->T_ray) return false;
+    // ray = si->intr.SpawnRayTo(pLight): interaction.h:103-107
+    RayOD nr = SpawnRayTo(si.pi, si.n, pLight);
+    st->medium = SurfaceMedium(sv.meshes[si.mesh], si.n, nr.d, st->medium);
+    st->ro = nr.o;
+    st->rd = nr.d;  // (tMax stays sr.tMax, intersect.h:176,185)
+    return !(st->rd.x == 0 && st->rd.y == 0 && st->rd.z == 0);
+}
+WF_HD void TrFinish(const WorkState &ws, int i, const TrState &st) {
+    if (st.T_ray) {
+        F4 d4 = ws.sq.d[i];
+        const int pixelIndex = (int)FloatToBits(d4.w);
+        S4 Ld = toS4(ws.sq.Ld[i]);
+        const S4 sr_u = toS4(ws.sq.r_u[i]), sr_l = toS4(ws.sq.r_l[i]);
+        Ld = Ld * (st.T_ray / (sr_u * st.r_u + sr_l * st.r_l).Average());
         ws.L[pixelIndex] = toF4(toS4(ws.L[pixelIndex]) + Ld);
     }
+}
+WF_HD void TrStore(const WorkState &ws, int i, const TrState &st) {
+    ws.trO[i] = F4{st.ro.x, st.ro.y, st.ro.z, 0.f};
+    ws.trD[i] = F4{st.rd.x, st.rd.y, st.rd.z, BitsToFloat((uint32_t)st.medium)};
+    ws.trT[i] = toF4(st.T_ray); ws.trRu[i] = toF4(st.r_u); ws.trRl[i] = toF4(st.r_l);
+    ws.trRng[i] = I4{(int32_t)(uint32_t)st.rng.state, (int32_t)(uint32_t)(st.rng.state >> 32), (int32_t)(uint32_t)st.rng.inc, (int32_t)(uint32_t)(st.rng.inc >> 32)};
+}
+WF_HD void TrLoad(const WorkState &ws, int i, TrState *st) {
+    F4 o = ws.trO[i], d = ws.trD[i];
+    st->ro = V3{o.x, o.y, o.z}; st->rd = V3{d.x, d.y, d.z};
+    st->medium = (int)FloatToBits(d.w);
+    st->T_ray = toS4(ws.trT[i]); st->r_u = toS4(ws.trRu[i]); st->r_l = toS4(ws.trRl[i]);
+    I4 r = ws.trRng[i];
+    st->rng.state = (uint64_t)(uint32_t)r.x | ((uint64_t)(uint32_t)r.y << 32);
+    st->rng.inc = (uint64_t)(uint32_t)r.z | ((uint64_t)(uint32_t)r.w << 32);
+}
+// trace(o, d, tMax, &prim, &inst, &b0, &b1, &b2) -> closest hit?
+template <typename Trace>
+WF_HD void KTraceTransmittanceFrom(const SceneView &sv, const WorkState &ws, int i, TrState &st, Trace trace) {
+    const float tMax = ws.sq.o[i].w;
+    while (!(st.rd.x == 0 && st.rd.y == 0 && st.rd.z == 0)) {
+        int prim = -1, inst = -1;
+        float b0 = 0, b1 = 0, b2 = 0;
+        bool hit = trace(st.ro, st.rd, tMax, &prim, &inst, &b0, &b1, &b2);
+        if (!TrSegment(sv, ws, i, &st, hit, prim, inst, b0, b1, b2)) break;
+    }
+    TrFinish(ws, i, st);
+}
+template <typename Trace>
+WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, Trace trace) {
+    TrState st;
+    TrBegin(ws, i, &st);
+    KTraceTransmittanceFrom(sv, ws, i, st, trace);
 }
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537

@@ -72,6 +72,11 @@ struct wf_ctx {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool retracePending = false, deferJoin = false;
     int overlapRetrace = 1;      // WF_OVERLAP_RETRACE=0: everything on one stream
+    // the transmittance wavefront: -1 = for two-level scenes only (default), 1 = always, 0 = never (WF_TR_WAVEFRONT).  Measured on the
+    // cloud-like spec scene (14 triangles, 512^3 grid; gpurun_out/r3j_bench_cloud_tr*.json): per-lane loop 27.9 ms per 16 spp, wavefront
+    // 31.4 ms (begin 3.3 + trace 3.7 + segment 24.1 + rest 0.3) — the time is the ratio tracking through the grid, not the walk, and the
+    // per-lane loop keeps its state in registers; with object instances the per-lane alternative is the reference-order walk (1 wave / SIMD)
+    int trWavefront = -1;
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves and alpha on quadrics, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
@@ -959,6 +964,78 @@ __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, W
         });
 }
 
+// ---- the transmittance wavefront (round 3): TraceTransmittance as launches instead of one loop per lane ------------------------------
+// k_tr_begin sets up the state of every shadow ray (TrBegin) and the first index queue; per segment k_tr_trace walks the live rays
+// with the production closest-hit traversal (two-level scenes included; near ties resolved inside the walk: the scenes of the
+// GEN <= 1 variants) and records the hits in ws.hit / ws.hitInst — free at this point of the depth — and k_tr_segment runs the rest
+// of the loop body (interaction, ratio tracking along the segment, respawn behind an interface), finishing rays or queuing them for
+// the next segment.  After WF_TR_SEGMENTS rounds k_tr_rest finishes what is still alive with the per-lane loop (reference-order walk).
+#ifndef WF_TR_SEGMENTS
+#define WF_TR_SEGMENTS 4
+#endif
+__global__ void __launch_bounds__(BLOCK) k_tr_begin(const SceneView sv, WorkState ws) {
+    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        TrState st;
+        TrBegin(ws, i, &st);
+        if (st.rd.x == 0 && st.rd.y == 0 && st.rd.z == 0) { TrFinish(ws, i, st); continue; }
+        TrStore(ws, i, st);
+        ws.trQ[0][QueueAlloc(&ws.counters[(CNT_TR0) * CNT_STRIDE])] = i;
+    }
+}
+template <int GEN, bool INST>
+__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST) k_tr_trace(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp) {
+    const int n = ws.counters[(CNT_TR0 + cur) * CNT_STRIDE];
+    const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    const int32_t *q = ws.trQ[cur];
+    TraceQueue<false, GEN, INST, true>(
+        sv, bvh, n, st,
+        [&](int j, V3 *o, V3 *d, float *tMax) {
+            const int i = q[j];
+            F4 o4 = ws.trO[i], d4 = ws.trD[i];
+            *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = ws.sq.o[i].w;
+        },
+        [&](int j, bool valid, const RayWalk &w) {
+            if (!valid) return;
+            const int i = q[j];
+            ws.hit[i] = F4{BitsToFloat((uint32_t)w.prim), w.b0, w.b1, w.b2};
+            if (INST) ws.hitInst[i] = w.prim >= 0 ? w.inst : -1;
+        });
+}
+__global__ void __launch_bounds__(BLOCK) k_tr_segment(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_TR0 + cur) * CNT_STRIDE];
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+        const int i = ws.trQ[cur][j];
+        TrState st;
+        TrLoad(ws, i, &st);
+        const F4 h = ws.hit[i];
+        const int prim = (int)FloatToBits(h.x);
+        if (TrSegment(sv, ws, i, &st, prim >= 0, prim, HitInst(sv, ws, i), h.y, h.z, h.w)) {
+            TrStore(ws, i, st);
+            ws.trQ[cur ^ 1][QueueAlloc(&ws.counters[(CNT_TR0 + (cur ^ 1)) * CNT_STRIDE])] = i;
+        } else TrFinish(ws, i, st);
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_tr_rest(const SceneView sv, WorkState ws, int cur, int *stackSpill) {
+    const int n = ws.counters[(CNT_TR0 + cur) * CNT_STRIDE];
+    if (n == 0) return;
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int j = gtid; j < n; j += stride) {
+        const int i = ws.trQ[cur][j];
+        TrState ts;
+        TrLoad(ws, i, &ts);
+        KTraceTransmittanceFrom(sv, ws, i, ts, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
+            ClosestHit ch;
+            st.n = 0;
+            bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+            if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
+            return found;
+        });
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_ESCAPED) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEscaped(sv, ws, cur, i);
@@ -1635,6 +1712,10 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
         if ((e = devAlloc(ctx, &ws.sampleTops, (size_t)5 * pixels_per_pass))) return e;
     if ((e = allocRayQueue(ctx, &ws.rq[0], n)) || (e = allocRayQueue(ctx, &ws.rq[1], n))) return e;
     if (ctx->svHost.haveMedia) {
+        if (getenv("WF_TR_WAVEFRONT")) ctx->trWavefront = atoi(getenv("WF_TR_WAVEFRONT"));
+        if ((e = devAlloc(ctx, &ws.trO, n)) || (e = devAlloc(ctx, &ws.trD, n)) || (e = devAlloc(ctx, &ws.trT, n)) || (e = devAlloc(ctx, &ws.trRu, n)) ||
+            (e = devAlloc(ctx, &ws.trRl, n)) || (e = devAlloc(ctx, &ws.trRng, n)) || (e = devAlloc(ctx, &ws.trQ[0], n)) || (e = devAlloc(ctx, &ws.trQ[1], n)))
+            return e;
         if ((e = devAlloc(ctx, &ws.hitT, n)) || (e = devAlloc(ctx, &ws.mediumSampleQ, n)) || (e = devAlloc(ctx, &ws.mediumScatterQ, n)) ||
             (e = devAlloc(ctx, &ws.scatterP, n)) || (e = devAlloc(ctx, &ws.sq.medium, n)))
             return e;
@@ -1841,7 +1922,24 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
 int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
-    if (ctx->fastOk && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the transmittance walk has no two-level variant yet)
+    if (ctx->fastOk && !ctx->countTraversal && RetraceInline(ctx->genMode) && (ctx->trWavefront == 1 || (ctx->trWavefront < 0 && ctx->svHost.nInstances > 0))) {
+        // the transmittance wavefront (see k_tr_begin)
+        LAUNCH("Reset transmittance queues", k_reset, 1, ctx->ws, (1u << CNT_TR0) | (1u << CNT_TR1), -1, 0);
+        LAUNCH("Intersect shadow (Tr): begin", k_tr_begin, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws);
+        for (int seg = 0; seg < WF_TR_SEGMENTS; ++seg) {
+            const int cur = seg & 1;
+            if (ctx->svHost.nInstances > 0) {
+                if (ctx->genMode == 0) LAUNCHT("Intersect shadow (Tr): trace", (k_tr_trace<0, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, cur, ctx->spillArea());
+                else LAUNCHT("Intersect shadow (Tr): trace", (k_tr_trace<1, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, cur, ctx->spillArea());
+            } else {
+                if (ctx->genMode == 0) LAUNCHT("Intersect shadow (Tr): trace", (k_tr_trace<0, false>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, cur, ctx->spillArea());
+                else LAUNCHT("Intersect shadow (Tr): trace", (k_tr_trace<1, false>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, cur, ctx->spillArea());
+            }
+            LAUNCH("Intersect shadow (Tr): segment", k_tr_segment, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, cur);
+            LAUNCH("Reset transmittance queues", k_reset, 1, ctx->ws, 1u << (CNT_TR0 + cur), -1, 0);
+        }
+        LAUNCH("Intersect shadow (Tr): rest", k_tr_rest, 128, ctx->svHost, ctx->ws, WF_TR_SEGMENTS & 1, ctx->stackSpill);
+    } else if (ctx->fastOk && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the per-lane production walk has no two-level variant)
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
     else

@@ -129,3 +129,5 @@ for name, cfg in make_scenes.BENCH_SMALL.items():
     shutil.rmtree(td)
 json.dump(hashes, open("tests/golden/bench_small_hashes.json", "w"), indent=1)
 PY
+# participating media + object instances: hand-edited tests/golden/media_instances.pbrt (media_box with its conductor box instanced)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_instances_ref.pfm $G/media_instances.pbrt
