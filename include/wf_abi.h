@@ -638,6 +638,23 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
                           wf_hit_record *out, int count_visits);
 int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax,
                       int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested);
+/* The same two calls on caller-owned DEVICE buffers (what a GPU-resident host integrator binds: its RayQueue / ShadowRayQueue stay on
+   the device): rays7 = n x {o[3], d[3], tMax} floats, out = n records / n flags, all device pointers of the context's
+   device; the launches go to the context's stream (wf_stream) and are NOT synchronised — order them with the stream.  The production
+   traversal (near ties resolved as in the render).  wf_device_alloc / free / upload / download are the plain allocation and copy calls
+   of that device for callers without a HIP runtime of their own (uploads and downloads are synchronous). */
+int wf_trace_closest_device(wf_ctx *ctx, int n, const float *rays7, wf_hit_record *out);
+int wf_trace_any_device(wf_ctx *ctx, int n, const float *rays7, int32_t *occluded);
+int wf_device_alloc(wf_ctx *ctx, uint64_t nbytes, void **dptr);
+int wf_device_free(wf_ctx *ctx, void *dptr);
+int wf_device_upload(wf_ctx *ctx, void *dst_device, const void *src_host, uint64_t nbytes);
+int wf_device_download(wf_ctx *ctx, void *dst_host, const void *src_device, uint64_t nbytes);
+/* WavefrontAggregate::IntersectShadowTr (integrator.h:48-50; TraceTransmittance, wavefront/intersect.h:165-274) on caller-supplied
+   shadow rays of a scene with media: per ray o[3], d[3], tmax, the medium id of ray.medium (-1: none), the four wavelengths, and the
+   item's Ld / r_u / r_l (4 floats each).  out_L[4 i ..] = Ld * T_ray / (r_u * r_u' + r_l * r_l').Average(), the value
+   RecordShadowRayResult's caller adds to the pixel (zero when the ray is blocked or the transmittance roulette ends it). */
+int wf_trace_shadow_tr_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const int32_t *medium, const float *lambda,
+                            const float *Ld, const float *r_u, const float *r_l, float *out_L);
 /* WavefrontAggregate::IntersectOneRandom (integrator.h:51-52) on caller-supplied probe segments p0 -> p1 (3 floats each): out[i] =
    the hit of a surface whose material id is material[i], chosen by the reference's weighted reservoir sampling (seed Hash(p0, p1))
    among all such hits along the segment, reservoir_pdf[i] its sample probability (0 and prim = -1: none) */

@@ -9,12 +9,14 @@
 //   IntersectShadow   shadow rays -> wf_trace_any_host -> the reference's RecordShadowRayResult
 //   Bounds            wf_aggregate_bounds
 //   IntersectOneRandom  probe segments -> wf_trace_one_random_host (reservoir over the hits of the item's material) -> SubsurfaceInteraction
-//   IntersectShadowTr: forwarded to the reference's CPUAggregate (scenes with media)
+//   IntersectShadowTr  shadow rays + the items' wavelengths / Ld / r_u / r_l -> wf_trace_shadow_tr_host (TraceTransmittance on the GPU:
+//                     the walk AND the ratio tracking through the scene's media) -> the contribution is added to the pixel sample
 //
 // Everything else — camera rays, samplers, materials, lights, film — stays the reference's CPU code, so the image must be
 // the one `pbrt --wavefront` writes, bit for bit (tests/test_gpu_parity.py::test_reference_integrator_over_hip_aggregate).
-// Scope: triangle meshes without alpha textures, no object instances (the primitive id -> reference primitive map below
-// covers top-level triangles).  Links the shimmed reference build (libpbrt_ref.a); nothing of the reference is modified —
+// Scope (round 3): triangle meshes with or without alpha textures (the GPU walk makes the reference's stochastic alpha test itself),
+// object instances (TransformedPrimitive: the hit's instance id selects the reference's primitive, whose transform takes the
+// interaction to render space exactly as TransformedPrimitive::Intersect does), media.  Quadrics / curves / patches: not mapped.  Links the shimmed reference build (libpbrt_ref.a); nothing of the reference is modified —
 // private members are reached with the test-only `#define private public`.
 //   pbrt_hipagg [--spp N] [--outfile out.pfm] scene.pbrt
 #include <algorithm>
@@ -98,18 +100,24 @@ class HipAggregate : public WavefrontAggregate {
             if (it == ours.end()) ErrorExit("pbrt_hipagg: a reference mesh (%d triangles) has no counterpart in the flat tables", tm->nTriangles);
             firstTri[m] = it->second.first[it->second.second++ % it->second.first.size()];
         }
+        std::vector<const TransformedPrimitive *> refInstances;
+        std::set<const void *> visitedDefs;
         std::function<void(Primitive)> visit = [&](Primitive p) {
             if (!p) return;
             if (p.Is<BVHAggregate>()) {
                 for (Primitive q : p.Cast<BVHAggregate>()->primitives) visit(q);
                 return;
             }
+            if (p.Is<TransformedPrimitive>()) {
+                const TransformedPrimitive *tp = p.Cast<TransformedPrimitive>();
+                refInstances.push_back(tp);
+                if (visitedDefs.insert(tp->primitive.ptr()).second) visit(tp->primitive);   // the definition's own primitives, once
+                return;
+            }
             Shape shape;
             if (p.Is<SimplePrimitive>()) shape = p.Cast<SimplePrimitive>()->shape;
-            else if (p.Is<GeometricPrimitive>()) {
-                shape = p.Cast<GeometricPrimitive>()->shape;
-                if (p.Cast<GeometricPrimitive>()->alpha) ErrorExit("pbrt_hipagg: alpha textures are outside this adapter's scope");
-            } else ErrorExit("pbrt_hipagg: object instances / animated primitives are outside this adapter's scope");
+            else if (p.Is<GeometricPrimitive>()) shape = p.Cast<GeometricPrimitive>()->shape;   // (alpha textures: tested by the GPU walk)
+            else ErrorExit("pbrt_hipagg: animated primitives are outside this adapter's scope");
             if (!shape.Is<Triangle>()) ErrorExit("pbrt_hipagg: only triangle meshes are inside this adapter's scope");
             const Triangle *t = shape.Cast<Triangle>();
             int id = firstTri[t->meshIndex] + t->triIndex;
@@ -117,12 +125,50 @@ class HipAggregate : public WavefrontAggregate {
             prims[id] = p;
             Material mat = p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->material : p.Cast<GeometricPrimitive>()->material;
             materialIds[mat.ptr()] = desc->meshes[desc->tri_mesh[id]].material;
+            if (p.Is<GeometricPrimitive>()) {
+                // the reference's Medium objects <-> the medium ids of the flat tables, through the surfaces that carry both
+                const GeometricPrimitive *g = p.Cast<GeometricPrimitive>();
+                const wf_mesh &mesh = desc->meshes[desc->tri_mesh[id]];
+                if (g->mediumInterface.inside) mediumIds[g->mediumInterface.inside.ptr()] = mesh.medium_inside;
+                if (g->mediumInterface.outside) mediumIds[g->mediumInterface.outside.ptr()] = mesh.medium_outside;
+            }
         };
         visit(cpu->aggregate);
         // identical meshes (same geometry, possibly different materials) may have been handed out in a different order than
         // the primitives were created in: every triangle must still have found exactly one primitive
         for (const Primitive &p : prims)
             if (!p) ErrorExit("pbrt_hipagg: ambiguous mesh matching (identical meshes with different roles)");
+        // object instances: ours (definition id, render-from-instance matrix) <-> the reference's TransformedPrimitive (the definition
+        // is identified through one of its triangles; identical placements of one definition are interchangeable)
+        if (desc->n_instances > 0) {
+            std::vector<int> triDef(nTriangles, -1);
+            for (int k = 0; k < desc->n_instance_defs; ++k)
+                for (int j = 0; j < desc->instance_defs[k].n_prims; ++j) {
+                    const int t = desc->bvh_prims[desc->instance_defs[k].first_prim + j];
+                    if (t >= 0 && t < nTriangles) triDef[t] = k;
+                }
+            std::function<int(Primitive)> anyTriangle = [&](Primitive p) -> int {
+                if (p.Is<BVHAggregate>()) { for (Primitive q : p.Cast<BVHAggregate>()->primitives) { int r = anyTriangle(q); if (r >= 0) return r; } return -1; }
+                Shape shape = p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->shape : p.Is<GeometricPrimitive>() ? p.Cast<GeometricPrimitive>()->shape : Shape();
+                if (!shape || !shape.Is<Triangle>()) return -1;
+                return firstTri[shape.Cast<Triangle>()->meshIndex] + shape.Cast<Triangle>()->triIndex;
+            };
+            instPrims.assign(desc->n_instances, nullptr);
+            std::vector<bool> used(refInstances.size(), false);
+            for (int k = 0; k < desc->n_instances; ++k) {
+                for (size_t r = 0; r < refInstances.size() && !instPrims[k]; ++r) {
+                    if (used[r]) continue;
+                    const int t = anyTriangle(refInstances[r]->primitive);
+                    if (t < 0 || triDef[t] != desc->instances[k].def) continue;
+                    const SquareMatrix<4> &m = refInstances[r]->renderFromPrimitive->GetMatrix();
+                    bool same = true;
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b) same &= std::memcmp(&m[a][b], &desc->instances[k].render_from_instance.m[a][b], 4) == 0 || m[a][b] == desc->instances[k].render_from_instance.m[a][b];
+                    if (same) { instPrims[k] = refInstances[r]; used[r] = true; }
+                }
+                if (!instPrims[k]) ErrorExit("pbrt_hipagg: object instance %d of the flat tables has no counterpart among the reference's primitives", k);
+            }
+        }
     }
 
     Bounds3f Bounds() const override {
@@ -156,12 +202,18 @@ class HipAggregate : public WavefrontAggregate {
             Primitive p = prims[h.prim];
             const Triangle *tri = (p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->shape : p.Cast<GeometricPrimitive>()->shape).Cast<Triangle>();
             TriangleIntersection ti{h.b0, h.b1, h.b2, h.t};
-            SurfaceInteraction intr = Triangle::InteractionFromIntersection(tri->GetMesh(), tri->triIndex, ti, r.ray.time, -r.ray.d);
-            if (p.Is<SimplePrimitive>()) intr.SetIntersectionProperties(p.Cast<SimplePrimitive>()->material, nullptr, nullptr, r.ray.medium);
+            // inside an object instance the interaction is built in the instance's space from the transformed ray and taken to render
+            // space by the instance's transform, as TransformedPrimitive::Intersect does (cpu/primitive.cpp:112-125)
+            const TransformedPrimitive *tp = h.instance >= 0 ? instPrims[h.instance] : nullptr;
+            Ray ray = r.ray;
+            if (tp) { Float tMax = Infinity; ray = tp->renderFromPrimitive->ApplyInverse(r.ray, &tMax); }
+            SurfaceInteraction intr = Triangle::InteractionFromIntersection(tri->GetMesh(), tri->triIndex, ti, ray.time, -ray.d);
+            if (p.Is<SimplePrimitive>()) intr.SetIntersectionProperties(p.Cast<SimplePrimitive>()->material, nullptr, nullptr, ray.medium);
             else {
                 const GeometricPrimitive *g = p.Cast<GeometricPrimitive>();
-                intr.SetIntersectionProperties(g->material, g->areaLight, &g->mediumInterface, r.ray.medium);
+                intr.SetIntersectionProperties(g->material, g->areaLight, &g->mediumInterface, ray.medium);
             }
+            if (tp) intr = (*tp->renderFromPrimitive)(intr);
             EnqueueWorkAfterIntersection(r, r.ray.medium, h.t, intr, mediumSampleQueue, nextRayQueue, hitAreaLightQueue, basicEvalMaterialQueue,
                                          universalEvalMaterialQueue);
         });
@@ -182,7 +234,37 @@ class HipAggregate : public WavefrontAggregate {
         ParallelFor(0, n, [&](int64_t index) { RecordShadowRayResult((*shadowRayQueue)[index], pixelSampleState, occluded[index] != 0); });
     }
 
-    void IntersectShadowTr(int maxRays, ShadowRayQueue *q, SOA<PixelSampleState> *ps) const override { cpu->IntersectShadowTr(maxRays, q, ps); }
+    // TraceTransmittance (wavefront/intersect.h:165-274) on the GPU: walk and ratio tracking over the flat tables' media
+    void IntersectShadowTr(int maxRays, ShadowRayQueue *q, SOA<PixelSampleState> *ps) const override {
+        const int n = q->Size();
+        if (n == 0) return;
+        std::vector<float> o(3 * (size_t)n), d(3 * (size_t)n), tmax(n), lambda(4 * (size_t)n), Ld(4 * (size_t)n), ru(4 * (size_t)n), rl(4 * (size_t)n), out(4 * (size_t)n);
+        std::vector<int32_t> medium(n);
+        for (int i = 0; i < n; ++i) {
+            const ShadowRayWorkItem w = (*q)[i];
+            o[3 * i] = w.ray.o.x; o[3 * i + 1] = w.ray.o.y; o[3 * i + 2] = w.ray.o.z;
+            d[3 * i] = w.ray.d.x; d[3 * i + 1] = w.ray.d.y; d[3 * i + 2] = w.ray.d.z;
+            tmax[i] = w.tMax;
+            medium[i] = -1;
+            if (w.ray.medium) {
+                auto it = mediumIds.find(w.ray.medium.ptr());
+                if (it == mediumIds.end()) ErrorExit("pbrt_hipagg: a shadow ray's medium has no counterpart in the flat tables");
+                medium[i] = it->second;
+            }
+            for (int c = 0; c < 4; ++c) { lambda[4 * i + c] = w.lambda[c]; Ld[4 * i + c] = w.Ld[c]; ru[4 * i + c] = w.r_u[c]; rl[4 * i + c] = w.r_l[c]; }
+        }
+        if (wf_trace_shadow_tr_host(ctx, n, o.data(), d.data(), tmax.data(), medium.data(), lambda.data(), Ld.data(), ru.data(), rl.data(), out.data()) != 0)
+            ErrorExit("wf_trace_shadow_tr_host: %s", wf_last_error());
+        ParallelFor(0, n, [&](int64_t i) {
+            const ShadowRayWorkItem w = (*q)[i];
+            SampledSpectrum add;
+            for (int c = 0; c < 4; ++c) add[c] = out[4 * i + c];
+            if (!add) return;   // blocked / ended by the roulette: nothing is added (intersect.h:267-272)
+            SampledSpectrum Lpixel = ps->L[w.pixelIndex];
+            ps->L[w.pixelIndex] = Lpixel + add;
+        });
+    }
+    void SetCameraMedium(Medium m, int id) { if (m) mediumIds[m.ptr()] = id; }
     // wavefront/aggregate.cpp:90-115: the probe segment's hits with the item's own material, one kept by weighted reservoir sampling
     void IntersectOneRandom(int maxRays, SubsurfaceScatterQueue *q) const override {
         const int n = q->Size();
@@ -219,6 +301,8 @@ class HipAggregate : public WavefrontAggregate {
     wf_ctx *ctx;
     std::vector<Primitive> prims;
     std::map<const void *, int32_t> materialIds;   // the reference's Material (tagged pointer payload) -> material id of the flat tables
+    std::map<const void *, int32_t> mediumIds;     // the reference's Medium -> medium id of the flat tables
+    std::vector<const TransformedPrimitive *> instPrims;   // object instance id of the flat tables -> the reference's primitive
 };
 
 int main(int argc, char **argv) {
@@ -264,7 +348,16 @@ int main(int argc, char **argv) {
             for (int m = 0; m < dd->n_meshes; ++m) { const float *P = dd->P + 3 * (size_t)dd->meshes[m].first_vertex; fprintf(stderr, "ours mesh %d ntris %d nverts %d p0 %a %a %a\n", m, dd->meshes[m].ntris, dd->meshes[m].nverts, P[0], P[1], P[2]); }
             for (size_t m = 0; m < Triangle::allMeshes->size(); ++m) { const TriangleMesh *tm = (*Triangle::allMeshes)[m]; fprintf(stderr, "ref mesh %zu ntris %d nverts %d p0 %a %a %a\n", m, tm->nTriangles, tm->nVertices, tm->p[0].x, tm->p[0].y, tm->p[0].z); }
         }
-        in->aggregate = new HipAggregate(cpu, dryRun ? nullptr : wfh_renderer_ctx(hs), wfh_scene_desc(hs));
+        HipAggregate *agg = new HipAggregate(cpu, dryRun ? nullptr : wfh_renderer_ctx(hs), wfh_scene_desc(hs));
+        {
+            Medium camMedium = nullptr;   // CameraBase::medium (every camera type derives from it)
+            if (in->camera.Is<PerspectiveCamera>()) camMedium = in->camera.Cast<PerspectiveCamera>()->medium;
+            else if (in->camera.Is<OrthographicCamera>()) camMedium = in->camera.Cast<OrthographicCamera>()->medium;
+            else if (in->camera.Is<SphericalCamera>()) camMedium = in->camera.Cast<SphericalCamera>()->medium;
+            else if (in->camera.Is<RealisticCamera>()) camMedium = in->camera.Cast<RealisticCamera>()->medium;
+            agg->SetCameraMedium(camMedium, wfh_scene_desc(hs)->camera.medium);
+        }
+        in->aggregate = agg;
         if (dryRun) { printf("dry run: meshes matched\n"); return 0; }
         Float seconds = in->Render();
         ImageMetadata metadata;

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../common/wf_kernels.h"
@@ -2175,6 +2176,46 @@ int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out) {
     return 0;
 }
 
+int wf_trace_closest_device(wf_ctx *ctx, int n, const float *rays7, wf_hit_record *out) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (n <= 0) return 0;
+    if (!ctx->fastOk) { LAUNCH("trace closest (device rays)", k_trace_closest, gridFor(n), ctx->svHost, n, rays7, out, ctx->stackSpill, 0); return 0; }
+    LAUNCHT_VARIANT("trace closest fast (device rays)", k_trace_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, rays7, out, ctx->spillArea());
+    // (the variants that do not resolve their near ties inside the walk mark them: re-traced in reference order)
+    if (!RetraceInline(ctx->genMode)) LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, rays7, out, ctx->stackSpill, 1);
+    return 0;
+}
+int wf_trace_any_device(wf_ctx *ctx, int n, const float *rays7, int32_t *occluded) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (n <= 0) return 0;
+    if (!ctx->fastOk) { LAUNCH("trace any (device rays)", k_trace_any, gridFor(n), ctx->svHost, n, rays7, occluded, (int32_t *)nullptr, (int32_t *)nullptr, ctx->stackSpill); return 0; }
+    LAUNCHT_VARIANT("trace any fast (device rays)", k_trace_any_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, rays7, occluded, ctx->spillArea());
+    return 0;
+}
+int wf_device_alloc(wf_ctx *ctx, uint64_t nbytes, void **dptr) {
+    if (!ctx || !dptr) return fail(-1, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMalloc(dptr, nbytes ? nbytes : 1));
+    return 0;
+}
+int wf_device_free(wf_ctx *ctx, void *dptr) {
+    if (!ctx) return fail(-1, "null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(dptr));
+    return 0;
+}
+int wf_device_upload(wf_ctx *ctx, void *dst_device, const void *src_host, uint64_t nbytes) {
+    if (!ctx) return fail(-1, "null context");
+    HIPCHK(hipMemcpyAsync(dst_device, src_host, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_device_download(wf_ctx *ctx, void *dst_host, const void *src_device, uint64_t nbytes) {
+    if (!ctx) return fail(-1, "null context");
+    HIPCHK(hipMemcpyAsync(dst_host, src_device, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, wf_hit_record *out, int count_visits) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     if (n <= 0) return 0;
@@ -2190,14 +2231,53 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
     HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (count_visits || !ctx->fastOk) {
         LAUNCH("trace closest (host rays)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 0);
-    } else {
-        LAUNCHT_VARIANT("trace closest fast (host rays)", k_trace_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dh, ctx->spillArea());
-        LAUNCH("trace closest (near-tie re-trace)", k_trace_closest, gridFor(n), ctx->svHost, n, dr, dh, ctx->stackSpill, 1);
-    }
+    } else if (int e = wf_trace_closest_device(ctx, n, dr, dh)) return e;
     HIPCHK(hipMemcpyAsync(out, dh, (size_t)n * sizeof(wf_hit_record), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(dr));
     HIPCHK(hipFree(dh));
+    return 0;
+}
+// IntersectShadowTr on caller-supplied shadow rays: a scratch WorkState over temporary device arrays (one "pixel" per ray) run through
+// the same transmittance kernels as the render
+int wf_trace_shadow_tr_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const int32_t *medium, const float *lambda,
+                            const float *Ld, const float *r_u, const float *r_l, float *out_L) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (!ctx->svHost.haveMedia) return fail(-1, "wf_trace_shadow_tr_host: the scene has no media");
+    if (n <= 0) return 0;
+    std::vector<F4> ho(n), hd(n), hl(n), hp(n, F4{1, 1, 1, 1});
+    for (int i = 0; i < n; ++i) {
+        ho[i] = F4{o[3 * i], o[3 * i + 1], o[3 * i + 2], tmax[i]};
+        hd[i] = F4{d[3 * i], d[3 * i + 1], d[3 * i + 2], BitsToFloat((uint32_t)i)};   // pixelIndex = i
+        hl[i] = F4{lambda[4 * i], lambda[4 * i + 1], lambda[4 * i + 2], lambda[4 * i + 3]};
+    }
+    WorkState ws = ctx->ws;   // counters / stats of the context, every per-item array replaced below
+    std::vector<void *> tmp;
+    auto up = [&](auto **dst, const void *src, size_t bytes) -> int {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, bytes));
+        tmp.push_back(p);
+        if (src) HIPCHK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        else HIPCHK(hipMemsetAsync(p, 0, bytes, ctx->stream));
+        *dst = (std::remove_reference_t<decltype(**dst)> *)p;
+        return 0;
+    };
+    int e;
+    int32_t *cnt = nullptr;
+    if ((e = up(&ws.sq.o, ho.data(), n * sizeof(F4))) || (e = up(&ws.sq.d, hd.data(), n * sizeof(F4))) || (e = up(&ws.sq.Ld, Ld, n * sizeof(F4))) ||
+        (e = up(&ws.sq.r_u, r_u, n * sizeof(F4))) || (e = up(&ws.sq.r_l, r_l, n * sizeof(F4))) || (e = up(&ws.sq.medium, medium, n * sizeof(int32_t))) ||
+        (e = up(&ws.lambda, hl.data(), n * sizeof(F4))) || (e = up(&ws.lambdaPdf, hp.data(), n * sizeof(F4))) || (e = up(&ws.L, nullptr, n * sizeof(F4))) ||
+        (e = up(&cnt, nullptr, (size_t)CNT_COUNT * CNT_STRIDE * sizeof(int32_t))))
+        return e;
+    HIPCHK(hipMemcpyAsync(cnt + CNT_SHADOW * CNT_STRIDE, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ws.counters = cnt;
+    if (ctx->fastOk && ctx->svHost.nInstances == 0) {
+        if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("shadow Tr (host rays)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ws, ctx->fast, ctx->spillArea());
+        else LAUNCHT("shadow Tr (host rays)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ws, ctx->fast, ctx->spillArea());
+    } else LAUNCH("shadow Tr (host rays)", k_shadow_tr, gridFor(n), ctx->svHost, ws, ctx->stackSpill);
+    HIPCHK(hipMemcpyAsync(out_L, ws.L, n * sizeof(F4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (void *p : tmp) HIPCHK(hipFree(p));
     return 0;
 }
 int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p1, const int32_t *material, wf_hit_record *out, float *reservoir_pdf) {
@@ -2237,9 +2317,7 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     if (nodes_visited || tris_tested || !ctx->fastOk) {
         LAUNCH("trace any (host rays)", k_trace_any, gridFor(n), ctx->svHost, n, dr, dres, dres + n, dres + 2 * (size_t)n, ctx->stackSpill);
-    } else {
-        LAUNCHT_VARIANT("trace any fast (host rays)", k_trace_any_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->fast, n, dr, dres, ctx->spillArea());
-    }
+    } else if (int e = wf_trace_any_device(ctx, n, dr, dres)) return e;
     HIPCHK(hipMemcpyAsync(occluded, dres, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (nodes_visited) HIPCHK(hipMemcpyAsync(nodes_visited, dres + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (tris_tested) HIPCHK(hipMemcpyAsync(tris_tested, dres + 2 * (size_t)n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -59,6 +59,7 @@ ABI_SYMBOLS = [
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_queue_size", "wf_queue_download",
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",
+    "wf_trace_closest_device", "wf_trace_any_device", "wf_device_alloc", "wf_device_free", "wf_device_upload", "wf_device_download", "wf_trace_shadow_tr_host",
 ]
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",

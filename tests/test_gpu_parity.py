@@ -408,7 +408,8 @@ def test_samples_per_pass_invariance(wfpt):
         assert st["shadow_rays"] == stats[0]["shadow_rays"]
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "subsurface"])
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "subsurface", "instances", "alpha_normalmap", "media_box", "media_instances",
+                                  "sanmiguel_like_small"])
 def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     """The drop-in boundary, compiled and run: oracle/_ref/pbrt_hipagg is the REFERENCE's own WavefrontPathIntegrator (its
     CPU camera / sampler / material / light / film code, linked from the unmodified sources) with its WavefrontAggregate
@@ -419,11 +420,55 @@ def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/pbrt_hipagg not built (needs /root/reference at build time)")
     out = str(tmp_path / "agg.pfm")
-    subprocess.run([exe, "--spp", "4", "--outfile", out, os.path.join(GOLDEN, name + ".pbrt")], check=True, cwd=str(tmp_path))
+    # (round 3: object instances — the hit's instance id selects the reference's TransformedPrimitive —, alpha cut-outs — tested by the
+    # GPU walk —, and scenes with media — IntersectShadowTr answered by wf_trace_shadow_tr_host — cross the boundary too, and with
+    # them the downscaled headline scene)
+    scene_path = os.path.join(GOLDEN, name + ".pbrt")
+    if name == "sanmiguel_like_small":
+        from conftest import bench_small_scene
+        scene_path, _ = bench_small_scene(name, tmp_path / "scene")
+    subprocess.run([exe, "--spp", "4", "--outfile", out, scene_path], check=True, cwd=str(tmp_path))
     img = read_pfm(out)
     ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))
     assert img.shape == ref.shape
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()
+
+
+def test_device_pointer_entry_points(wfpt, blobs):
+    """wf_trace_closest_device / wf_trace_any_device on caller-owned device buffers (wf_device_alloc / upload / download) return what the
+    host-array entry points return."""
+    import ctypes as C
+    _, hip = wfpt.libs()
+    lo, hi = blobs.bounds()
+    o, d, tmax = _random_rays(5000, lo, hi, 3)
+    want = blobs.trace_closest(o, d, tmax, reference_order=False)
+    occ_want, _, _ = blobs.trace_any(o, d, tmax, reference_order=False)
+    rays = np.ascontiguousarray(np.concatenate([o, d, tmax[:, None]], axis=1), dtype=np.float32)
+    n = rays.shape[0]
+    hip.wf_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    hip.wf_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    hip.wf_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    hip.wf_device_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    hip.wf_trace_closest_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    hip.wf_trace_any_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    d_rays, d_hits, d_occ = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.wf_device_alloc(blobs.ctx, rays.nbytes, C.byref(d_rays)) == 0
+    assert hip.wf_device_alloc(blobs.ctx, n * want.dtype.itemsize, C.byref(d_hits)) == 0
+    assert hip.wf_device_alloc(blobs.ctx, n * 4, C.byref(d_occ)) == 0
+    assert hip.wf_device_upload(blobs.ctx, d_rays, rays.ctypes.data, rays.nbytes) == 0
+    assert hip.wf_trace_closest_device(blobs.ctx, n, d_rays, d_hits) == 0
+    assert hip.wf_trace_any_device(blobs.ctx, n, d_rays, d_occ) == 0
+    got = np.empty(n, dtype=want.dtype)
+    occ = np.empty(n, dtype=np.int32)
+    assert hip.wf_device_download(blobs.ctx, got.ctypes.data, d_hits, got.nbytes) == 0     # (synchronises the context's stream)
+    assert hip.wf_device_download(blobs.ctx, occ.ctypes.data, d_occ, occ.nbytes) == 0
+    for f in ("prim", "instance"):
+        assert (got[f] == want[f]).all()
+    for f in ("t", "b0", "b1", "b2"):
+        assert (got[f].view(np.uint32) == want[f].view(np.uint32)).all()
+    assert (occ == occ_want).all()
+    for p in (d_rays, d_hits, d_occ):
+        assert hip.wf_device_free(blobs.ctx, p) == 0
 
 
 def test_strip_partition_two_contexts_bit_identical(wfpt, tmp_path, monkeypatch):
