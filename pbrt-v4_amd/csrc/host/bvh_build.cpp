@@ -2,11 +2,20 @@
 // Restates BVHAggregate: constructor cpu/aggregates.cpp:140-196; the SAH path buildRecursive :198-387 (12 buckets, leaf when
 // cost says so and n <= maxPrimsInNode); the HLBVH path buildHLBVH :389-447 + emitLBVH :449-503 + buildUpperSAH :626-722
 // (Morton codes of the centroids, stable radix sort — on the GPU through wf_morton_sort when a device is there —, one LBVH
-// treelet per 12-bit Morton prefix, SAH over the treelet roots); flattenBVH :505-521.  The builds are sequential (the
-// reference's parallel sections only permute the storage order of leaves, which no result depends on).
+// treelet per 12-bit Morton prefix, SAH over the treelet roots); flattenBVH :505-521.
+// The SAH build is task-parallel like the reference's (cpu/aggregates.cpp:366-381 builds the two children of a large span
+// concurrently) and, unlike it, deterministic: a leaf's primitives are written at the span's own offset — in sequential depth-first
+// order leaf k's first primitive IS position k of the partitioned span array — instead of at an atomic counter, so the node and
+// primitive arrays are the sequential build's for any thread count (round 3: 2.6 s -> see DESIGN.md 4.3 on the 10 M-triangle scene).
 #include "scene.h"
 
 #include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 
 namespace wf {
 namespace {
@@ -20,35 +29,57 @@ struct BuildNode {
     B3 bounds;
     BuildNode *children[2] = {nullptr, nullptr};
     int splitAxis = 0, firstPrimOffset = 0, nPrimitives = 0;
+    int nodeCount = 1;   // nodes of the subtree (flattening lays subtrees out at known offsets: in parallel)
 };
 MortonSortFn g_mortonSort = nullptr;
 
 struct Builder {
     int maxPrimsInNode;
-    std::vector<BuildNode> pool;
+    BuildNode *pool = nullptr;   // raw storage for 2 n nodes (not value-initialised: 450 MB for the 4 M-primitive top level)
+    ~Builder() { free(pool); }
     std::vector<int32_t> *ordered;
-    int totalNodes = 0;
-    size_t poolUsed = 0;
-    BuildNode *NewNode() { return &pool[poolUsed++]; }
+    std::atomic<int> totalNodes{0};
+    std::atomic<size_t> poolUsed{0};
+    BuildNode *NewNode() { return new (&pool[poolUsed++]) BuildNode(); }
+    // task parallelism of the SAH build: a span larger than kParallelSpan hands its first child to a helper thread while helpers are left
+    static constexpr int kParallelSpan = 16 * 1024;
+    static constexpr int kChunkedSpan = 256 * 1024;
+    std::atomic<int> helpersLeft{0};
 
-    void InitLeaf(BuildNode *node, BVHPrim *prims, int n, const B3 &bounds) {
-        int first = (int)ordered->size();
-        for (int i = 0; i < n; ++i) ordered->push_back(prims[i].index);
+    // (SAH path) prims = the span of the partitioned array that starts at position `first` of the whole array
+    void InitLeaf(BuildNode *node, BVHPrim *prims, int n, const B3 &bounds, int first) {
+        for (int i = 0; i < n; ++i) (*ordered)[first + i] = prims[i].index;
         node->firstPrimOffset = first;
         node->nPrimitives = n;
         node->bounds = bounds;
     }
 
-    BuildNode *Build(BVHPrim *prims, int n) {
+    BuildNode *Build(BVHPrim *prims, int n, int first) {
         BuildNode *node = NewNode();
         ++totalNodes;
-        B3 bounds;
-        for (int i = 0; i < n; ++i) bounds = Union(bounds, prims[i].bounds);
-        if (bounds.SurfaceArea() == 0 || n == 1) { InitLeaf(node, prims, n, bounds); return node; }
-        B3 centroidBounds;
-        for (int i = 0; i < n; ++i) centroidBounds = Union(centroidBounds, prims[i].Centroid());
+        // (spans of millions of primitives — the first levels of a large tree, where there are not yet enough subtrees to keep the
+        // helpers busy — run their reductions in chunks on helper threads: unions and counts are exact, so the result is the loop's)
+        const int nChunks = n >= kChunkedSpan ? std::min(16, std::max(1, helpersLeft.load())) : 1;
+        auto chunked = [&](auto &&body) {   // body(chunk, i0, i1)
+            if (nChunks <= 1) { body(0, 0, n); return; }
+            std::vector<std::thread> th;
+            for (int c = 1; c < nChunks; ++c) th.emplace_back([&, c] { body(c, (int)((long long)n * c / nChunks), (int)((long long)n * (c + 1) / nChunks)); });
+            body(0, 0, (int)((long long)n / nChunks));
+            for (auto &t : th) t.join();
+        };
+        B3 bounds, centroidBounds;
+        {
+            B3 pb[16], pc[16];
+            chunked([&](int c, int i0, int i1) {
+                B3 b, cb;
+                for (int i = i0; i < i1; ++i) { b = Union(b, prims[i].bounds); cb = Union(cb, prims[i].Centroid()); }
+                pb[c] = b; pc[c] = cb;
+            });
+            for (int c = 0; c < nChunks; ++c) { bounds = Union(bounds, pb[c]); centroidBounds = Union(centroidBounds, pc[c]); }
+        }
+        if (bounds.SurfaceArea() == 0 || n == 1) { InitLeaf(node, prims, n, bounds, first); return node; }
         int dim = centroidBounds.MaxDimension();
-        if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) { InitLeaf(node, prims, n, bounds); return node; }
+        if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) { InitLeaf(node, prims, n, bounds, first); return node; }
         int mid = n / 2;
         if (n <= 2) {
             std::nth_element(prims, prims + mid, prims + n,
@@ -56,11 +87,19 @@ struct Builder {
         } else {
             constexpr int nBuckets = 12;
             struct Bucket { int count = 0; B3 bounds; } buckets[nBuckets];
-            for (int i = 0; i < n; ++i) {
-                int b = nBuckets * centroidBounds.Offset(prims[i].Centroid())[dim];
-                if (b == nBuckets) b = nBuckets - 1;
-                buckets[b].count++;
-                buckets[b].bounds = Union(buckets[b].bounds, prims[i].bounds);
+            {
+                std::vector<std::array<Bucket, nBuckets>> part(nChunks);
+                chunked([&](int c, int i0, int i1) {
+                    std::array<Bucket, nBuckets> &bk = part[c];
+                    for (int i = i0; i < i1; ++i) {
+                        int b = nBuckets * centroidBounds.Offset(prims[i].Centroid())[dim];
+                        if (b == nBuckets) b = nBuckets - 1;
+                        bk[b].count++;
+                        bk[b].bounds = Union(bk[b].bounds, prims[i].bounds);
+                    }
+                });
+                for (int c = 0; c < nChunks; ++c)
+                    for (int b = 0; b < nBuckets; ++b) { buckets[b].count += part[c][b].count; buckets[b].bounds = Union(buckets[b].bounds, part[c][b].bounds); }
             }
             constexpr int nSplits = nBuckets - 1;
             float costs[nSplits] = {};
@@ -91,15 +130,25 @@ struct Builder {
                     return b <= minCostSplitBucket;
                 });
                 mid = int(midIter - prims);
-            } else { InitLeaf(node, prims, n, bounds); return node; }
+            } else { InitLeaf(node, prims, n, bounds, first); return node; }
         }
-        BuildNode *c0 = Build(prims, mid);
-        BuildNode *c1 = Build(prims + mid, n - mid);
+        BuildNode *c0 = nullptr, *c1 = nullptr;
+        if (n > kParallelSpan && helpersLeft.fetch_sub(1) > 0) {
+            std::thread helper([&] { c0 = Build(prims, mid, first); });
+            c1 = Build(prims + mid, n - mid, first + mid);
+            helper.join();
+            helpersLeft.fetch_add(1);
+        } else {
+            if (n > kParallelSpan) helpersLeft.fetch_add(1);   // (the failed reservation)
+            c0 = Build(prims, mid, first);
+            c1 = Build(prims + mid, n - mid, first + mid);
+        }
         node->children[0] = c0;
         node->children[1] = c1;
         node->bounds = Union(c0->bounds, c1->bounds);
         node->splitAxis = dim;
         node->nPrimitives = 0;
+        node->nodeCount = 1 + c0->nodeCount + c1->nodeCount;
         return node;
     }
 
@@ -140,6 +189,7 @@ struct Builder {
         node->bounds = Union(c0->bounds, c1->bounds);
         node->splitAxis = bitIndex % 3;
         node->nPrimitives = 0;
+        node->nodeCount = 1 + c0->nodeCount + c1->nodeCount;
         return node;
     }
     BuildNode *BuildUpperSAH(std::vector<BuildNode *> &roots, int start, int end) {
@@ -186,6 +236,7 @@ struct Builder {
         node->bounds = Union(c0->bounds, c1->bounds);
         node->splitAxis = dim;
         node->nPrimitives = 0;
+        node->nodeCount = 1 + c0->nodeCount + c1->nodeCount;
         return node;
     }
     BuildNode *BuildHLBVH(const BVHPrim *prims, int n) {
@@ -226,22 +277,32 @@ struct Builder {
         return BuildUpperSAH(treelets, 0, (int)treelets.size());
     }
 
-    int Flatten(const BuildNode *node, std::vector<wf_bvh_node> *out, int *offset) {
-        wf_bvh_node *ln = &(*out)[*offset];
+    // flattenBVH (cpu/aggregates.cpp:505-521): depth-first, first child right behind its parent; a subtree of k nodes occupies
+    // [at, at + k), so the two children of a large subtree are laid out concurrently
+    void Flatten(const BuildNode *node, wf_bvh_node *out, int at) {
+        wf_bvh_node *ln = &out[at];
+        *ln = wf_bvh_node{};
         for (int c = 0; c < 3; ++c) { ln->bmin[c] = node->bounds.pMin[c]; ln->bmax[c] = node->bounds.pMax[c]; }
-        int nodeOffset = (*offset)++;
         if (node->nPrimitives > 0) {
             ln->offset = node->firstPrimOffset;
             ln->nprims = (uint16_t)node->nPrimitives;
             ln->axis = 0;
-        } else {
-            ln->axis = (uint8_t)node->splitAxis;
-            ln->nprims = 0;
-            Flatten(node->children[0], out, offset);
-            int second = Flatten(node->children[1], out, offset);
-            (*out)[nodeOffset].offset = second;
+            return;
         }
-        return nodeOffset;
+        ln->axis = (uint8_t)node->splitAxis;
+        ln->nprims = 0;
+        const int second = at + 1 + node->children[0]->nodeCount;
+        ln->offset = second;
+        if (node->nodeCount > 2 * kParallelSpan && helpersLeft.fetch_sub(1) > 0) {
+            std::thread helper([&] { Flatten(node->children[0], out, at + 1); });
+            Flatten(node->children[1], out, second);
+            helper.join();
+            helpersLeft.fetch_add(1);
+        } else {
+            if (node->nodeCount > 2 * kParallelSpan) helpersLeft.fetch_add(1);
+            Flatten(node->children[0], out, at + 1);
+            Flatten(node->children[1], out, second);
+        }
     }
 };
 
@@ -266,15 +327,25 @@ int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode,
     for (int i = 0; i < nAll; ++i) { prims[i].index = primsIn[i].first; prims[i].bounds = primsIn[i].second; }
     const int nodeBase = (int)nodes->size(), primBase = (int)orderedPrims->size();
     std::vector<int32_t> ordered;
-    ordered.reserve(nAll);
+    if (splitMethod == 1) ordered.reserve(nAll);   // (the HLBVH path appends leaf by leaf)
+    else ordered.assign(nAll, -1);
     Builder bld;
     bld.maxPrimsInNode = std::min(255, maxPrimsInNode);
-    bld.pool.resize(2 * (size_t)nAll);
+    bld.pool = (BuildNode *)malloc(2 * (size_t)nAll * sizeof(BuildNode));
+    if (!bld.pool) return -1;
     bld.ordered = &ordered;
-    BuildNode *root = splitMethod == 1 ? bld.BuildHLBVH(prims.data(), nAll) : bld.Build(prims.data(), nAll);
-    std::vector<wf_bvh_node> local(bld.totalNodes, wf_bvh_node{});
-    int offset = 0;
-    bld.Flatten(root, &local, &offset);
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("WF_BUILD_THREADS")) threads = atoi(e);
+    bld.helpersLeft = std::max(0, std::min(threads, 256) - 1);
+    const bool timing = getenv("WF_LOAD_TIMING") != nullptr && nAll > 1000000;
+    auto t0 = std::chrono::steady_clock::now();
+    BuildNode *root = splitMethod == 1 ? bld.BuildHLBVH(prims.data(), nAll) : bld.Build(prims.data(), nAll, 0);
+    auto t1 = std::chrono::steady_clock::now();
+    if (root->nodeCount != bld.totalNodes) return -1;
+    std::vector<wf_bvh_node> local((size_t)bld.totalNodes);
+    bld.Flatten(root, local.data(), 0);
+    if (timing) fprintf(stderr, "[load]   BuildBVH(%d prims): build %.3f s, flatten %.3f s\n", nAll, std::chrono::duration<double>(t1 - t0).count(),
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     for (wf_bvh_node &n : local) n.offset += n.nprims > 0 ? primBase : nodeBase;  // leaf: primitivesOffset, interior: secondChildOffset
     nodes->insert(nodes->end(), local.begin(), local.end());
     orderedPrims->insert(orderedPrims->end(), ordered.begin(), ordered.end());

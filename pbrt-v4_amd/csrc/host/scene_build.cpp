@@ -22,7 +22,9 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <set>
 #include <thread>
+#include <mutex>
 #include <atomic>
 
 namespace wf {
@@ -1801,6 +1803,10 @@ struct MeshSource {
 };
 
 bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err);
+// PLY files read ahead by a pool of threads (PrefetchPLY below: a San-Miguel-class scene has thousands of them); an entry is handed
+// out once (moved), a file that failed to read stays absent and is read — and reported — again by the shape that names it
+struct PlyPrefetch { std::map<std::string, MeshSource> meshes; std::map<std::string, int> uses; };
+static thread_local PlyPrefetch *g_plyPrefetch = nullptr;
 
 bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSource *m) {
     const ParamSet &ps = sh.params;
@@ -1835,7 +1841,16 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         std::string fn = ps.GetOneString("filename", "");
         if (!fn.empty() && fn[0] != '/') fn = baseDir + "/" + fn;
         std::string err;
-        if (!ReadPLY(fn, m, &err)) Die(sh.loc, fn + ": " + err);
+        bool have = false;
+        if (g_plyPrefetch) {
+            auto it = g_plyPrefetch->meshes.find(fn);
+            if (it != g_plyPrefetch->meshes.end()) {
+                if (--g_plyPrefetch->uses[fn] <= 0) { *m = std::move(it->second); g_plyPrefetch->meshes.erase(it); }   // last user: no copy
+                else *m = it->second;
+                have = true;
+            }
+        }
+        if (!have && !ReadPLY(fn, m, &err)) Die(sh.loc, fn + ": " + err);
         if (!ps.GetTexture("displacement").empty()) Die(sh.loc, "plymesh displacement is not supported by this build");
         return true;
     }
@@ -2354,6 +2369,45 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         }
         commitMesh(mesh, meshId, sh, rfo, inDefinition);
     };
+    // read every PLY file the scene uses with a pool of threads first (the shape loop below then finds them in memory)
+    PlyPrefetch prefetch;
+    {
+        std::vector<std::string> files;
+        auto want = [&](const ShapeEntity &sh) {
+            if (sh.name != "plymesh") return;
+            std::string fn = sh.params.GetOneString("filename", "");
+            if (fn.empty()) return;
+            if (fn[0] != '/') fn = scene.baseDir + "/" + fn;
+            if (prefetch.uses[fn]++ == 0) files.push_back(fn);
+        };
+        for (const ShapeEntity &sh : scene.shapes) want(sh);
+        std::set<std::string> seenDefs;
+        for (const InstanceUse &u : scene.instances) {
+            auto it = scene.instanceDefinitions.find(u.name);
+            if (it == scene.instanceDefinitions.end() || !seenDefs.insert(u.name).second) continue;
+            for (const ShapeEntity &sh : it->second.shapes) want(sh);
+        }
+        if (files.size() >= 8) {
+            std::vector<MeshSource> loaded(files.size());
+            std::vector<char> ok(files.size(), 0);
+            std::atomic<size_t> next{0};
+            unsigned nt = std::max(1u, std::min((unsigned)files.size(), std::thread::hardware_concurrency()));
+            if (const char *e = getenv("WF_BUILD_THREADS")) nt = std::max(1, atoi(e));
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&] {
+                    for (size_t i = next++; i < files.size(); i = next++) {
+                        std::string err;
+                        try { ok[i] = ReadPLY(files[i], &loaded[i], &err) ? 1 : 0; } catch (...) { ok[i] = 0; }
+                    }
+                });
+            for (auto &th : pool) th.join();
+            for (size_t i = 0; i < files.size(); ++i)
+                if (ok[i]) prefetch.meshes.emplace(files[i], std::move(loaded[i]));
+            g_plyPrefetch = &prefetch;
+        }
+    }
+    struct PrefetchScope { ~PrefetchScope() { g_plyPrefetch = nullptr; } } prefetchScope;
     for (const ShapeEntity &sh : scene.shapes) addShape(sh, &topPrims, false);
     // instance definitions (scene.cpp:1522-1557): the shapes stay in the definition's own render space, each definition
     // gets its own BVH; only definitions that are used are built
@@ -2989,15 +3043,41 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         std::vector<wf_bvh_node> defNodes;
         std::vector<int32_t> defOrdered;
         T->instanceDefs.resize(defPrims.size());
-        for (size_t d = 0; d < defPrims.size(); ++d) {
-            wf_instance_def &def = T->instanceDefs[d];
-            def = wf_instance_def{};
-            def.first_prim = (int)defOrdered.size();
-            def.n_prims = (int)defPrims[d].size();
-            def.bvh_root = BuildBVH(defPrims[d], 1, &defNodes, &defOrdered);
-            def.n_nodes = (int)defNodes.size() - (def.bvh_root < 0 ? (int)defNodes.size() : def.bvh_root);
-            if (def.bvh_root >= 0)
-                for (int c = 0; c < 3; ++c) { def.bounds[c] = defNodes[def.bvh_root].bmin[c]; def.bounds[3 + c] = defNodes[def.bvh_root].bmax[c]; }
+        {
+            // the definitions' trees are independent: built concurrently into local arrays (a pool of threads takes them in turn), then
+            // appended in definition order — the arrays are the sequential loop's
+            std::vector<std::vector<wf_bvh_node>> ln(defPrims.size());
+            std::vector<std::vector<int32_t>> lo(defPrims.size());
+            std::vector<int> lroot(defPrims.size(), -1);
+            std::atomic<size_t> next{0};
+            unsigned nt = std::max(1u, std::min((unsigned)defPrims.size(), std::thread::hardware_concurrency()));
+            if (const char *e = getenv("WF_BUILD_THREADS")) nt = std::max(1, atoi(e));
+            std::vector<std::thread> pool;
+            std::string firstError;
+            std::mutex errMutex;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&] {
+                    for (size_t d = next++; d < defPrims.size(); d = next++) {
+                        try { lroot[d] = BuildBVH(defPrims[d], 1, &ln[d], &lo[d]); }
+                        catch (const std::exception &e) { std::lock_guard<std::mutex> g(errMutex); if (firstError.empty()) firstError = e.what(); }
+                    }
+                });
+            for (auto &th : pool) th.join();
+            if (!firstError.empty()) throw SceneError(firstError);
+            for (size_t d = 0; d < defPrims.size(); ++d) {
+                wf_instance_def &def = T->instanceDefs[d];
+                def = wf_instance_def{};
+                def.first_prim = (int)defOrdered.size();
+                def.n_prims = (int)defPrims[d].size();
+                const int nodeBase = (int)defNodes.size(), primBase = (int)defOrdered.size();
+                def.bvh_root = lroot[d] < 0 ? -1 : nodeBase + lroot[d];
+                for (wf_bvh_node &n : ln[d]) n.offset += n.nprims > 0 ? primBase : nodeBase;
+                defNodes.insert(defNodes.end(), ln[d].begin(), ln[d].end());
+                defOrdered.insert(defOrdered.end(), lo[d].begin(), lo[d].end());
+                def.n_nodes = (int)defNodes.size() - (def.bvh_root < 0 ? (int)defNodes.size() : def.bvh_root);
+                if (def.bvh_root >= 0)
+                    for (int c = 0; c < 3; ++c) { def.bounds[c] = defNodes[def.bvh_root].bmin[c]; def.bounds[3 + c] = defNodes[def.bvh_root].bmax[c]; }
+            }
         }
         tick("instance-definition BVHs (SAH)");
         // the instances (scene.cpp:1560-1577): TransformedPrimitive(definition, renderFromInstance), after the shapes
