@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 5
+#define WF_ABI_VERSION 6
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -49,7 +49,9 @@ typedef struct wf_transform {    /* util/transform.h:Transform — m and its inv
  * phase function.  Spectra are DenselySampledSpectrum tables (471 floats each in spectrum_data), already
  * multiplied by the medium's "scale" / Le scale as the reference's constructors do (media.h:233-241). */
 enum wf_medium_type { WF_MEDIUM_HOMOGENEOUS = 0, WF_MEDIUM_GRID = 1, WF_MEDIUM_RGB_GRID = 2,
-                      WF_MEDIUM_CLOUD = 3 /* media.h:430-525: procedural density from Perlin noise inside `bounds`, one homogeneous majorant */ };
+                      WF_MEDIUM_CLOUD = 3 /* media.h:430-525: procedural density from Perlin noise inside `bounds`, one homogeneous majorant */,
+                      WF_MEDIUM_NANOVDB = 4 /* media.h:599-679: density (and temperature) FloatGrids, expanded to dense blocks over their index
+                                               bounding boxes; 64^3 majorant grid over the world bounding box.  Parity unpinned (third-party format) */ };
 typedef struct wf_medium {
     int32_t type;
     int32_t sigma_a_offset, sigma_s_offset, le_offset;   /* offsets into spectrum_data */
@@ -70,6 +72,14 @@ typedef struct wf_medium {
     float temperature_shift, temperature_scale;
     /* CloudMedium */
     float cloud_density, cloud_wispiness, cloud_frequency;
+    /* NanoVDBMedium: the dense density block = medium_data[density_offset ..], vdb_dim[0] * vdb_dim[1] * vdb_dim[2] floats, x fastest,
+       voxel (i, j, k) at (i - vdb_min[0], ...); index coordinates of a medium-space point p: vdb_inv_mat * (p - vdb_vec)
+       (nanovdb::Map::applyInverseMapF); vdb_background outside the block.  The temperature grid (temperature_offset; -1: none) likewise;
+       le_scale = "Lescale", temperature_shift / temperature_scale as for the grid medium */
+    int32_t vdb_min[3], vdb_dim[3];
+    float vdb_inv_mat[9], vdb_vec[3], vdb_background;
+    int32_t vdbt_min[3], vdbt_dim[3];
+    float vdbt_inv_mat[9], vdbt_vec[3], vdbt_background;
 } wf_medium;
 
 /* Spectrum (util/spectrum.h:48-67 TaggedPointer family) flattened to a 32-byte descriptor.

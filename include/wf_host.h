@@ -58,6 +58,12 @@ int wfh_write_image(const char *path, const float *rgb, int w, int h);
    Call with pixels = NULL to get the size; returns 0, or -1 with wfh_last_error(). format: 0 8-bit, 1 half, 2 float storage. */
 int wfh_read_image(const char *path, const char *encoding, int32_t *width, int32_t *height, int32_t *n_channels, int32_t *format, float *pixels);
 
+/* The NanoVDB reader of the "nanovdb" medium (csrc/host/nanovdb_io.cpp; parity unpinned: third-party format), for tools and tests:
+   the float grid `grid_name` of `path` expanded over its index bounding box.  min / dim = origin and size of the block, inv_mat (9) and
+   vec (3) = the grid's index-from-world map (index = inv_mat * (p - vec)), background; values = dim[0] * dim[1] * dim[2] floats (x
+   fastest) or NULL to query the sizes first.  Returns 0, 1 if the file has no grid of that name, -1 on error (wfh_last_error). */
+int wfh_read_nanovdb(const char *path, const char *grid_name, int32_t min[3], int32_t dim[3], float inv_mat[9], float vec[3], float *background, float *values);
+
 #ifdef __cplusplus
 }
 #endif

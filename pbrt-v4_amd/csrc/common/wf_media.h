@@ -133,6 +133,22 @@ WF_HD S4 RGBGridLookup(const float *v, int nx, int ny, int nz, V3 p, const S4 &l
     S4 d11 = LerpS(d.x, RGBGridCell(v, nx, ny, nz, ix, iy + 1, iz + 1, lam), RGBGridCell(v, nx, ny, nz, ix + 1, iy + 1, iz + 1, lam));
     return LerpS(d.z, LerpS(d.y, d00, d10), LerpS(d.y, d01, d11));
 }
+// nanovdb::SampleFromVoxels<Tree, 1, false> on a dense block: Map::applyInverseMapF (fmaf chain of matMult), Floor, TrilinearSampler::sample
+WF_HD float VdbSample(const float *data, const int32_t vmin[3], const int32_t vdim[3], float background, const float m[9], const float vec[3], V3 p) {
+    const float x = p.x - vec[0], y = p.y - vec[1], z = p.z - vec[2];
+    float u = fma(x, m[0], fma(y, m[1], z * m[2])), v = fma(x, m[3], fma(y, m[4], z * m[5])), w = fma(x, m[6], fma(y, m[7], z * m[8]));
+    const float fu = floor(u), fv = floor(v), fw = floor(w);
+    u -= fu; v -= fv; w -= fw;
+    const int i = (int)fu - vmin[0], j = (int)fv - vmin[1], k = (int)fw - vmin[2];
+    auto at = [&](int a, int b, int c) -> float {
+        const int xi = i + a, yj = j + b, zk = k + c;
+        if (!(xi >= 0 && xi < vdim[0] && yj >= 0 && yj < vdim[1] && zk >= 0 && zk < vdim[2])) return background;
+        return data[((size_t)zk * vdim[1] + yj) * vdim[0] + xi];
+    };
+    auto lerp = [](float a, float b, float t) { return a + t * (b - a); };
+    return lerp(lerp(lerp(at(0, 0, 0), at(0, 0, 1), w), lerp(at(0, 1, 0), at(0, 1, 1), w), v),
+                lerp(lerp(at(1, 0, 0), at(1, 0, 1), w), lerp(at(1, 1, 0), at(1, 1, 1), w), v), u);
+}
 WF_HD MediumAtLambda MediumSpectra(const SceneView &sv, const wf_medium &M, const Wavelengths &lambda) {
     MediumAtLambda ml;
     ml.sigma_a = DenseSample(sv, M.sigma_a_offset, lambda);
@@ -181,6 +197,26 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
         mp.sigma_a = d * ml.sigma_a;
         mp.sigma_s = d * ml.sigma_s;
         mp.Le = S4c(0.f);
+        return mp;
+    }
+    if (M.type == WF_MEDIUM_NANOVDB) {
+        // NanoVDBMedium::SamplePoint + Le (media.h:615-632, 655-668): densityFloatGrid->worldToIndexF(p), then
+        // SampleFromVoxels<TreeType, 1, false> = trilinear interpolation of the eight surrounding voxels (parity unpinned: see wf_abi.h)
+        const float d = VdbSample(sv.mediumData + M.density_offset, M.vdb_min, M.vdb_dim, M.vdb_background, M.vdb_inv_mat, M.vdb_vec, p);
+        mp.sigma_a = ml.sigma_a * d;
+        mp.sigma_s = ml.sigma_s * d;
+        mp.Le = S4c(0.f);
+        if (M.is_emissive) {
+            float temp = VdbSample(sv.mediumData + M.temperature_offset, M.vdbt_min, M.vdbt_dim, M.vdbt_background, M.vdbt_inv_mat, M.vdbt_vec, p);
+            temp = (temp - M.temperature_shift) * M.temperature_scale;
+            if (temp > 100.f) {
+                float lambdaMax = 2.8977721e-3f / temp;
+                float norm = 1 / Blackbody(lambdaMax * 1e9f, temp);
+                S4 bb;
+                for (int i = 0; i < 4; ++i) bb[i] = Blackbody(ml.lam[i], temp) * norm;
+                mp.Le = M.le_scale * bb;
+            }
+        }
         return mp;
     }
     p = BoundsOffset(M.bounds, p);

@@ -6,6 +6,7 @@
 #include "hmath.h"
 #include "spectra.h"
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -209,6 +210,17 @@ struct HostImage {
 };
 // Image::Read (util/image.cpp:1000-1040) for .pfm and .png; throws SceneError with the reference's wording
 void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img);
+// a NanoVDB float grid expanded over its index bounding box (nanovdb_io.cpp; values[(z * dim[1] + y) * dim[0] + x], origin min)
+struct VdbGrid {
+    bool found = false;
+    int min[3] = {0, 0, 0}, dim[3] = {0, 0, 0};
+    std::vector<float> values;
+    float invMat[9] = {}, vec[3] = {};   // Map: index = invMat * (p - vec) (worldToIndexF)
+    double worldBBox[6] = {};
+    float background = 0;
+    int gridClass = 0;
+};
+void ReadNanoVDBGrid(const std::string &filename, const std::string &gridName, VdbGrid *out);
 float RoundToHalf(float f);
 
 // Shape "loopsubdiv" (loopsubdiv.cpp): the limit-surface triangle mesh of a control mesh, in object space

@@ -1256,7 +1256,74 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
             for (int c = 0; c < 3; ++c) { M.bounds[c] = std::min(p0[c], p1[c]); M.bounds[3 + c] = std::max(p0[c], p1[c]); }
             M.render_from_medium = scene.mediaTransforms.at(nm.first).abi();
             LoadNoisePerm(T);
-        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid, rgbgrid, cloud)");
+        } else if (e.name == "nanovdb") {
+            // NanoVDBMedium::Create + ctor (media.cpp:512-660).  Parity unpinned: nanovdb_io.cpp.
+            M.type = WF_MEDIUM_NANOVDB;
+            std::string fn = ps.GetOneString("filename", "");
+            if (fn.empty()) Die(e.loc, "Must supply \"filename\" to \"nanovdb\" medium.");
+            if (fn[0] != '/') fn = scene.baseDir + "/" + fn;
+            VdbGrid dg, tg;
+            ReadNanoVDBGrid(fn, ps.GetOneString("gridname", "density"), &dg);
+            if (!dg.found) Die(e.loc, fn + ": didn't find \"density\" grid.");
+            ReadNanoVDBGrid(fn, ps.GetOneString("temperaturename", "temperature"), &tg);
+            M.le_scale = ps.GetOneFloat("Lescale", 1.f);
+            M.temperature_shift = ps.GetOneFloat("temperatureoffset", ps.GetOneFloat("temperaturecutoff", 0.f));
+            M.temperature_scale = ps.GetOneFloat("temperaturescale", 1.f);
+            M.le_offset = T->pool.AddDense(*MakeDense(*MakeConstant(0.f)));
+            M.is_emissive = tg.found && M.le_scale > 0;   // IsEmissive(), media.h:612
+            M.render_from_medium = scene.mediaTransforms.at(nm.first).abi();
+            auto put = [&](const VdbGrid &g, int32_t vmin[3], int32_t vdim[3], float inv[9], float vec[3], float *bg) {
+                for (int a = 0; a < 3; ++a) { vmin[a] = g.min[a]; vdim[a] = g.dim[a]; vec[a] = g.vec[a]; }
+                for (int a = 0; a < 9; ++a) inv[a] = g.invMat[a];
+                *bg = g.background;
+                if ((long long)T->mediumData.size() + (long long)g.values.size() > (1ll << 31) - 1) Die(e.loc, fn + ": the dense grids exceed this build's 2^31-float medium pool");
+                int off = (int)T->mediumData.size();
+                T->mediumData.insert(T->mediumData.end(), g.values.begin(), g.values.end());
+                if (g.values.empty()) T->mediumData.push_back(g.background);
+                return off;
+            };
+            M.density_offset = put(dg, M.vdb_min, M.vdb_dim, M.vdb_inv_mat, M.vdb_vec, &M.vdb_background);
+            M.temperature_offset = tg.found ? put(tg, M.vdbt_min, M.vdbt_dim, M.vdbt_inv_mat, M.vdbt_vec, &M.vdbt_background) : -1;
+            // bounds = the density grid's world bounding box, joined with the temperature grid's (media.cpp:540-556), as floats
+            for (int c = 0; c < 3; ++c) { M.bounds[c] = (float)dg.worldBBox[c]; M.bounds[3 + c] = (float)dg.worldBBox[3 + c]; }
+            if (tg.found)
+                for (int c = 0; c < 3; ++c) { M.bounds[c] = std::min(M.bounds[c], (float)tg.worldBBox[c]); M.bounds[3 + c] = std::max(M.bounds[3 + c], (float)tg.worldBBox[3 + c]); }
+            // the 64^3 majorant grid (media.cpp:571-623): per cell the maximum voxel value over the cell's index-space extent +- 1
+            M.maj_res[0] = M.maj_res[1] = M.maj_res[2] = 64;
+            M.maj_offset = (int)T->mediumData.size();
+            T->mediumData.resize(T->mediumData.size() + 64 * 64 * 64);
+            float *maj = &T->mediumData[M.maj_offset];
+            auto lerpB = [&](int c, float t) { return (1 - t) * M.bounds[c] + t * M.bounds[3 + c]; };   // Bounds3::Lerp -> Lerp(t, pMin, pMax)
+            auto toIndex = [&](const float w[3], float out[3]) {
+                const float x = w[0] - dg.vec[0], y = w[1] - dg.vec[1], z = w[2] - dg.vec[2];
+                for (int r = 0; r < 3; ++r) out[r] = std::fmaf(x, dg.invMat[3 * r], std::fmaf(y, dg.invMat[3 * r + 1], z * dg.invMat[3 * r + 2]));
+            };
+            auto value = [&](int x, int y, int z) -> float {
+                x -= dg.min[0]; y -= dg.min[1]; z -= dg.min[2];
+                if (!(x >= 0 && x < dg.dim[0] && y >= 0 && y < dg.dim[1] && z >= 0 && z < dg.dim[2])) return dg.background;
+                return dg.values[((size_t)z * dg.dim[1] + y) * dg.dim[0] + x];
+            };
+            for (int z = 0; z < 64; ++z)
+                for (int y = 0; y < 64; ++y)
+                    for (int x = 0; x < 64; ++x) {
+                        const float w0[3] = {lerpB(0, float(x) / 64), lerpB(1, float(y) / 64), lerpB(2, float(z) / 64)};
+                        const float w1[3] = {lerpB(0, float(x + 1) / 64), lerpB(1, float(y + 1) / 64), lerpB(2, float(z + 1) / 64)};
+                        float i0[3], i1[3];
+                        toIndex(w0, i0);
+                        toIndex(w1, i1);
+                        const float delta = 1.f;
+                        int lo[3], hi[3];
+                        for (int a = 0; a < 3; ++a) {
+                            lo[a] = std::max(int(i0[a] - delta), dg.min[a]);
+                            hi[a] = std::min(int(i1[a] + delta), dg.min[a] + dg.dim[a] - 1);
+                        }
+                        float mx = 0;
+                        for (int zz = lo[2]; zz <= hi[2]; ++zz)
+                            for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                                for (int xx = lo[0]; xx <= hi[0]; ++xx) mx = std::max(mx, value(xx, yy, zz));
+                        maj[(z * 64 + y) * 64 + x] = mx;
+                    }
+        } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid, rgbgrid, cloud, nanovdb)");
         (*ids)[nm.first] = (int)T->media.size();
         T->media.push_back(M);
     }

@@ -121,6 +121,19 @@ int wfh_scene_info(wfh_scene *s, wfh_info *out) {
     return 0;
 }
 
+int wfh_read_nanovdb(const char *path, const char *grid_name, int32_t min[3], int32_t dim[3], float inv_mat[9], float vec[3], float *background, float *values) {
+    if (!path || !grid_name) return -1;
+    return Guard<int>(-1, [&] {
+        VdbGrid g;
+        ReadNanoVDBGrid(path, grid_name, &g);
+        if (!g.found) return 1;
+        for (int a = 0; a < 3; ++a) { if (min) min[a] = g.min[a]; if (dim) dim[a] = g.dim[a]; if (vec) vec[a] = g.vec[a]; }
+        if (inv_mat) for (int a = 0; a < 9; ++a) inv_mat[a] = g.invMat[a];
+        if (background) *background = g.background;
+        if (values && !g.values.empty()) memcpy(values, g.values.data(), g.values.size() * sizeof(float));
+        return 0;
+    });
+}
 int wfh_renderer_create(wfh_scene *s, int device, int samples_per_pass) {
     if (!s) return -1;
     return Guard<int>(-1, [&] { s->renderer = std::make_unique<WavefrontRenderer>(s->T, device, samples_per_pass); return 0; });

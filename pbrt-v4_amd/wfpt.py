@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
     "wfh_renderer_create", "wfh_renderer_create_strips", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
-    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image",
+    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image", "wfh_read_nanovdb",
 ]
 
 _hip = None
@@ -353,6 +353,24 @@ def read_image(path, encoding=None):
     if host.wfh_read_image(os.fsencode(path), enc, None, None, None, None, px.ctypes.data) != 0:
         raise WfError(host.wfh_last_error().decode())
     return px, fmt.value
+
+
+def read_nanovdb(path, grid_name):
+    """The float grid `grid_name` of a NanoVDB file through the host library's own reader (parity unpinned): None if the file has no
+    such grid, else dict(min, dim, inv_mat, vec, background, values[z][y][x])."""
+    host, _ = libs()
+    mn, dm = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    inv, vec, bg = (C.c_float * 9)(), (C.c_float * 3)(), C.c_float()
+    host.wfh_read_nanovdb.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = host.wfh_read_nanovdb(os.fsencode(path), grid_name.encode(), mn, dm, inv, vec, C.byref(bg), None)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise WfError(host.wfh_last_error().decode(errors="replace"))
+    vals = np.empty((dm[2], dm[1], dm[0]), np.float32)
+    if host.wfh_read_nanovdb(os.fsencode(path), grid_name.encode(), mn, dm, inv, vec, C.byref(bg), vals.ctypes.data) != 0:
+        raise WfError(host.wfh_last_error().decode(errors="replace"))
+    return {"min": list(mn), "dim": list(dm), "inv_mat": list(inv), "vec": list(vec), "background": bg.value, "values": vals}
 
 
 def read_pfm(path):

@@ -231,6 +231,24 @@ def test_full_wavefront_pass_takes_the_cursor_and_tie_paths(wfpt, tmp_path):
     s.close()
 
 
+def test_nanovdb_medium_gpu_equals_port(wfpt, tmp_path):
+    """NanoVDBMedium (dense blocks + 64^3 majorant grid, emissive temperature grid): the HIP path against the CPU port on the fixture
+    scene, bit for bit, ray counts equal.  (Parity with the REFERENCE is unpinned for this medium — NanoVDB is a third-party submodule,
+    stubbed in the oracle —; tests/test_host.py pins its estimator to the reference's GridMedium in expectation.)"""
+    import make_scenes
+    d = tmp_path / "nv"
+    os.makedirs(d, exist_ok=True)
+    path = str(d / "nanovdb_smoke.pbrt")
+    make_scenes.nanovdb_smoke(path, (96, 72), 8, codec="zip")
+    s = wfpt.Scene(path=path, spp=8)
+    s.create_renderer(0)
+    img, cpu, j = _render_both(s, path, 8, tmp_path)
+    assert s.total_rays() == j["rays"]
+    assert np.isfinite(img).all() and img.mean() > 0.1
+    assert (img.view(np.uint32) == cpu.view(np.uint32)).all(), (img.view(np.uint32) == cpu.view(np.uint32)).mean()
+    s.close()
+
+
 def test_mix_material(wfpt, tmp_path):
     """MixMaterial (resolved when the hit is routed, intersect.h:92-97): the HIP path makes the same hashed choices as
     the port (same ray counts, same image); against the reference,

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT
+from conftest import GOLDEN, ROOT, load_pkg, read_pfm
 
 
 class BvhNode(C.Structure):
@@ -195,3 +195,73 @@ def test_parallel_bvh_build_is_deterministic(wfpt, tmp_path, monkeypatch):
     # those few bytes differ between any two runs; every table behind it must be identical)
     diff = np.nonzero(blobs[0] != blobs[1])[0]
     assert diff.size < 256 and (diff.size == 0 or diff.max() < 2048), (diff.size, diff[:8], diff[-4:])
+
+
+def _nanovdb_scene(tmp_path, spp, res=(96, 72)):
+    import make_scenes
+    d = tmp_path / "nv"
+    os.makedirs(d, exist_ok=True)
+    path = str(d / "nanovdb_smoke.pbrt")
+    make_scenes.nanovdb_smoke(path, res, spp)
+    return path
+
+
+def test_nanovdb_reader_round_trip(wfpt, tmp_path):
+    """The own NanoVDB reader (csrc/host/nanovdb_io.cpp; PARITY UNPINNED — third-party format, stubbed in the oracle) against files
+    tools/make_nanovdb.py writes in the same restated 32.x layout: uncompressed and ZIP codec, two grids per file, index bounding box,
+    map, every voxel value; malformed files are errors, not crashes."""
+    import make_nanovdb
+    dens, temp = make_nanovdb.smoke_grid()
+    org, vox, tr = (-20, -6, -20), 0.05, (0.0, 0.3, 0.0)
+    for codec in ("none", "zip"):
+        fn = str(tmp_path / ("smoke_%s.nvdb" % codec))
+        make_nanovdb.write_nvdb(fn, [("density", dens, org, vox, tr), ("temperature", temp, org, vox, tr)], codec=codec)
+        for name, arr in (("density", dens), ("temperature", temp)):
+            g = wfpt.read_nanovdb(fn, name)
+            zz, yy, xx = np.nonzero(arr)
+            assert g["min"] == [int(xx.min()) + org[0], int(yy.min()) + org[1], int(zz.min()) + org[2]]
+            assert g["dim"] == [int(xx.max() - xx.min()) + 1, int(yy.max() - yy.min()) + 1, int(zz.max() - zz.min()) + 1]
+            sub = arr[zz.min():zz.max() + 1, yy.min():yy.max() + 1, xx.min():xx.max() + 1]
+            assert (g["values"] == sub).all()
+            assert g["background"] == 0 and np.allclose(g["inv_mat"], [20, 0, 0, 0, 20, 0, 0, 0, 20]) and np.allclose(g["vec"], tr)
+        assert wfpt.read_nanovdb(fn, "no-such-grid") is None
+    raw = open(fn, "rb").read()
+    bad = tmp_path / "bad.nvdb"
+    for blob, what in ((b"XXXXXXXX" + raw[8:], "magic"), (raw[:8] + (31 << 21).to_bytes(4, "little") + raw[12:], "version"), (raw[:300], "truncated")):
+        bad.write_bytes(blob)
+        with pytest.raises(wfpt.WfError):
+            wfpt.read_nanovdb(str(bad), "density")
+
+
+def test_nanovdb_medium_agrees_with_the_pinned_grid_medium(built, tmp_path):
+    """An indirect pin for the unpinned NanoVDB medium: the same density field as a `uniformgrid` medium whose cell centres are the
+    NanoVDB voxels (bounds = index bounding box widened by half a voxel) interpolates identically (SampledGrid::Lookup at p * res - 0.5
+    = SampleFromVoxels at the index coordinates); only the majorant grids differ (64^3 over the world box vs 16^3), i.e. the tracking
+    sample sequence, so the two renders agree in expectation: 8x8 block means within 4 % at 256 spp, image means within 1 %.  The
+    GridMedium path is bit-identical to the reference (goldens)."""
+    import make_nanovdb
+    from conftest import run_wf_cpu
+    path = _nanovdb_scene(tmp_path, 256, res=(48, 40))
+    text = open(path).read().replace('"float Lescale" [ 0.6 ]', '"float Lescale" [ 0 ]')
+    open(path, "w").write(text)
+    g = load_pkg().read_nanovdb(os.path.join(os.path.dirname(path), "smoke.nvdb"), "density")
+    vox, tr = 0.05, (0.0, 0.3, 0.0)
+    p0 = [vox * (g["min"][a] - 0.5) + tr[a] for a in range(3)]
+    p1 = [vox * (g["min"][a] + g["dim"][a] - 0.5) + tr[a] for a in range(3)]
+    dens = " ".join("%.9g" % v for v in g["values"].reshape(-1))
+    grid_medium = ('MakeNamedMedium "smoke" "string type" [ "uniformgrid" ] "integer nx" [ %d ] "integer ny" [ %d ] "integer nz" [ %d ] "point3 p0" [ %.9g %.9g %.9g ] '
+                   '"point3 p1" [ %.9g %.9g %.9g ] "rgb sigma_a" [ 0.6 0.6 0.6 ] "rgb sigma_s" [ 2.5 2.6 2.8 ] "float scale" [ 4 ] "float g" [ 0.4 ] "float density" [ %s ]\n'
+                   % (g["dim"][0], g["dim"][1], g["dim"][2], *p0, *p1, dens))
+    lines = text.splitlines(keepends=True)
+    i0 = next(i for i, l in enumerate(lines) if l.lstrip().startswith("MakeNamedMedium"))
+    grid_path = os.path.join(os.path.dirname(path), "grid_smoke.pbrt")
+    open(grid_path, "w").write("".join(lines[:i0]) + grid_medium + "".join(lines[i0 + 2:]))
+    a_out, b_out = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+    run_wf_cpu(path, a_out, 256)
+    run_wf_cpu(grid_path, b_out, 256)
+    a, b = read_pfm(a_out), read_pfm(b_out)
+    assert np.isfinite(a).all() and a.shape == b.shape
+    assert abs(a.mean() - b.mean()) < 0.01 * b.mean(), (a.mean(), b.mean())
+    blocks = lambda im: im.reshape(5, 8, 6, 8, 3).mean(axis=(1, 3, 4))
+    rel = np.abs(blocks(a) - blocks(b)) / blocks(b)
+    assert rel.max() < 0.04, rel.max()
