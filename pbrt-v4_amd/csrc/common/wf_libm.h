@@ -30,6 +30,13 @@
 #else
 #define WFLM_HD inline
 #endif
+// the entry points (sinf, cosf, ...): WF_LIBM_NOINLINE makes them real calls on the device (code-size experiments on the material
+// kernels, which reach them from hundreds of sites)
+#if defined(__HIPCC__) && defined(WF_LIBM_NOINLINE) && defined(__HIP_DEVICE_COMPILE__)
+#define WFLM_FN __host__ __device__ __attribute__((noinline))
+#else
+#define WFLM_FN WFLM_HD
+#endif
 
 namespace glibc235 {
 
@@ -137,7 +144,7 @@ WFLM_HD double reduce_large(uint32_t xi, int *np) {
 }
 WFLM_HD uint32_t abstop12(float x) { return (asuint(x) >> 20) & 0x7ff; }
 
-WFLM_HD float sinf(float y) {
+WFLM_FN float sinf(float y) {
     double x = y;
     int n;
     uint32_t top = abstop12(y);
@@ -158,7 +165,7 @@ WFLM_HD float sinf(float y) {
     }
     return fnan();  // inf or NaN
 }
-WFLM_HD float cosf(float y) {
+WFLM_FN float cosf(float y) {
     double x = y;
     int n;
     uint32_t top = abstop12(y);
@@ -193,7 +200,7 @@ WFLM_HD uint64_t exp2f_tab(int i) {
         0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
     return t[i];
 }
-WFLM_HD float expf(float x) {
+WFLM_FN float expf(float x) {
     double xd = (double)x;
     uint32_t abstop = (asuint(x) >> 20) & 0x7ff;
     if (abstop >= 0x42b) {  // |x| >= 88 or NaN
@@ -234,7 +241,7 @@ WFLM_HD void logf_tab(int i, double *invc, double *logc) {
     *invc = t[i][0];
     *logc = t[i][1];
 }
-WFLM_HD float logf(float x) {
+WFLM_FN float logf(float x) {
     uint32_t ix = asuint(x);
     if (ix == 0x3f800000u) return 0.0f;
     if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
@@ -262,7 +269,7 @@ WFLM_HD float logf(float x) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // atanf (s_atanf.c), atan2f (e_atan2f.c)
-WFLM_HD float atanf(float x) {
+WFLM_FN float atanf(float x) {
     const float atanhi[4] = {asfloat(0x3eed6338u), asfloat(0x3f490fdau), asfloat(0x3f7b985eu), asfloat(0x3fc90fdau)};
     const float atanlo[4] = {asfloat(0x31ac3769u), asfloat(0x33222168u), asfloat(0x33140fb4u), asfloat(0x33a22168u)};
     const float aT0 = asfloat(0x3eaaaaabu), aT1 = asfloat(0xbe4ccccdu), aT2 = asfloat(0x3e124925u), aT3 = asfloat(0xbde38e38u),
@@ -307,7 +314,7 @@ WFLM_HD float atanf(float x) {
     z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
     return (hx < 0) ? -z : z;
 }
-WFLM_HD float atan2f(float y, float x) {
+WFLM_FN float atan2f(float y, float x) {
     const float tiny = asfloat(0x0da24260u), pi_o_4 = asfloat(0x3f490fdbu), pi_o_2 = asfloat(0x3fc90fdbu), pi = asfloat(0x40490fdbu),
                 pi_lo = asfloat(0xb3bbbd2eu);
     int32_t hx = (int32_t)asuint(x), hy = (int32_t)asuint(y);
@@ -357,7 +364,7 @@ WFLM_HD float atan2f(float y, float x) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // asinf (e_asinf.c, minimax variant of glibc >= 2.27) and acosf (e_acosf.c)
-WFLM_HD float asinf(float x) {
+WFLM_FN float asinf(float x) {
     const float pio2_hi = asfloat(0x3fc90fdbu), pio2_lo = asfloat(0xb33bbd2eu), pio4_hi = asfloat(0x3f490fdbu);
     const float p0 = asfloat(0x3e2aaae4u), p1 = asfloat(0x3d9980f2u), p2 = asfloat(0x3d3a3f25u), p3 = asfloat(0x3cc6141eu),
                 p4 = asfloat(0x3d2cb694u);
@@ -388,7 +395,7 @@ WFLM_HD float asinf(float x) {
     }
     return (hx > 0) ? t : -t;
 }
-WFLM_HD float acosf(float x) {
+WFLM_FN float acosf(float x) {
     const float pi = asfloat(0x40490fdau), pio2_hi = asfloat(0x3fc90fdau), pio2_lo = asfloat(0x33a22168u);
     const float pS0 = asfloat(0x3e2aaaabu), pS1 = asfloat(0xbea6b090u), pS2 = asfloat(0x3e4e0aa8u), pS3 = asfloat(0xbd241146u),
                 pS4 = asfloat(0x3a4f7f04u), pS5 = asfloat(0x3811ef08u), qS1 = asfloat(0xc019d139u), qS2 = asfloat(0x4001572du),
@@ -442,7 +449,7 @@ WFLM_HD float expm1f_k0(float x) {
     float e = hxs * ((r1 - t) / (6.0f - x * t));
     return x - (x * e - hxs);
 }
-WFLM_HD float coshf(float x) {
+WFLM_FN float coshf(float x) {
     int32_t ix = (int32_t)asuint(x) & 0x7fffffff;
     if (ix < 0x41b00000) {  // |x| < 22
         if (ix < 0x3eb17218) {
@@ -466,7 +473,7 @@ WFLM_HD float coshf(float x) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // sinhf (e_sinhf.c) over the full expm1f (s_expm1f.c) and expf
-WFLM_HD float expm1f(float x) {
+WFLM_FN float expm1f(float x) {
     const float o_threshold = asfloat(0x42b17180u), ln2_hi = asfloat(0x3f317180u), ln2_lo = asfloat(0x3717f7d1u), invln2 = asfloat(0x3fb8aa3bu);
     const float Q1 = asfloat(0xbd088889u), Q2 = asfloat(0x3ad00d01u), Q3 = asfloat(0xb8a670cdu), Q4 = asfloat(0x36867e54u),
                 Q5 = asfloat(0xb457edbbu);
@@ -528,7 +535,7 @@ WFLM_HD float expm1f(float x) {
     }
     return y;
 }
-WFLM_HD float sinhf(float x) {
+WFLM_FN float sinhf(float x) {
     const int32_t jx = (int32_t)asuint(x), ix = jx & 0x7fffffff;
     if (ix >= 0x7f800000) return x + x;
     float h = jx < 0 ? -0.5f : 0.5f;
@@ -549,7 +556,7 @@ WFLM_HD float sinhf(float x) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // atanhf (e_atanhf.c) over log1pf (s_log1pf.c)
-WFLM_HD float log1pf(float x) {
+WFLM_FN float log1pf(float x) {
     const float ln2_hi = asfloat(0x3f317180u), ln2_lo = asfloat(0x3717f7d1u);
     const float Lp1 = asfloat(0x3f2aaaabu), Lp2 = asfloat(0x3ecccccdu), Lp3 = asfloat(0x3e924925u), Lp4 = asfloat(0x3e638e29u),
                 Lp5 = asfloat(0x3e3a3325u), Lp6 = asfloat(0x3e1cd04fu), Lp7 = asfloat(0x3e178897u);
@@ -614,7 +621,7 @@ WFLM_HD float log1pf(float x) {
     if (k == 0) return f - (hfsq - s * (hfsq + R));
     return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
 }
-WFLM_HD float atanhf(float x) {
+WFLM_FN float atanhf(float x) {
     float xa = ffabs(x);
     float t;
     if (xa < 0.5f) {
@@ -678,7 +685,7 @@ WFLM_HD float kernel_tanf(float x, float y, int iy) {
     s = 1.0f + t * z;
     return t + a * (s + t * v);
 }
-WFLM_HD float tanf(float x) {
+WFLM_FN float tanf(float x) {
     const int32_t hx = (int32_t)asuint(x);
     const int32_t ix = hx & 0x7fffffff;
     if (ix <= 0x3f490fda) return kernel_tanf(x, 0.0f, 1);   // |x| ~< pi/4
