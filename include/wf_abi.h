@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 6
+#define WF_ABI_VERSION 7
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -397,7 +397,13 @@ typedef struct wf_film {
     int32_t rbar_offset, gbar_offset, bbar_offset; /* dense spectra in spectrum_data */
     float XYZFromSensorRGB[3][3];
     float outputRGBFromSensorRGB[3][3];
+    /* film type (film.h): RGBFilm, or SpectralFilm (film.h:401-530) — the RGB accumulators plus n_buckets spectral buckets over
+       [lambda_min, lambda_max]; wavelengths are then sampled uniformly over that range (SampledWavelengths::SampleUniform) */
+    int32_t type;                         /* enum wf_film_type */
+    int32_t n_buckets;
+    float lambda_min, lambda_max;
 } wf_film;
+enum wf_film_type { WF_FILM_RGB = 0, WF_FILM_SPECTRAL = 1 };
 
 enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1, WF_SAMPLER_STRATIFIED = 2, WF_SAMPLER_PADDED_SOBOL = 3,
                        WF_SAMPLER_HALTON = 4, WF_SAMPLER_SOBOL = 5 /* samplers.h:479-565: needs wf_scene_desc.sobol_matrices */ };
@@ -629,6 +635,8 @@ int wf_set_strips(wf_ctx *ctx, int rank, int count, int height, int *local_rows)
 
 /* results */
 int wf_film_download(wf_ctx *ctx, double *rgb_sum_weight /* [H][W][4] */);
+/* SpectralFilm only: the spectral accumulators, per pixel n_buckets bucketSums followed by n_buckets weightSums (doubles) */
+int wf_film_spectral_download(wf_ctx *ctx, double *dst /* [H][W][2 * n_buckets] */);
 int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes); /* for the RCCL film reduce */
 int wf_film_upload(wf_ctx *ctx, const double *rgb_sum_weight);
 int wf_film_copy_to_device(wf_ctx *ctx, void *dst_device);         /* D2D, wf_film_device_ptr's size */

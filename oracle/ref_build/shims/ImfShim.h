@@ -1,7 +1,12 @@
-// Build shim: type-level stand-in for the OpenEXR 3 API surface referenced by the reference's
-// util/image.cpp:1023-1253. Every file operation throws, so ReadEXR/WriteEXR report an error;
-// the oracle build reads and writes PFM only.
+// Build shim: stand-in for the OpenEXR 3 API surface referenced by the reference's util/image.cpp:1023-1253.
+// Reading throws (the oracle build reads PFM / PNG).  WRITING works since round 3: OutputFile writes a minimal but valid OpenEXR
+// file — version 2, single part, scan lines, NO compression, the header's channels (HALF / FLOAT, alphabetical as the format
+// requires), data and display windows — so that the reference's SpectralFilm and GBufferFilm, which only write .exr
+// (film.cpp:1045-1047, 760-762), can produce golden images in this build.  Attributes other than the required ones are dropped.
 #pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -103,8 +108,53 @@ class InputFile {
 };
 class OutputFile {
   public:
-    OutputFile(const char *, const Header &) { throw std::runtime_error("OpenEXR unavailable in oracle build (use .pfm)"); }
-    void setFrameBuffer(const FrameBuffer &) {}
-    void writePixels(int) {}
+    OutputFile(const char *name, const Header &h) : name_(name), h_(h) {}
+    void setFrameBuffer(const FrameBuffer &fb) { fb_ = fb; }
+    void writePixels(int nLines) {
+        FILE *f = fopen(name_.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot open " + name_ + " for writing");
+        auto put32 = [&](int32_t v) { fwrite(&v, 4, 1, f); };
+        auto putStr = [&](const std::string &s) { fwrite(s.c_str(), 1, s.size() + 1, f); };
+        auto attr = [&](const char *n, const char *type, int32_t size) { putStr(n); putStr(type); put32(size); };
+        const Imath::Box2i dw = h_.dataWindow(), disp = h_.displayWindow();
+        const int w = dw.max.x - dw.min.x + 1, hgt = dw.max.y - dw.min.y + 1;
+        if (nLines != hgt) { fclose(f); throw std::runtime_error("shim OutputFile: partial writes are not supported"); }
+        put32(20000630); put32(2);
+        // channels (the std::map iterates alphabetically): name, pixel type, pLinear + 3 reserved, x / y sampling
+        int32_t chSize = 1;
+        for (auto it = h_.channels().begin(); it != h_.channels().end(); ++it) chSize += (int32_t)strlen(it.name()) + 1 + 16;
+        attr("channels", "chlist", chSize);
+        for (auto it = h_.channels().begin(); it != h_.channels().end(); ++it) {
+            putStr(it.name());
+            put32((int32_t)it.channel().type); put32(0); put32(1); put32(1);
+        }
+        fputc(0, f);
+        attr("compression", "compression", 1); fputc(0, f);
+        attr("dataWindow", "box2i", 16); put32(dw.min.x); put32(dw.min.y); put32(dw.max.x); put32(dw.max.y);
+        attr("displayWindow", "box2i", 16); put32(disp.min.x); put32(disp.min.y); put32(disp.max.x); put32(disp.max.y);
+        attr("lineOrder", "lineOrder", 1); fputc(0, f);
+        attr("pixelAspectRatio", "float", 4); { float one = 1; fwrite(&one, 4, 1, f); }
+        attr("screenWindowCenter", "v2f", 8); { float z[2] = {0, 0}; fwrite(z, 4, 2, f); }
+        attr("screenWindowWidth", "float", 4); { float one = 1; fwrite(&one, 4, 1, f); }
+        fputc(0, f);
+        size_t lineBytes = 0;
+        for (auto it = h_.channels().begin(); it != h_.channels().end(); ++it) lineBytes += (size_t)w * (it.channel().type == HALF ? 2 : 4);
+        const long tablePos = ftell(f);
+        uint64_t off = (uint64_t)tablePos + 8ull * hgt;
+        for (int y = 0; y < hgt; ++y) { fwrite(&off, 8, 1, f); off += 8 + lineBytes; }
+        for (int y = 0; y < hgt; ++y) {
+            put32(dw.min.y + y); put32((int32_t)lineBytes);
+            for (auto it = fb_.begin(); it != fb_.end(); ++it) {   // (same alphabetical order as the header's channel list)
+                const Slice &s = it.slice();
+                const size_t bytes = s.type == HALF ? 2 : 4;
+                for (int x = 0; x < w; ++x) fwrite(s.base + (size_t)(dw.min.x + x) * s.xStride + (size_t)(dw.min.y + y) * s.yStride, bytes, 1, f);
+            }
+        }
+        fclose(f);
+    }
+  private:
+    std::string name_;
+    Header h_;
+    FrameBuffer fb_;
 };
 }  // namespace Imf

@@ -395,6 +395,7 @@ static int Main(int argc, char **argv) {
     const wf_film &F = T.desc.film;
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
     ws.film = Alloc<double>((size_t)W * H * 4);
+    ws.filmSpectral = F.type == WF_FILM_SPECTRAL ? Alloc<double>((size_t)W * H * 2 * F.n_buckets) : nullptr;
     ws.stats = Alloc<unsigned long long>(129);
     unsigned long long nodesVisited = 0, trisTested = 0, sssProbes = 0, sssExits = 0;
     std::atomic<unsigned long long> shadowNodes{0}, shadowTris{0};
@@ -698,6 +699,13 @@ static int Main(int argc, char **argv) {
         fclose(f);
     }
     // RGBFilm::GetPixelRGB (film.h:258-275) + GetImage (film.cpp:533-565), float output
+    if (F.type == WF_FILM_SPECTRAL) {   // SpectralFilm::GetImage + WriteImage: R G B + one channel per bucket, .exr
+        std::vector<std::string> names;
+        std::vector<float> chans;
+        SpectralFilmImage(F, ws.film, ws.filmSpectral, W, H, T.saveFP16, &names, &chans);
+        if (!T.imageFile.empty()) WriteEXRChannels(T.imageFile, names, chans.data(), W, H, T.saveFP16);
+        return 0;
+    }
     std::vector<float> rgb((size_t)W * H * 3);
     FilmToRGB(F, ws.film, W, H, rgb.data(), T.saveFP16);
     if (!T.imageFile.empty()) WriteImage(T.imageFile, rgb.data(), W, H);

@@ -124,6 +124,7 @@ struct WorkState {
     int32_t *trQ[2];
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
     double *film;                   // [pixels][4]: rgbSum[3], weightSum (film.h:302-307)
+    double *filmSpectral;           // SpectralFilm: [pixels][2 * n_buckets]: bucketSums, weightSums (film.h:514-524); else null
     unsigned long long *stats;      // cameraRays, indirect[64], shadow[64]
     unsigned long long *trav;       // wf_traversal_counters (8 x u64) or null
 };
@@ -273,7 +274,7 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     if (useTops) sampler.SetTop(tops[0]);
     float lu = sampler.Get1D();
     if (sv.options.disable_wavelength_jitter) lu = 0.5f;
-    Wavelengths lambda = SampleVisible(lu);
+    Wavelengths lambda = F.type == WF_FILM_SPECTRAL ? SampleUniformWavelengths(lu, F.lambda_min, F.lambda_max) : SampleVisible(lu);   // Film::SampleWavelengths
     // GetCameraSample, samplers.h:796-814
     if (useTops) sampler.SetTop(tops[tstride]);
     FilterSampleR fs = FilterSample(sv, sampler.GetPixel2D());
@@ -1310,6 +1311,21 @@ WF_HD void KUpdateFilm(const SceneView &sv, const WorkState &ws, int p, int nSam
         px[1] += filterWeight * g;
         px[2] += filterWeight * b;
         px[3] += filterWeight;
+        if (F.type == WF_FILM_SPECTRAL) {
+            // SpectralFilm::AddSample, the spectral part (film.h:432-457): the radiance itself — not divided by the wavelengths' PDF,
+            // which is uniform —, clamped, times weight * CIE_Y_integral, into the buckets of its four wavelengths
+            S4 Ls = Lw;
+            const float lm = Ls.MaxComponentValue();
+            if (lm > F.max_component_value) Ls = Ls * (F.max_component_value / lm);
+            Ls = Ls * (filterWeight * 106.856895f);
+            double *sp = ws.filmSpectral + (size_t)2 * F.n_buckets * idx;
+            for (int i = 0; i < 4; ++i) {
+                int b = (int)(F.n_buckets * (lambda.lambda[i] - F.lambda_min) / (F.lambda_max - F.lambda_min));
+                b = b < 0 ? 0 : (b > F.n_buckets - 1 ? F.n_buckets - 1 : b);
+                sp[b] += Ls[i];
+                sp[F.n_buckets + b] += filterWeight;
+            }
+        }
     }
 }
 

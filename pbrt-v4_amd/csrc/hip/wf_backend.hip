@@ -1654,6 +1654,11 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
+    ctx->ws.filmSpectral = nullptr;
+    if (d->film.type == WF_FILM_SPECTRAL) {
+        if (d->film.n_buckets < 1 || d->film.n_buckets > 4096 || !(d->film.lambda_max > d->film.lambda_min)) return fail(-1, "spectral film: bad bucket count / wavelength range");
+        if ((e = devAlloc(ctx, &ctx->ws.filmSpectral, (size_t)ctx->W * ctx->H * 2 * d->film.n_buckets))) return e;
+    }
     if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)129))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.trav, (size_t)8))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT * CNT_STRIDE))) return e;
@@ -1790,6 +1795,7 @@ int wf_set_strips(wf_ctx *ctx, int rank, int count, int height, int *local_rows)
 int wf_film_clear(wf_ctx *ctx) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     HIPCHK(hipMemsetAsync(ctx->ws.film, 0, (size_t)ctx->W * ctx->H * 4 * sizeof(double), ctx->stream));
+    if (ctx->ws.filmSpectral) HIPCHK(hipMemsetAsync(ctx->ws.filmSpectral, 0, (size_t)ctx->W * ctx->H * 2 * ctx->svHost.film.n_buckets * sizeof(double), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->ws.stats, 0, 129 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->ws.trav, 0, 8 * sizeof(unsigned long long), ctx->stream));
     return 0;
@@ -2066,6 +2072,13 @@ int wf_render_pass(wf_ctx *ctx, int y0, int sample_index) {
 int wf_film_download(wf_ctx *ctx, double *dst) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     HIPCHK(hipMemcpyAsync(dst, ctx->ws.film, (size_t)ctx->W * ctx->H * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_film_spectral_download(wf_ctx *ctx, double *dst) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (!ctx->ws.filmSpectral) return fail(-1, "wf_film_spectral_download: the scene's film is not a spectral film");
+    HIPCHK(hipMemcpyAsync(dst, ctx->ws.filmSpectral, (size_t)ctx->W * ctx->H * 2 * ctx->svHost.film.n_buckets * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -498,6 +499,99 @@ void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, b
             for (int r = 0; r < 3; ++r) { if (o[r] > 65504.f) o[r] = 65504.f; o[r] = RoundToHalf(o[r]); }
         }
         rgb[3 * i] = o[0]; rgb[3 * i + 1] = o[1]; rgb[3 * i + 2] = o[2];
+    }
+}
+
+// float -> half bits, round to nearest even (the values written below have already been through RoundToHalf: exact)
+static uint16_t FloatToHalfBits(float f) {
+    const float r = RoundToHalf(f);
+    uint32_t x;
+    memcpy(&x, &r, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, mag = x & 0x7fffffffu;
+    if (mag >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((mag & 0x7fffffu) ? 0x200u : 0));
+    if (mag == 0) return (uint16_t)sign;
+    const int e = (int)(mag >> 23) - 127;
+    if (e < -14) {   // half subnormal: value = m * 2^-24
+        float a;
+        memcpy(&a, &mag, 4);
+        return (uint16_t)(sign | (uint32_t)(a * 16777216.f));
+    }
+    return (uint16_t)(sign | (uint32_t)((e + 15) << 10) | ((mag >> 13) & 0x3ffu));
+}
+// Image::WriteEXR for an image with named channels (util/image.cpp:1173-1253): single part, scan lines, no compression; the file
+// stores channels alphabetically.  data[(y * w + x) * nc + c]; half = PixelFormat::Half channels (values already representable).
+bool WriteEXRChannels(const std::string &path, const std::vector<std::string> &names, const float *data, int w, int h, bool half) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const int nc = (int)names.size();
+    std::vector<int> order(nc);
+    for (int i = 0; i < nc; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return names[a] < names[b]; });
+    auto put32 = [&](uint32_t v) { fwrite(&v, 4, 1, f); };
+    auto putStr = [&](const char *s) { fwrite(s, 1, strlen(s) + 1, f); };
+    put32(20000630); put32(2);
+    uint32_t chSize = 1;
+    for (const std::string &n : names) chSize += (uint32_t)n.size() + 1 + 16;
+    putStr("channels"); putStr("chlist"); put32(chSize);
+    for (int c : order) { putStr(names[c].c_str()); put32(half ? 1 : 2); put32(0); put32(1); put32(1); }
+    fputc(0, f);
+    putStr("compression"); putStr("compression"); put32(1); fputc(0, f);
+    putStr("dataWindow"); putStr("box2i"); put32(16); put32(0); put32(0); put32(w - 1); put32(h - 1);
+    putStr("displayWindow"); putStr("box2i"); put32(16); put32(0); put32(0); put32(w - 1); put32(h - 1);
+    putStr("lineOrder"); putStr("lineOrder"); put32(1); fputc(0, f);
+    putStr("pixelAspectRatio"); putStr("float"); put32(4); { float one = 1; fwrite(&one, 4, 1, f); }
+    putStr("screenWindowCenter"); putStr("v2f"); put32(8); { float z[2] = {0, 0}; fwrite(z, 4, 2, f); }
+    putStr("screenWindowWidth"); putStr("float"); put32(4); { float one = 1; fwrite(&one, 4, 1, f); }
+    fputc(0, f);
+    const uint64_t tableStart = (uint64_t)ftell(f), bytesPer = half ? 2 : 4, lineBytes = 8 + bytesPer * nc * (uint64_t)w;
+    for (int y = 0; y < h; ++y) { uint64_t off = tableStart + 8 * (uint64_t)h + lineBytes * y; fwrite(&off, 8, 1, f); }
+    std::vector<float> chan(w);
+    std::vector<uint16_t> chanH(w);
+    for (int y = 0; y < h; ++y) {
+        put32((uint32_t)y); put32((uint32_t)(bytesPer * nc * w));
+        for (int c : order) {
+            for (int x = 0; x < w; ++x) chan[x] = data[((size_t)y * w + x) * nc + c];
+            if (half) { for (int x = 0; x < w; ++x) chanH[x] = FloatToHalfBits(chan[x]); fwrite(chanH.data(), 2, w, f); }
+            else fwrite(chan.data(), 4, w, f);
+        }
+    }
+    fclose(f);
+    return true;
+}
+
+// SpectralFilm::GetImage (film.cpp:961-1027): R G B (GetPixelRGB) followed by one channel "S0.<bucket centre>nm" per bucket (the '.' of
+// the number written as ','), c = bucketSums / weightSums where the weight is positive.  film = the RGB accumulators [pixels][4],
+// spectral = [pixels][2 * n_buckets]; out = [pixels][3 + n_buckets].
+void SpectralFilmImage(const wf_film &F, const double *film, const double *spectral, int w, int h, bool saveFP16, std::vector<std::string> *names, std::vector<float> *out) {
+    const int nb = F.n_buckets, nc = 3 + nb;
+    names->assign({"R", "G", "B"});
+    for (int i = 0; i < nb; ++i) {
+        const float t = (i + 0.5f) / nb;
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%.3fnm", (double)((1 - t) * F.lambda_min + t * F.lambda_max));
+        std::string lam = buf;
+        std::replace(lam.begin(), lam.end(), '.', ',');
+        names->push_back("S0." + lam);
+    }
+    out->assign((size_t)w * h * nc, 0.f);
+    std::vector<float> rgb((size_t)w * h * 3);
+    FilmToRGB(F, film, w, h, rgb.data(), false);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        float *o = &(*out)[i * nc];
+        for (int c = 0; c < 3; ++c) {
+            float v = rgb[3 * i + c];
+            if (saveFP16) { if (v > 65504.f) v = 65504.f; v = RoundToHalf(v); }
+            o[c] = v;
+        }
+        const double *sp = spectral + (size_t)2 * nb * i;
+        for (int b = 0; b < nb; ++b) {
+            float c = 0;
+            if (sp[nb + b] > 0) {
+                c = (float)(sp[b] / sp[nb + b]);   // (+ splatScale * bucketSplats / filterIntegral: no splats on this path)
+                if (saveFP16) { if (c > 65504.f) c = 65504.f; c = RoundToHalf(c); }
+            }
+            o[3 + b] = c;
+        }
     }
 }
 

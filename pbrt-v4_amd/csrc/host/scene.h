@@ -233,5 +233,7 @@ bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);
 bool WriteImage(const std::string &path, const float *rgb, int w, int h);  // by extension: .pfm, .exr
 // film accumulators ([h][w][4] doubles: rgbSum, weightSum) -> output RGB, as RGBFilm::GetImage does
 void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, bool saveFP16);
+bool WriteEXRChannels(const std::string &path, const std::vector<std::string> &names, const float *data, int w, int h, bool half);
+void SpectralFilmImage(const wf_film &F, const double *film, const double *spectral, int w, int h, bool saveFP16, std::vector<std::string> *names, std::vector<float> *out);
 
 }  // namespace wf

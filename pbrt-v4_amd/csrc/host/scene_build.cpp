@@ -859,8 +859,19 @@ void BuildFilter(const ParsedScene &scene, SceneTables *T) {
 // ---- film / sampler / camera -------------------------------------------------------------------------
 void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
     const ParamSet &ps = scene.film.params;
-    if (scene.film.name != "rgb") Die(scene.film.loc, scene.film.name + ": only the \"rgb\" film is supported by this build");
+    if (scene.film.name != "rgb" && scene.film.name != "spectral") Die(scene.film.loc, scene.film.name + ": film type not supported by this build (rgb, spectral)");
     wf_film &F = T->desc.film;
+    F.type = scene.film.name == "spectral" ? WF_FILM_SPECTRAL : WF_FILM_RGB;
+    F.n_buckets = 0;
+    F.lambda_min = 360.f; F.lambda_max = 830.f;
+    if (F.type == WF_FILM_SPECTRAL) {
+        // SpectralFilm::Create (film.cpp:1037-1069)
+        F.n_buckets = ps.GetOneInt("nbuckets", 16);
+        F.lambda_min = ps.GetOneFloat("lambdamin", 360.f);
+        F.lambda_max = ps.GetOneFloat("lambdamax", 830.f);
+        if (F.lambda_min < 360.f || F.lambda_max > 830.f) Die(scene.film.loc, "Unfortunately pbrt must be recompiled to render wavelengths beyond the [360,830] range");
+        if (F.n_buckets < 1) Die(scene.film.loc, "spectral film: \"nbuckets\" must be positive");
+    }
     float exposureTime = scene.camera.params.GetOneFloat("shutterclose", 1.f) - scene.camera.params.GetOneFloat("shutteropen", 0.f);
     F.max_component_value = ps.GetOneFloat("maxcomponentvalue", WF_INFINITY);
     T->saveFP16 = ps.GetOneBool("savefp16", true);
@@ -909,6 +920,8 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
     T->imageFile = ps.GetOneString("filename", "");
     if (!opt.imageFile.empty()) T->imageFile = opt.imageFile;
     else if (T->imageFile.empty()) T->imageFile = "pbrt.pfm";
+    if (F.type == WF_FILM_SPECTRAL && (T->imageFile.size() < 4 || T->imageFile.substr(T->imageFile.size() - 4) != ".exr"))
+        Die(scene.film.loc, T->imageFile + ": EXR is the only output format supported by the SpectralFilm.");
     F.full_res[0] = ps.GetOneInt("xresolution", 1280);
     F.full_res[1] = ps.GetOneInt("yresolution", 720);
     int pb[4] = {0, 0, F.full_res[0], F.full_res[1]};  // xmin, ymin, xmax, ymax

@@ -78,3 +78,41 @@ def bench_small_scene(name, tmp_dir):
     want = json.load(open(os.path.join(GOLDEN, "bench_small_hashes.json")))[name]
     assert make_scenes.tree_hash(str(tmp_dir)) == want, "the generator of %s drifted from the one its golden was rendered from" % name
     return path, make_scenes.BENCH_SMALL[name]["spp"]
+
+
+def read_exr_channels(path):
+    """Minimal OpenEXR reader for the tests: single-part scan-line files WITHOUT compression (what the oracle build's OpenEXR stand-in
+    and the product's multi-channel writer produce) -> {channel name: float32 array [h][w]} (half channels are widened)."""
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<I", b, 0)[0] == 20000630, "not an OpenEXR file"
+    pos = 8
+    chans, dw, comp = [], None, None
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); pos = e + 1
+        size = struct.unpack_from("<i", b, pos)[0]; pos += 4
+        v = b[pos:pos + size]; pos += size
+        if name == "channels":
+            p = 0
+            while v[p] != 0:
+                e = v.index(b"\0", p); cn = v[p:e].decode(); p = e + 1
+                chans.append((cn, struct.unpack_from("<i", v, p)[0])); p += 16
+        elif name == "dataWindow":
+            dw = struct.unpack("<4i", v)
+        elif name == "compression":
+            comp = v[0]
+    pos += 1
+    assert comp == 0 and dw is not None, "only uncompressed files"
+    w, h = dw[2] - dw[0] + 1, dw[3] - dw[1] + 1
+    out = {cn: np.zeros((h, w), np.float32) for cn, _ in chans}
+    offs = struct.unpack_from("<%dQ" % h, b, pos)
+    for off in offs:
+        y, nbytes = struct.unpack_from("<ii", b, off)
+        p = off + 8
+        for cn, ty in chans:
+            if ty == 1:
+                out[cn][y - dw[1]] = np.frombuffer(b, dtype="<f2", count=w, offset=p).astype(np.float32); p += 2 * w
+            else:
+                out[cn][y - dw[1]] = np.frombuffer(b, dtype="<f4", count=w, offset=p); p += 4 * w
+    return out

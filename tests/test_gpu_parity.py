@@ -249,6 +249,26 @@ def test_nanovdb_medium_gpu_equals_port(wfpt, tmp_path):
     s.close()
 
 
+def test_spectral_film_vs_reference(wfpt, tmp_path):
+    """SpectralFilm on the GPU: R G B + 8 spectral buckets against the reference's .exr (golden), bit for bit; the product's own .exr
+    writer round-trips through the test reader."""
+    from conftest import read_exr_channels
+    s = wfpt.Scene(path=os.path.join(GOLDEN, "spectral_film.pbrt"), spp=4)
+    s.create_renderer(0)
+    s.render()
+    names, px = s.spectral_image()
+    ref = read_exr_channels(os.path.join(GOLDEN, "spectral_film_ref.exr"))
+    assert sorted(names) == sorted(ref)
+    for i, k in enumerate(names):
+        assert (px[:, :, i].view(np.uint32) == ref[k].view(np.uint32)).all(), k
+    out = str(tmp_path / "gpu.exr")
+    s.write_film_image(out)
+    got = read_exr_channels(out)
+    for k in ref:
+        assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), k
+    s.close()
+
+
 def test_mix_material(wfpt, tmp_path):
     """MixMaterial (resolved when the hit is routed, intersect.h:92-97): the HIP path makes the same hashed choices as
     the port (same ray counts, same image); against the reference,

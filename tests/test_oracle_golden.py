@@ -71,6 +71,20 @@ def test_cpu_checker_matches_reference_on_benchmark_standins(built, tmp_path, na
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(), "fraction identical: %f" % (img == ref).mean()
 
 
+def test_spectral_film_matches_reference(built, tmp_path):
+    """SpectralFilm (film.h:401-530): uniform wavelength sampling over [lambdamin, lambdamax], the RGB accumulators plus the spectral
+    buckets, GetImage's channel layout (R G B S0.<centre>nm ...) — the port's .exr against the one `pbrt --wavefront` wrote (through
+    the oracle build's OpenEXR stand-in), every channel bit for bit."""
+    from conftest import read_exr_channels
+    out = str(tmp_path / "cpu.exr")
+    run_wf_cpu(os.path.join(GOLDEN, "spectral_film.pbrt"), out, 4)
+    ref, got = read_exr_channels(os.path.join(GOLDEN, "spectral_film_ref.exr")), read_exr_channels(out)
+    assert sorted(ref) == sorted(got) and len(ref) == 11
+    for k in ref:
+        assert (ref[k].view(np.uint32) == got[k].view(np.uint32)).all(), k
+    assert ref["S0.555,000nm"].mean() > 0.05
+
+
 def test_mix_material_matches_reference_statistically(built, tmp_path):
     """MixMaterial::ChooseMaterial hashes the two materials' tagged POINTERS (materials.h:292): the reference's own
     choice changes with heap layout, so there is no sample-aligned comparison.  64 spp, 8x8-pixel block means of the

@@ -131,3 +131,7 @@ json.dump(hashes, open("tests/golden/bench_small_hashes.json", "w"), indent=1)
 PY
 # participating media + object instances: hand-edited tests/golden/media_instances.pbrt (media_box with its conductor box instanced)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_instances_ref.pfm $G/media_instances.pbrt
+# SpectralFilm (film.h:401-530): cornell64 with `Film "spectral"` (8 buckets over 380-780 nm, maxcomponentvalue 6); the oracle build's OpenEXR
+# stand-in writes uncompressed scan-line files (oracle/ref_build/shims/ImfShim.h)
+sed 's/^Film "rgb".*/Film "spectral" "integer nbuckets" [ 8 ] "float lambdamin" [ 380 ] "float lambdamax" [ 780 ] "float maxcomponentvalue" [ 6 ] "string filename" [ "spectral_film.exr" ] "integer xresolution" [ 64 ] "integer yresolution" [ 64 ] "bool savefp16" [ false ]/' $G/cornell64.pbrt > $G/spectral_film.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spectral_film_ref.exr $G/spectral_film.pbrt
