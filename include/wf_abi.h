@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 7
+#define WF_ABI_VERSION 8
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -402,8 +402,22 @@ typedef struct wf_film {
     int32_t type;                         /* enum wf_film_type */
     int32_t n_buckets;
     float lambda_min, lambda_max;
+    /* GBufferFilm (film.h:319-400): the geometry channels are stored in `outputFromRender` space — the camera's (RenderFromCamera
+       applied inversely: apply_inverse = 1, "coordinatesystem" "camera", the default) or the world's (WorldFromRender) */
+    wf_transform gbuffer_from_render;
+    int32_t apply_inverse;
+    float RGBFromXYZ[3][3];               /* the film colour space's matrix (albedo -> RGB, SampledSpectrum::ToRGB) */
+    int32_t illuminant_offset;            /* the film colour space's illuminant, dense, in spectrum_data (albedo * illuminant, film.cpp:631-633) */
 } wf_film;
-enum wf_film_type { WF_FILM_RGB = 0, WF_FILM_SPECTRAL = 1 };
+enum wf_film_type { WF_FILM_RGB = 0, WF_FILM_SPECTRAL = 1, WF_FILM_GBUFFER = 2 };
+/* GBufferFilm::Pixel (film.h:375-387) beside the RGB accumulators: one record per pixel */
+typedef struct wf_gbuffer_pixel {
+    double gbuffer_weight_sum, rgb_albedo_sum[3];
+    int64_t var_n[3];                     /* VarianceEstimator<Float> rgbVariance[3] (util/sampling.h:484-520): n, mean, S */
+    float var_mean[3], var_s[3];
+    float p_sum[3], dzdx_sum, dzdy_sum, n_sum[3], ns_sum[3], uv_sum[2];
+    float pad;
+} wf_gbuffer_pixel;
 
 enum wf_sampler_type { WF_SAMPLER_ZSOBOL = 0, WF_SAMPLER_INDEPENDENT = 1, WF_SAMPLER_STRATIFIED = 2, WF_SAMPLER_PADDED_SOBOL = 3,
                        WF_SAMPLER_HALTON = 4, WF_SAMPLER_SOBOL = 5 /* samplers.h:479-565: needs wf_scene_desc.sobol_matrices */ };
@@ -637,6 +651,8 @@ int wf_set_strips(wf_ctx *ctx, int rank, int count, int height, int *local_rows)
 int wf_film_download(wf_ctx *ctx, double *rgb_sum_weight /* [H][W][4] */);
 /* SpectralFilm only: the spectral accumulators, per pixel n_buckets bucketSums followed by n_buckets weightSums (doubles) */
 int wf_film_spectral_download(wf_ctx *ctx, double *dst /* [H][W][2 * n_buckets] */);
+/* GBufferFilm only: the per-pixel geometry / albedo / variance accumulators */
+int wf_film_gbuffer_download(wf_ctx *ctx, wf_gbuffer_pixel *dst /* [H][W] */);
 int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes); /* for the RCCL film reduce */
 int wf_film_upload(wf_ctx *ctx, const double *rgb_sum_weight);
 int wf_film_copy_to_device(wf_ctx *ctx, void *dst_device);         /* D2D, wf_film_device_ptr's size */

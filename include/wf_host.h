@@ -58,11 +58,12 @@ int wfh_write_image(const char *path, const float *rgb, int w, int h);
    Call with pixels = NULL to get the size; returns 0, or -1 with wfh_last_error(). format: 0 8-bit, 1 half, 2 float storage. */
 int wfh_read_image(const char *path, const char *encoding, int32_t *width, int32_t *height, int32_t *n_channels, int32_t *format, float *pixels);
 
-/* SpectralFilm (film.h:401-530): the final image of a scene whose film is "spectral" — R, G, B and one channel per wavelength bucket
-   ("S0.<centre>nm") — from the renderer's accumulators (SpectralFilm::GetImage).  n_channels = 3 + nbuckets; names = n_channels
-   strings of 32 bytes each (or NULL); pixels = [height][width][n_channels] floats (or NULL to query n_channels first).
-   wfh_write_film_image writes the scene's film — whatever its type — to `path` (.pfm / .exr for RGB films, .exr for spectral ones). */
-int wfh_spectral_image(wfh_scene *s, int32_t *n_channels, char *names, float *pixels);
+/* SpectralFilm (film.h:401-530) and GBufferFilm (film.h:319-400): the final multi-channel image of a scene whose film is "spectral" —
+   R, G, B and one channel per wavelength bucket ("S0.<centre>nm") — or "gbuffer" — R G B Albedo.{R,G,B} P.{X,Y,Z} dzdx dzdy N.{X,Y,Z}
+   Ns.{X,Y,Z} u v Variance.{R,G,B} RelativeVariance.{R,G,B} — from the renderer's accumulators (GetImage).  names = n_channels strings of
+   32 bytes each (or NULL); pixels = [height][width][n_channels] floats (or NULL to query n_channels first).
+   wfh_write_film_image writes the scene's film — whatever its type — to `path` (.pfm / .exr for RGB films, .exr for the others). */
+int wfh_film_channels(wfh_scene *s, int32_t *n_channels, char *names, float *pixels);
 int wfh_write_film_image(wfh_scene *s, const char *path);
 /* The NanoVDB reader of the "nanovdb" medium (csrc/host/nanovdb_io.cpp; parity unpinned: third-party format), for tools and tests:
    the float grid `grid_name` of `path` expanded over its index bounding box.  min / dim = origin and size of the block, inv_mat (9) and

@@ -396,6 +396,8 @@ static int Main(int argc, char **argv) {
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
     ws.film = Alloc<double>((size_t)W * H * 4);
     ws.filmSpectral = F.type == WF_FILM_SPECTRAL ? Alloc<double>((size_t)W * H * 2 * F.n_buckets) : nullptr;
+    ws.filmGBuffer = F.type == WF_FILM_GBUFFER ? Alloc<wf_gbuffer_pixel>((size_t)W * H) : nullptr;
+    if (F.type == WF_FILM_GBUFFER) { ws.vsP = Alloc<F4>(n); ws.vsN = Alloc<F4>(n); ws.vsNs = Alloc<F4>(n); ws.vsDpdx = Alloc<F4>(n); ws.vsDpdy = Alloc<F4>(n); ws.vsAlbedo = Alloc<F4>(n); }
     ws.stats = Alloc<unsigned long long>(129);
     unsigned long long nodesVisited = 0, trisTested = 0, sssProbes = 0, sssExits = 0;
     std::atomic<unsigned long long> shadowNodes{0}, shadowTris{0};
@@ -699,10 +701,11 @@ static int Main(int argc, char **argv) {
         fclose(f);
     }
     // RGBFilm::GetPixelRGB (film.h:258-275) + GetImage (film.cpp:533-565), float output
-    if (F.type == WF_FILM_SPECTRAL) {   // SpectralFilm::GetImage + WriteImage: R G B + one channel per bucket, .exr
+    if (F.type != WF_FILM_RGB) {   // SpectralFilm / GBufferFilm::GetImage + WriteImage: the multi-channel .exr
         std::vector<std::string> names;
         std::vector<float> chans;
-        SpectralFilmImage(F, ws.film, ws.filmSpectral, W, H, T.saveFP16, &names, &chans);
+        if (F.type == WF_FILM_SPECTRAL) SpectralFilmImage(F, ws.film, ws.filmSpectral, W, H, T.saveFP16, &names, &chans);
+        else GBufferFilmImage(F, ws.film, ws.filmGBuffer, W, H, T.saveFP16, &names, &chans);
         if (!T.imageFile.empty()) WriteEXRChannels(T.imageFile, names, chans.data(), W, H, T.saveFP16);
         return 0;
     }

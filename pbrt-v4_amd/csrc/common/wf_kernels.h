@@ -125,6 +125,10 @@ struct WorkState {
     int32_t *counters;              // CNT_* (x CNT_STRIDE ints apart)
     double *film;                   // [pixels][4]: rgbSum[3], weightSum (film.h:302-307)
     double *filmSpectral;           // SpectralFilm: [pixels][2 * n_buckets]: bucketSums, weightSums (film.h:514-524); else null
+    wf_gbuffer_pixel *filmGBuffer;  // GBufferFilm: one record per pixel; else null
+    // PixelSampleState::visibleSurface (workitems.h:113; film.h:34-62), GBufferFilm only: p.xyz + set flag, n.xyz + uv.x, ns.xyz + uv.y,
+    // dpdx.xyz + time, dpdy.xyz, albedo
+    F4 *vsP, *vsN, *vsNs, *vsDpdx, *vsDpdy, *vsAlbedo;
     unsigned long long *stats;      // cameraRays, indirect[64], shadow[64]
     unsigned long long *trav;       // wf_traversal_counters (8 x u64) or null
 };
@@ -292,6 +296,7 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     }
     CameraRayR cr = GenerateCameraRay(sv, pFilm, time, pLens);
     ws.L[pixelIndex] = F4{0, 0, 0, 0};
+    if (F.type == WF_FILM_GBUFFER) ws.vsP[pixelIndex] = F4{0, 0, 0, 0};   // visibleSurface = VisibleSurface() (wavefront/camera.cpp:70-71)
     StoreLambda(ws, pixelIndex, lambda);
     ws.filterWeight[pixelIndex] = filterWeight;
     if (cr.valid) {
@@ -973,10 +978,12 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         // differentials of position and (u, v) at the intersection (surfscatter.cpp:73-104)
         TexCtx tc;
         tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
+        V3 dpdxVS{0, 0, 0}, dpdyVS{0, 0, 0};   // the dpdx / dpdy of surfscatter.cpp:77-79 (the visible surface keeps them)
         if constexpr (TEXCTX)
         if (!sv.options.disable_texture_filtering) {
             // movingFromCamera is the identity transform
             ApproximateDpDxy(sv, tc.p, si.n, &tc.dpdx, &tc.dpdy);
+            dpdxVS = tc.dpdx; dpdyVS = tc.dpdy;
             V3 dpdu = si.dpdu, dpdv = si.dpdv;
             float ata00 = Dot(dpdu, dpdu), ata01 = Dot(dpdu, dpdv), ata11 = Dot(dpdv, dpdv);
             float invDet = 1 / DifferenceOfProducts(ata00, ata11, ata01, ata01);
@@ -1036,6 +1043,33 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         BSDF<BxDF> bsdf(ns, dpdus, bxdf);
         if (lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
         if (sv.regularize && anyNonSpecularBounces0) bsdf.Regularize();
+        if constexpr (VARIANT == 2)
+        if (depth == 0 && sv.film.type == WF_FILM_GBUFFER) {
+            // Initialize VisibleSurface at the first intersection (surfscatter.cpp:147-180): geometry + the BSDF's albedo, estimated
+            // with the reference's 16 fixed samples (BxDF::rho, bxdfs.cpp:1131-1144)
+            const float ucRho[16] = {0.75741637f, 0.37870818f, 0.7083487f, 0.18935409f, 0.9149363f, 0.35417435f, 0.5990858f, 0.09467703f,
+                                     0.8578725f, 0.45746812f, 0.686759f, 0.17708716f, 0.9674518f, 0.2995429f, 0.5083201f, 0.047338516f};
+            const float uRho[16][2] = {{0.855985f, 0.570367f}, {0.381823f, 0.851844f}, {0.285328f, 0.764262f}, {0.733380f, 0.114073f},
+                                       {0.542663f, 0.344465f}, {0.127274f, 0.414848f}, {0.964700f, 0.947162f}, {0.594089f, 0.643463f},
+                                       {0.095109f, 0.170369f}, {0.825444f, 0.263359f}, {0.429467f, 0.454469f}, {0.244460f, 0.816459f},
+                                       {0.756135f, 0.731258f}, {0.516165f, 0.152852f}, {0.180888f, 0.214174f}, {0.898579f, 0.503897f}};
+            S4 albedo = S4c(0.f);
+            const V3 woLocal = bsdf.RenderToLocal(wo);
+            if (woLocal.z != 0) {
+                for (int k = 0; k < 16; ++k) {
+                    BSDFSample rs = bsdf.bxdf.Sample_f(woLocal, ucRho[k], V2{uRho[k][0], uRho[k][1]}, MODE_RADIANCE, REFLTRANS_ALL);
+                    if (rs.valid && rs.pdf > 0) albedo = albedo + rs.f * AbsCosTheta(rs.wi) / rs.pdf;
+                }
+                albedo = albedo / 16.f;
+            }
+            const N3 nf = FaceForward(si.n, wo), nsf = FaceForward(ns, wo);
+            ws.vsP[pixelIndex] = F4{tc.p.x, tc.p.y, tc.p.z, 1.f};
+            ws.vsN[pixelIndex] = F4{nf.x, nf.y, nf.z, tc.uv.x};
+            ws.vsNs[pixelIndex] = F4{nsf.x, nsf.y, nsf.z, tc.uv.y};
+            ws.vsDpdx[pixelIndex] = F4{dpdxVS.x, dpdxVS.y, dpdxVS.z, time};
+            ws.vsDpdy[pixelIndex] = F4{dpdyVS.x, dpdyVS.y, dpdyVS.z, 0.f};
+            ws.vsAlbedo[pixelIndex] = toF4(albedo);
+        }
 
         S4 wbeta = toS4(q.beta[i]), wr_u = toS4(q.r_u[i]);
         F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
@@ -1311,6 +1345,56 @@ WF_HD void KUpdateFilm(const SceneView &sv, const WorkState &ws, int p, int nSam
         px[1] += filterWeight * g;
         px[2] += filterWeight * b;
         px[3] += filterWeight;
+        if (F.type == WF_FILM_GBUFFER) {
+            // GBufferFilm::AddSample (film.cpp:588-641), the part beside the RGB accumulators
+            const F4 vp = ws.vsP[pixelIndex];
+            if (vp.w != 0) {
+                wf_gbuffer_pixel &gb = ws.filmGBuffer[idx];
+                gb.gbuffer_weight_sum += filterWeight;
+                const float rgbv[3] = {r, g, b};
+                for (int c = 0; c < 3; ++c) {   // VarianceEstimator::Add (util/sampling.h:488-494)
+                    ++gb.var_n[c];
+                    const float delta = rgbv[c] - gb.var_mean[c];
+                    gb.var_mean[c] += delta / gb.var_n[c];
+                    const float delta2 = rgbv[c] - gb.var_mean[c];
+                    gb.var_s[c] += delta * delta2;
+                }
+                const F4 vn = ws.vsN[pixelIndex], vns = ws.vsNs[pixelIndex], vdx = ws.vsDpdx[pixelIndex], vdy = ws.vsDpdy[pixelIndex];
+                const wf_transform &X = F.gbuffer_from_render;
+                V3 po, dx, dy;
+                N3 no, nso;
+                if (F.apply_inverse) {   // Transform::ApplyInverse of points / normals / vectors (util/transform.h:385-414)
+                    po = XfInvPointM(X.mInv, V3{vp.x, vp.y, vp.z});
+                    no = XfNormal(X.m, N3{vn.x, vn.y, vn.z});
+                    nso = XfNormal(X.m, N3{vns.x, vns.y, vns.z});
+                    dx = XfVector3(X.mInv, V3{vdx.x, vdx.y, vdx.z});
+                    dy = XfVector3(X.mInv, V3{vdy.x, vdy.y, vdy.z});
+                } else {
+                    po = XfInvPointM(X.m, V3{vp.x, vp.y, vp.z});
+                    no = XfNormal(X.mInv, N3{vn.x, vn.y, vn.z});
+                    nso = XfNormal(X.mInv, N3{vns.x, vns.y, vns.z});
+                    dx = XfVector3(X.m, V3{vdx.x, vdx.y, vdx.z});
+                    dy = XfVector3(X.m, V3{vdy.x, vdy.y, vdy.z});
+                }
+                gb.p_sum[0] += filterWeight * po.x; gb.p_sum[1] += filterWeight * po.y; gb.p_sum[2] += filterWeight * po.z;
+                gb.n_sum[0] += filterWeight * no.x; gb.n_sum[1] += filterWeight * no.y; gb.n_sum[2] += filterWeight * no.z;
+                gb.ns_sum[0] += filterWeight * nso.x; gb.ns_sum[1] += filterWeight * nso.y; gb.ns_sum[2] += filterWeight * nso.z;
+                gb.dzdx_sum += filterWeight * dx.z;
+                gb.dzdy_sum += filterWeight * dy.z;
+                gb.uv_sum[0] += filterWeight * vn.w; gb.uv_sum[1] += filterWeight * vns.w;
+                // albedo * the colour space's illuminant -> RGB (SampledSpectrum::ToRGB, util/spectrum.cpp:205-228)
+                const S4 alb = toS4(ws.vsAlbedo[pixelIndex]) * DenseSample(sv, F.illuminant_offset, lambda);
+                const S4 pdf = lambda.PDF();
+                const float xyz[3] = {SafeDiv(DenseSample(sv, F.rbar_offset, lambda) * alb, pdf).Average() / 106.856895f,
+                                      SafeDiv(DenseSample(sv, F.gbar_offset, lambda) * alb, pdf).Average() / 106.856895f,
+                                      SafeDiv(DenseSample(sv, F.bbar_offset, lambda) * alb, pdf).Average() / 106.856895f};
+                for (int c = 0; c < 3; ++c) {
+                    float v = 0;   // Mul<RGB>(RGBFromXYZ, xyz) (util/math.h: generic accumulation)
+                    for (int k = 0; k < 3; ++k) v += F.RGBFromXYZ[c][k] * xyz[k];
+                    gb.rgb_albedo_sum[c] += filterWeight * v;
+                }
+            }
+        }
         if (F.type == WF_FILM_SPECTRAL) {
             // SpectralFilm::AddSample, the spectral part (film.h:432-457): the radiance itself — not divided by the wavelengths' PDF,
             // which is uniform —, clamped, times weight * CIE_Y_integral, into the buckets of its four wavelengths

@@ -1655,6 +1655,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
     ctx->ws.filmSpectral = nullptr;
+    ctx->ws.filmGBuffer = nullptr;
+    if (d->film.type == WF_FILM_GBUFFER && (e = devAlloc(ctx, &ctx->ws.filmGBuffer, (size_t)ctx->W * ctx->H))) return e;
     if (d->film.type == WF_FILM_SPECTRAL) {
         if (d->film.n_buckets < 1 || d->film.n_buckets > 4096 || !(d->film.lambda_max > d->film.lambda_min)) return fail(-1, "spectral film: bad bucket count / wavelength range");
         if ((e = devAlloc(ctx, &ctx->ws.filmSpectral, (size_t)ctx->W * ctx->H * 2 * d->film.n_buckets))) return e;
@@ -1710,6 +1712,10 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if ((e = devAlloc(ctx, &ws.filterWeight, n)) || (e = devAlloc(ctx, &ws.pPixel, n)) || (e = devAlloc(ctx, &ws.lambda, n)) ||
         (e = devAlloc(ctx, &ws.lambdaPdf, n)) || (e = devAlloc(ctx, &ws.L, n)) || (e = devAlloc(ctx, &ws.cameraRayWeight, n)) ||
         (e = devAlloc(ctx, &ws.samples0, n)) || (e = devAlloc(ctx, &ws.samples1, n)))
+        return e;
+    if (ctx->svHost.film.type == WF_FILM_GBUFFER &&
+        ((e = devAlloc(ctx, &ws.vsP, n)) || (e = devAlloc(ctx, &ws.vsN, n)) || (e = devAlloc(ctx, &ws.vsNs, n)) || (e = devAlloc(ctx, &ws.vsDpdx, n)) ||
+         (e = devAlloc(ctx, &ws.vsDpdy, n)) || (e = devAlloc(ctx, &ws.vsAlbedo, n))))
         return e;
     // pixel-only sample-index digits (wf_camera.h TopDigits): usable while the permuted index fits 32 bits
     ws.sampleTops = nullptr;
@@ -1795,6 +1801,7 @@ int wf_set_strips(wf_ctx *ctx, int rank, int count, int height, int *local_rows)
 int wf_film_clear(wf_ctx *ctx) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     HIPCHK(hipMemsetAsync(ctx->ws.film, 0, (size_t)ctx->W * ctx->H * 4 * sizeof(double), ctx->stream));
+    if (ctx->ws.filmGBuffer) HIPCHK(hipMemsetAsync(ctx->ws.filmGBuffer, 0, (size_t)ctx->W * ctx->H * sizeof(wf_gbuffer_pixel), ctx->stream));
     if (ctx->ws.filmSpectral) HIPCHK(hipMemsetAsync(ctx->ws.filmSpectral, 0, (size_t)ctx->W * ctx->H * 2 * ctx->svHost.film.n_buckets * sizeof(double), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->ws.stats, 0, 129 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->ws.trav, 0, 8 * sizeof(unsigned long long), ctx->stream));
@@ -1977,7 +1984,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     {
         Prof prof_(ctx, names[material_type]);
         const bool tex = ctx->svHost.texNeedsFootprint != 0;
-        const bool rare = ctx->rareLights;   // a portal infinite light: the variant whose light sampling can reach it
+        const bool rare = ctx->rareLights || ctx->svHost.film.type == WF_FILM_GBUFFER;   // a portal infinite light, or a GBufferFilm: the variant that can reach the portal samplers / fills the visible surface
         switch (material_type) {
         case 1: (rare ? wf_launch_eval_material_1_2 : tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 2: (rare ? wf_launch_eval_material_2_2 : tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
@@ -2079,6 +2086,13 @@ int wf_film_spectral_download(wf_ctx *ctx, double *dst) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     if (!ctx->ws.filmSpectral) return fail(-1, "wf_film_spectral_download: the scene's film is not a spectral film");
     HIPCHK(hipMemcpyAsync(dst, ctx->ws.filmSpectral, (size_t)ctx->W * ctx->H * 2 * ctx->svHost.film.n_buckets * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int wf_film_gbuffer_download(wf_ctx *ctx, wf_gbuffer_pixel *dst) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (!ctx->ws.filmGBuffer) return fail(-1, "wf_film_gbuffer_download: the scene's film is not a gbuffer film");
+    HIPCHK(hipMemcpyAsync(dst, ctx->ws.filmGBuffer, (size_t)ctx->W * ctx->H * sizeof(wf_gbuffer_pixel), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

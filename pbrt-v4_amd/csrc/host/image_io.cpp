@@ -595,6 +595,51 @@ void SpectralFilmImage(const wf_film &F, const double *film, const double *spect
     }
 }
 
+// GBufferFilm::GetImage (film.cpp:688-803): 25 channels from the RGB accumulators [pixels][4] and the per-pixel records
+void GBufferFilmImage(const wf_film &F, const double *film, const wf_gbuffer_pixel *gb, int w, int h, bool saveFP16, std::vector<std::string> *names, std::vector<float> *out) {
+    names->assign({"R", "G", "B", "Albedo.R", "Albedo.G", "Albedo.B", "P.X", "P.Y", "P.Z", "dzdx", "dzdy", "N.X", "N.Y", "N.Z", "Ns.X", "Ns.Y", "Ns.Z", "u", "v",
+                   "Variance.R", "Variance.G", "Variance.B", "RelativeVariance.R", "RelativeVariance.G", "RelativeVariance.B"});
+    const int nc = 25;
+    out->assign((size_t)w * h * nc, 0.f);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        const double *px = film + 4 * i;
+        const wf_gbuffer_pixel &g = gb[i];
+        float rgb[3] = {(float)px[0], (float)px[1], (float)px[2]}, alb[3] = {(float)g.rgb_albedo_sum[0], (float)g.rgb_albedo_sum[1], (float)g.rgb_albedo_sum[2]};
+        const float weightSum = (float)px[3], gws = (float)g.gbuffer_weight_sum;
+        float pt[3] = {g.p_sum[0], g.p_sum[1], g.p_sum[2]}, uv[2] = {g.uv_sum[0], g.uv_sum[1]}, dzdx = g.dzdx_sum, dzdy = g.dzdy_sum;
+        if (weightSum != 0) for (int c = 0; c < 3; ++c) { rgb[c] /= weightSum; alb[c] /= weightSum; }
+        if (gws != 0) {
+            for (int c = 0; c < 3; ++c) pt[c] /= gws;
+            uv[0] /= gws; uv[1] /= gws;
+            dzdx /= gws; dzdy /= gws;
+        }
+        float o[3];
+        for (int r = 0; r < 3; ++r) {
+            o[r] = 0;
+            for (int k = 0; k < 3; ++k) o[r] += F.outputRGBFromSensorRGB[r][k] * rgb[k];
+        }
+        if (saveFP16) for (int c = 0; c < 3; ++c) if (o[c] > 65504.f) o[c] = 65504.f;
+        auto normalized = [](const float v[3], float n[3]) {
+            const float l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            if (!(l2 > 0)) { n[0] = n[1] = n[2] = 0; return; }
+            const float l = std::sqrt(l2);
+            n[0] = v[0] / l; n[1] = v[1] / l; n[2] = v[2] / l;
+        };
+        float n[3], ns[3];
+        normalized(g.n_sum, n);
+        normalized(g.ns_sum, ns);
+        float var[3], rel[3];
+        for (int c = 0; c < 3; ++c) {
+            var[c] = g.var_n[c] > 1 ? g.var_s[c] / (g.var_n[c] - 1) : 0.f;
+            rel[c] = (g.var_n[c] < 1 || g.var_mean[c] == 0) ? 0.f : var[c] / g.var_mean[c];
+        }
+        const float ch[nc] = {o[0], o[1], o[2], alb[0], alb[1], alb[2], pt[0], pt[1], pt[2], std::fabs(dzdx), std::fabs(dzdy), n[0], n[1], n[2], ns[0], ns[1], ns[2],
+                              uv[0], uv[1], var[0], var[1], var[2], rel[0], rel[1], rel[2]};
+        float *dst = &(*out)[i * nc];
+        for (int c = 0; c < nc; ++c) dst[c] = saveFP16 ? RoundToHalf(ch[c]) : ch[c];
+    }
+}
+
 bool WriteImage(const std::string &path, const float *rgb, int w, int h) {
     size_t dot = path.find_last_of('.');
     std::string ext = dot == std::string::npos ? "" : path.substr(dot);

@@ -112,12 +112,18 @@ static int Main(int argc, char **argv) {
     std::vector<double> film((size_t)W * H * 4);
     renderer.DownloadFilm(film.data());
     std::vector<float> rgb((size_t)W * H * 3);
-    if (F.type == WF_FILM_SPECTRAL) {   // SpectralFilm::WriteImage: R G B + the spectral buckets, .exr
-        std::vector<double> spectral((size_t)W * H * 2 * F.n_buckets);
-        if (wf_film_spectral_download(renderer.Context(), spectral.data()) != 0) { fprintf(stderr, "Error: %s\n", wf_last_error()); return 1; }
+    if (F.type != WF_FILM_RGB) {   // SpectralFilm / GBufferFilm::WriteImage: the multi-channel .exr
         std::vector<std::string> names;
         std::vector<float> chans;
-        SpectralFilmImage(F, film.data(), spectral.data(), W, H, T.saveFP16, &names, &chans);
+        if (F.type == WF_FILM_SPECTRAL) {
+            std::vector<double> spectral((size_t)W * H * 2 * F.n_buckets);
+            if (wf_film_spectral_download(renderer.Context(), spectral.data()) != 0) { fprintf(stderr, "Error: %s\n", wf_last_error()); return 1; }
+            SpectralFilmImage(F, film.data(), spectral.data(), W, H, T.saveFP16, &names, &chans);
+        } else {
+            std::vector<wf_gbuffer_pixel> gb((size_t)W * H);
+            if (wf_film_gbuffer_download(renderer.Context(), gb.data()) != 0) { fprintf(stderr, "Error: %s\n", wf_last_error()); return 1; }
+            GBufferFilmImage(F, film.data(), gb.data(), W, H, T.saveFP16, &names, &chans);
+        }
         if (!WriteEXRChannels(T.imageFile, names, chans.data(), W, H, T.saveFP16)) { fprintf(stderr, "Error: couldn't write %s\n", T.imageFile.c_str()); return 1; }
         return 0;
     }

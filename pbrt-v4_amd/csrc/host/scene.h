@@ -234,6 +234,7 @@ bool WriteImage(const std::string &path, const float *rgb, int w, int h);  // by
 // film accumulators ([h][w][4] doubles: rgbSum, weightSum) -> output RGB, as RGBFilm::GetImage does
 void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, bool saveFP16);
 bool WriteEXRChannels(const std::string &path, const std::vector<std::string> &names, const float *data, int w, int h, bool half);
+void GBufferFilmImage(const wf_film &F, const double *film, const wf_gbuffer_pixel *gb, int w, int h, bool saveFP16, std::vector<std::string> *names, std::vector<float> *out);
 void SpectralFilmImage(const wf_film &F, const double *film, const double *spectral, int w, int h, bool saveFP16, std::vector<std::string> *names, std::vector<float> *out);
 
 }  // namespace wf

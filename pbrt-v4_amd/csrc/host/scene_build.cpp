@@ -859,9 +859,17 @@ void BuildFilter(const ParsedScene &scene, SceneTables *T) {
 // ---- film / sampler / camera -------------------------------------------------------------------------
 void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
     const ParamSet &ps = scene.film.params;
-    if (scene.film.name != "rgb" && scene.film.name != "spectral") Die(scene.film.loc, scene.film.name + ": film type not supported by this build (rgb, spectral)");
+    if (scene.film.name != "rgb" && scene.film.name != "spectral" && scene.film.name != "gbuffer")
+        Die(scene.film.loc, scene.film.name + ": film type not supported by this build (rgb, gbuffer, spectral)");
     wf_film &F = T->desc.film;
-    F.type = scene.film.name == "spectral" ? WF_FILM_SPECTRAL : WF_FILM_RGB;
+    F.type = scene.film.name == "spectral" ? WF_FILM_SPECTRAL : scene.film.name == "gbuffer" ? WF_FILM_GBUFFER : WF_FILM_RGB;
+    F.apply_inverse = 0;
+    if (F.type == WF_FILM_GBUFFER) {
+        // GBufferFilm::Create (film.cpp:806-846); the transform itself is set once the camera is known (BuildSceneTables)
+        const std::string cs = ps.GetOneString("coordinatesystem", "camera");
+        if (cs != "camera" && cs != "world") Die(scene.film.loc, cs + ": unknown coordinate system for GBufferFilm. (Expecting \"camera\" or \"world\".)");
+        F.apply_inverse = cs == "camera" ? 1 : 0;
+    }
     F.n_buckets = 0;
     F.lambda_min = 360.f; F.lambda_max = 830.f;
     if (F.type == WF_FILM_SPECTRAL) {
@@ -916,12 +924,14 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
     Mat3 out = cs->RGBFromXYZ * XYZFromSensorRGB;  // film.cpp:496
     std::memcpy(F.XYZFromSensorRGB, XYZFromSensorRGB.m, sizeof(F.XYZFromSensorRGB));
     std::memcpy(F.outputRGBFromSensorRGB, out.m, sizeof(F.outputRGBFromSensorRGB));
+    std::memcpy(F.RGBFromXYZ, cs->RGBFromXYZ.m, sizeof(F.RGBFromXYZ));
+    F.illuminant_offset = F.type == WF_FILM_GBUFFER ? T->pool.AddDense(*MakeDense(*cs->illuminant)) : -1;
     // FilmBaseParameters (film.cpp:66-172)
     T->imageFile = ps.GetOneString("filename", "");
     if (!opt.imageFile.empty()) T->imageFile = opt.imageFile;
     else if (T->imageFile.empty()) T->imageFile = "pbrt.pfm";
-    if (F.type == WF_FILM_SPECTRAL && (T->imageFile.size() < 4 || T->imageFile.substr(T->imageFile.size() - 4) != ".exr"))
-        Die(scene.film.loc, T->imageFile + ": EXR is the only output format supported by the SpectralFilm.");
+    if (F.type != WF_FILM_RGB && (T->imageFile.size() < 4 || T->imageFile.substr(T->imageFile.size() - 4) != ".exr"))
+        Die(scene.film.loc, T->imageFile + (F.type == WF_FILM_SPECTRAL ? ": EXR is the only output format supported by the SpectralFilm." : ": EXR is the only format supported by the GBufferFilm."));
     F.full_res[0] = ps.GetOneInt("xresolution", 1280);
     F.full_res[1] = ps.GetOneInt("yresolution", 720);
     int pb[4] = {0, 0, F.full_res[0], F.full_res[1]};  // xmin, ymin, xmax, ymax
@@ -2147,6 +2157,10 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     BuildFilm(scene, opt, T);
     BuildSampler(scene, opt, T);
     BuildCamera(scene, renderFromWorld, T);
+    if (T->desc.film.type == WF_FILM_GBUFFER) {
+        // outputFromRender: cameraTransform.RenderFromCamera() applied inversely ("camera"), or WorldFromRender ("world") — film.cpp:828-839
+        T->desc.film.gbuffer_from_render = T->desc.film.apply_inverse ? T->desc.camera.renderFromCamera : worldFromRender.abi();
+    }
 
     T->desc.options.seed = opt.seed;
     T->desc.options.disable_pixel_jitter = opt.disablePixelJitter;

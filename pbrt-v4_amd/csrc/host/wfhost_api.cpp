@@ -121,20 +121,33 @@ int wfh_scene_info(wfh_scene *s, wfh_info *out) {
     return 0;
 }
 
-int wfh_spectral_image(wfh_scene *s, int32_t *n_channels, char *names, float *pixels) {
+// the final multi-channel image of a spectral or gbuffer film (SpectralFilm / GBufferFilm::GetImage) from the renderer's accumulators
+static void FilmChannels(wfh_scene *s, std::vector<std::string> *nm, std::vector<float> *chans) {
+    const wf_film &F = s->T.desc.film;
+    const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
+    std::vector<double> film((size_t)W * H * 4);
+    s->renderer->DownloadFilm(film.data());
+    if (F.type == WF_FILM_SPECTRAL) {
+        std::vector<double> spectral((size_t)W * H * 2 * F.n_buckets);
+        if (wf_film_spectral_download(s->renderer->Context(), spectral.data()) != 0) throw SceneError(wf_last_error());
+        SpectralFilmImage(F, film.data(), spectral.data(), W, H, s->T.saveFP16, nm, chans);
+    } else if (F.type == WF_FILM_GBUFFER) {
+        std::vector<wf_gbuffer_pixel> gb((size_t)W * H);
+        if (wf_film_gbuffer_download(s->renderer->Context(), gb.data()) != 0) throw SceneError(wf_last_error());
+        GBufferFilmImage(F, film.data(), gb.data(), W, H, s->T.saveFP16, nm, chans);
+    } else throw SceneError("the scene's film is an RGB film (use wfh_download_film / wfh_film_to_rgb)");
+}
+int wfh_film_channels(wfh_scene *s, int32_t *n_channels, char *names, float *pixels) {
     if (!s || !s->renderer) return -1;
     return Guard<int>(-1, [&] {
         const wf_film &F = s->T.desc.film;
-        if (F.type != WF_FILM_SPECTRAL) throw SceneError("wfh_spectral_image: the scene's film is not a spectral film");
-        const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
-        if (n_channels) *n_channels = 3 + F.n_buckets;
+        const int nc = F.type == WF_FILM_SPECTRAL ? 3 + F.n_buckets : F.type == WF_FILM_GBUFFER ? 25 : 0;
+        if (nc == 0) throw SceneError("wfh_film_channels: the scene's film is an RGB film");
+        if (n_channels) *n_channels = nc;
         if (!names && !pixels) return 0;
-        std::vector<double> film((size_t)W * H * 4), spectral((size_t)W * H * 2 * F.n_buckets);
-        s->renderer->DownloadFilm(film.data());
-        if (wf_film_spectral_download(s->renderer->Context(), spectral.data()) != 0) throw SceneError(wf_last_error());
         std::vector<std::string> nm;
         std::vector<float> chans;
-        SpectralFilmImage(F, film.data(), spectral.data(), W, H, s->T.saveFP16, &nm, &chans);
+        FilmChannels(s, &nm, &chans);
         if (names) for (size_t i = 0; i < nm.size(); ++i) snprintf(names + 32 * i, 32, "%s", nm[i].c_str());
         if (pixels) memcpy(pixels, chans.data(), chans.size() * sizeof(float));
         return 0;
@@ -145,16 +158,14 @@ int wfh_write_film_image(wfh_scene *s, const char *path) {
     return Guard<int>(-1, [&] {
         const wf_film &F = s->T.desc.film;
         const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
-        std::vector<double> film((size_t)W * H * 4);
-        s->renderer->DownloadFilm(film.data());
-        if (F.type == WF_FILM_SPECTRAL) {
-            std::vector<double> spectral((size_t)W * H * 2 * F.n_buckets);
-            if (wf_film_spectral_download(s->renderer->Context(), spectral.data()) != 0) throw SceneError(wf_last_error());
+        if (F.type != WF_FILM_RGB) {
             std::vector<std::string> nm;
             std::vector<float> chans;
-            SpectralFilmImage(F, film.data(), spectral.data(), W, H, s->T.saveFP16, &nm, &chans);
+            FilmChannels(s, &nm, &chans);
             return WriteEXRChannels(path, nm, chans.data(), W, H, s->T.saveFP16) ? 0 : -1;
         }
+        std::vector<double> film((size_t)W * H * 4);
+        s->renderer->DownloadFilm(film.data());
         std::vector<float> rgb((size_t)W * H * 3);
         FilmToRGB(F, film.data(), W, H, rgb.data(), s->T.saveFP16);
         return WriteImage(path, rgb.data(), W, H) ? 0 : -1;

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "wf_medium_sample", "wf_intersect_shadow_tr", "wf_subsurface_probe", "wf_intersect_one_random", "wf_subsurface_scatter", "wf_trace_one_random_host", "wf_morton_sort", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_set_strips", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
     "wf_gen_camera_rays", "wf_gen_ray_samples", "wf_intersect_closest", "wf_handle_escaped", "wf_handle_emissive",
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
-    "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
+    "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_queue_size", "wf_queue_download",
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",
@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
     "wfh_renderer_create", "wfh_renderer_create_strips", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
-    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image", "wfh_read_nanovdb", "wfh_spectral_image", "wfh_write_film_image",
+    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image", "wfh_read_nanovdb", "wfh_film_channels", "wfh_write_film_image",
 ]
 
 _hip = None
@@ -221,16 +221,16 @@ class Scene:
     def image(self):
         return self.film_to_rgb(self.film())
 
-    def spectral_image(self):
-        """SpectralFilm::GetImage of a scene with `Film "spectral"`: (channel names, float32 array [H][W][3 + nbuckets])"""
+    def film_channels(self):
+        """SpectralFilm / GBufferFilm::GetImage of a scene with `Film "spectral"` or `Film "gbuffer"`: (channel names, float32 array [H][W][n])"""
         host, _ = libs()
-        host.wfh_spectral_image.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_char_p, C.c_void_p]
+        host.wfh_film_channels.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_char_p, C.c_void_p]
         nc = C.c_int32(0)
-        if host.wfh_spectral_image(self.h, C.byref(nc), None, None) != 0:
+        if host.wfh_film_channels(self.h, C.byref(nc), None, None) != 0:
             raise WfError(host.wfh_last_error().decode(errors="replace"))
         names = C.create_string_buffer(32 * nc.value)
         px = np.empty((self.info.height, self.info.width, nc.value), np.float32)
-        if host.wfh_spectral_image(self.h, C.byref(nc), names, px.ctypes.data) != 0:
+        if host.wfh_film_channels(self.h, C.byref(nc), names, px.ctypes.data) != 0:
             raise WfError(host.wfh_last_error().decode(errors="replace"))
         return [names.raw[32 * i:32 * (i + 1)].split(b"\0")[0].decode() for i in range(nc.value)], px
 

@@ -256,7 +256,7 @@ def test_spectral_film_vs_reference(wfpt, tmp_path):
     s = wfpt.Scene(path=os.path.join(GOLDEN, "spectral_film.pbrt"), spp=4)
     s.create_renderer(0)
     s.render()
-    names, px = s.spectral_image()
+    names, px = s.film_channels()
     ref = read_exr_channels(os.path.join(GOLDEN, "spectral_film_ref.exr"))
     assert sorted(names) == sorted(ref)
     for i, k in enumerate(names):
@@ -266,6 +266,21 @@ def test_spectral_film_vs_reference(wfpt, tmp_path):
     got = read_exr_channels(out)
     for k in ref:
         assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), k
+    s.close()
+
+
+def test_gbuffer_film_vs_reference(wfpt):
+    """GBufferFilm on the GPU (the material kernels' visible-surface variant, the gbuffer part of UpdateFilm): all 25 channels against
+    the reference's .exr (golden), bit for bit."""
+    from conftest import read_exr_channels
+    s = wfpt.Scene(path=os.path.join(GOLDEN, "gbuffer_film.pbrt"), spp=4)
+    s.create_renderer(0)
+    s.render()
+    names, px = s.film_channels()
+    ref = read_exr_channels(os.path.join(GOLDEN, "gbuffer_film_ref.exr"))
+    assert sorted(names) == sorted(ref) and len(names) == 25
+    for i, k in enumerate(names):
+        assert (px[:, :, i].view(np.uint32) == ref[k].view(np.uint32)).all(), (k, (px[:, :, i].view(np.uint32) == ref[k].view(np.uint32)).mean())
     s.close()
 
 

@@ -85,6 +85,21 @@ def test_spectral_film_matches_reference(built, tmp_path):
     assert ref["S0.555,000nm"].mean() > 0.05
 
 
+def test_gbuffer_film_matches_reference(built, tmp_path):
+    """GBufferFilm (film.h:319-400): the visible surface recorded at the first intersection (surfscatter.cpp:147-180: position, normals,
+    dpdx / dpdy, uv, the BSDF's albedo from BxDF::rho with the reference's 16 fixed samples — every material type of the
+    materials_lights scene), transformed to camera space and accumulated with the Welford variance estimators; all 25 channels of the
+    port's .exr against the reference's, bit for bit."""
+    from conftest import read_exr_channels
+    out = str(tmp_path / "cpu.exr")
+    run_wf_cpu(os.path.join(GOLDEN, "gbuffer_film.pbrt"), out, 4)
+    ref, got = read_exr_channels(os.path.join(GOLDEN, "gbuffer_film_ref.exr")), read_exr_channels(out)
+    assert sorted(ref) == sorted(got) and len(ref) == 25
+    for k in ref:
+        assert (ref[k].view(np.uint32) == got[k].view(np.uint32)).all(), k
+    assert ref["Albedo.G"].mean() > 0.2 and ref["Variance.R"].max() > 0
+
+
 def test_mix_material_matches_reference_statistically(built, tmp_path):
     """MixMaterial::ChooseMaterial hashes the two materials' tagged POINTERS (materials.h:292): the reference's own
     choice changes with heap layout, so there is no sample-aligned comparison.  64 spp, 8x8-pixel block means of the

@@ -135,3 +135,7 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/media_ins
 # stand-in writes uncompressed scan-line files (oracle/ref_build/shims/ImfShim.h)
 sed 's/^Film "rgb".*/Film "spectral" "integer nbuckets" [ 8 ] "float lambdamin" [ 380 ] "float lambdamax" [ 780 ] "float maxcomponentvalue" [ 6 ] "string filename" [ "spectral_film.exr" ] "integer xresolution" [ 64 ] "integer yresolution" [ 64 ] "bool savefp16" [ false ]/' $G/cornell64.pbrt > $G/spectral_film.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spectral_film_ref.exr $G/spectral_film.pbrt
+# GBufferFilm (film.h:319-400): the materials_lights scene with `Film "gbuffer"` — 25 channels (RGB, albedo from BxDF::rho with the
+# reference's 16 fixed samples, camera-space position / normals / dz, uv, Welford variance)
+sed 's/^Film "rgb".*/Film "gbuffer" "string filename" [ "gbuffer_film.exr" ] "integer xresolution" [ 64 ] "integer yresolution" [ 64 ] "bool savefp16" [ false ]/' $G/materials_lights.pbrt > $G/gbuffer_film.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/gbuffer_film_ref.exr $G/gbuffer_film.pbrt
