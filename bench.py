@@ -219,9 +219,14 @@ def main():
     # timed region: K steps = sample indices 0 .. K-1 of this rank's part of the image (or this rank's sample indices), then the
     # film reduce to rank 0
     multigpu.render_partition(scene, rank, world, 0, K, a.partition)
+    t_render = time.perf_counter() - t0          # (render_partition returns after the context's stream is synchronised)
+    t_copy = t_reduce = 0.0
     if dist is not None:
         scene.film_to_tensor(film_t)
+        t_copy = time.perf_counter() - t0 - t_render
         multigpu.reduce_film(film_t, dist, 0)
+        torch.cuda.synchronize()
+        t_reduce = time.perf_counter() - t0 - t_render - t_copy
     barrier()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
@@ -231,6 +236,13 @@ def main():
         dist.all_reduce(rays_t)
     T = float(elapsed.item())
     total_rays = float(rays_t.item())
+    # per-rank phases of the timed region (ms): render of the rank's strips, film copy into the RCCL buffer, reduce to rank 0
+    phases = torch.tensor([1e3 * t_render, 1e3 * t_copy, 1e3 * t_reduce], dtype=torch.float64, device="cuda")
+    all_phases = [torch.zeros_like(phases) for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(all_phases, phases)
+    else:
+        all_phases = [phases]
 
     if rank == 0:
         samples = float(info.width) * info.height * K
@@ -248,6 +260,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "mray_per_s": total_rays / T / 1e6,
+            "per_rank_ms": [{"render": round(float(p[0]), 3), "film_copy": round(float(p[1]), 3), "reduce": round(float(p[2]), 3)} for p in all_phases],
             "load_s": {"generate_scene_files": round(t_gen, 2), "parse_and_host_bvh_build": round(t_parse, 2), "upload_and_device_layout": round(t_upload, 2)},
             "config": {"workload": ("Transparent Machines 4K 1024spp (BASELINE.json configs[4]) on the tm-like stand-in (SURVEY 8(d) row 5: nested dielectric shells "
                                     "eta 1.3-1.7, a quarter of them rough, coated-conductor frames, 2000 small area lights, image infinite light): %d triangles, "
