@@ -562,13 +562,12 @@ def test_strip_partition_two_contexts_bit_identical(wfpt, tmp_path, monkeypatch)
 
 
 def test_two_ranks_on_one_device_bench_code_path(wfpt, tmp_path, monkeypatch):
-    """A single-box dry run of `bench.py --gpus 2`: two renderers created as ranks of a strip partition (create_renderer(strips=...):
-    queues sized for the rank's own rows, passes of rowsPerPass = the rank's rows carrying twice the sample indices), rendered through
-    multigpu.render_partition, films copied to torch CUDA tensors and reduced to rank 0 with the module's own reduce (a one-process gloo
-    group standing in for RCCL; the second rank's film is added as the reduce would) — the result equals the one-context film bit for bit."""
+    """A single-box dry run of `bench.py --gpus 2`'s render path: two renderers created as ranks of a strip partition
+    (create_renderer(strips=...): queues sized for the rank's own rows, a pass carries more sample indices of fewer pixels), rendered
+    through multigpu.render_partition; the sum of the two films — what the reduce to rank 0 computes (tests/test_distributed.py runs
+    the module's reduce itself over gloo) — equals the one-context film bit for bit.  (No torch import here: on a fresh GPU box it costs
+    minutes.)"""
     import importlib.util
-    import torch
-    import torch.distributed as dist
     spec = importlib.util.spec_from_file_location("multigpu", os.path.join(ROOT, "pbrt-v4_amd", "multigpu.py"))
     multigpu = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(multigpu)
@@ -581,26 +580,18 @@ def test_two_ranks_on_one_device_bench_code_path(wfpt, tmp_path, monkeypatch):
     want = full.film()
     spp1 = full.samples_per_pass
     full.close()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group(backend="gloo", rank=0, world_size=1)
-    try:
-        total = torch.zeros((want.shape[0], want.shape[1], 4), dtype=torch.float64)
-        for rank in range(2):
-            s = wfpt.Scene(path=path, spp=8)
-            s.create_renderer(0, strips=(rank, 2, multigpu.STRIP_HEIGHT))
-            assert s.samples_per_pass >= spp1    # fewer pixels per pass, at least as many sample indices
-            multigpu.render_partition(s, rank, 2, 0, 8, "strips")
-            film_t = torch.zeros((want.shape[0], want.shape[1], 4), dtype=torch.float64, device="cuda")
-            s.film_to_tensor(film_t)
-            f = multigpu.reduce_film(film_t.cpu(), dist, 0)
-            owned = np.where(f[..., 3].numpy().sum(axis=1) > 0)[0]
-            assert (owned == multigpu.strip_rows(rank, 2, want.shape[0])).all()
-            total += f
-            s.close()
-    finally:
-        dist.destroy_process_group()
-    assert (total.numpy().view(np.uint64) == want.view(np.uint64)).all()
+    total = np.zeros_like(want)
+    for rank in range(2):
+        s = wfpt.Scene(path=path, spp=8)
+        s.create_renderer(0, strips=(rank, 2, multigpu.STRIP_HEIGHT))
+        assert s.samples_per_pass >= spp1    # fewer pixels per pass, at least as many sample indices
+        multigpu.render_partition(s, rank, 2, 0, 8, "strips")
+        f = s.film()
+        owned = np.where(f[..., 3].sum(axis=1) > 0)[0]
+        assert (owned == multigpu.strip_rows(rank, 2, want.shape[0])).all()
+        total += f
+        s.close()
+    assert (total.view(np.uint64) == want.view(np.uint64)).all()
 
 
 def test_device_morton_sort_builds_the_same_hlbvh(wfpt, tmp_path, monkeypatch):
