@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 8
+#define WF_ABI_VERSION 9
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -155,8 +155,9 @@ enum wf_material_type {
     WF_MAT_COATED_CONDUCTOR = 7,     /* materials.h:611-669 */
     WF_MAT_SUBSURFACE = 8,           /* materials.h:696-790: dielectric boundary + TabulatedBSSRDF (K12, wf_sample_subsurface) */
     WF_MAT_HAIR = 9,                 /* materials.h:353-427: HairBxDF (bxdfs.h:921-1019); h = -1 + 2 v */
-    WF_MAT_NTYPES = 10,              /* the types above have an evaluation queue + kernel each */
-    WF_MAT_MIX = 10                  /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
+    WF_MAT_MEASURED = 10,            /* materials.h:849-892: MeasuredBxDF (bxdfs.h:1022-1069, bxdfs.cpp:998-1113) over the tables at measured_table */
+    WF_MAT_NTYPES = 11,              /* the types above have an evaluation queue + kernel each */
+    WF_MAT_MIX = 11                  /* materials.h:272-332: resolved to one of mix[0..1] when the hit is routed (intersect.h:92-97) */
 };
 /* tex[] slots */
 #define WF_MT_REFLECTANCE 0   /* diffuse / conductor(reflectance) / difftrans / coated diffuse */
@@ -198,7 +199,13 @@ typedef struct wf_material {
     float sss_eta;               /* WF_MAT_SUBSURFACE: the scalar eta of SubsurfaceMaterial (materials.h:786) */
     int32_t sss_table;           /* offset into table_data of the material's BSSRDFTable (100 albedo x 64 radius samples, bssrdf.h:73-96):
                                     rhoSamples[100] radiusSamples[64] profile[6400] rhoEff[100] profileCDF[6400]; "scale" is `scale` above */
+    int32_t measured_table;      /* WF_MAT_MEASURED: offset into table_data of the MeasuredBxDFData (bxdfs.cpp:846-865), WF_MEASURED_HEADER_WORDS
+                                    int32 words (stored as float bit patterns) followed anywhere in table_data by the arrays they point to:
+                                    [0] isotropic, [16 + 16 k ...] the PiecewiseLinear2D (util/sampling.h:1298-1745) k = 0 ndf, 1 sigma, 2 vndf,
+                                    3 luminance, 4 spectra as: size_x, size_y, param_size[3], param_stride[3], param_values offset[3], data offset,
+                                    marginal_cdf offset, conditional_cdf offset (-1: built without cdf); all offsets absolute in table_data */
 } wf_material;
+#define WF_MEASURED_HEADER_WORDS 96
 #define WF_MATFLAG_REMAP_ROUGHNESS 1
 #define WF_MATFLAG_CONDUCTOR_REFLECTANCE 2
 #define WF_MATFLAG_SSS_COEFFICIENTS 4   /* subsurface: sigma_a / sigma_s textures given (else reflectance + mfp) */
@@ -698,6 +705,13 @@ int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p
    primitive in Morton order; the host builder emits the treelets and the SAH upper tree from them.  Needs no context; non-zero
    when no device is visible. */
 int wf_morton_sort(int n, const float *centroids, const float bounds[6], uint32_t *codes, uint32_t *order);
+/* The SAH build on the device (BVHAggregate::buildRecursive + flattenBVH, cpu/aggregates.cpp:198-387, 505-521): from the
+   bounds of n primitives (min.xyz max.xyz each, input order) the reference's tree NODE FOR NODE — nodes_out[0 .. *n_nodes_out) in the
+   reference's depth-first LinearBVHNode layout (leaf offsets = positions in order_out, interior offsets = second-child indices, both
+   relative to this tree), order_out[n] = the input position of the primitive at each leaf slot (std::partition's order).  nodes_out needs
+   room for 2 n - 1 records.  Needs no context; -1 when no device is visible, another negative value when the build gave up (degenerate
+   input: the caller falls back to the host builder, csrc/host/bvh_build.cpp). */
+int wf_build_bvh_sah(int n, const float *bounds, int max_prims_in_node, wf_bvh_node *nodes_out, int32_t *order_out, int32_t *n_nodes_out);
 /* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample */
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index,
                      int start_dim, int ndims, float *out);

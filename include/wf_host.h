@@ -70,6 +70,10 @@ int wfh_write_film_image(wfh_scene *s, const char *path);
    vec (3) = the grid's index-from-world map (index = inv_mat * (p - vec)), background; values = dim[0] * dim[1] * dim[2] floats (x
    fastest) or NULL to query the sizes first.  Returns 0, 1 if the file has no grid of that name, -1 on error (wfh_last_error). */
 int wfh_read_nanovdb(const char *path, const char *grid_name, int32_t min[3], int32_t dim[3], float inv_mat[9], float vec[3], float *background, float *values);
+/* The host SAH builder (csrc/host/bvh_build.cpp: BVHAggregate::buildRecursive + flattenBVH, cpu/aggregates.cpp:198-387, 505-521; pinned to the
+   reference by tests/golden/bvh_stats.json) with the signature of the device builder wf_build_bvh_sah (include/wf_abi.h), for tools and the test
+   that compares the two node for node: n boxes (min.xyz max.xyz) -> nodes_out (room for 2 n - 1), order_out[n], *n_nodes_out.  0 or -1. */
+int wfh_build_bvh_host(int n, const float *bounds, int max_prims_in_node, wf_bvh_node *nodes_out, int32_t *order_out, int32_t *n_nodes_out);
 
 #ifdef __cplusplus
 }

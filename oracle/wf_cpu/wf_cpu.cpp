@@ -632,6 +632,7 @@ static int Main(int argc, char **argv) {
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_CONDUCTOR>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_SUBSURFACE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_SUBSURFACE>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_HAIR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_HAIR>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_MEASURED) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_MEASURED>(sv, ws, cur, i, true); });
                 auto traceShadowRays = [&]() {  // TraceShadowRays, integrator.cpp:575-586
                     const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
                     if (sv.haveMedia)

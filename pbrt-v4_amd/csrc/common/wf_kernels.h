@@ -23,6 +23,7 @@
 #include "wf_media.h"
 #include "wf_bssrdf.h"
 #include "wf_hair.h"
+#include "wf_measured.h"
 
 namespace wf {
 
@@ -915,6 +916,10 @@ template <> struct MatBxDF<WF_MAT_SUBSURFACE> {
 template <> struct MatBxDF<WF_MAT_HAIR> {
     using T = HairBxDF;
     WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetHairBxDF(sv, m, l, tc); }
+};
+template <> struct MatBxDF<WF_MAT_MEASURED> {
+    using T = MeasuredBxDF;
+    WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetMeasuredBxDF(sv, m, l, tc); }
 };
 template <> struct MatBxDF<WF_MAT_COATED_DIFFUSE> {
     using T = CoatedDiffuseBxDF;

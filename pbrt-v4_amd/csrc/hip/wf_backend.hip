@@ -1050,7 +1050,7 @@ extern "C" {
 #define WF_DECL_MAT(n) void wf_launch_eval_material_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
                        void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int); \
                        void wf_launch_eval_material_##n##_2(hipStream_t, int, const SceneView *, const WorkState *, int);
-WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8) WF_DECL_MAT(9)
+WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8) WF_DECL_MAT(9) WF_DECL_MAT(10)
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
     for (int p = blockIdx.x * BLOCK + threadIdx.x; p < ws.pixelsPerPass; p += gridDim.x * BLOCK) KUpdateFilm(sv, ws, p, nSamples);
@@ -1562,6 +1562,29 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if (d->materials[i].sss_table < 0 || (size_t)d->materials[i].sss_table + BSSRDF_TABLE_FLOATS > (size_t)d->n_table_floats)
                 return fail(-1, "subsurface material %d: BSSRDF table outside table_data", i);
         }
+        if (t == WF_MAT_MEASURED) {
+            // every array the five interpolants point to must lie inside table_data (the kernels index them unchecked)
+            const int64_t nT = d->n_table_floats, h = d->materials[i].measured_table;
+            if (h < 0 || h + WF_MEASURED_HEADER_WORDS > nT) return fail(-1, "measured material %d: header outside table_data", i);
+            auto word = [&](int64_t k) { int32_t v; memcpy(&v, &d->table_data[h + k], 4); return (int64_t)v; };
+            static const int nParams[5] = {0, 0, 2, 2, 3};
+            static const bool hasCdf[5] = {false, false, true, true, false};
+            for (int k = 0; k < 5; ++k) {
+                const int64_t b = 16 + 16 * k, sx = word(b), sy = word(b + 1);
+                if (sx < 2 || sy < 2 || sx > (1 << 20) || sy > (1 << 20)) return fail(-1, "measured material %d: interpolant %d has size %lld x %lld", i, k, (long long)sx, (long long)sy);
+                int64_t slices = 1;
+                for (int p = nParams[k] - 1; p >= 0; --p) {
+                    const int64_t ps = word(b + 2 + p), st = word(b + 5 + p), po = word(b + 8 + p);
+                    if (ps < 1 || ps > (1 << 20) || po < 0 || po + ps > nT || st != (ps > 1 ? slices : 0)) return fail(-1, "measured material %d: interpolant %d, parameter %d invalid", i, k, p);
+                    slices *= ps;
+                    if (slices > nT) return fail(-1, "measured material %d: interpolant %d larger than table_data", i, k);
+                }
+                const int64_t dataOff = word(b + 11), margOff = word(b + 12), condOff = word(b + 13);
+                if (dataOff < 0 || dataOff + slices * sx * sy > nT) return fail(-1, "measured material %d: interpolant %d data outside table_data", i, k);
+                if (hasCdf[k] && (margOff < 0 || margOff + slices * sy > nT || condOff < 0 || condOff + slices * sx * sy > nT))
+                    return fail(-1, "measured material %d: interpolant %d cdf outside table_data", i, k);
+            }
+        }
     }
     ctx->W = d->film.pixel_max[0] - d->film.pixel_min[0];
     ctx->H = d->film.pixel_max[1] - d->film.pixel_min[1];
@@ -1978,7 +2001,8 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     static const char *names[WF_MAT_NTYPES] = {"", "DiffuseMaterial + BxDF eval (Basic tex)", "ConductorMaterial + BxDF eval (Basic tex)",
                                                "DielectricMaterial + BxDF eval (Basic tex)", "ThinDielectricMaterial + BxDF eval (Basic tex)",
                                                "DiffuseTransmissionMaterial + BxDF eval (Basic tex)", "CoatedDiffuseMaterial + BxDF eval (Basic tex)",
-                                               "CoatedConductorMaterial + BxDF eval (Basic tex)", "SubsurfaceMaterial + BxDF eval (Basic tex)", "HairMaterial + BxDF eval (Basic tex)"};
+                                               "CoatedConductorMaterial + BxDF eval (Basic tex)", "SubsurfaceMaterial + BxDF eval (Basic tex)", "HairMaterial + BxDF eval (Basic tex)",
+                                               "MeasuredMaterial + BxDF eval (Basic tex)"};
     if (material_type == WF_MAT_INTERFACE) return 0;
     if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
     {
@@ -1995,6 +2019,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
         case 7: (rare ? wf_launch_eval_material_7_2 : tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 8: (rare ? wf_launch_eval_material_8_2 : tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 9: (rare ? wf_launch_eval_material_9_2 : tex ? wf_launch_eval_material_9_1 : wf_launch_eval_material_9_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 10: (rare ? wf_launch_eval_material_10_2 : tex ? wf_launch_eval_material_10_1 : wf_launch_eval_material_10_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         }
     }
     return 0;

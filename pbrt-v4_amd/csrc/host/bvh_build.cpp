@@ -32,6 +32,7 @@ struct BuildNode {
     int nodeCount = 1;   // nodes of the subtree (flattening lays subtrees out at known offsets: in parallel)
 };
 MortonSortFn g_mortonSort = nullptr;
+SahBuildFn g_sahBuild = nullptr;
 
 struct Builder {
     int maxPrimsInNode;
@@ -338,13 +339,44 @@ B3 TriangleBounds(const std::vector<float> &P, const std::vector<int32_t> &triIn
 }
 
 void SetMortonSort(MortonSortFn fn) { g_mortonSort = fn; }
+void SetSahBuild(SahBuildFn fn) { g_sahBuild = fn; }
 
-int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims, int splitMethod) {
+int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims, int splitMethod, bool forceHost) {
     const int nAll = (int)primsIn.size();
     if (nAll == 0) return -1;
     std::vector<BVHPrim> prims(nAll);
     for (int i = 0; i < nAll; ++i) { prims[i].index = primsIn[i].first; prims[i].bounds = primsIn[i].second; }
     const int nodeBase = (int)nodes->size(), primBase = (int)orderedPrims->size();
+    const bool timing = getenv("WF_LOAD_TIMING") != nullptr && nAll > 1000000;
+    if (splitMethod == 0 && g_sahBuild && !forceHost && !getenv("WF_HOST_BVH_BUILD")) {
+        // device path (csrc/hip/wf_bvh_build.hip): the same nodes and primitive order as the recursion below
+        int minPrims = 200000;
+        if (const char *e = getenv("WF_DEVICE_BVH_MIN")) minPrims = atoi(e);
+        if (nAll >= minPrims) {
+            auto t0 = std::chrono::steady_clock::now();
+            std::vector<float> b6(6 * (size_t)nAll);
+            for (int i = 0; i < nAll; ++i) {
+                const B3 &b = primsIn[i].second;
+                float *o = &b6[6 * (size_t)i];
+                o[0] = b.pMin.x; o[1] = b.pMin.y; o[2] = b.pMin.z; o[3] = b.pMax.x; o[4] = b.pMax.y; o[5] = b.pMax.z;
+            }
+            std::vector<wf_bvh_node> local(2 * (size_t)nAll);
+            std::vector<int32_t> order(nAll);
+            int32_t nNodes = 0;
+            const int rc = g_sahBuild(nAll, b6.data(), std::min(255, maxPrimsInNode), local.data(), order.data(), &nNodes);
+            if (rc != 0 && rc != -1 && getenv("WF_LOAD_TIMING")) fprintf(stderr, "[load]   BuildBVH(%d prims): device build gave up (%d), host build instead\n", nAll, rc);
+            if (rc == 0 && nNodes > 0) {
+                local.resize(nNodes);
+                for (wf_bvh_node &n : local) n.offset += n.nprims > 0 ? primBase : nodeBase;
+                nodes->insert(nodes->end(), local.begin(), local.end());
+                const size_t at = orderedPrims->size();
+                orderedPrims->resize(at + nAll);
+                for (int i = 0; i < nAll; ++i) (*orderedPrims)[at + i] = primsIn[order[i]].first;
+                if (timing) fprintf(stderr, "[load]   BuildBVH(%d prims): device build %.3f s\n", nAll, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                return nodeBase;
+            }
+        }
+    }
     std::vector<int32_t> ordered;
     if (splitMethod == 1) ordered.reserve(nAll);   // (the HLBVH path appends leaf by leaf)
     else ordered.assign(nAll, -1);
@@ -356,7 +388,6 @@ int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode,
     int threads = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("WF_BUILD_THREADS")) threads = atoi(e);
     bld.helpersLeft = std::max(0, std::min(threads, 256) - 1);
-    const bool timing = getenv("WF_LOAD_TIMING") != nullptr && nAll > 1000000;
     auto t0 = std::chrono::steady_clock::now();
     BuildNode *root = splitMethod == 1 ? bld.BuildHLBVH(prims.data(), nAll) : bld.Build(prims.data(), nAll, 0);
     auto t1 = std::chrono::steady_clock::now();

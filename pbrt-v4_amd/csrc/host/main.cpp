@@ -77,6 +77,8 @@ static int Main(int argc, char **argv) {
         dataDir = (p == std::string::npos ? std::string(".") : self.substr(0, p)) + "/../data";
     }
     SpectralData::Init(dataDir, dataDir + "/cache");
+    SetMortonSort(&wf_morton_sort);   // as wfh_init does: the device parts of the BVH builds when a GPU is visible
+    SetSahBuild(&wf_build_bvh_sah);
     ParsedScene parsed;
     ParseFiles({scenePath}, &opt, &parsed);
     SceneTables T;

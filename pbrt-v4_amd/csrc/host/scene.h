@@ -165,11 +165,15 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
 // prims: the primitives in the reference's creation order as (primitive id, render-space bounds).  Nodes and ordered
 // primitive ids are APPENDED to *nodes / *orderedPrims (child and primitive offsets absolute); returns the root index.
 // splitMethod: 0 = "sah" (cpu/aggregates.cpp:198-387), 1 = "hlbvh" (:389-503, 626-722)
-int BuildBVH(const std::vector<std::pair<int, B3>> &prims, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims, int splitMethod = 0);
+int BuildBVH(const std::vector<std::pair<int, B3>> &prims, int maxPrimsInNode, std::vector<wf_bvh_node> *nodes, std::vector<int32_t> *orderedPrims, int splitMethod = 0, bool forceHost = false);
 // Morton codes (10 bits per axis of the centroids' offsets in `bounds`) + stable sort, on the device: order[i] = input position of the
 // i-th primitive in Morton order, codes[i] its code.  Non-zero return: not available (the host path is used).
 typedef int (*MortonSortFn)(int n, const float *centroids, const float bounds[6], uint32_t *codes, uint32_t *order);
 void SetMortonSort(MortonSortFn fn);
+// the SAH build on the device (include/wf_abi.h: wf_build_bvh_sah), used for trees of at least WF_DEVICE_BVH_MIN primitives (default 200000) when a
+// device is visible and WF_HOST_BVH_BUILD is not set: the same tree node for node; a non-zero return falls back to the host build
+typedef int (*SahBuildFn)(int n, const float *bounds, int maxPrimsInNode, wf_bvh_node *nodesOut, int32_t *orderOut, int32_t *nNodesOut);
+void SetSahBuild(SahBuildFn fn);
 // Triangle::Bounds (shapes.cpp:283-290) of global triangle i
 B3 TriangleBounds(const std::vector<float> &P, const std::vector<int32_t> &triIndices, int i);
 // light BVH (lightbvh_build.cpp): BVHLightSampler ctor (lightsamplers.cpp:105-232)
@@ -221,6 +225,8 @@ struct VdbGrid {
     int gridClass = 0;
 };
 void ReadNanoVDBGrid(const std::string &filename, const std::string &gridName, VdbGrid *out);
+// a measured BRDF (.bsdf tensor file) appended to a table_data vector; returns the header offset (measured_io.cpp)
+int ReadMeasuredBRDF(const std::string &filename, std::vector<float> *table);
 float RoundToHalf(float f);
 
 // Shape "loopsubdiv" (loopsubdiv.cpp): the limit-surface triangle mesh of a control mesh, in object space

@@ -303,6 +303,7 @@ struct TexBuilder {
     std::map<std::string, int> imageCache;
     int ewaLutOffset = -1;
     std::map<std::string, int> namedMaterialIds;  // in definition order: a "mix" material names earlier ones
+    std::map<std::string, int> measuredCache;     // .bsdf file -> header offset in tableData
     // Image::ResampleWeights / FloatResizeUp (util/image.cpp:386-497): separable windowed-sinc up-sampling to the next
     // power of two; the result per pixel does not depend on the reference's tiling
     static void FloatResizeUp(const HostImage &img, int wm, int nw, int nh, std::vector<float> *out) {
@@ -731,6 +732,19 @@ struct TexBuilder {
             m.tex[WF_MT_HAIR_BETA_N] = GetFloatTexture(ps, "beta_n", 0.3f);
             m.tex[WF_MT_HAIR_ALPHA] = GetFloatTexture(ps, "alpha", 2.f);
             m.displacement = -1; m.normalmap = -1;   // GetDisplacement() / GetNormalMap() return null
+        } else if (name == "measured") {
+            // MeasuredMaterial::Create (materials.cpp:610-621); the data of one file is shared by its materials (MeasuredBxDF::BRDFDataFromFile, bxdfs.cpp:974-980)
+            m.type = WF_MAT_MEASURED;
+            std::string filename = ps.GetOneString("filename", "");
+            if (filename.empty()) Die(e.loc, "Filename must be provided for MeasuredMaterial");
+            if (filename[0] != '/') filename = scene->baseDir + "/" + filename;
+            auto it = measuredCache.find(filename);
+            if (it == measuredCache.end()) {
+                int at = -1;
+                try { at = ReadMeasuredBRDF(filename, &T->tableData); } catch (const SceneError &err) { Die(e.loc, std::string(err.what()).substr(7)); }
+                it = measuredCache.emplace(filename, at).first;
+            }
+            m.measured_table = it->second;
         } else if (name == "interface" || name == "none" || name.empty()) {
             m.type = WF_MAT_INTERFACE;
         } else if (name == "mix") {
@@ -3132,11 +3146,51 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     if (split != "sah" && split != "hlbvh") { fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str()); split = "sah"; }
     int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
     {
-        // instance definitions first (their bounds enter the top-level build): BVHAggregate(prims) with the constructor's
-        // default maxPrimsInNode = 1 (scene.cpp:1539-1543, cpu/aggregates.h:34)
+        // The top-level tree needs only the BOUNDS of the instance definitions (= the union of their primitives' bounds, what the root of
+        // BVHAggregate(prims) holds), so it is built CONCURRENTLY with the definitions' trees: on the device when it is large and a GPU is visible
+        // (csrc/hip/wf_bvh_build.hip — the host cores stay with the definitions), else by the host builder's own helper threads.
+        // Definitions: BVHAggregate(prims) with the constructor's default maxPrimsInNode = 1 (scene.cpp:1539-1543, cpu/aggregates.h:34).
         std::vector<wf_bvh_node> defNodes;
         std::vector<int32_t> defOrdered;
         T->instanceDefs.resize(defPrims.size());
+        std::vector<B3> defBounds(defPrims.size());
+        {
+            std::atomic<size_t> next{0};
+            unsigned nt = std::max(1u, std::min((unsigned)defPrims.size(), std::thread::hardware_concurrency()));
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&] {
+                    for (size_t d = next++; d < defPrims.size(); d = next++) {
+                        B3 b;   // (in creation order, as the builder's root does: the first of two signed zeros stays)
+                        for (const auto &p : defPrims[d]) b = Union(b, p.second);
+                        defBounds[d] = b;
+                    }
+                });
+            for (auto &th : pool) th.join();
+        }
+        // the instances (scene.cpp:1560-1577): TransformedPrimitive(definition, renderFromInstance), after the shapes
+        const int nTrisAll = (int)T->triIndices.size() / 3, nQuads = (int)T->quadrics.size();
+        for (const InstanceUse &u : scene.instances) {
+            const int d = defIndex.at(u.name);
+            if (defPrims[d].empty()) continue;  // empty instance
+            wf_instance in{};
+            in.render_from_instance = u.renderFromInstance.abi();
+            for (int j = 0; j < 3; ++j)
+                if (u.renderFromInstance.m.m[3][j] != 0 || u.renderFromInstance.m.m[3][3] != 1) Die("", u.name + ": only affine instance transformations are supported");
+            in.def = d;
+            // TransformedPrimitive::Bounds = (*renderFromPrimitive)(primitive.Bounds()): the 8 corners (util/transform.cpp:134-139)
+            const B3 &db = defBounds[d];
+            const float b[6] = {db.pMin.x, db.pMin.y, db.pMin.z, db.pMax.x, db.pMax.y, db.pMax.z};
+            B3 wb;
+            for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}));
+            topPrims.emplace_back(nTrisAll + nQuads + (int)T->instances.size(), wb);
+            T->instances.push_back(in);
+        }
+        std::string topError;
+        std::thread topBuild([&] {
+            try { BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims, split == "hlbvh" ? 1 : 0); }
+            catch (const std::exception &e) { topError = e.what(); }
+        });
         {
             // the definitions' trees are independent: built concurrently into local arrays (a pool of threads takes them in turn), then
             // appended in definition order — the arrays are the sequential loop's
@@ -3149,15 +3203,15 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             std::vector<std::thread> pool;
             std::string firstError;
             std::mutex errMutex;
-            for (unsigned t = 0; t < nt; ++t)
+            for (unsigned t = 0; t < nt && !defPrims.empty(); ++t)
                 pool.emplace_back([&] {
                     for (size_t d = next++; d < defPrims.size(); d = next++) {
-                        try { lroot[d] = BuildBVH(defPrims[d], 1, &ln[d], &lo[d]); }
+                        try { lroot[d] = BuildBVH(defPrims[d], 1, &ln[d], &lo[d], 0, /* forceHost: the device is busy with the top level */ true); }
                         catch (const std::exception &e) { std::lock_guard<std::mutex> g(errMutex); if (firstError.empty()) firstError = e.what(); }
                     }
                 });
             for (auto &th : pool) th.join();
-            if (!firstError.empty()) throw SceneError(firstError);
+            if (!firstError.empty()) { topBuild.join(); throw SceneError(firstError); }
             for (size_t d = 0; d < defPrims.size(); ++d) {
                 wf_instance_def &def = T->instanceDefs[d];
                 def = wf_instance_def{};
@@ -3174,25 +3228,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             }
         }
         tick("instance-definition BVHs (SAH)");
-        // the instances (scene.cpp:1560-1577): TransformedPrimitive(definition, renderFromInstance), after the shapes
-        const int nTrisAll = (int)T->triIndices.size() / 3, nQuads = (int)T->quadrics.size();
-        for (const InstanceUse &u : scene.instances) {
-            const int d = defIndex.at(u.name);
-            if (T->instanceDefs[d].bvh_root < 0) continue;  // empty instance
-            wf_instance in{};
-            in.render_from_instance = u.renderFromInstance.abi();
-            for (int j = 0; j < 3; ++j)
-                if (u.renderFromInstance.m.m[3][j] != 0 || u.renderFromInstance.m.m[3][3] != 1) Die("", u.name + ": only affine instance transformations are supported");
-            in.def = d;
-            // TransformedPrimitive::Bounds = (*renderFromPrimitive)(primitive.Bounds()): the 8 corners (util/transform.cpp:134-139)
-            const float *b = T->instanceDefs[d].bounds;
-            B3 wb;
-            for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}));
-            topPrims.emplace_back(nTrisAll + nQuads + (int)T->instances.size(), wb);
-            T->instances.push_back(in);
-        }
-        BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims, split == "hlbvh" ? 1 : 0);
-        tick(split == "hlbvh" ? "top-level BVH (HLBVH)" : "top-level BVH (SAH)");
+        topBuild.join();
+        if (!topError.empty()) throw SceneError(topError);
+        tick(split == "hlbvh" ? "top-level BVH (HLBVH), the part not hidden behind the definitions" : "top-level BVH (SAH), the part not hidden behind the definitions");
         T->nTopBvhNodes = (int)T->bvhNodes.size();
         T->nTopPrims = (int)T->bvhPrims.size();
         const int nodeShift = T->nTopBvhNodes, primShift = T->nTopPrims;

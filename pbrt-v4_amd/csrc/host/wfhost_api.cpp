@@ -42,6 +42,7 @@ int wfh_init(const char *data_dir) {
     if (d.empty()) return -1;
     SpectralData::Init(d, d + "/cache");
     SetMortonSort(&wf_morton_sort);  // the HLBVH build's Morton sort runs on the GPU when one is visible (WF_HOST_MORTON_SORT=1: never)
+    SetSahBuild(&wf_build_bvh_sah);  // large SAH trees are built on the GPU when one is visible (WF_HOST_BVH_BUILD=1: never)
     g_init = true;
     return 0;
 }
@@ -181,6 +182,25 @@ int wfh_read_nanovdb(const char *path, const char *grid_name, int32_t min[3], in
         if (inv_mat) for (int a = 0; a < 9; ++a) inv_mat[a] = g.invMat[a];
         if (background) *background = g.background;
         if (values && !g.values.empty()) memcpy(values, g.values.data(), g.values.size() * sizeof(float));
+        return 0;
+    });
+}
+int wfh_build_bvh_host(int n, const float *bounds, int max_prims_in_node, wf_bvh_node *nodes_out, int32_t *order_out, int32_t *n_nodes_out) {
+    if (n <= 0 || !bounds || !nodes_out || !order_out || !n_nodes_out) return -1;
+    return Guard<int>(-1, [&] {
+        std::vector<std::pair<int, B3>> prims((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const float *b = bounds + 6 * (size_t)i;
+            prims[i].first = i;
+            prims[i].second.pMin = V3{b[0], b[1], b[2]};
+            prims[i].second.pMax = V3{b[3], b[4], b[5]};
+        }
+        std::vector<wf_bvh_node> nodes;
+        std::vector<int32_t> order;
+        if (BuildBVH(prims, max_prims_in_node, &nodes, &order, 0, true) != 0) return -1;
+        memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(wf_bvh_node));
+        memcpy(order_out, order.data(), order.size() * sizeof(int32_t));
+        *n_nodes_out = (int32_t)nodes.size();
         return 0;
     });
 }

@@ -52,7 +52,7 @@ class ProfileEntry(C.Structure):
 # every symbol include/wf_abi.h and include/wf_host.h declare (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "wf_last_error", "wf_abi_version", "wf_ctx_create", "wf_ctx_destroy", "wf_sync", "wf_stream", "wf_scene_upload",
-    "wf_medium_sample", "wf_intersect_shadow_tr", "wf_subsurface_probe", "wf_intersect_one_random", "wf_subsurface_scatter", "wf_trace_one_random_host", "wf_morton_sort", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_set_strips", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
+    "wf_medium_sample", "wf_intersect_shadow_tr", "wf_subsurface_probe", "wf_intersect_one_random", "wf_subsurface_scatter", "wf_trace_one_random_host", "wf_morton_sort", "wf_build_bvh_sah", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_set_strips", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
     "wf_gen_camera_rays", "wf_gen_ray_samples", "wf_intersect_closest", "wf_handle_escaped", "wf_handle_emissive",
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
     "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
 HOST_SYMBOLS = [
     "wfh_init", "wfh_last_error", "wfh_scene_load", "wfh_scene_load_string", "wfh_scene_free", "wfh_scene_desc", "wfh_scene_info",
     "wfh_renderer_create", "wfh_renderer_create_strips", "wfh_renderer_set_strips", "wfh_renderer_samples_per_pass", "wfh_renderer_ctx", "wfh_render", "wfh_clear_film", "wfh_download_film", "wfh_stats",
-    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image", "wfh_read_nanovdb", "wfh_film_channels", "wfh_write_film_image",
+    "wfh_film_to_rgb", "wfh_write_image", "wfh_read_image", "wfh_read_nanovdb", "wfh_build_bvh_host", "wfh_film_channels", "wfh_write_film_image",
 ]
 
 _hip = None

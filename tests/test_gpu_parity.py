@@ -115,7 +115,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "bilinear", "bilinear_lights", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "quadrics_alpha", "goniometric_png",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "quadrics_alpha", "goniometric_png",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton", "cornell64_sobol", "cornell64_sobol_owen"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
@@ -632,3 +632,64 @@ def test_device_morton_sort_builds_the_same_hlbvh(wfpt, tmp_path, monkeypatch):
     perm = np.argsort(want, kind="stable")
     assert (order == perm).all() and (codes == want[perm]).all()
     a.close(); b.close()
+
+
+def test_device_sah_build_gives_the_host_tree_node_for_node(wfpt, tmp_path, monkeypatch):
+    """The SAH build on the device (csrc/hip/wf_bvh_build.hip: level-synchronous buildRecursive, std::partition's permutation from a prefix
+    sum, cpu/aggregates.cpp:198-387 + flattenBVH :505-521) against the host builder, which is pinned to the reference (bvh_stats.json): the
+    LinearBVHNode arrays (bounds compared as floats: the atomics canonicalise -0) and the primitive order must be EQUAL — on a 30 k-triangle
+    mesh (top-level maxprims 4), on a two-level scene (instance definitions: maxprims 1) and on random / degenerate boxes through the C entry."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_scenes
+    from test_host import desc_fields, BvhNode
+
+    def nodes(scene):
+        h = desc_fields(wfpt, scene)
+        raw = np.ctypeslib.as_array((C.c_uint32 * (8 * h.n_bvh_nodes)).from_address(h.bvh_nodes)).copy().reshape(-1, 8)
+        return raw, np.ctypeslib.as_array((C.c_int32 * h.n_triangles).from_address(h.bvh_prims)).copy()
+
+    def same(a, b):
+        (na, pa), (nb, pb) = a, b
+        assert na.shape == nb.shape and (pa == pb).all()
+        assert (na[:, :6].view(np.float32) == nb[:, :6].view(np.float32)).all() and (na[:, 6:] == nb[:, 6:]).all()
+
+    for maker, args in ((make_scenes.killeroo_like, ((96, 54), 1)), (make_scenes.bench_small, None)):
+        path = str(tmp_path / "s.pbrt")
+        if args is None:
+            path = maker("sanmiguel_like_small", str(tmp_path))
+        else:
+            maker(path, *args)
+        monkeypatch.setenv("WF_DEVICE_BVH_MIN", "1000")
+        monkeypatch.delenv("WF_HOST_BVH_BUILD", raising=False)
+        a = wfpt.Scene(path=path, spp=1)
+        monkeypatch.setenv("WF_HOST_BVH_BUILD", "1")
+        b = wfpt.Scene(path=path, spp=1)
+        assert a.info.n_triangles > 20000
+        same(nodes(a), nodes(b))
+        a.close(); b.close()
+    monkeypatch.delenv("WF_HOST_BVH_BUILD", raising=False)
+    # the C entry on boxes the scenes do not have: duplicates, zero-extent boxes, equal centroids, tiny and large counts
+    host, hip = wfpt.libs()
+    hip.wf_build_bvh_sah.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    host.wfh_build_bvh_host.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    for n, maxp, kind in ((1, 4, "u"), (2, 4, "u"), (3, 1, "u"), (37, 4, "dup"), (5000, 1, "u"), (5000, 4, "line"), (70000, 4, "flat"), (300000, 4, "u"), (300000, 255, "dup")):
+        lo = (rng.random((n, 3), dtype=np.float32) * np.float32(20) - np.float32(10))
+        ext = rng.random((n, 3), dtype=np.float32) ** 3 * np.float32(0.5)
+        if kind == "dup":
+            lo = lo[rng.integers(0, max(1, n // 7), n)]
+            ext[:] = np.float32(0.25)
+        elif kind == "line":
+            lo[:, 1:] = 0; ext[:, 1:] = np.float32(0.125); lo[:, 0] = np.float32(2) ** rng.integers(-6, 6, n).astype(np.float32)
+        elif kind == "flat":
+            lo[:, 2] = np.float32(-1); ext[:, 2] = 0
+        boxes = np.ascontiguousarray(np.concatenate([lo, lo + ext], axis=1).astype(np.float32))
+        out = []
+        for fn in (hip.wf_build_bvh_sah, host.wfh_build_bvh_host):
+            nd = np.zeros((2 * n + 2, 8), np.uint32); order = np.zeros(n, np.int32); cnt = C.c_int32(0)
+            assert fn(n, boxes.ctypes.data, maxp, nd.ctypes.data, order.ctypes.data, C.byref(cnt)) == 0, (n, kind)
+            out.append((nd[:cnt.value], order))
+        same(out[0], out[1])
+        leaves = out[0][0][(out[0][0][:, 7] & 0xffff) > 0]
+        assert (leaves[:, 7] & 0xffff).sum() == n and sorted(out[0][1].tolist()) == list(range(n))

@@ -34,7 +34,7 @@ def test_cornell_tables(wfpt):
     # wavefront/integrator.cpp:227-236
     assert (s.info.max_queue_size, s.info.n_passes, s.info.scanlines_per_pass) == (160000, 1, 400)
     h = desc_fields(wfpt, s)
-    assert h.abi_version == 8 and h.n_triangles == 32
+    assert h.abi_version == 9 and h.n_triangles == 32
     nodes = (BvhNode * h.n_bvh_nodes).from_address(h.bvh_nodes)
     prims = np.ctypeslib.as_array((C.c_int32 * h.n_triangles).from_address(h.bvh_prims))
     assert sorted(prims.tolist()) == list(range(32))  # every triangle exactly once
@@ -265,3 +265,51 @@ def test_nanovdb_medium_agrees_with_the_pinned_grid_medium(built, tmp_path):
     blocks = lambda im: im.reshape(5, 8, 6, 8, 3).mean(axis=(1, 3, 4))
     rel = np.abs(blocks(a) - blocks(b)) / blocks(b)
     assert rel.max() < 0.04, rel.max()
+
+
+def test_measured_brdf_files_are_validated(wfpt, tmp_path):
+    """The .bsdf tensor reader (csrc/host/measured_io.cpp): the fixtures of tools/make_bsdf.py load into table_data with the layout
+    include/wf_abi.h describes; truncated files, a wrong magic, a field that points outside the file, a missing field, an unsupported
+    phi_i span and a missing filename are scene errors — never a read outside the file."""
+    import shutil
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_bsdf
+    scene = 'Film "rgb" "integer xresolution" 8 "integer yresolution" 8\nWorldBegin\nLightSource "infinite"\nMaterial "measured" "string filename" "%s"\nShape "sphere"\n'
+    good = str(tmp_path / "good.bsdf")
+    shutil.copy(os.path.join(GOLDEN, "measured_aniso.bsdf"), good)
+    s = wfpt.Scene(text=scene % good, spp=1)
+    assert s.info.n_lights == 1
+    s.close()
+    blob = open(good, "rb").read()
+
+    def refused(data, needle):
+        fn = str(tmp_path / "bad.bsdf")
+        open(fn, "wb").write(data)
+        with pytest.raises(wfpt.WfError) as e:
+            wfpt.Scene(text=scene % fn, spp=1)
+        assert needle in str(e.value), str(e.value)
+    refused(blob[:10], "too small")
+    refused(b"tensor_fiel\0" + blob[12:], "invalid header")
+    refused(blob[:len(blob) // 2], "Unable to read")
+    # the first field's byte offset moved past the end of the file
+    name_len = struct.unpack_from("<H", blob, 18)[0]
+    at = 18 + 2 + name_len + 2 + 1
+    refused(blob[:at] + struct.pack("<Q", len(blob) - 3) + blob[at + 8:], "Unable to read")
+    # a shape whose product overflows / exceeds the file
+    refused(blob[:at + 8] + struct.pack("<Q", 1 << 62) + blob[at + 16:], "larger than the file")
+    refused(blob.replace(b"sigma", b"sigmb", 1), 'no field "sigma"')
+    fn = str(tmp_path / "half.bsdf")
+    make_bsdf.synth(fn, n_phi=5, n_theta=3, res=4)
+    data = bytearray(open(fn, "rb").read())
+    # phi_i spanning only half the circle: "reduction 2 (!= 1) not supported" (bxdfs.cpp:931-935)
+    import numpy as np
+    phi = np.linspace(-np.pi, np.pi, 5).astype(np.float32).tobytes()
+    k = bytes(data).find(phi)
+    assert k > 0
+    data[k:k + 20] = np.linspace(0, np.pi, 5).astype(np.float32).tobytes()
+    refused(bytes(data), "reduction 2")
+    with pytest.raises(wfpt.WfError) as e:
+        wfpt.Scene(text='Film "rgb"\nWorldBegin\nMaterial "measured"\nShape "sphere"\n', spp=1)
+    assert "Filename must be provided" in str(e.value)
