@@ -271,11 +271,16 @@ typedef struct wf_image_light {
  * util/image.cpp) stored one after the other in table_data, level 0 first, rows top to bottom, channels interleaved */
 enum wf_wrap_mode { WF_WRAP_BLACK = 0, WF_WRAP_CLAMP = 1, WF_WRAP_REPEAT = 2, WF_WRAP_OCTAHEDRAL = 3 };
 enum wf_mip_filter { WF_MIP_POINT = 0, WF_MIP_BILINEAR = 1, WF_MIP_TRILINEAR = 2, WF_MIP_EWA = 3 };
+enum wf_texel_format { WF_TEXEL_FLOAT = 0, WF_TEXEL_U8 = 1, WF_TEXEL_HALF = 2 };
 typedef struct wf_tex_image {
     int32_t res[2];
     int32_t n_levels, n_channels;   /* 1 (Y), 3 (R G B) or 4 (R G B A: float lookups return A, util/mipmap.cpp:403-405) */
     int32_t wrap, filter;
     int32_t level_offset[20];       /* float offsets of the levels in table_data */
+    int32_t format;                 /* WF_TEXEL_FLOAT: n floats per level; WF_TEXEL_U8: the level's texels as bytes packed from its offset
+                                       (PixelFormat::U256 images, util/image.h:40-60), value = table_data[lut_offset + code] — the 256-entry
+                                       table of the image's ColorEncoding::ToLinear; WF_TEXEL_HALF: IEEE half bit patterns, 2 bytes per texel */
+    int32_t lut_offset;
     int32_t ewa_lut_offset;         /* WF_MIP_EWA: the 128-entry Gaussian weight table (util/mipmap.cpp:59-191) in table_data */
     float max_anisotropy;           /* WF_MIP_EWA: MIPMapFilterOptions::maxAnisotropy */
 } wf_tex_image;

@@ -296,6 +296,16 @@ WF_HD void RGBToSpectrumCoeffs(const SceneView &sv, const float rgb[3], float c[
     RGBToSpectrumCoeffsP(sv.rgb2specCoeffs, sv.rgb2specZNodes, rgb[0], rgb[1], rgb[2], &c[0], &c[1], &c[2]);
 }
 WF_HD int ModI(int a, int b) { int r = a - (a / b) * b; return r < 0 ? r + b : r; }  // util/math.h:251-254
+// IEEE half bit pattern -> float (exact; util/float.h Half::operator float)
+WF_HD float HalfBitsToFloat(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    if (exp == 0) {
+        const float v = (float)man * 5.9604644775390625e-08f;   // zero / subnormal half: man * 2^-24, exact in float
+        return BitsToFloat(FloatToBits(v) | sign);
+    }
+    if (exp == 31) return BitsToFloat(sign | 0x7f800000u | (man << 13));
+    return BitsToFloat(sign | ((exp + 112) << 23) | (man << 13));
+}
 WF_HD float ImageTexel(const float *table, const wf_tex_image &im, int level, int x, int y, int c) {
     const int rx = im.res[0] >> level > 0 ? im.res[0] >> level : 1, ry = im.res[1] >> level > 0 ? im.res[1] >> level : 1;
     // RemapPixelCoords (util/image.h:96-147)
@@ -318,7 +328,12 @@ WF_HD float ImageTexel(const float *table, const wf_tex_image &im, int level, in
             else return 0.f;
         }
     }
-    return table[im.level_offset[level] + ((size_t)y * rx + x) * im.n_channels + c];
+    const size_t i = ((size_t)y * rx + x) * im.n_channels + c;
+    if (im.format == WF_TEXEL_FLOAT) return table[im.level_offset[level] + i];
+    // texels kept in the source image's format, as the reference's MIP levels are (Image::GetChannel, util/image.h:204-221): a quarter / half of
+    // the bytes per gather, decoded through the encoding's 256-entry table / by widening the half
+    if (im.format == WF_TEXEL_U8) return table[im.lut_offset + reinterpret_cast<const uint8_t *>(table + im.level_offset[level])[i]];
+    return HalfBitsToFloat(reinterpret_cast<const uint16_t *>(table + im.level_offset[level])[i]);
 }
 WF_HD float ImageBilerpChannel(const float *table, const wf_tex_image &im, int level, V2 p, int c) {
     const int rx = im.res[0] >> level > 0 ? im.res[0] >> level : 1, ry = im.res[1] >> level > 0 ? im.res[1] >> level : 1;

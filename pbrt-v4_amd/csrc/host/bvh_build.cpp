@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <thread>
 
 namespace wf {
@@ -360,15 +361,15 @@ int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode,
                 float *o = &b6[6 * (size_t)i];
                 o[0] = b.pMin.x; o[1] = b.pMin.y; o[2] = b.pMin.z; o[3] = b.pMax.x; o[4] = b.pMax.y; o[5] = b.pMax.z;
             }
-            std::vector<wf_bvh_node> local(2 * (size_t)nAll);
-            std::vector<int32_t> order(nAll);
+            std::unique_ptr<wf_bvh_node[]> local(new wf_bvh_node[2 * (size_t)nAll]);   // (not value-initialised: 256 MB for the 4 M-primitive top level)
+            std::unique_ptr<int32_t[]> order(new int32_t[nAll]);
             int32_t nNodes = 0;
-            const int rc = g_sahBuild(nAll, b6.data(), std::min(255, maxPrimsInNode), local.data(), order.data(), &nNodes);
+            const int rc = g_sahBuild(nAll, b6.data(), std::min(255, maxPrimsInNode), local.get(), order.get(), &nNodes);
             if (rc != 0 && rc != -1 && getenv("WF_LOAD_TIMING")) fprintf(stderr, "[load]   BuildBVH(%d prims): device build gave up (%d), host build instead\n", nAll, rc);
             if (rc == 0 && nNodes > 0) {
-                local.resize(nNodes);
-                for (wf_bvh_node &n : local) n.offset += n.nprims > 0 ? primBase : nodeBase;
-                nodes->insert(nodes->end(), local.begin(), local.end());
+                if (primBase != 0 || nodeBase != 0)
+                    for (int i = 0; i < nNodes; ++i) local[i].offset += local[i].nprims > 0 ? primBase : nodeBase;
+                nodes->insert(nodes->end(), local.get(), local.get() + nNodes);
                 const size_t at = orderedPrims->size();
                 orderedPrims->resize(at + nAll);
                 for (int i = 0; i < nAll; ++i) (*orderedPrims)[at + i] = primsIn[order[i]].first;

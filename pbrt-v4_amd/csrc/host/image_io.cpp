@@ -90,6 +90,11 @@ float HostImage::Quantize(float v) const {
     if (format == Half) return RoundToHalf(v);
     return v;
 }
+uint32_t HostImage::QuantizeCode(float v) const {
+    if (format == U256) return enc.FromLinear(v);
+    if (format == Half) return FloatToHalfBits(v);
+    return 0;
+}
 void HostImage::SelectChannels(int first, int count) {
     if (first == 0 && count == nc) return;
     const size_t n = (size_t)w * h;
@@ -503,7 +508,7 @@ void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, b
 }
 
 // float -> half bits, round to nearest even (the values written below have already been through RoundToHalf: exact)
-static uint16_t FloatToHalfBits(float f) {
+uint16_t FloatToHalfBits(float f) {
     const float r = RoundToHalf(f);
     uint32_t x;
     memcpy(&x, &r, 4);

@@ -210,6 +210,7 @@ struct HostImage {
     std::vector<float> p32;    // Half (already rounded to half) and Float
     float Get(size_t i) const { return format == U256 ? enc.ToLinear(p8[i]) : p32[i]; }   // Image::GetChannel's decode
     float Quantize(float v) const;   // what SetChannel / CopyRectIn followed by GetChannel gives back for this format
+    uint32_t QuantizeCode(float v) const;   // the stored code itself: the byte (U256) or the half bit pattern (Half)
     void SelectChannels(int first, int count);   // Image::SelectChannels for a channel range
 };
 // Image::Read (util/image.cpp:1000-1040) for .pfm and .png; throws SceneError with the reference's wording
@@ -228,6 +229,7 @@ void ReadNanoVDBGrid(const std::string &filename, const std::string &gridName, V
 // a measured BRDF (.bsdf tensor file) appended to a table_data vector; returns the header offset (measured_io.cpp)
 int ReadMeasuredBRDF(const std::string &filename, std::vector<float> *table);
 float RoundToHalf(float f);
+uint16_t FloatToHalfBits(float f);
 
 // Shape "loopsubdiv" (loopsubdiv.cpp): the limit-surface triangle mesh of a control mesh, in object space
 void LoopSubdivide(int nLevels, const std::vector<int> &vertexIndices, const std::vector<V3> &P, std::vector<int> *outIndices,

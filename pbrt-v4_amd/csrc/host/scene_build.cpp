@@ -304,6 +304,7 @@ struct TexBuilder {
     int ewaLutOffset = -1;
     std::map<std::string, int> namedMaterialIds;  // in definition order: a "mix" material names earlier ones
     std::map<std::string, int> measuredCache;     // .bsdf file -> header offset in tableData
+    std::map<std::string, int> texelLutCache;     // colour encoding -> its 256-entry ToLinear table in tableData (8-bit image maps)
     // Image::ResampleWeights / FloatResizeUp (util/image.cpp:386-497): separable windowed-sinc up-sampling to the next
     // power of two; the result per pixel does not depend on the reference's tiling
     static void FloatResizeUp(const HostImage &img, int wm, int nw, int nh, std::vector<float> *out) {
@@ -398,6 +399,16 @@ struct TexBuilder {
         wf_tex_image im{};
         im.res[0] = w; im.res[1] = h; im.n_channels = nc; im.wrap = wm; im.filter = ff;
         im.max_anisotropy = maxAniso;
+        im.format = img.format == HostImage::U256 ? WF_TEXEL_U8 : img.format == HostImage::Half ? WF_TEXEL_HALF : WF_TEXEL_FLOAT;
+        if (getenv("WF_TEXELS_FLOAT")) { /* A/B and debugging: every image map as decoded floats, 4 bytes per texel */ im.format = WF_TEXEL_FLOAT; }
+        if (im.format == WF_TEXEL_U8) {
+            auto it = texelLutCache.find(img.enc.Key());
+            if (it == texelLutCache.end()) {
+                it = texelLutCache.emplace(img.enc.Key(), (int)T->tableData.size()).first;
+                for (int code = 0; code < 256; ++code) T->tableData.push_back(img.enc.ToLinear((uint8_t)code));
+            }
+            im.lut_offset = it->second;
+        }
         if (ff == WF_MIP_EWA) {
             // MIPFilterLUT (util/mipmap.cpp:45-191): the table's literals are exp(-2 r2) - exp(-2) in float, r2 = i / 127
             if (ewaLutOffset < 0) {
@@ -414,8 +425,16 @@ struct TexBuilder {
         if (im.n_levels > 20) Die(te.loc, "texture too large");
         for (int l = 0; l < im.n_levels; ++l) {
             im.level_offset[l] = (int)T->tableData.size();
-            if (img.format == HostImage::Float) T->tableData.insert(T->tableData.end(), level.begin(), level.end());
-            else for (float v : level) T->tableData.push_back(img.Quantize(v));   // CopyRectIn into the level's format, then GetChannel
+            if (im.format == WF_TEXEL_FLOAT) { for (float v : level) T->tableData.push_back(img.Quantize(v)); }   // (Float images: Quantize is the identity)
+            else {
+                // CopyRectIn into the level's format (util/image.cpp:370-372): the codes are stored, GetChannel's decode happens at the lookup
+                const size_t bytesPer = img.format == HostImage::U256 ? 1 : 2, nBytes = level.size() * bytesPer;
+                const size_t at = T->tableData.size();
+                T->tableData.resize(at + (nBytes + 3) / 4, 0.f);
+                uint8_t *dst = reinterpret_cast<uint8_t *>(&T->tableData[at]);
+                if (bytesPer == 1) for (size_t i = 0; i < level.size(); ++i) dst[i] = (uint8_t)img.QuantizeCode(level[i]);
+                else for (size_t i = 0; i < level.size(); ++i) { const uint16_t hb = (uint16_t)img.QuantizeCode(level[i]); memcpy(dst + 2 * i, &hb, 2); }
+            }
             if (l == im.n_levels - 1) break;
             int nw = std::max(1, lw / 2), nh = std::max(1, lh / 2);
             std::vector<float> next((size_t)nw * nh * nc);

@@ -313,3 +313,21 @@ def test_measured_brdf_files_are_validated(wfpt, tmp_path):
     with pytest.raises(wfpt.WfError) as e:
         wfpt.Scene(text='Film "rgb"\nWorldBegin\nMaterial "measured"\nShape "sphere"\n', spp=1)
     assert "Filename must be provided" in str(e.value)
+
+
+def test_8bit_image_maps_take_a_quarter_of_the_table(wfpt, tmp_path, monkeypatch):
+    """The compact texel store (WF_TEXEL_U8 / WF_TEXEL_HALF, include/wf_abi.h): the table file of the PNG-textured golden scene is less than
+    half the file of the all-float store (its maps are 8-bit, a few are 16-bit; the rest of the file is the scene's other tables)."""
+    path = os.path.join(GOLDEN, "png_textures.pbrt")
+    sizes = {}
+    for mode in ("compact", "float"):
+        d = tmp_path / mode
+        d.mkdir()
+        monkeypatch.setenv("WF_TABLE_CACHE", str(d))
+        if mode == "float":
+            monkeypatch.setenv("WF_TEXELS_FLOAT", "1")
+        wfpt.Scene(path=path, spp=1).close()
+        files = [f for f in os.listdir(d) if f.endswith(".wftab")]
+        assert len(files) == 1
+        sizes[mode] = os.path.getsize(d / files[0])
+    assert sizes["compact"] < 0.5 * sizes["float"], sizes

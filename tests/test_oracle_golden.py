@@ -124,3 +124,16 @@ def test_cpu_checker_mean_matches_volpath(built, tmp_path):
     run_wf_cpu(os.path.join(GOLDEN, "cornell64.pbrt"), out, 64)
     img = read_pfm(out)
     assert abs(img.mean() - ref.mean()) / ref.mean() < 0.025
+
+
+def test_compact_texel_store_equals_the_float_store(built, tmp_path, monkeypatch):
+    """8-bit and half image maps keep their source format in table_data (WF_TEXEL_U8 + the encoding's 256-entry table, WF_TEXEL_HALF: a quarter /
+    half of the bytes per texel, what the reference's MIP levels hold) — the png_textures scene (every PNG colour type and depth, sRGB / linear /
+    gamma encodings, RGBA alpha, resampled non-power-of-two maps) renders the reference's image with either store."""
+    ref = read_pfm(os.path.join(GOLDEN, "png_textures_ref.pfm"))
+    for mode in ("compact", "float"):
+        if mode == "float":
+            monkeypatch.setenv("WF_TEXELS_FLOAT", "1")
+        out = str(tmp_path / (mode + ".pfm"))
+        run_wf_cpu(os.path.join(GOLDEN, "png_textures.pbrt"), out, 4)
+        assert (read_pfm(out).view(np.uint32) == ref.view(np.uint32)).all(), mode
