@@ -36,6 +36,7 @@ WF_HD S4 toS4(F4 f) { return S4{{f.x, f.y, f.z, f.w}}; }
 enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
     CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS, CNT_CURSOR, CNT_TR0, CNT_TR1,
+    CNT_RETRACE_HEAD, CNT_WAVES_DONE,   // the closest-hit kernel's in-kernel near-tie queue (wf_backend.hip: DrainRetrace)
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -114,6 +115,7 @@ struct WorkState {
     int32_t *mixQ;    // HIP traversal kernel only: hits on a MixMaterial, resolved by the kernel that follows it
     uint32_t *routeCode;  // HIP traversal kernel only (split routing): per ray slot, the hit primitive's routing code | ROUTE_SKIP
     int32_t *retraceQ;  // HIP traversal kernel only: rays whose closest hit was a near-tie (wf_traverse.h), re-traced in reference order
+    unsigned long long *retraceQ64;  // the same for the kernels that drain the queue themselves: ray index | bound bits << 32, ~0 = not yet written
     int32_t *matQ[WF_MAT_NTYPES];
     struct BssrdfItem *bssrdfQ;       // GetBSSRDFAndProbeRayQueue / SubsurfaceScatterQueue (K12; allocated when sv.haveSubsurface)
     struct SubsurfaceItem *sssQ;

@@ -572,13 +572,15 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
 #ifndef WF_REFILL_AT
 #define WF_REFILL_AT 40
 #endif
-template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
-__device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
+template <bool ANY, int GEN, bool INST = false, bool DEFER = false, typename Fetch, typename Finish>
+__device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4,
+                                        int workBlocks = 0) {
     LoadTreeTop(bvh);
-    if (n < 2 * (int)gridDim.x * TBLOCK) cursor = nullptr;
+    if (workBlocks <= 0) workBlocks = (int)gridDim.x;   // (the first workBlocks workgroups of the grid walk rays; the rest, if any, have another job)
+    if (n < 2 * workBlocks * TBLOCK) cursor = nullptr;
     if (cursor && st.dbg && threadIdx.x == 0 && blockIdx.x == 0) atomicOr(st.dbg + 3, 1);
     const int lane = threadIdx.x & 63;
-    const int waveId = (blockIdx.x * TBLOCK + threadIdx.x) >> 6, nWaves = (gridDim.x * TBLOCK) >> 6;
+    const int waveId = (blockIdx.x * TBLOCK + threadIdx.x) >> 6, nWaves = (workBlocks * TBLOCK) >> 6;
     const int runRays = cursor ? 64 * chunk : 64;
     int next = 0, end = 0, staticJ = 0;   // the wave's private run [next, end) of ray indices (uniform)
     bool exhausted = false;
@@ -591,7 +593,9 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
     w.b0 = w.b1 = w.b2 = 0;
     w.inst = w.curInst = -1;
     auto retire = [&]() {
-        if constexpr (!ANY && RetraceInline(GEN)) {
+        // DEFER: `finish` queues a near-tie ray and the kernel resolves it after its walks (DrainRetrace) — the reference-order walk inlined HERE
+        // costs the closest-hit kernel 37 % (76.9 vs 56.0 ms per 16 spp on the spec scene), without it the refill gains 28 % (40.3 ms)
+        if constexpr (!ANY && RetraceInline(GEN) && !DEFER) {
             if (WalkAmbiguous(w)) {
                 V3 o, d;
                 float t0;
@@ -662,13 +666,91 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
 #define WF_REFILL_SHADOW 1
 #endif
 #ifndef WF_REFILL_CLOSEST
-#define WF_REFILL_CLOSEST 0
+#define WF_REFILL_CLOSEST 1   // with the near-tie walk out of the loop (DrainRetrace): 56.0 -> see DESIGN 4.1
 #endif
 // PERLANE: `finish` has no workgroup barrier (every caller but the workgroup-routed closest-hit variant, SPLIT = false)
-template <bool ANY, int GEN, bool INST, bool PERLANE, typename Fetch, typename Finish>
-__device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
-    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW : WF_REFILL_CLOSEST)) BatchTraceRefill<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
+// DEFER (closest-hit only): the caller queues near-tie rays in `finish` and drains the queue itself after this returns
+template <bool ANY, int GEN, bool INST, bool PERLANE, bool DEFER = false, typename Fetch, typename Finish>
+__device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4,
+                                  int workBlocks = 0) {
+    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : DEFER)) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
     else BatchTrace<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
+}
+// The near-tie rays of a closest-hit launch, resolved inside the launch (round 3, second step).  A walk that ends on a near-tie publishes
+// (ray index | starting bound) with ONE 64-bit atomic into retraceQ64 (slots are ~0 until written).  The reference-order walks of the
+// queued rays are long single-lane walks (the old re-trace launch: 1.4-2 ms for its longest one), so they must run BESIDE the production
+// walks, not after them: the last WF_SERVICE_BLOCKS workgroups of the grid walk no rays — they poll the queue (s_sleep between polls),
+// take up to 64 entries per wave at a time, one walk per lane, until every worker wave has signed off and the queue is empty.  A worker
+// wave that runs out of rays also takes what is queued at that moment before it signs off.  The wave that signs off last rewinds the
+// counters for the next launch.  Nothing waits for a wave that is not resident: workers never wait, and the service workgroups occupy a
+// fixed handful of slots.  (Grids too small to spare service workgroups: the worker that signs off last takes the rest.)
+#ifndef WF_SERVICE_BLOCKS
+#define WF_SERVICE_BLOCKS 8
+#endif
+__device__ inline int ServiceBlocks() { return (int)gridDim.x >= 8 * WF_SERVICE_BLOCKS ? WF_SERVICE_BLOCKS : 0; }
+template <int GEN, bool INST>
+__device__ inline void DrainRetrace(const SceneView &sv, const WorkState &ws, const FastBVH &bvh, int cur, LdsStackT &st, bool service) {
+    int *cnt = ws.counters + CNT_RETRACE * CNT_STRIDE, *head = ws.counters + CNT_RETRACE_HEAD * CNT_STRIDE, *done = ws.counters + CNT_WAVES_DONE * CNT_STRIDE;
+    const int lane = threadIdx.x & 63;
+    const int totalWaves = (int)gridDim.x * (TBLOCK / 64), workerWaves = ((int)gridDim.x - ServiceBlocks()) * (TBLOCK / 64);
+    const RayQueueV &q = ws.rq[cur];
+    auto takeSome = [&]() -> bool {
+        int base = 0, take = 0;
+        if (lane == 0) {
+            while (true) {
+                const int h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h >= c) break;
+                const int t = c - h < 64 ? c - h : 64;
+                if (atomicCAS(head, h, h + t) == h) { base = h; take = t; break; }
+            }
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        take = __builtin_amdgcn_readfirstlane(take);
+        if (take == 0) return false;
+        if (lane < take) {
+            unsigned long long e;
+            while ((e = __hip_atomic_load(&ws.retraceQ64[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {}   // reserved, store in flight
+            __hip_atomic_store(&ws.retraceQ64[base + lane], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int i = (int)(uint32_t)(e & 0xffffffffull);
+            const float tB = BitsToFloat((uint32_t)(e >> 32));
+            const F4 o = q.o[i], d = q.d[i];
+            const RefHit rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+            ws.routeCode[i] = rh.route;
+            ws.hit[i] = F4{BitsToFloat((uint32_t)rh.prim), rh.b0, rh.b1, rh.b2};
+            if (INST) ws.hitInst[i] = rh.prim >= 0 ? rh.inst : -1;
+            if (sv.haveMedia) ws.hitT[i] = rh.prim >= 0 ? rh.t : WF_INFINITY;
+        }
+        return true;
+    };
+    auto signOff = [&]() -> int {
+        int prev = 0;
+        if (lane == 0) { __threadfence(); prev = atomicAdd(done, 1); }
+        return __builtin_amdgcn_readfirstlane(prev);
+    };
+    bool last;
+    if (!service) {
+        while (takeSome()) {}
+        last = signOff() == totalWaves - 1;   // (only without service workgroups can a worker be the last)
+        if (last) while (takeSome()) {}
+    } else {
+        while (true) {
+            if (takeSome()) continue;
+            int dn = 0;
+            if (lane == 0) dn = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dn = __builtin_amdgcn_readfirstlane(dn);
+            if (dn >= workerWaves) {      // no more pushes: one last look
+                if (takeSome()) continue;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+        last = signOff() == totalWaves - 1;
+    }
+    if (last && lane == 0) {
+        __hip_atomic_store(head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a second launch without the stage reset must not find stale entries)
+        __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // SPLIT = false: a workgroup routes its 256 hits together at the end of every batch (KRouteHitBlock: one atomic per destination queue
@@ -682,7 +764,11 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOS
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     const RayQueueV q = ws.rq[cur];
-    TraceQueue<false, GEN, INST, SPLIT>(
+    // near-ties resolved by this launch itself: the kernels that would otherwise inline the reference-order walk (RetraceInline), walking with refill
+    constexpr bool DRAIN = SPLIT && RetraceInline(GEN) && WF_REFILL_CLOSEST != 0;
+    const int workBlocks = DRAIN ? (int)gridDim.x - ServiceBlocks() : (int)gridDim.x;
+    if (DRAIN && (int)blockIdx.x >= workBlocks) { DrainRetrace<GEN, INST>(sv, ws, bvh, cur, st, true); return; }   // a service workgroup
+    TraceQueue<false, GEN, INST, SPLIT, DRAIN>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
             F4 o4 = q.o[i], d4 = q.d[i];
@@ -692,8 +778,15 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOS
             // near-tie seen (wf_traverse.h): the reference-order walk decides (k_closest_retrace)
             const bool amb = valid && WalkAmbiguous(w);
             if (amb) {
-                ws.retraceQ[atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1)] = i;
-                ws.hit[i] = F4{0, 2 * WalkBound(bvh, WalkT(w)) - WalkT(w), 0, 0};  // the re-trace's starting bound, see k_closest_retrace
+                const int slot = atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1);
+                const float bound = 2 * WalkBound(bvh, WalkT(w)) - WalkT(w);   // the re-trace's starting bound, see k_closest_retrace
+                if constexpr (DRAIN) {
+                    __hip_atomic_store(&ws.retraceQ64[slot], (unsigned long long)(uint32_t)i | ((unsigned long long)FloatToBits(bound) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;   // DrainRetrace writes the ray's record
+                } else {
+                    ws.retraceQ[slot] = i;
+                    ws.hit[i] = F4{0, bound, 0, 0};
+                }
             }
             if constexpr (SPLIT) {
                 if (!valid) return;
@@ -704,7 +797,8 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOS
                 if (sv.haveMedia) ws.hitT[i] = w.prim >= 0 ? WalkT(w) : WF_INFINITY;
             } else
             KRouteHitBlock<(GEN > 1) || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
-        }, SPLIT ? cursor : nullptr, chunk);
+        }, SPLIT ? cursor : nullptr, chunk, workBlocks);
+    if constexpr (DRAIN) DrainRetrace<GEN, INST>(sv, ws, bvh, cur, st, false);
 }
 // the routing pass of the SPLIT traversal: EnqueueWorkAfterIntersection / Miss for every ray of the queue (block-aggregated pushes)
 // (1024 threads per workgroup: one returning atomic per destination queue per 1024 rays — a queue counter sustains ~88 of them per
@@ -1757,7 +1851,8 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     }
     if (ctx->svHost.haveMix && ((e = devAlloc(ctx, &ws.mixMat, n)) || (e = devAlloc(ctx, &ws.mixQ, n)))) return e;
     if (ctx->svHost.haveSubsurface && ((e = devAlloc(ctx, &ws.samples2, n)) || (e = devAlloc(ctx, &ws.bssrdfQ, n)) || (e = devAlloc(ctx, &ws.sssQ, n)))) return e;
-    if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n)) || (e = devAlloc(ctx, &ws.retraceQ, n))) return e;
+    if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n)) || (e = devAlloc(ctx, &ws.retraceQ, n)) || (e = devAlloc(ctx, &ws.retraceQ64, n))) return e;
+    HIPCHK(hipMemset(ws.retraceQ64, 0xff, (size_t)n * sizeof(unsigned long long)));   // every slot "not yet written"
     if (ctx->svHost.nInstances > 0 && (e = devAlloc(ctx, &ws.hitInst, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
         if ((e = devAlloc(ctx, &ws.matQ[m], ctx->matPresent[m] ? n : (size_t)1))) return e;  // workqueue.h:152-155
@@ -1842,6 +1937,7 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
     mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE) | (1u << CNT_BSSRDF) | (1u << CNT_SSS);
+    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + statDepth(depth), CNT_RAY0 + cur);
     return 0;
