@@ -888,6 +888,109 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// The light sample of next-event estimation (surfscatter.cpp:253-266: lightSampler.Sample, then light.SampleLi) for a whole workgroup.
+// Which code a lane runs here depends on the light it draws — the sky (image infinite light: two binary searches), the sun (a handful of
+// instructions), an emitter (light-BVH descent, then spherical-triangle sampling with its inverse trigonometry) — and on the spec scene
+// the three are interleaved 1 : 1 : 1 over the lanes of a wave, which then executes all three in turn with a third of its lanes each.
+// The first decision of the sampler (u against pInfinite, lightsamplers.h:270-283) is known up front, so the workgroup's requests are
+// SORTED by it through LDS (a counting sort over eight classes: 21 floats per lane each way), every lane serves the request that lands
+// in its slot — whole waves of one class — and the results travel back the same way.  Same arithmetic on the same inputs: bit-identical.
+struct LightPick {
+    int lightId = -1;
+    float pmf = 0;
+    LightLiSample ls{};
+};
+template <bool RARE>
+WF_HD LightPick SampleLightDirect(const SceneView &sv, const LightCtx &ctx, float u0, V2 u, const Wavelengths &lambda) {
+    LightPick pk;
+    pk.ls.valid = false;
+    pk.lightId = LightSamplerSample(sv, ctx, u0, &pk.pmf);
+    if (pk.lightId >= 0) pk.ls = LightSampleLi<RARE>(sv, sv.lights[pk.lightId], ctx, u, lambda, true);
+    return pk;
+}
+#ifndef WF_NEE_REGROUP
+#define WF_NEE_REGROUP 1
+#endif
+template <bool RARE>
+WF_HD LightPick SampleLightForBlock(const SceneView &sv, bool want, const LightCtx &ctx, float u0, V2 u, const Wavelengths &lambda) {
+#if defined(__HIP_DEVICE_COMPILE__) && WF_NEE_REGROUP
+    constexpr int NF = 21, NT = 256, NK = 8;   // (the material kernels run 256-thread workgroups: wf_mat.hip MBLOCK)
+    __shared__ float s_x[NF][NT];
+    __shared__ int s_cnt[NK][NT / 64];
+    // class of the request: the branch LightSamplerSample takes first
+    int key = NK - 1;   // no request
+    if (want) {
+        if (sv.lightSampler == WF_LS_BVH) {
+            const int nInf = sv.nInfiniteLights;
+            const float pInfinite = float(nInf) / float(nInf + (sv.nLightBvhNodes == 0 ? 0 : 1));
+            if (u0 < pInfinite) {
+                int index = (int)(u0 / pInfinite * nInf);
+                if (index > nInf - 1) index = nInf - 1;
+                key = index < NK - 2 ? index : NK - 3;
+            } else key = NK - 2;
+        } else key = 0;
+    }
+    const unsigned lane = __lane_id();
+    const int wave = threadIdx.x >> 6;
+    int rank = 0;
+    for (int k = 0; k < NK; ++k) {
+        const unsigned long long m = __ballot(key == k);
+        if (lane == 0) s_cnt[k][wave] = __popcll(m);
+        if (key == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    int dst = rank;
+    for (int k = 0; k < NK; ++k)
+        for (int w = 0; w < NT / 64; ++w)
+            if (k < key || (k == key && w < wave)) dst += s_cnt[k][w];
+    // request -> slot dst
+    {
+        const float f[NF] = {ctx.pi.lo.x, ctx.pi.lo.y, ctx.pi.lo.z, ctx.pi.hi.x, ctx.pi.hi.y, ctx.pi.hi.z, ctx.n.x, ctx.n.y, ctx.n.z, ctx.ns.x, ctx.ns.y, ctx.ns.z,
+                             u0, u.x, u.y, lambda.lambda[0], lambda.lambda[1], lambda.lambda[2], lambda.lambda[3], BitsToFloat((uint32_t)key), 0.f};
+#pragma unroll
+        for (int k = 0; k < NF; ++k) s_x[k][dst] = f[k];
+    }
+    __syncthreads();
+    // serve the request in slot threadIdx.x
+    {
+        const int t = threadIdx.x;
+        LightPick pk;
+        pk.ls.valid = false;
+        pk.ls.L = S4c(0.f); pk.ls.wi = V3{0, 0, 0}; pk.ls.pdf = 0; pk.ls.pLightPi = P3i{V3{0, 0, 0}, V3{0, 0, 0}}; pk.ls.pLightN = N3{0, 0, 0};
+        if ((int)FloatToBits(s_x[19][t]) != NK - 1) {
+            LightCtx c;
+            c.pi.lo = V3{s_x[0][t], s_x[1][t], s_x[2][t]}; c.pi.hi = V3{s_x[3][t], s_x[4][t], s_x[5][t]};
+            c.n = N3{s_x[6][t], s_x[7][t], s_x[8][t]}; c.ns = N3{s_x[9][t], s_x[10][t], s_x[11][t]};
+            Wavelengths l;
+            for (int k = 0; k < 4; ++k) { l.lambda[k] = s_x[15 + k][t]; l.pdf[k] = 0; }
+            pk = SampleLightDirect<RARE>(sv, c, s_x[12][t], V2{s_x[13][t], s_x[14][t]}, l);
+        }
+        const float r[NF] = {BitsToFloat((uint32_t)pk.lightId), pk.pmf, pk.ls.L[0], pk.ls.L[1], pk.ls.L[2], pk.ls.L[3], pk.ls.wi.x, pk.ls.wi.y, pk.ls.wi.z, pk.ls.pdf,
+                             pk.ls.pLightPi.lo.x, pk.ls.pLightPi.lo.y, pk.ls.pLightPi.lo.z, pk.ls.pLightPi.hi.x, pk.ls.pLightPi.hi.y, pk.ls.pLightPi.hi.z,
+                             pk.ls.pLightN.x, pk.ls.pLightN.y, pk.ls.pLightN.z, pk.ls.valid ? 1.f : 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NF; ++k) s_x[k][t] = r[k];
+    }
+    __syncthreads();
+    LightPick out;
+    out.lightId = (int)FloatToBits(s_x[0][dst]);
+    out.pmf = s_x[1][dst];
+    out.ls.L = S4{{s_x[2][dst], s_x[3][dst], s_x[4][dst], s_x[5][dst]}};
+    out.ls.wi = V3{s_x[6][dst], s_x[7][dst], s_x[8][dst]};
+    out.ls.pdf = s_x[9][dst];
+    out.ls.pLightPi.lo = V3{s_x[10][dst], s_x[11][dst], s_x[12][dst]}; out.ls.pLightPi.hi = V3{s_x[13][dst], s_x[14][dst], s_x[15][dst]};
+    out.ls.pLightN = N3{s_x[16][dst], s_x[17][dst], s_x[18][dst]};
+    out.ls.valid = s_x[19][dst] != 0.f;
+    __syncthreads();   // the slots are reused by the next call
+    if (!want) { out.lightId = -1; out.ls.valid = false; }
+    return out;
+#else
+    if (!want) { LightPick pk; pk.ls.valid = false; return pk; }
+    return SampleLightDirect<RARE>(sv, ctx, u0, u, lambda);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // K9: EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>, wavefront/surfscatter.cpp:57-328
 template <int MAT> struct MatBxDF;
 template <> struct MatBxDF<WF_MAT_DIFFUSE> {
@@ -956,7 +1059,13 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
     // shadow-ray payload
     RayOD sr{V3{0, 0, 0}, V3{0, 0, 0}};
     S4 sLd = S4c(0.f), sr_u = S4c(0.f), sr_l = S4c(0.f);
-    if (valid) {
+    // `live`: an idle lane of the last workgroup shadows the queue's last item with every side effect off, so that all lanes reach the
+    // workgroup-wide light sampling below (SampleLightForBlock) with well-defined operands
+    const bool live = valid;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!valid) qi = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE] - 1;
+#endif
+    {
         int i = ws.matQ[MAT][qi];
         I4 meta = q.meta[i];
         pixelIndex = meta.x;
@@ -1048,10 +1157,10 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         Wavelengths lambda = LoadLambda(ws, pixelIndex);
         BxDF bxdf = MatBxDF<MAT>::Get(sv, mat, lambda, tc);
         BSDF<BxDF> bsdf(ns, dpdus, bxdf);
-        if (lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
+        if (live && lambda.SecondaryTerminated()) StoreLambda(ws, pixelIndex, lambda);
         if (sv.regularize && anyNonSpecularBounces0) bsdf.Regularize();
         if constexpr (VARIANT == 2)
-        if (depth == 0 && sv.film.type == WF_FILM_GBUFFER) {
+        if (live && depth == 0 && sv.film.type == WF_FILM_GBUFFER) {
             // Initialize VisibleSurface at the first intersection (surfscatter.cpp:147-180): geometry + the BSDF's albedo, estimated
             // with the reference's 16 fixed samples (BxDF::rho, bxdfs.cpp:1131-1144)
             const float ucRho[16] = {0.75741637f, 0.37870818f, 0.7083487f, 0.18935409f, 0.9149363f, 0.35417435f, 0.5990858f, 0.09467703f,
@@ -1100,6 +1209,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                 else beta = beta / (1 - qq);
             }
             if (MAT == WF_MAT_SUBSURFACE && beta && bs.IsTransmission()) {
+                if (live) {
                 // the path enters the medium: K12 takes over (surfscatter.cpp:226-231)
                 BssrdfItem b;
                 b.beta = toF4(beta); b.r_u = toF4(r_u);
@@ -1109,6 +1219,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                 b.mediumInside = transition ? mesh.medium_inside : meta.w;
                 b.mediumOutside = transition ? mesh.medium_outside : meta.w;
                 ws.bssrdfQ[QueueAlloc(&ws.counters[(CNT_BSSRDF) * CNT_STRIDE])] = b;
+                }
             } else
             if (beta) {
                 pushRay = true;
@@ -1127,38 +1238,37 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
 #if defined(WF_EXP) && (WF_EXP & 1)
         flags = 0;
 #endif
-        if (IsNonSpecular(flags)) {
-            LightCtx ctx{si.pi, si.n, ns};
+        const bool wantLight = IsNonSpecular(flags);
+        LightCtx ctx{si.pi, si.n, ns};
+        if (wantLight) {
             if (IsReflective(flags) && !IsTransmissive(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, wo));
             else if (IsTransmissive(flags) && IsReflective(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, -wo));
-            float lightPMF = 0;
-            int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
-            if (lightId >= 0) {
-                const wf_light &light = sv.lights[lightId];
-#if defined(WF_EXP) && (WF_EXP & 4)
-                LightLiSample ls{};
-                ls.valid = true; ls.L = S4c(1.f); ls.pdf = 1.f; ls.wi = V3{s0.y, s0.z, 0.5f}; ls.pLightPi = ctx.pi; ls.pLightN = N3{0, 1, 0};
-#else
-                LightLiSample ls = LightSampleLi<RARE_LIGHTS>(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
-#endif
-                if (ls.valid && ls.L && ls.pdf != 0) {
-                    V3 wi = ls.wi;
-                    S4 f = bsdf.f(wo, wi);
-                    if (f) {
-                        S4 beta = wbeta * f * AbsDot(wi, ns);
-                        float lightPDF = ls.pdf * lightPMF;
-                        float bsdfPDF = IsDeltaLight(light) ? 0.f : bsdf.PDF(wo, wi);
-                        sr_u = wr_u * bsdfPDF;
-                        sr_l = wr_u * lightPDF;
-                        sLd = beta * ls.L;
-                        sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
-                        if (sv.haveMedia) smedium = SurfaceMedium(mesh, si.n, sr.d, meta.w);
-                        pushShadow = true;
-                    }
+        }
+        const LightPick pick = SampleLightForBlock<RARE_LIGHTS>(sv, wantLight, ctx, s0.x, V2{s0.y, s0.z}, lambda);
+        if (wantLight && pick.lightId >= 0) {
+            const int lightId = pick.lightId;
+            const float lightPMF = pick.pmf;
+            const wf_light &light = sv.lights[lightId];
+            const LightLiSample &ls = pick.ls;
+            if (ls.valid && ls.L && ls.pdf != 0) {
+                V3 wi = ls.wi;
+                S4 f = bsdf.f(wo, wi);
+                if (f) {
+                    S4 beta = wbeta * f * AbsDot(wi, ns);
+                    float lightPDF = ls.pdf * lightPMF;
+                    float bsdfPDF = IsDeltaLight(light) ? 0.f : bsdf.PDF(wo, wi);
+                    sr_u = wr_u * bsdfPDF;
+                    sr_l = wr_u * lightPDF;
+                    sLd = beta * ls.L;
+                    sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
+                    if (sv.haveMedia) smedium = SurfaceMedium(mesh, si.n, sr.d, meta.w);
+                    pushShadow = true;
                 }
             }
         }
     }
+    pushRay = pushRay && live;
+    pushShadow = pushShadow && live;
     int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], pushRay);
     if (pushRay) {
         nq.o[slot] = F4{ro.x, ro.y, ro.z, time};

@@ -685,7 +685,7 @@ __device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n
 // counters for the next launch.  Nothing waits for a wave that is not resident: workers never wait, and the service workgroups occupy a
 // fixed handful of slots.  (Grids too small to spare service workgroups: the worker that signs off last takes the rest.)
 #ifndef WF_SERVICE_BLOCKS
-#define WF_SERVICE_BLOCKS 8
+#define WF_SERVICE_BLOCKS 16   // spec scene, 16 spp, same box: closest-hit 54.6 ms at 4, 48.0 at 8, 42.5 at 16, 44.4 at 32, 48.1 at 64 (gpurun_out/r3t_, r3u_ab_sm16.txt)
 #endif
 __device__ inline int ServiceBlocks() { return (int)gridDim.x >= 8 * WF_SERVICE_BLOCKS ? WF_SERVICE_BLOCKS : 0; }
 template <int GEN, bool INST>
