@@ -1233,6 +1233,22 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             }
         }
 
+        // the indirect ray leaves NOW (the reference pushes it here too, surfscatter.cpp:232-249): its 35 values are not carried through
+        // the light sampling below
+        pushRay = pushRay && live;
+        {
+            const int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], pushRay);
+            if (pushRay) {
+                nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
+                nq.d[slot] = F4{rwi.x, rwi.y, rwi.z, retaScale};
+                nq.beta[slot] = toF4(rbeta);
+                nq.r_u[slot] = toF4(rr_u);
+                nq.r_l[slot] = toF4(rr_l);
+                StoreCtx(nq, slot, rctx);
+                nq.meta[slot] = I4{pixelIndex, depth + 1, rflags, rmedium};
+            }
+        }
+
         // Sample light and enqueue shadow ray
         int flags = bsdf.Flags();
 #if defined(WF_EXP) && (WF_EXP & 1)
@@ -1267,19 +1283,8 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             }
         }
     }
-    pushRay = pushRay && live;
     pushShadow = pushShadow && live;
-    int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], pushRay);
-    if (pushRay) {
-        nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
-        nq.d[slot] = F4{rwi.x, rwi.y, rwi.z, retaScale};
-        nq.beta[slot] = toF4(rbeta);
-        nq.r_u[slot] = toF4(rr_u);
-        nq.r_l[slot] = toF4(rr_l);
-        StoreCtx(nq, slot, rctx);
-        nq.meta[slot] = I4{pixelIndex, depth + 1, rflags, rmedium};
-    }
-    slot = BlockAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE], pushShadow);
+    const int slot = BlockAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE], pushShadow);
     if (pushShadow) {
         ws.sq.o[slot] = F4{sr.o.x, sr.o.y, sr.o.z, 1 - ShadowEpsilon};
         ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)pixelIndex)};
