@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <array>
 #include <sstream>
 #include <set>
 #include <thread>
@@ -920,12 +922,57 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
     float ISO = ps.GetOneFloat("iso", 100.f);
     float whiteBalanceTemp = ps.GetOneFloat("whitebalance", 0);
     std::string sensorName = ps.GetOneString("sensor", "cie1931");
-    if (sensorName != "cie1931") Die(scene.film.loc, sensorName + ": only the \"cie1931\" sensor is supported by this build");
+    // "Pass through 0 for cie1931 if it's unspecified so that it doesn't do any white balancing. For actual sensors, 6500 is the default"
+    if (sensorName != "cie1931" && whiteBalanceTemp == 0) whiteBalanceTemp = 6500;
     F.imaging_ratio = exposureTime * ISO / 100;
     const SpectralData &sd = SpectralData::Get();
     const ColorSpace *cs = scene.filmColorSpace;
     Mat3 XYZFromSensorRGB = Mat3::Identity();
-    if (whiteBalanceTemp != 0) {
+    SpectrumP rBar = sd.X, gBar = sd.Y, bBar = sd.Z;
+    if (sensorName != "cie1931") {
+        // PixelSensor ctor for a measured sensor (film.h:45-78): the response curves densely sampled, XYZFromSensorRGB = the linear
+        // least-squares fit that takes the sensor's RGB of the 24 ColorChecker swatches under the white-balance illuminant to
+        // their XYZ under the output colour space's illuminant
+        SpectrumP r = sd.Named(sensorName + "_r"), g = sd.Named(sensorName + "_g"), b = sd.Named(sensorName + "_b");
+        if (!r || !g || !b) Die(scene.film.loc, sensorName + ": unknown sensor type");
+        rBar = MakeDense(*r); gBar = MakeDense(*g); bBar = MakeDense(*b);
+        SpectrumP sensorIllum = DaylightD(whiteBalanceTemp);
+        constexpr int nSwatch = 24;
+        // PixelSensor::ProjectReflectance (film.h:119-131): float accumulation over the integer wavelengths 360..830
+        auto Project = [](const SpectrumH &refl, const SpectrumH &illum, const SpectrumH &b1, const SpectrumH &b2, const SpectrumH &b3, float out[3]) {
+            float res[3] = {0, 0, 0}, g_integral = 0;
+            for (float lambda = 360; lambda <= 830; ++lambda) {
+                g_integral += b2(lambda) * illum(lambda);
+                res[0] += b1(lambda) * refl(lambda) * illum(lambda);
+                res[1] += b2(lambda) * refl(lambda) * illum(lambda);
+                res[2] += b3(lambda) * refl(lambda) * illum(lambda);
+            }
+            for (int c = 0; c < 3; ++c) out[c] = res[c] / g_integral;
+        };
+        float rgbCamera[nSwatch][3], xyzOutput[nSwatch][3];
+        const float sensorWhiteG = InnerProduct(*sensorIllum, *gBar);
+        const float sensorWhiteY = InnerProduct(*sensorIllum, *sd.Y);
+        for (int i = 0; i < nSwatch; ++i) {
+            SpectrumP sw = MakeFromInterleaved(sd.raw.at("swatch_" + std::to_string(i)), false);
+            Project(*sw, *sensorIllum, *rBar, *gBar, *bBar, rgbCamera[i]);
+            float xyz[3];
+            Project(*sw, *cs->illuminant, *sd.X, *sd.Y, *sd.Z, xyz);
+            const float k = sensorWhiteY / sensorWhiteG;
+            for (int c = 0; c < 3; ++c) xyzOutput[i][c] = k * xyz[c];
+        }
+        // LinearLeastSquares (util/math.h:701-718)
+        Mat3 AtA{}, AtB{};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int r2 = 0; r2 < nSwatch; ++r2) {
+                    AtA.m[i][j] += rgbCamera[r2][i] * rgbCamera[r2][j];
+                    AtB.m[i][j] += rgbCamera[r2][i] * xyzOutput[r2][j];
+                }
+        Mat3 AtAi;
+        if (!Inverse(AtA, &AtAi)) Die(scene.film.loc, "Sensor XYZ from RGB matrix could not be solved.");
+        const Mat3 prod = AtAi * AtB;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) XYZFromSensorRGB.m[i][j] = prod.m[j][i];
+    } else if (whiteBalanceTemp != 0) {
         // PixelSensor ctor for the XYZ matching functions (film.h:78-90): XYZFromSensorRGB = WhiteBalance(xy of the D illuminant of
         // that temperature, the output colour space's white), the Bradford transform of util/color.h:541-560
         SpectrumP dIllum = DaylightD(whiteBalanceTemp);
@@ -951,9 +998,9 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
         for (int i = 0; i < 3; ++i) LMScorrect.m[i][i] = dstLMS[i] / srcLMS[i];
         XYZFromSensorRGB = XYZFromLMS * LMScorrect * LMSFromXYZ;
     }
-    F.rbar_offset = T->pool.AddDense(*sd.X);
-    F.gbar_offset = T->pool.AddDense(*sd.Y);
-    F.bbar_offset = T->pool.AddDense(*sd.Z);
+    F.rbar_offset = T->pool.AddDense(*rBar);
+    F.gbar_offset = T->pool.AddDense(*gBar);
+    F.bbar_offset = T->pool.AddDense(*bBar);
     Mat3 out = cs->RGBFromXYZ * XYZFromSensorRGB;  // film.cpp:496
     std::memcpy(F.XYZFromSensorRGB, XYZFromSensorRGB.m, sizeof(F.XYZFromSensorRGB));
     std::memcpy(F.outputRGBFromSensorRGB, out.m, sizeof(F.outputRGBFromSensorRGB));
@@ -1931,6 +1978,81 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err);
 struct PlyPrefetch { std::map<std::string, MeshSource> meshes; std::map<std::string, int> uses; };
 static thread_local PlyPrefetch *g_plyPrefetch = nullptr;
 
+// TriQuadMesh::ComputeNormals (util/mesh.cpp:444-467): area-unweighted sum of the unit face normals
+static void ComputeMeshNormals(MeshSource *m) {
+    m->N.assign(m->P.size(), V3{0, 0, 0});
+    for (size_t i = 0; i + 2 < m->indices.size(); i += 3) {
+        const int v[3] = {m->indices[i], m->indices[i + 1], m->indices[i + 2]};
+        const V3 v10 = m->P[v[1]] - m->P[v[0]], v21 = m->P[v[2]] - m->P[v[1]];
+        V3 vn = Cross(v10, v21);
+        if (LengthSquared(vn) > 0) {
+            vn = vn / Length(vn);
+            for (int k = 0; k < 3; ++k) m->N[v[k]] = m->N[v[k]] + vn;
+        }
+    }
+    for (V3 &n : m->N) if (LengthSquared(n) > 0) n = n / Length(n);
+}
+// TriQuadMesh::Displace + Refine (util/mesh.h:91-181) as the "plymesh" shape calls it (shapes.cpp:1417-1455): every triangle
+// is split at the midpoint of its longest edge until all three edges are shorter than maxDist in render space (a split edge is
+// split once: the midpoint vertex is shared through the edge map), the vertices are moved along their normals by the
+// displacement texture's value, the normals are recomputed.  Host-only load-time work, like the reference's.
+static void DisplaceMesh(MeshSource *m, const Transform &rfo, float maxDist, const std::function<float(V3, V2)> &displacement, const std::string &loc) {
+    if (m->uv.empty()) Die(loc, "Vertex uvs are currently required by Displace(). Sorry.");
+    // TriQuadMesh::ConvertToOnlyTriangles (util/mesh.cpp:425-442); the quads are stored f0 f1 f3 f2 here as there
+    for (size_t i = 0; i + 3 < m->quads.size(); i += 4) {
+        const int *q = &m->quads[i];
+        const int t[6] = {q[0], q[1], q[3], q[0], q[3], q[2]};
+        m->indices.insert(m->indices.end(), t, t + 6);
+    }
+    m->quads.clear();
+    if (m->N.empty()) ComputeMeshNormals(m);
+    std::vector<int> oldTriIndices;
+    oldTriIndices.swap(m->indices);
+    std::map<std::pair<int, int>, int> edgeSplit;
+    auto dist = [&](V3 a, V3 b) { return Distance(rfo.Point(a), rfo.Point(b)); };
+    // explicit stack in the recursion's order (first child, then second)
+    std::vector<std::array<int, 3>> stack;
+    for (size_t i = 0; i + 2 < oldTriIndices.size(); i += 3) {
+        stack.push_back({oldTriIndices[i], oldTriIndices[i + 1], oldTriIndices[i + 2]});
+        while (!stack.empty()) {
+            const std::array<int, 3> t = stack.back();
+            stack.pop_back();
+            const int v0 = t[0], v1 = t[1], v2 = t[2];
+            const V3 p0 = m->P[v0], p1 = m->P[v1], p2 = m->P[v2];
+            const float d01 = dist(p0, p1), d12 = dist(p1, p2), d20 = dist(p2, p0);
+            if (d01 < maxDist && d12 < maxDist && d20 < maxDist) {
+                m->indices.push_back(v0); m->indices.push_back(v1); m->indices.push_back(v2);
+                continue;
+            }
+            if (m->P.size() > (size_t)1 << 28) Die(loc, "plymesh displacement: more than 2^28 vertices (\"edgelength\" too small, or a non-finite edge length)");
+            std::array<int, 3> v;   // the first two vertices have the longest edge
+            if (d01 > d12) { if (d01 > d20) v = {v0, v1, v2}; else v = {v2, v0, v1}; }
+            else { if (d12 > d20) v = {v1, v2, v0}; else v = {v2, v0, v1}; }
+            std::pair<int, int> edge(v[0], v[1]);
+            if (v[0] > v[1]) std::swap(edge.first, edge.second);
+            int vmid;
+            auto it = edgeSplit.find(edge);
+            if (it != edgeSplit.end()) vmid = it->second;
+            else {
+                vmid = (int)m->P.size();
+                edgeSplit.emplace(edge, vmid);
+                m->P.push_back((m->P[v[0]] + m->P[v[1]]) / 2.f);
+                V3 nn = m->N[v[0]] + m->N[v[1]];
+                if (LengthSquared(nn) > 0) nn = nn / Length(nn);
+                m->N.push_back(nn);
+                m->uv.push_back(V2{(m->uv[v[0]].x + m->uv[v[1]].x) / 2.f, (m->uv[v[0]].y + m->uv[v[1]].y) / 2.f});
+            }
+            stack.push_back({vmid, v[1], v[2]});
+            stack.push_back({v[0], vmid, v[2]});
+        }
+    }
+    for (size_t i = 0; i < m->P.size(); ++i) {
+        const float d = displacement(m->P[i], m->uv[i]);
+        m->P[i] = m->P[i] + V3{d * m->N[i].x, d * m->N[i].y, d * m->N[i].z};
+    }
+    ComputeMeshNormals(m);
+}
+
 bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSource *m) {
     const ParamSet &ps = sh.params;
     if (sh.name == "trianglemesh") {
@@ -1974,8 +2096,7 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
             }
         }
         if (!have && !ReadPLY(fn, m, &err)) Die(sh.loc, fn + ": " + err);
-        if (!ps.GetTexture("displacement").empty()) Die(sh.loc, "plymesh displacement is not supported by this build");
-        return true;
+        return true;   // a "displacement" texture is applied by the caller (DisplaceMesh: it needs the scene's textures)
     }
     if (sh.name == "bilinearmesh") {
         // BilinearPatch::CreateMesh (shapes.cpp:910-1010)
@@ -2426,6 +2547,20 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (!LoadShapeGeometry(sh, scene.baseDir, &src)) return;
         Transform rfo = sh.renderFromObject;
         if (extra) rfo = Transform(((*extra) * sh.renderFromObject).m);
+        if (sh.name == "plymesh" && !sh.params.GetTexture("displacement").empty()) {
+            // shapes.cpp:1417-1455: UniversalTextureEvaluator on a TextureEvalContext that holds only p (object space) and uv
+            const std::string texName = sh.params.GetTexture("displacement");
+            auto it = tb.floatTextures.find(texName);
+            if (it == tb.floatTextures.end()) Die(sh.loc, texName + ": no such texture defined.");
+            const int texId = it->second;
+            const float edgeLength = sh.params.GetOneFloat("edgelength", 1.f);   // x Options->displacementEdgeScale (1: no such flag here)
+            SceneView tv{};
+            tv.textures = T->textures.data(); tv.texImages = T->texImages.data(); tv.tableData = T->tableData.data();
+            tv.lightXforms = T->lightTransforms.data(); tv.noisePerm = T->noisePerm.empty() ? nullptr : T->noisePerm.data();
+            tv.spectra = T->pool.spectra.data(); tv.spectrumData = T->pool.data.data();
+            tv.self = &tv;
+            DisplaceMesh(&src, rfo, edgeLength, [&](V3 p, V2 uv) { TexCtx tc; tc.p = p; tc.uv = uv; return EvalFloatTexture(tv, texId, tc); }, sh.loc);
+        }
         wf_mesh mesh{};
         mesh.first_tri = (int)T->triIndices.size() / 3;
         mesh.ntris = (int)src.indices.size() / 3;

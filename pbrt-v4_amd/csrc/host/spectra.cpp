@@ -209,18 +209,20 @@ void SpectralData::Init(const std::string &dataDir, const std::string &cacheDir)
     g_sd = sd;
     sd->cacheDir = cacheDir;
     sd->dataDir = dataDir;
-    std::ifstream in(dataDir + "/spectral_tables.txt");
-    if (!in) { fprintf(stderr, "cannot open %s/spectral_tables.txt\n", dataDir.c_str()); exit(1); }
-    std::string line;
-    while (std::getline(in, line)) {
-        if (line.empty() || line[0] == '#') continue;
-        std::istringstream hs(line);
-        std::string name; int n;
-        hs >> name >> n;
-        std::vector<float> v(n);
-        for (int i = 0; i < n; ++i) { std::string tok; in >> tok; v[i] = strtof(tok.c_str(), nullptr); }
-        std::getline(in, line);
-        sd->raw[name] = v;
+    for (const char *file : {"/spectral_tables.txt", "/sensor_tables.txt"}) {
+        std::ifstream in(dataDir + file);
+        if (!in) { fprintf(stderr, "cannot open %s%s\n", dataDir.c_str(), file); exit(1); }
+        std::string line;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream hs(line);
+            std::string name; int n;
+            hs >> name >> n;
+            std::vector<float> v(n);
+            for (int i = 0; i < n; ++i) { std::string tok; in >> tok; v[i] = strtof(tok.c_str(), nullptr); }
+            std::getline(in, line);
+            sd->raw[name] = v;
+        }
     }
     // Spectra::Init (util/spectrum.cpp:2585-2596)
     const auto &lam = sd->raw.at("CIE_lambda");
@@ -242,6 +244,12 @@ void SpectralData::Init(const std::string &dataDir, const std::string &cacheDir)
         std::string e = std::string(m) + "_eta", k = std::string(m) + "_k";
         plain(e.c_str(), ("metal-" + std::string(m) + "-eta").c_str());
         plain(k.c_str(), ("metal-" + std::string(m) + "-k").c_str());
+    }
+    // the camera sensors' response curves (util/spectrum.cpp:2700-2830: "<sensor>_r", "_g", "_b"), data/sensor_tables.txt
+    for (const auto &kv : sd->raw) {
+        const std::string &n = kv.first;
+        if (n.size() > 2 && n[n.size() - 2] == '_' && (n.back() == 'r' || n.back() == 'g' || n.back() == 'b') && islower((unsigned char)n[0]))
+            sd->named[n] = MakeFromInterleaved(kv.second, false);
     }
 }
 

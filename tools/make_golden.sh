@@ -69,6 +69,11 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/portal_un
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/loopsubdiv_ref.pfm $G/loopsubdiv.pbrt
 # film "whitebalance" + "iso" (the cornell64 scene with a 4200 K sensor illuminant): film_whitebalance.pbrt is a sed of cornell64.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_whitebalance_ref.pfm $G/film_whitebalance.pbrt
+# measured camera sensors (PixelSensor's least-squares XYZ matrix over the ColorChecker swatches; default and explicit white balance): seds of film_whitebalance.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_sensor_ref.pfm $G/film_sensor.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_sensor_wb_ref.pfm $G/film_sensor_wb.pbrt
+# plymesh "displacement" (TriQuadMesh::Displace: triangle + quad faces, with / without normals, in an instance, as an emitter): hand-written, displace_*.ply
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/displacement_ref.pfm $G/displacement.pbrt
 # alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # a goniometric light from an 8-bit R G B PNG (channel average re-quantised into an 8-bit "Y" image)
