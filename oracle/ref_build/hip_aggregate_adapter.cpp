@@ -16,7 +16,9 @@
 // the one `pbrt --wavefront` writes, bit for bit (tests/test_gpu_parity.py::test_reference_integrator_over_hip_aggregate).
 // Scope (round 3): triangle meshes with or without alpha textures (the GPU walk makes the reference's stochastic alpha test itself),
 // object instances (TransformedPrimitive: the hit's instance id selects the reference's primitive, whose transform takes the
-// interaction to render space exactly as TransformedPrimitive::Intersect does), media.  Quadrics / curves / patches: not mapped.  Links the shimmed reference build (libpbrt_ref.a); nothing of the reference is modified —
+// interaction to render space exactly as TransformedPrimitive::Intersect does), media, and (round 3, second step) spheres / disks /
+// cylinders / bilinear patches / curves: the hit's primitive id selects the reference's primitive (matched by content), whose own
+// Intersect rebuilds the interaction the reference would have built for that primitive (alpha recursion included).  Links the shimmed reference build (libpbrt_ref.a); nothing of the reference is modified —
 // private members are reached with the test-only `#define private public`.
 //   pbrt_hipagg [--spp N] [--outfile out.pfm] scene.pbrt
 #include <algorithm>
@@ -100,6 +102,11 @@ class HipAggregate : public WavefrontAggregate {
             if (it == ours.end()) ErrorExit("pbrt_hipagg: a reference mesh (%d triangles) has no counterpart in the flat tables", tm->nTriangles);
             firstTri[m] = it->second.first[it->second.second++ % it->second.first.size()];
         }
+        // quadric records (spheres, disks, cylinders, bilinear patches, curve segments) by content, like the meshes
+        nTri = nTriangles;
+        quadPrims.assign(desc->n_quadrics, Primitive());
+        std::map<uint64_t, std::pair<std::vector<int>, size_t>> ourQuadrics;
+        for (int q = 0; q < desc->n_quadrics; ++q) ourQuadrics[QuadricKeyOurs(desc->quadrics[q])].first.push_back(q);
         std::vector<const TransformedPrimitive *> refInstances;
         std::set<const void *> visitedDefs;
         std::function<void(Primitive)> visit = [&](Primitive p) {
@@ -118,7 +125,23 @@ class HipAggregate : public WavefrontAggregate {
             if (p.Is<SimplePrimitive>()) shape = p.Cast<SimplePrimitive>()->shape;
             else if (p.Is<GeometricPrimitive>()) shape = p.Cast<GeometricPrimitive>()->shape;   // (alpha textures: tested by the GPU walk)
             else ErrorExit("pbrt_hipagg: animated primitives are outside this adapter's scope");
-            if (!shape.Is<Triangle>()) ErrorExit("pbrt_hipagg: only triangle meshes are inside this adapter's scope");
+            if (!shape.Is<Triangle>()) {
+                // spheres / disks / cylinders / bilinear patches / curves: the quadric record with the same content
+                const uint64_t k = QuadricKeyRef(shape);
+                auto it = ourQuadrics.find(k);
+                if (it == ourQuadrics.end()) ErrorExit("pbrt_hipagg: a reference %s has no counterpart among the flat tables' quadric records", shape.ToString());
+                const int q = it->second.first[it->second.second++ % it->second.first.size()];
+                quadPrims[q] = p;
+                const wf_mesh &mesh = desc->meshes[desc->quadrics[q].mesh];
+                Material mat = p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->material : p.Cast<GeometricPrimitive>()->material;
+                materialIds[mat.ptr()] = mesh.material;
+                if (p.Is<GeometricPrimitive>()) {
+                    const GeometricPrimitive *g = p.Cast<GeometricPrimitive>();
+                    if (g->mediumInterface.inside) mediumIds[g->mediumInterface.inside.ptr()] = mesh.medium_inside;
+                    if (g->mediumInterface.outside) mediumIds[g->mediumInterface.outside.ptr()] = mesh.medium_outside;
+                }
+                return;
+            }
             const Triangle *t = shape.Cast<Triangle>();
             int id = firstTri[t->meshIndex] + t->triIndex;
             CHECK(id >= 0 && id < nTriangles);
@@ -138,19 +161,24 @@ class HipAggregate : public WavefrontAggregate {
         // the primitives were created in: every triangle must still have found exactly one primitive
         for (const Primitive &p : prims)
             if (!p) ErrorExit("pbrt_hipagg: ambiguous mesh matching (identical meshes with different roles)");
+        for (const Primitive &p : quadPrims)
+            if (!p) ErrorExit("pbrt_hipagg: a quadric record of the flat tables has no counterpart among the reference's primitives");
         // object instances: ours (definition id, render-from-instance matrix) <-> the reference's TransformedPrimitive (the definition
         // is identified through one of its triangles; identical placements of one definition are interchangeable)
         if (desc->n_instances > 0) {
-            std::vector<int> triDef(nTriangles, -1);
+            std::vector<int> triDef(nTriangles + desc->n_quadrics, -1);   // primitive id (triangle or quadric) -> its definition
             for (int k = 0; k < desc->n_instance_defs; ++k)
                 for (int j = 0; j < desc->instance_defs[k].n_prims; ++j) {
                     const int t = desc->bvh_prims[desc->instance_defs[k].first_prim + j];
-                    if (t >= 0 && t < nTriangles) triDef[t] = k;
+                    if (t >= 0 && t < nTriangles + desc->n_quadrics) triDef[t] = k;
                 }
+            std::map<const void *, int> quadOfPrim;   // reference primitive -> quadric id (filled by visit above)
+            for (int q = 0; q < desc->n_quadrics; ++q) quadOfPrim[quadPrims[q].ptr()] = q;
             std::function<int(Primitive)> anyTriangle = [&](Primitive p) -> int {
                 if (p.Is<BVHAggregate>()) { for (Primitive q : p.Cast<BVHAggregate>()->primitives) { int r = anyTriangle(q); if (r >= 0) return r; } return -1; }
                 Shape shape = p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->shape : p.Is<GeometricPrimitive>() ? p.Cast<GeometricPrimitive>()->shape : Shape();
-                if (!shape || !shape.Is<Triangle>()) return -1;
+                if (!shape) return -1;
+                if (!shape.Is<Triangle>()) { auto it = quadOfPrim.find(p.ptr()); return it == quadOfPrim.end() ? -1 : nTriangles + it->second; }
                 return firstTri[shape.Cast<Triangle>()->meshIndex] + shape.Cast<Triangle>()->triIndex;
             };
             instPrims.assign(desc->n_instances, nullptr);
@@ -196,6 +224,24 @@ class HipAggregate : public WavefrontAggregate {
             const wf_hit_record &h = hits[index];
             if (h.prim < 0) {
                 EnqueueWorkAfterMiss(r, mediumSampleQueue, escapedRayQueue);
+                return;
+            }
+            if (h.prim >= nTri) {
+                // a sphere / disk / cylinder / patch / curve segment: the reference's own primitive rebuilds its interaction from the
+                // (instance-space) ray — Shape::Intersect + the alpha recursion + SetIntersectionProperties of
+                // GeometricPrimitive / SimplePrimitive::Intersect (cpu/primitive.cpp:50-110) — and must find the GPU's distance
+                const TransformedPrimitive *tpq = h.instance >= 0 ? instPrims[h.instance] : nullptr;
+                Ray rq = r.ray;
+                if (tpq) { Float tMax = Infinity; rq = tpq->renderFromPrimitive->ApplyInverse(r.ray, &tMax); }
+                pstd::optional<ShapeIntersection> si = quadPrims[h.prim - nTri].Intersect(rq, Infinity);
+                if (!si || si->tHit != h.t) {
+                    if (tMismatch.fetch_add(1) < 8) fprintf(stderr, "pbrt_hipagg: primitive %d: the GPU's hit distance %a is not the reference primitive's %a\n", h.prim, h.t, si ? si->tHit : -1.f);
+                    if (!si) { EnqueueWorkAfterMiss(r, mediumSampleQueue, escapedRayQueue); return; }
+                }
+                SurfaceInteraction intr = si->intr;
+                if (tpq) intr = (*tpq->renderFromPrimitive)(intr);
+                EnqueueWorkAfterIntersection(r, r.ray.medium, si->tHit, intr, mediumSampleQueue, nextRayQueue, hitAreaLightQueue, basicEvalMaterialQueue,
+                                             universalEvalMaterialQueue);
                 return;
             }
             // what Triangle::Intersect + GeometricPrimitive / SimplePrimitive::Intersect build from the hit
@@ -286,6 +332,7 @@ class HipAggregate : public WavefrontAggregate {
             const wf_hit_record &h = hits[index];
             q->reservoirPDF[index] = h.prim < 0 ? 0.f : pdf[index];
             if (h.prim < 0) return;
+            if (h.prim >= nTri) ErrorExit("pbrt_hipagg: subsurface probes that hit quadrics / patches / curves are outside this adapter's scope");
             Primitive p = prims[h.prim];
             const Triangle *tri = (p.Is<SimplePrimitive>() ? p.Cast<SimplePrimitive>()->shape : p.Cast<GeometricPrimitive>()->shape).Cast<Triangle>();
             TriangleIntersection ti{h.b0, h.b1, h.b2, h.t};
@@ -296,9 +343,61 @@ class HipAggregate : public WavefrontAggregate {
         });
     }
 
+    int64_t DistanceMismatches() const { return tMismatch.load(); }
+
   private:
+    // content keys of the non-triangle shapes: the same fields on both sides (FNV-1a over their bits; -0 == +0)
+    static void Mix(uint64_t &h, float f) { f += 0.0f; uint32_t u; std::memcpy(&u, &f, 4); h = (h ^ u) * 1099511628211ull; }
+    static void MixMatrix(uint64_t &h, const SquareMatrix<4> &m) { for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Mix(h, m[a][b]); }
+    static void MixMatrix(uint64_t &h, const float m[4][4]) { for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Mix(h, m[a][b]); }
+    static uint64_t QuadricKeyOurs(const wf_quadric &q) {
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)q.type;
+        switch (q.type) {
+        case WF_QUADRIC_SPHERE: Mix(h, q.radius); Mix(h, q.z_min); Mix(h, q.z_max); Mix(h, q.phi_max); MixMatrix(h, q.render_from_object.m); break;
+        case WF_QUADRIC_DISK: Mix(h, q.z_min); Mix(h, q.radius); Mix(h, q.inner_radius); Mix(h, q.phi_max); MixMatrix(h, q.render_from_object.m); break;
+        case WF_QUADRIC_CYLINDER: Mix(h, q.radius); Mix(h, q.z_min); Mix(h, q.z_max); Mix(h, q.phi_max); MixMatrix(h, q.render_from_object.m); break;
+        case WF_QUADRIC_BILINEAR: { const float *p = &q.render_from_object.m[0][0]; for (int i = 0; i < 12; ++i) Mix(h, p[i]); break; }
+        case WF_QUADRIC_CURVE:
+            for (int i = 0; i < 12; ++i) Mix(h, q.ext[i]);
+            Mix(h, q.radius); Mix(h, q.theta_z_min); Mix(h, q.z_min); Mix(h, q.z_max); Mix(h, q.inner_radius); MixMatrix(h, q.render_from_object.m);
+            break;
+        }
+        return h;
+    }
+    static uint64_t QuadricKeyRef(Shape shape) {
+        uint64_t h = 1469598103934665603ull;
+        if (shape.Is<Sphere>()) {
+            const Sphere *s = shape.Cast<Sphere>();
+            h ^= (uint64_t)WF_QUADRIC_SPHERE;
+            Mix(h, s->radius); Mix(h, s->zMin); Mix(h, s->zMax); Mix(h, s->phiMax); MixMatrix(h, s->renderFromObject->GetMatrix());
+        } else if (shape.Is<Disk>()) {
+            const Disk *s = shape.Cast<Disk>();
+            h ^= (uint64_t)WF_QUADRIC_DISK;
+            Mix(h, s->height); Mix(h, s->radius); Mix(h, s->innerRadius); Mix(h, s->phiMax); MixMatrix(h, s->renderFromObject->GetMatrix());
+        } else if (shape.Is<Cylinder>()) {
+            const Cylinder *s = shape.Cast<Cylinder>();
+            h ^= (uint64_t)WF_QUADRIC_CYLINDER;
+            Mix(h, s->radius); Mix(h, s->zMin); Mix(h, s->zMax); Mix(h, s->phiMax); MixMatrix(h, s->renderFromObject->GetMatrix());
+        } else if (shape.Is<BilinearPatch>()) {
+            const BilinearPatch *s = shape.Cast<BilinearPatch>();
+            const BilinearPatchMesh *mesh = s->GetMesh();
+            const int *v = &mesh->vertexIndices[4 * s->blpIndex];
+            h ^= (uint64_t)WF_QUADRIC_BILINEAR;
+            for (int k = 0; k < 4; ++k) { Mix(h, mesh->p[v[k]].x); Mix(h, mesh->p[v[k]].y); Mix(h, mesh->p[v[k]].z); }
+        } else if (shape.Is<Curve>()) {
+            const Curve *s = shape.Cast<Curve>();
+            const CurveCommon *c = s->common;
+            h ^= (uint64_t)WF_QUADRIC_CURVE;
+            for (int k = 0; k < 4; ++k) { Mix(h, c->cpObj[k].x); Mix(h, c->cpObj[k].y); Mix(h, c->cpObj[k].z); }
+            Mix(h, c->width[0]); Mix(h, c->width[1]); Mix(h, s->uMin); Mix(h, s->uMax); Mix(h, (float)(int)c->type); MixMatrix(h, c->renderFromObject->GetMatrix());
+        } else ErrorExit("pbrt_hipagg: shape type outside this adapter's scope: %s", shape.ToString());
+        return h;
+    }
     CPUAggregate *cpu;
     wf_ctx *ctx;
+    int nTri = 0;
+    std::vector<Primitive> quadPrims;              // quadric id of the flat tables -> the reference's primitive
+    mutable std::atomic<int64_t> tMismatch{0};
     std::vector<Primitive> prims;
     std::map<const void *, int32_t> materialIds;   // the reference's Material (tagged pointer payload) -> material id of the flat tables
     std::map<const void *, int32_t> mediumIds;     // the reference's Medium -> medium id of the flat tables
@@ -345,7 +444,7 @@ int main(int argc, char **argv) {
         CHECK(cpu);
         if (dryRun) {
             const wf_scene_desc *dd = wfh_scene_desc(hs);
-            for (int m = 0; m < dd->n_meshes; ++m) { const float *P = dd->P + 3 * (size_t)dd->meshes[m].first_vertex; fprintf(stderr, "ours mesh %d ntris %d nverts %d p0 %a %a %a\n", m, dd->meshes[m].ntris, dd->meshes[m].nverts, P[0], P[1], P[2]); }
+            for (int m = 0; m < dd->n_meshes; ++m) { if (dd->meshes[m].nverts <= 0) continue; const float *P = dd->P + 3 * (size_t)dd->meshes[m].first_vertex; fprintf(stderr, "ours mesh %d ntris %d nverts %d p0 %a %a %a\n", m, dd->meshes[m].ntris, dd->meshes[m].nverts, P[0], P[1], P[2]); }
             for (size_t m = 0; m < Triangle::allMeshes->size(); ++m) { const TriangleMesh *tm = (*Triangle::allMeshes)[m]; fprintf(stderr, "ref mesh %zu ntris %d nverts %d p0 %a %a %a\n", m, tm->nTriangles, tm->nVertices, tm->p[0].x, tm->p[0].y, tm->p[0].z); }
         }
         HipAggregate *agg = new HipAggregate(cpu, dryRun ? nullptr : wfh_renderer_ctx(hs), wfh_scene_desc(hs));
@@ -365,7 +464,8 @@ int main(int argc, char **argv) {
         metadata.renderTimeSeconds = seconds;
         metadata.samplesPerPixel = in->sampler.SamplesPerPixel();
         in->film.WriteImage(metadata);
-        printf("{\"adapter\": \"HipAggregate\", \"seconds\": %.3f, \"triangles\": %d}\n", (double)seconds, info.n_triangles);
+        printf("{\"adapter\": \"HipAggregate\", \"seconds\": %.3f, \"triangles\": %d, \"distance_mismatches\": %lld}\n", (double)seconds, info.n_triangles,
+               (long long)agg->DistanceMismatches());
     }
     CleanupPBRT();
     return 0;

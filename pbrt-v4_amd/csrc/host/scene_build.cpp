@@ -2593,10 +2593,17 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         if (!src.quads.empty()) {
             // BilinearPatchMesh + BilinearPatch::CreatePatches (util/mesh.cpp:183-230, shapes.cpp:1040-1060): after the shape's triangles,
             // in render space, sharing the shape's wf_mesh (material, media, orientation)
-            if (sh.lightIndex >= 0 && mesh.ntris > 0) Die(sh.loc, "an emissive plymesh with both triangle and quad faces is not supported by this build yet");
-            if (mesh.ntris > 0 && (!sh.params.GetTexture("alpha").empty() || sh.params.GetOneFloat("alpha", 1.f) < 1.f))
-                Die(sh.loc, "alpha on a plymesh with both triangle and quad faces is not supported by this build yet");
-            if (mesh.ntris == 0) mesh.first_tri = -1;  // set to the first patch's primitive id once the triangle count is known
+            // a PLY file with both triangle and quad faces: the patches get a wf_mesh entry of their own (same vertices, material, alpha,
+            // media), so that a hit finds its emitter as first_light + (primitive id - first_tri) in either part; the reference creates
+            // the triangles' lights first, then the patches' (shapes.cpp:1458-1471, scene.cpp:1290-1340)
+            int patchMeshId = meshId;
+            wf_mesh patchMesh = mesh;
+            if (mesh.ntris > 0) {
+                commitMesh(mesh, meshId, sh, rfo, inDefinition);
+                patchMeshId = (int)T->meshes.size();
+                patchMesh.ntris = 0;
+            }
+            patchMesh.first_tri = -1;  // set to the first patch's primitive id once the triangle count is known
             const size_t v0 = (size_t)mesh.first_vertex;
             auto P3 = [&](int vi) { return V3{T->P[3 * (v0 + vi)], T->P[3 * (v0 + vi) + 1], T->P[3 * (v0 + vi) + 2]}; };
             auto N3f = [&](int vi) { return V3{T->N[3 * (v0 + vi)], T->N[3 * (v0 + vi) + 1], T->N[3 * (v0 + vi) + 2]}; };
@@ -2604,7 +2611,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             for (size_t q = 0; q + 3 < src.quads.size(); q += 4) {
                 PendingSphere p{};
                 p.s.type = WF_QUADRIC_BILINEAR;
-                p.s.mesh = meshId;
+                p.s.mesh = patchMeshId;
                 p.s.pad[0] = (float)((src.N.empty() ? 0 : 1) | (src.uv.empty() ? 0 : 2));
                 float *a = &p.s.render_from_object.m[0][0], *b = &p.s.render_from_object.mInv[0][0];
                 const int *vi = &src.quads[q];
@@ -2625,9 +2632,11 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
                 if (rect) p.s.pad[0] = (float)((int)p.s.pad[0] | 4);
                 p.s.radius = BlpArea(bd, rect);
                 prims->emplace_back(-1 - (int)spheres.size(), p.bounds);
-                patchesOfMesh[meshId].push_back((int)spheres.size());
+                patchesOfMesh[patchMeshId].push_back((int)spheres.size());
                 spheres.push_back(p);
             }
+            commitMesh(patchMesh, patchMeshId, sh, rfo, inDefinition);
+            return;
         }
         commitMesh(mesh, meshId, sh, rfo, inDefinition);
     };

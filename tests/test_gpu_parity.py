@@ -115,7 +115,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "quadrics_alpha", "goniometric_png",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "quadrics_alpha", "goniometric_png",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton", "cornell64_sobol", "cornell64_sobol_owen"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
@@ -462,7 +462,7 @@ def test_samples_per_pass_invariance(wfpt):
 
 
 @pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "subsurface", "instances", "alpha_normalmap", "media_box", "media_instances",
-                                  "sanmiguel_like_small"])
+                                  "sanmiguel_like_small", "spheres", "quadrics", "quadrics_alpha", "bilinear", "bilinear_lights", "curves", "instances_quadrics"])
 def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     """The drop-in boundary, compiled and run: oracle/_ref/pbrt_hipagg is the REFERENCE's own WavefrontPathIntegrator (its
     CPU camera / sampler / material / light / film code, linked from the unmodified sources) with its WavefrontAggregate
@@ -480,7 +480,11 @@ def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     if name == "sanmiguel_like_small":
         from conftest import bench_small_scene
         scene_path, _ = bench_small_scene(name, tmp_path / "scene")
-    subprocess.run([exe, "--spp", "4", "--outfile", out, scene_path], check=True, cwd=str(tmp_path))
+    # (round 3, second step: spheres / disks / cylinders / bilinear patches / curves — the hit's primitive id selects the reference's
+    # primitive, whose own Intersect rebuilds the interaction; it must find the GPU's hit distance bit for bit)
+    p = subprocess.run([exe, "--spp", "4", "--outfile", out, scene_path], check=True, cwd=str(tmp_path), capture_output=True, text=True)
+    summary = json.loads(p.stdout.strip().splitlines()[-1])
+    assert summary["distance_mismatches"] == 0, p.stderr[-2000:]
     img = read_pfm(out)
     ref = read_pfm(os.path.join(GOLDEN, name + "_ref.pfm"))
     assert img.shape == ref.shape

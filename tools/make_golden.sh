@@ -74,6 +74,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_sens
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_sensor_wb_ref.pfm $G/film_sensor_wb.pbrt
 # plymesh "displacement" (TriQuadMesh::Displace: triangle + quad faces, with / without normals, in an instance, as an emitter): hand-written, displace_*.ply
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/displacement_ref.pfm $G/displacement.pbrt
+# a PLY file with triangle AND quad faces as an emitter and alpha-tested (the patches get their own mesh entry): hand-written
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/plymesh_mixed_ref.pfm $G/plymesh_mixed.pbrt
 # alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # a goniometric light from an 8-bit R G B PNG (channel average re-quantised into an 8-bit "Y" image)
