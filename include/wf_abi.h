@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 9
+#define WF_ABI_VERSION 10
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -44,6 +44,18 @@ typedef struct wf_transform {    /* util/transform.h:Transform — m and its inv
     float m[4][4];
     float mInv[4][4];
 } wf_transform;
+/* AnimatedTransform (util/transform.h:444-560, util/transform.cpp:375-395): the transformations at the two ends of the
+ * TransformTimes interval and their decomposition (translation, rotation quaternion x y z w, scale matrix) as the reference's
+ * constructor computes it at load; AnimatedTransform::Interpolate (util/transform.cpp:1062-1081) is evaluated from these. */
+typedef struct wf_animated_transform {
+    wf_transform start, end;
+    float start_time, end_time;
+    int32_t actually_animated;    /* startTransform != endTransform */
+    int32_t has_rotation;
+    float T[2][3];
+    float R[2][4];
+    float S[2][4][4];
+} wf_animated_transform;
 
 /* Medium (media.h:226-352): HomogeneousMedium and GridMedium ("uniformgrid"), both with the Henyey-Greenstein
  * phase function.  Spectra are DenselySampledSpectrum tables (471 floats each in spectrum_data), already
@@ -384,6 +396,9 @@ typedef struct wf_camera {
     float physical_extent[4];                    /* film rectangle pMin.xy, pMax.xy (metres) */
     float film_diagonal;                         /* Film::Diagonal() (metres) */
     int32_t aperture_image;                      /* index into tex_images (one channel, level 0) or -1: circular stop */
+    /* camera motion blur: CameraTransform::renderFromCamera as the AnimatedTransform it is (cameras.h:27-110).  When
+       anim.actually_animated is 0 the kernels use renderFromCamera above (= anim.start) and nothing else of it. */
+    wf_animated_transform anim;
 } wf_camera;
 
 enum wf_filter_type { WF_FILTER_BOX = 0, WF_FILTER_GAUSSIAN = 1, WF_FILTER_MITCHELL = 2,

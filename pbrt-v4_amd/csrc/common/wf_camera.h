@@ -465,12 +465,98 @@ WF_HD void XfRay(const float m[4][4], V3 *o, V3 *d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Camera motion blur: CameraTransform::renderFromCamera is an AnimatedTransform (cameras.h:27-110).
+// AnimatedTransform::Interpolate (util/transform.cpp:1062-1081) over the decomposition made at load: the translation and the scale
+// matrix interpolated linearly, the rotation by Slerp (util/vecmath.h:1138-1151), recomposed as Translate(trans) * Transform(rotate) *
+// Transform(scale) — Transform::operator* multiplies m and mInv separately with the generic FMA-accumulated product
+// (util/transform.cpp:141-143, util/math.h:1497-1508), Transform(SquareMatrix<4>) inverts numerically (util/transform.h:44-57).
+struct Quat { float x, y, z, w; };
+WF_HD float QDot(Quat a, Quat b) { return (a.x * b.x + a.y * b.y + a.z * b.z) + a.w * b.w; }   // Dot(q1.v, q2.v) + q1.w * q2.w
+WF_HD float SinXOverX(float x) {   // util/math.h:340-344
+    if (1 - x * x == 1) return 1;
+    return sin(x) / x;
+}
+WF_HD Quat Slerp(float t, Quat q1, Quat q2) {
+    // AngleBetween(Quaternion, Quaternion), util/vecmath.h:1138-1143
+    float theta;
+    if (QDot(q1, q2) < 0) {
+        const Quat s{q1.x + q2.x, q1.y + q2.y, q1.z + q2.z, q1.w + q2.w};
+        theta = Pi - 2 * SafeASin(sqrt(QDot(s, s)) / 2);
+    } else {
+        const Quat d{q2.x - q1.x, q2.y - q1.y, q2.z - q1.z, q2.w - q1.w};
+        theta = 2 * SafeASin(sqrt(QDot(d, d)) / 2);
+    }
+    const float sinThetaOverTheta = SinXOverX(theta);
+    // q1 * (1 - t) * SinXOverX((1 - t) * theta) / sinThetaOverTheta + q2 * t * SinXOverX(t * theta) / sinThetaOverTheta, left to right
+    const float a = 1 - t, sa = SinXOverX((1 - t) * theta), sb = SinXOverX(t * theta);
+    const Quat u{q1.x * a * sa / sinThetaOverTheta, q1.y * a * sa / sinThetaOverTheta, q1.z * a * sa / sinThetaOverTheta, q1.w * a * sa / sinThetaOverTheta};
+    const Quat v{q2.x * t * sb / sinThetaOverTheta, q2.y * t * sb / sinThetaOverTheta, q2.z * t * sb / sinThetaOverTheta, q2.w * t * sb / sinThetaOverTheta};
+    return Quat{u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+}
+WF_HD void MulFMA44(const float a[4][4], const float b[4][4], float r[4][4]) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0;
+            for (int k = 0; k < 4; ++k) acc = fma(a[i][k], b[k][j], acc);
+            r[i][j] = acc;
+        }
+}
+// out of line (pointer arguments): reached only by scenes whose camera moves
+WF_NI void AnimatedInterpolateP(const wf_animated_transform *A, float time, wf_transform *out) {
+    if (!A->actually_animated || time <= A->start_time) { *out = A->start; return; }
+    if (time >= A->end_time) { *out = A->end; return; }
+    const float dt = (time - A->start_time) / (A->end_time - A->start_time);
+    const float trans[3] = {(1 - dt) * A->T[0][0] + dt * A->T[1][0], (1 - dt) * A->T[0][1] + dt * A->T[1][1], (1 - dt) * A->T[0][2] + dt * A->T[1][2]};
+    const Quat q = Slerp(dt, Quat{A->R[0][0], A->R[0][1], A->R[0][2], A->R[0][3]}, Quat{A->R[1][0], A->R[1][1], A->R[1][2], A->R[1][3]});
+    M44 scale, scaleInv;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) scale.m[i][j] = A->S[0][i][j] * (1 - dt) + A->S[1][i][j] * dt;
+    if (!Inverse44(scale, &scaleInv)) {
+        const float nan = BitsToFloat(0x7fc00000u);
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) scaleInv.m[i][j] = nan;
+    }
+    // Transform(Quaternion), util/transform.h:367-384
+    const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+    const float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+    const float wx = q.x * q.w, wy = q.y * q.w, wz = q.z * q.w;
+    float rInv[4][4] = {{1 - 2 * (yy + zz), 2 * (xy + wz), 2 * (xz - wy), 0}, {2 * (xy - wz), 1 - 2 * (xx + zz), 2 * (yz + wx), 0},
+                        {2 * (xz + wy), 2 * (yz - wx), 1 - 2 * (xx + yy), 0}, {0, 0, 0, 1}};
+    float r[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r[i][j] = rInv[j][i];
+    // Translate(trans), util/transform.cpp:21-31
+    const float t[4][4] = {{1, 0, 0, trans[0]}, {0, 1, 0, trans[1]}, {0, 0, 1, trans[2]}, {0, 0, 0, 1}};
+    const float tInv[4][4] = {{1, 0, 0, -trans[0]}, {0, 1, 0, -trans[1]}, {0, 0, 1, -trans[2]}, {0, 0, 0, 1}};
+    float tr[4][4], trInv[4][4];
+    MulFMA44(t, r, tr);          // (Translate * Rotate).m
+    MulFMA44(rInv, tInv, trInv); // (Translate * Rotate).mInv = Rotate.mInv * Translate.mInv
+    MulFMA44(tr, scale.m, out->m);
+    MulFMA44(scaleInv.m, trInv, out->mInv);
+}
+// CameraTransform::RenderFromCamera(time) as a Transform: the interpolated transformation where the camera moves, the static one otherwise
+// (AnimatedTransform::operator()(Ray) / (Point3f, time) / ApplyInverse(..., time): util/transform.cpp:964-1014, util/transform.h:459-477
+// all reduce to Interpolate(time), which returns the end transforms outside (startTime, endTime))
+WF_HD void CameraRenderFromCameraAt(const wf_camera &C, float time, wf_transform *out) {
+    if (!C.anim.actually_animated) { *out = C.renderFromCamera; return; }
+    AnimatedInterpolateP(&C.anim, time, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // CameraBase::Approximate_dp_dxy (cameras.h:155-183) with RotateFromTo (util/transform.h:249-270): the texture
 // footprint of a surface point, from the camera's minimum ray differentials (FindMinimumDifferentials,
 // cameras.cpp:153-203, evaluated on the host)
-WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy) {
+// ANIM: compiled with the moving-camera path (CameraFromRender / RenderFromCamera at the ray's time); without it the static
+// renderFromCamera is used — the back end selects a kernel variant compiled with it when the scene's camera moves
+template <bool ANIM = true>
+WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy, float time = 0) {
     const wf_camera &C = sv.camera;
-    V3 pCamera = XfInvPointM(C.renderFromCamera.mInv, p);  // CameraFromRender(p, time)
+    const float (*rfcM)[4] = C.renderFromCamera.m;
+    const float (*rfcInv)[4] = C.renderFromCamera.mInv;
+    wf_transform moving;
+    if constexpr (ANIM)
+        if (C.anim.actually_animated) {
+            AnimatedInterpolateP(&C.anim, time, &moving);
+            rfcM = moving.m; rfcInv = moving.mInv;
+        }
+    V3 pCamera = XfInvPointM(rfcInv, p);  // CameraFromRender(p, time)
     // RotateFromTo(Normalize(pCamera), (0, 0, 1))
     V3 from = Normalize(pCamera), to{0, 0, 1};
     V3 refl;
@@ -490,7 +576,7 @@ WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy)
     };
     V3 pDownZ = fwdPoint(pCamera);
     // CameraFromRender(n, time) = renderFromCamera.ApplyInverse(Normal3f): m transposed (util/transform.h:409-415)
-    const float (*m)[4] = C.renderFromCamera.m;
+    const float (*m)[4] = rfcM;
     N3 nCam{m[0][0] * n.x + m[1][0] * n.y + m[2][0] * n.z, m[0][1] * n.x + m[1][1] * n.y + m[2][1] * n.z,
             m[0][2] * n.x + m[1][2] * n.y + m[2][2] * n.z};
     // DownZFromCamera(Normal3f): mInv transposed = r (mInv = Transpose(r))
@@ -509,8 +595,8 @@ WF_HD void ApproximateDpDxy(const SceneView &sv, V3 p, N3 n, V3 *dpdx, V3 *dpdy)
         return V3{r[0][0] * q.x + r[1][0] * q.y + r[2][0] * q.z, r[0][1] * q.x + r[1][1] * q.y + r[2][1] * q.z,
                   r[0][2] * q.x + r[1][2] * q.y + r[2][2] * q.z};
     };
-    *dpdx = sppScale * XfVector(C.renderFromCamera.m, invVec(px - pDownZ));
-    *dpdy = sppScale * XfVector(C.renderFromCamera.m, invVec(py - pDownZ));
+    *dpdx = sppScale * XfVector(rfcM, invVec(px - pDownZ));
+    *dpdy = sppScale * XfVector(rfcM, invVec(py - pDownZ));
 }
 
 
@@ -622,9 +708,23 @@ WF_HD float TraceLensesFromScene(const SceneView &sv, const wf_camera &C, V3 co,
 // GetCameraSample (samplers.h:796-814) + Perspective/OrthographicCamera::GenerateRay
 // (cameras.cpp:404-428, 283-307) + the identity "movingFromCamera" the wavefront loop applies
 // (wavefront/camera.cpp:64, integrator.cpp:364-368)
+// CameraTransform::RenderFromCamera(Ray) = AnimatedTransform::operator()(const Ray &) (util/transform.cpp:964-973)
+// (ANIM = false: a kernel instance for scenes whose camera does not move — the interpolation's registers and scratch stay out of it)
+template <bool ANIM = true>
+WF_HD void CameraXfRay(const wf_camera &C, float time, V3 *o, V3 *d) {
+    if (ANIM && C.anim.actually_animated && time > C.anim.start_time) {
+        if (time >= C.anim.end_time) XfRay(C.anim.end.m, o, d);
+        else {
+            wf_transform t;
+            AnimatedInterpolateP(&C.anim, time, &t);
+            XfRay(t.m, o, d);
+        }
+    } else XfRay(C.renderFromCamera.m, o, d);
+}
 struct CameraRayR { V3 o, d; float time; bool valid; float weight = 1; };
 // applyMoving: the identity "movingFromCamera" transform of the wavefront loop (it still walks the origin off its rounding-error
 // bound); Camera::GenerateRay itself, as FindMinimumDifferentials calls it at load, does not have it
+template <bool ANIM = true>
 WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSample, V2 pLens, bool applyMoving = true) {
     const wf_camera &C = sv.camera;
     if (C.type == WF_CAMERA_REALISTIC) {
@@ -649,7 +749,7 @@ WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSamp
         float weight = TraceLensesFromFilm(sv, C, pF, fd, &o, &d);
         if (weight == 0) return none;
         float time = Lerp(timeSample, C.shutterOpen, C.shutterClose);
-        XfRay(C.renderFromCamera.m, &o, &d);
+        CameraXfRay<ANIM>(C, time, &o, &d);
         d = Normalize(d);
         float cosT = Normalize(fd).z;
         weight *= Sqr(Sqr(cosT)) / (pdf * Sqr(lensRearZ));
@@ -677,7 +777,7 @@ WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSamp
         { float t = dir.y; dir.y = dir.z; dir.z = t; }
         V3 so{0, 0, 0};
         float stime = Lerp(timeSample, C.shutterOpen, C.shutterClose);
-        XfRay(C.renderFromCamera.m, &so, &dir);
+        CameraXfRay<ANIM>(C, stime, &so, &dir);
         const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
         XfRay(I, &so, &dir);
         return {so, dir, stime, true};
@@ -700,7 +800,7 @@ WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSamp
         o = V3{pl.x, pl.y, 0};  // both projective cameras (cameras.cpp:301,422)
         d = Normalize(pFocus - o);
     }
-    XfRay(C.renderFromCamera.m, &o, &d);
+    CameraXfRay<ANIM>(C, time, &o, &d);
     // movingFromCamera == identity Transform
     const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     XfRay(I, &o, &d);

@@ -262,6 +262,7 @@ WF_HD void KSampleTops(const SceneView &sv, const WorkState &ws, int item, int y
     ws.sampleTops[item] = (uint32_t)sampler.TopDigits();
 }
 
+template <bool ANIM = true>
 WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixelIndex, int y0, int sampleBase, int sampleStep, int nSamples,
                               bool useTops = false) {
     // pixelIndex = item index: sample slot s = pixelIndex / pixelsPerPass, band pixel p = pixelIndex % pixelsPerPass
@@ -297,7 +298,7 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
         pLens = V2{0.5f, 0.5f};
         filterWeight = 1;
     }
-    CameraRayR cr = GenerateCameraRay(sv, pFilm, time, pLens);
+    CameraRayR cr = GenerateCameraRay<ANIM>(sv, pFilm, time, pLens);
     ws.L[pixelIndex] = F4{0, 0, 0, 0};
     if (F.type == WF_FILM_GBUFFER) ws.vsP[pixelIndex] = F4{0, 0, 0, 0};   // visibleSurface = VisibleSurface() (wavefront/camera.cpp:70-71)
     StoreLambda(ws, pixelIndex, lambda);
@@ -1098,7 +1099,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         if constexpr (TEXCTX)
         if (!sv.options.disable_texture_filtering) {
             // movingFromCamera is the identity transform
-            ApproximateDpDxy(sv, tc.p, si.n, &tc.dpdx, &tc.dpdy);
+            ApproximateDpDxy<VARIANT == 2>(sv, tc.p, si.n, &tc.dpdx, &tc.dpdy, time);   // (a moving camera: variant 2)
             dpdxVS = tc.dpdx; dpdyVS = tc.dpdy;
             V3 dpdu = si.dpdu, dpdv = si.dpdv;
             float ata00 = Dot(dpdu, dpdu), ata01 = Dot(dpdu, dpdv), ata11 = Dot(dpdv, dpdv);

@@ -148,11 +148,13 @@ __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, in
 __global__ void __launch_bounds__(BLOCK) k_sample_tops(const SceneView sv, WorkState ws, int y0, int dim0) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < 5 * ws.pixelsPerPass; i += gridDim.x * BLOCK) KSampleTops(sv, ws, i, y0, dim0);
 }
+// ANIM: the instance for a moving camera (AnimatedTransform::Interpolate per ray); scenes with a static camera launch the other one
+template <bool ANIM>
 __global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleBase, int sampleStep, int nSamples) {
     if (sv.camera.type != WF_CAMERA_REALISTIC && blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, nSamples);
     const bool useTops = ws.sampleTops != nullptr;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
-        KGenerateCameraRay(sv, ws, i, y0, sampleBase, sampleStep, nSamples, useTops);
+        KGenerateCameraRay<ANIM>(sv, ws, i, y0, sampleBase, sampleStep, nSamples, useTops);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleBase, int sampleStep, int topsDepth) {
@@ -1948,7 +1950,10 @@ int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
     if (ctx->ws.sampleTops) LAUNCH("Sampler index prefixes", k_sample_tops, gridFor(5 * ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, y0, 0);
     if (ctx->svHost.camera.type == WF_CAMERA_REALISTIC)  // rays blocked by the lenses leave no queue entry: the kernel appends
         LAUNCH("Reset ray queue", k_reset, 1, ctx->ws, 1u << CNT_RAY0, -1, 0);
-    LAUNCH("Generate camera rays", k_gen_camera_rays, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index, ctx->passStep, ctx->passSamples);
+    if (ctx->svHost.camera.anim.actually_animated)
+        LAUNCH("Generate camera rays", k_gen_camera_rays<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index, ctx->passStep, ctx->passSamples);
+    else
+        LAUNCH("Generate camera rays", k_gen_camera_rays<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, y0, sample_index, ctx->passStep, ctx->passSamples);
     LAUNCH("Update camera ray stats", k_reset, 1, ctx->ws, 0u, 0, CNT_RAY0);
     return 0;
 }
@@ -2104,7 +2109,7 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     {
         Prof prof_(ctx, names[material_type]);
         const bool tex = ctx->svHost.texNeedsFootprint != 0;
-        const bool rare = ctx->rareLights || ctx->svHost.film.type == WF_FILM_GBUFFER;   // a portal infinite light, or a GBufferFilm: the variant that can reach the portal samplers / fills the visible surface
+        const bool rare = ctx->rareLights || ctx->svHost.film.type == WF_FILM_GBUFFER || ctx->svHost.camera.anim.actually_animated;   // a portal infinite light, or a GBufferFilm: the variant that can reach the portal samplers / fills the visible surface
         switch (material_type) {
         case 1: (rare ? wf_launch_eval_material_1_2 : tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 2: (rare ? wf_launch_eval_material_2_2 : tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;

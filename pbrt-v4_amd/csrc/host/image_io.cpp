@@ -393,7 +393,10 @@ void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img) {
     if (ext == "pfm") ReadPFMImage(path, img);
     else if (ext == "png") ReadPNG(path, enc, img);
     else if (ext == "exr") ReadEXR(path, img);
-    else Die("", path + ": no support for reading images with this extension (this build reads .pfm, .png and .exr)");
+    else if (ext == "qoi") ReadQOI(path, img);
+    else if (ext == "hdr") ReadHDR(path, img);
+    else if (ext == "tga") ReadTGA(path, img);   // (the reference reaches TGA through stb_image's catch-all stbi_load, util/image.cpp:888-916)
+    else Die("", path + ": no support for reading images with this extension (this build reads .pfm, .png, .exr, .qoi, .hdr and .tga)");
 }
 
 bool WritePFM(const std::string &path, const float *rgb, int w, int h) {

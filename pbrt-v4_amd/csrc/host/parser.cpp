@@ -1,9 +1,10 @@
 // parser.cpp — .pbrt (v4 syntax) tokenizer + directive interpreter.  Restates the behaviour of
 // src/pbrt/parser.cpp (tokenizer :140-330, parameter lists :434-600, directives :600-1000) and the
-// graphics-state bookkeeping of BasicSceneBuilder (src/pbrt/scene.cpp:80-620) for the static
-// (non-animated) subset: ActiveTransform is tracked (start- and end-time CTM); creating something where the two differ is refused; TransformTimes are accepted
-// and ignored.
+// graphics-state bookkeeping of BasicSceneBuilder (src/pbrt/scene.cpp:80-620).  ActiveTransform is tracked (start- and end-time
+// CTM) and TransformTimes kept: a CAMERA created under two different CTMs moves over that interval (camera motion blur — what the
+// reference's own GPU path supports too); creating a shape, light or medium where the two differ (AnimatedPrimitive) is refused.
 #include "scene.h"
+#include "hanimated.h"
 
 #include <cctype>
 #include <cstdarg>
@@ -289,7 +290,8 @@ struct Interpreter {
     GraphicsState gs;
     std::vector<GraphicsState> pushed;
     std::vector<char> pushKinds;
-    std::map<std::string, Transform> namedCoordinateSystems;
+    std::map<std::string, std::pair<Transform, Transform>> namedCoordinateSystems;   // TransformSet: start- and end-time transformation
+    float transformStartTime = 0, transformEndTime = 1;   // TransformTimes
     Transform renderFromWorld;
     bool inWorld = false;
     InstanceDefinition *activeInstance = nullptr;
@@ -395,7 +397,7 @@ struct Interpreter {
                 else if (a == "EndTime") gs.activeBits = 2;
                 else if (a == "All") gs.activeBits = 3;
                 else Fatal(loc, "Unknown ActiveTransform \"%s\".", a.c_str());
-            } else if (tok == "TransformTimes") { nextFloat(); nextFloat(); }
+            } else if (tok == "TransformTimes") { transformStartTime = nextFloat(); transformEndTime = nextFloat(); }
             else if (tok == "AreaLightSource") {
                 gs.areaLightName = nextString();
                 gs.areaLightParams = MakeParams(ParseParams(tz), gs.lightAttributes);
@@ -411,11 +413,11 @@ struct Interpreter {
                 Transform t = TransposeT(Transform(mm));
                 if (gs.activeBits & 1) gs.ctm = (tok == "Transform") ? t : gs.ctm * t;
                 if (gs.activeBits & 2) gs.ctmEnd = (tok == "Transform") ? t : gs.ctmEnd * t;
-            } else if (tok == "CoordinateSystem") namedCoordinateSystems[nextString()] = gs.ctm;
+            } else if (tok == "CoordinateSystem") namedCoordinateSystems[nextString()] = {gs.ctm, gs.ctmEnd};
             else if (tok == "CoordSysTransform") {
                 std::string n = nextString();
                 auto it = namedCoordinateSystems.find(n);
-                if (it != namedCoordinateSystems.end()) { if (gs.activeBits & 1) gs.ctm = it->second; if (gs.activeBits & 2) gs.ctmEnd = it->second; }
+                if (it != namedCoordinateSystems.end()) { if (gs.activeBits & 1) gs.ctm = it->second.first; if (gs.activeBits & 2) gs.ctmEnd = it->second.second; }
                 else fprintf(stderr, "Warning: %s: Couldn't find named coordinate system \"%s\"\n", loc.c_str(), n.c_str());
             } else if (tok == "ColorSpace") {
                 std::string n = nextString();
@@ -424,15 +426,23 @@ struct Interpreter {
                 gs.colorSpace = cs;
             } else if (tok == "Camera") {
                 basicParamDirective(&scene->camera);
-                RequireStaticCTM(loc);
+                // BasicSceneBuilder::Camera (scene.cpp:232-262): the camera keeps BOTH CTMs — a camera created under two different
+                // ones moves over [TransformTimes] (camera motion blur)
                 scene->cameraFromWorld = gs.ctm;
                 scene->worldFromCamera = Inverse(gs.ctm);
-                namedCoordinateSystems["camera"] = Inverse(gs.ctm);
+                scene->worldFromCameraEnd = Inverse(gs.ctmEnd);
+                scene->transformStartTime = transformStartTime;
+                scene->transformEndTime = transformEndTime;
+                namedCoordinateSystems["camera"] = {Inverse(gs.ctm), Inverse(gs.ctmEnd)};
                 scene->cameraMedium = gs.currentOutsideMedium;
-                // CameraTransform (cameras.cpp:27-57), camera-world rendering space (options default)
-                V3 pCamera = scene->worldFromCamera.Point(V3{0, 0, 0});
+                // CameraTransform (cameras.cpp:27-57), camera-world rendering space (options default): render space is world space
+                // translated to the camera's position at the middle of the time interval
+                const wf_animated_transform wfc = MakeAnimatedTransform(scene->worldFromCamera, transformStartTime, scene->worldFromCameraEnd, transformEndTime);
+                const float tMid = (transformStartTime + transformEndTime) / 2;
+                V3 pCamera = AnimatedAt(wfc, tMid).Point(V3{0, 0, 0});
                 Transform worldFromRender = Translate(pCamera);
                 renderFromWorld = Inverse(worldFromRender);
+                scene->renderFromWorld = renderFromWorld;
             } else if (tok == "Film") { basicParamDirective(&scene->film); scene->filmColorSpace = gs.colorSpace; }
             else if (tok == "Integrator") basicParamDirective(&scene->integrator);
             else if (tok == "Include" || tok == "Import") {
@@ -570,7 +580,7 @@ struct Interpreter {
                 inWorld = true;
                 gs.ctm = gs.ctmEnd = Transform();
                 gs.activeBits = 3;
-                namedCoordinateSystems["world"] = gs.ctm;
+                namedCoordinateSystems["world"] = {gs.ctm, gs.ctmEnd};
             } else if (tok == "WorldEnd") {
             } else Fatal(loc, "%s: unknown directive", tok.c_str());
         }
@@ -593,6 +603,7 @@ static void InitDefaults(ParsedScene *scene, Interpreter *in) {
     diffuse.name = "diffuse";
     diffuse.params.colorSpace = in->gs.colorSpace;
     scene->materials.push_back(diffuse);  // material index 0: default "diffuse" (scene.cpp:97-100)
+    scene->renderFromWorld = Inverse(Translate(V3{0, 0, 0}));   // a scene without a Camera directive: the default camera at the origin
 }
 
 void ParseFiles(const std::vector<std::string> &files, RenderOptions *opt, ParsedScene *scene) {

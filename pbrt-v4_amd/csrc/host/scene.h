@@ -97,7 +97,10 @@ struct RenderOptions {  // subset of PBRTOptions (options.h)
 
 struct ParsedScene {
     Entity camera, film, sampler, filter, integrator, accelerator;
-    Transform cameraFromWorld, worldFromCamera;  // CTM at Camera
+    Transform cameraFromWorld, worldFromCamera;  // CTM at Camera (start time)
+    Transform worldFromCameraEnd;                // the end-time one: differs for a moving camera (ActiveTransform)
+    Transform renderFromWorld;                   // CameraTransform::RenderFromWorld()
+    float transformStartTime = 0, transformEndTime = 1;  // TransformTimes at the Camera directive
     std::string cameraMedium;
     const ColorSpace *filmColorSpace = nullptr;
     std::vector<TextureEntity> textures;
@@ -215,6 +218,10 @@ struct HostImage {
 };
 // Image::Read (util/image.cpp:1000-1040) for .pfm and .png; throws SceneError with the reference's wording
 void ReadImage(const std::string &path, const ColorEnc &enc, HostImage *img);
+// image_formats.cpp: .qoi, Radiance .hdr and .tga as the reference's third-party decoders (ext/qoi, stb_image) read them
+void ReadQOI(const std::string &path, HostImage *img);
+void ReadHDR(const std::string &path, HostImage *img);
+void ReadTGA(const std::string &path, HostImage *img);
 // a NanoVDB float grid expanded over its index bounding box (nanovdb_io.cpp; values[(z * dim[1] + y) * dim[0] + x], origin min)
 struct VdbGrid {
     bool found = false;

@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <zlib.h>
 #include "../common/wf_camera.h"
+#include "hanimated.h"
 #include "../common/wf_shapes.h"
 #include "../common/wf_bssrdf.h"
 #include "../common/wf_lights.h"
@@ -1592,6 +1593,8 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
     C.medium = -1;
     Transform renderFromCamera = renderFromWorld * scene.worldFromCamera;  // cameras.cpp:52-56
     C.renderFromCamera = renderFromCamera.abi();
+    // ... as the AnimatedTransform it is: rfc[1] = renderFromWorld * worldFromCamera.endTransform over the camera's TransformTimes
+    C.anim = MakeAnimatedTransform(renderFromCamera, scene.transformStartTime, renderFromWorld * scene.worldFromCameraEnd, scene.transformEndTime);
     float lensradius = ps.GetOneFloat("lensradius", 0.f);
     float focaldistance = ps.GetOneFloat("focaldistance", 1e6f);
     float frame = ps.GetOneFloat("frameaspectratio", float(F.full_res[0]) / float(F.full_res[1]));
@@ -1816,9 +1819,11 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
                     CameraRayR ry = GenerateCameraRay(sv0, V2{pFilm.x, pFilm.y + eps}, 0.5f, V2{0.5f, 0.5f}, false);
                     if (ry.valid) { ryo = cr.o + (ry.o - cr.o) / eps; ryd = cr.d + (ry.d - cr.d) / eps; break; }
                 }
-                V3 dox = XfVector(C.renderFromCamera.mInv, rxo - cr.o);
+                wf_transform rfcT;   // CameraFromRender(v, ray.time): the camera's transformation at the ray's time (a moving camera)
+                CameraRenderFromCameraAt(C, cr.time, &rfcT);
+                V3 dox = XfVector(rfcT.mInv, rxo - cr.o);
                 if (Length(dox) < Length(minPosX)) minPosX = dox;
-                V3 doy = XfVector(C.renderFromCamera.mInv, ryo - cr.o);
+                V3 doy = XfVector(rfcT.mInv, ryo - cr.o);
                 if (Length(doy) < Length(minPosY)) minPosY = doy;
                 V3 rd = Normalize(cr.d);
                 rxd = Normalize(rxd); ryd = Normalize(ryd);
@@ -1891,9 +1896,11 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
             CameraRayR ry = GenerateCameraRay(tmp, V2{pFilm.x, pFilm.y + eps}, 0.5f, V2{0.5f, 0.5f});
             V3 rxo = cr.o + (rx.o - cr.o) / eps, rxd = cr.d + (rx.d - cr.d) / eps;
             V3 ryo = cr.o + (ry.o - cr.o) / eps, ryd = cr.d + (ry.d - cr.d) / eps;
-            V3 dox = XfVector(C.renderFromCamera.mInv, rxo - cr.o);
+            wf_transform rfcT;
+            CameraRenderFromCameraAt(C, cr.time, &rfcT);
+            V3 dox = XfVector(rfcT.mInv, rxo - cr.o);
             if (Length(dox) < Length(minPosX)) minPosX = dox;
-            V3 doy = XfVector(C.renderFromCamera.mInv, ryo - cr.o);
+            V3 doy = XfVector(rfcT.mInv, ryo - cr.o);
             if (Length(doy) < Length(minPosY)) minPosY = doy;
             V3 rd = Normalize(cr.d);
             rxd = Normalize(rxd); ryd = Normalize(ryd);
@@ -1941,13 +1948,17 @@ void BuildCamera(const ParsedScene &scene, const Transform &renderFromWorld, Sce
                 ryd = Normalize(pCamera + dy);
             }
             // RenderFromCamera(RayDifferential), util/transform.h:350-360
+            // (AnimatedTransform::operator()(RayDifferential), util/transform.cpp: the transformation at the ray's time
+            // Lerp(sample.time = 0.5, shutterOpen, shutterClose) when the camera moves)
+            wf_transform rfcT;
+            CameraRenderFromCameraAt(C, Lerp(0.5f, C.shutterOpen, C.shutterClose), &rfcT);
             V3 ro = o, rd = d;
-            XfRay(C.renderFromCamera.m, &ro, &rd);
-            rxo = XfPoint(C.renderFromCamera.m, rxo); ryo = XfPoint(C.renderFromCamera.m, ryo);
-            rxd = XfVector(C.renderFromCamera.m, rxd); ryd = XfVector(C.renderFromCamera.m, ryd);
-            V3 dox = XfVector(C.renderFromCamera.mInv, rxo - ro);
+            XfRay(rfcT.m, &ro, &rd);
+            rxo = XfPoint(rfcT.m, rxo); ryo = XfPoint(rfcT.m, ryo);
+            rxd = XfVector(rfcT.m, rxd); ryd = XfVector(rfcT.m, ryd);
+            V3 dox = XfVector(rfcT.mInv, rxo - ro);
             if (Length(dox) < Length(minPosX)) minPosX = dox;
-            V3 doy = XfVector(C.renderFromCamera.mInv, ryo - ro);
+            V3 doy = XfVector(rfcT.mInv, ryo - ro);
             if (Length(doy) < Length(minPosY)) minPosY = doy;
             rd = Normalize(rd); rxd = Normalize(rxd); ryd = Normalize(ryd);
             Frame f = Frame::FromZ(rd);
@@ -2303,9 +2314,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
         tPhase = now;
     };
     // rendering space: camera-world (cameras.cpp:35-41)
-    V3 pCamera = scene.worldFromCamera.Point(V3{0, 0, 0});
-    Transform worldFromRender = Translate(pCamera);
-    Transform renderFromWorld = Inverse(worldFromRender);
+    // (for a moving camera: its position at the middle of the TransformTimes interval — computed where the Camera directive is parsed)
+    Transform renderFromWorld = scene.renderFromWorld;
+    Transform worldFromRender = Inverse(renderFromWorld);
 
     BuildFilter(scene, T);
     BuildFilm(scene, opt, T);
@@ -2314,6 +2325,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     if (T->desc.film.type == WF_FILM_GBUFFER) {
         // outputFromRender: cameraTransform.RenderFromCamera() applied inversely ("camera"), or WorldFromRender ("world") — film.cpp:828-839
         T->desc.film.gbuffer_from_render = T->desc.film.apply_inverse ? T->desc.camera.renderFromCamera : worldFromRender.abi();
+        if (T->desc.film.apply_inverse && T->desc.camera.anim.actually_animated)
+            Die(scene.film.loc, "gbuffer film: \"coordinatesystem\" \"camera\" with a moving camera is not supported by this build (use \"world\")");
     }
 
     T->desc.options.seed = opt.seed;

@@ -76,6 +76,11 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/film_sens
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/displacement_ref.pfm $G/displacement.pbrt
 # a PLY file with triangle AND quad faces as an emitter and alpha-tested (the patches get their own mesh entry): hand-written
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/plymesh_mixed_ref.pfm $G/plymesh_mixed.pbrt
+# camera motion blur (ActiveTransform StartTime / EndTime around Camera, TransformTimes, shutter inside / outside the interval):
+# camera_motion.pbrt = image_textures.pbrt under a moving, rotating, scaling perspective camera with a lens; camera_motion_spherical.pbrt =
+# spherical_camera.pbrt under a translating camera
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/camera_motion_ref.pfm $G/camera_motion.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/camera_motion_spherical_ref.pfm $G/camera_motion_spherical.pbrt
 # alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # a goniometric light from an 8-bit R G B PNG (channel average re-quantised into an 8-bit "Y" image)
