@@ -236,3 +236,234 @@ def test_ply_ascii_little_big_endian_and_gzip_load_the_same_mesh(wfpt, tmp_path)
     assert imgs[0].max() > 0
     for im in imgs[1:]:
         assert (im.view(np.uint32) == imgs[0].view(np.uint32)).all()
+
+
+# ---- .qoi / .hdr / .tga (csrc/host/image_formats.cpp): files written here from known pixels; the decoders of the reference (ext/qoi,
+# stb_image) are absent submodules, so these known-answer tests are what pins the decode -------------------------------------------
+def _qoi_encode(px, colorspace):
+    """QOI 1.0 encoder (all six chunk types) for an [h][w][3|4] uint8 array."""
+    h, w, nc = px.shape
+    out = bytearray(b"qoif" + struct.pack(">IIBB", w, h, nc, colorspace))
+    index = [(0, 0, 0, 0)] * 64
+    prev = (0, 0, 0, 255)
+    run = 0
+    flat = px.reshape(-1, nc)
+    for k in range(flat.shape[0]):
+        r, g, b = (int(v) for v in flat[k][:3])
+        a = int(flat[k][3]) if nc == 4 else 255
+        cur = (r, g, b, a)
+        if cur == prev:
+            run += 1
+            if run == 62 or k == flat.shape[0] - 1:
+                out.append(0xc0 | (run - 1))
+                run = 0
+            continue
+        if run:
+            out.append(0xc0 | (run - 1))
+            run = 0
+        ip = (r * 3 + g * 5 + b * 7 + a * 11) % 64
+        if index[ip] == cur:
+            out.append(ip)
+        else:
+            index[ip] = cur
+            if a == prev[3]:
+                vr, vg, vb = ((r - prev[0] + 128) % 256) - 128, ((g - prev[1] + 128) % 256) - 128, ((b - prev[2] + 128) % 256) - 128
+                if -2 <= vr <= 1 and -2 <= vg <= 1 and -2 <= vb <= 1:
+                    out.append(0x40 | (vr + 2) << 4 | (vg + 2) << 2 | (vb + 2))
+                elif -32 <= vg <= 31 and -8 <= vr - vg <= 7 and -8 <= vb - vg <= 7:
+                    out += bytes([0x80 | (vg + 32), (vr - vg + 8) << 4 | (vb - vg + 8)])
+                else:
+                    out += bytes([0xfe, r, g, b])
+            else:
+                out += bytes([0xff, r, g, b, a])
+        prev = cur
+    return bytes(out) + b"\0" * 7 + b"\1"
+
+
+def _smooth_image(rng, h, w, nc):
+    """an image with runs, small differences, repeated colours and noise: every QOI chunk type / RLE packet kind occurs"""
+    base = np.cumsum(rng.integers(-3, 4, size=(h, w, nc)), axis=1) + rng.integers(0, 256, size=(h, 1, nc))
+    px = (base % 256).astype(np.uint8)
+    px[:, w // 3: w // 3 + 9] = px[:, w // 3: w // 3 + 1]          # runs
+    px[h // 2:, : w // 4] = rng.integers(0, 256, size=(h - h // 2, w // 4, nc))   # noise
+    px[1::2, w // 2:] = px[0:-1:2, w // 2:] if h % 2 == 0 else px[1::2, w // 2:]  # repeated colours
+    return px
+
+
+@pytest.mark.parametrize("nc,colorspace", [(3, 0), (4, 0), (3, 1), (4, 1)])
+def test_qoi_decodes_to_the_encoded_texels(wfpt, tmp_path, nc, colorspace):
+    rng = np.random.default_rng(7 + nc + colorspace)
+    px = _smooth_image(rng, 24, 70, nc)
+    if nc == 4:
+        px[..., 3] = np.where(rng.random((24, 70)) < 0.8, 255, px[..., 3])
+    path = str(tmp_path / "t.qoi")
+    open(path, "wb").write(_qoi_encode(px, colorspace))
+    img, fmt = wfpt.read_image(path, "gamma 2.2")   # (the file's colour-space byte decides, not the caller's encoding: ReadQOI)
+    assert fmt == 0 and img.shape == px.shape
+    want = px.astype(np.float32) / np.float32(255) if colorspace == 1 else _srgb_lut()[px]
+    assert (img == want).all()
+
+
+def _hdr_encode(rgbe, rle):
+    h, w, _ = rgbe.shape
+    out = bytearray(b"#?RADIANCE\n# written by the test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1\n\n" + ("-Y %d +X %d\n" % (h, w)).encode())
+    for y in range(h):
+        if not rle:
+            out += rgbe[y].tobytes()
+            continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            row = rgbe[y, :, k].tobytes()
+            i = 0
+            while i < w:
+                j = i
+                while j + 1 < w and row[j + 1] == row[i] and j - i < 126:
+                    j += 1
+                if j - i >= 3:
+                    out += bytes([128 + (j - i + 1), row[i]])
+                    i = j + 1
+                else:
+                    j = i
+                    while j < w and j - i < 127 and not (j + 3 < w and row[j] == row[j + 1] == row[j + 2] == row[j + 3]):
+                        j += 1
+                    j = max(j, i + 1)
+                    out += bytes([j - i]) + row[i:j]
+                    i = j
+    return bytes(out)
+
+
+@pytest.mark.parametrize("w,rle", [(40, True), (40, False), (6, False)])
+def test_hdr_decodes_like_stb(wfpt, tmp_path, w, rle):
+    rng = np.random.default_rng(11 + w)
+    h = 9
+    rgbe = rng.integers(0, 256, size=(h, w, 4)).astype(np.uint8)
+    rgbe[..., 3] = rng.integers(100, 150, size=(h, w))
+    rgbe[2, 3:20] = rgbe[2, 3]          # runs in every component plane
+    rgbe[4, :, 3] = 0                   # exponent 0: black
+    if not rle:
+        rgbe[0, 0, 0] = 200             # (a flat file whose first bytes looked like an RLE header would be read as one)
+    path = str(tmp_path / "t.hdr")
+    open(path, "wb").write(_hdr_encode(rgbe, rle))
+    img, fmt = wfpt.read_image(path)
+    assert fmt == 2 and img.shape == (h, w, 3)
+    f1 = np.ldexp(np.float32(1), rgbe[..., 3].astype(np.int32) - 136).astype(np.float32)
+    want = np.where(rgbe[..., 3:4] != 0, rgbe[..., :3].astype(np.float32) * f1[..., None], np.float32(0))
+    assert (img == want).all()
+
+
+def _tga_encode(px, bpp, rle, top_down, grey=False, palette=False):
+    """px: [h][w][nc] uint8 R G B (A) or Y (A); 16 bpp = 5-5-5 colour (or grey + alpha when grey)."""
+    h, w, nc = px.shape
+    rows = px if top_down else px[::-1]
+    def pixel(v):
+        if bpp == 8:
+            return bytes([int(v[0])])
+        if bpp == 16 and grey:
+            return bytes([int(v[0]), int(v[1])])
+        if bpp == 16:
+            r, g, b = int(v[0]) >> 3, int(v[1]) >> 3, int(v[2]) >> 3
+            return struct.pack("<H", r << 10 | g << 5 | b)
+        return bytes([int(v[2]), int(v[1]), int(v[0])] + ([int(v[3])] if bpp == 32 else []))
+    body = bytearray()
+    pal = b""
+    pal_len = 0
+    flat = rows.reshape(-1, nc)
+    if palette:
+        colours, inv = np.unique(flat, axis=0, return_inverse=True)
+        pal_len = len(colours)
+        pal = b"".join(bytes([int(c[2]), int(c[1]), int(c[0])]) for c in colours)
+        codes = [bytes([int(i)]) for i in np.asarray(inv).reshape(-1)]
+    else:
+        codes = [pixel(v) for v in flat]
+    if not rle:
+        body = b"".join(codes)
+    else:
+        i = 0
+        while i < len(codes):
+            j = i
+            while j + 1 < len(codes) and codes[j + 1] == codes[i] and j - i < 127:
+                j += 1
+            if j > i:
+                body += bytes([0x80 | (j - i)]) + codes[i]
+                i = j + 1
+            else:
+                j = i
+                while j + 1 < len(codes) and codes[j + 1] != codes[j] and j - i < 127:
+                    j += 1
+                body += bytes([j - i]) + b"".join(codes[i:j + 1])
+                i = j + 1
+    itype = (1 if palette else 3 if grey else 2) + (8 if rle else 0)
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 1 if palette else 0, itype, 0, pal_len, 24 if palette else 0, 0, 0, w, h, 8 if palette else bpp,
+                      (0x20 if top_down else 0) | (8 if bpp == 32 else 0))
+    return hdr + pal + bytes(body)
+
+
+@pytest.mark.parametrize("bpp,rle,top_down,grey,palette", [(24, False, False, False, False), (24, True, True, False, False), (32, True, False, False, False),
+                                                            (16, False, False, False, False), (16, True, True, False, False), (8, True, False, True, False),
+                                                            (16, False, True, True, False), (24, True, False, False, True)])
+def test_tga_decodes_like_stb(wfpt, tmp_path, bpp, rle, top_down, grey, palette):
+    rng = np.random.default_rng(bpp + 2 * rle + 4 * top_down)
+    nc = (2 if bpp == 16 else 1) if grey else (4 if bpp == 32 else 3)
+    px = _smooth_image(rng, 13, 37, nc)
+    if palette:
+        px = (px // 64 * 64).astype(np.uint8)   # few colours
+    path = str(tmp_path / "t.tga")
+    open(path, "wb").write(_tga_encode(px, bpp, rle, top_down, grey, palette))
+    img, fmt = wfpt.read_image(path, "linear")   # (stb's 8-bit loads are taken as sRGB whatever the caller asks for: util/image.cpp:888-916)
+    want = px
+    if bpp == 16 and not grey:
+        want = ((px >> 3).astype(np.uint32) * 255 // 31).astype(np.uint8)
+    if grey:
+        want = want[..., :1]
+    elif nc == 4:
+        want = want[..., :3]
+    assert fmt == 0 and img.shape == want.shape
+    assert (img == _srgb_lut()[want]).all()
+
+
+@pytest.mark.parametrize("ext", ["qoi", "hdr", "tga"])
+def test_malformed_image_files_raise(wfpt, tmp_path, ext):
+    rng = np.random.default_rng(3)
+    px = _smooth_image(rng, 8, 16, 3)
+    good = {"qoi": _qoi_encode(px, 0), "hdr": _hdr_encode(np.concatenate([px, px[..., :1]], axis=2), True), "tga": _tga_encode(px, 24, True, False)}[ext]
+    cases = [good[:10], b"", bytes(rng.integers(0, 256, size=200, dtype=np.uint8))]
+    if ext != "qoi":
+        cases.append(good[: len(good) // 2])   # (qoi_decode itself tolerates a short chunk stream: the last pixel repeats — kept)
+    for k, bad in enumerate(cases):
+        path = str(tmp_path / ("bad%d.%s" % (k, ext)))
+        open(path, "wb").write(bad)
+        with pytest.raises(Exception):
+            wfpt.read_image(path)
+
+
+def test_qoi_and_tga_textures_render_like_the_same_png(tmp_path):
+    """The 8-bit texels of a .qoi / .tga file enter the texture pipeline exactly as a PNG's do (U256 + sRGB encoding, the MIP pyramid's
+    per-level re-quantisation included): one scene rendered with the same pixels from the three containers gives one image.  The PNG path
+    is pinned to the reference by the png_textures golden."""
+    import shutil
+    from conftest import read_pfm, run_wf_cpu
+    px, ctype, depth, _ = _png_pixels(os.path.join(GOLDEN, "png_rgb8.png"))
+    assert ctype == 2 and depth == 8
+    px = px.astype(np.uint8)
+    shutil.copy(os.path.join(GOLDEN, "png_rgb8.png"), str(tmp_path / "tex.png"))
+    open(str(tmp_path / "tex.qoi"), "wb").write(_qoi_encode(px, 0))
+    open(str(tmp_path / "tex.tga"), "wb").write(_tga_encode(px, 24, True, False))
+    imgs = {}
+    for ext in ("png", "qoi", "tga"):
+        scene = str(tmp_path / ("s_%s.pbrt" % ext))
+        open(scene, "w").write('''LookAt 0 2.5 -4  0 0 0  0 1 0
+Camera "perspective" "float fov" [ 40 ]
+Sampler "zsobol" "integer pixelsamples" [ 4 ]
+Film "rgb" "integer xresolution" [ 48 ] "integer yresolution" [ 48 ] "string filename" [ "o.pfm" ] "bool savefp16" [ false ]
+WorldBegin
+LightSource "distant" "point3 from" [ 1 3 -2 ] "point3 to" [ 0 0 0 ] "rgb L" [ 3 3 3 ]
+Texture "t" "spectrum" "imagemap" "string filename" [ "tex.%s" ] "float uscale" [ 3 ] "float vscale" [ 3 ]
+Material "diffuse" "texture reflectance" "t"
+Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point3 P" [-3 0 -3 -3 0 3 3 0 3 3 0 -3] "point2 uv" [0 0 0 1 1 1 1 0]
+''' % ext)
+        out = str(tmp_path / ("o_%s.pfm" % ext))
+        run_wf_cpu(scene, out, spp=4)
+        imgs[ext] = read_pfm(out)
+    assert imgs["png"].mean() > 0.01
+    assert (imgs["qoi"].view(np.uint32) == imgs["png"].view(np.uint32)).all()
+    assert (imgs["tga"].view(np.uint32) == imgs["png"].view(np.uint32)).all()
