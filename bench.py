@@ -103,6 +103,57 @@ def cpu_baseline(scene_path, spp, read_pfm):
     return None, None
 
 
+def measure_traffic(scene_path, spp):
+    """HBM bytes per ray of the two traversal kernels, MEASURED in this run: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they do
+    not fit one pass; --kernel-trace only beside --pmc) over child processes that render the benchmarked scene file at `spp` with the
+    product's CLI.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950; ray counts from the child's --stats output.
+    Returns None when rocprofv3 or the CLI is unavailable (the bench line then falls back to the committed profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    exe = os.path.join(ROOT, "pbrt-v4_amd", "_build", "pbrt_amd")
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or not os.path.exists(prof):
+        return None
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    totals = {}
+    rays = None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, counter)
+            try:
+                pr = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "k", "--",
+                                     exe, "--stats", "--spp", str(spp), "--outfile", os.path.join(td, "k.pfm"), scene_path],
+                                    capture_output=True, text=True, timeout=400, cwd="/tmp", env=env)
+            except Exception:
+                return None
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if pr.returncode != 0 or not files:
+                return None
+            for r in csv.DictReader(open(files[0])):
+                k = r["Kernel_Name"].split("(")[0]
+                kind = "closest" if "k_closest_fast" in k else ("shadow" if "k_shadow_fast" in k else None)
+                if kind and r.get("Counter_Name", counter) == counter:
+                    totals[(kind, counter)] = totals.get((kind, counter), 0.0) + float(r["Counter_Value"])
+            txt = pr.stdout + pr.stderr
+            cam = re.findall(r"Camera rays\s+(\d+)", txt)
+            ind = re.findall(r"Indirect rays, depth\s+\d+\s+(\d+)", txt)
+            sh = re.findall(r"Shadow rays, depth\s+\d+\s+(\d+)", txt)
+            if cam:
+                rays = {"closest": int(cam[-1]) + sum(int(v) for v in ind), "shadow": sum(int(v) for v in sh)}
+    if not rays or rays["closest"] <= 0:
+        return None
+    res = {"spp": spp}
+    for kind in ("closest", "shadow"):
+        f, w = totals.get((kind, "FETCH_SIZE")), totals.get((kind, "WRITE_SIZE"))
+        if f is None or w is None or rays[kind] <= 0:
+            continue
+        # the counters are in KiB
+        res[kind] = {"hbm_bytes_per_ray": (2 * f + w) * 1024.0 / rays[kind], "write_bytes_per_ray": w * 1024.0 / rays[kind], "rays": rays[kind]}
+    return res if "closest" in res else None
+
+
 def shadow_bytes(c):
     """B_shadow = 124/ray + 32/node + 48/triangle test + 32 per unoccluded ray (the L read-modify-write)"""
     return 124 * c["shadow_rays"] + 32 * c["shadow_nodes"] + 48 * c["shadow_tris"] + 32 * c["shadow_unoccluded"]
@@ -115,6 +166,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pmc-spp", type=int, default=4, help="spp of the rocprofv3 PMC passes that measure roofline.traffic in this run (0 = use the committed profile)")
     ap.add_argument("--breakdown", action="store_true", help="time EVERY launch of the timed region with HIP events and add the per-stage totals "
                     "(\"stage_ms\") to the JSON line; the near-tie re-trace of general-primitive scenes then runs on the main stream (no overlap)")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="sample indices carried per pass (0 = automatic, ~64 M rays in flight)")
@@ -306,6 +358,21 @@ def main():
                 pj = json.load(open(tp)).get(a.workload, {})
                 if not isinstance(pj, dict):
                     pj = {}
+            # ... unless this run can measure it itself: two rocprofv3 PMC child processes on the same scene file (N = 1 only)
+            live = None
+            if world == 1 and a.pmc_spp > 0 and a.workload != "tm-like":
+                t_pmc0 = time.perf_counter()
+                live = measure_traffic(scene_path, a.pmc_spp)
+                if live:
+                    pj = dict(pj)
+                    pj["hbm_bytes_per_ray"] = live["closest"]["hbm_bytes_per_ray"]
+                    pj["write_bytes_per_ray"] = live["closest"]["write_bytes_per_ray"]
+                    if "shadow" in live:
+                        pj["shadow_hbm_bytes_per_ray"] = live["shadow"]["hbm_bytes_per_ray"]
+                        pj["shadow_write_bytes_per_ray"] = live["shadow"]["write_bytes_per_ray"]
+                    pj["source"] = ("MEASURED IN THIS RUN: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over child processes "
+                                    "rendering this scene file at %d spp with pbrt_amd (%.0f s); 2 x FETCH_SIZE + WRITE_SIZE, bytes per ray x this run's rays per launch"
+                                    % (a.pmc_spp, time.perf_counter() - t_pmc0))
             if launches > 0 and walk_ms > 0:
                 avg_ms = walk_ms / launches
                 bytes_per_launch = bytes_per_ray * rays_closest / launches
@@ -316,7 +383,8 @@ def main():
                 out["roofline"] = {
                     "bound": "hbm", "kernel": "Intersect closest (k_closest_fast)", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": (pj.get("source", "profiles/pmc_traffic.json") + " (rocprofv3 PMC of the same kernel and workload, bytes per ray x this run's rays per launch; not measured in this process)") if traffic else None,
+                    "traffic_source": (pj.get("source", "profiles/pmc_traffic.json") + ("" if live else " (rocprofv3 PMC of the same kernel and workload, bytes per ray x this run's rays per launch; not measured in this process)")) if traffic else None,
+                    "traffic_bytes_per_ray": per_ray, "write_bytes_per_ray": pj.get("write_bytes_per_ray"),
                     # the whole stage the bytes are charged to: walk + routing pass (+ the near-tie re-trace launch of scenes that have one)
                     "stage_frac": bytes_per_launch / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "stage_ms_per_launch": {"walk": avg_ms, "route_hits": route_ms / launches, "retrace": retrace_ms / launches, "retrace_launches": retrace_launches},
