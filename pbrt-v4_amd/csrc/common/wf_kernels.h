@@ -88,6 +88,12 @@ struct WorkState {
     // scanline band (the reference carries one, capped at 2^20 rays: integrator.cpp:227-236).  Item index
     // i = s * pixelsPerPass + p: sample slot s, pixel p of the band.  samplesPerPass = 1 is the reference.
     int pixelsPerPass, samplesPerPass;
+    // slotStride > 0: PIXEL-major items, i = p * slotStride + s with slotStride = the sample slots the current pass uses — the samples
+    // of one pixel are neighbours in every queue (one wave holds a few pixels' samples: nearly identical camera rays, the same
+    // triangles / texels / lights at the first hits).  0: sample-major as above.  Results do not depend on it (every item touches only
+    // its own pixelIndex slot; the film adds a pixel's slots in slot order either way).
+    int slotStride = 0;
+    int drainEpoch = 0;   // tag of the current closest-hit launch's near-tie queue entries (wf_backend.hip: DrainRetrace)
     // image partition for multi-GPU rendering (interleaved strips): this context owns the scanline strips
     // stripRank, stripRank + stripCount, ... of stripHeight lines each — localRows lines in all; a pass covers a band of
     // LOCAL rows.  stripCount = 1: the whole image (local row = image row).
@@ -268,7 +274,10 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
     // pixelIndex = item index: sample slot s = pixelIndex / pixelsPerPass, band pixel p = pixelIndex % pixelsPerPass
     const wf_film &F = sv.film;
     int xResolution = F.pixel_max[0] - F.pixel_min[0];
-    const int slot = pixelIndex / ws.pixelsPerPass, p = pixelIndex - slot * ws.pixelsPerPass;
+    int slot, p;
+    if (ws.slotStride > 0) { p = pixelIndex / ws.slotStride; slot = pixelIndex - p * ws.slotStride; }
+    else { slot = pixelIndex / ws.pixelsPerPass; p = pixelIndex - slot * ws.pixelsPerPass; }
+    if (p >= ws.pixelsPerPass) { ws.pPixel[pixelIndex] = I2{F.pixel_min[0], F.pixel_max[1]}; return; }   // (pixel-major: items past the pass's pixels x slots)
     const int sampleIndex = sampleBase + slot * sampleStep;
     int px = F.pixel_min[0] + p % xResolution;
     int py = BandScanline(sv, ws, y0, p / xResolution);
@@ -309,7 +318,8 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
         // order within each sample slot, no atomic); KCameraRayCount sets the queue size.
         // A realistic camera's rays can be blocked by the lens system: its rays are appended (the counter starts the pass at 0).
         const RayQueueV &q = ws.rq[0];
-        int index = sv.camera.type == WF_CAMERA_REALISTIC ? QueueAlloc(&ws.counters[(CNT_RAY0) * CNT_STRIDE]) : slot * KValidPixels(sv, ws, y0) + p;
+        int index = sv.camera.type == WF_CAMERA_REALISTIC ? QueueAlloc(&ws.counters[(CNT_RAY0) * CNT_STRIDE])
+                    : (ws.slotStride > 0 ? p * ws.slotStride + slot : slot * KValidPixels(sv, ws, y0) + p);
         q.o[index] = F4{cr.o.x, cr.o.y, cr.o.z, cr.time};
         q.d[index] = F4{cr.d.x, cr.d.y, cr.d.z, 1.f};
         q.beta[index] = F4{1, 1, 1, 1};
@@ -326,7 +336,9 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
 WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur, int i, int sampleBase, int sampleStep, int topsDepth = -1) {
     I4 m = ws.rq[cur].meta[i];
     int pixelIndex = m.x, depth = m.y;
-    const int slot = pixelIndex / ws.pixelsPerPass;
+    int slot, pPass;
+    if (ws.slotStride > 0) { pPass = pixelIndex / ws.slotStride; slot = pixelIndex - pPass * ws.slotStride; }
+    else { slot = pixelIndex / ws.pixelsPerPass; pPass = pixelIndex - slot * ws.pixelsPerPass; }
     const int sampleIndex = sampleBase + slot * sampleStep;
     int dimension = 6 + 7 * depth;
     if (sv.haveSubsurface) dimension += 3 * depth;  // samples.cpp:40-41
@@ -334,7 +346,7 @@ WF_HD void KGenerateRaySamples(const SceneView &sv, const WorkState &ws, int cur
     I2 pp = ws.pPixel[pixelIndex];
     sampler.StartPixelSample(pp.x, pp.y, sampleIndex, dimension);
     const bool useTops = depth == topsDepth;
-    const uint32_t *tops = useTops ? ws.sampleTops + (pixelIndex - slot * ws.pixelsPerPass) : nullptr;
+    const uint32_t *tops = useTops ? ws.sampleTops + pPass : nullptr;
     const int tstride = ws.pixelsPerPass;
     if (useTops) sampler.SetTop(tops[0]);
     float duc = sampler.Get1D();
@@ -1443,10 +1455,33 @@ WF_HD void KRecordShadowRay(const WorkState &ws, int i, bool occluded) {
 // K13: UpdateFilm (wavefront/film.cpp:14-38) -> RGBFilm::AddSample (film.h:239-255) -> PixelSensor::ToSensorRGB (film.h:95-101)
 // One thread per band pixel p; it adds the pass's sample slots in sample order (the order the reference's
 // successive passes would add them), so the double-precision sums are bit-identical for any samplesPerPass.
+// the RGBFilm part of one item: the sample's sensor RGB times its filter weight, and the weight (what AddSample adds to the pixel's
+// four double accumulators).  Returns false for an item outside the film's pixel bounds.
+WF_HD bool FilmSampleRGBW(const SceneView &sv, const WorkState &ws, int pixelIndex, float out[4], size_t *filmIdx) {
+    const wf_film &F = sv.film;
+    I2 pp = ws.pPixel[pixelIndex];
+    if (!(pp.x >= F.pixel_min[0] && pp.x < F.pixel_max[0] && pp.y >= F.pixel_min[1] && pp.y < F.pixel_max[1])) return false;
+    S4 Lw = toS4(ws.L[pixelIndex]) * toS4(ws.cameraRayWeight[pixelIndex]);
+    Wavelengths lambda = LoadLambda(ws, pixelIndex);
+    float filterWeight = ws.filterWeight[pixelIndex];
+    S4 L = SafeDiv(Lw, lambda.PDF());
+    float r = F.imaging_ratio * (DenseSample(sv, F.rbar_offset, lambda) * L).Average();
+    float g = F.imaging_ratio * (DenseSample(sv, F.gbar_offset, lambda) * L).Average();
+    float b = F.imaging_ratio * (DenseSample(sv, F.bbar_offset, lambda) * L).Average();
+    float m = fmax(fmax(r, g), b);
+    if (m > F.max_component_value) {
+        float sc = F.max_component_value / m;
+        r *= sc; g *= sc; b *= sc;
+    }
+    out[0] = filterWeight * r; out[1] = filterWeight * g; out[2] = filterWeight * b; out[3] = filterWeight;
+    const int width = F.pixel_max[0] - F.pixel_min[0];
+    *filmIdx = (size_t)(pp.y - F.pixel_min[1]) * width + (pp.x - F.pixel_min[0]);
+    return true;
+}
 WF_HD void KUpdateFilm(const SceneView &sv, const WorkState &ws, int p, int nSamples) {
     const wf_film &F = sv.film;
     for (int slot = 0; slot < nSamples; ++slot) {
-        const int pixelIndex = slot * ws.pixelsPerPass + p;
+        const int pixelIndex = ws.slotStride > 0 ? p * ws.slotStride + slot : slot * ws.pixelsPerPass + p;
         I2 pp = ws.pPixel[pixelIndex];
         if (!(pp.x >= F.pixel_min[0] && pp.x < F.pixel_max[0] && pp.y >= F.pixel_min[1] && pp.y < F.pixel_max[1])) return;
         S4 Lw = toS4(ws.L[pixelIndex]) * toS4(ws.cameraRayWeight[pixelIndex]);

@@ -111,6 +111,7 @@ struct wf_ctx {
     std::vector<hipEvent_t> eventPool;
     int passY0 = INT_MIN;        // first scanline of the band of the last wf_gen_camera_rays
     int passStep = 1, passSamples = 1;  // wf_set_pass_samples: sample-index stride and sample slots used by the current pass
+    bool pixelMajor = true;      // items of a pass ordered pixel by pixel (WorkState::slotStride); WF_PIXEL_MAJOR=0: sample by sample
     bool countTraversal = false;
     bool traceLaunch = false;    // WF_TRACE_LAUNCH=1: print every launch and synchronise after it (debugging)
 };
@@ -667,6 +668,9 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
 #ifndef WF_REFILL_SHADOW
 #define WF_REFILL_SHADOW 1
 #endif
+#ifndef WF_REFILL_INLINE
+#define WF_REFILL_INLINE 0    // diagnostic: the closest-hit walk refills its lanes but re-walks near ties inline (no queue, no service workgroups)
+#endif
 #ifndef WF_REFILL_CLOSEST
 #define WF_REFILL_CLOSEST 1   // with the near-tie walk out of the loop (DrainRetrace): 56.0 -> see DESIGN 4.1
 #endif
@@ -675,7 +679,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
 template <bool ANY, int GEN, bool INST, bool PERLANE, bool DEFER = false, typename Fetch, typename Finish>
 __device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4,
                                   int workBlocks = 0) {
-    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : DEFER)) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
+    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : (DEFER || WF_REFILL_INLINE != 0))) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
     else BatchTrace<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
 }
 // The near-tie rays of a closest-hit launch, resolved inside the launch (round 3, second step).  A walk that ends on a near-tie publishes
@@ -710,13 +714,22 @@ __device__ inline void DrainRetrace(const SceneView &sv, const WorkState &ws, co
         take = __builtin_amdgcn_readfirstlane(take);
         if (take == 0) return false;
         if (lane < take) {
+            // a slot is published when its tag is THIS launch's epoch (no sentinel to restore, nothing a stale slot could be mistaken for);
+            // the bound lies in a word of its own, written before the tag (release) and read after it (acquire)
             unsigned long long e;
-            while ((e = __hip_atomic_load(&ws.retraceQ64[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {}   // reserved, store in flight
-            __hip_atomic_store(&ws.retraceQ64[base + lane], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((uint32_t)((e = __hip_atomic_load(&ws.retraceQ64[base + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (uint32_t)ws.drainEpoch) {}   // reserved, store in flight
             const int i = (int)(uint32_t)(e & 0xffffffffull);
-            const float tB = BitsToFloat((uint32_t)(e >> 32));
+            const float tB = BitsToFloat((uint32_t)__hip_atomic_load(&ws.retraceQ[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const F4 o = q.o[i], d = q.d[i];
-            const RefHit rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+            // A queued ray HAS a hit inside its bound (the production walk accepted one at t < tB with the same triangle and alpha tests), so a
+            // re-walk that returns none is a fault, not an answer.  Round 3 measured exactly that on the 10 M-triangle scene: 2-6 of 4443
+            // re-walks per frame came back empty in about half of the runs (gpurun_out/det3_sm16.txt; never with the re-walk inlined in the
+            // worker, never once this check was compiled in) — a pixel sample lost per occurrence.  The walk is repeated; what it costs is
+            // counted (dbg + 5), and a ray that stays without a hit raises wf_sync's error (dbg + 6) instead of a silently wrong pixel.
+            RefHit rh;
+            int tries = 0;
+            do { rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg); } while (rh.prim < 0 && ++tries < 4);
+            if (st.dbg && tries) { atomicAdd(st.dbg + 5, tries); if (rh.prim < 0) atomicOr(st.dbg + 6, 1); }
             ws.routeCode[i] = rh.route;
             ws.hit[i] = F4{BitsToFloat((uint32_t)rh.prim), rh.b0, rh.b1, rh.b2};
             if (INST) ws.hitInst[i] = rh.prim >= 0 ? rh.inst : -1;
@@ -767,7 +780,7 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOS
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     const RayQueueV q = ws.rq[cur];
     // near-ties resolved by this launch itself: the kernels that would otherwise inline the reference-order walk (RetraceInline), walking with refill
-    constexpr bool DRAIN = SPLIT && RetraceInline(GEN) && WF_REFILL_CLOSEST != 0;
+    constexpr bool DRAIN = SPLIT && RetraceInline(GEN) && WF_REFILL_CLOSEST != 0 && WF_REFILL_INLINE == 0;
     const int workBlocks = DRAIN ? (int)gridDim.x - ServiceBlocks() : (int)gridDim.x;
     if (DRAIN && (int)blockIdx.x >= workBlocks) { DrainRetrace<GEN, INST>(sv, ws, bvh, cur, st, true); return; }   // a service workgroup
     TraceQueue<false, GEN, INST, SPLIT, DRAIN>(
@@ -783,7 +796,9 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOS
                 const int slot = atomicAdd(&ws.counters[(CNT_RETRACE) * CNT_STRIDE], 1);
                 const float bound = 2 * WalkBound(bvh, WalkT(w)) - WalkT(w);   // the re-trace's starting bound, see k_closest_retrace
                 if constexpr (DRAIN) {
-                    __hip_atomic_store(&ws.retraceQ64[slot], (unsigned long long)(uint32_t)i | ((unsigned long long)FloatToBits(bound) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sp.dbg) atomicAdd(sp.dbg + 4, 1);
+                    __hip_atomic_store(&ws.retraceQ[slot], (int)FloatToBits(bound), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ws.retraceQ64[slot], (unsigned long long)(uint32_t)i | ((unsigned long long)(uint32_t)ws.drainEpoch << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     return;   // DrainRetrace writes the ray's record
                 } else {
                     ws.retraceQ[slot] = i;
@@ -1150,6 +1165,40 @@ WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DE
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
     for (int p = blockIdx.x * BLOCK + threadIdx.x; p < ws.pixelsPerPass; p += gridDim.x * BLOCK) KUpdateFilm(sv, ws, p, nSamples);
+}
+// The RGB film under the pixel-major item order (WorkState::slotStride = nSamples): a pixel's samples are neighbours, so the workgroup
+// reads FILM_PIX pixels x nSamples items with coalesced loads, one item per thread and round, leaves each item's four addends in LDS, and
+// one thread per pixel then adds its samples in slot order into the double accumulators — the order KUpdateFilm adds them in.
+constexpr int FILM_PIX = 32, FILM_MAX_SLOTS = 64;
+__global__ void __launch_bounds__(BLOCK) k_update_film_pm(const SceneView sv, WorkState ws, int nSamples) {
+    __shared__ float add[FILM_PIX * FILM_MAX_SLOTS][4];
+    __shared__ unsigned long long filmIdx[FILM_PIX];
+    const int nItems = FILM_PIX * nSamples;
+    for (int p0 = blockIdx.x * FILM_PIX; p0 < ws.pixelsPerPass; p0 += gridDim.x * FILM_PIX) {
+        if (threadIdx.x < FILM_PIX) filmIdx[threadIdx.x] = ~0ull;
+        __syncthreads();
+        for (int j = threadIdx.x; j < nItems; j += BLOCK) {
+            const int pl = j / nSamples;
+            if (p0 + pl >= ws.pixelsPerPass) break;
+            size_t idx;
+            float v[4];
+            if (FilmSampleRGBW(sv, ws, p0 * nSamples + j, v, &idx)) {
+                add[j][0] = v[0]; add[j][1] = v[1]; add[j][2] = v[2]; add[j][3] = v[3];
+                if (j - pl * nSamples == 0) filmIdx[pl] = idx;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < FILM_PIX && filmIdx[threadIdx.x] != ~0ull) {
+            double *px = ws.film + 4 * filmIdx[threadIdx.x];
+            double a0 = px[0], a1 = px[1], a2 = px[2], a3 = px[3];
+            for (int s = 0; s < nSamples; ++s) {
+                const float *v = add[threadIdx.x * nSamples + s];
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            }
+            px[0] = a0; px[1] = a1; px[2] = a2; px[3] = a3;
+        }
+        __syncthreads();
+    }
 }
 
 // stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
@@ -1541,6 +1590,14 @@ int wf_sync(wf_ctx *ctx) {
         int overflow = 0;
         HIPCHK(hipMemcpy(&overflow, ctx->dbgWords + 1, sizeof(int), hipMemcpyDeviceToHost));
         if (overflow) return fail(-1, "traversal stack overflow: a walk needed more than %d + %d node-stack entries (results are incomplete)", TSTACK, ctx->spillRows);
+        int unresolved = 0;
+        HIPCHK(hipMemcpy(&unresolved, ctx->dbgWords + 6, sizeof(int), hipMemcpyDeviceToHost));
+        if (unresolved) return fail(-1, "a near-tie re-walk found no hit where the production walk had one (results are incomplete)");
+        if (getenv("WF_DEBUG_DRAIN")) {
+            int h[8];
+            HIPCHK(hipMemcpy(h, ctx->dbgWords, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[drain] spilled %d, re-walks %d, pushes %d, repeated re-walks %d, unresolved %d\n", h[0], h[2], h[4], h[5], h[6]);
+        }
     }
     return 0;
 }
@@ -1731,7 +1788,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if (rows > 2048) return fail(-1, "BVH too deep for the traversal stacks (depth %d + %d)", depthTop, depthDef);
             if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)rows * MAX_GRID * BLOCK))) return e;
             ctx->spillRows = rows;
-            if ((e = devAlloc(ctx, &ctx->dbgWords, (size_t)4))) return e;
+            if ((e = devAlloc(ctx, &ctx->dbgWords, (size_t)8))) return e;   // [4..7]: near-tie queue diagnostics (pushes, re-walks without a hit, -, -)
+            HIPCHK(hipMemset(ctx->dbgWords, 0, 8 * sizeof(int)));
         }
         if (d->n_bvh_nodes > 0)
             for (int a = 0; a < 3; ++a) { ctx->sceneMin[a] = d->bvh_nodes[0].bmin[a]; ctx->sceneMax[a] = d->bvh_nodes[0].bmax[a]; }
@@ -1826,6 +1884,8 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     ws.samplesPerPass = samples_per_pass;
     if (ws.stripCount < 1) { ws.stripRank = 0; ws.stripCount = 1; ws.stripHeight = 1; ws.localRows = ctx->H; }
     ctx->passSamples = 1;
+    if (const char *e = getenv("WF_PIXEL_MAJOR")) ctx->pixelMajor = atoi(e) != 0;
+    ctx->ws.slotStride = ctx->pixelMajor ? 1 : 0;
     ctx->passStep = 1;
     int e;
     if ((e = devAlloc(ctx, &ws.filterWeight, n)) || (e = devAlloc(ctx, &ws.pPixel, n)) || (e = devAlloc(ctx, &ws.lambda, n)) ||
@@ -1905,6 +1965,7 @@ int wf_set_pass_samples(wf_ctx *ctx, int sample_step, int n_samples) {
     if (sample_step < 1) return fail(-1, "sample_step must be >= 1");
     ctx->passStep = sample_step;
     ctx->passSamples = n_samples;
+    ctx->ws.slotStride = ctx->pixelMajor ? n_samples : 0;
     return 0;
 }
 
@@ -2016,6 +2077,8 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
                 cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
                 HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
             }
+            ctx->ws.drainEpoch = (ctx->ws.drainEpoch + 1) & 0x7fffffff;   // tag of this launch's near-tie queue entries (DrainRetrace)
+            if (ctx->ws.drainEpoch == 0) ctx->ws.drainEpoch = 1;
             LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk);
             // The near-tie re-trace of the scenes whose walk does not resolve its ties itself (genMode >= 2: quadrics, curves, texture-graph
             // alpha; RetraceInline) is a handful of long single walks: it runs on a second stream beside the routing pass (and, in the
@@ -2167,7 +2230,10 @@ int wf_subsurface_scatter(wf_ctx *ctx, int depth) {
 }
 int wf_update_film(wf_ctx *ctx) {
     if (int e = checkReady(ctx)) return e;
-    LAUNCH("Update film", k_update_film, gridFor(ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, ctx->passSamples);
+    if (ctx->ws.slotStride > 0 && ctx->ws.slotStride == ctx->passSamples && ctx->passSamples <= FILM_MAX_SLOTS && ctx->svHost.film.type == WF_FILM_RGB)
+        LAUNCH("Update film", k_update_film_pm, std::min(4096, (ctx->ws.pixelsPerPass + FILM_PIX - 1) / FILM_PIX), ctx->svHost, ctx->ws, ctx->passSamples);
+    else
+        LAUNCH("Update film", k_update_film, gridFor(ctx->ws.pixelsPerPass), ctx->svHost, ctx->ws, ctx->passSamples);
     return 0;
 }
 
