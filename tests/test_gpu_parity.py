@@ -167,6 +167,31 @@ def test_benchmark_standins_vs_oracle_and_reference(wfpt, tmp_path, name):
     s.close()
 
 
+def test_repeated_renders_are_identical(wfpt, tmp_path):
+    """The same frame rendered six times by one context gives one image and one set of ray counts.  Round 3's near-tie queue (the
+    closest-hit launch's service workgroups) once lost a handful of re-walks per frame in a third of the runs on the 10 M-triangle
+    scene — a pixel sample each — while every golden stayed green: a restored-sentinel slot protocol, since replaced by launch-epoch
+    tags.  This is the regression guard on the downscaled headline scene (two-level tree, alpha, near ties on the floor)."""
+    from conftest import bench_small_scene
+    path, spp = bench_small_scene("sanmiguel_like_small", tmp_path / "scene")
+    s = wfpt.Scene(path=path, spp=16)
+    s.create_renderer(0)
+    first, first_rays = None, None
+    for k in range(6):
+        s.clear_film()
+        before = s.total_rays()
+        s.render()
+        img = s.image().copy()
+        rays = s.total_rays() - before
+        if first is None:
+            first, first_rays = img, rays
+            assert np.isfinite(img).all() and img.mean() > 0.01
+        else:
+            assert rays == first_rays, (k, rays, first_rays)
+            assert (img.view(np.uint32) == first.view(np.uint32)).all(), (k, int((img.view(np.uint32) != first.view(np.uint32)).sum()))
+    s.close()
+
+
 def test_big_two_level_tree_hits_bit_exact_and_rare_paths_taken(wfpt, tmp_path):
     """The production traversal on a 500 k-triangle two-level tree (the san-miguel-like generator: 40 top-level meshes + 60 in 10
     definitions instanced 95 times, alpha cut-outs): closest hits (primitive, instance, t, barycentrics) bit-exact against the port's
