@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 tools/exp/false_share.hip -o tools/exp/false_share ; result on MI355X (round 3): 0 of 4 M records lost in 20 trials
 // Do plain stores from workgroups on DIFFERENT XCDs into the same 128-byte line both survive?  (diagnostic for the near-tie queue:
 // service workgroups write hit records whose neighbours in the line are written by worker workgroups)
 #include <hip/hip_runtime.h>
