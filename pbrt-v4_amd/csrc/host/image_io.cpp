@@ -157,28 +157,68 @@ static void ReadPNG(const std::string &path, const ColorEnc &encIn, HostImage *i
     const int srcNc = ct == 0 ? 1 : ct == 2 ? 3 : ct == 3 ? 1 : ct == 4 ? 2 : ct == 6 ? 4 : 0;
     if (!png.w || !png.h || png.w > 65536u || png.h > 65536u || !srcNc || (png.depth != 1 && png.depth != 2 && png.depth != 4 && png.depth != 8 && png.depth != 16))
         Die("", path + ": malformed PNG header (dimensions / colour type / bit depth)");
-    if (png.interlace) Die("", path + ": interlaced PNG images are not supported by this build");
+    if (png.interlace > 1) Die("", path + ": malformed PNG header (interlace method)");
     const size_t bpp = std::max<size_t>(1, (size_t)srcNc * png.depth / 8), stride = ((size_t)png.w * srcNc * png.depth + 7) / 8;
-    std::vector<uint8_t> raw((stride + 1) * png.h);
-    uLongf rawLen = raw.size();
-    if (uncompress(raw.data(), &rawLen, png.idat.data(), png.idat.size()) != Z_OK || rawLen != raw.size())
-        Die("", path + ": corrupt PNG image data");
-    // un-filter in place (the filter byte stays in front of each row)
-    for (uint32_t y = 0; y < png.h; ++y) {
-        uint8_t *row = &raw[(stride + 1) * y + 1];
-        const uint8_t *up = y ? row - (stride + 1) : nullptr;
-        const int ft = row[-1];
-        if (ft > 4) Die("", path + ": corrupt PNG filter type");
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? row[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
-            int pred = 0;
-            switch (ft) {
-            case 1: pred = a; break;
-            case 2: pred = b; break;
-            case 3: pred = (a + b) >> 1; break;
-            case 4: pred = PaethPredictor(a, b, c); break;
+    const size_t bitsPerPixel = (size_t)srcNc * png.depth;
+    // un-filter `rows` scanlines of `rowBytes` bytes in place (the filter byte stays in front of each row)
+    auto unfilter = [&](uint8_t *base, size_t rows, size_t rowBytes) {
+        for (size_t y = 0; y < rows; ++y) {
+            uint8_t *row = base + (rowBytes + 1) * y + 1;
+            const uint8_t *up = y ? row - (rowBytes + 1) : nullptr;
+            const int ft = row[-1];
+            if (ft > 4) Die("", path + ": corrupt PNG filter type");
+            for (size_t i = 0; i < rowBytes; ++i) {
+                const int a = i >= bpp ? row[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+                int pred = 0;
+                switch (ft) {
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: pred = PaethPredictor(a, b, c); break;
+                }
+                row[i] = (uint8_t)(row[i] + pred);
             }
-            row[i] = (uint8_t)(row[i] + pred);
+        }
+    };
+    std::vector<uint8_t> raw((stride + 1) * png.h);
+    if (!png.interlace) {
+        uLongf rawLen = raw.size();
+        if (uncompress(raw.data(), &rawLen, png.idat.data(), png.idat.size()) != Z_OK || rawLen != raw.size())
+            Die("", path + ": corrupt PNG image data");
+        unfilter(raw.data(), png.h, stride);
+    } else {
+        // Adam7 (PNG specification 1.2, section 8.2): seven reduced images, each filtered on its own, concatenated in one zlib stream;
+        // their pixels are scattered into the non-interlaced layout the code below reads
+        static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+        size_t total = 0, pw[7], ph[7], prow[7];
+        for (int p = 0; p < 7; ++p) {
+            pw[p] = png.w > (uint32_t)xs[p] ? (png.w - xs[p] + dx[p] - 1) / dx[p] : 0;
+            ph[p] = png.h > (uint32_t)ys[p] ? (png.h - ys[p] + dy[p] - 1) / dy[p] : 0;
+            prow[p] = (pw[p] * bitsPerPixel + 7) / 8;
+            if (pw[p] && ph[p]) total += (prow[p] + 1) * ph[p];
+        }
+        std::vector<uint8_t> passes(total);
+        uLongf rawLen = passes.size();
+        if (uncompress(passes.data(), &rawLen, png.idat.data(), png.idat.size()) != Z_OK || rawLen != passes.size())
+            Die("", path + ": corrupt PNG image data");
+        size_t off = 0;
+        for (int p = 0; p < 7; ++p) {
+            if (!pw[p] || !ph[p]) continue;
+            unfilter(&passes[off], ph[p], prow[p]);
+            for (size_t py = 0; py < ph[p]; ++py) {
+                const uint8_t *src = &passes[off + (prow[p] + 1) * py + 1];
+                uint8_t *dst = &raw[(stride + 1) * (ys[p] + py * dy[p]) + 1];
+                for (size_t px = 0; px < pw[p]; ++px) {
+                    const size_t x = xs[p] + px * dx[p];
+                    if (bitsPerPixel >= 8) memcpy(dst + x * (bitsPerPixel / 8), src + px * (bitsPerPixel / 8), bitsPerPixel / 8);
+                    else {
+                        const size_t sb = px * bitsPerPixel, db = x * bitsPerPixel;
+                        const unsigned v = (src[sb >> 3] >> (8 - bitsPerPixel - (sb & 7))) & ((1u << bitsPerPixel) - 1);
+                        dst[db >> 3] = (uint8_t)((dst[db >> 3] & ~(((1u << bitsPerPixel) - 1) << (8 - bitsPerPixel - (db & 7)))) | (v << (8 - bitsPerPixel - (db & 7))));
+                    }
+                }
+            }
+            off += (prow[p] + 1) * ph[p];
         }
     }
     const bool grey = ct == 0 || ct == 4, hasAlpha = ct == 6, wide = png.depth == 16;
@@ -268,11 +308,12 @@ static void ReadEXR(const std::string &path, HostImage *img) {
     auto rdStr = [&]() { std::string r; while (true) { need(1); char c = (char)file[pos++]; if (!c) break; r.push_back(c); } return r; };
     if (rd32() != 20000630u) fail("not an OpenEXR file");
     const uint32_t version = rd32();
-    if (version & 0x200u) fail("tiled OpenEXR files are not supported by this build");
+    const bool tiled = (version & 0x200u) != 0;   // single-part tiled file: level (0, 0) is read (ONE_LEVEL, or the finest level of a MIP / RIP map)
     if (version & 0x1800u) fail("deep / multi-part OpenEXR files are not supported by this build");
     struct Chan { std::string name; int type; };
     std::vector<Chan> chans;
     int compression = -1, dw[4] = {0, 0, -1, -1}, lineOrder = 0;
+    uint32_t tileW = 0, tileH = 0;
     while (true) {
         std::string name = rdStr();
         if (name.empty()) break;
@@ -297,6 +338,11 @@ static void ReadEXR(const std::string &path, HostImage *img) {
         } else if (name == "compression") { if (size != 1) fail("malformed compression attribute"); compression = v[0]; }
         else if (name == "dataWindow") { if (size != 16) fail("malformed dataWindow attribute"); memcpy(dw, v, 16); }
         else if (name == "lineOrder") { if (size != 1) fail("malformed lineOrder attribute"); lineOrder = v[0]; }
+        else if (name == "tiles") {   // tiledesc: xSize, ySize, mode (level mode | rounding mode << 4)
+            if (size != 9) fail("malformed tiles attribute");
+            memcpy(&tileW, v, 4); memcpy(&tileH, v + 4, 4);
+            if ((v[8] & 0xf) > 2) fail("malformed tiles attribute (level mode)");
+        }
         else if (name == "chromaticities" && size >= 32) {
             // RGBColorSpace::Lookup (util/colorspace.cpp): this build's image maps are sRGB / Rec.709
             float c[8]; memcpy(c, v, 32);
@@ -331,57 +377,83 @@ static void ReadEXR(const std::string &path, HostImage *img) {
     img->format = isHalf ? HostImage::Half : HostImage::Float;
     img->w = w; img->h = h; img->nc = nc;
     img->p32.assign((size_t)w * h * nc, 0.f);
-    const int nChunks = (h + linesPerChunk - 1) / linesPerChunk;
+    std::vector<uint8_t> raw, tmp;
+    // one compressed block -> `expect` raw bytes (rows of channels); NONE / RLE / ZIPS / ZIP (OpenEXR file layout, "scan line / tile blocks")
+    auto decodeBlock = [&](const uint8_t *data, size_t dataSize, size_t expect) {
+        raw.resize(expect);
+        if (dataSize == expect) { memcpy(raw.data(), data, expect); return; }   // stored uncompressed (also when compression did not help)
+        if (compression == 0) fail("chunk size does not match the data window");
+        tmp.resize(expect);
+        if (compression == 1) {
+            // RLE: a signed count byte; negative = that many literal bytes, otherwise count + 1 copies of the next byte
+            size_t o = 0, i = 0;
+            while (i < dataSize) {
+                int c = (int8_t)data[i++];
+                if (c < 0) { size_t n = (size_t)-c; if (i + n > dataSize || o + n > expect) fail("corrupt RLE data"); memcpy(&tmp[o], &data[i], n); o += n; i += n; }
+                else { size_t n = (size_t)c + 1; if (i >= dataSize || o + n > expect) fail("corrupt RLE data"); memset(&tmp[o], data[i++], n); o += n; }
+            }
+            if (o != expect) fail("corrupt RLE data");
+        } else {
+            uLongf outLen = expect;
+            if (uncompress(tmp.data(), &outLen, data, dataSize) != Z_OK || outLen != expect) fail("corrupt zip data");
+        }
+        // undo the byte predictor, then re-interleave the two halves
+        for (size_t i = 1; i < expect; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);
+        const size_t half = (expect + 1) / 2;
+        for (size_t i = 0; i < expect; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+    };
+    // rows of `bw` pixels per channel -> the image rectangle at (x0, y0)
+    auto scatter = [&](int x0, int y0, int bw, int nLines) {
+        const size_t rowBytes = (size_t)bw * bytesPer * chans.size();
+        for (int l = 0; l < nLines; ++l) {
+            const int y = y0 + l;
+            const uint8_t *line = raw.data() + rowBytes * l;
+            for (int c = 0; c < nc; ++c) {
+                const uint8_t *cp = line + (size_t)src[c] * bw * bytesPer;
+                for (int x = 0; x < bw; ++x) {
+                    float v;
+                    if (isHalf) { uint16_t hb; memcpy(&hb, cp + 2 * (size_t)x, 2); v = HalfBitsToFloat(hb); }
+                    else memcpy(&v, cp + 4 * (size_t)x, 4);
+                    img->p32[((size_t)y * w + x0 + x) * nc + c] = v;
+                }
+            }
+        }
+    };
     const size_t tablePos = pos;
+    if (tiled) {
+        if (tileW == 0 || tileH == 0 || tileW > 65536u || tileH > 65536u) fail("malformed tiles attribute");
+        const int ntx = (w + (int)tileW - 1) / (int)tileW, nty = (h + (int)tileH - 1) / (int)tileH;
+        // the offset table lists the tiles of level (0, 0) first (then the coarser levels of a MIP / RIP map, which are not read)
+        need((size_t)8 * ntx * nty);
+        std::vector<char> seen((size_t)ntx * nty, 0);
+        for (int t = 0; t < ntx * nty; ++t) {
+            uint64_t off; memcpy(&off, &file[tablePos + 8 * (size_t)t], 8);
+            if (off > file.size() || file.size() - off < 20) fail("tile offset out of range");
+            int32_t tx, ty, lx, ly, dataSize;
+            memcpy(&tx, &file[off], 4); memcpy(&ty, &file[off + 4], 4); memcpy(&lx, &file[off + 8], 4); memcpy(&ly, &file[off + 12], 4); memcpy(&dataSize, &file[off + 16], 4);
+            if (lx != 0 || ly != 0 || tx < 0 || ty < 0 || tx >= ntx || ty >= nty || seen[(size_t)ty * ntx + tx]) fail("malformed tile header");
+            if (dataSize < 0 || (size_t)dataSize > file.size() - off - 20) fail("tile size out of range");
+            seen[(size_t)ty * ntx + tx] = 1;
+            const int x0 = tx * (int)tileW, y0 = ty * (int)tileH;
+            const int bw = std::min((int)tileW, w - x0), bh = std::min((int)tileH, h - y0);
+            decodeBlock(&file[off + 20], (size_t)dataSize, (size_t)bw * bytesPer * chans.size() * bh);
+            scatter(x0, y0, bw, bh);
+        }
+        return;
+    }
+    const int nChunks = (h + linesPerChunk - 1) / linesPerChunk;
     need((size_t)8 * nChunks);
     const size_t lineBytes = (size_t)w * bytesPer * chans.size();
-    std::vector<uint8_t> raw, tmp;
     for (int ck = 0; ck < nChunks; ++ck) {
         uint64_t off; memcpy(&off, &file[tablePos + 8 * (size_t)ck], 8);
         if (off > file.size() || file.size() - off < 8) fail("chunk offset out of range");
         int32_t y0, dataSize;
         memcpy(&y0, &file[off], 4); memcpy(&dataSize, &file[off + 4], 4);
         if (dataSize < 0 || (size_t)dataSize > file.size() - off - 8) fail("chunk size out of range");
-        const uint8_t *data = &file[off + 8];
         if (y0 < dw[1] || y0 > dw[3]) fail("chunk outside the data window");
         const int nLines = std::min(linesPerChunk, dw[3] - y0 + 1);
-        const size_t expect = lineBytes * nLines;
-        raw.resize(expect);
-        if ((size_t)dataSize == expect) memcpy(raw.data(), data, expect);   // stored uncompressed (also when compression did not help)
-        else if (compression == 0) fail("chunk size does not match the data window");
-        else {
-            tmp.resize(expect);
-            if (compression == 1) {
-                // RLE: a signed count byte; negative = that many literal bytes, otherwise count + 1 copies of the next byte
-                size_t o = 0, i = 0;
-                while (i < (size_t)dataSize) {
-                    int c = (int8_t)data[i++];
-                    if (c < 0) { size_t n = (size_t)-c; if (i + n > (size_t)dataSize || o + n > expect) fail("corrupt RLE data"); memcpy(&tmp[o], &data[i], n); o += n; i += n; }
-                    else { size_t n = (size_t)c + 1; if (i >= (size_t)dataSize || o + n > expect) fail("corrupt RLE data"); memset(&tmp[o], data[i++], n); o += n; }
-                }
-                if (o != expect) fail("corrupt RLE data");
-            } else {
-                uLongf outLen = expect;
-                if (uncompress(tmp.data(), &outLen, data, dataSize) != Z_OK || outLen != expect) fail("corrupt zip data");
-            }
-            // undo the byte predictor, then re-interleave the two halves
-            for (size_t i = 1; i < expect; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);
-            const size_t half = (expect + 1) / 2;
-            for (size_t i = 0; i < expect; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
-        }
-        for (int l = 0; l < nLines; ++l) {
-            const int y = y0 - dw[1] + l;
-            const uint8_t *line = raw.data() + lineBytes * l;
-            for (int c = 0; c < nc; ++c) {
-                const uint8_t *cp = line + (size_t)src[c] * w * bytesPer;
-                for (int x = 0; x < w; ++x) {
-                    float v;
-                    if (isHalf) { uint16_t hb; memcpy(&hb, cp + 2 * (size_t)x, 2); v = HalfBitsToFloat(hb); }
-                    else memcpy(&v, cp + 4 * (size_t)x, 4);
-                    img->p32[((size_t)y * w + x) * nc + c] = v;
-                }
-            }
-        }
+        decodeBlock(&file[off + 8], (size_t)dataSize, lineBytes * nLines);
+        scatter(0, y0 - dw[1], w, nLines);
     }
 }
 
