@@ -286,6 +286,7 @@ static int Main(int argc, char **argv) {
         auto next = [&]() -> std::string { if (i + 1 >= argc) { fprintf(stderr, "missing value after %s\n", a.c_str()); exit(1); } return argv[++i]; };
         if (a == "--spp") opt.pixelSamples = atoi(next().c_str());
         else if (a == "--seed") opt.seed = atoi(next().c_str());
+        else if (a == "--displacement-edge-scale") opt.displacementEdgeScale = (float)atof(next().c_str());
         else if (a == "--nthreads") gThreads = atoi(next().c_str());
         else if (a == "--outfile") opt.imageFile = next();
         else if (a == "--dump-film") dumpFilm = next();

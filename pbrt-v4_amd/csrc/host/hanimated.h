@@ -5,6 +5,7 @@
 #pragma once
 
 #include "hmath.h"
+#include <stdexcept>
 #include "../common/wf_camera.h"
 
 namespace wf {
@@ -29,7 +30,7 @@ inline wf_animated_transform MakeAnimatedTransform(const Transform &startTransfo
         Mat4 R = M;
         do {
             Mat4 Rit;
-            if (!Inverse(Transpose(R), &Rit)) { fprintf(stderr, "Unable to invert matrix (AnimatedTransform decomposition)\n"); exit(1); }
+            if (!Inverse(Transpose(R), &Rit)) throw std::runtime_error("Unable to invert matrix (AnimatedTransform decomposition of a singular camera transformation)");
             Mat4 Rnext;
             for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Rnext.m[i][j] = (R.m[i][j] + Rit.m[i][j]) / 2;
             norm = 0;
@@ -40,7 +41,7 @@ inline wf_animated_transform MakeAnimatedTransform(const Transform &startTransfo
             R = Rnext;
         } while (++count < 100 && norm > .0001);   // (a double comparison in the reference: float promoted)
         Mat4 Rinv;
-        if (!Inverse(R, &Rinv)) { fprintf(stderr, "Unable to invert matrix (AnimatedTransform decomposition)\n"); exit(1); }
+        if (!Inverse(R, &Rinv)) throw std::runtime_error("Unable to invert matrix (AnimatedTransform decomposition of a singular camera transformation)");
         const Mat4 Sm = Rinv * M;
         std::memcpy(S, Sm.m, sizeof(Sm.m));
         // Transform::operator Quaternion() on Transform(R): only m is read

@@ -21,6 +21,7 @@ static void usage() {
             "  --gpu-device <n>       HIP device index (default 0)\n"
             "  --pixelbounds x0,x1,y0,y1 / --cropwindow x0,x1,y0,y1\n"
             "  --disable-pixel-jitter / --disable-wavelength-jitter / --disable-texture-filtering\n"
+            "  --displacement-edge-scale <s>   scale the target edge length of displaced meshes\n"
             "  --datadir <dir>        directory holding spectral_tables.txt\n"
             "  --stats                print ray counts and the per-kernel profile\n"
             "  --quiet, --gpu, --wavefront (accepted)\n");
@@ -63,6 +64,7 @@ static int Main(int argc, char **argv) {
         } else if (a == "--disable-pixel-jitter") opt.disablePixelJitter = true;
         else if (a == "--disable-wavelength-jitter") opt.disableWavelengthJitter = true;
         else if (a == "--disable-texture-filtering") opt.disableTextureFiltering = true;
+        else if (a == "--displacement-edge-scale" && i + 1 < argc) opt.displacementEdgeScale = (float)atof(argv[++i]);
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--stats") stats = true;
         else if (a == "--gpu" || a == "--wavefront") {}

@@ -93,6 +93,7 @@ struct RenderOptions {  // subset of PBRTOptions (options.h)
     float cropWindow[4] = {0, 0, 0, 0};  // --cropwindow
     bool hasPixelBounds = false, hasCropWindow = false;
     std::string imageFile;
+    float displacementEdgeScale = 1;     // --displacement-edge-scale (options.h: scales the target edge length of displaced meshes)
 };
 
 struct ParsedScene {

@@ -2566,7 +2566,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
             auto it = tb.floatTextures.find(texName);
             if (it == tb.floatTextures.end()) Die(sh.loc, texName + ": no such texture defined.");
             const int texId = it->second;
-            const float edgeLength = sh.params.GetOneFloat("edgelength", 1.f);   // x Options->displacementEdgeScale (1: no such flag here)
+            float edgeLength = sh.params.GetOneFloat("edgelength", 1.f);
+            edgeLength *= opt.displacementEdgeScale;   // Options->displacementEdgeScale (--displacement-edge-scale)
             SceneView tv{};
             tv.textures = T->textures.data(); tv.texImages = T->texImages.data(); tv.tableData = T->tableData.data();
             tv.lightXforms = T->lightTransforms.data(); tv.noisePerm = T->noisePerm.empty() ? nullptr : T->noisePerm.data();
