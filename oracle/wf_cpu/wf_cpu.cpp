@@ -287,6 +287,7 @@ static int Main(int argc, char **argv) {
         if (a == "--spp") opt.pixelSamples = atoi(next().c_str());
         else if (a == "--seed") opt.seed = atoi(next().c_str());
         else if (a == "--displacement-edge-scale") opt.displacementEdgeScale = (float)atof(next().c_str());
+        else if (a == "--render-coord-sys") { const std::string v = next(); opt.renderingSpace = v == "camera" ? 0 : (v == "world" ? 2 : 1); }
         else if (a == "--nthreads") gThreads = atoi(next().c_str());
         else if (a == "--outfile") opt.imageFile = next();
         else if (a == "--dump-film") dumpFilm = next();

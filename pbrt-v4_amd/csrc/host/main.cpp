@@ -22,6 +22,7 @@ static void usage() {
             "  --pixelbounds x0,x1,y0,y1 / --cropwindow x0,x1,y0,y1\n"
             "  --disable-pixel-jitter / --disable-wavelength-jitter / --disable-texture-filtering\n"
             "  --displacement-edge-scale <s>   scale the target edge length of displaced meshes\n"
+            "  --render-coord-sys <name>       camera, cameraworld (default) or world\n"
             "  --datadir <dir>        directory holding spectral_tables.txt\n"
             "  --stats                print ray counts and the per-kernel profile\n"
             "  --quiet, --gpu, --wavefront (accepted)\n");
@@ -65,6 +66,13 @@ static int Main(int argc, char **argv) {
         else if (a == "--disable-wavelength-jitter") opt.disableWavelengthJitter = true;
         else if (a == "--disable-texture-filtering") opt.disableTextureFiltering = true;
         else if (a == "--displacement-edge-scale" && i + 1 < argc) opt.displacementEdgeScale = (float)atof(argv[++i]);
+        else if (a == "--render-coord-sys" && i + 1 < argc) {
+            const std::string v = argv[++i];
+            if (v == "camera") opt.renderingSpace = 0;
+            else if (v == "cameraworld") opt.renderingSpace = 1;
+            else if (v == "world") opt.renderingSpace = 2;
+            else { fprintf(stderr, "%s: unknown rendering coordinate system.\n", v.c_str()); return 1; }
+        }
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--stats") stats = true;
         else if (a == "--gpu" || a == "--wavefront") {}

@@ -439,8 +439,9 @@ struct Interpreter {
                 // translated to the camera's position at the middle of the time interval
                 const wf_animated_transform wfc = MakeAnimatedTransform(scene->worldFromCamera, transformStartTime, scene->worldFromCameraEnd, transformEndTime);
                 const float tMid = (transformStartTime + transformEndTime) / 2;
-                V3 pCamera = AnimatedAt(wfc, tMid).Point(V3{0, 0, 0});
-                Transform worldFromRender = Translate(pCamera);
+                Transform worldFromRender;   // RenderingCoordinateSystem::World: the identity
+                if (opt->renderingSpace == 0) worldFromRender = AnimatedAt(wfc, tMid);   // Camera: worldFromCamera.Interpolate(tMid)
+                else if (opt->renderingSpace == 1) worldFromRender = Translate(AnimatedAt(wfc, tMid).Point(V3{0, 0, 0}));   // CameraWorld
                 renderFromWorld = Inverse(worldFromRender);
                 scene->renderFromWorld = renderFromWorld;
             } else if (tok == "Film") { basicParamDirective(&scene->film); scene->filmColorSpace = gs.colorSpace; }
@@ -525,14 +526,39 @@ struct Interpreter {
                 u.renderFromInstance = RenderFromObject() * Inverse(renderFromWorld);
                 scene->instances.push_back(u);
             } else if (tok == "Option") {
-                std::vector<Param> ps = ParseParams(tz);
-                for (const Param &p : ps) {
-                    if (p.name == "seed" && !p.ints.empty()) opt->seed = p.ints[0];
-                    else if (p.name == "disablepixeljitter" && !p.bools.empty()) opt->disablePixelJitter = p.bools[0];
-                    else if (p.name == "disablewavelengthjitter" && !p.bools.empty()) opt->disableWavelengthJitter = p.bools[0];
-                    else if (p.name == "disabletexturefiltering" && !p.bools.empty()) opt->disableTextureFiltering = p.bools[0];
-                    else fprintf(stderr, "Warning: %s: Option \"%s\" ignored\n", loc.c_str(), p.name.c_str());
-                }
+                // parser.cpp:877-880 + BasicSceneBuilder::Option (scene.cpp:489-575): `Option "name" value` — the name without a type, the value a bare
+                // token (true / false / number) or a quoted string
+                std::string name = nextString(), nName;
+                for (char ch : name) if (ch != '_' && ch != '-') nName.push_back((char)tolower((unsigned char)ch));   // normalizeArg
+                const std::string value = nextRequired("option value");
+                auto boolean = [&](bool *dst) {
+                    if (value == "true") *dst = true;
+                    else if (value == "false") *dst = false;
+                    else Fatal(loc, "%s: expected \"true\" or \"false\" for option value", value.c_str());
+                };
+                auto quoted = [&]() {
+                    if (value.size() < 3 || value.front() != '"' || value.back() != '"') Fatal(loc, "%s: expected quoted string for option value", value.c_str());
+                    return value.substr(1, value.size() - 2);
+                };
+                if (nName == "disablepixeljitter") boolean(&opt->disablePixelJitter);
+                else if (nName == "disabletexturefiltering") boolean(&opt->disableTextureFiltering);
+                else if (nName == "disablewavelengthjitter") boolean(&opt->disableWavelengthJitter);
+                else if (nName == "displacementedgescale") {
+                    char *end = nullptr;
+                    opt->displacementEdgeScale = strtof(value.c_str(), &end);
+                    if (end == value.c_str() || *end) Fatal(loc, "%s: expected floating-point option value", value.c_str());
+                } else if (nName == "rendercoordsys") {
+                    // (takes effect at the Camera directive, like the reference's CameraTransform)
+                    const std::string v = quoted();
+                    if (v == "camera") opt->renderingSpace = 0;
+                    else if (v == "cameraworld") opt->renderingSpace = 1;
+                    else if (v == "world") opt->renderingSpace = 2;
+                    else Fatal(loc, "%s: unknown rendering coordinate system.", v.c_str());
+                } else if (nName == "seed") opt->seed = atoi(value.c_str());
+                else if (nName == "forcediffuse") { bool b = false; boolean(&b); if (b) Fatal(loc, "The wavefront integrator does not support --force-diffuse."); }
+                else if (nName == "pixelstats") { bool b = false; boolean(&b); if (b) Fatal(loc, "The wavefront integrator does not support --pixelstats."); }
+                else if (nName == "wavefront" || nName == "msereferenceimage" || nName == "msereferenceout") {}   // (this IS the wavefront path; no MSE reference output here)
+                else Fatal(loc, "%s: unknown option", name.c_str());
             } else if (tok == "PixelFilter") basicParamDirective(&scene->filter);
             else if (tok == "ReverseOrientation") gs.reverseOrientation = !gs.reverseOrientation;
             else if (tok == "Rotate") {

@@ -93,6 +93,7 @@ struct RenderOptions {  // subset of PBRTOptions (options.h)
     float cropWindow[4] = {0, 0, 0, 0};  // --cropwindow
     bool hasPixelBounds = false, hasCropWindow = false;
     std::string imageFile;
+    int renderingSpace = 1;              // --render-coord-sys / Option "rendercoordsys": 0 camera, 1 cameraworld (default), 2 world (cameras.cpp:27-47)
     float displacementEdgeScale = 1;     // --displacement-edge-scale (options.h: scales the target edge length of displaced meshes)
 };
 
