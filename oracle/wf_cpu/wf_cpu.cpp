@@ -289,6 +289,15 @@ static int Main(int argc, char **argv) {
         else if (a == "--displacement-edge-scale") opt.displacementEdgeScale = (float)atof(next().c_str());
         else if (a == "--render-coord-sys") { const std::string v = next(); opt.renderingSpace = v == "camera" ? 0 : (v == "world" ? 2 : 1); }
         else if (a == "--nthreads") gThreads = atoi(next().c_str());
+        else if (a == "--cropwindow") { if (sscanf(next().c_str(), "%f,%f,%f,%f", &opt.cropWindow[0], &opt.cropWindow[1], &opt.cropWindow[2], &opt.cropWindow[3]) == 4) opt.hasCropWindow = true; }
+        else if (a == "--pixelbounds") { if (sscanf(next().c_str(), "%d,%d,%d,%d", &opt.pixelBounds[0], &opt.pixelBounds[1], &opt.pixelBounds[2], &opt.pixelBounds[3]) == 4) opt.hasPixelBounds = true; }
+        else if (a == "--disable-pixel-jitter") opt.disablePixelJitter = true;
+        else if (a == "--disable-wavelength-jitter") opt.disableWavelengthJitter = true;
+        else if (a == "--disable-texture-filtering") opt.disableTextureFiltering = true;
+        else if (a == "--quick") opt.quickRender = true;
+        else if (a == "--disable-image-textures") opt.disableImageTextures = true;
+        else if (a == "--pixel") { int px = 0, py = 0; sscanf(next().c_str(), "%d,%d", &px, &py); opt.pixelBounds[0] = px; opt.pixelBounds[1] = px + 1; opt.pixelBounds[2] = py; opt.pixelBounds[3] = py + 1; opt.hasPixelBounds = true; }
+        else if (a == "--debugstart") { int f = 0, c = 1; if (sscanf(next().c_str(), "%d,%d", &f, &c) < 2) c = 1; sampleBegin = f; sampleEnd = f + c; }
         else if (a == "--outfile") opt.imageFile = next();
         else if (a == "--dump-film") dumpFilm = next();
         else if (a == "--datadir") dataDir = next();

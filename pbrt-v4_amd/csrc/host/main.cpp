@@ -23,6 +23,7 @@ static void usage() {
             "  --disable-pixel-jitter / --disable-wavelength-jitter / --disable-texture-filtering\n"
             "  --displacement-edge-scale <s>   scale the target edge length of displaced meshes\n"
             "  --render-coord-sys <name>       camera, cameraworld (default) or world\n"
+            "  --pixel <x,y>  --debugstart <first[,count]>  --quick  --disable-image-textures  --nthreads <n>\n"
             "  --datadir <dir>        directory holding spectral_tables.txt\n"
             "  --stats                print ray counts and the per-kernel profile\n"
             "  --quiet, --gpu, --wavefront (accepted)\n");
@@ -42,6 +43,7 @@ static int Main(int argc, char **argv) {
     std::string scenePath, dataDir;
     int device = 0;
     bool stats = false;
+    int debugFirst = -1, debugCount = 1;   // --debugstart
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto value = [&]() -> std::string {
@@ -73,6 +75,18 @@ static int Main(int argc, char **argv) {
             else if (v == "world") opt.renderingSpace = 2;
             else { fprintf(stderr, "%s: unknown rendering coordinate system.\n", v.c_str()); return 1; }
         }
+        else if (a == "--quick") opt.quickRender = true;
+        else if (a == "--disable-image-textures") opt.disableImageTextures = true;
+        else if (is("--pixel")) {   // cmd/pbrt.cpp:136-143
+            int px, py;
+            if (sscanf(value().c_str(), "%d,%d", &px, &py) != 2) { usage(); return 1; }
+            opt.pixelBounds[0] = px; opt.pixelBounds[1] = px + 1; opt.pixelBounds[2] = py; opt.pixelBounds[3] = py + 1;
+            opt.hasPixelBounds = true;
+        } else if (is("--debugstart")) {   // wavefront/integrator.cpp:320-332: first sample index [, number of sample indices]
+            int nv = sscanf(value().c_str(), "%d,%d", &debugFirst, &debugCount);
+            if (nv < 1) { fprintf(stderr, "Expected either one or two integer values for --debugstart.\n"); return 1; }
+            if (nv == 1) debugCount = 1;
+        } else if (is("--nthreads")) { const std::string n = value(); setenv("WF_BUILD_THREADS", n.c_str(), 1); }
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--stats") stats = true;
         else if (a == "--gpu" || a == "--wavefront") {}
@@ -98,8 +112,9 @@ static int Main(int argc, char **argv) {
 
     WavefrontRenderer renderer(T, device);
     if (stats) wf_profile_enable(renderer.Context(), 1);
-    double seconds = renderer.Render(0, T.spp, 1);
-    if (!opt.quiet) fprintf(stderr, "Rendering finished: %.3f s, %.2f Msamples/s\n", seconds, (double)W * H * T.spp / seconds / 1e6);
+    const int firstSample = debugFirst >= 0 ? debugFirst : 0, lastSample = debugFirst >= 0 ? debugFirst + debugCount : T.spp;
+    double seconds = renderer.Render(firstSample, lastSample, 1);
+    if (!opt.quiet) fprintf(stderr, "Rendering finished: %.3f s, %.2f Msamples/s\n", seconds, (double)W * H * (lastSample - firstSample) / seconds / 1e6);
     if (stats) {
         wf_render_stats st;
         renderer.Stats(&st);

@@ -93,6 +93,8 @@ struct RenderOptions {  // subset of PBRTOptions (options.h)
     float cropWindow[4] = {0, 0, 0, 0};  // --cropwindow
     bool hasPixelBounds = false, hasCropWindow = false;
     std::string imageFile;
+    bool quickRender = false;            // --quick: a quarter of the resolution, one sample per pixel (film.cpp:92-95, samplers.cpp)
+    bool disableImageTextures = false;   // --disable-image-textures: every image map reduced to the coarsest level of its pyramid (util/mipmap.cpp:199-203)
     int renderingSpace = 1;              // --render-coord-sys / Option "rendercoordsys": 0 camera, 1 cameraworld (default), 2 world (cameras.cpp:27-47)
     float displacementEdgeScale = 1;     // --displacement-edge-scale (options.h: scales the target edge length of displaced meshes)
 };

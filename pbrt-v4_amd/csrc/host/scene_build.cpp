@@ -186,6 +186,7 @@ struct TexBuilder {
     SceneTables *T;
     std::map<std::string, int> floatTextures, spectrumTexturesAlbedo, spectrumTexturesUnbounded, spectrumTexturesIllum;
     const ParsedScene *scene;
+    bool disableImageTextures = false;
 
     std::vector<int> texDepth;  // nesting depth of every texture node: the device walks the graph with a WF_TEX_MAX_DEPTH stack
     int AddTex(const wf_texture &t) {
@@ -452,6 +453,12 @@ struct TexBuilder {
             }
             level.swap(next);
             lw = nw; lh = nh;
+        }
+        if (disableImageTextures) {
+            // MIPMap ctor with Options->disableImageTextures (util/mipmap.cpp:199-203): the pyramid is its last (coarsest) level alone
+            im.level_offset[0] = im.level_offset[im.n_levels - 1];
+            im.n_levels = 1;
+            im.res[0] = lw; im.res[1] = lh;
         }
         int id = (int)T->texImages.size();
         T->texImages.push_back(im);
@@ -1015,6 +1022,7 @@ void BuildFilm(const ParsedScene &scene, const RenderOptions &opt, SceneTables *
         Die(scene.film.loc, T->imageFile + (F.type == WF_FILM_SPECTRAL ? ": EXR is the only output format supported by the SpectralFilm." : ": EXR is the only format supported by the GBufferFilm."));
     F.full_res[0] = ps.GetOneInt("xresolution", 1280);
     F.full_res[1] = ps.GetOneInt("yresolution", 720);
+    if (opt.quickRender) { F.full_res[0] = std::max(1, F.full_res[0] / 4); F.full_res[1] = std::max(1, F.full_res[1] / 4); }   // film.cpp:92-95
     int pb[4] = {0, 0, F.full_res[0], F.full_res[1]};  // xmin, ymin, xmax, ymax
     auto intersect = [&](int x0, int y0, int x1, int y1) {
         pb[0] = std::max(pb[0], x0); pb[1] = std::max(pb[1], y0); pb[2] = std::min(pb[2], x1); pb[3] = std::min(pb[3], y1);
@@ -1103,8 +1111,8 @@ void BuildSampler(const ParsedScene &scene, const RenderOptions &opt, SceneTable
         if (nsamp & (nsamp - 1)) fprintf(stderr, "Warning: Non power-of-two sample count %d will perform suboptimally with the SobolSampler.\n", nsamp);
         S.spp = nsamp;
         {
-            const ParamSet &fp = scene.film.params;
-            int rx = fp.GetOneInt("xresolution", 1280), ry = fp.GetOneInt("yresolution", 720);
+            // film.FullResolution() (scene.cpp:771): the film built just before this, --quick's quartering included
+            const int rx = T->desc.film.full_res[0], ry = T->desc.film.full_res[1];
             int sc = 1;
             while (sc < std::max(rx, ry)) sc *= 2;  // RoundUpPow2
             S.sobol_scale = sc;
@@ -2301,7 +2309,11 @@ bool ReadPLY(const std::string &fn, MeshSource *out, std::string *err) {
 }  // namespace
 
 // ---- main entry ---------------------------------------------------------------------------------------
-void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneTables *T) {
+void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, SceneTables *T) {
+    RenderOptions opt = optIn;
+    // the samplers' Create functions: `if (Options->quickRender) nsamp = 1` after the --spp override (samplers.cpp:74,113,152,214,264,314 —
+    // every sampler but the independent one, which keeps its sample count)
+    if (opt.quickRender && scene.sampler.name != "independent") opt.pixelSamples = 1;
     const SpectralData &sd = SpectralData::Get();
     (void)sd;
     // WF_LOAD_TIMING=1: where the load time goes (stderr)
@@ -2357,6 +2369,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &opt, SceneT
     TexBuilder tb;
     tb.T = T;
     tb.scene = &scene;
+    tb.disableImageTextures = opt.disableImageTextures;
     tb.CreateNamedTextures();
     std::map<std::string, int> &namedMaterialIds = tb.namedMaterialIds;
     for (const auto &nm : scene.namedMaterials) namedMaterialIds[nm.first] = tb.CreateMaterial(nm.second);
