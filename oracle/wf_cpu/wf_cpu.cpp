@@ -723,6 +723,6 @@ static int Main(int argc, char **argv) {
     }
     std::vector<float> rgb((size_t)W * H * 3);
     FilmToRGB(F, ws.film, W, H, rgb.data(), T.saveFP16);
-    if (!T.imageFile.empty()) WriteImage(T.imageFile, rgb.data(), W, H);
+    if (!T.imageFile.empty()) WriteFilmImage(T, T.imageFile, rgb, W, H);
     return 0;
 }

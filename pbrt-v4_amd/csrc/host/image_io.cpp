@@ -720,6 +720,24 @@ void GBufferFilmImage(const wf_film &F, const double *film, const wf_gbuffer_pix
     }
 }
 
+bool WriteFilmImage(const SceneTables &T, const std::string &path, std::vector<float> &rgb, int w, int h) {
+    const size_t dot = path.find_last_of('.');
+    const bool exr = dot != std::string::npos && path.substr(dot) == ".exr";
+    if (!exr && T.sRGBFromFilmRGB.size() == 9) {
+        fprintf(stderr, "Warning: %s: converting pixel colors to sRGB to match output image format.\n", path.c_str());
+        const float *m = T.sRGBFromFilmRGB.data();
+        for (size_t i = 0; i < (size_t)w * h; ++i) {   // Mul<RGB>(m, channels): sums accumulated from 0, left to right (util/math.h:1404-1413)
+            const float v[3] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+            for (int r = 0; r < 3; ++r) {
+                float acc = 0;
+                for (int c = 0; c < 3; ++c) acc += m[3 * r + c] * v[c];
+                rgb[3 * i + r] = acc;
+            }
+        }
+    }
+    return WriteImage(path, rgb.data(), w, h);
+}
+
 bool WriteImage(const std::string &path, const float *rgb, int w, int h) {
     size_t dot = path.find_last_of('.');
     std::string ext = dot == std::string::npos ? "" : path.substr(dot);

@@ -155,6 +155,6 @@ static int Main(int argc, char **argv) {
         return 0;
     }
     FilmToRGB(F, film.data(), W, H, rgb.data(), T.saveFP16);
-    if (!WriteImage(T.imageFile, rgb.data(), W, H)) { fprintf(stderr, "Error: couldn't write %s\n", T.imageFile.c_str()); return 1; }
+    if (!WriteFilmImage(T, T.imageFile, rgb, W, H)) { fprintf(stderr, "Error: couldn't write %s\n", T.imageFile.c_str()); return 1; }
     return 0;
 }

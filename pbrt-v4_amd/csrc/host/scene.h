@@ -152,6 +152,9 @@ struct SceneTables {
     std::vector<float> tableData;
     std::vector<wf_medium> media;
     std::vector<float> mediumData;
+    // Image::Write (util/image.cpp:986-1005): an image whose colour space is not sRGB is converted to sRGB when the file format cannot say
+    // otherwise (everything but .exr).  9 floats (row major) = sRGB.RGBFromXYZ * film.XYZFromRGB when the film's colour space is not sRGB, else empty
+    std::vector<float> sRGBFromFilmRGB;
     std::string imageFile;
     bool saveFP16 = true;  // Film "savefp16" (film.cpp:579)
     int spp = 1;
@@ -250,6 +253,10 @@ void LoopSubdivide(int nLevels, const std::vector<int> &vertexIndices, const std
 bool WritePFM(const std::string &path, const float *rgb, int w, int h);
 bool ReadPFM(const std::string &path, std::vector<float> *rgb, int *w, int *h);
 bool WriteImage(const std::string &path, const float *rgb, int w, int h);  // by extension: .pfm, .exr
+struct SceneTables;
+// the film's RGB image as Film::WriteImage -> Image::Write leaves it in `path`: converted to sRGB for formats other than .exr when the film's
+// colour space is another one (SceneTables::sRGBFromFilmRGB)
+bool WriteFilmImage(const SceneTables &T, const std::string &path, std::vector<float> &rgb, int w, int h);
 // film accumulators ([h][w][4] doubles: rgbSum, weightSum) -> output RGB, as RGBFilm::GetImage does
 void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, bool saveFP16);
 bool WriteEXRChannels(const std::string &path, const std::vector<std::string> &names, const float *data, int w, int h, bool half);

@@ -517,7 +517,14 @@ void GenerateRGBToSpectrumTable(const std::string &gamut, RGBToSpectrumTable *ou
     if (gamut == "sRGB") { fillIllum("CIE_Illum_D6500", 10566.864005283874576, 4); std::memcpy(r2s->xyz_to_rgb, xyz_to_srgb, 72); std::memcpy(r2s->rgb_to_xyz, srgb_to_xyz, 72); }
     else if (gamut == "REC2020") { fillIllum("CIE_Illum_D6500", 10566.864005283874576, 4); std::memcpy(r2s->xyz_to_rgb, xyz_to_rec2020, 72); std::memcpy(r2s->rgb_to_xyz, rec2020_to_xyz, 72); }
     else if (gamut == "DCI_P3") { fillIllum("CIE_Illum_D6500", 10566.864005283874576, 4); std::memcpy(r2s->xyz_to_rgb, xyz_to_dcip3, 72); std::memcpy(r2s->rgb_to_xyz, dcip3_to_xyz, 72); }
-    else if (gamut == "ACES2065_1") { fillIllum("ACES_Illum_D60", 10536.3, 6); std::memcpy(r2s->xyz_to_rgb, xyz_to_aces, 72); std::memcpy(r2s->rgb_to_xyz, aces_to_xyz, 72); }
+    else if (gamut == "ACES2065_1") {
+        // the tool's own cie_d60 table (cmd/rgb2spec_opt.cpp:166-188, N(x) = x / 10536.3): not the ACES_Illum_D60 of util/spectrum.cpp re-sampled —
+        // the two differ in the last digits, and the tool's initialiser list is one short (its 830 nm sample is 0)
+        const auto &d60 = dbl["R2S_cie_d60"];
+        if ((int)d60.size() != R2S::CIE_SAMPLES) { fprintf(stderr, "rgb2spec: data/spectral_tables.txt lacks R2S_cie_d60 (tools/extract_spectral_tables.py)\n"); exit(1); }
+        for (int i = 0; i < R2S::CIE_SAMPLES; ++i) r2s->illum[i] = d60[i] / 10536.3;
+        std::memcpy(r2s->xyz_to_rgb, xyz_to_aces, 72); std::memcpy(r2s->rgb_to_xyz, aces_to_xyz, 72);
+    }
     else { fprintf(stderr, "rgb2spec: unsupported gamut %s\n", gamut.c_str()); exit(1); }
     r2s->init_tables();
 

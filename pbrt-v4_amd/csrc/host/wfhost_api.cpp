@@ -169,7 +169,7 @@ int wfh_write_film_image(wfh_scene *s, const char *path) {
         s->renderer->DownloadFilm(film.data());
         std::vector<float> rgb((size_t)W * H * 3);
         FilmToRGB(F, film.data(), W, H, rgb.data(), s->T.saveFP16);
-        return WriteImage(path, rgb.data(), W, H) ? 0 : -1;
+        return WriteFilmImage(s->T, path, rgb, W, H) ? 0 : -1;
     });
 }
 int wfh_read_nanovdb(const char *path, const char *grid_name, int32_t min[3], int32_t dim[3], float inv_mat[9], float vec[3], float *background, float *values) {

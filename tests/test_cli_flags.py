@@ -55,3 +55,24 @@ def test_unknown_option_directive_is_an_error(tmp_path):
         open(p, "w").write(line + "\n" + text)
         r = subprocess.run([WF_CPU, "--quiet", "--spp", "1", "--outfile", str(tmp_path / "o.pfm"), p], capture_output=True, text=True)
         assert r.returncode != 0, line
+
+
+@pytest.mark.parametrize("film_cs,world_cs", [("rec2020", None), ("dci-p3", None), ("aces2065-1", None), ("aces2065-1", "srgb"), (None, "aces2065-1"), (None, "rec2020")])
+def test_colour_spaces_match_the_reference(tmp_path, film_cs, world_cs):
+    """ColorSpace before Film (the film's colour space: the sensor matrix, and Image::Write's conversion of a non-sRGB image to sRGB for .pfm
+    output) and inside the world block (RGB parameters through that gamut's RGB -> spectrum table; ACES2065-1's is optimised against the
+    table generator's own D60 table), against pbrt_ref run here."""
+    if not os.path.exists(PBRT_REF):
+        pytest.skip("oracle/_ref/pbrt_ref not built")
+    text = open(os.path.join(GOLDEN, "film_whitebalance.pbrt")).read()
+    if film_cs:
+        text = 'ColorSpace "%s"\n' % film_cs + text
+    if world_cs:
+        text = text.replace("WorldBegin", 'WorldBegin\nColorSpace "%s"' % world_cs, 1)
+    path = str(tmp_path / "cs.pbrt")
+    open(path, "w").write(text)
+    ref, ours = str(tmp_path / "ref.pfm"), str(tmp_path / "ours.pfm")
+    subprocess.run([PBRT_REF, "--wavefront", "--quiet", "--seed", "0", "--spp", "4", "--outfile", ref, path], check=True, capture_output=True, cwd=str(tmp_path))
+    subprocess.run([WF_CPU, "--quiet", "--spp", "4", "--outfile", ours, path], check=True, capture_output=True, cwd=str(tmp_path))
+    a, b = read_pfm(ours), read_pfm(ref)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all(), "fraction identical %f" % (a == b).mean()

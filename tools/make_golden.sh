@@ -84,6 +84,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/camera_mo
 # Option "rendercoordsys" camera / world (+ "displacementedgescale"): camera_motion.pbrt and displacement.pbrt with the Option lines in front
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rendercoordsys_camera_ref.pfm $G/rendercoordsys_camera.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rendercoordsys_world_ref.pfm $G/rendercoordsys_world.pbrt
+# parser / parameter torture scene (hand-written: see its header)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/parser_torture_ref.pfm $G/parser_torture.pbrt
 # alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # a goniometric light from an 8-bit R G B PNG (channel average re-quantised into an 8-bit "Y" image)
