@@ -115,9 +115,13 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "camera_motion", "camera_motion_spherical", "rendercoordsys_camera", "rendercoordsys_world", "quadrics_alpha", "goniometric_png",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "camera_motion", "camera_motion_spherical", "quadrics_alpha", "goniometric_png",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton", "cornell64_sobol", "cornell64_sobol_owen"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
+    _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
+
+
+def _check_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     path = os.path.join(GOLDEN, name + ".pbrt")
     spp = 0 if name.startswith("cornell64_") else 4   # the sampler scenes keep their samplers' default sample counts
     s = wfpt.Scene(path=path, spp=spp)
@@ -722,3 +726,11 @@ def test_device_sah_build_gives_the_host_tree_node_for_node(wfpt, tmp_path, monk
         same(out[0], out[1])
         leaves = out[0][0][(out[0][0][:, 7] & 0xffff) > 0]
         assert (leaves[:, 7] & 0xffff).sum() == n and sorted(out[0][1].tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("name", ["rendercoordsys_camera", "rendercoordsys_world"])
+def test_image_vs_oracle_and_reference_late_goldens(wfpt, tmp_path, name):
+    """Goldens added after round 3's GPU minutes were spent (host-side changes only: Option "rendercoordsys"): bit-identical with the
+    reference on the CPU port (tests/test_oracle_golden.py), first GPU run at the round's end — kept last so that the suite's order
+    of evidence is: everything measured on the device during the round, then these."""
+    _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
