@@ -277,6 +277,7 @@ int main(int argc, char **argv) {
 static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
+    std::string lightProbeIn, lightProbeOut, reProbeIn, reProbeOut;
     bool simulateWaves = false;
     int sampleBegin = 0, sampleEnd = -1, sampleStep = 1, probeStartDim = 0, probeNDims = 0;
     int stripRank = 0, stripCount = 1, stripHeight = 16;
@@ -307,6 +308,8 @@ static int Main(int argc, char **argv) {
         else if (a == "--simulate-waves") simulateWaves = true;
         else if (a == "--strips") { stripRank = atoi(next().c_str()); stripCount = atoi(next().c_str()); stripHeight = atoi(next().c_str()); }
         else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
+        else if (a == "--reintersect-probe") { reProbeIn = next(); reProbeOut = next(); }
+        else if (a == "--light-probe") { lightProbeIn = next(); lightProbeOut = next(); }
         else if (a == "--sampler-probe") { probeIn = next(); probeOut = next(); probeStartDim = atoi(next().c_str()); probeNDims = atoi(next().c_str()); }
         else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
         else scenePath = a;
@@ -346,6 +349,118 @@ static int Main(int argc, char **argv) {
             for (int d = 0; d < probeNDims; ++d) out[(size_t)i * probeNDims + d] = s.Get1D();
         }
         f = fopen(probeOut.c_str(), "wb");
+        fwrite(out.data(), 4, out.size(), f);
+        fclose(f);
+        return 0;
+    }
+
+    // light-sampler probe (the reference's BVHLightSampling / PowerLightSampling unit tests run against the scene's sampler,
+    // tests/test_reference_known_answers.py): in = n x {p[3], n[3], uLight, u[2]} floats -> out = n x 7 floats
+    // {sampled light id or -1, its probability, LightSampler::PMF of that light, the sampled light's SampleLi is valid,
+    //  light 0's SampleLi is valid, light 0's SampleLi carries radiance, LightSampler::PMF of light 0}
+    if (!lightProbeIn.empty()) {
+        FILE *f = fopen(lightProbeIn.c_str(), "rb");
+        if (!f) { perror(lightProbeIn.c_str()); return 1; }
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        int n = (int)(sz / (9 * sizeof(float)));
+        std::vector<float> in((size_t)n * 9), out((size_t)n * 7);
+        if (fread(in.data(), 4, in.size(), f) != in.size()) return 1;
+        fclose(f);
+        const Wavelengths lambda = SampleUniformWavelengths(0.5f);
+        ParallelFor(n, [&](int i) {
+            const float *r = &in[(size_t)i * 9];
+            LightCtx ctx;
+            ctx.pi = MakeP3i(V3{r[0], r[1], r[2]}, V3{0, 0, 0});
+            ctx.n = ctx.ns = N3{r[3], r[4], r[5]};
+            float pmf = 0;
+            const int id = LightSamplerSample(sv, ctx, r[6], &pmf);
+            float *o = &out[(size_t)i * 7];
+            o[0] = (float)id;
+            o[1] = id >= 0 ? pmf : 0.f;
+            o[2] = id >= 0 ? LightSamplerPMF(sv, ctx, id) : 0.f;
+            o[3] = id >= 0 && LightSampleLi(sv, sv.lights[id], ctx, V2{r[7], r[8]}, lambda, true).valid ? 1.f : 0.f;
+            o[4] = o[5] = o[6] = 0;
+            if (sv.nLights > 0) {
+                o[6] = LightSamplerPMF(sv, ctx, 0);
+                const LightLiSample ls = LightSampleLi(sv, sv.lights[0], ctx, V2{r[7], r[8]}, lambda, true);
+                o[4] = ls.valid ? 1.f : 0.f;
+                o[5] = ls.valid && (ls.L[0] != 0 || ls.L[1] != 0 || ls.L[2] != 0 || ls.L[3] != 0) ? 1.f : 0.f;
+            }
+        });
+        f = fopen(lightProbeOut.c_str(), "wb");
+        fwrite(out.data(), 4, out.size(), f);
+        fclose(f);
+        return 0;
+    }
+
+    // re-intersection probe (the reference's Triangle.Reintersect / TestReintersectConvex, shapes_test.cpp:156-206, 255-312, run on
+    // the scene's primitives one at a time): in = n x {prim, convex, o[3], d[3], seed} floats -> out = n x {hit, rays leaving the
+    // intersection point in 1000 random directions that meet the same primitive again, the same for 1000 rays toward random points
+    // with tMax = 1}.  The interaction is the one the kernels rebuild from a hit record (HitInteraction), the rays leave it through
+    // SpawnRay / SpawnRayTo (OffsetRayOrigin over the interaction's error bounds) as the kernels' rays do.
+    if (!reProbeIn.empty()) {
+        FILE *f = fopen(reProbeIn.c_str(), "rb");
+        if (!f) { perror(reProbeIn.c_str()); return 1; }
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        int n = (int)(sz / (9 * sizeof(float)));
+        std::vector<float> in((size_t)n * 9), out((size_t)n * 3);
+        if (fread(in.data(), 4, in.size(), f) != in.size()) return 1;
+        fclose(f);
+        auto hitPrim = [&](int prim, V3 o, V3 d, float tMax, float b[3]) -> bool {
+            if (prim < sv.nTriangles) {
+                V3 p0, p1, p2;
+                TriVerts(sv, prim, &p0, &p1, &p2);
+                TriHit h;
+                if (!IntersectTriangle(o, d, tMax, p0, p1, p2, &h)) return false;
+                b[0] = h.b0; b[1] = h.b1; b[2] = h.b2;
+                return true;
+            }
+            QuadricHit qh;
+            if (!QuadricIntersect(sv, prim, o, d, tMax, &qh)) return false;
+            b[0] = qh.pObj.x; b[1] = qh.pObj.y; b[2] = qh.pObj.z;
+            return true;
+        };
+        ParallelFor(n, [&](int i) {
+            const float *r = &in[(size_t)i * 9];
+            float *res = &out[(size_t)i * 3];
+            res[0] = res[1] = res[2] = 0;
+            const int prim = (int)r[0];
+            const bool convex = r[1] != 0;
+            const V3 o{r[2], r[3], r[4]}, d{r[5], r[6], r[7]};
+            float b[3];
+            if (prim < 0 || prim >= sv.nTriangles + sv.nQuadrics || !hitPrim(prim, o, d, WF_INFINITY, b)) return;
+            res[0] = 1;
+            SurfIntr si;
+            HitInteraction(sv, prim, -1, b[0], b[1], b[2], &si, o, d);
+            uint64_t st = 0x853c49e6748fea9bull ^ ((uint64_t)(uint32_t)(int)r[8] * 0x9E3779B97F4A7C15ull);
+            auto uni = [&]() {   // xorshift64*, 24 bits
+                st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+                return (float)((st * 0x2545F4914F6CDD1Dull) >> 40) * (1.f / 16777216.f);
+            };
+            auto pExp = [&]() { return std::pow(10.f, -8.f + 16.f * uni()); };
+            if (r[1] == 2) {   // BilinearPatch.Offset (shapes_test.cpp:451-492): the ray continued in its own direction
+                RayOD ro = SpawnRay(si.pi, si.n, d);
+                float bb[3];
+                if (hitPrim(prim, ro.o, ro.d, WF_INFINITY, bb)) res[1] += 1;
+                return;
+            }
+            for (int j = 0; j < 1000; ++j) {
+                V3 w = SampleUniformSphere(V2{uni(), uni()});
+                if (convex) w = FaceForward(w, toV(si.n));
+                RayOD ro = SpawnRay(si.pi, si.n, w);
+                float bb[3];
+                if (hitPrim(prim, ro.o, ro.d, WF_INFINITY, bb)) res[1] += 1;
+                V3 p2{pExp(), pExp(), pExp()};
+                if (convex) p2 = si.pi.mid() + FaceForward(p2 - si.pi.mid(), toV(si.n));
+                ro = SpawnRayTo(si.pi, si.n, p2);
+                if (hitPrim(prim, ro.o, ro.d, 1.f, bb)) res[2] += 1;
+            }
+        });
+        f = fopen(reProbeOut.c_str(), "wb");
         fwrite(out.data(), 4, out.size(), f);
         fclose(f);
         return 0;
