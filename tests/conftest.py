@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 WF_CPU = os.path.join(ROOT, "oracle", "_build", "wf_cpu")
 WF_PROBE = os.path.join(ROOT, "oracle", "_build", "wf_probe")
+WF_PROPS = os.path.join(ROOT, "oracle", "_build", "wf_props")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
@@ -27,7 +28,7 @@ def load_pkg():
 @pytest.fixture(scope="session")
 def built():
     """In-tree build of the product libraries and of the CPU checker (no GPU needed: hipcc cross-compiles)."""
-    need = [os.path.join(ROOT, "pbrt-v4_amd", "_build", "libwfhip.so"), os.path.join(ROOT, "pbrt-v4_amd", "_build", "libwfhost.so"), WF_CPU, WF_PROBE]
+    need = [os.path.join(ROOT, "pbrt-v4_amd", "_build", "libwfhip.so"), os.path.join(ROOT, "pbrt-v4_amd", "_build", "libwfhost.so"), WF_CPU, WF_PROBE, WF_PROPS]
     if not all(os.path.exists(p) for p in need):
         sys.path.insert(0, ROOT)
         import __graft_entry__

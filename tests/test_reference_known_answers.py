@@ -359,3 +359,36 @@ def test_bilinear_patch_offset(built, tmp_path):
     out = reintersect_probe(tmp_path, world, rec)
     assert out[:, 0].mean() > 0.9
     assert out[:, 1].sum() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bsdfs_test.cpp: BSDFEnergyConservation, BSDFSampling (Sample_f against f / PDF and against uniform sampling) and the Hair
+# tests, on the restated BxDFs the material kernels run (oracle/wf_cpu/wf_props.cpp tells which reference test each one is).
+import json
+from conftest import WF_PROPS
+
+
+@pytest.fixture(scope="module")
+def bxdf_props(built):
+    p = subprocess.run([WF_PROPS], check=True, capture_output=True, text=True)
+    return {j["test"]: j for j in map(json.loads, p.stdout.strip().splitlines())}
+
+
+BXDF_PROPS = (["BSDFEnergyConservation." + n for n in
+               ["LambertianReflection", "MicrofacetReflectionTrowbridgeReitz_alpha0.5_cond", "MicrofacetReflectionTrowbridgeReitz_aniso_cond",
+                "DiffuseTransmission", "ThinDielectric"] +
+               ["MicrofacetReflectionTrowbridgeReitz_%s_%s" % (r, e) for r in ("1.50", "1.00", "0.50", "0.10", "0.01") for e in ("1.5", "inv1.5_importance")] +
+               ["Coated%s_%d" % (k, v) for k in ("Diffuse", "Conductor") for v in range(3)]] +
+              ["BSDFSampling." + n for n in ["Lambertian", "TRCondIso", "TRCondAniso", "TRDielIso", "TRDielAniso", "TRDielIsoInv", "TRDielAnisoInv",
+                                             "DiffuseTransmission", "Hair"]] +
+              ["Hair." + n for n in ["WhiteFurnace", "HOnTheEdge", "WhiteFurnaceSampled", "SamplingWeights", "SamplingConsistency"]])
+
+
+@pytest.mark.parametrize("name", BXDF_PROPS)
+def test_bxdf_property(bxdf_props, name):
+    assert name in bxdf_props, sorted(bxdf_props)
+    assert bxdf_props[name]["ok"], bxdf_props[name]["detail"]
+
+
+def test_bxdf_property_list_is_complete(bxdf_props):
+    assert sorted(bxdf_props) == sorted(BXDF_PROPS)
