@@ -342,10 +342,18 @@ static int Main(int argc, char **argv) {
         std::vector<int32_t> in((size_t)n * 3);
         if (fread(in.data(), 4, in.size(), f) != in.size()) return 1;
         fclose(f);
+        // ndims = -2: the sample's GetPixel2D() instead (samplers_test.cpp's elementary-interval tests read it)
+        const bool pixel2D = probeNDims == -2;
+        if (pixel2D) probeNDims = 2;
         std::vector<float> out((size_t)n * probeNDims);
         for (int i = 0; i < n; ++i) {
             PixelSampler s(sv);
             s.StartPixelSample(in[3 * i], in[3 * i + 1], in[3 * i + 2], probeStartDim);
+            if (pixel2D) {
+                V2 p = s.GetPixel2D();
+                out[(size_t)i * 2] = p.x; out[(size_t)i * 2 + 1] = p.y;
+                continue;
+            }
             for (int d = 0; d < probeNDims; ++d) out[(size_t)i * probeNDims + d] = s.Get1D();
         }
         f = fopen(probeOut.c_str(), "wb");

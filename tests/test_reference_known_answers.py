@@ -392,3 +392,49 @@ def test_bxdf_property(bxdf_props, name):
 
 def test_bxdf_property_list_is_complete(bxdf_props):
     assert sorted(bxdf_props) == sorted(BXDF_PROPS)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# samplers_test.cpp: {PaddedSobol, ZSobol, SobolUnscrambled, SobolXORScrambled, SobolOwenScrambled}Sampler.ElementaryIntervals
+# (:75-160) on the restated samplers (csrc/common/wf_camera.h) behind the scene's Sampler directive: the GetPixel2D() samples of a
+# pixel are a (0, m, 2)-net — every elementary interval of 2^m cells holds exactly one of its 2^m samples.
+def pixel_samples(tmp_path, sampler_line, res, spp, seed=0):
+    scene = str(tmp_path / "sampler.pbrt")
+    open(scene, "w").write('Film "rgb" "integer xresolution" [ %d ] "integer yresolution" [ %d ] "string filename" [ "x.pfm" ]\n%s\nWorldBegin\n' % (res, res, sampler_line) +
+                           point_light([0, 0, 0]) + 'Shape "sphere"\n')
+    px, py, idx = np.meshgrid(np.arange(res), np.arange(res), np.arange(spp), indexing="ij")
+    fin, fout = str(tmp_path / "s_in.bin"), str(tmp_path / "s_out.bin")
+    np.stack([px.ravel(), py.ravel(), idx.ravel()], axis=1).astype(np.int32).tofile(fin)
+    subprocess.run([WF_CPU, "--quiet", "--seed", str(seed), "--sampler-probe", fin, fout, "0", "-2", scene], check=True, capture_output=True)
+    return np.fromfile(fout, np.float32).reshape(res * res, spp, 2)
+
+
+def check_elementary(samples, log_samples):
+    assert samples.shape[1] == 1 << log_samples
+    assert (samples >= 0).all() and (samples < 1).all()
+    for i in range(log_samples + 1):
+        nx, ny = 1 << i, 1 << (log_samples - i)
+        cell = np.floor(ny * samples[..., 1]).astype(int) * nx + np.floor(nx * samples[..., 0]).astype(int)
+        assert (np.sort(cell, axis=1) == np.arange(1 << log_samples)).all(), (nx, ny)
+
+
+@pytest.mark.parametrize("rand", ["none", "permutedigits"])
+def test_padded_sobol_elementary_intervals(built, tmp_path, rand):
+    for log_samples in range(2, 11):
+        s = pixel_samples(tmp_path, 'Sampler "paddedsobol" "integer pixelsamples" [ %d ] "string randomization" "%s"' % (1 << log_samples, rand), 1, 1 << log_samples)
+        check_elementary(s, log_samples)
+
+
+@pytest.mark.parametrize("rand", ["none", "permutedigits"])
+def test_zsobol_elementary_intervals(built, tmp_path, rand):
+    for seed in (0, 1, 5, 6, 10, 15):
+        for log_samples in range(2, 9):
+            s = pixel_samples(tmp_path, 'Sampler "zsobol" "integer pixelsamples" [ %d ] "string randomization" "%s"' % (1 << log_samples, rand), 10, 1 << log_samples, seed)
+            check_elementary(s, log_samples)
+
+
+@pytest.mark.parametrize("rand", ["none", "permutedigits", "owen"])
+def test_sobol_elementary_intervals(built, tmp_path, rand):
+    for log_samples in range(2, 11):
+        s = pixel_samples(tmp_path, 'Sampler "sobol" "integer pixelsamples" [ %d ] "string randomization" "%s"' % (1 << log_samples, rand), 1, 1 << log_samples)
+        check_elementary(s, log_samples)
