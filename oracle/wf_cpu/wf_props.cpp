@@ -212,6 +212,53 @@ static void HairTests() {
     }
 }
 
+// media_test.cpp:15-98 — HGPhaseFunction = HenyeyGreenstein(Dot(wo, wi), g) / SampleHenyeyGreenstein (media.h:77-105)
+static void HGTests() {
+    Rng rng(9);
+    {
+        bool ok = true;
+        float worst = 0;
+        for (float g = -.75f; g <= 0.75f; g += 0.25f)
+            for (int i = 0; i < 100; ++i) {
+                V3 wo = SampleUniformSphere(V2{rng(), rng()});
+                float pdf = 0;
+                V3 wi = SampleHenyeyGreenstein(wo, g, V2{rng(), rng()}, &pdf);
+                float p = HenyeyGreenstein(Dot(wo, wi), g);
+                worst = fmax(worst, fabs(p - pdf));
+                ok &= fabs(p - pdf) <= 1e-4f && pdf > 0;
+            }
+        Report("HenyeyGreenstein.SamplingMatch", ok, "worst |p - pdf| = " + std::to_string(worst));
+    }
+    for (int back = 0; back < 2; ++back) {
+        int nForward = 0, nBackward = 0;
+        for (int i = 0; i < 100; ++i) {
+            V3 wi = SampleHenyeyGreenstein(V3{-1, 0, 0}, back ? -0.95f : 0.95f, V2{rng(), rng()}, nullptr);
+            (wi.x > 0 ? nForward : nBackward)++;
+        }
+        Report(back ? "HenyeyGreenstein.SamplingOrientationBackward" : "HenyeyGreenstein.SamplingOrientationForward",
+               back ? nBackward >= 10 * nForward : nForward >= 10 * nBackward, std::to_string(nForward) + " forward, " + std::to_string(nBackward) + " backward");
+    }
+    {
+        bool okN = true, okG = true;
+        for (float g = -.75f; g <= 0.75f; g += 0.25f) {
+            V3 wo = SampleUniformSphere(V2{rng(), rng()});
+            double sum = 0, sumG = 0;
+            const int sq = 64;
+            for (int a = 0; a < sq; ++a)
+                for (int b = 0; b < sq; ++b) {
+                    V3 wi = SampleUniformSphere(V2{(a + rng()) / sq, (b + rng()) / sq});
+                    float p = HenyeyGreenstein(Dot(wo, wi), g);
+                    sum += p;
+                    sumG += p * -Dot(wo, wi);
+                }
+            okN &= fabs(sum / (sq * sq) - 1 / (4 * Pi)) <= 1e-3;
+            okG &= fabs(sumG / (sq * sq * (1 / (4 * Pi))) - g) <= .01;
+        }
+        Report("HenyeyGreenstein.Normalized", okN, "");
+        Report("HenyeyGreenstein.g", okG, "");
+    }
+}
+
 int main() {
     // bsdfs_test.cpp:560-650
     EnergyConservation(DiffuseBxDF{S4c(1.f)}, "LambertianReflection");
@@ -249,5 +296,6 @@ int main() {
         SamplingConsistency(hair, "Hair");
     }
     HairTests();
+    HGTests();
     return 0;
 }

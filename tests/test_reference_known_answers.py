@@ -381,7 +381,8 @@ BXDF_PROPS = (["BSDFEnergyConservation." + n for n in
                ["Coated%s_%d" % (k, v) for k in ("Diffuse", "Conductor") for v in range(3)]] +
               ["BSDFSampling." + n for n in ["Lambertian", "TRCondIso", "TRCondAniso", "TRDielIso", "TRDielAniso", "TRDielIsoInv", "TRDielAnisoInv",
                                              "DiffuseTransmission", "Hair"]] +
-              ["Hair." + n for n in ["WhiteFurnace", "HOnTheEdge", "WhiteFurnaceSampled", "SamplingWeights", "SamplingConsistency"]])
+              ["Hair." + n for n in ["WhiteFurnace", "HOnTheEdge", "WhiteFurnaceSampled", "SamplingWeights", "SamplingConsistency"]] +
+              ["HenyeyGreenstein." + n for n in ["SamplingMatch", "SamplingOrientationForward", "SamplingOrientationBackward", "Normalized", "g"]])
 
 
 @pytest.mark.parametrize("name", BXDF_PROPS)
