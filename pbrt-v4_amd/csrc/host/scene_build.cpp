@@ -2727,7 +2727,22 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             addShape(sh, &defPrims.back(), true);
         }
     }
-    if (T->triIndices.empty() && spheres.empty()) Die("", "scene has no geometry");
+    if (T->triIndices.empty() && spheres.empty()) {
+        // A scene without geometry renders (the reference's aggregate is then empty: every ray escapes, scene.cpp:1590-1600,
+        // wavefront/aggregate.cpp:24-32).  The tables keep one primitive that no ray can hit — a triangle whose three vertices are the
+        // render-space origin: IntersectTriangle's first test rejects a zero-area triangle (shapes.cpp:172-173), and the scene bounds it
+        // gives Light::Preprocess (centre 0, radius 0) are those of the reference's empty Bounds3f.
+        if (scene.materials.empty()) Die("", "scene has no geometry");
+        ShapeEntity ph;
+        ph.name = "trianglemesh";
+        ph.loc = "(placeholder of a scene without geometry)";
+        Param idx; idx.type = "integer"; idx.name = "indices"; idx.ints = {0, 1, 2};
+        Param pos; pos.type = "point3"; pos.name = "P"; pos.floats.assign(9, 0.f);
+        ph.params.params = {idx, pos};
+        ph.materialIndex = 0;
+        addShape(ph, &topPrims, false);
+        if (T->triIndices.empty()) Die("", "scene has no geometry");
+    }
     // spheres: primitive ids follow the triangles'
     {
         const int nTris = (int)T->triIndices.size() / 3;

@@ -728,9 +728,10 @@ def test_device_sah_build_gives_the_host_tree_node_for_node(wfpt, tmp_path, monk
         assert (leaves[:, 7] & 0xffff).sum() == n and sorted(out[0][1].tolist()) == list(range(n))
 
 
-@pytest.mark.parametrize("name", ["rendercoordsys_camera", "rendercoordsys_world"])
+@pytest.mark.parametrize("name", ["rendercoordsys_camera", "rendercoordsys_world", "empty_scene"])
 def test_image_vs_oracle_and_reference_late_goldens(wfpt, tmp_path, name):
-    """Goldens added after round 3's GPU minutes were spent (host-side changes only: Option "rendercoordsys"): bit-identical with the
+    """Goldens added after round 3's GPU minutes were spent (host-side changes only: Option "rendercoordsys", the
+    placeholder primitive of a scene without geometry): bit-identical with the
     reference on the CPU port (tests/test_oracle_golden.py), first GPU run at the round's end — kept last so that the suite's order
     of evidence is: everything measured on the device during the round, then these."""
     _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)

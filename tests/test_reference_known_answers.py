@@ -118,9 +118,7 @@ def light_probe(tmp_path, world, p, u_light, n=None, u2=None, sampler="bvh"):
     rec[:, 6] = u_light
     rec[:, 7:9] = 0.5 if u2 is None else u2
     scene = str(tmp_path / "lights.pbrt")
-    # (this build refuses a scene without geometry: one non-emissive triangle far from everything)
-    filler = 'Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point3 P" [ 1e5 1e5 1e5  1e5 1.00001e5 1e5  1e5 1e5 1.00001e5 ]\n'
-    open(scene, "w").write(HEADER % ('Integrator "volpath" "string lightsampler" "%s"' % sampler) + world + filler)
+    open(scene, "w").write(HEADER % ('Integrator "volpath" "string lightsampler" "%s"' % sampler) + world)   # (a scene without geometry is fine)
     fin, fout = str(tmp_path / "probe_in.bin"), str(tmp_path / "probe_out.bin")
     rec.tofile(fin)
     subprocess.run([WF_CPU, "--quiet", "--light-probe", fin, fout, scene], check=True, capture_output=True)

@@ -86,6 +86,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rendercoo
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/rendercoordsys_world_ref.pfm $G/rendercoordsys_world.pbrt
 # parser / parameter torture scene (hand-written: see its header)
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/parser_torture_ref.pfm $G/parser_torture.pbrt
+# a scene without geometry (the product keeps one unhittable placeholder triangle; the reference an empty aggregate)
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/empty_scene_ref.pfm $G/empty_scene.pbrt
 # alpha textures on spheres / disks / cylinders / bilinear patches (re-intersection behind a rejected hit), an alpha-masked emissive sphere
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/quadrics_alpha_ref.pfm $G/quadrics_alpha.pbrt
 # a goniometric light from an 8-bit R G B PNG (channel average re-quantised into an 8-bit "Y" image)
