@@ -37,6 +37,7 @@ SahBuildFn g_sahBuild = nullptr;
 
 struct Builder {
     int maxPrimsInNode;
+    int splitMethod = 0;   // 0 SAH, 2 Middle, 3 EqualCounts (1 = HLBVH: BuildHLBVH)
     BuildNode *pool = nullptr;   // raw storage for 2 n nodes (not value-initialised: 450 MB for the 4 M-primitive top level)
     ~Builder() { free(pool); }
     std::vector<int32_t> *ordered;
@@ -95,7 +96,21 @@ struct Builder {
         int dim = centroidBounds.MaxDimension();
         if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) { InitLeaf(node, prims, n, bounds, first); return node; }
         int mid = n / 2;
-        if (n <= 2) {
+        if (splitMethod == 2 || splitMethod == 3) {
+            // SplitMethod::Middle / EqualCounts (cpu/aggregates.cpp:239-263): a leaf only for one primitive or degenerate bounds (above)
+            bool parted = false;
+            if (splitMethod == 2) {
+                const float pmid = (centroidBounds.pMin[dim] + centroidBounds.pMax[dim]) / 2;
+                BVHPrim *midIter = std::partition(prims, prims + n, [dim, pmid](const BVHPrim &pi) { return pi.Centroid()[dim] < pmid; });
+                mid = int(midIter - prims);
+                parted = mid != 0 && mid != n;   // "for lots of prims with large overlapping bounding boxes, this may fail to partition": EqualCounts then
+            }
+            if (!parted) {
+                mid = n / 2;
+                std::nth_element(prims, prims + mid, prims + n,
+                                 [dim](const BVHPrim &a, const BVHPrim &b) { return a.Centroid()[dim] < b.Centroid()[dim]; });
+            }
+        } else if (n <= 2) {
             std::nth_element(prims, prims + mid, prims + n,
                              [dim](const BVHPrim &a, const BVHPrim &b) { return a.Centroid()[dim] < b.Centroid()[dim]; });
         } else {
@@ -383,6 +398,7 @@ int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode,
     else ordered.assign(nAll, -1);
     Builder bld;
     bld.maxPrimsInNode = std::min(255, maxPrimsInNode);
+    bld.splitMethod = splitMethod;
     bld.pool = (BuildNode *)malloc((2 * (size_t)nAll + 1024 * 1024) * sizeof(BuildNode));   // (+ the unused tails of the threads' runs)
     if (!bld.pool) return -1;
     bld.ordered = &ordered;

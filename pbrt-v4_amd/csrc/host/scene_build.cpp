@@ -2605,6 +2605,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         if (sh.reverseOrientation ^ swaps) mesh.flags |= WF_MESH_FLIP_NORMAL;
         for (size_t i = 0; i < src.P.size(); ++i) {
             V3 p = rfo.Point(src.P[i]);
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z))
+                Die(sh.loc, sh.name + ": vertex " + std::to_string(i) + " is not finite in render space (a NaN or infinite position or transformation)");
             T->P.push_back(p.x); T->P.push_back(p.y); T->P.push_back(p.z);
             N3 n{0, 0, 0};
             if (!src.N.empty()) {
@@ -3350,10 +3352,18 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
 
     tick("textures, materials, shapes (PLY), lights");
     // ---- acceleration structure (scene.cpp:1575-1591, cpu/aggregates.cpp:725-744) ----
-    if (scene.accelerator.name != "bvh") fprintf(stderr, "Warning: accelerator \"%s\" is replaced by the BVH\n", scene.accelerator.name.c_str());
+    // CreateAccelerator (cpu/aggregates.cpp:1163-1178): "bvh" | "kdtree", anything else is an error.  A kd-tree finds the same closest hit and
+    // the same occlusion as the BVH (exact ties between coplanar primitives aside): it is replaced by the BVH, as the reference's own GPU path
+    // replaces every accelerator by its own
+    if (scene.accelerator.name == "kdtree") fprintf(stderr, "Warning: accelerator \"kdtree\" is replaced by the BVH\n");
+    else if (scene.accelerator.name != "bvh") Die(scene.accelerator.loc, scene.accelerator.name + ": accelerator type unknown.");
     std::string split = scene.accelerator.params.GetOneString("splitmethod", "sah");
     if (getenv("WF_BVH_SPLIT")) split = getenv("WF_BVH_SPLIT");   // load-time experiments: build the top-level tree with the other method
-    if (split != "sah" && split != "hlbvh") { fprintf(stderr, "Warning: BVH split method \"%s\" is replaced by \"sah\"\n", split.c_str()); split = "sah"; }
+    if (split != "sah" && split != "hlbvh" && split != "middle" && split != "equal") {
+        fprintf(stderr, "Warning: BVH split method \"%s\" unknown.  Using \"sah\".\n", split.c_str());   // cpu/aggregates.cpp:737-740
+        split = "sah";
+    }
+    const int splitCode = split == "hlbvh" ? 1 : split == "middle" ? 2 : split == "equal" ? 3 : 0;
     int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
     {
         // The top-level tree needs only the BOUNDS of the instance definitions (= the union of their primitives' bounds, what the root of
@@ -3364,6 +3374,18 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         std::vector<int32_t> defOrdered;
         T->instanceDefs.resize(defPrims.size());
         std::vector<B3> defBounds(defPrims.size());
+        // a vertex, radius or transformation that is not finite (NaN / infinite bounds) would index outside the builders' buckets:
+        // refused here, before any builder sees it (the reference's builder has the same undefined bucket index, cpu/aggregates.cpp:268-275)
+        auto requireFinite = [&](const PrimList &prims, const std::string &what) {
+            for (const auto &p : prims) {
+                const B3 &b = p.second;
+                const float v[6] = {b.pMin.x, b.pMin.y, b.pMin.z, b.pMax.x, b.pMax.y, b.pMax.z};
+                for (float f : v)
+                    if (!std::isfinite(f)) Die("", what + ": a primitive has bounds that are not finite (a NaN or infinite vertex position, radius or transformation)");
+            }
+        };
+        requireFinite(topPrims, "scene");
+        for (size_t d = 0; d < defPrims.size(); ++d) requireFinite(defPrims[d], "object instance definition");
         {
             std::atomic<size_t> next{0};
             unsigned nt = std::max(1u, std::min((unsigned)defPrims.size(), std::thread::hardware_concurrency()));
@@ -3393,12 +3415,14 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             const float b[6] = {db.pMin.x, db.pMin.y, db.pMin.z, db.pMax.x, db.pMax.y, db.pMax.z};
             B3 wb;
             for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}));
+            for (int c = 0; c < 3; ++c)
+                if (!std::isfinite(wb.pMin[c]) || !std::isfinite(wb.pMax[c])) Die("", u.name + ": the bounds of an object instance are not finite (its transformation?)");
             topPrims.emplace_back(nTrisAll + nQuads + (int)T->instances.size(), wb);
             T->instances.push_back(in);
         }
         std::string topError;
         std::thread topBuild([&] {
-            try { BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims, split == "hlbvh" ? 1 : 0); }
+            try { BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims, splitCode); }
             catch (const std::exception &e) { topError = e.what(); }
         });
         {

@@ -93,6 +93,10 @@ def _bvh_stat_scenes(tmp_path):
     import make_scenes
     from conftest import GOLDEN
     out = [(n, os.path.join(GOLDEN, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap", "blobs_hlbvh")]
+    for m in ("middle", "equal"):   # SplitMethod::Middle / EqualCounts (cpu/aggregates.cpp:239-263)
+        v = str(tmp_path / ("blobs_%s.pbrt" % m))
+        open(v, "w").write(open(os.path.join(GOLDEN, "blobs_small.pbrt")).read().replace("\nWorldBegin", '\nAccelerator "bvh" "string splitmethod" "%s"\nWorldBegin' % m, 1))
+        out.append(("blobs_" + m, v, 4))
     k = str(tmp_path / "killeroo_like_240.pbrt")
     make_scenes.killeroo_like(k, (240, 135), 1)
     out.append(("killeroo_like_240x135_1spp", k, 1))
@@ -168,6 +172,22 @@ def test_scene_errors_are_returned_not_fatal(wfpt):
     with pytest.raises(wfpt.WfError) as e:   # animated transformation: refused, not rendered in the wrong place
         wfpt.Scene(text=base.replace("WorldBegin", "WorldBegin\nActiveTransform EndTime\nTranslate 1 0 0\nActiveTransform All", 1), spp=1)
     assert "animated" in str(e.value)
+    with pytest.raises(wfpt.WfError) as e:   # CreateAccelerator (cpu/aggregates.cpp:1163-1171)
+        wfpt.Scene(text=base.replace("WorldBegin", 'Accelerator "octree"\nWorldBegin', 1), spp=1)
+    assert "accelerator type unknown" in str(e.value)
+    with pytest.raises(wfpt.WfError) as e:   # wavefront/integrator.cpp:179
+        wfpt.Scene(text='Film "rgb"\nWorldBegin\nShape "sphere"\n', spp=1)
+    assert "No light sources specified" in str(e.value)
+    for bad in ("nan", "inf", "-inf"):       # a vertex that is not finite: an error before any BVH builder indexes a bucket with it (fuzzing, round 3)
+        with pytest.raises(wfpt.WfError) as e:
+            wfpt.Scene(text='Film "rgb"\nWorldBegin\nLightSource "infinite"\nShape "trianglemesh" "integer indices" [0 1 2] "point3 P" [0 0 0 1 %s 0 0 1 0]\n' % bad, spp=1)
+        assert "not finite" in str(e.value)
+    with pytest.raises(wfpt.WfError) as e:
+        wfpt.Scene(text='Film "rgb"\nWorldBegin\nLightSource "infinite"\nScale 1e30 1e30 1e30\nShape "sphere" "float radius" 1e30\n', spp=1)
+    assert "not finite" in str(e.value)
+    s = wfpt.Scene(text='Film "rgb"\nWorldBegin\nLightSource "infinite"\n', spp=1)   # no geometry at all: fine (the reference's empty aggregate)
+    assert s.info.n_triangles == 1
+    s.close()
     s = wfpt.Scene(text=base, spp=1)   # and the library is still usable
     assert s.info.n_triangles > 0
     s.close()

@@ -29,6 +29,11 @@ def ref_stats(path, spp):
 
 def scenes(td):
     out = [(n, os.path.join(G, n + ".pbrt"), 4) for n in ("cornell64", "blobs_small", "materials_lights", "alpha_normalmap", "instances", "envmap", "blobs_hlbvh")]
+    # SplitMethod::Middle / EqualCounts: blobs_small with the Accelerator directive in front of WorldBegin
+    for m in ("middle", "equal"):
+        v = os.path.join(td, "blobs_%s.pbrt" % m)
+        open(v, "w").write(open(os.path.join(G, "blobs_small.pbrt")).read().replace("\nWorldBegin", '\nAccelerator "bvh" "string splitmethod" "%s"\nWorldBegin' % m, 1))
+        out.append(("blobs_" + m, v, 4))
     k = os.path.join(td, "killeroo_like_240.pbrt")
     make_scenes.killeroo_like(k, (240, 135), 1)
     out.append(("killeroo_like_240x135_1spp", k, 1))
