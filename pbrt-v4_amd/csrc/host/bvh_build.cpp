@@ -159,7 +159,13 @@ struct Builder {
                 if (costs[i] < minCost) { minCost = costs[i]; minCostSplitBucket = i; }
             float leafCost = n;
             minCost = 1.f / 2.f + minCost / bounds.SurfaceArea();
-            if (n > maxPrimsInNode || minCost < leafCost) {
+            if (minCostSplitBucket < 0) {
+                // every cost overflowed or is NaN (scene_build refuses such extents before they get here; the reference would recurse
+                // on the unsplit span for ever): split the span in the middle
+                mid = n / 2;
+                std::nth_element(prims, prims + mid, prims + n,
+                                 [dim](const BVHPrim &a, const BVHPrim &b) { return a.Centroid()[dim] < b.Centroid()[dim]; });
+            } else if (n > maxPrimsInNode || minCost < leafCost) {
                 BVHPrim *midIter = std::partition(prims, prims + n, [=](const BVHPrim &bp) {
                     int b = nBuckets * centroidBounds.Offset(bp.Centroid())[dim];
                     if (b == nBuckets) b = nBuckets - 1;

@@ -3377,6 +3377,16 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         // a vertex, radius or transformation that is not finite (NaN / infinite bounds) would index outside the builders' buckets:
         // refused here, before any builder sees it (the reference's builder has the same undefined bucket index, cpu/aggregates.cpp:268-275)
         auto requireFinite = [&](const PrimList &prims, const std::string &what) {
+            // ... and neither may the extent of the whole set overflow: the SAH costs are surface areas, the bucket index divides by the
+            // centroid extent — with infinite values no split is ever chosen and the recursion (the reference's too) never ends
+            B3 all;
+            for (const auto &p : prims) all = Union(all, p.second);
+            if (!prims.empty()) {
+                const V3 d = all.Diagonal();
+                // (count x surface area: the largest SAH cost the builders can form)
+                if (!std::isfinite(d.x) || !std::isfinite(d.y) || !std::isfinite(d.z) || !std::isfinite((float)prims.size() * all.SurfaceArea()))
+                    Die("", what + ": the extent of the primitives overflows single precision (coordinates of the order of 1e19 or more)");
+            }
             for (const auto &p : prims) {
                 const B3 &b = p.second;
                 const float v[6] = {b.pMin.x, b.pMin.y, b.pMin.z, b.pMax.x, b.pMax.y, b.pMax.z};

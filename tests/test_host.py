@@ -184,7 +184,10 @@ def test_scene_errors_are_returned_not_fatal(wfpt):
         assert "not finite" in str(e.value)
     with pytest.raises(wfpt.WfError) as e:
         wfpt.Scene(text='Film "rgb"\nWorldBegin\nLightSource "infinite"\nScale 1e30 1e30 1e30\nShape "sphere" "float radius" 1e30\n', spp=1)
-    assert "not finite" in str(e.value)
+    assert "not finite" in str(e.value) or "overflows single precision" in str(e.value)
+    with pytest.raises(wfpt.WfError) as e:   # finite, but the SAH costs (count x surface area) are not: no split would ever be chosen
+        wfpt.Scene(text='Film "rgb"\nWorldBegin\nLightSource "infinite"\nShape "trianglemesh" "integer indices" [0 1 2 1 2 3] "point3 P" [0 0 0 1 1e38 0 0 1 0 1 1 1]\n', spp=1)
+    assert "overflows single precision" in str(e.value)
     s = wfpt.Scene(text='Film "rgb"\nWorldBegin\nLightSource "infinite"\n', spp=1)   # no geometry at all: fine (the reference's empty aggregate)
     assert s.info.n_triangles == 1
     s.close()
