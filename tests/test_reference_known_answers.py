@@ -89,13 +89,20 @@ def test_furnace_radiance_matches_gpu(wfpt, tmp_path, world, sampler, camera):
     s.create_renderer(0)
     s.render()
     img = s.image()
+    rays = s.total_rays()
     s.close()
     check_scene_average(img)
     path = str(tmp_path / "furnace.pbrt")
     open(path, "w").write(text)
     out = str(tmp_path / "cpu.pfm")
-    run_wf_cpu(path, out)
-    assert (read_pfm(out).view(np.uint32) == img.view(np.uint32)).all()
+    j = run_wf_cpu(path, out)
+    cpu = read_pfm(out)
+    # the f32 tolerance of the north_star on every value (expected and so far always measured: bit-identical), equal ray counts
+    from conftest import image_error
+    rel = image_error(img, cpu)
+    print(world, sampler, camera, "max rel", rel.max(), "bit-identical fraction", (cpu.view(np.uint32) == img.view(np.uint32)).mean())
+    assert rel.max() <= 1e-3
+    assert rays == j["rays"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
