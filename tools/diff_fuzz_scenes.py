@@ -1,0 +1,426 @@
+#!/usr/bin/env python3
+"""tools/diff_fuzz_scenes.py — differential fuzzing of the restated path against the reference itself.
+
+    python tools/diff_fuzz_scenes.py [--n 200] [--seed 0] [--keep DIR]
+
+Writes random small scenes (random camera, sampler, filter, film / sensor parameters, lights, textures, materials, shapes, object
+instances, media — combinations no hand-written golden has), renders each with oracle/_ref/pbrt_ref --wavefront (the unmodified
+reference built here) and with oracle/_build/wf_cpu (the stage bodies the HIP kernels run, compiled for the host) and compares the
+images BIT FOR BIT, or the fact that both refuse the scene.  A difference is a parity bug in code the GPU shares: the scene is kept.
+Needs /root/reference's build (oracle/_ref); test infrastructure only."""
+import argparse
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import read_pfm  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
+CPU = os.path.join(ROOT, "oracle", "_build", "wf_cpu")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def f(*v):
+    return " ".join("%.6g" % x for x in v)
+
+
+class Gen:
+    def __init__(self, seed):
+        self.r = random.Random(seed)
+        self.float_tex, self.spec_tex, self.materials = [], [], []
+        self.media = []
+
+    def u(self, a=0.0, b=1.0):
+        return self.r.uniform(a, b)
+
+    def rgb(self, lo=0.05, hi=0.95):
+        return "[ %s ]" % f(self.u(lo, hi), self.u(lo, hi), self.u(lo, hi))
+
+    def pick(self, xs):
+        return self.r.choice(xs)
+
+    # ---- header -------------------------------------------------------------------------------------------------
+    def header(self):
+        r = self.r
+        out = []
+        if r.random() < 0.15:
+            out.append('Option "string rendercoordsys" "%s"' % self.pick(["camera", "cameraworld", "world"]))
+        if r.random() < 0.1:
+            out.append('ColorSpace "%s"' % self.pick(["srgb", "rec2020", "dci-p3", "aces2065-1"]))
+        out.append("LookAt %s  %s  0 0 1" % (f(self.u(-1, 1), -7 + self.u(-1, 1), 2.5 + self.u(-1, 1)), f(self.u(-.5, .5), self.u(-.5, .5), 1 + self.u(-.3, .3))))
+        cam = self.pick(["perspective"] * 4 + ["orthographic", "spherical", "realistic"])
+        if cam == "perspective":
+            out.append('Camera "perspective" "float fov" [ %s ]' % f(self.u(25, 70)) +
+                       (' "float lensradius" [ %s ] "float focaldistance" [ %s ]' % (f(self.u(0.01, 0.2)), f(self.u(4, 9))) if r.random() < 0.3 else "") +
+                       (' "float shutteropen" [ 0.1 ] "float shutterclose" [ 0.8 ]' if r.random() < 0.2 else ""))
+        elif cam == "orthographic":
+            out.append('Camera "orthographic" "float screenwindow" [ -4 4 -3 3 ]' + (' "float lensradius" [ 0.05 ] "float focaldistance" [ 7 ]' if r.random() < 0.3 else ""))
+        elif cam == "spherical":
+            out.append('Camera "spherical" "string mapping" "%s"' % self.pick(["equalarea", "equirectangular"]))
+        else:
+            out.append('Camera "realistic" "string lensfile" "%s" "float aperturediameter" [ %s ] "float focusdistance" [ %s ]'
+                       % (os.path.join(GOLDEN, "dgauss50.dat"), f(self.u(4, 17)), f(self.u(5, 9))))
+        spp = self.pick([1, 2, 3, 4, 8])
+        samp = self.pick(["zsobol"] * 3 + ["halton", "sobol", "paddedsobol", "independent", "stratified"])
+        if samp == "stratified":
+            out.append('Sampler "stratified" "integer xsamples" [ %d ] "integer ysamples" [ %d ] "bool jitter" %s' % (self.pick([1, 2, 3]), self.pick([1, 2]), self.pick(["true", "false"])))
+        else:
+            rnd = ""
+            if samp in ("zsobol", "sobol", "paddedsobol") and r.random() < 0.5:
+                rnd = ' "string randomization" "%s"' % self.pick(["none", "permutedigits", "fastowen", "owen"])
+            if samp == "halton" and r.random() < 0.5:
+                rnd = ' "string randomization" "%s"' % self.pick(["none", "permutedigits", "owen"])
+            out.append('Sampler "%s" "integer pixelsamples" [ %d ]%s' % (samp, spp, rnd))
+        out.append('Integrator "volpath" "integer maxdepth" [ %d ]' % self.pick([0, 1, 3, 5, 9]) + (' "bool regularize" true' if r.random() < 0.15 else "") +
+                   (' "string lightsampler" "%s"' % self.pick(["bvh", "power", "uniform"]) if r.random() < 0.4 else ""))
+        filt = self.pick(["gaussian", "box", "mitchell", "sinc", "triangle", None])
+        if filt:
+            out.append('PixelFilter "%s"' % filt + (' "float xradius" [ %s ] "float yradius" [ %s ]' % (f(self.u(0.5, 2.5)), f(self.u(0.5, 2.5))) if r.random() < 0.5 else ""))
+        film = 'Film "rgb" "string filename" [ "fz.pfm" ] "integer xresolution" [ %d ] "integer yresolution" [ %d ] "bool savefp16" [ false ]' % (self.pick([16, 24, 33]), self.pick([12, 16, 19]))
+        if r.random() < 0.2:
+            film += ' "float iso" [ %s ]' % f(self.u(50, 400))
+        if r.random() < 0.15:
+            film += ' "float whitebalance" [ %s ]' % f(self.u(3000, 9000))
+        if r.random() < 0.15:
+            film += ' "string sensor" "%s"' % self.pick(["cie1931", "canon_eos_5d_mkiv", "nikon_d850", "sony_ilce_7rm3"])
+        if r.random() < 0.15:
+            film += ' "float maxcomponentvalue" [ %s ]' % f(self.u(0.5, 5))
+        if r.random() < 0.15:
+            film += ' "float cropwindow" [ 0.1 0.8 0.2 0.9 ]'
+        out.append(film)
+        if r.random() < 0.2:
+            out.append('MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" %s "rgb sigma_s" %s "float scale" [ %s ] "float g" [ %s ]'
+                       % (self.rgb(0.01, 0.2), self.rgb(0.01, 0.3), f(self.u(0.05, 0.5)), f(self.u(-0.6, 0.8))))
+            self.media.append("fog")
+        return out
+
+    # ---- world --------------------------------------------------------------------------------------------------
+    def spectrum_param(self, name, lo=0.05, hi=0.95):
+        k = self.r.random()
+        if k < 0.6 or not self.spec_tex:
+            if k < 0.1:
+                return '"spectrum %s" [ 300 %s 500 %s 800 %s ]' % (name, f(self.u(lo, hi)), f(self.u(lo, hi)), f(self.u(lo, hi)))
+            return '"rgb %s" %s' % (name, self.rgb(lo, hi))
+        return '"texture %s" "%s"' % (name, self.pick(self.spec_tex))
+
+    def float_param(self, name, lo, hi):
+        if self.float_tex and self.r.random() < 0.25:
+            return '"texture %s" "%s"' % (name, self.pick(self.float_tex))
+        return '"float %s" [ %s ]' % (name, f(self.u(lo, hi)))
+
+    def mapping(self):
+        m = self.pick(["uv", "uv", "spherical", "cylindrical", "planar"])
+        s = ' "string mapping" "%s"' % m
+        if m == "uv":
+            s += ' "float uscale" [ %s ] "float vscale" [ %s ] "float udelta" [ %s ]' % (f(self.u(0.5, 6)), f(self.u(0.5, 6)), f(self.u(0, 1)))
+        elif m == "planar":
+            s += ' "vector3 v1" [ 1 0 0.2 ] "vector3 v2" [ 0 1 0.3 ]'
+        return s
+
+    def textures(self):
+        out = []
+        for i in range(self.r.randrange(0, 5)):
+            name = "ft%d" % i
+            kind = self.pick(["constant", "scale", "mix", "checkerboard", "fbm", "wrinkled", "windy", "dots", "bilerp", "imagemap", "directionmix"])
+            if kind == "constant":
+                out.append('Texture "%s" "float" "constant" "float value" [ %s ]' % (name, f(self.u(0, 1))))
+            elif kind in ("scale", "mix", "directionmix") and self.float_tex:
+                if kind == "scale":
+                    out.append('Texture "%s" "float" "scale" "texture tex" "%s" "float scale" [ %s ]' % (name, self.pick(self.float_tex), f(self.u(0.2, 1.5))))
+                elif kind == "mix":
+                    out.append('Texture "%s" "float" "mix" "texture tex1" "%s" "float tex2" [ %s ] "float amount" [ %s ]' % (name, self.pick(self.float_tex), f(self.u()), f(self.u())))
+                else:
+                    out.append('Texture "%s" "float" "directionmix" "texture tex1" "%s" "float tex2" [ %s ] "vector3 dir" [ 0.3 0.2 1 ]' % (name, self.pick(self.float_tex), f(self.u())))
+            elif kind == "checkerboard":
+                out.append('Texture "%s" "float" "checkerboard" "float tex1" [ %s ] "float tex2" [ %s ]' % (name, f(self.u()), f(self.u())) + (' "integer dimension" 3' if self.r.random() < 0.3 else self.mapping()))
+            elif kind in ("fbm", "wrinkled"):
+                out.append('Texture "%s" "float" "%s" "integer octaves" [ %d ] "float roughness" [ %s ]' % (name, kind, self.pick([2, 5, 8]), f(self.u(0.3, 0.7))))
+            elif kind == "windy":
+                out.append('Texture "%s" "float" "windy"' % name)
+            elif kind == "dots":
+                out.append('Texture "%s" "float" "dots" "float inside" [ %s ] "float outside" [ %s ]' % (name, f(self.u()), f(self.u())) + self.mapping())
+            elif kind == "bilerp":
+                out.append('Texture "%s" "float" "bilerp" "float v00" [ %s ] "float v01" [ %s ] "float v10" [ %s ] "float v11" [ %s ]' % (name, f(self.u()), f(self.u()), f(self.u()), f(self.u())))
+            elif kind == "imagemap":
+                out.append('Texture "%s" "float" "imagemap" "string filename" "%s" "string filter" "%s" "string wrap" "%s"'
+                           % (name, os.path.join(GOLDEN, self.pick(["alpha.pfm", "bump.pfm", "png_grey8.png"])), self.pick(["bilinear", "point", "trilinear", "ewa"]), self.pick(["repeat", "clamp", "black", "octahedralsphere"])) + self.mapping())
+            else:
+                continue
+            self.float_tex.append(name)
+        for i in range(self.r.randrange(0, 5)):
+            name = "st%d" % i
+            kind = self.pick(["constant", "scale", "mix", "checkerboard", "marble", "imagemap", "bilerp", "dots"])
+            if kind == "constant":
+                out.append('Texture "%s" "spectrum" "constant" "rgb value" %s' % (name, self.rgb()))
+            elif kind == "scale" and self.spec_tex:
+                out.append('Texture "%s" "spectrum" "scale" "texture tex" "%s" "float scale" [ %s ]' % (name, self.pick(self.spec_tex), f(self.u(0.2, 1))))
+            elif kind == "mix" and self.spec_tex:
+                out.append('Texture "%s" "spectrum" "mix" "texture tex1" "%s" "rgb tex2" %s %s' % (name, self.pick(self.spec_tex), self.rgb(), self.float_param("amount", 0, 1)))
+            elif kind == "checkerboard":
+                out.append('Texture "%s" "spectrum" "checkerboard" "rgb tex1" %s "rgb tex2" %s' % (name, self.rgb(), self.rgb()) + self.mapping())
+            elif kind == "marble":
+                out.append('Texture "%s" "spectrum" "marble" "float scale" [ %s ] "float variation" [ %s ]' % (name, f(self.u(0.5, 3)), f(self.u(0.1, 0.5))))
+            elif kind == "imagemap":
+                out.append('Texture "%s" "spectrum" "imagemap" "string filename" "%s" "string filter" "%s" "float scale" [ %s ] "bool invert" %s'
+                           % (name, os.path.join(GOLDEN, self.pick(["wood.pfm", "png_rgb8.png", "png_rgba8.png", "png_rgb16.png", "png_pal8.png"])), self.pick(["bilinear", "point", "trilinear", "ewa"]), f(self.u(0.5, 1.2)), self.pick(["true", "false"])) + self.mapping())
+            elif kind == "bilerp":
+                out.append('Texture "%s" "spectrum" "bilerp" "rgb v00" %s "rgb v01" %s "rgb v10" %s "rgb v11" %s' % (name, self.rgb(), self.rgb(), self.rgb(), self.rgb()))
+            elif kind == "dots":
+                out.append('Texture "%s" "spectrum" "dots" "rgb inside" %s "rgb outside" %s' % (name, self.rgb(), self.rgb()) + self.mapping())
+            else:
+                continue
+            self.spec_tex.append(name)
+        return out
+
+    def material(self, name):
+        t = self.pick(["diffuse"] * 3 + ["conductor", "dielectric", "thindielectric", "diffusetransmission", "coateddiffuse", "coatedconductor", "hair", "subsurface", "measured", "interface"])   # ("mix" hashes heap pointers in the reference: statistical, tests/test_oracle_golden.py)
+        rough = lambda pre="": ('%s "bool remaproughness" %s' % (self.float_param(pre + "roughness", 0, 0.6), self.pick(["true", "false"]))
+                                if self.r.random() < 0.6 else '"float %suroughness" [ %s ] "float %svroughness" [ %s ]' % (pre, f(self.u(0, 0.5)), pre, f(self.u(0, 0.5))))
+        extra = ""
+        if self.r.random() < 0.15 and self.float_tex:
+            extra = ' "texture displacement" "%s"' % self.pick(self.float_tex)
+        if self.r.random() < 0.1:
+            extra += ' "string normalmap" "%s"' % os.path.join(GOLDEN, self.pick(["normal.pfm", "png_normal.png"]))
+        if t == "diffuse":
+            body = self.spectrum_param("reflectance")
+        elif t == "conductor":
+            body = ('"spectrum eta" "%s" "spectrum k" "%s" ' % self.pick([("metal-Cu-eta", "metal-Cu-k"), ("metal-Au-eta", "metal-Au-k"), ("metal-Al-eta", "metal-Al-k")])
+                    if self.r.random() < 0.5 else self.spectrum_param("reflectance", 0.3, 0.95) + " ") + rough()
+        elif t == "dielectric":
+            body = ('"float eta" [ %s ] ' % f(self.u(1.1, 2.2)) if self.r.random() < 0.7 else '"spectrum eta" "%s" ' % self.pick(["glass-BK7", "glass-F11", "glass-SF11"])) + rough()
+        elif t == "thindielectric":
+            body = '"float eta" [ %s ]' % f(self.u(1.1, 2))
+        elif t == "diffusetransmission":
+            body = self.spectrum_param("reflectance", 0.05, 0.6) + " " + self.spectrum_param("transmittance", 0.05, 0.6) + ' "float scale" [ %s ]' % f(self.u(0.5, 1.2))
+        elif t == "coateddiffuse":
+            body = self.spectrum_param("reflectance") + " " + rough() + ' "float thickness" [ %s ] "float g" [ %s ] "rgb albedo" %s "integer maxdepth" [ %d ] "integer nsamples" [ %d ]' % (
+                f(self.u(0.001, 0.1)), f(self.u(-0.5, 0.7)), self.pick(["[ 0 0 0 ]", self.rgb(0, 0.8)]), self.pick([3, 10]), self.pick([1, 2]))
+        elif t == "coatedconductor":
+            body = rough("interface.") + " " + rough("conductor.") + ' "float thickness" [ %s ] "rgb albedo" %s "float g" [ %s ]' % (f(self.u(0.001, 0.1)), self.pick(["[ 0 0 0 ]", self.rgb(0, 0.6)]), f(self.u(-0.5, 0.7)))
+            if self.r.random() < 0.5:
+                body += " " + self.spectrum_param("reflectance", 0.3, 0.95)
+        elif t == "hair":
+            body = self.pick(['"float eumelanin" [ %s ] "float pheomelanin" [ %s ]' % (f(self.u(0, 4)), f(self.u(0, 2))), '"rgb reflectance" %s' % self.rgb(), '"rgb sigma_a" %s' % self.rgb(0.05, 2)]) + \
+                ' "float beta_m" [ %s ] "float beta_n" [ %s ] "float alpha" [ %s ]' % (f(self.u(0.1, 0.9)), f(self.u(0.1, 0.9)), f(self.u(0, 4)))
+        elif t == "subsurface":
+            body = self.pick(['"string name" "%s"' % self.pick(["Skin1", "Marble", "Ketchup", "Apple"]), '"rgb reflectance" %s "rgb mfp" %s' % (self.rgb(0.3, 0.9), self.rgb(0.05, 0.5)),
+                              '"rgb sigma_a" %s "rgb sigma_s" %s' % (self.rgb(0.001, 0.05), self.rgb(0.5, 3))]) + ' "float scale" [ %s ] "float eta" [ %s ] "float g" [ %s ] ' % (f(self.u(0.5, 20)), f(self.u(1.2, 1.6)), f(self.u(-0.3, 0.6))) + rough()
+        elif t == "measured":
+            body = '"string filename" "%s"' % os.path.join(GOLDEN, self.pick(["measured_iso.bsdf", "measured_aniso.bsdf"]))
+        elif t == "interface":
+            body = ""
+            extra = ""
+        else:   # mix of two earlier named materials
+            prev = [m for m in self.materials if m[1] not in ("interface", "mix", "subsurface")]
+            if len(prev) < 2:
+                return self.material(name)
+            a, b = self.r.sample(prev, 2)
+            body = '"string materials" [ "%s" "%s" ] %s' % (a[0], b[0], self.float_param("amount", 0, 1))
+            extra = ""
+        self.materials.append((name, t))
+        return 'MakeNamedMaterial "%s" "string type" "%s" %s%s' % (name, t, body, extra)
+
+    def lights(self):
+        out = []
+        n = self.r.randrange(1, 4)
+        kinds = ["infinite", "infinite_image", "infinite_portal", "distant", "point", "spot", "goniometric", "projection"]
+        for _ in range(n):
+            k = self.pick(kinds)
+            sc = ' "float scale" [ %s ]' % f(self.u(0.5, 2)) if self.r.random() < 0.3 else ""
+            if k == "infinite":
+                out.append('LightSource "infinite" "rgb L" %s' % self.rgb(0.1, 0.6) + sc + (' "float illuminance" [ %s ]' % f(self.u(1, 5)) if self.r.random() < 0.2 else ""))
+            elif k == "infinite_image":
+                out.append('AttributeBegin\nRotate %s 0 0 1\nLightSource "infinite" "string filename" "%s"%s\nAttributeEnd' % (f(self.u(0, 360)), os.path.join(GOLDEN, "sky.pfm"), sc))
+            elif k == "infinite_portal":
+                out.append('LightSource "infinite" "string filename" "%s" "point3 portal" [ -3 5 0  3 5 0  3 5 5  -3 5 5 ]' % os.path.join(GOLDEN, "sky.pfm"))
+            elif k == "distant":
+                out.append('LightSource "distant" "point3 from" [ %s ] "point3 to" [ 0 0 0 ] "rgb L" %s' % (f(self.u(-4, 4), self.u(-4, 4), self.u(3, 9)), self.rgb(0.5, 2)) + sc)
+            elif k == "point":
+                out.append('LightSource "point" "point3 from" [ %s ] "rgb I" %s' % (f(self.u(-4, 4), self.u(-5, 1), self.u(2, 6)), self.rgb(5, 40)) + (' "float power" [ %s ]' % f(self.u(50, 400)) if self.r.random() < 0.3 else ""))
+            elif k == "spot":
+                out.append('LightSource "spot" "point3 from" [ %s ] "point3 to" [ %s ] "float coneangle" [ %s ] "float conedeltaangle" [ %s ] "rgb I" %s'
+                           % (f(self.u(-4, 4), self.u(-5, 0), self.u(3, 6)), f(self.u(-1, 1), self.u(-1, 1), 1), f(self.u(15, 50)), f(self.u(1, 12)), self.rgb(20, 90)))
+            elif k == "goniometric":
+                out.append('AttributeBegin\nTranslate %s\nLightSource "goniometric" "string filename" "%s" "rgb I" %s\nAttributeEnd' % (f(self.u(-2, 2), self.u(-3, 0), self.u(2, 5)), os.path.join(GOLDEN, "sky.pfm"), self.rgb(5, 30)))
+            else:
+                out.append('AttributeBegin\nTranslate %s\nRotate 120 1 0 0\nLightSource "projection" "string filename" "%s" "float fov" [ %s ] "float scale" [ %s ]\nAttributeEnd'
+                           % (f(self.u(-2, 2), self.u(-5, -2), self.u(2, 5)), os.path.join(GOLDEN, "wood.pfm"), f(self.u(30, 80)), f(self.u(20, 80))))
+        return out
+
+    def shape(self):
+        """one random shape around the origin of its own frame (unit-ish size)"""
+        k = self.pick(["quad", "quad", "blob", "sphere", "sphere", "disk", "cylinder", "bilinear", "curve", "subdiv", "ply"])
+        alpha = ""
+        if self.r.random() < 0.15:
+            alpha = ' "float alpha" [ %s ]' % f(self.pick([0.0, 0.4, 0.7])) if self.r.random() < 0.5 or not self.float_tex else ' "texture alpha" "%s"' % self.pick(self.float_tex)
+        if k == "quad":
+            uv = ' "point2 uv" [ 0 0 1 0 1 1 0 1 ]' if self.r.random() < 0.7 else ""
+            nrm = ' "normal N" [ 0.1 0 1  0 0.1 1  -0.1 0 1  0 -0.1 1 ]' if self.r.random() < 0.3 else ""
+            return 'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point3 P" [ -1 -1 0  1 -1 0  1 1 0  -1 1 0 ]' + uv + nrm + alpha
+        if k == "blob":
+            # an octahedron with perturbed vertices
+            P = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+            P = [tuple(c + self.u(-0.2, 0.2) for c in p) for p in P]
+            idx = "0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5"
+            return 'Shape "trianglemesh" "integer indices" [ %s ] "point3 P" [ %s ]' % (idx, " ".join(f(*p) for p in P)) + alpha
+        if k == "sphere":
+            s = 'Shape "sphere" "float radius" [ %s ]' % f(self.u(0.4, 1.2))
+            if self.r.random() < 0.4:
+                s += ' "float zmin" [ %s ] "float zmax" [ %s ] "float phimax" [ %s ]' % (f(self.u(-0.9, -0.1)), f(self.u(0.1, 0.9)), f(self.u(90, 360)))
+            return s + alpha
+        if k == "disk":
+            return 'Shape "disk" "float radius" [ %s ] "float innerradius" [ %s ] "float height" [ %s ] "float phimax" [ %s ]' % (f(self.u(0.5, 1.3)), f(self.pick([0, self.u(0.1, 0.4)])), f(self.u(-0.3, 0.3)), f(self.pick([360, self.u(90, 350)]))) + alpha
+        if k == "cylinder":
+            return 'Shape "cylinder" "float radius" [ %s ] "float zmin" [ %s ] "float zmax" [ %s ] "float phimax" [ %s ]' % (f(self.u(0.3, 0.9)), f(self.u(-1, -0.2)), f(self.u(0.2, 1)), f(self.pick([360, self.u(90, 350)]))) + alpha
+        if k == "bilinear":
+            return 'Shape "bilinearmesh" "integer indices" [ 0 1 2 3 ] "point3 P" [ -1 -1 %s  1 -1 %s  -1 1 %s  1 1 %s ]' % (f(self.u(-.4, .4)), f(self.u(-.4, .4)), f(self.u(-.4, .4)), f(self.u(-.4, .4))) + \
+                (' "point2 uv" [ 0 0 1 0 0 1 1 1 ]' if self.r.random() < 0.5 else "") + alpha
+        if k == "curve":
+            return 'Shape "curve" "string type" "%s" "point3 P" [ -1 0 0  -0.3 %s 0.5  0.4 %s -0.3  1 0 0.2 ] "float width0" [ %s ] "float width1" [ %s ]' % (
+                self.pick(["flat", "cylinder", "ribbon"]), f(self.u(-1, 1)), f(self.u(-1, 1)), f(self.u(0.05, 0.3)), f(self.u(0.02, 0.3))) + \
+                (' "normal N" [ 0 0 1  0 1 1 ]' if self.r.random() < 0.5 else "")
+        if k == "subdiv":
+            return ('Shape "loopsubdiv" "integer levels" [ %d ] "integer indices" [ 0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5 ] '
+                    '"point3 P" [ 1 0 0  -1 0 0  0 1 0  0 -1 0  0 0 1  0 0 -1 ]' % self.pick([1, 2, 3]))
+        return 'Shape "plymesh" "string filename" "%s"' % os.path.join(GOLDEN, self.pick(["bilinear_quads.ply", "displace_cone.ply", "ball.ply.gz"])) + \
+            (' "texture displacement" "%s" "float edgelength" [ 0.5 ]' % self.pick(self.float_tex) if self.float_tex and self.r.random() < 0.3 else "")
+
+    def placed(self, body):
+        return "AttributeBegin\n  Translate %s\n  Rotate %s %s\n  Scale %s\n%s\nAttributeEnd" % (
+            f(self.u(-3, 3), self.u(-2.5, 2.5), self.u(0.3, 2.5)), f(self.u(0, 360)), f(self.u(-1, 1), self.u(-1, 1), self.u(0.2, 1)),
+            f(self.u(0.4, 1.3), self.u(0.4, 1.3), self.u(0.4, 1.3)) if self.r.random() < 0.8 else f(-0.8, 0.9, 1.1), body)
+
+    def world(self):
+        out = ["WorldBegin"]
+        if "fog" in self.media:
+            # the camera's `MediumInterface "" "fog"` stays in the graphics state: shapes would inherit an interface with an empty inside,
+            # on which the reference is not deterministic (tests/golden/open_partial_medium_interface.pbrt)
+            out.append('MediumInterface "fog" "fog"')
+        out += self.lights()
+        out += self.textures()
+        if self.r.random() < 0.25:
+            if self.r.random() < 0.5:
+                out.append('MakeNamedMedium "cloud" "string type" "uniformgrid" "integer nx" 2 "integer ny" 2 "integer nz" 2 "float density" [ 0.2 1 0.5 0.8 1 0.1 0.6 0.9 ] '
+                           '"point3 p0" [ -1 -1 -1 ] "point3 p1" [ 1 1 1 ] "rgb sigma_a" [ 0.1 0.1 0.1 ] "rgb sigma_s" [ 0.8 0.8 0.8 ] "float scale" [ %s ]' % f(self.u(0.5, 4)))
+            else:
+                out.append('MakeNamedMedium "cloud" "string type" "homogeneous" "string preset" "%s" "float scale" [ %s ]' % (self.pick(["Skin1", "Wholemilk", "Ketchup"]), f(self.u(0.01, 0.2))))
+            self.media.append("cloud")
+        for i in range(self.r.randrange(2, 6)):
+            out.append(self.material("m%d" % i))
+        # ground
+        ground = [m for m in self.materials if m[1] not in ("interface", "hair")]
+        out.append('NamedMaterial "%s"' % (self.pick(ground)[0] if ground else "m0"))
+        out.append('Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point3 P" [ -7 -7 0  7 -7 0  7 7 0  -7 7 0 ] "point2 uv" [ 0 0 4 0 4 4 0 4 ]')
+        # an object instance definition
+        have_def = self.r.random() < 0.3
+        if have_def:
+            solid = [m for m in self.materials if m[1] != "interface"]
+            out.append('ObjectBegin "thing"\n  NamedMaterial "%s"\n  %s\n  Translate 0 0 1.2\n  %s\nObjectEnd' % (self.pick(solid)[0] if solid else "m0", self.shape(), self.shape()))
+        for i in range(self.r.randrange(2, 7)):
+            name, t = self.pick(self.materials)
+            body = '  NamedMaterial "%s"\n' % name
+            if t == "interface":
+                if not self.media:
+                    continue
+                body += '  MediumInterface "%s" "%s"\n' % (self.pick(self.media), "fog" if "fog" in self.media else "")
+            elif self.media and t in ("dielectric", "thindielectric") and self.r.random() < 0.3:
+                body += '  MediumInterface "%s" "%s"\n' % (self.pick(self.media), "fog" if "fog" in self.media else "")
+            if self.r.random() < 0.2 and t not in ("interface",):
+                body += '  AreaLightSource "diffuse" "rgb L" %s%s\n' % (self.rgb(1, 8), ' "bool twosided" true' if self.r.random() < 0.5 else "") + \
+                        (('  # image emission\n') if False else "")
+            if self.r.random() < 0.15:
+                body += "  ReverseOrientation\n"
+            body += "  " + self.shape()
+            out.append(self.placed(body))
+        if have_def:
+            for _ in range(self.r.randrange(1, 4)):
+                out.append(self.placed('  ObjectInstance "thing"'))
+        return out
+
+    def scene(self):
+        h = self.header()
+        # the camera medium must be declared in front of the camera
+        if "fog" in self.media:
+            i = next(k for k, l in enumerate(h) if l.startswith("Camera"))
+            mk = next(k for k, l in enumerate(h) if l.startswith("MakeNamedMedium"))
+            decl = h.pop(mk)
+            h.insert(i, 'MediumInterface "" "fog"')
+            h.insert(i, decl)
+        return "\n".join(h + self.world()) + "\n"
+
+
+def render(exe, args, path, out):
+    try:
+        p = subprocess.run([exe] + args + ["--outfile", out, path], capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return "timeout", ""
+    if p.returncode != 0 or not os.path.exists(out):
+        return "error(%d)" % p.returncode, (p.stdout + p.stderr)[-400:]
+    return "ok", ""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--keep", default="/tmp/wf_diff_findings")
+    a = ap.parse_args()
+    work = tempfile.mkdtemp(prefix="wf_diff_")
+    stats = {"identical": 0, "both_refuse": 0, "mismatch": 0, "status_differs": 0}
+    for i in range(a.n):
+        seed = a.seed * 100000 + i
+        text = Gen(seed).scene()
+        path = os.path.join(work, "s%d.pbrt" % seed)
+        open(path, "w").write(text)
+        ro, co = os.path.join(work, "ref.pfm"), os.path.join(work, "cpu.pfm")
+        for q in (ro, co):
+            if os.path.exists(q):
+                os.unlink(q)
+        rs, rmsg = render(REF, ["--wavefront", "--quiet", "--seed", "0", "--nthreads", "4"], path, ro)
+        cs, cmsg = render(CPU, ["--quiet", "--nthreads", "4"], path, co)
+        verdict = None
+        if rs == "ok" and cs == "ok":
+            r, c = read_pfm(ro), read_pfm(co)
+            if r.shape == c.shape and (r.view(np.uint32) == c.view(np.uint32)).all():
+                stats["identical"] += 1
+            else:
+                # is the reference itself deterministic here?  (it is not on medium transitions with an empty side: see
+                # tests/golden/open_partial_medium_interface.pbrt)
+                ro2 = os.path.join(work, "ref2.pfm")
+                rs2, _ = render(REF, ["--wavefront", "--quiet", "--seed", "0", "--nthreads", "2"], path, ro2)
+                if rs2 == "ok" and not (read_pfm(ro2).view(np.uint32) == r.view(np.uint32)).all():
+                    stats["reference_nondeterministic"] = stats.get("reference_nondeterministic", 0) + 1
+                    print("seed %d: the reference gives two different images in two runs (no parity target)" % seed, flush=True)
+                    os.unlink(path)
+                    continue
+                verdict = "MISMATCH"
+                if r.shape == c.shape:
+                    d = np.abs(r - c) / np.maximum(np.abs(r), 1e-2)
+                    verdict += " max rel %.3g, %.2f %% of values differ" % (d.max(), 100 * (r.view(np.uint32) != c.view(np.uint32)).mean())
+                stats["mismatch"] += 1
+        elif rs != "ok" and cs != "ok":
+            stats["both_refuse"] += 1
+            if rs.startswith("error(-") or rs == "timeout":   # the reference crashed: not a refusal; say so
+                print("seed %d: reference %s, port %s" % (seed, rs, cs), flush=True)
+        else:
+            verdict = "STATUS reference %s / port %s: %s" % (rs, cs, (rmsg or cmsg).strip().splitlines()[-1] if (rmsg or cmsg).strip() else "")
+            stats["status_differs"] += 1
+        if verdict:
+            os.makedirs(a.keep, exist_ok=True)
+            shutil.copy(path, os.path.join(a.keep, os.path.basename(path)))
+            print("seed %d: %s" % (seed, verdict), flush=True)
+        os.unlink(path)
+    shutil.rmtree(work, ignore_errors=True)
+    print(stats)
+    sys.exit(1 if stats["mismatch"] or stats["status_differs"] else 0)
+
+
+if __name__ == "__main__":
+    main()
