@@ -5,6 +5,7 @@
 // reference's own GPU path supports too); creating a shape, light or medium where the two differ (AnimatedPrimitive) is refused.
 #include "scene.h"
 #include "hanimated.h"
+#include <algorithm>
 
 #include <cctype>
 #include <cstdarg>
@@ -299,8 +300,12 @@ struct Interpreter {
     ParamSet MakeParams(std::vector<Param> params, const std::vector<Param> &attrs) {
         ParamSet ps;
         ps.colorSpace = gs.colorSpace;
+        // ParameterDictionary's constructors (paramdict.cpp:141-160) REVERSE both lists: of two parameters with one name the one written
+        // last is the one the look-ups find (differential fuzzing, round 3: "bool remaproughness" given twice); the attributes keep their
+        // lower precedence (looked up after the explicit ones)
         ps.params = std::move(params);
-        for (const Param &a : attrs) ps.params.push_back(a);  // lower precedence: looked up after explicit ones
+        std::reverse(ps.params.begin(), ps.params.end());
+        ps.params.insert(ps.params.end(), attrs.rbegin(), attrs.rend());
         return ps;
     }
     // a static render uses the start-time transformation; something created under two different CTMs is animated (AnimatedTransform /
