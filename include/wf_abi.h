@@ -732,7 +732,9 @@ int wf_morton_sort(int n, const float *centroids, const float bounds[6], uint32_
    room for 2 n - 1 records.  Needs no context; -1 when no device is visible, another negative value when the build gave up (degenerate
    input: the caller falls back to the host builder, csrc/host/bvh_build.cpp). */
 int wf_build_bvh_sah(int n, const float *bounds, int max_prims_in_node, wf_bvh_node *nodes_out, int32_t *order_out, int32_t *n_nodes_out);
-/* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample */
+/* Sampler probe for parity tests: fills out[n][dims] with the sampler's values for pixel/sample (Get1D() from start_dim).
+   ndims = -2: GetPixel2D() (2 floats per record); -3: ten times (Get2D, Get1D), the sequence of the reference's Sampler.ConsistentValues
+   test (30 floats); -4: the ZSobol sample index at start_dim (ZSobolSampler.ValidIndices): its low / high 32 bits as two float bit patterns */
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index,
                      int start_dim, int ndims, float *out);
 /* Elementary-function probe for parity tests: out[i] = f(in[i]) evaluated on the device with the kernels' own
@@ -740,6 +742,11 @@ int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, c
    fn: 0 sin, 1 cos, 2 exp, 3 log, 4 atan, 5 asin, 6 acos, 7 cosh, 8 atanh, 9 atan2 (in = n (y, x) pairs).
    Needs a context only (no scene). */
 int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out);
+/* Known-answer probe for parity tests (csrc/common/wf_kat.h): n records of 16 uint64 in, n records of 8 uint64 out — the restated PCG32
+   (util/rng.h: SetSequence / Advance / Uniform / operator-), MurmurHash64A / Hash / HashFloat / MixBits (util/hash.h) and IntersectTriangle
+   (shapes.cpp:168-269) evaluated on the device; the reference's answers are tests/golden/kat_out.bin (oracle/ref_build/ref_kat.cpp).
+   Needs a context only (no scene). */
+int wf_kat_probe(wf_ctx *ctx, int n, const uint64_t *in, uint64_t *out);
 /* debug/parity access to queues: downloads the named SoA member */
 int wf_queue_size(wf_ctx *ctx, const char *queue, int *size);
 int wf_queue_download(wf_ctx *ctx, const char *queue, const char *member, void *dst, uint64_t nbytes);

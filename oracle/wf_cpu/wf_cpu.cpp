@@ -277,6 +277,7 @@ int main(int argc, char **argv) {
 static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
+    bool tracePath = false;   // print the path state after every stage (the lines oracle/_ref/ref_trace prints; tools/trace_diff.py)
     std::string lightProbeIn, lightProbeOut, reProbeIn, reProbeOut;
     bool simulateWaves = false;
     int sampleBegin = 0, sampleEnd = -1, sampleStep = 1, probeStartDim = 0, probeNDims = 0;
@@ -305,6 +306,7 @@ static int Main(int argc, char **argv) {
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
         else if (a == "--dump-stages") dumpStages = next();
+        else if (a == "--trace-path") tracePath = true;
         else if (a == "--simulate-waves") simulateWaves = true;
         else if (a == "--strips") { stripRank = atoi(next().c_str()); stripCount = atoi(next().c_str()); stripHeight = atoi(next().c_str()); }
         else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
@@ -330,6 +332,8 @@ static int Main(int argc, char **argv) {
     FillSobol2D(sobol);
     SceneView sv = MakeHostView(T.desc, sobol);
     sv.self = &sv;
+    static int32_t fatalWord = 0;
+    sv.fatal = &fatalWord;   // RaiseFatal (wf_scene.h): checked at the end of the render
 
     // sampler probe: in = n x {px, py, sampleIndex} int32 -> out = n x ndims floats (Get1D from startDim)
     if (!probeIn.empty()) {
@@ -343,12 +347,17 @@ static int Main(int argc, char **argv) {
         if (fread(in.data(), 4, in.size(), f) != in.size()) return 1;
         fclose(f);
         // ndims = -2: the sample's GetPixel2D() instead (samplers_test.cpp's elementary-interval tests read it)
-        const bool pixel2D = probeNDims == -2;
-        if (pixel2D) probeNDims = 2;
+        // ndims = -3: ten times (Get2D, Get1D), the sequence Sampler.ConsistentValues draws (samplers_test.cpp:46-52): 30 floats;
+        // ndims = -4: the ZSobol sample index at the start dimension (ZSobolSampler.ValidIndices, :168-196): low / high 32 bits in two float slots
+        const bool pixel2D = probeNDims == -2, pattern = probeNDims == -3, zindex = probeNDims == -4;
+        if (pixel2D || zindex) probeNDims = 2;
+        if (pattern) probeNDims = 30;
         std::vector<float> out((size_t)n * probeNDims);
         for (int i = 0; i < n; ++i) {
             PixelSampler s(sv);
             s.StartPixelSample(in[3 * i], in[3 * i + 1], in[3 * i + 2], probeStartDim);
+            SamplerProbeRecord(s, pixel2D ? -2 : pattern ? -3 : zindex ? -4 : probeNDims, &out[(size_t)i * probeNDims]);
+            continue;
             if (pixel2D) {
                 V2 p = s.GetPixel2D();
                 out[(size_t)i * 2] = p.x; out[(size_t)i * 2 + 1] = p.y;
@@ -536,6 +545,42 @@ static int Main(int argc, char **argv) {
     unsigned long long nodesVisited = 0, trisTested = 0, sssProbes = 0, sssExits = 0;
     std::atomic<unsigned long long> shadowNodes{0}, shadowTris{0};
 
+
+    // --trace-path: the lines of oracle/ref_build/ref_trace.cpp
+    auto s4 = [](F4 v) { char b[160]; snprintf(b, sizeof(b), "%a %a %a %a", v.x, v.y, v.z, v.w); return std::string(b); };
+    auto traceLines = [](const char *tag, int depth, std::vector<std::pair<int, std::string>> &v) {
+        std::sort(v.begin(), v.end());
+        for (auto &p : v) printf("d%d %s pix %d %s\n", depth, tag, p.first, p.second.c_str());
+    };
+    auto traceL = [&](const char *tag, int depth) {
+        if (!tracePath) return;
+        for (int i = 0; i < n; ++i) printf("d%d L.%s pix %d %s\n", depth, tag, i, s4(ws.L[i]).c_str());
+    };
+    auto tpRays = [&](const char *tag, int depth, int q) {
+        if (!tracePath) return;
+        std::vector<std::pair<int, std::string>> v;
+        for (int i = 0; i < ws.counters[(CNT_RAY0 + q) * CNT_STRIDE]; ++i) {
+            const RayQueueV &r = ws.rq[q];
+            char b[1024];
+            snprintf(b, sizeof(b), "o %a %a %a d %a %a %a depth %d beta %s r_u %s r_l %s etaScale %a spec %d anyns %d medium %d", r.o[i].x, r.o[i].y, r.o[i].z, r.d[i].x, r.d[i].y,
+                     r.d[i].z, r.meta[i].y, s4(r.beta[i]).c_str(), s4(r.r_u[i]).c_str(), s4(r.r_l[i]).c_str(), r.d[i].w, (r.meta[i].z & RAYFLAG_SPECULAR_BOUNCE) ? 1 : 0,
+                     (r.meta[i].z & RAYFLAG_ANY_NONSPECULAR) ? 1 : 0, r.meta[i].w >= 0 ? 1 : 0);
+            v.emplace_back(r.meta[i].x, b);
+        }
+        traceLines(tag, depth, v);
+    };
+    auto traceShadow = [&](const char *tag, int depth) {
+        if (!tracePath) return;
+        std::vector<std::pair<int, std::string>> v;
+        for (int i = 0; i < ws.counters[(CNT_SHADOW) * CNT_STRIDE]; ++i) {
+            const ShadowQueueV &r = ws.sq;
+            char b[1024];
+            snprintf(b, sizeof(b), "o %a %a %a d %a %a %a tMax %a Ld %s r_u %s r_l %s", r.o[i].x, r.o[i].y, r.o[i].z, r.d[i].x, r.d[i].y, r.d[i].z, r.o[i].w, s4(r.Ld[i]).c_str(),
+                     s4(r.r_u[i]).c_str(), s4(r.r_l[i]).c_str());
+            v.emplace_back((int)FloatToBits(r.d[i].w), b);
+        }
+        traceLines(tag, depth, v);
+    };
     auto t0 = std::chrono::steady_clock::now();
     const int maxDepth = T.desc.max_depth;
     if (sampleEnd < 0) sampleEnd = T.spp;
@@ -544,6 +589,7 @@ static int Main(int argc, char **argv) {
             ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, 1);
             ParallelFor(n, [&](int i) { KGenerateCameraRay(sv, ws, i, y0, sampleIndex, sampleStep, 1); });
             ws.stats[0] += ws.counters[(CNT_RAY0) * CNT_STRIDE];
+            tpRays("camera", 0, 0);
             const bool dumpNow = !dumpStages.empty() && sampleIndex == sampleBegin && y0 == F.pixel_min[1];
             if (dumpNow) {
                 {
@@ -748,14 +794,19 @@ static int Main(int argc, char **argv) {
                     }
                     fclose(f);
                 }
+                if (tracePath)
+                    printf("d%d after-closest rays %d escaped %d hitlight %d medium %d next_pre %d\n", depth, nRays, ws.counters[(CNT_ESCAPED) * CNT_STRIDE],
+                           ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE], ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
                 if (sv.haveMedia) {
                     // SampleMediumInteraction, integrator.cpp:416 (K5, then K6 unless this is the last depth)
                     ParallelFor(ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE], [&](int i) { KSampleMediumInteraction(sv, ws, cur, i); });
                     if (depth != maxDepth)
                         ParallelFor(ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE], [&](int i) { KSampleMediumScattering(sv, ws, cur, i); });
                 }
+                if (sv.haveMedia) traceL("medium", depth);
                 ParallelFor(ws.counters[(CNT_ESCAPED) * CNT_STRIDE], [&](int i) { KHandleEscaped(sv, ws, cur, i); });
                 ParallelFor(ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
+                traceL("emitted", depth);
                 if (depth == maxDepth) break;
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_CONDUCTOR>(sv, ws, cur, i, true); });
@@ -791,8 +842,12 @@ static int Main(int argc, char **argv) {
                     ws.stats[65 + depth] += nShadow;
                     ws.counters[(CNT_SHADOW) * CNT_STRIDE] = 0;
                 };
+                tpRays("next", depth, cur ^ 1);
+                traceShadow("shadow", depth);
                 traceShadowRays();
+                traceL("shadowed", depth);
                 if (sv.haveSubsurface) {
+                    if (tracePath) printf("d%d bssrdf-items %d\n", depth, ws.counters[(CNT_BSSRDF) * CNT_STRIDE]);
                     // SampleSubsurface, integrator.cpp:431 -> wavefront/subsurface.cpp:18-203
                     ParallelFor(ws.counters[(CNT_BSSRDF) * CNT_STRIDE], [&](int i) { KSubsurfaceProbe(sv, ws, i); });
                     ParallelFor(ws.counters[(CNT_SSS) * CNT_STRIDE], [&](int i) { ArrayStack st; KIntersectOneRandom(sv, ws, i, st); });
@@ -800,12 +855,21 @@ static int Main(int argc, char **argv) {
                     sssProbes += ws.counters[(CNT_SSS) * CNT_STRIDE];
                     for (int i = 0; i < ws.counters[(CNT_SSS) * CNT_STRIDE]; ++i) sssExits += ws.sssQ[i].reservoirPDF != 0;
                     traceShadowRays();
+                    if (tracePath) printf("d%d sss-items %d\n", depth, ws.counters[(CNT_SSS) * CNT_STRIDE]);
+                    tpRays("next+sss", depth, cur ^ 1);
+                    traceL("sss", depth);
                 }
+                if (tracePath && ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE] == 0) break;
             }
             ParallelFor(n, [&](int i) { KUpdateFilm(sv, ws, i, 1); });
         }
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (fatalWord) {
+        // the reference's LOG_FATAL inside a kernel body (shapes.cpp:736-760: a sample drawn from an emissive curve) aborts the process
+        fprintf(stderr, "Fatal: %s not implemented.\n", fatalWord == WF_FATAL_CURVE_SAMPLE ? "Curve::Sample" : fatalWord == WF_FATAL_CURVE_PDF ? "Curve::PDF" : "?");
+        return 1;
+    }
 
     unsigned long long rays = ws.stats[0];
     for (int d = 0; d < 64; ++d) rays += ws.stats[1 + d] * (d > 0) + ws.stats[65 + d];

@@ -807,4 +807,19 @@ WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSamp
     return {o, d, time, true};
 }
 
+// One record of the sampler probes (wf_sampler_probe, wf_cpu --sampler-probe) from a sampler positioned by StartPixelSample:
+// mode > 0: that many Get1D(); -2: GetPixel2D(); -3: ten times (Get2D, Get1D) — the sequence Sampler.ConsistentValues draws
+// (samplers_test.cpp:46-52), 30 floats; -4: the ZSobol sample index (ZSobolSampler.ValidIndices, :168-196), low / high word as the bit
+// patterns of two floats.
+WF_HD void SamplerProbeRecord(PixelSampler &s, int mode, float *out) {
+    if (mode == -2) { V2 p = s.GetPixel2D(); out[0] = p.x; out[1] = p.y; }
+    else if (mode == -3) {
+        for (int k = 0; k < 10; ++k) { V2 p = s.Get2D(); out[3 * k] = p.x; out[3 * k + 1] = p.y; out[3 * k + 2] = s.Get1D(); }
+    } else if (mode == -4) {
+        const uint64_t idx = s.z.GetSampleIndex();
+        out[0] = BitsToFloat((uint32_t)idx); out[1] = BitsToFloat((uint32_t)(idx >> 32));
+    } else
+        for (int d = 0; d < mode; ++d) out[d] = s.Get1D();
+}
+
 }  // namespace wf

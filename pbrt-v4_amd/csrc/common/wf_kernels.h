@@ -872,7 +872,12 @@ WF_HD void KHandleEmissive(const SceneView &sv, const WorkState &ws, int cur, in
     F4 h = ws.hit[i];
     int prim = (int)FloatToBits(h.x);
     SurfIntr si;
-    HitInteraction(sv, prim, -1, h.y, h.z, h.w, &si, V3{0, 0, 0}, V3{0, 0, 0});  // emitters are top-level primitives (no area lights inside object instances), never curves
+    {
+        // emitters are top-level primitives (no area lights inside object instances); an emissive curve's interaction needs the ray
+        V3 ro{0, 0, 0}, rd{0, 0, 0};
+        if (sv.haveCurves) { F4 o4 = q.o[i], dd = q.d[i]; ro = V3{o4.x, o4.y, o4.z}; rd = V3{dd.x, dd.y, dd.z}; }
+        HitInteraction(sv, prim, -1, h.y, h.z, h.w, &si, ro, rd);
+    }
     const wf_mesh &mesh = sv.meshes[si.mesh];
     int lightId = mesh.first_light + (prim - mesh.first_tri);
     const wf_light &light = sv.lights[lightId];
@@ -1149,7 +1154,11 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             ns = FaceForward(ns, si.n);
         } else if (mat.displacement >= 0) {
             // BumpMap (materials.h:109-138) and the shading frame rebuilt from it (surfscatter.cpp:120-130)
-            TexCtx sh = tc;
+            // MaterialEvalWorkItem::GetNormalBumpEvalContext (wavefront/workitems.h:268-285) leaves ctx.n at its zero default: the
+            // three displacement lookups see n = 0 (a directionmix displacement weighs with |n . dir| = 0).  Reproduced as is.
+            TexCtx bc = tc;
+            bc.n = N3{0, 0, 0};
+            TexCtx sh = bc;
             float du = .5f * (abs(tc.dudx) + abs(tc.dudy));
             if (du == 0) du = .0005f;
             sh.p = tc.p + du * si.dpdus;
@@ -1160,7 +1169,7 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
             sh.p = tc.p + dv * si.dpdvs;
             sh.uv = V2{tc.uv.x + 0.f, tc.uv.y + dv};
             float vDisplace = EvalFloatTexture(sv, mat.displacement, sh);
-            float displace = EvalFloatTexture(sv, mat.displacement, tc);
+            float displace = EvalFloatTexture(sv, mat.displacement, bc);
             dpdus = si.dpdus + (uDisplace - displace) / du * toV(si.ns) + displace * toV(si.dndus);
             V3 dpdvs = si.dpdvs + (vDisplace - displace) / dv * toV(si.ns) + displace * toV(si.dndvs);
             ns = toN(Normalize(Cross(dpdus, dpdvs)));

@@ -617,6 +617,21 @@ struct RNG {
         return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
     }
     WF_HD float UniformFloat() { return fmin(OneMinusEpsilon, Uniform32() * 0x1p-32f); }
+    // RNG::operator- (util/rng.h:152-170): how many draws this generator is ahead of `other` (same sequence)
+    WF_HD int64_t operator-(const RNG &other) const {
+        uint64_t curMult = 0x5851f42d4c957f2dULL, curPlus = inc, curState = other.state;
+        uint64_t theBit = 1u, distance = 0u;
+        while (state != curState) {
+            if ((state & theBit) != (curState & theBit)) {
+                curState = curState * curMult + curPlus;
+                distance |= theBit;
+            }
+            theBit <<= 1;
+            curPlus = (curMult + 1ULL) * curPlus;
+            curMult *= curMult;
+        }
+        return (int64_t)distance;
+    }
 };
 
 // bit tricks (util/math.h:55-153)

@@ -74,7 +74,13 @@ struct SceneView {
     // this struct in memory the kernels can read (device memory on the GPU, the object itself on the host): what the few
     // out-of-line device functions take instead of the by-value kernel argument (whose address must never be taken)
     const SceneView *self;
+    // LOG_FATAL of the reference inside a kernel body (so far: Curve::Sample / Curve::PDF "not implemented", shapes.cpp:736-760, reached
+    // when a sample is drawn from an emissive curve): the body stores a WF_FATAL_* code here and carries on with a null result; wf_sync
+    // (the CPU checker: the end of its render) turns the code into the reference's fatal error.  Null: nothing to report to.
+    int32_t *fatal;
 };
+enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2 };
+WF_HD void RaiseFatal(const SceneView &sv, int code) { if (sv.fatal) *sv.fatal = code; }
 
 // SobolMatrices32 dimensions 0 and 1 (util/sobolmatrices.cpp:40-58).  Dimension 0 is the van der Corput
 // identity matrix, dimension 1 the Pascal-triangle matrix v[i] = v[i-1] ^ (v[i-1] >> 1); both are padded
@@ -173,7 +179,7 @@ WF_HD bool SpectrumIsConstant(const SceneView &sv, int id) { return sv.spectra[i
 
 // ---------------------------------------------------------------------------------------------
 // Texture evaluation over the flattened texture nodes (textures.h:1092-1155): constant, scale, mix, 2D checkerboard.
-// The nesting depth is bounded by WF_TEX_MAX_DEPTH (enforced by the host builder).  Image textures arrive with the
+// The nesting depth is bounded by WF_TEX_STACK frames of the explicit-stack evaluator (enforced by the host builder).  Image textures arrive with the
 // image-texture row of SURVEY.md §8(f).
 // TextureEvalContext (textures.h:33-61)
 struct TexCtx {
@@ -641,14 +647,16 @@ WF_HD bool InsidePolkaDot(const SceneView &sv, const wf_texture &t, const TexCtx
     return InsidePolkaDotP(sv.noisePerm, st.st.x, st.st.y);
 }
 
-// FloatTexture::Evaluate / SpectrumTexture::Evaluate over the flattened texture graph.  The reference recurses through
-// tagged pointers; the device code has no recursion: the walk is a template over the remaining depth, fully inlined.
-// With three interior node types the inlined code grows ~7x per level, so the bound is two interior levels above the
-// constants (e.g. mix(checkerboard(c, c), scale(c, c))); the host builder rejects deeper graphs.  (An explicit stack
-// machine was tried: it compiles in seconds for any depth but its indexed stack arrays live in scratch and the
-// material kernels then spill ~470 VGPRs: 22 -> 71 ms for the diffuse kernel.)
-#ifndef WF_TEX_MAX_DEPTH
-#define WF_TEX_MAX_DEPTH 2
+// FloatTexture::Evaluate / SpectrumTexture::Evaluate over the flattened texture graph (textures.h:1140-1155: the universal
+// evaluator dispatches to the texture, which evaluates its children the same way — any nesting).  The reference recurses through
+// tagged pointers; the device code has no recursion.  Until round 3 the walk was a template over the remaining depth, fully
+// inlined (three interior node types: the code grew ~7x per level and the bound was two interior levels; deeper graphs were
+// refused).  Since round 4 it is an EXPLICIT-STACK evaluator inside the out-of-line graph functions below: a frame per interior
+// node (node id, resume state, the weight and the first operand), WF_TEX_STACK frames, the same operations in the same order.
+// (As part of the inlined material code an explicit stack had cost 470 spilled VGPRs; behind the call its arrays are the callee's
+// scratch and the kernels' register budgets do not see them.)  The host builder refuses graphs nested deeper than WF_TEX_STACK.
+#ifndef WF_TEX_STACK
+#define WF_TEX_STACK 24
 #endif
 // the three texture types a production scene's parameters usually are: what the material kernels and the traversal kernels' alpha test
 // evaluate inline
@@ -662,41 +670,85 @@ WF_HD float EvalFloatTextureSimple(const SceneView &sv, const wf_texture &t, con
     return (1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11;
 }
 WF_HD bool IsSimpleFloatTexture(int type) { return type == WF_TEX_FLOAT_CONSTANT || type == WF_TEX_FLOAT_IMAGE || type == WF_TEX_FLOAT_BILERP; }
-template <int D>
-WF_HD float EvalFloatTextureD(const SceneView &sv, int id, const TexCtx &tc) {
-    const wf_texture t = sv.textures[id];
+// leaves of a float graph: constant / image / bilerp and the noise textures
+WF_HD bool IsLeafFloatTexture(int type) {
+    return IsSimpleFloatTexture(type) || type == WF_TEX_FLOAT_FBM || type == WF_TEX_FLOAT_WRINKLED || type == WF_TEX_FLOAT_WINDY;
+}
+WF_HD float EvalFloatTextureLeaf(const SceneView &sv, const wf_texture &t, const TexCtx &tc) {
     if (IsSimpleFloatTexture(t.type)) return EvalFloatTextureSimple(sv, t, tc);
-    if (t.type == WF_TEX_FLOAT_FBM || t.type == WF_TEX_FLOAT_WRINKLED || t.type == WF_TEX_FLOAT_WINDY) {
-        TexCtx cc = tc;
-        wf_texture tt = t;
-        return NoiseFloatTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc);
-    }
-    if constexpr (D > 0) {
-        if (t.type == WF_TEX_FLOAT_DOTS) return EvalFloatTextureD<D - 1>(sv, InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0, tc);
+    TexCtx cc = tc;
+    wf_texture tt = t;
+    return NoiseFloatTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc);
+}
+// The explicit-stack walk of a float graph.  Frame states: 0 = entered; SCALE: 1 = the scale factor returned, 2 = the texture
+// returned; MIX / CHECKERBOARD / DIRECTIONMIX: 1 = the amount returned (MIX only), 2 = tex0 ("tex1" of the reference's mix,
+// weighted 1 - amt) returned, 3 = tex1 returned.  DOTS replaces its own frame by the chosen child (a tail call).
+WF_HD float EvalFloatTextureStack(const SceneView &sv, int id, const TexCtx &tc) {
+    int fid[WF_TEX_STACK];
+    int fstate[WF_TEX_STACK];
+    float fw[WF_TEX_STACK], fa[WF_TEX_STACK];
+    int sp = 0;
+    fid[0] = id; fstate[0] = 0;
+    float ret = 0;
+    while (sp >= 0) {
+        const wf_texture t = sv.textures[fid[sp]];
+        int st = fstate[sp];
+        if (st == 0) {
+            if (IsLeafFloatTexture(t.type)) { ret = EvalFloatTextureLeaf(sv, t, tc); --sp; continue; }
+            if (t.type == WF_TEX_FLOAT_DOTS) { fid[sp] = InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0; continue; }
+            if (sp + 1 >= WF_TEX_STACK) { ret = 0; --sp; continue; }   // (refused at load: never reached)
+            if (t.type == WF_TEX_FLOAT_SCALE) {
+                // FloatScaledTexture::Evaluate, textures.h:1039-1044: the scale first
+                fstate[sp] = 1; ++sp; fid[sp] = t.tex1; fstate[sp] = 0;
+                continue;
+            }
+            if (t.type == WF_TEX_FLOAT_MIX) {
+                // FloatMixTexture::Evaluate (textures.h:810-818): the amount first
+                fstate[sp] = 1; ++sp; fid[sp] = t.tex2; fstate[sp] = 0;
+                continue;
+            }
+            if (t.type == WF_TEX_FLOAT_CHECKERBOARD || t.type == WF_TEX_FLOAT_DIRECTIONMIX) {
+                // FloatCheckerboardTexture::Evaluate (:370-378), FloatDirectionMixTexture::Evaluate (:839-847: amt * tex1 + (1 - amt) * tex2
+                // = the mix form with tex0 = "tex2")
+                ret = t.type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
+                st = 1;
+            } else { ret = 0; --sp; continue; }
+        }
         if (t.type == WF_TEX_FLOAT_SCALE) {
-            // FloatScaledTexture::Evaluate, textures.h:1039-1044
-            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
-            if (sc == 0) return 0;
-            return EvalFloatTextureD<D - 1>(sv, t.tex0, tc) * sc;
+            if (st == 1) {
+                if (ret == 0) { --sp; continue; }   // returns 0
+                fw[sp] = ret; fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0;
+                continue;
+            }
+            ret = ret * fw[sp];
+            --sp;
+            continue;
         }
-        if (t.type == WF_TEX_FLOAT_MIX || t.type == WF_TEX_FLOAT_CHECKERBOARD || t.type == WF_TEX_FLOAT_DIRECTIONMIX) {
-            // FloatMixTexture::Evaluate (textures.h:810-818), FloatCheckerboardTexture::Evaluate (:370-378),
-            // FloatDirectionMixTexture::Evaluate (:839-847: amt * tex1 + (1 - amt) * tex2 = this form with tex0 = "tex2")
-            float w = t.type == WF_TEX_FLOAT_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc)
-                      : t.type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
-            float t0 = 0, t1 = 0;
-            if (w != 1) t0 = EvalFloatTextureD<D - 1>(sv, t.tex0, tc);
-            if (w != 0) t1 = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
-            return (1 - w) * t0 + w * t1;
+        // mix family
+        if (st == 1) {
+            fw[sp] = ret;
+            fa[sp] = 0;
+            if (ret != 1) { fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0; continue; }
+            st = 2; ret = 0;
         }
+        if (st == 2) {
+            fa[sp] = ret;
+            if (fw[sp] != 0) { fstate[sp] = 3; ++sp; fid[sp] = t.tex1; fstate[sp] = 0; continue; }
+            ret = 0;
+        }
+        {
+            const float w = fw[sp];
+            ret = (1 - w) * fa[sp] + w * ret;
+        }
+        --sp;
     }
-    return 0.f;
+    return ret;
 }
 // Texture GRAPHS (scale / mix / checkerboard / directionmix over other textures) are evaluated out of line, through the
 // memory-resident SceneView: inlined at every material parameter, the depth-bounded recursion was 80 % of the material
 // kernels' code (683 KB -> 137 KB for the diffuse kernel, minutes -> seconds of compile time) for a path that scenes whose
 // parameters are constants or image maps never take.  A root that is a constant, an image map or a bilerp stays inline.
-WF_NI float EvalFloatTextureGraphP(const SceneView *svp, int id, const TexCtx *tc) { return EvalFloatTextureD<WF_TEX_MAX_DEPTH>(*svp, id, *tc); }
+WF_NI float EvalFloatTextureGraphP(const SceneView *svp, int id, const TexCtx *tc) { return EvalFloatTextureStack(*svp, id, *tc); }
 WF_HD float EvalFloatTexture(const SceneView &sv, int id, const TexCtx &tc) {
     const int type = sv.textures[id].type;
     if (IsSimpleFloatTexture(type)) return EvalFloatTextureSimple(sv, sv.textures[id], tc);
@@ -713,40 +765,71 @@ WF_HD S4 EvalSpectrumTextureSimple(const SceneView &sv, const wf_texture &t, con
     return ((1 - c.st.x) * (1 - c.st.y) * v00 + c.st.x * (1 - c.st.y) * v10 + (1 - c.st.x) * c.st.y * v01 + c.st.x * c.st.y * v11);
 }
 WF_HD bool IsSimpleSpectrumTexture(int type) { return type == WF_TEX_SPECTRUM_CONSTANT || type == WF_TEX_SPECTRUM_IMAGE || type == WF_TEX_SPECTRUM_BILERP; }
-template <int D>
-WF_HD S4 EvalSpectrumTextureD(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
-    const wf_texture t = sv.textures[id];
+WF_HD bool IsLeafSpectrumTexture(int type) { return IsSimpleSpectrumTexture(type) || type == WF_TEX_SPECTRUM_MARBLE; }
+WF_HD S4 EvalSpectrumTextureLeaf(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &tc) {
     if (IsSimpleSpectrumTexture(t.type)) return EvalSpectrumTextureSimple(sv, t, lambda, tc);
-    if (t.type == WF_TEX_SPECTRUM_MARBLE) {
-        TexCtx cc = tc;
-        wf_texture tt = t;
-        S4 r;
-        MarbleTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc, sv.rgb2specCoeffs, sv.rgb2specZNodes, lambda.lambda, r.v);
-        return r;
-    }
-    if constexpr (D > 0) {
-        if (t.type == WF_TEX_SPECTRUM_DOTS) return EvalSpectrumTextureD<D - 1>(sv, InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0, lambda, tc);
+    TexCtx cc = tc;
+    wf_texture tt = t;
+    S4 r;
+    MarbleTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc, sv.rgb2specCoeffs, sv.rgb2specZNodes, lambda.lambda, r.v);
+    return r;
+}
+// The explicit-stack walk of a spectrum graph; float operands (a scale factor, a mix amount) are float graphs of their own
+// (EvalFloatTexture).  Frame states as in EvalFloatTextureStack.
+WF_HD S4 EvalSpectrumTextureStack(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
+    int fid[WF_TEX_STACK];
+    int fstate[WF_TEX_STACK];
+    float fw[WF_TEX_STACK];
+    S4 fa[WF_TEX_STACK];
+    int sp = 0;
+    fid[0] = id; fstate[0] = 0;
+    S4 ret = S4c(0.f);
+    while (sp >= 0) {
+        const wf_texture t = sv.textures[fid[sp]];
+        const int st = fstate[sp];
+        if (st == 0) {
+            if (IsLeafSpectrumTexture(t.type)) { ret = EvalSpectrumTextureLeaf(sv, t, lambda, tc); --sp; continue; }
+            if (t.type == WF_TEX_SPECTRUM_DOTS) { fid[sp] = InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0; continue; }
+            if (sp + 1 >= WF_TEX_STACK) { ret = S4c(0.f); --sp; continue; }   // (refused at load: never reached)
+            if (t.type == WF_TEX_SPECTRUM_SCALE) {
+                // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
+                const float sc = EvalFloatTextureStack(sv, t.tex1, tc);
+                if (sc == 0) { ret = S4c(0.f); --sp; continue; }
+                fw[sp] = sc; fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0;
+                continue;
+            }
+            if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD || t.type == WF_TEX_SPECTRUM_DIRECTIONMIX) {
+                // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413),
+                // SpectrumDirectionMixTexture::Evaluate (:880-890)
+                const float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureStack(sv, t.tex2, tc)
+                                : t.type == WF_TEX_SPECTRUM_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
+                fw[sp] = w;
+                fa[sp] = S4c(0.f);
+                if (w != 1) { fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0; continue; }
+                ret = S4c(0.f);
+                // falls to the "tex0 returned" step below with t0 = 0
+            } else { ret = S4c(0.f); --sp; continue; }
+        }
         if (t.type == WF_TEX_SPECTRUM_SCALE) {
-            // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
-            float sc = EvalFloatTextureD<D - 1>(sv, t.tex1, tc);
-            if (sc == 0) return S4c(0.f);
-            return EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc) * sc;
+            ret = ret * fw[sp];
+            --sp;
+            continue;
         }
-        if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD || t.type == WF_TEX_SPECTRUM_DIRECTIONMIX) {
-            // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413),
-            // SpectrumDirectionMixTexture::Evaluate (:880-890)
-            float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureD<D - 1>(sv, t.tex2, tc)
-                      : t.type == WF_TEX_SPECTRUM_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
-            S4 t0 = S4c(0.f), t1 = S4c(0.f);
-            if (w != 1) t0 = EvalSpectrumTextureD<D - 1>(sv, t.tex0, lambda, tc);
-            if (w != 0) t1 = EvalSpectrumTextureD<D - 1>(sv, t.tex1, lambda, tc);
-            return (1 - w) * t0 + w * t1;
+        if (st != 3) {
+            fa[sp] = ret;
+            if (fw[sp] != 0) { fstate[sp] = 3; ++sp; fid[sp] = t.tex1; fstate[sp] = 0; continue; }
+            ret = S4c(0.f);
         }
+        {
+            const float w = fw[sp];
+            ret = (1 - w) * fa[sp] + w * ret;
+        }
+        --sp;
     }
-    return S4c(0.f);
+    return ret;
 }
 WF_NI void EvalSpectrumTextureGraphP(const SceneView *svp, int id, const Wavelengths *lambda, const TexCtx *tc, S4 *out) {
-    *out = EvalSpectrumTextureD<WF_TEX_MAX_DEPTH>(*svp, id, *lambda, *tc);
+    *out = EvalSpectrumTextureStack(*svp, id, *lambda, *tc);
 }
 WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const int type = sv.textures[id].type;

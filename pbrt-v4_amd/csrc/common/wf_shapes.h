@@ -697,6 +697,21 @@ WF_HD float QuadricArea(const wf_quadric &s) {
 // :79-84).  A triangle cannot be hit again by the ray respawned behind it, so a failed test simply drops the hit.
 // The texture sees TextureEvalContext(SurfaceInteraction) with all differentials zero (interaction.h: set only by
 // ComputeDifferentials, which this path never calls).
+// The interaction's geometric normal as Triangle::InteractionFromIntersection leaves it (shapes.h:936-938: Normalize(Cross(dp02, dp12)),
+// flipped by reverseOrientation ^ transformSwapsHandedness; shapes.h:1005 through SetShadingGeometry: face-forwarded to the interpolated
+// normal when the mesh has normals) — what TextureEvalContext(SurfaceInteraction) hands an alpha texture as ctx.n (textures.h:36-46).
+// Only a directionmix node reads it, so only texture GRAPHS pay for it.
+WF_HD N3 TriangleAlphaCtxNormal(const SceneView &sv, const wf_mesh &mesh, const int32_t *v, float b0, float b1, float b2) {
+    const V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
+    N3 n = toN(Normalize(Cross(p0 - p2, p1 - p2)));
+    if (mesh.flags & WF_MESH_FLIP_NORMAL) n = -n;
+    if (mesh.flags & WF_MESH_HAS_N) {
+        N3 ns = b0 * LoadN(sv, v[0]) + b1 * LoadN(sv, v[1]) + b2 * LoadN(sv, v[2]);
+        ns = LengthSquared(ns) > 0 ? Normalize(ns) : n;
+        n = FaceForward(n, ns);
+    }
+    return n;
+}
 WF_HD bool AlphaTestPasses(const SceneView &sv, int tri, float b0, float b1, float b2, V3 o, V3 d) {
     const wf_mesh &mesh = sv.meshes[sv.triMesh[tri]];
     if (mesh.alpha_tex < 0) return true;
@@ -706,6 +721,7 @@ WF_HD bool AlphaTestPasses(const SceneView &sv, int tri, float b0, float b1, flo
     TexCtx tc;
     tc.uv = V2{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
     tc.p = b0 * LoadP(sv, v[0]) + b1 * LoadP(sv, v[1]) + b2 * LoadP(sv, v[2]);  // intr.p() for the non-uv mappings (shapes.h:900)
+    if (!IsSimpleFloatTexture(sv.textures[mesh.alpha_tex].type)) tc.n = TriangleAlphaCtxNormal(sv, mesh, v, b0, b1, b2);
     float a = EvalFloatTexture(sv, mesh.alpha_tex, tc);
     if (!(a < 1)) return true;
     float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(o, d));
@@ -1981,6 +1997,12 @@ WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi,
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
     ShapeSampleR r;
+    if (s->type == WF_QUADRIC_CURVE) {
+        // Curve::Sample(const ShapeSampleContext &, Point2f): LOG_FATAL("Curve::Sample not implemented.") (shapes.cpp:748-752)
+        RaiseFatal(sv, WF_FATAL_CURVE_SAMPLE);
+        r.valid = false;
+        return r;
+    }
     if (s->type == WF_QUADRIC_BILINEAR) { BilinearSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxNs.x, ctxNs.y, ctxNs.z, u.x, u.y, &r); return r; }
     SphereSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, u.x, u.y, &r);
     return r;
@@ -2015,6 +2037,7 @@ WF_NI float SpherePDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, f
 WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, N3 ctxNs, V3 wi) {
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
+    if (s->type == WF_QUADRIC_CURVE) { RaiseFatal(sv, WF_FATAL_CURVE_PDF); return 0; }   // Curve::PDF: LOG_FATAL (shapes.cpp:754-757)
     if (s->type == WF_QUADRIC_BILINEAR) return BilinearPDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, ctxNs.x, ctxNs.y, ctxNs.z, wi.x, wi.y, wi.z);
     return SpherePDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, wi.x, wi.y, wi.z);
 }

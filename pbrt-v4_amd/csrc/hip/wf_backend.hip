@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../common/wf_kernels.h"
+#include "../common/wf_kat.h"
 #include "wf_traverse.h"
 
 using namespace wf;
@@ -1236,7 +1237,7 @@ __global__ void __launch_bounds__(BLOCK) k_sampler_probe(const SceneView sv, int
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         PixelSampler s(sv);
         s.StartPixelSample(px[i], py[i], si[i], startDim);
-        for (int d = 0; d < ndims; ++d) out[(size_t)i * ndims + d] = s.Get1D();
+        SamplerProbeRecord(s, ndims, out + (size_t)i * (ndims > 0 ? ndims : ndims == -3 ? 30 : 2));
     }
 }
 
@@ -1593,6 +1594,12 @@ int wf_sync(wf_ctx *ctx) {
         int unresolved = 0;
         HIPCHK(hipMemcpy(&unresolved, ctx->dbgWords + 6, sizeof(int), hipMemcpyDeviceToHost));
         if (unresolved) return fail(-1, "a near-tie re-walk found no hit where the production walk had one (results are incomplete)");
+        int fatal = 0;
+        HIPCHK(hipMemcpy(&fatal, ctx->dbgWords + 7, sizeof(int), hipMemcpyDeviceToHost));
+        // the reference's LOG_FATAL inside a kernel body (shapes.cpp:736-760): a sample was drawn from an emissive curve
+        if (fatal == WF_FATAL_CURVE_SAMPLE) return fail(-1, "Curve::Sample not implemented.");
+        if (fatal == WF_FATAL_CURVE_PDF) return fail(-1, "Curve::PDF not implemented.");
+        if (fatal) return fail(-1, "fatal error %d raised by a kernel", fatal);
         if (getenv("WF_DEBUG_DRAIN")) {
             int h[8];
             HIPCHK(hipMemcpy(h, ctx->dbgWords, sizeof(h), hipMemcpyDeviceToHost));
@@ -1845,6 +1852,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         SceneView *dev = nullptr;
         if ((e = devAlloc(ctx, &dev, (size_t)1))) return e;
         ctx->svHost.self = dev;  // the device copy points at itself: the address the out-of-line device functions are given
+        ctx->svHost.fatal = ctx->dbgWords ? ctx->dbgWords + 7 : nullptr;   // RaiseFatal (wf_scene.h): reported by wf_sync
         HIPCHK(hipMemcpyAsync(dev, &ctx->svHost, sizeof(SceneView), hipMemcpyHostToDevice, ctx->stream));
         ctx->svDev = dev;
     }
@@ -2548,6 +2556,9 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index, int start_dim, int ndims, float *out) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     if (n <= 0) return 0;
+    if (ndims == 0 || ndims < -4 || ndims == -1) return fail(-1, "wf_sampler_probe: ndims %d", ndims);
+    const int mode = ndims;
+    ndims = mode > 0 ? mode : mode == -3 ? 30 : 2;   // floats per record (SamplerProbeRecord, wf_camera.h)
     int32_t *din = nullptr;
     float *dout = nullptr;
     HIPCHK(hipMalloc((void **)&din, (size_t)3 * n * sizeof(int32_t)));
@@ -2555,7 +2566,7 @@ int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, c
     HIPCHK(hipMemcpyAsync(din, px, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(din + n, py, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(din + 2 * (size_t)n, sample_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    LAUNCH("sampler probe", k_sampler_probe, gridFor(n), ctx->svHost, n, din, din + n, din + 2 * (size_t)n, start_dim, ndims, dout);
+    LAUNCH("sampler probe", k_sampler_probe, gridFor(n), ctx->svHost, n, din, din + n, din + 2 * (size_t)n, start_dim, mode, dout);
     HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * ndims * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(din));
@@ -2597,6 +2608,24 @@ int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out) {
     HIPCHK(hipMemcpyAsync(din, in, nin * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     LAUNCH("libm probe", k_libm_probe, gridFor(n), fn, n, din, dout);
     HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(din));
+    HIPCHK(hipFree(dout));
+    return 0;
+}
+
+__global__ void k_kat_probe(int n, const uint64_t *in, uint64_t *out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) wf::KatRun(in + 16 * (size_t)i, out + 8 * (size_t)i);
+}
+int wf_kat_probe(wf_ctx *ctx, int n, const uint64_t *in, uint64_t *out) {
+    if (!ctx) return fail(-1, "null context");
+    if (n <= 0) return 0;
+    uint64_t *din = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&din, (size_t)n * 16 * sizeof(uint64_t)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)n * 8 * sizeof(uint64_t)));
+    HIPCHK(hipMemcpyAsync(din, in, (size_t)n * 16 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH("known-answer probe", k_kat_probe, gridFor(n), n, din, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(din));
     HIPCHK(hipFree(dout));

@@ -4,6 +4,7 @@
 
 #include <zlib.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
@@ -563,6 +564,12 @@ float RoundToHalf(float f) {
     return r;
 }
 
+// the reference logs every NaN channel (LOG_ERROR, util/image.h:428); a handful are enough here
+static void ReportNaN(size_t pixel, int w, int c) {
+    static std::atomic<int> reported{0};
+    if (reported.fetch_add(1) < 8) fprintf(stderr, "Error: NaN at pixel %d,%d comp %d\n", (int)(pixel % (size_t)w), (int)(pixel / (size_t)w), c);
+}
+
 // RGBFilm::GetPixelRGB (film.h:258-275, no splats) + RGBFilm::GetImage (film.cpp:533-565)
 void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, bool saveFP16) {
     for (size_t i = 0; i < (size_t)w * h; ++i) {
@@ -576,7 +583,12 @@ void FilmToRGB(const wf_film &F, const double *film, int w, int h, float *rgb, b
             for (int k = 0; k < 3; ++k) o[r] += F.outputRGBFromSensorRGB[r][k] * c[k];
         }
         if (saveFP16) {
-            for (int r = 0; r < 3; ++r) { if (o[r] > 65504.f) o[r] = 65504.f; o[r] = RoundToHalf(o[r]); }
+            for (int r = 0; r < 3; ++r) { if (o[r] > 65504.f) o[r] = 65504.f; }
+        }
+        // Image::SetChannel (util/image.h:425-432): a NaN is reported and stored as 0
+        for (int r = 0; r < 3; ++r) {
+            if (o[r] != o[r]) { ReportNaN(i, w, r); o[r] = 0; }
+            if (saveFP16) o[r] = RoundToHalf(o[r]);
         }
         rgb[3 * i] = o[0]; rgb[3 * i + 1] = o[1]; rgb[3 * i + 2] = o[2];
     }
@@ -668,6 +680,7 @@ void SpectralFilmImage(const wf_film &F, const double *film, const double *spect
             float c = 0;
             if (sp[nb + b] > 0) {
                 c = (float)(sp[b] / sp[nb + b]);   // (+ splatScale * bucketSplats / filterIntegral: no splats on this path)
+                if (c != c) { ReportNaN(i, w, 3 + b); c = 0; }   // Image::SetChannel
                 if (saveFP16) { if (c > 65504.f) c = 65504.f; c = RoundToHalf(c); }
             }
             o[3 + b] = c;
@@ -716,7 +729,11 @@ void GBufferFilmImage(const wf_film &F, const double *film, const wf_gbuffer_pix
         const float ch[nc] = {o[0], o[1], o[2], alb[0], alb[1], alb[2], pt[0], pt[1], pt[2], std::fabs(dzdx), std::fabs(dzdy), n[0], n[1], n[2], ns[0], ns[1], ns[2],
                               uv[0], uv[1], var[0], var[1], var[2], rel[0], rel[1], rel[2]};
         float *dst = &(*out)[i * nc];
-        for (int c = 0; c < nc; ++c) dst[c] = saveFP16 ? RoundToHalf(ch[c]) : ch[c];
+        for (int c = 0; c < nc; ++c) {
+            float v = ch[c];
+            if (v != v) { ReportNaN(i, w, c); v = 0; }   // Image::SetChannel
+            dst[c] = saveFP16 ? RoundToHalf(v) : v;
+        }
     }
 }
 

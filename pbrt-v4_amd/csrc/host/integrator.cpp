@@ -31,15 +31,35 @@ WavefrontRenderer::WavefrontRenderer(const SceneTables &tables, int device, int 
     Check(wf_scene_upload(ctx, &T.desc), "wf_scene_upload");
     localRows = T.desc.film.pixel_max[1] - T.desc.film.pixel_min[1];
     if (stripCount > 1) Check(wf_set_strips(ctx, stripRank, stripCount, stripHeight, &localRows), "wf_set_strips");
-    rowsPerPass = std::max(1, std::min(T.scanlinesPerPass, localRows));
-    const int pixelsPerPass = W * rowsPerPass;
     samplesPerPass = samplesPerPassArg;
     if (samplesPerPass <= 0) {
         const char *env = getenv("WF_SAMPLES_PER_PASS");
         if (env) samplesPerPass = atoi(env);
     }
-    if (samplesPerPass <= 0) samplesPerPass = std::max(1, (64 << 20) / pixelsPerPass);
-    samplesPerPass = std::min(samplesPerPass, std::max(1, T.spp));
+    // Pass geometry (round 4).  A pass costs a fixed ~6.5 ms of launch latencies and thin late-depth launches on top of its
+    // throughput-proportional work, so the frame is cut into as FEW passes as the 64 Mi-item queues allow: with few sample indices
+    // (bench --steps 20: 41.5 M rays) ONE pass over all rows instead of the reference's two 540-row bands; with many (256 spp) the
+    // band count that minimises bands x ceil(spp / samplesPerPass), ties going to the reference's banding (more sample slots per
+    // pixel in a pass: the samples of a pixel are neighbours in every queue).  The film adds a pixel's samples in sample order for
+    // any geometry: the image does not depend on it (test_samples_per_pass_invariance).
+    const long budget = 64l << 20;
+    const int refBands = std::max(1, (localRows + std::max(1, T.scanlinesPerPass) - 1) / std::max(1, T.scanlinesPerPass));
+    const int spp = std::max(1, T.spp);
+    int bestBands = refBands;
+    long bestPasses = -1;
+    for (int nb = 1; nb <= refBands; ++nb) {
+        const int rows = (localRows + nb - 1) / nb;
+        long S = samplesPerPass > 0 ? samplesPerPass : std::max(1l, budget / ((long)W * rows));
+        S = std::min<long>(S, spp);
+        if ((long)W * rows * S > budget && S > 1) continue;
+        const long passes = (long)((localRows + rows - 1) / rows) * ((spp + S - 1) / S);
+        if (bestPasses < 0 || passes <= bestPasses) { bestPasses = passes; bestBands = nb; }
+    }
+    if (getenv("WF_REFERENCE_BANDS")) bestBands = refBands;   // A/B: the round-3 geometry
+    rowsPerPass = std::max(1, (localRows + bestBands - 1) / bestBands);
+    const int pixelsPerPass = W * rowsPerPass;
+    if (samplesPerPass <= 0) samplesPerPass = (int)std::max(1l, budget / pixelsPerPass);
+    samplesPerPass = std::min(samplesPerPass, spp);
     Check(wf_queues_alloc(ctx, pixelsPerPass, samplesPerPass), "wf_queues_alloc");
     Check(wf_film_clear(ctx), "wf_film_clear");
     Check(wf_sync(ctx), "wf_sync");

@@ -174,9 +174,18 @@ SpectrumP ParamSet::GetOneSpectrum(const std::string &name, SpectrumP def, Spect
     }
     return def;
 }
+// ParameterDictionary::ReportUnused (paramdict.cpp:612-636): a parameter nobody looked up is the reference's ErrorExit — unless a
+// parameter of the same type and name in front of it was looked up (a Shape's parameter shadowing the material's, say).  Parameters of
+// an Attribute directive may stay unused (scene.cpp:208-212: mayBeUnused; the parser marks them looked-up when it appends them).
 void ParamSet::ReportUnused(const std::string &what) const {
-    for (const Param &p : params)
-        if (!p.lookedUp) fprintf(stderr, "Warning: %s: \"%s %s\": unused parameter in %s\n", p.loc.c_str(), p.type.c_str(), p.name.c_str(), what.c_str());
+    std::vector<const Param *> seen;
+    for (const Param &p : params) {
+        bool haveSeen = false;
+        for (const Param *q : seen) if (q->type == p.type && q->name == p.name) { haveSeen = true; break; }
+        if (p.lookedUp) { if (!haveSeen) seen.push_back(&p); }
+        else if (!haveSeen) throw SceneError("Error: " + p.loc + ": \"" + p.name + "\": unused parameter.");
+    }
+    (void)what;
 }
 
 // ---- tokenizer ------------------------------------------------------------------------------------

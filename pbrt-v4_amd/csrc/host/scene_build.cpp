@@ -188,13 +188,13 @@ struct TexBuilder {
     const ParsedScene *scene;
     bool disableImageTextures = false;
 
-    std::vector<int> texDepth;  // nesting depth of every texture node: the device walks the graph with a WF_TEX_MAX_DEPTH stack
+    std::vector<int> texDepth;  // nesting depth of every texture node: the device walks the graph with a stack of WF_TEX_STACK frames
     int AddTex(const wf_texture &t) {
         int d = 1;
         if (t.type != WF_TEX_SPECTRUM_BILERP)  // (its tex0..2 hold spectrum ids, not child textures)
             for (int c : {t.tex0, t.tex1, t.tex2})
                 if (c >= 0) d = std::max(d, 1 + texDepth[c]);
-        if (d > WF_TEX_MAX_DEPTH + 1) Die("", "texture graph nested deeper than " + std::to_string(WF_TEX_MAX_DEPTH + 1) + " levels");
+        if (d > WF_TEX_STACK) Die("", "texture graph nested deeper than " + std::to_string(WF_TEX_STACK) + " levels");
         texDepth.push_back(d);
         T->textures.push_back(t);
         return (int)T->textures.size() - 1;
@@ -547,6 +547,7 @@ struct TexBuilder {
                 } else Die(te.loc, te.name + ": float texture type not supported by this build");
                 if (floatTextures.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
                 floatTextures[te.texName] = AddTex(t);
+                ps.ReportUnused("Texture");   // FloatTexture::Create, textures.cpp:1490
             } else {
                 // the reference instantiates each spectrum texture three times, once per SpectrumType
                 for (SpectrumType st : {SpectrumType::Albedo, SpectrumType::Unbounded, SpectrumType::Illuminant}) {
@@ -617,6 +618,7 @@ struct TexBuilder {
                     auto &m = SpecMap(st);
                     if (st == SpectrumType::Albedo && m.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
                     m[te.texName] = AddTex(t);
+                    ps.ReportUnused("Texture");   // SpectrumTexture::Create, textures.cpp:1545
                 }
             }
         }
@@ -635,9 +637,12 @@ struct TexBuilder {
         wf_material m{};
         for (int &t : m.tex) t = -1;
         m.eta_spectrum = -1;
-        m.displacement = GetFloatTextureOrNull(ps, "displacement");
-        m.normalmap = LoadNormalMap(ps.GetOneString("normalmap", ""), e.loc);
         const std::string &name = e.name;
+        // "normalmap" is looked up for every material (scene.cpp:1142,1159), "displacement" by the Create() of the types that have one
+        // (materials.cpp: every type but hair, mix and interface) — which decides whether a stray one is an unused parameter
+        m.displacement = -1;
+        if (name != "hair" && name != "mix" && name != "interface" && name != "none" && !name.empty()) m.displacement = GetFloatTextureOrNull(ps, "displacement");
+        m.normalmap = LoadNormalMap(ps.GetOneString("normalmap", ""), e.loc);
         auto roughness = [&](const char *u, const char *v, const char *r, int us, int vs) {
             int ur = GetFloatTextureOrNull(ps, u), vr = GetFloatTextureOrNull(ps, v);
             if (ur < 0) ur = GetFloatTexture(ps, r, 0.f);
@@ -789,9 +794,16 @@ struct TexBuilder {
                 m.mix[i] = it->second;
             }
             m.tex[WF_MT_AMOUNT] = GetFloatTexture(ps, "amount", 0.5f);
+            ps.ReportUnused("Material");
+            // updateMaterialNeeds (wavefront/integrator.cpp:55-61) runs over every created material: the wavefront path refuses a mix whose
+            // amount the BasicTextureEvaluator cannot evaluate (textures.h:1162-1177: a constant or an image map)
+            if (const int ty = T->textures[m.tex[WF_MT_AMOUNT]].type; ty != WF_TEX_FLOAT_CONSTANT && ty != WF_TEX_FLOAT_IMAGE)
+                Die(e.loc, "\"mix\" material has a texture that can't be evaluated with the BasicTextureEvaluator, which is all that is currently supported "
+                           "int the wavefront renderer--sorry!");
             T->materials.push_back(m);
             return (int)T->materials.size() - 1;
-        } else Die(e.loc, name + ": material type not supported by this build");
+        } else Die(e.loc, name + ": material type unknown.");
+        if (m.type != WF_MAT_INTERFACE) ps.ReportUnused("Material");   // Material::Create, materials.cpp:688 ("interface" returns before it)
         T->materialTypePresent[m.type] = true;
         T->materials.push_back(m);
         return (int)T->materials.size() - 1;
@@ -1441,6 +1453,7 @@ static void BuildMedia(const ParsedScene &scene, SceneTables *T, std::map<std::s
                         maj[(z * 64 + y) * 64 + x] = mx;
                     }
         } else Die(e.loc, e.name + ": medium type is not supported by this build (homogeneous, uniformgrid, rgbgrid, cloud, nanovdb)");
+        ps.ReportUnused("MakeNamedMedium");   // Medium::Create, media.cpp:687
         (*ids)[nm.first] = (int)T->media.size();
         T->media.push_back(M);
     }
@@ -2410,7 +2423,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         }
         sh.params.ReportUnused("Shape");
     };
-    struct PendingSphere { wf_quadric s; B3 bounds; };
+    struct PendingSphere { wf_quadric s; B3 bounds; float area = 0; /* curves: Curve::Area */ };
+    std::map<int, std::vector<int>> curvesOfMesh;   // mesh id -> its Curve primitives (indices into spheres)
     std::vector<PendingSphere> spheres;
     std::map<int, int> sphereOfMesh;
     std::map<int, std::vector<int>> patchesOfMesh;  // mesh id -> its bilinear patches (indices into spheres)
@@ -2566,11 +2580,21 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
                     ob.pMin = ob.pMin - V3{e, e, e}; ob.pMax = ob.pMax + V3{e, e, e};
                     for (int cnr = 0; cnr < 8; ++cnr)
                         p.bounds = Union(p.bounds, rfo.Point(V3{(cnr & 1) ? ob.pMax.x : ob.pMin.x, (cnr & 2) ? ob.pMax.y : ob.pMin.y, (cnr & 4) ? ob.pMax.z : ob.pMin.z}));
+                    {
+                        // Curve::Area (shapes.cpp:530-540): the control polygon's length of the u-range times the average width
+                        V3 ca[4];
+                        CubicBezierControlPoints(b, uMin, uMax, ca);
+                        const float width0u = Lerp(uMin, w0, w1), width1u = Lerp(uMax, w0, w1);
+                        const float avgWidth = (width0u + width1u) * 0.5f;
+                        float approxLength = 0.f;
+                        for (int k = 0; k < 3; ++k) approxLength += Length(ca[k] - ca[k + 1]);
+                        p.area = approxLength * avgWidth;
+                    }
                     prims->emplace_back(-1 - (int)spheres.size(), p.bounds);
+                    curvesOfMesh[meshId].push_back((int)spheres.size());
                     spheres.push_back(p);
                 }
             }
-            if (sh.lightIndex >= 0) Die(sh.loc, "curve: Curve::Sample is not implemented in the reference either: curves cannot be area lights");
             commitMesh(mesh, meshId, sh, rfo, inDefinition);
             return;
         }
@@ -2968,6 +2992,42 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
                 addLightBounds(lightId, lb);
             }
         }
+        if (auto cit = curvesOfMesh.find(pa.mesh); cit != curvesOfMesh.end()) {
+            // An emissive curve: the reference creates one DiffuseAreaLight per Curve primitive like for any shape (scene.cpp:1290-1340) —
+            // area from Curve::Area, bounds from Curve::Bounds, NormalBounds = the entire sphere (shapes.h:1251) —, lets camera and specular
+            // rays see its emission, and aborts the moment a sample is drawn from it or its PDF is asked for (Curve::Sample / Curve::PDF:
+            // LOG_FATAL "not implemented", shapes.cpp:736-760).  Same here: SphereSample / SpherePDF raise the context's fatal flag.
+            const int nTris = (int)T->triIndices.size() / 3;
+            for (int si : cit->second) {
+                const PendingSphere &sp = spheres[si];
+                const float area = sp.area;
+                float sc = scale;
+                if (phi_v > 0) {
+                    float k_e = lightImage >= 0 ? imageLumAvg : 1.f;
+                    k_e *= (twoSided ? 2 : 1) * area * Pi;
+                    sc *= phi_v / k_e;
+                }
+                wf_light l{};
+                l.type = WF_LIGHT_DIFFUSE_AREA;
+                l.flags = (twoSided ? WF_LIGHTFLAG_TWOSIDED : 0) | (alphaZero ? WF_LIGHTFLAG_DELTA_POSITION : 0);
+                l.alpha_tex_plus1 = alphaZero ? 0 : mesh.alpha_tex + 1;
+                l.spectrum_offset = specOff;
+                l.scale = sc;
+                l.tri = nTris + si;
+                l.area = area;
+                l.bit_trail = -1; l.infinite_index = -1; l.xform = -1; l.image = lightImage;
+                int lightId = (int)T->lights.size();
+                T->lights.push_back(l);
+                LightBoundsH lb;
+                lb.bounds = sp.bounds;
+                lb.w = Normalize(V3{0, 0, 1});
+                lb.phi = LemitMax * (sc * area * Pi);
+                lb.cosTheta_o = -1.f;
+                lb.cosTheta_e = std::cos(Pi / 2);
+                lb.twoSided = twoSided;
+                addLightBounds(lightId, lb);
+            }
+        }
         ps.ReportUnused("AreaLightSource");
     }
     for (const LightEntity &le : scene.lights) {
@@ -3355,7 +3415,12 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
     // CreateAccelerator (cpu/aggregates.cpp:1163-1178): "bvh" | "kdtree", anything else is an error.  A kd-tree finds the same closest hit and
     // the same occlusion as the BVH (exact ties between coplanar primitives aside): it is replaced by the BVH, as the reference's own GPU path
     // replaces every accelerator by its own
-    if (scene.accelerator.name == "kdtree") fprintf(stderr, "Warning: accelerator \"kdtree\" is replaced by the BVH\n");
+    if (scene.accelerator.name == "kdtree") {
+        fprintf(stderr, "Warning: accelerator \"kdtree\" is replaced by the BVH\n");
+        // KdTreeAggregate::Create's parameters (cpu/aggregates.cpp:1151-1160) count as looked up
+        for (const char *k : {"intersectcost", "traversalcost", "maxprims", "maxdepth"}) scene.accelerator.params.GetOneInt(k, 0);
+        scene.accelerator.params.GetOneFloat("emptybonus", 0.5f);
+    }
     else if (scene.accelerator.name != "bvh") Die(scene.accelerator.loc, scene.accelerator.name + ": accelerator type unknown.");
     std::string split = scene.accelerator.params.GetOneString("splitmethod", "sah");
     if (getenv("WF_BVH_SPLIT")) split = getenv("WF_BVH_SPLIT");   // load-time experiments: build the top-level tree with the other method
@@ -3365,6 +3430,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
     }
     const int splitCode = split == "hlbvh" ? 1 : split == "middle" ? 2 : split == "equal" ? 3 : 0;
     int maxPrims = scene.accelerator.params.GetOneInt("maxnodeprims", 4);
+    scene.accelerator.params.ReportUnused("Accelerator");   // CreateAccelerator, cpu/aggregates.cpp:1176
     {
         // The top-level tree needs only the BOUNDS of the instance definitions (= the union of their primitives' bounds, what the root of
         // BVHAggregate(prims) holds), so it is built CONCURRENTLY with the definitions' trees: on the device when it is large and a GPU is visible
@@ -3533,7 +3599,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         T->scanlinesPerPass = (resy + T->nPasses - 1) / T->nPasses;
         T->maxQueueSize = resx * T->scanlinesPerPass;
     }
-    ip.ReportUnused("Integrator");
+    // (no ReportUnused: only Integrator::Create — the CPU integrators — reports the integrator's unused parameters, cpu/integrators.cpp:3691;
+    //  the wavefront integrator reads what it knows and ignores the rest)
     T->Finalize();
     tick("light sampler, finalisation");
 }

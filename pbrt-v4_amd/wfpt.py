@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
     "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
-    "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_queue_size", "wf_queue_download",
+    "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_kat_probe", "wf_queue_size", "wf_queue_download",
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",
     "wf_trace_closest_device", "wf_trace_any_device", "wf_device_alloc", "wf_device_free", "wf_device_upload", "wf_device_download", "wf_trace_shadow_tr_host",
 ]
@@ -122,6 +122,7 @@ def libs():
     _hip.wf_trace_any_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _hip.wf_sampler_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _hip.wf_libm_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    _hip.wf_kat_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _hip.wf_kernel_time_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _hip.wf_aggregate_bounds.argtypes = [C.c_void_p, C.c_void_p]
     _hip.wf_render_pass.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -291,7 +292,7 @@ class Scene:
         px = np.ascontiguousarray(px, dtype=np.int32)
         py = np.ascontiguousarray(py, dtype=np.int32)
         si = np.ascontiguousarray(sample_index, dtype=np.int32)
-        out = np.empty((px.shape[0], ndims), dtype=np.float32)
+        out = np.empty((px.shape[0], ndims if ndims > 0 else 30 if ndims == -3 else 2), dtype=np.float32)   # record sizes: include/wf_abi.h
         _check(hip.wf_sampler_probe(self.ctx, px.shape[0], px.ctypes.data, py.ctypes.data, si.ctypes.data, start_dim, ndims, out.ctypes.data),
                "wf_sampler_probe")
         return out
@@ -305,6 +306,14 @@ class Scene:
         n = x.shape[0]
         out = np.empty(n, dtype=np.float32)
         _check(hip.wf_libm_probe(self.ctx, self.LIBM_FNS.index(fn), n, x.ctypes.data, out.ctypes.data), "wf_libm_probe")
+        return out
+
+    def kat_probe(self, records):
+        """Device evaluation of the known-answer probe (csrc/common/wf_kat.h): (n, 16) uint64 records in, (n, 8) uint64 out."""
+        _, hip = libs()
+        records = np.ascontiguousarray(records, dtype=np.uint64).reshape(-1, 16)
+        out = np.empty((records.shape[0], 8), dtype=np.uint64)
+        _check(hip.wf_kat_probe(self.ctx, records.shape[0], records.ctypes.data, out.ctypes.data), "wf_kat_probe")
         return out
 
     def enable_profile(self, on=True):

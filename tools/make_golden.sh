@@ -46,6 +46,8 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/tempgrid_
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/texture_mappings_ref.pfm $G/texture_mappings.pbrt
 # bilerp and directionmix textures (float and spectrum): hand-written tests/golden/textures_extra.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_extra_ref.pfm $G/textures_extra.pbrt
+# texture graphs nested ten levels deep (float and spectrum chains; as reflectance, roughness, displacement and alpha): hand-written
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/textures_deep_ref.pfm $G/textures_deep.pbrt
 # image-textured diffuse area lights (triangles and a sphere): hand-written tests/golden/arealight_image.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/arealight_image_ref.pfm $G/arealight_image.pbrt
 # alpha-masked emitters (checkerboard cut-out, fractional alpha, the invisible alpha-0 DeltaPosition case): hand-written
