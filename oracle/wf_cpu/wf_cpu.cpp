@@ -277,6 +277,7 @@ int main(int argc, char **argv) {
 static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
+    bool emulateStaleDepth = false;   // g_msStaleDepth (wf_kernels.h): the reference's unwritten MediumSampleWorkItem::depth, sequential order only
     bool tracePath = false;   // print the path state after every stage (the lines oracle/_ref/ref_trace prints; tools/trace_diff.py)
     std::string lightProbeIn, lightProbeOut, reProbeIn, reProbeOut;
     bool simulateWaves = false;
@@ -307,6 +308,7 @@ static int Main(int argc, char **argv) {
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
         else if (a == "--dump-stages") dumpStages = next();
         else if (a == "--trace-path") tracePath = true;
+        else if (a == "--emulate-stale-medium-depth") emulateStaleDepth = true;
         else if (a == "--simulate-waves") simulateWaves = true;
         else if (a == "--strips") { stripRank = atoi(next().c_str()); stripCount = atoi(next().c_str()); stripHeight = atoi(next().c_str()); }
         else if (a == "--samples") { sampleBegin = atoi(next().c_str()); sampleEnd = atoi(next().c_str()); sampleStep = atoi(next().c_str()); }
@@ -535,6 +537,7 @@ static int Main(int argc, char **argv) {
         ws.scatterP = Alloc<F4>(n); ws.sq.medium = Alloc<int32_t>(n);
     }
     ws.counters = Alloc<int32_t>(CNT_COUNT * CNT_STRIDE);
+    if (emulateStaleDepth && sv.haveMedia) { g_msStaleDepth = Alloc<int32_t>(n); gThreads = 1; }
     const wf_film &F = T.desc.film;
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
     ws.film = Alloc<double>((size_t)W * H * 4);
@@ -867,7 +870,7 @@ static int Main(int argc, char **argv) {
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (fatalWord) {
         // the reference's LOG_FATAL inside a kernel body (shapes.cpp:736-760: a sample drawn from an emissive curve) aborts the process
-        fprintf(stderr, "Fatal: %s not implemented.\n", fatalWord == WF_FATAL_CURVE_SAMPLE ? "Curve::Sample" : fatalWord == WF_FATAL_CURVE_PDF ? "Curve::PDF" : "?");
+        fprintf(stderr, "Fatal: %s\n", FatalMessage(fatalWord));
         return 1;
     }
 

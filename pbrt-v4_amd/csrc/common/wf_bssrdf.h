@@ -306,7 +306,7 @@ WF_HD DielectricBxDF GetSubsurfaceBxDF(const SceneView &sv, const wf_material &m
         urough = TrowbridgeReitz::RoughnessToAlpha(urough);
         vrough = TrowbridgeReitz::RoughnessToAlpha(vrough);
     }
-    return DielectricBxDF{m.sss_eta, TrowbridgeReitz(urough, vrough)};
+    return DielectricBxDF{m.sss_eta, TrowbridgeReitz(urough, vrough), sv.fatal};
 }
 // SubsurfaceMaterial::GetBSSRDF (materials.h:747-765); ctx = (p, ns, wo, uv) of GetBSSRDFAndProbeRayWorkItem::GetMaterialEvalContext
 WF_HD TabulatedBSSRDF GetBSSRDF(const SceneView &sv, const wf_material &m, const Wavelengths &lambda, const TexCtx &tc, N3 ns, V3 wo) {

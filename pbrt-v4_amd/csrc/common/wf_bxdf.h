@@ -240,6 +240,7 @@ struct DiffuseTransmissionBxDF {
 struct DielectricBxDF {
     float eta;
     TrowbridgeReitz mfDistrib;
+    int32_t *fatal = nullptr;   // SceneView::fatal (wf_scene.h) where a material kernel built the BxDF: the reference's CHECK below reports there
     WF_HD int Flags() const {
         int flags = (eta == 1) ? BXDF_TRANSMISSION : (BXDF_REFLECTION | BXDF_TRANSMISSION);
         return flags | (mfDistrib.EffectivelySmooth() ? BXDF_SPECULAR : BXDF_GLOSSY);
@@ -289,6 +290,7 @@ struct DielectricBxDF {
                 float denom = Sqr(Dot(wi, wm) + Dot(wo, wm) / etap);
                 float dwm_dwi = AbsDot(wi, wm) / denom;
                 pdf = mfDistrib.PDF(wo, wm) * dwm_dwi * pt / (pr + pt);
+                if (pdf != pdf && fatal) *fatal = WF_FATAL_CHECK_NAN_PDF;   // CHECK(!IsNaN(pdf)), bxdfs.cpp:158 (a negative roughness gets here)
                 S4 ft = S4c(T * mfDistrib.D(wm) * mfDistrib.G(wo, wi) *
                             abs(Dot(wi, wm) * Dot(wo, wm) / (CosTheta(wi) * CosTheta(wo) * denom)));
                 if (mode == MODE_RADIANCE) ft = ft / Sqr(etap);
@@ -780,7 +782,7 @@ WF_HD DielectricBxDF GetDielectricBxDF(const SceneView &sv, const wf_material &m
         urough = TrowbridgeReitz::RoughnessToAlpha(urough);
         vrough = TrowbridgeReitz::RoughnessToAlpha(vrough);
     }
-    return DielectricBxDF{sampledEta, TrowbridgeReitz(urough, vrough)};
+    return DielectricBxDF{sampledEta, TrowbridgeReitz(urough, vrough), sv.fatal};
 }
 WF_HD ThinDielectricBxDF GetThinDielectricBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
     // materials.h:226-240
@@ -819,7 +821,7 @@ WF_HD CoatedDiffuseBxDF GetCoatedDiffuseBxDF(const SceneView &sv, const wf_mater
     float sampledEta = SampledEta(sv, m, lambda);
     S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda, tc));
     float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G], tc), -1.f, 1.f);
-    return CoatedDiffuseBxDF{DielectricBxDF{sampledEta, distrib}, DiffuseBxDF{r}, fmax(thick, 1.17549435e-38f), gg, a, m.maxdepth, m.nsamples,
+    return CoatedDiffuseBxDF{DielectricBxDF{sampledEta, distrib, sv.fatal}, DiffuseBxDF{r}, fmax(thick, 1.17549435e-38f), gg, a, m.maxdepth, m.nsamples,
                              sv.options.seed};
 }
 WF_HD CoatedConductorBxDF GetCoatedConductorBxDF(const SceneView &sv, const wf_material &m, Wavelengths &lambda, const TexCtx &tc) {
@@ -853,7 +855,7 @@ WF_HD CoatedConductorBxDF GetCoatedConductorBxDF(const SceneView &sv, const wf_m
     TrowbridgeReitz conductorDistrib(curough, cvrough);
     S4 a = ClampS01(EvalSpectrumTexture(sv, m.tex[WF_MT_ALBEDO], lambda, tc));
     float gg = Clamp(EvalFloatTexture(sv, m.tex[WF_MT_G], tc), -1.f, 1.f);
-    return CoatedConductorBxDF{DielectricBxDF{ieta, interfaceDistrib}, ConductorBxDF{conductorDistrib, ce, ck}, fmax(thick, 1.17549435e-38f), gg, a,
+    return CoatedConductorBxDF{DielectricBxDF{ieta, interfaceDistrib, sv.fatal}, ConductorBxDF{conductorDistrib, ce, ck}, fmax(thick, 1.17549435e-38f), gg, a,
                                m.maxdepth, m.nsamples, sv.options.seed};
 }
 

@@ -248,6 +248,9 @@ WF_HD HairBxDF GetHairBxDF(const SceneView &sv, const wf_material &m, Wavelength
         for (int i = 0; i < 4; ++i) sig_a[i] = scale * SigmoidPoly(lambda.lambda[i], cf[0], cf[1], cf[2]);
     }
     float h = -1 + 2 * tc.uv.y;
+    // HairBxDF ctor (bxdfs.cpp:278-280): CHECK(h >= -1 && h <= 1), CHECK(beta_m / beta_n in [0, 1]) — a hair material on a surface whose
+    // v leaves [0, 1] (a (u, v)-scaled quad) aborts the reference
+    if (!(h >= -1 && h <= 1) || !(bm >= 0 && bm <= 1) || !(bn >= 0 && bn <= 1)) RaiseFatal(sv, WF_FATAL_CHECK_HAIR);
     return HairBxDF(h, e, sig_a, bm, bn, a);
 }
 

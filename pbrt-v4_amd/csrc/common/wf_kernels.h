@@ -445,6 +445,14 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
     int slot = QueueAlloc(&ws.counters[(CNT_MAT0 + mtype) * CNT_STRIDE]);
     ws.matQ[mtype][slot] = i;
 }
+#if !defined(__HIPCC__)
+// CPU checker only (wf_cpu --emulate-stale-medium-depth, sequential execution): the reference's MediumSampleQueue::Push(RayWorkItem, tMax)
+// — the push of a ray that MISSED every surface, intersect.h:19-23 — writes every member of the item except `depth`
+// (wavefront/workitems.h:468-492), so SampleMediumInteraction reads the depth of whatever item used that queue slot last.  Which slot a
+// ray gets depends on the order the threads push in: the reference's image is order-dependent there (not a parity target).
+// In sequential order the effect can be reproduced, which is how the diagnosis was checked: one stale depth per medium-sample slot.
+inline int32_t *g_msStaleDepth = nullptr;
+#endif
 WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, int i, bool found, int prim, int inst, float tHit, float b0, float b1, float b2) {
     if (sv.nInstances > 0) ws.hitInst[i] = found ? inst : -1;
     if (sv.haveMedia && ws.rq[cur].meta[i].w >= 0) {
@@ -453,6 +461,12 @@ WF_HD void KAfterClosestHit(const SceneView &sv, const WorkState &ws, int cur, i
         ws.hitT[i] = found ? tHit : WF_INFINITY;
         int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE]);
         ws.mediumSampleQ[slot] = i;
+#if !defined(__HIPCC__)
+        if (g_msStaleDepth) {
+            if (found) g_msStaleDepth[slot] = ws.rq[cur].meta[i].y;
+            else ws.rq[cur].meta[i].y = g_msStaleDepth[slot];   // the item's consumers read the depth from the ray slot
+        }
+#endif
         return;
     }
     if (!found) {

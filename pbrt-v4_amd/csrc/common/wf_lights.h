@@ -76,6 +76,9 @@ WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavel
     if (py < 0) { px = res - 1 - px; py = -py; }
     else if (py >= res) { px = res - 1 - px; py = 2 * res - 1 - py; }
     if (res == 1) { px = 0; py = 0; }
+    // (a NaN or infinite direction — the tail of a path that already went wrong — gives coordinates the reflection above does not bring
+    //  back: the reference reads outside its image there; no kernel may)
+    px = Clamp(px, 0, res - 1); py = Clamp(py, 0, res - 1);
     const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
     return l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda);
 }

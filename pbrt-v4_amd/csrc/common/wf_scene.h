@@ -79,7 +79,14 @@ struct SceneView {
     // (the CPU checker: the end of its render) turns the code into the reference's fatal error.  Null: nothing to report to.
     int32_t *fatal;
 };
-enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2 };
+enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2,
+       WF_FATAL_CHECK_HAIR = 3,      // HairBxDF ctor: CHECK(h >= -1 && h <= 1) / beta_m / beta_n (bxdfs.cpp:278-280)
+       WF_FATAL_CHECK_NAN_PDF = 4 }; // DielectricBxDF::Sample_f: CHECK(!IsNaN(pdf)) of the rough transmission (bxdfs.cpp:158)
+WF_HD const char *FatalMessage(int code) {
+    return code == WF_FATAL_CURVE_SAMPLE ? "Curve::Sample not implemented." : code == WF_FATAL_CURVE_PDF ? "Curve::PDF not implemented."
+           : code == WF_FATAL_CHECK_HAIR ? "Check failed: h >= -1 && h <= 1 (HairBxDF)" : code == WF_FATAL_CHECK_NAN_PDF ? "Check failed: !IsNaN(pdf) (DielectricBxDF::Sample_f)"
+           : "fatal error raised by a kernel";
+}
 WF_HD void RaiseFatal(const SceneView &sv, int code) { if (sv.fatal) *sv.fatal = code; }
 
 // SobolMatrices32 dimensions 0 and 1 (util/sobolmatrices.cpp:40-58).  Dimension 0 is the van der Corput
@@ -322,6 +329,11 @@ WF_HD float ImageTexel(const float *table, const wf_tex_image &im, int level, in
         else if (y >= ry) { x = rx - 1 - x; y = 2 * ry - 1 - y; }
         if (rx == 1) x = 0;
         if (ry == 1) y = 0;
+        // Coordinates more than one image away (an octahedral map under a scaled (u, v) mapping) are still outside after the reflection:
+        // the reference then reads past its pixel array (util/image.h:100-121 has no second step) — undefined there, clamped here so that
+        // no kernel reads outside the table
+        x = Clamp(x, 0, rx - 1);
+        y = Clamp(y, 0, ry - 1);
     } else {
         if (!(x >= 0 && x < rx)) {
             if (im.wrap == WF_WRAP_REPEAT) x = ModI(x, rx);
@@ -652,11 +664,11 @@ WF_HD bool InsidePolkaDot(const SceneView &sv, const wf_texture &t, const TexCtx
 // tagged pointers; the device code has no recursion.  Until round 3 the walk was a template over the remaining depth, fully
 // inlined (three interior node types: the code grew ~7x per level and the bound was two interior levels; deeper graphs were
 // refused).  Since round 4 it is an EXPLICIT-STACK evaluator inside the out-of-line graph functions below: a frame per interior
-// node (node id, resume state, the weight and the first operand), WF_TEX_STACK frames, the same operations in the same order.
+// node (node id | resume state, the weight, the first operand), WF_TEX_STACK frames (16: no production scene nests that deep), the same operations in the same order.
 // (As part of the inlined material code an explicit stack had cost 470 spilled VGPRs; behind the call its arrays are the callee's
 // scratch and the kernels' register budgets do not see them.)  The host builder refuses graphs nested deeper than WF_TEX_STACK.
 #ifndef WF_TEX_STACK
-#define WF_TEX_STACK 24
+#define WF_TEX_STACK 16
 #endif
 // the three texture types a production scene's parameters usually are: what the material kernels and the traversal kernels' alpha test
 // evaluate inline
@@ -674,50 +686,51 @@ WF_HD bool IsSimpleFloatTexture(int type) { return type == WF_TEX_FLOAT_CONSTANT
 WF_HD bool IsLeafFloatTexture(int type) {
     return IsSimpleFloatTexture(type) || type == WF_TEX_FLOAT_FBM || type == WF_TEX_FLOAT_WRINKLED || type == WF_TEX_FLOAT_WINDY;
 }
-WF_HD float EvalFloatTextureLeaf(const SceneView &sv, const wf_texture &t, const TexCtx &tc) {
-    if (IsSimpleFloatTexture(t.type)) return EvalFloatTextureSimple(sv, t, tc);
+WF_HD float EvalFloatTextureLeaf(const SceneView &sv, const wf_texture *tp, const TexCtx &tc) {
+    if (IsSimpleFloatTexture(tp->type)) return EvalFloatTextureSimple(sv, *tp, tc);
     TexCtx cc = tc;
-    wf_texture tt = t;
-    return NoiseFloatTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc);
+    return NoiseFloatTextureP(sv.noisePerm, sv.lightXforms + tp->xform, tp, &cc);
 }
-// The explicit-stack walk of a float graph.  Frame states: 0 = entered; SCALE: 1 = the scale factor returned, 2 = the texture
-// returned; MIX / CHECKERBOARD / DIRECTIONMIX: 1 = the amount returned (MIX only), 2 = tex0 ("tex1" of the reference's mix,
+// The explicit-stack walk of a float graph.  A frame = (node id << 3 | state, weight, first operand); the node records are read in
+// place (no copies: the frames are all the scratch this costs).  States: 0 = entered; SCALE: 1 = the scale factor returned, 2 = the
+// texture returned; MIX / CHECKERBOARD / DIRECTIONMIX: 1 = the amount returned (MIX only), 2 = tex0 ("tex1" of the reference's mix,
 // weighted 1 - amt) returned, 3 = tex1 returned.  DOTS replaces its own frame by the chosen child (a tail call).
 WF_HD float EvalFloatTextureStack(const SceneView &sv, int id, const TexCtx &tc) {
-    int fid[WF_TEX_STACK];
-    int fstate[WF_TEX_STACK];
+    int fnode[WF_TEX_STACK];
     float fw[WF_TEX_STACK], fa[WF_TEX_STACK];
     int sp = 0;
-    fid[0] = id; fstate[0] = 0;
+    fnode[0] = id << 3;
     float ret = 0;
     while (sp >= 0) {
-        const wf_texture t = sv.textures[fid[sp]];
-        int st = fstate[sp];
+        const wf_texture *tp = sv.textures + (fnode[sp] >> 3);
+        const int type = tp->type;
+        int st = fnode[sp] & 7;
         if (st == 0) {
-            if (IsLeafFloatTexture(t.type)) { ret = EvalFloatTextureLeaf(sv, t, tc); --sp; continue; }
-            if (t.type == WF_TEX_FLOAT_DOTS) { fid[sp] = InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0; continue; }
+            if (IsLeafFloatTexture(type)) { ret = EvalFloatTextureLeaf(sv, tp, tc); --sp; continue; }
+            if (type == WF_TEX_FLOAT_DOTS) { fnode[sp] = (InsidePolkaDot(sv, *tp, tc) ? tp->tex1 : tp->tex0) << 3; continue; }
             if (sp + 1 >= WF_TEX_STACK) { ret = 0; --sp; continue; }   // (refused at load: never reached)
-            if (t.type == WF_TEX_FLOAT_SCALE) {
+            if (type == WF_TEX_FLOAT_SCALE) {
                 // FloatScaledTexture::Evaluate, textures.h:1039-1044: the scale first
-                fstate[sp] = 1; ++sp; fid[sp] = t.tex1; fstate[sp] = 0;
+                fnode[sp] |= 1; fnode[++sp] = tp->tex1 << 3;
                 continue;
             }
-            if (t.type == WF_TEX_FLOAT_MIX) {
+            if (type == WF_TEX_FLOAT_MIX) {
                 // FloatMixTexture::Evaluate (textures.h:810-818): the amount first
-                fstate[sp] = 1; ++sp; fid[sp] = t.tex2; fstate[sp] = 0;
+                fnode[sp] |= 1; fnode[++sp] = tp->tex2 << 3;
                 continue;
             }
-            if (t.type == WF_TEX_FLOAT_CHECKERBOARD || t.type == WF_TEX_FLOAT_DIRECTIONMIX) {
+            if (type == WF_TEX_FLOAT_CHECKERBOARD || type == WF_TEX_FLOAT_DIRECTIONMIX) {
                 // FloatCheckerboardTexture::Evaluate (:370-378), FloatDirectionMixTexture::Evaluate (:839-847: amt * tex1 + (1 - amt) * tex2
                 // = the mix form with tex0 = "tex2")
-                ret = t.type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
+                ret = type == WF_TEX_FLOAT_DIRECTIONMIX ? AbsDot(tc.n, N3{tp->map[4], tp->map[5], tp->map[6]}) : CheckerboardWeight(sv, *tp, tc);
                 st = 1;
             } else { ret = 0; --sp; continue; }
         }
-        if (t.type == WF_TEX_FLOAT_SCALE) {
+        const int self = fnode[sp] & ~7;
+        if (type == WF_TEX_FLOAT_SCALE) {
             if (st == 1) {
                 if (ret == 0) { --sp; continue; }   // returns 0
-                fw[sp] = ret; fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0;
+                fw[sp] = ret; fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3;
                 continue;
             }
             ret = ret * fw[sp];
@@ -728,12 +741,12 @@ WF_HD float EvalFloatTextureStack(const SceneView &sv, int id, const TexCtx &tc)
         if (st == 1) {
             fw[sp] = ret;
             fa[sp] = 0;
-            if (ret != 1) { fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0; continue; }
+            if (ret != 1) { fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3; continue; }
             st = 2; ret = 0;
         }
         if (st == 2) {
             fa[sp] = ret;
-            if (fw[sp] != 0) { fstate[sp] = 3; ++sp; fid[sp] = t.tex1; fstate[sp] = 0; continue; }
+            if (fw[sp] != 0) { fnode[sp] = self | 3; fnode[++sp] = tp->tex1 << 3; continue; }
             ret = 0;
         }
         {
@@ -766,58 +779,58 @@ WF_HD S4 EvalSpectrumTextureSimple(const SceneView &sv, const wf_texture &t, con
 }
 WF_HD bool IsSimpleSpectrumTexture(int type) { return type == WF_TEX_SPECTRUM_CONSTANT || type == WF_TEX_SPECTRUM_IMAGE || type == WF_TEX_SPECTRUM_BILERP; }
 WF_HD bool IsLeafSpectrumTexture(int type) { return IsSimpleSpectrumTexture(type) || type == WF_TEX_SPECTRUM_MARBLE; }
-WF_HD S4 EvalSpectrumTextureLeaf(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &tc) {
-    if (IsSimpleSpectrumTexture(t.type)) return EvalSpectrumTextureSimple(sv, t, lambda, tc);
+WF_HD S4 EvalSpectrumTextureLeaf(const SceneView &sv, const wf_texture *tp, const Wavelengths &lambda, const TexCtx &tc) {
+    if (IsSimpleSpectrumTexture(tp->type)) return EvalSpectrumTextureSimple(sv, *tp, lambda, tc);
     TexCtx cc = tc;
-    wf_texture tt = t;
     S4 r;
-    MarbleTextureP(sv.noisePerm, sv.lightXforms + t.xform, &tt, &cc, sv.rgb2specCoeffs, sv.rgb2specZNodes, lambda.lambda, r.v);
+    MarbleTextureP(sv.noisePerm, sv.lightXforms + tp->xform, tp, &cc, sv.rgb2specCoeffs, sv.rgb2specZNodes, lambda.lambda, r.v);
     return r;
 }
 // The explicit-stack walk of a spectrum graph; float operands (a scale factor, a mix amount) are float graphs of their own
-// (EvalFloatTexture).  Frame states as in EvalFloatTextureStack.
+// (EvalFloatTextureStack).  Frames and states as there.
 WF_HD S4 EvalSpectrumTextureStack(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
-    int fid[WF_TEX_STACK];
-    int fstate[WF_TEX_STACK];
+    int fnode[WF_TEX_STACK];
     float fw[WF_TEX_STACK];
     S4 fa[WF_TEX_STACK];
     int sp = 0;
-    fid[0] = id; fstate[0] = 0;
+    fnode[0] = id << 3;
     S4 ret = S4c(0.f);
     while (sp >= 0) {
-        const wf_texture t = sv.textures[fid[sp]];
-        const int st = fstate[sp];
+        const wf_texture *tp = sv.textures + (fnode[sp] >> 3);
+        const int type = tp->type;
+        const int st = fnode[sp] & 7;
+        const int self = fnode[sp] & ~7;
         if (st == 0) {
-            if (IsLeafSpectrumTexture(t.type)) { ret = EvalSpectrumTextureLeaf(sv, t, lambda, tc); --sp; continue; }
-            if (t.type == WF_TEX_SPECTRUM_DOTS) { fid[sp] = InsidePolkaDot(sv, t, tc) ? t.tex1 : t.tex0; continue; }
+            if (IsLeafSpectrumTexture(type)) { ret = EvalSpectrumTextureLeaf(sv, tp, lambda, tc); --sp; continue; }
+            if (type == WF_TEX_SPECTRUM_DOTS) { fnode[sp] = (InsidePolkaDot(sv, *tp, tc) ? tp->tex1 : tp->tex0) << 3; continue; }
             if (sp + 1 >= WF_TEX_STACK) { ret = S4c(0.f); --sp; continue; }   // (refused at load: never reached)
-            if (t.type == WF_TEX_SPECTRUM_SCALE) {
-                // SpectrumScaledTexture::Evaluate, textures.h:1059-1064
-                const float sc = EvalFloatTextureStack(sv, t.tex1, tc);
-                if (sc == 0) { ret = S4c(0.f); --sp; continue; }
-                fw[sp] = sc; fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0;
+            // the node's float operand — SpectrumScaledTexture's scale (textures.h:1059-1064: evaluated first, 0 ends the node), the amount of
+            // SpectrumMixTexture (:840-850), the checkerboard's (:404-413) or the direction mix's (:880-890) weight — from ONE call site:
+            // every inlined copy of the float walk would add its frames to the kernels' scratch
+            float w;
+            if (type == WF_TEX_SPECTRUM_SCALE || type == WF_TEX_SPECTRUM_MIX) w = EvalFloatTextureStack(sv, type == WF_TEX_SPECTRUM_SCALE ? tp->tex1 : tp->tex2, tc);
+            else if (type == WF_TEX_SPECTRUM_DIRECTIONMIX) w = AbsDot(tc.n, N3{tp->map[4], tp->map[5], tp->map[6]});
+            else if (type == WF_TEX_SPECTRUM_CHECKERBOARD) w = CheckerboardWeight(sv, *tp, tc);
+            else { ret = S4c(0.f); --sp; continue; }
+            fw[sp] = w;
+            if (type == WF_TEX_SPECTRUM_SCALE) {
+                if (w == 0) { ret = S4c(0.f); --sp; continue; }
+                fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3;
                 continue;
             }
-            if (t.type == WF_TEX_SPECTRUM_MIX || t.type == WF_TEX_SPECTRUM_CHECKERBOARD || t.type == WF_TEX_SPECTRUM_DIRECTIONMIX) {
-                // SpectrumMixTexture::Evaluate (textures.h:840-850), SpectrumCheckerboardTexture::Evaluate (:404-413),
-                // SpectrumDirectionMixTexture::Evaluate (:880-890)
-                const float w = t.type == WF_TEX_SPECTRUM_MIX ? EvalFloatTextureStack(sv, t.tex2, tc)
-                                : t.type == WF_TEX_SPECTRUM_DIRECTIONMIX ? AbsDot(tc.n, N3{t.map[4], t.map[5], t.map[6]}) : CheckerboardWeight(sv, t, tc);
-                fw[sp] = w;
-                fa[sp] = S4c(0.f);
-                if (w != 1) { fstate[sp] = 2; ++sp; fid[sp] = t.tex0; fstate[sp] = 0; continue; }
-                ret = S4c(0.f);
-                // falls to the "tex0 returned" step below with t0 = 0
-            } else { ret = S4c(0.f); --sp; continue; }
+            fa[sp] = S4c(0.f);
+            if (w != 1) { fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3; continue; }
+            ret = S4c(0.f);
+            // falls to the "tex0 returned" step below with t0 = 0
         }
-        if (t.type == WF_TEX_SPECTRUM_SCALE) {
+        if (type == WF_TEX_SPECTRUM_SCALE) {
             ret = ret * fw[sp];
             --sp;
             continue;
         }
         if (st != 3) {
             fa[sp] = ret;
-            if (fw[sp] != 0) { fstate[sp] = 3; ++sp; fid[sp] = t.tex1; fstate[sp] = 0; continue; }
+            if (fw[sp] != 0) { fnode[sp] = self | 3; fnode[++sp] = tp->tex1 << 3; continue; }
             ret = S4c(0.f);
         }
         {

@@ -1596,10 +1596,8 @@ int wf_sync(wf_ctx *ctx) {
         if (unresolved) return fail(-1, "a near-tie re-walk found no hit where the production walk had one (results are incomplete)");
         int fatal = 0;
         HIPCHK(hipMemcpy(&fatal, ctx->dbgWords + 7, sizeof(int), hipMemcpyDeviceToHost));
-        // the reference's LOG_FATAL inside a kernel body (shapes.cpp:736-760): a sample was drawn from an emissive curve
-        if (fatal == WF_FATAL_CURVE_SAMPLE) return fail(-1, "Curve::Sample not implemented.");
-        if (fatal == WF_FATAL_CURVE_PDF) return fail(-1, "Curve::PDF not implemented.");
-        if (fatal) return fail(-1, "fatal error %d raised by a kernel", fatal);
+        // the reference's LOG_FATAL / CHECK inside a kernel body (wf_scene.h: WF_FATAL_*), e.g. a sample drawn from an emissive curve
+        if (fatal) return fail(-1, "%s", FatalMessage(fatal));
         if (getenv("WF_DEBUG_DRAIN")) {
             int h[8];
             HIPCHK(hipMemcpy(h, ctx->dbgWords, sizeof(h), hipMemcpyDeviceToHost));

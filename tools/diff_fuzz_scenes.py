@@ -149,8 +149,12 @@ class Gen:
             elif kind == "bilerp":
                 out.append('Texture "%s" "float" "bilerp" "float v00" [ %s ] "float v01" [ %s ] "float v10" [ %s ] "float v11" [ %s ]' % (name, f(self.u()), f(self.u()), f(self.u()), f(self.u())))
             elif kind == "imagemap":
+                wrap = self.pick(["repeat", "clamp", "black", "octahedralsphere"])
+                # (an octahedral map addressed outside [0, 1]^2 by more than a texel makes the reference read past its pixel array,
+                #  util/image.h:100-121: undefined there — only the plain (u, v) mapping with it)
                 out.append('Texture "%s" "float" "imagemap" "string filename" "%s" "string filter" "%s" "string wrap" "%s"'
-                           % (name, os.path.join(GOLDEN, self.pick(["alpha.pfm", "bump.pfm", "png_grey8.png"])), self.pick(["bilinear", "point", "trilinear", "ewa"]), self.pick(["repeat", "clamp", "black", "octahedralsphere"])) + self.mapping())
+                           % (name, os.path.join(GOLDEN, self.pick(["alpha.pfm", "bump.pfm", "png_grey8.png"])), self.pick(["bilinear", "point", "trilinear", "ewa"]), wrap) +
+                           (' "string mapping" "uv"' if wrap == "octahedralsphere" else self.mapping()))
             else:
                 continue
             self.float_tex.append(name)
@@ -342,6 +346,15 @@ class Gen:
         if have_def:
             for _ in range(self.r.randrange(1, 4)):
                 out.append(self.placed('  ObjectInstance "thing"'))
+        if "fog" in self.media:
+            # A ray that travels in a medium and MISSES every surface is pushed by MediumSampleQueue::Push(RayWorkItem, tMax), which leaves the
+            # item's `depth` unwritten (wavefront/workitems.h:468-492): the reference then reads a stale depth and its image depends on
+            # the threads' push order.  With the camera inside a medium the scene is therefore closed by a far sphere: no ray misses.
+            solid = [m for m in self.materials if m[1] in ("diffuse", "conductor", "coateddiffuse", "diffusetransmission")]
+            if solid:
+                out.append('AttributeBegin\n  NamedMaterial "%s"\n  Shape "sphere" "float radius" [ 40 ]\nAttributeEnd' % self.pick(solid)[0])
+            else:
+                out.append('AttributeBegin\n  Material "diffuse"\n  Shape "sphere" "float radius" [ 40 ]\nAttributeEnd')
         return out
 
     def scene(self):
@@ -393,11 +406,24 @@ def main():
             else:
                 # is the reference itself deterministic here?  (it is not on medium transitions with an empty side: see
                 # tests/golden/open_partial_medium_interface.pbrt)
-                ro2 = os.path.join(work, "ref2.pfm")
+                ro2, ro3 = os.path.join(work, "ref2.pfm"), os.path.join(work, "ref3.pfm")
                 rs2, _ = render(REF, ["--wavefront", "--quiet", "--seed", "0", "--nthreads", "2"], path, ro2)
-                if rs2 == "ok" and not (read_pfm(ro2).view(np.uint32) == r.view(np.uint32)).all():
+                rs3, _ = render(REF, ["--wavefront", "--quiet", "--seed", "0", "--nthreads", "1"], path, ro3)
+                if (rs2 == "ok" and not (read_pfm(ro2).view(np.uint32) == r.view(np.uint32)).all()) or (rs3 == "ok" and not (read_pfm(ro3).view(np.uint32) == r.view(np.uint32)).all()):
                     stats["reference_nondeterministic"] = stats.get("reference_nondeterministic", 0) + 1
                     print("seed %d: the reference gives two different images in two runs (no parity target)" % seed, flush=True)
+                    os.unlink(path)
+                    continue
+                # The reference's MediumSampleQueue::Push(RayWorkItem, tMax) — the push of a ray that missed every surface — leaves the item's
+                # `depth` unwritten (wavefront/workitems.h:468-492): SampleMediumInteraction reads the depth of the slot's previous user, which
+                # depends on the order the threads push in.  Sequentially the port can reproduce it (wf_cpu --emulate-stale-medium-depth):
+                # a difference that goes away under it is the reference's order dependence, not a parity bug.
+                ro1, co1 = os.path.join(work, "ref1.pfm"), os.path.join(work, "cpu1.pfm")
+                rs1, _ = render(REF, ["--wavefront", "--quiet", "--seed", "0", "--nthreads", "1"], path, ro1)
+                cs1, _ = render(CPU, ["--quiet", "--emulate-stale-medium-depth"], path, co1)
+                if rs1 == "ok" and cs1 == "ok" and (read_pfm(ro1).view(np.uint32) == read_pfm(co1).view(np.uint32)).all():
+                    stats["reference_stale_medium_depth"] = stats.get("reference_stale_medium_depth", 0) + 1
+                    print("seed %d: differs only through the reference's unwritten MediumSampleWorkItem::depth (identical under sequential emulation)" % seed, flush=True)
                     os.unlink(path)
                     continue
                 verdict = "MISMATCH"
@@ -405,6 +431,10 @@ def main():
                     d = np.abs(r - c) / np.maximum(np.abs(r), 1e-2)
                     verdict += " max rel %.3g, %.2f %% of values differ" % (d.max(), 100 * (r.view(np.uint32) != c.view(np.uint32)).mean())
                 stats["mismatch"] += 1
+        elif rs == "timeout":
+            # (the reference needed more than five minutes — loop subdivision of an absurd level, a lens system traced over a huge film — : no verdict)
+            stats["reference_timeout"] = stats.get("reference_timeout", 0) + 1
+            print("seed %d: reference timeout, port %s" % (seed, cs), flush=True)
         elif rs != "ok" and cs != "ok":
             stats["both_refuse"] += 1
             if rs.startswith("error(-") or rs == "timeout":   # the reference crashed: not a refusal; say so
