@@ -276,7 +276,10 @@ def main():
     if dist is not None:
         scene.film_to_tensor(film_t)
         t_copy = time.perf_counter() - t0 - t_render
-        multigpu.reduce_film(film_t, dist, 0)
+        if a.partition == "strips":
+            multigpu.gather_film(film_t, dist, rank, world, 0)   # every rank sends only its own scanlines: 1 / world of the film
+        else:
+            multigpu.reduce_film(film_t, dist, 0)
         torch.cuda.synchronize()
         t_reduce = time.perf_counter() - t0 - t_render - t_copy
     barrier()

@@ -683,6 +683,12 @@ int wf_film_gbuffer_download(wf_ctx *ctx, wf_gbuffer_pixel *dst /* [H][W] */);
 int wf_film_device_ptr(wf_ctx *ctx, void **dptr, uint64_t *nbytes); /* for the RCCL film reduce */
 int wf_film_upload(wf_ctx *ctx, const double *rgb_sum_weight);
 int wf_film_copy_to_device(wf_ctx *ctx, void *dst_device);         /* D2D, wf_film_device_ptr's size */
+/* The gather of a strip-partitioned render inside one process (pbrt_amd --gpus N: one context and one host thread per device,
+   SURVEY 8(b) / 8(e)): copies the scanline strips `src` owns (wf_set_strips) from its film into `dst`'s — hipMemcpyPeerAsync over xGMI
+   between devices, device-to-device on one device; 1/N of the film per rank.  Both contexts hold the same scene and are idle.
+   wf_stats_add: src's ray counters added to dst's. */
+int wf_film_gather_strips(wf_ctx *dst, wf_ctx *src);
+int wf_stats_add(wf_ctx *dst, wf_ctx *src);
 int wf_film_copy_from_device(wf_ctx *ctx, const void *src_device);
 int wf_stats_download(wf_ctx *ctx, wf_render_stats *out);
 int wf_profile_report(wf_ctx *ctx, wf_kernel_profile_entry *entries, int max_entries, int *n_out);

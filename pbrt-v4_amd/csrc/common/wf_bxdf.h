@@ -290,7 +290,12 @@ struct DielectricBxDF {
                 float denom = Sqr(Dot(wi, wm) + Dot(wo, wm) / etap);
                 float dwm_dwi = AbsDot(wi, wm) / denom;
                 pdf = mfDistrib.PDF(wo, wm) * dwm_dwi * pt / (pr + pt);
-                if (pdf != pdf && fatal) *fatal = WF_FATAL_CHECK_NAN_PDF;   // CHECK(!IsNaN(pdf)), bxdfs.cpp:158 (a negative roughness gets here)
+                // CHECK(!IsNaN(pdf)), bxdfs.cpp:158 (a negative roughness gets here); raised as RaiseFatal does (wf_scene.h)
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (pdf != pdf) atomicOr(fatal, (int)WF_FATAL_CHECK_NAN_PDF);
+#else
+                if (pdf != pdf && fatal) *fatal = WF_FATAL_CHECK_NAN_PDF;
+#endif
                 S4 ft = S4c(T * mfDistrib.D(wm) * mfDistrib.G(wo, wi) *
                             abs(Dot(wi, wm) * Dot(wo, wm) / (CosTheta(wi) * CosTheta(wo) * denom)));
                 if (mode == MODE_RADIANCE) ft = ft / Sqr(etap);

@@ -79,15 +79,23 @@ struct SceneView {
     // (the CPU checker: the end of its render) turns the code into the reference's fatal error.  Null: nothing to report to.
     int32_t *fatal;
 };
-enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2,
-       WF_FATAL_CHECK_HAIR = 3,      // HairBxDF ctor: CHECK(h >= -1 && h <= 1) / beta_m / beta_n (bxdfs.cpp:278-280)
-       WF_FATAL_CHECK_NAN_PDF = 4 }; // DielectricBxDF::Sample_f: CHECK(!IsNaN(pdf)) of the rough transmission (bxdfs.cpp:158)
+enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2,   // (bit flags: several may be raised in one render)
+       WF_FATAL_CHECK_HAIR = 4,      // HairBxDF ctor: CHECK(h >= -1 && h <= 1) / beta_m / beta_n (bxdfs.cpp:278-280)
+       WF_FATAL_CHECK_NAN_PDF = 8 }; // DielectricBxDF::Sample_f: CHECK(!IsNaN(pdf)) of the rough transmission (bxdfs.cpp:158)
 WF_HD const char *FatalMessage(int code) {
-    return code == WF_FATAL_CURVE_SAMPLE ? "Curve::Sample not implemented." : code == WF_FATAL_CURVE_PDF ? "Curve::PDF not implemented."
-           : code == WF_FATAL_CHECK_HAIR ? "Check failed: h >= -1 && h <= 1 (HairBxDF)" : code == WF_FATAL_CHECK_NAN_PDF ? "Check failed: !IsNaN(pdf) (DielectricBxDF::Sample_f)"
+    return (code & WF_FATAL_CURVE_SAMPLE) ? "Curve::Sample not implemented." : (code & WF_FATAL_CURVE_PDF) ? "Curve::PDF not implemented."
+           : (code & WF_FATAL_CHECK_HAIR) ? "Check failed: h >= -1 && h <= 1 (HairBxDF)" : (code & WF_FATAL_CHECK_NAN_PDF) ? "Check failed: !IsNaN(pdf) (DielectricBxDF::Sample_f)"
            : "fatal error raised by a kernel";
 }
+// On the device the flag is raised with an atomic and WITHOUT a null test (the back end always allocates the word).  The obvious form,
+// `if (sv.fatal) *sv.fatal = code;`, inlined into the light-sampling code of the material kernels, made k_eval_material<1, 0> corrupt memory
+// (round 4: cornell64 rendered a different image on every run and one build faulted; the same source with this body, with the store
+// through sv.self->fatal, or without the call in SphereSample / SpherePDF is bit-identical and repeatable — DESIGN.md 4.2).
+#if defined(__HIP_DEVICE_COMPILE__)
+WF_HD void RaiseFatal(const SceneView &sv, int code) { atomicOr(sv.fatal, code); }
+#else
 WF_HD void RaiseFatal(const SceneView &sv, int code) { if (sv.fatal) *sv.fatal = code; }
+#endif
 
 // SobolMatrices32 dimensions 0 and 1 (util/sobolmatrices.cpp:40-58).  Dimension 0 is the van der Corput
 // identity matrix, dimension 1 the Pascal-triangle matrix v[i] = v[i-1] ^ (v[i-1] >> 1); both are padded

@@ -142,6 +142,11 @@ struct RayWalk {
     float b0, b1, b2;
     int inst;        // instance the hit primitive was reached through (-1: top level); only the INST kernel variants use it
     int curInst;     // instance whose definition is being walked (-1: top level)
+    // (round 4, WF_LAZY_INST) what of the per-ray state is still owed for the space being walked: 0 nothing; 1 inside an instance whose
+    // ray so far is the reference's transform WITHOUT its interval-arithmetic origin shift — good for the conservative box tests, not
+    // for a primitive test: o, the shear and tMax are made exact (WalkMakeExact) when a leaf holds one; 2 back at the top level with
+    // the shear of the render-space ray not recomputed yet
+    int lazy;
 };
 
 // Per-ray constants of the box test.  Bounds3::IntersectP (util/vecmath.h:1574-1608) computes, per axis,
@@ -154,12 +159,11 @@ struct RayWalk {
 #ifndef WF_SLAB_RCP
 #define WF_SLAB_RCP 1
 #endif
-__device__ inline void WalkSetRay(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
+// the slab constants alone (the box tests' part of the per-ray state)
+__device__ inline void WalkSetSlab(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
     constexpr float SLACK = 0x1p-20f;            // 16 ulp
     constexpr float G = 1 + 2 * gamma(3);        // the reference's tMax factor
     constexpr float INV_MAX = 1e28f;             // |1/d| clamp: keeps every product finite (no 0 * inf NaNs)
-    w.o = o;
-    w.sh = MakeRayShear(d);
     const float dd[3] = {d.x, d.y, d.z}, oo[3] = {o.x, o.y, o.z};
     float a[3], bn[3], af[3], bf[3];
     uint32_t sel[3];
@@ -178,6 +182,11 @@ __device__ inline void WalkSetRay(const float base[3], const float cell[3], RayW
     w.af = V3{af[0], af[1], af[2]}; w.bf = V3{bf[0], bf[1], bf[2]};
     w.selx = sel[0]; w.sely = sel[1]; w.selz = sel[2];
 }
+__device__ inline void WalkSetRay(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
+    w.o = o;
+    w.sh = MakeRayShear(d);
+    WalkSetSlab(base, cell, w, o, d);
+}
 __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, float tMax) {
     WalkSetRay(bvh.base, bvh.cell, w, o, d);
     w.tMax = tMax;
@@ -187,6 +196,7 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     w.b0 = w.b1 = w.b2 = 0;
     w.inst = -1;
     w.curInst = -1;
+    w.lazy = 0;
 }
 // Switch the lane into / out of an object instance (see the header comment).  oW, dW: the ray in render space.
 // Returns false when the instance is skipped.  (Round 3) The top-level leaf that holds an instance only says that the ray meets the
@@ -198,6 +208,9 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
 // (a few ulps of the coordinates plus the interval-width shift of the origin, util/transform.h:416-429).  The reference's own
 // root test (Bounds3::IntersectP on the exact box with the exactly transformed ray) cannot pass where this one fails, so skipping
 // changes no result.  Non-affine matrices (bottom row not 0 0 0 1) are never skipped.
+#ifndef WF_LAZY_INST
+#define WF_LAZY_INST 0   // measured on the spec scene, 16 spp, same box (gpurun_out/r04e, r04f): closest / any-hit 45.0 / 23.0 ms without, 49.4 / 26.1 with (exactified inside the leaf loop), 52.9 / 27.0 with the exactification parked like a transition: off
+#endif
 #ifndef WF_INST_PRETEST
 #define WF_INST_PRETEST 0   // measured on the spec scene (gpurun_out/r3e_ab_sm16.txt): closest 56.8 vs 56.5 ms, any-hit 22.9 vs 21.7 ms per 16 spp with / without — the entries it saves are too few to pay for the test; off
 #endif
@@ -240,6 +253,33 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
         return false;
     }
 #endif
+#if WF_LAZY_INST
+    {
+        // Round 4: the LAZY transition.  Eight instances are entered per ray on the spec scene, and three of four visits end without a
+        // single primitive test (3.2 triangle tests per ray in all) — yet every one paid the reference's interval-arithmetic ray
+        // transform, the triangle test's shear (two IEEE divisions) and the same again on the way out.  Transform::ApplyInverse(Ray,
+        // &tMax) (util/transform.h:416-429) = the plain transform of origin and direction, then the origin moved ALONG the ray by
+        // dt (the interval width over |d|) and tMax reduced by dt.  A ray whose origin slides along its own line meets every box at
+        // parameters shifted by exactly dt: with the UNSHIFTED origin and the unshifted (render-space) tMax the box tests prune
+        // nothing the reference's would keep (entry <= exit and entry <= tMax are the same comparisons, exit >= 0 is weaker by
+        // dt).  So the visit starts with the two plain transforms — the reference's own expressions, InstanceRay's first half —
+        // and the slab constants; the exact ray, its shear and the shifted tMax follow only if a leaf of the definition holds a
+        // primitive to test (WalkMakeExact), which also rebuilds the slab constants from the exact origin.
+        const float(*mi)[4] = in.render_from_instance.mInv;
+        if (mi[3][0] == 0 && mi[3][1] == 0 && mi[3][2] == 0 && mi[3][3] == 1) {   // (a projective instance matrix divides by w: exact path)
+            const V3 oI{(mi[0][0] * oW.x + mi[0][1] * oW.y) + (mi[0][2] * oW.z + mi[0][3]), (mi[1][0] * oW.x + mi[1][1] * oW.y) + (mi[1][2] * oW.z + mi[1][3]),
+                        (mi[2][0] * oW.x + mi[2][1] * oW.y) + (mi[2][2] * oW.z + mi[2][3])};
+            const V3 dI = XfVector3(mi, dW);
+            st.push((int)FloatToBits(w.tMax));
+            st.push(NODE_EXIT);
+            WalkSetSlab(fd.base, fd.cell, w, oI, dI);
+            w.curInst = inst;
+            w.node = fd.root;
+            w.lazy = 1;
+            return true;
+        }
+    }
+#endif
     float tI = __builtin_fabsf(w.tMax);
     V3 oI, dI;
     InstanceRay(in, oW, dW, &tI, &oI, &dI);
@@ -249,7 +289,25 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
     w.tMax = (FloatToBits(w.tMax) >> 31) ? -tI : tI;
     w.curInst = inst;
     w.node = fd.root;
+    w.lazy = 0;
     return true;
+}
+// the per-ray state a primitive test needs, made exact for the space being walked (RayWalk::lazy); oW, dW: the render-space ray
+__device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 dW) {
+    if (w.lazy == 1) {
+        const wf_instance &in = bvh.instances[w.curInst];
+        const FastDef fd = bvh.defs[in.def];
+        // no primitive of this visit has been tested yet: |w.tMax| is still the render-space bound the visit started with
+        float tI = __builtin_fabsf(w.tMax);
+        V3 oI, dI;
+        InstanceRay(in, oW, dW, &tI, &oI, &dI);
+        WalkSetRay(fd.base, fd.cell, w, oI, dI);
+        w.tMax = (FloatToBits(w.tMax) >> 31) ? -tI : tI;
+    } else {
+        w.o = oW;
+        w.sh = MakeRayShear(dW);
+    }
+    w.lazy = 0;
 }
 template <typename Stack>
 __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW) {
@@ -258,7 +316,12 @@ __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V
     // si->tHit (cpu/primitive.cpp:112-125); otherwise the world tMax is restored.  Near-tie marks are kept either way.
     const float tW = (w.inst == w.curInst) ? __builtin_fabsf(w.tMax) : __builtin_fabsf(saved);
     const bool mark = ((FloatToBits(w.tMax) | FloatToBits(saved)) >> 31) != 0;
+#if WF_LAZY_INST
+    WalkSetSlab(bvh.base, bvh.cell, w, oW, dW);   // the shear of the render-space ray when a top-level leaf asks for it (WalkMakeExact)
+    w.lazy = 2;
+#else
     WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
+#endif
     w.tMax = mark ? -tW : tW;
     w.curInst = -1;
     w.node = st.empty() ? NODE_NONE : st.pop();
@@ -371,6 +434,7 @@ __device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, c
 struct NoExtra {
     __device__ bool accept(int, float, float, float) const { return true; }
     __device__ bool sphere(int, float, QuadricHit *) const { return false; }
+    __device__ void exact(RayWalk &) const {}
 };
 template <bool ANY, bool ALPHA = false, bool INST = false, typename Stack, typename Extra = NoExtra>
 __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const Extra &ex = Extra()) {
@@ -386,6 +450,8 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
                 st.push((int)~(((unsigned)INST_FIRST + FloatToBits(tc.y)) << 4));
                 continue;
             }
+        if constexpr (INST)
+            if (w.lazy) ex.exact(w);   // the first primitive test since the walk changed spaces (WF_LAZY_INST)
         // closest hit: test against the relaxed bound so that near-ties are seen (WalkAccept sorts them out)
         const float tTest = ANY ? w.tMax : WalkBound(bvh, __builtin_fabsf(w.tMax));
         if constexpr (ALPHA)

@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
 
 namespace wf {
 
@@ -133,5 +136,53 @@ double WavefrontRenderer::Render(int sampleBegin, int sampleEnd, int sampleStep,
 void WavefrontRenderer::DownloadFilm(double *dst) { Check(wf_film_download(ctx, dst), "wf_film_download"); }
 void WavefrontRenderer::UploadFilm(const double *src) { Check(wf_film_upload(ctx, src), "wf_film_upload"); }
 void WavefrontRenderer::Stats(wf_render_stats *s) { Check(wf_stats_download(ctx, s), "wf_stats_download"); }
+
+MultiDeviceRenderer::MultiDeviceRenderer(const SceneTables &tables, const std::vector<int> &devices, int samplesPerPass, int stripHeight) {
+    const int n = (int)devices.size();
+    if (n < 1) throw SceneError("Fatal: MultiDeviceRenderer: no devices");
+    renderers.resize(n, nullptr);
+    // every context is created on the thread that will drive it later?  Not needed: the C ABI makes the context's device current in the
+    // calling thread at every entry (wf_backend.hip: useDevice).  The uploads run concurrently, one thread per device.
+    std::vector<std::thread> th;
+    std::vector<std::string> err(n);
+    for (int k = 0; k < n; ++k)
+        th.emplace_back([&, k]() {
+            try { renderers[k] = new WavefrontRenderer(tables, devices[k], samplesPerPass, k, n, stripHeight); } catch (const std::exception &e) { err[k] = e.what(); }
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n; ++k)
+        if (!err[k].empty()) {
+            for (WavefrontRenderer *r : renderers) delete r;
+            throw SceneError(err[k]);
+        }
+}
+
+MultiDeviceRenderer::~MultiDeviceRenderer() {
+    for (WavefrontRenderer *r : renderers) delete r;
+}
+
+double MultiDeviceRenderer::Render(int sampleBegin, int sampleEnd, std::vector<double> *perDevice) {
+    const int n = (int)renderers.size();
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<double> secs(n + 1, 0.0);
+    std::vector<std::string> err(n);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; ++k)
+        th.emplace_back([&, k]() {
+            try { secs[k] = renderers[k]->Render(sampleBegin, sampleEnd, 1); } catch (const std::exception &e) { err[k] = e.what(); }
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n; ++k)
+        if (!err[k].empty()) throw SceneError(err[k]);
+    auto tg = std::chrono::steady_clock::now();
+    for (int k = 1; k < n; ++k) {
+        Check(wf_film_gather_strips(renderers[0]->Context(), renderers[k]->Context()), "wf_film_gather_strips");
+        Check(wf_stats_add(renderers[0]->Context(), renderers[k]->Context()), "wf_stats_add");
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    secs[n] = std::chrono::duration<double>(t1 - tg).count();
+    if (perDevice) *perDevice = secs;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
 
 }  // namespace wf

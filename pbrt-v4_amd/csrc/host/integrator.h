@@ -37,4 +37,24 @@ class WavefrontRenderer {
     int rowsPerPass = 0;   // local rows one pass covers (the queues hold rowsPerPass x width x samplesPerPass items)
 };
 
+// Multi-GPU rendering inside ONE process (SURVEY 8(b) "one host thread per device", 8(e) "image tiled across the GPUs"; the reference
+// has nothing here: gpu/util.cpp:80-85 is one cudaSetDevice).  The scene tables are replicated, device k of `devices` owns the scanline
+// strips k, k + N, ... of 16 lines (wf_set_strips: interleaved, so that sky and foliage are dealt evenly) and renders them from a host
+// thread of its own, nothing is exchanged during rendering, and the strips are then copied peer to peer into the first device's film
+// (wf_film_gather_strips: 1/N of the film per device).  Every pixel's accumulators are formed on one device in the single-device
+// order: the gathered film is BIT-IDENTICAL to a single-device render.  `devices` may name one device several times (several
+// contexts on one GPU: how the path is tested on a one-GPU box).
+class MultiDeviceRenderer {
+  public:
+    MultiDeviceRenderer(const SceneTables &tables, const std::vector<int> &devices, int samplesPerPass = 0, int stripHeight = 16);
+    ~MultiDeviceRenderer();
+    // wall seconds of the slowest device + the gather; perDevice (optional): render seconds of every device, gather seconds last
+    double Render(int sampleBegin, int sampleEnd, std::vector<double> *perDevice = nullptr);
+    WavefrontRenderer &Primary() { return *renderers[0]; }   // holds the gathered film and the summed statistics after Render()
+    int Count() const { return (int)renderers.size(); }
+
+  private:
+    std::vector<WavefrontRenderer *> renderers;
+};
+
 }  // namespace wf

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,9 @@ static void usage() {
             "  --seed <n>             random seed\n"
             "  --outfile <file>       output image (.pfm or .exr)\n"
             "  --gpu-device <n>       HIP device index (default 0)\n"
+            "  --gpus <n>             render on HIP devices 0 .. n-1: the image in interleaved 16-line strips, one host thread per device,\n"
+            "                         the strips gathered peer to peer into device 0's film (bit-identical to one device)\n"
+            "  --gpu-devices a,b,...  the same on the listed devices (one may be named several times: several contexts on one GPU)\n"
             "  --pixelbounds x0,x1,y0,y1 / --cropwindow x0,x1,y0,y1\n"
             "  --disable-pixel-jitter / --disable-wavelength-jitter / --disable-texture-filtering\n"
             "  --displacement-edge-scale <s>   scale the target edge length of displaced meshes\n"
@@ -42,6 +46,7 @@ static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dataDir;
     int device = 0;
+    std::vector<int> devices;   // --gpus / --gpu-devices: more than one entry = the multi-device renderer
     bool stats = false;
     int debugFirst = -1, debugCount = 1;   // --debugstart
     for (int i = 1; i < argc; ++i) {
@@ -56,7 +61,22 @@ static int Main(int argc, char **argv) {
         if (is("--spp")) opt.pixelSamples = atoi(value().c_str());
         else if (is("--seed")) opt.seed = atoi(value().c_str());
         else if (is("--outfile")) opt.imageFile = value();
-        else if (is("--gpu-device")) device = atoi(value().c_str());
+        else if (is("--gpu-devices")) {
+            devices.clear();
+            const std::string v = value();
+            for (size_t p = 0; p < v.size();) {
+                size_t q = v.find(',', p);
+                if (q == std::string::npos) q = v.size();
+                devices.push_back(atoi(v.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+            if (devices.empty()) { usage(); return 1; }
+        } else if (is("--gpus")) {
+            const int n = atoi(value().c_str());
+            if (n < 1) { usage(); return 1; }
+            devices.clear();
+            for (int k = 0; k < n; ++k) devices.push_back(k);
+        } else if (is("--gpu-device")) device = atoi(value().c_str());
         else if (is("--datadir")) dataDir = value();
         else if (is("--pixelbounds")) {
             if (sscanf(value().c_str(), "%d,%d,%d,%d", &opt.pixelBounds[0], &opt.pixelBounds[1], &opt.pixelBounds[2], &opt.pixelBounds[3]) != 4) { usage(); return 1; }
@@ -110,10 +130,27 @@ static int Main(int argc, char **argv) {
     const wf_film &F = T.desc.film;
     const int W = F.pixel_max[0] - F.pixel_min[0], H = F.pixel_max[1] - F.pixel_min[1];
 
-    WavefrontRenderer renderer(T, device);
-    if (stats) wf_profile_enable(renderer.Context(), 1);
     const int firstSample = debugFirst >= 0 ? debugFirst : 0, lastSample = debugFirst >= 0 ? debugFirst + debugCount : T.spp;
-    double seconds = renderer.Render(firstSample, lastSample, 1);
+    std::unique_ptr<MultiDeviceRenderer> multi;
+    std::unique_ptr<WavefrontRenderer> single;
+    double seconds;
+    if (devices.size() > 1) {
+        if (F.type != WF_FILM_RGB) { fprintf(stderr, "Error: --gpus: only the \"rgb\" film is gathered across devices\n"); return 1; }
+        multi.reset(new MultiDeviceRenderer(T, devices));
+        if (stats) wf_profile_enable(multi->Primary().Context(), 1);
+        std::vector<double> per;
+        seconds = multi->Render(firstSample, lastSample, &per);
+        if (!opt.quiet) {
+            fprintf(stderr, "Rendering on %d devices:", (int)devices.size());
+            for (size_t k = 0; k + 1 < per.size(); ++k) fprintf(stderr, " [%d] %.3f s", devices[k], per[k]);
+            fprintf(stderr, ", gather %.4f s\n", per.back());
+        }
+    } else {
+        single.reset(new WavefrontRenderer(T, devices.empty() ? device : devices[0]));
+        if (stats) wf_profile_enable(single->Context(), 1);
+        seconds = single->Render(firstSample, lastSample, 1);
+    }
+    WavefrontRenderer &renderer = multi ? multi->Primary() : *single;
     if (!opt.quiet) fprintf(stderr, "Rendering finished: %.3f s, %.2f Msamples/s\n", seconds, (double)W * H * (lastSample - firstSample) / seconds / 1e6);
     if (stats) {
         wf_render_stats st;

@@ -32,6 +32,29 @@ def render_partition(scene, rank, world, sample_begin, sample_end, partition="st
     raise ValueError("unknown partition %r" % partition)
 
 
+def gather_film(film, dist, rank, world, dst=0, strip=STRIP_HEIGHT):
+    """The exchange of the strip partition: every rank sends ONLY the scanlines it owns (H / world of them: 1 / world of the film —
+    the reduce(SUM) of full films this replaces moved `world` films of mostly zeros) and rank `dst` puts them in place.
+    film: the rank's [H, W, 4] float64 accumulators as a torch tensor (CUDA for nccl = RCCL, CPU for gloo); after the call rank `dst`
+    holds the whole image's film, bit-identical to a single-GPU render (no arithmetic: rows are copied).  The collective is issued
+    even at world size 1 (a one-rank RCCL gather), so that a single-GPU box exercises the library path."""
+    import torch
+    if dist is None:
+        return film
+    H = film.shape[0]
+    rows = [torch.as_tensor(strip_rows(r, world, H, strip), device=film.device) for r in range(world)]
+    most = max(len(r) for r in rows)
+    mine = torch.zeros((most,) + tuple(film.shape[1:]), dtype=film.dtype, device=film.device)   # equal-sized pieces: ranks own 67 or 68 strips' worth
+    mine[:len(rows[rank])] = film.index_select(0, rows[rank])
+    pieces = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, pieces, dst=dst)
+    if rank == dst:
+        for r in range(world):
+            if r != dst:
+                film.index_copy_(0, rows[r], pieces[r][:len(rows[r])])
+    return film
+
+
 def reduce_film(film, dist, dst=0):
     """film: the rank's [H, W, 4] float64 accumulators as a torch tensor (CUDA for nccl, CPU for gloo).  After the call rank
     `dst` holds the whole image's film.  With the strip partition the addends of every element are zero on all ranks but one."""

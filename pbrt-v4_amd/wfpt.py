@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "wf_medium_sample", "wf_intersect_shadow_tr", "wf_subsurface_probe", "wf_intersect_one_random", "wf_subsurface_scatter", "wf_trace_one_random_host", "wf_morton_sort", "wf_build_bvh_sah", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_set_strips", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
     "wf_gen_camera_rays", "wf_gen_ray_samples", "wf_intersect_closest", "wf_handle_escaped", "wf_handle_emissive",
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
-    "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_stats_download",
+    "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_film_gather_strips", "wf_stats_add", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_kat_probe", "wf_queue_size", "wf_queue_download",
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",

@@ -43,7 +43,8 @@ WORKER = textwrap.dedent("""
     if partition == "strips":
         owned = np.where(s.film[..., 3].numpy().sum(axis=1) > 0)[0]
         assert (owned == multigpu.strip_rows(rank, world, H)).all(), (rank, owned)
-    film = multigpu.reduce_film(s.film, dist, 0)
+    # strips: every rank sends only its own scanlines (gather_film); samples: a true sum (reduce_film)
+    film = multigpu.gather_film(s.film, dist, rank, world, 0) if partition == "strips" else multigpu.reduce_film(s.film, dist, 0)
     if rank == 0:
         film.numpy().tofile(os.path.join(outdir, "film_%s_sum.bin" % partition))
     dist.barrier()
@@ -87,7 +88,7 @@ def test_strip_rows_partition_the_image():
 def test_strip_partition_film_reduce_gloo(built, tmp_path):
     a, b = _run(tmp_path, "strips", os.path.join(GOLDEN, "instances.pbrt"))
     assert a.shape == b.shape == (64 * 96 * 4,)
-    assert (a.view(np.uint64) == b.view(np.uint64)).all()   # disjoint strips: the reduce is a gather
+    assert (a.view(np.uint64) == b.view(np.uint64)).all()   # disjoint strips, rows copied into place: no arithmetic at all
     assert (a.reshape(-1, 4)[:, 3] > 0).all()
 
 

@@ -40,7 +40,7 @@ def test_triangle_golden_covers_hits_misses_edges():
     assert np.allclose(b.sum(axis=1), 1, atol=1e-5)
 
 
-@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("blobs_small", 4), ("materials_lights", 4), ("materials_lights_power", 4), ("media_box", 4), ("rgbgrid_medium", 4), ("tempgrid_medium", 4), ("envmap", 4), ("textures_bump", 4), ("spherical_camera", 4), ("image_textures", 4), ("alpha_normalmap", 4), ("spheres", 4), ("quadrics", 4), ("lights_extra", 4), ("texture_mappings", 4), ("textures_extra", 4), ("textures_deep", 4), ("arealight_image", 4), ("instances", 4), ("subsurface", 4), ("blobs_hlbvh", 4), ("textures_noise", 4), ("cloud_medium", 4), ("media_instances", 4), ("hair", 4), ("measured", 4), ("bilinear", 4), ("bilinear_lights", 4), ("instances_quadrics", 4), ("media_preset", 4), ("subsurface_named", 4), ("arealight_alpha", 4), ("png_textures", 4), ("textures_ewa", 4), ("curves", 4), ("realistic_camera", 4), ("realistic_camera_star", 4), ("portal_light", 4), ("portal_uniform", 4), ("loopsubdiv", 4), ("film_whitebalance", 4), ("film_sensor", 4), ("film_sensor_wb", 4), ("displacement", 4), ("plymesh_mixed", 4), ("camera_motion", 4), ("camera_motion_spherical", 4), ("rendercoordsys_camera", 4), ("rendercoordsys_world", 4), ("parser_torture", 4), ("empty_scene", 4), ("quadrics_alpha", 4), ("goniometric_png", 4),
+@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("cornell400", 16), ("blobs_small", 4), ("materials_lights", 4), ("materials_lights_power", 4), ("media_box", 4), ("rgbgrid_medium", 4), ("tempgrid_medium", 4), ("envmap", 4), ("textures_bump", 4), ("spherical_camera", 4), ("image_textures", 4), ("alpha_normalmap", 4), ("spheres", 4), ("quadrics", 4), ("lights_extra", 4), ("texture_mappings", 4), ("textures_extra", 4), ("textures_deep", 4), ("arealight_image", 4), ("instances", 4), ("subsurface", 4), ("blobs_hlbvh", 4), ("textures_noise", 4), ("cloud_medium", 4), ("media_instances", 4), ("hair", 4), ("measured", 4), ("bilinear", 4), ("bilinear_lights", 4), ("instances_quadrics", 4), ("media_preset", 4), ("subsurface_named", 4), ("arealight_alpha", 4), ("png_textures", 4), ("textures_ewa", 4), ("curves", 4), ("realistic_camera", 4), ("realistic_camera_star", 4), ("portal_light", 4), ("portal_uniform", 4), ("loopsubdiv", 4), ("film_whitebalance", 4), ("film_sensor", 4), ("film_sensor_wb", 4), ("displacement", 4), ("plymesh_mixed", 4), ("camera_motion", 4), ("camera_motion_spherical", 4), ("rendercoordsys_camera", 4), ("rendercoordsys_world", 4), ("parser_torture", 4), ("empty_scene", 4), ("quadrics_alpha", 4), ("goniometric_png", 4),
                                        ("cornell64_independent", 0), ("cornell64_stratified", 0), ("cornell64_paddedsobol", 0), ("cornell64_halton", 0), ("cornell64_sobol", 0), ("cornell64_sobol_owen", 0)])
 def test_cpu_checker_image_matches_reference_wavefront(built, tmp_path, scene, spp):
     """Whole path, sample-aligned: oracle/wf_cpu vs the reference's CPU WavefrontPathIntegrator
@@ -151,3 +151,17 @@ def test_partial_medium_interface_is_deterministic_here(built, tmp_path):
         assert j["indirect_rays"][1:6] == [865, 215, 111, 48, 19]
         imgs.append(read_pfm(out).copy())
     assert all((im.view(np.uint32) == imgs[0].view(np.uint32)).all() for im in imgs)
+
+
+# the fuzz corpus of the GPU leg (tests/golden/fuzz, tools/make_fuzz_goldens.py): the CPU port reproduces the reference's renders bit for bit
+FUZZ = os.path.join(GOLDEN, "fuzz")
+
+
+def test_fuzz_corpus_cpu_port(built, tmp_path):
+    names = open(os.path.join(FUZZ, "CORPUS.txt")).read().split()
+    assert len(names) >= 40
+    for name in names:
+        out = str(tmp_path / "c.pfm")
+        run_wf_cpu(os.path.join(FUZZ, name + ".pbrt"), out, None)
+        ref, cpu = read_pfm(os.path.join(FUZZ, name + "_ref.pfm")), read_pfm(out)
+        assert ref.shape == cpu.shape and (ref.view(np.uint32) == cpu.view(np.uint32)).all(), name

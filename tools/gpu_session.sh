@@ -53,7 +53,7 @@ for step in "$@"; do
       for b in $ROOT/pbrt-v4_amd/_build $ROOT/pbrt-v4_amd/_exp*; do
         [ -x $b/pbrt_amd ] || continue
         echo "== $b" | tee -a $OUT/${TAG}_${SCENE}_${SPP}spp_stats.txt
-        timeout 200 $b/pbrt_amd --stats --spp $SPP --outfile /tmp/x.pfm $f 2>&1 | grep -E "Rendering|${GREP:-Intersect|material|Medium|Total GPU|Film|Generate|escaped|emissive|Route}" | tee -a $OUT/${TAG}_${SCENE}_${SPP}spp_stats.txt
+        timeout 200 $b/pbrt_amd --stats --spp $SPP --outfile /tmp/x.pfm $f 2>&1 | grep -E "Rendering|${GREP:-Intersect|Material|Medium|medium|Total GPU|film|Generate|escaped|emitters|Route|ransmittance}" | tee -a $OUT/${TAG}_${SCENE}_${SPP}spp_stats.txt
       done;;
     pmc)
       f=$(scene_file)
@@ -96,7 +96,7 @@ PY
       IFS=';' read -ra envs <<< "${AB:-WF_NONE=1}"
       for e in "${envs[@]}"; do
         echo "== $e" | tee -a $OUT/${TAG}_${SCENE}_ab.txt
-        env $e timeout 200 $ROOT/pbrt-v4_amd/_build/pbrt_amd --stats --spp $SPP --outfile /tmp/x.pfm $f 2>&1 | grep -E "Rendering|${GREP:-Intersect|material|Total GPU}" | tee -a $OUT/${TAG}_${SCENE}_ab.txt
+        env $e timeout 200 $ROOT/pbrt-v4_amd/_build/pbrt_amd --stats --spp $SPP --outfile /tmp/x.pfm $f 2>&1 | grep -E "Rendering|${GREP:-Intersect|Material|Total GPU}" | tee -a $OUT/${TAG}_${SCENE}_ab.txt
       done;;
     *) echo "unknown step $step";;
   esac
