@@ -672,11 +672,17 @@ WF_HD bool InsidePolkaDot(const SceneView &sv, const wf_texture &t, const TexCtx
 // tagged pointers; the device code has no recursion.  Until round 3 the walk was a template over the remaining depth, fully
 // inlined (three interior node types: the code grew ~7x per level and the bound was two interior levels; deeper graphs were
 // refused).  Since round 4 it is an EXPLICIT-STACK evaluator inside the out-of-line graph functions below: a frame per interior
-// node (node id | resume state, the weight, the first operand), WF_TEX_STACK frames (16: no production scene nests that deep), the same operations in the same order.
+// node (node id | resume state, the weight, the first operand), WF_TEX_STACK frames, the same operations in the same order.
 // (As part of the inlined material code an explicit stack had cost 470 spilled VGPRs; behind the call its arrays are the callee's
 // scratch and the kernels' register budgets do not see them.)  The host builder refuses graphs nested deeper than WF_TEX_STACK.
+// (16 frames.  Larger frame counts are not a free way around register pressure: with 48 frames — 2.6-2.9 KB of scratch per lane in
+// the material kernels — the arealight_image golden rendered a different image on every run on the GPU while 16 frames are repeatable and
+// bit-identical; the cause was not isolated, the kernels' scratch is kept small.)
 #ifndef WF_TEX_STACK
 #define WF_TEX_STACK 16
+#endif
+#ifndef WF_TEX_FRAMES_STRUCT
+#define WF_TEX_FRAMES_STRUCT 1
 #endif
 // the three texture types a production scene's parameters usually are: what the material kernels and the traversal kernels' alpha test
 // evaluate inline
@@ -704,27 +710,43 @@ WF_HD float EvalFloatTextureLeaf(const SceneView &sv, const wf_texture *tp, cons
 // texture returned; MIX / CHECKERBOARD / DIRECTIONMIX: 1 = the amount returned (MIX only), 2 = tex0 ("tex1" of the reference's mix,
 // weighted 1 - amt) returned, 3 = tex1 returned.  DOTS replaces its own frame by the chosen child (a tail call).
 WF_HD float EvalFloatTextureStack(const SceneView &sv, int id, const TexCtx &tc) {
+    // ONE array of mixed-type frames (WF_TEX_FRAMES_STRUCT = 1) rather than three scalar arrays: arrays of <= 128 bytes are turned into
+    // VGPR vectors by AMDGPU's promote-alloca pass — 48 VGPRs at 16 frames, in kernels that sit at their register ceiling — while an
+    // array of structs stays in scratch, where this cold path belongs.  Same box, spec scene, 16 spp (gpurun_out/r04j): diffuse /
+    // conductor / coated diffuse 18.9 / 6.0 / 19.1 ms with the scalar arrays, 20.4 / 5.2 / 16.1 ms with the frames (44.6 -> 42.1 ms
+    // with the dielectric kernel), equal ray counts.
+#if WF_TEX_FRAMES_STRUCT
+    struct Frame { int node; float w, a; };
+    Frame fr[WF_TEX_STACK];
+#define F_NODE(i) fr[i].node
+#define F_W(i) fr[i].w
+#define F_A(i) fr[i].a
+#else
     int fnode[WF_TEX_STACK];
     float fw[WF_TEX_STACK], fa[WF_TEX_STACK];
+#define F_NODE(i) fnode[i]
+#define F_W(i) fw[i]
+#define F_A(i) fa[i]
+#endif
     int sp = 0;
-    fnode[0] = id << 3;
+    F_NODE(0) = id << 3;
     float ret = 0;
     while (sp >= 0) {
-        const wf_texture *tp = sv.textures + (fnode[sp] >> 3);
+        const wf_texture *tp = sv.textures + (F_NODE(sp) >> 3);
         const int type = tp->type;
-        int st = fnode[sp] & 7;
+        int st = F_NODE(sp) & 7;
         if (st == 0) {
             if (IsLeafFloatTexture(type)) { ret = EvalFloatTextureLeaf(sv, tp, tc); --sp; continue; }
-            if (type == WF_TEX_FLOAT_DOTS) { fnode[sp] = (InsidePolkaDot(sv, *tp, tc) ? tp->tex1 : tp->tex0) << 3; continue; }
+            if (type == WF_TEX_FLOAT_DOTS) { F_NODE(sp) = (InsidePolkaDot(sv, *tp, tc) ? tp->tex1 : tp->tex0) << 3; continue; }
             if (sp + 1 >= WF_TEX_STACK) { ret = 0; --sp; continue; }   // (refused at load: never reached)
             if (type == WF_TEX_FLOAT_SCALE) {
                 // FloatScaledTexture::Evaluate, textures.h:1039-1044: the scale first
-                fnode[sp] |= 1; fnode[++sp] = tp->tex1 << 3;
+                F_NODE(sp) |= 1; F_NODE(++sp) = tp->tex1 << 3;
                 continue;
             }
             if (type == WF_TEX_FLOAT_MIX) {
                 // FloatMixTexture::Evaluate (textures.h:810-818): the amount first
-                fnode[sp] |= 1; fnode[++sp] = tp->tex2 << 3;
+                F_NODE(sp) |= 1; F_NODE(++sp) = tp->tex2 << 3;
                 continue;
             }
             if (type == WF_TEX_FLOAT_CHECKERBOARD || type == WF_TEX_FLOAT_DIRECTIONMIX) {
@@ -734,32 +756,32 @@ WF_HD float EvalFloatTextureStack(const SceneView &sv, int id, const TexCtx &tc)
                 st = 1;
             } else { ret = 0; --sp; continue; }
         }
-        const int self = fnode[sp] & ~7;
+        const int self = F_NODE(sp) & ~7;
         if (type == WF_TEX_FLOAT_SCALE) {
             if (st == 1) {
                 if (ret == 0) { --sp; continue; }   // returns 0
-                fw[sp] = ret; fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3;
+                F_W(sp) = ret; F_NODE(sp) = self | 2; F_NODE(++sp) = tp->tex0 << 3;
                 continue;
             }
-            ret = ret * fw[sp];
+            ret = ret * F_W(sp);
             --sp;
             continue;
         }
         // mix family
         if (st == 1) {
-            fw[sp] = ret;
-            fa[sp] = 0;
-            if (ret != 1) { fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3; continue; }
+            F_W(sp) = ret;
+            F_A(sp) = 0;
+            if (ret != 1) { F_NODE(sp) = self | 2; F_NODE(++sp) = tp->tex0 << 3; continue; }
             st = 2; ret = 0;
         }
         if (st == 2) {
-            fa[sp] = ret;
-            if (fw[sp] != 0) { fnode[sp] = self | 3; fnode[++sp] = tp->tex1 << 3; continue; }
+            F_A(sp) = ret;
+            if (F_W(sp) != 0) { F_NODE(sp) = self | 3; F_NODE(++sp) = tp->tex1 << 3; continue; }
             ret = 0;
         }
         {
-            const float w = fw[sp];
-            ret = (1 - w) * fa[sp] + w * ret;
+            const float w = F_W(sp);
+            ret = (1 - w) * F_A(sp) + w * ret;
         }
         --sp;
     }
@@ -797,20 +819,25 @@ WF_HD S4 EvalSpectrumTextureLeaf(const SceneView &sv, const wf_texture *tp, cons
 // The explicit-stack walk of a spectrum graph; float operands (a scale factor, a mix amount) are float graphs of their own
 // (EvalFloatTextureStack).  Frames and states as there.
 WF_HD S4 EvalSpectrumTextureStack(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
+#if WF_TEX_FRAMES_STRUCT
+    struct Frame { int node; float w; S4 a; };   // (one array of mixed-type frames: see EvalFloatTextureStack)
+    Frame fr[WF_TEX_STACK];
+#else
     int fnode[WF_TEX_STACK];
     float fw[WF_TEX_STACK];
     S4 fa[WF_TEX_STACK];
+#endif
     int sp = 0;
-    fnode[0] = id << 3;
+    F_NODE(0) = id << 3;
     S4 ret = S4c(0.f);
     while (sp >= 0) {
-        const wf_texture *tp = sv.textures + (fnode[sp] >> 3);
+        const wf_texture *tp = sv.textures + (F_NODE(sp) >> 3);
         const int type = tp->type;
-        const int st = fnode[sp] & 7;
-        const int self = fnode[sp] & ~7;
+        const int st = F_NODE(sp) & 7;
+        const int self = F_NODE(sp) & ~7;
         if (st == 0) {
             if (IsLeafSpectrumTexture(type)) { ret = EvalSpectrumTextureLeaf(sv, tp, lambda, tc); --sp; continue; }
-            if (type == WF_TEX_SPECTRUM_DOTS) { fnode[sp] = (InsidePolkaDot(sv, *tp, tc) ? tp->tex1 : tp->tex0) << 3; continue; }
+            if (type == WF_TEX_SPECTRUM_DOTS) { F_NODE(sp) = (InsidePolkaDot(sv, *tp, tc) ? tp->tex1 : tp->tex0) << 3; continue; }
             if (sp + 1 >= WF_TEX_STACK) { ret = S4c(0.f); --sp; continue; }   // (refused at load: never reached)
             // the node's float operand — SpectrumScaledTexture's scale (textures.h:1059-1064: evaluated first, 0 ends the node), the amount of
             // SpectrumMixTexture (:840-850), the checkerboard's (:404-413) or the direction mix's (:880-890) weight — from ONE call site:
@@ -820,35 +847,38 @@ WF_HD S4 EvalSpectrumTextureStack(const SceneView &sv, int id, const Wavelengths
             else if (type == WF_TEX_SPECTRUM_DIRECTIONMIX) w = AbsDot(tc.n, N3{tp->map[4], tp->map[5], tp->map[6]});
             else if (type == WF_TEX_SPECTRUM_CHECKERBOARD) w = CheckerboardWeight(sv, *tp, tc);
             else { ret = S4c(0.f); --sp; continue; }
-            fw[sp] = w;
+            F_W(sp) = w;
             if (type == WF_TEX_SPECTRUM_SCALE) {
                 if (w == 0) { ret = S4c(0.f); --sp; continue; }
-                fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3;
+                F_NODE(sp) = self | 2; F_NODE(++sp) = tp->tex0 << 3;
                 continue;
             }
-            fa[sp] = S4c(0.f);
-            if (w != 1) { fnode[sp] = self | 2; fnode[++sp] = tp->tex0 << 3; continue; }
+            F_A(sp) = S4c(0.f);
+            if (w != 1) { F_NODE(sp) = self | 2; F_NODE(++sp) = tp->tex0 << 3; continue; }
             ret = S4c(0.f);
             // falls to the "tex0 returned" step below with t0 = 0
         }
         if (type == WF_TEX_SPECTRUM_SCALE) {
-            ret = ret * fw[sp];
+            ret = ret * F_W(sp);
             --sp;
             continue;
         }
         if (st != 3) {
-            fa[sp] = ret;
-            if (fw[sp] != 0) { fnode[sp] = self | 3; fnode[++sp] = tp->tex1 << 3; continue; }
+            F_A(sp) = ret;
+            if (F_W(sp) != 0) { F_NODE(sp) = self | 3; F_NODE(++sp) = tp->tex1 << 3; continue; }
             ret = S4c(0.f);
         }
         {
-            const float w = fw[sp];
-            ret = (1 - w) * fa[sp] + w * ret;
+            const float w = F_W(sp);
+            ret = (1 - w) * F_A(sp) + w * ret;
         }
         --sp;
     }
     return ret;
 }
+#undef F_NODE
+#undef F_W
+#undef F_A
 WF_NI void EvalSpectrumTextureGraphP(const SceneView *svp, int id, const Wavelengths *lambda, const TexCtx *tc, S4 *out) {
     *out = EvalSpectrumTextureStack(*svp, id, *lambda, *tc);
 }

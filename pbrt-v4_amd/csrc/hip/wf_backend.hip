@@ -1218,6 +1218,9 @@ __global__ void __launch_bounds__(BLOCK) k_update_film_pm(const SceneView sv, Wo
 
 // stand-alone traversal for parity tests / counters: rays as packed {o[3], d[3], tMax}
 // onlyMarked: the re-trace pass after k_trace_closest_fast — only the records it marked as near-ties (nodes_visited == -1)
+#ifndef WF_DBG_RETRACED
+#define WF_DBG_RETRACED 0
+#endif
 __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int n, const float *rays, wf_hit_record *out, int *stackSpill, int onlyMarked) {
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
@@ -1230,7 +1233,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int
         wf_hit_record h;
         h.prim = found ? ch.prim : -1;
         h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;
-        h.nodes_visited = onlyMarked ? 0 : ch.nodesVisited; h.tris_tested = onlyMarked ? 0 : ch.trisTested; h.instance = found ? ch.inst : -1;
+        h.nodes_visited = onlyMarked ? WF_DBG_RETRACED : ch.nodesVisited; h.tris_tested = onlyMarked ? 0 : ch.trisTested; h.instance = found ? ch.inst : -1;
         out[i] = h;
     }
 }
@@ -1552,7 +1555,9 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     {
         double ext = 0;
         for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
-        out->absBand = (float)(0x1p-20 * ext);
+        const double band = d->n_quadrics > 0 ? 0x1p-10 : 0x1p-20;   // (FastBVH::tieRel: quadric hits are accepted by interval bounds)
+        out->absBand = (float)(band * ext);
+        out->tieRel = (float)(1 + band);
     }
     defs->clear();
     for (int k = 0; k < d->n_instance_defs; ++k) {

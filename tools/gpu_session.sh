@@ -32,7 +32,8 @@ for step in "$@"; do
   echo "=== $step"
   case $step in
     tests)
-      timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $OUT/${TAG}_pytest_gpu.txt
+      timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_pytest_gpu_full.txt 2>&1
+      grep -E "passed|failed|FAILED|ERROR|error" $OUT/${TAG}_pytest_gpu_full.txt | tail -8 | tee $OUT/${TAG}_pytest_gpu.txt
       timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/${TAG}_smoke.txt;;
     bench)
       timeout 900 python bench.py --steps $STEPS --warmup 5 2> $OUT/${TAG}_bench_err.txt | tee $OUT/${TAG}_bench_k$STEPS.json
