@@ -332,7 +332,7 @@ def main():
                                     "(two-level BVH), 10 %% alpha-cut, 1k^2 image textures, diffuse / coated diffuse / dielectric / conductor, sun + 2k^2 image "
                                     "sky + 500 emitters, maxdepth %d, zsobol; step = 1 sample index x 1920x1080")
                                    % (info.n_triangles, info.max_depth),
-                       "resolution": [info.width, info.height], "spp": K, "samples_per_pass": scene.samples_per_pass, "partition": (("interleaved 16-line scanline strips x%d" if a.partition == "strips" else "sample-index round-robin x%d") % world) + " + RCCL film reduce to rank 0"
+                       "resolution": [info.width, info.height], "spp": K, "samples_per_pass": scene.samples_per_pass, "partition": (("interleaved 16-line scanline strips x%d" if a.partition == "strips" else "sample-index round-robin x%d") % world) + " + RCCL gather of the owned scanlines to rank 0"
                        if world > 1 else "single GPU"},
         }
         if not a.no_roofline and counters and counters["closest_rays"] > 0:
@@ -415,6 +415,38 @@ def main():
                     "mray_per_s": rays_shadow / (sh_ms * 1e-3) / 1e6,
                     "closest_mray_per_s": (rays_closest / (walk_ms * 1e-3) / 1e6) if walk_ms > 0 else None,
                 }
+            # ---- the material stage (K9) against the same roofline: B_mat = 252 + 48 bytes read per item (the reference's
+            # MaterialEvalWorkItem + its RaySamples) + 184 per spawned ray + 124 per shadow ray written; items from the queue
+            # counters (wf_material_items_download), time = the HIP-event durations of every "...Material + BxDF eval" launch of the timed region
+            try:
+                items = scene.material_items()
+                n_items = sum(v for k, v in items.items() if k != "medium_sample")
+                rep = [e for e in scene.profile_report()]
+                mat_ms = sum(e["total_ms"] for e in rep if "Material" in e["name"])
+                mat_launches = sum(e["launches"] for e in rep if "Material" in e["name"])
+                spawned = sum(st["indirect_rays"][1:]) - sum(stats_before["indirect_rays"][1:])
+                if n_items > 0 and mat_ms > 0:
+                    b = 300.0 * n_items + 184.0 * spawned + 124.0 * rays_shadow
+                    out["roofline_material"] = {
+                        "bound": "hbm", "kernel": "EvaluateMaterialAndBSDF (k_eval_material<type, variant>, all types)", "achieved": b / (mat_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / (mat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "items": n_items, "items_by_type": {str(k): v for k, v in items.items() if v and k != "medium_sample"}, "spawned_rays": spawned, "shadow_rays": rays_shadow,
+                        "algorithmic_bytes": b, "algorithmic_bytes_per_item": b / n_items, "total_ms": mat_ms, "launches": mat_launches,
+                        "mitems_per_s": n_items / (mat_ms * 1e-3) / 1e6,
+                    }
+                med_ms = sum(e["total_ms"] for e in rep if e["name"].startswith("Sample medium"))
+                med_launches = sum(e["launches"] for e in rep if e["name"].startswith("Sample medium"))
+                if items.get("medium_sample", 0) > 0 and med_ms > 0:
+                    # K5 (a14): 364 bytes read per MediumSampleWorkItem, 120 written per scattering event (a MediumScatterWorkItem; the
+                    # scattered items of a surface-free medium scene are the rays its scattering stage spawns)
+                    b = 364.0 * items["medium_sample"] + 120.0 * spawned
+                    out["roofline_medium"] = {
+                        "bound": "hbm", "kernel": "SampleMediumInteraction (k_medium_sample)", "achieved": b / (med_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": b / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "items": items["medium_sample"], "algorithmic_bytes": b,
+                        "total_ms": med_ms, "launches": med_launches, "mitems_per_s": items["medium_sample"] / (med_ms * 1e-3) / 1e6,
+                    }
+            except Exception as ex:   # (a measurement block must not take the bench line down)
+                out["roofline_material_error"] = str(ex)
         if a.breakdown:
             out["stage_ms"] = {e["name"]: {"launches": e["launches"], "total_ms": round(e["total_ms"], 3)} for e in scene.profile_report()}
         parity_fail = None

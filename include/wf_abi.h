@@ -753,6 +753,10 @@ int wf_libm_probe(wf_ctx *ctx, int fn, int n, const float *in, float *out);
    (shapes.cpp:168-269) evaluated on the device; the reference's answers are tests/golden/kat_out.bin (oracle/ref_build/ref_kat.cpp).
    Needs a context only (no scene). */
 int wf_kat_probe(wf_ctx *ctx, int n, const uint64_t *in, uint64_t *out);
+/* Items evaluated by the material stage since the last wf_film_clear, per material type (out[wf_material_type], < WF_MAT_NTYPES), and
+   the items of the medium-sample stage (out[WF_MAT_NTYPES]); out[12..15] = 0.  What bench.py's roofline_material / roofline_medium
+   divide the SURVEY 8(d) bytes per item by. */
+int wf_material_items_download(wf_ctx *ctx, uint64_t out[16]);
 /* debug/parity access to queues: downloads the named SoA member */
 int wf_queue_size(wf_ctx *ctx, const char *queue, int *size);
 int wf_queue_download(wf_ctx *ctx, const char *queue, const char *member, void *dst, uint64_t nbytes);

@@ -21,6 +21,9 @@
 // not reproduced; results, including infinities / NaN-ness, are.
 //
 // The file has no dependencies so the host checker can include it alone; compile with -ffp-contract=off.
+//
+// LICENCE: a derived work of glibc 2.35's flt-32 sources (LGPL 2.1 or later; the fdlibm-derived routines also carry Sun's
+// permissive notice) — see wf_libm.LICENSE next to this file, which must travel with it.
 #pragma once
 #include <cstdint>
 #include <cstring>

@@ -48,6 +48,27 @@ WF_HD float GridLookup(const float *v, int nx, int ny, int nz, V3 p) {
     float d11 = Lerp(d.x, GridLookupI(v, nx, ny, nz, ix, iy + 1, iz + 1), GridLookupI(v, nx, ny, nz, ix + 1, iy + 1, iz + 1));
     return Lerp(d.z, Lerp(d.y, d00, d10), Lerp(d.y, d01, d11));
 }
+// The same lookup over the corner-packed copy of the grid (SceneView::gridCorners): cell (ix + 1, iy + 1, iz + 1) of an
+// (nx + 1)(ny + 1)(nz + 1) table holds v(ix.., iy.., iz..) for the eight corners in the order the lerps below take them, zeros outside the
+// grid as GridLookupI returns them.  The same eight values through the same expressions: bit-identical.
+WF_HD float GridLookupPacked(const float *c, int nx, int ny, int nz, V3 p) {
+    V3 ps{p.x * nx - .5f, p.y * ny - .5f, p.z * nz - .5f};
+    int ix = (int)floor(ps.x), iy = (int)floor(ps.y), iz = (int)floor(ps.z);
+    V3 d{ps.x - (float)ix, ps.y - (float)iy, ps.z - (float)iz};
+    if (!(ix >= -1 && ix < nx && iy >= -1 && iy < ny && iz >= -1 && iz < nz)) {
+        // every corner lies outside the grid: the lerps of zeros
+        float z0 = Lerp(d.x, 0.f, 0.f);
+        return Lerp(d.z, Lerp(d.y, z0, z0), Lerp(d.y, z0, z0));
+    }
+    struct alignas(16) G4 { float a, b, c, d; };
+    const G4 *cell = reinterpret_cast<const G4 *>(c) + 2 * (((size_t)(iz + 1) * (ny + 1) + (iy + 1)) * (nx + 1) + (ix + 1));
+    const G4 lo = cell[0], hi = cell[1];
+    float d00 = Lerp(d.x, lo.a, lo.b);
+    float d10 = Lerp(d.x, lo.c, lo.d);
+    float d01 = Lerp(d.x, hi.a, hi.b);
+    float d11 = Lerp(d.x, hi.c, hi.d);
+    return Lerp(d.z, Lerp(d.y, d00, d10), Lerp(d.y, d01, d11));
+}
 // Bounds3::Offset (util/vecmath.h)
 WF_HD V3 BoundsOffset(const float b[6], V3 p) {
     V3 o{p.x - b[0], p.y - b[1], p.z - b[2]};
@@ -139,7 +160,13 @@ WF_HD float VdbSample(const float *data, const int32_t vmin[3], const int32_t vd
     float u = fma(x, m[0], fma(y, m[1], z * m[2])), v = fma(x, m[3], fma(y, m[4], z * m[5])), w = fma(x, m[6], fma(y, m[7], z * m[8]));
     const float fu = floor(u), fv = floor(v), fw = floor(w);
     u -= fu; v -= fv; w -= fw;
-    const int i = (int)fu - vmin[0], j = (int)fv - vmin[1], k = (int)fw - vmin[2];
+    // (indices clamped to just outside the block before the integer conversion: a point far outside — or a NaN — reads the background,
+    //  never an int overflow; inside the block nothing changes: ADVICE r3)
+    auto idx = [](float f, int lo, int n) {
+        const long long q = (long long)(int)fmin(fmax(f, -2147483000.f), 2147483000.f) - lo;
+        return (int)(q < -2 ? -2 : (q > (long long)n + 1 ? (long long)n + 1 : q));
+    };
+    const int i = idx(fu, vmin[0], vdim[0]), j = idx(fv, vmin[1], vdim[1]), k = idx(fw, vmin[2], vdim[2]);
     auto at = [&](int a, int b, int c) -> float {
         const int xi = i + a, yj = j + b, zk = k + c;
         if (!(xi >= 0 && xi < vdim[0] && yj >= 0 && yj < vdim[1] && zk >= 0 && zk < vdim[2])) return background;
@@ -241,7 +268,11 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
         }
         return mp;
     }
-    float d = GridLookup(sv.mediumData + M.density_offset, M.nx, M.ny, M.nz, p);
+    float d;
+    {
+        const long long cb = sv.gridCornerBase ? sv.gridCornerBase[&M - sv.media] : -1;
+        d = cb >= 0 ? GridLookupPacked(sv.gridCorners + cb, M.nx, M.ny, M.nz, p) : GridLookup(sv.mediumData + M.density_offset, M.nx, M.ny, M.nz, p);
+    }
     mp.sigma_a = mp.sigma_a * d;
     mp.sigma_s = mp.sigma_s * d;
     mp.Le = S4c(0.f);

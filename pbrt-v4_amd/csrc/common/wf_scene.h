@@ -43,6 +43,12 @@ struct SceneView {
     // participating media
     const wf_medium *media;
     const float *mediumData;
+    // (round 4, device only; null on the host) the density grids of the GridMedium media once more, CORNER-PACKED: for every lattice
+    // position the eight values a trilinear lookup there reads, 32 contiguous bytes — two dwordx4 loads instead of eight gathers
+    // into four rows of the grid, at 8x the memory (4.3 GB for the 512^3 cloud of BASELINE configs[3]; what 288 GB are for).
+    // gridCornerBase[medium id] = first float of the medium's table in gridCorners, or -1 (wf_media.h: GridLookupPacked)
+    const float *gridCorners;
+    const long long *gridCornerBase;
     // camera / film / filter / sampler
     wf_camera camera;
     wf_film film;

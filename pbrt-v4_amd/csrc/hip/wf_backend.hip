@@ -144,7 +144,13 @@ __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, in
         if (statSlot >= 0) ws.stats[statSlot] += (unsigned long long)ws.counters[(statCounter) * CNT_STRIDE];
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) ws.counters[(threadIdx.x) * CNT_STRIDE] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < CNT_COUNT && ((mask >> threadIdx.x) & 1u)) {
+        // the items a material queue held go to stats[129 + type] before the counter is zeroed (wf_material_items_download: the item
+        // counts of the material stage's roofline) — the same for the medium-sample queue at stats[129 + WF_MAT_NTYPES]
+        const int t = (int)threadIdx.x;
+        if (t >= CNT_MAT0 && t <= CNT_MEDIUM_SAMPLE) ws.stats[129 + (t - CNT_MAT0)] += (unsigned long long)ws.counters[t * CNT_STRIDE];
+        ws.counters[t * CNT_STRIDE] = 0;
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_sample_tops(const SceneView sv, WorkState ws, int y0, int dim0) {
@@ -745,6 +751,15 @@ __device__ inline void DrainRetrace(const SceneView &sv, const WorkState &ws, co
             int tries = 0;
             do { rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg); } while (rh.prim < 0 && ++tries < 4);
             if (st.dbg && tries) { atomicAdd(st.dbg + 5, tries); if (rh.prim < 0) atomicOr(st.dbg + 6, 1); }
+            // ... and the entry itself is validated instead of trusted: the ray index lies inside this launch's queue, the
+            // re-walk's hit lies inside the entry's bound, and the slot still carries this launch's tag after the walk.  A violation is
+            // wf_sync's error like an unresolved ray: wrong inputs that happen to yield SOME hit must not pass silently.
+            if (st.dbg) {
+                const bool badIndex = i < 0 || i >= ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
+                const bool badHit = rh.prim >= 0 && !(rh.t <= tB);
+                const bool badTag = (uint32_t)(__hip_atomic_load(&ws.retraceQ64[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != (uint32_t)ws.drainEpoch;
+                if (badIndex || badHit || badTag) atomicOr(st.dbg + 6, 2);
+            }
             ws.routeCode[i] = rh.route;
             ws.hit[i] = F4{BitsToFloat((uint32_t)rh.prim), rh.b0, rh.b1, rh.b2};
             if (INST) ws.hitInst[i] = rh.prim >= 0 ? rh.inst : -1;
@@ -1272,7 +1287,8 @@ struct Prof {
     bool on;
     Prof(wf_ctx *c, const char *name) : c(c), name(name) {
         if (c->traceLaunch) { fprintf(stderr, "[wf] launch %s\n", name); fflush(stderr); }
-        on = c->profile == 1 || (c->profile == 2 && (strncmp(name, "Intersect", 9) == 0 || strcmp(name, "Route hits") == 0));
+        on = c->profile == 1 || (c->profile == 2 && (strncmp(name, "Intersect", 9) == 0 || strcmp(name, "Route hits") == 0 || strstr(name, "Material") != nullptr ||
+                                                      strncmp(name, "Sample medium", 13) == 0));   // (2: the stages bench.py prices against a roofline)
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -1328,6 +1344,20 @@ struct Prof {
 // set maxdepth 100 and more) accumulate in the last slot instead of running past the array
 static int statDepth(int depth) { return depth < 63 ? depth : 63; }
 
+// SceneView::gridCorners: cell (cx, cy, cz) of the (nx + 1)(ny + 1)(nz + 1) table <- the eight values a trilinear lookup with
+// floor(p * res - .5) = (cx - 1, cy - 1, cz - 1) reads (wf_media.h: GridLookupPacked), zeros outside the grid
+__global__ void k_pack_grid_corners(const float *v, int nx, int ny, int nz, float *out) {
+    const size_t cells = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+        const int cx = (int)(c % (size_t)(nx + 1)), cy = (int)((c / (size_t)(nx + 1)) % (size_t)(ny + 1)), cz = (int)(c / ((size_t)(nx + 1) * (ny + 1)));
+        const int ix = cx - 1, iy = cy - 1, iz = cz - 1;
+        float *o = out + 8 * c;
+        o[0] = wf::GridLookupI(v, nx, ny, nz, ix, iy, iz);         o[1] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy, iz);
+        o[2] = wf::GridLookupI(v, nx, ny, nz, ix, iy + 1, iz);     o[3] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy + 1, iz);
+        o[4] = wf::GridLookupI(v, nx, ny, nz, ix, iy, iz + 1);     o[5] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy, iz + 1);
+        o[6] = wf::GridLookupI(v, nx, ny, nz, ix, iy + 1, iz + 1); o[7] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy + 1, iz + 1);
+    }
+}
 // HIP's current device is a property of the calling host thread: a context may be driven from any thread (pbrt_amd --gpus N runs one
 // host thread per device, SURVEY 8(b) "multi-GPU = one host thread per device"), so every stage entry makes the context's device current
 // — a thread-local compare when it already is
@@ -1621,7 +1651,8 @@ int wf_sync(wf_ctx *ctx) {
         if (overflow) return fail(-1, "traversal stack overflow: a walk needed more than %d + %d node-stack entries (results are incomplete)", TSTACK, ctx->spillRows);
         int unresolved = 0;
         HIPCHK(hipMemcpy(&unresolved, ctx->dbgWords + 6, sizeof(int), hipMemcpyDeviceToHost));
-        if (unresolved) return fail(-1, "a near-tie re-walk found no hit where the production walk had one (results are incomplete)");
+        if (unresolved & 1) return fail(-1, "a near-tie re-walk found no hit where the production walk had one (results are incomplete)");
+        if (unresolved & 2) return fail(-1, "a near-tie queue entry failed its validation (ray index, bound or launch tag): results are incomplete");
         int fatal = 0;
         HIPCHK(hipMemcpy(&fatal, ctx->dbgWords + 7, sizeof(int), hipMemcpyDeviceToHost));
         // the reference's LOG_FATAL / CHECK inside a kernel body (wf_scene.h: WF_FATAL_*), e.g. a sample drawn from an emissive curve
@@ -1693,6 +1724,41 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.csIlluminantOffset = d->cs_illuminant_offset;
     if ((e = devUpload(ctx, &sv.media, d->media, (size_t)d->n_media))) return e;
     if ((e = devUpload(ctx, &sv.mediumData, d->medium_data, (size_t)d->n_medium_floats))) return e;
+    {
+        // the corner-packed copies of the GridMedium density grids (SceneView::gridCorners), built on the device from the dense grids
+        // just uploaded.  WF_GRID_CORNERS=0: none (A/B); tables beyond WF_GRID_CORNERS_GB (default 32) gigabytes in all are left out
+        sv.gridCorners = nullptr;
+        sv.gridCornerBase = nullptr;
+        const char *knob = getenv("WF_GRID_CORNERS");
+        if (d->n_media > 0 && !(knob && atoi(knob) == 0)) {
+            const double budget = (getenv("WF_GRID_CORNERS_GB") ? atof(getenv("WF_GRID_CORNERS_GB")) : 32.0) * 1024.0 * 1024.0 * 1024.0;
+            std::vector<long long> base(d->n_media, -1);
+            size_t total = 0;
+            for (int m = 0; m < d->n_media; ++m) {
+                const wf_medium &M = d->media[m];
+                if (M.type != WF_MEDIUM_GRID || M.density_offset < 0 || M.nx < 1 || M.ny < 1 || M.nz < 1) continue;
+                const size_t cells = (size_t)(M.nx + 1) * (M.ny + 1) * (M.nz + 1);
+                if ((double)(total + 8 * cells) * sizeof(float) > budget) continue;
+                base[m] = (long long)total;
+                total += 8 * cells;
+            }
+            if (total > 0) {
+                float *corners = nullptr;
+                const long long *dbase = nullptr;
+                if ((e = devAlloc(ctx, &corners, total))) return e;
+                if ((e = devUpload(ctx, &dbase, base.data(), (size_t)d->n_media))) return e;
+                for (int m = 0; m < d->n_media; ++m) {
+                    if (base[m] < 0) continue;
+                    const wf_medium &M = d->media[m];
+                    const size_t cells = (size_t)(M.nx + 1) * (M.ny + 1) * (M.nz + 1);
+                    const int grid = (int)std::min<size_t>((cells + BLOCK - 1) / BLOCK, (size_t)MAX_GRID * 16);
+                    LAUNCH("Pack grid corners", k_pack_grid_corners, grid, sv.mediumData + M.density_offset, M.nx, M.ny, M.nz, corners + base[m]);
+                }
+                sv.gridCorners = corners;
+                sv.gridCornerBase = dbase;
+            }
+        }
+    }
     sv.nLights = d->n_lights;
     sv.nInfiniteLights = d->n_infinite_lights;
     sv.nLightBvhNodes = d->n_light_bvh_nodes;
@@ -1871,7 +1937,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         if (d->film.n_buckets < 1 || d->film.n_buckets > 4096 || !(d->film.lambda_max > d->film.lambda_min)) return fail(-1, "spectral film: bad bucket count / wavelength range");
         if ((e = devAlloc(ctx, &ctx->ws.filmSpectral, (size_t)ctx->W * ctx->H * 2 * d->film.n_buckets))) return e;
     }
-    if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)129))) return e;
+    if ((e = devAlloc(ctx, &ctx->ws.stats, (size_t)(129 + 16)))) return e;   // [129 ..]: items per material queue / the medium-sample queue
     if ((e = devAlloc(ctx, &ctx->ws.trav, (size_t)8))) return e;
     if ((e = devAlloc(ctx, &ctx->ws.counters, (size_t)CNT_COUNT * CNT_STRIDE))) return e;
     {
@@ -2022,7 +2088,7 @@ int wf_film_clear(wf_ctx *ctx) {
     HIPCHK(hipMemsetAsync(ctx->ws.film, 0, (size_t)ctx->W * ctx->H * 4 * sizeof(double), ctx->stream));
     if (ctx->ws.filmGBuffer) HIPCHK(hipMemsetAsync(ctx->ws.filmGBuffer, 0, (size_t)ctx->W * ctx->H * sizeof(wf_gbuffer_pixel), ctx->stream));
     if (ctx->ws.filmSpectral) HIPCHK(hipMemsetAsync(ctx->ws.filmSpectral, 0, (size_t)ctx->W * ctx->H * 2 * ctx->svHost.film.n_buckets * sizeof(double), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->ws.stats, 0, 129 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->ws.stats, 0, (129 + 16) * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->ws.trav, 0, 8 * sizeof(unsigned long long), ctx->stream));
     return 0;
 }
@@ -2400,6 +2466,18 @@ int wf_stats_add(wf_ctx *dst, wf_ctx *src) {
     useDevice(src);
     HIPCHK(hipMemset(src->ws.stats, 0, sizeof(b)));   // (moved, not copied: a second call adds only what src counted since)
     useDevice(dst);
+    return 0;
+}
+// items the material stage evaluated since the last wf_film_clear, per material type (out[0 .. WF_MAT_NTYPES)), and the items of the
+// medium-sample stage (out[WF_MAT_NTYPES]): the counts the queues held when they were reset, plus what they hold now
+int wf_material_items_download(wf_ctx *ctx, uint64_t out[16]) {
+    if (int e = checkReady(ctx)) return e;
+    unsigned long long h[16];
+    std::vector<int32_t> cnt((size_t)CNT_COUNT * CNT_STRIDE);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(h, ctx->ws.stats + 129, sizeof(h), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), ctx->ws.counters, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; ++i) out[i] = i <= WF_MAT_NTYPES ? h[i] + (uint64_t)cnt[(size_t)(CNT_MAT0 + i) * CNT_STRIDE] : 0;
     return 0;
 }
 int wf_stats_download(wf_ctx *ctx, wf_render_stats *out) {

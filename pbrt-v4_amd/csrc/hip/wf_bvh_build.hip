@@ -422,6 +422,14 @@ inline int GridFor(long long n) { long long g = (n + BLK - 1) / BLK; return (int
 extern "C" int wf_build_bvh_sah(int n, const float *bounds, int max_prims_in_node, wf_bvh_node *nodes_out, int32_t *order_out, int32_t *n_nodes_out) {
     int devCount = 0;
     if (hipGetDeviceCount(&devCount) != hipSuccess || devCount == 0) { (void)hipGetLastError(); return -1; }
+    // The tables are built before the renderer's device is known, on whatever device is current for the calling thread — device 0 in a
+    // fresh thread, for every rank of a multi-GPU job on one box.  WF_BUILD_DEVICE, else LOCAL_RANK (torch.distributed.run),
+    // names the device of this process's build; an allocation failure below returns a negative code and the host builder takes over.
+    {
+        const char *e = getenv("WF_BUILD_DEVICE");
+        if (!e) e = getenv("LOCAL_RANK");
+        if (e && atoi(e) >= 0 && atoi(e) < devCount) (void)hipSetDevice(atoi(e));
+    }
     if (n <= 0 || !bounds || !nodes_out || !order_out || !n_nodes_out) return -3;
     const size_t cap = 2 * (size_t)n + 2;
     const size_t levelCap = (size_t)n / (SMALL + 1) + 2;   // large open nodes of one level are disjoint spans of more than SMALL primitives

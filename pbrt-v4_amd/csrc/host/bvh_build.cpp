@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 namespace wf {
@@ -38,24 +39,42 @@ SahBuildFn g_sahBuild = nullptr;
 struct Builder {
     int maxPrimsInNode;
     int splitMethod = 0;   // 0 SAH, 2 Middle, 3 EqualCounts (1 = HLBVH: BuildHLBVH)
-    BuildNode *pool = nullptr;   // raw storage for 2 n nodes (not value-initialised: 450 MB for the 4 M-primitive top level)
-    ~Builder() { free(pool); }
+    // raw node storage (not value-initialised: 450 MB for the 4 M-primitive top level), in chunks that are added on demand: a tree has
+    // 2 n - 1 nodes, but every helper thread abandons the tail of its last run of 1024 when it exits, and the number of helper threads
+    // grows with n (a fixed pool of 2 n + 1 M nodes could be overrun by a large or skewed build — silently)
+    std::vector<BuildNode *> chunks;
+    size_t chunkCap = 0, chunkUsed = 0, firstChunk = 0;
+    std::mutex chunkMutex;
+    ~Builder() { for (BuildNode *c : chunks) free(c); }
+    BuildNode *NewRun() {   // 1024 nodes for one thread
+        std::lock_guard<std::mutex> lock(chunkMutex);
+        if (chunkUsed + 1024 > chunkCap) {
+            chunkCap = std::max<size_t>(firstChunk, 1u << 20);
+            BuildNode *c = (BuildNode *)malloc(chunkCap * sizeof(BuildNode));
+            if (!c) throw SceneError("Error: out of memory for the BVH build's nodes");
+            chunks.push_back(c);
+            chunkUsed = 0;
+        }
+        BuildNode *r = chunks.back() + chunkUsed;
+        chunkUsed += 1024;
+        return r;
+    }
     std::vector<int32_t> *ordered;
     std::atomic<int> totalNodes{0};
-    std::atomic<size_t> poolUsed{0};
+
     static inline std::atomic<uint64_t> nextId{1};
     const uint64_t id = nextId++;
     // nodes are handed out in runs of 1024 per thread (one shared counter touched by 256 builder threads for each of 8 M nodes is a
     // contended cache line: measured 27 s for the 4 M-primitive top level on the 256-core box, against 1.3 s sequentially)
     BuildNode *NewNode() {
         static thread_local uint64_t owner = 0;   // (a builder's id, not its address: successive builders share stack addresses)
-        static thread_local size_t next = 0, end = 0;
+        static thread_local BuildNode *next = nullptr, *end = nullptr;
         if (owner != id || next == end) {
             owner = id;
-            next = poolUsed.fetch_add(1024);
+            next = NewRun();
             end = next + 1024;
         }
-        return new (&pool[next++]) BuildNode();
+        return new (next++) BuildNode();
     }
     // task parallelism of the SAH build: a span larger than kParallelSpan hands its first child to a helper thread while helpers are left
     static constexpr int kParallelSpan = 16 * 1024;
@@ -405,8 +424,7 @@ int BuildBVH(const std::vector<std::pair<int, B3>> &primsIn, int maxPrimsInNode,
     Builder bld;
     bld.maxPrimsInNode = std::min(255, maxPrimsInNode);
     bld.splitMethod = splitMethod;
-    bld.pool = (BuildNode *)malloc((2 * (size_t)nAll + 1024 * 1024) * sizeof(BuildNode));   // (+ the unused tails of the threads' runs)
-    if (!bld.pool) return -1;
+    bld.firstChunk = 2 * (size_t)nAll + 64 * 1024;   // the first chunk holds a whole tree plus some abandoned run tails; more chunks follow on demand
     bld.ordered = &ordered;
     int threads = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("WF_BUILD_THREADS")) threads = atoi(e);

@@ -100,11 +100,20 @@ void Densify(const Blob &b, VdbGrid *g) {
         cells *= g->dim[a];
     }
     if (cells <= 0) { g->dim[0] = g->dim[1] = g->dim[2] = 0; g->values.clear(); return; }   // an empty grid: background everywhere
+    // (the dense expansion is bounded by what the FILE can describe, not only by the address range: a few header bytes must not ask for
+    //  gigabytes — every active leaf of 512 voxels takes at least 2 KB of the file)
+    if (cells > 4096ll * (long long)b.n + (1ll << 24))
+        Fail(b.fn, "the grid's index bounding box holds " + std::to_string(cells) + " voxels, implausibly many for a file of " + std::to_string(b.n) + " bytes");
     if (cells > (1ll << 31) - 1) Fail(b.fn, "the grid's index bounding box holds " + std::to_string(cells) + " voxels: more than this build's dense expansion addresses");
     g->values.assign((size_t)cells, rd.background);
     auto fill = [&](const int o[3], int size, float v) {   // a tile [o, o + size)^3 clipped to the block
+        // (64-bit bounds: a root key near 2^31 of a malformed file would overflow o + size; such a tile lies outside the block and is dropped)
         int lo[3], hi[3];
-        for (int a = 0; a < 3; ++a) { lo[a] = std::max(o[a], g->min[a]); hi[a] = std::min(o[a] + size, g->min[a] + g->dim[a]); if (lo[a] >= hi[a]) return; }
+        for (int a = 0; a < 3; ++a) {
+            const long long l = std::max<long long>(o[a], g->min[a]), h = std::min<long long>((long long)o[a] + size, (long long)g->min[a] + g->dim[a]);
+            if (l >= h) return;
+            lo[a] = (int)l; hi[a] = (int)h;
+        }
         for (int z = lo[2]; z < hi[2]; ++z)
             for (int y = lo[1]; y < hi[1]; ++y) {
                 float *row = &g->values[((size_t)(z - g->min[2]) * g->dim[1] + (y - g->min[1])) * g->dim[0]];
@@ -114,9 +123,9 @@ void Densify(const Blob &b, VdbGrid *g) {
     auto leaf = [&](size_t off, const int o[3]) {
         const uint8_t *vals = b.span(off + kLeafHeader, 512 * sizeof(float));
         for (int n = 0; n < 512; ++n) {   // LeafNode::CoordToOffset: x << 6 | y << 3 | z
-            const int c[3] = {o[0] + (n >> 6), o[1] + ((n >> 3) & 7), o[2] + (n & 7)};
+            const long long c[3] = {(long long)o[0] + (n >> 6), (long long)o[1] + ((n >> 3) & 7), (long long)o[2] + (n & 7)};
             bool in = true;
-            for (int a = 0; a < 3; ++a) in &= c[a] >= g->min[a] && c[a] < g->min[a] + g->dim[a];
+            for (int a = 0; a < 3; ++a) in &= c[a] >= g->min[a] && c[a] < (long long)g->min[a] + g->dim[a];
             if (!in) continue;
             float v;
             memcpy(&v, vals + 4 * (size_t)n, 4);

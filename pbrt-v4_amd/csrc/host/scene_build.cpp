@@ -3501,6 +3501,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             try { BuildBVH(topPrims, maxPrims, &T->bvhNodes, &T->bvhPrims, splitCode); }
             catch (const std::exception &e) { topError = e.what(); }
         });
+        // (an exception between here and the join — a bad_alloc of the definitions' arrays — must not destroy a joinable thread, which
+        // is std::terminate instead of a SceneError: ADVICE r3)
+        struct JoinGuard { std::thread &t; ~JoinGuard() { if (t.joinable()) t.join(); } } topBuildGuard{topBuild};
         {
             // the definitions' trees are independent: built concurrently into local arrays (a pool of threads takes them in turn), then
             // appended in definition order — the arrays are the sequential loop's

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "wf_medium_sample", "wf_intersect_shadow_tr", "wf_subsurface_probe", "wf_intersect_one_random", "wf_subsurface_scatter", "wf_trace_one_random_host", "wf_morton_sort", "wf_build_bvh_sah", "wf_aggregate_bounds", "wf_queues_alloc", "wf_set_pass_samples", "wf_set_strips", "wf_film_clear", "wf_reset_ray_queue", "wf_reset_stage_queues",
     "wf_gen_camera_rays", "wf_gen_ray_samples", "wf_intersect_closest", "wf_handle_escaped", "wf_handle_emissive",
     "wf_eval_material", "wf_intersect_shadow", "wf_update_film", "wf_render_pass", "wf_film_download",
-    "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_film_gather_strips", "wf_stats_add", "wf_stats_download",
+    "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_film_gather_strips", "wf_stats_add", "wf_material_items_download", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_kat_probe", "wf_queue_size", "wf_queue_download",
     "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",
@@ -123,6 +123,7 @@ def libs():
     _hip.wf_sampler_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _hip.wf_libm_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _hip.wf_kat_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _hip.wf_material_items_download.argtypes = [C.c_void_p, C.c_void_p]
     _hip.wf_kernel_time_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _hip.wf_aggregate_bounds.argtypes = [C.c_void_p, C.c_void_p]
     _hip.wf_render_pass.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -307,6 +308,15 @@ class Scene:
         out = np.empty(n, dtype=np.float32)
         _check(hip.wf_libm_probe(self.ctx, self.LIBM_FNS.index(fn), n, x.ctypes.data, out.ctypes.data), "wf_libm_probe")
         return out
+
+    def material_items(self):
+        """items the material stage evaluated since the last clear_film(): {material type: count}, plus "medium_sample" """
+        _, hip = libs()
+        out = (C.c_uint64 * 16)()
+        _check(hip.wf_material_items_download(self.ctx, out), "wf_material_items_download")
+        d = {i: int(out[i]) for i in range(11)}
+        d["medium_sample"] = int(out[11])
+        return d
 
     def kat_probe(self, records):
         """Device evaluation of the known-answer probe (csrc/common/wf_kat.h): (n, 16) uint64 records in, (n, 8) uint64 out."""

@@ -806,6 +806,9 @@ def test_bench_workload_line(workload):
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 4 and line["roofline"]["peak"] == 8000.0
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] >= 1
     assert line["parity"]["max_rel"] <= REL_TOL, line["parity"]
+    assert line["roofline_material"]["items"] > 0 and 0 < line["roofline_material"]["frac"] < 2, line.get("roofline_material_error")
+    if workload == "cloud-like":
+        assert line["roofline_medium"]["items"] > 0 and 0 < line["roofline_medium"]["frac"] < 2
     print(workload, line["value"], "Msamples/s", "parity", line["parity"]["max_rel"], line["parity"]["bit_identical_fraction"])
 
 
