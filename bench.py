@@ -133,7 +133,8 @@ def measure_traffic(scene_path, spp):
                 return None
             for r in csv.DictReader(open(files[0])):
                 k = r["Kernel_Name"].split("(")[0]
-                kind = "closest" if "k_closest_fast" in k else ("shadow" if "k_shadow_fast" in k else None)
+                kind = ("closest" if "k_closest_fast" in k else "shadow" if "k_shadow_fast" in k else "material" if "k_eval_material" in k
+                        else "medium" if "k_medium_sample" in k else None)
                 if kind and r.get("Counter_Name", counter) == counter:
                     totals[(kind, counter)] = totals.get((kind, counter), 0.0) + float(r["Counter_Value"])
             txt = pr.stdout + pr.stderr
@@ -142,12 +143,15 @@ def measure_traffic(scene_path, spp):
             sh = re.findall(r"Shadow rays, depth\s+\d+\s+(\d+)", txt)
             if cam:
                 rays = {"closest": int(cam[-1]) + sum(int(v) for v in ind), "shadow": sum(int(v) for v in sh)}
+                mi, me = re.findall(r"Material items\s+(\d+)", txt), re.findall(r"Medium-sample items\s+(\d+)", txt)
+                rays["material"] = int(mi[-1]) if mi else 0
+                rays["medium"] = int(me[-1]) if me else 0
     if not rays or rays["closest"] <= 0:
         return None
     res = {"spp": spp}
-    for kind in ("closest", "shadow"):
+    for kind in ("closest", "shadow", "material", "medium"):   # (material / medium: bytes per ITEM of the stage's kernels)
         f, w = totals.get((kind, "FETCH_SIZE")), totals.get((kind, "WRITE_SIZE"))
-        if f is None or w is None or rays[kind] <= 0:
+        if f is None or w is None or rays.get(kind, 0) <= 0:
             continue
         # the counters are in KiB
         res[kind] = {"hbm_bytes_per_ray": (2 * f + w) * 1024.0 / rays[kind], "write_bytes_per_ray": w * 1024.0 / rays[kind], "rays": rays[kind]}
@@ -434,6 +438,13 @@ def main():
                         "algorithmic_bytes": b, "algorithmic_bytes_per_item": b / n_items, "total_ms": mat_ms, "launches": mat_launches,
                         "mitems_per_s": n_items / (mat_ms * 1e-3) / 1e6,
                     }
+                    if live and "material" in live:   # HBM bytes per item of the k_eval_material kernels, from the same PMC child passes
+                        rm = out["roofline_material"]
+                        rm["traffic_bytes_per_item"] = live["material"]["hbm_bytes_per_ray"]
+                        rm["write_bytes_per_item"] = live["material"]["write_bytes_per_ray"]
+                        rm["traffic"] = rm["traffic_bytes_per_item"] * n_items / mat_launches
+                        rm["algorithmic_bytes_per_launch"] = b / mat_launches
+                        rm["traffic_source"] = "this run's rocprofv3 PMC child passes (2 x FETCH_SIZE + WRITE_SIZE of every k_eval_material dispatch / the items the child's --stats reports) x this run's items per launch"
                 med_ms = sum(e["total_ms"] for e in rep if e["name"].startswith("Sample medium"))
                 med_launches = sum(e["launches"] for e in rep if e["name"].startswith("Sample medium"))
                 if items.get("medium_sample", 0) > 0 and med_ms > 0:
@@ -445,6 +456,12 @@ def main():
                         "frac": b / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "items": items["medium_sample"], "algorithmic_bytes": b,
                         "total_ms": med_ms, "launches": med_launches, "mitems_per_s": items["medium_sample"] / (med_ms * 1e-3) / 1e6,
                     }
+                    if live and "medium" in live:
+                        rm = out["roofline_medium"]
+                        rm["traffic_bytes_per_item"] = live["medium"]["hbm_bytes_per_ray"]
+                        rm["write_bytes_per_item"] = live["medium"]["write_bytes_per_ray"]
+                        rm["traffic"] = rm["traffic_bytes_per_item"] * items["medium_sample"] / med_launches
+                        rm["algorithmic_bytes_per_launch"] = b / med_launches
             except Exception as ex:   # (a measurement block must not take the bench line down)
                 out["roofline_material_error"] = str(ex)
         if a.breakdown:

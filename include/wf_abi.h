@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 10
+#define WF_ABI_VERSION 11
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830
@@ -328,12 +328,14 @@ typedef struct wf_mesh {
     int32_t first_light;         /* light id of this mesh's first triangle's area light, or -1 */
     int32_t alpha_tex;           /* float texture id or -1 */
     int32_t medium_inside, medium_outside; /* medium ids or -1; both -1 = no MediumInterface */
-    int32_t pad[2];
+    int32_t first_s;             /* WF_MESH_HAS_S: index of the mesh's first shading tangent in wf_scene_desc.S (vertex i of the mesh: first_s + i) */
+    int32_t pad;
 } wf_mesh;
 #define WF_MESH_HAS_N 1
 #define WF_MESH_HAS_UV 2
 #define WF_MESH_FLIP_NORMAL 4    /* reverseOrientation ^ transformSwapsHandedness */
 #define WF_MESH_HAS_MEDIUM_INTERFACE 8
+#define WF_MESH_HAS_S 32            /* "S" shading tangents (util/mesh.h:43, shapes.h:951-959) */
 #define WF_MESH_REVERSE_ORIENTATION 16  /* the shape's own reverseOrientation (Sphere::Sample flips by it alone, shapes.h:274) */
 
 /* Sphere, Disk, Cylinder (shapes.h:107-383, 385-540, 543-748), kept in object space like the reference's: primitive
@@ -537,6 +539,9 @@ typedef struct wf_scene_desc {
     int32_t n_instances, n_instance_defs, n_top_bvh_nodes, n_top_prims;
     const wf_instance *instances;
     const wf_instance_def *instance_defs;
+    /* trianglemesh "S": per-vertex shading tangents in render space, only of the meshes that have them (wf_mesh.first_s) */
+    int64_t n_tangents;
+    const float *S;              /* [n_tangents][3] */
 } wf_scene_desc;
 
 /* ------------------------------------------------------------------------------------------- */

@@ -61,7 +61,7 @@ static void AllocRayQueue(RayQueueV *q, int n) {
 
 SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     SceneView sv{};
-    sv.P = d.P; sv.N = d.N; sv.UV = d.UV; sv.triIndices = d.tri_indices; sv.triMesh = d.tri_mesh; sv.meshes = d.meshes;
+    sv.P = d.P; sv.N = d.N; sv.UV = d.UV; sv.S = d.S; sv.triIndices = d.tri_indices; sv.triMesh = d.tri_mesh; sv.meshes = d.meshes;
     sv.bvhNodes = d.bvh_nodes; sv.bvhPrims = d.bvh_prims; sv.nTriangles = d.n_triangles; sv.nBvhNodes = d.n_bvh_nodes;
     sv.spectra = d.spectra; sv.spectrumData = d.spectrum_data; sv.textures = d.textures; sv.materials = d.materials;
     sv.lights = d.lights; sv.infiniteLights = d.infinite_lights; sv.lightBvh = d.light_bvh_nodes; sv.lightXforms = d.light_transforms;

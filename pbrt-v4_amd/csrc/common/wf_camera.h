@@ -362,15 +362,7 @@ struct PixelSampler {
 // ---------------------------------------------------------------------------------------------
 // Filter::Sample (filters.h): box/triangle analytic, the others through FilterSampler (filters.h:26-45)
 // = PiecewiseConstant2D::Sample (util/sampling.h:760-770) over PiecewiseConstant1D::Sample (:657-675).
-WF_HD float PC1DSample(const float *func, const float *cdf, int n, float funcInt, float mn, float mx, float u,
-                       float *pdf, int *offset) {
-    int o = FindInterval(n + 1, [&](int index) { return cdf[index] <= u; });
-    *offset = o;
-    float du = u - cdf[o];
-    if (cdf[o + 1] - cdf[o] > 0) du /= cdf[o + 1] - cdf[o];
-    *pdf = (funcInt > 0) ? func[o] / funcInt : 0;
-    return Lerp((o + du) / n, mn, mx);
-}
+// (PC1DSample: wf_shapes.h)
 WF_HD float SampleTent(float u, float r) {
     // util/sampling.h:247-258
     // SampleDiscrete({0.5, 0.5}, u, nullptr, &u)

@@ -36,22 +36,7 @@ WF_HD bool IsDeltaLight(const wf_light &l) {
 // ---------------------------------------------------------------------------------------------
 // ImageInfiniteLight (lights.h:566-662, lights.cpp:1042-1052)
 // PiecewiseConstant2D::Sample / PDF (util/sampling.h:760-780) over [0,1]^2
-WF_HD V2 PC2DSample(const float *D, const wf_pc2d &t, V2 u, float *pdf) {
-    float pdf1, pdf0;
-    int iv, iu;
-    float d1 = PC1DSample(D + t.marg_func_offset, D + t.marg_cdf_offset, t.ny, t.marg_int, 0.f, 1.f, u.y, &pdf1, &iv);
-    float d0 = PC1DSample(D + t.cond_func_offset + (size_t)iv * t.nx, D + t.cond_cdf_offset + (size_t)iv * (t.nx + 1), t.nx,
-                          D[t.cond_int_offset + iv], 0.f, 1.f, u.x, &pdf0, &iu);
-    *pdf = pdf0 * pdf1;
-    return V2{d0, d1};
-}
-WF_HD float PC2DPDF(const float *D, const wf_pc2d &t, V2 p) {
-    // domain.Offset(p) with domain [0,1]^2: (p - 0) / (1 - 0)
-    V2 o{(p.x - 0.f) / (1.f - 0.f), (p.y - 0.f) / (1.f - 0.f)};
-    int iu = Clamp((int)(o.x * t.nx), 0, t.nx - 1);
-    int iv = Clamp((int)(o.y * t.ny), 0, t.ny - 1);
-    return D[t.cond_func_offset + (size_t)iv * t.nx + iu] / t.marg_int;
-}
+// (PC2DSample / PC2DPDF: wf_shapes.h, where the bilinear patches' image distribution needs them too)
 // ImageInfiniteLight::ImageLe (lights.h:640-647): nearest texel with octahedral wrap (util/image.h:96-125,352-356),
 // RGBIlluminantSpectrum of the clamped RGB (util/spectrum.cpp:235-246, util/spectrum.h:606-626)
 // RGBIlluminantSpectrum(cs, ClampZero(rgb)).Sample(lambda) (util/spectrum.cpp:2674-2680, spectrum.h:620-640)

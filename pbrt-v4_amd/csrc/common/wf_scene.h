@@ -14,6 +14,7 @@ namespace wf {
 struct SceneView {
     // geometry (util/mesh.h TriangleMesh buffers, flattened over all meshes)
     const float *P, *N, *UV;
+    const float *S;   // shading tangents of the meshes with WF_MESH_HAS_S (LoadS)
     const int32_t *triIndices, *triMesh;
     const wf_mesh *meshes;
     const wf_bvh_node *bvhNodes;
@@ -902,6 +903,7 @@ WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lam
 // geometry accessors
 WF_HD V3 LoadP(const SceneView &sv, int v) { return V3{sv.P[3 * v], sv.P[3 * v + 1], sv.P[3 * v + 2]}; }
 WF_HD N3 LoadN(const SceneView &sv, int v) { return N3{sv.N[3 * v], sv.N[3 * v + 1], sv.N[3 * v + 2]}; }
+WF_HD V3 LoadS(const SceneView &sv, const wf_mesh &mesh, int v) { const float *p = sv.S + 3 * (size_t)(mesh.first_s + (v - mesh.first_vertex)); return V3{p[0], p[1], p[2]}; }
 WF_HD V2 LoadUV(const SceneView &sv, int v) { return V2{sv.UV[2 * v], sv.UV[2 * v + 1]}; }
 
 }  // namespace wf

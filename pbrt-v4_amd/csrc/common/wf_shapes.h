@@ -320,6 +320,32 @@ WF_HD bool CylinderBasicIntersect(const wf_quadric &s, V3 ro, V3 rd, float tMax,
     return true;
 }
 // ---------------------------------------------------------------------------------------------
+// PiecewiseConstant1D::Sample (util/sampling.h:657-675) and PiecewiseConstant2D::Sample / PDF (:760-780) over [0,1]^2 (wf_pc2d tables)
+WF_HD float PC1DSample(const float *func, const float *cdf, int n, float funcInt, float mn, float mx, float u,
+                       float *pdf, int *offset) {
+    int o = FindInterval(n + 1, [&](int index) { return cdf[index] <= u; });
+    *offset = o;
+    float du = u - cdf[o];
+    if (cdf[o + 1] - cdf[o] > 0) du /= cdf[o + 1] - cdf[o];
+    *pdf = (funcInt > 0) ? func[o] / funcInt : 0;
+    return Lerp((o + du) / n, mn, mx);
+}
+WF_HD V2 PC2DSample(const float *D, const wf_pc2d &t, V2 u, float *pdf) {
+    float pdf1, pdf0;
+    int iv, iu;
+    float d1 = PC1DSample(D + t.marg_func_offset, D + t.marg_cdf_offset, t.ny, t.marg_int, 0.f, 1.f, u.y, &pdf1, &iv);
+    float d0 = PC1DSample(D + t.cond_func_offset + (size_t)iv * t.nx, D + t.cond_cdf_offset + (size_t)iv * (t.nx + 1), t.nx,
+                          D[t.cond_int_offset + iv], 0.f, 1.f, u.x, &pdf0, &iu);
+    *pdf = pdf0 * pdf1;
+    return V2{d0, d1};
+}
+WF_HD float PC2DPDF(const float *D, const wf_pc2d &t, V2 p) {
+    // domain.Offset(p) with domain [0,1]^2: (p - 0) / (1 - 0)
+    V2 o{(p.x - 0.f) / (1.f - 0.f), (p.y - 0.f) / (1.f - 0.f)};
+    int iu = Clamp((int)(o.x * t.nx), 0, t.nx - 1);
+    int iv = Clamp((int)(o.y * t.ny), 0, t.ny - 1);
+    return D[t.cond_func_offset + (size_t)iv * t.nx + iu] / t.marg_int;
+}
 // BilinearPatch (shapes.h:1279-1510) as a wf_quadric of type WF_QUADRIC_BILINEAR (payload layout: include/wf_abi.h)
 struct BlpData { V3 p00, p10, p01, p11; N3 n00, n10, n01, n11; V2 uv00, uv10, uv01, uv11; bool hasN, hasUV; };
 WF_HD BlpData LoadBlp(const wf_quadric &s) {
@@ -1083,11 +1109,20 @@ WF_HD void TriangleInteraction(const SceneView &sv, int tri, float b0, float b1,
     si->dpdus = dpdu;
     si->dpdvs = dpdv;
     si->dndus = si->dndvs = N3{0, 0, 0};
-    if (mesh.flags & WF_MESH_HAS_N) {
-        N3 n0 = LoadN(sv, v[0]), n1 = LoadN(sv, v[1]), n2 = LoadN(sv, v[2]);
-        N3 ns = b0 * n0 + b1 * n1 + b2 * n2;
-        ns = LengthSquared(ns) > 0 ? Normalize(ns) : si->n;
+    if (mesh.flags & (WF_MESH_HAS_N | WF_MESH_HAS_S)) {   // shapes.h:940: mesh->n || mesh->s
+        const bool hasN = mesh.flags & WF_MESH_HAS_N;
+        N3 n0{0, 0, 0}, n1{0, 0, 0}, n2{0, 0, 0};
+        N3 ns = si->n;
+        if (hasN) {
+            n0 = LoadN(sv, v[0]); n1 = LoadN(sv, v[1]); n2 = LoadN(sv, v[2]);
+            ns = b0 * n0 + b1 * n1 + b2 * n2;
+            ns = LengthSquared(ns) > 0 ? Normalize(ns) : si->n;
+        }
         V3 ss = si->dpdu;
+        if (mesh.flags & WF_MESH_HAS_S) {   // the interpolated "S" tangent (shapes.h:951-959)
+            ss = b0 * LoadS(sv, mesh, v[0]) + b1 * LoadS(sv, mesh, v[1]) + b2 * LoadS(sv, mesh, v[2]);
+            if (LengthSquared(ss) == 0) ss = si->dpdu;
+        }
         V3 ts = Cross(ns, ss);
         if (LengthSquared(ts) > 0) ss = Cross(ts, ns);
         else CoordinateSystem(toV(ns), &ss, &ts);
@@ -1095,7 +1130,8 @@ WF_HD void TriangleInteraction(const SceneView &sv, int tri, float b0, float b1,
         N3 dn1 = n0 - n2, dn2 = n1 - n2;
         float det2 = DifferenceOfProducts(duv02.x, duv12.y, duv02.y, duv12.x);
         bool degUV = abs(det2) < 1e-9;  // double comparison in the reference (shapes.h:984)
-        if (degUV) {
+        if (!hasN) dndu = dndv = N3{0, 0, 0};   // shapes.h:1003-1004
+        else if (degUV) {
             V3 dn = Cross(toV(n2 - n0), toV(n1 - n0));
             if (LengthSquared(dn) == 0) dndu = dndv = N3{0, 0, 0};
             else {
@@ -1883,13 +1919,15 @@ WF_HD V2 BlpST(const BlpData &d, float u, float v) {
     return lerp2(u, lerp2(v, d.uv00, d.uv01), lerp2(v, d.uv10, d.uv11));
 }
 // BilinearPatch::Sample(Point2f u) (shapes.cpp:1155-1215)
-WF_HD ShapeSampleR BlpSampleArea(const BlpData &d, int meshFlags, bool rectangle, V2 u) {
+// `dist` / D: the mesh's image distribution ("emissionfilename", shapes.cpp:1165-1166) and the table it lives in, or null
+WF_HD ShapeSampleR BlpSampleArea(const BlpData &d, int meshFlags, bool rectangle, V2 u, const wf_pc2d *dist = nullptr, const float *D = nullptr) {
     ShapeSampleR r;
     r.valid = false;
     const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
     float pdf = 1;
     V2 uv;
-    if (!rectangle) {
+    if (dist) uv = PC2DSample(D, *dist, u, &pdf);
+    else if (!rectangle) {
         const float w[4] = {Length(Cross(p10 - p00, p01 - p00)), Length(Cross(p10 - p00, p11 - p10)), Length(Cross(p01 - p00, p11 - p01)), Length(Cross(p11 - p10, p11 - p01))};
         uv = SampleBilinear(u, w);
         pdf = BilinearPDF(uv, w);
@@ -1908,17 +1946,18 @@ WF_HD ShapeSampleR BlpSampleArea(const BlpData &d, int meshFlags, bool rectangle
     return r;
 }
 // BilinearPatch::Sample(const ShapeSampleContext &, Point2f) (shapes.cpp:1252-1327).  Out of line: pointer arguments only.
-WF_NI void BilinearSampleP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nsx, float nsy, float nsz, float ux, float uy, ShapeSampleR *out) {
+WF_NI void BilinearSampleP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nsx, float nsy, float nsz, float ux, float uy, ShapeSampleR *out, const float *D) {
     const BlpData d = LoadBlp(*sp);
     const bool rectangle = ((int)sp->pad[0] & 4) != 0;
+    const wf_pc2d *dist = ((int)sp->pad[0] & 8) ? (const wf_pc2d *)sp->ext : nullptr;   // "emissionfilename": always sampled by area (shapes.cpp:1265)
     const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
     const V3 ctxP = ctxPiP->mid();
     const N3 ctxNs{nsx, nsy, nsz};
     V2 u{ux, uy};
     V3 v00 = Normalize(p00 - ctxP), v10 = Normalize(p10 - ctxP);
     V3 v01 = Normalize(p01 - ctxP), v11 = Normalize(p11 - ctxP);
-    if (!rectangle || SphericalQuadArea(v00, v10, v11, v01) <= 1e-4f) {
-        ShapeSampleR ss = BlpSampleArea(d, meshFlags, rectangle, u);
+    if (!rectangle || dist || SphericalQuadArea(v00, v10, v11, v01) <= 1e-4f) {
+        ShapeSampleR ss = BlpSampleArea(d, meshFlags, rectangle, u, dist, D);
         ss.valid = ss.valid;
         if (ss.valid) {
             V3 wi = ss.pi.mid() - ctxP;
@@ -1952,9 +1991,10 @@ WF_NI void BilinearSampleP(const wf_quadric *sp, int meshFlags, const P3i *ctxPi
     *out = r;
 }
 // BilinearPatch::PDF(const ShapeSampleContext &, Vector3f wi) (shapes.cpp:1329-1368) over PDF(const Interaction &) (:1217-1250)
-WF_NI float BilinearPDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float nsx, float nsy, float nsz, float wx, float wy, float wz) {
+WF_NI float BilinearPDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP, float nx, float ny, float nz, float nsx, float nsy, float nsz, float wx, float wy, float wz, const float *D) {
     const BlpData d = LoadBlp(*sp);
     const bool rectangle = ((int)sp->pad[0] & 4) != 0;
+    const wf_pc2d *dist = ((int)sp->pad[0] & 8) ? (const wf_pc2d *)sp->ext : nullptr;
     const V3 p00 = d.p00, p10 = d.p10, p01 = d.p01, p11 = d.p11;
     const P3i ctxPi = *ctxPiP;
     const V3 ctxP = ctxPi.mid();
@@ -1968,12 +2008,13 @@ WF_NI float BilinearPDFP(const wf_quadric *sp, int meshFlags, const P3i *ctxPiP,
     const V3 pHit = si.pi.mid();
     V3 v00 = Normalize(p00 - ctxP), v10 = Normalize(p10 - ctxP);
     V3 v01 = Normalize(p01 - ctxP), v11 = Normalize(p11 - ctxP);
-    if (!rectangle || SphericalQuadArea(v00, v10, v11, v01) <= 1e-4f) {
+    if (!rectangle || dist || SphericalQuadArea(v00, v10, v11, v01) <= 1e-4f) {
         // PDF(isect->intr): parametric (u, v) back from the interaction's (s, t)
         V2 uv = si.uv;
         if (d.hasUV) uv = InvertBilinear(uv, d.uv00, d.uv10, d.uv01, d.uv11);
         float pdfA;
-        if (!rectangle) {
+        if (dist) pdfA = PC2DPDF(D, *dist, uv);   // shapes.cpp:1233-1234
+        else if (!rectangle) {
             const float w[4] = {Length(Cross(p10 - p00, p01 - p00)), Length(Cross(p10 - p00, p11 - p10)), Length(Cross(p01 - p00, p11 - p01)), Length(Cross(p11 - p10, p11 - p01))};
             pdfA = BilinearPDF(uv, w);
         } else pdfA = 1;
@@ -2003,7 +2044,7 @@ WF_HD ShapeSampleR SphereSample(const SceneView &sv, int prim, const P3i &ctxPi,
         r.valid = false;
         return r;
     }
-    if (s->type == WF_QUADRIC_BILINEAR) { BilinearSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxNs.x, ctxNs.y, ctxNs.z, u.x, u.y, &r); return r; }
+    if (s->type == WF_QUADRIC_BILINEAR) { BilinearSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxNs.x, ctxNs.y, ctxNs.z, u.x, u.y, &r, sv.tableData); return r; }
     SphereSampleP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, u.x, u.y, &r);
     return r;
 }
@@ -2038,7 +2079,7 @@ WF_HD float SpherePDF(const SceneView &sv, int prim, const P3i &ctxPi, N3 ctxN, 
     const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
     const P3i pi = ctxPi;
     if (s->type == WF_QUADRIC_CURVE) { RaiseFatal(sv, WF_FATAL_CURVE_PDF); return 0; }   // Curve::PDF: LOG_FATAL (shapes.cpp:754-757)
-    if (s->type == WF_QUADRIC_BILINEAR) return BilinearPDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, ctxNs.x, ctxNs.y, ctxNs.z, wi.x, wi.y, wi.z);
+    if (s->type == WF_QUADRIC_BILINEAR) return BilinearPDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, ctxNs.x, ctxNs.y, ctxNs.z, wi.x, wi.y, wi.z, sv.tableData);
     return SpherePDFP(s, sv.meshes[s->mesh].flags, &pi, ctxN.x, ctxN.y, ctxN.z, wi.x, wi.y, wi.z);
 }
 

@@ -609,7 +609,11 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
     int next = 0, end = 0, staticJ = 0;   // the wave's private run [next, end) of ray indices (uniform)
     bool exhausted = false;
     int idx = -1;
+#if WF_WALK_ZERO
+    RayWalk w{};
+#else
     RayWalk w;
+#endif
     w.node = NODE_NONE;
     w.prim = -1;
     w.route = 0;
@@ -1686,6 +1690,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.P, d->P, (size_t)3 * d->n_vertices))) return e;
     if ((e = devUpload(ctx, &sv.N, d->N, (size_t)3 * d->n_vertices))) return e;
     if ((e = devUpload(ctx, &sv.UV, d->UV, (size_t)2 * d->n_vertices))) return e;
+    if (d->n_tangents > 0 && (e = devUpload(ctx, &sv.S, d->S, (size_t)3 * d->n_tangents))) return e;
     if ((e = devUpload(ctx, &sv.triIndices, d->tri_indices, (size_t)3 * d->n_triangles))) return e;
     if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles + d->n_quadrics))) return e;
     if ((e = devUpload(ctx, &sv.quadrics, d->quadrics, (size_t)d->n_quadrics))) return e;

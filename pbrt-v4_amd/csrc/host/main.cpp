@@ -162,6 +162,12 @@ static int Main(int argc, char **argv) {
         for (int d = 0; d < 64; ++d)
             if (st.shadow_rays[d]) { printf("    Shadow rays, depth %-3d   %12llu\n", d, (unsigned long long)st.shadow_rays[d]); total += st.shadow_rays[d]; }
         printf("    Total rays %21llu  (%.2f Mray/s)\n", total, total / seconds / 1e6);
+        uint64_t items[16];
+        if (wf_material_items_download(renderer.Context(), items) == 0) {   // (the denominators of bench.py's roofline_material / roofline_medium traffic)
+            unsigned long long mat = 0;
+            for (int t = 0; t < WF_MAT_NTYPES; ++t) mat += items[t];
+            printf("    Material items %17llu\n    Medium-sample items %12llu\n", mat, (unsigned long long)items[WF_MAT_NTYPES]);
+        }
         std::vector<wf_kernel_profile_entry> ent(64);
         int n = 0;
         wf_profile_report(renderer.Context(), ent.data(), (int)ent.size(), &n);

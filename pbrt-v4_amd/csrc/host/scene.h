@@ -129,6 +129,7 @@ void ParseString(const std::string &text, RenderOptions *opt, ParsedScene *scene
 struct SceneTables {
     wf_scene_desc desc{};
     std::vector<float> P, N, UV;
+    std::vector<float> S;   // shading tangents of the meshes that have them (wf_mesh.first_s)
     std::vector<int32_t> triIndices, triMesh, bvhPrims, infiniteLights;
     std::vector<wf_mesh> meshes;
     std::vector<wf_quadric> quadrics;

@@ -55,6 +55,7 @@ void SceneTables::Finalize() {
     desc.n_meshes = (int)meshes.size();
     desc.n_bvh_nodes = (int)bvhNodes.size();
     desc.P = P.data(); desc.N = N.data(); desc.UV = UV.data();
+    desc.n_tangents = (int64_t)S.size() / 3; desc.S = S.empty() ? nullptr : S.data();
     desc.tri_indices = triIndices.data(); desc.tri_mesh = triMesh.data();
     desc.meshes = meshes.data(); desc.bvh_nodes = bvhNodes.data(); desc.bvh_prims = bvhPrims.data();
     desc.n_quadrics = (int)quadrics.size(); desc.quadrics = quadrics.data();
@@ -909,6 +910,29 @@ void BuildFilter(const ParsedScene &scene, SceneTables *T) {
     wfF.marg_func_offset = (int)D.size(); D.insert(D.end(), mFunc.begin(), mFunc.end());
     wfF.marg_cdf_offset = (int)D.size(); D.insert(D.end(), mCdf.begin(), mCdf.end());
     wfF.marg_int = mInt;
+}
+
+// PiecewiseConstant2D over [0,1]^2 (util/sampling.h:706-722) of a w x h function, appended to a float table
+static wf_pc2d AppendPC2D(std::vector<float> *Dp, const std::vector<float> &f, int w, int h) {
+    wf_pc2d t{};
+    t.nx = w; t.ny = h;
+    std::vector<float> condFunc, condCdf, condInt(h), mFunc, mCdf;
+    for (int v = 0; v < h; ++v) {
+        std::vector<float> fn, cdf;
+        float fi;
+        BuildPC1D(&f[(size_t)v * w], w, 0.f, 1.f, &fn, &cdf, &fi);
+        condFunc.insert(condFunc.end(), fn.begin(), fn.end());
+        condCdf.insert(condCdf.end(), cdf.begin(), cdf.end());
+        condInt[v] = fi;
+    }
+    BuildPC1D(condInt.data(), h, 0.f, 1.f, &mFunc, &mCdf, &t.marg_int);
+    std::vector<float> &D = *Dp;
+    t.cond_func_offset = (int)D.size(); D.insert(D.end(), condFunc.begin(), condFunc.end());
+    t.cond_cdf_offset = (int)D.size(); D.insert(D.end(), condCdf.begin(), condCdf.end());
+    t.cond_int_offset = (int)D.size(); D.insert(D.end(), condInt.begin(), condInt.end());
+    t.marg_func_offset = (int)D.size(); D.insert(D.end(), mFunc.begin(), mFunc.end());
+    t.marg_cdf_offset = (int)D.size(); D.insert(D.end(), mCdf.begin(), mCdf.end());
+    return t;
 }
 
 // ---- film / sampler / camera -------------------------------------------------------------------------
@@ -2006,6 +2030,8 @@ struct MeshSource {
     std::vector<int> indices;
     std::vector<int> quads;  // bilinear patches: p00 p10 p01 p11 per patch (a PLY quad face f0 f1 f2 f3 is stored f0 f1 f3 f2, util/mesh.cpp:302-305)
     std::vector<V3> P, N;
+    std::vector<V3> S;   // "S" shading tangents (trianglemesh only)
+    std::string emissionFilename;   // bilinearmesh "emissionfilename" (resolved when the patches are built)
     std::vector<V2> uv;
 };
 
@@ -2106,7 +2132,12 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         if (!m->uv.empty() && m->uv.size() != m->P.size()) m->uv.clear();
         if (!m->N.empty() && m->N.size() != m->P.size()) m->N.clear();
         for (int vi : m->indices) if (vi < 0 || vi >= (int)m->P.size()) { fprintf(stderr, "Error: %s: trianglemesh has out of-bounds vertex index %d\n", sh.loc.c_str(), vi); return false; }
-        if (!ps.GetTuple3Array("S", "vector3").empty()) fprintf(stderr, "Warning: %s: \"S\" tangents are ignored by this build\n", sh.loc.c_str());
+        m->S = ps.GetTuple3Array("S", "vector3");   // shading tangents (shapes.cpp:404-409)
+        if (m->S.empty()) m->S = ps.GetTuple3Array("S", "vector");
+        if (!m->S.empty() && m->S.size() != m->P.size()) {
+            fprintf(stderr, "Error: %s: Number of \"S\"s for triangle mesh must match \"P\"s. Discarding \"S\"s.\n", sh.loc.c_str());
+            m->S.clear();
+        }
         return true;
     } else if (sh.name == "loopsubdiv") {
         // shapes.cpp:1473-1490
@@ -2150,7 +2181,13 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         if (!m->uv.empty() && m->uv.size() != m->P.size()) m->uv.clear();
         if (!m->N.empty() && m->N.size() != m->P.size()) m->N.clear();
         for (int vi : m->quads) if (vi < 0 || vi >= (int)m->P.size()) { fprintf(stderr, "Error: %s: Bilinear patch mesh has out of-bounds vertex index %d\n", sh.loc.c_str(), vi); return false; }
-        if (!ps.GetOneString("emissionfilename", "").empty()) Die(sh.loc, "bilinearmesh \"emissionfilename\" is not supported by this build");
+        // "emissionfilename" (shapes.cpp:978-994): the patches are sampled by area with the image's distribution
+        m->emissionFilename = ps.GetOneString("emissionfilename", "");
+        if (!m->emissionFilename.empty() && m->emissionFilename[0] != '/') m->emissionFilename = baseDir + "/" + m->emissionFilename;
+        if (!m->emissionFilename.empty() && !m->uv.empty()) {
+            fprintf(stderr, "Error: %s: \"emissionfilename\" is currently ignored for bilinear patches if \"uv\" coordinates have been provided--sorry!\n", sh.loc.c_str());
+            m->emissionFilename.clear();
+        }
         return true;
     }
     Die(sh.loc, sh.name + ": shape type not supported by this build (trianglemesh, plymesh, loopsubdiv, bilinearmesh, curve, sphere, disk, cylinder)");
@@ -2627,6 +2664,11 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         if (!src.N.empty()) mesh.flags |= WF_MESH_HAS_N;
         if (!src.uv.empty()) mesh.flags |= WF_MESH_HAS_UV;
         if (sh.reverseOrientation ^ swaps) mesh.flags |= WF_MESH_FLIP_NORMAL;
+        if (!src.S.empty() && src.S.size() == src.P.size()) {   // TriangleMesh ctor, util/mesh.cpp:58-63: renderFromObject(Vector3f)
+            mesh.flags |= WF_MESH_HAS_S;
+            mesh.first_s = (int)(T->S.size() / 3);
+            for (const V3 &s : src.S) { const V3 r = rfo.Vector(s); T->S.push_back(r.x); T->S.push_back(r.y); T->S.push_back(r.z); }
+        }
         for (size_t i = 0; i < src.P.size(); ++i) {
             V3 p = rfo.Point(src.P[i]);
             if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z))
@@ -2666,11 +2708,31 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             auto P3 = [&](int vi) { return V3{T->P[3 * (v0 + vi)], T->P[3 * (v0 + vi) + 1], T->P[3 * (v0 + vi) + 2]}; };
             auto N3f = [&](int vi) { return V3{T->N[3 * (v0 + vi)], T->N[3 * (v0 + vi) + 1], T->N[3 * (v0 + vi) + 2]}; };
             auto UV2 = [&](int vi) { return V2{T->UV[2 * (v0 + vi)], T->UV[2 * (v0 + vi) + 1]}; };
+            // BilinearPatchMesh::imageDistribution (shapes.cpp:985-993): Image::Read, FlipY, GetSamplingDistribution (the average of
+            // ALL the image's channels per pixel, util/image.cpp:440-470), PiecewiseConstant2D over [0,1]^2; one table per mesh, its
+            // descriptor in every patch record (ext[0..7], flag bit 3)
+            wf_pc2d emissionDist{};
+            bool haveEmissionDist = false;
+            if (!src.emissionFilename.empty()) {
+                HostImage img;
+                try { ReadImage(src.emissionFilename, ColorEnc(), &img); } catch (const SceneError &e) { Die(sh.loc, std::string(e.what()).substr(7)); }
+                std::vector<float> d((size_t)img.w * img.h);
+                for (int y = 0; y < img.h; ++y)
+                    for (int x = 0; x < img.w; ++x) {
+                        float sum = 0;
+                        const size_t src0 = ((size_t)(img.h - 1 - y) * img.w + x) * img.nc;   // FlipY
+                        for (int c = 0; c < img.nc; ++c) sum += img.Get(src0 + c);
+                        d[(size_t)y * img.w + x] = sum / img.nc;
+                    }
+                emissionDist = AppendPC2D(&T->tableData, d, img.w, img.h);
+                haveEmissionDist = true;
+            }
             for (size_t q = 0; q + 3 < src.quads.size(); q += 4) {
                 PendingSphere p{};
                 p.s.type = WF_QUADRIC_BILINEAR;
                 p.s.mesh = patchMeshId;
-                p.s.pad[0] = (float)((src.N.empty() ? 0 : 1) | (src.uv.empty() ? 0 : 2));
+                p.s.pad[0] = (float)((src.N.empty() ? 0 : 1) | (src.uv.empty() ? 0 : 2) | (haveEmissionDist ? 8 : 0));
+                if (haveEmissionDist) memcpy(p.s.ext, &emissionDist, sizeof(emissionDist));
                 float *a = &p.s.render_from_object.m[0][0], *b = &p.s.render_from_object.mInv[0][0];
                 const int *vi = &src.quads[q];
                 for (int k = 0; k < 4; ++k) {

@@ -36,6 +36,8 @@ for step in "$@"; do
       grep -E "passed|failed|FAILED|ERROR|error" $OUT/${TAG}_pytest_gpu_full.txt | tail -8 | tee $OUT/${TAG}_pytest_gpu.txt
       timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/${TAG}_smoke.txt;;
     bench)
+      # the box itself (the pool's boxes differ by up to 17 % on the same binary: clocks / power cap recorded beside every bench line)
+      (rocm-smi --showclocks --showpower --showmaxpower --showperflevel 2>/dev/null | grep -E "clk|Power|Perf" | head -12) > $OUT/${TAG}_box.txt
       timeout 900 python bench.py --steps $STEPS --warmup 5 2> $OUT/${TAG}_bench_err.txt | tee $OUT/${TAG}_bench_k$STEPS.json
       tail -3 $OUT/${TAG}_bench_err.txt;;
     prof)
