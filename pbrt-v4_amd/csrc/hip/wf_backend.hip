@@ -26,8 +26,14 @@
 #include <type_traits>
 #include <vector>
 
+// This unit is compiled with -ftrivial-auto-var-init=zero (Makefile, BACKENDFLAGS; DESIGN 4.1 "Locals that start as undef"): the walk
+// loops below and in wf_traverse.h spill a third less when no local starts as undef.  The shared stage code keeps the default: its
+// out-of-line shape / texture functions grow by 15 VGPRs when initialised, which takes the general-primitive walk kernels (GEN = 2)
+// from 165 to 180 registers and from 3 waves to 2 (-9 / -12 % on the spec scene plus one sphere).
+#pragma clang attribute push(__attribute__((uninitialized)), apply_to = variable(is_local))
 #include "../common/wf_kernels.h"
 #include "../common/wf_kat.h"
+#pragma clang attribute pop
 #include "wf_traverse.h"
 
 using namespace wf;
@@ -354,6 +360,7 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
 }
 template <typename Fetch, int GEN>
 struct GeneralPrims {
+    static constexpr bool pairBands = GEN >= 2;   // quadrics / patches / curves in the scene: the near-tie band depends on the pair (wf_traverse.h)
     const SceneView &sv;
     const FastBVH &bvh;
     const RayWalk &w;
@@ -377,6 +384,7 @@ struct GeneralPrims {
 };
 // the two-level walk of a scene without alpha cut-outs or quadrics: only the lazy instance transition's hook (wf_traverse.h)
 struct InstOnlyPrims {
+    static constexpr bool pairBands = false;
     const FastBVH &bvh;
     __device__ bool accept(int, float, float, float) const { return true; }
     __device__ bool sphere(int, float, QuadricHit *) const { return false; }
@@ -807,8 +815,16 @@ __device__ inline void DrainRetrace(const SceneView &sv, const WorkState &ws, co
 // hitT, routeCode) and k_route_hits pushes the queue entries afterwards in one streaming pass; waves never meet, so a wave whose 64
 // walks are done moves on to its next 64 rays while the others still walk.
 constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes this ray
+// The occupancy target of a walk kernel.  The general-primitive variants (GEN >= 2) cannot reach the triangle kernels' 4-5 waves, but the
+// target still matters: the allocator spills towards it before the callees' frames are added (asked for 3 / 2 waves, which they could
+// reach, GEN = 2 / 3 ended at 2 / 1; asked for the triangle kernels' 4-5 they end at 3 / 2).  WF_TWAVES_GEN2: see the Makefile's note on
+// zero-initialised locals, which cost GEN = 2 fifteen registers at the old target.
+#ifndef WF_TWAVES_GEN2
+#define WF_TWAVES_GEN2 0   // 0: the triangle kernels' target
+#endif
+constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : triangleWaves; }
 template <int GEN, bool INST = false, bool SPLIT = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
@@ -996,7 +1012,7 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
 }
 template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES)) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
@@ -1074,6 +1090,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
 // production layout, one independent walk per lane (a transmittance ray alternates between tracing and
 // ratio tracking, so there is no batch to share)
 struct TrPrims {  // the same callbacks for the transmittance walk, whose ray is a local of its loop
+    static constexpr bool pairBands = true;   // (a per-lane loop over whole scenes, general shapes included)
     const SceneView &sv;
     V3 o, d;
     __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
@@ -1592,6 +1609,9 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         const double band = d->n_quadrics > 0 ? 0x1p-10 : 0x1p-20;   // (FastBVH::tieRel: quadric hits are accepted by interval bounds)
         out->absBand = (float)(band * ext);
         out->tieRel = (float)(1 + band);
+        out->absBandTri = (float)(0x1p-20 * ext);   // the band of a triangle / triangle pair (wf_traverse.h, WalkAccept<PAIRS>)
+        out->tieRelTri = (float)(1 + 0x1p-20);
+        out->firstGeneral = d->n_quadrics > 0 ? d->n_triangles : INT_MAX;
     }
     defs->clear();
     for (int k = 0; k < d->n_instance_defs; ++k) {

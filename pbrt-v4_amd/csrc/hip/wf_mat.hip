@@ -16,14 +16,14 @@ using namespace wf;
 constexpr int MBLOCK = 256;
 
 // minimum waves per SIMD (the register budget: 2 -> 256 VGPRs, 3 -> 168).  Measured per material on the spec scene, 2 vs 3 waves: diffuse
-// 24.1 -> 22.7 ms per 16 spp, conductor 6.27 -> 6.40, coated diffuse 17.4 -> 20.2 (its stochastic walks spill): only the diffuse kernel
-// takes the third wave.
+// 24.1 -> 22.7 ms per 16 spp, conductor 6.27 -> 6.40, coated diffuse 17.4 -> 20.2 (its stochastic walks spill).  Rounds 3-4 ran the diffuse
+// kernel at 3 waves for those 6 %; round 4 took it back: at 168 VGPRs the unit spills ~170 VGPRs beside ~300 SGPRs that the compiler
+// spills THROUGH VGPR lanes, and that build was the common factor of three wrong-code incidents that no source change explains — a
+// never-executed conditional store that made cornell64 differ from run to run, a 48-frame texture stack that made arealight_image
+// unrepeatable, and (after an unrelated header change) a memory access fault on every render of cornell64; the same source at 2 waves,
+// at -O2, with zero-initialised locals or with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 is correct each time.
 #ifndef WF_MAT_WAVES
-#if WF_MAT_INSTANCE == 1
-#define WF_MAT_WAVES 3
-#else
 #define WF_MAT_WAVES 2
-#endif
 #endif
 template <int MAT, int TEXCTX>
 __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const SceneView sv, WorkState ws, int cur) {

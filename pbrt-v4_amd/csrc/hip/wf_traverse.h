@@ -120,6 +120,12 @@ struct FastBVH {
     // decided by the visiting order: of two coincident cylinders the reference keeps the FIRST, this walk kept whichever its own
     // order met first and never marked the ray (fuzz finding s200010 on the GPU: 7 % of the pixels)
     float tieRel;
+    // ... but only a pair of candidates that INVOLVES such a shape needs the wide band (round 4, second step): two triangles are ordered
+    // by their exact t on both sides, 2^-20 decides.  With the wide band applied to every pair the 10 M-triangle scene plus ONE sphere
+    // marked so many rays that the re-trace launches took 162 ms of a 358 ms frame.  tieRelTri / absBandTri: the triangles' own band;
+    // firstGeneral: the first primitive id that is not a triangle (INT_MAX without such shapes; then both bands are the same).
+    float tieRelTri, absBandTri;
+    int firstGeneral;
     const struct FastDef *defs;       // per instance definition (scenes with object instances)
     const wf_instance *instances;
     const SceneView *sv;              // device-resident copy of the scene view, for the out-of-line general-primitive callbacks
@@ -346,9 +352,23 @@ __device__ inline float WalkBound(const FastBVH &, float t) { return t; }
 #endif
 // a candidate hit at t: clearly nearer -> new best (an older mark is dropped: those candidates lie beyond);
 // within the band of the best -> keep the nearer one, mark the ray
-__device__ inline bool WalkAccept(const FastBVH &bvh, RayWalk &w, float t) {
+// PAIRS (the kernels of scenes with quadrics / patches / curves): the band of a comparison is the wide one when the candidate or the best
+// hit so far is such a shape — or when the ray is already marked: a mark may stand for a general shape seen earlier whose t lies within
+// the wide band of the candidate, and it must not be dropped by a triangle that is nearer by the narrow band only
+template <bool PAIRS = false>
+__device__ inline float WalkTestBound(const FastBVH &bvh, const RayWalk &w, bool candGeneral) {
     const float cur = __builtin_fabsf(w.tMax);
-    if (!WF_TIE || WalkBound(bvh, t) < cur) { w.tMax = t; return true; }
+    if constexpr (PAIRS)
+        if (!(candGeneral || w.prim >= bvh.firstGeneral || WalkAmbiguous(w))) return fma(cur, bvh.tieRelTri, bvh.absBandTri);
+    return WalkBound(bvh, cur);
+}
+template <bool PAIRS = false>
+__device__ inline bool WalkAccept(const FastBVH &bvh, RayWalk &w, float t, bool candGeneral = false) {
+    const float cur = __builtin_fabsf(w.tMax);
+    float bt = WalkBound(bvh, t);
+    if constexpr (PAIRS)
+        if (!(candGeneral || w.prim >= bvh.firstGeneral || WalkAmbiguous(w))) bt = fma(t, bvh.tieRelTri, bvh.absBandTri);
+    if (!WF_TIE || bt < cur) { w.tMax = t; return true; }
     const bool nearer = t < cur;
     w.tMax = -(nearer ? t : cur);
     return nearer;
@@ -438,6 +458,7 @@ __device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, c
 // texture (ex.accept(prim, b0, b1, b2) decides), entries marked c.z == 3 are spheres (ex.sphere(prim, tMax, &hit);
 // the hit's pObj travels in b0..b2).  Scenes without either use the plain variants, which never see the marks.
 struct NoExtra {
+    static constexpr bool pairBands = false;
     __device__ bool accept(int, float, float, float) const { return true; }
     __device__ bool sphere(int, float, QuadricHit *) const { return false; }
     __device__ void exact(RayWalk &) const {}
@@ -459,16 +480,17 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
         if constexpr (INST)
             if (w.lazy) ex.exact(w);   // the first primitive test since the walk changed spaces (WF_LAZY_INST)
         // closest hit: test against the relaxed bound so that near-ties are seen (WalkAccept sorts them out)
-        const float tTest = ANY ? w.tMax : WalkBound(bvh, __builtin_fabsf(w.tMax));
+        constexpr bool PAIRS = Extra::pairBands;
         if constexpr (ALPHA)
             if (tc.z == 3.f) {
+                const float tTest = ANY ? w.tMax : WalkBound(bvh, __builtin_fabsf(w.tMax));
                 QuadricHit qh;
                 // (closest hit: against the RELAXED bound, like the triangles below — a quadric whose t lies inside the near-tie band of
                 //  the current best must reach WalkAccept to mark the ray; tested against the exact bound, the second of two coincident
                 //  quadrics was silently dropped and the visiting order decided: fuzz finding s200010 on the GPU, round 4)
                 if (ex.sphere((int)FloatToBits(tc.y), tTest, &qh)) {
                     if (ANY) { w.prim = (int)FloatToBits(tc.y); w.tMax = qh.tHit; done = true; break; }
-                    if (WalkAccept(bvh, w, qh.tHit)) {
+                    if (WalkAccept<PAIRS>(bvh, w, qh.tHit, true)) {
                         w.prim = (int)FloatToBits(tc.y);
                         w.inst = w.curInst;
                         w.route = FloatToBits(tc.w);
@@ -477,12 +499,13 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
                 }
                 continue;
             }
+        const float tTest = ANY ? w.tMax : WalkTestBound<PAIRS>(bvh, w, false);
         if ((ALPHA ? tc.z != 1.f : tc.z == 0.f) &&
             IntersectTriangleSheared(w.o, w.sh, tTest, V3{ta.x, ta.y, ta.z}, V3{ta.w, tb.x, tb.y}, V3{tb.z, tb.w, tc.x}, &h, false)) {
             if constexpr (ALPHA)
                 if (tc.z == 2.f && !ex.accept((int)FloatToBits(tc.y), h.b0, h.b1, h.b2)) continue;
             if (ANY) { w.prim = (int)FloatToBits(tc.y); w.tMax = h.t; done = true; break; }
-            if (WalkAccept(bvh, w, h.t)) {
+            if (WalkAccept<PAIRS>(bvh, w, h.t, false)) {
                 w.prim = (int)FloatToBits(tc.y);
                 w.inst = w.curInst;
                 w.route = FloatToBits(tc.w);

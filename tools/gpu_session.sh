@@ -11,7 +11,7 @@
 #   pmc              rocprofv3 PMC passes (SQ / TCP / TCC / FETCH / WRITE, one pass each) over the spec scene at $PMC_SPP spp
 #   soak             $SOAK renders of the spec scene at 4 spp: every image must be the first one (the near-tie queue's guard)
 #   ab               pbrt_amd --stats under each environment given in $AB (";"-separated) — knob A/B on one box
-# Environment: TAG (default r04), STEPS (20), SPP (16), PMC_SPP (4), SCENE (sanmiguel | killeroo | cloud | tm), GREP (kernel-name filter of sm16).
+# Environment: TAG (default r04), STEPS (20), SPP (16), PMC_SPP (4), SCENE (sanmiguel | sanmiguel_sphere | killeroo | cloud | tm), GREP (kernel-name filter of sm16).
 export TMPDIR=/tmp
 TAG=${TAG:-r04}; STEPS=${STEPS:-20}; SPP=${SPP:-16}; PMC_SPP=${PMC_SPP:-4}; SCENE=${SCENE:-sanmiguel}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -20,12 +20,16 @@ mkdir -p $OUT
 scene_file() {   # the benchmarked stand-in as a scene file under /tmp (generated once per box)
   case $SCENE in
     sanmiguel) d=/tmp/wfbench_sm; f=$d/sm.pbrt; gen="sanmiguel-like";;
+    sanmiguel_sphere) d=/tmp/wfbench_sms; f=$d/sm.pbrt; gen="sanmiguel-like";;   # + one sphere: the GEN = 2 kernels on the headline geometry
     killeroo)  d=/tmp/wfbench_k;  f=$d/k.pbrt;  gen="killeroo-like";;
     cloud)     d=/tmp/wfbench_c;  f=$d/c.pbrt;  gen="cloud-like";;
     tm)        d=/tmp/wfbench_tm; f=$d/tm.pbrt; gen="tm-like";;
   esac
   mkdir -p $d
-  [ -f $f ] || python $ROOT/tools/make_scenes.py $gen $f --spp 16 > /dev/null
+  if [ ! -f $f ]; then
+    python $ROOT/tools/make_scenes.py $gen $f --spp 16 > /dev/null
+    [ $SCENE = sanmiguel_sphere ] && printf 'AttributeBegin\n  Material "conductor" "float roughness" 0.1\n  Translate 0 1.5 0\n  Shape "sphere" "float radius" 0.75\nAttributeEnd\n' >> $f
+  fi
   echo $f
 }
 for step in "$@"; do
