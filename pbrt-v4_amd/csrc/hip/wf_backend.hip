@@ -704,6 +704,9 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
 #ifndef WF_REFILL_INLINE
 #define WF_REFILL_INLINE 0    // diagnostic: the closest-hit walk refills its lanes but re-walks near ties inline (no queue, no service workgroups)
 #endif
+#ifndef WF_REFILL_GEN2
+#define WF_REFILL_GEN2 1   // spec scene + one sphere, 16 spp, same box: closest-hit 73.4 -> 64.6 ms (profiles/r04_one_sphere_refill_ab_sm16.txt)
+#endif
 #ifndef WF_REFILL_CLOSEST
 #define WF_REFILL_CLOSEST 1   // with the near-tie walk out of the loop (DrainRetrace): 56.0 -> see DESIGN 4.1
 #endif
@@ -712,7 +715,9 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
 template <bool ANY, int GEN, bool INST, bool PERLANE, bool DEFER = false, typename Fetch, typename Finish>
 __device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4,
                                   int workBlocks = 0) {
-    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : (DEFER || WF_REFILL_INLINE != 0))) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
+    // (the closest-hit walk of scenes with general primitives, GEN >= 2: its near-ties go to the separate re-trace launch anyway, so the
+    //  refill loop carries no reference-order walk — WF_REFILL_GEN2, round 4)
+    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : (DEFER || WF_REFILL_INLINE != 0 || (WF_REFILL_GEN2 != 0 && !RetraceInline(GEN))))) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
     else BatchTrace<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
 }
 // The near-tie rays of a closest-hit launch, resolved inside the launch (round 3, second step).  A walk that ends on a near-tie publishes
