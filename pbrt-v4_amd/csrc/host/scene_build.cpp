@@ -113,7 +113,7 @@ bool SceneTables::Save(const std::string &path) const {
     putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, sobolMatrices); putVec(f, vdcSobol); putVec(f, vdcSobolInv); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
     putVec(f, haltonPerms); putVec(f, bvhNodes); putVec(f, pool.spectra); putVec(f, pool.data); putVec(f, textures); putVec(f, materials);
     putVec(f, lights); putVec(f, lightBvh); putVec(f, lightTransforms); putVec(f, filterData); putVec(f, powerAlias); putVec(f, imageLights);
-    putVec(f, noisePerm); putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile); putVec(f, sRGBFromFilmRGB);
+    putVec(f, noisePerm); putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile); putVec(f, sRGBFromFilmRGB); putVec(f, S);
     int32_t sc[8] = {nTopBvhNodes, nTopPrims, saveFP16 ? 1 : 0, spp, scanlinesPerPass, maxQueueSize, nPasses, desc.rgb2spec_coeffs ? 1 : 0};
     fwrite(sc, 4, 8, f);
     fwrite(materialTypePresent, sizeof(materialTypePresent), 1, f);
@@ -134,7 +134,7 @@ bool SceneTables::Load(const std::string &path) {
          getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, sobolMatrices) && getVec(f, vdcSobol) && getVec(f, vdcSobolInv) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
          getVec(f, haltonPerms) && getVec(f, bvhNodes) && getVec(f, pool.spectra) && getVec(f, pool.data) && getVec(f, textures) && getVec(f, materials) &&
          getVec(f, lights) && getVec(f, lightBvh) && getVec(f, lightTransforms) && getVec(f, filterData) && getVec(f, powerAlias) && getVec(f, imageLights) &&
-         getVec(f, noisePerm) && getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile) && getVec(f, sRGBFromFilmRGB);
+         getVec(f, noisePerm) && getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile) && getVec(f, sRGBFromFilmRGB) && getVec(f, S);
     int32_t sc[8];
     ok = ok && fread(sc, 4, 8, f) == 8 && fread(materialTypePresent, sizeof(materialTypePresent), 1, f) == 1;
     uint64_t end = 0;

@@ -171,6 +171,22 @@ def test_benchmark_standins_vs_oracle_and_reference(wfpt, tmp_path, name):
     s.close()
 
 
+def test_table_cache_keeps_shading_tangents(wfpt, tmp_path, monkeypatch):
+    """WF_TABLE_CACHE with a mesh that has "S" tangents (wf_scene_desc.S, added in round 4): the scene served from the cache renders the
+    same image as the freshly built one — the reference's (the tangents decide 39 % of this scene's pixels)."""
+    path = os.path.join(GOLDEN, "tangents_s.pbrt")
+    ref = read_pfm(os.path.join(GOLDEN, "tangents_s_ref.pfm"))
+    monkeypatch.setenv("WF_TABLE_CACHE", str(tmp_path))
+    for k in range(2):   # 0: built and written; 1: read back
+        s = wfpt.Scene(path=path, spp=4)
+        s.create_renderer(0)
+        s.render()
+        img = s.image().copy()
+        s.close()
+        assert len([f for f in os.listdir(tmp_path) if f.endswith(".wftab")]) == 1
+        assert (img.view(np.uint32) == ref.view(np.uint32)).all(), k
+
+
 def test_repeated_renders_are_identical(wfpt, tmp_path):
     """The same frame rendered six times by one context gives one image and one set of ray counts.  Round 3's near-tie queue (the
     closest-hit launch's service workgroups) once lost a handful of re-walks per frame in a third of the runs on the 10 M-triangle
