@@ -102,7 +102,7 @@ constexpr int NODE_NONE = (int)0x80000000;
 #define WF_TWAVES_INST 4   // the same for the two-level (object instance) variants, which carry the render-space ray as well
 #endif
 #ifndef WF_TWAVES_INST_SHADOW
-#define WF_TWAVES_INST_SHADOW 5   // the any-hit walk keeps no hit record: it fits 5 waves (96 VGPRs) two-level as well, -3 % (27.2 vs 28.1 ms)
+#define WF_TWAVES_INST_SHADOW 4   // round 3: 5 waves (96 VGPRs, 28 spilled) beat 4 by 3 %; round 4, after the zero-initialised locals: 4 waves (122 VGPRs, NOTHING spilled) 17.4 vs 18.5 ms per 16 spp (gpurun_out/r04aa)
 #endif
 constexpr int TOP_NODES = WF_TOP_NODES;  // QNodes cached in LDS per workgroup
 constexpr int TBLOCK = WF_TBLOCK;        // threads per workgroup of the traversal kernels
