@@ -1635,6 +1635,17 @@ extern "C" {
 const char *wf_last_error(void) { return g_err; }
 int wf_abi_version(void) { return WF_ABI_VERSION; }
 
+// The stream's scratch (private segment) grows whenever a kernel needs more per lane than any kernel before it; on about a third of the
+// pool's boxes every such growth costs the launch that triggers it 20-30 ms (round 4: the first frame of a process took 200 ms instead of
+// 112: "Handle escaped rays" 1264 B, "Handle emitters" 1424 B, conductor 1468 B, coated diffuse 1500 B per lane — four steps in launch
+// order).  One launch of a kernel whose private segment is at least the largest of the library's (k_eval_material<7, 2>: 3372 B) pays for
+// the growth once, when the context is created.  WF_SCRATCH_PRIME=0 skips it.
+constexpr int SCRATCH_PRIME_WORDS = 896;   // 3584 B per lane
+__global__ void k_scratch_prime(int *out, int n) {
+    volatile int buf[SCRATCH_PRIME_WORDS];
+    for (int i = 0; i < n; ++i) buf[(i * 131) % SCRATCH_PRIME_WORDS] = i;
+    out[threadIdx.x] = buf[(n * 7) % SCRATCH_PRIME_WORDS];
+}
 int wf_ctx_create(int device, wf_ctx **out) {
     if (!out) return fail(-1, "null out");
     int ndev = 0;
@@ -1650,6 +1661,15 @@ int wf_ctx_create(int device, wf_ctx **out) {
     HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
     if (const char *e = getenv("WF_OVERLAP_RETRACE")) c->overlapRetrace = atoi(e);
     c->traceLaunch = getenv("WF_TRACE_LAUNCH") != nullptr;
+    if (const char *e = getenv("WF_SCRATCH_PRIME"); !e || atoi(e) != 0) {
+        int *tmp = nullptr;
+        HIPCHK(hipMalloc(&tmp, 64 * sizeof(int)));
+        hipLaunchKernelGGL(k_scratch_prime, dim3(1), dim3(64), 0, c->stream, tmp, 8);
+        hipLaunchKernelGGL(k_scratch_prime, dim3(1), dim3(64), 0, c->stream2, tmp, 8);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        HIPCHK(hipFree(tmp));
+    }
     *out = c;
     return 0;
 }
