@@ -2653,6 +2653,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             tv.spectra = T->pool.spectra.data(); tv.spectrumData = T->pool.data.data();
             tv.self = &tv;
             DisplaceMesh(&src, rfo, edgeLength, [&](V3 p, V2 uv) { TexCtx tc; tc.p = p; tc.uv = uv; return EvalFloatTexture(tv, texId, tc); }, sh.loc);
+            src.S.clear();   // the displaced mesh is created without tangents (shapes.cpp:1458-1461)
         }
         wf_mesh mesh{};
         mesh.first_tri = (int)T->triIndices.size() / 3;
