@@ -827,7 +827,9 @@ constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes 
 #ifndef WF_TWAVES_GEN2
 #define WF_TWAVES_GEN2 0   // 0: the triangle kernels' target
 #endif
-constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : triangleWaves; }
+// (GEN = 3, the curve kernels: at the one-level kernels' 5-wave target they were the only kernels of the library that spilled an SGPR-spill
+//  carrier register — tools/check_spill_carriers.py; at the two-level kernels' 4 they do not)
+constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : gen >= 3 && triangleWaves > 4 ? 4 : triangleWaves; }
 template <int GEN, bool INST = false, bool SPLIT = false>
 __global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];

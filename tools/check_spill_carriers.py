@@ -7,8 +7,7 @@ material kernel at 168 VGPRs: a deterministic memory fault, and two nondetermini
 carriers in registers.  This script disassembles the gfx950 code object of every unit under the build directory (default
 pbrt-v4_amd/_build) and lists, per kernel / device function, the carrier VGPRs and how often each is stored to / loaded from scratch.
 
-Exit status 1 when a function spills a carrier, unless it is named in ALLOWED below (the curve kernels, GEN = 3: measured repeatable, two
-waves, and slow anyway).  `make -C pbrt-v4_amd` does not run it; tests/test_build_lint.py does (CPU suite), so that a change that pushes a
+Exit status 1 when a function spills a carrier, unless it is named in ALLOWED below (empty at the end of round 4).  `make -C pbrt-v4_amd` does not run it; tests/test_build_lint.py does (CPU suite), so that a change that pushes a
 kernel over the edge is seen before it reaches the GPU.
 """
 import collections
@@ -22,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernels that are known to spill a carrier and are accepted (regular expressions on the demangled name)
-ALLOWED = [r"k_closest_fast<3,", r"k_shadow_fast<3,", r"k_trace_closest_fast<3,", r"k_trace_any_fast<3,"]
+ALLOWED = []   # (round 4: the curve kernels, GEN = 3, were here until their occupancy target was lowered to 4 waves)
 
 
 def code_object(obj, out):
