@@ -409,7 +409,7 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
         // owes WalkMakeExact — the reference's interval-arithmetic ray transform, the shear, the slab constants again — before its
         // leaf can be processed: PARKED like a transition, so that this code too runs with several lanes at once (inside the leaf
         // loop, lane by lane, the lazy transition LOST: closest 49.4 vs 45.0 ms, any-hit 26.1 vs 23.0)
-        const bool owes = WF_LAZY_INST && w.node != NODE_NONE && !tr && w.lazy != 0;
+        const bool owes = WF_LAZY_INST && w.node != NODE_NONE && !tr && WF_LAZY_GET(w) != 0;
         if (w.node != NODE_NONE && !tr && !owes) {
             if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
             else LeafStep<ANY, false, true>(bvh, w, st, InstOnlyPrims{bvh});

@@ -141,6 +141,9 @@ constexpr int NODE_EXIT = (int)0x80000001;   // stack marker: leave the instance
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 
+#ifndef WF_LAZY_INST
+#define WF_LAZY_INST 0   // (measured and dropped, see below)
+#endif
 struct RayWalk {
     V3 o;
     RayShear sh;   // per-ray part of the triangle test (MakeRayShear)
@@ -148,6 +151,8 @@ struct RayWalk {
     // slab test in grid coordinates: entry t of an axis = fma(qNear, a, bn), exit t = fma(qFar, af, bf)
     V3 a, bn, af, bf;
     uint32_t selx, sely, selz;  // v_perm selectors: put the near plane in the low half, the far plane in the high half
+    // (round 4: deriving them from the sign of `a` at every node instead frees three registers on paper; the two-level closest-hit kernel
+    //  still spills the same 192 VGPRs at compile time — not pursued)
     int node;  // current ref; NODE_NONE = finished
     int prim;
     uint32_t route;  // routing code of the hit triangle (LeafTri.c.w)
@@ -158,8 +163,17 @@ struct RayWalk {
     // ray so far is the reference's transform WITHOUT its interval-arithmetic origin shift — good for the conservative box tests, not
     // for a primitive test: o, the shear and tMax are made exact (WalkMakeExact) when a leaf holds one; 2 back at the top level with
     // the shear of the render-space ray not recomputed yet
+#if WF_LAZY_INST
     int lazy;
+#endif
 };
+#if WF_LAZY_INST
+#define WF_LAZY_GET(w) ((w).lazy)
+#define WF_LAZY_SET(w, v) ((w).lazy = (v))
+#else
+#define WF_LAZY_GET(w) 0          // (the field costs a register and a test per leaf primitive: compiled out with the experiment)
+#define WF_LAZY_SET(w, v) ((void)0)
+#endif
 
 // Per-ray constants of the box test.  Bounds3::IntersectP (util/vecmath.h:1574-1608) computes, per axis,
 // tNear = (pNear - o) * invDir and tFar = (pFar - o) * invDir * (1 + 2 gamma(3)).  With pNear = base + q * cell
@@ -208,7 +222,7 @@ __device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, floa
     w.b0 = w.b1 = w.b2 = 0;
     w.inst = -1;
     w.curInst = -1;
-    w.lazy = 0;
+    WF_LAZY_SET(w, 0);
 }
 // Switch the lane into / out of an object instance (see the header comment).  oW, dW: the ray in render space.
 // Returns false when the instance is skipped.  (Round 3) The top-level leaf that holds an instance only says that the ray meets the
@@ -287,7 +301,7 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
             WalkSetSlab(fd.base, fd.cell, w, oI, dI);
             w.curInst = inst;
             w.node = fd.root;
-            w.lazy = 1;
+            WF_LAZY_SET(w, 1);
             return true;
         }
     }
@@ -301,12 +315,12 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
     w.tMax = (FloatToBits(w.tMax) >> 31) ? -tI : tI;
     w.curInst = inst;
     w.node = fd.root;
-    w.lazy = 0;
+    WF_LAZY_SET(w, 0);
     return true;
 }
 // the per-ray state a primitive test needs, made exact for the space being walked (RayWalk::lazy); oW, dW: the render-space ray
 __device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 dW) {
-    if (w.lazy == 1) {
+    if (WF_LAZY_GET(w) == 1) {
         const wf_instance &in = bvh.instances[w.curInst];
         const FastDef fd = bvh.defs[in.def];
         // no primitive of this visit has been tested yet: |w.tMax| is still the render-space bound the visit started with
@@ -319,7 +333,7 @@ __device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 d
         w.o = oW;
         w.sh = MakeRayShear(dW);
     }
-    w.lazy = 0;
+    WF_LAZY_SET(w, 0);
 }
 template <typename Stack>
 __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW) {
@@ -330,7 +344,7 @@ __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V
     const bool mark = ((FloatToBits(w.tMax) | FloatToBits(saved)) >> 31) != 0;
 #if WF_LAZY_INST
     WalkSetSlab(bvh.base, bvh.cell, w, oW, dW);   // the shear of the render-space ray when a top-level leaf asks for it (WalkMakeExact)
-    w.lazy = 2;
+    WF_LAZY_SET(w, 2);
 #else
     WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
 #endif
@@ -478,7 +492,7 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
                 continue;
             }
         if constexpr (INST)
-            if (w.lazy) ex.exact(w);   // the first primitive test since the walk changed spaces (WF_LAZY_INST)
+            if (WF_LAZY_GET(w)) ex.exact(w);   // the first primitive test since the walk changed spaces (WF_LAZY_INST)
         // closest hit: test against the relaxed bound so that near-ties are seen (WalkAccept sorts them out)
         constexpr bool PAIRS = Extra::pairBands;
         if constexpr (ALPHA)
