@@ -144,6 +144,12 @@ static int devUpload(wf_ctx *c, const T **p, const T *src, size_t n) {
 
 // ---------------------------------------------------------------------------------------------
 // kernels
+// Round 4: a kernel may read the scene view through the pointer to its device-resident copy (sv.self) instead of from its by-value
+// argument — what took 100 spilled SGPRs out of the material kernels (wf_mat.hip, WF_MAT_SV_PTR).  Measured per kernel on the spec scene
+// (gpurun_out/r04ad, 16 spp, same box): camera rays 4.03 -> 3.32 ms, route hits 1.81 -> 1.71; closest-hit 36.8 -> 39.0 (worse: it hardly
+// touches the view, and the indirection costs), escaped 3.02 -> 3.16, the others unchanged — so only the first two use it.
+template <bool VIA_SELF>
+__device__ inline const SceneView &SvOf(const SceneView &a) { return VIA_SELF ? *a.self : a; }
 __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, int statSlot, int statCounter) {
     // mask bit i: zero counters[(i) * CNT_STRIDE].  statSlot >= 0: stats[statSlot] += counters[(statCounter) * CNT_STRIDE] first.
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -159,19 +165,22 @@ __global__ void __launch_bounds__(BLOCK) k_reset(WorkState ws, unsigned mask, in
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_sample_tops(const SceneView sv, WorkState ws, int y0, int dim0) {
+__global__ void __launch_bounds__(BLOCK) k_sample_tops(const SceneView svArg, WorkState ws, int y0, int dim0) {
+    const SceneView &sv = SvOf<false>(svArg);
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < 5 * ws.pixelsPerPass; i += gridDim.x * BLOCK) KSampleTops(sv, ws, i, y0, dim0);
 }
 // ANIM: the instance for a moving camera (AnimatedTransform::Interpolate per ray); scenes with a static camera launch the other one
 template <bool ANIM>
-__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView sv, WorkState ws, int y0, int sampleBase, int sampleStep, int nSamples) {
+__global__ void __launch_bounds__(BLOCK) k_gen_camera_rays(const SceneView svArg, WorkState ws, int y0, int sampleBase, int sampleStep, int nSamples) {
+    const SceneView &sv = SvOf<true>(svArg);
     if (sv.camera.type != WF_CAMERA_REALISTIC && blockIdx.x == 0 && threadIdx.x == 0) ws.counters[(CNT_RAY0) * CNT_STRIDE] = KCameraRayCount(sv, ws, y0, nSamples);
     const bool useTops = ws.sampleTops != nullptr;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < ws.maxQueueSize; i += gridDim.x * BLOCK)
         KGenerateCameraRay<ANIM>(sv, ws, i, y0, sampleBase, sampleStep, nSamples, useTops);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView sv, WorkState ws, int cur, int sampleBase, int sampleStep, int topsDepth) {
+__global__ void __launch_bounds__(BLOCK) k_gen_ray_samples(const SceneView svArg, WorkState ws, int cur, int sampleBase, int sampleStep, int topsDepth) {
+    const SceneView &sv = SvOf<false>(svArg);
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KGenerateRaySamples(sv, ws, cur, i, sampleBase, sampleStep, topsDepth);
 }
@@ -831,7 +840,8 @@ constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes 
 //  carrier register — tools/check_spill_carriers.py; at the two-level kernels' 4 they do not)
 constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : gen >= 3 && triangleWaves > 4 ? 4 : triangleWaves; }
 template <int GEN, bool INST = false, bool SPLIT = false>
-__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView svArg, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+    const SceneView &sv = SvOf<false>(svArg);
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
@@ -879,7 +889,8 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST :
 // microsecond, which at 256 rays per workgroup was the whole cost of this pass)
 constexpr int RBLOCK = 1024;
 template <bool GENERAL>
-__global__ void __launch_bounds__(RBLOCK) k_route_hits(const SceneView sv, WorkState ws, int cur) {
+__global__ void __launch_bounds__(RBLOCK) k_route_hits(const SceneView svArg, WorkState ws, int cur) {
+    const SceneView &sv = SvOf<true>(svArg);
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     for (int base = blockIdx.x * RBLOCK; base < n; base += gridDim.x * RBLOCK) {
         const int i = base + threadIdx.x;
@@ -1019,7 +1030,8 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
 }
 template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES)) k_shadow_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES)) k_shadow_fast(const SceneView svArg, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+    const SceneView &sv = SvOf<false>(svArg);
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
@@ -1206,11 +1218,13 @@ __global__ void __launch_bounds__(BLOCK) k_tr_rest(const SceneView sv, WorkState
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView sv, WorkState ws, int cur) {
+__global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView svArg, WorkState ws, int cur) {
+    const SceneView &sv = SvOf<false>(svArg);
     const int n = ws.counters[(CNT_ESCAPED) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEscaped(sv, ws, cur, i);
 }
-__global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView sv, WorkState ws, int cur) {
+__global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView svArg, WorkState ws, int cur) {
+    const SceneView &sv = SvOf<false>(svArg);
     const int n = ws.counters[(CNT_HITLIGHT) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEmissive(sv, ws, cur, i);
 }

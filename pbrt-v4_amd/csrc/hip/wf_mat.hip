@@ -25,8 +25,20 @@ constexpr int MBLOCK = 256;
 #ifndef WF_MAT_WAVES
 #define WF_MAT_WAVES 2
 #endif
+// WF_MAT_SV_PTR (round 4): the scene view read through the pointer to its device-resident copy instead of from the kernel
+// arguments — every field that is live across the kernel is an SGPR pair either way, but a by-value argument invites the compiler to keep
+// all of them (300-400 spilled SGPRs per material kernel)
+#ifndef WF_MAT_SV_PTR
+#define WF_MAT_SV_PTR 1   // spec scene, 16 spp, same box: diffuse 21.4 -> 20.6, conductor 5.25 -> 4.98, coated diffuse 16.0 -> 15.7 ms; conductor 314 -> 204 spilled SGPRs (profiles/r04_material_sv_pointer_ab_sm16.txt)
+#endif
+#if WF_MAT_SV_PTR
+template <int MAT, int TEXCTX>
+__global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const SceneView *__restrict__ svp, WorkState ws, int cur) {
+    const SceneView &sv = *svp;
+#else
 template <int MAT, int TEXCTX>
 __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const SceneView sv, WorkState ws, int cur) {
+#endif
     const int n = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE];
     // block-uniform trip count: BlockAlloc inside the body synchronises the workgroup
     for (int base = blockIdx.x * MBLOCK; base < n; base += gridDim.x * MBLOCK) {
@@ -40,5 +52,9 @@ __global__ void __launch_bounds__(MBLOCK, WF_MAT_WAVES) k_eval_material(const Sc
 // WF_MAT_TEXCTX = 1: some texture depends on the footprint, or some material has a displacement texture / normal map;
 // 2: the same plus the rarely used light types (KEvalMaterial)
 extern "C" void WF_CAT3(wf_launch_eval_material_, WF_MAT_INSTANCE, _, WF_MAT_TEXCTX)(hipStream_t stream, int grid, const SceneView *sv, const WorkState *ws, int cur) {
+#if WF_MAT_SV_PTR
+    hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, WF_MAT_TEXCTX>), dim3(grid), dim3(MBLOCK), 0, stream, sv->self, *ws, cur);
+#else
     hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, WF_MAT_TEXCTX>), dim3(grid), dim3(MBLOCK), 0, stream, *sv, *ws, cur);
+#endif
 }
