@@ -267,7 +267,14 @@ class Gen:
         if k == "quad":
             uv = ' "point2 uv" [ 0 0 1 0 1 1 0 1 ]' if self.r.random() < 0.7 else ""
             nrm = ' "normal N" [ 0.1 0 1  0 0.1 1  -0.1 0 1  0 -0.1 1 ]' if self.r.random() < 0.3 else ""
-            return 'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point3 P" [ -1 -1 0  1 -1 0  1 1 0  -1 1 0 ]' + uv + nrm + alpha
+            # (round 4) "S" shading tangents: random vectors, one of them sometimes zero (the dpdu fallback of shapes.h:956-957)
+            tan = ""
+            if self.r.random() < 0.25:
+                S = [(self.u(-1, 1), self.u(-1, 1), self.u(-0.3, 0.3)) for _ in range(4)]
+                if self.r.random() < 0.3:
+                    S[self.r.randrange(4)] = (0.0, 0.0, 0.0)
+                tan = ' "vector3 S" [ %s ]' % "  ".join(f(*v) for v in S)
+            return 'Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point3 P" [ -1 -1 0  1 -1 0  1 1 0  -1 1 0 ]' + uv + nrm + tan + alpha
         if k == "blob":
             # an octahedron with perturbed vertices
             P = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
@@ -285,7 +292,8 @@ class Gen:
             return 'Shape "cylinder" "float radius" [ %s ] "float zmin" [ %s ] "float zmax" [ %s ] "float phimax" [ %s ]' % (f(self.u(0.3, 0.9)), f(self.u(-1, -0.2)), f(self.u(0.2, 1)), f(self.pick([360, self.u(90, 350)]))) + alpha
         if k == "bilinear":
             return 'Shape "bilinearmesh" "integer indices" [ 0 1 2 3 ] "point3 P" [ -1 -1 %s  1 -1 %s  -1 1 %s  1 1 %s ]' % (f(self.u(-.4, .4)), f(self.u(-.4, .4)), f(self.u(-.4, .4)), f(self.u(-.4, .4))) + \
-                (' "point2 uv" [ 0 0 1 0 0 1 1 1 ]' if self.r.random() < 0.5 else "") + alpha
+                (' "point2 uv" [ 0 0 1 0 0 1 1 1 ]' if self.r.random() < 0.5 else "") + \
+                (' "string emissionfilename" "%s"' % os.path.join(GOLDEN, self.pick(["sky.pfm", "wood.pfm", "alpha.pfm"])) if self.r.random() < 0.3 else "") + alpha
         if k == "curve":
             return 'Shape "curve" "string type" "%s" "point3 P" [ -1 0 0  -0.3 %s 0.5  0.4 %s -0.3  1 0 0.2 ] "float width0" [ %s ] "float width1" [ %s ]' % (
                 self.pick(["flat", "cylinder", "ribbon"]), f(self.u(-1, 1)), f(self.u(-1, 1)), f(self.u(0.05, 0.3)), f(self.u(0.02, 0.3))) + \
