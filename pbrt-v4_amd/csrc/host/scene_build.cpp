@@ -498,6 +498,25 @@ struct TexBuilder {
                     t.type = WF_TEX_FLOAT_SCALE;
                     t.tex0 = GetFloatTexture(ps, "tex", 1.f);
                     t.tex1 = GetFloatTexture(ps, "scale", 1.f);
+                    // FloatScaledTexture::Create (textures.cpp:892-925) folds a CONSTANT factor away: a factor of 1 returns the other
+                    // texture itself, a constant times an image texture returns a copy of the image texture with its own scale multiplied
+                    // (MultiplyScale) — in either argument order.  Not an optimisation only: the result is an image texture, which the
+                    // wavefront path's BasicTextureEvaluator evaluates, and the factor is applied before `invert` (fuzz finding s600258).
+                    int a = t.tex0, b = t.tex1, folded = -1;
+                    for (int i = 0; i < 2 && folded < 0; ++i) {
+                        if (T->textures[b].type == WF_TEX_FLOAT_CONSTANT) {
+                            const float cs = T->textures[b].f0;
+                            if (cs == 1) folded = a;
+                            else if (T->textures[a].type == WF_TEX_FLOAT_IMAGE) { wf_texture c = T->textures[a]; c.f0 *= cs; folded = AddTex(c); }
+                        }
+                        std::swap(a, b);
+                    }
+                    if (folded >= 0) {
+                        if (floatTextures.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
+                        floatTextures[te.texName] = folded;
+                        ps.ReportUnused("Texture");
+                        continue;
+                    }
                 } else if (te.name == "mix") {
                     t.type = WF_TEX_FLOAT_MIX;
                     t.tex0 = GetFloatTexture(ps, "tex1", 0.f);
@@ -562,6 +581,23 @@ struct TexBuilder {
                         t.type = WF_TEX_SPECTRUM_SCALE;
                         t.tex0 = GetSpectrumTexture(ps, "tex", *MakeConstant(1.f), st);
                         t.tex1 = GetFloatTexture(ps, "scale", 1.f);
+                        // SpectrumScaledTexture::Create (textures.cpp:927-957): a constant factor of 1 returns `tex` itself, a constant times
+                        // an image texture returns a copy of the image texture with the factor in its own scale — applied to the RGB texel
+                        // BEFORE `invert`, the clamp and the RGB -> spectrum conversion, and evaluated by the BasicTextureEvaluator
+                        // (fuzz finding s600258: a diffuse transmittance 9.6 % off)
+                        if (T->textures[t.tex1].type == WF_TEX_FLOAT_CONSTANT) {
+                            const float cs = T->textures[t.tex1].f0;
+                            int folded = -1;
+                            if (cs == 1) folded = t.tex0;
+                            else if (T->textures[t.tex0].type == WF_TEX_SPECTRUM_IMAGE) { wf_texture c = T->textures[t.tex0]; c.f0 *= cs; folded = AddTex(c); }
+                            if (folded >= 0) {
+                                auto &fm = SpecMap(st);
+                                if (st == SpectrumType::Albedo && fm.count(te.texName)) Die(te.loc, "Redefining texture \"" + te.texName + "\".");
+                                fm[te.texName] = folded;
+                                ps.ReportUnused("Texture");
+                                continue;
+                            }
+                        }
                     } else if (te.name == "mix") {
                         t.type = WF_TEX_SPECTRUM_MIX;
                         t.tex0 = GetSpectrumTexture(ps, "tex1", *MakeConstant(0.f), st);

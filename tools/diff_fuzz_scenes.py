@@ -54,7 +54,15 @@ class Gen:
             out.append('Option "string rendercoordsys" "%s"' % self.pick(["camera", "cameraworld", "world"]))
         if r.random() < 0.1:
             out.append('ColorSpace "%s"' % self.pick(["srgb", "rec2020", "dci-p3", "aces2065-1"]))
+        self.camera_motion = r.random() < 0.12   # (round 4, end) ActiveTransform StartTime / EndTime around the camera: AnimatedTransform
+        if self.camera_motion:
+            out.append("TransformTimes 0 1")
+            out.append("ActiveTransform StartTime")
         out.append("LookAt %s  %s  0 0 1" % (f(self.u(-1, 1), -7 + self.u(-1, 1), 2.5 + self.u(-1, 1)), f(self.u(-.5, .5), self.u(-.5, .5), 1 + self.u(-.3, .3))))
+        if self.camera_motion:
+            out.append("ActiveTransform EndTime")
+            out.append("LookAt %s  %s  %s" % (f(self.u(-1, 1), -7 + self.u(-1, 1), 2.5 + self.u(-1, 1)), f(self.u(-.5, .5), self.u(-.5, .5), 1 + self.u(-.3, .3)), f(self.u(-0.1, 0.1), 0, 1)))
+            out.append("ActiveTransform All")
         cam = self.pick(["perspective"] * 4 + ["orthographic", "spherical", "realistic"])
         if cam == "perspective":
             out.append('Camera "perspective" "float fov" [ %s ]' % f(self.u(25, 70)) +
@@ -321,8 +329,26 @@ class Gen:
             if self.r.random() < 0.5:
                 out.append('MakeNamedMedium "cloud" "string type" "uniformgrid" "integer nx" 2 "integer ny" 2 "integer nz" 2 "float density" [ 0.2 1 0.5 0.8 1 0.1 0.6 0.9 ] '
                            '"point3 p0" [ -1 -1 -1 ] "point3 p1" [ 1 1 1 ] "rgb sigma_a" [ 0.1 0.1 0.1 ] "rgb sigma_s" [ 0.8 0.8 0.8 ] "float scale" [ %s ]' % f(self.u(0.5, 4)))
-            else:
+            elif self.r.random() < 0.4:
                 out.append('MakeNamedMedium "cloud" "string type" "homogeneous" "string preset" "%s" "float scale" [ %s ]' % (self.pick(["Skin1", "Wholemilk", "Ketchup"]), f(self.u(0.01, 0.2))))
+            else:
+                # (round 4, end) the other medium types of the path: rgb grid with emission, density grid with a temperature grid, procedural cloud
+                k = self.pick(["rgbgrid", "tempgrid", "cloud"])
+                g = f(self.u(-0.4, 0.8))
+                if k == "rgbgrid":
+                    v = lambda lo, hi: " ".join(f(self.u(lo, hi)) for _ in range(24))
+                    out.append('MakeNamedMedium "cloud" "string type" "rgbgrid" "integer nx" 2 "integer ny" 2 "integer nz" 2 "point3 p0" [ -1 -1 -1 ] "point3 p1" [ 1 1 1 ] '
+                               '"float scale" [ %s ] "float g" [ %s ] "float Lescale" [ %s ] "rgb sigma_a" [ %s ] "rgb sigma_s" [ %s ] "rgb Le" [ %s ]'
+                               % (f(self.u(0.5, 4)), g, f(self.u(0, 2)), v(0.0, 0.1), v(0.0, 0.9), v(0.0, 0.5)))
+                elif k == "tempgrid":
+                    out.append('MakeNamedMedium "cloud" "string type" "uniformgrid" "integer nx" 2 "integer ny" 2 "integer nz" 2 "point3 p0" [ -1 -1 -1 ] "point3 p1" [ 1 1 1 ] '
+                               '"float scale" [ %s ] "float g" [ %s ] "float Lescale" [ %s ] "rgb sigma_a" [ 0.2 0.2 0.2 ] "rgb sigma_s" [ 0.9 0.9 1.1 ] '
+                               '"float temperaturescale" [ %s ] "float temperatureoffset" [ %s ] "float density" [ %s ] "float temperature" [ %s ]'
+                               % (f(self.u(0.5, 4)), g, f(self.u(0.2, 1.5)), f(self.u(0.8, 1.3)), f(self.u(0, 200)),
+                                  " ".join(f(self.u(0, 1)) for _ in range(8)), " ".join(f(self.u(250, 1400)) for _ in range(8))))
+                else:
+                    out.append('MakeNamedMedium "cloud" "string type" "cloud" "float density" [ %s ] "float wispiness" [ %s ] "float frequency" [ %s ] "float g" [ %s ] '
+                               '"point3 p0" [ -1 -1 -1 ] "point3 p1" [ 1 1 1 ]' % (f(self.u(0.5, 3)), f(self.u(0.5, 2)), f(self.u(2, 6)), g))
             self.media.append("cloud")
         for i in range(self.r.randrange(2, 6)):
             out.append(self.material("m%d" % i))
