@@ -141,7 +141,10 @@ class Gen:
                 out.append('Texture "%s" "float" "constant" "float value" [ %s ]' % (name, f(self.u(0, 1))))
             elif kind in ("scale", "mix", "directionmix") and self.float_tex:
                 if kind == "scale":
-                    out.append('Texture "%s" "float" "scale" "texture tex" "%s" "float scale" [ %s ]' % (name, self.pick(self.float_tex), f(self.u(0.2, 1.5))))
+                    if self.r.random() < 0.3:   # the other argument order (FloatScaledTexture::Create tries both)
+                        out.append('Texture "%s" "float" "scale" "float tex" [ %s ] "texture scale" "%s"' % (name, f(self.pick([1.0, self.u(0.2, 1.5)])), self.pick(self.float_tex)))
+                    else:
+                        out.append('Texture "%s" "float" "scale" "texture tex" "%s" "float scale" [ %s ]' % (name, self.pick(self.float_tex), f(self.pick([1.0, self.u(0.2, 1.5)]))))
                 elif kind == "mix":
                     out.append('Texture "%s" "float" "mix" "texture tex1" "%s" "float tex2" [ %s ] "float amount" [ %s ]' % (name, self.pick(self.float_tex), f(self.u()), f(self.u())))
                 else:
@@ -162,7 +165,9 @@ class Gen:
                 #  util/image.h:100-121: undefined there — only the plain (u, v) mapping with it)
                 out.append('Texture "%s" "float" "imagemap" "string filename" "%s" "string filter" "%s" "string wrap" "%s"'
                            % (name, os.path.join(GOLDEN, self.pick(["alpha.pfm", "bump.pfm", "png_grey8.png"])), self.pick(["bilinear", "point", "trilinear", "ewa"]), wrap) +
-                           (' "string mapping" "uv"' if wrap == "octahedralsphere" else self.mapping()))
+                           (' "string mapping" "uv"' if wrap == "octahedralsphere" else self.mapping()) +
+                           (' "float scale" [ %s ]' % f(self.u(0.3, 1.4)) if self.r.random() < 0.3 else "") + (' "bool invert" true' if self.r.random() < 0.2 else "") +
+                           (' "string encoding" "%s"' % self.pick(["sRGB", "linear", "gamma 2.2"]) if self.r.random() < 0.2 else ""))
             else:
                 continue
             self.float_tex.append(name)
@@ -172,7 +177,9 @@ class Gen:
             if kind == "constant":
                 out.append('Texture "%s" "spectrum" "constant" "rgb value" %s' % (name, self.rgb()))
             elif kind == "scale" and self.spec_tex:
-                out.append('Texture "%s" "spectrum" "scale" "texture tex" "%s" "float scale" [ %s ]' % (name, self.pick(self.spec_tex), f(self.u(0.2, 1))))
+                # (a constant factor is folded into an image texture at creation, textures.cpp:927-957; a textured factor is not)
+                fac = '"texture scale" "%s"' % self.pick(self.float_tex) if self.float_tex and self.r.random() < 0.3 else '"float scale" [ %s ]' % f(self.pick([1.0, self.u(0.2, 1)]))
+                out.append('Texture "%s" "spectrum" "scale" "texture tex" "%s" %s' % (name, self.pick(self.spec_tex), fac))
             elif kind == "mix" and self.spec_tex:
                 out.append('Texture "%s" "spectrum" "mix" "texture tex1" "%s" "rgb tex2" %s %s' % (name, self.pick(self.spec_tex), self.rgb(), self.float_param("amount", 0, 1)))
             elif kind == "checkerboard":
