@@ -160,7 +160,10 @@ class Gen:
             elif kind == "bilerp":
                 out.append('Texture "%s" "float" "bilerp" "float v00" [ %s ] "float v01" [ %s ] "float v10" [ %s ] "float v11" [ %s ]' % (name, f(self.u()), f(self.u()), f(self.u()), f(self.u())))
             elif kind == "imagemap":
-                wrap = self.pick(["repeat", "clamp", "black", "octahedralsphere"])
+                # ("octahedralsphere" is no longer drawn: the ground quad's (u, v) run to 4 and a bump lookup steps beyond 1 — outside [0, 1]^2 by
+                #  more than a texel the reference reads past its pixel array (below); s800146 was that, not a parity finding.  The wrap mode
+                #  has its goldens.)
+                wrap = self.pick(["repeat", "clamp", "black"])
                 # (an octahedral map addressed outside [0, 1]^2 by more than a texel makes the reference read past its pixel array,
                 #  util/image.h:100-121: undefined there — only the plain (u, v) mapping with it)
                 out.append('Texture "%s" "float" "imagemap" "string filename" "%s" "string filter" "%s" "string wrap" "%s"'
@@ -246,6 +249,15 @@ class Gen:
         self.materials.append((name, t))
         return 'MakeNamedMaterial "%s" "string type" "%s" %s%s' % (name, t, body, extra)
 
+    def emit(self, name, lo, hi):
+        """an emission parameter: rgb (RGBIlluminantSpectrum), a blackbody temperature, or a named illuminant (round 4, end)"""
+        k = self.r.random()
+        if k < 0.7:
+            return '"rgb %s" %s' % (name, self.rgb(lo, hi))
+        if k < 0.85:
+            return '"blackbody %s" [ %s ]' % (name, f(self.u(2500, 9000)))
+        return '"spectrum %s" "%s"' % (name, self.pick(["stdillum-D65", "stdillum-A", "illum-F4", "stdillum-D50"]))
+
     def lights(self):
         out = []
         n = self.r.randrange(1, 4)
@@ -260,17 +272,22 @@ class Gen:
             elif k == "infinite_portal":
                 out.append('LightSource "infinite" "string filename" "%s" "point3 portal" [ -3 5 0  3 5 0  3 5 5  -3 5 5 ]' % os.path.join(GOLDEN, "sky.pfm"))
             elif k == "distant":
-                out.append('LightSource "distant" "point3 from" [ %s ] "point3 to" [ 0 0 0 ] "rgb L" %s' % (f(self.u(-4, 4), self.u(-4, 4), self.u(3, 9)), self.rgb(0.5, 2)) + sc)
+                out.append('LightSource "distant" "point3 from" [ %s ] "point3 to" [ 0 0 0 ] %s' % (f(self.u(-4, 4), self.u(-4, 4), self.u(3, 9)), self.emit("L", 0.5, 2)) + sc +
+                           (' "float illuminance" [ %s ]' % f(self.u(1, 6)) if self.r.random() < 0.2 else ""))
             elif k == "point":
-                out.append('LightSource "point" "point3 from" [ %s ] "rgb I" %s' % (f(self.u(-4, 4), self.u(-5, 1), self.u(2, 6)), self.rgb(5, 40)) + (' "float power" [ %s ]' % f(self.u(50, 400)) if self.r.random() < 0.3 else ""))
+                out.append('LightSource "point" "point3 from" [ %s ] %s' % (f(self.u(-4, 4), self.u(-5, 1), self.u(2, 6)), self.emit("I", 5, 40)) + (' "float power" [ %s ]' % f(self.u(50, 400)) if self.r.random() < 0.3 else ""))
             elif k == "spot":
                 out.append('LightSource "spot" "point3 from" [ %s ] "point3 to" [ %s ] "float coneangle" [ %s ] "float conedeltaangle" [ %s ] "rgb I" %s'
-                           % (f(self.u(-4, 4), self.u(-5, 0), self.u(3, 6)), f(self.u(-1, 1), self.u(-1, 1), 1), f(self.u(15, 50)), f(self.u(1, 12)), self.rgb(20, 90)))
+                           % (f(self.u(-4, 4), self.u(-5, 0), self.u(3, 6)), f(self.u(-1, 1), self.u(-1, 1), 1), f(self.u(15, 50)), f(self.u(1, 12)), self.rgb(20, 90)) +
+                           (' "float power" [ %s ]' % f(self.u(50, 500)) if self.r.random() < 0.25 else ""))
             elif k == "goniometric":
-                out.append('AttributeBegin\nTranslate %s\nLightSource "goniometric" "string filename" "%s" "rgb I" %s\nAttributeEnd' % (f(self.u(-2, 2), self.u(-3, 0), self.u(2, 5)), os.path.join(GOLDEN, "sky.pfm"), self.rgb(5, 30)))
+                out.append('AttributeBegin\nTranslate %s\nLightSource "goniometric" "string filename" "%s" "rgb I" %s%s\nAttributeEnd' % (f(self.u(-2, 2), self.u(-3, 0), self.u(2, 5)), os.path.join(GOLDEN, "sky.pfm"), self.rgb(5, 30),
+                           ' "float power" [ %s ]' % f(self.u(50, 400)) if self.r.random() < 0.25 else ""))
             else:
                 out.append('AttributeBegin\nTranslate %s\nRotate 120 1 0 0\nLightSource "projection" "string filename" "%s" "float fov" [ %s ] "float scale" [ %s ]\nAttributeEnd'
-                           % (f(self.u(-2, 2), self.u(-5, -2), self.u(2, 5)), os.path.join(GOLDEN, "wood.pfm"), f(self.u(30, 80)), f(self.u(20, 80))))
+                           % (f(self.u(-2, 2), self.u(-5, -2), self.u(2, 5)), os.path.join(GOLDEN, "wood.pfm"), f(self.u(30, 80)), f(self.u(20, 80))) if self.r.random() < 0.75 else
+                           'AttributeBegin\nTranslate %s\nRotate 120 1 0 0\nLightSource "projection" "string filename" "%s" "float fov" [ %s ] "float power" [ %s ]\nAttributeEnd'
+                           % (f(self.u(-2, 2), self.u(-5, -2), self.u(2, 5)), os.path.join(GOLDEN, "wood.pfm"), f(self.u(30, 80)), f(self.u(100, 900))))
         return out
 
     def shape(self):
@@ -320,6 +337,8 @@ class Gen:
             (' "texture displacement" "%s" "float edgelength" [ 0.5 ]' % self.pick(self.float_tex) if self.float_tex and self.r.random() < 0.3 else "")
 
     def placed(self, body):
+        if self.r.random() < 0.12:   # (round 4, end) ConcatTransform with a sheared matrix on top of the usual chain
+            body = "  ConcatTransform [ 1 %s 0 0  0 1 0 0  %s 0 1 0  0 0 0 1 ]\n" % (f(self.u(-0.4, 0.4)), f(self.u(-0.3, 0.3))) + body
         return "AttributeBegin\n  Translate %s\n  Rotate %s %s\n  Scale %s\n%s\nAttributeEnd" % (
             f(self.u(-3, 3), self.u(-2.5, 2.5), self.u(0.3, 2.5)), f(self.u(0, 360)), f(self.u(-1, 1), self.u(-1, 1), self.u(0.2, 1)),
             f(self.u(0.4, 1.3), self.u(0.4, 1.3), self.u(0.4, 1.3)) if self.r.random() < 0.8 else f(-0.8, 0.9, 1.1), body)
