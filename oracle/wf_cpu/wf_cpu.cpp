@@ -359,13 +359,6 @@ static int Main(int argc, char **argv) {
             PixelSampler s(sv);
             s.StartPixelSample(in[3 * i], in[3 * i + 1], in[3 * i + 2], probeStartDim);
             SamplerProbeRecord(s, pixel2D ? -2 : pattern ? -3 : zindex ? -4 : probeNDims, &out[(size_t)i * probeNDims]);
-            continue;
-            if (pixel2D) {
-                V2 p = s.GetPixel2D();
-                out[(size_t)i * 2] = p.x; out[(size_t)i * 2 + 1] = p.y;
-                continue;
-            }
-            for (int d = 0; d < probeNDims; ++d) out[(size_t)i * probeNDims + d] = s.Get1D();
         }
         f = fopen(probeOut.c_str(), "wb");
         fwrite(out.data(), 4, out.size(), f);
@@ -811,16 +804,19 @@ static int Main(int argc, char **argv) {
                 ParallelFor(ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], [&](int i) { KHandleEmissive(sv, ws, cur, i); });
                 traceL("emitted", depth);
                 if (depth == maxDepth) break;
-                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE>(sv, ws, cur, i, true); });
-                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_CONDUCTOR>(sv, ws, cur, i, true); });
-                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIELECTRIC>(sv, ws, cur, i, true); });
-                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_THIN_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_THIN_DIELECTRIC>(sv, ws, cur, i, true); });
-                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i, true); });
+                // in the order of the reference's Material::Types (base/material.h:36-39; ForEachType, integrator.cpp EvaluateMaterialsAndBSDFs): the image
+                // does not depend on it, but the ORDER of the next ray queue does, and with it which medium-sample slot a ray gets at the next
+                // depth — what --emulate-stale-medium-depth reproduces (the reference's unwritten MediumSampleWorkItem::depth)
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_DIFFUSE>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_COATED_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_COATED_CONDUCTOR>(sv, ws, cur, i, true); });
-                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_SUBSURFACE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_SUBSURFACE>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_CONDUCTOR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_CONDUCTOR>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIELECTRIC>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_DIFFUSE_TRANSMISSION) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_DIFFUSE_TRANSMISSION>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_HAIR) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_HAIR>(sv, ws, cur, i, true); });
                 ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_MEASURED) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_MEASURED>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_SUBSURFACE) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_SUBSURFACE>(sv, ws, cur, i, true); });
+                ParallelFor(ws.counters[(CNT_MAT0 + WF_MAT_THIN_DIELECTRIC) * CNT_STRIDE], [&](int i) { KEvalMaterial<WF_MAT_THIN_DIELECTRIC>(sv, ws, cur, i, true); });
                 auto traceShadowRays = [&]() {  // TraceShadowRays, integrator.cpp:575-586
                     const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
                     if (sv.haveMedia)

@@ -294,7 +294,7 @@ struct DielectricBxDF {
 #if defined(__HIP_DEVICE_COMPILE__)
                 if (pdf != pdf) atomicOr(fatal, (int)WF_FATAL_CHECK_NAN_PDF);
 #else
-                if (pdf != pdf && fatal) *fatal = WF_FATAL_CHECK_NAN_PDF;
+                if (pdf != pdf && fatal) *fatal |= WF_FATAL_CHECK_NAN_PDF;
 #endif
                 S4 ft = S4c(T * mfDistrib.D(wm) * mfDistrib.G(wo, wi) *
                             abs(Dot(wi, wm) * Dot(wo, wm) / (CosTheta(wi) * CosTheta(wo) * denom)));

@@ -101,7 +101,7 @@ WF_HD const char *FatalMessage(int code) {
 #if defined(__HIP_DEVICE_COMPILE__)
 WF_HD void RaiseFatal(const SceneView &sv, int code) { atomicOr(sv.fatal, code); }
 #else
-WF_HD void RaiseFatal(const SceneView &sv, int code) { if (sv.fatal) *sv.fatal = code; }
+WF_HD void RaiseFatal(const SceneView &sv, int code) { if (sv.fatal) *sv.fatal |= code; }   // (the codes are OR-able bit flags)
 #endif
 
 // SobolMatrices32 dimensions 0 and 1 (util/sobolmatrices.cpp:40-58).  Dimension 0 is the van der Corput

@@ -1402,11 +1402,9 @@ __global__ void k_pack_grid_corners(const float *v, int nx, int ny, int nz, floa
 }
 // HIP's current device is a property of the calling host thread: a context may be driven from any thread (pbrt_amd --gpus N runs one
 // host thread per device, SURVEY 8(b) "multi-GPU = one host thread per device"), so every stage entry makes the context's device current
-// — a thread-local compare when it already is
-static void useDevice(const wf_ctx *ctx) {
-    static thread_local int current = -1;
-    if (current != ctx->device) { (void)hipSetDevice(ctx->device); current = ctx->device; }
-}
+// — unconditionally: other entry points of this library (wf_ctx_create, wf_build_bvh_sah, ...) and the application itself (torch in the
+// same thread) change the current device too, so a cached "current" would go stale; hipSetDevice on the current device is a TLS write
+static void useDevice(const wf_ctx *ctx) { (void)hipSetDevice(ctx->device); }
 static int checkReady(wf_ctx *ctx) {
     if (!ctx) return fail(-1, "null context");
     if (!ctx->sceneLoaded) return fail(-1, "no scene uploaded");
@@ -2522,12 +2520,14 @@ int wf_film_gather_strips(wf_ctx *dst, wf_ctx *src) {
 // the ray counters of another context added to this one's (the statistics of a multi-device render, summed on the gathering context)
 int wf_stats_add(wf_ctx *dst, wf_ctx *src) {
     if (!dst || !src || !dst->sceneLoaded || !src->sceneLoaded) return fail(-1, "wf_stats_add: no scene uploaded");
-    unsigned long long a[129], b[129];
+    // cameraRays + indirect[64] + shadow[64], then the per-material-type and medium-sample item counters ([129, 129 + 16))
+    constexpr int NSTAT = 129 + 16;
+    unsigned long long a[NSTAT], b[NSTAT];
     useDevice(src);
     HIPCHK(hipMemcpy(b, src->ws.stats, sizeof(b), hipMemcpyDeviceToHost));
     useDevice(dst);
     HIPCHK(hipMemcpy(a, dst->ws.stats, sizeof(a), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 129; ++i) a[i] += b[i];
+    for (int i = 0; i < NSTAT; ++i) a[i] += b[i];
     HIPCHK(hipMemcpy(dst->ws.stats, a, sizeof(a), hipMemcpyHostToDevice));
     useDevice(src);
     HIPCHK(hipMemset(src->ws.stats, 0, sizeof(b)));   // (moved, not copied: a second call adds only what src counted since)

@@ -2174,6 +2174,14 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
             fprintf(stderr, "Error: %s: Number of \"S\"s for triangle mesh must match \"P\"s. Discarding \"S\"s.\n", sh.loc.c_str());
             m->S.clear();
         }
+        // "faceIndices" (shapes.cpp:426-433): read by the reference and handed to the textures as TextureEvalContext::faceIndex, whose only
+        // consumer is the Ptex texture (not in this build, nor in the oracle's); looked up so that ReportUnused agrees with the reference
+        {
+            const std::vector<int> faceIndices = ps.GetIntArray("faceIndices");
+            if (!faceIndices.empty() && faceIndices.size() != m->indices.size() / 3)
+                fprintf(stderr, "Error: %s: Number of face indices %d does not match number of triangles %d. Discarding face indices.\n", sh.loc.c_str(),
+                        (int)faceIndices.size(), (int)(m->indices.size() / 3));
+        }
         return true;
     } else if (sh.name == "loopsubdiv") {
         // shapes.cpp:1473-1490
@@ -2217,6 +2225,7 @@ bool LoadShapeGeometry(const ShapeEntity &sh, const std::string &baseDir, MeshSo
         if (!m->uv.empty() && m->uv.size() != m->P.size()) m->uv.clear();
         if (!m->N.empty() && m->N.size() != m->P.size()) m->N.clear();
         for (int vi : m->quads) if (vi < 0 || vi >= (int)m->P.size()) { fprintf(stderr, "Error: %s: Bilinear patch mesh has out of-bounds vertex index %d\n", sh.loc.c_str(), vi); return false; }
+        (void)ps.GetIntArray("faceIndices");   // shapes.cpp:965-973: read (Ptex's face index; no consumer in this build), so not "unused"
         // "emissionfilename" (shapes.cpp:978-994): the patches are sampled by area with the image's distribution
         m->emissionFilename = ps.GetOneString("emissionfilename", "");
         if (!m->emissionFilename.empty() && m->emissionFilename[0] != '/') m->emissionFilename = baseDir + "/" + m->emissionFilename;

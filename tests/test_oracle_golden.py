@@ -165,3 +165,24 @@ def test_fuzz_corpus_cpu_port(built, tmp_path):
         run_wf_cpu(os.path.join(FUZZ, name + ".pbrt"), out, None)
         ref, cpu = read_pfm(os.path.join(FUZZ, name + "_ref.pfm")), read_pfm(out)
         assert ref.shape == cpu.shape and (ref.view(np.uint32) == cpu.view(np.uint32)).all(), name
+
+
+def test_stale_medium_depth_finding_is_the_reference_defect(built, tmp_path):
+    """tests/golden/fuzz/stale_depth_s1300285.pbrt (fuzz seed 13 of round 4, left open there): the reference's
+    MediumSampleQueue::Push(RayWorkItem, tMax) — the push of a ray in a medium that missed every surface — never writes the item's
+    `depth` (wavefront/workitems.h:466-491; read at wavefront/media.cpp:75,163,331,346), so SampleMediumInteraction sees the depth of
+    the slot's previous occupant.  The golden is pbrt_ref --wavefront --nthreads 1 (4 threads give the same image on this scene).
+    Sequentially, with the material stage run in the order of the reference's Material::Types (which fixes the order of the next ray
+    queue and with it the medium-sample slot of every ray), the emulation reproduces the reference bit for bit; without it exactly the
+    two pixels whose paths leave the scene through the fog at depth >= 1 differ."""
+    path = os.path.join(FUZZ, "stale_depth_s1300285.pbrt")
+    ref = read_pfm(os.path.join(FUZZ, "stale_depth_s1300285_ref.pfm"))
+    out = str(tmp_path / "emu.pfm")
+    run_wf_cpu(path, out, None, extra=("--emulate-stale-medium-depth",))
+    emu = read_pfm(out)
+    assert ref.shape == emu.shape and (ref.view(np.uint32) == emu.view(np.uint32)).all()
+    out2 = str(tmp_path / "plain.pfm")
+    run_wf_cpu(path, out2, None, extra=("--nthreads", "4"))
+    plain = read_pfm(out2)
+    differ = np.argwhere((ref.view(np.uint32) != plain.view(np.uint32)).any(axis=2)).tolist()
+    assert differ == [[0, 19], [5, 25]], differ   # (row, column): the two paths that read a stale depth in the reference
