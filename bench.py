@@ -118,25 +118,31 @@ def measure_traffic(scene_path, spp):
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     totals = {}
+    kernels = {}   # kind -> {kernel name: weight}: which kernels the stage's dispatches were (the heaviest one is reported)
     rays = None
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(td, counter)
+        # (third pass, round 5: the SQ counters of "wave occupancy under divergence" — lanes active per VALU instruction, the share of a
+        # wave's lifetime spent waiting / issuing)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", SQ_PASS):
+            out = os.path.join(td, counter.split()[0])
             try:
-                pr = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "k", "--",
+                pr = subprocess.run([prof, "--pmc"] + counter.split() + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "k", "--",
                                      exe, "--stats", "--spp", str(spp), "--outfile", os.path.join(td, "k.pfm"), scene_path],
                                     capture_output=True, text=True, timeout=400, cwd="/tmp", env=env)
             except Exception:
                 return None
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if pr.returncode != 0 or not files:
+                if counter == SQ_PASS:
+                    break   # (the SQ pass is an extra: the traffic figures stand without it)
                 return None
             for r in csv.DictReader(open(files[0])):
                 k = r["Kernel_Name"].split("(")[0]
-                kind = ("closest" if "k_closest_fast" in k else "shadow" if "k_shadow_fast" in k else "material" if "k_eval_material" in k
-                        else "medium" if "k_medium_sample" in k else None)
-                if kind and r.get("Counter_Name", counter) == counter:
-                    totals[(kind, counter)] = totals.get((kind, counter), 0.0) + float(r["Counter_Value"])
+                kind = kernel_kind(k)
+                cname = r.get("Counter_Name", counter)
+                if kind and cname in counter.split():
+                    totals[(kind, cname)] = totals.get((kind, cname), 0.0) + float(r["Counter_Value"])
+                    kernels.setdefault(kind, {})[k.strip()] = kernels.setdefault(kind, {}).get(k.strip(), 0.0) + (float(r["Counter_Value"]) if cname in ("FETCH_SIZE", "SQ_WAVE_CYCLES") else 0.0)
             txt = pr.stdout + pr.stderr
             cam = re.findall(r"Camera rays\s+(\d+)", txt)
             ind = re.findall(r"Indirect rays, depth\s+\d+\s+(\d+)", txt)
@@ -155,7 +161,51 @@ def measure_traffic(scene_path, spp):
             continue
         # the counters are in KiB
         res[kind] = {"hbm_bytes_per_ray": (2 * f + w) * 1024.0 / rays[kind], "write_bytes_per_ray": w * 1024.0 / rays[kind], "rays": rays[kind]}
+        wc, wa, ia = totals.get((kind, "SQ_WAVE_CYCLES")), totals.get((kind, "SQ_WAIT_ANY")), totals.get((kind, "SQ_ACTIVE_INST_ANY"))
+        tc, av = totals.get((kind, "SQ_THREAD_CYCLES_VALU")), totals.get((kind, "SQ_ACTIVE_INST_VALU"))
+        if wc and av:
+            # lanes active per VALU instruction = thread-cycles / (64 x instruction-cycles); wait / issue = share of the waves' lifetime
+            res[kind]["sq"] = {"lanes_active": tc / (64.0 * av), "wait_frac": wa / wc, "issue_frac": ia / wc}
+        if kind in kernels:
+            res[kind]["kernels"] = sorted(kernels[kind], key=lambda n: -kernels[kind][n])
     return res if "closest" in res else None
+
+
+SQ_PASS = "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"
+
+
+def kernel_kind(k):
+    return ("closest" if "k_closest_fast" in k else "shadow" if "k_shadow_fast" in k
+            else "material" if ("k_eval_material" in k or "k_mat_shade" in k or "k_mat_nee" in k)
+            else "medium" if "k_medium_sample" in k else None)
+
+
+def code_object_occupancy(names=None):
+    """waves per SIMD each kernel of libwfhip.so can hold, from its code object's metadata (tools/kernel_resources.py): 512 unified
+    registers per SIMD lane in granules of 8 (VGPRs + AGPRs), at most 8 waves per SIMD, 160 KB of LDS per CU shared by the workgroups
+    resident on its 4 SIMDs (MI355X_MICROARCH.md).  names: substrings to keep."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import kernel_resources
+        rows = kernel_resources.kernel_rows(os.path.join(ROOT, "pbrt-v4_amd", "_build", "libwfhip.so"))
+    except Exception:
+        return None
+    out = {}
+    for r in rows:
+        name = r["demangled"]
+        if names and not any(n in name for n in names):
+            continue
+        regs = int(r.get("vgpr_count") or 0) + int(r.get("agpr_count") or 0)
+        regs = max(8, (regs + 7) // 8 * 8)
+        wg = int(r.get("max_flat_workgroup_size") or 256)
+        lds = int(r.get("group_segment_fixed_size") or 0)
+        by_regs = min(8, 512 // regs)
+        waves_per_wg = max(1, (wg + 63) // 64)
+        by_lds = 8 if lds == 0 else min(8.0, (160 * 1024 // lds) * waves_per_wg / 4.0)
+        out[name] = {"vgpr": int(r.get("vgpr_count") or 0), "agpr": int(r.get("agpr_count") or 0), "scratch_bytes": int(r.get("private_segment_fixed_size") or 0),
+                     "spilled_vgprs": int(r.get("vgpr_spill_count") or 0), "lds_bytes": lds, "workgroup": wg,
+                     "waves_per_simd": min(by_regs, by_lds), "limited_by": "registers" if by_regs <= by_lds else "lds"}
+    return out
 
 
 def shadow_bytes(c):
@@ -464,6 +514,32 @@ def main():
                         rm["algorithmic_bytes_per_launch"] = b / med_launches
             except Exception as ex:   # (a measurement block must not take the bench line down)
                 out["roofline_material_error"] = str(ex)
+        # wave occupancy under divergence (north_star): the dominant kernels' waves per SIMD from the code object, and — when this run's PMC
+        # child passes ran — the lanes active per VALU instruction and the share of the waves' lifetime spent waiting / issuing
+        try:
+            if not a.no_roofline and counters and counters["closest_rays"] > 0:
+                occ = code_object_occupancy(["k_closest_fast", "k_shadow_fast", "k_mat_shade", "k_mat_nee", "k_medium_sample"]) or {}
+                ran = {}
+                for kind in ("closest", "shadow", "material", "medium"):
+                    if live and kind in live:
+                        ks = [k for k in live[kind].get("kernels", []) if any(k.replace("void ", "") in o or o in k for o in occ)]
+                        ran[kind] = {"kernels": {k: next((occ[o] for o in occ if o in k or k.replace("void ", "") in o), None) for k in ks[:4]}}
+                        if "sq" in live[kind]:
+                            ran[kind].update(live[kind]["sq"])
+                if ran:
+                    out["occupancy"] = ran
+                    for kind, key in (("closest", "roofline"), ("shadow", "roofline_shadow"), ("material", "roofline_material"), ("medium", "roofline_medium")):
+                        if kind in ran and key in out:
+                            for f in ("lanes_active", "wait_frac", "issue_frac"):
+                                if f in ran[kind]:
+                                    out[key][f] = ran[kind][f]
+                            w = [v["waves_per_simd"] for v in ran[kind]["kernels"].values() if v]
+                            if w:
+                                out[key]["waves_per_simd"] = w[0]
+                elif occ:
+                    out["occupancy"] = {"code_object": {k: v for k, v in occ.items() if "<1, true, true>" in k or "<1, true>" in k or "<1, 1>" in k or "<1, false>" in k}}
+        except Exception as ex:
+            out["occupancy_error"] = str(ex)
         if a.breakdown:
             out["stage_ms"] = {e["name"]: {"launches": e["launches"], "total_ms": round(e["total_ms"], 3)} for e in scene.profile_report()}
         parity_fail = None

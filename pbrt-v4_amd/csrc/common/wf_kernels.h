@@ -126,6 +126,8 @@ struct WorkState {
     struct BssrdfItem *bssrdfQ;       // GetBSSRDFAndProbeRayQueue / SubsurfaceScatterQueue (K12; allocated when sv.haveSubsurface)
     struct SubsurfaceItem *sssQ;
     ShadowQueueV sq;
+    // the state of the material stage's items between its two kernels (wf_mat.hip: NeeIO): planes of maxQueueSize x 16 bytes
+    F4 *neeRec = nullptr;
     // the transmittance wavefront (HIP back end, scenes with media): per shadow ray the state of TraceTransmittance between segments —
     // current origin / direction (+ medium id in trD.w), T_ray, r_u, r_l, the PCG32 state — and two index queues of the live rays
     F4 *trO, *trD, *trT, *trRu, *trRl;
@@ -1023,7 +1025,7 @@ WF_HD LightPick SampleLightForBlock(const SceneView &sv, bool want, const LightC
 }
 
 // ---------------------------------------------------------------------------------------------
-// K9: EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>, wavefront/surfscatter.cpp:57-328
+// K9: EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>, wavefront/surfscatter.cpp:57-328 — the BxDF of each material type
 template <int MAT> struct MatBxDF;
 template <> struct MatBxDF<WF_MAT_DIFFUSE> {
     using T = DiffuseBxDF;
@@ -1067,37 +1069,62 @@ template <> struct MatBxDF<WF_MAT_COATED_CONDUCTOR> {
     WF_HD static T Get(const SceneView &sv, const wf_material &m, Wavelengths &l, const TexCtx &tc) { return GetCoatedConductorBxDF(sv, m, l, tc); }
 };
 
+// K9 runs in two halves since round 5 (the reference hands the stage a self-contained 252-byte MaterialEvalWorkItem, workitems.h:265-325;
+// the state between the halves below is this build's equivalent, SURVEY 8(d) budgets for it):
+//   MatShade   the interaction rebuilt from (primitive, barycentrics), normal / bump mapping, the textures, the BxDF, the BSDF sample
+//              and the push of the indirect ray (surfscatter.cpp:57-249) — gather work: triangle -> vertices -> texels
+//   MatNee     next-event estimation (surfscatter.cpp:251-327): the light sample of the workgroup (SampleLightForBlock), f / PDF, MIS,
+//              the push of the shadow ray — arithmetic on the item's NeeItem and the light tables, nothing of the hit is touched again
+// One function after the other is the fused stage (KEvalMaterial: the CPU checker); the HIP back end runs them as two kernels per material
+// type with the NeeItem in HBM between them (wf_mat.hip: k_mat_shade / k_mat_nee), so that the light-BVH descents and the light sampling —
+// 60 % of the fused kernel's time — run at the occupancy of THEIR register need, not of the interaction + texture + BSDF-sampling code's.
+template <int MAT>
+struct NeeItem {
+    using BxDF = typename MatBxDF<MAT>::T;
+    bool want = false;     // next-event estimation takes place: IsNonSpecular(bsdf.Flags()), on a live item
+    P3i pi{V3{0, 0, 0}, V3{0, 0, 0}};   // the interaction: position interval, geometric and shading normal, shading dpdu (the BSDF's frame), wo
+    N3 n{0, 0, 0}, ns{0, 0, 1};
+    V3 dpdus{1, 0, 0}, wo{0, 0, 1};
+    // the light sample context's reference point (surfscatter.cpp:255-259): the interaction point offset along +-n for a BSDF that
+    // reflects (only / also), as a degenerate interval; ctxIsPoint = false: the interaction's own interval
+    V3 ctxP{0, 0, 0};
+    bool ctxIsPoint = false;
+    float u0 = 0;          // raySamples.direct.uc
+    V2 u{0, 0};            // raySamples.direct.u
+    int pixelIndex = 0;
+    int mediumInside = -1, mediumOutside = -1;   // GetMedium() of a ray leaving the surface against / along n (interaction.h:117-121)
+    S4 beta = S4c(0.f), r_u = S4c(0.f);
+    float lambda[4] = {0, 0, 0, 0};
+    BxDF bxdf{};           // after Regularize()
+};
+
 // TEXCTX = false: the scene has neither footprint-dependent textures nor displacement, so the differentials and
 // the bump-mapping block (whose only consumers those are) are compiled out — a separate kernel variant, because
 // their registers cost the common case ~25 % (35 spilled VGPRs in the diffuse kernel).
 // VARIANT 2 = 1 + the rarely used light types (portal infinite lights): their out-of-line samplers cost the material kernels 4-6 % by being
 // reachable at all (call-site spills), so scenes without them run variants that cannot reach them.
+// `shadowIdle` (the fused device kernel only): an idle lane of the last workgroup shadows the queue's last item with every side effect off, so
+// that all lanes reach the workgroup-wide light sampling of MatNee with well-defined operands.
 template <int MAT, int VARIANT = 2>
-WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid) {
+WF_HD void MatShade(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid, NeeItem<MAT> *out, bool shadowIdle = false) {
     constexpr bool TEXCTX = VARIANT != 0;
-    constexpr bool RARE_LIGHTS = VARIANT == 2;
-    // `valid` = this thread has an item.  The two queue pushes go through BlockAlloc, which every thread of
-    // the workgroup must reach: control flow below is flattened into the flags pushRay / pushShadow.
+    // `valid` = this thread has an item.  The queue push goes through BlockAlloc, which every thread of
+    // the workgroup must reach: control flow below is flattened into the flag pushRay.
     using BxDF = typename MatBxDF<MAT>::T;
     const RayQueueV &q = ws.rq[cur];
     const RayQueueV &nq = ws.rq[cur ^ 1];
-    bool pushRay = false, pushShadow = false;
+    bool pushRay = false;
     // next-ray payload
     V3 ro{0, 0, 0}, rwi{0, 0, 0};
     S4 rbeta = S4c(0.f), rr_u = S4c(0.f), rr_l = S4c(0.f);
     float retaScale = 0, time = 0;
-    int rflags = 0, rmedium = -1, smedium = -1, pixelIndex = 0, depth = 0;
+    int rflags = 0, rmedium = -1, pixelIndex = 0, depth = 0;
     LightCtx rctx{};
-    // shadow-ray payload
-    RayOD sr{V3{0, 0, 0}, V3{0, 0, 0}};
-    S4 sLd = S4c(0.f), sr_u = S4c(0.f), sr_l = S4c(0.f);
-    // `live`: an idle lane of the last workgroup shadows the queue's last item with every side effect off, so that all lanes reach the
-    // workgroup-wide light sampling below (SampleLightForBlock) with well-defined operands
     const bool live = valid;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (!valid) qi = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE] - 1;
+    if (!valid && shadowIdle) qi = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE] - 1;
 #endif
-    {
+    if (valid || shadowIdle) {
         int i = ws.matQ[MAT][qi];
         I4 meta = q.meta[i];
         pixelIndex = meta.x;
@@ -1227,9 +1254,6 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
         F4 s0 = ws.samples0[pixelIndex], s1 = ws.samples1[pixelIndex];
         // Sample BSDF and enqueue indirect ray
         BSDFSample bs = bsdf.Sample_f(wo, s0.w, V2{s1.x, s1.y});
-#if defined(WF_EXP) && (WF_EXP & 2)
-        bs.valid = false;
-#endif
         if (bs.valid) {
             V3 wi = bs.wi;
             S4 beta = wbeta * bs.f * AbsDot(wi, ns) / bs.pdf;
@@ -1268,54 +1292,89 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
                 rflags = (bs.IsSpecularS() ? RAYFLAG_SPECULAR_BOUNCE : 0) | (anyNonSpecularBounces ? RAYFLAG_ANY_NONSPECULAR : 0);
             }
         }
-
-        // the indirect ray leaves NOW (the reference pushes it here too, surfscatter.cpp:232-249): its 35 values are not carried through
-        // the light sampling below
-        pushRay = pushRay && live;
+        // what next-event estimation needs of this item (surfscatter.cpp:251-327 reads it from the MaterialEvalWorkItem and the BSDF)
         {
-            const int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], pushRay);
-            if (pushRay) {
-                nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
-                nq.d[slot] = F4{rwi.x, rwi.y, rwi.z, retaScale};
-                nq.beta[slot] = toF4(rbeta);
-                nq.r_u[slot] = toF4(rr_u);
-                nq.r_l[slot] = toF4(rr_l);
-                StoreCtx(nq, slot, rctx);
-                nq.meta[slot] = I4{pixelIndex, depth + 1, rflags, rmedium};
+            const int flags = bsdf.Flags();
+            out->want = IsNonSpecular(flags);
+            if (out->want) {
+                if (IsReflective(flags) && !IsTransmissive(flags)) { out->ctxP = OffsetRayOrigin(si.pi, si.n, wo); out->ctxIsPoint = true; }
+                else if (IsTransmissive(flags) && IsReflective(flags)) { out->ctxP = OffsetRayOrigin(si.pi, si.n, -wo); out->ctxIsPoint = true; }
             }
         }
-
-        // Sample light and enqueue shadow ray
-        int flags = bsdf.Flags();
-#if defined(WF_EXP) && (WF_EXP & 1)
-        flags = 0;
-#endif
-        const bool wantLight = IsNonSpecular(flags);
-        LightCtx ctx{si.pi, si.n, ns};
-        if (wantLight) {
-            if (IsReflective(flags) && !IsTransmissive(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, wo));
-            else if (IsTransmissive(flags) && IsReflective(flags)) ctx.pi = MakeP3i(OffsetRayOrigin(ctx.pi, si.n, -wo));
+        out->pi = si.pi; out->n = si.n; out->ns = ns; out->dpdus = dpdus; out->wo = wo;
+        out->u0 = s0.x; out->u = V2{s0.y, s0.z};
+        out->pixelIndex = pixelIndex;
+        if (sv.haveMedia) {
+            const bool transition = mesh.medium_inside != mesh.medium_outside;
+            out->mediumInside = transition ? mesh.medium_inside : meta.w;
+            out->mediumOutside = transition ? mesh.medium_outside : meta.w;
         }
-        const LightPick pick = SampleLightForBlock<RARE_LIGHTS>(sv, wantLight, ctx, s0.x, V2{s0.y, s0.z}, lambda);
-        if (wantLight && pick.lightId >= 0) {
-            const int lightId = pick.lightId;
-            const float lightPMF = pick.pmf;
-            const wf_light &light = sv.lights[lightId];
-            const LightLiSample &ls = pick.ls;
-            if (ls.valid && ls.L && ls.pdf != 0) {
-                V3 wi = ls.wi;
-                S4 f = bsdf.f(wo, wi);
-                if (f) {
-                    S4 beta = wbeta * f * AbsDot(wi, ns);
-                    float lightPDF = ls.pdf * lightPMF;
-                    float bsdfPDF = IsDeltaLight(light) ? 0.f : bsdf.PDF(wo, wi);
-                    sr_u = wr_u * bsdfPDF;
-                    sr_l = wr_u * lightPDF;
-                    sLd = beta * ls.L;
-                    sr = SpawnRayTo(si.pi, si.n, ls.pLightPi, ls.pLightN);
-                    if (sv.haveMedia) smedium = SurfaceMedium(mesh, si.n, sr.d, meta.w);
-                    pushShadow = true;
-                }
+        out->beta = wbeta; out->r_u = wr_u;
+        for (int k = 0; k < 4; ++k) out->lambda[k] = lambda.lambda[k];
+        out->bxdf = bsdf.bxdf;
+    }
+
+    // the indirect ray leaves NOW (the reference pushes it here too, surfscatter.cpp:232-249): its 35 values are not carried through
+    // the light sampling
+    pushRay = pushRay && live;
+    {
+        const int slot = BlockAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE], pushRay);
+        if (pushRay) {
+            nq.o[slot] = F4{ro.x, ro.y, ro.z, time};
+            nq.d[slot] = F4{rwi.x, rwi.y, rwi.z, retaScale};
+            nq.beta[slot] = toF4(rbeta);
+            nq.r_u[slot] = toF4(rr_u);
+            nq.r_l[slot] = toF4(rr_l);
+            StoreCtx(nq, slot, rctx);
+            nq.meta[slot] = I4{pixelIndex, depth + 1, rflags, rmedium};
+        }
+    }
+}
+
+// Sample light and enqueue shadow ray (surfscatter.cpp:251-327), in two steps around the workgroup's light sampling: what the light sample
+// needs of an item (NeeRequest), and what is done with the sample (MatNeeFinish).  Every thread of the workgroup takes part (`live`: with
+// an item whose side effects count); an item without next-event estimation has want = false.
+struct NeeRequest {
+    bool want = false;
+    LightCtx ctx{P3i{V3{0, 0, 0}, V3{0, 0, 0}}, N3{0, 0, 0}, N3{0, 0, 0}};
+    float u0 = 0;
+    V2 u{0, 0};
+    Wavelengths lambda{};
+};
+template <int MAT>
+WF_HD NeeRequest MatNeeRequest(const NeeItem<MAT> &it) {
+    NeeRequest r;
+    r.want = it.want;
+    r.ctx = LightCtx{it.ctxIsPoint ? MakeP3i(it.ctxP) : it.pi, it.n, it.ns};
+    r.u0 = it.u0; r.u = it.u;
+    for (int k = 0; k < 4; ++k) { r.lambda.lambda[k] = it.lambda[k]; r.lambda.pdf[k] = 0; }   // (the lights read the wavelengths only)
+    return r;
+}
+template <int MAT>
+WF_HD void MatNeeFinish(const SceneView &sv, const WorkState &ws, const NeeItem<MAT> &it, const LightPick &pick, bool live) {
+    using BxDF = typename MatBxDF<MAT>::T;
+    bool pushShadow = false;
+    RayOD sr{V3{0, 0, 0}, V3{0, 0, 0}};
+    S4 sLd = S4c(0.f), sr_u = S4c(0.f), sr_l = S4c(0.f);
+    int smedium = -1;
+    if (it.want && pick.lightId >= 0) {
+        const float lightPMF = pick.pmf;
+        const wf_light &light = sv.lights[pick.lightId];
+        const LightLiSample &ls = pick.ls;
+        if (ls.valid && ls.L && ls.pdf != 0) {
+            const BSDF<BxDF> bsdf(it.ns, it.dpdus, it.bxdf);
+            V3 wi = ls.wi;
+            S4 f = bsdf.f(it.wo, wi);
+            if (f) {
+                S4 beta = it.beta * f * AbsDot(wi, it.ns);
+                float lightPDF = ls.pdf * lightPMF;
+                float bsdfPDF = IsDeltaLight(light) ? 0.f : bsdf.PDF(it.wo, wi);
+                sr_u = it.r_u * bsdfPDF;
+                sr_l = it.r_u * lightPDF;
+                sLd = beta * ls.L;
+                sr = SpawnRayTo(it.pi, it.n, ls.pLightPi, ls.pLightN);
+                if (sv.haveMedia) smedium = Dot(sr.d, it.n) > 0 ? it.mediumOutside : it.mediumInside;   // SurfaceMedium
+                pushShadow = true;
             }
         }
     }
@@ -1323,12 +1382,31 @@ WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int 
     const int slot = BlockAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE], pushShadow);
     if (pushShadow) {
         ws.sq.o[slot] = F4{sr.o.x, sr.o.y, sr.o.z, 1 - ShadowEpsilon};
-        ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)pixelIndex)};
+        ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)it.pixelIndex)};
         ws.sq.Ld[slot] = toF4(sLd);
         ws.sq.r_u[slot] = toF4(sr_u);
         ws.sq.r_l[slot] = toF4(sr_l);
         if (sv.haveMedia) ws.sq.medium[slot] = smedium;
     }
+}
+template <int MAT, bool RARE_LIGHTS>
+WF_HD void MatNee(const SceneView &sv, const WorkState &ws, const NeeItem<MAT> &it, bool live) {
+    const NeeRequest rq = MatNeeRequest(it);
+    const LightPick pick = SampleLightForBlock<RARE_LIGHTS>(sv, rq.want, rq.ctx, rq.u0, rq.u, rq.lambda);
+    MatNeeFinish(sv, ws, it, pick, live);
+}
+
+// K9 fused: EvaluateMaterialAndBSDF<M, BasicTextureEvaluator>, wavefront/surfscatter.cpp:57-328 (the CPU checker; the HIP back end's
+// WF_MAT_SPLIT=0 kernels)
+template <int MAT, int VARIANT = 2>
+WF_HD void KEvalMaterial(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid) {
+    NeeItem<MAT> it;
+#if defined(__HIP_DEVICE_COMPILE__)
+    MatShade<MAT, VARIANT>(sv, ws, cur, qi, valid, &it, true);
+#else
+    MatShade<MAT, VARIANT>(sv, ws, cur, qi, valid, &it);
+#endif
+    MatNee<MAT, VARIANT == 2>(sv, ws, it, valid);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,10 @@ struct wf_ctx {
     // 31.4 ms (begin 3.3 + trace 3.7 + segment 24.1 + rest 0.3) — the time is the ratio tracking through the grid, not the walk, and the
     // per-lane loop keeps its state in registers; with object instances the per-lane alternative is the reference-order walk (1 wave / SIMD)
     int trWavefront = -1;
+    int matStreams = 1;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
+    hipStream_t matStream[WF_MAT_NTYPES] = {};
+    hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
+    bool matSplit = true;        // the material stage as two kernels per type (WF_MAT_SPLIT=0 with a MATFUSED build: the one-kernel stage)
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves and alpha on quadrics, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
@@ -1233,7 +1237,25 @@ extern "C" {
 #define WF_DECL_MAT(n) void wf_launch_eval_material_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
                        void wf_launch_eval_material_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int); \
                        void wf_launch_eval_material_##n##_2(hipStream_t, int, const SceneView *, const WorkState *, int);
+#if defined(WF_HAVE_FUSED_MAT)   // (make MATFUSED=1: the one-kernel material stage of rounds 1-4 beside the split one, for same-box A/B runs)
 WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8) WF_DECL_MAT(9) WF_DECL_MAT(10)
+#endif
+// the two halves of the material stage (wf_mat.hip): shade variant 0 | 1 | 2, next-event estimation variant 0 | 1
+#define WF_DECL_SPLIT(n) void wf_launch_mat_shade_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
+                         void wf_launch_mat_shade_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int); \
+                         void wf_launch_mat_shade_##n##_2(hipStream_t, int, const SceneView *, const WorkState *, int); \
+                         void wf_launch_mat_nee_##n##_0(hipStream_t, int, const SceneView *, const WorkState *); \
+                         void wf_launch_mat_nee_##n##_1(hipStream_t, int, const SceneView *, const WorkState *);
+WF_DECL_SPLIT(1) WF_DECL_SPLIT(2) WF_DECL_SPLIT(3) WF_DECL_SPLIT(4) WF_DECL_SPLIT(5) WF_DECL_SPLIT(6) WF_DECL_SPLIT(7) WF_DECL_SPLIT(8) WF_DECL_SPLIT(9) WF_DECL_SPLIT(10)
+}
+// bytes of one NeeItem's BxDF (wf_kernels.h) -> 16-byte planes of the record between the two kernels (wf_mat.hip: NeeIO)
+template <int MAT> constexpr int NeePlanesOf() { return 10 + (int)((sizeof(typename MatBxDF<MAT>::T) + 15) / 16); }
+static int NeePlanes(int m) {
+    switch (m) {
+    case 1: return NeePlanesOf<1>(); case 2: return NeePlanesOf<2>(); case 3: return NeePlanesOf<3>(); case 4: return NeePlanesOf<4>(); case 5: return NeePlanesOf<5>();
+    case 6: return NeePlanesOf<6>(); case 7: return NeePlanesOf<7>(); case 8: return NeePlanesOf<8>(); case 9: return NeePlanesOf<9>(); case 10: return NeePlanesOf<10>();
+    }
+    return 0;
 }
 __global__ void __launch_bounds__(BLOCK) k_update_film(const SceneView sv, WorkState ws, int nSamples) {
     for (int p = blockIdx.x * BLOCK + threadIdx.x; p < ws.pixelsPerPass; p += gridDim.x * BLOCK) KUpdateFilm(sv, ws, p, nSamples);
@@ -1327,7 +1349,8 @@ struct Prof {
     hipEvent_t a = nullptr, b = nullptr;
     const char *name;
     bool on;
-    Prof(wf_ctx *c, const char *name) : c(c), name(name) {
+    hipStream_t s;
+    Prof(wf_ctx *c, const char *name, hipStream_t onStream = nullptr) : c(c), name(name), s(onStream ? onStream : c->stream) {
         if (c->traceLaunch) { fprintf(stderr, "[wf] launch %s\n", name); fflush(stderr); }
         on = c->profile == 1 || (c->profile == 2 && (strncmp(name, "Intersect", 9) == 0 || strcmp(name, "Route hits") == 0 || strstr(name, "Material") != nullptr ||
                                                       strncmp(name, "Sample medium", 13) == 0));   // (2: the stages bench.py prices against a roofline)
@@ -1339,15 +1362,15 @@ struct Prof {
             return e;
         };
         a = get(); b = get();
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, s);
     }
     ~Prof() {
         if (c->traceLaunch) {
-            hipError_t e = hipStreamSynchronize(c->stream);
+            hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess) { fprintf(stderr, "[wf] %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
         }
         if (!on) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, s);
         c->events.push_back({name, a, b});
     }
 };
@@ -1674,6 +1697,8 @@ int wf_ctx_create(int device, wf_ctx **out) {
     HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
     if (const char *e = getenv("WF_OVERLAP_RETRACE")) c->overlapRetrace = atoi(e);
+    if (const char *e = getenv("WF_MAT_STREAMS")) c->matStreams = atoi(e);
+    HIPCHK(hipEventCreateWithFlags(&c->evMatFork, hipEventDisableTiming));
     c->traceLaunch = getenv("WF_TRACE_LAUNCH") != nullptr;
     if (const char *e = getenv("WF_SCRATCH_PRIME"); !e || atoi(e) != 0) {
         int *tmp = nullptr;
@@ -1699,6 +1724,11 @@ int wf_ctx_destroy(wf_ctx *ctx) {
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+    if (ctx->evMatFork) (void)hipEventDestroy(ctx->evMatFork);
+    for (int m = 0; m < WF_MAT_NTYPES; ++m) {
+        if (ctx->matStream[m]) (void)hipStreamDestroy(ctx->matStream[m]);
+        if (ctx->evMatJoin[m]) (void)hipEventDestroy(ctx->evMatJoin[m]);
+    }
     delete ctx;
     return 0;
 }
@@ -2087,6 +2117,18 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if ((e = devAlloc(ctx, &ws.sq.o, n)) || (e = devAlloc(ctx, &ws.sq.d, n)) || (e = devAlloc(ctx, &ws.sq.Ld, n)) ||
         (e = devAlloc(ctx, &ws.sq.r_u, n)) || (e = devAlloc(ctx, &ws.sq.r_l, n)))
         return e;
+#if defined(WF_HAVE_FUSED_MAT)
+#if defined(WF_MAT_SPLIT_DEFAULT)
+    ctx->matSplit = WF_MAT_SPLIT_DEFAULT != 0;
+#endif
+    if (const char *sp = getenv("WF_MAT_SPLIT")) ctx->matSplit = atoi(sp) != 0;
+#endif
+    if (ctx->matSplit) {
+        // the NeeItems between the material stage's two kernels: as many 16-byte planes as the widest record of the material types present
+        int planes = 0;
+        for (int m = 1; m < WF_MAT_NTYPES; ++m) if (ctx->matPresent[m]) planes = std::max(planes, NeePlanes(m));
+        if (planes > 0 && (e = devAlloc(ctx, &ws.neeRec, n * (size_t)planes))) return e;
+    }
     ctx->splitRoute = getenv("WF_SPLIT_ROUTE") ? atoi(getenv("WF_SPLIT_ROUTE")) : 2;
     if (getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = std::max(1, atoi(getenv("WF_CURSOR_CHUNK")));  // (default: chosen at scene upload)
     if (ctx->splitRoute && (e = devAlloc(ctx, &ws.routeCode, n))) return e;
@@ -2327,8 +2369,42 @@ int wf_handle_emissive(wf_ctx *ctx, int depth) {
     LAUNCH("Handle emitters hit by indirect rays", k_handle_emissive, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
 }
+static int EvalMaterialOn(wf_ctx *ctx, int material_type, int depth, hipStream_t stream, bool timed);
 int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     if (int e = checkReady(ctx)) return e;
+    return EvalMaterialOn(ctx, material_type, depth, ctx->stream, true);
+}
+// The material stage of one depth for every type present.  The kernels of different types share nothing but queue counters (atomic pushes
+// into the next ray queue and the shadow queue; every item touches only its own pixel sample's state): with WF_MAT_STREAMS (default on)
+// each type's pair of kernels runs on a stream of its own, forked from and joined to the render stream — the small queues (dielectric,
+// conductor) run in the shadow of the large ones and no launch waits for the tail of the previous type's.  The full per-stage profile
+// (profile 1: pbrt_amd --stats) keeps everything on the render stream, one timed launch after the other.
+static int EvalMaterials(wf_ctx *ctx, int depth) {
+    int present = 0;
+    for (int m = 1; m < WF_MAT_NTYPES; ++m) present += ctx->matPresent[m] ? 1 : 0;
+    const bool parallel = ctx->matStreams && present > 1 && ctx->profile != 1 && !ctx->traceLaunch && ctx->matSplit;
+    if (!parallel) {
+        for (int m = 1; m < WF_MAT_NTYPES; ++m)
+            if (ctx->matPresent[m])
+                if (int e = EvalMaterialOn(ctx, m, depth, ctx->stream, true)) return e;
+        return 0;
+    }
+    Prof prof_(ctx, "Material stage: all types, shade + next-event estimation (parallel streams)");   // (profile 2: what bench.py prices; on the render stream, fork to join)
+    HIPCHK(hipEventRecord(ctx->evMatFork, ctx->stream));
+    for (int m = 1; m < WF_MAT_NTYPES; ++m) {
+        if (!ctx->matPresent[m]) continue;
+        if (!ctx->matStream[m]) {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->matStream[m], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ctx->evMatJoin[m], hipEventDisableTiming));
+        }
+        HIPCHK(hipStreamWaitEvent(ctx->matStream[m], ctx->evMatFork, 0));
+        if (int e = EvalMaterialOn(ctx, m, depth, ctx->matStream[m], false)) return e;
+        HIPCHK(hipEventRecord(ctx->evMatJoin[m], ctx->matStream[m]));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evMatJoin[m], 0));
+    }
+    return 0;
+}
+static int EvalMaterialOn(wf_ctx *ctx, int material_type, int depth, hipStream_t stream, bool timed) {
     const int g = gridFor(ctx->maxQueueSize), cur = depth & 1;
     static const char *names[WF_MAT_NTYPES] = {"", "DiffuseMaterial + BxDF eval (Basic tex)", "ConductorMaterial + BxDF eval (Basic tex)",
                                                "DielectricMaterial + BxDF eval (Basic tex)", "ThinDielectricMaterial + BxDF eval (Basic tex)",
@@ -2337,21 +2413,60 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
                                                "MeasuredMaterial + BxDF eval (Basic tex)"};
     if (material_type == WF_MAT_INTERFACE) return 0;
     if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
-    {
-        Prof prof_(ctx, names[material_type]);
-        const bool tex = ctx->svHost.texNeedsFootprint != 0;
-        const bool rare = ctx->rareLights || ctx->svHost.film.type == WF_FILM_GBUFFER || ctx->svHost.camera.anim.actually_animated;   // a portal infinite light, or a GBufferFilm: the variant that can reach the portal samplers / fills the visible surface
+    const bool tex = ctx->svHost.texNeedsFootprint != 0;
+    const bool vs = ctx->svHost.film.type == WF_FILM_GBUFFER || ctx->svHost.camera.anim.actually_animated;   // the variant that fills the visible surface / differentiates a moving camera
+#if defined(WF_HAVE_FUSED_MAT)
+    if (!ctx->matSplit) {
+        Prof prof_(ctx, timed ? names[material_type] : "(untimed)", stream);
+        const bool rare = ctx->rareLights || vs;   // a portal infinite light, or a GBufferFilm: the variant that can reach the portal samplers / fills the visible surface
         switch (material_type) {
-        case 1: (rare ? wf_launch_eval_material_1_2 : tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 2: (rare ? wf_launch_eval_material_2_2 : tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 3: (rare ? wf_launch_eval_material_3_2 : tex ? wf_launch_eval_material_3_1 : wf_launch_eval_material_3_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 4: (rare ? wf_launch_eval_material_4_2 : tex ? wf_launch_eval_material_4_1 : wf_launch_eval_material_4_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 5: (rare ? wf_launch_eval_material_5_2 : tex ? wf_launch_eval_material_5_1 : wf_launch_eval_material_5_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 6: (rare ? wf_launch_eval_material_6_2 : tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 7: (rare ? wf_launch_eval_material_7_2 : tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 8: (rare ? wf_launch_eval_material_8_2 : tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 9: (rare ? wf_launch_eval_material_9_2 : tex ? wf_launch_eval_material_9_1 : wf_launch_eval_material_9_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 10: (rare ? wf_launch_eval_material_10_2 : tex ? wf_launch_eval_material_10_1 : wf_launch_eval_material_10_0)(ctx->stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 1: (rare ? wf_launch_eval_material_1_2 : tex ? wf_launch_eval_material_1_1 : wf_launch_eval_material_1_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 2: (rare ? wf_launch_eval_material_2_2 : tex ? wf_launch_eval_material_2_1 : wf_launch_eval_material_2_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 3: (rare ? wf_launch_eval_material_3_2 : tex ? wf_launch_eval_material_3_1 : wf_launch_eval_material_3_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 4: (rare ? wf_launch_eval_material_4_2 : tex ? wf_launch_eval_material_4_1 : wf_launch_eval_material_4_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 5: (rare ? wf_launch_eval_material_5_2 : tex ? wf_launch_eval_material_5_1 : wf_launch_eval_material_5_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 6: (rare ? wf_launch_eval_material_6_2 : tex ? wf_launch_eval_material_6_1 : wf_launch_eval_material_6_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 7: (rare ? wf_launch_eval_material_7_2 : tex ? wf_launch_eval_material_7_1 : wf_launch_eval_material_7_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 8: (rare ? wf_launch_eval_material_8_2 : tex ? wf_launch_eval_material_8_1 : wf_launch_eval_material_8_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 9: (rare ? wf_launch_eval_material_9_2 : tex ? wf_launch_eval_material_9_1 : wf_launch_eval_material_9_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 10: (rare ? wf_launch_eval_material_10_2 : tex ? wf_launch_eval_material_10_1 : wf_launch_eval_material_10_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        }
+        return 0;
+    }
+#endif
+    // the two halves (wf_kernels.h MatShade / MatNee; the items' NeeItems stay in ws.neeRec between them)
+    {
+        Prof prof_(ctx, timed ? names[material_type] : "(untimed)", stream);
+        switch (material_type) {
+        case 1: (vs ? wf_launch_mat_shade_1_2 : tex ? wf_launch_mat_shade_1_1 : wf_launch_mat_shade_1_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 2: (vs ? wf_launch_mat_shade_2_2 : tex ? wf_launch_mat_shade_2_1 : wf_launch_mat_shade_2_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 3: (vs ? wf_launch_mat_shade_3_2 : tex ? wf_launch_mat_shade_3_1 : wf_launch_mat_shade_3_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 4: (vs ? wf_launch_mat_shade_4_2 : tex ? wf_launch_mat_shade_4_1 : wf_launch_mat_shade_4_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 5: (vs ? wf_launch_mat_shade_5_2 : tex ? wf_launch_mat_shade_5_1 : wf_launch_mat_shade_5_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 6: (vs ? wf_launch_mat_shade_6_2 : tex ? wf_launch_mat_shade_6_1 : wf_launch_mat_shade_6_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 7: (vs ? wf_launch_mat_shade_7_2 : tex ? wf_launch_mat_shade_7_1 : wf_launch_mat_shade_7_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 8: (vs ? wf_launch_mat_shade_8_2 : tex ? wf_launch_mat_shade_8_1 : wf_launch_mat_shade_8_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 9: (vs ? wf_launch_mat_shade_9_2 : tex ? wf_launch_mat_shade_9_1 : wf_launch_mat_shade_9_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 10: (vs ? wf_launch_mat_shade_10_2 : tex ? wf_launch_mat_shade_10_1 : wf_launch_mat_shade_10_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        }
+    }
+    {
+        static const char *neeNames[WF_MAT_NTYPES] = {"", "DiffuseMaterial: next-event estimation", "ConductorMaterial: next-event estimation", "DielectricMaterial: next-event estimation",
+                                                      "ThinDielectricMaterial: next-event estimation", "DiffuseTransmissionMaterial: next-event estimation",
+                                                      "CoatedDiffuseMaterial: next-event estimation", "CoatedConductorMaterial: next-event estimation",
+                                                      "SubsurfaceMaterial: next-event estimation", "HairMaterial: next-event estimation", "MeasuredMaterial: next-event estimation"};
+        Prof prof_(ctx, timed ? neeNames[material_type] : "(untimed)", stream);
+        switch (material_type) {
+        case 1: (ctx->rareLights ? wf_launch_mat_nee_1_1 : wf_launch_mat_nee_1_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 2: (ctx->rareLights ? wf_launch_mat_nee_2_1 : wf_launch_mat_nee_2_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 3: (ctx->rareLights ? wf_launch_mat_nee_3_1 : wf_launch_mat_nee_3_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 4: (ctx->rareLights ? wf_launch_mat_nee_4_1 : wf_launch_mat_nee_4_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 5: (ctx->rareLights ? wf_launch_mat_nee_5_1 : wf_launch_mat_nee_5_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 6: (ctx->rareLights ? wf_launch_mat_nee_6_1 : wf_launch_mat_nee_6_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 7: (ctx->rareLights ? wf_launch_mat_nee_7_1 : wf_launch_mat_nee_7_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 8: (ctx->rareLights ? wf_launch_mat_nee_8_1 : wf_launch_mat_nee_8_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 9: (ctx->rareLights ? wf_launch_mat_nee_9_1 : wf_launch_mat_nee_9_0)(stream, g, &ctx->svHost, &ctx->ws); break;
+        case 10: (ctx->rareLights ? wf_launch_mat_nee_10_1 : wf_launch_mat_nee_10_0)(stream, g, &ctx->svHost, &ctx->ws); break;
         }
     }
     return 0;
@@ -2424,9 +2539,7 @@ int wf_render_pass(wf_ctx *ctx, int y0, int sample_index) {
         if ((e = wf_handle_escaped(ctx, depth))) return e;
         if ((e = wf_handle_emissive(ctx, depth))) return e;
         if (depth == ctx->maxDepth) break;
-        for (int m = 0; m < WF_MAT_NTYPES; ++m)
-            if (ctx->matPresent[m] && m != WF_MAT_INTERFACE)
-                if ((e = wf_eval_material(ctx, m, depth))) return e;
+        if ((e = EvalMaterials(ctx, depth))) return e;
         if ((e = ctx->svHost.haveMedia ? wf_intersect_shadow_tr(ctx, depth) : wf_intersect_shadow(ctx, depth))) return e;
         if (ctx->svHost.haveSubsurface) {  // SampleSubsurface (integrator.cpp:431) ends with its own TraceShadowRays
             if ((e = wf_subsurface_probe(ctx, depth)) || (e = wf_intersect_one_random(ctx)) || (e = wf_subsurface_scatter(ctx, depth))) return e;

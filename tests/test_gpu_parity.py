@@ -924,3 +924,55 @@ def test_cli_multi_device_contexts_on_one_gpu_bit_identical(tmp_path, devices):
         q = subprocess.run([exe, "--quiet", "--spp", str(spp), "--stats", "--outfile", one, scene], check=True, timeout=600, capture_output=True, text=True)
         total = lambda t: [l for l in t.splitlines() if "Total rays" in l][0].split()[2]
         assert total(p.stdout) == total(q.stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The physical oracle (north_star: "matches pbrt's CPU VolPathIntegrator").  Everything above compares with
+# `pbrt --wavefront`, sample for sample; VolPath (cpu/integrators.cpp:953-1390) draws its samples in another order, so the agreement is in
+# expectation: tests/golden/volpath/<scene>.json holds the block means of TWO independent VolPath renders (seeds 0, 1; 2048 spp each;
+# tools/make_volpath_goldens.py) of the downscaled stand-ins of BASELINE configs 1-4.  The GPU renders the same scene at 1024 spp.
+# Tolerances, in the spirit of the reference's own CheckSceneAverage (cpu/integrators_test.cpp:50-65: |mean - expected| <= 0.025 at
+# expected ~ 1): the image mean within 2.5 % of the goldens' mean; every block of the 8 x 8 grid within 5 % of the goldens' block mean
+# plus four times the goldens' own disagreement on that block (floored at the grid's median disagreement) — the stated confidence interval.
+VOLPATH = os.path.join(GOLDEN, "volpath")
+VOLPATH_GPU_SPP = 1024
+
+
+def _volpath_scene(name, tmp_path):
+    import make_scenes
+    if name == "killeroo_like_small":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_volpath_goldens
+        p = str(tmp_path / (name + ".pbrt"))
+        make_scenes.killeroo_like(p, make_volpath_goldens.KILLEROO_SMALL["res"], make_volpath_goldens.KILLEROO_SMALL["spp"])
+        return p
+    from conftest import bench_small_scene
+    return bench_small_scene(name, tmp_path)[0]
+
+
+@pytest.mark.parametrize("name", ["sanmiguel_like_small", "tm_like_small", "cloud_like_small", "killeroo_like_small"])
+def test_volpath_in_expectation(wfpt, tmp_path, name):
+    gold = json.load(open(os.path.join(VOLPATH, name + ".json")))
+    path = _volpath_scene(name, tmp_path / "scene")
+    s = wfpt.Scene(path=path, spp=VOLPATH_GPU_SPP)
+    s.create_renderer(0)
+    s.clear_film()
+    s.render(0, VOLPATH_GPU_SPP, 1)
+    img = s.image().astype(np.float64)
+    s.close()
+    assert [img.shape[1], img.shape[0]] == gold["resolution"] and np.isfinite(img).all()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_volpath_goldens import block_means
+    a, b = np.array(gold["blocks_a"]), np.array(gold["blocks_b"])
+    ref = 0.5 * (a + b)
+    g = block_means(img, gold["grid"])
+    mean_ref = 0.5 * (np.array(gold["mean_a"]) + np.array(gold["mean_b"]))
+    mean_gpu = img.mean(axis=(0, 1))
+    rel_mean = np.abs(mean_gpu / mean_ref - 1).max()
+    noise = np.abs(a - b)
+    noise = np.maximum(noise, np.median(noise))
+    tol = 0.05 * ref + 4 * noise
+    excess = (np.abs(g - ref) - tol) / np.maximum(ref, 1e-6)
+    print(name, "image mean gpu", mean_gpu, "volpath", mean_ref, "rel", rel_mean, "worst block excess", excess.max(), "max block rel diff", (np.abs(g - ref) / np.maximum(ref, 1e-6)).max())
+    assert rel_mean <= 0.025, (mean_gpu, mean_ref)
+    assert (excess <= 0).all(), (np.argwhere(excess > 0).tolist(), excess.max())

@@ -13,7 +13,7 @@
 #   ab               pbrt_amd --stats under each environment given in $AB (";"-separated) — knob A/B on one box
 # Environment: TAG (default r04), STEPS (20), SPP (16), PMC_SPP (4), SCENE (sanmiguel | sanmiguel_sphere | killeroo | cloud | tm), GREP (kernel-name filter of sm16).
 export TMPDIR=/tmp
-TAG=${TAG:-r04}; STEPS=${STEPS:-20}; SPP=${SPP:-16}; PMC_SPP=${PMC_SPP:-4}; SCENE=${SCENE:-sanmiguel}
+TAG=${TAG:-r05}; STEPS=${STEPS:-20}; SPP=${SPP:-16}; PMC_SPP=${PMC_SPP:-4}; SCENE=${SCENE:-sanmiguel}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -36,7 +36,7 @@ for step in "$@"; do
   echo "=== $step"
   case $step in
     tests)
-      timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/${TAG}_pytest_gpu_full.txt 2>&1
+      timeout 1500 python -m pytest tests -x -q -s -m gpu ${PYTEST_ARGS:-} > $OUT/${TAG}_pytest_gpu_full.txt 2>&1
       grep -E "passed|failed|FAILED|ERROR|error" $OUT/${TAG}_pytest_gpu_full.txt | tail -8 | tee $OUT/${TAG}_pytest_gpu.txt
       timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/${TAG}_smoke.txt;;
     bench)
@@ -62,6 +62,19 @@ for step in "$@"; do
         echo "== $b" | tee -a $OUT/${TAG}_${SCENE}_${SPP}spp_stats.txt
         timeout 200 $b/pbrt_amd --stats --spp $SPP --outfile /tmp/x.pfm $f 2>&1 | grep -E "Rendering|${GREP:-Intersect|Material|Medium|medium|Total GPU|film|Generate|escaped|emitters|Route|ransmittance}" | tee -a $OUT/${TAG}_${SCENE}_${SPP}spp_stats.txt
       done;;
+    wall)
+      # whole-render wall time (no per-stage profile: the material stage's parallel streams are on) of every build, under each environment of $AB
+      f=$(scene_file)
+      $ROOT/pbrt-v4_amd/_build/pbrt_amd --quiet --spp 4 --outfile /tmp/x.pfm $f > /dev/null 2>&1
+      IFS=';' read -ra envs <<< "${AB:-WF_NONE=1}"
+      for b in $ROOT/pbrt-v4_amd/_build $ROOT/pbrt-v4_amd/_exp*; do
+        [ -x $b/pbrt_amd ] || continue
+        for e in "${envs[@]}"; do
+          for rep in 1 2; do
+            echo "== $b $e: $(env $e timeout 200 $b/pbrt_amd --spp $SPP --outfile /tmp/x.pfm $f 2>&1 | grep -E 'Rendering finished')" | tee -a $OUT/${TAG}_${SCENE}_${SPP}spp_wall.txt
+          done
+        done
+      done;;
     pmc)
       f=$(scene_file)
       pass() {
@@ -78,7 +91,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0][-46:]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
 for k in sorted(agg):
-    if any(s in k for s in ("closest", "shadow", "route", "material", "gen_", "medium", "tr_", "film")):
+    if any(s in k for s in ("closest", "shadow", "route", "material", "k_mat_", "gen_", "medium", "tr_", "film")):
         print(k, len(cnt[k]), {c: "%.4g" % v for c, v in agg[k].items()})   # totals over the dispatches
 PY
       }
