@@ -186,3 +186,30 @@ def test_stale_medium_depth_finding_is_the_reference_defect(built, tmp_path):
     plain = read_pfm(out2)
     differ = np.argwhere((ref.view(np.uint32) != plain.view(np.uint32)).any(axis=2)).tolist()
     assert differ == [[0, 19], [5, 25]], differ   # (row, column): the two paths that read a stale depth in the reference
+
+
+@pytest.mark.parametrize("name", ["sanmiguel_like_small", "cloud_like_small", "killeroo_like_small"])
+def test_volpath_in_expectation_cpu_port(built, tmp_path, name):
+    """The physical oracle of the north_star — pbrt's CPU VolPathIntegrator (cpu/integrators.cpp:953-1390) — in expectation, on the CPU
+    port of the wavefront path (the stage bodies the HIP kernels run; the GPU leg is tests/test_gpu_parity.py::test_volpath_in_expectation
+    at 1024 spp).  tests/golden/volpath/<scene>.json = block means of two independent VolPath renders (tools/make_volpath_goldens.py);
+    the port renders 256 spp.  Tolerances as on the GPU: image mean within 2.5 % (the reference's CheckSceneAverage,
+    cpu/integrators_test.cpp:50-65), every block of the 8 x 8 grid within 5 % + 4 x the goldens' own disagreement."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from make_volpath_goldens import block_means, scene_for
+    gold = json.load(open(os.path.join(GOLDEN, "volpath", name + ".json")))
+    sd = tmp_path / "scene"
+    sd.mkdir()
+    path = scene_for(name, str(sd))
+    out = str(tmp_path / "port.pfm")
+    run_wf_cpu(path, out, 256, extra=("--nthreads", str(min(8, os.cpu_count() or 1))))
+    img = read_pfm(out).astype(np.float64)
+    a, b = np.array(gold["blocks_a"]), np.array(gold["blocks_b"])
+    ref, g = 0.5 * (a + b), block_means(img, gold["grid"])
+    mean_ref = 0.5 * (np.array(gold["mean_a"]) + np.array(gold["mean_b"]))
+    assert np.abs(img.mean(axis=(0, 1)) / mean_ref - 1).max() <= 0.025
+    noise = np.abs(a - b)
+    noise = np.maximum(noise, np.median(noise))
+    assert (np.abs(g - ref) <= 0.05 * ref + 4 * noise).all()
