@@ -37,6 +37,8 @@ enum {
     CNT_RAY0 = 0, CNT_RAY1 = 1, CNT_ESCAPED = 2, CNT_HITLIGHT = 3, CNT_SHADOW = 4, CNT_MAT0 = 5,
     CNT_MEDIUM_SAMPLE = CNT_MAT0 + WF_MAT_NTYPES, CNT_MEDIUM_SCATTER, CNT_MIX, CNT_RETRACE, CNT_BSSRDF, CNT_SSS, CNT_CURSOR, CNT_TR0, CNT_TR1,
     CNT_RETRACE_HEAD, CNT_WAVES_DONE,   // the closest-hit kernel's in-kernel near-tie queue (wf_backend.hip: DrainRetrace)
+    CNT_CURSOR_SHADOW,                  // the any-hit launch's work cursor (CNT_CURSOR: the closest-hit launch's)
+    CNT_MEDIUM_ROUTE,                   // medium-sample items that reached their surface (KMediumRoute)
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -116,6 +118,7 @@ struct WorkState {
     // MediumSampleQueue / MediumScatterQueue (workitems.h:219-262) as index queues over the current ray queue: the
     // items' payload is the ray slot itself (+ hit / hitT), beta, r_u, r_l are updated in place in the ray queue
     int32_t *mediumSampleQ, *mediumScatterQ;
+    int32_t *mediumRouteQ = nullptr;   // HIP back end only: ray slots whose medium sampling ended at the surface (routed by KMediumRoute)
     F4 *scatterP;  // per ray slot: scattering point p.xyz, HG g
     int32_t *mixMat;  // per ray slot: the material id a MixMaterial hit resolved to (allocated when sv.haveMix)
     int32_t *mixQ;    // HIP traversal kernel only: hits on a MixMaterial, resolved by the kernel that follows it
@@ -666,7 +669,23 @@ WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, in
         }
         return;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the HIP back end routes the rays that reached their surface in a kernel of its own (KMediumRoute over ws.mediumRouteQ): the routing
+    // rebuilds the interaction of interface hits and resolves MixMaterials — code whose registers the delta-tracking loop above should
+    // not pay for (k_medium_sample: 219 -> 128 VGPRs, round 5)
+    {
+        int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_ROUTE) * CNT_STRIDE]);
+        ws.mediumRouteQ[slot] = i;
+    }
+#else
     RouteSurfaceHit(sv, ws, cur, i, prim, HitInst(sv, ws, i), h.y, h.z, h.w);
+#endif
+}
+// the second half of K5 on the HIP back end: EnqueueWorkAfterIntersection for the medium-sample items that reached their surface
+WF_HD void KMediumRoute(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    const int i = ws.mediumRouteQ[qi];
+    const F4 h = ws.hit[i];
+    RouteSurfaceHit(sv, ws, cur, i, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w);
 }
 
 // K6: SampleMediumScattering<HGPhaseFunction>, wavefront/media.cpp:259-352

@@ -85,7 +85,8 @@ struct wf_ctx {
     // 31.4 ms (begin 3.3 + trace 3.7 + segment 24.1 + rest 0.3) — the time is the ratio tracking through the grid, not the walk, and the
     // per-lane loop keeps its state in registers; with object instances the per-lane alternative is the reference-order walk (1 wave / SIMD)
     int trWavefront = -1;
-    int matStreams = 1;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
+    bool cursorDirty[2] = {false, false};   // the closest-hit / any-hit work cursor has been used since a k_reset last zeroed it
+    int matStreams = 0;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
     hipStream_t matStream[WF_MAT_NTYPES] = {};
     hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
     bool matSplit = true;        // the material stage as two kernels per type (WF_MAT_SPLIT=0 with a MATFUSED build: the one-kernel stage)
@@ -1088,9 +1089,18 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mix(const SceneView sv, WorkS
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KResolveMix(sv, ws, cur, i);
 }
 // K5 / K6 / K11: participating media (wf_media.h, wf_kernels.h)
-__global__ void __launch_bounds__(BLOCK) k_medium_sample(const SceneView sv, WorkState ws, int cur) {
+// (round 5) the delta-tracking loop alone: the routing of the items that reach their surface — interaction rebuild of interface hits,
+// MixMaterial resolve — is the kernel after it (219 VGPRs / 604 B of scratch -> 207 / 0 for the loop; WF_MEDIUM_WAVES sets its occupancy target)
+#ifndef WF_MEDIUM_WAVES
+#define WF_MEDIUM_WAVES 2
+#endif
+__global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction(sv, ws, cur, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_medium_route(const SceneView sv, WorkState ws, int cur) {
+    const int n = ws.counters[(CNT_MEDIUM_ROUTE) * CNT_STRIDE];
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KMediumRoute(sv, ws, cur, i);
 }
 __global__ void __launch_bounds__(BLOCK) k_medium_scatter(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE];
@@ -2103,7 +2113,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
         if ((e = devAlloc(ctx, &ws.trO, n)) || (e = devAlloc(ctx, &ws.trD, n)) || (e = devAlloc(ctx, &ws.trT, n)) || (e = devAlloc(ctx, &ws.trRu, n)) ||
             (e = devAlloc(ctx, &ws.trRl, n)) || (e = devAlloc(ctx, &ws.trRng, n)) || (e = devAlloc(ctx, &ws.trQ[0], n)) || (e = devAlloc(ctx, &ws.trQ[1], n)))
             return e;
-        if ((e = devAlloc(ctx, &ws.hitT, n)) || (e = devAlloc(ctx, &ws.mediumSampleQ, n)) || (e = devAlloc(ctx, &ws.mediumScatterQ, n)) ||
+        if ((e = devAlloc(ctx, &ws.hitT, n)) || (e = devAlloc(ctx, &ws.mediumSampleQ, n)) || (e = devAlloc(ctx, &ws.mediumScatterQ, n)) || (e = devAlloc(ctx, &ws.mediumRouteQ, n)) ||
             (e = devAlloc(ctx, &ws.scatterP, n)) || (e = devAlloc(ctx, &ws.sq.medium, n)))
             return e;
     }
@@ -2210,9 +2220,10 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
     mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE) | (1u << CNT_BSSRDF) | (1u << CNT_SSS);
-    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE);
+    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE) | (1u << CNT_CURSOR) | (1u << CNT_MEDIUM_ROUTE);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + statDepth(depth), CNT_RAY0 + cur);
+    ctx->cursorDirty[0] = false;
     return 0;
 }
 int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
@@ -2284,8 +2295,12 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
         if (ctx->splitRoute) {
             int *cursor = nullptr;
             if (ctx->splitRoute > 1) {
+                // the work cursor starts at 0: zeroed by the stage's "Reset queues" launch (wf_reset_stage_queues) — a memset node of its own
+                // cost a launch's latency per traversal launch (139 fillBuffer launches, 6 ms, in three renders of the spec scene, round 4);
+                // only a caller that launches twice without that reset in between pays for one here
                 cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
-                HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+                if (ctx->cursorDirty[0]) HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+                ctx->cursorDirty[0] = true;
             }
             ctx->ws.drainEpoch = (ctx->ws.drainEpoch + 1) & 0x7fffffff;   // tag of this launch's near-tie queue entries (DrainRetrace)
             if (ctx->ws.drainEpoch == 0) ctx->ws.drainEpoch = 1;
@@ -2325,6 +2340,7 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return 0;
     LAUNCH("Sample medium interaction", k_medium_sample, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    LAUNCH("Sample medium interaction: route surface hits", k_medium_route, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     if (depth == ctx->maxDepth) return 0;
     LAUNCH("Sample direct/indirect - Henyey-Greenstein", k_medium_scatter, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
@@ -2375,10 +2391,11 @@ int wf_eval_material(wf_ctx *ctx, int material_type, int depth) {
     return EvalMaterialOn(ctx, material_type, depth, ctx->stream, true);
 }
 // The material stage of one depth for every type present.  The kernels of different types share nothing but queue counters (atomic pushes
-// into the next ray queue and the shadow queue; every item touches only its own pixel sample's state): with WF_MAT_STREAMS (default on)
-// each type's pair of kernels runs on a stream of its own, forked from and joined to the render stream — the small queues (dielectric,
-// conductor) run in the shadow of the large ones and no launch waits for the tail of the previous type's.  The full per-stage profile
-// (profile 1: pbrt_amd --stats) keeps everything on the render stream, one timed launch after the other.
+// into the next ray queue and the shadow queue; every item touches only its own pixel sample's state): with WF_MAT_STREAMS=1
+// each type's pair of kernels runs on a stream of its own, forked from and joined to the render stream.  MEASURED AND LEFT OFF (round 5,
+// spec scene, 16 spp, same box, profiles/r05_material_split_ab_sm16.txt): 0.111-0.112 s per render with the streams against 0.108 s
+// without — the kernels run at 2-4 waves per SIMD by their register need, a second kernel finds no free slots beside the first, and the
+// interleaved queues only cost cache locality; VERDICT r4 item 8 asked for the experiment.
 static int EvalMaterials(wf_ctx *ctx, int depth) {
     int present = 0;
     for (int m = 1; m < WF_MAT_NTYPES; ++m) present += ctx->matPresent[m] ? 1 : 0;
@@ -2480,14 +2497,16 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
             if (int e = SortQueue(ctx, true, 0)) return e;
         int *cursor = nullptr;
         if (ctx->splitRoute > 1) {
-            cursor = ctx->ws.counters + CNT_CURSOR * CNT_STRIDE;
-            HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+            cursor = ctx->ws.counters + CNT_CURSOR_SHADOW * CNT_STRIDE;   // (zeroed by the "Reset shadowRayQueue" launch that follows every any-hit launch)
+            if (ctx->cursorDirty[1]) HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+            ctx->cursorDirty[1] = true;
         }
         LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk);
     } else
         LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
-    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW) | (1u << CNT_CURSOR_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
+    ctx->cursorDirty[1] = false;
     return 0;
 }
 // K12: SampleSubsurface (wavefront/subsurface.cpp:18-203) in its three launches

@@ -30,8 +30,18 @@ constexpr int MBLOCK = 256;
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 2
 #endif
+// Round 5, the two halves on the spec scene (16 spp, same box; profiles/r05_material_split_ab_sm16.txt, r05_material_occupancy_ab_sm16.txt):
+//   next-event estimation, diffuse / conductor / coated diffuse, ms:  2 waves 12.75 / 2.89 / 9.89   3 waves 9.95 / 2.33 / 9.08
+//                                                                      4 waves  8.47 / 2.09 / 8.80   5 waves 8.99 / 2.13 / 11.09   6 waves 9.34 / 2.50 / 12.38
+//   shade:                                                             2 waves 10.88 / 3.17 / 7.44   3 waves 11.27 / 4.47 / 8.49   4 waves 12.24 / 4.81 / 9.00
+// The light sampling (descent of the light BVH, shape sampling) is a chain of dependent gathers and pays for occupancy even with 100-600
+// spilled VGPRs; the shade half is dominated by its own loads and stores, and spills only add to them.
 #ifndef WF_NEE_WAVES
+#if WF_MAT_INSTANCE == 10 && WF_MAT_PART == 2 && WF_MAT_TEXCTX == 1
+#define WF_NEE_WAVES 2   // (k_mat_nee<measured, rare lights> at 4 waves spills a carrier register: tools/check_spill_carriers.py)
+#else
 #define WF_NEE_WAVES 4
+#endif
 #endif
 // The scene view is read through the pointer to its device-resident copy instead of from the kernel arguments (round 4) — every field that
 // is live across the kernel is an SGPR pair either way, but a by-value argument invites the compiler to keep all of them (300-400 spilled

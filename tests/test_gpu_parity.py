@@ -943,6 +943,7 @@ def _volpath_scene(name, tmp_path):
     if name == "killeroo_like_small":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import make_volpath_goldens
+        os.makedirs(str(tmp_path), exist_ok=True)
         p = str(tmp_path / (name + ".pbrt"))
         make_scenes.killeroo_like(p, make_volpath_goldens.KILLEROO_SMALL["res"], make_volpath_goldens.KILLEROO_SMALL["spp"])
         return p
