@@ -689,6 +689,8 @@ WF_HD void KMediumRoute(const SceneView &sv, const WorkState &ws, int cur, int q
 }
 
 // K6: SampleMediumScattering<HGPhaseFunction>, wavefront/media.cpp:259-352
+// RARE_LIGHTS = false: the scene has neither portal lights nor emitters that are not triangles nor alpha-masked emitters (LightSampleLi<RARE>)
+template <bool RARE_LIGHTS = true>
 WF_HD void KSampleMediumScattering(const SceneView &sv, const WorkState &ws, int cur, int qi) {
     const int i = ws.mediumScatterQ[qi];
     const RayQueueV &q = ws.rq[cur];
@@ -708,7 +710,7 @@ WF_HD void KSampleMediumScattering(const SceneView &sv, const WorkState &ws, int
     int lightId = LightSamplerSample(sv, ctx, s0.x, &lightPMF);
     if (lightId >= 0) {
         const wf_light &light = sv.lights[lightId];
-        LightLiSample ls = LightSampleLi(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
+        LightLiSample ls = LightSampleLi<RARE_LIGHTS>(sv, light, ctx, V2{s0.y, s0.z}, lambda, true);
         if (ls.valid && ls.L && ls.pdf > 0) {
             V3 wi = ls.wi;
             S4 beta = wbeta * HenyeyGreenstein(Dot(wo, wi), g);
@@ -1156,7 +1158,7 @@ WF_HD void MatShade(const SceneView &sv, const WorkState &ws, int cur, int qi, b
         {
             V3 ro{0, 0, 0}, rd{0, 0, 0};   // only a curve's interaction needs the ray that found it
             if (sv.haveCurves) { F4 o4 = q.o[i], d4 = q.d[i]; ro = V3{o4.x, o4.y, o4.z}; rd = V3{d4.x, d4.y, d4.z}; }
-            HitInteraction(sv, prim, inst, h.y, h.z, h.w, &si, ro, rd);
+            HitInteraction<!WF_DEV_LEAN, !WF_DEV_LEAN>(sv, prim, inst, h.y, h.z, h.w, &si, ro, rd);   // (incl. alpha-textured curves)
         }
         const wf_mesh &mesh = sv.meshes[si.mesh];
         int matId = mesh.material;

@@ -80,8 +80,12 @@ WF_HD bool AreaLightAlphaMasked(const SceneView &sv, const wf_light &l, V3 p, V2
     return HashToFloat(Hash3f(p)) > a;
 }
 // DiffuseAreaLight::L, lights.h:441-463; with an image: Image::BilerpChannel at (u, 1 - v), clamp wrap
+// (ALPHA = false: a caller that knows no emitter of the scene has an alpha texture — the texture-graph evaluator behind AlphaMasked is an
+//  out-of-line callee of 160+ VGPRs, and a reachable callee sets the caller's allocation)
+template <bool ALPHA = true>
 WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, V3 p, N3 n, V2 uv, V3 w, const Wavelengths &lambda) {
     if (!(l.flags & WF_LIGHTFLAG_TWOSIDED) && Dot(n, w) < 0) return S4c(0.f);
+    if constexpr (ALPHA)
     if (AreaLightAlphaMasked(sv, l, p, uv)) return S4c(0.f);
     if (l.image >= 0) {
         const wf_tex_image im = sv.texImages[l.image];
@@ -259,10 +263,12 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
     ls.valid = false;
     switch (l.type) {
     case WF_LIGHT_DIFFUSE_AREA: {
-        ShapeSampleR ss = l.tri >= sv.nTriangles ? SphereSample(sv, l.tri, ctx.pi, ctx.n, ctx.ns, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
+        // (RARE = false: a kernel for scenes whose emitters are all triangles — the out-of-line sampler of sphere / disk / cylinder / patch
+        //  emitters needs 214 VGPRs, and a callee that is merely reachable sets the kernel's allocation: round 5, tools/exp/light_vgprs.hip)
+        ShapeSampleR ss = (RARE && l.tri >= sv.nTriangles) ? SphereSample(sv, l.tri, ctx.pi, ctx.n, ctx.ns, u) : TriangleSample(sv, l.tri, ctx.pi, ctx.ns, u);
         if (!ss.valid || ss.pdf == 0 || LengthSquared(ss.pi.mid() - ctx.p()) == 0) return ls;
         V3 wi = Normalize(ss.pi.mid() - ctx.p());
-        S4 Le = AreaLightL(sv, l, ss.pi.mid(), ss.n, ss.uv, -wi, lambda);
+        S4 Le = AreaLightL<RARE>(sv, l, ss.pi.mid(), ss.n, ss.uv, -wi, lambda);
         if (!Le) return ls;
         ls.L = Le; ls.wi = wi; ls.pdf = ss.pdf; ls.pLightPi = ss.pi; ls.pLightN = ss.n; ls.valid = true;
         return ls;

@@ -88,9 +88,10 @@ struct SceneView {
 };
 enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2,   // (bit flags: several may be raised in one render)
        WF_FATAL_CHECK_HAIR = 4,      // HairBxDF ctor: CHECK(h >= -1 && h <= 1) / beta_m / beta_n (bxdfs.cpp:278-280)
-       WF_FATAL_CHECK_NAN_PDF = 8 }; // DielectricBxDF::Sample_f: CHECK(!IsNaN(pdf)) of the rough transmission (bxdfs.cpp:158)
+       WF_FATAL_CHECK_NAN_PDF = 8,   // DielectricBxDF::Sample_f: CHECK(!IsNaN(pdf)) of the rough transmission (bxdfs.cpp:158)
+       WF_FATAL_LEAN_VARIANT = 16 }; // internal: a lean kernel variant (WF_DEV_LEAN) met a texture graph it was built without
 WF_HD const char *FatalMessage(int code) {
-    return (code & WF_FATAL_CURVE_SAMPLE) ? "Curve::Sample not implemented." : (code & WF_FATAL_CURVE_PDF) ? "Curve::PDF not implemented."
+    return (code & WF_FATAL_LEAN_VARIANT) ? "internal error: a lean kernel variant was launched on a scene it cannot render" : (code & WF_FATAL_CURVE_SAMPLE) ? "Curve::Sample not implemented." : (code & WF_FATAL_CURVE_PDF) ? "Curve::PDF not implemented."
            : (code & WF_FATAL_CHECK_HAIR) ? "Check failed: h >= -1 && h <= 1 (HairBxDF)" : (code & WF_FATAL_CHECK_NAN_PDF) ? "Check failed: !IsNaN(pdf) (DielectricBxDF::Sample_f)"
            : "fatal error raised by a kernel";
 }
@@ -198,6 +199,22 @@ WF_HD float SpectrumEval(const SceneView &sv, int id, float lambda) {
     }
 }
 WF_HD bool SpectrumIsConstant(const SceneView &sv, int id) { return sv.spectra[id].type == WF_SPEC_CONSTANT; }
+
+// ---------------------------------------------------------------------------------------------
+// LEAN DEVICE VARIANTS (round 5).  On gfx950 a kernel is allocated the registers of the hungriest function it can REACH — also of an
+// out-of-line callee behind a branch the scene never takes.  Measured (tools/exp/light_vgprs.hip and its siblings): the interaction of a
+// triangle hit incl. the instance transform needs 84 VGPRs, HitInteraction with the quadric / patch / curve callees reachable 235; the
+// inline texture roots (constant / image / bilerp) 88, with the texture-graph evaluator reachable 225; the whole light sample 93, with
+// the sampler of non-triangle emitters reachable 214.  The material kernels of rounds 1-4 therefore ran at 2 waves per SIMD on every
+// scene.  A translation unit compiled with -DWF_LEAN (wf_mat.hip's lean variants: the back end launches them only on scenes without
+// quadrics / patches / curves whose textures are all constants, image maps or bilerps — SceneLean()) compiles those callees OUT of the
+// DEVICE code; a texture graph met by such a kernel raises WF_FATAL_LEAN_VARIANT instead of being mis-evaluated.  Host code is the same
+// in every unit (no ODR difference on the host side; device code objects are per unit).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WF_LEAN)
+constexpr bool WF_DEV_LEAN = true;
+#else
+constexpr bool WF_DEV_LEAN = false;
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Texture evaluation over the flattened texture nodes (textures.h:1092-1155): constant, scale, mix, 2D checkerboard.
@@ -802,8 +819,11 @@ WF_NI float EvalFloatTextureGraphP(const SceneView *svp, int id, const TexCtx *t
 WF_HD float EvalFloatTexture(const SceneView &sv, int id, const TexCtx &tc) {
     const int type = sv.textures[id].type;
     if (IsSimpleFloatTexture(type)) return EvalFloatTextureSimple(sv, sv.textures[id], tc);
+    if constexpr (WF_DEV_LEAN) { RaiseFatal(sv, WF_FATAL_LEAN_VARIANT); return 0.f; }
+    else {
     TexCtx tmp = tc;
     return EvalFloatTextureGraphP(sv.self, id, &tmp);
+    }
 }
 WF_HD S4 EvalSpectrumTextureSimple(const SceneView &sv, const wf_texture &t, const Wavelengths &lambda, const TexCtx &tc) {
     if (t.type == WF_TEX_SPECTRUM_CONSTANT) return SpectrumSample(sv, t.spectrum, lambda);
@@ -892,11 +912,14 @@ WF_NI void EvalSpectrumTextureGraphP(const SceneView *svp, int id, const Wavelen
 WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lambda, const TexCtx &tc) {
     const int type = sv.textures[id].type;
     if (IsSimpleSpectrumTexture(type)) return EvalSpectrumTextureSimple(sv, sv.textures[id], lambda, tc);
+    if constexpr (WF_DEV_LEAN) { RaiseFatal(sv, WF_FATAL_LEAN_VARIANT); return S4c(0.f); }
+    else {
     TexCtx tmp = tc;
     Wavelengths l = lambda;
     S4 r;
     EvalSpectrumTextureGraphP(sv.self, id, &l, &tmp, &r);
     return r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

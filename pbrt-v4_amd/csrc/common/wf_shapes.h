@@ -701,12 +701,19 @@ WF_NI bool QuadricAlphaIntersectP(const SceneView *svp, int prim, float ox, floa
                                   float *tHit, float *px, float *py, float *pz);
 // the primitive `prim` (>= nTriangles) against the ray: the shape test, then the alpha test of its GeometricPrimitive when it has one
 // (RARE = false: a traversal kernel for scenes without curves and without alpha on quadrics — the two out-of-line callees stay out of its budget)
+// ... and for a curve (round 5): the same recursion; the accepted hit's (u, v), the SUM of the parametric distances, and — for the
+// interaction, which a curve builds in a frame aligned with the ray it was intersected with — the origin of the respawned ray that
+// found it and the distance along that ray
+WF_NI bool CurveAlphaIntersectP(const SceneView *svp, int prim, float ox, float oy, float oz, float dx, float dy, float dz, float tMax,
+                                float *tTotal, float *u, float *v, float *lastOrigin, float *tLocal);
 template <bool RARE = true>
 WF_HD bool QuadricIntersect(const SceneView &sv, int prim, V3 o, V3 d, float tMax, QuadricHit *qh) {
     constexpr bool CURVES = RARE;
     const wf_quadric &s = sv.quadrics[prim - sv.nTriangles];
     if (RARE && sv.haveQuadricAlpha && sv.meshes[s.mesh].alpha_tex >= 0) {
         float t, x, y, z;
+        // (a curve: (x, y, z) = (u, v, distance), the record of a curve hit — CurveHitInteractionP replays the recursion; the dispatch is
+        //  inside the callee, so that this site stays ONE out-of-line call)
         if (!QuadricAlphaIntersectP(sv.self, prim, o.x, o.y, o.z, d.x, d.y, d.z, tMax, &t, &x, &y, &z)) return false;
         qh->tHit = t; qh->pObj = V3{x, y, z}; qh->phi = 0;
         return true;
@@ -1582,10 +1589,13 @@ WF_NI void InstanceWoP(const wf_instance *in, float x, float y, float z, float *
     V3 w = Normalize(XfVector3(in->render_from_instance.m, Normalize(XfVector3(in->render_from_instance.mInv, V3{x, y, z}))));
     *ox = w.x; *oy = w.y; *oz = w.z;
 }
+// GENERAL = false (the default in a lean unit, WF_DEV_LEAN): the scene has triangles only — the quadric / patch / curve callees are not
+// reachable from the caller (see wf_scene.h "LEAN DEVICE VARIANTS")
+template <bool GENERAL = !WF_DEV_LEAN>
 WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
     if (inst >= 0) {
         V3 w;
-        if (prim >= sv.nTriangles) {
+        if (GENERAL && prim >= sv.nTriangles) {
             // a quadric inside an instance: built in object space from the instance-space ray (normalised there and after the transform
             // back to instance space), then taken to render space by the instance transform (normalised again)
             const wf_instance *in = sv.instances + inst;
@@ -1596,7 +1606,7 @@ WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
         InstanceWoP(sv.instances + inst, minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
         return w;
     }
-    if (prim < sv.nTriangles) return Normalize(minusD);
+    if (!GENERAL || prim < sv.nTriangles) return Normalize(minusD);
     V3 w;
     SphereWoP(sv.quadrics + (prim - sv.nTriangles), minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
     return w;
@@ -1604,14 +1614,38 @@ WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
 // the SurfaceInteraction of a hit record (prim, three floats): barycentrics for a triangle, pObj for a sphere
 // inst >= 0: the primitive was reached through that object instance — the interaction is built in the definition's
 // space and transformed (TransformedPrimitive::Intersect)
+// the interaction of a curve hit (u, v, distance) found by the ray (ro, rd) in the space the curve lives in — with an alpha texture, through
+// the replay of GeometricPrimitive::Intersect's alpha recursion (CurveAlphaIntersectP)
+WF_NI void CurveHitInteractionP(const SceneView *svp, int prim, float b0, float b1, float b2, float rox, float roy, float roz, float rdx, float rdy, float rdz, SurfIntr *out) {
+    const SceneView &sv = *svp;
+    const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
+    if (sv.haveQuadricAlpha && sv.meshes[s->mesh].alpha_tex >= 0) {
+        // GeometricPrimitive::Intersect's alpha recursion (cpu/primitive.cpp:56-72) found this hit with a ray respawned behind the
+        // rejected ones: the same deterministic recursion again (tMax = infinity: every hit up to the accepted one lies inside the
+        // bound the walk had) gives that ray's origin and the distance along it
+        float t, u, v, lo[3], tl;
+        if (CurveAlphaIntersectP(svp, prim, rox, roy, roz, rdx, rdy, rdz, WF_INFINITY, &t, &u, &v, lo, &tl)) {
+            CurveInteractionP(s, sv.meshes[s->mesh].flags, u, v, tl, lo[0], lo[1], lo[2], rdx, rdy, rdz, out);
+            return;
+        }
+    }
+    CurveInteractionP(s, sv.meshes[s->mesh].flags, b0, b1, b2, rox, roy, roz, rdx, rdy, rdz, out);
+}
 WF_HD bool IsCurvePrim(const SceneView &sv, int prim) { return sv.haveCurves && prim >= sv.nTriangles && sv.quadrics[prim - sv.nTriangles].type == WF_QUADRIC_CURVE; }
 // ro, rd: the render-space ray that found the hit — only a curve's interaction depends on it (its frame is ray-aligned)
+// CURVE_ALPHA: the caller may meet a curve with an alpha texture, whose interaction needs the replay of the alpha recursion
+// (CurveHitInteractionP: a deep out-of-line chain — curve intersector, texture evaluator).  Only the material stage's general shade kernels
+// ask for it: the scene builder admits alpha textures on curves with ordinary materials only (no interface / mix / subsurface material,
+// no emission), so no other consumer of a hit can meet one — and none of them pays for the chain's registers.
+template <bool GENERAL = !WF_DEV_LEAN, bool CURVE_ALPHA = false>
 WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si, V3 ro, V3 rd) {
+    if constexpr (!GENERAL) TriangleInteraction(sv, prim, b0, b1, b2, si);
+    else
     if (IsCurvePrim(sv, prim)) {
         if (inst >= 0) { float tm = WF_INFINITY; InstanceRay(sv.instances[inst], ro, rd, &tm, &ro, &rd); }
-        const wf_quadric *s = sv.quadrics + (prim - sv.nTriangles);
         SurfIntr tmp;
-        CurveInteractionP(s, sv.meshes[s->mesh].flags, b0, b1, b2, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, &tmp);
+        if constexpr (CURVE_ALPHA) CurveHitInteractionP(sv.self, prim, b0, b1, b2, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, &tmp);
+        else { const wf_quadric *s_ = sv.quadrics + (prim - sv.nTriangles); CurveInteractionP(s_, sv.meshes[s_->mesh].flags, b0, b1, b2, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, &tmp); }
         *si = tmp;
     } else if (prim >= sv.nTriangles) SphereInteraction(sv, prim, V3{b0, b1, b2}, si);
     else TriangleInteraction(sv, prim, b0, b1, b2, si);
@@ -1629,6 +1663,12 @@ WF_NI bool QuadricAlphaIntersectP(const SceneView *svp, int prim, float ox, floa
                                   float *tHit, float *px, float *py, float *pz) {
     const SceneView &sv = *svp;
     const wf_quadric &s = sv.quadrics[prim - sv.nTriangles];
+    if (s.type == WF_QUADRIC_CURVE) {
+        float lo[3], tl;
+        if (!CurveAlphaIntersectP(svp, prim, ox, oy, oz, dx, dy, dz, tMax, tHit, px, py, lo, &tl)) return false;
+        *pz = *tHit;
+        return true;
+    }
     const int alphaTex = sv.meshes[s.mesh].alpha_tex;
     V3 o{ox, oy, oz};
     const V3 d{dx, dy, dz};
@@ -1656,6 +1696,41 @@ WF_NI bool QuadricAlphaIntersectP(const SceneView *svp, int prim, float ox, floa
     float t = h.tHit;
     for (int i = n - 1; i >= 0; --i) t += ts[i];   // siNext->tHit += si->tHit, innermost first
     *tHit = t; *px = h.pObj.x; *py = h.pObj.y; *pz = h.pObj.z;
+    return true;
+}
+
+WF_NI bool CurveAlphaIntersectP(const SceneView *svp, int prim, float ox, float oy, float oz, float dx, float dy, float dz, float tMax,
+                                float *tTotal, float *uOut, float *vOut, float *lastOrigin, float *tLocal) {
+    const SceneView &sv = *svp;
+    const wf_quadric &s = sv.quadrics[prim - sv.nTriangles];
+    const int alphaTex = sv.meshes[s.mesh].alpha_tex;
+    V3 o{ox, oy, oz};
+    const V3 d{dx, dy, dz};
+    constexpr int MAXN = 16;
+    float ts[MAXN];
+    int n = 0;
+    QuadricHit h;
+    while (true) {
+        if (!CurveBasicIntersect(s, o, d, tMax, &h)) return false;
+        SurfIntr si;
+        CurveInteractionP(&s, sv.meshes[s.mesh].flags, h.pObj.x, h.pObj.y, h.pObj.z, o.x, o.y, o.z, d.x, d.y, d.z, &si);
+        TexCtx tc;
+        tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;
+        const float a = EvalFloatTexture(sv, alphaTex, tc);
+        bool accept = true;
+        if (a < 1) {
+            const float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(o, d));
+            if (u > a) accept = false;
+        }
+        if (accept || n == MAXN - 1) break;
+        ts[n++] = h.tHit;
+        o = OffsetRayOrigin(si.pi, si.n, d);   // si->intr.SpawnRay(r.d)
+        tMax = tMax - h.tHit;
+    }
+    float t = h.tHit;
+    for (int i = n - 1; i >= 0; --i) t += ts[i];   // siNext->tHit += si->tHit, innermost first
+    *tTotal = t; *uOut = h.pObj.x; *vOut = h.pObj.y; *tLocal = h.tHit;
+    lastOrigin[0] = o.x; lastOrigin[1] = o.y; lastOrigin[2] = o.z;
     return true;
 }
 

@@ -89,6 +89,7 @@ struct wf_ctx {
     int matStreams = 0;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
     hipStream_t matStream[WF_MAT_NTYPES] = {};
     hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
+    bool leanShade = false;      // the scene qualifies for the lean shade kernels (SceneLean: set at upload)
     bool matSplit = true;        // the material stage as two kernels per type (WF_MAT_SPLIT=0 with a MATFUSED build: the one-kernel stage)
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves and alpha on quadrics, 3 anything (see GeneralPrims)
@@ -843,7 +844,10 @@ constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes 
 #endif
 // (GEN = 3, the curve kernels: at the one-level kernels' 5-wave target they were the only kernels of the library that spilled an SGPR-spill
 //  carrier register — tools/check_spill_carriers.py; at the two-level kernels' 4 they do not)
-constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : gen >= 3 && triangleWaves > 4 ? 4 : triangleWaves; }
+// (round 5: with alpha textures on curves the GEN = 3 kernels reach the curve intersector through the alpha recursion as well — a chain of
+//  out-of-line callees the compiler gives 200+ VGPRs; it reported "final occupancy is 2" for every target above, and at a target of 4 the
+//  kernels spilled carriers again: their target is what they get)
+constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : gen >= 3 ? 2 : triangleWaves; }
 template <int GEN, bool INST = false, bool SPLIT = false>
 __global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView svArg, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
     const SceneView &sv = SvOf<false>(svArg);
@@ -1102,9 +1106,10 @@ __global__ void __launch_bounds__(BLOCK) k_medium_route(const SceneView sv, Work
     const int n = ws.counters[(CNT_MEDIUM_ROUTE) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KMediumRoute(sv, ws, cur, i);
 }
+template <bool RARE>
 __global__ void __launch_bounds__(BLOCK) k_medium_scatter(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE];
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumScattering(sv, ws, cur, i);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumScattering<RARE>(sv, ws, cur, i);
 }
 // reference-order variant (no production BVH, or WF_NO_FAST)
 __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkState ws, int *stackSpill) {
@@ -1250,10 +1255,11 @@ extern "C" {
 #if defined(WF_HAVE_FUSED_MAT)   // (make MATFUSED=1: the one-kernel material stage of rounds 1-4 beside the split one, for same-box A/B runs)
 WF_DECL_MAT(1) WF_DECL_MAT(2) WF_DECL_MAT(3) WF_DECL_MAT(4) WF_DECL_MAT(5) WF_DECL_MAT(6) WF_DECL_MAT(7) WF_DECL_MAT(8) WF_DECL_MAT(9) WF_DECL_MAT(10)
 #endif
-// the two halves of the material stage (wf_mat.hip): shade variant 0 | 1 | 2, next-event estimation variant 0 | 1
+// the two halves of the material stage (wf_mat.hip): shade variant 0 | 1 (lean) | 2 | 3, next-event estimation variant 0 | 1
 #define WF_DECL_SPLIT(n) void wf_launch_mat_shade_##n##_0(hipStream_t, int, const SceneView *, const WorkState *, int); \
                          void wf_launch_mat_shade_##n##_1(hipStream_t, int, const SceneView *, const WorkState *, int); \
                          void wf_launch_mat_shade_##n##_2(hipStream_t, int, const SceneView *, const WorkState *, int); \
+                         void wf_launch_mat_shade_##n##_3(hipStream_t, int, const SceneView *, const WorkState *, int); \
                          void wf_launch_mat_nee_##n##_0(hipStream_t, int, const SceneView *, const WorkState *); \
                          void wf_launch_mat_nee_##n##_1(hipStream_t, int, const SceneView *, const WorkState *);
 WF_DECL_SPLIT(1) WF_DECL_SPLIT(2) WF_DECL_SPLIT(3) WF_DECL_SPLIT(4) WF_DECL_SPLIT(5) WF_DECL_SPLIT(6) WF_DECL_SPLIT(7) WF_DECL_SPLIT(8) WF_DECL_SPLIT(9) WF_DECL_SPLIT(10)
@@ -1896,7 +1902,18 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.haveMix = 0;
     sv.haveSubsurface = 0;
     ctx->rareLights = false;
-    for (int i = 0; i < d->n_lights; ++i) if (d->lights[i].type == WF_LIGHT_PORTAL_INFINITE) ctx->rareLights = true;
+    // the lean shade kernels (wf_scene.h "LEAN DEVICE VARIANTS"): no quadrics / patches / curves, every texture a constant, an image map or a
+    // bilerp (WF_LEAN_SHADE=0 turns them off)
+    ctx->leanShade = d->n_quadrics == 0 && !(getenv("WF_LEAN_SHADE") && atoi(getenv("WF_LEAN_SHADE")) == 0);
+    for (int i = 0; i < d->n_textures && ctx->leanShade; ++i)
+        if (!wf::IsSimpleFloatTexture(d->textures[i].type) && !wf::IsSimpleSpectrumTexture(d->textures[i].type)) ctx->leanShade = false;
+    // ... and, since round 5, emitters that are not triangles (sphere / disk / cylinder / patch / curve lights: an out-of-line sampler of
+    // 214 VGPRs) and emitters with an alpha texture (the texture-graph evaluator): LightSampleLi<RARE>, AreaLightL<ALPHA> (wf_lights.h)
+    for (int i = 0; i < d->n_lights; ++i) {
+        const wf_light &l = d->lights[i];
+        if (l.type == WF_LIGHT_PORTAL_INFINITE) ctx->rareLights = true;
+        if (l.type == WF_LIGHT_DIFFUSE_AREA && (l.tri >= d->n_triangles || l.alpha_tex_plus1 != 0)) ctx->rareLights = true;
+    }
     sv.haveQuadricAlpha = 0;
     for (int i = 0; i < d->n_quadrics; ++i) if (d->meshes[d->quadrics[i].mesh].alpha_tex >= 0) sv.haveQuadricAlpha = 1;
     sv.haveCurves = 0;
@@ -2342,7 +2359,8 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
     LAUNCH("Sample medium interaction", k_medium_sample, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     LAUNCH("Sample medium interaction: route surface hits", k_medium_route, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     if (depth == ctx->maxDepth) return 0;
-    LAUNCH("Sample direct/indirect - Henyey-Greenstein", k_medium_scatter, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    if (ctx->rareLights) LAUNCH("Sample direct/indirect - Henyey-Greenstein", k_medium_scatter<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    else LAUNCH("Sample direct/indirect - Henyey-Greenstein", k_medium_scatter<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
 }
 // TraceShadowRays with media: IntersectShadowTr (wavefront/aggregate.cpp:70-88, intersect.h:165-274)
@@ -2454,17 +2472,20 @@ static int EvalMaterialOn(wf_ctx *ctx, int material_type, int depth, hipStream_t
     // the two halves (wf_kernels.h MatShade / MatNee; the items' NeeItems stay in ws.neeRec between them)
     {
         Prof prof_(ctx, timed ? names[material_type] : "(untimed)", stream);
+        // shade variant: 0 / 1 the LEAN kernels (triangle-only scenes whose textures are all constants, image maps or bilerps: SceneLean),
+        // without / with the texture footprint and bump block; 2 general; 3 general + visible surface / moving camera
+        const int v = vs ? 3 : (!ctx->leanShade ? 2 : (tex ? 1 : 0));
         switch (material_type) {
-        case 1: (vs ? wf_launch_mat_shade_1_2 : tex ? wf_launch_mat_shade_1_1 : wf_launch_mat_shade_1_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 2: (vs ? wf_launch_mat_shade_2_2 : tex ? wf_launch_mat_shade_2_1 : wf_launch_mat_shade_2_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 3: (vs ? wf_launch_mat_shade_3_2 : tex ? wf_launch_mat_shade_3_1 : wf_launch_mat_shade_3_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 4: (vs ? wf_launch_mat_shade_4_2 : tex ? wf_launch_mat_shade_4_1 : wf_launch_mat_shade_4_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 5: (vs ? wf_launch_mat_shade_5_2 : tex ? wf_launch_mat_shade_5_1 : wf_launch_mat_shade_5_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 6: (vs ? wf_launch_mat_shade_6_2 : tex ? wf_launch_mat_shade_6_1 : wf_launch_mat_shade_6_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 7: (vs ? wf_launch_mat_shade_7_2 : tex ? wf_launch_mat_shade_7_1 : wf_launch_mat_shade_7_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 8: (vs ? wf_launch_mat_shade_8_2 : tex ? wf_launch_mat_shade_8_1 : wf_launch_mat_shade_8_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 9: (vs ? wf_launch_mat_shade_9_2 : tex ? wf_launch_mat_shade_9_1 : wf_launch_mat_shade_9_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
-        case 10: (vs ? wf_launch_mat_shade_10_2 : tex ? wf_launch_mat_shade_10_1 : wf_launch_mat_shade_10_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 1: (v == 3 ? wf_launch_mat_shade_1_3 : v == 2 ? wf_launch_mat_shade_1_2 : v == 1 ? wf_launch_mat_shade_1_1 : wf_launch_mat_shade_1_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 2: (v == 3 ? wf_launch_mat_shade_2_3 : v == 2 ? wf_launch_mat_shade_2_2 : v == 1 ? wf_launch_mat_shade_2_1 : wf_launch_mat_shade_2_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 3: (v == 3 ? wf_launch_mat_shade_3_3 : v == 2 ? wf_launch_mat_shade_3_2 : v == 1 ? wf_launch_mat_shade_3_1 : wf_launch_mat_shade_3_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 4: (v == 3 ? wf_launch_mat_shade_4_3 : v == 2 ? wf_launch_mat_shade_4_2 : v == 1 ? wf_launch_mat_shade_4_1 : wf_launch_mat_shade_4_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 5: (v == 3 ? wf_launch_mat_shade_5_3 : v == 2 ? wf_launch_mat_shade_5_2 : v == 1 ? wf_launch_mat_shade_5_1 : wf_launch_mat_shade_5_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 6: (v == 3 ? wf_launch_mat_shade_6_3 : v == 2 ? wf_launch_mat_shade_6_2 : v == 1 ? wf_launch_mat_shade_6_1 : wf_launch_mat_shade_6_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 7: (v == 3 ? wf_launch_mat_shade_7_3 : v == 2 ? wf_launch_mat_shade_7_2 : v == 1 ? wf_launch_mat_shade_7_1 : wf_launch_mat_shade_7_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 8: (v == 3 ? wf_launch_mat_shade_8_3 : v == 2 ? wf_launch_mat_shade_8_2 : v == 1 ? wf_launch_mat_shade_8_1 : wf_launch_mat_shade_8_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 9: (v == 3 ? wf_launch_mat_shade_9_3 : v == 2 ? wf_launch_mat_shade_9_2 : v == 1 ? wf_launch_mat_shade_9_1 : wf_launch_mat_shade_9_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
+        case 10: (v == 3 ? wf_launch_mat_shade_10_3 : v == 2 ? wf_launch_mat_shade_10_2 : v == 1 ? wf_launch_mat_shade_10_1 : wf_launch_mat_shade_10_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
         }
     }
     {

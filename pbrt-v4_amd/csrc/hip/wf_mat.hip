@@ -9,13 +9,18 @@
 //                                      built only with `make MATFUSED=1`)
 #include <hip/hip_runtime.h>
 
-#include "../common/wf_kernels.h"
-
-using namespace wf;
-
 #if !defined(WF_MAT_INSTANCE) || !defined(WF_MAT_TEXCTX) || !defined(WF_MAT_PART)
 #error "compile with -DWF_MAT_INSTANCE=<wf_material_type> -DWF_MAT_PART=<0|1|2> -DWF_MAT_TEXCTX=<variant>"
 #endif
+// the LEAN shade variants (0, 1): device code without the quadric / patch / curve interaction callees and without the texture-graph
+// evaluator (wf_scene.h "LEAN DEVICE VARIANTS") — must be defined before the common headers are read
+#if WF_MAT_PART == 1 && WF_MAT_TEXCTX <= 1
+#define WF_LEAN 1
+#endif
+
+#include "../common/wf_kernels.h"
+
+using namespace wf;
 
 constexpr int MBLOCK = 256;
 
@@ -29,6 +34,9 @@ constexpr int MBLOCK = 256;
 #endif
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 2
+#endif
+#ifndef WF_SHADE_WAVES_LEAN
+#define WF_SHADE_WAVES_LEAN 4
 #endif
 // Round 5, the two halves on the spec scene (16 spp, same box; profiles/r05_material_split_ab_sm16.txt, r05_material_occupancy_ab_sm16.txt):
 //   next-event estimation, diffuse / conductor / coated diffuse, ms:  2 waves 12.75 / 2.89 / 9.89   3 waves 9.95 / 2.33 / 9.08
@@ -140,20 +148,20 @@ extern "C" void WF_CAT4(wf_launch_eval_material_, WF_MAT_INSTANCE, _, WF_MAT_TEX
     hipLaunchKernelGGL((k_eval_material<WF_MAT_INSTANCE, WF_MAT_TEXCTX>), dim3(grid), dim3(MBLOCK), 0, stream, sv->self, *ws, cur);
 }
 #elif WF_MAT_PART == 1
+// VARIANT (WF_MAT_TEXCTX): 0 lean, no texture needs the footprint and nothing is displaced; 1 lean, with the footprint / bump block;
+// 2 general (quadrics, patches, curves, texture graphs); 3 = 2 + the GBufferFilm's visible surface and the moving camera's differentials
 template <int MAT, int VARIANT>
-__global__ void __launch_bounds__(MBLOCK, WF_SHADE_WAVES) k_mat_shade(const SceneView *__restrict__ svp, WorkState ws, int cur) {
+__global__ void __launch_bounds__(MBLOCK, VARIANT <= 1 ? WF_SHADE_WAVES_LEAN : WF_SHADE_WAVES) k_mat_shade(const SceneView *__restrict__ svp, WorkState ws, int cur) {
     const SceneView &sv = *svp;
     const int n = ws.counters[(CNT_MAT0 + MAT) * CNT_STRIDE];
     const int rec0 = NeeIO<MAT>::Base(ws);
     for (int base = blockIdx.x * MBLOCK; base < n; base += gridDim.x * MBLOCK) {
         const int i = base + threadIdx.x;
         NeeItem<MAT> it;
-        MatShade<MAT, VARIANT>(sv, ws, cur, i, i < n, &it);
+        MatShade<MAT, (VARIANT == 0 ? 0 : (VARIANT == 3 ? 2 : 1))>(sv, ws, cur, i, i < n, &it);
         if (i < n) NeeIO<MAT>::Store(ws, rec0 + i, it);
     }
 }
-// WF_MAT_TEXCTX = 0: no texture needs the footprint, nothing is displaced; 1: the general case; 2: 1 + the GBufferFilm's visible surface
-// and the moving camera's differentials
 extern "C" void WF_CAT4(wf_launch_mat_shade_, WF_MAT_INSTANCE, _, WF_MAT_TEXCTX)(hipStream_t stream, int grid, const SceneView *sv, const WorkState *ws, int cur) {
     hipLaunchKernelGGL((k_mat_shade<WF_MAT_INSTANCE, WF_MAT_TEXCTX>), dim3(grid), dim3(MBLOCK), 0, stream, sv->self, *ws, cur);
 }

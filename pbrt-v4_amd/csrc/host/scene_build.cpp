@@ -2494,7 +2494,13 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         // getAlphaTexture (scene.cpp:1270-1286): a named float texture, or a constant when "float alpha" < 1
         if (!sh.params.GetTexture("alpha").empty()) mesh.alpha_tex = tb.GetFloatTextureOrNull(sh.params, "alpha");
         else if (float alpha = sh.params.GetOneFloat("alpha", 1.f); alpha < 1.f) mesh.alpha_tex = tb.FloatConst(alpha);
-        if (mesh.alpha_tex >= 0 && sh.name == "curve") Die(sh.loc, "alpha textures on curves are not supported by this build yet");
+        if (mesh.alpha_tex >= 0 && sh.name == "curve") {
+            // alpha on curves (round 5): the interaction of such a hit is rebuilt by replaying GeometricPrimitive::Intersect's alpha
+            // recursion, which only the material stage does (wf_shapes.h HitInteraction<GENERAL, CURVE_ALPHA>)
+            const int mt = mesh.material < 0 ? (int)WF_MAT_INTERFACE : T->materials[mesh.material].type;
+            if (mt == WF_MAT_INTERFACE || mt == WF_MAT_MIX || mt == WF_MAT_SUBSURFACE || sh.lightIndex >= 0)
+                Die(sh.loc, "an alpha texture on a curve with an interface / mix / subsurface material or an area light is not supported by this build");
+        }
         mesh.medium_inside = mediumId(sh.insideMedium, sh.loc);
         mesh.medium_outside = mediumId(sh.outsideMedium, sh.loc);
         if (!sh.insideMedium.empty() || !sh.outsideMedium.empty()) anyMediumInterface = true;

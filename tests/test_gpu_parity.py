@@ -79,7 +79,7 @@ def _random_rays(n, bounds_lo, bounds_hi, seed):
     return o, d.astype(np.float32), tmax
 
 
-@pytest.mark.parametrize("scene_name", ["cornell64", "blobs_small", "instances", "alpha_normalmap", "spheres", "bilinear", "instances_quadrics", "curves", "quadrics_alpha"])
+@pytest.mark.parametrize("scene_name", ["cornell64", "blobs_small", "instances", "alpha_normalmap", "spheres", "bilinear", "instances_quadrics", "curves", "quadrics_alpha", "curves_alpha"])
 def test_closest_hit_bit_exact_vs_oracle(wfpt, tmp_path, scene_name):
     """k_intersect_closest's traversal (LDS stack) vs the oracle's BVHAggregate::Intersect restatement: same
     triangle, same t and barycentrics (bit-exact), same number of nodes visited and triangles tested."""
@@ -128,7 +128,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "textures_deep", "textures_scale_fold", "tangents_s", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "bilinear_emission", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "camera_motion", "camera_motion_spherical", "quadrics_alpha", "goniometric_png",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "textures_deep", "textures_scale_fold", "tangents_s", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "bilinear_emission", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "camera_motion", "camera_motion_spherical", "quadrics_alpha", "curves_alpha", "goniometric_png",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton", "cornell64_sobol", "cornell64_sobol_owen"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
@@ -539,7 +539,7 @@ def test_samples_per_pass_invariance(wfpt):
 
 
 @pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "subsurface", "instances", "alpha_normalmap", "media_box", "media_instances",
-                                  "sanmiguel_like_small", "spheres", "quadrics", "quadrics_alpha", "bilinear", "bilinear_lights", "curves", "instances_quadrics"])
+                                  "sanmiguel_like_small", "spheres", "quadrics", "quadrics_alpha", "bilinear", "bilinear_lights", "curves", "curves_alpha", "instances_quadrics"])
 def test_reference_integrator_over_hip_aggregate(tmp_path, name):
     """The drop-in boundary, compiled and run: oracle/_ref/pbrt_hipagg is the REFERENCE's own WavefrontPathIntegrator (its
     CPU camera / sampler / material / light / film code, linked from the unmodified sources) with its WavefrontAggregate
