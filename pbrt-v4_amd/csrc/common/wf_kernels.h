@@ -867,6 +867,7 @@ WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, 
 }
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537
+template <bool RARE_LIGHTS = true>
 WF_HD void KHandleEscaped(const SceneView &sv, const WorkState &ws, int cur, int qi) {
     int i = ws.escapedQ[qi];
     const RayQueueV &q = ws.rq[cur];
@@ -881,14 +882,14 @@ WF_HD void KHandleEscaped(const SceneView &sv, const WorkState &ws, int cur, int
     for (int k = 0; k < sv.nInfiniteLights; ++k) {
         int lightId = sv.infiniteLights[k];
         const wf_light &light = sv.lights[lightId];
-        S4 Le = LightLe(sv, light, rayo, rayd, lambda);
+        S4 Le = LightLe<RARE_LIGHTS>(sv, light, rayo, rayd, lambda);
         if (Le) {
             if (depth == 0 || specularBounce) {
                 L = L + beta * Le / r_u.Average();
             } else {
                 LightCtx ctx = LoadCtx(q, i);
                 float lightChoicePDF = LightSamplerPMF(sv, ctx, lightId);
-                S4 r_l = r_l0 * lightChoicePDF * LightPDF_Li(sv, light, ctx, rayd, true);
+                S4 r_l = r_l0 * lightChoicePDF * LightPDF_Li<false, RARE_LIGHTS>(sv, light, ctx, rayd, true);   // (infinite lights only)
                 L = L + beta * Le / (r_u + r_l).Average();
             }
         }

@@ -371,10 +371,14 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
     }
 }
 
+// AREA = false: the caller only ever asks for infinite lights (HandleEscapedRays); RARE = false: no portal infinite light, no emitter that
+// is not a triangle — the callees a kernel cannot reach do not set its register allocation (wf_scene.h "LEAN DEVICE VARIANTS")
+template <bool AREA = true, bool RARE = true>
 WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &ctx, V3 wi, bool allowIncompletePDF) {
     switch (l.type) {
     case WF_LIGHT_DIFFUSE_AREA:
-        return l.tri >= sv.nTriangles ? SpherePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi) : TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
+        if constexpr (!AREA) return 0.f;
+        else return (RARE && l.tri >= sv.nTriangles) ? SpherePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi) : TrianglePDF(sv, l.tri, ctx.pi, ctx.n, ctx.ns, wi);
     case WF_LIGHT_UNIFORM_INFINITE: return allowIncompletePDF ? 0.f : Inv4Pi;
     case WF_LIGHT_IMAGE_INFINITE: {
         // lights.cpp:1042-1052
@@ -384,15 +388,19 @@ WF_HD float LightPDF_Li(const SceneView &sv, const wf_light &l, const LightCtx &
         return PC2DPDF(sv.tableData, allowIncompletePDF ? im.compensated : im.distribution, uv) / (4 * Pi);
     }
     case WF_LIGHT_PORTAL_INFINITE: {
+        if constexpr (!RARE) return 0.f;
+        else {
         const V3 p = ctx.p();
         return PortalPDFLiP(sv.self, l.image, p.x, p.y, p.z, wi.x, wi.y, wi.z);
+        }
     }
     default: return 0.f;
     }
 }
 // Light::Le for infinite lights (lights.h:172-174 for the others)
+template <bool RARE = true>
 WF_HD S4 LightLe(const SceneView &sv, const wf_light &l, V3 rayo, V3 rayd, const Wavelengths &lambda) {
-    if (l.type == WF_LIGHT_PORTAL_INFINITE) {
+    if (RARE && l.type == WF_LIGHT_PORTAL_INFINITE) {
         S4 Le;
         const Wavelengths lam = lambda;
         PortalLeP(sv.self, l.image, l.scale, rayo.x, rayo.y, rayo.z, rayd.x, rayd.y, rayd.z, &lam, &Le);

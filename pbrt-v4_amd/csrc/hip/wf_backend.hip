@@ -89,6 +89,7 @@ struct wf_ctx {
     int matStreams = 0;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
     hipStream_t matStream[WF_MAT_NTYPES] = {};
     hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
+    bool portalLights = false;   // the scene has a portal infinite light (k_handle_escaped<RARE>)
     bool leanShade = false;      // the scene qualifies for the lean shade kernels (SceneLean: set at upload)
     bool matSplit = true;        // the material stage as two kernels per type (WF_MAT_SPLIT=0 with a MATFUSED build: the one-kernel stage)
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
@@ -1237,10 +1238,13 @@ __global__ void __launch_bounds__(BLOCK) k_tr_rest(const SceneView sv, WorkState
     }
 }
 
+// RARE = false: no portal infinite light (k_handle_escaped: 328 VGPRs + 72 AGPRs — one wave per SIMD — with the portal callees and the area
+// lights' PDFs reachable; round 5)
+template <bool RARE>
 __global__ void __launch_bounds__(BLOCK) k_handle_escaped(const SceneView svArg, WorkState ws, int cur) {
     const SceneView &sv = SvOf<false>(svArg);
     const int n = ws.counters[(CNT_ESCAPED) * CNT_STRIDE];
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEscaped(sv, ws, cur, i);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KHandleEscaped<RARE>(sv, ws, cur, i);
 }
 __global__ void __launch_bounds__(BLOCK) k_handle_emissive(const SceneView svArg, WorkState ws, int cur) {
     const SceneView &sv = SvOf<false>(svArg);
@@ -1901,7 +1905,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.matTypeMask = 0;
     sv.haveMix = 0;
     sv.haveSubsurface = 0;
-    ctx->rareLights = false;
+    ctx->rareLights = ctx->portalLights = false;
     // the lean shade kernels (wf_scene.h "LEAN DEVICE VARIANTS"): no quadrics / patches / curves, every texture a constant, an image map or a
     // bilerp (WF_LEAN_SHADE=0 turns them off)
     ctx->leanShade = d->n_quadrics == 0 && !(getenv("WF_LEAN_SHADE") && atoi(getenv("WF_LEAN_SHADE")) == 0);
@@ -1911,7 +1915,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     // 214 VGPRs) and emitters with an alpha texture (the texture-graph evaluator): LightSampleLi<RARE>, AreaLightL<ALPHA> (wf_lights.h)
     for (int i = 0; i < d->n_lights; ++i) {
         const wf_light &l = d->lights[i];
-        if (l.type == WF_LIGHT_PORTAL_INFINITE) ctx->rareLights = true;
+        if (l.type == WF_LIGHT_PORTAL_INFINITE) ctx->rareLights = ctx->portalLights = true;
         if (l.type == WF_LIGHT_DIFFUSE_AREA && (l.tri >= d->n_triangles || l.alpha_tex_plus1 != 0)) ctx->rareLights = true;
     }
     sv.haveQuadricAlpha = 0;
@@ -2395,7 +2399,8 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
 int wf_handle_escaped(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->svHost.nInfiniteLights == 0) return 0;  // escapedRayQueue == nullptr (integrator.cpp:496-497)
-    LAUNCH("Handle escaped rays", k_handle_escaped, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    if (ctx->portalLights) LAUNCH("Handle escaped rays", k_handle_escaped<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    else LAUNCH("Handle escaped rays", k_handle_escaped<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     return 0;
 }
 int wf_handle_emissive(wf_ctx *ctx, int depth) {

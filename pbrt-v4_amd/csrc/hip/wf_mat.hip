@@ -35,8 +35,14 @@ constexpr int MBLOCK = 256;
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 2
 #endif
+// the lean shade kernels (profiles/r05_lean_variants_ab_sm16.txt; spec scene, 16 spp, same box; general kernel at 2 waves -> lean at 3 / 4 / 5):
+//   diffuse 10.87 -> 9.26 / 9.03 / 13.96 ms   conductor 3.19 -> 3.04 / 3.31 / 4.73   coated diffuse 7.43 -> 6.55 / 8.14 / 10.48
 #ifndef WF_SHADE_WAVES_LEAN
+#if WF_MAT_INSTANCE == 1
 #define WF_SHADE_WAVES_LEAN 4
+#else
+#define WF_SHADE_WAVES_LEAN 3
+#endif
 #endif
 // Round 5, the two halves on the spec scene (16 spp, same box; profiles/r05_material_split_ab_sm16.txt, r05_material_occupancy_ab_sm16.txt):
 //   next-event estimation, diffuse / conductor / coated diffuse, ms:  2 waves 12.75 / 2.89 / 9.89   3 waves 9.95 / 2.33 / 9.08
