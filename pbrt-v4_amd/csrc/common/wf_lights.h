@@ -88,7 +88,7 @@ WF_HD S4 AreaLightL(const SceneView &sv, const wf_light &l, V3 p, N3 n, V2 uv, V
     if constexpr (ALPHA)
     if (AreaLightAlphaMasked(sv, l, p, uv)) return S4c(0.f);
     if (l.image >= 0) {
-        const wf_tex_image im = sv.texImages[l.image];
+        const wf_tex_image &im = sv.texImages[l.image];
         V2 st{uv.x, 1 - uv.y};
         float r = ImageBilerpChannel(sv.tableData, im, 0, st, 0), g = ImageBilerpChannel(sv.tableData, im, 0, st, 1);
         float b = ImageBilerpChannel(sv.tableData, im, 0, st, 2);

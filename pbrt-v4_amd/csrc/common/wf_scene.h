@@ -215,6 +215,14 @@ constexpr bool WF_DEV_LEAN = true;
 #else
 constexpr bool WF_DEV_LEAN = false;
 #endif
+// the image record of a lookup, read IN PLACE (round 5): a local copy (`const wf_tex_image im = *imp;`, rounds 1-4) lives in scratch — its
+// level arrays are indexed dynamically — : 128 B written and 100-280 scratch loads per lookup in the MIP filter callees.
+// -DWF_TEX_IMAGE_COPY=1 restores the copy (A/B builds).
+#if defined(WF_TEX_IMAGE_COPY) && WF_TEX_IMAGE_COPY
+#define WF_TEX_IMAGE_LOCAL(im, imp) const wf_tex_image im = *(imp)
+#else
+#define WF_TEX_IMAGE_LOCAL(im, imp) const wf_tex_image &im = *(imp)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Texture evaluation over the flattened texture nodes (textures.h:1092-1155): constant, scale, mix, 2D checkerboard.
@@ -416,7 +424,7 @@ WF_HD float MIPBilerpFloat(const float *table, const wf_tex_image &im, int level
 }
 // the texel triple NormalMap() reads (materials.h:86-95): Image::BilerpChannel of channels 0..2 at (u, 1-v), repeat wrap
 WF_NI void NormalMapTexelP(const float *table, const wf_tex_image *imp, float u, float v, float *x, float *y, float *z) {
-    const wf_tex_image im = *imp;
+    WF_TEX_IMAGE_LOCAL(im, imp);
     const V2 uv{u, 1 - v};
     *x = 2 * ImageBilerpChannel(table, im, 0, uv, 0) - 1;
     *y = 2 * ImageBilerpChannel(table, im, 0, uv, 1) - 1;
@@ -496,17 +504,17 @@ WF_HD RGB3 MIPFilterEWA(const float *table, const wf_tex_image &im, V2 st, V2 ds
 // EWA lookups out of line on their own: the point / bilinear / trilinear functions below are called from the traversal kernels' alpha
 // test, and a callee's register use is paid at every call (callee-saved registers) whether the branch is taken or not
 WF_NI void MIPFilterEWARGBP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy, float *r, float *g, float *b) {
-    const wf_tex_image im = *imp;
+    WF_TEX_IMAGE_LOCAL(im, imp);
     RGB3 o = MIPFilterEWA<false>(table, im, V2{s_, t_}, V2{dsdx, dtdx}, V2{dsdy, dtdy});
     *r = o.r; *g = o.g; *b = o.b;
 }
 WF_NI float MIPFilterEWAFloatP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy) {
-    const wf_tex_image im = *imp;
+    WF_TEX_IMAGE_LOCAL(im, imp);
     return MIPFilterEWA<true>(table, im, V2{s_, t_}, V2{dsdx, dtdx}, V2{dsdy, dtdy}).r;
 }
 WF_NI void MIPFilterRGBP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy, float *r, float *g, float *b) {
     if (imp->filter == WF_MIP_EWA) { MIPFilterEWARGBP(table, imp, s_, t_, dsdx, dtdx, dsdy, dtdy, r, g, b); return; }
-    const wf_tex_image im = *imp;
+    WF_TEX_IMAGE_LOCAL(im, imp);
     const V2 st{s_, t_};
     RGB3 o = [&]() -> RGB3 {
     float level;
@@ -529,7 +537,7 @@ WF_HD RGB3 MIPFilterRGB(const SceneView &sv, int image, V2 st, float dsdx, float
     return o;
 }
 WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s_, float t_, float dsdx, float dtdx, float dsdy, float dtdy) {
-    const wf_tex_image im = *imp;
+    WF_TEX_IMAGE_LOCAL(im, imp);
     const V2 st{s_, t_};
     float level;
     int iLevel;
@@ -548,7 +556,7 @@ WF_NI float MIPFilterFloatP(const float *table, const wf_tex_image *imp, float s
 // nLevels - 1 + log2(1e-8) < 0 for any pyramid, so point filtering reads a level-0 texel and bilinear / trilinear both return
 // Bilerp(0, st): the same arithmetic as MIPFilterFloatP on these inputs, in a callee a tenth of its size.
 WF_NI float MIPFilterFloatZeroP(const float *table, const wf_tex_image *imp, float s_, float t_) {
-    const wf_tex_image im = *imp;
+    WF_TEX_IMAGE_LOCAL(im, imp);
     if (im.filter == WF_MIP_POINT) return ImageTexel(table, im, 0, (int)roundf(s_ * im.res[0] - 0.5f), (int)roundf(t_ * im.res[1] - 0.5f), 0);
     return MIPBilerpFloat(table, im, 0, V2{s_, t_});
 }

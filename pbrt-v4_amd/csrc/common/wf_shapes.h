@@ -1563,7 +1563,7 @@ WF_HD P3i XfP3i(const float m[4][4], const P3i &in) {
 }
 // Transform::operator()(SurfaceInteraction) (util/transform.cpp:229-261): what TransformedPrimitive::Intersect applies to
 // the interaction found in the instance's space.  Out of line: pointer arguments only (see WF_NI).
-WF_NI void InstanceInteractionP(const wf_instance *in, SurfIntr *si) {
+WF_HD void InstanceInteraction(const wf_instance *in, SurfIntr *si) {
     const float(*m)[4] = in->render_from_instance.m;
     const float(*mi)[4] = in->render_from_instance.mInv;
     SurfIntr r;
@@ -1583,6 +1583,7 @@ WF_NI void InstanceInteractionP(const wf_instance *in, SurfIntr *si) {
     r.mesh = si->mesh;
     *si = r;
 }
+WF_NI void InstanceInteractionP(const wf_instance *in, SurfIntr *si) { InstanceInteraction(in, si); }
 WF_NI void InstanceWoP(const wf_instance *in, float x, float y, float z, float *ox, float *oy, float *oz) {
     // the instance-space interaction's wo = Normalize(-ApplyInverse(ray.d)) (interaction.h:40-43), transformed back and
     // normalised again (util/transform.cpp:235)
@@ -1637,6 +1638,9 @@ WF_HD bool IsCurvePrim(const SceneView &sv, int prim) { return sv.haveCurves && 
 // (CurveHitInteractionP: a deep out-of-line chain — curve intersector, texture evaluator).  Only the material stage's general shade kernels
 // ask for it: the scene builder admits alpha textures on curves with ordinary materials only (no interface / mix / subsurface material,
 // no emission), so no other consumer of a hit can meet one — and none of them pays for the chain's registers.
+#ifndef WF_LEAN_INLINE_INSTANCE
+#define WF_LEAN_INLINE_INSTANCE 1
+#endif
 template <bool GENERAL = !WF_DEV_LEAN, bool CURVE_ALPHA = false>
 WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si, V3 ro, V3 rd) {
     if constexpr (!GENERAL) TriangleInteraction(sv, prim, b0, b1, b2, si);
@@ -1650,9 +1654,14 @@ WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, flo
     } else if (prim >= sv.nTriangles) SphereInteraction(sv, prim, V3{b0, b1, b2}, si);
     else TriangleInteraction(sv, prim, b0, b1, b2, si);
     if (inst >= 0) {
+        // (a lean kernel — triangles only, 4 waves — applies the transform in line: the out-of-line call passes the 45-float interaction
+        //  through scratch both ways, ~360 B of the 640 B per item k_mat_shade<diffuse> wrote; round 5)
+        if constexpr (!GENERAL && WF_LEAN_INLINE_INSTANCE) InstanceInteraction(sv.instances + inst, si);
+        else {
         SurfIntr tmp = *si;
         InstanceInteractionP(sv.instances + inst, &tmp);
         *si = tmp;
+        }
     }
 }
 
