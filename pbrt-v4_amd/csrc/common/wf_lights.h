@@ -416,18 +416,48 @@ WF_HD S4 LightLe(const SceneView &sv, const wf_light &l, V3 rayo, V3 rayd, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// CompactLightBounds::Importance, lightsamplers.h:144-201
-WF_HD float LightBoundsImportance(const SceneView &sv, const wf_light_bvh_node &nd, V3 p, N3 n) {
-    const float *ab = sv.allLightBounds;
+// CompactLightBounds::Importance, lightsamplers.h:144-201 — in two parts (round 5).  Everything the reference recomputes from the node's
+// quantised fields at every visit is a CONSTANT of the node: the de-quantised bounds (six divisions by 65535 and six lerps), the two cone
+// cosines (two divisions), sin(theta_o) (a square root), the octahedral axis (two divisions, a normalisation), the bounds' centre, half
+// diagonal and bounding-sphere radius (BoundSubtendedDirections, util/vecmath.h; three more square roots).  ExpandLightNode evaluates
+// them — the reference's expressions, in its order — and LightBoundsImportanceX does the point-dependent rest.  The HIP back end expands
+// every node once at upload (SceneView::lightBvhX, 80 bytes per node instead of 32) and the descents of next-event estimation run the second
+// part only: the two child evaluations of a level cost about half the instructions (IEEE division is ten instructions on gfx950).
+// The CPU checker expands on the fly: the same two functions, the same bits.
+#ifndef WF_LIGHT_NODES_EXPANDED
+#define WF_LIGHT_NODES_EXPANDED 1   // 0: the device expands at every visit too (A/B builds)
+#endif
+struct alignas(16) LightNodeX {
+    V3 pMin; float phi;
+    V3 pMax; float radius;      // Bounds3::BoundingSphere: Inside(centre, b) ? Distance(centre, pMax) : 0
+    V3 pc; float halfDiag;      // (pMin + pMax) / 2, Length(Diagonal()) / 2
+    V3 w; float cosTheta_o;
+    float sinTheta_o, cosTheta_e;
+    uint32_t twoSided, child_or_light;
+};
+WF_HD LightNodeX ExpandLightNode(const float *ab, const wf_light_bvh_node &nd) {
+    LightNodeX x;
+    x.pMin = V3{Lerp(nd.qb[0][0] / 65535.f, ab[0], ab[3]), Lerp(nd.qb[0][1] / 65535.f, ab[1], ab[4]), Lerp(nd.qb[0][2] / 65535.f, ab[2], ab[5])};
+    x.pMax = V3{Lerp(nd.qb[1][0] / 65535.f, ab[0], ab[3]), Lerp(nd.qb[1][1] / 65535.f, ab[1], ab[4]), Lerp(nd.qb[1][2] / 65535.f, ab[2], ab[5])};
+    const uint32_t qo = nd.cos_bits & 0x7fffu, qe = (nd.cos_bits >> 15) & 0x7fffu;
+    x.twoSided = (nd.cos_bits >> 30) & 1u;
+    x.cosTheta_o = 2 * (qo / 32767.f) - 1;
+    x.cosTheta_e = 2 * (qe / 32767.f) - 1;
+    x.sinTheta_o = SafeSqrt(1 - Sqr(x.cosTheta_o));
     B3 bounds;
-    bounds.pMin = V3{Lerp(nd.qb[0][0] / 65535.f, ab[0], ab[3]), Lerp(nd.qb[0][1] / 65535.f, ab[1], ab[4]), Lerp(nd.qb[0][2] / 65535.f, ab[2], ab[5])};
-    bounds.pMax = V3{Lerp(nd.qb[1][0] / 65535.f, ab[0], ab[3]), Lerp(nd.qb[1][1] / 65535.f, ab[1], ab[4]), Lerp(nd.qb[1][2] / 65535.f, ab[2], ab[5])};
-    uint32_t qo = nd.cos_bits & 0x7fffu, qe = (nd.cos_bits >> 15) & 0x7fffu;
-    bool twoSided = (nd.cos_bits >> 30) & 1u;
-    float cosTheta_o = 2 * (qo / 32767.f) - 1, cosTheta_e = 2 * (qe / 32767.f) - 1;
-    V3 pc = (bounds.pMin + bounds.pMax) / 2;
+    bounds.pMin = x.pMin; bounds.pMax = x.pMax;
+    x.pc = (bounds.pMin + bounds.pMax) / 2;
+    x.halfDiag = Length(bounds.Diagonal()) / 2;
+    x.radius = Inside(x.pc, bounds) ? Distance(x.pc, bounds.pMax) : 0;
+    x.w = OctahedralToVector(nd.w_oct[0], nd.w_oct[1]);
+    x.phi = nd.phi;
+    x.child_or_light = nd.child_or_light;
+    return x;
+}
+WF_HD float LightBoundsImportanceX(const LightNodeX &x, V3 p, N3 n) {
+    const V3 pc = x.pc;
     float d2 = DistanceSquared(p, pc);
-    d2 = fmax(d2, Length(bounds.Diagonal()) / 2);
+    d2 = fmax(d2, x.halfDiag);
     auto cosSubClamped = [](float sinTheta_a, float cosTheta_a, float sinTheta_b, float cosTheta_b) -> float {
         if (cosTheta_a > cosTheta_b) return 1;
         return cosTheta_a * cosTheta_b + sinTheta_a * sinTheta_b;
@@ -437,18 +467,22 @@ WF_HD float LightBoundsImportance(const SceneView &sv, const wf_light_bvh_node &
         return sinTheta_a * cosTheta_b - cosTheta_a * sinTheta_b;
     };
     V3 wi = Normalize(p - pc);
-    V3 w = OctahedralToVector(nd.w_oct[0], nd.w_oct[1]);
-    float cosTheta_w = Dot(w, wi);
-    if (twoSided) cosTheta_w = abs(cosTheta_w);
+    float cosTheta_w = Dot(x.w, wi);
+    if (x.twoSided) cosTheta_w = abs(cosTheta_w);
     float sinTheta_w = SafeSqrt(1 - Sqr(cosTheta_w));
-    float cosTheta_b = BoundSubtendedDirections(bounds, p).cosTheta;
+    // BoundSubtendedDirections(bounds, p).cosTheta (wf_math.h) with the node's centre and radius
+    float cosTheta_b;
+    if (DistanceSquared(p, pc) < Sqr(x.radius)) cosTheta_b = -1.f;
+    else {
+        float sin2ThetaMax = Sqr(x.radius) / DistanceSquared(pc, p);
+        cosTheta_b = SafeSqrt(1 - sin2ThetaMax);
+    }
     float sinTheta_b = SafeSqrt(1 - Sqr(cosTheta_b));
-    float sinTheta_o = SafeSqrt(1 - Sqr(cosTheta_o));
-    float cosTheta_x = cosSubClamped(sinTheta_w, cosTheta_w, sinTheta_o, cosTheta_o);
-    float sinTheta_x = sinSubClamped(sinTheta_w, cosTheta_w, sinTheta_o, cosTheta_o);
+    float cosTheta_x = cosSubClamped(sinTheta_w, cosTheta_w, x.sinTheta_o, x.cosTheta_o);
+    float sinTheta_x = sinSubClamped(sinTheta_w, cosTheta_w, x.sinTheta_o, x.cosTheta_o);
     float cosThetap = cosSubClamped(sinTheta_x, cosTheta_x, sinTheta_b, cosTheta_b);
-    if (cosThetap <= cosTheta_e) return 0;
-    float importance = nd.phi * cosThetap / d2;
+    if (cosThetap <= x.cosTheta_e) return 0;
+    float importance = x.phi * cosThetap / d2;
     if (!IsZero(n)) {
         float cosTheta_i = AbsDot(wi, n);
         float sinTheta_i = SafeSqrt(1 - Sqr(cosTheta_i));
@@ -457,6 +491,15 @@ WF_HD float LightBoundsImportance(const SceneView &sv, const wf_light_bvh_node &
     }
     importance = fmax(importance, 0.f);
     return importance;
+}
+// the importance of node `index` for the point (p, n): from the expanded table on the device, expanded on the fly on the host
+WF_HD float LightNodeImportance(const SceneView &sv, int index, V3 p, N3 n) {
+#if defined(__HIP_DEVICE_COMPILE__) && WF_LIGHT_NODES_EXPANDED
+    const LightNodeX x = sv.lightBvhX[index];
+    return LightBoundsImportanceX(x, p, n);
+#else
+    return LightBoundsImportanceX(ExpandLightNode(sv.allLightBounds, sv.lightBvh[index]), p, n);
+#endif
 }
 
 // LightSampler::Sample(ctx, u): returns light id or -1, and its pmf
@@ -506,15 +549,15 @@ WF_HD int LightSamplerSample(const SceneView &sv, const LightCtx &ctx, float u, 
         bool isLeaf = node.child_or_light >> 31;
         int childOrLight = (int)(node.child_or_light & 0x7fffffffu);
         if (!isLeaf) {
-            float ci0 = LightBoundsImportance(sv, sv.lightBvh[nodeIndex + 1], p, n);
-            float ci1 = LightBoundsImportance(sv, sv.lightBvh[childOrLight], p, n);
+            float ci0 = LightNodeImportance(sv, nodeIndex + 1, p, n);
+            float ci1 = LightNodeImportance(sv, childOrLight, p, n);
             if (ci0 == 0 && ci1 == 0) return -1;
             float nodePMF;
             int child = SampleDiscrete2(ci0, ci1, u, &nodePMF, &u);
             pmf *= nodePMF;
             nodeIndex = (child == 0) ? (nodeIndex + 1) : childOrLight;
         } else {
-            if (nodeIndex > 0 || LightBoundsImportance(sv, node, p, n) > 0) {
+            if (nodeIndex > 0 || LightNodeImportance(sv, nodeIndex, p, n) > 0) {
                 *pmfOut = pmf;
                 return childOrLight;
             }
@@ -542,7 +585,7 @@ WF_HD float LightSamplerPMF(const SceneView &sv, const LightCtx &ctx, int lightI
         const wf_light_bvh_node node = sv.lightBvh[nodeIndex];
         if (node.child_or_light >> 31) return pmf;
         int child1 = (int)(node.child_or_light & 0x7fffffffu);
-        float ci[2] = {LightBoundsImportance(sv, sv.lightBvh[nodeIndex + 1], p, n), LightBoundsImportance(sv, sv.lightBvh[child1], p, n)};
+        float ci[2] = {LightNodeImportance(sv, nodeIndex + 1, p, n), LightNodeImportance(sv, child1, p, n)};
         pmf *= ci[bitTrail & 1] / (ci[0] + ci[1]);
         nodeIndex = (bitTrail & 1) ? child1 : (nodeIndex + 1);
         bitTrail >>= 1;

@@ -29,6 +29,7 @@ struct SceneView {
     const wf_light *lights;
     const int32_t *infiniteLights;
     const wf_light_bvh_node *lightBvh;
+    const struct LightNodeX *lightBvhX;   // device only: every node's constants expanded once at upload (wf_lights.h ExpandLightNode)
     const wf_transform *lightXforms;
     int nLights, nInfiniteLights, nLightBvhNodes, lightSampler;
     const float *powerAlias;  // PowerLightSampler's AliasTable bins: nLights x {q, p, alias (int bits)}

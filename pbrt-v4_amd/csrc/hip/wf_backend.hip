@@ -1827,6 +1827,13 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.lights, d->lights, (size_t)d->n_lights))) return e;
     if ((e = devUpload(ctx, &sv.infiniteLights, d->infinite_lights, (size_t)d->n_infinite_lights))) return e;
     if ((e = devUpload(ctx, &sv.lightBvh, d->light_bvh_nodes, (size_t)d->n_light_bvh_nodes))) return e;
+    {
+        // the light BVH's nodes with their per-node constants expanded (wf_lights.h ExpandLightNode: the reference's own expressions, evaluated
+        // once here instead of at every visit of every descent)
+        std::vector<wf::LightNodeX> xs((size_t)d->n_light_bvh_nodes);
+        for (int i = 0; i < d->n_light_bvh_nodes; ++i) xs[i] = wf::ExpandLightNode(d->all_light_bounds, d->light_bvh_nodes[i]);
+        if ((e = devUpload(ctx, &sv.lightBvhX, xs.data(), xs.size()))) return e;
+    }
     if ((e = devUpload(ctx, &sv.lightXforms, d->light_transforms, (size_t)d->n_light_transforms))) return e;
     if ((e = devUpload(ctx, &sv.powerAlias, d->power_alias, d->light_sampler == WF_LS_POWER ? (size_t)3 * d->n_lights : (size_t)0))) return e;
     if ((e = devUpload(ctx, &sv.imageLights, d->image_lights, (size_t)d->n_image_lights))) return e;
