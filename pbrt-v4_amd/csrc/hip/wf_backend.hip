@@ -1525,6 +1525,85 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         else { subFirst[i] = subFirst[i + 1]; subCount[i] = subCount[i + 1] + subCount[L[i].offset]; }
     }
     auto leafLike = [&](int i) { return L[i].nprims > 0 || subCount[i] <= collapse; };
+    // TIGHT INSTANCE BOXES (round 5).  The reference bounds an instance by the box of the eight transformed corners of its definition's
+    // box (TransformedPrimitive::Bounds) — for a rotated definition up to three times the surface area of the box of the transformed
+    // GEOMETRY — and the spec scene's rays entered eight instances each, three of four visits without a single primitive test.  The
+    // production walk only has to visit a superset of what can be hit, so its top-level tree carries, for an instance of an all-triangle
+    // definition, the box of the definition's transformed vertices (widened by 2^-18 of the magnitudes involved: the transform's rounding
+    // and the instance-space ray's), clipped to the reference's box, and interior boxes re-united bottom-up.  Topology, leaves and the
+    // reference-layout nodes (counting kernels, near-tie re-walk, CPU checker) are untouched: same hits, fewer entries.  WF_TIGHT_INSTANCES=0: off.
+    std::vector<wf_bvh_node> tightTop;
+    if (d->n_instances > 0 && d->n_top_bvh_nodes > 0 && !(getenv("WF_TIGHT_INSTANCES") && atoi(getenv("WF_TIGHT_INSTANCES")) == 0)) {
+        const int nTop = d->n_top_bvh_nodes;
+        std::vector<std::vector<int32_t>> defVerts((size_t)d->n_instance_defs);
+        std::vector<char> defGeneral((size_t)d->n_instance_defs, 0);
+        for (int k = 0; k < d->n_instance_defs; ++k) {
+            const wf_instance_def &def = d->instance_defs[k];
+            std::vector<int32_t> &v = defVerts[k];
+            for (int j = def.first_prim; j < def.first_prim + def.n_prims; ++j) {
+                const int t = d->bvh_prims[j];
+                if (t >= d->n_triangles) { defGeneral[k] = 1; break; }
+                const int32_t *ix = d->tri_indices + 3 * (size_t)t;
+                v.push_back(ix[0]); v.push_back(ix[1]); v.push_back(ix[2]);
+            }
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            if (v.empty()) defGeneral[k] = 1;
+        }
+        std::vector<std::array<float, 6>> ib((size_t)d->n_instances);
+        std::vector<char> ibOk((size_t)d->n_instances, 0);
+        for (int i = 0; i < d->n_instances; ++i) {
+            const wf_instance &in = d->instances[i];
+            if (defGeneral[in.def]) continue;
+            const float(*m)[4] = in.render_from_instance.m;
+            if (m[3][0] != 0 || m[3][1] != 0 || m[3][2] != 0 || m[3][3] != 1) continue;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, mag = 0;
+            for (int32_t vi : defVerts[in.def]) {
+                const float *pp = d->P + 3 * (size_t)vi;
+                for (int a = 0; a < 3; ++a) {
+                    const double c = (double)m[a][0] * pp[0] + (double)m[a][1] * pp[1] + (double)m[a][2] * pp[2] + (double)m[a][3];
+                    lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
+                    mag = std::max(mag, std::fabs((double)m[a][0] * pp[0]) + std::fabs((double)m[a][1] * pp[1]) + std::fabs((double)m[a][2] * pp[2]) + std::fabs((double)m[a][3]));
+                }
+            }
+            bool finite = true;
+            for (int a = 0; a < 3; ++a) {
+                const double pad = 0x1p-18 * (mag + (hi[a] - lo[a])) + 1e-30;
+                ib[i][a] = (float)(lo[a] - pad); ib[i][3 + a] = (float)(hi[a] + pad);
+                if (!((double)ib[i][a] <= lo[a] - 0.5 * pad)) ib[i][a] = NextFloatDown(ib[i][a]);
+                if (!((double)ib[i][3 + a] >= hi[a] + 0.5 * pad)) ib[i][3 + a] = NextFloatUp(ib[i][3 + a]);
+                finite = finite && std::isfinite(ib[i][a]) && std::isfinite(ib[i][3 + a]);
+            }
+            ibOk[i] = finite;
+        }
+        tightTop.assign(L, L + nTop);
+        for (int i = nTop - 1; i >= 0; --i) {
+            wf_bvh_node &t = tightTop[i];
+            float b[6];
+            bool have = false, keep = false;
+            if (L[i].nprims > 0) {
+                for (int j = L[i].offset; j < L[i].offset + L[i].nprims && !keep; ++j) {
+                    const int pr = d->bvh_prims[j];
+                    if (pr < nGeom || !ibOk[pr - nGeom]) { keep = true; break; }   // a triangle / quadric or an instance left alone: the reference's box stands
+                    const std::array<float, 6> &q = ib[pr - nGeom];
+                    if (!have) { for (int a = 0; a < 6; ++a) b[a] = q[a]; have = true; }
+                    else for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], q[a]); b[3 + a] = std::max(b[3 + a], q[3 + a]); }
+                }
+            } else {
+                const wf_bvh_node &c0 = tightTop[i + 1], &c1 = tightTop[L[i].offset];
+                for (int a = 0; a < 3; ++a) { b[a] = std::min(c0.bmin[a], c1.bmin[a]); b[3 + a] = std::max(c0.bmax[a], c1.bmax[a]); }
+                have = true;
+            }
+            if (keep || !have) continue;
+            for (int a = 0; a < 3; ++a) {   // clipped to the reference's box (the geometry lies in both)
+                t.bmin[a] = std::max(L[i].bmin[a], b[a]);
+                t.bmax[a] = std::min(L[i].bmax[a], b[3 + a]);
+                if (!(t.bmin[a] <= t.bmax[a])) { t.bmin[a] = L[i].bmin[a]; t.bmax[a] = L[i].bmax[a]; }
+            }
+        }
+    }
+    // the boxes the production tree is packed from: the tightened ones for the top-level tree, the reference's everywhere else
+    auto BoxOf = [&](int i) -> const wf_bvh_node & { return (!tightTop.empty() && i < (int)tightTop.size()) ? tightTop[i] : L[i]; };
     // one tree: linear nodes [root, ...) reachable from root; grid written to base / cell; returns the root's QNode index
     int lastTreeDepth = 0;   // levels of the four-wide tree buildTree made last (a single leaf-like root: 1)
     auto buildTree = [&](int root, float baseOut[3], float cellOut[3]) -> int {
@@ -1571,7 +1650,8 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
 #if WF_BVH4
         auto emptyBox = [&](uint32_t q[12], int slot) { for (int a = 0; a < 3; ++a) q[slot * 3 + a] = 0x0000ffffu; };
         auto area = [&](int i) {
-            double dx = (double)L[i].bmax[0] - L[i].bmin[0], dy = (double)L[i].bmax[1] - L[i].bmin[1], dz = (double)L[i].bmax[2] - L[i].bmin[2];
+            const wf_bvh_node &bx = BoxOf(i);
+            double dx = (double)bx.bmax[0] - bx.bmin[0], dy = (double)bx.bmax[1] - bx.bmin[1], dz = (double)bx.bmax[2] - bx.bmin[2];
             return dx * dy + dy * dz + dz * dx;
         };
         auto packBox4 = [&](const wf_bvh_node &b, uint32_t q[12], int slot) {
@@ -1579,7 +1659,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         };
         if (leafLike(root)) {
             QNode qn{};
-            packBox4(L[root], qn.q, 0);
+            packBox4(BoxOf(root), qn.q, 0);
             qn.child[0] = leafRef(root);
             for (int c = 1; c < 4; ++c) { emptyBox(qn.q, c); qn.child[c] = NODE_NONE; }
             nodes->push_back(qn);
@@ -1616,7 +1696,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             for (int c = 0; c < 4; ++c) {
                 int k = kidsOf[h][c];
                 if (k < 0) { emptyBox(qn.q, c); qn.child[c] = NODE_NONE; continue; }
-                packBox4(L[k], qn.q, c);
+                packBox4(BoxOf(k), qn.q, c);
                 qn.child[c] = !leafLike(k) ? bfsIndex[k] : leafRef(k);
             }
             (*nodes)[(size_t)qBase + h] = qn;
