@@ -370,7 +370,9 @@ typedef struct wf_quadric {
 typedef struct wf_instance {
     wf_transform render_from_instance;  /* TransformedPrimitive::renderFromPrimitive: m and mInv */
     int32_t def;                        /* index into instance_defs */
-    int32_t pad[3];
+    int32_t anim_plus1;                 /* AnimatedPrimitive (cpu/primitive.h:103): 1 + index into wf_scene_desc.animated, 0 = a static instance
+                                           (render_from_instance then holds the start transformation) */
+    int32_t pad[2];
 } wf_instance;
 typedef struct wf_instance_def {
     int32_t bvh_root;                   /* root of the definition's BVH in bvh_nodes */
@@ -542,6 +544,10 @@ typedef struct wf_scene_desc {
     /* trianglemesh "S": per-vertex shading tangents in render space, only of the meshes that have them (wf_mesh.first_s) */
     int64_t n_tangents;
     const float *S;              /* [n_tangents][3] */
+    /* AnimatedPrimitive (round 5): the AnimatedTransforms of animated shapes and object instances (wf_instance.anim_plus1); a shape created
+       under an animated CTM is an instance definition of its own (its shapes in object space) used once with the animated transformation */
+    int32_t n_animated, pad_animated;
+    const wf_animated_transform *animated;
 } wf_scene_desc;
 
 /* ------------------------------------------------------------------------------------------- */

@@ -88,6 +88,7 @@ SceneView MakeHostView(const wf_scene_desc &d, const uint32_t *sobol) {
     sv.matTypeMask = 0;
     sv.quadrics = d.quadrics; sv.nQuadrics = d.n_quadrics;
     sv.instances = d.instances; sv.instanceDefs = d.instance_defs; sv.nInstances = d.n_instances;
+    sv.animated = d.animated; sv.haveAnimated = d.n_animated > 0;
     sv.sobolMatrices = d.sobol_matrices; sv.vdcSobol = d.vdc_sobol; sv.vdcSobolInv = d.vdc_sobol_inv;
     sv.haltonPrimes = d.halton_primes; sv.haltonPermOffsets = d.halton_perm_offsets; sv.haltonPerms = d.halton_perms;
     sv.haveMix = 0;
@@ -525,6 +526,7 @@ static int Main(int argc, char **argv) {
     ws.escapedQ = Alloc<int32_t>(n); ws.hitLightQ = Alloc<int32_t>(n);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ws.matQ[m] = Alloc<int32_t>(T.materialTypePresent[m] ? n : 1);
     ws.sq.o = Alloc<F4>(n); ws.sq.d = Alloc<F4>(n); ws.sq.Ld = Alloc<F4>(n); ws.sq.r_u = Alloc<F4>(n); ws.sq.r_l = Alloc<F4>(n);
+    if (sv.haveAnimated) ws.pathTime = Alloc<float>(n);
     if (sv.haveMedia) {
         ws.hitT = Alloc<float>(n); ws.mediumSampleQ = Alloc<int32_t>(n); ws.mediumScatterQ = Alloc<int32_t>(n);
         ws.scatterP = Alloc<F4>(n); ws.sq.medium = Alloc<int32_t>(n);
@@ -721,7 +723,7 @@ static int Main(int argc, char **argv) {
                     F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
                     ArrayStack st;
                     ClosestHit ch;
-                    bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
+                    bool found = BVHIntersectClosest<true>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch, o.w);   // (o.w: the ray's time, for AnimatedPrimitive)
                     nv += ch.nodesVisited; nt += ch.trisTested;
                     if (getenv("WF_DEBUG_PIXEL") && depth == 0 && ws.rq[cur].meta[i].x == atoi(getenv("WF_DEBUG_PIXEL")) && found) {
                         fprintf(stderr, "dbg hit prim %d inst %d t %a b %a %a %a\n  o %a %a %a d %a %a %a\n", ch.prim, ch.inst, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2, o.x, o.y, o.z, d.x, d.y, d.z);
@@ -834,7 +836,8 @@ static int Main(int argc, char **argv) {
                         F4 o = ws.sq.o[i], d = ws.sq.d[i];
                         ArrayStack st;
                         int v = 0, t = 0;
-                        bool occluded = BVHIntersectAny(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t);
+                        const float time = ws.pathTime ? ws.pathTime[(int)FloatToBits(d.w)] : 0.f;   // the shadow ray's time = its path's (ShadowRayWorkItem.ray.time)
+                        bool occluded = BVHIntersectAny<true>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t, time);
                         shadowNodes += (unsigned long long)v; shadowTris += (unsigned long long)t;
                         KRecordShadowRay(ws, i, occluded);
                     });

@@ -131,6 +131,9 @@ struct WorkState {
     ShadowQueueV sq;
     // the state of the material stage's items between its two kernels (wf_mat.hip: NeeIO): planes of maxQueueSize x 16 bytes
     F4 *neeRec = nullptr;
+    // the time of every pixel sample's path (= its camera ray's: every ray of a path carries it), kept for the shadow rays of scenes with
+    // animated primitives (the shadow queue has the pixel index, not the time); null otherwise
+    float *pathTime = nullptr;
     // the transmittance wavefront (HIP back end, scenes with media): per shadow ray the state of TraceTransmittance between segments —
     // current origin / direction (+ medium id in trD.w), T_ray, r_u, r_l, the PCG32 state — and two index queues of the live rays
     F4 *trO, *trD, *trT, *trRu, *trRl;
@@ -332,6 +335,7 @@ WF_HD void KGenerateCameraRay(const SceneView &sv, const WorkState &ws, int pixe
         q.r_l[index] = F4{1, 1, 1, 1};
         q.meta[index] = I4{pixelIndex, 0, 0, sv.camera.medium};
         ws.cameraRayWeight[pixelIndex] = F4{cr.weight, cr.weight, cr.weight, cr.weight};
+        if (ws.pathTime) ws.pathTime[pixelIndex] = cr.time;
     } else ws.cameraRayWeight[pixelIndex] = F4{0, 0, 0, 0};
 }
 
@@ -1130,6 +1134,14 @@ struct NeeItem {
 template <int MAT, int VARIANT = 2>
 WF_HD void MatShade(const SceneView &sv, const WorkState &ws, int cur, int qi, bool valid, NeeItem<MAT> *out, bool shadowIdle = false) {
     constexpr bool TEXCTX = VARIANT != 0;
+    // animated instances (AnimatedPrimitive) and alpha-textured curves are met by the VARIANT 2 kernels only (the back end selects them for
+    // such scenes): the interpolation of the transformation and the replay of the alpha recursion are out-of-line callee chains the
+    // other variants must not be able to reach (on the host: no such cost)
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool ANIM = VARIANT == 2;
+#else
+    constexpr bool ANIM = true;
+#endif
     // `valid` = this thread has an item.  The queue push goes through BlockAlloc, which every thread of
     // the workgroup must reach: control flow below is flattened into the flag pushRay.
     using BxDF = typename MatBxDF<MAT>::T;
@@ -1159,7 +1171,7 @@ WF_HD void MatShade(const SceneView &sv, const WorkState &ws, int cur, int qi, b
         {
             V3 ro{0, 0, 0}, rd{0, 0, 0};   // only a curve's interaction needs the ray that found it
             if (sv.haveCurves) { F4 o4 = q.o[i], d4 = q.d[i]; ro = V3{o4.x, o4.y, o4.z}; rd = V3{d4.x, d4.y, d4.z}; }
-            HitInteraction<!WF_DEV_LEAN, !WF_DEV_LEAN>(sv, prim, inst, h.y, h.z, h.w, &si, ro, rd);   // (incl. alpha-textured curves)
+            HitInteraction<!WF_DEV_LEAN, ANIM, ANIM>(sv, prim, inst, h.y, h.z, h.w, &si, ro, rd, q.o[i].w);   // (incl. alpha-textured curves and animated instances)
         }
         const wf_mesh &mesh = sv.meshes[si.mesh];
         int matId = mesh.material;
@@ -1171,7 +1183,7 @@ WF_HD void MatShade(const SceneView &sv, const WorkState &ws, int cur, int qi, b
         // intr.wo: the Interaction constructor normalises it (interaction.h:40-43), also for unit-length ray.d;
         // items enqueued by the medium stage carry -ray.d as it is (media.cpp:240)
         V3 wo{-d4.x, -d4.y, -d4.z};
-        if (!(sv.haveMedia && meta.w >= 0)) wo = IntrWo(sv, prim, inst, wo);
+        if (!(sv.haveMedia && meta.w >= 0)) wo = IntrWo<!WF_DEV_LEAN, ANIM>(sv, prim, inst, wo, time);
         // differentials of position and (u, v) at the intersection (surfscatter.cpp:73-104)
         TexCtx tc;
         tc.p = si.pi.mid(); tc.n = si.n; tc.uv = si.uv;

@@ -73,6 +73,9 @@ struct SceneView {
     const wf_instance *instances;
     const wf_instance_def *instanceDefs;
     int nInstances;
+    // AnimatedPrimitive (round 5): the AnimatedTransforms of animated shapes / instances (wf_instance.anim_plus1); haveAnimated: the scene has one
+    const wf_animated_transform *animated;
+    int haveAnimated;
     int haveQuadricAlpha;   // some sphere / disk / cylinder / patch has an alpha texture (QuadricAlphaIntersectP)
     int haveCurves;         // some primitive is a Curve segment: its interaction is rebuilt from the ray (HitInteraction)
     int haveSubsurface;     // some material is a SubsurfaceMaterial: K12 runs, and every depth draws 3 more sample dimensions

@@ -492,6 +492,7 @@ WF_HD bool Inverse44(const M44 &a, M44 *out) {
     r[3][3] = s * InnerProductD(m[2][0], s3, m[2][2], s0, -m[2][1], s1);
     return true;
 }
+#include "wf_animated.h"   // AnimatedTransform::Interpolate (needs M44 / Inverse44 above)
 // LookAt (util/transform.cpp:81-113): returns cameraFromWorld (the numeric inverse) and worldFromCamera
 WF_HD bool LookAtD(V3 pos, V3 look, V3 up, M44 *cameraFromWorld, M44 *worldFromCamera) {
     M44 w{};
@@ -791,6 +792,21 @@ WF_HD void InstanceRay(const wf_instance &in, V3 o, V3 d, float *tMax, V3 *oOut,
     *dOut = dd;
 }
 
+// AnimatedPrimitive::Intersect (cpu/primitive.cpp:140-153): the instance record with renderFromPrimitive.Interpolate(ray.time) in place of
+// the static transformation — what InstanceRay / InstanceInteraction / InstanceWoP are then applied to.  A static instance is returned as it is.
+// ANIM = false (the default): the caller cannot meet an animated instance — the interpolation (a quaternion slerp, a 4 x 4 inverse: an
+// out-of-line callee) is then not reachable from it and does not set its register allocation (wf_scene.h "LEAN DEVICE VARIANTS").  The
+// scene builder admits animated shapes / instances only where the consumers that ask for ANIM can meet them: ordinary materials, no media.
+template <bool ANIM>
+WF_HD const wf_instance &InstanceAt(const SceneView &sv, const wf_instance &in, float time, wf_instance *tmp) {
+    if constexpr (!ANIM) return in;
+    if (!sv.haveAnimated || in.anim_plus1 == 0) return in;
+    tmp->def = in.def;
+    tmp->anim_plus1 = in.anim_plus1;
+    AnimatedInterpolateP(sv.animated + (in.anim_plus1 - 1), time, &tmp->render_from_instance);
+    return *tmp;
+}
+
 // BVHAggregate::Intersect / IntersectP of an instance definition's own BVH (triangles only), on the shared stack above
 // its current top.  tMax is updated in place; returns whether a hit was recorded.
 template <typename Stack>
@@ -902,8 +918,8 @@ WF_HD bool BVHIntersectAnyDef(const SceneView &sv, int root, V3 o, V3 d, float t
 // Reference-order BVH walk.  Stack is any type with push(int)/pop()/empty(); the HIP kernels pass an
 // LDS-backed short stack (csrc/hip/wf_traverse.hip), the CPU checker a plain array.
 
-template <typename Stack>
-WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, ClosestHit *out) {
+template <bool ANIM = false, typename Stack>
+WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, ClosestHit *out, float time = 0) {
     out->prim = -1;
     out->inst = -1;
     out->nodesVisited = 0;
@@ -922,7 +938,8 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
                         // an object instance: TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125).  tHit stays the
                         // instance ray's parameter (the reference does not add the origin shift dt back either).
                         const int inst = tri - sv.nTriangles - sv.nQuadrics;
-                        const wf_instance &in = sv.instances[inst];
+                        wf_instance inTmp;
+                        const wf_instance &in = InstanceAt<ANIM>(sv, sv.instances[inst], time, &inTmp);
                         float tI = tMax;
                         V3 oI, dI;
                         InstanceRay(in, o, d, &tI, &oI, &dI);
@@ -975,8 +992,8 @@ WF_HD bool BVHIntersectClosest(const SceneView &sv, V3 o, V3 d, float tMax, Stac
     return out->prim >= 0;
 }
 
-template <typename Stack>
-WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, int *nodesVisited, int *trisTested) {
+template <bool ANIM = false, typename Stack>
+WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &stack, int *nodesVisited, int *trisTested, float time = 0) {
     V3 invDir{1.f / d.x, 1.f / d.y, 1.f / d.z};
     int negMask = int(invDir.x < 0) | (int(invDir.y < 0) << 1) | (int(invDir.z < 0) << 2);
     int currentNodeIndex = 0;
@@ -990,7 +1007,8 @@ WF_HD bool BVHIntersectAny(const SceneView &sv, V3 o, V3 d, float tMax, Stack &s
                 for (int i = 0; i < node->nprims && !found; ++i) {
                     int tri = sv.bvhPrims[node->offset + i];
                     if (tri >= sv.nTriangles + sv.nQuadrics) {
-                        const wf_instance &in = sv.instances[tri - sv.nTriangles - sv.nQuadrics];
+                        wf_instance inTmp;
+                        const wf_instance &in = InstanceAt<ANIM>(sv, sv.instances[tri - sv.nTriangles - sv.nQuadrics], time, &inTmp);
                         float tI = tMax;
                         V3 oI, dI;
                         InstanceRay(in, o, d, &tI, &oI, &dI);
@@ -1592,19 +1610,20 @@ WF_NI void InstanceWoP(const wf_instance *in, float x, float y, float z, float *
 }
 // GENERAL = false (the default in a lean unit, WF_DEV_LEAN): the scene has triangles only — the quadric / patch / curve callees are not
 // reachable from the caller (see wf_scene.h "LEAN DEVICE VARIANTS")
-template <bool GENERAL = !WF_DEV_LEAN>
-WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD) {
+template <bool GENERAL = !WF_DEV_LEAN, bool ANIM = false>
+WF_HD V3 IntrWo(const SceneView &sv, int prim, int inst, V3 minusD, float time = 0) {
     if (inst >= 0) {
         V3 w;
+        wf_instance inTmp;
+        const wf_instance *in = &InstanceAt<ANIM>(sv, sv.instances[inst], time, &inTmp);
         if (GENERAL && prim >= sv.nTriangles) {
             // a quadric inside an instance: built in object space from the instance-space ray (normalised there and after the transform
             // back to instance space), then taken to render space by the instance transform (normalised again)
-            const wf_instance *in = sv.instances + inst;
             V3 vI = XfVector3(in->render_from_instance.mInv, minusD);
             SphereWoP(sv.quadrics + (prim - sv.nTriangles), vI.x, vI.y, vI.z, &w.x, &w.y, &w.z);
             return Normalize(XfVector3(in->render_from_instance.m, w));
         }
-        InstanceWoP(sv.instances + inst, minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
+        InstanceWoP(in, minusD.x, minusD.y, minusD.z, &w.x, &w.y, &w.z);
         return w;
     }
     if (!GENERAL || prim < sv.nTriangles) return Normalize(minusD);
@@ -1641,12 +1660,14 @@ WF_HD bool IsCurvePrim(const SceneView &sv, int prim) { return sv.haveCurves && 
 #ifndef WF_LEAN_INLINE_INSTANCE
 #define WF_LEAN_INLINE_INSTANCE 1
 #endif
-template <bool GENERAL = !WF_DEV_LEAN, bool CURVE_ALPHA = false>
-WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si, V3 ro, V3 rd) {
+template <bool GENERAL = !WF_DEV_LEAN, bool CURVE_ALPHA = false, bool ANIM = false>
+WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, float b1, float b2, SurfIntr *si, V3 ro, V3 rd, float time = 0) {
+    wf_instance inTmp;
+    const wf_instance *inp = inst >= 0 ? &InstanceAt<ANIM>(sv, sv.instances[inst], time, &inTmp) : nullptr;
     if constexpr (!GENERAL) TriangleInteraction(sv, prim, b0, b1, b2, si);
     else
     if (IsCurvePrim(sv, prim)) {
-        if (inst >= 0) { float tm = WF_INFINITY; InstanceRay(sv.instances[inst], ro, rd, &tm, &ro, &rd); }
+        if (inst >= 0) { float tm = WF_INFINITY; InstanceRay(*inp, ro, rd, &tm, &ro, &rd); }
         SurfIntr tmp;
         if constexpr (CURVE_ALPHA) CurveHitInteractionP(sv.self, prim, b0, b1, b2, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, &tmp);
         else { const wf_quadric *s_ = sv.quadrics + (prim - sv.nTriangles); CurveInteractionP(s_, sv.meshes[s_->mesh].flags, b0, b1, b2, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, &tmp); }
@@ -1656,10 +1677,10 @@ WF_HD void HitInteraction(const SceneView &sv, int prim, int inst, float b0, flo
     if (inst >= 0) {
         // (a lean kernel — triangles only, 4 waves — applies the transform in line: the out-of-line call passes the 45-float interaction
         //  through scratch both ways, ~360 B of the 640 B per item k_mat_shade<diffuse> wrote; round 5)
-        if constexpr (!GENERAL && WF_LEAN_INLINE_INSTANCE) InstanceInteraction(sv.instances + inst, si);
+        if constexpr (!GENERAL && WF_LEAN_INLINE_INSTANCE) InstanceInteraction(inp, si);
         else {
         SurfIntr tmp = *si;
-        InstanceInteractionP(sv.instances + inst, &tmp);
+        InstanceInteractionP(inp, &tmp);
         *si = tmp;
         }
     }

@@ -219,7 +219,9 @@ __device__ inline unsigned long long waveSum(unsigned long long v) {
     return v;
 }
 
-template <bool COUNT>
+// ANIM: the scene has animated shapes / instances (AnimatedPrimitive, round 5): the walk interpolates their transformation at the ray's time.
+// Such scenes are walked by these reference-order kernels only (no production tree: ctx->fastOk is false for them).
+template <bool COUNT, bool ANIM = false>
 __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv, WorkState ws, int cur, int *stackSpill) {
     const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv,
         F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
         ClosestHit ch;
         st.n = 0;
-        bool found = BVHIntersectClosest(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch);
+        bool found = BVHIntersectClosest<ANIM>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch, o.w);
         KAfterClosestHit(sv, ws, cur, i, found, ch.prim, ch.inst, ch.h.t, ch.h.b0, ch.h.b1, ch.h.b2);
         if (COUNT) { nv += ch.nodesVisited; nt += ch.trisTested; nh += found; nr += 1; }
     }
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv,
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool ANIM = false>
 __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, WorkState ws, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
@@ -251,7 +253,8 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, 
         F4 o = ws.sq.o[i], d = ws.sq.d[i];
         int v = 0, t = 0;
         st.n = 0;
-        bool occluded = BVHIntersectAny(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t);
+        const float time = ANIM ? ws.pathTime[(int)FloatToBits(d.w)] : 0.f;   // ShadowRayWorkItem.ray.time = the path's time
+        bool occluded = BVHIntersectAny<ANIM>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t, time);
         KRecordShadowRay(ws, i, occluded);
         if (COUNT) { nv += v; nt += t; nu += !occluded; nr += 1; }
     }
@@ -1898,6 +1901,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if ((e = devUpload(ctx, &sv.instances, d->instances, (size_t)d->n_instances))) return e;
     if ((e = devUpload(ctx, &sv.instanceDefs, d->instance_defs, (size_t)d->n_instance_defs))) return e;
     sv.nInstances = d->n_instances;
+    if ((e = devUpload(ctx, &sv.animated, d->animated, (size_t)d->n_animated))) return e;
+    sv.haveAnimated = d->n_animated > 0;
     sv.nTriangles = d->n_triangles;
     sv.nBvhNodes = d->n_bvh_nodes;
     if ((e = devUpload(ctx, &sv.spectra, d->spectra, (size_t)d->n_spectra))) return e;
@@ -1995,7 +2000,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     ctx->rareLights = ctx->portalLights = false;
     // the lean shade kernels (wf_scene.h "LEAN DEVICE VARIANTS"): no quadrics / patches / curves, every texture a constant, an image map or a
     // bilerp (WF_LEAN_SHADE=0 turns them off)
-    ctx->leanShade = d->n_quadrics == 0 && !(getenv("WF_LEAN_SHADE") && atoi(getenv("WF_LEAN_SHADE")) == 0);
+    ctx->leanShade = d->n_quadrics == 0 && d->n_animated == 0 && !(getenv("WF_LEAN_SHADE") && atoi(getenv("WF_LEAN_SHADE")) == 0);
     for (int i = 0; i < d->n_textures && ctx->leanShade; ++i)
         if (!wf::IsSimpleFloatTexture(d->textures[i].type) && !wf::IsSimpleSpectrumTexture(d->textures[i].type)) ctx->leanShade = false;
     // ... and, since round 5, emitters that are not triangles (sphere / disk / cylinder / patch / curve lights: an out-of-line sampler of
@@ -2139,6 +2144,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if ((e = residentGrid(kc, &ctx->persistentGrid)) || (e = residentGrid(ks, &ctx->persistentGridShadow))) return e;
         }
         if (getenv("WF_NO_FAST")) ctx->fastOk = false;
+        if (d->n_animated > 0) ctx->fastOk = false;   // AnimatedPrimitive: the reference-order walks interpolate the transformation per ray; the production walk does not
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
@@ -2241,6 +2247,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
 #endif
     if (const char *sp = getenv("WF_MAT_SPLIT")) ctx->matSplit = atoi(sp) != 0;
 #endif
+    if (ctx->svHost.haveAnimated && (e = devAlloc(ctx, &ws.pathTime, n))) return e;   // the paths' times, for the shadow rays (AnimatedPrimitive)
     if (ctx->matSplit) {
         // the NeeItems between the material stage's two kernels: as many 16-byte planes as the widest record of the material types present
         int planes = 0;
@@ -2396,7 +2403,8 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
     // counting on: the reference-order walk (its visit counts define the algorithmic bytes);
     // otherwise the production traversal (wf_traverse.h)
     if (ctx->countTraversal)
-        LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
+        { if (ctx->svHost.haveAnimated) LAUNCH("Intersect closest", (k_intersect_closest<true, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
+          else LAUNCH("Intersect closest", k_intersect_closest<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill); }
     else if (ctx->fastOk) {
         if ((ctx->raySort & 1) && depth >= 1)
             if (int e = SortQueue(ctx, false, depth & 1)) return e;
@@ -2440,7 +2448,8 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
         LAUNCH("Intersect closest: near-tie re-trace", k_closest_retrace, 128, ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
         if (ctx->svHost.haveMix) LAUNCH("Resolve MixMaterial hits", k_resolve_mix, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     } else
-        LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
+        { if (ctx->svHost.haveAnimated) LAUNCH("Intersect closest", (k_intersect_closest<false, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill);
+          else LAUNCH("Intersect closest", k_intersect_closest<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, ctx->stackSpill); }
     return 0;
 }
 // SampleMediumInteraction (wavefront/media.cpp:22-257): K5, then K6 for the Henyey-Greenstein phase function
@@ -2541,7 +2550,8 @@ static int EvalMaterialOn(wf_ctx *ctx, int material_type, int depth, hipStream_t
     if (material_type == WF_MAT_INTERFACE) return 0;
     if (material_type < 0 || material_type >= WF_MAT_NTYPES) return fail(-1, "material type %d has no HIP kernel", material_type);
     const bool tex = ctx->svHost.texNeedsFootprint != 0;
-    const bool vs = ctx->svHost.film.type == WF_FILM_GBUFFER || ctx->svHost.camera.anim.actually_animated;   // the variant that fills the visible surface / differentiates a moving camera
+    const bool vs = ctx->svHost.film.type == WF_FILM_GBUFFER || ctx->svHost.camera.anim.actually_animated || ctx->svHost.haveAnimated ||
+                    (ctx->svHost.haveCurves && ctx->svHost.haveQuadricAlpha);   // the variant that fills the visible surface / differentiates a moving camera / meets animated instances or alpha-textured curves
 #if defined(WF_HAVE_FUSED_MAT)
     if (!ctx->matSplit) {
         Prof prof_(ctx, timed ? names[material_type] : "(untimed)", stream);
@@ -2604,7 +2614,8 @@ static int EvalMaterialOn(wf_ctx *ctx, int material_type, int depth, hipStream_t
 int wf_intersect_shadow(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (ctx->countTraversal)
-        LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+        { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow", (k_intersect_shadow<true, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+          else LAUNCH("Intersect shadow", k_intersect_shadow<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill); }
     else if (ctx->fastOk) {
         if ((ctx->raySort & 2) && (depth >= 1 || (ctx->raySort & 4)))
             if (int e = SortQueue(ctx, true, 0)) return e;
@@ -2616,7 +2627,8 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
         }
         LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk);
     } else
-        LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+        { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow", (k_intersect_shadow<false, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+          else LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill); }
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW) | (1u << CNT_CURSOR_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
     ctx->cursorDirty[1] = false;

@@ -325,6 +325,12 @@ struct Interpreter {
                 if (gs.ctm.m.m[i][j] != gs.ctmEnd.m.m[i][j]) Fatal(loc, "animated transformations (ActiveTransform StartTime / EndTime with different CTMs) are not supported by this build");
     }
     Transform RenderFromObject() const { return Transform((renderFromWorld * gs.ctm).m); }
+    bool CTMIsAnimated() const {   // TransformSet::IsAnimated (scene.h): ctm[0] != ctm[1]
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                if (gs.ctm.m.m[i][j] != gs.ctmEnd.m.m[i][j]) return true;
+        return false;
+    }
 
     std::vector<Param> ParseParams(Tokenizer &tz) {
         std::vector<Param> out;
@@ -535,9 +541,15 @@ struct Interpreter {
                 if (activeInstance) Fatal(loc, "ObjectInstance can't be called inside instance definition");
                 InstanceUse u;
                 u.name = name;
-                // scene.cpp:398-430: renderFromInstance = RenderFromObject() * worldFromRender
-                RequireStaticCTM(loc);
+                // scene.cpp:365-395: renderFromInstance = RenderFromObject() * worldFromRender; under an animated CTM an AnimatedTransform of the
+                // two, unless they come out equal
                 u.renderFromInstance = RenderFromObject() * Inverse(renderFromWorld);
+                u.loc = loc;
+                if (CTMIsAnimated()) {
+                    u.renderFromInstanceEnd = Transform((renderFromWorld * gs.ctmEnd).m) * Inverse(renderFromWorld);
+                    u.startTime = transformStartTime; u.endTime = transformEndTime;
+                    u.animated = u.renderFromInstance != u.renderFromInstanceEnd;
+                }
                 scene->instances.push_back(u);
             } else if (tok == "Option") {
                 // parser.cpp:877-880 + BasicSceneBuilder::Option (scene.cpp:489-575): `Option "name" value` — the name without a type, the value a bare
@@ -594,13 +606,29 @@ struct Interpreter {
                     e.lightIndex = (int)scene->areaLights.size() - 1;
                     if (activeInstance) fprintf(stderr, "Warning: %s: Area lights not supported with object instancing\n", loc.c_str());
                 }
-                RequireStaticCTM(loc);
-                e.renderFromObject = RenderFromObject();
+                const bool animated = CTMIsAnimated();
+                e.renderFromObject = animated ? Transform() : RenderFromObject();   // (scene.cpp:277-285: an animated shape is created with the identity)
                 e.reverseOrientation = gs.reverseOrientation;
                 e.materialIndex = gs.currentMaterialIndex;
                 e.materialName = gs.currentMaterialName;
                 e.insideMedium = gs.currentInsideMedium;
                 e.outsideMedium = gs.currentOutsideMedium;
+                if (animated) {
+                    // AnimatedShapeSceneEntity -> AnimatedPrimitive(BVH of the entity's shapes, renderFromShape) (scene.cpp:1452-1506): here a hidden
+                    // instance definition with this one entity, used once with the animated transformation RenderFromObject()
+                    if (activeInstance) Fatal(loc, "animated shapes inside an object instance definition are not supported by this build");
+                    if (e.lightIndex >= 0) Fatal(loc, "Animated area lights are not supported.");   // scene.cpp:1485-1488
+                    InstanceUse u;
+                    u.name = std::string("\x01animated-shape#") + std::to_string(scene->animatedShapes.size());
+                    u.animated = true;
+                    u.renderFromInstance = RenderFromObject();
+                    u.renderFromInstanceEnd = Transform((renderFromWorld * gs.ctmEnd).m);
+                    u.startTime = transformStartTime; u.endTime = transformEndTime;
+                    u.loc = loc;
+                    scene->instanceDefinitions[u.name].name = u.name;
+                    scene->instanceDefinitions[u.name].shapes.push_back(std::move(e));
+                    scene->animatedShapes.push_back(std::move(u));
+                } else
                 if (activeInstance) activeInstance->shapes.push_back(std::move(e));
                 else scene->shapes.push_back(std::move(e));
             } else if (tok == "Texture") {

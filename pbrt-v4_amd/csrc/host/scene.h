@@ -81,7 +81,15 @@ struct ShapeEntity : Entity {
     std::string insideMedium, outsideMedium;
 };
 struct InstanceDefinition { std::string name; std::vector<ShapeEntity> shapes; };
-struct InstanceUse { std::string name; Transform renderFromInstance; };
+struct InstanceUse {
+    std::string name;
+    Transform renderFromInstance;   // (animated: the start-time transformation)
+    // AnimatedPrimitive (round 5): the use was created under an animated CTM (ActiveTransform StartTime / EndTime with different CTMs)
+    bool animated = false;
+    Transform renderFromInstanceEnd;
+    float startTime = 0, endTime = 1;
+    std::string loc;
+};
 
 struct RenderOptions {  // subset of PBRTOptions (options.h)
     int seed = 0;
@@ -115,6 +123,9 @@ struct ParsedScene {
     std::vector<ShapeEntity> shapes;
     std::map<std::string, InstanceDefinition> instanceDefinitions;
     std::vector<InstanceUse> instances;
+    // shapes created under an animated CTM (scene.cpp:277-290: AnimatedShapeSceneEntity): each is a hidden instance definition (its shapes in
+    // object space) used once with the animated transformation; they precede the object instances among the top-level primitives (scene.cpp:1511-1577)
+    std::vector<InstanceUse> animatedShapes;
     std::vector<std::pair<std::string, Entity>> media;
     std::map<std::string, Transform> mediaTransforms;
     std::string baseDir;
@@ -135,6 +146,7 @@ struct SceneTables {
     std::vector<wf_quadric> quadrics;
     std::vector<wf_instance> instances;
     std::vector<wf_instance_def> instanceDefs;
+    std::vector<wf_animated_transform> animated;   // wf_instance.anim_plus1
     int nTopBvhNodes = 0, nTopPrims = 0;
     std::vector<uint32_t> sobolMatrices;       // data/sobol_matrices.bin when the sampler is "sobol"
     std::vector<uint64_t> vdcSobol, vdcSobolInv;

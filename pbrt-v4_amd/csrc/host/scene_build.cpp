@@ -61,6 +61,7 @@ void SceneTables::Finalize() {
     desc.n_quadrics = (int)quadrics.size(); desc.quadrics = quadrics.data();
     desc.n_instances = (int)instances.size(); desc.instances = instances.data();
     desc.n_instance_defs = (int)instanceDefs.size(); desc.instance_defs = instanceDefs.data();
+    desc.n_animated = (int)animated.size(); desc.animated = animated.empty() ? nullptr : animated.data();
     desc.n_top_bvh_nodes = nTopBvhNodes; desc.n_top_prims = nTopPrims;
     desc.sobol_matrices = sobolMatrices.empty() ? nullptr : sobolMatrices.data();
     desc.vdc_sobol = vdcSobol.empty() ? nullptr : vdcSobol.data();
@@ -110,7 +111,7 @@ bool SceneTables::Save(const std::string &path) const {
     fwrite(hdr, 8, 4, f);
     fwrite(&desc, sizeof(desc), 1, f);
     putVec(f, P); putVec(f, N); putVec(f, UV); putVec(f, triIndices); putVec(f, triMesh); putVec(f, bvhPrims); putVec(f, infiniteLights);
-    putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, sobolMatrices); putVec(f, vdcSobol); putVec(f, vdcSobolInv); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
+    putVec(f, meshes); putVec(f, quadrics); putVec(f, instances); putVec(f, instanceDefs); putVec(f, animated); putVec(f, sobolMatrices); putVec(f, vdcSobol); putVec(f, vdcSobolInv); putVec(f, haltonPrimes); putVec(f, haltonPermOffsets);
     putVec(f, haltonPerms); putVec(f, bvhNodes); putVec(f, pool.spectra); putVec(f, pool.data); putVec(f, textures); putVec(f, materials);
     putVec(f, lights); putVec(f, lightBvh); putVec(f, lightTransforms); putVec(f, filterData); putVec(f, powerAlias); putVec(f, imageLights);
     putVec(f, noisePerm); putVec(f, texImages); putVec(f, tableData); putVec(f, media); putVec(f, mediumData); putVec(f, imageFile); putVec(f, sRGBFromFilmRGB); putVec(f, S);
@@ -131,7 +132,7 @@ bool SceneTables::Load(const std::string &path) {
     bool ok = fread(hdr, 8, 4, f) == 4 && hdr[0] == kTablesMagic && hdr[1] == (uint64_t)WF_ABI_VERSION && hdr[2] == sizeof(wf_scene_desc) && hdr[3] == sizeof(SceneTables);
     ok = ok && fread(&desc, sizeof(desc), 1, f) == 1;
     ok = ok && getVec(f, P) && getVec(f, N) && getVec(f, UV) && getVec(f, triIndices) && getVec(f, triMesh) && getVec(f, bvhPrims) && getVec(f, infiniteLights) &&
-         getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, sobolMatrices) && getVec(f, vdcSobol) && getVec(f, vdcSobolInv) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
+         getVec(f, meshes) && getVec(f, quadrics) && getVec(f, instances) && getVec(f, instanceDefs) && getVec(f, animated) && getVec(f, sobolMatrices) && getVec(f, vdcSobol) && getVec(f, vdcSobolInv) && getVec(f, haltonPrimes) && getVec(f, haltonPermOffsets) &&
          getVec(f, haltonPerms) && getVec(f, bvhNodes) && getVec(f, pool.spectra) && getVec(f, pool.data) && getVec(f, textures) && getVec(f, materials) &&
          getVec(f, lights) && getVec(f, lightBvh) && getVec(f, lightTransforms) && getVec(f, filterData) && getVec(f, powerAlias) && getVec(f, imageLights) &&
          getVec(f, noisePerm) && getVec(f, texImages) && getVec(f, tableData) && getVec(f, media) && getVec(f, mediumData) && getVec(f, imageFile) && getVec(f, sRGBFromFilmRGB) && getVec(f, S);
@@ -2825,7 +2826,9 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         };
         for (const ShapeEntity &sh : scene.shapes) want(sh);
         std::set<std::string> seenDefs;
-        for (const InstanceUse &u : scene.instances) {
+        std::vector<InstanceUse> allUsesPrefetch(scene.animatedShapes);
+        allUsesPrefetch.insert(allUsesPrefetch.end(), scene.instances.begin(), scene.instances.end());
+        for (const InstanceUse &u : allUsesPrefetch) {
             auto it = scene.instanceDefinitions.find(u.name);
             if (it == scene.instanceDefinitions.end() || !seenDefs.insert(u.name).second) continue;
             for (const ShapeEntity &sh : it->second.shapes) want(sh);
@@ -2856,7 +2859,11 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
     // gets its own BVH; only definitions that are used are built
     std::map<std::string, int> defIndex;
     std::vector<PrimList> defPrims;
-    for (const InstanceUse &u : scene.instances) {
+    // the animated shapes' hidden definitions first, then the object instances: the order of the reference's top-level primitives
+    // (shapes, animated shapes, instances: scene.cpp:1441-1577)
+    std::vector<InstanceUse> allUses(scene.animatedShapes);
+    allUses.insert(allUses.end(), scene.instances.begin(), scene.instances.end());
+    for (const InstanceUse &u : allUses) {
         auto it = scene.instanceDefinitions.find(u.name);
         if (it == scene.instanceDefinitions.end()) Die("", u.name + ": object instance not defined");
         if (defIndex.count(u.name)) continue;
@@ -3592,7 +3599,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
         }
         // the instances (scene.cpp:1560-1577): TransformedPrimitive(definition, renderFromInstance), after the shapes
         const int nTrisAll = (int)T->triIndices.size() / 3, nQuads = (int)T->quadrics.size();
-        for (const InstanceUse &u : scene.instances) {
+        for (const InstanceUse &u : allUses) {
             const int d = defIndex.at(u.name);
             if (defPrims[d].empty()) continue;  // empty instance
             wf_instance in{};
@@ -3604,6 +3611,51 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             const B3 &db = defBounds[d];
             const float b[6] = {db.pMin.x, db.pMin.y, db.pMin.z, db.pMax.x, db.pMax.y, db.pMax.z};
             B3 wb;
+            if (u.animated) {
+                // AnimatedPrimitive (cpu/primitive.cpp:132-153): Bounds() = renderFromPrimitive.MotionBounds(primitive.Bounds())
+                // (util/transform.cpp:1083-1096).  Without rotation that is the union of the start and end boxes — restated exactly.  WITH
+                // rotation the reference bounds every corner's path through the zeros of the motion derivative (its c1..c5 terms: 530
+                // lines of generated coefficient code, not restated): here the path of every corner is sampled at 1025 times and the box
+                // widened by the largest step between neighbouring samples, which contains the path.  A top-level box only decides which
+                // nodes a ray visits, not what it hits; the tree built over this box can differ from the reference's, which matters for
+                // the ORDER of candidates at exactly coincident geometry only (stated in DESIGN.md 2).
+                for (int j = 0; j < 3; ++j)
+                    if (u.renderFromInstanceEnd.m.m[3][j] != 0 || u.renderFromInstanceEnd.m.m[3][3] != 1) Die(u.loc, "only affine animated transformations are supported");
+                // what this build admits (the consumers of a hit that interpolate the transformation are the walks and the material stage:
+                // wf_shapes.h InstanceAt<ANIM>): no participating media in the scene, ordinary materials on the animated primitives
+                if (!T->media.empty()) Die(u.loc, "animated shapes / instances in a scene with participating media are not supported by this build");
+                for (const auto &pr : defPrims[d]) {
+                    const int meshId = pr.first < nTrisAll ? T->triMesh[pr.first] : T->quadrics[pr.first - nTrisAll].mesh;
+                    const int mt = T->meshes[meshId].material < 0 ? (int)WF_MAT_INTERFACE : T->materials[T->meshes[meshId].material].type;
+                    if (mt == WF_MAT_INTERFACE || mt == WF_MAT_MIX || mt == WF_MAT_SUBSURFACE)
+                        Die(u.loc, "an animated shape / instance with an interface, mix or subsurface material is not supported by this build");
+                }
+                const wf_animated_transform A = MakeAnimatedTransform(u.renderFromInstance, u.startTime, u.renderFromInstanceEnd, u.endTime);
+                in.anim_plus1 = (int)T->animated.size() + 1;
+                T->animated.push_back(A);
+                auto corner = [&](int c) { return V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}; };
+                if (!A.has_rotation) {
+                    for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(corner(c)));
+                    B3 we;
+                    for (int c = 0; c < 8; ++c) we = Union(we, u.renderFromInstanceEnd.Point(corner(c)));
+                    wb = Union(wb, we);
+                } else {
+                    constexpr int NS = 1024;
+                    float pad = 0;
+                    for (int c = 0; c < 8; ++c) {
+                        V3 prev{0, 0, 0};
+                        for (int k = 0; k <= NS; ++k) {
+                            const float time = u.startTime + (u.endTime - u.startTime) * ((float)k / NS);
+                            const V3 q = AnimatedAt(A, k == 0 ? u.startTime : k == NS ? u.endTime : time).Point(corner(c));
+                            wb = Union(wb, q);
+                            if (k > 0) pad = std::max(pad, Length(q - prev));
+                            prev = q;
+                        }
+                    }
+                    wb.pMin = wb.pMin - V3{pad, pad, pad};
+                    wb.pMax = wb.pMax + V3{pad, pad, pad};
+                }
+            } else
             for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}));
             for (int c = 0; c < 3; ++c)
                 if (!std::isfinite(wb.pMin[c]) || !std::isfinite(wb.pMax[c])) Die("", u.name + ": the bounds of an object instance are not finite (its transformation?)");

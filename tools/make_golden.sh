@@ -161,3 +161,4 @@ oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/spectral_
 sed 's/^Film "rgb".*/Film "gbuffer" "string filename" [ "gbuffer_film.exr" ] "integer xresolution" [ 64 ] "integer yresolution" [ 64 ] "bool savefp16" [ false ]/' $G/materials_lights.pbrt > $G/gbuffer_film.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/gbuffer_film_ref.exr $G/gbuffer_film.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/curves_alpha_ref.pfm $G/curves_alpha.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/animated_ref.pfm $G/animated.pbrt
