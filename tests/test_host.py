@@ -354,3 +354,12 @@ def test_8bit_image_maps_take_a_quarter_of_the_table(wfpt, tmp_path, monkeypatch
         assert len(files) == 1
         sizes[mode] = os.path.getsize(d / files[0])
     assert sizes["compact"] < 0.5 * sizes["float"], sizes
+
+
+def test_reference_parameter_names_are_looked_up():
+    """ParameterDictionary::ReportUnused is an ErrorExit in the reference and here: every parameter name the reference's Create() functions
+    read on this path must be looked up by this build too, or a valid scene fails with "unused parameter" ("faceIndices").
+    tools/param_audit.py compares the names (from /root/reference where present, else the committed list) with the host sources."""
+    import subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "..", "tools", "param_audit.py")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout

@@ -336,9 +336,19 @@ class Gen:
         return 'Shape "plymesh" "string filename" "%s"' % os.path.join(GOLDEN, self.pick(["bilinear_quads.ply", "displace_cone.ply", "ball.ply.gz"])) + \
             (' "texture displacement" "%s" "float edgelength" [ 0.5 ]' % self.pick(self.float_tex) if self.float_tex and self.r.random() < 0.3 else "")
 
-    def placed(self, body):
+    def placed(self, body, may_animate=False):
         if self.r.random() < 0.12:   # (round 4, end) ConcatTransform with a sheared matrix on top of the usual chain
             body = "  ConcatTransform [ 1 %s 0 0  0 1 0 0  %s 0 1 0  0 0 0 1 ]\n" % (f(self.u(-0.4, 0.4)), f(self.u(-0.3, 0.3))) + body
+        # (round 5) AnimatedPrimitive: the shape / instance under an animated CTM — where this build admits it: no media in the scene, no
+        # emitter, an ordinary material (the caller says so).  A translation, half of the time a scale too; NO rotation: the reference
+        # bounds a rotating primitive through the zeros of its motion derivative (util/transform.cpp:434-960, not restated), this build
+        # through samples of the path — the boxes, and with them the scene bounds the lights are preprocessed with, differ in the last
+        # bits, and the comparison here is bit for bit (tests/golden/animated.pbrt has rotations under a ground plane that fixes the bounds)
+        if may_animate and not self.media and self.r.random() < 0.25:
+            anim = "  ActiveTransform EndTime\n  Translate %s\n" % f(self.u(-0.6, 0.6), self.u(-0.6, 0.6), self.u(-0.3, 0.5))
+            if self.r.random() < 0.5:
+                anim += "  Scale %s\n" % f(self.u(0.7, 1.4), self.u(0.7, 1.4), self.u(0.7, 1.4))
+            body = anim + "  ActiveTransform All\n" + body
         return "AttributeBegin\n  Translate %s\n  Rotate %s %s\n  Scale %s\n%s\nAttributeEnd" % (
             f(self.u(-3, 3), self.u(-2.5, 2.5), self.u(0.3, 2.5)), f(self.u(0, 360)), f(self.u(-1, 1), self.u(-1, 1), self.u(0.2, 1)),
             f(self.u(0.4, 1.3), self.u(0.4, 1.3), self.u(0.4, 1.3)) if self.r.random() < 0.8 else f(-0.8, 0.9, 1.1), body)
@@ -386,7 +396,9 @@ class Gen:
         have_def = self.r.random() < 0.3
         if have_def:
             solid = [m for m in self.materials if m[1] != "interface"]
-            out.append('ObjectBegin "thing"\n  NamedMaterial "%s"\n  %s\n  Translate 0 0 1.2\n  %s\nObjectEnd' % (self.pick(solid)[0] if solid else "m0", self.shape(), self.shape()))
+            def_mat = self.pick(solid) if solid else ("m0", self.materials[0][1] if self.materials else "diffuse")
+            def_mat_type = def_mat[1]
+            out.append('ObjectBegin "thing"\n  NamedMaterial "%s"\n  %s\n  Translate 0 0 1.2\n  %s\nObjectEnd' % (def_mat[0], self.shape(), self.shape()))
         for i in range(self.r.randrange(2, 7)):
             name, t = self.pick(self.materials)
             body = '  NamedMaterial "%s"\n' % name
@@ -396,16 +408,18 @@ class Gen:
                 body += '  MediumInterface "%s" "%s"\n' % (self.pick(self.media), "fog" if "fog" in self.media else "")
             elif self.media and t in ("dielectric", "thindielectric") and self.r.random() < 0.3:
                 body += '  MediumInterface "%s" "%s"\n' % (self.pick(self.media), "fog" if "fog" in self.media else "")
+            emitter = False
             if self.r.random() < 0.2 and t not in ("interface",):
                 body += '  AreaLightSource "diffuse" "rgb L" %s%s\n' % (self.rgb(1, 8), ' "bool twosided" true' if self.r.random() < 0.5 else "") + \
                         (('  # image emission\n') if False else "")
+                emitter = True
             if self.r.random() < 0.15:
                 body += "  ReverseOrientation\n"
             body += "  " + self.shape()
-            out.append(self.placed(body))
+            out.append(self.placed(body, may_animate=not emitter and t not in ("interface", "mix", "subsurface")))
         if have_def:
             for _ in range(self.r.randrange(1, 4)):
-                out.append(self.placed('  ObjectInstance "thing"'))
+                out.append(self.placed('  ObjectInstance "thing"', may_animate=def_mat_type not in ("interface", "mix", "subsurface")))
         if "fog" in self.media:
             # A ray that travels in a medium and MISSES every surface is pushed by MediumSampleQueue::Push(RayWorkItem, tMax), which leaves the
             # item's `depth` unwritten (wavefront/workitems.h:468-492): the reference then reads a stale depth and its image depends on
