@@ -823,10 +823,11 @@ static int Main(int argc, char **argv) {
                     const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
                     if (sv.haveMedia)
                         ParallelFor(nShadow, [&](int i) {
-                            KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
+                            const float time = ws.pathTime ? ws.pathTime[(int)FloatToBits(ws.sq.d[i].w)] : 0.f;   // the shadow ray's (and its respawned segments') time
+                            KTraceTransmittance<true>(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
                                 ArrayStack st;
                                 ClosestHit ch;
-                                bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+                                bool found = BVHIntersectClosest<true>(sv, o, d, tMax, st, &ch, time);
                                 if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
                                 return found;
                             });

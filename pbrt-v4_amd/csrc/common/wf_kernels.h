@@ -777,6 +777,8 @@ WF_HD void TrBegin(const WorkState &ws, int i, TrState *st) {
     st->T_ray = S4c(1.f); st->r_u = S4c(1.f); st->r_l = S4c(1.f);
 }
 // one turn of the loop body after the closest hit of (ro, rd, tMax) is known; returns whether the ray goes on (a new segment in st)
+// ANIM: the scene has animated primitives (the interaction of a hit through one needs the path's time: ws.pathTime)
+template <bool ANIM = false>
 WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *st, bool hit, int prim, int inst, float b0, float b1, float b2) {
     F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
     const float tMax = o4.w;
@@ -784,7 +786,7 @@ WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *s
     SurfIntr si;
     bool opaque = false;
     if (hit) {
-        HitInteraction(sv, prim, inst, b0, b1, b2, &si, st->ro, st->rd);
+        HitInteraction<!WF_DEV_LEAN, false, ANIM>(sv, prim, inst, b0, b1, b2, &si, st->ro, st->rd, (ANIM && ws.pathTime) ? ws.pathTime[(int)FloatToBits(d4.w)] : 0.f);
         opaque = sv.meshes[si.mesh].material >= 0;
     }
     if (opaque) {
@@ -852,22 +854,22 @@ WF_HD void TrLoad(const WorkState &ws, int i, TrState *st) {
     st->rng.inc = (uint64_t)(uint32_t)r.z | ((uint64_t)(uint32_t)r.w << 32);
 }
 // trace(o, d, tMax, &prim, &inst, &b0, &b1, &b2) -> closest hit?
-template <typename Trace>
+template <bool ANIM = false, typename Trace>
 WF_HD void KTraceTransmittanceFrom(const SceneView &sv, const WorkState &ws, int i, TrState &st, Trace trace) {
     const float tMax = ws.sq.o[i].w;
     while (!(st.rd.x == 0 && st.rd.y == 0 && st.rd.z == 0)) {
         int prim = -1, inst = -1;
         float b0 = 0, b1 = 0, b2 = 0;
         bool hit = trace(st.ro, st.rd, tMax, &prim, &inst, &b0, &b1, &b2);
-        if (!TrSegment(sv, ws, i, &st, hit, prim, inst, b0, b1, b2)) break;
+        if (!TrSegment<ANIM>(sv, ws, i, &st, hit, prim, inst, b0, b1, b2)) break;
     }
     TrFinish(ws, i, st);
 }
-template <typename Trace>
+template <bool ANIM = false, typename Trace>
 WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, Trace trace) {
     TrState st;
     TrBegin(ws, i, &st);
-    KTraceTransmittanceFrom(sv, ws, i, st, trace);
+    KTraceTransmittanceFrom<ANIM>(sv, ws, i, st, trace);
 }
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537

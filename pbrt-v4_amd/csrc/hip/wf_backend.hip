@@ -1116,18 +1116,21 @@ __global__ void __launch_bounds__(BLOCK) k_medium_scatter(const SceneView sv, Wo
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumScattering<RARE>(sv, ws, cur, i);
 }
 // reference-order variant (no production BVH, or WF_NO_FAST)
+template <bool ANIM>
 __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkState ws, int *stackSpill) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
-    for (int i = gtid; i < n; i += stride)
-        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
+    for (int i = gtid; i < n; i += stride) {
+        const float time = ANIM ? ws.pathTime[(int)FloatToBits(ws.sq.d[i].w)] : 0.f;   // the shadow ray's time = its path's
+        KTraceTransmittance<ANIM>(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
             ClosestHit ch;
             st.n = 0;
-            bool found = BVHIntersectClosest(sv, o, d, tMax, st, &ch);
+            bool found = BVHIntersectClosest<ANIM>(sv, o, d, tMax, st, &ch, time);
             if (found) { *prim = ch.prim; *inst = ch.inst; *b0 = ch.h.b0; *b1 = ch.h.b1; *b2 = ch.h.b2; }
             return found;
         });
+    }
 }
 // production layout, one independent walk per lane (a transmittance ray alternates between tracing and
 // ratio tracking, so there is no batch to share)
@@ -2488,7 +2491,8 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
     else
-        LAUNCH("Intersect shadow (Tr)", k_shadow_tr, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+        { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow (Tr)", k_shadow_tr<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+          else LAUNCH("Intersect shadow (Tr)", k_shadow_tr<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill); }
     LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
     return 0;
 }
@@ -2988,7 +2992,7 @@ int wf_trace_shadow_tr_host(wf_ctx *ctx, int n, const float *o, const float *d, 
     if (ctx->fastOk && ctx->svHost.nInstances == 0) {
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("shadow Tr (host rays)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ws, ctx->fast, ctx->spillArea());
         else LAUNCHT("shadow Tr (host rays)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ws, ctx->fast, ctx->spillArea());
-    } else LAUNCH("shadow Tr (host rays)", k_shadow_tr, gridFor(n), ctx->svHost, ws, ctx->stackSpill);
+    } else LAUNCH("shadow Tr (host rays)", k_shadow_tr<false>, gridFor(n), ctx->svHost, ws, ctx->stackSpill);
     HIPCHK(hipMemcpyAsync(out_L, ws.L, n * sizeof(F4), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (void *p : tmp) HIPCHK(hipFree(p));

@@ -3621,9 +3621,8 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
                 // the ORDER of candidates at exactly coincident geometry only (stated in DESIGN.md 2).
                 for (int j = 0; j < 3; ++j)
                     if (u.renderFromInstanceEnd.m.m[3][j] != 0 || u.renderFromInstanceEnd.m.m[3][3] != 1) Die(u.loc, "only affine animated transformations are supported");
-                // what this build admits (the consumers of a hit that interpolate the transformation are the walks and the material stage:
-                // wf_shapes.h InstanceAt<ANIM>): no participating media in the scene, ordinary materials on the animated primitives
-                if (!T->media.empty()) Die(u.loc, "animated shapes / instances in a scene with participating media are not supported by this build");
+                // what this build admits (the consumers of a hit that interpolate the transformation are the walks, the transmittance trace and
+                // the material stage: wf_shapes.h InstanceAt<ANIM>): ordinary materials on the animated primitives
                 for (const auto &pr : defPrims[d]) {
                     const int meshId = pr.first < nTrisAll ? T->triMesh[pr.first] : T->quadrics[pr.first - nTrisAll].mesh;
                     const int mt = T->meshes[meshId].material < 0 ? (int)WF_MAT_INTERFACE : T->materials[T->meshes[meshId].material].type;
@@ -3633,6 +3632,16 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
                 const wf_animated_transform A = MakeAnimatedTransform(u.renderFromInstance, u.startTime, u.renderFromInstanceEnd, u.endTime);
                 in.anim_plus1 = (int)T->animated.size() + 1;
                 T->animated.push_back(A);
+                {
+                    // Transform::Decompose leaves a mirror in R ("XXX TODO FIXME deal with flip", util/transform.cpp:223): the quaternion of an
+                    // improper R is not a unit one, and the reference's in-between matrices and motion bounds are off.  The matrices are
+                    // restated (so the motion is the reference's); the bounds are this build's samples of it — say so.
+                    const auto &m = u.renderFromInstance.m.m;
+                    const float det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                                      m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+                    if (det < 0 && A.actually_animated)
+                        fprintf(stderr, "Warning: %s: animated transformation with a mirror: the reference's decomposition does not handle the flip; images may differ from it where its motion bounds cut the primitive\n", u.loc.c_str());
+                }
                 auto corner = [&](int c) { return V3{b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]}; };
                 if (!A.has_rotation) {
                     for (int c = 0; c < 8; ++c) wb = Union(wb, u.renderFromInstance.Point(corner(c)));

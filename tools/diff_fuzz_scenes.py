@@ -339,19 +339,23 @@ class Gen:
     def placed(self, body, may_animate=False):
         if self.r.random() < 0.12:   # (round 4, end) ConcatTransform with a sheared matrix on top of the usual chain
             body = "  ConcatTransform [ 1 %s 0 0  0 1 0 0  %s 0 1 0  0 0 0 1 ]\n" % (f(self.u(-0.4, 0.4)), f(self.u(-0.3, 0.3))) + body
-        # (round 5) AnimatedPrimitive: the shape / instance under an animated CTM — where this build admits it: no media in the scene, no
+        # (round 5) AnimatedPrimitive: the shape / instance under an animated CTM — where this build admits it: no
         # emitter, an ordinary material (the caller says so).  A translation, half of the time a scale too; NO rotation: the reference
         # bounds a rotating primitive through the zeros of its motion derivative (util/transform.cpp:434-960, not restated), this build
         # through samples of the path — the boxes, and with them the scene bounds the lights are preprocessed with, differ in the last
         # bits, and the comparison here is bit for bit (tests/golden/animated.pbrt has rotations under a ground plane that fixes the bounds)
-        if may_animate and not self.media and self.r.random() < 0.25:
+        animated = may_animate and self.r.random() < 0.25
+        if animated:
             anim = "  ActiveTransform EndTime\n  Translate %s\n" % f(self.u(-0.6, 0.6), self.u(-0.6, 0.6), self.u(-0.3, 0.5))
             if self.r.random() < 0.5:
                 anim += "  Scale %s\n" % f(self.u(0.7, 1.4), self.u(0.7, 1.4), self.u(0.7, 1.4))
             body = anim + "  ActiveTransform All\n" + body
         return "AttributeBegin\n  Translate %s\n  Rotate %s %s\n  Scale %s\n%s\nAttributeEnd" % (
             f(self.u(-3, 3), self.u(-2.5, 2.5), self.u(0.3, 2.5)), f(self.u(0, 360)), f(self.u(-1, 1), self.u(-1, 1), self.u(0.2, 1)),
-            f(self.u(0.4, 1.3), self.u(0.4, 1.3), self.u(0.4, 1.3)) if self.r.random() < 0.8 else f(-0.8, 0.9, 1.1), body)
+            # (the mirror never under an animated CTM: Transform::Decompose leaves the flip in R — "XXX TODO FIXME deal with flip",
+            # util/transform.cpp:223 —, the quaternion of an improper R is not a unit one, hasRotation comes out true for a pure
+            # translation and the reference's interpolated matrices and motion bounds are both off: seeds 1400047/50/68/73/79/89)
+            f(self.u(0.4, 1.3), self.u(0.4, 1.3), self.u(0.4, 1.3)) if self.r.random() < 0.8 or animated else f(-0.8, 0.9, 1.1), body)
 
     def world(self):
         out = ["WorldBegin"]
