@@ -721,6 +721,7 @@ static int Main(int argc, char **argv) {
                 std::atomic<unsigned long long> nv{0}, nt{0};
                 ParallelFor(nRays, [&](int i) {
                     F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+                    if (ws.pathTime) ws.pathTime[ws.rq[cur].meta[i].x] = o.w;   // the path's time, for the shadow rays this depth spawns
                     ArrayStack st;
                     ClosestHit ch;
                     bool found = BVHIntersectClosest<true>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch, o.w);   // (o.w: the ray's time, for AnimatedPrimitive)
@@ -823,7 +824,7 @@ static int Main(int argc, char **argv) {
                     const int nShadow = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
                     if (sv.haveMedia)
                         ParallelFor(nShadow, [&](int i) {
-                            const float time = ws.pathTime ? ws.pathTime[(int)FloatToBits(ws.sq.d[i].w)] : 0.f;   // the shadow ray's (and its respawned segments') time
+                            const float time = ShadowTime<true>(ws, ws.sq.d[i].w);   // the shadow ray's (and its respawned segments') time
                             KTraceTransmittance<true>(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
                                 ArrayStack st;
                                 ClosestHit ch;
@@ -837,7 +838,7 @@ static int Main(int argc, char **argv) {
                         F4 o = ws.sq.o[i], d = ws.sq.d[i];
                         ArrayStack st;
                         int v = 0, t = 0;
-                        const float time = ws.pathTime ? ws.pathTime[(int)FloatToBits(d.w)] : 0.f;   // the shadow ray's time = its path's (ShadowRayWorkItem.ray.time)
+                        const float time = ShadowTime<true>(ws, d.w);   // ShadowRayWorkItem.ray.time
                         bool occluded = BVHIntersectAny<true>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t, time);
                         shadowNodes += (unsigned long long)v; shadowTris += (unsigned long long)t;
                         KRecordShadowRay(ws, i, occluded);
@@ -853,7 +854,7 @@ static int Main(int argc, char **argv) {
                     if (tracePath) printf("d%d bssrdf-items %d\n", depth, ws.counters[(CNT_BSSRDF) * CNT_STRIDE]);
                     // SampleSubsurface, integrator.cpp:431 -> wavefront/subsurface.cpp:18-203
                     ParallelFor(ws.counters[(CNT_BSSRDF) * CNT_STRIDE], [&](int i) { KSubsurfaceProbe(sv, ws, i); });
-                    ParallelFor(ws.counters[(CNT_SSS) * CNT_STRIDE], [&](int i) { ArrayStack st; KIntersectOneRandom(sv, ws, i, st); });
+                    ParallelFor(ws.counters[(CNT_SSS) * CNT_STRIDE], [&](int i) { ArrayStack st; KIntersectOneRandom<true>(sv, ws, i, st); });
                     ParallelFor(ws.counters[(CNT_SSS) * CNT_STRIDE], [&](int i) { KSubsurfaceScatter(sv, ws, cur, i); });
                     sssProbes += ws.counters[(CNT_SSS) * CNT_STRIDE];
                     for (int i = 0; i < ws.counters[(CNT_SSS) * CNT_STRIDE]; ++i) sssExits += ws.sssQ[i].reservoirPDF != 0;

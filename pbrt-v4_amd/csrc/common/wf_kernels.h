@@ -776,6 +776,17 @@ WF_HD void TrBegin(const WorkState &ws, int i, TrState *st) {
     st->rng = RNG(Hash3f(st->ro), Hash3f(st->rd));
     st->T_ray = S4c(1.f); st->r_u = S4c(1.f); st->r_l = S4c(1.f);
 }
+// The shadow queue's d.w: the pixel index in the low 31 bits.  Bit 31 marks the shadow ray of a subsurface exit, which the reference
+// spawns at time 0 whatever the path's time ("Float time = 0;  // TODO: pipe through", wavefront/subsurface.cpp:70) — it only matters
+// to scenes with animated primitives (ws.pathTime != nullptr), the only ones that set it.
+constexpr uint32_t SHADOW_TIME_ZERO = 0x80000000u;
+WF_HD int ShadowPixel(float dw) { return (int)(FloatToBits(dw) & ~SHADOW_TIME_ZERO); }
+// ShadowRayWorkItem.ray.time: the time of the path the ray was spawned on (ws.pathTime: written with every ray the closest-hit stage takes)
+template <bool ANIM>
+WF_HD float ShadowTime(const WorkState &ws, float dw) {
+    const uint32_t b = FloatToBits(dw);
+    return (ANIM && ws.pathTime && !(b & SHADOW_TIME_ZERO)) ? ws.pathTime[b & ~SHADOW_TIME_ZERO] : 0.f;
+}
 // one turn of the loop body after the closest hit of (ro, rd, tMax) is known; returns whether the ray goes on (a new segment in st)
 // ANIM: the scene has animated primitives (the interaction of a hit through one needs the path's time: ws.pathTime)
 template <bool ANIM = false>
@@ -786,7 +797,7 @@ WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *s
     SurfIntr si;
     bool opaque = false;
     if (hit) {
-        HitInteraction<!WF_DEV_LEAN, false, ANIM>(sv, prim, inst, b0, b1, b2, &si, st->ro, st->rd, (ANIM && ws.pathTime) ? ws.pathTime[(int)FloatToBits(d4.w)] : 0.f);
+        HitInteraction<!WF_DEV_LEAN, false, ANIM>(sv, prim, inst, b0, b1, b2, &si, st->ro, st->rd, ShadowTime<ANIM>(ws, d4.w));
         opaque = sv.meshes[si.mesh].material >= 0;
     }
     if (opaque) {
@@ -794,7 +805,7 @@ WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *s
         return false;
     }
     if (st->medium >= 0) {
-        const int pixelIndex = (int)FloatToBits(d4.w);
+        const int pixelIndex = ShadowPixel(d4.w);
         Wavelengths lambda = LoadLambda(ws, pixelIndex);
         float tEnd = !hit ? tMax : (Distance(st->ro, si.pi.mid()) / Length(st->rd));
         float u0 = st->rng.UniformFloat();
@@ -831,7 +842,7 @@ WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *s
 WF_HD void TrFinish(const WorkState &ws, int i, const TrState &st) {
     if (st.T_ray) {
         F4 d4 = ws.sq.d[i];
-        const int pixelIndex = (int)FloatToBits(d4.w);
+        const int pixelIndex = ShadowPixel(d4.w);
         S4 Ld = toS4(ws.sq.Ld[i]);
         const S4 sr_u = toS4(ws.sq.r_u[i]), sr_l = toS4(ws.sq.r_l[i]);
         Ld = Ld * (st.T_ray / (sr_u * st.r_u + sr_l * st.r_l).Average());
@@ -1465,7 +1476,8 @@ WF_HD void KSubsurfaceProbe(const SceneView &sv, const WorkState &ws, int i) {
 }
 // WavefrontAggregate::IntersectOneRandom (CPUAggregate: wavefront/aggregate.cpp:90-115; OptiX: gpu/optix/optix.cu:474-573)
 // returns the reservoir's sample probability (0: the segment meets no surface of `material`) and the kept hit
-template <typename Stack>
+// ANIM: the scene has animated primitives; the probe rays are spawned from an Interaction of time 0 ("FIXME time", aggregate.cpp:96)
+template <bool ANIM = false, typename Stack>
 WF_HD float IntersectOneRandom(const SceneView &sv, V3 p0, V3 p1, int material, Stack &st, ClosestHit *kept, SurfIntr *keptSi) {
     RNG rng;
     rng.SetSequence(Hash6f(p0, p1));   // WeightedReservoirSampler(seed) -> RNG(seed)
@@ -1477,9 +1489,9 @@ WF_HD float IntersectOneRandom(const SceneView &sv, V3 p0, V3 p1, int material, 
         if (r.d.x == 0 && r.d.y == 0 && r.d.z == 0) break;
         ClosestHit ch;
         st.n = 0;
-        if (!BVHIntersectClosest(sv, r.o, r.d, 1.f, st, &ch)) break;
+        if (!BVHIntersectClosest<ANIM>(sv, r.o, r.d, 1.f, st, &ch, 0.f)) break;
         SurfIntr si;
-        HitInteraction(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si, r.o, r.d);
+        HitInteraction<!WF_DEV_LEAN, false, ANIM>(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si, r.o, r.d, 0.f);
         basePi = si.pi; baseN = si.n;
         if (sv.meshes[si.mesh].material == material) {
             // wrs.Add(SubsurfaceInteraction(si->intr), 1.f)  (util/sampling.h:535-546)
@@ -1493,12 +1505,12 @@ WF_HD float IntersectOneRandom(const SceneView &sv, V3 p0, V3 p1, int material, 
     }
     return weightSum > 0 ? reservoirWeight / weightSum : 0.f;
 }
-template <typename Stack>
+template <bool ANIM = false, typename Stack>
 WF_HD void KIntersectOneRandom(const SceneView &sv, const WorkState &ws, int i, Stack &st) {
     SubsurfaceItem &w = ws.sssQ[i];
     ClosestHit ch;
     SurfIntr si;
-    w.reservoirPDF = IntersectOneRandom(sv, w.p0, w.p1, w.material, st, &ch, &si);
+    w.reservoirPDF = IntersectOneRandom<ANIM>(sv, w.p0, w.p1, w.material, st, &ch, &si);
     if (w.reservoirPDF != 0) { w.pi = si.pi; w.n = si.n; w.ns = si.ns; w.dpdu = si.dpdu; w.dpdv = si.dpdv; w.dpdus = si.dpdus; w.dpdvs = si.dpdvs; }
 }
 // "Handle out-scattering after SSS" (:49-199)
@@ -1572,7 +1584,7 @@ WF_HD void KSubsurfaceScatter(const SceneView &sv, const WorkState &ws, int cur,
         RayOD sr = SpawnRayTo(w.pi, w.n, ls.pLightPi, ls.pLightN);
         int slot = QueueAlloc(&ws.counters[(CNT_SHADOW) * CNT_STRIDE]);
         ws.sq.o[slot] = F4{sr.o.x, sr.o.y, sr.o.z, 1 - ShadowEpsilon};
-        ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)w.pixelIndex)};
+        ws.sq.d[slot] = F4{sr.d.x, sr.d.y, sr.d.z, BitsToFloat((uint32_t)w.pixelIndex | (ws.pathTime ? SHADOW_TIME_ZERO : 0u))};   // time 0: see SHADOW_TIME_ZERO
         ws.sq.Ld[slot] = toF4(Ld);
         ws.sq.r_u[slot] = toF4(r_u);
         ws.sq.r_l[slot] = toF4(r_l);
@@ -1584,7 +1596,7 @@ WF_HD void KSubsurfaceScatter(const SceneView &sv, const WorkState &ws, int cur,
 WF_HD void KRecordShadowRay(const WorkState &ws, int i, bool occluded) {
     if (occluded) return;
     S4 Ld = toS4(ws.sq.Ld[i]) / (toS4(ws.sq.r_u[i]) + toS4(ws.sq.r_l[i])).Average();
-    int pixelIndex = (int)FloatToBits(ws.sq.d[i].w);
+    int pixelIndex = ShadowPixel(ws.sq.d[i].w);
     S4 Lpixel = toS4(ws.L[pixelIndex]);
     ws.L[pixelIndex] = toF4(Lpixel + Ld);
 }

@@ -229,6 +229,8 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_closest(const SceneView sv,
     unsigned long long nv = 0, nt = 0, nh = 0, nr = 0;
     for (int i = gtid; i < n; i += stride) {
         F4 o = ws.rq[cur].o[i], d = ws.rq[cur].d[i];
+        // the path's time, for the shadow rays this depth spawns (a subsurface exit continues at time 0: subsurface.cpp:70)
+        if (ANIM) ws.pathTime[ws.rq[cur].meta[i].x] = o.w;
         ClosestHit ch;
         st.n = 0;
         bool found = BVHIntersectClosest<ANIM>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, WF_INFINITY, st, &ch, o.w);
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, 
         F4 o = ws.sq.o[i], d = ws.sq.d[i];
         int v = 0, t = 0;
         st.n = 0;
-        const float time = ANIM ? ws.pathTime[(int)FloatToBits(d.w)] : 0.f;   // ShadowRayWorkItem.ray.time = the path's time
+        const float time = ShadowTime<ANIM>(ws, d.w);
         bool occluded = BVHIntersectAny<ANIM>(sv, V3{o.x, o.y, o.z}, V3{d.x, d.y, d.z}, o.w, st, &v, &t, time);
         KRecordShadowRay(ws, i, occluded);
         if (COUNT) { nv += v; nt += t; nu += !occluded; nr += 1; }
@@ -1015,11 +1017,12 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_probe(const SceneView sv, 
     const int n = ws.counters[(CNT_BSSRDF) * CNT_STRIDE];
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceProbe(sv, ws, i);
 }
+template <bool ANIM>
 __global__ void __launch_bounds__(BLOCK) k_intersect_one_random(const SceneView sv, WorkState ws, int *stackSpill) {
     const int n = ws.counters[(CNT_SSS) * CNT_STRIDE];
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
-    for (int i = gtid; i < n; i += stride) KIntersectOneRandom(sv, ws, i, st);
+    for (int i = gtid; i < n; i += stride) KIntersectOneRandom<ANIM>(sv, ws, i, st);
 }
 // IntersectOneRandom on caller-supplied probe segments (the boundary adapter's path): segs = p0.xyz p1.xyz per item
 __global__ void __launch_bounds__(BLOCK) k_trace_one_random(const SceneView sv, int n, const float *segs, const int32_t *material, wf_hit_record *out, float *pdf,
@@ -1122,7 +1125,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
     for (int i = gtid; i < n; i += stride) {
-        const float time = ANIM ? ws.pathTime[(int)FloatToBits(ws.sq.d[i].w)] : 0.f;   // the shadow ray's time = its path's
+        const float time = ShadowTime<ANIM>(ws, ws.sq.d[i].w);
         KTraceTransmittance<ANIM>(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
             ClosestHit ch;
             st.n = 0;
@@ -2650,7 +2653,8 @@ int wf_intersect_one_random(wf_ctx *ctx) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveSubsurface) return 0;
     // reference-order walk (the chain of probe hits is a dependent sequence per item; the subsurface path is a side path)
-    LAUNCH("Intersect one random (subsurface probe)", k_intersect_one_random, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    if (ctx->svHost.haveAnimated) LAUNCH("Intersect one random (subsurface probe)", k_intersect_one_random<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
+    else LAUNCH("Intersect one random (subsurface probe)", k_intersect_one_random<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
     return 0;
 }
 int wf_subsurface_scatter(wf_ctx *ctx, int depth) {

@@ -162,4 +162,5 @@ sed 's/^Film "rgb".*/Film "gbuffer" "string filename" [ "gbuffer_film.exr" ] "in
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/gbuffer_film_ref.exr $G/gbuffer_film.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/curves_alpha_ref.pfm $G/curves_alpha.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/animated_ref.pfm $G/animated.pbrt
+oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/animated_sss_ref.pfm $G/animated_sss.pbrt
 oracle/_ref/pbrt_ref --wavefront --quiet --seed 0 --spp 4 --outfile $G/face_indices_ref.pfm $G/face_indices.pbrt
