@@ -482,7 +482,7 @@ def main():
                 if n_items > 0 and mat_ms > 0:
                     b = 300.0 * n_items + 184.0 * spawned + 124.0 * rays_shadow
                     out["roofline_material"] = {
-                        "bound": "hbm", "kernel": "EvaluateMaterialAndBSDF (k_eval_material<type, variant>, all types)", "achieved": b / (mat_ms * 1e-3) / 1e9,
+                        "bound": "hbm", "kernel": "EvaluateMaterialAndBSDF (k_mat_shade<type, variant> + k_mat_nee<type, rare>, all types)", "achieved": b / (mat_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / (mat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "items": n_items, "items_by_type": {str(k): v for k, v in items.items() if v and k != "medium_sample"}, "spawned_rays": spawned, "shadow_rays": rays_shadow,
                         "algorithmic_bytes": b, "algorithmic_bytes_per_item": b / n_items, "total_ms": mat_ms, "launches": mat_launches,
@@ -494,7 +494,7 @@ def main():
                         rm["write_bytes_per_item"] = live["material"]["write_bytes_per_ray"]
                         rm["traffic"] = rm["traffic_bytes_per_item"] * n_items / mat_launches
                         rm["algorithmic_bytes_per_launch"] = b / mat_launches
-                        rm["traffic_source"] = "this run's rocprofv3 PMC child passes (2 x FETCH_SIZE + WRITE_SIZE of every k_eval_material dispatch / the items the child's --stats reports) x this run's items per launch"
+                        rm["traffic_source"] = "this run's rocprofv3 PMC child passes (2 x FETCH_SIZE + WRITE_SIZE of every k_mat_shade / k_mat_nee dispatch / the items the child's --stats reports) x this run's items per launch"
                 med_ms = sum(e["total_ms"] for e in rep if e["name"].startswith("Sample medium"))
                 med_launches = sum(e["launches"] for e in rep if e["name"].startswith("Sample medium"))
                 if items.get("medium_sample", 0) > 0 and med_ms > 0:

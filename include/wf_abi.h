@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 11
+#define WF_ABI_VERSION 12          /* 12 (round 5): wf_instance.anim_plus1, wf_scene_desc.n_animated / animated (AnimatedPrimitive) */
 #define WF_NSPECTRUM 4           /* NSpectrumSamples, util/spectrum.h:36 */
 #define WF_LAMBDA_MIN 360
 #define WF_LAMBDA_MAX 830

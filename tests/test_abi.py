@@ -28,7 +28,7 @@ def test_libraries_export_every_declared_symbol(wfpt):
     for name in declared("wf_host.h"):
         assert hasattr(host, name), name
     hip.wf_abi_version.restype = ctypes.c_int
-    assert hip.wf_abi_version() == 11   # include/wf_abi.h WF_ABI_VERSION (11: wf_scene_desc.S, wf_mesh.first_s)
+    assert hip.wf_abi_version() == 12   # include/wf_abi.h WF_ABI_VERSION (12: wf_instance.anim_plus1, wf_scene_desc.animated)
 
 
 def test_no_cpu_fallback_in_product():

@@ -34,7 +34,7 @@ def test_cornell_tables(wfpt):
     # wavefront/integrator.cpp:227-236
     assert (s.info.max_queue_size, s.info.n_passes, s.info.scanlines_per_pass) == (160000, 1, 400)
     h = desc_fields(wfpt, s)
-    assert h.abi_version == 11 and h.n_triangles == 32
+    assert h.abi_version == 12 and h.n_triangles == 32
     nodes = (BvhNode * h.n_bvh_nodes).from_address(h.bvh_nodes)
     prims = np.ctypeslib.as_array((C.c_int32 * h.n_triangles).from_address(h.bvh_prims))
     assert sorted(prims.tolist()) == list(range(32))  # every triangle exactly once

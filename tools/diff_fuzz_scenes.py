@@ -51,7 +51,7 @@ class Gen:
         r = self.r
         out = []
         if r.random() < 0.15:
-            out.append('Option "string rendercoordsys" "%s"' % self.pick(["camera", "cameraworld", "world"]))
+            out.append('Option "rendercoordsys" "%s"' % self.pick(["camera", "cameraworld", "world"]))
         if r.random() < 0.1:
             out.append('ColorSpace "%s"' % self.pick(["srgb", "rec2020", "dci-p3", "aces2065-1"]))
         self.camera_motion = r.random() < 0.12   # (round 4, end) ActiveTransform StartTime / EndTime around the camera: AnimatedTransform
