@@ -552,11 +552,16 @@ WF_HD void CubicBezierControlPoints(const V3 *cp, float uMin, float uMax, V3 *ou
     out[2] = BlossomCubicBezier(cp, uMin, uMax, uMax);
     out[3] = BlossomCubicBezier(cp, uMax, uMax, uMax);
 }
-WF_HD int Log2IntF(float v) {   // util/math.h:372-384
-    if (v < 1) return -Log2IntF(1 / v);
+// util/math.h:372-384.  The reference recurses once for v < 1 (-Log2Int(1 / v)); written out here: a recursive device function makes
+// every kernel that can REACH it a kernel with a dynamically sized stack (.uses_dynamic_stack, tools/stack_audit.py) — all the general
+// shade / traversal variants, through the curve code.  (A negative v recurses for ever in the reference; here it is an answer.)
+WF_HD int Log2IntF(float v) {
+    const bool inverted = v < 1;
+    if (inverted) v = 1 / v;
     const uint32_t midsignif = 0x3504f3u;
     const uint32_t bits = FloatToBits(v);
-    return ((int)(bits >> 23) - 127) + (((bits & ((1u << 23) - 1)) >= midsignif) ? 1 : 0);
+    const int r = ((int)(bits >> 23) - 127) + (((bits & ((1u << 23) - 1)) >= midsignif) ? 1 : 0);
+    return inverted ? -r : r;
 }
 struct CurveData { V3 cp[4]; float width0, width1, uMin, uMax, normalAngle, invSinNormalAngle; int type; N3 n0, n1; };
 WF_HD CurveData LoadCurve(const wf_quadric &s) {

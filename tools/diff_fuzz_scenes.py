@@ -452,6 +452,11 @@ def render(exe, args, path, out):
         p = subprocess.run([exe] + args + ["--outfile", out, path], capture_output=True, text=True, timeout=300)
     except subprocess.TimeoutExpired:
         return "timeout", ""
+    # "CHECK_RARE failures" (pbrt.cpp:146): the reference's CPU build counts how often a rare branch is taken (a total internal reflection
+    # in a rough dielectric, ...: CHECK_RARE, util/check.h:96-112 — compiled OUT of its GPU code, :89-92) and exits with status 1 AFTER the
+    # image is written when a frequency is above its threshold, which a 33 x 19 image at 4 spp reaches easily: the image is the verdict
+    if p.returncode == 1 and os.path.exists(out) and "CHECK_RARE failures" in (p.stdout + p.stderr):
+        return "ok", ""
     if p.returncode != 0 or not os.path.exists(out):
         return "error(%d)" % p.returncode, (p.stdout + p.stderr)[-400:]
     return "ok", ""
