@@ -73,6 +73,30 @@ def audit(name, ins, verbose=True):
                     group |= {a, b}
                     changed = True
     findings = []
+    # (round 5, the mechanism of the round-4 incident) an ORDINARY vector instruction inside a whole-wave bracket writes the lanes of threads
+    # that are inactive at that point — lanes whose values thread-level liveness (and the restore that follows under the region's EXEC) does
+    # not cover.  Only the `s_or_saveexec_b64 sX, -1` / `s_mov_b64 exec, -1` brackets count: a callee's prologue (s_xor_saveexec) and the
+    # SGPR-to-memory idiom (exec = 2^n - 1) enable lanes on purpose.
+    full, inb = [], False
+    for l in ins:
+        f = l.replace(",", "")
+        if re.match(r"s_or_saveexec_b64 \S+ -1", f) or re.match(r"s_mov_b64 exec -1$", f):
+            inb = True
+            full.append(False)
+            continue
+        if re.match(r"s_mov_b64 exec ", f) or re.match(r"s_(and|or|xor|andn2)\w*_b64 exec ", f):
+            inb = False
+        full.append(inb)
+    for k, l in enumerate(ins):
+        if not full[k]:
+            continue
+        op, _, rest = l.partition(" ")
+        toks = [t.strip() for t in rest.split(",")]
+        if not op.startswith("v_") or op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane", "v_nop")):
+            continue
+        dst = regs_of(toks[0]) if toks else set()
+        if dst and not (dst & group):
+            findings.append((name, min(dst), k, "ordinary vector instruction with ALL lanes enabled (inside a whole-wave bracket): " + l))
     for v in sorted(group):
         # per-lane bookkeeping in program order: which lanes hold a spilled SGPR.  None = unknown (a reload of a slot not seen stored)
         ev, valid, slots = [], set(), {}
@@ -157,17 +181,21 @@ def main():
             allf += f
             nfun += g > 0
             nreg += g
-    hard = [f for f in allf if "readlane of lane" not in f[3]]
+    hard = [f for f in allf if "readlane of lane" not in f[3] and "ALL lanes enabled" not in f[3]]
+    wave = [f for f in allf if "ALL lanes enabled" in f[3]]
     soft = [f for f in allf if "readlane of lane" in f[3]]
     print("\n%d unit(s), %d function(s) with lane-carrying VGPRs, %d such registers" % (len(objs), nfun, nreg))
     print("%d save / reload of live lanes under a partial EXEC (the defect class)" % len(hard))
     for f in hard:
         print("  %s v%d @%d: %s" % f)
+    print("%d ordinary vector instruction(s) executed inside a whole-wave bracket (the mechanism of the round-4 incident: DESIGN.md 4.2)" % len(wave))
+    for f in wave[:40]:
+        print("  %s v%d @%d: %s" % f)
     print("%d readlane(s) that precede the writelane of their lane IN LISTING ORDER (loop-carried SGPRs look like this: a hint, not a verdict)" % len(soft))
     if verbose:
         for f in soft:
             print("  %s v%d @%d: %s" % f)
-    sys.exit(1 if hard else 0)
+    sys.exit(1 if hard or wave else 0)
 
 
 if __name__ == "__main__":
