@@ -60,8 +60,9 @@ def audit(name, ins, verbose=True):
             continue
         wwm.append(inw)
     carriers = {int(m.group(1)) for l in ins for m in [re.match(r"v_writelane_b32 v(\d+),", l)] if m}
+    carriers_r = {int(m.group(1)) for l in ins for m in [re.match(r"v_readlane_b32 s\d+, v(\d+),", l)] if m}   # reload targets of a carrier's slot
     # the compiler splits the live range of a carrier with whole-wave copies (v_mov under EXEC = -1): their other side holds lanes too
-    group = set(carriers)
+    group = set(carriers) | carriers_r
     changed = True
     while changed:
         changed = False
@@ -92,7 +93,7 @@ def audit(name, ins, verbose=True):
             continue
         op, _, rest = l.partition(" ")
         toks = [t.strip() for t in rest.split(",")]
-        if not op.startswith("v_") or op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane", "v_nop")):
+        if not op.startswith(("v_", "scratch_load", "global_load", "flat_load", "buffer_load", "ds_read")) or op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane", "v_nop")):
             continue
         dst = regs_of(toks[0]) if toks else set()
         if dst and not (dst & group):
