@@ -1,4 +1,4 @@
-"""Build-time lint for the toolchain defect of DESIGN.md 4.2 (CPU suite: it only disassembles the built objects).
+"""Build-time lint for the toolchain defect of DESIGN.md 4.6 (CPU suite: it only disassembles the built objects).
 
 Every kernel of the shipped build keeps the VGPRs that carry its spilled SGPRs in registers; the three wrong-code incidents of rounds
 3-4 were all builds in which such a carrier register was itself spilled to scratch (tools/check_spill_carriers.py).  A source change that

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/carrier_audit.py unit.o [function-regex] — what happens to the SGPR-spill carrier VGPRs of a gfx950 code object, in program order.
 
-The defect class of DESIGN.md 4.2: a kernel whose carrier VGPR (the target of v_writelane_b32: SGPRs spilled into its lanes) is itself
+The defect class of DESIGN.md 4.6: a kernel whose carrier VGPR (the target of v_writelane_b32: SGPRs spilled into its lanes) is itself
 saved to scratch.  v_writelane / v_readlane ignore EXEC, an ordinary scratch store does not: a carrier saved or reloaded under a partial
 EXEC loses the lanes of the inactive threads — and with them spilled SGPRs (pointers, saved EXEC masks).  For every carrier this prints the
 sequence of events (W writelane, R readlane, S / s scratch store whole-wave / under the current EXEC, L / l scratch load likewise, C / c
@@ -189,7 +189,7 @@ def main():
     print("%d save / reload of live lanes under a partial EXEC (the defect class)" % len(hard))
     for f in hard:
         print("  %s v%d @%d: %s" % f)
-    print("%d ordinary vector instruction(s) executed inside a whole-wave bracket (the mechanism of the round-4 incident: DESIGN.md 4.2)" % len(wave))
+    print("%d ordinary vector instruction(s) executed inside a whole-wave bracket (the mechanism of the round-4 incident: DESIGN.md 4.6)" % len(wave))
     for f in wave[:40]:
         print("  %s v%d @%d: %s" % f)
     print("%d readlane(s) that precede the writelane of their lane IN LISTING ORDER (loop-carried SGPRs look like this: a hint, not a verdict)" % len(soft))

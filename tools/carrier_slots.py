@@ -4,7 +4,7 @@
 StackSlotColoring lets spill slots with disjoint live ranges share their bytes.  A carrier VGPR (lanes = spilled SGPRs) is saved with ALL
 lanes enabled; an ordinary spill writes the ACTIVE lanes only.  When the two share a slot, what a carrier reload returns for an inactive
 lane depends on whole-wave liveness, which is not what thread-level live ranges describe.  This lists, per kernel, every kernel-frame slot
-that a carrier is saved to and every other register stored to overlapping bytes (DESIGN.md 4.2: the round-4 incident kernel has two).
+that a carrier is saved to and every other register stored to overlapping bytes (DESIGN.md 4.6: the round-4 incident kernel has two).
 Build-time analysis only."""
 import collections
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/check_spill_carriers.py [build dir] — a build-time lint for the toolchain defect of DESIGN.md 4.2.
+"""tools/check_spill_carriers.py [build dir] — a build-time lint for the toolchain defect of DESIGN.md 4.6.
 
 ROCm 7.2's compiler spills SGPRs through the lanes of "carrier" VGPRs (v_writelane_b32 / v_readlane_b32).  When a kernel is so short of
 VGPRs that a carrier is ITSELF spilled to scratch and reloaded (whole-wave mode), this tree has seen wrong code three times (a diffuse

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/exp/r04_incident_patch.py in.so out.so — the causal test of DESIGN.md 4.2's mechanism.
+"""tools/exp/r04_incident_patch.py in.so out.so — the causal test of DESIGN.md 4.6's mechanism.
 
 In the round-4 incident kernel (k_eval_material<1, 0> of commit f38bd9e, default flags) the compiler emits, twice:
     s_or_saveexec_b64 s[100:101], -1          ; all lanes on, for the whole-wave copy of an SGPR-spill carrier

@@ -4,7 +4,7 @@
 NP uniform pointers + NC uniform floats are live across the whole body (more scalars than there are SGPRs: they are spilled through the lanes
 of carrier VGPRs), NV per-lane values are live across it (more than the launch bound leaves VGPRs: carriers get split and spilled too),
 inside randomly nested divergent branches and variable-trip loops.  Only + - * / sqrt fma fabs: correctly rounded on both sides, so
-out_prefix.hip (kernel k_syn) and out_prefix_ref.cpp (ref_syn) must agree bit for bit.  DESIGN.md 4.2."""
+out_prefix.hip (kernel k_syn) and out_prefix_ref.cpp (ref_syn) must agree bit for bit.  DESIGN.md 4.6."""
 import random
 import sys
 

@@ -4,7 +4,7 @@
 A gfx950 kernel gets `.private_segment_fixed_size` bytes of scratch per lane; its own frame sits at the bottom, it sets the stack pointer
 (s32) above it and every device function it calls bumps s32 by its own frame (`s_addk_i32 s32, N` / `s_add_i32 s32, s32, N`).  A call chain
 deeper than the allocation writes into the scratch of other lanes / waves: silent corruption, unrepeatable images, memory faults — the
-symptoms of DESIGN.md 4.2's toolchain defect.  This walks the call graph of every code object (direct calls: s_getpc_b64 + s_add_u32 +
+symptoms of DESIGN.md 4.6's toolchain defect.  This walks the call graph of every code object (direct calls: s_getpc_b64 + s_add_u32 +
 s_swappc_b64; an indirect call is reported), sums the frames along the deepest chain and compares with the allocation.
 Build-time analysis only (llvm-objdump / llvm-readelf); nothing is executed."""
 import os
