@@ -93,6 +93,12 @@ def audit(name, ins, verbose=True):
             continue
         op, _, rest = l.partition(" ")
         toks = [t.strip() for t in rest.split(",")]
+        if op.startswith("scratch_store") and len(toks) > 1 and toks[0] == "off":
+            # an ordinary SPILL STORE with all lanes enabled overwrites the slot's bytes of the inactive threads (synthetic seed 5)
+            src = regs_of(toks[1])
+            if src and not (src & group):
+                findings.append((name, min(src), k, "ordinary spill store with ALL lanes enabled (inside a whole-wave bracket): " + l))
+            continue
         if not op.startswith(("v_", "scratch_load", "global_load", "flat_load", "buffer_load", "ds_read")) or op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane", "v_nop")):
             continue
         dst = regs_of(toks[0]) if toks else set()
