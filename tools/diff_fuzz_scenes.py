@@ -55,8 +55,12 @@ class Gen:
         if r.random() < 0.1:
             out.append('ColorSpace "%s"' % self.pick(["srgb", "rec2020", "dci-p3", "aces2065-1"]))
         self.camera_motion = r.random() < 0.12   # (round 4, end) ActiveTransform StartTime / EndTime around the camera: AnimatedTransform
+        # (round 5, end) the interval the animated transformations are defined over: inside, around and beside the shutter (times outside
+        # it clamp to the start / end transformation; a subsurface exit continues at time 0, which -0.5 .. 1 puts in between)
+        tt = self.pick(["0 1"] * 3 + ["-0.5 1", "0.2 0.7", "0 1.5", "-1 0.4"])
+        if self.camera_motion or r.random() < 0.3:
+            out.append("TransformTimes " + tt)
         if self.camera_motion:
-            out.append("TransformTimes 0 1")
             out.append("ActiveTransform StartTime")
         out.append("LookAt %s  %s  0 0 1" % (f(self.u(-1, 1), -7 + self.u(-1, 1), 2.5 + self.u(-1, 1)), f(self.u(-.5, .5), self.u(-.5, .5), 1 + self.u(-.3, .3))))
         if self.camera_motion:
@@ -327,9 +331,10 @@ class Gen:
                 (' "point2 uv" [ 0 0 1 0 0 1 1 1 ]' if self.r.random() < 0.5 else "") + \
                 (' "string emissionfilename" "%s"' % os.path.join(GOLDEN, self.pick(["sky.pfm", "wood.pfm", "alpha.pfm"])) if self.r.random() < 0.3 else "") + alpha
         if k == "curve":
+            ctype = self.pick(["flat", "cylinder", "ribbon"])
             return 'Shape "curve" "string type" "%s" "point3 P" [ -1 0 0  -0.3 %s 0.5  0.4 %s -0.3  1 0 0.2 ] "float width0" [ %s ] "float width1" [ %s ]' % (
-                self.pick(["flat", "cylinder", "ribbon"]), f(self.u(-1, 1)), f(self.u(-1, 1)), f(self.u(0.05, 0.3)), f(self.u(0.02, 0.3))) + \
-                (' "normal N" [ 0 0 1  0 1 1 ]' if self.r.random() < 0.5 else "")
+                ctype, f(self.u(-1, 1)), f(self.u(-1, 1)), f(self.u(0.05, 0.3)), f(self.u(0.02, 0.3))) + \
+                (' "normal N" [ 0 0 1  0 1 1 ]' if ctype == "ribbon" or self.r.random() < 0.3 else "")   # (a ribbon without N is the reference's ErrorExit: one scene in fifteen was lost to it)
         if k == "subdiv":
             return ('Shape "loopsubdiv" "integer levels" [ %d ] "integer indices" [ 0 2 4  2 1 4  1 3 4  3 0 4  2 0 5  1 2 5  3 1 5  0 3 5 ] '
                     '"point3 P" [ 1 0 0  -1 0 0  0 1 0  0 -1 0  0 0 1  0 0 -1 ]' % self.pick([1, 2, 3]))
