@@ -11,6 +11,7 @@
 #   pmc              rocprofv3 PMC passes (SQ / TCP / TCC / FETCH / WRITE, one pass each) over the spec scene at $PMC_SPP spp
 #   soak             $SOAK renders of the spec scene at 4 spp: every image must be the first one (the near-tie queue's guard)
 #   ab               pbrt_amd --stats under each environment given in $AB (";"-separated) — knob A/B on one box
+#   goldens          every tests/golden scene with a reference render through the native binary, pixel payloads compared bit for bit (no torch import: about a minute)
 # Environment: TAG (default r04), STEPS (20), SPP (16), PMC_SPP (4), SCENE (sanmiguel | sanmiguel_sphere | killeroo | cloud | tm), GREP (kernel-name filter of sm16).
 export TMPDIR=/tmp
 TAG=${TAG:-r05}; STEPS=${STEPS:-20}; SPP=${SPP:-16}; PMC_SPP=${PMC_SPP:-4}; SCENE=${SCENE:-sanmiguel}
@@ -111,6 +112,36 @@ PY
         $ROOT/pbrt-v4_amd/_build/pbrt_amd --quiet --spp 4 --outfile /tmp/soak_$i.pfm $f > /dev/null 2>&1 || echo "render $i failed"
         cmp -s /tmp/soak_1.pfm /tmp/soak_$i.pfm && echo "render $i identical" || echo "render $i DIFFERS"
       done | tee $OUT/${TAG}_${SCENE}_soak.txt;;
+    goldens)
+      # every golden scene that has a reference render (tests/golden/<name>_ref.pfm, written by pbrt_ref --wavefront) through the NATIVE binary
+      # (no Python / torch import: a fresh box answers within a minute), compared byte for byte: the quick whole-corpus identity check
+      # of a freshly built tree.  Scenes whose reference render was made with other options than "--spp 4" are left to the pytest suite.
+      for p in $ROOT/tests/golden/*.pbrt; do
+        n=$(basename $p .pbrt); r=$ROOT/tests/golden/${n}_ref.pfm
+        [ -f $r ] || continue
+        case $n in cornell64_*) spp="";; cornell400|gbuffer_film*|spectral_film*|*_small|volpath_*|mix_materials) continue;; *) spp="--spp 4";; esac
+        (cd $ROOT/tests/golden && timeout 60 ${GOLDEN_BIN:-$ROOT/pbrt-v4_amd/_build/pbrt_amd} --quiet $spp --outfile /tmp/g_$n.pfm $p > /tmp/g_$n.log 2>&1)
+      done
+      # the pixel payloads bit for bit (the two writers' header lines differ in how they print the scale)
+      python3 - $ROOT/tests/golden <<'PY' | tee $OUT/${TAG}_goldens_native.txt
+import glob, os, sys
+import numpy as np
+def pixels(path):
+    with open(path, "rb") as f:
+        magic = f.readline().strip(); w, h = map(int, f.readline().split()); f.readline()
+        return magic, w, h, np.frombuffer(f.read(), dtype=np.uint32)
+n = bad = 0
+for g in sorted(glob.glob("/tmp/g_*.pfm")):
+    name = os.path.basename(g)[2:-4]
+    a, b = pixels(g), pixels(os.path.join(sys.argv[1], name + "_ref.pfm"))
+    n += 1
+    same = a[:3] == b[:3] and a[3].size == b[3].size and bool((a[3] == b[3]).all())
+    if not same:
+        bad += 1
+        print("DIFFERS:", name, "identical fraction", float((a[3] == b[3]).mean()) if a[3].size == b[3].size else "size")
+print("goldens through the native binary: %d rendered, %d differ from the reference's render (bit for bit)" % (n, bad))
+PY
+      ;;
     ab)
       f=$(scene_file)
       IFS=';' read -ra envs <<< "${AB:-WF_NONE=1}"
