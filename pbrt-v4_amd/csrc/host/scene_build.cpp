@@ -3526,7 +3526,7 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
             l.infinite_index = (int)T->infiniteLights.size();
             T->infiniteLights.push_back(lightId);
             T->lights.push_back(l);
-        } else Die(le.loc, le.name + ": light type not supported by this build (point, spot, distant, infinite)");
+        } else Die(le.loc, le.name + ": light type not supported by this build (point, spot, projection, goniometric, distant, infinite)");
         ps.ReportUnused("LightSource");
     }
     if (T->lights.empty()) Die("", "No light sources specified");
