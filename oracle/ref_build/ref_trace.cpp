@@ -128,6 +128,17 @@ int main(int argc, char **argv) {
             printf("d%d after-closest rays %d escaped %d hitlight %d medium %d next_pre %d\n", depth, in->CurrentRayQueue(depth)->Size(),
                    in->escapedRayQueue ? in->escapedRayQueue->Size() : 0, in->hitAreaLightQueue->Size(), in->mediumSampleQueue ? in->mediumSampleQueue->Size() : 0,
                    in->NextRayQueue(depth)->Size());
+            if (in->mediumSampleQueue) {
+                // the medium-sample items: tMax seeds the delta-tracking RNG (media.cpp:44), the ray's time picks an AnimatedPrimitive's transformation
+                std::vector<std::pair<int, std::string>> v;
+                for (int i = 0; i < in->mediumSampleQueue->Size(); ++i) {
+                    MediumSampleWorkItem w = (*in->mediumSampleQueue)[i];
+                    char b[256];
+                    snprintf(b, sizeof(b), "tMax %a time %a", w.tMax, w.ray.time);
+                    v.emplace_back(w.pixelIndex, b);
+                }
+                Lines("msample", depth, v);
+            }
             in->SampleMediumInteraction(depth);
             if (in->haveMedia) DumpL(in, "medium", depth, nPix);
             in->HandleEscapedRays();

@@ -796,6 +796,11 @@ static int Main(int argc, char **argv) {
                 if (tracePath)
                     printf("d%d after-closest rays %d escaped %d hitlight %d medium %d next_pre %d\n", depth, nRays, ws.counters[(CNT_ESCAPED) * CNT_STRIDE],
                            ws.counters[(CNT_HITLIGHT) * CNT_STRIDE], ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE], ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
+                if (tracePath && sv.haveMedia)
+                    for (int k = 0; k < ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE]; ++k) {
+                        const int i = ws.mediumSampleQ[k];
+                        printf("d%d msample pix %d tMax %a time %a\n", depth, ws.rq[cur].meta[i].x, ws.hitT[i], ws.rq[cur].o[i].w);
+                    }
                 if (sv.haveMedia) {
                     // SampleMediumInteraction, integrator.cpp:416 (K5, then K6 unless this is the last depth)
                     ParallelFor(ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE], [&](int i) { KSampleMediumInteraction(sv, ws, cur, i); });

@@ -415,7 +415,11 @@ WF_HD int ResolveMix(const SceneView &sv, int matId, int prim, int inst, float b
 }
 // routing of a surface hit whose record is already in ws.hit[i] (beta, r_u, r_l are read from the ray slot by the
 // consumers): interface re-push / area light / material queue
-WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, int i, int prim, int inst, float b0, float b1, float b2) {
+// fromMedium: the caller is the medium stage (SampleMediumInteraction's copy of this routing, media.cpp:176-201).  There the reference
+// continues a ray through an interface surface from `Interaction intr(w.pi, w.n)` — an interaction whose time is the member's default, 0 —
+// while EnqueueWorkAfterIntersection (intersect.h:99-106) spawns it from the full SurfaceInteraction, which carries the ray's time.  The
+// time of a ray only matters to AnimatedPrimitives (and to the shadow rays' path time): fuzz finding s1800074, round 5.
+WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, int i, int prim, int inst, float b0, float b1, float b2, bool fromMedium = false) {
     const wf_mesh mesh = sv.meshes[sv.triMesh[prim]];
     if (mesh.material < 0) {
         // "interface" material: the ray continues in the same direction at the same depth (intersect.h:93-101)
@@ -427,7 +431,7 @@ WF_HD void RouteSurfaceHit(const SceneView &sv, const WorkState &ws, int cur, in
         HitInteraction(sv, prim, inst, b0, b1, b2, &si, V3{o.x, o.y, o.z}, rd);
         V3 no = OffsetRayOrigin(si.pi, si.n, rd);
         int slot = QueueAlloc(&ws.counters[(CNT_RAY0 + (cur ^ 1)) * CNT_STRIDE]);
-        nq.o[slot] = F4{no.x, no.y, no.z, o.w};
+        nq.o[slot] = F4{no.x, no.y, no.z, fromMedium ? 0.f : o.w};
         nq.d[slot] = d;
         nq.beta[slot] = q.beta[i];
         nq.r_u[slot] = q.r_u[i];
@@ -682,14 +686,14 @@ WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, in
         ws.mediumRouteQ[slot] = i;
     }
 #else
-    RouteSurfaceHit(sv, ws, cur, i, prim, HitInst(sv, ws, i), h.y, h.z, h.w);
+    RouteSurfaceHit(sv, ws, cur, i, prim, HitInst(sv, ws, i), h.y, h.z, h.w, /* fromMedium */ true);
 #endif
 }
 // the second half of K5 on the HIP back end: EnqueueWorkAfterIntersection for the medium-sample items that reached their surface
 WF_HD void KMediumRoute(const SceneView &sv, const WorkState &ws, int cur, int qi) {
     const int i = ws.mediumRouteQ[qi];
     const F4 h = ws.hit[i];
-    RouteSurfaceHit(sv, ws, cur, i, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w);
+    RouteSurfaceHit(sv, ws, cur, i, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, /* fromMedium */ true);
 }
 
 // K6: SampleMediumScattering<HGPhaseFunction>, wavefront/media.cpp:259-352

@@ -166,6 +166,17 @@ struct Transform {
         if (wp == 1) return V3{xp, yp, zp};
         return V3{xp, yp, zp} / wp;
     }
+    // Transform::ApplyInverse(Point3) (util/transform.h:386-398): the inverse matrix, and the sum associated in PAIRS — not the
+    // left-to-right sum of operator()(Point3) above; the two differ in the last bit
+    V3 ApplyInversePoint(V3 p) const {
+        const auto &a = mInv.m;
+        float xp = (a[0][0] * p.x + a[0][1] * p.y) + (a[0][2] * p.z + a[0][3]);
+        float yp = (a[1][0] * p.x + a[1][1] * p.y) + (a[1][2] * p.z + a[1][3]);
+        float zp = (a[2][0] * p.x + a[2][1] * p.y) + (a[2][2] * p.z + a[2][3]);
+        float wp = (a[3][0] * p.x + a[3][1] * p.y) + (a[3][2] * p.z + a[3][3]);
+        if (wp == 1) return V3{xp, yp, zp};
+        return V3{xp, yp, zp} / wp;
+    }
     V3 Vector(V3 v) const {
         const auto &a = m.m;
         return V3{a[0][0] * v.x + a[0][1] * v.y + a[0][2] * v.z, a[1][0] * v.x + a[1][1] * v.y + a[1][2] * v.z,

@@ -3406,7 +3406,10 @@ void BuildSceneTables(const ParsedScene &scene, const RenderOptions &optIn, Scen
                     im.res = w;
                     V3 P[4];
                     for (int i = 0; i < 4; ++i) {
-                        P[i] = renderFromWorld.Point(portal[i]);   // cameraTransform.RenderFromWorld(p): the portal is given in world space
+                        // cameraTransform.RenderFromWorld(p) = worldFromRender.ApplyInverse(p) (cameras.h:42): the portal is given in world space.
+                        // (ApplyInverse sums in pairs: with a rotation in worldFromRender — rendercoordsys camera — the left-to-right sum of
+                        //  operator() lands a last bit away: fuzz finding s1800141, round 5)
+                        P[i] = Inverse(renderFromWorld).ApplyInversePoint(portal[i]);
                         im.portal[i][0] = P[i].x; im.portal[i][1] = P[i].y; im.portal[i][2] = P[i].z;
                     }
                     V3 p01 = Normalize(P[1] - P[0]), p12 = Normalize(P[2] - P[1]), p32 = Normalize(P[2] - P[3]), p03 = Normalize(P[3] - P[0]);

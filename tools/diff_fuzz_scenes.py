@@ -472,10 +472,11 @@ def main():
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--keep", default="/tmp/wf_diff_findings")
+    ap.add_argument("--first", type=int, default=0, help="index of the first scene of the seed's sequence (re-run one scene: --first I --n 1)")
     a = ap.parse_args()
     work = tempfile.mkdtemp(prefix="wf_diff_")
     stats = {"identical": 0, "both_refuse": 0, "mismatch": 0, "status_differs": 0}
-    for i in range(a.n):
+    for i in range(a.first, a.first + a.n):
         seed = a.seed * 100000 + i
         text = Gen(seed).scene()
         path = os.path.join(work, "s%d.pbrt" % seed)
@@ -512,6 +513,31 @@ def main():
                 if rs1 == "ok" and cs1 == "ok" and (read_pfm(ro1).view(np.uint32) == read_pfm(co1).view(np.uint32)).all():
                     stats["reference_stale_medium_depth"] = stats.get("reference_stale_medium_depth", 0) + 1
                     print("seed %d: differs only through the reference's unwritten MediumSampleWorkItem::depth (identical under sequential emulation)" % seed, flush=True)
+                    os.unlink(path)
+                    continue
+                # ... and the unwritten depth of a slot that NO ray has used before is whatever the heap held (the queues come from
+                # plain operator new): scenes whose loading frees large blocks (PLY readers, animated shapes) hand the queue recycled
+                # memory, ref_trace prints depths like 2118233313, and an UNUSED texture declaration changes the reference's image
+                # (finding s1800074, round 5).  glibc's MALLOC_PERTURB_ fills every allocation with a byte pattern: a reference whose
+                # image changes under it reads memory it never wrote — no parity target.  (A port bug in such a scene stays unseen.)
+                uninit = False
+                if rs1 == "ok":
+                    base = read_pfm(ro1)
+                    for pat in ("85", "170"):
+                        rop = os.path.join(work, "refp.pfm")
+                        if os.path.exists(rop):
+                            os.unlink(rop)
+                        os.environ["MALLOC_PERTURB_"] = pat
+                        rsp, _ = render(REF, ["--wavefront", "--quiet", "--seed", "0", "--nthreads", "1"], path, rop)
+                        del os.environ["MALLOC_PERTURB_"]
+                        if rsp == "ok":
+                            pert = read_pfm(rop)
+                            if pert.shape != base.shape or not (pert.view(np.uint32) == base.view(np.uint32)).all():
+                                uninit = True
+                                break
+                if uninit:
+                    stats["reference_uninitialised_read"] = stats.get("reference_uninitialised_read", 0) + 1
+                    print("seed %d: the reference's image changes under MALLOC_PERTURB_ (it reads memory it never wrote: no parity target)" % seed, flush=True)
                     os.unlink(path)
                     continue
                 verdict = "MISMATCH"

@@ -122,6 +122,13 @@ PY
         case $n in cornell64_*) spp="";; cornell400|gbuffer_film*|spectral_film*|*_small|volpath_*|mix_materials) continue;; *) spp="--spp 4";; esac
         (cd $ROOT/tests/golden && timeout 60 ${GOLDEN_BIN:-$ROOT/pbrt-v4_amd/_build/pbrt_amd} --quiet $spp --outfile /tmp/g_$n.pfm $p > /tmp/g_$n.log 2>&1)
       done
+      # ... and the committed corpus of the differential fuzzer (tests/golden/fuzz: generated scenes + the reduced findings) at the scenes' own spp
+      for p in $ROOT/tests/golden/fuzz/*.pbrt; do
+        n=$(basename $p .pbrt); r=$ROOT/tests/golden/fuzz/${n}_ref.pfm
+        [ -f $r ] || continue
+        case $n in stale_depth_*) continue;; esac   # (the reference's order-dependent image: checked under the checker's sequential emulation only)
+        (cd $ROOT/tests/golden/fuzz && timeout 60 ${GOLDEN_BIN:-$ROOT/pbrt-v4_amd/_build/pbrt_amd} --quiet --outfile /tmp/g_fuzz__$n.pfm $p > /tmp/g_fuzz__$n.log 2>&1)
+      done
       # the pixel payloads bit for bit (the two writers' header lines differ in how they print the scale)
       python3 - $ROOT/tests/golden <<'PY' | tee $OUT/${TAG}_goldens_native.txt
 import glob, os, sys
@@ -133,7 +140,8 @@ def pixels(path):
 n = bad = 0
 for g in sorted(glob.glob("/tmp/g_*.pfm")):
     name = os.path.basename(g)[2:-4]
-    a, b = pixels(g), pixels(os.path.join(sys.argv[1], name + "_ref.pfm"))
+    ref = os.path.join(sys.argv[1], "fuzz", name[6:] + "_ref.pfm") if name.startswith("fuzz__") else os.path.join(sys.argv[1], name + "_ref.pfm")
+    a, b = pixels(g), pixels(ref)
     n += 1
     same = a[:3] == b[:3] and a[3].size == b[3].size and bool((a[3] == b[3]).all())
     if not same:

@@ -16,13 +16,34 @@ def differs(text):
     for q in (ro, co):
         if os.path.exists(q): os.unlink(q)
     try:
-        a = subprocess.run([REF, "--wavefront", "--quiet", "--seed", "0", "--nthreads", "4", "--outfile", ro, p], capture_output=True, timeout=8)
-        b = subprocess.run([CPU, "--quiet", "--nthreads", "4", "--outfile", co, p], capture_output=True, timeout=8)
+        if os.environ.get("REDUCE_SEQ"):
+            # REDUCE_SEQ=1: the sequential pair (one reference thread against the checker's emulation of the reference's unwritten
+            # MediumSampleWorkItem::depth) — for findings that are NOT that order dependence, in scenes with media: without it the
+            # reduction drifts to a scene that differs through the stale depth only
+            a = subprocess.run([REF, "--wavefront", "--quiet", "--seed", "0", "--nthreads", "1", "--outfile", ro, p], capture_output=True, timeout=20)
+            b = subprocess.run([CPU, "--quiet", "--emulate-stale-medium-depth", "--outfile", co, p], capture_output=True, timeout=20)
+        else:
+            a = subprocess.run([REF, "--wavefront", "--quiet", "--seed", "0", "--nthreads", "4", "--outfile", ro, p], capture_output=True, timeout=8)
+            b = subprocess.run([CPU, "--quiet", "--nthreads", "4", "--outfile", co, p], capture_output=True, timeout=8)
     except subprocess.TimeoutExpired:
         return False
     if a.returncode or b.returncode or not os.path.exists(ro) or not os.path.exists(co): return False
     r, c = read_pfm(ro), read_pfm(co)
-    return r.shape != c.shape or not (r.view(np.uint32) == c.view(np.uint32)).all()
+    if r.shape == c.shape and (r.view(np.uint32) == c.view(np.uint32)).all(): return False
+    if os.environ.get("REDUCE_SEQ"):
+        # ... and the reference must not be reading memory it never wrote (the unwritten depth of a never-used slot: heap contents):
+        # its image has to survive glibc's allocation fill pattern, or the reduction drifts to THAT difference
+        rp = os.path.join(td, "rp.pfm")
+        if os.path.exists(rp): os.unlink(rp)
+        try:
+            e = subprocess.run([REF, "--wavefront", "--quiet", "--seed", "0", "--nthreads", "1", "--outfile", rp, p], capture_output=True, timeout=20,
+                               env=dict(os.environ, MALLOC_PERTURB_="85"))
+        except subprocess.TimeoutExpired:
+            return False
+        if e.returncode or not os.path.exists(rp): return False
+        q = read_pfm(rp)
+        if q.shape != r.shape or not (q.view(np.uint32) == r.view(np.uint32)).all(): return False
+    return True
 
 def units(lines):
     out, i = [], 0
