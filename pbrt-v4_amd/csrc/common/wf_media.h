@@ -316,7 +316,11 @@ struct MajorantIter {
             *out = seg;
             return true;
         }
-        if (tMin >= tMax) return false;
+        // (the reference: `if (tMin >= tMax) return {}`, media.h:181.  Written so that a NaN interval ends the iteration as well: a ray with a NaN
+        //  direction — it happens: a light sample that came out NaN, the path the library carries on with after WF_FATAL_CHECK_NAN_PDF — has
+        //  tMax = NaN, every crossing time NaN, and would step through the grid's memory backwards for ever; the reference turns the NaN
+        //  coordinate into voxel INT_MIN and segfaults (fuzz scenes s2400094, s3200123).  Same result for every ordered pair.)
+        if (!(tMin < tMax)) return false;
         int bits = ((nextCrossingT[0] < nextCrossingT[1]) << 2) + ((nextCrossingT[0] < nextCrossingT[2]) << 1) +
                    ((nextCrossingT[1] < nextCrossingT[2]));
         // cmpToAxis = {2, 1, 2, 1, 2, 2, 0, 0}

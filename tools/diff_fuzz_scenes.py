@@ -43,6 +43,7 @@ class StressRandom(random.Random):
 
 
 STRESS = False
+EXTENDED_OPTIONS = False
 
 
 class Gen:
@@ -66,6 +67,16 @@ class Gen:
         out = []
         if r.random() < 0.15:
             out.append('Option "rendercoordsys" "%s"' % self.pick(["camera", "cameraworld", "world"]))
+        if EXTENDED_OPTIONS:
+            # (round 5, last session; drawn only under --options so that the scenes of the earlier seeds can be regenerated) the other Option
+            # directives of the path (scene.cpp BasicSceneBuilder::Option): bare-token values
+            for name in ("disablepixeljitter", "disablewavelengthjitter", "disabletexturefiltering"):
+                if r.random() < 0.08:
+                    out.append('Option "%s" true' % name)
+            if r.random() < 0.08:
+                out.append('Option "seed" %d' % r.randrange(1, 1000))
+            if r.random() < 0.08:
+                out.append('Option "displacementedgescale" %s' % f(self.u(0.5, 2)))
         if r.random() < 0.1:
             out.append('ColorSpace "%s"' % self.pick(["srgb", "rec2020", "dci-p3", "aces2065-1"]))
         self.camera_motion = r.random() < 0.12   # (round 4, end) ActiveTransform StartTime / EndTime around the camera: AnimatedTransform
@@ -487,10 +498,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--keep", default="/tmp/wf_diff_findings")
     ap.add_argument("--first", type=int, default=0, help="index of the first scene of the seed's sequence (re-run one scene: --first I --n 1)")
+    ap.add_argument("--options", action="store_true", help="also draw the Option directives disablepixeljitter / disablewavelengthjitter / disabletexturefiltering / seed / displacementedgescale")
     ap.add_argument("--stress", action="store_true", help="rare grammar features two to three times as often (StressRandom)")
     a = ap.parse_args()
-    global STRESS
+    global STRESS, EXTENDED_OPTIONS
     STRESS = a.stress
+    EXTENDED_OPTIONS = a.options
     work = tempfile.mkdtemp(prefix="wf_diff_")
     stats = {"identical": 0, "both_refuse": 0, "mismatch": 0, "status_differs": 0}
     for i in range(a.first, a.first + a.n):
@@ -570,6 +583,11 @@ def main():
             stats["both_refuse"] += 1
             if rs.startswith("error(-") or rs == "timeout":   # the reference crashed: not a refusal; say so
                 print("seed %d: reference %s, port %s" % (seed, rs, cs), flush=True)
+        elif rs == "error(-11)" and cs == "ok":
+            # the reference died of a SIGSEGV (not an ErrorExit, not a CHECK): nothing to match.  Known case: a ray with a NaN direction in a
+            # grid medium — its DDAMajorantIterator indexes voxel INT_MIN — where this build's iterator ends (wf_media.h MajorantIter::Next)
+            stats["reference_segfault"] = stats.get("reference_segfault", 0) + 1
+            print("seed %d: the reference segfaults, the port renders (no parity target)" % seed, flush=True)
         else:
             verdict = "STATUS reference %s / port %s: %s" % (rs, cs, (rmsg or cmsg).strip().splitlines()[-1] if (rmsg or cmsg).strip() else "")
             stats["status_differs"] += 1
