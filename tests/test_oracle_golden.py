@@ -153,6 +153,15 @@ def test_partial_medium_interface_is_deterministic_here(built, tmp_path):
     assert all((im.view(np.uint32) == imgs[0].view(np.uint32)).all() for im in imgs)
 
 
+def test_nan_ray_in_a_grid_medium_ends(built, tmp_path):
+    """tests/golden/nan_ray_grid_medium.pbrt (fuzz scene s2400094 reduced): a shadow ray with a NaN direction reaches a grid medium.  The
+    reference segfaults there (its DDA iterator turns the NaN grid coordinate into a voxel index, media.h:141-178), so there is no image to
+    match; the restated iterator used to do the same on the host and would have walked the grid's memory on the device.  It must end."""
+    out = str(tmp_path / "c.pfm")
+    j = run_wf_cpu(os.path.join(GOLDEN, "nan_ray_grid_medium.pbrt"), out, None)
+    assert j["camera_rays"] > 0 and os.path.exists(out)
+
+
 # the fuzz corpus of the GPU leg (tests/golden/fuzz, tools/make_fuzz_goldens.py): the CPU port reproduces the reference's renders bit for bit
 FUZZ = os.path.join(GOLDEN, "fuzz")
 
