@@ -783,6 +783,14 @@ int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out);
    entry was dropped; wf_sync returns an error as well), out[2] near-tie rays re-walked in reference order inside the walk kernel,
    out[3] != 0: a launch dealt its rays through the shared cursor.  reset != 0 zeroes the words after reading. */
 int wf_debug_counters(wf_ctx *ctx, uint64_t out[4], int reset);
+/* Host-only self-check of the production traversal layout (no device needed; CPU suite, tests/test_fastbvh_host.py): builds the
+   QNode / LeafTri / instance-entry arrays wf_scene_upload would upload for `d` (round 6: with the top-level tree rebuilt over
+   partially re-braided instances, WF_BRAID) and walks them on the host with n_rays random rays in double arithmetic, without
+   pruning by distance.  out[0] QNodes, out[1] LeafTri records, out[2] instance entries, out[3] nodes visited by the rays,
+   out[4] (ray, triangle) pairs that really intersect (brute force over top-level triangles and every (instance, triangle) pair),
+   out[5] of those NOT among the triangles the walk tested (must be 0: the tree owes a superset), out[6] triangles tested,
+   out[7] instance entries taken.  Replaces nothing in the reference (its accelerator is OptiX's, gpu/optix/aggregate.cpp). */
+int wf_debug_fastbvh_check(const wf_scene_desc *d, int n_rays, uint64_t seed, int64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ enum {
     CNT_RETRACE_HEAD, CNT_WAVES_DONE,   // the closest-hit kernel's in-kernel near-tie queue (wf_backend.hip: DrainRetrace)
     CNT_CURSOR_SHADOW,                  // the any-hit launch's work cursor (CNT_CURSOR: the closest-hit launch's)
     CNT_MEDIUM_ROUTE,                   // medium-sample items that reached their surface (KMediumRoute)
+    CNT_DEFER, CNT_DEFER_SHADOW,        // rays the triangle walk handed to the general-primitive walk (round 6, wf_backend.hip "TWO-CLASS TRAVERSAL")
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
@@ -123,6 +124,7 @@ struct WorkState {
     int32_t *mixMat;  // per ray slot: the material id a MixMaterial hit resolved to (allocated when sv.haveMix)
     int32_t *mixQ;    // HIP traversal kernel only: hits on a MixMaterial, resolved by the kernel that follows it
     uint32_t *routeCode;  // HIP traversal kernel only (split routing): per ray slot, the hit primitive's routing code | ROUTE_SKIP
+    int32_t *deferQ;    // HIP traversal kernels only: rays (indices into the ray / shadow queue) whose triangle walk met a quadric / patch / curve leaf
     int32_t *retraceQ;  // HIP traversal kernel only: rays whose closest hit was a near-tie (wf_traverse.h), re-traced in reference order
     unsigned long long *retraceQ64;  // the same for the kernels that drain the queue themselves: ray index | bound bits << 32, ~0 = not yet written
     int32_t *matQ[WF_MAT_NTYPES];

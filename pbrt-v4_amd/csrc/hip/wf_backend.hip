@@ -21,8 +21,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -96,7 +99,12 @@ struct wf_ctx {
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves and alpha on quadrics, 3 anything (see GeneralPrims)
     int persistentGrid = 1024;   // resident workgroups for the persistent traversal kernels (closest-hit variant of the scene)
     int persistentGridShadow = 1024;
-    static bool splitRouteWanted() { return !getenv("WF_SPLIT_ROUTE") || atoi(getenv("WF_SPLIT_ROUTE")) != 0; }
+    // TWO-CLASS TRAVERSAL (round 6): the triangle kernels (genTri = 0 | 1, in their handing-over variants) walk every ray, the general
+    // kernels (genMode >= 2) only the rays handed to deferQ; persistentGrid / persistentGridShadow are then the triangle kernels' grids
+    bool deferGeneral = false;
+    int genTri = 0;
+    int persistentGridGen = 1024, persistentGridShadowGen = 1024;
+    static bool splitRouteWanted() { return true; }
     // ray-coherence pass (SortRayQueue): bit 0 sorts the ray queue before the closest-hit launch of depth >= 1, bit 1 the shadow queue
     int raySort = 0;
     int cursorChunk = 2;         // 64-ray batches a wave takes per cursor fetch (WF_CURSOR_CHUNK): 1 is best on the 10 M-triangle scene
@@ -379,9 +387,22 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
     float u = (a <= 0) ? 1.f : HashToFloat(Hash6f(V3{ox, oy, oz}, V3{dx, dy, dz}));
     return !(u > a);
 }
-template <typename Fetch, int GEN>
+// ---- TWO-CLASS TRAVERSAL (round 6) ----------------------------------------------------------------------------------------------
+// Until round 5 ONE quadric, patch or curve anywhere in a scene moved every ray onto the general-primitive walk kernels (GEN >= 2: the
+// shape intersectors inline, 165-260 VGPRs, a separate near-tie re-trace launch): the 10 M-triangle scene plus one sphere rendered 1.56x
+// slower.  Now the triangle kernels (GEN 0 / 1) walk such a scene first in their DEFER variants (template value 4 + GEN): a walk that
+// meets a leaf entry of the other class (LeafTri c.z == 3) stops and hands its ray to `deferQ`; a second, small launch of the general
+// kernel walks only those rays, from the start.  A ray that is not handed over never had such a primitive's leaf box within its
+// pruning bound — a superset of the primitives that could have been its hit or a near-tie partner of its hit (the wide band of a pair
+// that involves such a shape only matters to candidates NEARER than the triangle hit: wf_traverse.h) — so both classes of rays end
+// with the result the general kernel alone computes.  The reference keeps such shapes in acceleration structures of their own too
+// (gpu/optix/aggregate.cpp:916-1025: one GAS per shape class under the root IAS).
+constexpr int GenBase(int g) { return g >= 4 ? g - 4 : g; }
+constexpr bool GenDefer(int g) { return g >= 4; }
+template <typename Fetch, int GEN, bool DEFER = false>
 struct GeneralPrims {
     static constexpr bool pairBands = GEN >= 2;   // quadrics / patches / curves in the scene: the near-tie band depends on the pair (wf_traverse.h)
+    static constexpr bool deferGeneral = DEFER;
     const SceneView &sv;
     const FastBVH &bvh;
     const RayWalk &w;
@@ -404,12 +425,21 @@ struct GeneralPrims {
     __device__ void exact(RayWalk &wm) const { WalkMakeExact(bvh, wm, WorldRayO(), WorldRayD()); }
 };
 // the two-level walk of a scene without alpha cut-outs or quadrics: only the lazy instance transition's hook (wf_traverse.h)
+template <bool DEFER = false>
 struct InstOnlyPrims {
     static constexpr bool pairBands = false;
+    static constexpr bool deferGeneral = DEFER;
     const FastBVH &bvh;
     __device__ bool accept(int, float, float, float) const { return true; }
     __device__ bool sphere(int, float, QuadricHit *) const { return false; }
     __device__ void exact(RayWalk &wm) const { WalkMakeExact(bvh, wm, WorldRayO(), WorldRayD()); }
+};
+struct DeferOnlyPrims {   // the one-level triangle walk of a scene that also holds primitives of the other class
+    static constexpr bool pairBands = false;
+    static constexpr bool deferGeneral = true;
+    __device__ bool accept(int, float, float, float) const { return true; }
+    __device__ bool sphere(int, float, QuadricHit *) const { return false; }
+    __device__ void exact(RayWalk &) const {}
 };
 // The part of a "while-while" iteration that follows the interior descent: every lane sits at a leaf run, at an instance transition
 // (an instance entry popped from the stack, or the NODE_EXIT marker) or is done.  Leaves are processed first; the transitions —
@@ -422,8 +452,10 @@ struct InstOnlyPrims {
 #define WF_TRANS_BATCH 6   // spec scene, 16 spp, same box (gpurun_out/r3f_ab_sm16.txt): closest / any-hit 60.1 / 22.0 ms at 0, 56.5 / 20.2 at 6, 58.4 / 20.5 at 12, 62.4 / 21.1 at 24
 #endif
 __device__ inline bool AtTransition(int node) { return node < 0 && node != NODE_NONE && (node == NODE_EXIT || (int)((~(unsigned)node) >> 4) >= INST_FIRST); }
-template <bool ANY, int GEN, bool INST, typename Fetch>
+template <bool ANY, int GENX, bool INST, typename Fetch>
 __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWalk &w, LdsStackT &st, const Fetch &fetch, int idx) {
+    constexpr int GEN = GenBase(GENX);
+    constexpr bool DF = GenDefer(GENX);
     if constexpr (INST) {
         bool tr = AtTransition(w.node);
         // (round 4, WF_LAZY_INST) a lane that sits at a leaf while its ray state is not exact for the space it walks (RayWalk::lazy)
@@ -432,8 +464,8 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
         // loop, lane by lane, the lazy transition LOST: closest 49.4 vs 45.0 ms, any-hit 26.1 vs 23.0)
         const bool owes = WF_LAZY_INST && w.node != NODE_NONE && !tr && WF_LAZY_GET(w) != 0;
         if (w.node != NODE_NONE && !tr && !owes) {
-            if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
-            else LeafStep<ANY, false, true>(bvh, w, st, InstOnlyPrims{bvh});
+            if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF>{sv, bvh, w, fetch, idx});
+            else LeafStep<ANY, false, true>(bvh, w, st, InstOnlyPrims<DF>{bvh});
         }
         if constexpr (WF_TRANS_BATCH > 0) {
             tr = AtTransition(w.node);
@@ -444,11 +476,17 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
         if (owes) WalkMakeExact(bvh, w, WorldRayO(), WorldRayD());   // (its leaf is processed in the next iteration)
         else if (tr) {
             const V3 o = WorldRayO(), d = WorldRayD();
+#if WF_FUSE_EXIT_ENTER
+            if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
+            if (IsInstanceEntry(w.node)) EnterInstance(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST);   // (also the entry an exit has just popped)
+#else
             if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
             else EnterInstance(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST);
+#endif
         }
     } else if (w.node != NODE_NONE) {
-        if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN>{sv, bvh, w, fetch, idx});
+        if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF>{sv, bvh, w, fetch, idx});
+        else if constexpr (DF) LeafStep<ANY, false, false>(bvh, w, st, DeferOnlyPrims{});
         else LeafStep<ANY>(bvh, w, st);
     }
 }
@@ -494,6 +532,9 @@ __device__ inline __attribute__((always_inline)) bool RefOrderTree(const SceneVi
                             continue;
                         }
                     }
+                    // (a quadric / patch / curve — only in the scenes of the two-class traversal — cannot decide a near tie between the
+                    //  triangles of a ray that was not handed to the general walk: it lies beyond their band)
+                    if (tri >= sv.nTriangles) continue;
                     V3 p0, p1, p2;
                     TriVerts(sv, tri, &p0, &p1, &p2);
                     TriHit h;
@@ -599,13 +640,13 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
             }
             LeafPhase<ANY, GEN, INST>(sv, bvh, w, st, fetch, idx);
         }
-        if constexpr (!ANY && RetraceInline(GEN)) {
+        if constexpr (!ANY && RetraceInline(GenBase(GEN))) {
             if (valid && WalkAmbiguous(w)) {
                 V3 o, d;
                 float t0;
                 fetch(idx, &o, &d, &t0);
                 const float tB = __builtin_fminf(2 * WalkBound(bvh, WalkT(w)) - WalkT(w), t0);
-                const RefHit rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+                const RefHit rh = RetraceRefOrder<GenBase(GEN)>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
                 w.prim = rh.prim; w.inst = rh.inst; w.route = rh.route;
                 w.tMax = rh.t; w.b0 = rh.b0; w.b1 = rh.b1; w.b2 = rh.b2;
             }
@@ -652,13 +693,13 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
     auto retire = [&]() {
         // DEFER: `finish` queues a near-tie ray and the kernel resolves it after its walks (DrainRetrace) — the reference-order walk inlined HERE
         // costs the closest-hit kernel 37 % (76.9 vs 56.0 ms per 16 spp on the spec scene), without it the refill gains 28 % (40.3 ms)
-        if constexpr (!ANY && RetraceInline(GEN) && !DEFER) {
+        if constexpr (!ANY && RetraceInline(GenBase(GEN)) && !DEFER) {
             if (WalkAmbiguous(w)) {
                 V3 o, d;
                 float t0;
                 fetch(idx, &o, &d, &t0);
                 const float tB = __builtin_fminf(2 * WalkBound(bvh, WalkT(w)) - WalkT(w), t0);
-                const RefHit rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+                const RefHit rh = RetraceRefOrder<GenBase(GEN)>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
                 w.prim = rh.prim; w.inst = rh.inst; w.route = rh.route;
                 w.tMax = rh.t; w.b0 = rh.b0; w.b1 = rh.b1; w.b2 = rh.b2;
             }
@@ -738,7 +779,7 @@ __device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n
                                   int workBlocks = 0) {
     // (the closest-hit walk of scenes with general primitives, GEN >= 2: its near-ties go to the separate re-trace launch anyway, so the
     //  refill loop carries no reference-order walk — WF_REFILL_GEN2, round 4)
-    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : (DEFER || WF_REFILL_INLINE != 0 || (WF_REFILL_GEN2 != 0 && !RetraceInline(GEN))))) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
+    if constexpr (PERLANE && (ANY ? WF_REFILL_SHADOW != 0 : (DEFER || WF_REFILL_INLINE != 0 || (WF_REFILL_GEN2 != 0 && !RetraceInline(GenBase(GEN)))))) BatchTraceRefill<ANY, GEN, INST, DEFER>(sv, bvh, n, st, fetch, finish, cursor, chunk, workBlocks);
     else BatchTrace<ANY, GEN, INST>(sv, bvh, n, st, fetch, finish, cursor, chunk);
 }
 // The near-tie rays of a closest-hit launch, resolved inside the launch (round 3, second step).  A walk that ends on a near-tie publishes
@@ -853,11 +894,15 @@ constexpr uint32_t ROUTE_SKIP = 0x80000000u;   // near-tie: the re-trace routes 
 // (round 5: with alpha textures on curves the GEN = 3 kernels reach the curve intersector through the alpha recursion as well — a chain of
 //  out-of-line callees the compiler gives 200+ VGPRs; it reported "final occupancy is 2" for every target above, and at a target of 4 the
 //  kernels spilled carriers again: their target is what they get)
-constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : gen >= 3 ? 2 : triangleWaves; }
-template <int GEN, bool INST = false, bool SPLIT = false>
-__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView svArg, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+constexpr int TWavesFor(int gen, int triangleWaves) { return gen == 2 && WF_TWAVES_GEN2 > 0 ? WF_TWAVES_GEN2 : gen == 3 ? 2 : triangleWaves; }
+// GENX: 0 - 3 as above; 4 / 5 = GEN 0 / 1 handing rays that meet a quadric / patch / curve to `deferQ` (TWO-CLASS TRAVERSAL).
+// list != nullptr: walk the rays list[0 .. counters[CNT_DEFER]) of the queue instead of all of it (the second launch of that scheme).
+template <int GENX, bool INST = false, bool SPLIT = false>
+__global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GENX), INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST)) k_closest_fast(const SceneView svArg, WorkState ws, FastBVH bvh, int cur, SpillArea sp, int *cursor = nullptr, int chunk = 4, const int *list = nullptr) {
+    constexpr int GEN = GenBase(GENX);
     const SceneView &sv = SvOf<false>(svArg);
-    const int n = ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
+    if constexpr (!SPLIT) list = nullptr;   // (only the launches of the routing-split path take a list)
+    const int n = list ? ws.counters[(CNT_DEFER) * CNT_STRIDE] : ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     const RayQueueV q = ws.rq[cur];
@@ -865,13 +910,21 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST :
     constexpr bool DRAIN = SPLIT && RetraceInline(GEN) && WF_REFILL_CLOSEST != 0 && WF_REFILL_INLINE == 0;
     const int workBlocks = DRAIN ? (int)gridDim.x - ServiceBlocks() : (int)gridDim.x;
     if (DRAIN && (int)blockIdx.x >= workBlocks) { DrainRetrace<GEN, INST>(sv, ws, bvh, cur, st, true); return; }   // a service workgroup
-    TraceQueue<false, GEN, INST, SPLIT, DRAIN>(
+    TraceQueue<false, GENX, INST, SPLIT, DRAIN>(
         sv, bvh, n, st,
-        [&](int i, V3 *o, V3 *d, float *tMax) {
+        [&](int i0, V3 *o, V3 *d, float *tMax) {
+            const int i = list ? list[i0] : i0;
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
         },
-        [&](int i, bool valid, const RayWalk &w) {
+        [&](int i0, bool valid, const RayWalk &w) {
+            const int i = (list && valid) ? list[i0] : i0;
+            if constexpr (GenDefer(GENX) && SPLIT)
+                if (valid && (w.route & WALK_DEFER)) {   // the general-primitive launch walks this ray (and writes its record)
+                    ws.deferQ[QueueAlloc(&ws.counters[(CNT_DEFER) * CNT_STRIDE])] = i;
+                    ws.routeCode[i] = ROUTE_SKIP;
+                    return;
+                }
             // near-tie seen (wf_traverse.h): the reference-order walk decides (k_closest_retrace)
             const bool amb = valid && WalkAmbiguous(w);
             if (amb) {
@@ -1046,18 +1099,28 @@ __global__ void __launch_bounds__(BLOCK) k_subsurface_scatter(const SceneView sv
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSubsurfaceScatter(sv, ws, cur, i);
 }
 template <int GEN, bool INST = false>
-__global__ void __launch_bounds__(TBLOCK, TWavesFor(GEN, INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES)) k_shadow_fast(const SceneView svArg, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4) {
+__global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GEN), INST ? WF_TWAVES_INST_SHADOW : WF_TWAVES)) k_shadow_fast(const SceneView svArg, WorkState ws, FastBVH bvh, SpillArea sp, int *cursor = nullptr, int chunk = 4, const int *list = nullptr) {
     const SceneView &sv = SvOf<false>(svArg);
-    const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
+    const int n = list ? ws.counters[(CNT_DEFER_SHADOW) * CNT_STRIDE] : ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
     TraceQueue<true, GEN, INST, true>(
         sv, bvh, n, st,
-        [&](int i, V3 *o, V3 *d, float *tMax) {
+        [&](int i0, V3 *o, V3 *d, float *tMax) {
+            const int i = list ? list[i0] : i0;
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
         },
-        [&](int i, bool valid, const RayWalk &w) { if (valid) KRecordShadowRay(ws, i, w.prim >= 0); }, cursor, chunk);
+        [&](int i0, bool valid, const RayWalk &w) {
+            if (!valid) return;
+            const int i = list ? list[i0] : i0;
+            if constexpr (GenDefer(GEN))
+                if (w.route & WALK_DEFER) {   // (the walk stops at its first occluder: a ray handed over has none among the triangles before the leaf it met)
+                    ws.deferQ[QueueAlloc(&ws.counters[(CNT_DEFER_SHADOW) * CNT_STRIDE])] = i;
+                    return;
+                }
+            KRecordShadowRay(ws, i, w.prim >= 0);
+        }, cursor, chunk);
 }
 
 // GENERAL: the scene has alpha-tested triangles or quadrics (the variant the render uses then)
@@ -1139,6 +1202,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_tr(const SceneView sv, WorkSta
 // ratio tracking, so there is no batch to share)
 struct TrPrims {  // the same callbacks for the transmittance walk, whose ray is a local of its loop
     static constexpr bool pairBands = true;   // (a per-lane loop over whole scenes, general shapes included)
+    static constexpr bool deferGeneral = false;
     const SceneView &sv;
     V3 o, d;
     __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
@@ -1420,13 +1484,22 @@ struct Prof {
             else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<3, false>), __VA_ARGS__); } \
         }                                                                                                      \
     } while (0)
-// the closest-hit walk with the routing split off (ctx->splitRoute)
-#define LAUNCHT_CLOSEST_SPLIT(name, ...)                                                                       \
+// ... and with the variant given (GENV = 0 .. 3, or 4 / 5: the handing-over triangle kernels of the two-class traversal)
+#define LAUNCHT_VARIANT_GEN(name, KERNEL, GENV, ...)                                                           \
     do {                                                                                                       \
-        const int gen_ = ctx->genMode;                                                                         \
+        const int gen_ = (GENV);                                                                               \
         const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
-        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<3, true, true>), __VA_ARGS__); } \
-        else { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, false, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, false, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, false, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<3, false, true>), __VA_ARGS__); } \
+        if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (KERNEL<3, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (KERNEL<4, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<5, true>), __VA_ARGS__); } \
+        else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (KERNEL<3, false>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (KERNEL<4, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<5, false>), __VA_ARGS__); } \
+    } while (0)
+// the closest-hit walk with the routing split off (ctx->splitRoute)
+#define LAUNCHT_CLOSEST_SPLIT(name, ...) LAUNCHT_CLOSEST_SPLIT_GEN(name, ctx->genMode, __VA_ARGS__)
+#define LAUNCHT_CLOSEST_SPLIT_GEN(name, GENV, ...)                                                             \
+    do {                                                                                                       \
+        const int gen_ = (GENV);                                                                               \
+        const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
+        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (k_closest_fast<3, true, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (k_closest_fast<4, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<5, true, true>), __VA_ARGS__); } \
+        else { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, false, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, false, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, false, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (k_closest_fast<3, false, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (k_closest_fast<4, false, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<5, false, true>), __VA_ARGS__); } \
     } while (0)
 #define LAUNCHT(name, kernel, grid, ...)                                                   \
     do {                                                                                   \
@@ -1469,9 +1542,120 @@ static int checkReady(wf_ctx *ctx) {
 // numbering per tree, quantised child boxes on the tree's own grid) + LeafTri (vertices in leaf order).  The top-level
 // tree comes first; every instance definition's tree follows with its own grid (FastDef).  See wf_traverse.h.
 struct FastDepths { int top = 0, def = 0, maxLeafInstances = 0; };   // levels of the four-wide trees (top level / deepest definition), most instances in one leaf
-static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, std::vector<FastDef> *defs, FastBVH *out, FastDepths *depths) {
-    const wf_bvh_node *L = d->bvh_nodes;
-    const int n = d->n_bvh_nodes;
+// ---- the top-level tree of a two-level scene, rebuilt over RE-BRAIDED instances (round 6; SubEntry in wf_traverse.h) ----
+// One primitive of the builder: a top-level triangle / quadric (its LeafTri record of the scene's leaf order) or an instance entry.
+struct TopPrim {
+    float b[6];
+    int kind;   // 0: the LeafTri record `idx` of the reference's leaf order; 1: instance entry `idx` (FastBVH::subs)
+    int idx;
+};
+// Binned SAH (16 bins on the axis of the largest centroid extent, the reference's cost model: cpu/aggregates.cpp:270-370 — this tree is
+// the production walk's own, nothing is pinned to it), written as reference-layout nodes (depth first: left child = i + 1, right child =
+// offset) so that the four-wide collapse and the quantisation below take it like a reference tree.  A leaf holds at most four LeafTri
+// records; an instance entry is always a leaf of its own, referenced by the node itself (offset = INST_FIRST + entry: the walk pops
+// the entry without a LeafTri fetch).  `order` receives the primitives in leaf order.
+struct TopTreeBuilder {
+    std::vector<TopPrim> &P;
+    std::vector<wf_bvh_node> &out;
+    int leafBase;   // LeafTri index of P[0] in the new leaf order
+    static double Area(const float b[6]) {
+        const double dx = (double)b[3] - b[0], dy = (double)b[4] - b[1], dz = (double)b[5] - b[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    int Build(int lo, int hi) {
+        const int me = (int)out.size();
+        out.emplace_back();
+        float bb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, cb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        bool anyEntry = false;
+        for (int i = lo; i < hi; ++i) {
+            const TopPrim &p = P[i];
+            anyEntry = anyEntry || p.kind == 1;
+            for (int a = 0; a < 3; ++a) {
+                bb[a] = std::min(bb[a], p.b[a]); bb[3 + a] = std::max(bb[3 + a], p.b[3 + a]);
+                const float c = 0.5f * p.b[a] + 0.5f * p.b[3 + a];
+                cb[a] = std::min(cb[a], c); cb[3 + a] = std::max(cb[3 + a], c);
+            }
+        }
+        const int count = hi - lo;
+        auto makeLeaf = [&]() {
+            wf_bvh_node &nd = out[me];
+            for (int a = 0; a < 3; ++a) { nd.bmin[a] = bb[a]; nd.bmax[a] = bb[3 + a]; }
+            nd.axis = 0; nd.pad = 0;
+            nd.nprims = (uint16_t)count;
+            nd.offset = (count == 1 && P[lo].kind == 1) ? INST_FIRST + P[lo].idx : leafBase + lo;
+            return me;
+        };
+        if (count == 1) return makeLeaf();
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (cb[3 + a] - cb[a] > cb[3 + axis] - cb[axis]) axis = a;
+        int mid = (lo + hi) / 2;
+        const float cmin = cb[axis], cext = cb[3 + axis] - cb[axis];
+        bool split = false;
+        if (cext > 0) {
+            constexpr int NB = 16;
+            int cnt[NB] = {};
+            float bbox[NB][6];
+            for (int k = 0; k < NB; ++k) for (int a = 0; a < 3; ++a) { bbox[k][a] = INFINITY; bbox[k][3 + a] = -INFINITY; }
+            auto binOf = [&](const TopPrim &p) {
+                const float c = 0.5f * p.b[axis] + 0.5f * p.b[3 + axis];
+                int k = (int)(NB * ((c - cmin) / cext));
+                return k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+            };
+            for (int i = lo; i < hi; ++i) {
+                const int k = binOf(P[i]);
+                ++cnt[k];
+                for (int a = 0; a < 3; ++a) { bbox[k][a] = std::min(bbox[k][a], P[i].b[a]); bbox[k][3 + a] = std::max(bbox[k][3 + a], P[i].b[3 + a]); }
+            }
+            double costR[NB] = {};
+            {
+                float r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int c = 0;
+                for (int k = NB - 1; k >= 1; --k) {
+                    if (cnt[k]) for (int a = 0; a < 3; ++a) { r[a] = std::min(r[a], bbox[k][a]); r[3 + a] = std::max(r[3 + a], bbox[k][3 + a]); }
+                    c += cnt[k];
+                    costR[k] = c ? c * Area(r) : 0;
+                }
+            }
+            float l[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int c = 0, best = -1;
+            double bestCost = 0;
+            for (int k = 0; k + 1 < NB; ++k) {
+                if (cnt[k]) for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], bbox[k][a]); l[3 + a] = std::max(l[3 + a], bbox[k][3 + a]); }
+                c += cnt[k];
+                if (c == 0 || c == count) continue;
+                const double cost = c * Area(l) + costR[k + 1];
+                if (best < 0 || cost < bestCost) { best = k; bestCost = cost; }
+            }
+            if (best >= 0) {
+                const double area = Area(bb);
+                const double minCost = 0.5 + (area > 0 ? bestCost / area : 0);
+                if (count <= 4 && !anyEntry && !(minCost < count)) return makeLeaf();
+                TopPrim *m = std::partition(P.data() + lo, P.data() + hi, [&](const TopPrim &p) { return binOf(p) <= best; });
+                mid = (int)(m - P.data());
+                split = mid > lo && mid < hi;
+            }
+        }
+        if (!split) {
+            // coincident centroids: up to four records share a leaf, more (or any instance entry) are dealt half and half
+            if (count <= 4 && !anyEntry) return makeLeaf();
+            mid = (lo + hi) / 2;
+        }
+        Build(lo, mid);
+        const int right = Build(mid, hi);
+        wf_bvh_node &nd = out[me];
+        for (int a = 0; a < 3; ++a) { nd.bmin[a] = bb[a]; nd.bmax[a] = bb[3 + a]; }
+        nd.axis = (uint8_t)axis; nd.pad = 0;
+        nd.nprims = 0;
+        nd.offset = right;
+        return me;
+    }
+};
+
+static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std::vector<LeafTri> *tris, std::vector<FastDef> *defs, std::vector<SubEntry> *subs,
+                         FastBVH *out, FastDepths *depths) {
+    const wf_bvh_node *L = d->bvh_nodes;   // (rebound to the extended array once the re-braided top-level tree has been appended)
+    int n = d->n_bvh_nodes;
+    const int nRef = n;                    // nodes of the reference's trees
     const int nGeom = d->n_triangles + d->n_quadrics;
     const int nPrims = nGeom + d->n_instances;  // entries of bvh_prims: every triangle / quadric once, every instance once
     if (n == 0 || (size_t)nPrims >= (size_t)INST_FIRST || d->n_instances >= INST_FIRST) return false;
@@ -1529,10 +1713,13 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     int collapse = 1;
     if (const char *e = getenv("WF_LEAF_COLLAPSE")) collapse = std::min(16, std::max(1, atoi(e)));
     std::vector<int> subFirst(n), subCount(n);
-    for (int i = n - 1; i >= 0; --i) {
-        if (L[i].nprims > 0) { subFirst[i] = L[i].offset; subCount[i] = L[i].nprims; }
-        else { subFirst[i] = subFirst[i + 1]; subCount[i] = subCount[i + 1] + subCount[L[i].offset]; }
-    }
+    auto fillSubRanges = [&](int from, int to) {   // nodes [from, to): a complete set of depth-first trees
+        for (int i = to - 1; i >= from; --i) {
+            if (L[i].nprims > 0) { subFirst[i] = L[i].offset; subCount[i] = L[i].nprims; }
+            else { subFirst[i] = subFirst[i + 1]; subCount[i] = subCount[i + 1] + subCount[L[i].offset]; }
+        }
+    };
+    fillSubRanges(0, n);
     auto leafLike = [&](int i) { return L[i].nprims > 0 || subCount[i] <= collapse; };
     // TIGHT INSTANCE BOXES (round 5).  The reference bounds an instance by the box of the eight transformed corners of its definition's
     // box (TransformedPrimitive::Bounds) — for a rotated definition up to three times the surface area of the box of the transformed
@@ -1541,8 +1728,13 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     // definition, the box of the definition's transformed vertices (widened by 2^-18 of the magnitudes involved: the transform's rounding
     // and the instance-space ray's), clipped to the reference's box, and interior boxes re-united bottom-up.  Topology, leaves and the
     // reference-layout nodes (counting kernels, near-tie re-walk, CPU checker) are untouched: same hits, fewer entries.  WF_TIGHT_INSTANCES=0: off.
+    // WF_BRAID = most entries one instance is opened into (round 6, SubEntry in wf_traverse.h; 0: one entry per instance in the reference's
+    // own top-level tree, as in round 5)
+    int braidMax = 0;   // (measured on the spec scene, profiles/r06_rebraid_ab_sm16.txt: see DESIGN 4.1 — off by default)
+    if (const char *e = getenv("WF_BRAID")) braidMax = std::min(256, std::max(0, atoi(e)));
+    const bool braid = braidMax > 0 && d->n_instances > 0 && d->n_top_bvh_nodes > 0 && L[0].nprims == 0;
     std::vector<wf_bvh_node> tightTop;
-    if (d->n_instances > 0 && d->n_top_bvh_nodes > 0 && !(getenv("WF_TIGHT_INSTANCES") && atoi(getenv("WF_TIGHT_INSTANCES")) == 0)) {
+    if (!braid && d->n_instances > 0 && d->n_top_bvh_nodes > 0 && !(getenv("WF_TIGHT_INSTANCES") && atoi(getenv("WF_TIGHT_INSTANCES")) == 0)) {
         const int nTop = d->n_top_bvh_nodes;
         std::vector<std::vector<int32_t>> defVerts((size_t)d->n_instance_defs);
         std::vector<char> defGeneral((size_t)d->n_instance_defs, 0);
@@ -1615,6 +1807,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     auto BoxOf = [&](int i) -> const wf_bvh_node & { return (!tightTop.empty() && i < (int)tightTop.size()) ? tightTop[i] : L[i]; };
     // one tree: linear nodes [root, ...) reachable from root; grid written to base / cell; returns the root's QNode index
     int lastTreeDepth = 0;   // levels of the four-wide tree buildTree made last (a single leaf-like root: 1)
+    std::vector<std::array<int, 4>> qKids;   // per QNode: the reference-layout nodes its four children stand for (-1: empty slot)
     auto buildTree = [&](int root, float baseOut[3], float cellOut[3]) -> int {
         lastTreeDepth = 1;
         // Quantisation grid over the root bounds.  A plane is the REAL number base + q * cell (the device never forms
@@ -1672,6 +1865,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             qn.child[0] = leafRef(root);
             for (int c = 1; c < 4; ++c) { emptyBox(qn.q, c); qn.child[c] = NODE_NONE; }
             nodes->push_back(qn);
+            qKids.push_back({root, -1, -1, -1});
             return qBase;
         }
         // four-way collapse of the binary tree: a node's children are its two binary children, the largest interior ones
@@ -1700,6 +1894,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             kidsOf.push_back(kids);
         }
         nodes->resize((size_t)qBase + order.size());
+        qKids.insert(qKids.end(), kidsOf.begin(), kidsOf.end());
         for (size_t h = 0; h < order.size(); ++h) {
             QNode qn{};
             for (int c = 0; c < 4; ++c) {
@@ -1746,14 +1941,197 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
 #endif
         return qBase;
     };
-    buildTree(0, out->base, out->cell);
-    depths->top = lastTreeDepth;
-    for (int i = 0; i < n; ++i)
+    // the definitions' trees first (the entries of the re-braided top-level tree name their nodes), then the top-level tree; afterwards
+    // the top-level tree is moved to the FRONT of the array: the walk starts at node 0 and caches nodes [0, TOP_NODES) in LDS
+    for (int i = 0; i < nRef; ++i)
         if (leafLike(i)) {
             int ni = 0;
             for (int k = 0; k < subCount[i]; ++k) ni += d->bvh_prims[subFirst[i] + k] >= nGeom;
             depths->maxLeafInstances = std::max(depths->maxLeafInstances, ni);
         }
+    defs->clear();
+    for (int k = 0; k < d->n_instance_defs; ++k) {
+        FastDef fd{};
+        fd.root = d->instance_defs[k].bvh_root >= 0 ? buildTree(d->instance_defs[k].bvh_root, fd.base, fd.cell) : -1;
+        if (d->instance_defs[k].bvh_root >= 0) depths->def = std::max(depths->def, lastTreeDepth);
+        defs->push_back(fd);
+    }
+    const int nDefQ = (int)nodes->size();
+    subs->clear();
+    std::vector<wf_bvh_node> Lx;
+    int topRoot = 0;
+    if (braid && WF_BVH4) {
+        // ---- partial re-braiding: the entries of every instance
+        const int nTop = d->n_top_bvh_nodes;
+        std::vector<char> defGeneral((size_t)d->n_instance_defs, 0);
+        for (int k = 0; k < d->n_instance_defs; ++k) {
+            const wf_instance_def &def = d->instance_defs[k];
+            if (def.bvh_root < 0 || def.n_prims <= 0) { defGeneral[k] = 1; continue; }
+            for (int j = def.first_prim; j < def.first_prim + def.n_prims; ++j)
+                if (d->bvh_prims[j] >= d->n_triangles) { defGeneral[k] = 1; break; }
+        }
+        double sceneMag = 0;
+        for (int a = 0; a < 3; ++a) sceneMag = std::max(sceneMag, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
+        struct Entry { int bnode; float b[6]; };
+        std::vector<std::vector<Entry>> entriesOf((size_t)d->n_instances);
+        // the box of a definition's subtree under an instance's transformation: its triangles' transformed vertices (double arithmetic),
+        // widened by 2^-18 of the magnitudes involved plus 2^-19 of the SCENE's (the instance-space ray the reference decides hits with
+        // carries the rounding of the render-space ray's origin and of the distance travelled — ADVICE r5: not of the instance's own
+        // coordinates only)
+        auto subtreeBox = [&](const wf_instance &in, int bnode, float b[6]) {
+            const float(*m)[4] = in.render_from_instance.m;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, mag = 0;
+            for (int j = subFirst[bnode]; j < subFirst[bnode] + subCount[bnode]; ++j) {
+                const LeafTri &lt = (*tris)[j];
+                const float v[3][3] = {{lt.a.x, lt.a.y, lt.a.z}, {lt.a.w, lt.b.x, lt.b.y}, {lt.b.z, lt.b.w, lt.c.x}};
+                for (int q = 0; q < 3; ++q)
+                    for (int a = 0; a < 3; ++a) {
+                        const double t0 = (double)m[a][0] * v[q][0], t1 = (double)m[a][1] * v[q][1], t2 = (double)m[a][2] * v[q][2];
+                        const double c = t0 + t1 + t2 + (double)m[a][3];
+                        lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
+                        mag = std::max(mag, std::fabs(t0) + std::fabs(t1) + std::fabs(t2) + std::fabs((double)m[a][3]));
+                    }
+            }
+            bool finite = true;
+            for (int a = 0; a < 3; ++a) {
+                const double pad = 0x1p-18 * (mag + (hi[a] - lo[a])) + 0x1p-19 * sceneMag + 1e-30;
+                b[a] = (float)(lo[a] - pad); b[3 + a] = (float)(hi[a] + pad);
+                if (!((double)b[a] <= lo[a] - 0.5 * pad)) b[a] = NextFloatDown(b[a]);
+                if (!((double)b[3 + a] >= hi[a] + 0.5 * pad)) b[3 + a] = NextFloatUp(b[3 + a]);
+                finite = finite && std::isfinite(b[a]) && std::isfinite(b[3 + a]);
+            }
+            return finite;
+        };
+        auto refOf = [&](int bnode) { return leafLike(bnode) ? (int)~(((unsigned)subFirst[bnode] << 4) | (unsigned)(subCount[bnode] - 1)) : bfsIndex[bnode]; };
+        double minFrac = 1.0 / 64;   // an entry smaller than this fraction of the instance's own box is not opened further
+        if (const char *e = getenv("WF_BRAID_MIN_FRAC")) minFrac = atof(e);
+        auto openInstance = [&](int i) {
+            const wf_instance &in = d->instances[i];
+            std::vector<Entry> &es = entriesOf[i];
+            if (in.def < 0 || in.def >= d->n_instance_defs || defGeneral[in.def]) return;
+            const float(*m)[4] = in.render_from_instance.m;
+            if (m[3][0] != 0 || m[3][1] != 0 || m[3][2] != 0 || m[3][3] != 1) return;
+            Entry root;
+            root.bnode = d->instance_defs[in.def].bvh_root;
+            if (!subtreeBox(in, root.bnode, root.b)) return;
+            const double rootArea = TopTreeBuilder::Area(root.b);
+            es.push_back(root);
+            while ((int)es.size() < braidMax) {
+                int best = -1;
+                double bestArea = minFrac * rootArea;
+                for (int k = 0; k < (int)es.size(); ++k) {
+                    if (leafLike(es[k].bnode)) continue;
+                    const double ar = TopTreeBuilder::Area(es[k].b);
+                    if (ar > bestArea) { best = k; bestArea = ar; }
+                }
+                if (best < 0) break;
+                const std::array<int, 4> &kids = qKids[(size_t)bfsIndex[es[best].bnode]];
+                int nk = 0;
+                for (int c = 0; c < 4; ++c) nk += kids[c] >= 0;
+                if ((int)es.size() - 1 + nk > braidMax) break;
+                Entry ch[4];
+                bool ok = true;
+                int w = 0;
+                for (int c = 0; c < 4 && ok; ++c)
+                    if (kids[c] >= 0) { ch[w].bnode = kids[c]; ok = subtreeBox(in, kids[c], ch[w].b); ++w; }
+                if (!ok) break;
+                es[best] = ch[0];
+                for (int c = 1; c < w; ++c) es.push_back(ch[c]);
+            }
+        };
+        {
+            unsigned nThreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+            if ((unsigned)d->n_instances < 4 * nThreads) nThreads = 1;
+            std::atomic<int> next{0};
+            auto worker = [&]() { for (int i; (i = next.fetch_add(1)) < d->n_instances;) openInstance(i); };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
+            worker();
+            for (std::thread &t : pool) t.join();
+        }
+        // ---- the primitives of the new top-level tree, in the reference's leaf order (deterministic)
+        std::vector<TopPrim> P;
+        P.reserve((size_t)subCount[0] + (size_t)d->n_instances * 4);
+        for (int i = 0; i < nTop; ++i) {
+            if (L[i].nprims == 0) continue;
+            for (int j = L[i].offset; j < L[i].offset + L[i].nprims; ++j) {
+                const int t = d->bvh_prims[j];
+                TopPrim p;
+                if (t < d->n_triangles) {
+                    const LeafTri &lt = (*tris)[j];
+                    const float v[3][3] = {{lt.a.x, lt.a.y, lt.a.z}, {lt.a.w, lt.b.x, lt.b.y}, {lt.b.z, lt.b.w, lt.c.x}};
+                    for (int a = 0; a < 3; ++a) { p.b[a] = std::min(v[0][a], std::min(v[1][a], v[2][a])); p.b[3 + a] = std::max(v[0][a], std::max(v[1][a], v[2][a])); }
+                    p.kind = 0; p.idx = j;
+                    P.push_back(p);
+                } else if (t < nGeom) {   // a quadric / patch / curve: the reference's leaf box bounds it
+                    for (int a = 0; a < 3; ++a) { p.b[a] = L[i].bmin[a]; p.b[3 + a] = L[i].bmax[a]; }
+                    p.kind = 0; p.idx = j;
+                    P.push_back(p);
+                } else {
+                    const int ii = t - nGeom;
+                    const wf_instance &in = d->instances[ii];
+                    if (entriesOf[ii].empty()) {   // left alone (general primitives inside, a projective matrix): one entry at the definition's root, the reference's leaf box
+                        for (int a = 0; a < 3; ++a) { p.b[a] = L[i].bmin[a]; p.b[3 + a] = L[i].bmax[a]; }
+                        p.kind = 1; p.idx = (int)subs->size();
+                        const int root = (in.def >= 0 && in.def < d->n_instance_defs) ? d->instance_defs[in.def].bvh_root : -1;
+                        subs->push_back(SubEntry{ii, root >= 0 ? refOf(root) : NODE_NONE});
+                        P.push_back(p);
+                    } else
+                        for (const Entry &e : entriesOf[ii]) {
+                            for (int a = 0; a < 6; ++a) p.b[a] = e.b[a];
+                            p.kind = 1; p.idx = (int)subs->size();
+                            subs->push_back(SubEntry{ii, refOf(e.bnode)});
+                            P.push_back(p);
+                        }
+                }
+            }
+        }
+        if (P.empty() || subs->size() >= (size_t)INST_FIRST) return false;
+        // ---- the tree, as reference-layout nodes behind the reference's own
+        const int leafBase = (int)tris->size();
+        Lx.assign(L, L + n);
+        TopTreeBuilder tb{P, Lx, leafBase};
+        // (node indices of the builder are positions in Lx: it appends)
+        topRoot = tb.Build(0, (int)P.size());
+        tris->resize((size_t)leafBase + P.size());
+        for (size_t k = 0; k < P.size(); ++k) {
+            if (P[k].kind == 0) (*tris)[(size_t)leafBase + k] = (*tris)[(size_t)P[k].idx];
+            else (*tris)[(size_t)leafBase + k].c = F4{0, BitsToFloat((uint32_t)P[k].idx), 4.f, BitsToFloat(0u)};   // (never read: an entry is a leaf of its own)
+        }
+        if (tris->size() >= (size_t)INST_FIRST) return false;
+        L = Lx.data();
+        n = (int)Lx.size();
+        subFirst.resize(n); subCount.resize(n); bfsIndex.resize(n, -1);
+        fillSubRanges(nRef, n);
+        if (const char *e = getenv("WF_BRAID_VERBOSE")) if (atoi(e)) fprintf(stderr, "[wf] re-braided top-level tree: %d instances -> %zu entries, %zu primitives, %d nodes\n", d->n_instances, subs->size(), P.size(), n - nRef);
+    } else {
+        // one entry per instance, at its definition's root
+        for (int i = 0; i < d->n_instances; ++i) {
+            const int def = d->instances[i].def;
+            const int root = (def >= 0 && def < d->n_instance_defs) ? d->instance_defs[def].bvh_root : -1;
+            subs->push_back(SubEntry{i, root < 0 ? NODE_NONE : (leafLike(root) ? (int)~(((unsigned)subFirst[root] << 4) | (unsigned)(subCount[root] - 1)) : bfsIndex[root])});
+        }
+    }
+    buildTree(topRoot, out->base, out->cell);
+    depths->top = lastTreeDepth;
+    {
+        // the top-level tree to the front
+        const int nAll = (int)nodes->size(), nTopQ = nAll - nDefQ;
+        auto remap = [&](int r) { return r < 0 ? r : (r >= nDefQ ? r - nDefQ : r + nTopQ); };
+        std::vector<QNode> moved((size_t)nAll);
+        for (int i = 0; i < nAll; ++i) {
+            QNode qn = (*nodes)[(size_t)i];
+#if WF_BVH4
+            for (int c = 0; c < 4; ++c) qn.child[c] = remap(qn.child[c]);
+#else
+            qn.left = remap(qn.left); qn.right = remap(qn.right);
+#endif
+            moved[(size_t)remap(i)] = qn;
+        }
+        nodes->swap(moved);
+        for (FastDef &fd : *defs) fd.root = fd.root < 0 ? 0 : remap(fd.root);
+        for (SubEntry &se : *subs) se.node = remap(se.node);
+    }
     {
         double ext = 0;
         for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
@@ -1764,22 +2142,179 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         out->tieRelTri = (float)(1 + 0x1p-20);
         out->firstGeneral = d->n_quadrics > 0 ? d->n_triangles : INT_MAX;
     }
-    defs->clear();
-    for (int k = 0; k < d->n_instance_defs; ++k) {
-        FastDef fd{};
-        fd.root = d->instance_defs[k].bvh_root >= 0 ? buildTree(d->instance_defs[k].bvh_root, fd.base, fd.cell) : 0;
-        if (d->instance_defs[k].bvh_root >= 0) depths->def = std::max(depths->def, lastTreeDepth);
-        defs->push_back(fd);
-    }
     if (!gridOk) return false;
     out->nNodes = (int)nodes->size();
     return true;
 }
 
+// ---- host-only self-check of the production layout (wf_debug_fastbvh_check; CPU suite) ----------------------------------------------
+// Walks the QNode / LeafTri / SubEntry arrays on the HOST with random rays, in double arithmetic and without pruning by distance, and
+// checks that every triangle a ray really hits (brute force over the top-level triangles and every (instance, triangle) pair, in the
+// instance's space) is among the triangles the walk tests — the one property the production tree owes (wf_traverse.h: "a superset of
+// visited nodes, the exact triangle test decides").  No device is needed: BuildFastBVH is host code.
+namespace {
+struct CheckWalk {
+    const std::vector<QNode> &nodes;
+    const std::vector<LeafTri> &tris;
+    const std::vector<FastDef> &defs;
+    const std::vector<SubEntry> &subs;
+    const wf_scene_desc *d;
+    const FastBVH &top;
+    std::vector<std::pair<int, int>> tested;   // (triangle id, instance or -1)
+    long long nodesVisited = 0, entries = 0;
+    static bool Slab(const float base[3], const float cell[3], const uint32_t q[3], const double o[3], const double dir[3]) {
+        double t0 = 0, t1 = 1e300;
+        for (int a = 0; a < 3; ++a) {
+            const double lo = (double)base[a] + (double)(q[a] & 0xffffu) * (double)cell[a], hi = (double)base[a] + (double)(q[a] >> 16) * (double)cell[a];
+            if (lo > hi) return false;   // an empty slot
+            if (dir[a] == 0) { if (o[a] < lo || o[a] > hi) return false; continue; }
+            double tn = (lo - o[a]) / dir[a], tf = (hi - o[a]) / dir[a];
+            if (tn > tf) std::swap(tn, tf);
+            t0 = std::max(t0, tn); t1 = std::min(t1, tf);
+        }
+        return t0 <= t1;
+    }
+    void Leaf(int ref, int inst, const double o[3], const double dir[3]) {
+        const unsigned r = ~(unsigned)ref;
+        const int first = (int)(r >> 4), count = (int)(r & 15u) + 1;
+        if (first >= INST_FIRST) { Enter(first - INST_FIRST, o, dir); return; }
+        for (int i = 0; i < count; ++i) {
+            const LeafTri &lt = tris[(size_t)first + i];
+            if (lt.c.z == 4.f) { if (inst < 0) Enter((int)FloatToBits(lt.c.y), o, dir); continue; }
+            tested.push_back({(int)FloatToBits(lt.c.y), inst});
+        }
+    }
+    void Tree(int ref, const float base[3], const float cell[3], int inst, const double o[3], const double dir[3]) {
+        std::vector<int> st{ref};
+        while (!st.empty()) {
+            const int r = st.back();
+            st.pop_back();
+            if (r == NODE_NONE) continue;
+            if (r < 0) { Leaf(r, inst, o, dir); continue; }
+            ++nodesVisited;
+            const QNode &qn = nodes[(size_t)r];
+#if WF_BVH4
+            for (int c = 0; c < 4; ++c)
+                if (qn.child[c] != NODE_NONE && Slab(base, cell, qn.q + 3 * c, o, dir)) st.push_back(qn.child[c]);
+#else
+            if (Slab(base, cell, qn.q, o, dir)) st.push_back(qn.left);
+            if (Slab(base, cell, qn.q + 3, o, dir)) st.push_back(qn.right);
+#endif
+        }
+    }
+    void Enter(int entry, const double oW[3], const double dW[3]) {
+        ++entries;
+        const SubEntry se = subs[(size_t)entry];
+        if (se.node == NODE_NONE) return;
+        const wf_instance &in = d->instances[se.inst];
+        const float(*mi)[4] = in.render_from_instance.mInv;
+        double o[3], dir[3];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = (double)mi[a][0] * oW[0] + (double)mi[a][1] * oW[1] + (double)mi[a][2] * oW[2] + (double)mi[a][3];
+            dir[a] = (double)mi[a][0] * dW[0] + (double)mi[a][1] * dW[1] + (double)mi[a][2] * dW[2];
+        }
+        const FastDef &fd = defs[(size_t)in.def];
+        Tree(se.node, fd.base, fd.cell, se.inst, o, dir);
+    }
+};
+// does the ray hit the triangle well inside (barycentrics > eps, in front of the origin)?  Moeller-Trumbore in double arithmetic
+bool HitsClearly(const double o[3], const double dir[3], const float *p0, const float *p1, const float *p2) {
+    double e1[3], e2[3], pv[3], tv[3], qv[3];
+    for (int a = 0; a < 3; ++a) { e1[a] = (double)p1[a] - p0[a]; e2[a] = (double)p2[a] - p0[a]; tv[a] = o[a] - p0[a]; }
+    pv[0] = dir[1] * e2[2] - dir[2] * e2[1]; pv[1] = dir[2] * e2[0] - dir[0] * e2[2]; pv[2] = dir[0] * e2[1] - dir[1] * e2[0];
+    const double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    const double scale = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) * (e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]) * (dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]));
+    if (!(std::fabs(det) > 1e-9 * scale)) return false;
+    const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+    qv[0] = tv[1] * e1[2] - tv[2] * e1[1]; qv[1] = tv[2] * e1[0] - tv[0] * e1[2]; qv[2] = tv[0] * e1[1] - tv[1] * e1[0];
+    const double v = (dir[0] * qv[0] + dir[1] * qv[1] + dir[2] * qv[2]) / det;
+    const double t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+    return u > 1e-4 && v > 1e-4 && u + v < 1 - 1e-4 && t > 1e-6;
+}
+}  // namespace
+
 extern "C" {
 
 const char *wf_last_error(void) { return g_err; }
 int wf_abi_version(void) { return WF_ABI_VERSION; }
+
+int wf_debug_fastbvh_check(const wf_scene_desc *d, int n_rays, uint64_t seed, int64_t out[8]) {
+    if (!d || !out || n_rays < 0) return fail(-1, "wf_debug_fastbvh_check: bad arguments");
+    std::vector<QNode> qn;
+    std::vector<LeafTri> lt;
+    std::vector<FastDef> fdefs;
+    std::vector<SubEntry> fsubs;
+    FastBVH fast{};
+    FastDepths fdep;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    if (!BuildFastBVH(d, &qn, &lt, &fdefs, &fsubs, &fast, &fdep)) return fail(-1, "wf_debug_fastbvh_check: the scene has no production layout");
+    out[0] = (int64_t)qn.size(); out[1] = (int64_t)lt.size(); out[2] = (int64_t)fsubs.size(); out[3] = fdep.top;
+    // structure: every child reference names a node / a leaf run / an entry inside the arrays
+    for (size_t i = 0; i < qn.size(); ++i)
+#if WF_BVH4
+        for (int c = 0; c < 4; ++c) {
+            const int r = qn[i].child[c];
+#else
+        for (int c = 0; c < 2; ++c) {
+            const int r = c ? qn[i].right : qn[i].left;
+#endif
+            if (r == NODE_NONE) continue;
+            if (r >= 0) { if ((size_t)r >= qn.size()) return fail(-1, "wf_debug_fastbvh_check: node %zu child %d out of range", i, c); continue; }
+            const unsigned u = ~(unsigned)r;
+            const size_t first = u >> 4, count = (u & 15u) + 1;
+            if (first >= (size_t)INST_FIRST ? first - INST_FIRST >= fsubs.size() : first + count > lt.size()) return fail(-1, "wf_debug_fastbvh_check: node %zu child %d: leaf run out of range", i, c);
+        }
+    for (const SubEntry &se : fsubs)
+        if (se.inst < 0 || se.inst >= d->n_instances || (se.node >= 0 && (size_t)se.node >= qn.size())) return fail(-1, "wf_debug_fastbvh_check: entry out of range");
+    // coverage with random rays through the scene's box
+    uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
+    const wf_bvh_node &root = d->bvh_nodes[0];
+    CheckWalk cw{qn, lt, fdefs, fsubs, d, fast, {}};
+    const int nGeom = d->n_triangles + d->n_quadrics;
+    for (int r = 0; r < n_rays; ++r) {
+        double o[3], dir[3], tgt[3];
+        for (int a = 0; a < 3; ++a) {
+            const double lo = root.bmin[a], hi = root.bmax[a], ext = hi - lo;
+            o[a] = lo - 0.1 * ext + 1.2 * ext * rnd();
+            tgt[a] = lo + ext * rnd();
+            dir[a] = tgt[a] - o[a];
+        }
+        cw.tested.clear();
+        cw.Tree(0, fast.base, fast.cell, -1, o, dir);
+        std::sort(cw.tested.begin(), cw.tested.end());
+        out[6] += (int64_t)cw.tested.size();
+        auto check = [&](int tri, int inst, const double oo[3], const double dd[3]) {
+            const int32_t *v = d->tri_indices + 3 * (size_t)tri;
+            if (!HitsClearly(oo, dd, d->P + 3 * (size_t)v[0], d->P + 3 * (size_t)v[1], d->P + 3 * (size_t)v[2])) return;
+            ++out[4];
+            if (!std::binary_search(cw.tested.begin(), cw.tested.end(), std::make_pair(tri, inst))) ++out[5];
+        };
+        // the top-level primitives and, per instance, its definition's
+        int nTopPrims = 0;
+        for (int i = 0; i < (d->n_top_bvh_nodes > 0 ? d->n_top_bvh_nodes : d->n_bvh_nodes); ++i) nTopPrims += d->bvh_nodes[i].nprims;
+        for (int j = 0; j < nTopPrims; ++j) {
+            const int t = d->bvh_prims[j];
+            if (t < d->n_triangles) { check(t, -1, o, dir); continue; }
+            if (t < nGeom) continue;
+            const int ii = t - nGeom;
+            const wf_instance &in = d->instances[ii];
+            if (in.def < 0 || in.def >= d->n_instance_defs) continue;
+            const float(*mi)[4] = in.render_from_instance.mInv;
+            double oI[3], dI[3];
+            for (int a = 0; a < 3; ++a) {
+                oI[a] = (double)mi[a][0] * o[0] + (double)mi[a][1] * o[1] + (double)mi[a][2] * o[2] + (double)mi[a][3];
+                dI[a] = (double)mi[a][0] * dir[0] + (double)mi[a][1] * dir[1] + (double)mi[a][2] * dir[2];
+            }
+            const wf_instance_def &def = d->instance_defs[in.def];
+            for (int k = def.first_prim; k < def.first_prim + def.n_prims; ++k)
+                if (d->bvh_prims[k] < d->n_triangles) check(d->bvh_prims[k], ii, oI, dI);
+        }
+    }
+    out[7] = cw.entries;
+    out[3] = cw.nodesVisited;
+    return 0;
+}
 
 // The stream's scratch (private segment) grows whenever a kernel needs more per lane than any kernel before it; on about a third of the
 // pool's boxes every such growth costs the launch that triggers it 20-30 ms (round 4: the first frame of a process took 200 ms instead of
@@ -2071,19 +2606,31 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         {
             ctx->genMode = 0;
             if (d->n_quadrics > 0) ctx->genMode = (sv.haveCurves || sv.haveQuadricAlpha) ? 3 : 2;
-            for (int i = 0; i < d->n_meshes && ctx->genMode < 2; ++i)
+            int alphaGen = 0;   // what the TRIANGLES of the scene ask of the walk: 0 nothing, 1 simple alpha cut-outs, 2 texture-graph alpha
+            for (int i = 0; i < d->n_meshes && alphaGen < 2; ++i)
                 if (d->meshes[i].alpha_tex >= 0) {
                     const int tt = d->textures[d->meshes[i].alpha_tex].type;
                     // the inline test looks an image map up without a footprint (MIPFilterFloatZeroP): uv-mapped, not EWA-filtered
                     const wf_texture &at = d->textures[d->meshes[i].alpha_tex];
                     const bool lean = tt == WF_TEX_FLOAT_CONSTANT || (at.mapping == WF_TEXMAP_UV && (tt != WF_TEX_FLOAT_IMAGE || d->tex_images[at.i0].filter != WF_MIP_EWA));
-                    ctx->genMode = std::max(ctx->genMode, ((tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) && lean) ? 1 : 2);
+                    alphaGen = std::max(alphaGen, ((tt == WF_TEX_FLOAT_CONSTANT || tt == WF_TEX_FLOAT_IMAGE || tt == WF_TEX_FLOAT_BILERP) && lean) ? 1 : 2);
                 }
+            ctx->genMode = std::max(ctx->genMode, alphaGen);
             if (getenv("WF_GEN_MODE")) ctx->genMode = std::max(ctx->genMode, atoi(getenv("WF_GEN_MODE")));  // timing experiments: force the general variant
+            // TWO-CLASS TRAVERSAL: the scene's quadrics / patches / curves are few beside its triangles, and the triangles themselves need no
+            // more than the simple alpha test — the triangle kernels walk first, the general kernels only the rays handed over
+            // (WF_DEFER_GENERAL=1 | 0 forces / forbids it for any scene with such shapes)
+            ctx->genTri = std::min(alphaGen, 1);
+            ctx->deferGeneral = false;
+            if (d->n_quadrics > 0 && alphaGen <= 1 && ctx->genMode >= 2 && wf_ctx::splitRouteWanted()) {
+                const bool few = (int64_t)d->n_quadrics * 16 <= (int64_t)d->n_triangles;
+                ctx->deferGeneral = getenv("WF_DEFER_GENERAL") ? atoi(getenv("WF_DEFER_GENERAL")) != 0 : few;
+            }
         }
         std::vector<FastDef> fdefs;
+        std::vector<SubEntry> fsubs;
         FastDepths fdep;
-        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &ctx->fast, &fdep);
+        ctx->fastOk = BuildFastBVH(d, &qn, &lt, &fdefs, &fsubs, &ctx->fast, &fdep);
         {
             // traversal stacks: LDS entries per lane + rows of `stackSpill` behind them, sized from the trees' ACTUAL depths: the
             // reference-order walk pushes one sibling per level of the reference's binary trees (top level, then an instance
@@ -2119,6 +2666,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if ((e = devUpload(ctx, &ctx->fast.nodes, qn.data(), qn.size()))) return e;
             if ((e = devUpload(ctx, &ctx->fast.tris, lt.data(), lt.size()))) return e;
             if ((e = devUpload(ctx, &ctx->fast.defs, fdefs.data(), fdefs.size()))) return e;
+            if ((e = devUpload(ctx, &ctx->fast.subs, fsubs.data(), fsubs.size()))) return e;
             // rays of a scene whose trees do not fit the caches walk long enough for one cursor fetch per 64 rays (measured: -3 % on
             // the 10 M-triangle scene); a cache-resident scene traces so fast that the cursor's atomics would bound it (see cursorChunk)
             if (!getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = (qn.size() * sizeof(QNode) + lt.size() * sizeof(LeafTri) > ((size_t)256 << 20)) ? 1 : 2;
@@ -2143,11 +2691,18 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             const void *kc, *ks;
 #define WF_PICK(K, ...) (inst ? (gen == 0 ? (const void *)K<0, true __VA_ARGS__> : gen == 1 ? (const void *)K<1, true __VA_ARGS__> : gen == 2 ? (const void *)K<2, true __VA_ARGS__> : (const void *)K<3, true __VA_ARGS__>) \
                               : (gen == 0 ? (const void *)K<0, false __VA_ARGS__> : gen == 1 ? (const void *)K<1, false __VA_ARGS__> : gen == 2 ? (const void *)K<2, false __VA_ARGS__> : (const void *)K<3, false __VA_ARGS__>))
-            if (split) kc = WF_PICK(k_closest_fast, , true);
-            else kc = WF_PICK(k_closest_fast, , false);
+            (void)split;
+            kc = WF_PICK(k_closest_fast, , true);
             ks = WF_PICK(k_shadow_fast);
 #undef WF_PICK
             if ((e = residentGrid(kc, &ctx->persistentGrid)) || (e = residentGrid(ks, &ctx->persistentGridShadow))) return e;
+            if (ctx->deferGeneral) {
+                ctx->persistentGridGen = ctx->persistentGrid; ctx->persistentGridShadowGen = ctx->persistentGridShadow;
+                const bool t1 = ctx->genTri == 1;
+                kc = inst ? (t1 ? (const void *)k_closest_fast<5, true, true> : (const void *)k_closest_fast<4, true, true>) : (t1 ? (const void *)k_closest_fast<5, false, true> : (const void *)k_closest_fast<4, false, true>);
+                ks = inst ? (t1 ? (const void *)k_shadow_fast<5, true> : (const void *)k_shadow_fast<4, true>) : (t1 ? (const void *)k_shadow_fast<5, false> : (const void *)k_shadow_fast<4, false>);
+                if ((e = residentGrid(kc, &ctx->persistentGrid)) || (e = residentGrid(ks, &ctx->persistentGridShadow))) return e;
+            }
         }
         if (getenv("WF_NO_FAST")) ctx->fastOk = false;
         if (d->n_animated > 0) ctx->fastOk = false;   // AnimatedPrimitive: the reference-order walks interpolate the transformation per ray; the production walk does not
@@ -2240,6 +2795,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     if (ctx->svHost.haveMix && ((e = devAlloc(ctx, &ws.mixMat, n)) || (e = devAlloc(ctx, &ws.mixQ, n)))) return e;
     if (ctx->svHost.haveSubsurface && ((e = devAlloc(ctx, &ws.samples2, n)) || (e = devAlloc(ctx, &ws.bssrdfQ, n)) || (e = devAlloc(ctx, &ws.sssQ, n)))) return e;
     if ((e = devAlloc(ctx, &ws.hit, n)) || (e = devAlloc(ctx, &ws.escapedQ, n)) || (e = devAlloc(ctx, &ws.hitLightQ, n)) || (e = devAlloc(ctx, &ws.retraceQ, n)) || (e = devAlloc(ctx, &ws.retraceQ64, n))) return e;
+    if ((e = devAlloc(ctx, &ws.deferQ, n))) return e;
     HIPCHK(hipMemset(ws.retraceQ64, 0xff, (size_t)n * sizeof(unsigned long long)));   // every slot "not yet written"
     if (ctx->svHost.nInstances > 0 && (e = devAlloc(ctx, &ws.hitInst, n))) return e;
     for (int m = 0; m < WF_MAT_NTYPES; ++m)
@@ -2260,7 +2816,9 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
         for (int m = 1; m < WF_MAT_NTYPES; ++m) if (ctx->matPresent[m]) planes = std::max(planes, NeePlanes(m));
         if (planes > 0 && (e = devAlloc(ctx, &ws.neeRec, n * (size_t)planes))) return e;
     }
-    ctx->splitRoute = getenv("WF_SPLIT_ROUTE") ? atoi(getenv("WF_SPLIT_ROUTE")) : 2;
+    // (round 6: WF_SPLIT_ROUTE=0 — the walk routing its hits per workgroup, the round-2 path — is gone: its kernel variants were the ones that
+    //  kept tripping the spill-carrier lint whenever anything near them changed; 1 = no work cursor, 2 = the default)
+    ctx->splitRoute = getenv("WF_SPLIT_ROUTE") ? std::max(1, atoi(getenv("WF_SPLIT_ROUTE"))) : 2;
     if (getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = std::max(1, atoi(getenv("WF_CURSOR_CHUNK")));  // (default: chosen at scene upload)
     if (ctx->splitRoute && (e = devAlloc(ctx, &ws.routeCode, n))) return e;
     ctx->raySort = getenv("WF_RAY_SORT") ? atoi(getenv("WF_RAY_SORT")) : 0;
@@ -2341,7 +2899,7 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
     mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE) | (1u << CNT_BSSRDF) | (1u << CNT_SSS);
-    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE) | (1u << CNT_CURSOR) | (1u << CNT_MEDIUM_ROUTE);
+    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE) | (1u << CNT_CURSOR) | (1u << CNT_MEDIUM_ROUTE) | (1u << CNT_DEFER);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + statDepth(depth), CNT_RAY0 + cur);
     ctx->cursorDirty[0] = false;
@@ -2426,7 +2984,12 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
             }
             ctx->ws.drainEpoch = (ctx->ws.drainEpoch + 1) & 0x7fffffff;   // tag of this launch's near-tie queue entries (DrainRetrace)
             if (ctx->ws.drainEpoch == 0) ctx->ws.drainEpoch = 1;
-            LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk);
+            if (ctx->deferGeneral) {
+                // TWO-CLASS TRAVERSAL: every ray through the triangle kernel; the rays it hands over (deferQ) through the general kernel
+                LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest", 4 + ctx->genTri, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
+                LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest: rays that met a general primitive", ctx->genMode, ctx->persistentGridGen, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), (int *)nullptr, ctx->cursorChunk, (const int *)ctx->ws.deferQ);
+            } else
+            LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
             // The near-tie re-trace of the scenes whose walk does not resolve its ties itself (genMode >= 2: quadrics, curves, texture-graph
             // alpha; RetraceInline) is a handful of long single walks: it runs on a second stream beside the routing pass (and, in the
             // fused pass, the next sample-generation launch) — they touch disjoint rays and share only the queue counters, through
@@ -2445,8 +3008,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
                 if (ctx->genMode > 1 || ctx->svHost.nInstances > 0) hipLaunchKernelGGL(k_route_hits<true>, dim3(g), dim3(RBLOCK), 0, ctx->stream, ctx->svHost, ctx->ws, depth & 1);
                 else hipLaunchKernelGGL(k_route_hits<false>, dim3(g), dim3(RBLOCK), 0, ctx->stream, ctx->svHost, ctx->ws, depth & 1);
             }
-        } else
-        LAUNCHT_VARIANT("Intersect closest", k_closest_fast, 0, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea());
+        }
         if (ctx->retracePending) {
             if (ctx->deferJoin) return 0;   // the fused pass joins after its sample-generation launch (JoinRetrace)
             if (int e = JoinRetrace(ctx)) return e;
@@ -2632,12 +3194,16 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
             if (ctx->cursorDirty[1]) HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
             ctx->cursorDirty[1] = true;
         }
-        LAUNCHT_VARIANT("Intersect shadow", k_shadow_fast, 0, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk);
+        if (ctx->deferGeneral && ctx->splitRoute) {
+            LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, 4 + ctx->genTri, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
+            LAUNCHT_VARIANT_GEN("Intersect shadow: rays that met a general primitive", k_shadow_fast, ctx->genMode, ctx->persistentGridShadowGen, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), (int *)nullptr, ctx->cursorChunk, (const int *)ctx->ws.deferQ);
+        } else
+        LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, ctx->genMode, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
     } else
         { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow", (k_intersect_shadow<false, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
           else LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill); }
     // "Reset shadowRayQueue": stats->shadowRays[depth] += size; Reset (integrator.cpp:581-585)
-    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW) | (1u << CNT_CURSOR_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
+    LAUNCH("Reset shadowRayQueue", k_reset, 1, ctx->ws, (1u << CNT_SHADOW) | (1u << CNT_CURSOR_SHADOW) | (1u << CNT_DEFER_SHADOW), 65 + statDepth(depth), CNT_SHADOW);
     ctx->cursorDirty[1] = false;
     return 0;
 }

@@ -127,6 +127,7 @@ struct FastBVH {
     float tieRelTri, absBandTri;
     int firstGeneral;
     const struct FastDef *defs;       // per instance definition (scenes with object instances)
+    const struct SubEntry *subs;      // the instance entries of the top-level tree (round 6: partial re-braiding, see SubEntry)
     const wf_instance *instances;
     const SceneView *sv;              // device-resident copy of the scene view, for the out-of-line general-primitive callbacks
 };
@@ -135,8 +136,22 @@ struct FastDef {
     float base[3], cell[3];  // its quantisation grid
     int pad;
 };
-constexpr int INST_FIRST = 1 << 26;          // leaf references with first >= INST_FIRST: object instance (first - INST_FIRST)
+// An ENTRY of the top-level tree into an object instance (round 6).  Until round 5 an instance was one leaf entry of the top-level tree,
+// bounded by one box, and its walk started at the definition's root: on the spec scene a ray entered eight instances and six of the
+// visits ended without a primitive test — the box of a cluster of objects is mostly empty, and every visit pays the reference's
+// interval-arithmetic ray transform twice (in and out).  PARTIAL RE-BRAIDING (Benthin, Woop, Wald, Afra: "Improved two-level BVHs using
+// partial re-braiding", HPG 2017): the top-level tree is built over the instances OPENED a few levels into their definitions' trees —
+// an entry is (instance, node of the definition's production tree), bounded by the box of that subtree's transformed vertices — so
+// the top-level tree separates the objects of a cluster, and a ray changes spaces only for subtrees whose own box it meets.  The walk
+// inside is the same; only its starting node differs.  Which triangles can be reached is a superset of the reference's hits as
+// before (the exact triangle test decides, near ties are re-walked in the reference's order).
+struct SubEntry {
+    int inst;   // wf_instance index
+    int node;   // where the walk starts in the definition's production tree: QNode index (>= 0) or a leaf reference (< 0)
+};
+constexpr int INST_FIRST = 1 << 26;          // leaf references with first >= INST_FIRST: instance entry (first - INST_FIRST) of FastBVH::subs
 constexpr int NODE_EXIT = (int)0x80000001;   // stack marker: leave the instance (the world tMax is the entry below it)
+constexpr int INST_STALE = 1 << 30;          // RayWalk::inst flag while its instance is being re-visited (EnterInstance)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -270,11 +285,19 @@ __device__ inline bool InstancePretestMiss(const wf_instance &in, const FastDef 
     return !(t0 <= t1);   // (NaNs never skip)
 }
 template <typename Stack>
-__device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int inst) {
+__device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int entry) {
+    const SubEntry se = bvh.subs[entry];
+    const int inst = se.inst;
+    if (se.node == NODE_NONE) {   // an instance of an empty definition
+        WalkSetRay(bvh.base, bvh.cell, w, oW, dW);   // (a fused exit may have left the previous instance's constants: ExitInstance)
+        w.node = st.empty() ? NODE_NONE : st.pop();
+        return false;
+    }
     const wf_instance &in = bvh.instances[inst];
     const FastDef fd = bvh.defs[in.def];
 #if WF_INST_PRETEST
     if (InstancePretestMiss(in, fd, oW, dW, WalkBound(bvh, __builtin_fabsf(w.tMax)))) {
+        WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
         w.node = st.empty() ? NODE_NONE : st.pop();
         return false;
     }
@@ -300,7 +323,7 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
             st.push(NODE_EXIT);
             WalkSetSlab(fd.base, fd.cell, w, oI, dI);
             w.curInst = inst;
-            w.node = fd.root;
+            w.node = se.node;
             WF_LAZY_SET(w, 1);
             return true;
         }
@@ -313,8 +336,12 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
     st.push(NODE_EXIT);
     WalkSetRay(fd.base, fd.cell, w, oI, dI);
     w.tMax = (FloatToBits(w.tMax) >> 31) ? -tI : tI;
+    // (a re-braided instance is entered once per subtree the ray meets: the best hit so far may lie in THIS instance from an earlier
+    //  visit — marked stale, so that ExitInstance can tell a hit found during this visit, whose t becomes the render-space tMax as it
+    //  is, from none, after which the saved tMax is restored)
+    if (w.inst == inst) w.inst = inst | INST_STALE;
     w.curInst = inst;
-    w.node = fd.root;
+    w.node = se.node;
     WF_LAZY_SET(w, 0);
     return true;
 }
@@ -335,6 +362,12 @@ __device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 d
     }
     WF_LAZY_SET(w, 0);
 }
+// an instance ENTRY on the stack / in a child slot (not the exit marker)
+__device__ inline bool IsInstanceEntry(int node) { return node < 0 && node != NODE_NONE && node != NODE_EXIT && (int)((~(unsigned)node) >> 4) >= INST_FIRST; }
+#ifndef WF_FUSE_EXIT_ENTER
+#define WF_FUSE_EXIT_ENTER 1   // round 6: a lane that leaves an instance and pops another instance's entry enters it in the same step, and
+                               // the render-space shear / slab constants in between are not rebuilt (three IEEE divisions, three v_rcp)
+#endif
 template <typename Stack>
 __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW) {
     const float saved = BitsToFloat((uint32_t)st.pop());
@@ -342,15 +375,30 @@ __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V
     // si->tHit (cpu/primitive.cpp:112-125); otherwise the world tMax is restored.  Near-tie marks are kept either way.
     const float tW = (w.inst == w.curInst) ? __builtin_fabsf(w.tMax) : __builtin_fabsf(saved);
     const bool mark = ((FloatToBits(w.tMax) | FloatToBits(saved)) >> 31) != 0;
+    const int next = st.empty() ? NODE_NONE : st.pop();
+#if WF_FUSE_EXIT_ENTER
+    // the next entry on the stack is another subtree of the SAME instance (re-braided instances): the lane stays in the instance's space
+    // and walks on there — one visit for the reference too, whose tMax runs through the whole definition
+    if (IsInstanceEntry(next)) {
+        const SubEntry se = bvh.subs[(int)((~(unsigned)next) >> 4) - INST_FIRST];
+        if (se.inst == w.curInst && se.node != NODE_NONE) {
+            st.push((int)FloatToBits(saved));
+            st.push(NODE_EXIT);
+            w.node = se.node;
+            return;
+        }
+    }
+#endif
+    if (w.inst == (w.curInst | INST_STALE)) w.inst = w.curInst;   // the hit of an earlier visit of this instance stands
 #if WF_LAZY_INST
     WalkSetSlab(bvh.base, bvh.cell, w, oW, dW);   // the shear of the render-space ray when a top-level leaf asks for it (WalkMakeExact)
     WF_LAZY_SET(w, 2);
 #else
-    WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
+    if (!(WF_FUSE_EXIT_ENTER && IsInstanceEntry(next))) WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
 #endif
     w.tMax = mark ? -tW : tW;
     w.curInst = -1;
-    w.node = st.empty() ? NODE_NONE : st.pop();
+    w.node = next;
 }
 
 __device__ inline bool WalkAmbiguous(const RayWalk &w) { return (FloatToBits(w.tMax) >> 31) != 0; }
@@ -471,8 +519,12 @@ __device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, c
 // The general-primitive variants (ALPHA): leaf entries marked c.z == 2 are triangles whose mesh carries an alpha
 // texture (ex.accept(prim, b0, b1, b2) decides), entries marked c.z == 3 are spheres (ex.sphere(prim, tMax, &hit);
 // the hit's pObj travels in b0..b2).  Scenes without either use the plain variants, which never see the marks.
+// RayWalk::route bit: the walk met a leaf entry only the general-primitive kernels can test (a quadric / patch / curve: c.z == 3) and
+// stopped — the ray is walked again by those kernels (round 6, wf_backend.hip "TWO-CLASS TRAVERSAL").  Extra::deferGeneral selects it.
+constexpr uint32_t WALK_DEFER = 0x40000000u;
 struct NoExtra {
     static constexpr bool pairBands = false;
+    static constexpr bool deferGeneral = false;
     __device__ bool accept(int, float, float, float) const { return true; }
     __device__ bool sphere(int, float, QuadricHit *) const { return false; }
     __device__ void exact(RayWalk &) const {}
@@ -493,6 +545,8 @@ __device__ inline void LeafStep(const FastBVH &bvh, RayWalk &w, Stack &st, const
             }
         if constexpr (INST)
             if (WF_LAZY_GET(w)) ex.exact(w);   // the first primitive test since the walk changed spaces (WF_LAZY_INST)
+        if constexpr (Extra::deferGeneral)
+            if (tc.z == 3.f) { w.route |= WALK_DEFER; done = true; break; }
         // closest hit: test against the relaxed bound so that near-ties are seen (WalkAccept sorts them out)
         constexpr bool PAIRS = Extra::pairBands;
         if constexpr (ALPHA)

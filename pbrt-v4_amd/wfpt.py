@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_film_gather_strips", "wf_stats_add", "wf_material_items_download", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_kat_probe", "wf_queue_size", "wf_queue_download",
-    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters",
+    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters", "wf_debug_fastbvh_check",
     "wf_trace_closest_device", "wf_trace_any_device", "wf_device_alloc", "wf_device_free", "wf_device_upload", "wf_device_download", "wf_trace_shadow_tr_host",
 ]
 HOST_SYMBOLS = [
@@ -325,6 +325,18 @@ class Scene:
         out = np.empty((records.shape[0], 8), dtype=np.uint64)
         _check(hip.wf_kat_probe(self.ctx, records.shape[0], records.ctypes.data, out.ctypes.data), "wf_kat_probe")
         return out
+
+    def fastbvh_check(self, n_rays=32, seed=1):
+        """host-only self-check of the production traversal layout (wf_debug_fastbvh_check): needs no device.  Returns a dict."""
+        host, hip = libs()
+        out = (C.c_int64 * 8)()
+        hip.wf_debug_fastbvh_check.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_int64)]
+        rc = hip.wf_debug_fastbvh_check(host.wfh_scene_desc(self.h), n_rays, seed, out)
+        if rc != 0:
+            hip.wf_last_error.restype = C.c_char_p
+            raise WfError("wf_debug_fastbvh_check: " + hip.wf_last_error().decode())
+        keys = ["qnodes", "leaf_records", "entries", "nodes_visited", "true_hits", "missed", "tested", "entries_taken"]
+        return dict(zip(keys, [int(v) for v in out]))
 
     def enable_profile(self, on=True):
         _, hip = libs()
