@@ -716,6 +716,12 @@ int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, co
                           wf_hit_record *out, int count_visits);
 int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax,
                       int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested);
+/* ... with the rays' TIMES (round 6): the reference's WavefrontAggregate reads ray.time (integrator.h:32-54) and an AnimatedPrimitive
+   (cpu/primitive.cpp:132-158) is intersected with its transformation interpolated at that time.  On a scene with animated primitives
+   the untimed calls above and below (and wf_trace_shadow_tr_host / wf_trace_one_random_host) return an error instead of answering
+   for the start-time geometry; these two walk in the reference's order (cpu/aggregates.cpp:529-579) at time[i].  Any scene. */
+int wf_trace_closest_host_t(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const float *time, wf_hit_record *out);
+int wf_trace_any_host_t(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const float *time, int32_t *occluded);
 /* The same two calls on caller-owned DEVICE buffers (what a GPU-resident host integrator binds: its RayQueue / ShadowRayQueue stay on
    the device): rays7 = n x {o[3], d[3], tMax} floats, out = n records / n flags, all device pointers of the context's
    device; the launches go to the context's stream (wf_stream) and are NOT synchronised — order them with the stream.  The production

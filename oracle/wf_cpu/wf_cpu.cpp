@@ -278,6 +278,7 @@ int main(int argc, char **argv) {
 static int Main(int argc, char **argv) {
     RenderOptions opt;
     std::string scenePath, dumpFilm, dataDir, traceRays, traceHits, probeIn, probeOut, dumpStages;
+    bool traceTimed = false;
     bool emulateStaleDepth = false;   // g_msStaleDepth (wf_kernels.h): the reference's unwritten MediumSampleWorkItem::depth, sequential order only
     bool tracePath = false;   // print the path state after every stage (the lines oracle/_ref/ref_trace prints; tools/trace_diff.py)
     std::string lightProbeIn, lightProbeOut, reProbeIn, reProbeOut;
@@ -307,6 +308,7 @@ static int Main(int argc, char **argv) {
         else if (a == "--datadir") dataDir = next();
         else if (a == "--quiet") opt.quiet = true;
         else if (a == "--trace") { traceRays = next(); traceHits = next(); }
+        else if (a == "--trace-timed") { traceRays = next(); traceHits = next(); traceTimed = true; }   // records of 8 floats: o, d, tMax, time (AnimatedPrimitive)
         else if (a == "--dump-stages") dumpStages = next();
         else if (a == "--trace-path") tracePath = true;
         else if (a == "--emulate-stale-medium-depth") emulateStaleDepth = true;
@@ -486,16 +488,18 @@ static int Main(int argc, char **argv) {
         fseek(f, 0, SEEK_END);
         long sz = ftell(f);
         fseek(f, 0, SEEK_SET);
-        int n = (int)(sz / (7 * sizeof(float)));
-        std::vector<float> rays((size_t)n * 7);
+        const int rec = traceTimed ? 8 : 7;
+        int n = (int)(sz / (rec * sizeof(float)));
+        std::vector<float> rays((size_t)n * rec);
         if (fread(rays.data(), sizeof(float), rays.size(), f) != rays.size()) return 1;
         fclose(f);
         std::vector<wf_hit_record> hits(n);
         ParallelFor(n, [&](int i) {
-            const float *r = &rays[(size_t)i * 7];
+            const float *r = &rays[(size_t)i * rec];
             ArrayStack st;
             ClosestHit ch;
-            bool found = BVHIntersectClosest(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &ch);
+            bool found = traceTimed ? BVHIntersectClosest<true>(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &ch, r[7])
+                                    : BVHIntersectClosest(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &ch);
             wf_hit_record &h = hits[i];
             h.prim = found ? ch.prim : -1;
             h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;

@@ -1409,6 +1409,33 @@ __global__ void __launch_bounds__(BLOCK) k_trace_closest(const SceneView sv, int
         out[i] = h;
     }
 }
+// ... and at the rays' own TIMES (AnimatedPrimitive, cpu/primitive.cpp:132-158: the reference's WavefrontAggregate reads ray.time): the
+// reference-order walks with the per-ray interpolation of the animated transformations (wf_trace_*_host_t)
+__global__ void __launch_bounds__(BLOCK) k_trace_closest_timed(const SceneView sv, int n, const float *rays, const float *times, wf_hit_record *out, int *stackSpill) {
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride) {
+        const float *r = rays + (size_t)7 * i;
+        ClosestHit ch;
+        st.n = 0;
+        bool found = BVHIntersectClosest<true>(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &ch, times[i]);
+        wf_hit_record h;
+        h.prim = found ? ch.prim : -1;
+        h.t = found ? ch.h.t : 0; h.b0 = found ? ch.h.b0 : 0; h.b1 = found ? ch.h.b1 : 0; h.b2 = found ? ch.h.b2 : 0;
+        h.nodes_visited = ch.nodesVisited; h.tris_tested = ch.trisTested; h.instance = found ? ch.inst : -1;
+        out[i] = h;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_trace_any_timed(const SceneView sv, int n, const float *rays, const float *times, int32_t *occluded, int *stackSpill) {
+    const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    LdsStack st{stackSpill + gtid, stride, 0};
+    for (int i = gtid; i < n; i += stride) {
+        const float *r = rays + (size_t)7 * i;
+        int v = 0, t = 0;
+        st.n = 0;
+        occluded[i] = BVHIntersectAny<true>(sv, V3{r[0], r[1], r[2]}, V3{r[3], r[4], r[5]}, r[6], st, &v, &t, times[i]);
+    }
+}
 __global__ void __launch_bounds__(BLOCK) k_trace_any(const SceneView sv, int n, const float *rays, int32_t *occluded, int32_t *nodes, int32_t *tris, int *stackSpill) {
     const int gtid = blockIdx.x * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
     LdsStack st{stackSpill + gtid, stride, 0};
@@ -1730,7 +1757,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
     // reference-layout nodes (counting kernels, near-tie re-walk, CPU checker) are untouched: same hits, fewer entries.  WF_TIGHT_INSTANCES=0: off.
     // WF_BRAID = most entries one instance is opened into (round 6, SubEntry in wf_traverse.h; 0: one entry per instance in the reference's
     // own top-level tree, as in round 5)
-    int braidMax = 0;   // (measured on the spec scene, profiles/r06_rebraid_ab_sm16.txt: see DESIGN 4.1 — off by default)
+    int braidMax = 2;   // (measured on the spec scene, profiles/r06_rebraid_ab_sm16.txt: 2 is the optimum — DESIGN 4.1)
     if (const char *e = getenv("WF_BRAID")) braidMax = std::min(256, std::max(0, atoi(e)));
     const bool braid = braidMax > 0 && d->n_instances > 0 && d->n_top_bvh_nodes > 0 && L[0].nprims == 0;
     std::vector<wf_bvh_node> tightTop;
@@ -2986,7 +3013,11 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
             if (ctx->ws.drainEpoch == 0) ctx->ws.drainEpoch = 1;
             if (ctx->deferGeneral) {
                 // TWO-CLASS TRAVERSAL: every ray through the triangle kernel; the rays it hands over (deferQ) through the general kernel
-                LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest", 4 + ctx->genTri, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
+                // (the triangle kernels know one near-tie band: the triangles' own, 2^-20 — the scene-wide band of FastBVH is the wide one of
+                //  the pairs that involve a quadric, which only the general kernel's rays can meet)
+                FastBVH triFast = ctx->fast;
+                triFast.absBand = triFast.absBandTri; triFast.tieRel = triFast.tieRelTri;
+                LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest", 4 + ctx->genTri, ctx->persistentGrid, ctx->svHost, ctx->ws, triFast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
                 LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest: rays that met a general primitive", ctx->genMode, ctx->persistentGridGen, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), (int *)nullptr, ctx->cursorChunk, (const int *)ctx->ws.deferQ);
             } else
             LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
@@ -3462,6 +3493,7 @@ int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out) {
 
 int wf_trace_closest_device(wf_ctx *ctx, int n, const float *rays7, wf_hit_record *out) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (ctx->svHost.haveAnimated) return fail(-1, "%s: the scene has animated primitives — a ray needs its time (wf_trace_closest_host_t / wf_trace_any_host_t)", __func__);
     useDevice(ctx);
     if (n <= 0) return 0;
     if (!ctx->fastOk) { LAUNCH("trace closest (device rays)", k_trace_closest, gridFor(n), ctx->svHost, n, rays7, out, ctx->stackSpill, 0); return 0; }
@@ -3472,6 +3504,7 @@ int wf_trace_closest_device(wf_ctx *ctx, int n, const float *rays7, wf_hit_recor
 }
 int wf_trace_any_device(wf_ctx *ctx, int n, const float *rays7, int32_t *occluded) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (ctx->svHost.haveAnimated) return fail(-1, "%s: the scene has animated primitives — a ray needs its time (wf_trace_closest_host_t / wf_trace_any_host_t)", __func__);
     useDevice(ctx);
     if (n <= 0) return 0;
     if (!ctx->fastOk) { LAUNCH("trace any (device rays)", k_trace_any, gridFor(n), ctx->svHost, n, rays7, occluded, (int32_t *)nullptr, (int32_t *)nullptr, ctx->stackSpill); return 0; }
@@ -3504,6 +3537,7 @@ int wf_device_download(wf_ctx *ctx, void *dst_host, const void *src_device, uint
 }
 int wf_trace_closest_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, wf_hit_record *out, int count_visits) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (ctx->svHost.haveAnimated) return fail(-1, "%s: the scene has animated primitives — a ray needs its time (wf_trace_closest_host_t / wf_trace_any_host_t)", __func__);
     useDevice(ctx);
     if (n <= 0) return 0;
     std::vector<float> rays((size_t)n * 7);
@@ -3532,6 +3566,7 @@ int wf_trace_shadow_tr_host(wf_ctx *ctx, int n, const float *o, const float *d, 
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     useDevice(ctx);
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_trace_shadow_tr_host: the scene has no media");
+    if (ctx->svHost.haveAnimated) return fail(-1, "wf_trace_shadow_tr_host: the scene has animated primitives and this entry point carries no ray times (not supported)");
     if (n <= 0) return 0;
     std::vector<F4> ho(n), hd(n), hl(n), hp(n, F4{1, 1, 1, 1});
     for (int i = 0; i < n; ++i) {
@@ -3571,6 +3606,9 @@ int wf_trace_shadow_tr_host(wf_ctx *ctx, int n, const float *o, const float *d, 
 int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p1, const int32_t *material, wf_hit_record *out, float *reservoir_pdf) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
     useDevice(ctx);
+    // (the reference walks its subsurface probe segments at time 0, wavefront/subsurface.cpp:70: an animated scene would need that walk's
+    //  ANIM variant here — refused instead of answered for the start-time geometry)
+    if (ctx->svHost.haveAnimated) return fail(-1, "wf_trace_one_random_host: the scene has animated primitives (not supported by this entry point)");
     if (n <= 0) return 0;
     std::vector<float> segs((size_t)n * 6);
     for (int i = 0; i < n; ++i)
@@ -3593,6 +3631,7 @@ int wf_trace_one_random_host(wf_ctx *ctx, int n, const float *p0, const float *p
 }
 int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, int32_t *occluded, int32_t *nodes_visited, int32_t *tris_tested) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (ctx->svHost.haveAnimated) return fail(-1, "%s: the scene has animated primitives — a ray needs its time (wf_trace_closest_host_t / wf_trace_any_host_t)", __func__);
     useDevice(ctx);
     if (n <= 0) return 0;
     std::vector<float> rays((size_t)n * 7);
@@ -3615,6 +3654,41 @@ int wf_trace_any_host(wf_ctx *ctx, int n, const float *o, const float *d, const 
     HIPCHK(hipFree(dr));
     HIPCHK(hipFree(dres));
     return 0;
+}
+// IntersectClosest / IntersectShadow on caller-supplied rays WITH their times (the untimed entry points would walk an animated
+// scene at its start time): the reference-order walks, interpolating every AnimatedPrimitive's transformation at the ray's time
+static int TraceTimed(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const float *time, wf_hit_record *hits, int32_t *occluded) {
+    if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    if (!o || !d || !tmax || !time) return fail(-1, "wf_trace_*_host_t: null ray arrays");
+    useDevice(ctx);
+    if (n <= 0) return 0;
+    std::vector<float> rays((size_t)n * 8);
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { rays[(size_t)i * 7 + k] = o[3 * i + k]; rays[(size_t)i * 7 + 3 + k] = d[3 * i + k]; }
+        rays[(size_t)i * 7 + 6] = tmax[i];
+        rays[(size_t)n * 7 + i] = time[i];
+    }
+    float *dr = nullptr;
+    void *dres = nullptr;
+    const size_t resBytes = hits ? (size_t)n * sizeof(wf_hit_record) : (size_t)n * sizeof(int32_t);
+    HIPCHK(hipMalloc((void **)&dr, rays.size() * sizeof(float)));
+    HIPCHK(hipMalloc(&dres, resBytes));
+    HIPCHK(hipMemcpyAsync(dr, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (hits) LAUNCH("trace closest (host rays with times)", k_trace_closest_timed, gridFor(n), ctx->svHost, n, dr, dr + (size_t)n * 7, (wf_hit_record *)dres, ctx->stackSpill);
+    else LAUNCH("trace any (host rays with times)", k_trace_any_timed, gridFor(n), ctx->svHost, n, dr, dr + (size_t)n * 7, (int32_t *)dres, ctx->stackSpill);
+    HIPCHK(hipMemcpyAsync(hits ? (void *)hits : (void *)occluded, dres, resBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(dr));
+    HIPCHK(hipFree(dres));
+    return 0;
+}
+int wf_trace_closest_host_t(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const float *time, wf_hit_record *out) {
+    if (!out) return fail(-1, "wf_trace_closest_host_t: null out");
+    return TraceTimed(ctx, n, o, d, tmax, time, out, nullptr);
+}
+int wf_trace_any_host_t(wf_ctx *ctx, int n, const float *o, const float *d, const float *tmax, const float *time, int32_t *occluded) {
+    if (!occluded) return fail(-1, "wf_trace_any_host_t: null occluded");
+    return TraceTimed(ctx, n, o, d, tmax, time, nullptr, occluded);
 }
 int wf_sampler_probe(wf_ctx *ctx, int n, const int32_t *px, const int32_t *py, const int32_t *sample_index, int start_dim, int ndims, float *out) {
     if (!ctx || !ctx->sceneLoaded) return fail(-1, "no scene uploaded");

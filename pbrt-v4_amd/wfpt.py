@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_film_gather_strips", "wf_stats_add", "wf_material_items_download", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_kat_probe", "wf_queue_size", "wf_queue_download",
-    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters", "wf_debug_fastbvh_check",
+    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters", "wf_debug_fastbvh_check", "wf_trace_closest_host_t", "wf_trace_any_host_t",
     "wf_trace_closest_device", "wf_trace_any_device", "wf_device_alloc", "wf_device_free", "wf_device_upload", "wf_device_download", "wf_trace_shadow_tr_host",
 ]
 HOST_SYMBOLS = [
@@ -264,6 +264,25 @@ class Scene:
         n = o.shape[0]
         out = (HitRecord * n)()
         _check(hip.wf_trace_closest_host(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, out, 1 if reference_order else 0), "wf_trace_closest_host")
+        return np.frombuffer(out, dtype=np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
+                                                  ("nodes_visited", "<i4"), ("tris_tested", "<i4"), ("instance", "<i4")])).copy()
+
+    def trace_timed(self, o, d, tmax, time, any_hit=False):
+        """wf_trace_closest_host_t / wf_trace_any_host_t: the reference-order walks at the rays' own times (AnimatedPrimitive)"""
+        _, hip = libs()
+        o = np.ascontiguousarray(o, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        tmax = np.ascontiguousarray(tmax, dtype=np.float32)
+        time = np.ascontiguousarray(time, dtype=np.float32)
+        n = o.shape[0]
+        for f in (hip.wf_trace_closest_host_t, hip.wf_trace_any_host_t):
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        if any_hit:
+            occ = np.empty(n, dtype=np.int32)
+            _check(hip.wf_trace_any_host_t(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, time.ctypes.data, occ.ctypes.data), "wf_trace_any_host_t")
+            return occ
+        out = (HitRecord * n)()
+        _check(hip.wf_trace_closest_host_t(self.ctx, n, o.ctypes.data, d.ctypes.data, tmax.ctypes.data, time.ctypes.data, C.addressof(out)), "wf_trace_closest_host_t")
         return np.frombuffer(out, dtype=np.dtype([("prim", "<i4"), ("t", "<f4"), ("b0", "<f4"), ("b1", "<f4"), ("b2", "<f4"),
                                                   ("nodes_visited", "<i4"), ("tris_tested", "<i4"), ("instance", "<i4")])).copy()
 

@@ -202,8 +202,9 @@ def test_volpath_in_expectation_cpu_port(built, tmp_path, name):
     """The physical oracle of the north_star — pbrt's CPU VolPathIntegrator (cpu/integrators.cpp:953-1390) — in expectation, on the CPU
     port of the wavefront path (the stage bodies the HIP kernels run; the GPU leg is tests/test_gpu_parity.py::test_volpath_in_expectation
     at 1024 spp).  tests/golden/volpath/<scene>.json = block means of two independent VolPath renders (tools/make_volpath_goldens.py);
-    the port renders 256 spp.  Tolerances as on the GPU: image mean within 2.5 % (the reference's CheckSceneAverage,
-    cpu/integrators_test.cpp:50-65), every block of the 8 x 8 grid within 5 % + 4 x the goldens' own disagreement."""
+    the port renders 256 spp (the GPU 8192, with a block tolerance of 2 %).  Tolerances here: image mean within 2.5 % (the reference's
+    CheckSceneAverage, cpu/integrators_test.cpp:50-65), every block of the 8 x 8 grid within 5 % + 8 x the goldens' own disagreement (the goldens
+    are 8192-spp renders since round 6: their disagreement is half of what it was, this render's noise is not)."""
     import json
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
@@ -221,4 +222,4 @@ def test_volpath_in_expectation_cpu_port(built, tmp_path, name):
     assert np.abs(img.mean(axis=(0, 1)) / mean_ref - 1).max() <= 0.025
     noise = np.abs(a - b)
     noise = np.maximum(noise, np.median(noise))
-    assert (np.abs(g - ref) <= 0.05 * ref + 4 * noise).all()
+    assert (np.abs(g - ref) <= 0.05 * ref + 8 * noise).all()
