@@ -94,6 +94,9 @@ struct wf_ctx {
     hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
     bool portalLights = false;   // the scene has a portal infinite light (k_handle_escaped<RARE>)
     bool leanShade = false;      // the scene qualifies for the lean shade kernels (SceneLean: set at upload)
+    // ... per MATERIAL TYPE since round 6: a type none of whose materials sits on a quadric / patch / curve keeps its lean shade kernel
+    // when such shapes appear elsewhere in the scene (their hits are items of other types' queues)
+    bool leanType[WF_MAT_NTYPES] = {};
     bool matSplit = true;        // the material stage as two kernels per type (WF_MAT_SPLIT=0 with a MATFUSED build: the one-kernel stage)
     bool rareLights = false;     // the scene has a light type only the VARIANT 2 material kernels sample (portal infinite lights)
     int genMode = 0;             // general-primitive strength of the traversal kernels: 0 triangles only, 1 simple alpha, 2 anything but curves and alpha on quadrics, 3 anything (see GeneralPrims)
@@ -2569,8 +2572,31 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     // the lean shade kernels (wf_scene.h "LEAN DEVICE VARIANTS"): no quadrics / patches / curves, every texture a constant, an image map or a
     // bilerp (WF_LEAN_SHADE=0 turns them off)
     ctx->leanShade = d->n_quadrics == 0 && d->n_animated == 0 && !(getenv("WF_LEAN_SHADE") && atoi(getenv("WF_LEAN_SHADE")) == 0);
-    for (int i = 0; i < d->n_textures && ctx->leanShade; ++i)
-        if (!wf::IsSimpleFloatTexture(d->textures[i].type) && !wf::IsSimpleSpectrumTexture(d->textures[i].type)) ctx->leanShade = false;
+    bool simpleTextures = true;
+    for (int i = 0; i < d->n_textures && simpleTextures; ++i)
+        if (!wf::IsSimpleFloatTexture(d->textures[i].type) && !wf::IsSimpleSpectrumTexture(d->textures[i].type)) simpleTextures = false;
+    ctx->leanShade = ctx->leanShade && simpleTextures;
+    {
+        // the material types met on shapes that are not triangles (through MixMaterials, whose hits join the queue of the chosen material's type)
+        bool onGeneral[WF_MAT_NTYPES] = {};
+        std::vector<int> todo;
+        for (int i = 0; i < d->n_quadrics; ++i) {
+            const int m = d->meshes[d->quadrics[i].mesh].material;
+            if (m >= 0 && m < d->n_materials) todo.push_back(m);
+        }
+        std::vector<char> seen((size_t)std::max(d->n_materials, 1), 0);
+        while (!todo.empty()) {
+            const int m = todo.back();
+            todo.pop_back();
+            if (m < 0 || m >= d->n_materials || seen[m]) continue;
+            seen[m] = 1;
+            const int t = d->materials[m].type;
+            if (t == WF_MAT_MIX) { todo.push_back(d->materials[m].mix[0]); todo.push_back(d->materials[m].mix[1]); }
+            else if (t >= 0 && t < WF_MAT_NTYPES) onGeneral[t] = true;
+        }
+        const bool wanted = !(getenv("WF_LEAN_SHADE") && atoi(getenv("WF_LEAN_SHADE")) == 0) && !(getenv("WF_LEAN_PER_TYPE") && atoi(getenv("WF_LEAN_PER_TYPE")) == 0);
+        for (int t = 0; t < WF_MAT_NTYPES; ++t) ctx->leanType[t] = ctx->leanShade || (wanted && simpleTextures && d->n_animated == 0 && !onGeneral[t]);
+    }
     // ... and, since round 5, emitters that are not triangles (sphere / disk / cylinder / patch / curve lights: an out-of-line sampler of
     // 214 VGPRs) and emitters with an alpha texture (the texture-graph evaluator): LightSampleLi<RARE>, AreaLightL<ALPHA> (wf_lights.h)
     for (int i = 0; i < d->n_lights; ++i) {
@@ -3176,7 +3202,7 @@ static int EvalMaterialOn(wf_ctx *ctx, int material_type, int depth, hipStream_t
         Prof prof_(ctx, timed ? names[material_type] : "(untimed)", stream);
         // shade variant: 0 / 1 the LEAN kernels (triangle-only scenes whose textures are all constants, image maps or bilerps: SceneLean),
         // without / with the texture footprint and bump block; 2 general; 3 general + visible surface / moving camera
-        const int v = vs ? 3 : (!ctx->leanShade ? 2 : (tex ? 1 : 0));
+        const int v = vs ? 3 : (!ctx->leanType[material_type] ? 2 : (tex ? 1 : 0));
         switch (material_type) {
         case 1: (v == 3 ? wf_launch_mat_shade_1_3 : v == 2 ? wf_launch_mat_shade_1_2 : v == 1 ? wf_launch_mat_shade_1_1 : wf_launch_mat_shade_1_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;
         case 2: (v == 3 ? wf_launch_mat_shade_2_3 : v == 2 ? wf_launch_mat_shade_2_2 : v == 1 ? wf_launch_mat_shade_2_1 : wf_launch_mat_shade_2_0)(stream, g, &ctx->svHost, &ctx->ws, cur); break;

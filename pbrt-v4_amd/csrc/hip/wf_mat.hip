@@ -37,6 +37,19 @@ constexpr int MBLOCK = 256;
 #endif
 // the lean shade kernels (profiles/r05_lean_variants_ab_sm16.txt; spec scene, 16 spp, same box; general kernel at 2 waves -> lean at 3 / 4 / 5):
 //   diffuse 10.87 -> 9.26 / 9.03 / 13.96 ms   conductor 3.19 -> 3.04 / 3.31 / 4.73   coated diffuse 7.43 -> 6.55 / 8.14 / 10.48
+// per-type overrides for A/B builds (tools/build_variant.sh ... "-DWF_SHADE_LEAN_W1=3 -DWF_NEE_W6=2")
+#if WF_MAT_INSTANCE == 1 && defined(WF_SHADE_LEAN_W1)
+#define WF_SHADE_WAVES_LEAN WF_SHADE_LEAN_W1
+#elif WF_MAT_INSTANCE == 2 && defined(WF_SHADE_LEAN_W2)
+#define WF_SHADE_WAVES_LEAN WF_SHADE_LEAN_W2
+#elif WF_MAT_INSTANCE == 6 && defined(WF_SHADE_LEAN_W6)
+#define WF_SHADE_WAVES_LEAN WF_SHADE_LEAN_W6
+#endif
+#if WF_MAT_INSTANCE == 6 && defined(WF_NEE_W6)
+#define WF_NEE_WAVES WF_NEE_W6
+#elif WF_MAT_INSTANCE == 2 && defined(WF_NEE_W2)
+#define WF_NEE_WAVES WF_NEE_W2
+#endif
 #ifndef WF_SHADE_WAVES_LEAN
 #if WF_MAT_INSTANCE == 1
 #define WF_SHADE_WAVES_LEAN 4
@@ -51,8 +64,8 @@ constexpr int MBLOCK = 256;
 // The light sampling (descent of the light BVH, shape sampling) is a chain of dependent gathers and pays for occupancy even with 100-600
 // spilled VGPRs; the shade half is dominated by its own loads and stores, and spills only add to them.
 #ifndef WF_NEE_WAVES
-#if WF_MAT_INSTANCE == 10 && WF_MAT_PART == 2 && WF_MAT_TEXCTX == 1
-#define WF_NEE_WAVES 2   // (k_mat_nee<measured, rare lights> at 4 waves spills a carrier register: tools/check_spill_carriers.py)
+#if (WF_MAT_INSTANCE == 10 || WF_MAT_INSTANCE == 7) && WF_MAT_PART == 2 && WF_MAT_TEXCTX == 1
+#define WF_NEE_WAVES 2   // (k_mat_nee<measured, rare lights> — and, since round 6's inlined item I/O, <coated conductor, rare lights> — at 4 waves spill a carrier register: tools/check_spill_carriers.py)
 #else
 #define WF_NEE_WAVES 4
 #endif
@@ -70,7 +83,7 @@ struct NeeIO {
     using BxDF = typename MatBxDF<MAT>::T;
     static constexpr int NBX = (sizeof(BxDF) + 15) / 16;
     struct Packed { F4 v[NBX]; };
-    __device__ static int Base(const WorkState &ws) {
+    __device__ __attribute__((always_inline)) static int Base(const WorkState &ws) {
         int base = 0;
 #pragma unroll
         for (int t = 1; t < MAT; ++t) base += ws.counters[(CNT_MAT0 + t) * CNT_STRIDE];
@@ -79,7 +92,9 @@ struct NeeIO {
     // planes: 0 pi.lo, pi.hi.x | 1 pi.hi.yz, n.xy | 2 n.z, ns | 3 dpdus, wo.x | 4 wo.yz, u0, u.x | 5 u.y, pixelIndex (-1: no next-event
     // estimation), mediumInside, mediumOutside | 6 beta | 7 r_u | 8 lambda | 9 ctxP, ctxIsPoint | 10.. the BxDF
     static constexpr int NFIX = 10;
-    __device__ static void Store(const WorkState &ws, int k, const NeeItem<MAT> &it) {
+    // (always_inline: out of line — the conductor and the layered types' units until round 6 — the whole item crossed scratch: written by
+    //  the shade code, read back here, 200-270 B each way per item, and the same again on the next-event side)
+    __device__ __attribute__((always_inline)) static void Store(const WorkState &ws, int k, const NeeItem<MAT> &it) {
         const size_t S = (size_t)ws.maxQueueSize;
         F4 *r = ws.neeRec + k;
         r[5 * S] = F4{it.u.y, BitsToFloat((uint32_t)(it.want ? it.pixelIndex : -1)), BitsToFloat((uint32_t)it.mediumInside), BitsToFloat((uint32_t)it.mediumOutside)};
@@ -99,7 +114,7 @@ struct NeeIO {
         for (int b = 0; b < NBX; ++b) r[(NFIX + b) * S] = pk.v[b];
     }
     // what the light sample needs (MatNeeRequest of the stored item) ...
-    __device__ static void LoadRequest(const WorkState &ws, int k, NeeRequest *rq) {
+    __device__ __attribute__((always_inline)) static void LoadRequest(const WorkState &ws, int k, NeeRequest *rq) {
         const size_t S = (size_t)ws.maxQueueSize;
         const F4 *r = ws.neeRec + k;
         const F4 p5 = r[5 * S];
@@ -114,7 +129,7 @@ struct NeeIO {
         rq->lambda.pdf[0] = rq->lambda.pdf[1] = rq->lambda.pdf[2] = rq->lambda.pdf[3] = 0;
     }
     // ... and what MatNeeFinish reads of it
-    __device__ static void Load(const WorkState &ws, int k, NeeItem<MAT> *it) {
+    __device__ __attribute__((always_inline)) static void Load(const WorkState &ws, int k, NeeItem<MAT> *it) {
         const size_t S = (size_t)ws.maxQueueSize;
         const F4 *r = ws.neeRec + k;
         const F4 p5 = r[5 * S];

@@ -977,12 +977,12 @@ def test_cli_multi_device_contexts_on_one_gpu_bit_identical(tmp_path, devices):
 # The physical oracle (north_star: "matches pbrt's CPU VolPathIntegrator").  Everything above compares with
 # `pbrt --wavefront`, sample for sample; VolPath (cpu/integrators.cpp:953-1390) draws its samples in another order, so the agreement is in
 # expectation: tests/golden/volpath/<scene>.json holds the block means of TWO independent VolPath renders (seeds 0, 1; 8192 spp each since round 6;
-# tools/make_volpath_goldens.py) of the downscaled stand-ins of BASELINE configs 1-4.  The GPU renders the same scene at 8192 spp.
+# tools/make_volpath_goldens.py) of the downscaled stand-ins of BASELINE configs 1-4.  The GPU renders the same scene at 4096 spp.
 # Tolerances, in the spirit of the reference's own CheckSceneAverage (cpu/integrators_test.cpp:50-65: |mean - expected| <= 0.025 at
 # expected ~ 1): the image mean within 1 % of the goldens' mean; every block of the 8 x 8 grid within 2 % of the goldens' block mean (5 % until round 5)
 # plus four times the goldens' own disagreement on that block (floored at the grid's median disagreement) — the stated confidence interval.
 VOLPATH = os.path.join(GOLDEN, "volpath")
-VOLPATH_GPU_SPP = 8192   # (round 6: as many as each of the two golden renders; ~1 s per scene on the GPU)
+VOLPATH_GPU_SPP = 4096   # (round 6: half of each of the two golden renders; ~1 s per scene on the GPU)
 
 
 def _volpath_scene(name, tmp_path):

@@ -59,11 +59,33 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=48)
     ap.add_argument("--seed", type=int, default=4)
+    ap.add_argument("--append", action="store_true", help="keep the committed corpus and add --n scenes of a NEW seed base to it (round 6: 54 -> 300+ scenes for the GPU leg)")
+    ap.add_argument("--stress", action="store_true", help="diff_fuzz_scenes.py --stress: the grammar's rare features two to three times as often")
+    ap.add_argument("--options", action="store_true", help="diff_fuzz_scenes.py --options: also draw the extended Option directives")
     a = ap.parse_args()
-    shutil.rmtree(OUT, ignore_errors=True)
-    os.makedirs(OUT)
-    work = tempfile.mkdtemp(prefix="wf_fuzzgold_")
+    fz.STRESS, fz.EXTENDED_OPTIONS = a.stress, a.options
     kept = []
+    if a.append:
+        kept = open(os.path.join(OUT, "CORPUS.txt")).read().split()
+    else:
+        shutil.rmtree(OUT, ignore_errors=True)
+        os.makedirs(OUT)
+    n_target = len(kept) + a.n
+    work = tempfile.mkdtemp(prefix="wf_fuzzgold_")
+    i = 0
+    while a.append and len(kept) < n_target and i < 40 * a.n:
+        seed = a.seed * 100000 + i
+        i += 1
+        if "s%d" % seed in kept:
+            continue
+        if try_scene("s%d" % seed, fz.Gen(seed).scene(), work):
+            kept.append("s%d" % seed)
+            print("kept s%d (%d / %d)" % (seed, len(kept), n_target), flush=True)
+            open(os.path.join(OUT, "CORPUS.txt"), "w").write("\n".join(kept) + "\n")
+    if a.append:
+        shutil.rmtree(work, ignore_errors=True)
+        print("%d scenes in %s" % (len(kept), OUT))
+        return
     i = 0
     while len(kept) < a.n and i < 40 * a.n:
         seed = a.seed * 100000 + i
