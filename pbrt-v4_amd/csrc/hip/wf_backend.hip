@@ -63,7 +63,7 @@ constexpr int STACK_LDS = 24;   // LDS stack entries per lane: 24 x 4 B x 256 la
 constexpr int STACK_MAX = 64;   // nodesToVisit[64], cpu/aggregates.cpp:538
 constexpr int MAX_GRID = 256 * 8;  // 256 CUs x up to 8 resident 256-thread workgroups
 
-struct SpillArea { int *base; int rows; int *dbg; };   // the context's stackSpill rows + the debug words (kernel argument of the production traversal)
+struct SpillArea { int *base; int rows; int *dbg; F4 *save; };   // the context's stackSpill rows + the debug words (kernel argument of the production traversal)
 
 struct wf_ctx {
     int device = 0;
@@ -76,7 +76,8 @@ struct wf_ctx {
     int *stackSpill = nullptr;   // [rows][MAX_GRID*BLOCK], rows from the trees' depths (wf_scene_upload)
     int spillRows = 0;
     int *dbgWords = nullptr;     // [4] spilled stack entries, stack-overflow flag, inline near-tie re-traces, cursor path taken (wf_debug_counters)
-    SpillArea spillArea() const { return SpillArea{stackSpill, spillRows, dbgWords}; }
+    F4 *walkSave = nullptr;      // [4][MAX_GRID*BLOCK]: every lane's render-space walk constants, reloaded when it leaves an instance (LdsStackT::loadWorld)
+    SpillArea spillArea() const { return SpillArea{stackSpill, spillRows, dbgWords, walkSave}; }
     FastBVH fast{};              // production traversal layout (wf_traverse.h); built at upload
     bool fastOk = false;         // false: leaf sizes > 16 -> only the reference-order kernels are used
     hipStream_t stream2 = nullptr;   // the near-tie re-trace runs here, beside the routing pass and the next stage's sample generation
@@ -310,6 +311,30 @@ struct LdsStackT {
     int lo;       // entries [0, lo) are in the HBM column, [lo, n) in the LDS ring (n - lo <= TSTACK)
     int rows;     // capacity of the HBM column
     int *dbg;
+    // The render-space constants of the lane's ray (slab constants on the top-level grid, the triangle test's shear: 16 dwords), written
+    // once when the ray starts and RELOADED whenever the lane leaves an instance (round 6).  Until round 5 ExitInstance recomputed them —
+    // three IEEE divisions, three v_rcp, ~95 VALU instructions of a walk that is bound by VALU issue at a quarter of its lanes — eight
+    // times per ray on the spec scene.  Four 16-byte planes per lane, lane-major: a wave reads 1 KiB per instruction, mostly from L2.
+    F4 *save = nullptr;
+    __device__ void saveWorld(const RayWalk &w) const {
+        const size_t S = (size_t)spillStride;
+        save[0] = F4{w.a.x, w.a.y, w.a.z, w.bn.x};
+        save[S] = F4{w.bn.y, w.bn.z, w.af.x, w.af.y};
+        save[2 * S] = F4{w.af.z, w.bf.x, w.bf.y, w.bf.z};
+        save[3 * S] = F4{BitsToFloat((uint32_t)w.sh.kz), w.sh.Sx, w.sh.Sy, w.sh.Sz};
+    }
+    __device__ void loadWorld(RayWalk &w, V3 oW) const {
+        const size_t S = (size_t)spillStride;
+        const F4 p0 = save[0], p1 = save[S], p2 = save[2 * S], p3 = save[3 * S];
+        w.o = oW;
+        w.a = V3{p0.x, p0.y, p0.z}; w.bn = V3{p0.w, p1.x, p1.y};
+        w.af = V3{p1.z, p1.w, p2.x}; w.bf = V3{p2.y, p2.z, p2.w};
+        w.sh.kz = (int)FloatToBits(p3.x); w.sh.Sx = p3.y; w.sh.Sy = p3.z; w.sh.Sz = p3.w;
+        // (the v_perm selectors follow the direction's sign, which is the sign of `a`: WalkSetSlab)
+        w.selx = (FloatToBits(p0.x) >> 31) ? 0x01000302u : 0x03020100u;
+        w.sely = (FloatToBits(p0.y) >> 31) ? 0x01000302u : 0x03020100u;
+        w.selz = (FloatToBits(p0.z) >> 31) ? 0x01000302u : 0x03020100u;
+    }
     static constexpr int MASK = TSTACK - 1;
     static_assert((TSTACK & (TSTACK - 1)) == 0, "WF_TSTACK must be a power of two (ring indexing)");
     __device__ void reset() { n = 0; lo = 0; }
@@ -626,6 +651,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
             fetch(idx, &o, &d, &tMax);
             WalkInit(bvh, w, o, d, tMax);
             if constexpr (INST || GEN > 0) StoreWorldRay(o, d);
+            if constexpr (INST && WF_SAVE_WORLD) st.saveWorld(w);
             st.reset();
         }
         // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
@@ -745,6 +771,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
                 fetch(idx, &o, &d, &tMax);
                 WalkInit(bvh, w, o, d, tMax);
                 if constexpr (INST || GEN > 0) StoreWorldRay(o, d);
+                if constexpr (INST && WF_SAVE_WORLD) st.saveWorld(w);
                 st.reset();
             }
             if (exhausted && !__any(w.node != NODE_NONE)) break;
@@ -907,7 +934,7 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GENX), INST ? WF_TWA
     if constexpr (!SPLIT) list = nullptr;   // (only the launches of the routing-split path take a list)
     const int n = list ? ws.counters[(CNT_DEFER) * CNT_STRIDE] : ws.counters[(CNT_RAY0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     const RayQueueV q = ws.rq[cur];
     // near-ties resolved by this launch itself: the kernels that would otherwise inline the reference-order walk (RetraceInline), walking with refill
     constexpr bool DRAIN = SPLIT && RetraceInline(GEN) && WF_REFILL_CLOSEST != 0 && WF_REFILL_INLINE == 0;
@@ -1106,7 +1133,7 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GEN), INST ? WF_TWAV
     const SceneView &sv = SvOf<false>(svArg);
     const int n = list ? ws.counters[(CNT_DEFER_SHADOW) * CNT_STRIDE] : ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     TraceQueue<true, GEN, INST, true>(
         sv, bvh, n, st,
         [&](int i0, V3 *o, V3 *d, float *tMax) {
@@ -1130,7 +1157,7 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GEN), INST ? WF_TWAV
 template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, wf_hit_record *out, SpillArea sp) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     TraceQueue<false, GEN, INST, true>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
@@ -1151,7 +1178,7 @@ __global__ void __launch_bounds__(TBLOCK) k_trace_closest_fast(const SceneView s
 template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK) k_trace_any_fast(const SceneView sv, FastBVH bvh, int n, const float *rays, int32_t *occluded, SpillArea sp) {
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     TraceQueue<true, GEN, INST, true>(
         sv, bvh, n, st,
         [&](int i, V3 *o, V3 *d, float *tMax) {
@@ -1215,7 +1242,7 @@ template <bool ALPHA>
 __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     LoadTreeTop(bvh);
     for (int i = gtid; i < n; i += stride)
         KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
@@ -1265,7 +1292,7 @@ template <int GEN, bool INST>
 __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOSEST) k_tr_trace(const SceneView sv, WorkState ws, FastBVH bvh, int cur, SpillArea sp) {
     const int n = ws.counters[(CNT_TR0 + cur) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
-    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg};
+    LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     const int32_t *q = ws.trQ[cur];
     TraceQueue<false, GEN, INST, true>(
         sv, bvh, n, st,
@@ -2709,6 +2736,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             const int rows = std::max(std::max(needRef - std::min(STACK_LDS, TSTACK), needFast - TSTACK), STACK_MAX - std::min(STACK_LDS, TSTACK));
             if (rows > 2048) return fail(-1, "BVH too deep for the traversal stacks (depth %d + %d)", depthTop, depthDef);
             if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)rows * MAX_GRID * BLOCK))) return e;
+            if ((e = devAlloc(ctx, &ctx->walkSave, (size_t)4 * MAX_GRID * BLOCK))) return e;
             ctx->spillRows = rows;
             if ((e = devAlloc(ctx, &ctx->dbgWords, (size_t)8))) return e;   // [4..7]: near-tie queue diagnostics (pushes, re-walks without a hit, -, -)
             HIPCHK(hipMemset(ctx->dbgWords, 0, 8 * sizeof(int)));

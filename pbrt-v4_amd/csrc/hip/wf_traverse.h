@@ -364,6 +364,9 @@ __device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 d
 }
 // an instance ENTRY on the stack / in a child slot (not the exit marker)
 __device__ inline bool IsInstanceEntry(int node) { return node < 0 && node != NODE_NONE && node != NODE_EXIT && (int)((~(unsigned)node) >> 4) >= INST_FIRST; }
+#ifndef WF_SAVE_WORLD
+#define WF_SAVE_WORLD 1   // round 6: ExitInstance reloads the lane's render-space walk constants instead of recomputing them (wf_backend.hip LdsStackT::loadWorld)
+#endif
 #ifndef WF_FUSE_EXIT_ENTER
 #define WF_FUSE_EXIT_ENTER 1   // round 6: a lane that leaves an instance and pops another instance's entry enters it in the same step, and
                                // the render-space shear / slab constants in between are not rebuilt (three IEEE divisions, three v_rcp)
@@ -394,7 +397,11 @@ __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V
     WalkSetSlab(bvh.base, bvh.cell, w, oW, dW);   // the shear of the render-space ray when a top-level leaf asks for it (WalkMakeExact)
     WF_LAZY_SET(w, 2);
 #else
+#if WF_SAVE_WORLD
+    if (!(WF_FUSE_EXIT_ENTER && IsInstanceEntry(next))) st.loadWorld(w, oW);   // the render-space constants, saved when the ray started (LdsStackT)
+#else
     if (!(WF_FUSE_EXIT_ENTER && IsInstanceEntry(next))) WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
+#endif
 #endif
     w.tMax = mark ? -tW : tW;
     w.curInst = -1;

@@ -97,3 +97,65 @@ def test_sample_partition_film_reduce_gloo(built, tmp_path):
     # identical sample sets; only the order of the double-precision additions differs
     assert np.allclose(a, b, rtol=1e-12, atol=0)
     assert (a.reshape(-1, 4)[:, 3] > 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same N > 1 path with the PRODUCT renderer: two processes on the one GPU of the box — each with a context of its
+# own on cuda:0, its strip set, its queues sized for its rows (create_renderer(strips=...)), multigpu.render_partition — and the strip
+# gather over gloo (RCCL refuses two ranks on one device; the collective's payload and the row bookkeeping are the same).  The film on
+# rank 0 must be bit-identical with a single-context render of the same scene.
+GPU_WORKER = textwrap.dedent("""
+    import importlib.util, os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    root, scene_path, outdir = sys.argv[1:4]
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    wfpt = load("wfpt", os.path.join(root, "pbrt-v4_amd", "wfpt.py"))
+    multigpu = load("multigpu", os.path.join(root, "pbrt-v4_amd", "multigpu.py"))
+    spp = 4
+    s = wfpt.Scene(path=scene_path, spp=spp)
+    s.create_renderer(0, strips=(rank, world, multigpu.STRIP_HEIGHT))
+    s.clear_film()
+    multigpu.render_partition(s, rank, world, 0, spp, "strips")
+    film = torch.from_numpy(np.ascontiguousarray(s.film()))
+    H = film.shape[0]
+    owned = np.where(film[..., 3].numpy().sum(axis=1) > 0)[0]
+    assert (owned == multigpu.strip_rows(rank, world, H)).all(), (rank, owned)
+    film = multigpu.gather_film(film, dist, rank, world, 0)
+    if rank == 0:
+        film.numpy().tofile(os.path.join(outdir, "film_product_gathered.bin"))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["instances", "cornell64"])
+def test_strip_partition_product_renderer_two_ranks_one_gpu(wfpt, tmp_path, scene):
+    worker = tmp_path / "gpu_worker.py"
+    worker.write_text(GPU_WORKER)
+    path = os.path.join(GOLDEN, scene + ".pbrt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(worker), ROOT, path, str(tmp_path)]
+    subprocess.run(cmd, check=True, timeout=900, cwd=ROOT)
+    s = wfpt.Scene(path=path, spp=4)
+    s.create_renderer(0)
+    s.clear_film()
+    s.render(0, 4, 1)
+    single = np.ascontiguousarray(s.film()).astype(np.float64)
+    s.close()
+    got = np.fromfile(tmp_path / "film_product_gathered.bin", dtype=np.float64)
+    assert got.size == single.size
+    assert (got.view(np.uint64) == single.reshape(-1).view(np.uint64)).all()
+    assert (single[..., 3] > 0).all()

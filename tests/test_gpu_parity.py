@@ -912,6 +912,38 @@ def test_bench_workload_line(workload):
     print(workload, line["value"], "Msamples/s", "parity", line["parity"]["max_rel"], line["parity"]["bit_identical_fraction"])
 
 
+def test_config5_tm_like_4k_crop_window_vs_reference_run_here(wfpt, tmp_path):
+    """BASELINE configs[4] at its FULL size with a parity check in front of the driver: the tm-like stand-in at 3840 x 2160,
+    a crop window of 9 % of the image (the film's `cropwindow`, which both sides parse: film.cpp FilmBaseParameters), one sample per pixel,
+    rendered here by the reference's own CPU wavefront path (oracle/_ref/pbrt_ref --wavefront travels to the GPU box with the repository;
+    the whole 4K image costs it 250 s on 256 cores, the window about a tenth) and by the product: bit-identical."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "pbrt_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/pbrt_ref is not built (it needs /root/reference at build time)")
+    import make_scenes
+    d = tmp_path / "tm4k"
+    d.mkdir()
+    path = str(d / "tm.pbrt")
+    make_scenes.tm_like(path, (3840, 2160), 1)
+    text = open(path).read()
+    film = '"integer yresolution" [ 2160 ]'
+    assert text.count(film) == 1
+    open(path, "w").write(text.replace(film, film + ' "float cropwindow" [ 0.35 0.65 0.35 0.65 ]'))
+    ref_out = str(tmp_path / "ref.pfm")
+    subprocess.run([ref_bin, "--wavefront", "--quiet", "--seed", "0", "--spp", "1", "--outfile", ref_out, path], check=True, timeout=1500, cwd=str(d))
+    s = wfpt.Scene(path=path, spp=1)
+    assert (s.info.width, s.info.height) == (1152, 648)   # the window's pixels
+    s.create_renderer(0)
+    s.clear_film()
+    s.render(0, 1, 1)
+    out = str(tmp_path / "gpu.pfm")
+    s.write_film_image(out)
+    s.close()
+    img, ref = read_pfm(out), read_pfm(ref_out)
+    assert img.shape == ref.shape == (648, 1152, 3) and ref.mean() > 0.01
+    assert_image_parity("tm_like_4k_crop", img, ref)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Multi-GPU readiness on a one-GPU box (VERDICT r3 item 6).
 def test_rccl_film_gather_and_reduce_world_size_one(wfpt, tmp_path):
