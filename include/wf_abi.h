@@ -789,6 +789,11 @@ int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out);
    entry was dropped; wf_sync returns an error as well), out[2] near-tie rays re-walked in reference order inside the walk kernel,
    out[3] != 0: a launch dealt its rays through the shared cursor.  reset != 0 zeroes the words after reading. */
 int wf_debug_counters(wf_ctx *ctx, uint64_t out[4], int reset);
+/* Which kernel variants the uploaded scene runs (tests assert that a scene takes the path they mean to cover): key = "fast_ok" (the
+   production traversal layout is in use), "gen_mode" (0 - 3: strength of the walk kernels), "gen_tri", "defer_general" (the two-class
+   traversal), "anim_fast" (AnimatedPrimitives on the production walk), "lean_shade", "lean_type_<material type>", "rare_lights",
+   "instances".  Introspection only; nothing in the reference corresponds. */
+int wf_ctx_query(wf_ctx *ctx, const char *key, int64_t *value);
 /* Host-only self-check of the production traversal layout (no device needed; CPU suite, tests/test_fastbvh_host.py): builds the
    QNode / LeafTri / instance-entry arrays wf_scene_upload would upload for `d` (round 6: with the top-level tree rebuilt over
    partially re-braided instances, WF_BRAID) and walks them on the host with n_rays random rays in double arithmetic, without

@@ -107,6 +107,7 @@ struct wf_ctx {
     // kernels (genMode >= 2) only the rays handed to deferQ; persistentGrid / persistentGridShadow are then the triangle kernels' grids
     bool deferGeneral = false;
     int genTri = 0;
+    bool animFast = false;       // the scene's AnimatedPrimitives are walked by the production kernels' ANIM variants (round 6; genMode <= 1 only)
     int persistentGridGen = 1024, persistentGridShadowGen = 1024;
     static bool splitRouteWanted() { return true; }
     // ray-coherence pass (SortRayQueue): bit 0 sorts the ray queue before the closest-hit launch of depth >= 1, bit 1 the shadow queue
@@ -290,6 +291,8 @@ __device__ inline void StoreWorldRay(V3 o, V3 d) {
     g_ray[0 * TBLOCK + threadIdx.x] = o.x; g_ray[1 * TBLOCK + threadIdx.x] = o.y; g_ray[2 * TBLOCK + threadIdx.x] = o.z;
     g_ray[3 * TBLOCK + threadIdx.x] = d.x; g_ray[4 * TBLOCK + threadIdx.x] = d.y; g_ray[5 * TBLOCK + threadIdx.x] = d.z;
 }
+// the ray's time, for the kernels of scenes with animated primitives (written by their fetch functors, read at instance entries)
+__shared__ float g_time[TBLOCK];
 __device__ inline V3 WorldRayO() { return V3{g_ray[0 * TBLOCK + threadIdx.x], g_ray[1 * TBLOCK + threadIdx.x], g_ray[2 * TBLOCK + threadIdx.x]}; }
 __device__ inline V3 WorldRayD() { return V3{g_ray[3 * TBLOCK + threadIdx.x], g_ray[4 * TBLOCK + threadIdx.x], g_ray[5 * TBLOCK + threadIdx.x]}; }
 // the HBM spill path of the stack is out of line so that the compiler cannot merge it with the LDS path
@@ -425,9 +428,11 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
 // that involves such a shape only matters to candidates NEARER than the triangle hit: wf_traverse.h) — so both classes of rays end
 // with the result the general kernel alone computes.  The reference keeps such shapes in acceleration structures of their own too
 // (gpu/optix/aggregate.cpp:916-1025: one GAS per shape class under the root IAS).
-constexpr int GenBase(int g) { return g >= 4 ? g - 4 : g; }
-constexpr bool GenDefer(int g) { return g >= 4; }
-template <typename Fetch, int GEN, bool DEFER = false>
+// (kernel template value = strength 0 .. 3 | 4: hands general primitives over | 8: ANIMATED instances, see EnterInstance<ANIM>)
+constexpr int GenBase(int g) { return g & 3; }
+constexpr bool GenDefer(int g) { return (g & 4) != 0; }
+constexpr bool GenAnim(int g) { return (g & 8) != 0; }
+template <typename Fetch, int GEN, bool DEFER = false, bool ANIM = false>
 struct GeneralPrims {
     static constexpr bool pairBands = GEN >= 2;   // quadrics / patches / curves in the scene: the near-tie band depends on the pair (wf_traverse.h)
     static constexpr bool deferGeneral = DEFER;
@@ -438,7 +443,10 @@ struct GeneralPrims {
     int idx;
     __device__ V3 dir() const {
         V3 d = WorldRayD();
-        if (w.curInst >= 0) d = XfVector3(bvh.instances[w.curInst].render_from_instance.mInv, d);  // = InstanceRay's direction
+        if (w.curInst >= 0) {
+            wf_instance moving;
+            d = XfVector3(InstanceAt<ANIM>(*bvh.sv, bvh.instances[w.curInst], g_time[threadIdx.x], &moving).render_from_instance.mInv, d);  // = InstanceRay's direction
+        }
         return d;
     }
     __device__ bool accept(int prim, float b0, float b1, float b2) const {
@@ -483,7 +491,7 @@ __device__ inline bool AtTransition(int node) { return node < 0 && node != NODE_
 template <bool ANY, int GENX, bool INST, typename Fetch>
 __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWalk &w, LdsStackT &st, const Fetch &fetch, int idx) {
     constexpr int GEN = GenBase(GENX);
-    constexpr bool DF = GenDefer(GENX);
+    constexpr bool DF = GenDefer(GENX), ANIM = GenAnim(GENX);
     if constexpr (INST) {
         bool tr = AtTransition(w.node);
         // (round 4, WF_LAZY_INST) a lane that sits at a leaf while its ray state is not exact for the space it walks (RayWalk::lazy)
@@ -492,7 +500,7 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
         // loop, lane by lane, the lazy transition LOST: closest 49.4 vs 45.0 ms, any-hit 26.1 vs 23.0)
         const bool owes = WF_LAZY_INST && w.node != NODE_NONE && !tr && WF_LAZY_GET(w) != 0;
         if (w.node != NODE_NONE && !tr && !owes) {
-            if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF>{sv, bvh, w, fetch, idx});
+            if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF, ANIM>{sv, bvh, w, fetch, idx});
             else LeafStep<ANY, false, true>(bvh, w, st, InstOnlyPrims<DF>{bvh});
         }
         if constexpr (WF_TRANS_BATCH > 0) {
@@ -506,10 +514,10 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
             const V3 o = WorldRayO(), d = WorldRayD();
 #if WF_FUSE_EXIT_ENTER
             if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
-            if (IsInstanceEntry(w.node)) EnterInstance(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST);   // (also the entry an exit has just popped)
+            if (IsInstanceEntry(w.node)) EnterInstance<ANIM>(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST, ANIM ? g_time[threadIdx.x] : 0.f);   // (also the entry an exit has just popped)
 #else
             if (w.node == NODE_EXIT) ExitInstance(bvh, w, st, o, d);
-            else EnterInstance(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST);
+            else EnterInstance<ANIM>(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST, ANIM ? g_time[threadIdx.x] : 0.f);
 #endif
         }
     } else if (w.node != NODE_NONE) {
@@ -529,8 +537,8 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
 // launch), so that it fits the walk's own register budget.  Cost: the few waves that hold a marked lane run one short walk at 1/64
 // lane utilisation (a marked ray's bound is tight: it descends to its hit and little else).
 struct RefHit { int prim, inst; float t, b0, b1, b2; uint32_t route; };
-template <int GEN, bool TOP>
-__device__ inline __attribute__((always_inline)) bool RefOrderTree(const SceneView *svp, int root, V3 o, V3 d, float *tMaxIO, LdsStackT &st, RefHit *out) {
+template <int GEN, bool TOP, bool ANIM = false>
+__device__ inline __attribute__((always_inline)) bool RefOrderTree(const SceneView *svp, int root, V3 o, V3 d, float *tMaxIO, LdsStackT &st, RefHit *out, float time = 0) {
     const SceneView &sv = *svp;
     float tMax = *tMaxIO;
     bool hitAny = false;
@@ -548,7 +556,8 @@ __device__ inline __attribute__((always_inline)) bool RefOrderTree(const SceneVi
                     if constexpr (TOP) {
                         if (tri >= sv.nTriangles + sv.nQuadrics) {  // TransformedPrimitive::Intersect (cpu/primitive.cpp:112-125)
                             const int inst = tri - sv.nTriangles - sv.nQuadrics;
-                            const wf_instance &in = sv.instances[inst];
+                            wf_instance moving;
+                            const wf_instance &in = InstanceAt<ANIM>(sv, sv.instances[inst], time, &moving);   // (AnimatedPrimitive::Intersect, cpu/primitive.cpp:140-153)
                             float tI = tMax;
                             V3 oI, dI;
                             InstanceRay(in, o, d, &tI, &oI, &dI);
@@ -593,13 +602,13 @@ __device__ inline __attribute__((always_inline)) bool RefOrderTree(const SceneVi
     *tMaxIO = tMax;
     return hitAny;
 }
-template <int GEN>
+template <int GEN, bool ANIM = false>
 __device__ inline __attribute__((always_inline)) RefHit RetraceRefOrder(const SceneView *svp, float ox, float oy, float oz, float dx, float dy, float dz, float tBound,
-                                                           int *spill, int spillStride, int rows, int *dbg) {
+                                                           int *spill, int spillStride, int rows, int *dbg, float time = 0) {
     LdsStackT st{spill, spillStride, 0, 0, rows, dbg};
     RefHit out{-1, -1, 0, 0, 0, 0, 0};
     float tMax = tBound;
-    RefOrderTree<GEN, true>(svp, 0, V3{ox, oy, oz}, V3{dx, dy, dz}, &tMax, st, &out);
+    RefOrderTree<GEN, true, ANIM>(svp, 0, V3{ox, oy, oz}, V3{dx, dy, dz}, &tMax, st, &out, time);
     if (out.prim >= 0) {
         // the routing code BuildFastBVH stores per LeafTri (EnqueueWorkAfterIntersection, intersect.h:48-156)
         const wf_mesh &mesh = svp->meshes[svp->triMesh[out.prim]];
@@ -675,7 +684,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
                 float t0;
                 fetch(idx, &o, &d, &t0);
                 const float tB = __builtin_fminf(2 * WalkBound(bvh, WalkT(w)) - WalkT(w), t0);
-                const RefHit rh = RetraceRefOrder<GenBase(GEN)>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+                const RefHit rh = RetraceRefOrder<GenBase(GEN), GenAnim(GEN)>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg, GenAnim(GEN) ? g_time[threadIdx.x] : 0.f);
                 w.prim = rh.prim; w.inst = rh.inst; w.route = rh.route;
                 w.tMax = rh.t; w.b0 = rh.b0; w.b1 = rh.b1; w.b2 = rh.b2;
             }
@@ -728,7 +737,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
                 float t0;
                 fetch(idx, &o, &d, &t0);
                 const float tB = __builtin_fminf(2 * WalkBound(bvh, WalkT(w)) - WalkT(w), t0);
-                const RefHit rh = RetraceRefOrder<GenBase(GEN)>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg);
+                const RefHit rh = RetraceRefOrder<GenBase(GEN), GenAnim(GEN)>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg, GenAnim(GEN) ? g_time[threadIdx.x] : 0.f);
                 w.prim = rh.prim; w.inst = rh.inst; w.route = rh.route;
                 w.tMax = rh.t; w.b0 = rh.b0; w.b1 = rh.b1; w.b2 = rh.b2;
             }
@@ -824,7 +833,7 @@ __device__ inline void TraceQueue(const SceneView &sv, const FastBVH &bvh, int n
 #define WF_SERVICE_BLOCKS 16   // spec scene, 16 spp, same box: closest-hit 54.6 ms at 4, 48.0 at 8, 42.5 at 16, 44.4 at 32, 48.1 at 64 (gpurun_out/r3t_, r3u_ab_sm16.txt)
 #endif
 __device__ inline int ServiceBlocks() { return (int)gridDim.x >= 8 * WF_SERVICE_BLOCKS ? WF_SERVICE_BLOCKS : 0; }
-template <int GEN, bool INST>
+template <int GEN, bool INST, bool ANIM = false>
 __device__ inline void DrainRetrace(const SceneView &sv, const WorkState &ws, const FastBVH &bvh, int cur, LdsStackT &st, bool service) {
     int *cnt = ws.counters + CNT_RETRACE * CNT_STRIDE, *head = ws.counters + CNT_RETRACE_HEAD * CNT_STRIDE, *done = ws.counters + CNT_WAVES_DONE * CNT_STRIDE;
     const int lane = threadIdx.x & 63;
@@ -858,7 +867,7 @@ __device__ inline void DrainRetrace(const SceneView &sv, const WorkState &ws, co
             // counted (dbg + 5), and a ray that stays without a hit raises wf_sync's error (dbg + 6) instead of a silently wrong pixel.
             RefHit rh;
             int tries = 0;
-            do { rh = RetraceRefOrder<GEN>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg); } while (rh.prim < 0 && ++tries < 4);
+            do { rh = RetraceRefOrder<GEN, ANIM>(bvh.sv, o.x, o.y, o.z, d.x, d.y, d.z, tB, st.spill, st.spillStride, st.rows, st.dbg, o.w); } while (rh.prim < 0 && ++tries < 4);
             if (st.dbg && tries) { atomicAdd(st.dbg + 5, tries); if (rh.prim < 0) atomicOr(st.dbg + 6, 1); }
             // ... and the entry itself is validated instead of trusted: the ray index lies inside this launch's queue, the
             // re-walk's hit lies inside the entry's bound, and the slot still carries this launch's tag after the walk.  A violation is
@@ -939,13 +948,17 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GENX), INST ? WF_TWA
     // near-ties resolved by this launch itself: the kernels that would otherwise inline the reference-order walk (RetraceInline), walking with refill
     constexpr bool DRAIN = SPLIT && RetraceInline(GEN) && WF_REFILL_CLOSEST != 0 && WF_REFILL_INLINE == 0;
     const int workBlocks = DRAIN ? (int)gridDim.x - ServiceBlocks() : (int)gridDim.x;
-    if (DRAIN && (int)blockIdx.x >= workBlocks) { DrainRetrace<GEN, INST>(sv, ws, bvh, cur, st, true); return; }   // a service workgroup
+    if (DRAIN && (int)blockIdx.x >= workBlocks) { DrainRetrace<GEN, INST, GenAnim(GENX)>(sv, ws, bvh, cur, st, true); return; }   // a service workgroup
     TraceQueue<false, GENX, INST, SPLIT, DRAIN>(
         sv, bvh, n, st,
         [&](int i0, V3 *o, V3 *d, float *tMax) {
             const int i = list ? list[i0] : i0;
             F4 o4 = q.o[i], d4 = q.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = WF_INFINITY;
+            if constexpr (GenAnim(GENX)) {
+                g_time[threadIdx.x] = o4.w;
+                ws.pathTime[q.meta[i].x] = o4.w;   // the path's time, for the shadow rays this depth spawns (k_intersect_closest<.., ANIM>)
+            }
         },
         [&](int i0, bool valid, const RayWalk &w) {
             const int i = (list && valid) ? list[i0] : i0;
@@ -980,7 +993,7 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GENX), INST ? WF_TWA
             } else
             KRouteHitBlock<(GEN > 1) || INST>(sv, ws, cur, i, valid && !amb, w.prim, w.route, WalkT(w), w.b0, w.b1, w.b2, INST ? w.inst : -1);
         }, SPLIT ? cursor : nullptr, chunk, workBlocks);
-    if constexpr (DRAIN) DrainRetrace<GEN, INST>(sv, ws, bvh, cur, st, false);
+    if constexpr (DRAIN) DrainRetrace<GEN, INST, GenAnim(GENX)>(sv, ws, bvh, cur, st, false);
 }
 // the routing pass of the SPLIT traversal: EnqueueWorkAfterIntersection / Miss for every ray of the queue (block-aggregated pushes)
 // (1024 threads per workgroup: one returning atomic per destination queue per 1024 rays — a queue counter sustains ~88 of them per
@@ -1140,6 +1153,7 @@ __global__ void __launch_bounds__(TBLOCK, TWavesFor(GenBase(GEN), INST ? WF_TWAV
             const int i = list ? list[i0] : i0;
             F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
             *o = V3{o4.x, o4.y, o4.z}; *d = V3{d4.x, d4.y, d4.z}; *tMax = o4.w;
+            if constexpr (GenAnim(GEN)) g_time[threadIdx.x] = ShadowTime<true>(ws, d4.w);
         },
         [&](int i0, bool valid, const RayWalk &w) {
             if (!valid) return;
@@ -1546,7 +1560,7 @@ struct Prof {
     do {                                                                                                       \
         const int gen_ = (GENV);                                                                               \
         const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
-        if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (KERNEL<3, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (KERNEL<4, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<5, true>), __VA_ARGS__); } \
+        if (inst_) { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (KERNEL<3, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (KERNEL<4, true>), __VA_ARGS__); else if (gen_ == 5) LAUNCHT(name, (KERNEL<5, true>), __VA_ARGS__); else if (gen_ == 8) LAUNCHT(name, (KERNEL<8, true>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<9, true>), __VA_ARGS__); } \
         else { if (gen_ == 0) LAUNCHT(name, (KERNEL<0, false>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (KERNEL<1, false>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (KERNEL<2, false>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (KERNEL<3, false>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (KERNEL<4, false>), __VA_ARGS__); else LAUNCHT(name, (KERNEL<5, false>), __VA_ARGS__); } \
     } while (0)
 // the closest-hit walk with the routing split off (ctx->splitRoute)
@@ -1555,7 +1569,7 @@ struct Prof {
     do {                                                                                                       \
         const int gen_ = (GENV);                                                                               \
         const bool inst_ = ctx->svHost.nInstances > 0;                                                         \
-        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (k_closest_fast<3, true, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (k_closest_fast<4, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<5, true, true>), __VA_ARGS__); } \
+        if (inst_) { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, true, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, true, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, true, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (k_closest_fast<3, true, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (k_closest_fast<4, true, true>), __VA_ARGS__); else if (gen_ == 5) LAUNCHT(name, (k_closest_fast<5, true, true>), __VA_ARGS__); else if (gen_ == 8) LAUNCHT(name, (k_closest_fast<8, true, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<9, true, true>), __VA_ARGS__); } \
         else { if (gen_ == 0) LAUNCHT(name, (k_closest_fast<0, false, true>), __VA_ARGS__); else if (gen_ == 1) LAUNCHT(name, (k_closest_fast<1, false, true>), __VA_ARGS__); else if (gen_ == 2) LAUNCHT(name, (k_closest_fast<2, false, true>), __VA_ARGS__); else if (gen_ == 3) LAUNCHT(name, (k_closest_fast<3, false, true>), __VA_ARGS__); else if (gen_ == 4) LAUNCHT(name, (k_closest_fast<4, false, true>), __VA_ARGS__); else LAUNCHT(name, (k_closest_fast<5, false, true>), __VA_ARGS__); } \
     } while (0)
 #define LAUNCHT(name, kernel, grid, ...)                                                   \
@@ -1812,7 +1826,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         std::vector<char> ibOk((size_t)d->n_instances, 0);
         for (int i = 0; i < d->n_instances; ++i) {
             const wf_instance &in = d->instances[i];
-            if (defGeneral[in.def]) continue;
+            if (defGeneral[in.def] || in.anim_plus1 != 0) continue;   // (an AnimatedPrimitive keeps the reference's motion bounds)
             const float(*m)[4] = in.render_from_instance.m;
             if (m[3][0] != 0 || m[3][1] != 0 || m[3][2] != 0 || m[3][3] != 1) continue;
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, mag = 0;
@@ -2066,6 +2080,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             const wf_instance &in = d->instances[i];
             std::vector<Entry> &es = entriesOf[i];
             if (in.def < 0 || in.def >= d->n_instance_defs || defGeneral[in.def]) return;
+            if (in.anim_plus1 != 0) return;   // an AnimatedPrimitive: one entry under the reference's motion bounds (its leaf's box)
             const float(*m)[4] = in.render_from_instance.m;
             if (m[3][0] != 0 || m[3][1] != 0 || m[3][2] != 0 || m[3][3] != 1) return;
             Entry root;
@@ -2786,7 +2801,16 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             }
         }
         if (getenv("WF_NO_FAST")) ctx->fastOk = false;
-        if (d->n_animated > 0) ctx->fastOk = false;   // AnimatedPrimitive: the reference-order walks interpolate the transformation per ray; the production walk does not
+        // AnimatedPrimitive: the production walks' ANIM variants (triangles + simple alpha cut-outs, two-level: an animated shape entity is an
+        // instance) interpolate the transformation per ray since round 6; scenes that also hold quadrics / curves / texture-graph alpha keep the
+        // reference-order walks (WF_ANIM_FAST=0: every animated scene does)
+        ctx->animFast = d->n_animated > 0 && ctx->fastOk && ctx->genMode <= 1 && ctx->svHost.nInstances > 0 && !(getenv("WF_ANIM_FAST") && atoi(getenv("WF_ANIM_FAST")) == 0);
+        if (d->n_animated > 0 && !ctx->animFast) ctx->fastOk = false;
+        if (ctx->animFast) {
+            const bool g1 = ctx->genMode == 1;
+            if ((e = residentGrid(g1 ? (const void *)k_closest_fast<9, true, true> : (const void *)k_closest_fast<8, true, true>, &ctx->persistentGrid)) ||
+                (e = residentGrid(g1 ? (const void *)k_shadow_fast<9, true> : (const void *)k_shadow_fast<8, true>, &ctx->persistentGridShadow))) return e;
+        }
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
@@ -2811,6 +2835,23 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     ctx->fast.sv = ctx->svDev;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sv / sobol live on the host stack
     ctx->sceneLoaded = true;
+    return 0;
+}
+
+int wf_ctx_query(wf_ctx *ctx, const char *key, int64_t *value) {
+    if (!ctx || !key || !value) return fail(-1, "wf_ctx_query: null argument");
+    if (!ctx->sceneLoaded) return fail(-1, "no scene uploaded");
+    const std::string k = key;
+    if (k == "fast_ok") *value = ctx->fastOk;
+    else if (k == "gen_mode") *value = ctx->genMode;
+    else if (k == "gen_tri") *value = ctx->genTri;
+    else if (k == "defer_general") *value = ctx->deferGeneral;
+    else if (k == "anim_fast") *value = ctx->animFast;
+    else if (k == "lean_shade") *value = ctx->leanShade;
+    else if (k == "rare_lights") *value = ctx->rareLights;
+    else if (k.rfind("lean_type_", 0) == 0 && atoi(key + 10) >= 0 && atoi(key + 10) < WF_MAT_NTYPES) *value = ctx->leanType[atoi(key + 10)];
+    else if (k == "instances") *value = ctx->svHost.nInstances;
+    else return fail(-1, "wf_ctx_query: unknown key '%s'", key);
     return 0;
 }
 
@@ -3074,7 +3115,7 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
                 LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest", 4 + ctx->genTri, ctx->persistentGrid, ctx->svHost, ctx->ws, triFast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
                 LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest: rays that met a general primitive", ctx->genMode, ctx->persistentGridGen, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), (int *)nullptr, ctx->cursorChunk, (const int *)ctx->ws.deferQ);
             } else
-            LAUNCHT_CLOSEST_SPLIT("Intersect closest", ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
+            LAUNCHT_CLOSEST_SPLIT_GEN("Intersect closest", ctx->animFast ? 8 + ctx->genMode : ctx->genMode, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, depth & 1, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
             // The near-tie re-trace of the scenes whose walk does not resolve its ties itself (genMode >= 2: quadrics, curves, texture-graph
             // alpha; RetraceInline) is a handful of long single walks: it runs on a second stream beside the routing pass (and, in the
             // fused pass, the next sample-generation launch) — they touch disjoint rays and share only the queue counters, through
@@ -3283,7 +3324,7 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
             LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, 4 + ctx->genTri, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
             LAUNCHT_VARIANT_GEN("Intersect shadow: rays that met a general primitive", k_shadow_fast, ctx->genMode, ctx->persistentGridShadowGen, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), (int *)nullptr, ctx->cursorChunk, (const int *)ctx->ws.deferQ);
         } else
-        LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, ctx->genMode, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
+        LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, ctx->animFast ? 8 + ctx->genMode : ctx->genMode, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
     } else
         { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow", (k_intersect_shadow<false, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
           else LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill); }

@@ -284,8 +284,13 @@ __device__ inline bool InstancePretestMiss(const wf_instance &in, const FastDef 
     }
     return !(t0 <= t1);   // (NaNs never skip)
 }
-template <typename Stack>
-__device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int entry) {
+// ANIM (round 6): the instance may be an AnimatedPrimitive (cpu/primitive.cpp:132-158) — its transformation is interpolated at the ray's
+// `time` (wf_animated.h: the reference's AnimatedTransform::Interpolate restated), as the reference-order walks do (InstanceAt<true>, wf_shapes.h).
+// An animated instance is one entry of the top-level tree, bounded by the reference's motion bounds; the walk inside is the static one.
+// Only the kernels of scenes that have such primitives are built with ANIM: the interpolation is an out-of-line callee whose registers
+// every kernel that can reach it is allocated.
+template <bool ANIM = false, typename Stack>
+__device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V3 oW, V3 dW, int entry, float time = 0) {
     const SubEntry se = bvh.subs[entry];
     const int inst = se.inst;
     if (se.node == NODE_NONE) {   // an instance of an empty definition
@@ -293,7 +298,8 @@ __device__ inline bool EnterInstance(const FastBVH &bvh, RayWalk &w, Stack &st, 
         w.node = st.empty() ? NODE_NONE : st.pop();
         return false;
     }
-    const wf_instance &in = bvh.instances[inst];
+    wf_instance moving;
+    const wf_instance &in = InstanceAt<ANIM>(*bvh.sv, bvh.instances[inst], time, &moving);
     const FastDef fd = bvh.defs[in.def];
 #if WF_INST_PRETEST
     if (InstancePretestMiss(in, fd, oW, dW, WalkBound(bvh, __builtin_fabsf(w.tMax)))) {
@@ -365,7 +371,11 @@ __device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 d
 // an instance ENTRY on the stack / in a child slot (not the exit marker)
 __device__ inline bool IsInstanceEntry(int node) { return node < 0 && node != NODE_NONE && node != NODE_EXIT && (int)((~(unsigned)node) >> 4) >= INST_FIRST; }
 #ifndef WF_SAVE_WORLD
-#define WF_SAVE_WORLD 1   // round 6: ExitInstance reloads the lane's render-space walk constants instead of recomputing them (wf_backend.hip LdsStackT::loadWorld)
+#define WF_SAVE_WORLD 0   // MEASURED AND LEFT OFF (round 6, spec scene, 16 spp, same box, profiles/r06_walk_constants_reload_ab_sm16.txt): ExitInstance
+                          // reloading the lane's render-space walk constants (16 dwords saved per ray: LdsStackT::loadWorld) instead of recomputing
+                          // them (three IEEE divisions, three v_rcp: ~95 VALU instructions) — closest-hit 39.3 ms against 35.9, any-hit 16.8 against
+                          // 16.3: four dependent 16-byte loads in front of every walk that leaves an instance stall the whole wave longer than the
+                          // arithmetic occupies its issue slots
 #endif
 #ifndef WF_FUSE_EXIT_ENTER
 #define WF_FUSE_EXIT_ENTER 1   // round 6: a lane that leaves an instance and pops another instance's entry enters it in the same step, and

@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "wf_film_device_ptr", "wf_film_upload", "wf_film_spectral_download", "wf_film_gbuffer_download", "wf_film_copy_to_device", "wf_film_copy_from_device", "wf_film_gather_strips", "wf_stats_add", "wf_material_items_download", "wf_stats_download",
     "wf_profile_report", "wf_profile_enable",
     "wf_trace_closest_host", "wf_trace_any_host", "wf_sampler_probe", "wf_libm_probe", "wf_kat_probe", "wf_queue_size", "wf_queue_download",
-    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters", "wf_debug_fastbvh_check", "wf_trace_closest_host_t", "wf_trace_any_host_t",
+    "wf_counters_enable", "wf_counters_download", "wf_kernel_time_ms", "wf_debug_counters", "wf_debug_fastbvh_check", "wf_trace_closest_host_t", "wf_trace_any_host_t", "wf_ctx_query",
     "wf_trace_closest_device", "wf_trace_any_device", "wf_device_alloc", "wf_device_free", "wf_device_upload", "wf_device_download", "wf_trace_shadow_tr_host",
 ]
 HOST_SYMBOLS = [
@@ -344,6 +344,14 @@ class Scene:
         out = np.empty((records.shape[0], 8), dtype=np.uint64)
         _check(hip.wf_kat_probe(self.ctx, records.shape[0], records.ctypes.data, out.ctypes.data), "wf_kat_probe")
         return out
+
+    def query(self, key):
+        """wf_ctx_query: which kernel variants the uploaded scene runs ("fast_ok", "gen_mode", "defer_general", "anim_fast", "lean_type_2", ...)"""
+        _, hip = libs()
+        v = C.c_int64(0)
+        hip.wf_ctx_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        _check(hip.wf_ctx_query(self.ctx, key.encode(), C.byref(v)), "wf_ctx_query")
+        return int(v.value)
 
     def fastbvh_check(self, n_rays=32, seed=1):
         """host-only self-check of the production traversal layout (wf_debug_fastbvh_check): needs no device.  Returns a dict."""

@@ -163,7 +163,7 @@ def _render_both(scene, path, spp, tmp_path):
     return img, read_pfm(out), j
 
 
-@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "textures_deep", "textures_scale_fold", "tangents_s", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "bilinear_emission", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "camera_motion", "camera_motion_spherical", "quadrics_alpha", "curves_alpha", "animated", "animated_sss", "face_indices", "goniometric_png",
+@pytest.mark.parametrize("name", ["cornell64", "blobs_small", "materials_lights", "materials_lights_power", "media_box", "rgbgrid_medium", "tempgrid_medium", "envmap", "textures_bump", "spherical_camera", "image_textures", "alpha_normalmap", "spheres", "quadrics", "lights_extra", "texture_mappings", "textures_extra", "textures_deep", "textures_scale_fold", "tangents_s", "arealight_image", "instances", "subsurface", "blobs_hlbvh", "textures_noise", "cloud_medium", "media_instances", "hair", "measured", "bilinear", "bilinear_lights", "bilinear_emission", "instances_quadrics", "media_preset", "subsurface_named", "arealight_alpha", "png_textures", "textures_ewa", "curves", "realistic_camera", "realistic_camera_star", "portal_light", "portal_uniform", "loopsubdiv", "film_whitebalance", "film_sensor", "film_sensor_wb", "displacement", "plymesh_mixed", "camera_motion", "camera_motion_spherical", "quadrics_alpha", "curves_alpha", "animated", "animated_sss", "animated_tris", "animated_tris_alpha", "face_indices", "goniometric_png",
                                   "cornell64_independent", "cornell64_stratified", "cornell64_paddedsobol", "cornell64_halton", "cornell64_sobol", "cornell64_sobol_owen"])
 def test_image_vs_oracle_and_reference(wfpt, tmp_path, name):
     _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
@@ -203,6 +203,44 @@ def test_two_class_traversal_and_rebraided_instances(wfpt, tmp_path, monkeypatch
     monkeypatch.setenv("WF_DEFER_GENERAL", "1")
     monkeypatch.setenv("WF_BRAID", str(braid))
     _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
+
+
+@pytest.mark.parametrize("name", ["animated", "animated_sss", "animated_tris", "animated_tris_alpha"])
+def test_animated_primitives_on_the_production_walk(wfpt, tmp_path, monkeypatch, name):
+    """AnimatedPrimitive (cpu/primitive.cpp:132-158) through the production traversal kernels' ANIM variants (round 6: one entry of the
+    top-level tree under the reference's motion bounds, the transformation interpolated at the ray's time when the walk enters it) —
+    and, with WF_ANIM_FAST=0, through the reference-order walks as in round 5: both bit-identical with the reference's render."""
+    path = os.path.join(GOLDEN, name + ".pbrt")
+    s = wfpt.Scene(path=path, spp=4)
+    s.create_renderer(0)
+    fast = s.query("anim_fast") == 1 and s.query("fast_ok") == 1
+    s.close()
+    # (the two scenes with quadrics keep the reference-order walks: genMode >= 2; the triangle-only ones take the production walk)
+    assert fast == name.startswith("animated_tris"), (name, fast)
+    _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
+    monkeypatch.setenv("WF_ANIM_FAST", "0")
+    _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
+
+
+def test_variant_selection_queries(wfpt):
+    """which kernel variants a scene runs (wf_ctx_query): the paths the parity tests mean to cover are the paths taken"""
+    def q(name, keys, **env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            s = wfpt.Scene(path=os.path.join(GOLDEN, name + ".pbrt"), spp=4)
+            s.create_renderer(0)
+            r = {k: s.query(k) for k in keys}
+            s.close()
+            return r
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert q("cornell64", ["fast_ok", "gen_mode", "lean_shade", "defer_general"]) == {"fast_ok": 1, "gen_mode": 0, "lean_shade": 1, "defer_general": 0}
+    r = q("instances_quadrics", ["fast_ok", "gen_mode", "defer_general", "instances"], WF_DEFER_GENERAL=1)
+    assert r["fast_ok"] == 1 and r["gen_mode"] >= 2 and r["defer_general"] == 1 and r["instances"] > 0, r
+    assert q("instances_quadrics", ["defer_general"], WF_DEFER_GENERAL=0)["defer_general"] == 0
+    assert q("animated_sss", ["fast_ok", "anim_fast"], WF_ANIM_FAST=0) == {"fast_ok": 0, "anim_fast": 0}
 
 
 @pytest.mark.parametrize("name", ["sanmiguel_like_small", "tm_like_small", "cloud_like_small"])

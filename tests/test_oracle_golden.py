@@ -40,7 +40,7 @@ def test_triangle_golden_covers_hits_misses_edges():
     assert np.allclose(b.sum(axis=1), 1, atol=1e-5)
 
 
-@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("cornell400", 16), ("blobs_small", 4), ("materials_lights", 4), ("materials_lights_power", 4), ("media_box", 4), ("rgbgrid_medium", 4), ("tempgrid_medium", 4), ("envmap", 4), ("textures_bump", 4), ("spherical_camera", 4), ("image_textures", 4), ("alpha_normalmap", 4), ("spheres", 4), ("quadrics", 4), ("lights_extra", 4), ("texture_mappings", 4), ("textures_extra", 4), ("textures_deep", 4), ("textures_scale_fold", 4), ("tangents_s", 4), ("arealight_image", 4), ("instances", 4), ("subsurface", 4), ("blobs_hlbvh", 4), ("textures_noise", 4), ("cloud_medium", 4), ("media_instances", 4), ("hair", 4), ("measured", 4), ("bilinear", 4), ("bilinear_lights", 4), ("bilinear_emission", 4), ("instances_quadrics", 4), ("media_preset", 4), ("subsurface_named", 4), ("arealight_alpha", 4), ("png_textures", 4), ("textures_ewa", 4), ("curves", 4), ("realistic_camera", 4), ("realistic_camera_star", 4), ("portal_light", 4), ("portal_uniform", 4), ("loopsubdiv", 4), ("film_whitebalance", 4), ("film_sensor", 4), ("film_sensor_wb", 4), ("displacement", 4), ("plymesh_mixed", 4), ("camera_motion", 4), ("camera_motion_spherical", 4), ("rendercoordsys_camera", 4), ("rendercoordsys_world", 4), ("parser_torture", 4), ("empty_scene", 4), ("quadrics_alpha", 4), ("curves_alpha", 4), ("animated", 4), ("animated_sss", 4), ("face_indices", 4), ("goniometric_png", 4),
+@pytest.mark.parametrize("scene,spp", [("cornell64", 4), ("cornell400", 16), ("blobs_small", 4), ("materials_lights", 4), ("materials_lights_power", 4), ("media_box", 4), ("rgbgrid_medium", 4), ("tempgrid_medium", 4), ("envmap", 4), ("textures_bump", 4), ("spherical_camera", 4), ("image_textures", 4), ("alpha_normalmap", 4), ("spheres", 4), ("quadrics", 4), ("lights_extra", 4), ("texture_mappings", 4), ("textures_extra", 4), ("textures_deep", 4), ("textures_scale_fold", 4), ("tangents_s", 4), ("arealight_image", 4), ("instances", 4), ("subsurface", 4), ("blobs_hlbvh", 4), ("textures_noise", 4), ("cloud_medium", 4), ("media_instances", 4), ("hair", 4), ("measured", 4), ("bilinear", 4), ("bilinear_lights", 4), ("bilinear_emission", 4), ("instances_quadrics", 4), ("media_preset", 4), ("subsurface_named", 4), ("arealight_alpha", 4), ("png_textures", 4), ("textures_ewa", 4), ("curves", 4), ("realistic_camera", 4), ("realistic_camera_star", 4), ("portal_light", 4), ("portal_uniform", 4), ("loopsubdiv", 4), ("film_whitebalance", 4), ("film_sensor", 4), ("film_sensor_wb", 4), ("displacement", 4), ("plymesh_mixed", 4), ("camera_motion", 4), ("camera_motion_spherical", 4), ("rendercoordsys_camera", 4), ("rendercoordsys_world", 4), ("parser_torture", 4), ("empty_scene", 4), ("quadrics_alpha", 4), ("curves_alpha", 4), ("animated", 4), ("animated_sss", 4), ("animated_tris", 4), ("animated_tris_alpha", 4), ("face_indices", 4), ("goniometric_png", 4),
                                        ("cornell64_independent", 0), ("cornell64_stratified", 0), ("cornell64_paddedsobol", 0), ("cornell64_halton", 0), ("cornell64_sobol", 0), ("cornell64_sobol_owen", 0)])
 def test_cpu_checker_image_matches_reference_wavefront(built, tmp_path, scene, spp):
     """Whole path, sample-aligned: oracle/wf_cpu vs the reference's CPU WavefrontPathIntegrator
