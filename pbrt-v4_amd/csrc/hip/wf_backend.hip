@@ -291,6 +291,10 @@ __device__ inline void StoreWorldRay(V3 o, V3 d) {
     g_ray[0 * TBLOCK + threadIdx.x] = o.x; g_ray[1 * TBLOCK + threadIdx.x] = o.y; g_ray[2 * TBLOCK + threadIdx.x] = o.z;
     g_ray[3 * TBLOCK + threadIdx.x] = d.x; g_ray[4 * TBLOCK + threadIdx.x] = d.y; g_ray[5 * TBLOCK + threadIdx.x] = d.z;
 }
+// WF_SAVE_WORLD == 2: nine of the lane's render-space walk constants (a, bk of WalkSetSlab and the shear's S: what costs a reciprocal or an
+// IEEE division to rebuild), kept in LDS from the ray's start for every exit from an instance — 9 KiB per workgroup: with them the
+// two-level kernels use 39 KiB, four workgroups still fit a CU's 160 KiB
+__shared__ float g_save[9 * TBLOCK];
 // the ray's time, for the kernels of scenes with animated primitives (written by their fetch functors, read at instance entries)
 __shared__ float g_time[TBLOCK];
 __device__ inline V3 WorldRayO() { return V3{g_ray[0 * TBLOCK + threadIdx.x], g_ray[1 * TBLOCK + threadIdx.x], g_ray[2 * TBLOCK + threadIdx.x]}; }
@@ -326,7 +330,23 @@ struct LdsStackT {
         save[2 * S] = F4{w.af.z, w.bf.x, w.bf.y, w.bf.z};
         save[3 * S] = F4{BitsToFloat((uint32_t)w.sh.kz), w.sh.Sx, w.sh.Sy, w.sh.Sz};
     }
-    __device__ void loadWorld(RayWalk &w, V3 oW) const {
+    __device__ void saveWorldLds(const float a[3], const float bk[3], const RayShear &sh) const {
+        const int t = threadIdx.x;
+        g_save[0 * TBLOCK + t] = a[0]; g_save[1 * TBLOCK + t] = a[1]; g_save[2 * TBLOCK + t] = a[2];
+        g_save[3 * TBLOCK + t] = bk[0]; g_save[4 * TBLOCK + t] = bk[1]; g_save[5 * TBLOCK + t] = bk[2];
+        g_save[6 * TBLOCK + t] = sh.Sx; g_save[7 * TBLOCK + t] = sh.Sy; g_save[8 * TBLOCK + t] = sh.Sz;
+    }
+    __device__ void loadWorld(RayWalk &w, V3 oW, V3 dW) const {
+#if WF_SAVE_WORLD == 2
+        const int t = threadIdx.x;
+        const float a[3] = {g_save[0 * TBLOCK + t], g_save[1 * TBLOCK + t], g_save[2 * TBLOCK + t]};
+        const float bk[3] = {g_save[3 * TBLOCK + t], g_save[4 * TBLOCK + t], g_save[5 * TBLOCK + t]};
+        w.o = oW;
+        w.sh.kz = MaxComponentIndex(Abs(dW));   // (MakeRayShear's permutation; its three divisions are the saved S)
+        w.sh.Sx = g_save[6 * TBLOCK + t]; w.sh.Sy = g_save[7 * TBLOCK + t]; w.sh.Sz = g_save[8 * TBLOCK + t];
+        WalkSlabFromAB(w, a, bk);
+        return;
+#endif
         const size_t S = (size_t)spillStride;
         const F4 p0 = save[0], p1 = save[S], p2 = save[2 * S], p3 = save[3 * S];
         w.o = oW;
@@ -658,9 +678,11 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
             V3 o, d;
             float tMax;
             fetch(idx, &o, &d, &tMax);
-            WalkInit(bvh, w, o, d, tMax);
+            float sa[3], sb[3];
+            WalkInit(bvh, w, o, d, tMax, sa, sb);
             if constexpr (INST || GEN > 0) StoreWorldRay(o, d);
-            if constexpr (INST && WF_SAVE_WORLD) st.saveWorld(w);
+            if constexpr (INST && WF_SAVE_WORLD == 1) st.saveWorld(w);
+            if constexpr (INST && WF_SAVE_WORLD == 2) st.saveWorldLds(sa, sb, w.sh);
             st.reset();
         }
         // (Measured and dropped: parking a lane's first leaf and descending on speculatively — 11 % slower; continuous
@@ -778,9 +800,11 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
                 V3 o, d;
                 float tMax;
                 fetch(idx, &o, &d, &tMax);
-                WalkInit(bvh, w, o, d, tMax);
+                float sa[3], sb[3];
+                WalkInit(bvh, w, o, d, tMax, sa, sb);
                 if constexpr (INST || GEN > 0) StoreWorldRay(o, d);
-                if constexpr (INST && WF_SAVE_WORLD) st.saveWorld(w);
+                if constexpr (INST && WF_SAVE_WORLD == 1) st.saveWorld(w);
+                if constexpr (INST && WF_SAVE_WORLD == 2) st.saveWorldLds(sa, sb, w.sh);
                 st.reset();
             }
             if (exhausted && !__any(w.node != NODE_NONE)) break;
@@ -3161,7 +3185,9 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
 int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
-    if (ctx->fastOk && !ctx->countTraversal && RetraceInline(ctx->genMode) && (ctx->trWavefront == 1 || (ctx->trWavefront < 0 && ctx->svHost.nInstances > 0))) {
+    // (a scene with AnimatedPrimitives keeps the reference-order transmittance walk, which interpolates their transformations at the shadow
+    //  ray's time: the transmittance wavefront's walk kernel has no ANIM variant — fuzz scene s6300008, round 6)
+    if (ctx->fastOk && !ctx->animFast && !ctx->countTraversal && RetraceInline(ctx->genMode) && (ctx->trWavefront == 1 || (ctx->trWavefront < 0 && ctx->svHost.nInstances > 0))) {
         // the transmittance wavefront (see k_tr_begin)
         LAUNCH("Reset transmittance queues", k_reset, 1, ctx->ws, (1u << CNT_TR0) | (1u << CNT_TR1), -1, 0);
         LAUNCH("Intersect shadow (Tr): begin", k_tr_begin, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws);
@@ -3178,7 +3204,7 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
             LAUNCH("Reset transmittance queues", k_reset, 1, ctx->ws, 1u << (CNT_TR0 + cur), -1, 0);
         }
         LAUNCH("Intersect shadow (Tr): rest", k_tr_rest, 128, ctx->svHost, ctx->ws, WF_TR_SEGMENTS & 1, ctx->stackSpill);
-    } else if (ctx->fastOk && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the per-lane production walk has no two-level variant)
+    } else if (ctx->fastOk && !ctx->animFast && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the per-lane production walk has no two-level variant)
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
     else

@@ -201,35 +201,43 @@ struct RayWalk {
 #define WF_SLAB_RCP 1
 #endif
 // the slab constants alone (the box tests' part of the per-ray state)
-__device__ inline void WalkSetSlab(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
+// the slab constants from the per-axis products a = cell / d and bk = (base - o) / d (the part of WalkSetSlab that needs no reciprocal)
+__device__ inline void WalkSlabFromAB(RayWalk &w, const float a[3], const float bk[3]) {
     constexpr float SLACK = 0x1p-20f;            // 16 ulp
     constexpr float G = 1 + 2 * gamma(3);        // the reference's tMax factor
-    constexpr float INV_MAX = 1e28f;             // |1/d| clamp: keeps every product finite (no 0 * inf NaNs)
-    const float dd[3] = {d.x, d.y, d.z}, oo[3] = {o.x, o.y, o.z};
-    float a[3], bn[3], af[3], bf[3];
+    float bn[3], af[3], bf[3];
     uint32_t sel[3];
     for (int k = 0; k < 3; ++k) {
-        // v_rcp_f32 (1 ulp) instead of the IEEE division (ten instructions): the constants feed the conservative slab test only, and
-        // the 16-ulp SLACK below covers one more ulp in a and b (the exact triangle test keeps its IEEE divisions, MakeRayShear)
-        float inv = WF_SLAB_RCP ? __builtin_amdgcn_rcpf(dd[k]) : 1 / dd[k];
-        if (!(fabsf(inv) <= INV_MAX)) inv = copysignf(INV_MAX, dd[k]);
-        const float ak = cell[k] * inv, bk = (base[k] - oo[k]) * inv;
-        const float delta = SLACK * fma(65535.f, fabsf(ak), fabsf(bk));
-        a[k] = ak; bn[k] = bk - delta;
-        af[k] = ak * G; bf[k] = fma(bk, G, delta * 1.001f);
-        sel[k] = (FloatToBits(dd[k]) >> 31) ? 0x01000302u : 0x03020100u;  // negative direction (incl. -0): swap halves
+        const float delta = SLACK * fma(65535.f, fabsf(a[k]), fabsf(bk[k]));
+        bn[k] = bk[k] - delta;
+        af[k] = a[k] * G; bf[k] = fma(bk[k], G, delta * 1.001f);
+        sel[k] = (FloatToBits(a[k]) >> 31) ? 0x01000302u : 0x03020100u;  // negative direction (incl. -0: the sign of 1/d, kept by the clamp): swap halves
     }
     w.a = V3{a[0], a[1], a[2]}; w.bn = V3{bn[0], bn[1], bn[2]};
     w.af = V3{af[0], af[1], af[2]}; w.bf = V3{bf[0], bf[1], bf[2]};
     w.selx = sel[0]; w.sely = sel[1]; w.selz = sel[2];
 }
-__device__ inline void WalkSetRay(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d) {
+__device__ inline void WalkSetSlab(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d, float *aOut = nullptr, float *bkOut = nullptr) {
+    constexpr float INV_MAX = 1e28f;             // |1/d| clamp: keeps every product finite (no 0 * inf NaNs)
+    const float dd[3] = {d.x, d.y, d.z}, oo[3] = {o.x, o.y, o.z};
+    float a[3], bk[3];
+    for (int k = 0; k < 3; ++k) {
+        // v_rcp_f32 (1 ulp) instead of the IEEE division (ten instructions): the constants feed the conservative slab test only, and
+        // the 16-ulp SLACK covers one more ulp in a and b (the exact triangle test keeps its IEEE divisions, MakeRayShear)
+        float inv = WF_SLAB_RCP ? __builtin_amdgcn_rcpf(dd[k]) : 1 / dd[k];
+        if (!(fabsf(inv) <= INV_MAX)) inv = copysignf(INV_MAX, dd[k]);
+        a[k] = cell[k] * inv; bk[k] = (base[k] - oo[k]) * inv;
+        if (aOut) { aOut[k] = a[k]; bkOut[k] = bk[k]; }
+    }
+    WalkSlabFromAB(w, a, bk);
+}
+__device__ inline void WalkSetRay(const float base[3], const float cell[3], RayWalk &w, V3 o, V3 d, float *aOut = nullptr, float *bkOut = nullptr) {
     w.o = o;
     w.sh = MakeRayShear(d);
-    WalkSetSlab(base, cell, w, o, d);
+    WalkSetSlab(base, cell, w, o, d, aOut, bkOut);
 }
-__device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, float tMax) {
-    WalkSetRay(bvh.base, bvh.cell, w, o, d);
+__device__ inline void WalkInit(const FastBVH &bvh, RayWalk &w, V3 o, V3 d, float tMax, float *aOut = nullptr, float *bkOut = nullptr) {
+    WalkSetRay(bvh.base, bvh.cell, w, o, d, aOut, bkOut);
     w.tMax = tMax;
     w.node = 0;
     w.prim = -1;
@@ -371,7 +379,7 @@ __device__ inline void WalkMakeExact(const FastBVH &bvh, RayWalk &w, V3 oW, V3 d
 // an instance ENTRY on the stack / in a child slot (not the exit marker)
 __device__ inline bool IsInstanceEntry(int node) { return node < 0 && node != NODE_NONE && node != NODE_EXIT && (int)((~(unsigned)node) >> 4) >= INST_FIRST; }
 #ifndef WF_SAVE_WORLD
-#define WF_SAVE_WORLD 0   // MEASURED AND LEFT OFF (round 6, spec scene, 16 spp, same box, profiles/r06_walk_constants_reload_ab_sm16.txt): ExitInstance
+#define WF_SAVE_WORLD 0   // 0 = recompute (shipped); 2 = nine of the constants kept in LDS (flat: 35.8 against 36.0 ms, profiles/r06_walk_constants_lds_ab_sm16.txt); 1 = through HBM, MEASURED AND LEFT OFF (round 6, spec scene, 16 spp, same box, profiles/r06_walk_constants_reload_ab_sm16.txt): ExitInstance
                           // reloading the lane's render-space walk constants (16 dwords saved per ray: LdsStackT::loadWorld) instead of recomputing
                           // them (three IEEE divisions, three v_rcp: ~95 VALU instructions) — closest-hit 39.3 ms against 35.9, any-hit 16.8 against
                           // 16.3: four dependent 16-byte loads in front of every walk that leaves an instance stall the whole wave longer than the
@@ -408,7 +416,7 @@ __device__ inline void ExitInstance(const FastBVH &bvh, RayWalk &w, Stack &st, V
     WF_LAZY_SET(w, 2);
 #else
 #if WF_SAVE_WORLD
-    if (!(WF_FUSE_EXIT_ENTER && IsInstanceEntry(next))) st.loadWorld(w, oW);   // the render-space constants, saved when the ray started (LdsStackT)
+    if (!(WF_FUSE_EXIT_ENTER && IsInstanceEntry(next))) st.loadWorld(w, oW, dW);   // the render-space constants, saved when the ray started (LdsStackT)
 #else
     if (!(WF_FUSE_EXIT_ENTER && IsInstanceEntry(next))) WalkSetRay(bvh.base, bvh.cell, w, oW, dW);
 #endif
