@@ -552,6 +552,15 @@ def main():
                         "algorithmic_bytes": b, "algorithmic_bytes_per_item": b / n_items, "total_ms": mat_ms, "launches": mat_launches,
                         "mitems_per_s": n_items / (mat_ms * 1e-3) / 1e6,
                     }
+                    # what the split stage moves BY DESIGN on top of the SURVEY 8(d) bytes: k_mat_shade stores the item's NeeItem,
+                    # k_mat_nee loads it — (10 + NBX(type)) planes of 16 B each way (wf_mat.hip NeeIO; NBX = ceil(sizeof(BxDF) / 16)).  Reported
+                    # beside `frac` (which stays the contract's 300 B/item model), not folded into it.
+                    nbx = {1: 1, 2: 3, 3: 2, 4: 1, 5: 2, 6: 5, 7: 7, 8: 2, 9: 5, 10: 2}
+                    nee_b = sum(2.0 * 16.0 * (10 + nbx.get(int(k), 2)) * v for k, v in items.items() if k != "medium_sample" and v)
+                    out["roofline_material"]["as_built"] = {
+                        "nee_record_bytes_per_item": nee_b / n_items, "bytes_per_item": (b + nee_b) / n_items,
+                        "achieved": (b + nee_b) / (mat_ms * 1e-3) / 1e9, "frac": (b + nee_b) / (mat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "SURVEY 8(d) bytes + the NeeItem the two material kernels hand over through HBM (store + load)"}
                     if live and "material" in live:   # HBM bytes per item of the k_eval_material kernels, from the same PMC child passes
                         rm = out["roofline_material"]
                         rm["traffic_bytes_per_item"] = live["material"]["hbm_bytes_per_ray"]

@@ -579,7 +579,7 @@ static int Main(int argc, char **argv) {
             char b[1024];
             snprintf(b, sizeof(b), "o %a %a %a d %a %a %a tMax %a Ld %s r_u %s r_l %s", r.o[i].x, r.o[i].y, r.o[i].z, r.d[i].x, r.d[i].y, r.d[i].z, r.o[i].w, s4(r.Ld[i]).c_str(),
                      s4(r.r_u[i]).c_str(), s4(r.r_l[i]).c_str());
-            v.emplace_back((int)FloatToBits(r.d[i].w), b);
+            v.emplace_back(ShadowPixel(r.d[i].w), b);   // (the pixel without the SHADOW_TIME_ZERO flag bit: ADVICE r5)
         }
         traceLines(tag, depth, v);
     };

@@ -40,11 +40,13 @@ enum {
     CNT_CURSOR_SHADOW,                  // the any-hit launch's work cursor (CNT_CURSOR: the closest-hit launch's)
     CNT_MEDIUM_ROUTE,                   // medium-sample items that reached their surface (KMediumRoute)
     CNT_DEFER, CNT_DEFER_SHADOW,        // rays the triangle walk handed to the general-primitive walk (round 6, wf_backend.hip "TWO-CLASS TRAVERSAL")
+    CNT_CURSOR_MEDIUM,                  // the medium-sample launch's work cursor (round 6: k_medium_sample with wave-level refill)
     CNT_COUNT
 };
 // every counter sits alone in its own 256-byte line: same-line atomics serialise at one L2 channel
 // (~88 returning atomics/us on MI355X), and with adjacent ints every queue of a stage shared that budget
 constexpr int CNT_STRIDE = 64;
+static_assert(CNT_COUNT <= 32, "k_reset takes the counters to zero as a 32-bit mask");
 enum { RAYFLAG_SPECULAR_BOUNCE = 1, RAYFLAG_ANY_NONSPECULAR = 2 };
 
 struct RayQueueV {
@@ -604,75 +606,150 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
 // K5: SampleMediumInteraction, wavefront/media.cpp:22-257.  The MediumSampleWorkItem is the ray slot i of the
 // current queue + its hit record; beta / r_u / r_l are written back into the slot, so the consumers that follow
 // (escaped, emitter hit, material evaluation, medium scattering) see the medium-attenuated values.
-WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+// Round 6: the delta-tracking loop as an explicit state (MediumTrack) with three pieces — Begin (load the item, seed the RNG, set up the
+// majorant iterator), Step (at most one majorant segment fetched and one tentative collision taken; false = the item is finished) and End
+// (write-back and routing) — so that the HIP kernel can run it with WAVE-LEVEL REFILL (k_medium_sample, wf_backend.hip: a wave whose items
+// are mostly finished retires them and takes new ones instead of idling until the longest walk of its 64 ends; the lever the traversal
+// kernels use).  SampleT_maj's two nested loops (media.h:724-800) are the same sequence of operations per item: the
+// outer loop's "next segment" and the inner loop's "next exponential step" are the two halves of Step.  The CPU checker and the
+// reference-order path run Begin; while (Step); End — the same code.
+struct MediumTrack {
+    int i;               // ray slot (-1: the lane holds no item)
+    int pixelIndex, depth, medium;
+    V3 o, d;             // origin, NORMALISED direction (SampleT_maj normalises first)
+    float tMaxHit;       // the ray's hit distance as recorded (ws.hitT: in units of the unnormalised direction)
+    MediumAtLambda ml;
+    MajorantIter iter;
+    MajorantSeg seg;
+    float tMin;
+    bool inSeg, scattered, stopped;   // stopped: the callback ended the walk (SampleT_maj then returns 1, not the running T_maj)
+    S4 T_maj, beta, r_u, r_l, L;
+    RNG rng;
+    float u, uMode;
+};
+WF_HD void MediumTrackBegin(const SceneView &sv, const WorkState &ws, int cur, int qi, MediumTrack &s) {
     const int i = ws.mediumSampleQ[qi];
     const RayQueueV &q = ws.rq[cur];
     F4 o4 = q.o[i], d4 = q.d[i];
     I4 meta = q.meta[i];
-    const int pixelIndex = meta.x, depth = meta.y, medium = meta.w;
+    s.i = i;
+    s.pixelIndex = meta.x; s.depth = meta.y; s.medium = meta.w;
     V3 ro{o4.x, o4.y, o4.z}, rd{d4.x, d4.y, d4.z};
-    F4 h = ws.hit[i];
-    const int prim = (int)FloatToBits(h.x);
-    const float tMax = ws.hitT[i];
-    Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]), r_l = toS4(q.r_l[i]);
-    S4 L = S4c(0.f);
-    RNG rng(Hash3f1(ro, tMax), Hash3f(rd));
-    bool scattered = false;
-    float uDist = rng.UniformFloat();
-    float uMode = rng.UniformFloat();
-    S4 T_maj = SampleT_maj(sv, medium, ro, rd, tMax, uDist, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
-        // emission, scaled by sigma_a / sigma_maj at every event (media.cpp:72-83)
-        if (depth < sv.maxDepth && mp.Le) {
-            float pr = sigma_maj[0] * T_maj[0];
-            S4 r_e = r_u * sigma_maj * T_maj / pr;
-            if (r_e) L = L + beta * mp.sigma_a * T_maj * mp.Le / (pr * r_e.Average());
+    float tMax = ws.hitT[i];
+    s.tMaxHit = tMax;
+    Wavelengths lambda = LoadLambda(ws, s.pixelIndex);
+    s.beta = toS4(q.beta[i]); s.r_u = toS4(q.r_u[i]); s.r_l = toS4(q.r_l[i]);
+    s.L = S4c(0.f);
+    s.rng = RNG(Hash3f1(ro, tMax), Hash3f(rd));
+    s.scattered = false;
+    s.stopped = false;
+    s.u = s.rng.UniformFloat();
+    s.uMode = s.rng.UniformFloat();
+    // SampleT_maj's preamble (media.h:728-741)
+    const wf_medium &M = sv.media[s.medium];
+    tMax *= Length(rd);
+    s.o = ro;
+    s.d = Normalize(rd);
+    s.ml = MediumSpectra(sv, M, lambda);
+    s.iter = MediumSampleRay(sv, M, s.ml, s.o, s.d, tMax);
+    s.T_maj = S4c(1.f);
+    s.inSeg = false;
+    s.tMin = 0;
+}
+// the callback of SampleMediumInteraction (wavefront/media.cpp:60-140) at a tentative collision; false = the walk ends here
+WF_HD bool MediumTrackEvent(const SceneView &sv, const WorkState &ws, int cur, MediumTrack &s, V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
+    // emission, scaled by sigma_a / sigma_maj at every event (media.cpp:72-83)
+    if (s.depth < sv.maxDepth && mp.Le) {
+        float pr = sigma_maj[0] * T_maj[0];
+        S4 r_e = s.r_u * sigma_maj * T_maj / pr;
+        if (r_e) s.L = s.L + s.beta * mp.sigma_a * T_maj * mp.Le / (pr * r_e.Average());
+    }
+    float pAbsorb = mp.sigma_a[0] / sigma_maj[0];
+    float pScatter = mp.sigma_s[0] / sigma_maj[0];
+    float pNull = fmax(0.f, 1 - pAbsorb - pScatter);
+    const float w3[3] = {pAbsorb, pScatter, pNull};
+    int mode = SampleDiscreteN(w3, 3, s.uMode);
+    if (mode == 0) {
+        s.beta = S4c(0.f);
+        return false;
+    } else if (mode == 1) {
+        float pr = T_maj[0] * mp.sigma_s[0];
+        s.beta = s.beta * (T_maj * mp.sigma_s / pr);
+        s.r_u = s.r_u * (T_maj * mp.sigma_s / pr);
+        if (s.beta && s.r_u) {
+            // MediumScatterWorkItem push (media.cpp:104-113)
+            const RayQueueV &q = ws.rq[cur];
+            q.beta[s.i] = toF4(s.beta);
+            q.r_u[s.i] = toF4(s.r_u);
+            ws.scatterP[s.i] = F4{p.x, p.y, p.z, mp.g};
+            int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE]);
+            ws.mediumScatterQ[slot] = s.i;
         }
-        float pAbsorb = mp.sigma_a[0] / sigma_maj[0];
-        float pScatter = mp.sigma_s[0] / sigma_maj[0];
-        float pNull = fmax(0.f, 1 - pAbsorb - pScatter);
-        const float w3[3] = {pAbsorb, pScatter, pNull};
-        int mode = SampleDiscreteN(w3, 3, uMode);
-        if (mode == 0) {
-            beta = S4c(0.f);
-            return false;
-        } else if (mode == 1) {
-            float pr = T_maj[0] * mp.sigma_s[0];
-            beta = beta * (T_maj * mp.sigma_s / pr);
-            r_u = r_u * (T_maj * mp.sigma_s / pr);
-            if (beta && r_u) {
-                // MediumScatterWorkItem push (media.cpp:104-113)
-                q.beta[i] = toF4(beta);
-                q.r_u[i] = toF4(r_u);
-                ws.scatterP[i] = F4{p.x, p.y, p.z, mp.g};
-                int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE]);
-                ws.mediumScatterQ[slot] = i;
-            }
-            scattered = true;
-            return false;
-        } else {
-            S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
-            float pr = T_maj[0] * sigma_n[0];
-            beta = beta * (T_maj * sigma_n / pr);
-            if (pr == 0) beta = S4c(0.f);
-            r_u = r_u * (T_maj * sigma_n / pr);
-            r_l = r_l * (T_maj * sigma_maj / pr);
-            uMode = rng.UniformFloat();
-            return bool(beta) && bool(r_u);
+        s.scattered = true;
+        return false;
+    } else {
+        S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
+        float pr = T_maj[0] * sigma_n[0];
+        s.beta = s.beta * (T_maj * sigma_n / pr);
+        if (pr == 0) s.beta = S4c(0.f);
+        s.r_u = s.r_u * (T_maj * sigma_n / pr);
+        s.r_l = s.r_l * (T_maj * sigma_maj / pr);
+        s.uMode = s.rng.UniformFloat();
+        return bool(s.beta) && bool(s.r_u);
+    }
+}
+WF_HD bool MediumTrackStep(const SceneView &sv, const WorkState &ws, int cur, MediumTrack &s) {
+    if (!s.inSeg) {
+        // the outer loop of SampleT_maj: the next majorant segment
+        if (!s.iter.Next(&s.seg)) return false;
+        if (s.seg.sigma_maj[0] == 0) {
+            float dt = s.seg.tMax - s.seg.tMin;
+            if (IsInf(dt)) dt = WF_FLT_MAX;
+            s.T_maj = s.T_maj * FastExp(-dt * s.seg.sigma_maj);
+            return true;
         }
-    });
-    if (!scattered && beta) {
+        s.tMin = s.seg.tMin;
+        s.inSeg = true;
+    }
+    // the inner loop: one exponential step inside the segment
+    float t = s.tMin + SampleExponential(s.u, s.seg.sigma_maj[0]);
+    s.u = s.rng.UniformFloat();
+    if (t < s.seg.tMax) {
+        s.T_maj = s.T_maj * FastExp(-(t - s.tMin) * s.seg.sigma_maj);
+        V3 p = s.o + s.d * t;
+        const wf_medium &M = sv.media[s.medium];
+        MediumProps mp = MediumSamplePoint(sv, M, s.ml, p);
+        if (!MediumTrackEvent(sv, ws, cur, s, p, mp, s.seg.sigma_maj, s.T_maj)) {
+            s.stopped = true;
+            return false;
+        }
+        s.T_maj = S4c(1.f);
+        s.tMin = t;
+    } else {
+        float dt = s.seg.tMax - s.tMin;
+        if (IsInf(dt)) dt = WF_FLT_MAX;
+        s.T_maj = s.T_maj * FastExp(-dt * s.seg.sigma_maj);
+        s.inSeg = false;
+    }
+    return true;
+}
+WF_HD void MediumTrackEnd(const SceneView &sv, const WorkState &ws, int cur, MediumTrack &s) {
+    const int i = s.i;
+    const RayQueueV &q = ws.rq[cur];
+    const S4 T_maj = s.stopped ? S4c(1.f) : s.T_maj;
+    S4 beta = s.beta, r_u = s.r_u, r_l = s.r_l;
+    if (!s.scattered && beta) {
         beta = beta * (T_maj / T_maj[0]);
         r_u = r_u * (T_maj / T_maj[0]);
         r_l = r_l * (T_maj / T_maj[0]);
     }
-    if (L) ws.L[pixelIndex] = toF4(toS4(ws.L[pixelIndex]) + L);
-    if (scattered || !beta || !r_u || depth == sv.maxDepth) return;
+    if (s.L) ws.L[s.pixelIndex] = toF4(toS4(ws.L[s.pixelIndex]) + s.L);
+    if (s.scattered || !beta || !r_u || s.depth == sv.maxDepth) return;
     // the ray reached the surface (or left the scene): route it as EnqueueWorkAfterIntersection would have
     q.beta[i] = toF4(beta);
     q.r_u[i] = toF4(r_u);
     q.r_l[i] = toF4(r_l);
-    if (IsInf(tMax)) {
+    if (IsInf(s.tMaxHit)) {
         if (sv.nInfiniteLights > 0) {
             int slot = QueueAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE]);
             ws.escapedQ[slot] = i;
@@ -688,8 +765,15 @@ WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, in
         ws.mediumRouteQ[slot] = i;
     }
 #else
-    RouteSurfaceHit(sv, ws, cur, i, prim, HitInst(sv, ws, i), h.y, h.z, h.w, /* fromMedium */ true);
+    const F4 h = ws.hit[i];
+    RouteSurfaceHit(sv, ws, cur, i, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, /* fromMedium */ true);
 #endif
+}
+WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, int cur, int qi) {
+    MediumTrack s;
+    MediumTrackBegin(sv, ws, cur, qi, s);
+    while (MediumTrackStep(sv, ws, cur, s)) {}
+    MediumTrackEnd(sv, ws, cur, s);
 }
 // the second half of K5 on the HIP back end: EnqueueWorkAfterIntersection for the medium-sample items that reached their surface
 WF_HD void KMediumRoute(const SceneView &sv, const WorkState &ws, int cur, int qi) {

@@ -1707,6 +1707,9 @@ WF_NI bool QuadricAlphaIntersectP(const SceneView *svp, int prim, float ox, floa
     const int alphaTex = sv.meshes[s.mesh].alpha_tex;
     V3 o{ox, oy, oz};
     const V3 d{dx, dy, dz};
+    // (the reference recurses without a bound, GeometricPrimitive::Intersect; here the chain of rejected hits is capped at MAXN - 1 and the
+    //  next hit accepted.  Unreachable for a quadric — a ray meets one at most twice, and every respawned ray starts beyond the rejected
+    //  hit — and for a curve only by a ray that crosses the ribbon's alpha-rejected parts fifteen times: ADVICE r5, documented, not a parity case)
     constexpr int MAXN = 16;
     float ts[MAXN];
     int n = 0;

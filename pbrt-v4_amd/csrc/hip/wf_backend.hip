@@ -89,7 +89,8 @@ struct wf_ctx {
     // 31.4 ms (begin 3.3 + trace 3.7 + segment 24.1 + rest 0.3) — the time is the ratio tracking through the grid, not the walk, and the
     // per-lane loop keeps its state in registers; with object instances the per-lane alternative is the reference-order walk (1 wave / SIMD)
     int trWavefront = -1;
-    bool cursorDirty[2] = {false, false};   // the closest-hit / any-hit work cursor has been used since a k_reset last zeroed it
+    bool cursorDirty[3] = {false, false, false};   // the closest-hit / any-hit / medium-sample work cursor has been used since a k_reset last zeroed it
+    int mediumGrid = 512;        // resident workgroups of the persistent k_medium_sample
     int matStreams = 0;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
     hipStream_t matStream[WF_MAT_NTYPES] = {};
     hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_shadow(const SceneView sv, 
 
 // ---- production traversal: persistent waves over QNode/LeafTri with the tree top in LDS (wf_traverse.h) ----
 __shared__ int g_tstack[TSTACK * TBLOCK];
-__shared__ U4 g_top[QNODE_U4 * TOP_NODES];
+__shared__ U4 g_top[QNODE_U4 * (TOP_NODES > 0 ? TOP_NODES : 1)];   // (WF_TOP_NODES=0: no LDS copy of the tree top — every node fetch is a plain global load)
 // the render-space ray of every lane (o.xyz, d.xyz), for the instance transitions and the alpha test of the two-level / general
 // variants: re-reading it from the queue (round 2) put an L2 round trip in front of every transition — eight per ray on the spec scene
 __shared__ float g_ray[6 * TBLOCK];
@@ -382,6 +383,7 @@ struct LdsStackT {
 
 __device__ inline void LoadTreeTop(const FastBVH &bvh) {
     const U4 *src = reinterpret_cast<const U4 *>(bvh.nodes);
+    if constexpr (TOP_NODES == 0) return;
     const int n = QNODE_U4 * (bvh.nNodes < TOP_NODES ? bvh.nNodes : TOP_NODES);
     for (int i = threadIdx.x; i < n; i += TBLOCK) g_top[i] = src[i];
     __syncthreads();
@@ -390,6 +392,11 @@ __device__ inline void LoadTreeTop(const FastBVH &bvh) {
 // into separate loops so that each is a pure ds_read / global_load costs more in extra wave serialisation than the
 // merged flat load does: 0.57 ms vs 0.45 ms per launch.)
 __device__ inline void FetchNode(const FastBVH &bvh, int node, U4 *n) {
+    if constexpr (TOP_NODES == 0) {
+        const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + node);
+        for (int k = 0; k < QNODE_U4; ++k) n[k] = p[k];
+        return;
+    }
     const U4 *p = node < TOP_NODES ? g_top + QNODE_U4 * node : reinterpret_cast<const U4 *>(bvh.nodes + node);
     for (int k = 0; k < QNODE_U4; ++k) n[k] = p[k];
 }
@@ -519,7 +526,7 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
         // leaf can be processed: PARKED like a transition, so that this code too runs with several lanes at once (inside the leaf
         // loop, lane by lane, the lazy transition LOST: closest 49.4 vs 45.0 ms, any-hit 26.1 vs 23.0)
         const bool owes = WF_LAZY_INST && w.node != NODE_NONE && !tr && WF_LAZY_GET(w) != 0;
-        if (w.node != NODE_NONE && !tr && !owes) {
+        if (w.node < 0 && w.node != NODE_NONE && !tr && !owes) {   // (w.node >= 0: a lane the descent left at an interior node, WF_SCHED_Q)
             if constexpr (GEN > 0) LeafStep<ANY, true, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF, ANIM>{sv, bvh, w, fetch, idx});
             else LeafStep<ANY, false, true>(bvh, w, st, InstOnlyPrims<DF>{bvh});
         }
@@ -540,7 +547,7 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
             else EnterInstance<ANIM>(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST, ANIM ? g_time[threadIdx.x] : 0.f);
 #endif
         }
-    } else if (w.node != NODE_NONE) {
+    } else if (w.node < 0 && w.node != NODE_NONE) {
         if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF>{sv, bvh, w, fetch, idx});
         else if constexpr (DF) LeafStep<ANY, false, false>(bvh, w, st, DeferOnlyPrims{});
         else LeafStep<ANY>(bvh, w, st);
@@ -640,6 +647,26 @@ __device__ inline __attribute__((always_inline)) RefHit RetraceRefOrder(const Sc
 // which kernel variants resolve their near-ties themselves
 constexpr bool RetraceInline(int gen) { return gen <= 1; }
 
+// Does the wave take another interior step?  WF_SCHED_Q = 0: while ANY lane sits at an interior node (the "while-while" loop of rounds
+// 1-5: the descent ends when its LAST lane has reached a leaf, the other lanes wait masked off).  WF_SCHED_Q = q > 0 (round 6): only while
+// the lanes at interior nodes are at least q/4 of the lanes that wait at a leaf — otherwise the leaves are processed
+// first and the few lanes still descending go on in the next round, together with the lanes whose leaves sent them back into the tree.
+// Which lanes step when changes no result: every lane's own sequence of visits is the same.
+#ifndef WF_SCHED_Q
+#define WF_SCHED_Q 4   // spec scene, 16 spp, same box (profiles/r06_descent_scheduling_ab_sm16.txt): closest / any-hit 35.9 / 16.4 ms at 0, 31.5 / 13.4 at 2, 31.6 / 13.4 at 4, 31.9 / 13.8 at 8
+#endif
+template <bool INST>
+__device__ inline bool WalkDescend(const RayWalk &w) {
+#if WF_SCHED_Q == 0
+    return __any(w.node >= 0);
+#else
+    const int nI = __popcll(__ballot(w.node >= 0));
+    if (nI == 0) return false;
+    // (lanes at an instance transition do not count: LeafPhase may leave them parked, and a round must always make progress)
+    const int nL = __popcll(__ballot(w.node < 0 && w.node != NODE_NONE && !(INST && AtTransition(w.node))));
+    return 4 * nI >= WF_SCHED_Q * nL;
+#endif
+}
 template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
     LoadTreeTop(bvh);
@@ -691,7 +718,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
         // accesses (7.2e8 vs 1.45e8 per 8.5 M-ray launch): lanes at unrelated depths of the tree no longer share
         // cache lines, and the walk becomes L1-bound: 33 ms vs 27 ms per 16 spp.  DESIGN.md §4.)
         while (__any(w.node != NODE_NONE)) {
-            while (__any(w.node >= 0)) {
+            while (WalkDescend<INST>(w)) {
                 if (w.node >= 0) {
                     U4 nd[QNODE_U4];
                     FetchNode(bvh, w.node, nd);
@@ -809,7 +836,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
             }
             if (exhausted && !__any(w.node != NODE_NONE)) break;
         } else if (nAct == 0) break;
-        while (__any(w.node >= 0)) {
+        while (WalkDescend<INST>(w)) {
             if (w.node >= 0) {
                 U4 nd[QNODE_U4];
                 FetchNode(bvh, w.node, nd);
@@ -1236,9 +1263,73 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mix(const SceneView sv, WorkS
 #ifndef WF_MEDIUM_WAVES
 #define WF_MEDIUM_WAVES 2
 #endif
-__global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const SceneView sv, WorkState ws, int cur) {
+// (round 6) WAVE-LEVEL REFILL of the delta-tracking loop.  Until round 5 a wave kept its 64 items until the longest
+// of their walks ended: on the cloud scene 24 % of the VALU lanes were active over a wave's lifetime (walks of one to a hundred and more
+// steps: majorant cells crossed, null collisions taken), at two waves per SIMD that wait for their density gathers 79 % of the time.
+// Now the kernel is persistent (one resident grid, work dealt in runs of 64 items from a shared cursor): a wave whose active lanes drop
+// to WF_MEDIUM_REFILL_AT or fewer takes new items for its idle lanes (MediumTrackBegin) and goes on stepping; a lane whose walk ends
+// retires its item at once (MediumTrackEnd: per-lane stores, wave-aggregated queue pushes — nothing waits for the workgroup).  The same
+// operations per item in the same order as the one-loop form (the CPU checker's KSampleMediumInteraction): bit-identical images.
+#ifndef WF_MEDIUM_REFILL
+#define WF_MEDIUM_REFILL 0
+#endif
+#ifndef WF_MEDIUM_REFILL_AT
+#define WF_MEDIUM_REFILL_AT 40
+#endif
+#ifndef WF_MEDIUM_STEPS
+#define WF_MEDIUM_STEPS 4   // steps between two looks at the wave's occupancy
+#endif
+__global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const SceneView sv, WorkState ws, int cur, int *cursor) {
     const int n = ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE];
+#if WF_MEDIUM_REFILL
+    const int lane = threadIdx.x & 63;
+    const int waveId = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nWaves = ((int)gridDim.x * BLOCK) >> 6;
+    if (n < 2 * nWaves * 64) cursor = nullptr;   // (a short queue is dealt statically: every wave starts at once, no atomics)
+    MediumTrack s;
+    s.i = -1;
+    int next = 0, end = 0, staticJ = 0;   // the wave's private run [next, end) of queue indices (uniform)
+    bool exhausted = false;
+    while (true) {
+        const unsigned long long act = __ballot(s.i >= 0);
+        const int nAct = __popcll(act);
+        if (nAct <= WF_MEDIUM_REFILL_AT && !exhausted) {
+            const bool idle = s.i < 0;
+            const int need = 64 - nAct;
+            const int rank = __popcll(~act & ((1ull << lane) - 1ull));
+            int served = 0, qi = -1;
+            while (served < need) {
+                if (next >= end) {
+                    int b;
+                    if (cursor) {
+                        b = 0;
+                        if (lane == 0) b = atomicAdd(cursor, 64);
+                        b = __builtin_amdgcn_readfirstlane(b);
+                    } else {
+                        b = (staticJ * nWaves + waveId) * 64;
+                        ++staticJ;
+                    }
+                    next = b;
+                    end = b + 64 < n ? b + 64 : n;
+                    if (next >= n) { exhausted = true; break; }
+                }
+                const int take = need - served < end - next ? need - served : end - next;
+                if (idle && rank >= served && rank < served + take) qi = next + (rank - served);
+                next += take;
+                served += take;
+            }
+            if (qi >= 0) MediumTrackBegin(sv, ws, cur, qi, s);
+            if (!__any(s.i >= 0)) break;   // (nothing was dealt and nothing is left)
+        } else if (nAct == 0) break;
+        for (int k = 0; k < WF_MEDIUM_STEPS; ++k) {
+            if (s.i >= 0 && !MediumTrackStep(sv, ws, cur, s)) {
+                MediumTrackEnd(sv, ws, cur, s);
+                s.i = -1;
+            }
+        }
+    }
+#else
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction(sv, ws, cur, i);
+#endif
 }
 __global__ void __launch_bounds__(BLOCK) k_medium_route(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_MEDIUM_ROUTE) * CNT_STRIDE];
@@ -1848,6 +1939,10 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
         }
         std::vector<std::array<float, 6>> ib((size_t)d->n_instances);
         std::vector<char> ibOk((size_t)d->n_instances, 0);
+        // (the pad also carries 2^-19 of the SCENE's magnitude, like the re-braided entries' boxes below: the instance-space ray the
+        //  reference decides hits with carries the rounding of the render-space origin and of the distance travelled — ADVICE r5)
+        double sceneMagT = 0;
+        for (int a = 0; a < 3; ++a) sceneMagT = std::max(sceneMagT, std::max(std::fabs((double)L[0].bmin[a]), std::fabs((double)L[0].bmax[a])) + ((double)L[0].bmax[a] - L[0].bmin[a]));
         for (int i = 0; i < d->n_instances; ++i) {
             const wf_instance &in = d->instances[i];
             if (defGeneral[in.def] || in.anim_plus1 != 0) continue;   // (an AnimatedPrimitive keeps the reference's motion bounds)
@@ -1864,7 +1959,7 @@ static bool BuildFastBVH(const wf_scene_desc *d, std::vector<QNode> *nodes, std:
             }
             bool finite = true;
             for (int a = 0; a < 3; ++a) {
-                const double pad = 0x1p-18 * (mag + (hi[a] - lo[a])) + 1e-30;
+                const double pad = 0x1p-18 * (mag + (hi[a] - lo[a])) + 0x1p-19 * sceneMagT + 1e-30;
                 ib[i][a] = (float)(lo[a] - pad); ib[i][3 + a] = (float)(hi[a] + pad);
                 if (!((double)ib[i][a] <= lo[a] - 0.5 * pad)) ib[i][a] = NextFloatDown(ib[i][a]);
                 if (!((double)ib[i][3 + a] >= hi[a] + 0.5 * pad)) ib[i][3 + a] = NextFloatUp(ib[i][3 + a]);
@@ -2836,6 +2931,11 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
                 (e = residentGrid(g1 ? (const void *)k_shadow_fast<9, true> : (const void *)k_shadow_fast<8, true>, &ctx->persistentGridShadow))) return e;
         }
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
+        {
+            int perCU = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)k_medium_sample, BLOCK, 0));
+            ctx->mediumGrid = std::min(MAX_GRID, std::max(1, perCU) * prop.multiProcessorCount);
+        }
     }
     if ((e = devAlloc(ctx, &ctx->ws.film, (size_t)ctx->W * ctx->H * 4))) return e;
     ctx->ws.filmSpectral = nullptr;
@@ -3045,10 +3145,11 @@ int wf_reset_stage_queues(wf_ctx *ctx, int depth) {
     unsigned mask = (1u << (CNT_RAY0 + (cur ^ 1))) | (1u << CNT_ESCAPED) | (1u << CNT_HITLIGHT);
     for (int m = 0; m < WF_MAT_NTYPES; ++m) mask |= 1u << (CNT_MAT0 + m);
     mask |= (1u << CNT_MEDIUM_SAMPLE) | (1u << CNT_MEDIUM_SCATTER) | (1u << CNT_MIX) | (1u << CNT_RETRACE) | (1u << CNT_BSSRDF) | (1u << CNT_SSS);
-    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE) | (1u << CNT_CURSOR) | (1u << CNT_MEDIUM_ROUTE) | (1u << CNT_DEFER);
+    mask |= (1u << CNT_RETRACE_HEAD) | (1u << CNT_WAVES_DONE) | (1u << CNT_CURSOR) | (1u << CNT_MEDIUM_ROUTE) | (1u << CNT_DEFER) | (1u << CNT_CURSOR_MEDIUM);
     // stats->indirectRays[depth] += queue size (integrator.cpp:411-414)
     LAUNCH("Reset queues before tracing rays", k_reset, 1, ctx->ws, mask, 1 + statDepth(depth), CNT_RAY0 + cur);
     ctx->cursorDirty[0] = false;
+    ctx->cursorDirty[2] = false;
     return 0;
 }
 int wf_gen_camera_rays(wf_ctx *ctx, int y0, int sample_index) {
@@ -3174,7 +3275,13 @@ int wf_intersect_closest(wf_ctx *ctx, int depth) {
 int wf_medium_sample(wf_ctx *ctx, int depth) {
     if (int e = checkReady(ctx)) return e;
     if (!ctx->svHost.haveMedia) return 0;
-    LAUNCH("Sample medium interaction", k_medium_sample, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
+    {
+        // persistent launch with wave-level refill: one resident grid, the items dealt from a work cursor (zeroed by the stage's reset launch)
+        int *cursor = ctx->ws.counters + CNT_CURSOR_MEDIUM * CNT_STRIDE;
+        if (ctx->cursorDirty[2]) HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
+        ctx->cursorDirty[2] = true;
+        LAUNCH("Sample medium interaction", k_medium_sample, WF_MEDIUM_REFILL ? std::min(ctx->mediumGrid, gridFor(ctx->maxQueueSize)) : gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, cursor);
+    }
     LAUNCH("Sample medium interaction: route surface hits", k_medium_route, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     if (depth == ctx->maxDepth) return 0;
     if (ctx->rareLights) LAUNCH("Sample direct/indirect - Henyey-Greenstein", k_medium_scatter<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
