@@ -662,7 +662,7 @@ WF_HD CameraRayR GenerateCameraRay(const SceneView &sv, V2 pFilm, float timeSamp
         float rFilm = sqrt(Sqr(pF.x) + Sqr(pF.y));
         int rIndex = (int)(rFilm / (C.film_diagonal / 2) * C.n_exit_pupil_bounds);
         rIndex = rIndex < C.n_exit_pupil_bounds - 1 ? rIndex : C.n_exit_pupil_bounds - 1;
-        const float *pb = sv.tableData + C.exit_pupil_offset + 4 * rIndex;
+        const auto pb = sv.tableData + C.exit_pupil_offset + 4 * rIndex;
         CameraRayR none{V3{0, 0, 0}, V3{0, 0, 0}, 0, false, 0};
         if (pb[0] >= pb[2] || pb[1] >= pb[3]) return none;   // Bounds2::IsDegenerate
         V2 pLensS{(1 - pLens.x) * pb[0] + pLens.x * pb[2], (1 - pLens.y) * pb[1] + pLens.y * pb[3]};

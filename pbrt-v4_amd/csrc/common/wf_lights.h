@@ -64,7 +64,7 @@ WF_HD S4 ImageLightLe(const SceneView &sv, const wf_light &l, V2 uv, const Wavel
     // (a NaN or infinite direction — the tail of a path that already went wrong — gives coordinates the reflection above does not bring
     //  back: the reference reads outside its image there; no kernel may)
     px = Clamp(px, 0, res - 1); py = Clamp(py, 0, res - 1);
-    const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
+    const auto texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
     return l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda);
 }
 // DiffuseAreaLight::AlphaMasked (lights.h:486-496): the alpha texture sees TextureEvalContext(Interaction(p, uv));
@@ -198,7 +198,7 @@ WF_HD S4 PortalImageLookup(const SceneView &sv, float scale, const wf_image_ligh
     int px = (int)(uv.x * res), py = (int)(uv.y * res);
     px = px < 0 ? 0 : (px > res - 1 ? res - 1 : px);
     py = py < 0 ? 0 : (py > res - 1 ? res - 1 : py);
-    const float *texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
+    const auto texel = sv.tableData + im.pixel_offset + 3 * ((size_t)py * res + px);
     return scale * RGBIlluminantSample(sv, fmax(0.f, texel[0]), fmax(0.f, texel[1]), fmax(0.f, texel[2]), lambda);
 }
 // out of line: the sampling loops are long and only scenes with a portal light reach them
@@ -214,7 +214,7 @@ WF_NI void PortalSampleLiP(const SceneView *svp, int image, float scale, float s
     B2 b;
     if (!PortalImageBounds(im, p, &b)) return;
     const float *func = sv.tableData + im.func_offset;
-    const double *sum = (const double *)(sv.tableData + im.sat_offset);
+    const double *sum = (const double *)((const float *)sv.tableData + im.sat_offset);
     float mapPDF;
     V2 uv;
     if (!WindowedSample(func, sum, im.res, V2{u0, u1}, b, &uv, &mapPDF)) return;
@@ -234,7 +234,7 @@ WF_NI float PortalPDFLiP(const SceneView *svp, int image, float px, float py, fl
     if (!PortalImageFromRender(im, V3{wx, wy, wz}, &uv, &duv_dw) || duv_dw == 0) return 0;
     B2 b;
     if (!PortalImageBounds(im, V3{px, py, pz}, &b)) return 0;
-    const double *sum = (const double *)(sv.tableData + im.sat_offset);
+    const double *sum = (const double *)((const float *)sv.tableData + im.sat_offset);
     float funcInt = SATIntegral(sum, im.res, b);
     if (funcInt == 0) return 0;
     return WindowedEval(sv.tableData + im.func_offset, im.res, uv) / funcInt / duv_dw;
@@ -325,7 +325,7 @@ WF_HD LightLiSample LightSampleLi(const SceneView &sv, const wf_light &l, const 
         int x = (int)(uv.x * im.res[0]), y = (int)(uv.y * im.res[1]);
         x = x < 0 ? 0 : (x > im.res[0] - 1 ? im.res[0] - 1 : x);
         y = y < 0 ? 0 : (y > im.res[1] - 1 ? im.res[1] - 1 : y);
-        const float *texel = sv.tableData + im.level_offset[0] + 3 * ((size_t)y * im.res[0] + x);
+        const auto texel = sv.tableData + im.level_offset[0] + 3 * ((size_t)y * im.res[0] + x);
         S4 Li = l.scale * RGBIlluminantSample(sv, texel[0], texel[1], texel[2], lambda) / DistanceSquared(p, ctx.p());
         if (!Li) return ls;
         ls.L = Li; ls.wi = wi; ls.pdf = 1; ls.pLightPi = MakeP3i(p); ls.pLightN = N3{0, 0, 0}; ls.valid = true;
@@ -518,7 +518,7 @@ WF_HD int LightSamplerSample(const SceneView &sv, const LightCtx &ctx, float u, 
         int offset = (int)(u * sv.nLights);
         if (offset > sv.nLights - 1) offset = sv.nLights - 1;
         float up = fmin(u * sv.nLights - offset, OneMinusEpsilon);
-        const float *bin = sv.powerAlias + 3 * offset;
+        const auto bin = sv.powerAlias + 3 * offset;
         if (up < bin[0]) {
             *pmfOut = bin[1];
             return offset;

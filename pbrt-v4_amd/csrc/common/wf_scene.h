@@ -5,76 +5,105 @@
 // reference's TaggedPointer dispatch (util/taggedptr.h:736-870) becomes a switch on an integer tag.
 #pragma once
 
+#include <type_traits>
 #include "wf_math.h"
 #include "wf_noise.h"
 #include "../../../include/wf_abi.h"
 
 namespace wf {
 
+// A pointer to one of the scene's tables (round 6).  The tables live in global memory, but a pointer that a kernel LOADS — the kernels read
+// the view through its device-resident copy, the out-of-line callees take `const SceneView *` — is a generic pointer to the compiler, and
+// every access through it a FLAT instruction: address on both the LDS and the memory path, both wait counters
+// (k_mat_shade<diffuse>: 253 flat loads against 20 global ones).  Indexing a GPtr of scalars (vertex data, index triples, texels, tables of
+// floats) reads through an address-space-1 pointer instead: a global load.  (An assumption `!is_shared && !is_private` on the pointer is not
+// picked up by this toolchain's address-space inference, and a cast to address space 1 and back is folded away: measured on a stand-alone kernel.)
+// Tables of records keep their generic references (the records are passed on by reference).  On the host: a plain pointer.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WF_NO_GPTR)
+#define WF_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define WF_GLOBAL_AS
+#endif
+template <typename T>
+struct GPtr {
+    T *p;
+    GPtr() = default;
+    WF_HD GPtr(T *q) : p(q) {}
+    WF_HD operator T *() const { return p; }
+    WF_HD T *operator->() const { return p; }
+    template <typename I>
+    WF_HD GPtr operator+(I off) const { return GPtr(p + off); }
+    // scalars by value through the global address space; records by (generic) reference
+    template <typename I, typename U = T>
+    WF_HD typename std::enable_if<std::is_arithmetic<U>::value, typename std::remove_const<U>::type>::type operator[](I i) const { return ((WF_GLOBAL_AS T *)p)[i]; }
+    template <typename I, typename U = T>
+    WF_HD typename std::enable_if<!std::is_arithmetic<U>::value, U &>::type operator[](I i) const { return p[i]; }
+};
+
 struct SceneView {
     // geometry (util/mesh.h TriangleMesh buffers, flattened over all meshes)
-    const float *P, *N, *UV;
-    const float *S;   // shading tangents of the meshes with WF_MESH_HAS_S (LoadS)
-    const int32_t *triIndices, *triMesh;
-    const wf_mesh *meshes;
-    const wf_bvh_node *bvhNodes;
-    const int32_t *bvhPrims;
+    GPtr<const float> P, N, UV;
+    GPtr<const float> S;   // shading tangents of the meshes with WF_MESH_HAS_S (LoadS)
+    GPtr<const int32_t> triIndices, triMesh;
+    GPtr<const wf_mesh> meshes;
+    GPtr<const wf_bvh_node> bvhNodes;
+    GPtr<const int32_t> bvhPrims;
     int nTriangles, nBvhNodes;
     // shading
-    const wf_spectrum *spectra;
-    const float *spectrumData;
-    const wf_texture *textures;
-    const wf_material *materials;
+    GPtr<const wf_spectrum> spectra;
+    GPtr<const float> spectrumData;
+    GPtr<const wf_texture> textures;
+    GPtr<const wf_material> materials;
     // lights
-    const wf_light *lights;
-    const int32_t *infiniteLights;
-    const wf_light_bvh_node *lightBvh;
-    const struct LightNodeX *lightBvhX;   // device only: every node's constants expanded once at upload (wf_lights.h ExpandLightNode)
-    const wf_transform *lightXforms;
+    GPtr<const wf_light> lights;
+    GPtr<const int32_t> infiniteLights;
+    GPtr<const wf_light_bvh_node> lightBvh;
+    GPtr<const struct LightNodeX> lightBvhX;   // device only: every node's constants expanded once at upload (wf_lights.h ExpandLightNode)
+    GPtr<const wf_transform> lightXforms;
     int nLights, nInfiniteLights, nLightBvhNodes, lightSampler;
-    const float *powerAlias;  // PowerLightSampler's AliasTable bins: nLights x {q, p, alias (int bits)}
+    GPtr<const float> powerAlias;  // PowerLightSampler's AliasTable bins: nLights x {q, p, alias (int bits)}
     float allLightBounds[6];
     // image infinite lights
-    const wf_image_light *imageLights;
-    const wf_tex_image *texImages;
-    const float *tableData;
-    const float *rgb2specCoeffs;
-    const float *rgb2specZNodes;  // [64]
-    const int32_t *noisePerm;     // [512] Perlin permutation (procedural textures, cloud medium), or null
+    GPtr<const wf_image_light> imageLights;
+    GPtr<const wf_tex_image> texImages;
+    GPtr<const float> tableData;
+    GPtr<const float> rgb2specCoeffs;
+    GPtr<const float> rgb2specZNodes;  // [64]
+    GPtr<const int32_t> noisePerm;     // [512] Perlin permutation (procedural textures, cloud medium), or null
     int csIlluminantOffset;
     // participating media
-    const wf_medium *media;
-    const float *mediumData;
+    GPtr<const wf_medium> media;
+    GPtr<const float> mediumData;
     // (round 4, device only; null on the host) the density grids of the GridMedium media once more, CORNER-PACKED: for every lattice
     // position the eight values a trilinear lookup there reads, 32 contiguous bytes — two dwordx4 loads instead of eight gathers
     // into four rows of the grid, at 8x the memory (4.3 GB for the 512^3 cloud of BASELINE configs[3]; what 288 GB are for).
     // gridCornerBase[medium id] = first float of the medium's table in gridCorners, or -1 (wf_media.h: GridLookupPacked)
-    const float *gridCorners;
-    const long long *gridCornerBase;
+    GPtr<const float> gridCorners;
+    GPtr<const long long> gridCornerBase;
     // camera / film / filter / sampler
     wf_camera camera;
     wf_film film;
     wf_filter filter;
-    const float *filterData;
+    GPtr<const float> filterData;
     wf_sampler sampler;
-    const uint32_t *sobol;  // WF_SOBOL_WORDS: SobolMatrices32 columns of dimensions 0 and 1 (2 x 52), then their byte tables (FillSobol2D)
+    GPtr<const uint32_t> sobol;  // WF_SOBOL_WORDS: SobolMatrices32 columns of dimensions 0 and 1 (2 x 52), then their byte tables (FillSobol2D)
     // integrator
     int maxDepth, regularize, haveMedia;
     int matTypeMask;  // bit t set: some material has wf_material_type t (which eval queues can be non-empty)
     int texNeedsFootprint;  // some texture's value depends on the TextureEvalContext (checkerboard, image) or some material
                             // is bump- or normal-mapped: selects the material-kernel variant that computes the differentials
-    const uint32_t *sobolMatrices;   // SobolSampler: SobolMatrices32 [1024][52]
-    const uint64_t *vdcSobol, *vdcSobolInv;
-    const int32_t *haltonPrimes, *haltonPermOffsets;
-    const uint16_t *haltonPerms;
-    const wf_quadric *quadrics;
+    GPtr<const uint32_t> sobolMatrices;   // SobolSampler: SobolMatrices32 [1024][52]
+    GPtr<const uint64_t> vdcSobol, vdcSobolInv;
+    GPtr<const int32_t> haltonPrimes, haltonPermOffsets;
+    GPtr<const uint16_t> haltonPerms;
+    GPtr<const wf_quadric> quadrics;
     int nQuadrics;
     // object instances (include/wf_abi.h wf_instance): primitive id nTriangles + nQuadrics + instance index
-    const wf_instance *instances;
-    const wf_instance_def *instanceDefs;
+    GPtr<const wf_instance> instances;
+    GPtr<const wf_instance_def> instanceDefs;
     int nInstances;
     // AnimatedPrimitive (round 5): the AnimatedTransforms of animated shapes / instances (wf_instance.anim_plus1); haveAnimated: the scene has one
-    const wf_animated_transform *animated;
+    GPtr<const wf_animated_transform> animated;
     int haveAnimated;
     int haveQuadricAlpha;   // some sphere / disk / cylinder / patch has an alpha texture (QuadricAlphaIntersectP)
     int haveCurves;         // some primitive is a Curve segment: its interaction is rebuilt from the ray (HitInteraction)
@@ -84,11 +113,11 @@ struct SceneView {
     wf_options options;
     // this struct in memory the kernels can read (device memory on the GPU, the object itself on the host): what the few
     // out-of-line device functions take instead of the by-value kernel argument (whose address must never be taken)
-    const SceneView *self;
+    GPtr<const SceneView> self;
     // LOG_FATAL of the reference inside a kernel body (so far: Curve::Sample / Curve::PDF "not implemented", shapes.cpp:736-760, reached
     // when a sample is drawn from an emissive curve): the body stores a WF_FATAL_* code here and carries on with a null result; wf_sync
     // (the CPU checker: the end of its render) turns the code into the reference's fatal error.  Null: nothing to report to.
-    int32_t *fatal;
+    GPtr<int32_t> fatal;
 };
 enum { WF_FATAL_CURVE_SAMPLE = 1, WF_FATAL_CURVE_PDF = 2,   // (bit flags: several may be raised in one render)
        WF_FATAL_CHECK_HAIR = 4,      // HairBxDF ctor: CHECK(h >= -1 && h <= 1) / beta_m / beta_n (bxdfs.cpp:278-280)
@@ -391,11 +420,12 @@ WF_HD float ImageTexel(const float *table, const wf_tex_image &im, int level, in
         }
     }
     const size_t i = ((size_t)y * rx + x) * im.n_channels + c;
-    if (im.format == WF_TEXEL_FLOAT) return table[im.level_offset[level] + i];
+    const WF_GLOBAL_AS float *tg = (const WF_GLOBAL_AS float *)table;   // (the texel table is global memory: a global load, not a flat one — GPtr above)
+    if (im.format == WF_TEXEL_FLOAT) return tg[im.level_offset[level] + i];
     // texels kept in the source image's format, as the reference's MIP levels are (Image::GetChannel, util/image.h:204-221): a quarter / half of
     // the bytes per gather, decoded through the encoding's 256-entry table / by widening the half
-    if (im.format == WF_TEXEL_U8) return table[im.lut_offset + reinterpret_cast<const uint8_t *>(table + im.level_offset[level])[i]];
-    return HalfBitsToFloat(reinterpret_cast<const uint16_t *>(table + im.level_offset[level])[i]);
+    if (im.format == WF_TEXEL_U8) return tg[im.lut_offset + reinterpret_cast<const WF_GLOBAL_AS uint8_t *>(tg + im.level_offset[level])[i]];
+    return HalfBitsToFloat(reinterpret_cast<const WF_GLOBAL_AS uint16_t *>(tg + im.level_offset[level])[i]);
 }
 WF_HD float ImageBilerpChannel(const float *table, const wf_tex_image &im, int level, V2 p, int c) {
     const int rx = im.res[0] >> level > 0 ? im.res[0] >> level : 1, ry = im.res[1] >> level > 0 ? im.res[1] >> level : 1;
@@ -938,7 +968,7 @@ WF_HD S4 EvalSpectrumTexture(const SceneView &sv, int id, const Wavelengths &lam
 // geometry accessors
 WF_HD V3 LoadP(const SceneView &sv, int v) { return V3{sv.P[3 * v], sv.P[3 * v + 1], sv.P[3 * v + 2]}; }
 WF_HD N3 LoadN(const SceneView &sv, int v) { return N3{sv.N[3 * v], sv.N[3 * v + 1], sv.N[3 * v + 2]}; }
-WF_HD V3 LoadS(const SceneView &sv, const wf_mesh &mesh, int v) { const float *p = sv.S + 3 * (size_t)(mesh.first_s + (v - mesh.first_vertex)); return V3{p[0], p[1], p[2]}; }
+WF_HD V3 LoadS(const SceneView &sv, const wf_mesh &mesh, int v) { const auto p = sv.S + 3 * (size_t)(mesh.first_s + (v - mesh.first_vertex)); return V3{p[0], p[1], p[2]}; }
 WF_HD V2 LoadUV(const SceneView &sv, int v) { return V2{sv.UV[2 * v], sv.UV[2 * v + 1]}; }
 
 }  // namespace wf

@@ -118,7 +118,7 @@ WF_HD bool BoxIntersectP(const float bmin[3], const float bmax[3], V3 o, float r
 }
 
 WF_HD void TriVerts(const SceneView &sv, int tri, V3 *p0, V3 *p1, V3 *p2) {
-    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const auto v = sv.triIndices + 3 * (size_t)tri;
     *p0 = LoadP(sv, v[0]); *p1 = LoadP(sv, v[1]); *p2 = LoadP(sv, v[2]);
 }
 
@@ -754,7 +754,7 @@ WF_HD N3 TriangleAlphaCtxNormal(const SceneView &sv, const wf_mesh &mesh, const 
 WF_HD bool AlphaTestPasses(const SceneView &sv, int tri, float b0, float b1, float b2, V3 o, V3 d) {
     const wf_mesh &mesh = sv.meshes[sv.triMesh[tri]];
     if (mesh.alpha_tex < 0) return true;
-    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const auto v = sv.triIndices + 3 * (size_t)tri;
     V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
     if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
     TexCtx tc;
@@ -1087,7 +1087,7 @@ WF_HD N3 DifferenceOfProductsN(float a, N3 b, float c, N3 d) {
 
 // Triangle::InteractionFromIntersection, shapes.h:884-1010.  `full` = also the shading derivatives.
 WF_HD void TriangleInteraction(const SceneView &sv, int tri, float b0, float b1, float b2, SurfIntr *si) {
-    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const auto v = sv.triIndices + 3 * (size_t)tri;
     const int meshId = sv.triMesh[tri];
     const wf_mesh mesh = sv.meshes[meshId];
     si->mesh = meshId;
@@ -1218,7 +1218,7 @@ WF_HD V2 TriSampleUV(const SceneView &sv, const wf_mesh &mesh, const int32_t *v,
 WF_HD ShapeSampleR TriangleSample(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxNs, V2 u) {
     ShapeSampleR r{};
     r.valid = false;
-    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const auto v = sv.triIndices + 3 * (size_t)tri;
     const wf_mesh mesh = sv.meshes[sv.triMesh[tri]];
     V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
     V3 rp = ctxPi.mid();
@@ -1270,7 +1270,7 @@ WF_HD ShapeSampleR TriangleSample(const SceneView &sv, int tri, const P3i &ctxPi
 
 // Triangle::PDF(const ShapeSampleContext &, Vector3f wi), shapes.h:1133-1171
 WF_HD float TrianglePDF(const SceneView &sv, int tri, const P3i &ctxPi, N3 ctxN, N3 ctxNs, V3 wi) {
-    const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+    const auto v = sv.triIndices + 3 * (size_t)tri;
     V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
     V3 rp = ctxPi.mid();
     float solidAngle = TriangleSolidAngle(p0, p1, p2, rp);

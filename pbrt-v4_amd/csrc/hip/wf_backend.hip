@@ -391,10 +391,18 @@ __device__ inline void LoadTreeTop(const FastBVH &bvh) {
 // a node's 16-byte words: tree top from LDS, the rest from global memory.  (Measured: splitting the two fetch paths
 // into separate loops so that each is a pure ds_read / global_load costs more in extra wave serialisation than the
 // merged flat load does: 0.57 ms vs 0.45 ms per launch.)
+#ifndef WF_FETCH_ALL
+#define WF_FETCH_ALL 0
+#endif
 __device__ inline void FetchNode(const FastBVH &bvh, int node, U4 *n) {
     if constexpr (TOP_NODES == 0) {
         const U4 *p = reinterpret_cast<const U4 *>(bvh.nodes + node);
         for (int k = 0; k < QNODE_U4; ++k) n[k] = p[k];
+#if WF_FETCH_ALL
+        // the child references (the node's last 16 bytes) are only read when a child is hit, and the compiler sinks their load behind the
+        // slab tests: a second dependent round trip per step.  Pinned here, the four loads of a node issue together.
+        asm volatile("" : "+v"(n[QNODE_U4 - 1].x), "+v"(n[QNODE_U4 - 1].y), "+v"(n[QNODE_U4 - 1].z), "+v"(n[QNODE_U4 - 1].w));
+#endif
         return;
     }
     const U4 *p = node < TOP_NODES ? g_top + QNODE_U4 * node : reinterpret_cast<const U4 *>(bvh.nodes + node);
@@ -428,7 +436,7 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
     float a;
     if (t.type == WF_TEX_FLOAT_CONSTANT) a = t.f0;
     else {
-        const int32_t *v = sv.triIndices + 3 * (size_t)tri;
+        const auto v = sv.triIndices + 3 * (size_t)tri;
         V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
         if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
         const V2 uv{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
@@ -511,12 +519,18 @@ struct DeferOnlyPrims {   // the one-level triangle walk of a scene that also ho
 // until no lane has anything else to do: a parked lane loses nothing (its wave-mates' steps would have been issued with its lane
 // masked anyway), and the expensive code then runs with several times the lanes.  (0: run every transition in the iteration it is
 // popped in, as in round 2.)
+#ifndef WF_WALK_STATS
+#define WF_WALK_STATS 0   // (diagnostic builds: WalkStats below)
+#endif
+#ifndef WF_TRANS_Q
+#define WF_TRANS_Q 2   // spec scene, 16 spp, same box (profiles/r06_transition_parking_ab_sm16.txt): closest / any-hit 28.2 / 12.4 ms at 0, 27.6 / 12.1 at 2, 28.0 / 12.2 at 4
+#endif
 #ifndef WF_TRANS_BATCH
 #define WF_TRANS_BATCH 6   // spec scene, 16 spp, same box (gpurun_out/r3f_ab_sm16.txt): closest / any-hit 60.1 / 22.0 ms at 0, 56.5 / 20.2 at 6, 58.4 / 20.5 at 12, 62.4 / 21.1 at 24
 #endif
 __device__ inline bool AtTransition(int node) { return node < 0 && node != NODE_NONE && (node == NODE_EXIT || (int)((~(unsigned)node) >> 4) >= INST_FIRST); }
 template <bool ANY, int GENX, bool INST, typename Fetch>
-__device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWalk &w, LdsStackT &st, const Fetch &fetch, int idx) {
+__device__ inline int LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWalk &w, LdsStackT &st, const Fetch &fetch, int idx) {
     constexpr int GEN = GenBase(GENX);
     constexpr bool DF = GenDefer(GENX), ANIM = GenAnim(GENX);
     if constexpr (INST) {
@@ -533,8 +547,17 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
         if constexpr (WF_TRANS_BATCH > 0) {
             tr = AtTransition(w.node);
             const int nT = __popcll(__ballot(tr || owes));
-            if (nT == 0) return;
-            if (nT < WF_TRANS_BATCH && __any(w.node != NODE_NONE && !tr && !owes)) return;   // parked: the others still have nodes and leaves to visit
+            if (nT == 0) return 0;
+#if WF_TRANS_Q > 0
+            {
+                // (round 6) ... and, like the descent (WalkDescend), until the lanes that wait for a transition are at least WF_TRANS_Q / 4 of
+                // the lanes that have nodes and leaves to visit: the transition is the walk's most expensive code (~400 instructions)
+                const int nO = __popcll(__ballot(w.node != NODE_NONE && !tr && !owes));
+                if (nO > 0 && (nT < WF_TRANS_BATCH || 4 * nT < WF_TRANS_Q * nO)) return 0;
+            }
+#else
+            if (nT < WF_TRANS_BATCH && __any(w.node != NODE_NONE && !tr && !owes)) return 0;   // parked: the others still have nodes and leaves to visit
+#endif
         } else tr = AtTransition(w.node);
         if (owes) WalkMakeExact(bvh, w, WorldRayO(), WorldRayD());   // (its leaf is processed in the next iteration)
         else if (tr) {
@@ -547,11 +570,13 @@ __device__ inline void LeafPhase(const SceneView &sv, const FastBVH &bvh, RayWal
             else EnterInstance<ANIM>(bvh, w, st, o, d, (int)((~(unsigned)w.node) >> 4) - INST_FIRST, ANIM ? g_time[threadIdx.x] : 0.f);
 #endif
         }
+        return WF_WALK_STATS ? __popcll(__ballot(tr)) : 0;
     } else if (w.node < 0 && w.node != NODE_NONE) {
         if constexpr (GEN > 0) LeafStep<ANY, true>(bvh, w, st, GeneralPrims<Fetch, GEN, DF>{sv, bvh, w, fetch, idx});
         else if constexpr (DF) LeafStep<ANY, false, false>(bvh, w, st, DeferOnlyPrims{});
         else LeafStep<ANY>(bvh, w, st);
     }
+    return 0;
 }
 
 // ---- near-tie resolution inside the production walk (round 3) -------------------------------------------------------------------
@@ -647,13 +672,32 @@ __device__ inline __attribute__((always_inline)) RefHit RetraceRefOrder(const Sc
 // which kernel variants resolve their near-ties themselves
 constexpr bool RetraceInline(int gen) { return gen <= 1; }
 
+// -DWF_WALK_STATS (diagnostic builds only): per-phase counts of the closest-hit (slot 0) and any-hit (slot 1) production walks — how often a
+// wave ran the interior step / the leaf step / an instance transition / a refill, and how many lanes were active each time — summed
+// over the launch into 64-bit words behind the debug words (wf_sync prints them under WF_DEBUG_DRAIN).  What the round-6 scheduling
+// decisions were checked against: profiles/r06_walk_phase_stats.txt.
+struct WalkStats {
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // iterations / lanes of: interior, leaf, transition, refill
+    __device__ void add(int phase, bool active) {
+#if WF_WALK_STATS
+        const int n = __popcll(__ballot(active));
+        if (n) { c[2 * phase] += 1; c[2 * phase + 1] += (unsigned long long)n; }
+#endif
+    }
+    __device__ void flush(int *dbg, int slot) {
+#if WF_WALK_STATS
+        if (dbg && (threadIdx.x & 63) == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(dbg + 8) + slot * 8 + k, c[k]);
+#endif
+    }
+};
 // Does the wave take another interior step?  WF_SCHED_Q = 0: while ANY lane sits at an interior node (the "while-while" loop of rounds
 // 1-5: the descent ends when its LAST lane has reached a leaf, the other lanes wait masked off).  WF_SCHED_Q = q > 0 (round 6): only while
 // the lanes at interior nodes are at least q/4 of the lanes that wait at a leaf — otherwise the leaves are processed
 // first and the few lanes still descending go on in the next round, together with the lanes whose leaves sent them back into the tree.
 // Which lanes step when changes no result: every lane's own sequence of visits is the same.
 #ifndef WF_SCHED_Q
-#define WF_SCHED_Q 4   // spec scene, 16 spp, same box (profiles/r06_descent_scheduling_ab_sm16.txt): closest / any-hit 35.9 / 16.4 ms at 0, 31.5 / 13.4 at 2, 31.6 / 13.4 at 4, 31.9 / 13.8 at 8
+#define WF_SCHED_Q 3   // spec scene, 16 spp, same box (profiles/r06_descent_scheduling_ab_sm16.txt): closest / any-hit 35.9 / 16.4 ms at 0, 31.5 / 13.4 at 2, 31.6 / 13.4 at 4, 31.9 / 13.8 at 8; second box (r06_tree_top_global_loads_and_knobs_ab_sm16.txt): 31.6 / 13.9 at 1, 31.0 / 13.4 at 3, 31.3 / 13.5 at 4
 #endif
 template <bool INST>
 __device__ inline bool WalkDescend(const RayWalk &w) {
@@ -777,6 +821,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
     w.tMax = 0;
     w.b0 = w.b1 = w.b2 = 0;
     w.inst = w.curInst = -1;
+    WalkStats ws_;
     auto retire = [&]() {
         // DEFER: `finish` queues a near-tie ray and the kernel resolves it after its walks (DrainRetrace) — the reference-order walk inlined HERE
         // costs the closest-hit kernel 37 % (76.9 vs 56.0 ms per 16 spp on the spec scene), without it the refill gains 28 % (40.3 ms)
@@ -823,6 +868,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
                 next += take;
                 served += take;
             }
+            ws_.add(3, idle && idx >= 0);
             if (idle && idx >= 0) {
                 V3 o, d;
                 float tMax;
@@ -837,14 +883,18 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
             if (exhausted && !__any(w.node != NODE_NONE)) break;
         } else if (nAct == 0) break;
         while (WalkDescend<INST>(w)) {
+            ws_.add(0, w.node >= 0);
             if (w.node >= 0) {
                 U4 nd[QNODE_U4];
                 FetchNode(bvh, w.node, nd);
                 InteriorStep<!ANY>(bvh, w, st, nd);
             }
         }
-        LeafPhase<ANY, GEN, INST>(sv, bvh, w, st, fetch, idx);
+        if constexpr (WF_WALK_STATS != 0) ws_.add(1, w.node < 0 && w.node != NODE_NONE && !(INST && AtTransition(w.node)));
+        const int ranT = LeafPhase<ANY, GEN, INST>(sv, bvh, w, st, fetch, idx);
+        if constexpr (WF_WALK_STATS != 0) { if (ranT) { ws_.c[4] += 1; ws_.c[5] += (unsigned long long)ranT; } }
     }
+    ws_.flush(st.dbg, ANY ? 1 : 0);
     if (idx >= 0) retire();   // the rays still held when the queue ran out
 }
 // Measured on the spec scene (16 spp, same box; gpurun_out/r3b_ab_sm16.txt): the any-hit walk gains (30.1 -> 25.2 ms at a threshold of
@@ -1328,7 +1378,11 @@ __global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const 
         }
     }
 #else
+#if defined(WF_MEDIUM_NESTED)
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteractionNested(sv, ws, cur, i);
+#else
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction(sv, ws, cur, i);
+#endif
 #endif
 }
 __global__ void __launch_bounds__(BLOCK) k_medium_route(const SceneView sv, WorkState ws, int cur) {
@@ -2589,6 +2643,15 @@ int wf_sync(wf_ctx *ctx) {
             int h[8];
             HIPCHK(hipMemcpy(h, ctx->dbgWords, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[drain] spilled %d, re-walks %d, pushes %d, repeated re-walks %d, unresolved %d\n", h[0], h[2], h[4], h[5], h[6]);
+#if WF_WALK_STATS
+            unsigned long long c[16];
+            HIPCHK(hipMemcpy(c, ctx->dbgWords + 8, sizeof(c), hipMemcpyDeviceToHost));
+            const char *ph[4] = {"interior", "leaf", "transition", "refill"};
+            for (int k = 0; k < 2; ++k)
+                for (int q = 0; q < 4; ++q)
+                    fprintf(stderr, "[walk stats] %s %-26s wave iterations %llu, lanes %llu (%.1f per iteration)\n", k ? "any-hit" : "closest", ph[q], c[k * 8 + 2 * q], c[k * 8 + 2 * q + 1],
+                            c[k * 8 + 2 * q] ? (double)c[k * 8 + 2 * q + 1] / (double)c[k * 8 + 2 * q] : 0.0);
+#endif
         }
     }
     return 0;
@@ -2872,8 +2935,8 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if ((e = devAlloc(ctx, &ctx->stackSpill, (size_t)rows * MAX_GRID * BLOCK))) return e;
             if ((e = devAlloc(ctx, &ctx->walkSave, (size_t)4 * MAX_GRID * BLOCK))) return e;
             ctx->spillRows = rows;
-            if ((e = devAlloc(ctx, &ctx->dbgWords, (size_t)8))) return e;   // [4..7]: near-tie queue diagnostics (pushes, re-walks without a hit, -, -)
-            HIPCHK(hipMemset(ctx->dbgWords, 0, 8 * sizeof(int)));
+            if ((e = devAlloc(ctx, &ctx->dbgWords, (size_t)8 + 32))) return e;   // [8..39]: -DWF_WALK_STATS builds: sixteen 64-bit phase counters (WalkStats)   // [4..7]: near-tie queue diagnostics (pushes, re-walks without a hit, -, -)
+            HIPCHK(hipMemset(ctx->dbgWords, 0, (8 + 32) * sizeof(int)));
         }
         if (d->n_bvh_nodes > 0)
             for (int a = 0; a < 3; ++a) { ctx->sceneMin[a] = d->bvh_nodes[0].bmin[a]; ctx->sceneMax[a] = d->bvh_nodes[0].bmax[a]; }

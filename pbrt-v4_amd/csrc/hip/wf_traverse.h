@@ -84,7 +84,11 @@ struct alignas(16) U4 { uint32_t x, y, z, w; };
 
 constexpr int NODE_NONE = (int)0x80000000;
 #ifndef WF_TOP_NODES
-#define WF_TOP_NODES (WF_BVH4 ? 128 : 512)   // 128 x 64 B = 8 KiB: with the 16 KiB stack ring five 256-thread workgroups fit a CU's 160 KiB (256 nodes: four; any-hit -9 %)
+// QNodes of the tree's top copied into LDS by every workgroup.  Rounds 1-5: 128 (WF_BVH4; 256: any-hit -9 % in round 3) — the walk then fetched a node
+// through a pointer that is either LDS or global memory, which the compiler can only issue as FLAT loads.  Round 6: 0 — no copy, every
+// node fetch is a plain global load (the top of the tree lives in the vector L1 / L2 anyway): closest-hit 31.3 -> 28.4 ms, any-hit
+// 13.5 -> 12.5 ms per 16 spp on the spec scene, same box (profiles/r06_tree_top_global_loads_and_knobs_ab_sm16.txt), and 8 KiB of LDS less per workgroup.
+#define WF_TOP_NODES 0
 #endif
 #ifndef WF_TBLOCK
 #define WF_TBLOCK 256
