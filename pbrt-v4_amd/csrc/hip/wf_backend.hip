@@ -163,6 +163,14 @@ static int devUpload(wf_ctx *c, const T **p, const T *src, size_t n) {
     return 0;
 }
 
+template <typename T>
+static int devUpload(wf_ctx *c, wf::GPtr<const T> *p, const T *src, size_t n) {   // (a SceneView table pointer, wf_scene.h)
+    const T *d = nullptr;
+    if (int e = devUpload(c, &d, src, n)) return e;
+    *p = d;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // Round 4: a kernel may read the scene view through the pointer to its device-resident copy (sv.self) instead of from its by-value
@@ -369,6 +377,19 @@ struct LdsStackT {
             if (dbg) atomicAdd(dbg, 1);
             ++lo;
         }
+        g_tstack[(n & MASK) * TBLOCK + threadIdx.x] = v;
+        ++n;
+    }
+    // room for k more entries at once (k <= 3: the interior step's pushes), so that the pushes themselves need no test (WF_PUSH_RESERVE)
+    __device__ void reserve(int k) {
+        while (__builtin_expect(n - lo + k > TSTACK, 0)) {
+            if (__builtin_expect(lo >= rows, 0)) { if (dbg) atomicOr(dbg + 1, 1); return; }
+            SpillWrite(&spill[(size_t)lo * spillStride], g_tstack[(lo & MASK) * TBLOCK + threadIdx.x]);
+            if (dbg) atomicAdd(dbg, 1);
+            ++lo;
+        }
+    }
+    __device__ void pushReserved(int v) {
         g_tstack[(n & MASK) * TBLOCK + threadIdx.x] = v;
         ++n;
     }

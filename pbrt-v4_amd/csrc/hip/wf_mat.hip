@@ -64,8 +64,8 @@ constexpr int MBLOCK = 256;
 // The light sampling (descent of the light BVH, shape sampling) is a chain of dependent gathers and pays for occupancy even with 100-600
 // spilled VGPRs; the shade half is dominated by its own loads and stores, and spills only add to them.
 #ifndef WF_NEE_WAVES
-#if (WF_MAT_INSTANCE == 10 || WF_MAT_INSTANCE == 7) && WF_MAT_PART == 2 && WF_MAT_TEXCTX == 1
-#define WF_NEE_WAVES 2   // (k_mat_nee<measured, rare lights> — and, since round 6's inlined item I/O, <coated conductor, rare lights> — at 4 waves spill a carrier register: tools/check_spill_carriers.py)
+#if (WF_MAT_INSTANCE == 10 || WF_MAT_INSTANCE == 7 || WF_MAT_INSTANCE == 9) && WF_MAT_PART == 2 && WF_MAT_TEXCTX == 1
+#define WF_NEE_WAVES 2   // (k_mat_nee<measured, rare lights> — and, since round 6's inlined item I/O, <coated conductor, rare lights>, since its global table loads <type 9, rare lights> — at 4 waves spill a carrier register: tools/check_spill_carriers.py)
 #else
 #define WF_NEE_WAVES 4
 #endif

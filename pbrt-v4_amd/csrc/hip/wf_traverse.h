@@ -491,6 +491,9 @@ __device__ inline void CSwap(float &ka, int &ra, float &kb, int &rb) {
 #ifndef WF_ANY_NOSORT
 #define WF_ANY_NOSORT 0
 #endif
+#ifndef WF_PUSH_RESERVE
+#define WF_PUSH_RESERVE 0
+#endif
 template <bool RELAX = true, typename Stack>
 __device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, const U4 *n) {
     const float tPrune = RELAX ? WalkBound(bvh, __builtin_fabsf(w.tMax)) : w.tMax;
@@ -525,9 +528,21 @@ __device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, c
     CSwap(k0, r0, k1, r1); CSwap(k2, r2, k3, r3); CSwap(k0, r0, k2, r2); CSwap(k1, r1, k3, r3); CSwap(k1, r1, k2, r2);
     const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (nh == 0) { w.node = st.empty() ? NODE_NONE : st.pop(); return; }
+#if WF_PUSH_RESERVE
+    // one ring-full test for the step's pushes instead of one per push (a full ring with a spill row overflow drops entries in both forms: wf_sync reports it)
+    if (nh > 1) {
+        st.reserve(nh - 1);
+        if (st.n - st.lo + (nh - 1) <= TSTACK) {
+            if (nh > 3) st.pushReserved(r3);
+            if (nh > 2) st.pushReserved(r2);
+            st.pushReserved(r1);
+        }
+    }
+#else
     if (nh > 3) st.push(r3);
     if (nh > 2) st.push(r2);
     if (nh > 1) st.push(r1);
+#endif
     w.node = r0;
 }
 #else
