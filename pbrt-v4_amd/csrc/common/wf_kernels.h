@@ -775,97 +775,6 @@ WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, in
     while (MediumTrackStep(sv, ws, cur, s)) {}
     MediumTrackEnd(sv, ws, cur, s);
 }
-#if defined(WF_MEDIUM_NESTED)
-// (A/B builds only, -DWF_MEDIUM_NESTED: the stage as rounds 1-5 wrote it — SampleT_maj's nested loops with the event as a callback — for
-//  same-box timing against the state machine above; the same operations per item)
-WF_HD void KSampleMediumInteractionNested(const SceneView &sv, const WorkState &ws, int cur, int qi) {
-    const int i = ws.mediumSampleQ[qi];
-    const RayQueueV &q = ws.rq[cur];
-    F4 o4 = q.o[i], d4 = q.d[i];
-    I4 meta = q.meta[i];
-    const int pixelIndex = meta.x, depth = meta.y, medium = meta.w;
-    V3 ro{o4.x, o4.y, o4.z}, rd{d4.x, d4.y, d4.z};
-    F4 h = ws.hit[i];
-    const int prim = (int)FloatToBits(h.x);
-    const float tMax = ws.hitT[i];
-    Wavelengths lambda = LoadLambda(ws, pixelIndex);
-    S4 beta = toS4(q.beta[i]), r_u = toS4(q.r_u[i]), r_l = toS4(q.r_l[i]);
-    S4 L = S4c(0.f);
-    RNG rng(Hash3f1(ro, tMax), Hash3f(rd));
-    bool scattered = false;
-    float uDist = rng.UniformFloat();
-    float uMode = rng.UniformFloat();
-    S4 T_maj = SampleT_maj(sv, medium, ro, rd, tMax, uDist, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
-        // emission, scaled by sigma_a / sigma_maj at every event (media.cpp:72-83)
-        if (depth < sv.maxDepth && mp.Le) {
-            float pr = sigma_maj[0] * T_maj[0];
-            S4 r_e = r_u * sigma_maj * T_maj / pr;
-            if (r_e) L = L + beta * mp.sigma_a * T_maj * mp.Le / (pr * r_e.Average());
-        }
-        float pAbsorb = mp.sigma_a[0] / sigma_maj[0];
-        float pScatter = mp.sigma_s[0] / sigma_maj[0];
-        float pNull = fmax(0.f, 1 - pAbsorb - pScatter);
-        const float w3[3] = {pAbsorb, pScatter, pNull};
-        int mode = SampleDiscreteN(w3, 3, uMode);
-        if (mode == 0) {
-            beta = S4c(0.f);
-            return false;
-        } else if (mode == 1) {
-            float pr = T_maj[0] * mp.sigma_s[0];
-            beta = beta * (T_maj * mp.sigma_s / pr);
-            r_u = r_u * (T_maj * mp.sigma_s / pr);
-            if (beta && r_u) {
-                // MediumScatterWorkItem push (media.cpp:104-113)
-                q.beta[i] = toF4(beta);
-                q.r_u[i] = toF4(r_u);
-                ws.scatterP[i] = F4{p.x, p.y, p.z, mp.g};
-                int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE]);
-                ws.mediumScatterQ[slot] = i;
-            }
-            scattered = true;
-            return false;
-        } else {
-            S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
-            float pr = T_maj[0] * sigma_n[0];
-            beta = beta * (T_maj * sigma_n / pr);
-            if (pr == 0) beta = S4c(0.f);
-            r_u = r_u * (T_maj * sigma_n / pr);
-            r_l = r_l * (T_maj * sigma_maj / pr);
-            uMode = rng.UniformFloat();
-            return bool(beta) && bool(r_u);
-        }
-    });
-    if (!scattered && beta) {
-        beta = beta * (T_maj / T_maj[0]);
-        r_u = r_u * (T_maj / T_maj[0]);
-        r_l = r_l * (T_maj / T_maj[0]);
-    }
-    if (L) ws.L[pixelIndex] = toF4(toS4(ws.L[pixelIndex]) + L);
-    if (scattered || !beta || !r_u || depth == sv.maxDepth) return;
-    // the ray reached the surface (or left the scene): route it as EnqueueWorkAfterIntersection would have
-    q.beta[i] = toF4(beta);
-    q.r_u[i] = toF4(r_u);
-    q.r_l[i] = toF4(r_l);
-    if (IsInf(tMax)) {
-        if (sv.nInfiniteLights > 0) {
-            int slot = QueueAlloc(&ws.counters[(CNT_ESCAPED) * CNT_STRIDE]);
-            ws.escapedQ[slot] = i;
-        }
-        return;
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the HIP back end routes the rays that reached their surface in a kernel of its own (KMediumRoute over ws.mediumRouteQ): the routing
-    // rebuilds the interaction of interface hits and resolves MixMaterials — code whose registers the delta-tracking loop above should
-    // not pay for (k_medium_sample: 219 -> 128 VGPRs, round 5)
-    {
-        int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_ROUTE) * CNT_STRIDE]);
-        ws.mediumRouteQ[slot] = i;
-    }
-#else
-    RouteSurfaceHit(sv, ws, cur, i, prim, HitInst(sv, ws, i), h.y, h.z, h.w, /* fromMedium */ true);
-#endif
-}
-#endif
 // the second half of K5 on the HIP back end: EnqueueWorkAfterIntersection for the medium-sample items that reached their surface
 WF_HD void KMediumRoute(const SceneView &sv, const WorkState &ws, int cur, int qi) {
     const int i = ws.mediumRouteQ[qi];
@@ -1672,7 +1581,9 @@ WF_HD float IntersectOneRandom(const SceneView &sv, V3 p0, V3 p1, int material, 
         st.n = 0;
         if (!BVHIntersectClosest<ANIM>(sv, r.o, r.d, 1.f, st, &ch, 0.f)) break;
         SurfIntr si;
-        HitInteraction<!WF_DEV_LEAN, false, ANIM>(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si, r.o, r.d, 0.f);
+        // (CURVE_ALPHA: a probe segment that crosses an alpha-textured curve is respawned from the interaction the reference's recursion ends
+        //  with — GeometricPrimitive::Intersect's replay, wf_shapes.h — not from the first candidate's: ADVICE r5)
+        HitInteraction<!WF_DEV_LEAN, true, ANIM>(sv, ch.prim, ch.inst, ch.h.b0, ch.h.b1, ch.h.b2, &si, r.o, r.d, 0.f);
         basePi = si.pi; baseN = si.n;
         if (sv.meshes[si.mesh].material == material) {
             // wrs.Add(SubsurfaceInteraction(si->intr), 1.f)  (util/sampling.h:535-546)

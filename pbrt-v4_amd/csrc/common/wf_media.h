@@ -396,6 +396,10 @@ WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, cons
     return it;
 }
 
+// (Round 6, measured and dropped for THIS function: the two nested loops flattened into one, as the medium-sample stage's state machine
+//  does (MediumTrackStep, wf_kernels.h: -15 % there) — the transmittance walks that call this lose: 21.3 against 19.2 ms on the cloud scene,
+//  same box, profiles/r06_sampleT_maj_flattened_for_transmittance_ab_cloud16.txt.  Their callback is a few multiplications: the nested form's
+//  tight inner loop is worth more than the lanes the flattening keeps busy.)
 // SampleT_maj, media.h:724-800.  callback(p, mp, sigma_maj, T_maj) -> continue?
 template <typename F>
 WF_HD S4 SampleT_maj(const SceneView &sv, int mediumId, V3 o, V3 d, float tMax, float u, RNG &rng, const Wavelengths &lambda, F callback) {

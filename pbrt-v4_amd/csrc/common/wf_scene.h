@@ -40,9 +40,14 @@ struct GPtr {
     WF_HD typename std::enable_if<!std::is_arithmetic<U>::value, U &>::type operator[](I i) const { return p[i]; }
 };
 
+// (round 6, device only) a triangle's vertex data de-indexed: what the material stage's interaction rebuild gathers — three indices, then three
+// positions, normals and (u, v) pairs from three tables, 13 scattered sectors behind a dependent load — as ONE 96-byte record per triangle
+// (zeros where the mesh has no normals / no (u, v)).  1 GB for the 10 M-triangle scene: what 288 GB are for.
+struct alignas(16) ShadeTri { float p[9], n[9], uv[6]; };
 struct SceneView {
     // geometry (util/mesh.h TriangleMesh buffers, flattened over all meshes)
     GPtr<const float> P, N, UV;
+    GPtr<const ShadeTri> shadeTris;   // [nTriangles], or null (the host checker; WF_SHADE_TRIS=0)
     GPtr<const float> S;   // shading tangents of the meshes with WF_MESH_HAS_S (LoadS)
     GPtr<const int32_t> triIndices, triMesh;
     GPtr<const wf_mesh> meshes;

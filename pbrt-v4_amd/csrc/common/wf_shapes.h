@@ -1091,9 +1091,19 @@ WF_HD void TriangleInteraction(const SceneView &sv, int tri, float b0, float b1,
     const int meshId = sv.triMesh[tri];
     const wf_mesh mesh = sv.meshes[meshId];
     si->mesh = meshId;
-    V3 p0 = LoadP(sv, v[0]), p1 = LoadP(sv, v[1]), p2 = LoadP(sv, v[2]);
+    V3 p0, p1, p2;
     V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
-    if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+    N3 n0{0, 0, 0}, n1{0, 0, 0}, n2{0, 0, 0};
+    const bool deindexed = (const ShadeTri *)sv.shadeTris != nullptr;   // (the same values either way: the record is a copy of the tables' entries)
+    if (deindexed) {
+        const ShadeTri st = sv.shadeTris[tri];
+        p0 = V3{st.p[0], st.p[1], st.p[2]}; p1 = V3{st.p[3], st.p[4], st.p[5]}; p2 = V3{st.p[6], st.p[7], st.p[8]};
+        if (mesh.flags & WF_MESH_HAS_UV) { uv0 = V2{st.uv[0], st.uv[1]}; uv1 = V2{st.uv[2], st.uv[3]}; uv2 = V2{st.uv[4], st.uv[5]}; }
+        if (mesh.flags & WF_MESH_HAS_N) { n0 = N3{st.n[0], st.n[1], st.n[2]}; n1 = N3{st.n[3], st.n[4], st.n[5]}; n2 = N3{st.n[6], st.n[7], st.n[8]}; }
+    } else {
+        p0 = LoadP(sv, v[0]); p1 = LoadP(sv, v[1]); p2 = LoadP(sv, v[2]);
+        if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+    }
     V2 duv02{uv0.x - uv2.x, uv0.y - uv2.y}, duv12{uv1.x - uv2.x, uv1.y - uv2.y};
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     float determinant = DifferenceOfProducts(duv02.x, duv12.y, duv02.y, duv12.x);
@@ -1141,10 +1151,9 @@ WF_HD void TriangleInteraction(const SceneView &sv, int tri, float b0, float b1,
     si->dndus = si->dndvs = N3{0, 0, 0};
     if (mesh.flags & (WF_MESH_HAS_N | WF_MESH_HAS_S)) {   // shapes.h:940: mesh->n || mesh->s
         const bool hasN = mesh.flags & WF_MESH_HAS_N;
-        N3 n0{0, 0, 0}, n1{0, 0, 0}, n2{0, 0, 0};
         N3 ns = si->n;
         if (hasN) {
-            n0 = LoadN(sv, v[0]); n1 = LoadN(sv, v[1]); n2 = LoadN(sv, v[2]);
+            if (!deindexed) { n0 = LoadN(sv, v[0]); n1 = LoadN(sv, v[1]); n2 = LoadN(sv, v[2]); }
             ns = b0 * n0 + b1 * n1 + b2 * n2;
             ns = LengthSquared(ns) > 0 ? Normalize(ns) : si->n;
         }

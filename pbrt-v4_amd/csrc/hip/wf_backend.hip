@@ -389,6 +389,10 @@ struct LdsStackT {
             ++lo;
         }
     }
+    __device__ void pushIf(int v, bool wanted) {
+        g_tstack[(n & MASK) * TBLOCK + threadIdx.x] = v;
+        n += wanted ? 1 : 0;
+    }
     __device__ void pushReserved(int v) {
         g_tstack[(n & MASK) * TBLOCK + threadIdx.x] = v;
         ++n;
@@ -459,7 +463,12 @@ __device__ __attribute__((noinline)) bool AlphaTestSimpleP(const SceneView *svp,
     else {
         const auto v = sv.triIndices + 3 * (size_t)tri;
         V2 uv0{0, 0}, uv1{1, 0}, uv2{1, 1};
-        if (mesh.flags & WF_MESH_HAS_UV) { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+        if (mesh.flags & WF_MESH_HAS_UV) {
+            if ((const ShadeTri *)sv.shadeTris != nullptr) {   // the triangle's de-indexed record (wf_scene.h): one 24-byte gather instead of an index triple + three
+                const float *q = sv.shadeTris[tri].uv;
+                uv0 = V2{q[0], q[1]}; uv1 = V2{q[2], q[3]}; uv2 = V2{q[4], q[5]};
+            } else { uv0 = LoadUV(sv, v[0]); uv1 = LoadUV(sv, v[1]); uv2 = LoadUV(sv, v[2]); }
+        }
         const V2 uv{b0 * uv0.x + b1 * uv1.x + b2 * uv2.x, b0 * uv0.y + b1 * uv1.y + b2 * uv2.y};
         const V2 st{t.map[0] * uv.x + t.map[2], t.map[1] * uv.y + t.map[3]};
         if (t.type == WF_TEX_FLOAT_IMAGE) {
@@ -1399,11 +1408,8 @@ __global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const 
         }
     }
 #else
-#if defined(WF_MEDIUM_NESTED)
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteractionNested(sv, ws, cur, i);
-#else
+    // (the nested-loop form of rounds 1-5 measured 43.2 ms against this form's 36.5 on the cloud scene, same box: profiles/r06_medium_nested_vs_state_machine_ab_cloud16.txt)
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction(sv, ws, cur, i);
-#endif
 #endif
 }
 __global__ void __launch_bounds__(BLOCK) k_medium_route(const SceneView sv, WorkState ws, int cur) {
@@ -2701,6 +2707,26 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     if (d->n_tangents > 0 && (e = devUpload(ctx, &sv.S, d->S, (size_t)3 * d->n_tangents))) return e;
     if ((e = devUpload(ctx, &sv.triIndices, d->tri_indices, (size_t)3 * d->n_triangles))) return e;
     if ((e = devUpload(ctx, &sv.triMesh, d->tri_mesh, (size_t)d->n_triangles + d->n_quadrics))) return e;
+    // the de-indexed per-triangle vertex records of the material stage (wf_scene.h ShadeTri); WF_SHADE_TRIS=0: the indexed tables only
+    sv.shadeTris = nullptr;
+    if (d->n_triangles > 0 && !(getenv("WF_SHADE_TRIS") && atoi(getenv("WF_SHADE_TRIS")) == 0)) {
+        std::vector<ShadeTri> st((size_t)d->n_triangles);
+        for (size_t t = 0; t < (size_t)d->n_triangles; ++t) {
+            const int32_t *ix = d->tri_indices + 3 * t;
+            const int flags = d->meshes[d->tri_mesh[t]].flags;
+            ShadeTri r{};
+            for (int k = 0; k < 3; ++k) {
+                for (int a = 0; a < 3; ++a) r.p[3 * k + a] = d->P[3 * (size_t)ix[k] + a];
+                if ((flags & WF_MESH_HAS_N) && d->N) for (int a = 0; a < 3; ++a) r.n[3 * k + a] = d->N[3 * (size_t)ix[k] + a];
+                if ((flags & WF_MESH_HAS_UV) && d->UV) for (int a = 0; a < 2; ++a) r.uv[2 * k + a] = d->UV[2 * (size_t)ix[k] + a];
+            }
+            st[t] = r;
+        }
+        const ShadeTri *dst = nullptr;
+        if ((e = devUpload(ctx, &dst, st.data(), st.size()))) return e;
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // (the staging vector dies here)
+        sv.shadeTris = dst;
+    }
     if ((e = devUpload(ctx, &sv.quadrics, d->quadrics, (size_t)d->n_quadrics))) return e;
     if ((e = devUpload(ctx, &sv.sobolMatrices, d->sobol_matrices, d->sobol_matrices ? (size_t)1024 * 52 : (size_t)0)) ||
         (e = devUpload(ctx, &sv.vdcSobol, d->vdc_sobol, d->vdc_sobol ? (size_t)25 * 52 : (size_t)0)) ||

@@ -528,8 +528,18 @@ __device__ inline void InteriorStep(const FastBVH &bvh, RayWalk &w, Stack &st, c
     CSwap(k0, r0, k1, r1); CSwap(k2, r2, k3, r3); CSwap(k0, r0, k2, r2); CSwap(k1, r1, k3, r3); CSwap(k1, r1, k2, r2);
     const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     if (nh == 0) { w.node = st.empty() ? NODE_NONE : st.pop(); return; }
-#if WF_PUSH_RESERVE
+#if WF_PUSH_RESERVE == 2
+    // branch-free pushes: room for three entries is made first (rarely needed), then every candidate is WRITTEN to the ring and the
+    // count advances only for the ones that are wanted — no exec-masked region per push
+    st.reserve(3);
+    if (st.n - st.lo + 3 <= TSTACK) {
+        st.pushIf(r3, nh > 3);
+        st.pushIf(r2, nh > 2);
+        st.pushIf(r1, nh > 1);
+    }
+#elif WF_PUSH_RESERVE
     // one ring-full test for the step's pushes instead of one per push (a full ring with a spill row overflow drops entries in both forms: wf_sync reports it)
+    // (measured, round 6: 28.5 against 27.4 ms closest-hit — left off)
     if (nh > 1) {
         st.reserve(nh - 1);
         if (st.n - st.lo + (nh - 1) <= TSTACK) {

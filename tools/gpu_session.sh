@@ -12,7 +12,7 @@
 #   soak             $SOAK renders of the spec scene at 4 spp: every image must be the first one (the near-tie queue's guard)
 #   ab               pbrt_amd --stats under each environment given in $AB (";"-separated) — knob A/B on one box
 #   goldens          every tests/golden scene with a reference render through the native binary, pixel payloads compared bit for bit (no torch import: about a minute)
-# Environment: TAG (default r04), STEPS (20), SPP (16), PMC_SPP (4), SCENE (sanmiguel | sanmiguel_sphere | killeroo | cloud | tm), GREP (kernel-name filter of sm16).
+# Environment: TAG (default r04), STEPS (20), SPP (16), PMC_SPP (4), SCENE (sanmiguel | sanmiguel_sphere | sanmiguel_marble | killeroo | cloud | tm), GREP (kernel-name filter of sm16).
 export TMPDIR=/tmp
 TAG=${TAG:-r05}; STEPS=${STEPS:-20}; SPP=${SPP:-16}; PMC_SPP=${PMC_SPP:-4}; SCENE=${SCENE:-sanmiguel}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -22,6 +22,7 @@ scene_file() {   # the benchmarked stand-in as a scene file under /tmp (generate
   case $SCENE in
     sanmiguel) d=/tmp/wfbench_sm; f=$d/sm.pbrt; gen="sanmiguel-like";;
     sanmiguel_sphere) d=/tmp/wfbench_sms; f=$d/sm.pbrt; gen="sanmiguel-like";;   # + one sphere: the GEN = 2 kernels on the headline geometry
+    sanmiguel_marble) d=/tmp/wfbench_smm; f=$d/sm.pbrt; gen="sanmiguel-like";;   # + one marble-textured quad: a texture graph on the commonest material type
     killeroo)  d=/tmp/wfbench_k;  f=$d/k.pbrt;  gen="killeroo-like";;
     cloud)     d=/tmp/wfbench_c;  f=$d/c.pbrt;  gen="cloud-like";;
     tm)        d=/tmp/wfbench_tm; f=$d/tm.pbrt; gen="tm-like";;
@@ -29,6 +30,7 @@ scene_file() {   # the benchmarked stand-in as a scene file under /tmp (generate
   mkdir -p $d
   if [ ! -f $f ]; then
     python $ROOT/tools/make_scenes.py $gen $f --spp 16 > /dev/null
+    [ $SCENE = sanmiguel_marble ] && printf 'AttributeBegin\n  Texture "marb" "spectrum" "marble" "float scale" 3\n  Material "diffuse" "texture reflectance" "marb"\n  Translate 0 -6 0.02\n  Shape "trianglemesh" "point3 P" [ -1.5 -1.5 0  1.5 -1.5 0  1.5 1.5 0  -1.5 1.5 0 ] "integer indices" [ 0 1 2 0 2 3 ]\nAttributeEnd\n' >> $f
     [ $SCENE = sanmiguel_sphere ] && printf 'AttributeBegin\n  Material "conductor" "float roughness" 0.1\n  Translate 0 1.5 0\n  Shape "sphere" "float radius" 0.75\nAttributeEnd\n' >> $f
   fi
   echo $f
