@@ -113,7 +113,9 @@ struct wf_ctx {
     static bool splitRouteWanted() { return true; }
     // ray-coherence pass (SortRayQueue): bit 0 sorts the ray queue before the closest-hit launch of depth >= 1, bit 1 the shadow queue
     int raySort = 0;
-    int cursorChunk = 2;         // 64-ray batches a wave takes per cursor fetch (WF_CURSOR_CHUNK): 1 is best on the 10 M-triangle scene
+    int cursorChunk = 2;         // 64-ray batches a closest-hit wave takes per cursor fetch (WF_CURSOR_CHUNK sets both)
+    int cursorChunkShadow = 2;   // ... an any-hit wave (round 6, with the descent scheduling, 10 M-triangle scene: closest-hit 27.7 ms at 1, 26.7 at 3, 27.0 at 4, 27.4 at 8, 29.9 at 16;
+                                 // any-hit 12.15 at 1, 12.16 at 3, 12.4 at 4, 13.0 at 8: profiles/r06_cursor_chunk_ab_sm16.txt)
                                  // (-3 %), but on a 30 k-triangle scene one fetch per 64 rays is 83 atomics/us on one counter: the kernel's bound
     int splitRoute = 2;          // WF_SPLIT_ROUTE: 0 = the closest-hit walk routes its hits per workgroup (KRouteHitBlock inside the walk);
                                  // 1 = walk without the workgroup barrier + k_route_hits; 2 (default) = 1 + waves draw their rays from a shared cursor
@@ -2994,7 +2996,11 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             if ((e = devUpload(ctx, &ctx->fast.subs, fsubs.data(), fsubs.size()))) return e;
             // rays of a scene whose trees do not fit the caches walk long enough for one cursor fetch per 64 rays (measured: -3 % on
             // the 10 M-triangle scene); a cache-resident scene traces so fast that the cursor's atomics would bound it (see cursorChunk)
-            if (!getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = (qn.size() * sizeof(QNode) + lt.size() * sizeof(LeafTri) > ((size_t)256 << 20)) ? 1 : 2;
+            if (!getenv("WF_CURSOR_CHUNK")) {
+                const bool big = qn.size() * sizeof(QNode) + lt.size() * sizeof(LeafTri) > ((size_t)256 << 20);
+                ctx->cursorChunk = big ? 3 : 2;
+                ctx->cursorChunkShadow = big ? 1 : 2;
+            }
             ctx->fast.instances = ctx->svHost.instances;
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
@@ -3175,7 +3181,7 @@ int wf_queues_alloc(wf_ctx *ctx, int pixels_per_pass, int samples_per_pass) {
     // (round 6: WF_SPLIT_ROUTE=0 — the walk routing its hits per workgroup, the round-2 path — is gone: its kernel variants were the ones that
     //  kept tripping the spill-carrier lint whenever anything near them changed; 1 = no work cursor, 2 = the default)
     ctx->splitRoute = getenv("WF_SPLIT_ROUTE") ? std::max(1, atoi(getenv("WF_SPLIT_ROUTE"))) : 2;
-    if (getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = std::max(1, atoi(getenv("WF_CURSOR_CHUNK")));  // (default: chosen at scene upload)
+    if (getenv("WF_CURSOR_CHUNK")) ctx->cursorChunk = ctx->cursorChunkShadow = std::max(1, atoi(getenv("WF_CURSOR_CHUNK")));  // (default: chosen at scene upload)
     if (ctx->splitRoute && (e = devAlloc(ctx, &ws.routeCode, n))) return e;
     ctx->raySort = getenv("WF_RAY_SORT") ? atoi(getenv("WF_RAY_SORT")) : 0;
     if (!ctx->fastOk) ctx->raySort = 0;
@@ -3564,10 +3570,10 @@ int wf_intersect_shadow(wf_ctx *ctx, int depth) {
             ctx->cursorDirty[1] = true;
         }
         if (ctx->deferGeneral && ctx->splitRoute) {
-            LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, 4 + ctx->genTri, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
-            LAUNCHT_VARIANT_GEN("Intersect shadow: rays that met a general primitive", k_shadow_fast, ctx->genMode, ctx->persistentGridShadowGen, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), (int *)nullptr, ctx->cursorChunk, (const int *)ctx->ws.deferQ);
+            LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, 4 + ctx->genTri, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunkShadow, (const int *)nullptr);
+            LAUNCHT_VARIANT_GEN("Intersect shadow: rays that met a general primitive", k_shadow_fast, ctx->genMode, ctx->persistentGridShadowGen, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), (int *)nullptr, ctx->cursorChunkShadow, (const int *)ctx->ws.deferQ);
         } else
-        LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, ctx->animFast ? 8 + ctx->genMode : ctx->genMode, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunk, (const int *)nullptr);
+        LAUNCHT_VARIANT_GEN("Intersect shadow", k_shadow_fast, ctx->animFast ? 8 + ctx->genMode : ctx->genMode, ctx->persistentGridShadow, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea(), cursor, ctx->cursorChunkShadow, (const int *)nullptr);
     } else
         { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow", (k_intersect_shadow<false, true>), gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
           else LAUNCH("Intersect shadow", k_intersect_shadow<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill); }

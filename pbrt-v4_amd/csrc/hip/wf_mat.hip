@@ -50,12 +50,11 @@ constexpr int MBLOCK = 256;
 #elif WF_MAT_INSTANCE == 2 && defined(WF_NEE_W2)
 #define WF_NEE_WAVES WF_NEE_W2
 #endif
+// (round 6: the diffuse kernel too runs at 3 waves — 167 VGPRs, NOTHING spilled, 24 scratch stores in the whole kernel — instead of 4
+//  (128 VGPRs, 44 spilled): 7.39 against 7.34 ms per 16 spp, profiles/r06_material_occupancy_ab2_sm16.txt: the same time without the
+//  spills' HBM traffic)
 #ifndef WF_SHADE_WAVES_LEAN
-#if WF_MAT_INSTANCE == 1
-#define WF_SHADE_WAVES_LEAN 4
-#else
 #define WF_SHADE_WAVES_LEAN 3
-#endif
 #endif
 // Round 5, the two halves on the spec scene (16 spp, same box; profiles/r05_material_split_ab_sm16.txt, r05_material_occupancy_ab_sm16.txt):
 //   next-event estimation, diffuse / conductor / coated diffuse, ms:  2 waves 12.75 / 2.89 / 9.89   3 waves 9.95 / 2.33 / 9.08
