@@ -731,17 +731,18 @@ struct WalkStats {
 #ifndef WF_SCHED_Q
 #define WF_SCHED_Q 3   // spec scene, 16 spp, same box (profiles/r06_descent_scheduling_ab_sm16.txt): closest / any-hit 35.9 / 16.4 ms at 0, 31.5 / 13.4 at 2, 31.6 / 13.4 at 4, 31.9 / 13.8 at 8; second box (r06_tree_top_global_loads_and_knobs_ab_sm16.txt): 31.6 / 13.9 at 1, 31.0 / 13.4 at 3, 31.3 / 13.5 at 4
 #endif
-template <bool INST>
+#ifndef WF_SCHED_Q_ANY
+#define WF_SCHED_Q_ANY WF_SCHED_Q   // the any-hit walks' own threshold (measured: see DESIGN 4.1)
+#endif
+template <bool INST, bool ANY = false>
 __device__ inline bool WalkDescend(const RayWalk &w) {
-#if WF_SCHED_Q == 0
-    return __any(w.node >= 0);
-#else
+    constexpr int Q = ANY ? WF_SCHED_Q_ANY : WF_SCHED_Q;
+    if constexpr (Q == 0) return __any(w.node >= 0);
     const int nI = __popcll(__ballot(w.node >= 0));
     if (nI == 0) return false;
     // (lanes at an instance transition do not count: LeafPhase may leave them parked, and a round must always make progress)
     const int nL = __popcll(__ballot(w.node < 0 && w.node != NODE_NONE && !(INST && AtTransition(w.node))));
-    return 4 * nI >= WF_SCHED_Q * nL;
-#endif
+    return 4 * nI >= Q * nL;
 }
 template <bool ANY, int GEN, bool INST = false, typename Fetch, typename Finish>
 __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4) {
@@ -794,7 +795,7 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
         // accesses (7.2e8 vs 1.45e8 per 8.5 M-ray launch): lanes at unrelated depths of the tree no longer share
         // cache lines, and the walk becomes L1-bound: 33 ms vs 27 ms per 16 spp.  DESIGN.md §4.)
         while (__any(w.node != NODE_NONE)) {
-            while (WalkDescend<INST>(w)) {
+            while (WalkDescend<INST, ANY>(w)) {
                 if (w.node >= 0) {
                     U4 nd[QNODE_U4];
                     FetchNode(bvh, w.node, nd);
@@ -829,6 +830,12 @@ __device__ inline void BatchTrace(const SceneView &sv, const FastBVH &bvh, int n
 #ifndef WF_REFILL_AT
 #define WF_REFILL_AT 40
 #endif
+#ifndef WF_GUIDED_CHUNK
+#define WF_GUIDED_CHUNK 6   // 0: fixed runs of `chunk` x 64 rays; > 0: the any-hit walks take guided runs of at most this many x 64
+#endif
+#ifndef WF_GUIDED_DIV
+#define WF_GUIDED_DIV 4
+#endif
 template <bool ANY, int GEN, bool INST = false, bool DEFER = false, typename Fetch, typename Finish>
 __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh, int n, LdsStackT &st, Fetch fetch, Finish finish, int *cursor = nullptr, int chunk = 4,
                                         int workBlocks = 0) {
@@ -840,6 +847,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
     const int waveId = (blockIdx.x * TBLOCK + threadIdx.x) >> 6, nWaves = (workBlocks * TBLOCK) >> 6;
     const int runRays = cursor ? 64 * chunk : 64;
     int next = 0, end = 0, staticJ = 0;   // the wave's private run [next, end) of ray indices (uniform)
+    int lastB = 0;                        // the cursor's value at the wave's last fetch (WF_GUIDED_CHUNK)
     bool exhausted = false;
     int idx = -1;
 #if WF_WALK_ZERO
@@ -883,16 +891,26 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
             while (served < need) {
                 if (next >= end) {
                     int b;
+                    int rr = runRays;
                     if (cursor) {
+#if WF_GUIDED_CHUNK
+                        // guided self-scheduling (any-hit walks): long runs (neighbouring rays, refill after refill) while the queue is long,
+                        // short ones towards its end, where a wave that still owns a long run would be the launch's tail.  Spec scene, 16 spp,
+                        // same box, three runs (profiles/r06_guided_chunk_ab_sm16.txt): any-hit 12.2 -> 11.95 ms; the closest-hit walk
+                        // LOSES with it (26.9 -> 28.4) and keeps its fixed runs of 3 x 64
+                        // (triangle kernels only: with it k_shadow_fast<2, false> spilled an SGPR-spill carrier — tools/check_spill_carriers.py)
+                        if constexpr (ANY && GenBase(GEN) <= 1) { int c = (n - lastB) / (nWaves * 64 * WF_GUIDED_DIV); c = c < 1 ? 1 : (c > WF_GUIDED_CHUNK ? WF_GUIDED_CHUNK : c); rr = 64 * c; }
+#endif
                         b = 0;
-                        if (lane == 0) b = atomicAdd(cursor, runRays);
+                        if (lane == 0) b = atomicAdd(cursor, rr);
                         b = __builtin_amdgcn_readfirstlane(b);
+                        lastB = b < n ? b : n;
                     } else {
                         b = (staticJ * nWaves + waveId) * 64;
                         ++staticJ;
                     }
                     next = b;
-                    end = b + runRays < n ? b + runRays : n;
+                    end = b + rr < n ? b + rr : n;
                     if (next >= n) { exhausted = true; break; }
                 }
                 const int take = need - served < end - next ? need - served : end - next;
@@ -914,7 +932,7 @@ __device__ inline void BatchTraceRefill(const SceneView &sv, const FastBVH &bvh,
             }
             if (exhausted && !__any(w.node != NODE_NONE)) break;
         } else if (nAct == 0) break;
-        while (WalkDescend<INST>(w)) {
+        while (WalkDescend<INST, ANY>(w)) {
             ws_.add(0, w.node >= 0);
             if (w.node >= 0) {
                 U4 nd[QNODE_U4];
