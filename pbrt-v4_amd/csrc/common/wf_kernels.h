@@ -613,6 +613,9 @@ __device__ inline void KRouteHitBlock(const SceneView &sv, const WorkState &ws, 
 // kernels use).  SampleT_maj's two nested loops (media.h:724-800) are the same sequence of operations per item: the
 // outer loop's "next segment" and the inner loop's "next exponential step" are the two halves of Step.  The CPU checker and the
 // reference-order path run Begin; while (Step); End — the same code.
+#ifndef WF_MEDIUM_SPEC
+#define WF_MEDIUM_SPEC 0   // measured and LEFT OFF (round 6, cloud scene, 16 spp, same box, profiles/r06_medium_two_collisions_per_step_ab_cloud16.txt): 46.3 against 36.4 ms
+#endif
 struct MediumTrack {
     int i;               // ray slot (-1: the lane holds no item)
     int pixelIndex, depth, medium;
@@ -623,10 +626,12 @@ struct MediumTrack {
     MajorantSeg seg;
     float tMin;
     bool inSeg, scattered, stopped;   // stopped: the callback ended the walk (SampleT_maj then returns 1, not the running T_maj)
+    bool pushScatter;                 // a MediumScatterWorkItem is owed (pushed in MediumTrackEnd)
     S4 T_maj, beta, r_u, r_l, L;
     RNG rng;
     float u, uMode;
 };
+template <bool LEAN = false>
 WF_HD void MediumTrackBegin(const SceneView &sv, const WorkState &ws, int cur, int qi, MediumTrack &s) {
     const int i = ws.mediumSampleQ[qi];
     const RayQueueV &q = ws.rq[cur];
@@ -643,6 +648,7 @@ WF_HD void MediumTrackBegin(const SceneView &sv, const WorkState &ws, int cur, i
     s.rng = RNG(Hash3f1(ro, tMax), Hash3f(rd));
     s.scattered = false;
     s.stopped = false;
+    s.pushScatter = false;
     s.u = s.rng.UniformFloat();
     s.uMode = s.rng.UniformFloat();
     // SampleT_maj's preamble (media.h:728-741)
@@ -651,7 +657,7 @@ WF_HD void MediumTrackBegin(const SceneView &sv, const WorkState &ws, int cur, i
     s.o = ro;
     s.d = Normalize(rd);
     s.ml = MediumSpectra(sv, M, lambda);
-    s.iter = MediumSampleRay(sv, M, s.ml, s.o, s.d, tMax);
+    s.iter = MediumSampleRay<LEAN>(sv, M, s.ml, s.o, s.d, tMax);
     s.T_maj = S4c(1.f);
     s.inSeg = false;
     s.tMin = 0;
@@ -682,8 +688,10 @@ WF_HD bool MediumTrackEvent(const SceneView &sv, const WorkState &ws, int cur, M
             q.beta[s.i] = toF4(s.beta);
             q.r_u[s.i] = toF4(s.r_u);
             ws.scatterP[s.i] = F4{p.x, p.y, p.z, mp.g};
-            int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE]);
-            ws.mediumScatterQ[slot] = s.i;
+            // (the queue slot is taken in MediumTrackEnd, where the wave's lanes meet again: here every lane arrives in its own iteration of
+            //  the walk and the wave-aggregated QueueAlloc degenerates into one returning atomic per lane or two — the delta-tracking
+            //  kernel was bound by the scatter counter's atomic rate, which is why neither occupancy nor the density table's layout moved it)
+            s.pushScatter = true;
         }
         s.scattered = true;
         return false;
@@ -698,6 +706,7 @@ WF_HD bool MediumTrackEvent(const SceneView &sv, const WorkState &ws, int cur, M
         return bool(s.beta) && bool(s.r_u);
     }
 }
+template <bool LEAN = false>
 WF_HD bool MediumTrackStep(const SceneView &sv, const WorkState &ws, int cur, MediumTrack &s) {
     if (!s.inSeg) {
         // the outer loop of SampleT_maj: the next majorant segment
@@ -718,13 +727,41 @@ WF_HD bool MediumTrackStep(const SceneView &sv, const WorkState &ws, int cur, Me
         s.T_maj = s.T_maj * FastExp(-(t - s.tMin) * s.seg.sigma_maj);
         V3 p = s.o + s.d * t;
         const wf_medium &M = sv.media[s.medium];
-        MediumProps mp = MediumSamplePoint(sv, M, s.ml, p);
+#if WF_MEDIUM_SPEC
+        // TWO tentative collisions per step for the grid media (round 6; bit-identical, but slower: the walks of the dense cloud are short — one or two
+        // events — so most second lookups are wasted, and the step's code doubles).  Where the NEXT exponential step lands depends only on this one's
+        // position and on the sample value already drawn (s.u) — not on the density here — so its position is known now, and the density
+        // gathers of both points (two dependent-free pairs of 16-byte loads out of a multi-GB table: what this kernel waits for 79 % of its
+        // time at two waves per SIMD) are issued together.  If this event ends the walk the second lookup is wasted (once per item);
+        // otherwise the second event runs exactly as the next step would: the same operands, the RNG draws in the same order.
+        const bool gridMedium = M.type == WF_MEDIUM_GRID || M.type == WF_MEDIUM_RGB_GRID || M.type == WF_MEDIUM_NANOVDB;
+        const float t2 = t + SampleExponential(s.u, s.seg.sigma_maj[0]);   // (the next step's `tMin + SampleExponential(u, ...)` with tMin = t)
+        const bool spec = gridMedium && t2 < s.seg.tMax;
+        MediumProps mp = MediumSamplePoint<LEAN>(sv, M, s.ml, p);
+        V3 p2 = p;
+        MediumProps mp2 = mp;
+        if (spec) { p2 = s.o + s.d * t2; mp2 = MediumSamplePoint<LEAN>(sv, M, s.ml, p2); }
+#else
+        MediumProps mp = MediumSamplePoint<LEAN>(sv, M, s.ml, p);
+#endif
         if (!MediumTrackEvent(sv, ws, cur, s, p, mp, s.seg.sigma_maj, s.T_maj)) {
             s.stopped = true;
             return false;
         }
         s.T_maj = S4c(1.f);
         s.tMin = t;
+#if WF_MEDIUM_SPEC
+        if (spec) {
+            s.u = s.rng.UniformFloat();
+            s.T_maj = s.T_maj * FastExp(-(t2 - s.tMin) * s.seg.sigma_maj);
+            if (!MediumTrackEvent(sv, ws, cur, s, p2, mp2, s.seg.sigma_maj, s.T_maj)) {
+                s.stopped = true;
+                return false;
+            }
+            s.T_maj = S4c(1.f);
+            s.tMin = t2;
+        }
+#endif
     } else {
         float dt = s.seg.tMax - s.tMin;
         if (IsInf(dt)) dt = WF_FLT_MAX;
@@ -744,6 +781,10 @@ WF_HD void MediumTrackEnd(const SceneView &sv, const WorkState &ws, int cur, Med
         r_l = r_l * (T_maj / T_maj[0]);
     }
     if (s.L) ws.L[s.pixelIndex] = toF4(toS4(ws.L[s.pixelIndex]) + s.L);
+    if (s.pushScatter) {   // MediumScatterWorkItem push (media.cpp:104-113)
+        int slot = QueueAlloc(&ws.counters[(CNT_MEDIUM_SCATTER) * CNT_STRIDE]);
+        ws.mediumScatterQ[slot] = i;
+    }
     if (s.scattered || !beta || !r_u || s.depth == sv.maxDepth) return;
     // the ray reached the surface (or left the scene): route it as EnqueueWorkAfterIntersection would have
     q.beta[i] = toF4(beta);
@@ -769,10 +810,11 @@ WF_HD void MediumTrackEnd(const SceneView &sv, const WorkState &ws, int cur, Med
     RouteSurfaceHit(sv, ws, cur, i, (int)FloatToBits(h.x), HitInst(sv, ws, i), h.y, h.z, h.w, /* fromMedium */ true);
 #endif
 }
+template <bool LEAN = false>
 WF_HD void KSampleMediumInteraction(const SceneView &sv, const WorkState &ws, int cur, int qi) {
     MediumTrack s;
-    MediumTrackBegin(sv, ws, cur, qi, s);
-    while (MediumTrackStep(sv, ws, cur, s)) {}
+    MediumTrackBegin<LEAN>(sv, ws, cur, qi, s);
+    while (MediumTrackStep<LEAN>(sv, ws, cur, s)) {}
     MediumTrackEnd(sv, ws, cur, s);
 }
 // the second half of K5 on the HIP back end: EnqueueWorkAfterIntersection for the medium-sample items that reached their surface

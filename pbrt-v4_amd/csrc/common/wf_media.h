@@ -51,6 +51,23 @@ WF_HD float GridLookup(const float *v, int nx, int ny, int nz, V3 p) {
 // The same lookup over the corner-packed copy of the grid (SceneView::gridCorners): cell (ix + 1, iy + 1, iz + 1) of an
 // (nx + 1)(ny + 1)(nz + 1) table holds v(ix.., iy.., iz..) for the eight corners in the order the lerps below take them, zeros outside the
 // grid as GridLookupI returns them.  The same eight values through the same expressions: bit-identical.
+// Where cell (cx, cy, cz) of the corner-packed table lives (round 6): the table is BRICKED — 8 x 8 x 8 cells of 32 bytes = one 16 KiB brick,
+// bricks in row-major order — so that lookups that are close in space (neighbouring rays, successive steps of one ray) fall into the same pages and
+// lines.  In the plain row-major table of round 4 a step along z moved 8.4 MB (512^3 grid): the delta-tracking kernel's gathers missed the TLB
+// on nearly every access, and more waves in flight bought nothing (2, 3 or 4 waves per SIMD: the same 36.4 ms on the cloud scene).
+#ifndef WF_GRID_BRICKS
+#define WF_GRID_BRICKS 1   // 0: the row-major table of round 4 (A/B builds)
+#endif
+WF_HD size_t GridCornerBricks(int n) { return (size_t)((n + 1 + 7) >> 3); }   // bricks along an axis of n voxels (n + 1 cells)
+WF_HD size_t GridCornerCells(int nx, int ny, int nz) {   // cells the table holds, padding included
+    if (!WF_GRID_BRICKS) return (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    return GridCornerBricks(nx) * GridCornerBricks(ny) * GridCornerBricks(nz) * 512;
+}
+WF_HD size_t GridCornerIndex(int nx, int ny, int cx, int cy, int cz) {
+    if (!WF_GRID_BRICKS) return ((size_t)cz * (ny + 1) + cy) * (nx + 1) + cx;
+    const size_t brick = ((size_t)(cz >> 3) * GridCornerBricks(ny) + (size_t)(cy >> 3)) * GridCornerBricks(nx) + (size_t)(cx >> 3);
+    return brick * 512 + (size_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7));
+}
 WF_HD float GridLookupPacked(const float *c, int nx, int ny, int nz, V3 p) {
     V3 ps{p.x * nx - .5f, p.y * ny - .5f, p.z * nz - .5f};
     int ix = (int)floor(ps.x), iy = (int)floor(ps.y), iz = (int)floor(ps.z);
@@ -61,7 +78,7 @@ WF_HD float GridLookupPacked(const float *c, int nx, int ny, int nz, V3 p) {
         return Lerp(d.z, Lerp(d.y, z0, z0), Lerp(d.y, z0, z0));
     }
     struct alignas(16) G4 { float a, b, c, d; };
-    const G4 *cell = reinterpret_cast<const G4 *>(c) + 2 * (((size_t)(iz + 1) * (ny + 1) + (iy + 1)) * (nx + 1) + (ix + 1));
+    const G4 *cell = reinterpret_cast<const G4 *>(c) + 2 * GridCornerIndex(nx, ny, ix + 1, iy + 1, iz + 1);
     const G4 lo = cell[0], hi = cell[1];
     float d00 = Lerp(d.x, lo.a, lo.b);
     float d10 = Lerp(d.x, lo.c, lo.d);
@@ -184,6 +201,10 @@ WF_HD MediumAtLambda MediumSpectra(const SceneView &sv, const wf_medium &M, cons
     for (int i = 0; i < 4; ++i) ml.lam[i] = lambda.lambda[i];
     return ml;
 }
+// LEAN (round 6, the device's k_medium_sample<true>): homogeneous media and non-emissive uniform-grid media only — the procedural cloud's
+// noise, the NanoVDB sampler, the RGB grids and the blackbody emission are compiled out, so that the delta-tracking kernel of a scene
+// without them is not allocated their registers ("a kernel is allocated what it can reach").  Same arithmetic on the types it keeps.
+template <bool LEAN = false>
 WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, const MediumAtLambda &ml, V3 p) {
     MediumProps mp;
     mp.g = M.g;
@@ -194,6 +215,7 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
         return mp;
     }
     p = XfInvPoint(M.render_from_medium, p);
+    if constexpr (!LEAN)
     if (M.type == WF_MEDIUM_CLOUD) {
         // CloudMedium::SamplePoint + Density (media.h:464-471, 493-517)
         const int32_t *perm = sv.noisePerm;
@@ -226,6 +248,7 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
         mp.Le = S4c(0.f);
         return mp;
     }
+    if constexpr (!LEAN)
     if (M.type == WF_MEDIUM_NANOVDB) {
         // NanoVDBMedium::SamplePoint + Le (media.h:615-632, 655-668): densityFloatGrid->worldToIndexF(p), then
         // SampleFromVoxels<TreeType, 1, false> = trilinear interpolation of the eight surrounding voxels (parity unpinned: see wf_abi.h)
@@ -247,6 +270,7 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
         return mp;
     }
     p = BoundsOffset(M.bounds, p);
+    if constexpr (!LEAN)
     if (M.type == WF_MEDIUM_RGB_GRID) {
         // RGBGridMedium::SamplePoint, media.h:377-401 (ml.Le = the colour space's illuminant at lambda)
         mp.sigma_a = M.sigma_scale * (M.rgb_a_offset >= 0 ? RGBGridLookup(sv.mediumData + M.rgb_a_offset, M.nx, M.ny, M.nz, p, ml.lam) : S4c(1.f));
@@ -276,6 +300,7 @@ WF_HD MediumProps MediumSamplePoint(const SceneView &sv, const wf_medium &M, con
     mp.sigma_a = mp.sigma_a * d;
     mp.sigma_s = mp.sigma_s * d;
     mp.Le = S4c(0.f);
+    if constexpr (!LEAN)
     if (M.is_emissive) {
         float scale = GridLookup(sv.mediumData + M.le_scale_offset, M.le_nx, M.le_ny, M.le_nz, p);
         if (scale > 0) {
@@ -342,6 +367,7 @@ struct MajorantIter {
 };
 
 // Medium::SampleRay for a ray with unit-length direction (SampleT_maj normalises first)
+template <bool LEAN = false>
 WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, const MediumAtLambda &ml, V3 o, V3 d, float raytMax) {
     MajorantIter it;
     S4 sigma_a = ml.sigma_a;
@@ -358,6 +384,7 @@ WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, cons
     it.tMax = -WF_INFINITY;
     XfInvRay(M.render_from_medium, &o, &d, &raytMax);
     float tMin, tMax;
+    if constexpr (!LEAN)
     if (M.type == WF_MEDIUM_CLOUD) {
         // CloudMedium::SampleRay (media.h:474-488): one HomogeneousMajorantIterator over the box overlap (none: the default iterator)
         it.homogeneous = true;

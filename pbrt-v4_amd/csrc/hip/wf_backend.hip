@@ -91,6 +91,7 @@ struct wf_ctx {
     int trWavefront = -1;
     bool cursorDirty[3] = {false, false, false};   // the closest-hit / any-hit / medium-sample work cursor has been used since a k_reset last zeroed it
     int mediumGrid = 512;        // resident workgroups of the persistent k_medium_sample
+    bool mediumLean = false;     // every medium is homogeneous or a non-emissive uniform grid: k_medium_sample<true>
     int matStreams = 0;          // WF_MAT_STREAMS=0: the material kernels of one depth one after the other on the render stream
     hipStream_t matStream[WF_MAT_NTYPES] = {};
     hipEvent_t evMatFork = nullptr, evMatJoin[WF_MAT_NTYPES] = {};
@@ -1379,7 +1380,13 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_mix(const SceneView sv, WorkS
 #ifndef WF_MEDIUM_STEPS
 #define WF_MEDIUM_STEPS 4   // steps between two looks at the wave's occupancy
 #endif
-__global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const SceneView sv, WorkState ws, int cur, int *cursor) {
+// LEAN: every medium of the scene is homogeneous or a non-emissive uniform grid (ctx->mediumLean, set at upload): the kernel is built without the
+// procedural cloud, NanoVDB, RGB-grid and blackbody code and compiled for WF_MEDIUM_WAVES_LEAN waves
+#ifndef WF_MEDIUM_WAVES_LEAN
+#define WF_MEDIUM_WAVES_LEAN 3
+#endif
+template <bool LEAN>
+__global__ void __launch_bounds__(BLOCK, LEAN ? WF_MEDIUM_WAVES_LEAN : WF_MEDIUM_WAVES) k_medium_sample(const SceneView sv, WorkState ws, int cur, int *cursor) {
     const int n = ws.counters[(CNT_MEDIUM_SAMPLE) * CNT_STRIDE];
 #if WF_MEDIUM_REFILL
     const int lane = threadIdx.x & 63;
@@ -1417,11 +1424,11 @@ __global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const 
                 next += take;
                 served += take;
             }
-            if (qi >= 0) MediumTrackBegin(sv, ws, cur, qi, s);
+            if (qi >= 0) MediumTrackBegin<LEAN>(sv, ws, cur, qi, s);
             if (!__any(s.i >= 0)) break;   // (nothing was dealt and nothing is left)
         } else if (nAct == 0) break;
         for (int k = 0; k < WF_MEDIUM_STEPS; ++k) {
-            if (s.i >= 0 && !MediumTrackStep(sv, ws, cur, s)) {
+            if (s.i >= 0 && !MediumTrackStep<LEAN>(sv, ws, cur, s)) {
                 MediumTrackEnd(sv, ws, cur, s);
                 s.i = -1;
             }
@@ -1429,7 +1436,7 @@ __global__ void __launch_bounds__(BLOCK, WF_MEDIUM_WAVES) k_medium_sample(const 
     }
 #else
     // (the nested-loop form of rounds 1-5 measured 43.2 ms against this form's 36.5 on the cloud scene, same box: profiles/r06_medium_nested_vs_state_machine_ab_cloud16.txt)
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction(sv, ws, cur, i);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) KSampleMediumInteraction<LEAN>(sv, ws, cur, i);
 #endif
 }
 __global__ void __launch_bounds__(BLOCK) k_medium_route(const SceneView sv, WorkState ws, int cur) {
@@ -1805,7 +1812,7 @@ __global__ void k_pack_grid_corners(const float *v, int nx, int ny, int nz, floa
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
         const int cx = (int)(c % (size_t)(nx + 1)), cy = (int)((c / (size_t)(nx + 1)) % (size_t)(ny + 1)), cz = (int)(c / ((size_t)(nx + 1) * (ny + 1)));
         const int ix = cx - 1, iy = cy - 1, iz = cz - 1;
-        float *o = out + 8 * c;
+        float *o = out + 8 * wf::GridCornerIndex(nx, ny, cx, cy, cz);   // (bricked: wf_media.h)
         o[0] = wf::GridLookupI(v, nx, ny, nz, ix, iy, iz);         o[1] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy, iz);
         o[2] = wf::GridLookupI(v, nx, ny, nz, ix, iy + 1, iz);     o[3] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy + 1, iz);
         o[4] = wf::GridLookupI(v, nx, ny, nz, ix, iy, iz + 1);     o[5] = wf::GridLookupI(v, nx, ny, nz, ix + 1, iy, iz + 1);
@@ -2805,7 +2812,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
             for (int m = 0; m < d->n_media; ++m) {
                 const wf_medium &M = d->media[m];
                 if (M.type != WF_MEDIUM_GRID || M.density_offset < 0 || M.nx < 1 || M.ny < 1 || M.nz < 1) continue;
-                const size_t cells = (size_t)(M.nx + 1) * (M.ny + 1) * (M.nz + 1);
+                const size_t cells = wf::GridCornerCells(M.nx, M.ny, M.nz);   // (whole 8 x 8 x 8 bricks)
                 if ((double)(total + 8 * cells) * sizeof(float) > budget) continue;
                 base[m] = (long long)total;
                 total += 8 * cells;
@@ -2854,6 +2861,10 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
     sv.maxDepth = d->max_depth;
     sv.regularize = d->regularize;
     sv.haveMedia = d->have_media;
+    // the lean delta-tracking kernel (k_medium_sample<true>): no procedural cloud, NanoVDB, RGB grid or emissive grid in the scene (WF_MEDIUM_LEAN=0: off)
+    ctx->mediumLean = d->n_media > 0 && !(getenv("WF_MEDIUM_LEAN") && atoi(getenv("WF_MEDIUM_LEAN")) == 0);
+    for (int m = 0; m < d->n_media; ++m)
+        if (!(d->media[m].type == WF_MEDIUM_HOMOGENEOUS || (d->media[m].type == WF_MEDIUM_GRID && !d->media[m].is_emissive))) ctx->mediumLean = false;
     sv.options = d->options;
     for (int m = 0; m < WF_MAT_NTYPES; ++m) ctx->matPresent[m] = false;
     sv.matTypeMask = 0;
@@ -3067,7 +3078,7 @@ int wf_scene_upload(wf_ctx *ctx, const wf_scene_desc *d) {
         if ((e = devAlloc(ctx, &ctx->probeCursor, (size_t)1))) return e;
         {
             int perCU = 0;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)k_medium_sample, BLOCK, 0));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)k_medium_sample<false>, BLOCK, 0));
             ctx->mediumGrid = std::min(MAX_GRID, std::max(1, perCU) * prop.multiProcessorCount);
         }
     }
@@ -3414,7 +3425,9 @@ int wf_medium_sample(wf_ctx *ctx, int depth) {
         int *cursor = ctx->ws.counters + CNT_CURSOR_MEDIUM * CNT_STRIDE;
         if (ctx->cursorDirty[2]) HIPCHK(hipMemsetAsync(cursor, 0, sizeof(int), ctx->stream));
         ctx->cursorDirty[2] = true;
-        LAUNCH("Sample medium interaction", k_medium_sample, WF_MEDIUM_REFILL ? std::min(ctx->mediumGrid, gridFor(ctx->maxQueueSize)) : gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1, cursor);
+        const int grid = WF_MEDIUM_REFILL ? std::min(ctx->mediumGrid, gridFor(ctx->maxQueueSize)) : gridFor(ctx->maxQueueSize);
+        if (ctx->mediumLean) LAUNCH("Sample medium interaction", k_medium_sample<true>, grid, ctx->svHost, ctx->ws, depth & 1, cursor);
+        else LAUNCH("Sample medium interaction", k_medium_sample<false>, grid, ctx->svHost, ctx->ws, depth & 1, cursor);
     }
     LAUNCH("Sample medium interaction: route surface hits", k_medium_route, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, depth & 1);
     if (depth == ctx->maxDepth) return 0;
