@@ -53,10 +53,10 @@ WF_HD float GridLookup(const float *v, int nx, int ny, int nz, V3 p) {
 // grid as GridLookupI returns them.  The same eight values through the same expressions: bit-identical.
 // Where cell (cx, cy, cz) of the corner-packed table lives (round 6): the table is BRICKED — 8 x 8 x 8 cells of 32 bytes = one 16 KiB brick,
 // bricks in row-major order — so that lookups that are close in space (neighbouring rays, successive steps of one ray) fall into the same pages and
-// lines.  In the plain row-major table of round 4 a step along z moved 8.4 MB (512^3 grid): the delta-tracking kernel's gathers missed the TLB
-// on nearly every access, and more waves in flight bought nothing (2, 3 or 4 waves per SIMD: the same 36.4 ms on the cloud scene).
+// lines (in the row-major table a step along z moves 8.4 MB on a 512^3 grid).  Built on the suspicion that the delta-tracking kernel was TLB-bound; it was
+// not (see WF_GRID_BRICKS).
 #ifndef WF_GRID_BRICKS
-#define WF_GRID_BRICKS 1   // 0: the row-major table of round 4 (A/B builds)
+#define WF_GRID_BRICKS 0   // 1: the bricked table (A/B builds) — measured once the kernel's real bound (the scatter counter's atomics) was gone: 12.2 against 12.1 ms, no gain: the row-major table of round 4 stays
 #endif
 WF_HD size_t GridCornerBricks(int n) { return (size_t)((n + 1 + 7) >> 3); }   // bricks along an axis of n voxels (n + 1 cells)
 WF_HD size_t GridCornerCells(int nx, int ny, int nz) {   // cells the table holds, padding included
