@@ -921,7 +921,7 @@ WF_HD float ShadowTime(const WorkState &ws, float dw) {
 }
 // one turn of the loop body after the closest hit of (ro, rd, tMax) is known; returns whether the ray goes on (a new segment in st)
 // ANIM: the scene has animated primitives (the interaction of a hit through one needs the path's time: ws.pathTime)
-template <bool ANIM = false>
+template <bool ANIM = false, bool MLEAN = false>
 WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *st, bool hit, int prim, int inst, float b0, float b1, float b2) {
     F4 o4 = ws.sq.o[i], d4 = ws.sq.d[i];
     const float tMax = o4.w;
@@ -943,7 +943,7 @@ WF_HD bool TrSegment(const SceneView &sv, const WorkState &ws, int i, TrState *s
         float u0 = st->rng.UniformFloat();
         S4 &T_ray = st->T_ray, &r_u = st->r_u, &r_l = st->r_l;
         RNG &rng = st->rng;
-        S4 T_maj = SampleT_maj(sv, st->medium, st->ro, st->rd, tEnd, u0, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
+        S4 T_maj = SampleT_maj<MLEAN>(sv, st->medium, st->ro, st->rd, tEnd, u0, rng, lambda, [&](V3 p, const MediumProps &mp, S4 sigma_maj, S4 T_maj) {
             S4 sigma_n = ClampZero(sigma_maj - mp.sigma_a - mp.sigma_s);
             // ratio tracking: only null scattering is evaluated
             float pr = T_maj[0] * sigma_maj[0];
@@ -997,22 +997,22 @@ WF_HD void TrLoad(const WorkState &ws, int i, TrState *st) {
     st->rng.inc = (uint64_t)(uint32_t)r.z | ((uint64_t)(uint32_t)r.w << 32);
 }
 // trace(o, d, tMax, &prim, &inst, &b0, &b1, &b2) -> closest hit?
-template <bool ANIM = false, typename Trace>
+template <bool ANIM = false, bool MLEAN = false, typename Trace>
 WF_HD void KTraceTransmittanceFrom(const SceneView &sv, const WorkState &ws, int i, TrState &st, Trace trace) {
     const float tMax = ws.sq.o[i].w;
     while (!(st.rd.x == 0 && st.rd.y == 0 && st.rd.z == 0)) {
         int prim = -1, inst = -1;
         float b0 = 0, b1 = 0, b2 = 0;
         bool hit = trace(st.ro, st.rd, tMax, &prim, &inst, &b0, &b1, &b2);
-        if (!TrSegment<ANIM>(sv, ws, i, &st, hit, prim, inst, b0, b1, b2)) break;
+        if (!TrSegment<ANIM, MLEAN>(sv, ws, i, &st, hit, prim, inst, b0, b1, b2)) break;
     }
     TrFinish(ws, i, st);
 }
-template <bool ANIM = false, typename Trace>
+template <bool ANIM = false, bool MLEAN = false, typename Trace>
 WF_HD void KTraceTransmittance(const SceneView &sv, const WorkState &ws, int i, Trace trace) {
     TrState st;
     TrBegin(ws, i, &st);
-    KTraceTransmittanceFrom<ANIM>(sv, ws, i, st, trace);
+    KTraceTransmittanceFrom<ANIM, MLEAN>(sv, ws, i, st, trace);
 }
 
 // K7: HandleEscapedRays, wavefront/integrator.cpp:495-537

@@ -428,13 +428,17 @@ WF_HD MajorantIter MediumSampleRay(const SceneView &sv, const wf_medium &M, cons
 //  same box, profiles/r06_sampleT_maj_flattened_for_transmittance_ab_cloud16.txt.  Their callback is a few multiplications: the nested form's
 //  tight inner loop is worth more than the lanes the flattening keeps busy.)
 // SampleT_maj, media.h:724-800.  callback(p, mp, sigma_maj, T_maj) -> continue?
-template <typename F>
+#ifndef WF_TMAJ_SPEC
+#define WF_TMAJ_SPEC 0   // measured and LEFT OFF (round 6, cloud scene: Intersect shadow (Tr) 19.2 against 19.0 ms, profiles/r06_sampleT_maj_two_collisions_ab_cloud16.txt)
+#endif
+// MLEAN: the lean medium code (MediumSamplePoint<true>: homogeneous and non-emissive uniform-grid media only), for the transmittance kernels of scenes with no other medium type
+template <bool MLEAN = false, typename F>
 WF_HD S4 SampleT_maj(const SceneView &sv, int mediumId, V3 o, V3 d, float tMax, float u, RNG &rng, const Wavelengths &lambda, F callback) {
     const wf_medium &M = sv.media[mediumId];
     tMax *= Length(d);
     d = Normalize(d);
     const MediumAtLambda ml = MediumSpectra(sv, M, lambda);
-    MajorantIter iter = MediumSampleRay(sv, M, ml, o, d, tMax);
+    MajorantIter iter = MediumSampleRay<MLEAN>(sv, M, ml, o, d, tMax);
     S4 T_maj = S4c(1.f);
     bool done = false;
     while (!done) {
@@ -453,13 +457,43 @@ WF_HD S4 SampleT_maj(const SceneView &sv, int mediumId, V3 o, V3 d, float tMax, 
             if (t < seg.tMax) {
                 T_maj = T_maj * FastExp(-(t - tMin) * seg.sigma_maj);
                 V3 p = o + d * t;
-                MediumProps mp = MediumSamplePoint(sv, M, ml, p);
+#if WF_TMAJ_SPEC
+                // TWO tentative collisions per iteration for the grid media (round 6): where the next exponential step lands depends only on
+                // this one's position and on the sample value already drawn (u), not on the density here, so both points' density gathers are
+                // issued together; the second event then runs exactly as the next iteration would (same operands, the RNG draws in the same
+                // order).  Bit-identical; no gain on the cloud scene's transmittance walks either.
+                const bool gridMedium = M.type == WF_MEDIUM_GRID || M.type == WF_MEDIUM_RGB_GRID || M.type == WF_MEDIUM_NANOVDB;
+                const float t2 = t + SampleExponential(u, seg.sigma_maj[0]);
+                const bool spec = gridMedium && t2 < seg.tMax;
+                MediumProps mp = MediumSamplePoint<MLEAN>(sv, M, ml, p);
+                V3 p2 = p;
+                MediumProps mp2 = mp;
+                if (spec) { p2 = o + d * t2; mp2 = MediumSamplePoint<MLEAN>(sv, M, ml, p2); }
                 if (!callback(p, mp, seg.sigma_maj, T_maj)) {
                     done = true;
                     break;
                 }
                 T_maj = S4c(1.f);
                 tMin = t;
+                if (spec) {
+                    u = rng.UniformFloat();
+                    T_maj = T_maj * FastExp(-(t2 - tMin) * seg.sigma_maj);
+                    if (!callback(p2, mp2, seg.sigma_maj, T_maj)) {
+                        done = true;
+                        break;
+                    }
+                    T_maj = S4c(1.f);
+                    tMin = t2;
+                }
+#else
+                MediumProps mp = MediumSamplePoint<MLEAN>(sv, M, ml, p);
+                if (!callback(p, mp, seg.sigma_maj, T_maj)) {
+                    done = true;
+                    break;
+                }
+                T_maj = S4c(1.f);
+                tMin = t;
+#endif
             } else {
                 float dt = seg.tMax - tMin;
                 if (IsInf(dt)) dt = WF_FLT_MAX;

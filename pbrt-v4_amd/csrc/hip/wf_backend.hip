@@ -1475,14 +1475,15 @@ struct TrPrims {  // the same callbacks for the transmittance walk, whose ray is
     __device__ bool accept(int prim, float b0, float b1, float b2) const { return AlphaTestPasses(sv, prim, b0, b1, b2, o, d); }
     __device__ bool sphere(int prim, float tMax, QuadricHit *qh) const { return QuadricIntersect(sv, prim, o, d, tMax, qh); }
 };
-template <bool ALPHA>
+// MLEAN: the lean medium code (ctx->mediumLean, as k_medium_sample<true>)
+template <bool ALPHA, bool MLEAN = false>
 __global__ void __launch_bounds__(TBLOCK) k_shadow_tr_fast(const SceneView sv, WorkState ws, FastBVH bvh, SpillArea sp) {
     const int n = ws.counters[(CNT_SHADOW) * CNT_STRIDE];
     const int gtid = blockIdx.x * TBLOCK + threadIdx.x, stride = gridDim.x * TBLOCK;
     LdsStackT st{sp.base + gtid, stride, 0, 0, sp.rows, sp.dbg, sp.save + gtid};
     LoadTreeTop(bvh);
     for (int i = gtid; i < n; i += stride)
-        KTraceTransmittance(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
+        KTraceTransmittance<false, MLEAN>(sv, ws, i, [&](V3 o, V3 d, float tMax, int *prim, int *inst, float *b0, float *b1, float *b2) {
             RayWalk w;
             WalkInit(bvh, w, o, d, tMax);
             st.reset();
@@ -1545,6 +1546,7 @@ __global__ void __launch_bounds__(TBLOCK, INST ? WF_TWAVES_INST : WF_TWAVES_CLOS
             if (INST) ws.hitInst[i] = w.prim >= 0 ? w.inst : -1;
         });
 }
+template <bool MLEAN>
 __global__ void __launch_bounds__(BLOCK) k_tr_segment(const SceneView sv, WorkState ws, int cur) {
     const int n = ws.counters[(CNT_TR0 + cur) * CNT_STRIDE];
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
@@ -1553,7 +1555,7 @@ __global__ void __launch_bounds__(BLOCK) k_tr_segment(const SceneView sv, WorkSt
         TrLoad(ws, i, &st);
         const F4 h = ws.hit[i];
         const int prim = (int)FloatToBits(h.x);
-        if (TrSegment(sv, ws, i, &st, prim >= 0, prim, HitInst(sv, ws, i), h.y, h.z, h.w)) {
+        if (TrSegment<false, MLEAN>(sv, ws, i, &st, prim >= 0, prim, HitInst(sv, ws, i), h.y, h.z, h.w)) {
             TrStore(ws, i, st);
             ws.trQ[cur ^ 1][QueueAlloc(&ws.counters[(CNT_TR0 + (cur ^ 1)) * CNT_STRIDE])] = i;
         } else TrFinish(ws, i, st);
@@ -3441,7 +3443,9 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
     if (!ctx->svHost.haveMedia) return fail(-1, "wf_intersect_shadow_tr: the scene has no media (use wf_intersect_shadow)");
     // (a scene with AnimatedPrimitives keeps the reference-order transmittance walk, which interpolates their transformations at the shadow
     //  ray's time: the transmittance wavefront's walk kernel has no ANIM variant — fuzz scene s6300008, round 6)
-    if (ctx->fastOk && !ctx->animFast && !ctx->countTraversal && RetraceInline(ctx->genMode) && (ctx->trWavefront == 1 || (ctx->trWavefront < 0 && ctx->svHost.nInstances > 0))) {
+    if (ctx->fastOk && !ctx->animFast && !ctx->countTraversal && RetraceInline(ctx->genMode) && (ctx->trWavefront == 1 || (ctx->trWavefront < 0 && (ctx->svHost.nInstances > 0 || ctx->mediumLean)))) {
+        // (round 6: also for one-level scenes whose media are all lean — k_tr_segment<true> runs at 3 waves (162 VGPRs) where the per-lane kernel is one
+        //  wave of 366 + 110 registers per SIMD: cloud scene 17.3 against 18.5 ms, profiles/r06_transmittance_lean_wavefront_ab_cloud16.txt)
         // the transmittance wavefront (see k_tr_begin)
         LAUNCH("Reset transmittance queues", k_reset, 1, ctx->ws, (1u << CNT_TR0) | (1u << CNT_TR1), -1, 0);
         LAUNCH("Intersect shadow (Tr): begin", k_tr_begin, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws);
@@ -3454,12 +3458,14 @@ int wf_intersect_shadow_tr(wf_ctx *ctx, int depth) {
                 if (ctx->genMode == 0) LAUNCHT("Intersect shadow (Tr): trace", (k_tr_trace<0, false>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, cur, ctx->spillArea());
                 else LAUNCHT("Intersect shadow (Tr): trace", (k_tr_trace<1, false>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, cur, ctx->spillArea());
             }
-            LAUNCH("Intersect shadow (Tr): segment", k_tr_segment, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, cur);
+            if (ctx->mediumLean) LAUNCH("Intersect shadow (Tr): segment", k_tr_segment<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, cur);
+            else LAUNCH("Intersect shadow (Tr): segment", k_tr_segment<false>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, cur);
             LAUNCH("Reset transmittance queues", k_reset, 1, ctx->ws, 1u << (CNT_TR0 + cur), -1, 0);
         }
         LAUNCH("Intersect shadow (Tr): rest", k_tr_rest, 128, ctx->svHost, ctx->ws, WF_TR_SEGMENTS & 1, ctx->stackSpill);
     } else if (ctx->fastOk && !ctx->animFast && !ctx->countTraversal && ctx->svHost.nInstances == 0)  // (the per-lane production walk has no two-level variant)
         if (ctx->svHost.haveAlpha || ctx->svHost.nQuadrics > 0) LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<true>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
+        else if (ctx->mediumLean) LAUNCHT("Intersect shadow (Tr)", (k_shadow_tr_fast<false, true>), ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
         else LAUNCHT("Intersect shadow (Tr)", k_shadow_tr_fast<false>, ctx->persistentGrid, ctx->svHost, ctx->ws, ctx->fast, ctx->spillArea());
     else
         { if (ctx->svHost.haveAnimated) LAUNCH("Intersect shadow (Tr)", k_shadow_tr<true>, gridFor(ctx->maxQueueSize), ctx->svHost, ctx->ws, ctx->stackSpill);
