@@ -791,7 +791,7 @@ int wf_counters_download(wf_ctx *ctx, wf_traversal_counters *out);
 int wf_debug_counters(wf_ctx *ctx, uint64_t out[4], int reset);
 /* Which kernel variants the uploaded scene runs (tests assert that a scene takes the path they mean to cover): key = "fast_ok" (the
    production traversal layout is in use), "gen_mode" (0 - 3: strength of the walk kernels), "gen_tri", "defer_general" (the two-class
-   traversal), "anim_fast" (AnimatedPrimitives on the production walk), "lean_shade", "lean_type_<material type>", "rare_lights",
+   traversal), "anim_fast" (AnimatedPrimitives on the production walk), "lean_shade", "lean_type_<material type>", "rare_lights", "medium_lean" (the lean delta-tracking / transmittance kernels),
    "instances".  Introspection only; nothing in the reference corresponds. */
 int wf_ctx_query(wf_ctx *ctx, const char *key, int64_t *value);
 /* Host-only self-check of the production traversal layout (no device needed; CPU suite, tests/test_fastbvh_host.py): builds the

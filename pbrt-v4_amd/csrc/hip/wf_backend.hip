@@ -3120,6 +3120,7 @@ int wf_ctx_query(wf_ctx *ctx, const char *key, int64_t *value) {
     else if (k == "anim_fast") *value = ctx->animFast;
     else if (k == "lean_shade") *value = ctx->leanShade;
     else if (k == "rare_lights") *value = ctx->rareLights;
+    else if (k == "medium_lean") *value = ctx->mediumLean;   // k_medium_sample<true> / k_tr_segment<true>: every medium is homogeneous or a non-emissive uniform grid
     else if (k.rfind("lean_type_", 0) == 0 && atoi(key + 10) >= 0 && atoi(key + 10) < WF_MAT_NTYPES) *value = ctx->leanType[atoi(key + 10)];
     else if (k == "instances") *value = ctx->svHost.nInstances;
     else return fail(-1, "wf_ctx_query: unknown key '%s'", key);

@@ -205,6 +205,22 @@ def test_two_class_traversal_and_rebraided_instances(wfpt, tmp_path, monkeypatch
     _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
 
 
+@pytest.mark.parametrize("name,lean", [("media_box", True), ("media_instances", True), ("cloud_medium", False), ("rgbgrid_medium", False), ("tempgrid_medium", False)])
+def test_lean_medium_kernels_selected_and_bit_identical(wfpt, tmp_path, monkeypatch, name, lean):
+    """Round 6: scenes whose media are all homogeneous or non-emissive uniform grids run the lean delta-tracking / transmittance kernels
+    (k_medium_sample<true>, k_tr_segment<true>: the procedural cloud, NanoVDB, RGB-grid and blackbody code compiled out); the others, and
+    every scene under WF_MEDIUM_LEAN=0, the general ones — the same image, bit for bit, as the reference's (media.h:283-352, 724-800)."""
+    s = wfpt.Scene(path=os.path.join(GOLDEN, name + ".pbrt"), spp=4)
+    s.create_renderer(0)
+    got = s.query("medium_lean") == 1
+    s.close()
+    assert got == lean, (name, got)
+    _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
+    if lean:
+        monkeypatch.setenv("WF_MEDIUM_LEAN", "0")
+        _check_image_vs_oracle_and_reference(wfpt, tmp_path, name)
+
+
 @pytest.mark.parametrize("name", ["animated", "animated_sss", "animated_tris", "animated_tris_alpha"])
 def test_animated_primitives_on_the_production_walk(wfpt, tmp_path, monkeypatch, name):
     """AnimatedPrimitive (cpu/primitive.cpp:132-158) through the production traversal kernels' ANIM variants (round 6: one entry of the
